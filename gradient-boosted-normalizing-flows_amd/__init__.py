@@ -1,0 +1,29 @@
+"""MI355X-native boosted normalizing-flow density evaluator (hot path only).
+
+Import name: ``gbnf_amd`` (the on-disk directory keeps the upstream project's
+hyphenated name, which Python cannot import directly; ``gbnf_amd/__init__.py``
+at the repo root aliases it).
+
+Public surface (mirrors models/boosted_flow.py of the reference):
+  BoostedFlow(args)                         -- drop-in host module, forward(x=, components=)
+  component_forward / component_log_prob / log_prob  -- convenience names of BASELINE.json
+  native                                    -- ctypes binding of libgbnf_hip.so (include/gbnf.h)
+"""
+from . import spec, synth  # noqa: F401  (pure-python, always importable)
+
+__all__ = ["spec", "synth", "native", "BoostedFlow"]
+
+
+def __getattr__(name):
+    # lazy so that ``import gbnf_amd`` works on a box where torch / the .so are absent;
+    # anything that computes fails loudly inside ``native``.
+    if name == "native":
+        from . import native as _n
+        return _n
+    if name in ("BoostedFlow", "boosted_flow"):
+        from . import boosted_flow as _b
+        return _b if name == "boosted_flow" else _b.BoostedFlow
+    if name == "sharded":
+        from . import sharded as _s
+        return _s
+    raise AttributeError(name)

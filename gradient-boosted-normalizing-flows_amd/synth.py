@@ -1,0 +1,108 @@
+"""Portable synthetic parameters for boosted-flow components.
+
+There are no datasets or checkpoints on the build / GPU boxes, so benchmarks,
+tests and the golden-fixture generator all draw component parameters from this
+one deterministic generator (legacy ``numpy.random.RandomState`` streams, which
+are stable across numpy versions).  The output is the plain "flow spec" data
+model described in ``spec.py``; the fixture generator loads the very same
+numbers into the reference modules with ``load_state_dict``.
+
+Parameter scales follow ``nn.Linear``'s default init U(-1/sqrt(in), 1/sqrt(in))
+(the reference never overrides it for TanhNet/ReLUNet, models/layers.py:208-243)
+times ``gain`` so shift/scale are non-trivial, and ActNorm / BatchNorm
+statistics are perturbed away from identity.
+"""
+from __future__ import annotations
+
+import numpy as np
+
+
+def _linear(rng, out_f, in_f, gain):
+    bound = gain / np.sqrt(in_f)
+    w = rng.uniform(-bound, bound, size=(out_f, in_f)).astype(np.float32)
+    b = rng.uniform(-bound, bound, size=(out_f,)).astype(np.float32)
+    return w, b
+
+
+def _net(rng, in_f, out_f, h, depth, act, gain):
+    layers = [_linear(rng, h, in_f, gain)]
+    for _ in range(depth):
+        layers.append(_linear(rng, h, h, gain))
+    layers.append(_linear(rng, out_f, h, gain))
+    return {"act": act, "layers": layers}
+
+
+def synth_glow_spec(d, h, K, depth=1, act="tanh", coupling="affine", permutation="shuffle",
+                    seed=0, gain=1.0):
+    """One tabular Glow component (models/glow.py FlowStep x K) with synthetic parameters."""
+    rng = np.random.RandomState(seed)
+    d1 = d // 2
+    d2 = d - d1
+    steps = []
+    for _ in range(K):
+        perm = np.arange(d - 1, -1, -1, dtype=np.int64)
+        if permutation == "shuffle":
+            perm = perm[rng.permutation(d)]
+        out_f = d2 * 2 if coupling == "affine" else d2
+        steps.append({
+            "an_bias": (0.1 * rng.standard_normal(d)).astype(np.float32),
+            "an_logs": (0.1 * rng.standard_normal(d)).astype(np.float32),
+            "perm": perm.astype(np.int64),
+            "net": _net(rng, d1, out_f, h, depth, act, gain),
+        })
+    return {"kind": "glow", "d": int(d), "coupling": coupling, "steps": steps}
+
+
+def synth_realnvp_spec(d, h, K, depth=1, coupling_network="tanh", batch_norm=True, flip_init=0,
+                       seed=0, gain=1.0):
+    """One RealNVPFlow component (models/realnvp.py:34-78) with synthetic parameters.
+
+    ``coupling_network``: "tanh" | "relu" | "mixed" (t_net ReLU, s_net Tanh, realnvp.py:47-51).
+    BatchNorm is present on every step but the last when ``batch_norm`` (realnvp.py:71-74).
+    """
+    rng = np.random.RandomState(seed)
+    steps = []
+    for k in range(K):
+        flipped = ((k + flip_init) % 2) > 0
+        if flipped:
+            out_f, in_f = d // 2, d - d // 2
+        else:
+            in_f, out_f = d // 2, d - d // 2
+        if coupling_network == "mixed":
+            t_act, s_act = "relu", "tanh"
+        else:
+            t_act = s_act = coupling_network
+        t_net = _net(rng, in_f, out_f, h, depth, t_act, gain)
+        # keep log-scales tame: the s-net's last layer is scaled down a little
+        s_net = _net(rng, in_f, out_f, h, depth, s_act, gain)
+        bn = None
+        if batch_norm and k < K - 1:
+            bn = {
+                "log_gamma": (0.1 * rng.standard_normal(d)).astype(np.float32),
+                "beta": (0.1 * rng.standard_normal(d)).astype(np.float32),
+                "running_mean": (0.1 * rng.standard_normal(d)).astype(np.float32),
+                "running_var": rng.uniform(0.5, 1.5, size=d).astype(np.float32),
+                "eps": 1e-5,
+            }
+        steps.append({"flipped": bool(flipped), "bn": bn, "t_net": t_net, "s_net": s_net})
+    return {"kind": "realnvp", "d": int(d), "steps": steps}
+
+
+def synth_boosted_specs(kind, C, d, h, K, seed=1, **kw):
+    """C components; component c uses stream ``seed*1000 + c`` (and flip_init=c for RealNVP,
+    as models/boosted_flow.py:46 does)."""
+    specs = []
+    for c in range(C):
+        if kind == "glow":
+            specs.append(synth_glow_spec(d, h, K, seed=seed * 1000 + c, **kw))
+        elif kind == "realnvp":
+            specs.append(synth_realnvp_spec(d, h, K, flip_init=c, seed=seed * 1000 + c, **kw))
+        else:
+            raise ValueError(kind)
+    return specs
+
+
+def synth_batch(N, d, seed=0, scale=1.0):
+    """z-scored-like N(0,1) inputs (the loaders z-score the data: utils/miniboone.py:57-67)."""
+    rng = np.random.RandomState(seed)
+    return (scale * rng.standard_normal((N, d))).astype(np.float32)

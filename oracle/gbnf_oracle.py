@@ -1,0 +1,319 @@
+"""CPU oracle for the boosted-flow density hot path.  TEST INFRASTRUCTURE ONLY.
+
+This file is the *checker*, never the product: only ``tests/``,
+``__graft_entry__.smoke()`` and ``bench.py``'s ``cpu_baseline`` leg may import
+it.  Nothing under ``gradient-boosted-normalizing-flows_amd/`` imports it, and
+it imports nothing from there (it consumes plain "flow spec" dicts, see below).
+
+It restates, function by function, the reference's PyTorch-CPU algorithm for
+
+  x (N,d) --[component c: K flow steps]--> z (N,d), log|det J| (N,)
+  ll_c = sum_j log N(z_j; 0, 1) + log|det J|
+  G    = recursive 2-way logsumexp over components with prefix-normalised rho
+
+Two back-ends share one code path:
+  * ``backend="torch"``  -- float32 torch CPU ops in the reference's op order
+    (the "port" that bench.py times as ``cpu_baseline``; uses the same aten
+    kernels as the reference, so it agrees with it to fp32 rounding);
+  * ``backend="numpy64"`` -- float64 numpy (precision anchor / noise floor).
+
+Parity pin: ``tests/golden/*.npz`` were produced by importing the reference
+itself (``tests/golden/make_golden.py``, run in the build container where
+``/root/reference`` exists); ``tests/test_oracle_golden.py`` checks this oracle
+against every one of them.  The reference has no tests / golden vectors of its
+own, so those fixtures are the pin.
+
+Flow spec (plain data, numpy float32 unless noted) -- one dict per component:
+  {"kind": "glow" | "realnvp", "d": int,
+   "coupling": "affine" | "additive"          (glow only),
+   "steps": [ step, ... ]}
+  glow step    = {"an_bias": (d,), "an_logs": (d,), "perm": int64 (d,),
+                  "net": net}
+  realnvp step = {"flipped": bool, "bn": None | {"log_gamma","beta",
+                  "running_mean","running_var": (d,), "eps": float},
+                  "t_net": net, "s_net": net}
+  net          = {"act": "tanh" | "relu", "layers": [(W (out,in), b (out,)), ...]}
+"""
+from __future__ import annotations
+
+import math
+
+import numpy as np
+
+try:  # torch is only needed for backend="torch"
+    import torch
+except Exception:  # pragma: no cover
+    torch = None
+
+LOG_2PI = math.log(2.0 * math.pi)
+
+
+# --------------------------------------------------------------------------
+# tiny array-API shim so the same restatement runs in torch-f32 and numpy-f64
+# --------------------------------------------------------------------------
+class _TorchOps:
+    name = "torch"
+
+    def arr(self, a):
+        return torch.as_tensor(np.asarray(a), dtype=torch.float32)
+
+    def idx(self, a):
+        return torch.as_tensor(np.asarray(a), dtype=torch.long)
+
+    exp = staticmethod(lambda a: torch.exp(a))
+    log = staticmethod(lambda a: torch.log(a))
+    sqrt = staticmethod(lambda a: torch.sqrt(a))
+    tanh = staticmethod(lambda a: torch.tanh(a))
+    sigmoid = staticmethod(lambda a: torch.sigmoid(a))
+    relu = staticmethod(lambda a: torch.relu(a))
+
+    def linear(self, x, w, b):
+        return torch.nn.functional.linear(x, w, b)
+
+    def cat(self, parts):
+        return torch.cat(parts, dim=1)
+
+    def sum1(self, a):
+        return torch.sum(a, dim=1)
+
+    def zeros(self, n):
+        return torch.zeros(n, dtype=torch.float32)
+
+    def lse2(self, a, b):
+        return torch.logsumexp(torch.stack([a, b], dim=1), dim=1)
+
+    def to_numpy(self, a):
+        return a.detach().cpu().numpy()
+
+
+class _Numpy64Ops:
+    name = "numpy64"
+
+    def arr(self, a):
+        return np.asarray(a, dtype=np.float64)
+
+    def idx(self, a):
+        return np.asarray(a, dtype=np.int64)
+
+    exp = staticmethod(np.exp)
+    log = staticmethod(np.log)
+    sqrt = staticmethod(np.sqrt)
+    tanh = staticmethod(np.tanh)
+    relu = staticmethod(lambda a: np.maximum(a, 0.0))
+
+    @staticmethod
+    def sigmoid(a):
+        return 1.0 / (1.0 + np.exp(-a))
+
+    def linear(self, x, w, b):
+        return x @ w.T + b
+
+    def cat(self, parts):
+        return np.concatenate(parts, axis=1)
+
+    def sum1(self, a):
+        return np.sum(a, axis=1)
+
+    def zeros(self, n):
+        return np.zeros(n, dtype=np.float64)
+
+    def lse2(self, a, b):
+        m = np.maximum(a, b)
+        return m + np.log(np.exp(a - m) + np.exp(b - m))
+
+    def to_numpy(self, a):
+        return np.asarray(a)
+
+
+def _ops(backend):
+    if backend == "torch":
+        if torch is None:
+            raise RuntimeError("torch backend requested but torch is not importable")
+        return _TorchOps()
+    if backend == "numpy64":
+        return _Numpy64Ops()
+    raise ValueError(f"unknown oracle backend {backend!r}")
+
+
+# --------------------------------------------------------------------------
+# primitive layers
+# --------------------------------------------------------------------------
+def coupling_net(ops, net, x):
+    """TanhNet / ReLUNet: Linear -> [act, Linear]*L -> act, Linear.
+
+    Follows models/layers.py:208-243 (nn.Linear: y = x W^T + b, W is (out,in)).
+    """
+    act = ops.tanh if net["act"] == "tanh" else ops.relu
+    layers = net["layers"]
+    h = ops.linear(x, ops.arr(layers[0][0]), ops.arr(layers[0][1]))
+    for w, b in layers[1:]:
+        h = ops.linear(act(h), ops.arr(w), ops.arr(b))
+    return h
+
+
+def actnorm1d(ops, step, x, ld):
+    """_ActNorm.forward (inited, forward direction): models/layers.py:488-533.
+
+    centre first ("x + bias"), then scale ("* exp(logs)"); logdet += sum(logs).
+    """
+    bias = ops.arr(step["an_bias"]).reshape(1, -1)
+    logs = ops.arr(step["an_logs"]).reshape(1, -1)
+    x = x + bias
+    x = x * ops.exp(logs)
+    return x, ld + logs.sum()
+
+
+def glow_step(ops, spec, step, x, ld):
+    """FlowStep.encode, tabular branch: models/glow.py:317-342."""
+    d = spec["d"]
+    z, ld = actnorm1d(ops, step, x, ld)
+    z = z[:, ops.idx(step["perm"])]                      # Permute1d, models/layers.py:661-668
+    z1, z2 = z[:, : d // 2], z[:, d // 2:]               # split_feature "split", utils/utilities.py:139-156
+    h = coupling_net(ops, step["net"], z1)
+    if spec["coupling"] == "additive":
+        z2 = z2 + h                                      # models/glow.py:328-329
+    else:
+        shift, raw = h[:, 0::2], h[:, 1::2]              # split_feature "cross"
+        scale = ops.sigmoid(raw + 2.0)                   # models/glow.py:333
+        z2 = z2 + shift
+        z2 = z2 * scale
+        ld = ops.sum1(ops.log(scale)) + ld               # models/glow.py:338
+    return ops.cat([z1, z2]), ld
+
+
+def batch_norm_eval(ops, bn, x):
+    """BatchNorm.forward in eval mode (running stats): models/layers.py:337-358."""
+    mean = ops.arr(bn["running_mean"])
+    var = ops.arr(bn["running_var"])
+    log_gamma = ops.arr(bn["log_gamma"])
+    beta = ops.arr(bn["beta"])
+    x_hat = (x - mean) / ops.sqrt(var + bn["eps"])
+    y = ops.exp(log_gamma) * x_hat + beta
+    ladj = log_gamma - 0.5 * ops.log(var + bn["eps"])
+    return y, ladj.sum()
+
+
+def realnvp_step(ops, spec, step, x):
+    """RealNVP.forward: models/transformations.py:560-579 (note the half swap when flipped)."""
+    d = spec["d"]
+    if step["bn"] is not None:
+        x, bn_ld = batch_norm_eval(ops, step["bn"], x)
+    else:
+        bn_ld = 0.0
+    lo, hi = x[:, : d // 2], x[:, d // 2:]
+    if step["flipped"]:
+        z2, z1 = lo, hi
+    else:
+        z1, z2 = lo, hi
+    shift = coupling_net(ops, step["t_net"], z1)
+    scale = coupling_net(ops, step["s_net"], z1)
+    z2 = shift + z2 * ops.exp(scale)
+    return ops.cat([z1, z2]), ops.sum1(scale) + bn_ld
+
+
+# --------------------------------------------------------------------------
+# component / mixture level
+# --------------------------------------------------------------------------
+def component_forward(spec, x, backend="torch", return_steps=False):
+    """One boosted component: x (N,d) -> z (N,d), ldj (N,).
+
+    glow:    Glow.encode tabular branch + FlowNet.encode, models/glow.py:92-110, 249-252
+    realnvp: RealNVPFlow.encode, models/realnvp.py:115-127
+    Reached through BoostedFlow.forward/encode, models/boosted_flow.py:220-228.
+    """
+    ops = _ops(backend)
+    z = ops.arr(x)
+    ld = ops.zeros(z.shape[0])
+    trace = []
+    for step in spec["steps"]:
+        if spec["kind"] == "glow":
+            z, ld = glow_step(ops, spec, step, z, ld)
+        elif spec["kind"] == "realnvp":
+            z, step_ld = realnvp_step(ops, spec, step, z)
+            ld = ld + step_ld
+        else:
+            raise ValueError(spec["kind"])
+        if return_steps:
+            trace.append((ops.to_numpy(z).copy(), ops.to_numpy(ld).copy()))
+    if return_steps:
+        return ops.to_numpy(z), ops.to_numpy(ld), trace
+    return ops.to_numpy(z), ops.to_numpy(ld)
+
+
+def log_normal_standard_sum(ops, z):
+    """log_normal_standard(z, reduce=True, dim=-1): utils/distributions.py:44-60."""
+    log_norm = (-0.5 * LOG_2PI) - (0.5 * z * z)
+    return ops.sum1(log_norm)
+
+
+def log_normal_base_sum(ops, z, mean, std):
+    """model.base_dist.log_prob(z).sum(1) with base_dist = Normal(base_dist_mean, base_dist_var)
+    (models/generative_flow.py:22-23, 38-42 -- the buffer named ``_var`` is used as the scale;
+    toy_experiment.py:424).  torch.distributions.Normal.log_prob:
+    -(z-mu)^2 / (2 sigma^2) - log(sigma) - log(sqrt(2 pi))."""
+    mean = ops.arr(mean)
+    std = ops.arr(std)
+    var = std * std
+    lp = -((z - mean) * (z - mean)) / (2 * var) - ops.log(std) - math.log(math.sqrt(2 * math.pi))
+    return ops.sum1(lp)
+
+
+def component_log_prob(spec, x, backend="torch", base=None):
+    """ll_c(x) = log N(z;0,I) + ldj   (density_experiment.py:565).
+    ``base=(mean, std)`` switches to the toy driver's base density."""
+    ops = _ops(backend)
+    z, ld = component_forward(spec, x, backend)
+    if base is not None:
+        return ops.to_numpy(log_normal_base_sum(ops, ops.arr(z), base[0], base[1]) + ops.arr(ld))
+    return ops.to_numpy(log_normal_standard_sum(ops, ops.arr(z)) + ops.arr(ld))
+
+
+def mixture_recursion(ll, rho, backend="torch"):
+    """Recursive prefix-normalised 2-way logsumexp of density_experiment.py:561-573.
+
+    ll: (C_used, N) per-component log-densities, rho: (>=C_used,) raw weights.
+    G_0 = ll_0;  r_c = rho_c / sum(rho[0..c]);
+    G_c = logsumexp([log(1-r_c) + G_{c-1}, log(r_c) + ll_c]).
+    """
+    ops = _ops(backend)
+    ll = ops.arr(ll)
+    rho = ops.arr(rho)
+    G = ll[0]
+    for c in range(1, ll.shape[0]):
+        simplex = rho[0:c + 1] / rho[0:c + 1].sum()
+        last = ops.log(1 - simplex[c]) + G
+        nxt = ops.log(simplex[c]) + ll[c]
+        G = ops.lse2(last, nxt)
+    return ops.to_numpy(G)
+
+
+def mixture_log_prob(specs, rho, x, n_used=None, backend="torch", base=None):
+    """The measured path: all used components, then the mixture recursion.
+
+    Mirrors density_experiment.evaluate's loop (density_experiment.py:561-573).
+    Returns (ll (C_used,N), G (N,)).
+    """
+    n_used = len(specs) if n_used is None else n_used
+    ll = np.stack([component_log_prob(specs[c], x, backend, base) for c in range(n_used)], axis=0)
+    return ll, mixture_recursion(ll, rho, backend)
+
+
+def rho_init(num_components, kind="decreasing"):
+    """BoostedFlow.__init__ rho buffer: models/boosted_flow.py:32-39."""
+    if kind == "decreasing":
+        c = np.arange(num_components, dtype=np.float32)
+        return np.maximum(np.float32(1.0) / np.power(np.float32(2.0), c), np.float32(0.05)).astype(np.float32)
+    return np.full(num_components, 1.0 / num_components, dtype=np.float32)
+
+
+def permute_indices_reverse(d):
+    """PermuteNd with shuffle=False: models/layers.py:636 (reversed arange)."""
+    return np.arange(d - 1, -1, -1, dtype=np.int64)
+
+
+def permute_inverse(indices):
+    """PermuteNd.indices_inverse: models/layers.py:639-640, 650-651."""
+    inv = np.zeros_like(indices)
+    for i in range(len(indices)):
+        inv[indices[i]] = i
+    return inv

@@ -1,0 +1,71 @@
+import glob
+import json
+import os
+import sys
+
+import numpy as np
+import pytest
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if REPO not in sys.path:
+    sys.path.insert(0, REPO)
+
+GOLDEN_DIR = os.path.join(REPO, "tests", "golden")
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+def golden_names():
+    return sorted(os.path.splitext(os.path.basename(p))[0] for p in glob.glob(os.path.join(GOLDEN_DIR, "*.npz")))
+
+
+class GoldenCase:
+    """A fixture written by tests/golden/make_golden.py (outputs of the reference itself)."""
+
+    def __init__(self, name):
+        from gbnf_amd import spec as gspec
+        from gbnf_amd import synth
+        self.name = name
+        self.data = dict(np.load(os.path.join(GOLDEN_DIR, name + ".npz")))
+        self.cfg = json.loads(bytes(self.data["config"]).decode())
+        cfg = self.cfg
+        self.rho = self.data["rho"]
+        self.n_used = cfg.get("n_used", cfg["C"])
+        if cfg["case"] == "native":
+            self.x = self.data["x"]
+            self.specs = [gspec.unflatten_spec(self.data, prefix=f"c{c}.") for c in range(cfg["C"])]
+        else:
+            self.x = synth.synth_batch(cfg["N"], cfg["d"], seed=cfg["x_seed"], scale=cfg.get("x_scale", 1.0))
+            self.specs = synth.synth_boosted_specs(cfg["kind"], cfg["C"], cfg["d"], cfg["h"], cfg["K"],
+                                                   seed=cfg["w_seed"], **cfg["synth_kw"])
+        self.base = None
+        if cfg["case"] == "toy":
+            self.base = (self.data["base_mean"], self.data["base_std"])
+        self.ll = self.data["ll"]
+        self.ldj = self.data["ldj"]
+        self.G = self.data["G"]
+
+    def z(self, c):
+        if "z" in self.data:
+            return self.data["z"][c]
+        return self.data["z_c0"] if c == 0 else None
+
+
+@pytest.fixture(scope="session")
+def golden_case():
+    cache = {}
+
+    def get(name):
+        if name not in cache:
+            cache[name] = GoldenCase(name)
+        return cache[name]
+    return get
+
+
+def rel_err(a, b):
+    """max |a-b| / max(|b|, 1) -- the 1e-5 relative log-likelihood bar of BASELINE.json."""
+    a = np.asarray(a, dtype=np.float64)
+    b = np.asarray(b, dtype=np.float64)
+    return float(np.max(np.abs(a - b) / np.maximum(np.abs(b), 1.0))) if a.size else 0.0

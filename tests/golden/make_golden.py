@@ -1,0 +1,259 @@
+#!/usr/bin/env python3
+"""Generate the golden fixtures in this directory by running THE REFERENCE itself.
+
+Run in the build container only (needs /root/reference, torch CPU):
+
+    PYTHONDONTWRITEBYTECODE=1 python tests/golden/make_golden.py
+
+It imports the reference's ``BoostedFlow`` (models/boosted_flow.py), builds models
+from a hand-made ``args`` Namespace (the fields its constructors read, SURVEY.md
+section 5), installs parameters, runs ``model(x=x, components=c)`` exactly as
+``density_experiment.evaluate`` does (density_experiment.py:561-573) and stores
+inputs + outputs as small ``.npz`` files.  Only data is committed -- no reference
+source or bytecode.  The reference has no tests or golden vectors of its own
+(SURVEY.md section 4); these files are the parity pin for ``oracle/`` and, through
+it and directly, for the HIP path.
+
+Two kinds of case:
+  * "synth" -- parameters come from this repo's portable generator
+    (``gbnf_amd.synth``) and are loaded INTO the reference modules; the fixture
+    stores only the generator arguments + x + the reference's outputs.
+  * "native" -- the reference initialises itself (its own nn.Linear init, ActNorm
+    data-dependent init on a batch in train mode, then a small perturbation); the
+    fixture stores the exported parameters too (exercises the module->spec export).
+"""
+import argparse
+import json
+import os
+import sys
+
+sys.dont_write_bytecode = True
+HERE = os.path.dirname(os.path.abspath(__file__))
+REPO = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, REPO)
+sys.path.insert(0, "/root/reference")
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+from gbnf_amd import spec as gspec  # noqa: E402
+from gbnf_amd import synth  # noqa: E402
+from models.boosted_flow import BoostedFlow as RefBoostedFlow  # noqa: E402  (the reference)
+from utils.distributions import log_normal_standard  # noqa: E402  (the reference)
+
+
+def ref_args(kind, d, h, K, C, depth=1, coupling_network="tanh", coupling="affine",
+             permutation="shuffle", batch_norm=True, rho_init="decreasing"):
+    return argparse.Namespace(
+        num_flows=K, z_size=d, density_evaluation=True, device=torch.device("cpu"), cuda=False,
+        component_type=kind, num_components=C, rho_init=rho_init, learn_top=False, y_classes=0,
+        y_condition=False, sample_size=4, input_size=[d], h_size=h, num_blocks=1, actnorm_scale=1.0,
+        flow_permutation=permutation, flow_coupling=coupling, LU_decomposed=False,
+        num_dequant_blocks=0, coupling_network=coupling_network, coupling_network_depth=depth,
+        batch_norm=batch_norm)
+
+
+def _load_net(ref_net, net):
+    linears = [m for m in ref_net.network if isinstance(m, torch.nn.Linear)]
+    assert len(linears) == len(net["layers"])
+    for m, (w, b) in zip(linears, net["layers"]):
+        assert tuple(m.weight.shape) == w.shape, (m.weight.shape, w.shape)
+        m.weight.data.copy_(torch.from_numpy(w))
+        m.bias.data.copy_(torch.from_numpy(b))
+
+
+def install_spec(ref_component, spec):
+    """Load a flow spec's numbers into a reference Glow / RealNVPFlow module."""
+    if spec["kind"] == "glow":
+        for layer, st in zip(ref_component.flow.layers, spec["steps"]):
+            layer.actnorm.bias.data.copy_(torch.from_numpy(st["an_bias"]).view(1, -1))
+            layer.actnorm.logs.data.copy_(torch.from_numpy(st["an_logs"]).view(1, -1))
+            layer.actnorm.inited = True
+            perm_mod = layer.shuffle if hasattr(layer, "shuffle") else layer.reverse
+            perm_mod.indices = torch.from_numpy(st["perm"]).long()
+            for i in range(perm_mod.num_dim):
+                perm_mod.indices_inverse[perm_mod.indices[i]] = i
+            _load_net(layer.block, st["net"])
+    else:
+        for k, (mods, st) in enumerate(zip(ref_component.flow_param, spec["steps"])):
+            assert (((k + ref_component.flip_init) % 2) > 0) == st["flipped"]
+            _load_net(mods[0], st["t_net"])
+            _load_net(mods[1], st["s_net"])
+            if st["bn"] is None:
+                assert mods[2] is None
+            else:
+                bn = mods[2]
+                bn.log_gamma.data.copy_(torch.from_numpy(st["bn"]["log_gamma"]))
+                bn.beta.data.copy_(torch.from_numpy(st["bn"]["beta"]))
+                bn.running_mean.copy_(torch.from_numpy(st["bn"]["running_mean"]))
+                bn.running_var.copy_(torch.from_numpy(st["bn"]["running_var"]))
+
+
+@torch.no_grad()
+def run_reference(model, x, n_used, base="standard", per_step=False):
+    """density_experiment.evaluate's exact loop (density_experiment.py:561-573);
+    base="toy" uses model.base_dist as toy_experiment.py:413-429 does."""
+    model.eval()
+    xt = torch.from_numpy(x)
+    zs, ldjs, lls = [], [], []
+    G = None
+    for c in range(n_used):
+        z, _, _, ldj, _ = model(x=xt.clone(), components=c)
+        if base == "toy":
+            ll = model.base_dist.log_prob(z).sum(1) + ldj
+        else:
+            ll = log_normal_standard(z, reduce=True, dim=-1, device=torch.device("cpu")) + ldj
+        if c == 0:
+            G = ll
+        else:
+            rho_simplex = model.rho[0:(c + 1)] / torch.sum(model.rho[0:(c + 1)])
+            last_ll = torch.log(1 - rho_simplex[c]) + G
+            next_ll = torch.log(rho_simplex[c]) + ll
+            G = torch.logsumexp(torch.cat([last_ll.view(-1, 1), next_ll.view(-1, 1)], dim=1), dim=1)
+        zs.append(z.numpy().copy())
+        ldjs.append(ldj.numpy().copy())
+        lls.append(ll.numpy().copy())
+    return np.stack(zs), np.stack(ldjs), np.stack(lls), G.numpy().copy()
+
+
+@torch.no_grad()
+def glow_step_trace(component, x):
+    """Per-FlowStep (z, logdet) of one reference Glow component (kernel bring-up aid)."""
+    z = torch.from_numpy(x).clone()
+    ld = torch.zeros(z.shape[0])
+    zs, lds = [], []
+    for layer in component.flow.layers:
+        z, ld = layer(z, ld, reverse=False)
+        zs.append(z.numpy().copy())
+        lds.append(ld.numpy().copy())
+    return np.stack(zs), np.stack(lds)
+
+
+def synth_case(name, kind, d, h, K, C, N, x_seed=0, w_seed=1, x_scale=1.0, n_used=None,
+               rho_init="decreasing", rho_override=None, **kw):
+    ref_kw = {}
+    synth_kw = {}
+    depth = kw.get("depth", 1)
+    if kind == "glow":
+        synth_kw = dict(depth=depth, act=kw.get("act", "tanh"), coupling=kw.get("coupling", "affine"),
+                        permutation=kw.get("permutation", "shuffle"), gain=kw.get("gain", 1.0))
+        ref_kw = dict(depth=depth, coupling_network=synth_kw["act"], coupling=synth_kw["coupling"],
+                      permutation=synth_kw["permutation"])
+    else:
+        synth_kw = dict(depth=depth, coupling_network=kw.get("coupling_network", "tanh"),
+                        batch_norm=kw.get("batch_norm", True), gain=kw.get("gain", 1.0))
+        ref_kw = dict(depth=depth, coupling_network=synth_kw["coupling_network"],
+                      batch_norm=synth_kw["batch_norm"])
+    torch.manual_seed(1234)
+    model = RefBoostedFlow(ref_args(kind, d, h, K, C, rho_init=rho_init, **ref_kw))
+    specs = synth.synth_boosted_specs(kind, C, d, h, K, seed=w_seed, **synth_kw)
+    for c in range(C):
+        install_spec(model.flows[c], specs[c])
+        # round-trip: exporting the reference module must give back the same numbers
+        back = gspec.spec_from_component(model.flows[c])
+        fa, fb = gspec.flatten_spec(specs[c]), gspec.flatten_spec(back)
+        assert fa.keys() == fb.keys()
+        for key in fa:
+            assert np.array_equal(fa[key], fb[key]), key
+    if rho_override is not None:
+        model.rho.copy_(torch.tensor(rho_override, dtype=torch.float32))
+    x = synth.synth_batch(N, d, seed=x_seed, scale=x_scale)
+    n_used = C if n_used is None else n_used
+    z, ldj, ll, G = run_reference(model, x, n_used)
+    cfg = dict(case="synth", kind=kind, d=d, h=h, K=K, C=C, N=N, x_seed=x_seed, w_seed=w_seed,
+               x_scale=x_scale, n_used=n_used, synth_kw=synth_kw)
+    out = dict(config=np.frombuffer(json.dumps(cfg).encode(), dtype=np.uint8),
+               rho=model.rho.numpy().copy(), ldj=ldj, ll=ll, G=G)
+    # z for every component is bulky at full width: keep all of it for small cases only
+    if z.nbytes <= 400_000:
+        out["z"] = z
+    else:
+        out["z_c0"] = z[0]
+    if kind == "glow" and h <= 64:
+        zs, lds = glow_step_trace(model.flows[0], x)
+        out["trace_z_c0"] = zs
+        out["trace_ld_c0"] = lds
+    np.savez_compressed(os.path.join(HERE, name + ".npz"), **out)
+    print(f"{name}: ll[0,:3]={ll[0, :3]}  G[:3]={G[:3]}  finite={np.isfinite(G).all()}")
+
+
+def native_glow_case(name, d=43, h=32, K=5, C=3, N=256):
+    """G2: the reference initialises itself (ActNorm data init + perturbed Linear weights)."""
+    torch.manual_seed(7)
+    np.random.seed(7)
+    model = RefBoostedFlow(ref_args("glow", d, h, K, C))
+    x = synth.synth_batch(N, d, seed=11)
+    model.train()
+    with torch.no_grad():
+        for c in range(C):   # ActNorm data-dependent init, density_experiment.py:346-356
+            model(x=torch.from_numpy(x).clone(), components=c)
+        for p in model.parameters():
+            p.add_(0.05 * torch.randn_like(p))
+    model.eval()
+    specs = [gspec.spec_from_component(model.flows[c]) for c in range(C)]
+    z, ldj, ll, G = run_reference(model, x, C)
+    zs, lds = glow_step_trace(model.flows[0], x)
+    cfg = dict(case="native", kind="glow", d=d, h=h, K=K, C=C, N=N, x_seed=11)
+    out = dict(config=np.frombuffer(json.dumps(cfg).encode(), dtype=np.uint8),
+               rho=model.rho.numpy().copy(), x=x, z=z, ldj=ldj, ll=ll, G=G,
+               trace_z_c0=zs, trace_ld_c0=lds)
+    for c in range(C):
+        out.update(gspec.flatten_spec(specs[c], prefix=f"c{c}."))
+    np.savez_compressed(os.path.join(HERE, name + ".npz"), **out)
+    print(f"{name}: ll[0,:3]={ll[0, :3]}  G[:3]={G[:3]}")
+
+
+def toy_case(name, N=64):
+    """G1: 8-Gaussians-shaped toy config: d=2 RealNVP C=2 K=1 h=64, uniform rho,
+    base density = model.base_dist = Normal(base_dist_mean, 3.0) (toy_experiment.py:413-429)."""
+    torch.manual_seed(3)
+    d, h, K, C = 2, 64, 1, 2
+    model = RefBoostedFlow(ref_args("realnvp", d, h, K, C, batch_norm=False, rho_init="uniform"))
+    specs = synth.synth_boosted_specs("realnvp", C, d, h, K, seed=5, batch_norm=False)
+    for c in range(C):
+        install_spec(model.flows[c], specs[c])
+    x = synth.synth_batch(N, d, seed=2, scale=2.0)
+    z, ldj, ll, G = run_reference(model, x, C, base="toy")
+    cfg = dict(case="toy", kind="realnvp", d=d, h=h, K=K, C=C, N=N, x_seed=2, w_seed=5, x_scale=2.0,
+               n_used=C, synth_kw=dict(batch_norm=False))
+    np.savez_compressed(
+        os.path.join(HERE, name + ".npz"),
+        config=np.frombuffer(json.dumps(cfg).encode(), dtype=np.uint8), rho=model.rho.numpy().copy(),
+        base_mean=model.base_dist_mean.numpy().copy(), base_std=model.base_dist_var.numpy().copy(),
+        z=z, ldj=ldj, ll=ll, G=G)
+    print(f"{name}: ll[0,:3]={ll[0, :3]}  G[:3]={G[:3]}")
+
+
+def main():
+    torch.set_num_threads(4)
+    toy_case("g1_toy_realnvp_c2")
+    native_glow_case("g2_glow_native_d43_h32_c3")
+    # G3: MINIBOONE full width (BASELINE.json metric config), synthetic weights
+    synth_case("g3_glow_d43_h215_c8", "glow", 43, 215, 5, 8, 256)
+    # G4: HEPMASS RealNVP, flip_init 0..7, BN with non-trivial running stats
+    synth_case("g4_realnvp_d21_h105_c8", "realnvp", 21, 105, 5, 8, 256)
+    synth_case("g4_realnvp_d21_h105_c2_mixed", "realnvp", 21, 105, 5, 2, 128, coupling_network="mixed")
+    synth_case("g4_realnvp_d21_h105_c2_relu_nobn", "realnvp", 21, 105, 3, 2, 128,
+               coupling_network="relu", batch_norm=False)
+    # G5: variants
+    synth_case("g5_glow_d43_h64_c2_additive", "glow", 43, 64, 5, 2, 128, coupling="additive")
+    synth_case("g5_glow_d43_h64_c2_reverse_relu", "glow", 43, 64, 5, 2, 128, permutation="reverse", act="relu")
+    synth_case("g5_glow_d43_h64_c2_depth2", "glow", 43, 64, 3, 2, 128, depth=2)
+    synth_case("g5_glow_d43_h64_c2_depth0", "glow", 43, 64, 3, 2, 128, depth=0)
+    synth_case("g5_glow_d6_h30_c2", "glow", 6, 30, 5, 2, 128)        # POWER
+    synth_case("g5_glow_d8_h40_c2", "glow", 8, 40, 5, 2, 128)        # GAS
+    synth_case("g5_glow_d21_h105_c2", "glow", 21, 105, 5, 2, 128)    # HEPMASS with Glow
+    synth_case("g5_glow_d63_h128_c2", "glow", 63, 128, 3, 2, 128)    # BSDS300 width class
+    synth_case("g5_realnvp_d43_h215_c2", "realnvp", 43, 215, 5, 2, 128)
+    synth_case("g5_realnvp_d6_h30_c3", "realnvp", 6, 30, 5, 3, 128)
+    # G6: edge cases
+    synth_case("g6_glow_d43_h64_n1", "glow", 43, 64, 5, 2, 1)
+    synth_case("g6_glow_d43_h64_n77", "glow", 43, 64, 5, 2, 77)      # not a tile multiple
+    synth_case("g6_glow_d43_h64_bigx", "glow", 43, 64, 5, 2, 96, x_scale=6.0, gain=3.0)  # saturating tanh/sigmoid
+    synth_case("g6_glow_d43_h64_c4_used2", "glow", 43, 64, 5, 4, 64, n_used=2)           # loaded < C
+    synth_case("g6_realnvp_d21_h64_n33", "realnvp", 21, 64, 5, 3, 33)
+    synth_case("g6_glow_d43_h64_c3_rho", "glow", 43, 64, 5, 3, 64, rho_override=[0.7, 3.0, 0.01])
+
+
+if __name__ == "__main__":
+    main()

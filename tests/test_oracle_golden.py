@@ -1,0 +1,62 @@
+"""CPU: the oracle restatement against every golden vector produced by the reference."""
+import numpy as np
+import pytest
+
+from conftest import golden_names, rel_err
+from oracle import gbnf_oracle as oracle
+
+LL_RTOL = 1e-5     # BASELINE.json: log-likelihood within 1e-5 relative
+TORCH_RTOL = 2e-6  # the torch back-end uses the reference's own aten kernels
+
+
+@pytest.mark.parametrize("name", golden_names())
+def test_oracle_torch_matches_reference(name, golden_case):
+    g = golden_case(name)
+    ll, G = oracle.mixture_log_prob(g.specs, g.rho, g.x, n_used=g.n_used, backend="torch", base=g.base)
+    assert ll.shape == g.ll.shape
+    assert rel_err(ll, g.ll) < TORCH_RTOL
+    assert rel_err(G, g.G) < TORCH_RTOL
+    for c in range(g.n_used):
+        z, ldj = oracle.component_forward(g.specs[c], g.x, backend="torch")
+        assert rel_err(ldj, g.ldj[c]) < TORCH_RTOL
+        if g.z(c) is not None:
+            np.testing.assert_allclose(z, g.z(c), rtol=0, atol=2e-5 * max(1.0, np.abs(g.z(c)).max()))
+
+
+@pytest.mark.parametrize("name", golden_names())
+def test_oracle_float64_matches_reference(name, golden_case):
+    """fp64 numpy restatement: anchors the fp32 noise floor of the reference itself."""
+    g = golden_case(name)
+    ll, G = oracle.mixture_log_prob(g.specs, g.rho, g.x, n_used=g.n_used, backend="numpy64", base=g.base)
+    assert rel_err(ll, g.ll) < LL_RTOL
+    assert rel_err(G, g.G) < LL_RTOL
+
+
+def test_step_trace_matches_reference(golden_case):
+    g = golden_case("g2_glow_native_d43_h32_c3")
+    z, ldj, trace = oracle.component_forward(g.specs[0], g.x, backend="torch", return_steps=True)
+    for k, (zk, ldk) in enumerate(trace):
+        np.testing.assert_allclose(zk, g.data["trace_z_c0"][k], rtol=0, atol=1e-5)
+        np.testing.assert_allclose(ldk, g.data["trace_ld_c0"][k], rtol=0, atol=2e-5)
+
+
+def test_one_shot_lse_equals_recursion(golden_case):
+    """LSE_c(ll_c + log(rho_c / sum rho)) == the recursive form."""
+    g = golden_case("g3_glow_d43_h215_c8")
+    rho = g.rho[: g.n_used].astype(np.float64)
+    lw = np.log(rho / rho.sum())
+    a = g.ll.astype(np.float64) + lw[:, None]
+    m = a.max(axis=0)
+    one_shot = m + np.log(np.exp(a - m).sum(axis=0))
+    assert rel_err(one_shot, g.G) < 5e-6
+
+
+def test_rho_init_and_permutations():
+    # models/boosted_flow.py:32-39: clamp(2^-c, min=0.05)
+    np.testing.assert_array_equal(
+        oracle.rho_init(8), np.array([1, .5, .25, .125, .0625, .05, .05, .05], dtype=np.float32))
+    np.testing.assert_allclose(oracle.rho_init(4, "uniform"), 0.25)
+    idx = oracle.permute_indices_reverse(5)
+    np.testing.assert_array_equal(idx, [4, 3, 2, 1, 0])
+    inv = oracle.permute_inverse(np.array([2, 0, 3, 1]))
+    np.testing.assert_array_equal(inv, [1, 3, 0, 2])
