@@ -17,13 +17,9 @@ __all__ = ["spec", "synth", "native", "BoostedFlow"]
 def __getattr__(name):
     # lazy so that ``import gbnf_amd`` works on a box where torch / the .so are absent;
     # anything that computes fails loudly inside ``native``.
-    if name == "native":
-        from . import native as _n
-        return _n
-    if name in ("BoostedFlow", "boosted_flow"):
-        from . import boosted_flow as _b
-        return _b if name == "boosted_flow" else _b.BoostedFlow
-    if name == "sharded":
-        from . import sharded as _s
-        return _s
+    import importlib
+    if name in ("native", "boosted_flow", "sharded"):
+        return importlib.import_module(__name__ + "." + name)
+    if name == "BoostedFlow":
+        return importlib.import_module(__name__ + ".boosted_flow").BoostedFlow
     raise AttributeError(name)

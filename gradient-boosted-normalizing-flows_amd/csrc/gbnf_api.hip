@@ -1,0 +1,614 @@
+// gbnf_api.hip -- C ABI of libgbnf_hip.so (include/gbnf.h): descriptor validation, host-side
+// parameter packing into MFMA fragment order, variant dispatch, the mixture log-sum-exp kernel.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "gbnf_flow_kernel.hip.h"
+
+namespace gbnf {
+
+// ------------------------------------------------------------------ error reporting
+static thread_local std::string g_err;
+
+static int fail(int code, const char* fmt, ...) {
+  char buf[512];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof(buf), fmt, ap);
+  va_end(ap);
+  g_err = buf;
+  return code;
+}
+
+#define GBNF_HIP(call)                                                                     \
+  do {                                                                                     \
+    hipError_t e_ = (call);                                                                \
+    if (e_ != hipSuccess) return fail(GBNF_ERR_HIP, "%s failed: %s", #call, hipGetErrorString(e_)); \
+  } while (0)
+
+// ------------------------------------------------------------------ variant registry
+struct Variant {
+  VariantKey key;
+  LaunchFn fn;
+  const char* name;
+};
+static std::vector<Variant>& variants() {
+  static std::vector<Variant> v;
+  return v;
+}
+void register_variant(const VariantKey& key, LaunchFn fn, const char* name) {
+  variants().push_back(Variant{key, fn, name});
+}
+
+// ------------------------------------------------------------------ handles
+struct NetDims {
+  int in_f = 0, hidden = 0, out_f = 0, depth = 0, act = 0;
+};
+
+}  // namespace gbnf
+
+struct gbnf_flow {
+  int kind = 0, d = 0, n_steps = 0, additive = 0;
+  int hidden = 0, depth = 0, act_a = 0, act_b = 0;
+  int ht = 0, ksl = 0, ot = 0;     // tile geometry (exact)
+  int var_ht = 0, var_ksl = 0, var_ot = 0;  // geometry of the compiled variant the blob was packed for
+  gbnf::LaunchFn launch_nt[3] = {nullptr, nullptr, nullptr};  // index = NT
+  const char* name_nt[3] = {nullptr, nullptr, nullptr};
+  uint32_t* blob_dev = nullptr;
+  const uint32_t** self_table_dev = nullptr;  // 1-entry blob table for single-flow launches
+  size_t blob_words = 0;
+  double macs = 0, padded_macs = 0;
+};
+
+struct gbnf_mixture {
+  std::vector<gbnf_flow*> flows;
+  const uint32_t** table_dev = nullptr;
+  float* base_dev = nullptr;  // [2][d] mean, std or null
+};
+
+namespace gbnf {
+
+static int ceil_div(int a, int b) { return (a + b - 1) / b; }
+
+// physical hidden position p = 16 t + 4 g + r  <->  logical unit 4*(4t + r) + g
+static int phys_to_logical(int p, int h) {
+  const int t = p / 16, gg = (p % 16) / 4, r = p % 4;
+  const int l = 4 * (4 * t + r) + gg;
+  return l < h ? l : -1;
+}
+
+static int check_net(const gbnf_net& net, int in_f, int out_f, NetDims* dims, const char* what) {
+  if (net.n_layers < 2 || net.layers == nullptr)
+    return fail(GBNF_ERR_INVALID, "%s: coupling network needs >= 2 Linear layers", what);
+  if (net.activation != GBNF_ACT_TANH && net.activation != GBNF_ACT_RELU)
+    return fail(GBNF_ERR_UNSUPPORTED, "%s: activation %d not supported (tanh / relu only; the reference's "
+                "ResidualNet is not on the supported path)", what, net.activation);
+  const int h = net.layers[0].out_features;
+  for (int l = 0; l < net.n_layers; ++l) {
+    const gbnf_linear& lin = net.layers[l];
+    const int want_in = (l == 0) ? in_f : h;
+    const int want_out = (l == net.n_layers - 1) ? out_f : h;
+    if (lin.weight == nullptr || lin.bias == nullptr)
+      return fail(GBNF_ERR_INVALID, "%s: layer %d has a null weight/bias", what, l);
+    if (lin.in_features != want_in || lin.out_features != want_out)
+      return fail(GBNF_ERR_INVALID, "%s: layer %d is %dx%d, expected %dx%d", what, l, lin.out_features,
+                  lin.in_features, want_out, want_in);
+  }
+  dims->in_f = in_f; dims->hidden = h; dims->out_f = out_f;
+  dims->depth = net.n_layers - 2; dims->act = net.activation;
+  return GBNF_OK;
+}
+
+// Pack one coupling network at word offset `base` of `blob` for variant geometry (HT, OT, LMID).
+// `paired_out` is informational only: the affine "cross" layout equals natural row order.
+static void pack_net(std::vector<uint32_t>& blob, size_t base, const gbnf_net& net, int HT, int OT, int LMID,
+                     int in_f, int h, int out_f) {
+  auto put = [&](size_t off, float v) { std::memcpy(&blob[base + off], &v, 4); };
+  const size_t W1 = 0;
+  const size_t B1 = W1 + (size_t)(KS1MAX + 1) * HT * 64;
+  const size_t MID0 = B1 + (size_t)HT * 16;
+  const size_t MID_W = (size_t)(HT + 1) * HT * 256;
+  const size_t MID_STRIDE = MID_W + (size_t)HT * 16;
+  const size_t W3 = MID0 + (size_t)LMID * MID_STRIDE;
+  const size_t B3 = W3 + (size_t)(HT + 1) * OT * 256;
+
+  // layer 0: A fragment for (k-step s, tile t): lane (i,g) = W0[unit(16t+i)][k = 4s+g]
+  const gbnf_linear& l0 = net.layers[0];
+  for (int s = 0; s < KS1MAX; ++s)
+    for (int t = 0; t < HT; ++t)
+      for (int lane = 0; lane < 64; ++lane) {
+        const int i = lane & 15, gg = lane >> 4;
+        const int u = phys_to_logical(16 * t + i, h), k = 4 * s + gg;
+        float v = 0.0f;
+        if (u >= 0 && k < in_f) v = l0.weight[(size_t)u * in_f + k];
+        put(W1 + ((size_t)s * HT + t) * 64 + lane, v);
+      }
+  for (int t = 0; t < HT; ++t)
+    for (int gg = 0; gg < 4; ++gg)
+      for (int r = 0; r < 4; ++r) {
+        const int u = phys_to_logical(16 * t + 4 * gg + r, h);
+        put(B1 + (size_t)t * 16 + gg * 4 + r, u >= 0 ? l0.bias[u] : 0.0f);
+      }
+  // hidden -> hidden layers: A fragment for (out tile u, k-chunk t): lane (i,g) reg r =
+  //   W[unit(16u+i)][unit(16t+4g+r)]
+  for (int m = 0; m < LMID; ++m) {
+    const gbnf_linear& lm = net.layers[1 + m];
+    const size_t wb = MID0 + (size_t)m * MID_STRIDE;
+    for (int u = 0; u < HT; ++u)
+      for (int t = 0; t < HT; ++t)
+        for (int lane = 0; lane < 64; ++lane) {
+          const int i = lane & 15, gg = lane >> 4;
+          const int uo = phys_to_logical(16 * u + i, h);
+          for (int r = 0; r < 4; ++r) {
+            const int ui = phys_to_logical(16 * t + 4 * gg + r, h);
+            float v = 0.0f;
+            if (uo >= 0 && ui >= 0) v = lm.weight[(size_t)uo * h + ui];
+            put(wb + (((size_t)u * HT + t) * 64 + lane) * 4 + r, v);
+          }
+        }
+    for (int u = 0; u < HT; ++u)
+      for (int gg = 0; gg < 4; ++gg)
+        for (int r = 0; r < 4; ++r) {
+          const int uo = phys_to_logical(16 * u + 4 * gg + r, h);
+          put(wb + MID_W + (size_t)u * 16 + gg * 4 + r, uo >= 0 ? lm.bias[uo] : 0.0f);
+        }
+  }
+  // last layer: A fragment for (k-chunk u, out tile o): lane (i,g) reg r = W[row 16o+i][unit(16u+4g+r)]
+  const gbnf_linear& ll = net.layers[net.n_layers - 1];
+  for (int u = 0; u < HT; ++u)
+    for (int o = 0; o < OT; ++o)
+      for (int lane = 0; lane < 64; ++lane) {
+        const int i = lane & 15, gg = lane >> 4;
+        const int row = 16 * o + i;
+        for (int r = 0; r < 4; ++r) {
+          const int ui = phys_to_logical(16 * u + 4 * gg + r, h);
+          float v = 0.0f;
+          if (row < out_f && ui >= 0) v = ll.weight[(size_t)row * h + ui];
+          put(W3 + (((size_t)u * OT + o) * 64 + lane) * 4 + r, v);
+        }
+      }
+  for (int o = 0; o < OT; ++o)
+    for (int gg = 0; gg < 4; ++gg)
+      for (int r = 0; r < 4; ++r) {
+        const int row = 16 * o + 4 * gg + r;
+        put(B3 + (size_t)o * 16 + gg * 4 + r, row < out_f ? ll.bias[row] : 0.0f);
+      }
+}
+
+static size_t net_words(int HT, int OT, int LMID) {
+  const size_t B1 = (size_t)(KS1MAX + 1) * HT * 64;
+  const size_t MID0 = B1 + (size_t)HT * 16;
+  const size_t MID_STRIDE = (size_t)(HT + 1) * HT * 256 + (size_t)HT * 16;
+  const size_t W3 = MID0 + (size_t)LMID * MID_STRIDE;
+  const size_t B3 = W3 + (size_t)(HT + 1) * OT * 256;
+  return B3 + (size_t)OT * 16;
+}
+
+static const Variant* find_variant(const VariantKey& k) {
+  for (const Variant& v : variants())
+    if (v.key == k) return &v;
+  return nullptr;
+}
+
+}  // namespace gbnf
+
+using namespace gbnf;
+
+extern "C" {
+
+int gbnf_version(void) { return GBNF_ABI_VERSION; }
+
+const char* gbnf_last_error(void) { return g_err.c_str(); }
+
+int gbnf_flow_create(const gbnf_flow_desc* desc, gbnf_flow** out) {
+  if (out == nullptr) return fail(GBNF_ERR_INVALID, "gbnf_flow_create: out is null");
+  *out = nullptr;
+  if (desc == nullptr) return fail(GBNF_ERR_INVALID, "gbnf_flow_create: desc is null");
+  const int d = desc->d, K = desc->n_steps;
+  if (d < 2 || d > ZSLOTS) return fail(GBNF_ERR_UNSUPPORTED, "d=%d outside the supported range [2,%d]", d, ZSLOTS);
+  if (K < 1) return fail(GBNF_ERR_INVALID, "n_steps must be >= 1");
+  if (desc->kind != GBNF_KIND_GLOW && desc->kind != GBNF_KIND_REALNVP)
+    return fail(GBNF_ERR_INVALID, "unknown flow kind %d", desc->kind);
+  const bool glow = desc->kind == GBNF_KIND_GLOW;
+  if (glow && desc->glow_steps == nullptr) return fail(GBNF_ERR_INVALID, "glow_steps is null");
+  if (!glow && desc->realnvp_steps == nullptr) return fail(GBNF_ERR_INVALID, "realnvp_steps is null");
+  const bool additive = glow && desc->coupling == GBNF_COUPLING_ADDITIVE;
+  if (glow && desc->coupling != GBNF_COUPLING_AFFINE && desc->coupling != GBNF_COUPLING_ADDITIVE)
+    return fail(GBNF_ERR_INVALID, "unknown coupling %d", desc->coupling);
+  const int d1 = d / 2, d2 = d - d1;
+
+  // ---- validate every step, collect the common network geometry
+  NetDims ref{};
+  int act_a = 0, act_b = 0;
+  int max_out_entries = 0;
+  for (int s = 0; s < K; ++s) {
+    NetDims a{}, b{};
+    int rc;
+    char what[64];
+    if (glow) {
+      const gbnf_glow_step& st = desc->glow_steps[s];
+      if (!st.actnorm_bias || !st.actnorm_logs || !st.perm_indices)
+        return fail(GBNF_ERR_INVALID, "glow step %d: null actnorm/permutation pointer", s);
+      std::vector<char> seen(d, 0);
+      for (int j = 0; j < d; ++j) {
+        const int64_t v = st.perm_indices[j];
+        if (v < 0 || v >= d || seen[v]) return fail(GBNF_ERR_INVALID, "glow step %d: perm_indices is not a permutation", s);
+        seen[v] = 1;
+      }
+      snprintf(what, sizeof(what), "glow step %d block", s);
+      rc = check_net(st.block, d1, additive ? d2 : 2 * d2, &a, what);
+      if (rc) return rc;
+      b = a;
+    } else {
+      const gbnf_realnvp_step& st = desc->realnvp_steps[s];
+      const int in_f = st.flipped ? d2 : d1, out_f = st.flipped ? d1 : d2;
+      if (st.has_batch_norm && (!st.bn_log_gamma || !st.bn_beta || !st.bn_running_mean || !st.bn_running_var))
+        return fail(GBNF_ERR_INVALID, "realnvp step %d: null batch-norm pointer", s);
+      snprintf(what, sizeof(what), "realnvp step %d t_net", s);
+      rc = check_net(st.t_net, in_f, out_f, &a, what);
+      if (rc) return rc;
+      snprintf(what, sizeof(what), "realnvp step %d s_net", s);
+      rc = check_net(st.s_net, in_f, out_f, &b, what);
+      if (rc) return rc;
+      if (a.hidden != b.hidden || a.depth != b.depth)
+        return fail(GBNF_ERR_UNSUPPORTED, "realnvp step %d: t_net and s_net differ in width/depth", s);
+    }
+    if (s == 0) {
+      ref = a; act_a = a.act; act_b = b.act;
+    } else if (a.hidden != ref.hidden || a.depth != ref.depth || a.act != act_a || b.act != act_b) {
+      return fail(GBNF_ERR_UNSUPPORTED, "step %d: coupling-network width/depth/activation differs from step 0", s);
+    }
+    if (a.in_f > 4 * KS1MAX)
+      return fail(GBNF_ERR_UNSUPPORTED, "coupling-net input width %d > %d", a.in_f, 4 * KS1MAX);
+    const int entries = (glow && !additive) ? ceil_div(a.out_f / 2, 8) * 2 : ceil_div(a.out_f, 16) * 4;
+    if (entries > max_out_entries) max_out_entries = entries;
+  }
+  const int h = ref.hidden, depth = ref.depth;
+  if (depth > 2) return fail(GBNF_ERR_UNSUPPORTED, "coupling_network_depth=%d > 2 has no compiled variant", depth);
+  const int ksh = ceil_div(h, 4);
+  const int ht = ceil_div(ksh, 4), ksl = ksh - 4 * (ht - 1);
+  // out tiles: glow affine -> pairs (shift_j, raw_j): 8 pairs per 16-row tile; else 16 rows per tile
+  const int max_out = glow ? (additive ? d2 : 2 * d2) : d2;  // realnvp: max(d1,d2) = d2
+  const int ot = ceil_div(max_out, 16);
+  if (max_out_entries > NENT || ot > 4)
+    return fail(GBNF_ERR_UNSUPPORTED, "coupled half of %d features exceeds the per-lane table (%d)", max_out, NENT);
+
+  // ---- pick compiled variants (exact geometry first, then the cheapest zero-padded superset)
+  gbnf_flow* f = new gbnf_flow();
+  f->kind = desc->kind; f->d = d; f->n_steps = K; f->additive = additive ? 1 : 0;
+  f->hidden = h; f->depth = depth; f->act_a = act_a; f->act_b = act_b;
+  f->ht = ht; f->ksl = ksl; f->ot = ot;
+  {
+    long best_cost = -1;
+    for (const Variant& v : variants()) {
+      const VariantKey& k = v.key;
+      if (k.kind != desc->kind || k.lmid != depth || k.act_a != act_a || k.act_b != act_b) continue;
+      if (k.ot < ot) continue;
+      // a variant processes hidden k-steps [0, 4(k.ht-1)+k.ksl); ours are [0, 4(ht-1)+ksl); extra ones
+      // multiply zero padding, so any superset is exact (just slower)
+      const bool covers_h = (k.ht > ht) || (k.ht == ht && k.ksl >= ksl);
+      if (!covers_h) continue;
+      // both NT=1 and NT=2 of the same geometry must exist
+      const Variant* v1 = find_variant(VariantKey{k.kind, k.ht, k.ksl, k.ot, 1, k.lmid, k.act_a, k.act_b});
+      const Variant* v2 = find_variant(VariantKey{k.kind, k.ht, k.ksl, k.ot, 2, k.lmid, k.act_a, k.act_b});
+      if (!v1 || !v2) continue;
+      const long cost = (long)(4 * (k.ht - 1) + k.ksl) * (k.ht * 16L * (depth > 0 ? depth : 0) + k.ot * 16L) + k.ht * 16L * 32;
+      if (best_cost < 0 || cost < best_cost) {
+        best_cost = cost;
+        f->var_ht = k.ht; f->var_ksl = k.ksl; f->var_ot = k.ot;
+        f->launch_nt[1] = v1->fn; f->name_nt[1] = v1->name;
+        f->launch_nt[2] = v2->fn; f->name_nt[2] = v2->name;
+      }
+    }
+    if (best_cost < 0) {
+      delete f;
+      return fail(GBNF_ERR_UNSUPPORTED,
+                  "no compiled kernel variant for kind=%d hidden=%d (tiles=%d,last k-steps=%d) out_tiles=%d depth=%d "
+                  "act=(%d,%d); add it to csrc/variants.list", desc->kind, h, ht, ksl, ot, depth, act_a, act_b);
+    }
+  }
+  const int HT = f->var_ht, OT = f->var_ot;
+
+  const int nnets = glow ? 1 : 2;
+  const size_t NW = net_words(HT, OT, depth);
+  const size_t step_words = SMALL_WORDS + nnets * NW;
+  const size_t total_words = step_words * K + 64;
+  std::vector<uint32_t> blob(total_words, 0u);
+
+  // slot map: sigma[j] = LDS slot of logical feature j at the current step
+  std::vector<int> sigma(d), prev(d);
+  for (int j = 0; j < d; ++j) sigma[j] = j;
+
+  auto put_f = [&](size_t off, float v) { std::memcpy(&blob[off], &v, 4); };
+  auto put_i = [&](size_t off, int v) { std::memcpy(&blob[off], &v, 4); };
+
+  double macs = 0, padded = 0;
+  for (int s = 0; s < K; ++s) {
+    const size_t sb = step_words * s;
+    prev = sigma;
+    int in_f, out_f;
+    // per logical (post-permutation) feature j: slot + norm params p0..p3
+    std::vector<float> P0(d, 0.f), P1(d, 1.f), P2(d, 1.f), P3(d, 0.f);
+    std::vector<int> in_feat, out_feat;  // logical (new order) feature ids feeding the net / being coupled
+    float ld_const = 0.f;
+    if (glow) {
+      const gbnf_glow_step& st = desc->glow_steps[s];
+      // z'[j] = actnorm(z)[perm[j]]
+      float sum_logs = 0.f;
+      for (int m = 0; m < d; ++m) sum_logs += st.actnorm_logs[m];   // torch.sum(logs), sequential f32
+      ld_const = sum_logs;
+      for (int j = 0; j < d; ++j) {
+        const int m = (int)st.perm_indices[j];
+        sigma[j] = prev[m];
+        P0[j] = st.actnorm_bias[m];
+        P1[j] = expf(st.actnorm_logs[m]);
+      }
+      in_f = d1; out_f = d2;
+      for (int j = 0; j < d1; ++j) in_feat.push_back(j);
+      for (int j = 0; j < d2; ++j) out_feat.push_back(d1 + j);
+    } else {
+      const gbnf_realnvp_step& st = desc->realnvp_steps[s];
+      // BN acts on the OLD logical order; new order = cat(z1, z2) with z1 = upper half when flipped
+      std::vector<float> q0(d, 0.f), q1(d, 1.f), q2(d, 1.f), q3(d, 0.f);
+      if (st.has_batch_norm) {
+        float acc = 0.f;
+        for (int m = 0; m < d; ++m) {
+          const float ve = st.bn_running_var[m] + st.bn_eps;
+          q0[m] = st.bn_running_mean[m];
+          q1[m] = sqrtf(ve);
+          q2[m] = expf(st.bn_log_gamma[m]);
+          q3[m] = st.bn_beta[m];
+          acc += st.bn_log_gamma[m] - 0.5f * logf(ve);      // models/layers.py:357-358
+        }
+        ld_const = acc;
+      }
+      in_f = st.flipped ? d2 : d1;
+      out_f = st.flipped ? d1 : d2;
+      for (int j = 0; j < d; ++j) {
+        int m;  // old logical index of new logical feature j
+        if (st.flipped) m = (j < d2) ? d1 + j : j - d2;
+        else m = j;
+        sigma[j] = prev[m];
+        P0[j] = q0[m]; P1[j] = q1[m]; P2[j] = q2[m]; P3[j] = q3[m];
+      }
+      for (int j = 0; j < in_f; ++j) in_feat.push_back(j);
+      for (int j = 0; j < out_f; ++j) out_feat.push_back(in_f + j);
+    }
+    const int ks1 = ceil_div(in_f, 4);
+    put_i(sb + 0, ks1);
+    put_f(sb + 1, ld_const);
+    // in tables [g][e]: k = 4e + g
+    for (int gg = 0; gg < 4; ++gg)
+      for (int e = 0; e < NENT; ++e) {
+        const int k = 4 * e + gg;
+        const size_t o = sb + SMALL_HDR + gg * NENT + e;
+        if (k < in_f) {
+          const int j = in_feat[k];
+          put_i(o, sigma[j]); put_f(o + 32, P0[j]); put_f(o + 64, P1[j]); put_f(o + 96, P2[j]); put_f(o + 128, P3[j]);
+        } else {
+          put_i(o, -1); put_f(o + 32, 0.f); put_f(o + 64, 1.f); put_f(o + 96, 1.f); put_f(o + 128, 0.f);
+        }
+      }
+    // out tables [g][e]: affine pairs j = 8o + 2g + pp (e = 2o + pp); plain j = 16o + 4g + r (e = 4o + r)
+    const bool paired = glow && !additive;
+    for (int gg = 0; gg < 4; ++gg)
+      for (int e = 0; e < NENT; ++e) {
+        int jj;
+        if (paired) jj = 8 * (e >> 1) + 2 * gg + (e & 1);
+        else jj = 16 * (e >> 2) + 4 * gg + (e & 3);
+        const size_t o = sb + SMALL_HDR + 160 + gg * NENT + e;
+        if (jj < out_f) {
+          const int j = out_feat[jj];
+          put_i(o, sigma[j]); put_f(o + 32, P0[j]); put_f(o + 64, P1[j]); put_f(o + 96, P2[j]); put_f(o + 128, P3[j]);
+        } else {
+          put_i(o, -1); put_f(o + 32, 0.f); put_f(o + 64, 1.f); put_f(o + 96, 1.f); put_f(o + 128, 0.f);
+        }
+      }
+    const int net_out = paired ? 2 * out_f : out_f;
+    if (glow) {
+      pack_net(blob, sb + SMALL_WORDS, desc->glow_steps[s].block, HT, OT, depth, in_f, h, net_out);
+    } else {
+      pack_net(blob, sb + SMALL_WORDS, desc->realnvp_steps[s].t_net, HT, OT, depth, in_f, h, net_out);
+      pack_net(blob, sb + SMALL_WORDS + NW, desc->realnvp_steps[s].s_net, HT, OT, depth, in_f, h, net_out);
+    }
+    macs += (double)nnets * ((double)in_f * h + (double)depth * h * h + (double)h * net_out);
+    const double kh = 4.0 * (HT - 1) + f->var_ksl;  // live hidden k-steps in the variant
+    padded += (double)nnets * (16.0 * HT * 4 * ks1 + depth * 16.0 * HT * 4 * kh + 16.0 * OT * 4 * kh);
+  }
+  for (int j = 0; j < d; ++j) put_i(step_words * K + j, sigma[j]);
+  f->macs = macs; f->padded_macs = padded;
+  f->blob_words = total_words;
+
+  hipError_t e = hipMalloc((void**)&f->blob_dev, total_words * 4);
+  if (e == hipSuccess) e = hipMemcpy(f->blob_dev, blob.data(), total_words * 4, hipMemcpyHostToDevice);
+  if (e == hipSuccess) e = hipMalloc((void**)&f->self_table_dev, sizeof(uint32_t*));
+  if (e == hipSuccess) e = hipMemcpy(f->self_table_dev, &f->blob_dev, sizeof(uint32_t*), hipMemcpyHostToDevice);
+  if (e != hipSuccess) {
+    if (f->blob_dev) (void)hipFree(f->blob_dev);
+    if (f->self_table_dev) (void)hipFree(f->self_table_dev);
+    delete f;
+    return fail(GBNF_ERR_HIP, "uploading packed parameters failed: %s", hipGetErrorString(e));
+  }
+  *out = f;
+  return GBNF_OK;
+}
+
+int gbnf_flow_destroy(gbnf_flow* flow) {
+  if (flow == nullptr) return GBNF_OK;
+  if (flow->blob_dev) (void)hipFree(flow->blob_dev);
+  if (flow->self_table_dev) (void)hipFree(flow->self_table_dev);
+  delete flow;
+  return GBNF_OK;
+}
+
+int gbnf_flow_info(const gbnf_flow* flow, gbnf_kernel_info* info) {
+  if (!flow || !info) return fail(GBNF_ERR_INVALID, "gbnf_flow_info: null argument");
+  info->hidden_tiles = flow->var_ht;
+  info->out_tiles = flow->var_ot;
+  info->samples_per_wave = 32;
+  info->n_steps = flow->n_steps;
+  info->macs_per_sample = flow->macs;
+  info->padded_macs_per_sample = flow->padded_macs;
+  info->packed_bytes = (int64_t)flow->blob_words * 4;
+  return GBNF_OK;
+}
+
+}  // extern "C"
+
+namespace gbnf {
+
+// samples per wave: 32 (NT=2) once there is enough work to give every SIMD of the chip a
+// wave that way (256 CUs x 4 SIMDs), otherwise 16 (NT=1) to expose more waves.
+static int pick_nt(int64_t n, int n_comp) {
+  const int64_t waves32 = ((n + 31) / 32) * n_comp;
+  return waves32 >= 1024 ? 2 : 1;
+}
+
+static int launch_flow(const gbnf_flow* f, const uint32_t* const* table, int c_begin, int n_comp, const float* x,
+                       int64_t n, float* z, float* ldj, float* ll, const float* base, hipStream_t stream) {
+  if (n == 0 || n_comp == 0) return GBNF_OK;
+  const int nt = pick_nt(n, n_comp);
+  const int64_t tiles = (n + 16 * nt - 1) / (16 * nt);
+  const int64_t grid = tiles * n_comp;
+  if (grid > 0x7fffffffLL) return fail(GBNF_ERR_UNSUPPORTED, "batch too large for one launch (%lld tiles)", (long long)grid);
+  FlowLaunch p{};
+  p.blobs = table; p.x = x; p.z_out = z; p.ldj_out = ldj; p.ll_out = ll;
+  p.base_mean = base; p.base_std = base ? base + f->d : nullptr;
+  p.n = n; p.d = f->d; p.n_steps = f->n_steps; p.c_begin = c_begin; p.n_comp = n_comp;
+  p.n_tiles = (int32_t)tiles; p.additive = f->additive;
+  hipError_t e = f->launch_nt[nt](p, (unsigned)grid, stream);
+  if (e != hipSuccess) return fail(GBNF_ERR_HIP, "launch of %s failed: %s", f->name_nt[nt], hipGetErrorString(e));
+  return GBNF_OK;
+}
+
+// G_0 = ll_0; G_c = LSE2(log(1 - r_c) + G_{c-1}, log r_c + ll_c), r_c = rho_c / sum(rho[0..c])
+// (density_experiment.py:567-571).  One thread per sample; rho prefix sums recomputed per
+// thread (C is tiny, the loads are wave-uniform).  torch.logsumexp semantics for the 2-way LSE.
+__global__ void __launch_bounds__(256) mixture_lse_kernel(const float* __restrict__ ll, int64_t stride,
+                                                          const float* __restrict__ rho, int n_comp, int64_t n,
+                                                          float* __restrict__ out) {
+  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= n) return;
+  float G = ll[idx];
+  float rsum = rho[0];
+  for (int c = 1; c < n_comp; ++c) {
+    rsum += rho[c];
+    const float r = rho[c] / rsum;
+    const float a = logf(1.0f - r) + G;
+    const float b = logf(r) + ll[(int64_t)c * stride + idx];
+    float m = fmaxf(a, b);
+    if (isinf(m)) m = 0.0f;
+    G = m + logf(expf(a - m) + expf(b - m));
+  }
+  out[idx] = G;
+}
+
+}  // namespace gbnf
+
+extern "C" {
+
+int gbnf_flow_forward(const gbnf_flow* flow, const float* x, int64_t n, float* z, float* ldj, float* ll,
+                      void* stream) {
+  if (!flow) return fail(GBNF_ERR_INVALID, "gbnf_flow_forward: flow is null");
+  if (n < 0) return fail(GBNF_ERR_INVALID, "gbnf_flow_forward: n < 0");
+  if (n > 0 && !x) return fail(GBNF_ERR_INVALID, "gbnf_flow_forward: x is null");
+  return launch_flow(flow, flow->self_table_dev, 0, 1, x, n, z, ldj, ll, nullptr, (hipStream_t)stream);
+}
+
+int gbnf_mixture_create(gbnf_flow* const* flows, int32_t n_flows, gbnf_mixture** out) {
+  if (!out) return fail(GBNF_ERR_INVALID, "gbnf_mixture_create: out is null");
+  *out = nullptr;
+  if (!flows || n_flows < 1) return fail(GBNF_ERR_INVALID, "gbnf_mixture_create: need >= 1 flow");
+  const gbnf_flow* f0 = flows[0];
+  std::vector<const uint32_t*> table(n_flows);
+  for (int c = 0; c < n_flows; ++c) {
+    const gbnf_flow* f = flows[c];
+    if (!f) return fail(GBNF_ERR_INVALID, "gbnf_mixture_create: flow %d is null", c);
+    if (f->kind != f0->kind || f->d != f0->d || f->n_steps != f0->n_steps || f->additive != f0->additive ||
+        f->hidden != f0->hidden || f->depth != f0->depth || f->act_a != f0->act_a || f->act_b != f0->act_b ||
+        f->var_ht != f0->var_ht || f->var_ksl != f0->var_ksl || f->var_ot != f0->var_ot)
+      return fail(GBNF_ERR_INVALID, "gbnf_mixture_create: flow %d has a different architecture than flow 0", c);
+    table[c] = f->blob_dev;
+  }
+  gbnf_mixture* m = new gbnf_mixture();
+  m->flows.assign(flows, flows + n_flows);
+  hipError_t e = hipMalloc((void**)&m->table_dev, sizeof(uint32_t*) * n_flows);
+  if (e == hipSuccess) e = hipMemcpy(m->table_dev, table.data(), sizeof(uint32_t*) * n_flows, hipMemcpyHostToDevice);
+  if (e != hipSuccess) {
+    if (m->table_dev) (void)hipFree(m->table_dev);
+    delete m;
+    return fail(GBNF_ERR_HIP, "gbnf_mixture_create: %s", hipGetErrorString(e));
+  }
+  *out = m;
+  return GBNF_OK;
+}
+
+int gbnf_mixture_destroy(gbnf_mixture* mix) {
+  if (!mix) return GBNF_OK;
+  if (mix->table_dev) (void)hipFree(mix->table_dev);
+  if (mix->base_dev) (void)hipFree(mix->base_dev);
+  delete mix;
+  return GBNF_OK;
+}
+
+int gbnf_mixture_set_base(gbnf_mixture* mix, const float* mean, const float* std) {
+  if (!mix) return fail(GBNF_ERR_INVALID, "gbnf_mixture_set_base: mix is null");
+  if ((mean == nullptr) != (std == nullptr))
+    return fail(GBNF_ERR_INVALID, "gbnf_mixture_set_base: mean and std must both be given or both be null");
+  GBNF_HIP(hipDeviceSynchronize());
+  if (mix->base_dev) { (void)hipFree(mix->base_dev); mix->base_dev = nullptr; }
+  if (mean == nullptr) return GBNF_OK;
+  const int d = mix->flows[0]->d;
+  for (int j = 0; j < d; ++j)
+    if (!(std[j] > 0.0f)) return fail(GBNF_ERR_INVALID, "gbnf_mixture_set_base: std[%d] must be > 0", j);
+  GBNF_HIP(hipMalloc((void**)&mix->base_dev, sizeof(float) * 2 * d));
+  GBNF_HIP(hipMemcpy(mix->base_dev, mean, sizeof(float) * d, hipMemcpyHostToDevice));
+  GBNF_HIP(hipMemcpy(mix->base_dev + d, std, sizeof(float) * d, hipMemcpyHostToDevice));
+  return GBNF_OK;
+}
+
+int gbnf_mixture_component_log_prob(const gbnf_mixture* mix, const float* x, int64_t n, int32_t c_begin,
+                                    int32_t c_end, float* ll, void* stream) {
+  if (!mix) return fail(GBNF_ERR_INVALID, "gbnf_mixture_component_log_prob: mix is null");
+  const int C = (int)mix->flows.size();
+  if (c_begin < 0 || c_end > C || c_begin > c_end)
+    return fail(GBNF_ERR_INVALID, "component range [%d,%d) outside [0,%d)", c_begin, c_end, C);
+  if (n < 0) return fail(GBNF_ERR_INVALID, "n < 0");
+  if (n > 0 && c_end > c_begin && (!x || !ll)) return fail(GBNF_ERR_INVALID, "x / ll is null");
+  return launch_flow(mix->flows[0], mix->table_dev, c_begin, c_end - c_begin, x, n, nullptr, nullptr, ll,
+                     mix->base_dev, (hipStream_t)stream);
+}
+
+int gbnf_mixture_lse(const float* ll, int64_t ll_row_stride, const float* rho_dev, int32_t n_components, int64_t n,
+                     float* out, void* stream) {
+  if (n_components < 1) return fail(GBNF_ERR_INVALID, "gbnf_mixture_lse: n_components < 1");
+  if (n < 0) return fail(GBNF_ERR_INVALID, "gbnf_mixture_lse: n < 0");
+  if (n == 0) return GBNF_OK;
+  if (!ll || !rho_dev || !out) return fail(GBNF_ERR_INVALID, "gbnf_mixture_lse: null pointer");
+  if (ll_row_stride < n) return fail(GBNF_ERR_INVALID, "gbnf_mixture_lse: row stride < n");
+  const int64_t blocks = (n + 255) / 256;
+  hipLaunchKernelGGL(mixture_lse_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, ll,
+                     ll_row_stride, rho_dev, n_components, n, out);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return fail(GBNF_ERR_HIP, "mixture_lse launch failed: %s", hipGetErrorString(e));
+  return GBNF_OK;
+}
+
+int gbnf_mixture_log_prob(const gbnf_mixture* mix, const float* x, int64_t n, int32_t n_used, const float* rho_dev,
+                          float* ll_workspace, float* out, void* stream) {
+  if (!mix) return fail(GBNF_ERR_INVALID, "gbnf_mixture_log_prob: mix is null");
+  if (n_used < 1 || n_used > (int)mix->flows.size())
+    return fail(GBNF_ERR_INVALID, "n_used=%d outside [1,%d]", n_used, (int)mix->flows.size());
+  int rc = gbnf_mixture_component_log_prob(mix, x, n, 0, n_used, ll_workspace, stream);
+  if (rc) return rc;
+  return gbnf_mixture_lse(ll_workspace, n, rho_dev, n_used, n, out, stream);
+}
+
+}  // extern "C"

@@ -1,0 +1,314 @@
+"""ctypes binding of ``libgbnf_hip.so`` (C ABI: ``include/gbnf.h``).
+
+There is NO fallback: if the shared library is missing, or a call fails, this
+module raises.  Device buffers are PyTorch-ROCm tensors; only their
+``data_ptr()`` and the current HIP stream cross the boundary.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libgbnf_hip.so")
+
+KIND = {"glow": 0, "realnvp": 1}
+ACT = {"tanh": 0, "relu": 1}
+COUPLING = {"affine": 0, "additive": 1}
+
+# every symbol include/gbnf.h declares (tests check the library exports exactly these)
+ABI_SYMBOLS = (
+    "gbnf_version", "gbnf_last_error",
+    "gbnf_flow_create", "gbnf_flow_destroy", "gbnf_flow_info", "gbnf_flow_forward",
+    "gbnf_mixture_create", "gbnf_mixture_destroy", "gbnf_mixture_set_base",
+    "gbnf_mixture_component_log_prob", "gbnf_mixture_lse", "gbnf_mixture_log_prob",
+)
+
+
+class GbnfError(RuntimeError):
+    pass
+
+
+class _Linear(C.Structure):
+    _fields_ = [("weight", C.POINTER(C.c_float)), ("bias", C.POINTER(C.c_float)),
+                ("out_features", C.c_int32), ("in_features", C.c_int32)]
+
+
+class _Net(C.Structure):
+    _fields_ = [("activation", C.c_int32), ("n_layers", C.c_int32), ("layers", C.POINTER(_Linear))]
+
+
+class _GlowStep(C.Structure):
+    _fields_ = [("actnorm_bias", C.POINTER(C.c_float)), ("actnorm_logs", C.POINTER(C.c_float)),
+                ("perm_indices", C.POINTER(C.c_int64)), ("block", _Net)]
+
+
+class _RealNVPStep(C.Structure):
+    _fields_ = [("flipped", C.c_int32), ("has_batch_norm", C.c_int32),
+                ("bn_log_gamma", C.POINTER(C.c_float)), ("bn_beta", C.POINTER(C.c_float)),
+                ("bn_running_mean", C.POINTER(C.c_float)), ("bn_running_var", C.POINTER(C.c_float)),
+                ("bn_eps", C.c_float), ("t_net", _Net), ("s_net", _Net)]
+
+
+class _FlowDesc(C.Structure):
+    _fields_ = [("kind", C.c_int32), ("d", C.c_int32), ("n_steps", C.c_int32), ("coupling", C.c_int32),
+                ("glow_steps", C.POINTER(_GlowStep)), ("realnvp_steps", C.POINTER(_RealNVPStep))]
+
+
+class KernelInfo(C.Structure):
+    _fields_ = [("hidden_tiles", C.c_int32), ("out_tiles", C.c_int32), ("samples_per_wave", C.c_int32),
+                ("n_steps", C.c_int32), ("macs_per_sample", C.c_double),
+                ("padded_macs_per_sample", C.c_double), ("packed_bytes", C.c_int64)]
+
+
+_lib = None
+
+
+def lib():
+    """Load the library (once).  Raises if it has not been built -- never falls back."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise GbnfError(
+            f"{LIB_PATH} not found: build it with `python __graft_entry__.py` "
+            "(or gradient-boosted-normalizing-flows_amd/csrc/build.py). There is no CPU fallback.")
+    L = C.CDLL(LIB_PATH)
+    vp, i32, i64 = C.c_void_p, C.c_int32, C.c_int64
+    L.gbnf_version.restype = C.c_int
+    L.gbnf_last_error.restype = C.c_char_p
+    L.gbnf_flow_create.argtypes = [C.POINTER(_FlowDesc), C.POINTER(vp)]
+    L.gbnf_flow_destroy.argtypes = [vp]
+    L.gbnf_flow_info.argtypes = [vp, C.POINTER(KernelInfo)]
+    L.gbnf_flow_forward.argtypes = [vp, vp, i64, vp, vp, vp, vp]
+    L.gbnf_mixture_create.argtypes = [C.POINTER(vp), i32, C.POINTER(vp)]
+    L.gbnf_mixture_destroy.argtypes = [vp]
+    L.gbnf_mixture_set_base.argtypes = [vp, C.POINTER(C.c_float), C.POINTER(C.c_float)]
+    L.gbnf_mixture_component_log_prob.argtypes = [vp, vp, i64, i32, i32, vp, vp]
+    L.gbnf_mixture_lse.argtypes = [vp, i64, vp, i32, i64, vp, vp]
+    L.gbnf_mixture_log_prob.argtypes = [vp, vp, i64, i32, vp, vp, vp, vp]
+    for name in ABI_SYMBOLS:
+        if name not in ("gbnf_version", "gbnf_last_error"):
+            getattr(L, name).restype = C.c_int
+    _lib = L
+    return L
+
+
+def _check(rc):
+    if rc != 0:
+        raise GbnfError(f"libgbnf_hip error {rc}: {lib().gbnf_last_error().decode(errors='replace')}")
+
+
+def _fptr(a):
+    return a.ctypes.data_as(C.POINTER(C.c_float))
+
+
+class _Keep:
+    """Keeps the numpy arrays / ctypes arrays referenced by a descriptor alive."""
+
+    def __init__(self):
+        self.refs = []
+
+    def f32(self, a):
+        a = np.ascontiguousarray(np.asarray(a, dtype=np.float32))
+        self.refs.append(a)
+        return _fptr(a)
+
+    def i64(self, a):
+        a = np.ascontiguousarray(np.asarray(a, dtype=np.int64))
+        self.refs.append(a)
+        return a.ctypes.data_as(C.POINTER(C.c_int64))
+
+    def net(self, net):
+        arr = (_Linear * len(net["layers"]))()
+        for k, (w, b) in enumerate(net["layers"]):
+            w = np.asarray(w)
+            arr[k] = _Linear(self.f32(w), self.f32(b), int(w.shape[0]), int(w.shape[1]))
+        self.refs.append(arr)
+        return _Net(ACT[net["act"]], len(net["layers"]), arr)
+
+
+def flow_desc_from_spec(spec):
+    """flow spec (see spec.py) -> (ctypes gbnf_flow_desc, keep-alive object)."""
+    keep = _Keep()
+    K = len(spec["steps"])
+    desc = _FlowDesc()
+    desc.kind = KIND[spec["kind"]]
+    desc.d = int(spec["d"])
+    desc.n_steps = K
+    desc.coupling = COUPLING[spec.get("coupling") or "affine"]
+    if spec["kind"] == "glow":
+        steps = (_GlowStep * K)()
+        for k, st in enumerate(spec["steps"]):
+            steps[k] = _GlowStep(keep.f32(st["an_bias"]), keep.f32(st["an_logs"]), keep.i64(st["perm"]),
+                                 keep.net(st["net"]))
+        desc.glow_steps = steps
+    else:
+        steps = (_RealNVPStep * K)()
+        for k, st in enumerate(spec["steps"]):
+            s = _RealNVPStep()
+            s.flipped = int(bool(st["flipped"]))
+            bn = st["bn"]
+            s.has_batch_norm = int(bn is not None)
+            if bn is not None:
+                s.bn_log_gamma = keep.f32(bn["log_gamma"])
+                s.bn_beta = keep.f32(bn["beta"])
+                s.bn_running_mean = keep.f32(bn["running_mean"])
+                s.bn_running_var = keep.f32(bn["running_var"])
+                s.bn_eps = float(bn["eps"])
+            s.t_net = keep.net(st["t_net"])
+            s.s_net = keep.net(st["s_net"])
+            steps[k] = s
+        desc.realnvp_steps = steps
+    keep.refs.append(steps)
+    return desc, keep
+
+
+def _require_device_f32(t, name):
+    import torch
+    if not isinstance(t, torch.Tensor) or not t.is_cuda:
+        raise GbnfError(f"{name} must be a tensor on the MI355X (cuda) device; there is no CPU path")
+    if t.dtype != torch.float32 or not t.is_contiguous():
+        raise GbnfError(f"{name} must be contiguous float32")
+    return t
+
+
+def _stream_ptr():
+    import torch
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+class NativeFlow:
+    """One packed component on the device (gbnf_flow)."""
+
+    def __init__(self, spec):
+        desc, keep = flow_desc_from_spec(spec)
+        h = C.c_void_p()
+        _check(lib().gbnf_flow_create(C.byref(desc), C.byref(h)))
+        del keep
+        self.handle = h
+        self.d = int(spec["d"])
+
+    def info(self):
+        ki = KernelInfo()
+        _check(lib().gbnf_flow_info(self.handle, C.byref(ki)))
+        return ki
+
+    def forward(self, x, want_z=True, want_ldj=True, want_ll=False):
+        """x (n,d) cuda f32 -> (z|None, ldj|None, ll|None); enqueued on the current stream."""
+        import torch
+        _require_device_f32(x, "x")
+        if x.dim() != 2 or x.shape[1] != self.d:
+            raise GbnfError(f"x must be (n,{self.d}), got {tuple(x.shape)}")
+        n = x.shape[0]
+        z = torch.empty_like(x) if want_z else None
+        ldj = torch.empty(n, dtype=torch.float32, device=x.device) if want_ldj else None
+        ll = torch.empty(n, dtype=torch.float32, device=x.device) if want_ll else None
+        ptr = lambda t: C.c_void_p(t.data_ptr()) if t is not None and t.numel() else C.c_void_p(0)
+        _check(lib().gbnf_flow_forward(self.handle, ptr(x), n, ptr(z), ptr(ldj), ptr(ll), _stream_ptr()))
+        return z, ldj, ll
+
+    def close(self):
+        if getattr(self, "handle", None):
+            lib().gbnf_flow_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class NativeMixture:
+    """C same-architecture components behind one launch (gbnf_mixture)."""
+
+    def __init__(self, flows):
+        self.flows = list(flows)           # keeps the NativeFlow handles alive
+        arr = (C.c_void_p * len(self.flows))(*[f.handle for f in self.flows])
+        h = C.c_void_p()
+        _check(lib().gbnf_mixture_create(arr, len(self.flows), C.byref(h)))
+        self.handle = h
+        self.d = self.flows[0].d
+
+    @property
+    def n_components(self):
+        return len(self.flows)
+
+    def set_base(self, mean=None, std=None):
+        if mean is None:
+            _check(lib().gbnf_mixture_set_base(self.handle, None, None))
+            return
+        m = np.ascontiguousarray(np.asarray(mean, dtype=np.float32))
+        s = np.ascontiguousarray(np.asarray(std, dtype=np.float32))
+        if m.shape != (self.d,) or s.shape != (self.d,):
+            raise GbnfError(f"base mean/std must have shape ({self.d},)")
+        _check(lib().gbnf_mixture_set_base(self.handle, _fptr(m), _fptr(s)))
+
+    def component_log_prob(self, x, c_begin=0, c_end=None, out=None):
+        """ll (c_end-c_begin, n) for components [c_begin, c_end) in one launch."""
+        import torch
+        _require_device_f32(x, "x")
+        if x.dim() != 2 or x.shape[1] != self.d:
+            raise GbnfError(f"x must be (n,{self.d}), got {tuple(x.shape)}")
+        c_end = self.n_components if c_end is None else c_end
+        n = x.shape[0]
+        if out is None:
+            out = torch.empty((c_end - c_begin, n), dtype=torch.float32, device=x.device)
+        else:
+            _require_device_f32(out, "out")
+            if tuple(out.shape) != (c_end - c_begin, n):
+                raise GbnfError("out has the wrong shape")
+        _check(lib().gbnf_mixture_component_log_prob(
+            self.handle, C.c_void_p(x.data_ptr() if n else 0), n, c_begin, c_end,
+            C.c_void_p(out.data_ptr() if out.numel() else 0), _stream_ptr()))
+        return out
+
+    def log_prob(self, x, rho, n_used=None, ll_out=None, out=None):
+        """The measured path: G (n,) = mixture log-density over components [0, n_used)."""
+        import torch
+        _require_device_f32(x, "x")
+        _require_device_f32(rho, "rho")
+        n_used = self.n_components if n_used is None else int(n_used)
+        n = x.shape[0]
+        if ll_out is None:
+            ll_out = torch.empty((n_used, n), dtype=torch.float32, device=x.device)
+        if out is None:
+            out = torch.empty(n, dtype=torch.float32, device=x.device)
+        if rho.numel() < n_used:
+            raise GbnfError("rho shorter than n_used")
+        _check(lib().gbnf_mixture_log_prob(
+            self.handle, C.c_void_p(x.data_ptr() if n else 0), n, n_used, C.c_void_p(rho.data_ptr()),
+            C.c_void_p(ll_out.data_ptr() if ll_out.numel() else 0),
+            C.c_void_p(out.data_ptr() if n else 0), _stream_ptr()))
+        return out, ll_out
+
+    def close(self):
+        if getattr(self, "handle", None):
+            lib().gbnf_mixture_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def mixture_lse(ll, rho, out=None):
+    """Recursive prefix-normalised log-sum-exp of (C,n) per-component log-densities."""
+    import torch
+    _require_device_f32(ll, "ll")
+    _require_device_f32(rho, "rho")
+    if ll.dim() != 2:
+        raise GbnfError("ll must be (C, n)")
+    c, n = ll.shape
+    if rho.numel() < c:
+        raise GbnfError("rho shorter than the number of components")
+    if out is None:
+        out = torch.empty(n, dtype=torch.float32, device=ll.device)
+    _check(lib().gbnf_mixture_lse(C.c_void_p(ll.data_ptr() if n else 0), n, C.c_void_p(rho.data_ptr()), c, n,
+                                  C.c_void_p(out.data_ptr() if n else 0), _stream_ptr()))
+    return out

@@ -1,0 +1,158 @@
+/*
+ * gbnf.h -- C ABI of libgbnf_hip.so: the MI355X (gfx950) boosted normalizing-flow
+ * density evaluator.
+ *
+ * The reference project has NO native / FFI layer: its boundary for this path is the
+ * Python call  BoostedFlow.forward(x=, components=c)  ->  self.flows[c](x)
+ * (models/boosted_flow.py:220-228) and the mixture arithmetic its callers write inline
+ * (density_experiment.py:561-573).  Each entry point below states which reference
+ * code it replaces.  INTEGRATION.md shows the ctypes binding a reference maintainer
+ * would add.
+ *
+ * Conventions
+ *  - plain C, no torch types.  `x`, `z`, `ldj`, `ll`, `rho_dev`, `out` are DEVICE pointers
+ *    to contiguous float32 owned by the caller (PyTorch tensors' data_ptr()); descriptor
+ *    pointers (`gbnf_*_desc`, `gbnf_linear.weight`, ...) are HOST pointers that only need
+ *    to stay valid for the duration of the create call (the handle owns packed copies).
+ *  - `stream` is a hipStream_t passed as void* (NULL = default stream).  Kernels are
+ *    enqueued on it; no call synchronises the device except create/destroy/set_base.
+ *  - every function returns GBNF_OK (0) or a negative gbnf_status; it never throws and
+ *    never exits.  gbnf_last_error() gives the message for the calling thread.
+ *  - handles are immutable after creation: concurrent forward calls on different streams
+ *    are safe; create/destroy must not race with in-flight work on the same handle.
+ */
+#ifndef GBNF_H_
+#define GBNF_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GBNF_ABI_VERSION 1
+
+typedef enum gbnf_status {
+  GBNF_OK = 0,
+  GBNF_ERR_INVALID = -1,      /* bad argument / inconsistent descriptor            */
+  GBNF_ERR_UNSUPPORTED = -2,  /* shape or option with no compiled kernel variant    */
+  GBNF_ERR_HIP = -3,          /* a HIP runtime call failed                          */
+  GBNF_ERR_NO_DEVICE = -4     /* no gfx950 device visible                           */
+} gbnf_status;
+
+enum { GBNF_KIND_GLOW = 0, GBNF_KIND_REALNVP = 1 };
+enum { GBNF_ACT_TANH = 0, GBNF_ACT_RELU = 1 };
+enum { GBNF_COUPLING_AFFINE = 0, GBNF_COUPLING_ADDITIVE = 1 };
+
+/* nn.Linear: y = x W^T + b, W row-major (out_features, in_features).
+ * TanhNet / ReLUNet layers, models/layers.py:208-243. */
+typedef struct gbnf_linear {
+  const float* weight;
+  const float* bias;
+  int32_t out_features;
+  int32_t in_features;
+} gbnf_linear;
+
+/* Coupling network: Linear -> [act, Linear] x depth -> act, Linear  (n_layers = depth + 2). */
+typedef struct gbnf_net {
+  int32_t activation; /* GBNF_ACT_* */
+  int32_t n_layers;
+  const gbnf_linear* layers;
+} gbnf_net;
+
+/* One tabular Glow FlowStep: ActNorm1d -> Permute1d -> coupling.  models/glow.py:317-342. */
+typedef struct gbnf_glow_step {
+  const float* actnorm_bias;   /* (d,)  _ActNorm.bias,  models/layers.py:467 */
+  const float* actnorm_logs;   /* (d,)  _ActNorm.logs,  models/layers.py:468 */
+  const int64_t* perm_indices; /* (d,)  PermuteNd.indices (NOT in state_dict), models/layers.py:636-651 */
+  gbnf_net block;              /* in d/2 -> out 2*(d-d/2) (affine) or d-d/2 (additive) */
+} gbnf_glow_step;
+
+/* One RealNVP step: [BatchNorm eval] -> split/swap -> t,s nets -> affine.
+ * models/transformations.py:560-579, models/layers.py:337-358. */
+typedef struct gbnf_realnvp_step {
+  int32_t flipped;             /* (k + flip_init) % 2, models/realnvp.py:38,118 */
+  int32_t has_batch_norm;
+  const float* bn_log_gamma;   /* (d,) each; ignored when !has_batch_norm */
+  const float* bn_beta;
+  const float* bn_running_mean;
+  const float* bn_running_var;
+  float bn_eps;
+  gbnf_net t_net;              /* shift net */
+  gbnf_net s_net;              /* log-scale net */
+} gbnf_realnvp_step;
+
+/* One boosted component = BoostedFlow.flows[c]  (models/boosted_flow.py:42-50). */
+typedef struct gbnf_flow_desc {
+  int32_t kind;      /* GBNF_KIND_* */
+  int32_t d;         /* features (z_size) */
+  int32_t n_steps;   /* K = num_flows */
+  int32_t coupling;  /* GBNF_COUPLING_* (glow only) */
+  const gbnf_glow_step* glow_steps;       /* n_steps entries when kind == GLOW */
+  const gbnf_realnvp_step* realnvp_steps; /* n_steps entries when kind == REALNVP */
+} gbnf_flow_desc;
+
+typedef struct gbnf_flow gbnf_flow;       /* one component, packed on the device */
+typedef struct gbnf_mixture gbnf_mixture; /* C same-architecture components      */
+
+/* What a handle's kernel variant looks like (for roofline accounting in bench.py). */
+typedef struct gbnf_kernel_info {
+  int32_t hidden_tiles;        /* 16-unit MFMA tiles per hidden layer            */
+  int32_t out_tiles;
+  int32_t samples_per_wave;    /* 16 or 32                                        */
+  int32_t n_steps;
+  double macs_per_sample;        /* algorithmic multiply-adds per sample per component */
+  double padded_macs_per_sample; /* what the MFMA tiles actually execute          */
+  int64_t packed_bytes;          /* device bytes of packed parameters per component */
+} gbnf_kernel_info;
+
+int gbnf_version(void);
+const char* gbnf_last_error(void);
+
+/* Replaces: constructing flows[c] + .to(device)  (models/boosted_flow.py:42-50).
+ * Packs (pads, tiles, folds slot maps) and uploads the parameters. */
+int gbnf_flow_create(const gbnf_flow_desc* desc, gbnf_flow** out);
+int gbnf_flow_destroy(gbnf_flow* flow);
+int gbnf_flow_info(const gbnf_flow* flow, gbnf_kernel_info* info);
+
+/* Replaces: z, _, _, ldj, _ = self.flows[c](x)   (models/boosted_flow.py:220-222 ->
+ * Glow.encode models/glow.py:92-110 / RealNVPFlow.encode models/realnvp.py:115-127).
+ * x (n,d) -> z (n,d), ldj (n,), ll (n,) = log N(z;0,I) + ldj  (utils/distributions.py:44-60,
+ * density_experiment.py:565).  Any of z / ldj / ll may be NULL to skip that output. */
+int gbnf_flow_forward(const gbnf_flow* flow, const float* x, int64_t n,
+                      float* z, float* ldj, float* ll, void* stream);
+
+/* Replaces: the nn.ModuleList of components (models/boosted_flow.py:42).  All flows must
+ * share one architecture (they do: every component is built from the same args).
+ * The mixture does NOT take ownership of the flows; they must outlive it. */
+int gbnf_mixture_create(gbnf_flow* const* flows, int32_t n_flows, gbnf_mixture** out);
+int gbnf_mixture_destroy(gbnf_mixture* mix);
+
+/* Optional base density N(mean_j, std_j) per feature instead of N(0,1): the toy driver's
+ * model.base_dist (models/generative_flow.py:22-23,38-42; toy_experiment.py:424).
+ * HOST pointers (d,), or NULL/NULL to restore the standard normal. */
+int gbnf_mixture_set_base(gbnf_mixture* mix, const float* mean, const float* std);
+
+/* Replaces: the loop  for c in range(...): model(x=x, components=c); log_normal_standard(z)+ldj
+ * (density_experiment.py:562-565) for components [c_begin, c_end) in ONE launch.
+ * ll is (c_end - c_begin, n) row-major. */
+int gbnf_mixture_component_log_prob(const gbnf_mixture* mix, const float* x, int64_t n,
+                                    int32_t c_begin, int32_t c_end, float* ll, void* stream);
+
+/* Replaces: the recursive prefix-normalised 2-way logsumexp (density_experiment.py:567-571):
+ *   G_0 = ll_0;  r_c = rho_c / sum(rho[0..c]);  G_c = LSE(log(1-r_c)+G_{c-1}, log(r_c)+ll_c).
+ * ll is (n_components, n) with row stride `ll_row_stride` floats; rho_dev is the DEVICE
+ * `rho` buffer (models/boosted_flow.py:32-39), at least n_components long. */
+int gbnf_mixture_lse(const float* ll, int64_t ll_row_stride, const float* rho_dev,
+                     int32_t n_components, int64_t n, float* out, void* stream);
+
+/* The measured path: component_log_prob for components [0, n_used) + mixture_lse.
+ * ll_workspace is (n_used, n) floats of caller-owned device scratch (also an output). */
+int gbnf_mixture_log_prob(const gbnf_mixture* mix, const float* x, int64_t n, int32_t n_used,
+                          const float* rho_dev, float* ll_workspace, float* out, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GBNF_H_ */
