@@ -27,9 +27,9 @@ def read_variants():
             line = line.split("#")[0].strip()
             if not line:
                 continue
-            kind, ht, ksl, ot, lmid, acta, actb = (int(v) for v in line.split())
+            kind, ht, ksl, ks1, ot, lmid, acta, actb = (int(v) for v in line.split())
             for nt in (1, 2):
-                out.append((kind, ht, ksl, ot, nt, lmid, acta, actb))
+                out.append((kind, ht, ksl, ks1, ot, nt, lmid, acta, actb))
     return sorted(set(out))
 
 

@@ -5,6 +5,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 #include <string>
@@ -58,7 +59,8 @@ struct gbnf_flow {
   int kind = 0, d = 0, n_steps = 0, additive = 0;
   int hidden = 0, depth = 0, act_a = 0, act_b = 0;
   int ht = 0, ksl = 0, ot = 0;     // tile geometry (exact)
-  int var_ht = 0, var_ksl = 0, var_ot = 0;  // geometry of the compiled variant the blob was packed for
+  int ks1 = 0;
+  int var_ht = 0, var_ksl = 0, var_ks1 = 0, var_ot = 0;  // geometry of the compiled variant the blob was packed for
   gbnf::LaunchFn launch_nt[3] = {nullptr, nullptr, nullptr};  // index = NT
   const char* name_nt[3] = {nullptr, nullptr, nullptr};
   uint32_t* blob_dev = nullptr;
@@ -106,41 +108,37 @@ static int check_net(const gbnf_net& net, int in_f, int out_f, NetDims* dims, co
   return GBNF_OK;
 }
 
-// Pack one coupling network at word offset `base` of `blob` for variant geometry (HT, OT, LMID).
-// `paired_out` is informational only: the affine "cross" layout equals natural row order.
-static void pack_net(std::vector<uint32_t>& blob, size_t base, const gbnf_net& net, int HT, int OT, int LMID,
-                     int in_f, int h, int out_f) {
+// Pack one coupling network at word offset `base` of `blob` for variant geometry (HT, KS1, OT, LMID).
+// The affine "cross" layout (shift_j, raw_j adjacent) equals natural row order of the last Linear.
+static void pack_net(std::vector<uint32_t>& blob, size_t base, const gbnf_net& net, int HT, int KS1, int OT,
+                     int LMID, int in_f, int h, int out_f) {
+  const NetLayoutRT L(HT, KS1, OT, LMID);
   auto put = [&](size_t off, float v) { std::memcpy(&blob[base + off], &v, 4); };
-  const size_t W1 = 0;
-  const size_t B1 = W1 + (size_t)(KS1MAX + 1) * HT * 64;
-  const size_t MID0 = B1 + (size_t)HT * 16;
-  const size_t MID_W = (size_t)(HT + 1) * HT * 256;
-  const size_t MID_STRIDE = MID_W + (size_t)HT * 16;
-  const size_t W3 = MID0 + (size_t)LMID * MID_STRIDE;
-  const size_t B3 = W3 + (size_t)(HT + 1) * OT * 256;
 
-  // layer 0: A fragment for (k-step s, tile t): lane (i,g) = W0[unit(16t+i)][k = 4s+g]
+  // layer 0: A fragment for tile t: lane (i,g) holds W0[unit(16t+i)][k = 4s+g] for s = 0..KS1-1
   const gbnf_linear& l0 = net.layers[0];
-  for (int s = 0; s < KS1MAX; ++s)
-    for (int t = 0; t < HT; ++t)
-      for (int lane = 0; lane < 64; ++lane) {
-        const int i = lane & 15, gg = lane >> 4;
-        const int u = phys_to_logical(16 * t + i, h), k = 4 * s + gg;
+  for (int t = 0; t < HT; ++t)
+    for (int lane = 0; lane < 64; ++lane) {
+      const int i = lane & 15, gg = lane >> 4;
+      const int u = phys_to_logical(16 * t + i, h);
+      for (int s = 0; s < 4 * L.KQ; ++s) {
+        const int k = 4 * s + gg;
         float v = 0.0f;
-        if (u >= 0 && k < in_f) v = l0.weight[(size_t)u * in_f + k];
-        put(W1 + ((size_t)s * HT + t) * 64 + lane, v);
+        if (u >= 0 && s < KS1 && k < in_f) v = l0.weight[(size_t)u * in_f + k];
+        put(L.W1 + (size_t)t * L.W1_TILE + (size_t)lane * L.KQ * 4 + s, v);
       }
+    }
   for (int t = 0; t < HT; ++t)
     for (int gg = 0; gg < 4; ++gg)
       for (int r = 0; r < 4; ++r) {
         const int u = phys_to_logical(16 * t + 4 * gg + r, h);
-        put(B1 + (size_t)t * 16 + gg * 4 + r, u >= 0 ? l0.bias[u] : 0.0f);
+        put(L.B1 + (size_t)t * 16 + gg * 4 + r, u >= 0 ? l0.bias[u] : 0.0f);
       }
   // hidden -> hidden layers: A fragment for (out tile u, k-chunk t): lane (i,g) reg r =
   //   W[unit(16u+i)][unit(16t+4g+r)]
   for (int m = 0; m < LMID; ++m) {
     const gbnf_linear& lm = net.layers[1 + m];
-    const size_t wb = MID0 + (size_t)m * MID_STRIDE;
+    const size_t wb = L.MID0 + (size_t)m * L.MID_STRIDE;
     for (int u = 0; u < HT; ++u)
       for (int t = 0; t < HT; ++t)
         for (int lane = 0; lane < 64; ++lane) {
@@ -157,7 +155,7 @@ static void pack_net(std::vector<uint32_t>& blob, size_t base, const gbnf_net& n
       for (int gg = 0; gg < 4; ++gg)
         for (int r = 0; r < 4; ++r) {
           const int uo = phys_to_logical(16 * u + 4 * gg + r, h);
-          put(wb + MID_W + (size_t)u * 16 + gg * 4 + r, uo >= 0 ? lm.bias[uo] : 0.0f);
+          put(wb + L.MID_W + (size_t)u * 16 + gg * 4 + r, uo >= 0 ? lm.bias[uo] : 0.0f);
         }
   }
   // last layer: A fragment for (k-chunk u, out tile o): lane (i,g) reg r = W[row 16o+i][unit(16u+4g+r)]
@@ -171,25 +169,18 @@ static void pack_net(std::vector<uint32_t>& blob, size_t base, const gbnf_net& n
           const int ui = phys_to_logical(16 * u + 4 * gg + r, h);
           float v = 0.0f;
           if (row < out_f && ui >= 0) v = ll.weight[(size_t)row * h + ui];
-          put(W3 + (((size_t)u * OT + o) * 64 + lane) * 4 + r, v);
+          put(L.W3 + (((size_t)u * OT + o) * 64 + lane) * 4 + r, v);
         }
       }
   for (int o = 0; o < OT; ++o)
     for (int gg = 0; gg < 4; ++gg)
       for (int r = 0; r < 4; ++r) {
         const int row = 16 * o + 4 * gg + r;
-        put(B3 + (size_t)o * 16 + gg * 4 + r, row < out_f ? ll.bias[row] : 0.0f);
+        put(L.B3 + (size_t)o * 16 + gg * 4 + r, row < out_f ? ll.bias[row] : 0.0f);
       }
 }
 
-static size_t net_words(int HT, int OT, int LMID) {
-  const size_t B1 = (size_t)(KS1MAX + 1) * HT * 64;
-  const size_t MID0 = B1 + (size_t)HT * 16;
-  const size_t MID_STRIDE = (size_t)(HT + 1) * HT * 256 + (size_t)HT * 16;
-  const size_t W3 = MID0 + (size_t)LMID * MID_STRIDE;
-  const size_t B3 = W3 + (size_t)(HT + 1) * OT * 256;
-  return B3 + (size_t)OT * 16;
-}
+static size_t net_words(int HT, int KS1, int OT, int LMID) { return (size_t)NetLayoutRT(HT, KS1, OT, LMID).NET_WORDS; }
 
 static const Variant* find_variant(const VariantKey& k) {
   for (const Variant& v : variants())
@@ -228,6 +219,7 @@ int gbnf_flow_create(const gbnf_flow_desc* desc, gbnf_flow** out) {
   NetDims ref{};
   int act_a = 0, act_b = 0;
   int max_out_entries = 0;
+  int max_in = 0;
   for (int s = 0; s < K; ++s) {
     NetDims a{}, b{};
     int rc;
@@ -267,6 +259,7 @@ int gbnf_flow_create(const gbnf_flow_desc* desc, gbnf_flow** out) {
     }
     if (a.in_f > 4 * KS1MAX)
       return fail(GBNF_ERR_UNSUPPORTED, "coupling-net input width %d > %d", a.in_f, 4 * KS1MAX);
+    if (a.in_f > max_in) max_in = a.in_f;
     const int entries = (glow && !additive) ? ceil_div(a.out_f / 2, 8) * 2 : ceil_div(a.out_f, 16) * 4;
     if (entries > max_out_entries) max_out_entries = entries;
   }
@@ -284,25 +277,26 @@ int gbnf_flow_create(const gbnf_flow_desc* desc, gbnf_flow** out) {
   gbnf_flow* f = new gbnf_flow();
   f->kind = desc->kind; f->d = d; f->n_steps = K; f->additive = additive ? 1 : 0;
   f->hidden = h; f->depth = depth; f->act_a = act_a; f->act_b = act_b;
-  f->ht = ht; f->ksl = ksl; f->ot = ot;
+  const int ks1 = ceil_div(max_in, 4);
+  f->ht = ht; f->ksl = ksl; f->ot = ot; f->ks1 = ks1;
   {
     long best_cost = -1;
     for (const Variant& v : variants()) {
       const VariantKey& k = v.key;
       if (k.kind != desc->kind || k.lmid != depth || k.act_a != act_a || k.act_b != act_b) continue;
-      if (k.ot < ot) continue;
+      if (k.ot < ot || k.ks1 < ks1) continue;
       // a variant processes hidden k-steps [0, 4(k.ht-1)+k.ksl); ours are [0, 4(ht-1)+ksl); extra ones
       // multiply zero padding, so any superset is exact (just slower)
       const bool covers_h = (k.ht > ht) || (k.ht == ht && k.ksl >= ksl);
       if (!covers_h) continue;
       // both NT=1 and NT=2 of the same geometry must exist
-      const Variant* v1 = find_variant(VariantKey{k.kind, k.ht, k.ksl, k.ot, 1, k.lmid, k.act_a, k.act_b});
-      const Variant* v2 = find_variant(VariantKey{k.kind, k.ht, k.ksl, k.ot, 2, k.lmid, k.act_a, k.act_b});
+      const Variant* v1 = find_variant(VariantKey{k.kind, k.ht, k.ksl, k.ks1, k.ot, 1, k.lmid, k.act_a, k.act_b});
+      const Variant* v2 = find_variant(VariantKey{k.kind, k.ht, k.ksl, k.ks1, k.ot, 2, k.lmid, k.act_a, k.act_b});
       if (!v1 || !v2) continue;
-      const long cost = (long)(4 * (k.ht - 1) + k.ksl) * (k.ht * 16L * (depth > 0 ? depth : 0) + k.ot * 16L) + k.ht * 16L * 32;
+      const long cost = (long)(4 * (k.ht - 1) + k.ksl) * (k.ht * 16L * depth + k.ot * 16L) + k.ht * 16L * 4 * k.ks1;
       if (best_cost < 0 || cost < best_cost) {
         best_cost = cost;
-        f->var_ht = k.ht; f->var_ksl = k.ksl; f->var_ot = k.ot;
+        f->var_ht = k.ht; f->var_ksl = k.ksl; f->var_ks1 = k.ks1; f->var_ot = k.ot;
         f->launch_nt[1] = v1->fn; f->name_nt[1] = v1->name;
         f->launch_nt[2] = v2->fn; f->name_nt[2] = v2->name;
       }
@@ -310,14 +304,15 @@ int gbnf_flow_create(const gbnf_flow_desc* desc, gbnf_flow** out) {
     if (best_cost < 0) {
       delete f;
       return fail(GBNF_ERR_UNSUPPORTED,
-                  "no compiled kernel variant for kind=%d hidden=%d (tiles=%d,last k-steps=%d) out_tiles=%d depth=%d "
-                  "act=(%d,%d); add it to csrc/variants.list", desc->kind, h, ht, ksl, ot, depth, act_a, act_b);
+                  "no compiled kernel variant for kind=%d hidden=%d (tiles=%d,last k-steps=%d) in k-steps=%d out_tiles=%d "
+                  "depth=%d act=(%d,%d); add it to csrc/variants.list", desc->kind, h, ht, ksl, ks1, ot, depth, act_a,
+                  act_b);
     }
   }
-  const int HT = f->var_ht, OT = f->var_ot;
+  const int HT = f->var_ht, OT = f->var_ot, KS1V = f->var_ks1;
 
   const int nnets = glow ? 1 : 2;
-  const size_t NW = net_words(HT, OT, depth);
+  const size_t NW = net_words(HT, KS1V, OT, depth);
   const size_t step_words = SMALL_WORDS + nnets * NW;
   const size_t total_words = step_words * K + 64;
   std::vector<uint32_t> blob(total_words, 0u);
@@ -381,8 +376,7 @@ int gbnf_flow_create(const gbnf_flow_desc* desc, gbnf_flow** out) {
       for (int j = 0; j < in_f; ++j) in_feat.push_back(j);
       for (int j = 0; j < out_f; ++j) out_feat.push_back(in_f + j);
     }
-    const int ks1 = ceil_div(in_f, 4);
-    put_i(sb + 0, ks1);
+    put_i(sb + 0, ceil_div(in_f, 4));
     put_f(sb + 1, ld_const);
     // in tables [g][e]: k = 4e + g
     for (int gg = 0; gg < 4; ++gg)
@@ -413,14 +407,14 @@ int gbnf_flow_create(const gbnf_flow_desc* desc, gbnf_flow** out) {
       }
     const int net_out = paired ? 2 * out_f : out_f;
     if (glow) {
-      pack_net(blob, sb + SMALL_WORDS, desc->glow_steps[s].block, HT, OT, depth, in_f, h, net_out);
+      pack_net(blob, sb + SMALL_WORDS, desc->glow_steps[s].block, HT, KS1V, OT, depth, in_f, h, net_out);
     } else {
-      pack_net(blob, sb + SMALL_WORDS, desc->realnvp_steps[s].t_net, HT, OT, depth, in_f, h, net_out);
-      pack_net(blob, sb + SMALL_WORDS + NW, desc->realnvp_steps[s].s_net, HT, OT, depth, in_f, h, net_out);
+      pack_net(blob, sb + SMALL_WORDS, desc->realnvp_steps[s].t_net, HT, KS1V, OT, depth, in_f, h, net_out);
+      pack_net(blob, sb + SMALL_WORDS + NW, desc->realnvp_steps[s].s_net, HT, KS1V, OT, depth, in_f, h, net_out);
     }
     macs += (double)nnets * ((double)in_f * h + (double)depth * h * h + (double)h * net_out);
     const double kh = 4.0 * (HT - 1) + f->var_ksl;  // live hidden k-steps in the variant
-    padded += (double)nnets * (16.0 * HT * 4 * ks1 + depth * 16.0 * HT * 4 * kh + 16.0 * OT * 4 * kh);
+    padded += (double)nnets * (16.0 * HT * 4 * KS1V + depth * 16.0 * HT * 4 * kh + 16.0 * OT * 4 * kh);
   }
   for (int j = 0; j < d; ++j) put_i(step_words * K + j, sigma[j]);
   f->macs = macs; f->padded_macs = padded;
@@ -467,9 +461,18 @@ namespace gbnf {
 // samples per wave: 32 (NT=2) once there is enough work to give every SIMD of the chip a
 // wave that way (256 CUs x 4 SIMDs), otherwise 16 (NT=1) to expose more waves.
 static int pick_nt(int64_t n, int n_comp) {
+  static const int forced = [] {
+    const char* e = getenv("GBNF_FORCE_NT");   // tuning / test knob: 1 or 2
+    return e ? atoi(e) : 0;
+  }();
+  if (forced == 1 || forced == 2) return forced;
   const int64_t waves32 = ((n + 31) / 32) * n_comp;
   return waves32 >= 1024 ? 2 : 1;
 }
+
+#ifdef GBNF_STAMPS
+static unsigned long long* g_stamp_buf = nullptr;
+#endif
 
 static int launch_flow(const gbnf_flow* f, const uint32_t* const* table, int c_begin, int n_comp, const float* x,
                        int64_t n, float* z, float* ldj, float* ll, const float* base, hipStream_t stream) {
@@ -483,6 +486,9 @@ static int launch_flow(const gbnf_flow* f, const uint32_t* const* table, int c_b
   p.base_mean = base; p.base_std = base ? base + f->d : nullptr;
   p.n = n; p.d = f->d; p.n_steps = f->n_steps; p.c_begin = c_begin; p.n_comp = n_comp;
   p.n_tiles = (int32_t)tiles; p.additive = f->additive;
+#ifdef GBNF_STAMPS
+  p.dbg = g_stamp_buf;
+#endif
   hipError_t e = f->launch_nt[nt](p, (unsigned)grid, stream);
   if (e != hipSuccess) return fail(GBNF_ERR_HIP, "launch of %s failed: %s", f->name_nt[nt], hipGetErrorString(e));
   return GBNF_OK;
@@ -512,6 +518,11 @@ __global__ void __launch_bounds__(256) mixture_lse_kernel(const float* __restric
 
 }  // namespace gbnf
 
+#ifdef GBNF_STAMPS
+// diagnostic builds only (not part of include/gbnf.h): device buffer of 8 u64 per block
+extern "C" int gbnf_debug_set_stamp_buffer(void* dev) { gbnf::g_stamp_buf = (unsigned long long*)dev; return 0; }
+#endif
+
 extern "C" {
 
 int gbnf_flow_forward(const gbnf_flow* flow, const float* x, int64_t n, float* z, float* ldj, float* ll,
@@ -533,7 +544,7 @@ int gbnf_mixture_create(gbnf_flow* const* flows, int32_t n_flows, gbnf_mixture**
     if (!f) return fail(GBNF_ERR_INVALID, "gbnf_mixture_create: flow %d is null", c);
     if (f->kind != f0->kind || f->d != f0->d || f->n_steps != f0->n_steps || f->additive != f0->additive ||
         f->hidden != f0->hidden || f->depth != f0->depth || f->act_a != f0->act_a || f->act_b != f0->act_b ||
-        f->var_ht != f0->var_ht || f->var_ksl != f0->var_ksl || f->var_ot != f0->var_ot)
+        f->var_ht != f0->var_ht || f->var_ksl != f0->var_ksl || f->var_ks1 != f0->var_ks1 || f->var_ot != f0->var_ot)
       return fail(GBNF_ERR_INVALID, "gbnf_mixture_create: flow %d has a different architecture than flow 0", c);
     table[c] = f->blob_dev;
   }

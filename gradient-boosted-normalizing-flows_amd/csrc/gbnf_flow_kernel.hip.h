@@ -15,6 +15,9 @@
 //   * weights are the A operand, pre-tiled at pack time into the exact lane order so
 //     every wave-load is one contiguous 1 KiB global_load_dwordx4 streamed from L2
 //     (one component per XCD => ~1.2 MB of weights stays in that XCD's 4 MiB L2);
+//   * with ~330 registers a wave runs alone on its SIMD, so the instruction stream itself
+//     interleaves MFMA, tanh (VALU) and weight prefetch (software pipelining by hand,
+//     fenced with sched_barrier so the compiler cannot sink the prefetches);
 //   * log|det J| partial sums stay in lanes and are folded across the 4 lane groups
 //     with two DPP/shuffle steps at the very end, together with sum_j z_j^2.
 //
@@ -43,20 +46,25 @@ constexpr int ZSLOTS = 64;   // features per sample <= 64
 constexpr int NENT = 8;      // per-lane table entries (in: k-steps, out: coupled features)
 constexpr int SMALL_HDR = 16;
 constexpr int SMALL_WORDS = SMALL_HDR + 10 * 4 * NENT;  // header + {slot,p0..p3} x {in,out}
+constexpr int LDS_TABLE_STEPS = 12;  // per-step tables are staged in LDS when K <= this
 
-// Packed-parameter layout of one coupling network, in 32-bit words (host packer and
-// kernel share it).  HT = hidden tiles of 16 units, OT = output tiles of 16 rows,
-// LMID = number of hidden->hidden layers (coupling_network_depth).
-template <int HT, int OT, int LMID>
-struct NetLayout {
-  static constexpr int W1 = 0;                                   // [KS1MAX+1][HT][64]        f32
-  static constexpr int B1 = W1 + (KS1MAX + 1) * HT * 64;         // [HT][4 g][4 r]
-  static constexpr int MID0 = B1 + HT * 16;                      // LMID x { W [HT+1][HT][64][4], B [HT][4][4] }
-  static constexpr int MID_W = (HT + 1) * HT * 256;
-  static constexpr int MID_STRIDE = MID_W + HT * 16;
-  static constexpr int W3 = MID0 + LMID * MID_STRIDE;            // [HT+1][OT][64][4]
-  static constexpr int B3 = W3 + (HT + 1) * OT * 256;            // [OT][4][4]
-  static constexpr int NET_WORDS = B3 + OT * 16;
+// Packed-parameter layout of one coupling network, in 32-bit words (host packer and kernel
+// share it).  HT = hidden tiles of 16 units, KS1 = first-layer k-steps, OT = output tiles of
+// 16 rows, LMID = number of hidden->hidden layers (coupling_network_depth).
+// "+1"/"+4" rows are zero pads that the software prefetch may touch past the end.
+struct NetLayoutRT {
+  int KQ, W1, W1_TILE, B1, MID0, MID_W, MID_STRIDE, W3, B3, NET_WORDS;
+  constexpr NetLayoutRT(int HT, int KS1, int OT, int LMID)
+      : KQ((KS1 + 3) / 4),
+        W1(0),
+        W1_TILE(64 * ((KS1 + 3) / 4) * 4),                       // [t][lane][KQ*4] f32
+        B1(W1 + (HT + 4) * W1_TILE),                              // [HT+4][4 g][4 r]
+        MID0(B1 + (HT + 4) * 16),                                 // LMID x { W [HT+1][HT][64][4], B [HT+1][4][4] }
+        MID_W((HT + 1) * HT * 256),
+        MID_STRIDE(MID_W + (HT + 1) * 16),
+        W3(MID0 + LMID * MID_STRIDE),                             // [HT+1][OT][64][4]
+        B3(W3 + (HT + 1) * OT * 256),                             // [OT][4][4]
+        NET_WORDS(B3 + OT * 16) {}
 };
 
 struct FlowLaunch {
@@ -74,22 +82,49 @@ struct FlowLaunch {
   int32_t n_comp;
   int32_t n_tiles;               // ceil(n / (16*NT))
   int32_t additive;              // glow: additive coupling
+  unsigned long long* dbg;       // diagnostic builds (-DGBNF_STAMPS) only: per-block phase cycle sums
 };
 
 __device__ __forceinline__ float as_f32(uint32_t u) { return __builtin_bit_cast(float, u); }
 
-// tanh with absolute error ~1e-7 (1 - 2/(e^{2|x|}+1) on v_exp_f32 / v_rcp_f32, 1 ulp each).
-// Hidden activations feed f32 dot products of O(1) terms, so absolute (not relative)
-// accuracy is what the log-likelihood sees; parity tests pin the end-to-end 1e-5 bar.
+// In-kernel phase stamps (cdna_hip_programming.md section 7).  Diagnostic builds only: the shipped
+// kernel is compiled without GBNF_STAMPS and then no stamp executes.
+struct Stamps {
+#ifdef GBNF_STAMPS
+  unsigned long long last = 0;
+  unsigned long long acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#endif
+  __device__ __forceinline__ void start() {
+#ifdef GBNF_STAMPS
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(last)::"memory");
+    __builtin_amdgcn_sched_barrier(0);
+#endif
+  }
+  __device__ __forceinline__ void mark(int k) {
+#ifdef GBNF_STAMPS
+    unsigned long long t;
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
+    __builtin_amdgcn_sched_barrier(0);
+    acc[k] += t - last;
+    last = t;
+#else
+    (void)k;
+#endif
+  }
+};
+
+// tanh with absolute error ~1e-7: 1 - 2/(e^{2x}+1) on v_exp_f32 / v_rcp_f32 (1 ulp each); saturates
+// correctly at +-inf.  Hidden activations feed f32 dot products of O(1) terms, so absolute (not
+// relative) accuracy is what the log-likelihood sees; parity tests pin the end-to-end 1e-5 bar.
 __device__ __forceinline__ float tanh_act(float x) {
 #ifdef GBNF_TANH_LIBM
   return tanhf(x);
 #else
-  float ax = __builtin_fabsf(x);
-  float e = __builtin_amdgcn_exp2f(ax * 2.8853900817779268f);  // e^{2|x|}
-  float r = __builtin_amdgcn_rcpf(e + 1.0f);
-  float t = __builtin_fmaf(-2.0f, r, 1.0f);
-  return __builtin_copysignf(t, x);
+  const float e = __builtin_amdgcn_exp2f(x * 2.8853900817779268f);  // e^{2x}
+  const float r = __builtin_amdgcn_rcpf(e + 1.0f);
+  return __builtin_fmaf(-2.0f, r, 1.0f);
 #endif
 }
 
@@ -106,107 +141,104 @@ __device__ __forceinline__ f32x4 mfma4(float a, float b, f32x4 c) {
   return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
 }
 
+// Scheduling fence that only MFMAs may not cross (VALU / SALU / transcendental / VMEM / DS may):
+// keeps the hand-written MFMA order -- accumulator chains alternating, so a dependent
+// v_mfma_f32_16x16x4_f32 (40-cycle latency, 32-cycle issue) is never issued back to back; left alone,
+// the scheduler groups each chain's MFMAs together and every one of them stalls on its predecessor.
+#define MFMA_ORDER_FENCE() __builtin_amdgcn_sched_barrier(0x7F6)
+
 // ---------------------------------------------------------------------------------
 // Register-resident coupling network for one wave.
-//   zb      : wave-private LDS scratch, zb[(s*NT+nt)*64 + lane] = B operand of first-layer
-//             k-step s (normalised z1 values), rows 0..ks1 valid (row ks1 is a zero pad)
-//   out     : OT x NT accumulator tiles of the last Linear (bias included)
-// KSL = live k-steps (1..4) in the LAST hidden tile (hidden width padded to a k-step
-// multiple; the padded units sit in whole trailing k-steps so they are skipped, not
-// multiplied by zero).
+//   zb  : first-layer B operands, zb[s][nt] = normalised input feature 4s+g of sample (nt, i)
+//   out : OT x NT accumulator tiles of the last Linear (bias included)
+// KSL = live k-steps (1..4) in the LAST hidden tile (hidden width padded to a k-step multiple;
+// the padded units sit in whole trailing k-steps so they are skipped, not multiplied by zero).
 // ---------------------------------------------------------------------------------
-template <int HT, int KSL, int OT, int NT, int LMID, int ACT>
-__device__ __forceinline__ void coupling_net(const uint32_t* __restrict__ net, const float* zb,
-                                             int ks1, int lane, int g, f32x4 (&out)[OT][NT]) {
-  using L = NetLayout<HT, OT, LMID>;
+template <int HT, int KSL, int KS1, int OT, int NT, int LMID, int ACT>
+__device__ __forceinline__ void coupling_net(const uint32_t* __restrict__ net, const float (&zb)[KS1][NT],
+                                             int lane, int g, f32x4 (&out)[OT][NT], Stamps& st) {
+  constexpr NetLayoutRT L(HT, KS1, OT, LMID);
+  constexpr int KQ = L.KQ;
+  const f32x4* w1 = reinterpret_cast<const f32x4*>(net + L.W1) + lane * KQ;   // + t*64*KQ
+  const f32x4* b1 = reinterpret_cast<const f32x4*>(net + L.B1) + g;           // + t*4
+  const f32x4* w3 = reinterpret_cast<const f32x4*>(net + L.W3) + lane;
+  const f32x4* b3 = reinterpret_cast<const f32x4*>(net + L.B3) + g;
 
-  // ---- layer 0: in -> hidden.  Rolled over k-steps, all HT*NT accumulators independent.
   f32x4 hA[HT][NT];
-  {
-    const float* w1 = reinterpret_cast<const float*>(net + L::W1) + lane;
-    const f32x4* b1 = reinterpret_cast<const f32x4*>(net + L::B1) + g;
-#pragma unroll
-    for (int t = 0; t < HT; ++t) {
-      f32x4 b = b1[t * 4];
-#pragma unroll
-      for (int nt = 0; nt < NT; ++nt) hA[t][nt] = b;
-    }
-    float wc[HT];
-#pragma unroll
-    for (int t = 0; t < HT; ++t) wc[t] = w1[t * 64];
-    float zc[NT];
-#pragma unroll
-    for (int nt = 0; nt < NT; ++nt) zc[nt] = zb[nt * 64 + lane];
-#pragma unroll 1
-    for (int s = 0; s < ks1; ++s) {
-      float zn[NT];
-#pragma unroll
-      for (int nt = 0; nt < NT; ++nt) zn[nt] = zb[((s + 1) * NT + nt) * 64 + lane];
-      const float* wn = w1 + (s + 1) * HT * 64;
-#pragma unroll
-      for (int t = 0; t < HT; ++t) {
-        float w = wc[t];
-        wc[t] = wn[t * 64];
-#pragma unroll
-        for (int nt = 0; nt < NT; ++nt) hA[t][nt] = mfma4(w, zc[nt], hA[t][nt]);
-      }
-#pragma unroll
-      for (int nt = 0; nt < NT; ++nt) zc[nt] = zn[nt];
-    }
-#pragma unroll
-    for (int t = 0; t < HT; ++t)
-#pragma unroll
-      for (int nt = 0; nt < NT; ++nt)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) hA[t][nt][r] = act_fn<ACT>(hA[t][nt][r]);
-  }
 
-  // ---- hidden -> hidden layers that are NOT the last one: fully unrolled (their output
-  //      tiles must land in a statically indexed register array).
+  // one tile of layer 0 (in -> hidden): KS1 k-steps, NT independent accumulator chains
+  auto layer0_tile = [&](const f32x4 (&w)[KQ], f32x4 bias, f32x4 (&h)[NT]) {
 #pragma unroll
-  for (int m = 0; m < LMID - 1; ++m) {
-    const f32x4* w = reinterpret_cast<const f32x4*>(net + L::MID0 + m * L::MID_STRIDE) + lane;
-    const f32x4* b = reinterpret_cast<const f32x4*>(net + L::MID0 + m * L::MID_STRIDE + L::MID_W) + g;
-    f32x4 hB[HT][NT];
+    for (int nt = 0; nt < NT; ++nt) h[nt] = bias;
 #pragma unroll
-    for (int u = 0; u < HT; ++u) {
-      f32x4 bb = b[u * 4];
+    for (int s = 0; s < KS1; ++s) {
 #pragma unroll
-      for (int nt = 0; nt < NT; ++nt) hB[u][nt] = bb;
+      for (int nt = 0; nt < NT; ++nt) {
+        h[nt] = mfma4(w[s >> 2][s & 3], zb[s][nt], h[nt]);
+        MFMA_ORDER_FENCE();
+      }
+    }
+  };
+  auto load_w1 = [&](int t, f32x4 (&w)[KQ]) {
+#pragma unroll
+    for (int q = 0; q < KQ; ++q) w[q] = w1[t * 64 * KQ + q];
+  };
+
+  if constexpr (LMID != 1) {
+    // ---- generic (not hand-pipelined) forms for depth 0 and depth >= 2
+    {
+      f32x4 wq[2][KQ];
+      f32x4 bq[2];
+      load_w1(0, wq[0]);
+      bq[0] = b1[0];
 #pragma unroll
       for (int t = 0; t < HT; ++t) {
-        f32x4 a = w[(u * HT + t) * 64];
+        load_w1(t + 1, wq[(t + 1) & 1]);
+        bq[(t + 1) & 1] = b1[(t + 1) * 4];
+        layer0_tile(wq[t & 1], bq[t & 1], hA[t]);
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          if (t < HT - 1 || r < KSL) {
+        for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
-            for (int nt = 0; nt < NT; ++nt) hB[u][nt] = mfma4(a[r], hA[t][nt][r], hB[u][nt]);
+          for (int r = 0; r < 4; ++r) hA[t][nt][r] = act_fn<ACT>(hA[t][nt][r]);
+      }
+    }
+    st.mark(1);
+#pragma unroll
+    for (int m = 0; m < LMID; ++m) {
+      const f32x4* w = reinterpret_cast<const f32x4*>(net + L.MID0 + m * L.MID_STRIDE) + lane;
+      const f32x4* b = reinterpret_cast<const f32x4*>(net + L.MID0 + m * L.MID_STRIDE + L.MID_W) + g;
+      f32x4 hB[HT][NT];
+#pragma unroll
+      for (int u = 0; u < HT; ++u) {
+        f32x4 bb = b[u * 4];
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) hB[u][nt] = bb;
+#pragma unroll
+        for (int t = 0; t < HT; ++t) {
+          f32x4 a = w[(u * HT + t) * 64];
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            if (t < HT - 1 || r < KSL) {
+#pragma unroll
+              for (int nt = 0; nt < NT; ++nt) hB[u][nt] = mfma4(a[r], hA[t][nt][r], hB[u][nt]);
+            }
           }
         }
       }
+#pragma unroll
+      for (int t = 0; t < HT; ++t)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) hA[t][nt][r] = act_fn<ACT>(hB[t][nt][r]);
     }
-#pragma unroll
-    for (int t = 0; t < HT; ++t)
-#pragma unroll
-      for (int nt = 0; nt < NT; ++nt)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) hA[t][nt][r] = act_fn<ACT>(hB[t][nt][r]);
-  }
-
-  // ---- output accumulators start at the last Linear's bias
-  const f32x4* w3 = reinterpret_cast<const f32x4*>(net + L::W3) + lane;
-  {
-    const f32x4* b3 = reinterpret_cast<const f32x4*>(net + L::B3) + g;
+    st.mark(2);
 #pragma unroll
     for (int o = 0; o < OT; ++o) {
       f32x4 b = b3[o * 4];
 #pragma unroll
       for (int nt = 0; nt < NT; ++nt) out[o][nt] = b;
     }
-  }
-
-  if constexpr (LMID == 0) {
-    // hidden -> out straight from hA
 #pragma unroll
     for (int t = 0; t < HT; ++t) {
 #pragma unroll
@@ -221,71 +253,184 @@ __device__ __forceinline__ void coupling_net(const uint32_t* __restrict__ net, c
         }
       }
     }
+    st.mark(4);
   } else {
-    // ---- last hidden->hidden layer fused with the output layer.  Rolled over output tile u:
-    //      tile u of the hidden layer is finished (all k), activated, and immediately
-    //      consumed as k-chunk u of the output layer -- it never exists outside 4*NT VGPRs.
-    //      Weight tiles for u+1 are requested right after tile u's registers are consumed
-    //      (one full tile time of prefetch distance; the blob has one pad row for u = HT).
-    const f32x4* w2 = reinterpret_cast<const f32x4*>(net + L::MID0 + (LMID - 1) * L::MID_STRIDE) + lane;
-    const f32x4* b2 = reinterpret_cast<const f32x4*>(net + L::MID0 + (LMID - 1) * L::MID_STRIDE + L::MID_W) + g;
-    f32x4 A[HT];
-#pragma unroll
-    for (int t = 0; t < HT; ++t) A[t] = w2[t * 64];
+    // ---- depth 1 (the reference default): Linear -> act -> Linear -> act -> Linear as ONE
+    //      hand-pipelined stream.  The wave runs alone on its SIMD, so MFMA, VALU (tanh) and the
+    //      weight prefetch are interleaved in program order:
+    //        pass u = 0 : region t = { 4*NT*.. MFMAs of hidden-layer tile 0, k-chunk t }  +
+    //                     { layer-0 tile t+1: KS1*NT MFMAs, then its tanh }  + prefetches
+    //        pass u >= 1: region t = { MFMAs of hidden tile u, k-chunk t } + one tanh value of tile
+    //                     u-1 per region; after the last tanh, tile u-1 is consumed as k-chunk u-1
+    //                     of the output layer.  Tile u never exists outside 4*NT registers.
+    //      Every region re-issues the weight tile it just consumed for the NEXT pass into the other
+    //      register set (ping-pong => no copies, a full pass of prefetch distance); biases are
+    //      fetched one pass ahead; sched_barrier fences keep the compiler from sinking the loads.
+    const f32x4* w2 = reinterpret_cast<const f32x4*>(net + L.MID0) + lane;           // [u][t][64]
+    const f32x4* b2 = reinterpret_cast<const f32x4*>(net + L.MID0 + L.MID_W) + g;    // [u][4]
+
+    f32x4 A0[HT], A1[HT];
     f32x4 A3[OT];
+    f32x4 wq[4][KQ];   // layer-0 weight tiles, ring of 4 (tile k lives in wq[k & 3])
+    f32x4 bq[4];
+    f32x4 bias_c, bias_n;
+
+    // prologue loads: everything the first pass needs
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      load_w1(k, wq[k]);          // tiles >= HT are zero pads
+      bq[k] = b1[k * 4];
+    }
+    bias_c = b2[0];
+#pragma unroll
+    for (int t = 0; t < HT; ++t) A0[t] = w2[t * 64];
 #pragma unroll
     for (int o = 0; o < OT; ++o) A3[o] = w3[o * 64];
+#pragma unroll
+    for (int o = 0; o < OT; ++o) {
+      f32x4 b = b3[o * 4];
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) out[o][nt] = b;
+    }
 
-    auto hidden_tile = [&](int u, f32x4 (&hb)[NT]) {
-      f32x4 bb = b2[u * 4];
+    // tanh of tile u-1 is sprinkled over regions R0 .. R0+NTR-1 of pass u (not region 0: its inputs
+    // are the previous pass's last MFMA results), then tile u-1 feeds the output layer in region TG
+    constexpr int NV = 4 * NT;                          // raw sums per hidden tile per lane
+    constexpr int R0 = (HT > 1) ? 1 : 0;
+    constexpr int VPT = (NV + (HT - R0) - 1) / (HT - R0);   // tanh values per region
+    constexpr int NTR = (NV + VPT - 1) / VPT;
+    constexpr int TG = (R0 + NTR < HT) ? R0 + NTR : HT - 1;
+
+    f32x4 pre[NT];   // raw sums of hidden tile u-1
+    f32x4 hb[NT];    // act(pre)
+
+    // k-chunk t of the current hidden tile; the NEXT pass's weight tiles are requested two per
+    // region, i.e. all of them in the first half of the pass, so that nothing young is in flight
+    // at the loop back-edge (the compiler drains vmcnt there)
+    auto region = [&](int t, f32x4 (&Ac)[HT], f32x4 (&An)[HT], const f32x4* wn, f32x4 (&acc)[NT]) {
+      if (2 * t < HT) An[2 * t] = wn[(2 * t) * 64];
+      if (2 * t + 1 < HT) An[2 * t + 1] = wn[(2 * t + 1) * 64];
 #pragma unroll
-      for (int nt = 0; nt < NT; ++nt) hb[nt] = bb;
-      const f32x4* wn = w2 + (u + 1) * HT * 64;
+      for (int r = 0; r < 4; ++r) {
+        if (t < HT - 1 || r < KSL) {
 #pragma unroll
-      for (int t = 0; t < HT; ++t) {
-        f32x4 a = A[t];
-        A[t] = wn[t * 64];
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          if (t < HT - 1 || r < KSL) {
-#pragma unroll
-            for (int nt = 0; nt < NT; ++nt) hb[nt] = mfma4(a[r], hA[t][nt][r], hb[nt]);
+          for (int nt = 0; nt < NT; ++nt) {
+            acc[nt] = mfma4(Ac[t][r], hA[t][nt][r], acc[nt]);
+            MFMA_ORDER_FENCE();
           }
+        } else {
+          // the skipped k-steps' weight registers must stay "used" until here: otherwise the
+          // allocator recycles them while the prefetch that writes them is still in flight and
+          // has to drain vmcnt(0) in the middle of a pass
+          asm volatile("" ::"v"(Ac[t][r]));
         }
       }
-#pragma unroll
-      for (int nt = 0; nt < NT; ++nt)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) hb[nt][r] = act_fn<ACT>(hb[nt][r]);
     };
-
-#pragma unroll 1
-    for (int u = 0; u < HT - 1; ++u) {
-      f32x4 hb[NT];
-      hidden_tile(u, hb);
-      const f32x4* w3n = w3 + (u + 1) * OT * 64;
+    auto out_chunk = [&](const f32x4* w3n, int nk) {
 #pragma unroll
       for (int o = 0; o < OT; ++o) {
         f32x4 a = A3[o];
         A3[o] = w3n[o * 64];
 #pragma unroll
-        for (int r = 0; r < 4; ++r)
+        for (int r = 0; r < 4; ++r) {
+          if (r < nk) {
 #pragma unroll
-          for (int nt = 0; nt < NT; ++nt) out[o][nt] = mfma4(a[r], hb[nt][r], out[o][nt]);
+            for (int nt = 0; nt < NT; ++nt) {
+              out[o][nt] = mfma4(a[r], hb[nt][r], out[o][nt]);
+              MFMA_ORDER_FENCE();
+            }
+          }
+        }
       }
-    }
+    };
+    auto pass = [&](int u, f32x4 (&Ac)[HT], f32x4 (&An)[HT]) {
+      f32x4 acc[NT];
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) acc[nt] = bias_c;
+      bias_n = b2[(u + 1) * 4];
+      const f32x4* wn = w2 + (u + 1) * HT * 64;
+#pragma unroll
+      for (int t = 0; t < HT; ++t) {
+        region(t, Ac, An, wn, acc);
+        if (t >= R0 && t - R0 < NTR) {
+#pragma unroll
+          for (int v = (t - R0) * VPT; v < (t - R0 + 1) * VPT && v < NV; ++v)
+            hb[v >> 2][v & 3] = act_fn<ACT>(pre[v >> 2][v & 3]);
+        }
+        if (t == TG) out_chunk(w3 + u * OT * 64, 4);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) pre[nt] = acc[nt];
+      bias_c = bias_n;
+    };
+
+    // layer-0 tiles 0 and 1 (tile 1 stays raw: it is activated during region 0)
+    f32x4 hraw[2][NT];
     {
-      f32x4 hb[NT];
-      hidden_tile(HT - 1, hb);
-#pragma unroll
-      for (int o = 0; o < OT; ++o) {
-        f32x4 a = A3[o];
-#pragma unroll
-        for (int r = 0; r < KSL; ++r)
-#pragma unroll
-          for (int nt = 0; nt < NT; ++nt) out[o][nt] = mfma4(a[r], hb[nt][r], out[o][nt]);
+      f32x4 h0[NT];
+      layer0_tile(wq[0], bq[0], h0);
+      if (HT > 1) layer0_tile(wq[1], bq[1], hraw[1]);
+      // ring slots 0 and 1 are free again: tiles 4 and 5 (region t refills slot (t+2)&3 with tile t+6)
+      if (4 < HT) {
+        load_w1(4, wq[0]);
+        bq[0] = b1[4 * 4];
       }
+      if (5 < HT) {
+        load_w1(5, wq[1]);
+        bq[1] = b1[5 * 4];
+      }
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) hA[0][nt][r] = act_fn<ACT>(h0[nt][r]);
     }
+    __builtin_amdgcn_sched_barrier(0);
+    st.mark(1);
+
+    // pass u = 0 with layer 0 folded in, two tiles of lookahead:
+    //   region t = { layer-0 MFMAs of tile t+2 } + { hidden-layer MFMAs, k-chunk t } + { tanh of tile t+1 }
+    {
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) pre[nt] = bias_c;
+      bias_n = b2[4];
+#pragma unroll
+      for (int t = 0; t < HT; ++t) {
+        if (t + 2 < HT) {
+          layer0_tile(wq[(t + 2) & 3], bq[(t + 2) & 3], hraw[t & 1]);
+          if (t + 6 < HT) {
+            load_w1(t + 6, wq[(t + 2) & 3]);
+            bq[(t + 2) & 3] = b1[(t + 6) * 4];
+          }
+        }
+        region(t, A0, A1, w2 + HT * 64, pre);
+        if (t + 1 < HT) {
+#pragma unroll
+          for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) hA[t + 1][nt][r] = act_fn<ACT>(hraw[(t + 1) & 1][nt][r]);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      bias_c = bias_n;
+    }
+    st.mark(2);
+    {
+      int u = 1;
+#pragma unroll 1
+      for (; u + 1 < HT; u += 2) {
+        pass(u, A1, A0);
+        pass(u + 1, A0, A1);
+      }
+      if (u < HT) pass(u, A1, A0);
+    }
+    st.mark(3);
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) hb[nt][r] = act_fn<ACT>(pre[nt][r]);
+    out_chunk(w3 + HT * OT * 64, KSL);
+    st.mark(4);
   }
 }
 
@@ -300,17 +445,67 @@ __device__ __forceinline__ float norm_fn(float v, float p0, float p1, float p2, 
   }
 }
 
-__device__ __forceinline__ float sigmoid_acc(float v) { return 1.0f / (1.0f + expf(-v)); }
+// scale = sigmoid(v) and log(scale) from one exp: e = exp(-v); scale = 1/(1+e); log scale = -log(1+e).
+// (the reference takes log() of the rounded sigmoid, models/glow.py:333-338; both are within an ulp or
+// two of the exact value).  v_exp_f32 / v_rcp_f32 / v_log_f32 are 1-ulp instructions.
+__device__ __forceinline__ void sigmoid_logsigmoid(float v, float& sc, float& lsc) {
+#ifdef GBNF_EPILOGUE_LIBM
+  sc = 1.0f / (1.0f + expf(-v));
+  lsc = logf(sc);
+#else
+  const float e = __builtin_amdgcn_exp2f(v * -1.4426950408889634f);
+  const float s1 = 1.0f + e;
+  sc = __builtin_amdgcn_rcpf(s1);
+  lsc = -0.69314718055994531f * __builtin_amdgcn_logf(s1);
+#endif
+}
 
-template <int KIND, int HT, int KSL, int OT, int NT, int LMID, int ACTA, int ACTB>
+// exp(v) on v_exp_f32 with the rounding error of v*log2(e) folded back in (keeps ~1-2 ulp for |v| < 64)
+__device__ __forceinline__ float exp_fast(float v) {
+#ifdef GBNF_EPILOGUE_LIBM
+  return expf(v);
+#else
+  const float t = v * 1.4426950408889634f;
+  const float lo = __builtin_fmaf(v, 1.4426950408889634f, -t) + v * 1.9259629911266175e-8f;  // log2(e) lo part
+  const float e = __builtin_amdgcn_exp2f(t);
+  return __builtin_fmaf(e, lo * 0.69314718055994531f, e);
+#endif
+}
+
+// per-lane view of one {slot, p0..p3} table (8 entries): works for LDS and global pointers
+struct LaneTable {
+  int slot[NENT];
+  float p0[NENT], p1[NENT], p2[NENT], p3[NENT];
+  template <typename P>
+  __device__ __forceinline__ void load(P tab) {   // tab -> [5 arrays][4 g][NENT], already offset by g*NENT
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      i32x4 s4 = *reinterpret_cast<const i32x4*>(tab + h * 4);
+      f32x4 a4 = *reinterpret_cast<const f32x4*>(tab + 32 + h * 4);
+      f32x4 b4 = *reinterpret_cast<const f32x4*>(tab + 64 + h * 4);
+      f32x4 c4 = *reinterpret_cast<const f32x4*>(tab + 96 + h * 4);
+      f32x4 d4 = *reinterpret_cast<const f32x4*>(tab + 128 + h * 4);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        slot[h * 4 + e] = s4[e]; p0[h * 4 + e] = a4[e]; p1[h * 4 + e] = b4[e];
+        p2[h * 4 + e] = c4[e]; p3[h * 4 + e] = d4[e];
+      }
+    }
+  }
+};
+
+template <int KIND, int HT, int KSL, int KS1, int OT, int NT, int LMID, int ACTA, int ACTB>
 __global__ void __launch_bounds__(64) flow_kernel(const FlowLaunch p) {
   constexpr int ZS = 16 * NT + 1;   // +1: conflict-free transposed x load / z store
   constexpr int NNETS = (KIND == GBNF_KIND_REALNVP) ? 2 : 1;
-  using L = NetLayout<HT, OT, LMID>;
-  constexpr int STEP_WORDS = SMALL_WORDS + NNETS * L::NET_WORDS;
+  constexpr NetLayoutRT L(HT, KS1, OT, LMID);
+  constexpr int STEP_WORDS = SMALL_WORDS + NNETS * L.NET_WORDS;
 
-  __shared__ float Z[ZSLOTS * ZS];
-  __shared__ float ZB[(KS1MAX + 1) * NT * 64];
+  // one dynamic LDS block (16-byte aligned base): [ per-step tables | Z ]
+  extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
+  const bool lds_tables = p.n_steps <= LDS_TABLE_STEPS;
+  uint32_t* SM = lds;
+  float* Z = reinterpret_cast<float*>(lds + (lds_tables ? p.n_steps * SMALL_WORDS : 0));
 
   const int lane = threadIdx.x;
   const int i = lane & 15;
@@ -333,7 +528,14 @@ __global__ void __launch_bounds__(64) flow_kernel(const FlowLaunch p) {
   const int d = p.d;
   const int64_t row0 = (int64_t)tile * (16 * NT);
 
-  // ---- x tile -> Z[feature][sample]  (rows of x are contiguous: coalesced 4*d-byte runs)
+  // ---- per-step index/normalisation tables -> LDS (1.3 KB per step), x tile -> Z[feature][sample]
+  if (lds_tables) {
+    for (int s = 0; s < p.n_steps; ++s) {
+      const uint32_t* src = blob + (size_t)s * STEP_WORDS;
+      for (int w = lane * 4; w < SMALL_WORDS; w += 256)
+        *reinterpret_cast<i32x4*>(SM + s * SMALL_WORDS + w) = *reinterpret_cast<const i32x4*>(src + w);
+    }
+  }
   if (lane < d) {
 #pragma unroll 8
     for (int r = 0; r < 16 * NT; ++r) {
@@ -343,127 +545,102 @@ __global__ void __launch_bounds__(64) flow_kernel(const FlowLaunch p) {
       Z[lane * ZS + r] = v;
     }
   }
-#pragma unroll
-  for (int nt = 0; nt < NT; ++nt) ZB[(KS1MAX * NT + nt) * 64 + lane] = 0.0f;
   __syncthreads();
 
   float ld[NT];
 #pragma unroll
   for (int nt = 0; nt < NT; ++nt) ld[nt] = 0.0f;
   float ld_const = 0.0f;
+  Stamps st;
+  st.start();
 
   for (int step = 0; step < p.n_steps; ++step) {
     const uint32_t* __restrict__ sp = blob + (size_t)step * STEP_WORDS;
-    const int ks1 = __builtin_amdgcn_readfirstlane((int)sp[0]);
-    ld_const += as_f32(sp[1]);
-    const uint32_t* tab = sp + SMALL_HDR + g * NENT;
+    LaneTable tin, tout;
+    if (lds_tables) {
+      const uint32_t* sm = SM + step * SMALL_WORDS;
+      ld_const += as_f32(sm[1]);
+      tin.load(sm + SMALL_HDR + g * NENT);
+      tout.load(sm + SMALL_HDR + 160 + g * NENT);
+    } else {
+      ld_const += as_f32(sp[1]);
+      tin.load(sp + SMALL_HDR + g * NENT);
+      tout.load(sp + SMALL_HDR + 160 + g * NENT);
+    }
 
-    // ---- normalise the coupling net's inputs in place and stage them as first-layer B operands
-    {
-      int slot[NENT];
-      float p0[NENT], p1[NENT], p2[NENT], p3[NENT];
+    // ---- normalise the coupling net's inputs in place; they are the first layer's B operands
+    float zb[KS1][NT];
 #pragma unroll
-      for (int h = 0; h < 2; ++h) {
-        i32x4 s4 = *reinterpret_cast<const i32x4*>(tab + h * 4);
-        f32x4 a4 = *reinterpret_cast<const f32x4*>(tab + 32 + h * 4);
-        f32x4 b4 = *reinterpret_cast<const f32x4*>(tab + 64 + h * 4);
-        f32x4 c4 = *reinterpret_cast<const f32x4*>(tab + 96 + h * 4);
-        f32x4 d4 = *reinterpret_cast<const f32x4*>(tab + 128 + h * 4);
+    for (int e = 0; e < KS1; ++e) {
+      const bool live = tin.slot[e] >= 0;
+      const int zoff = (live ? tin.slot[e] : 0) * ZS + i;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          slot[h * 4 + e] = s4[e]; p0[h * 4 + e] = a4[e]; p1[h * 4 + e] = b4[e];
-          p2[h * 4 + e] = c4[e]; p3[h * 4 + e] = d4[e];
-        }
-      }
-#pragma unroll
-      for (int e = 0; e < NENT; ++e) {
-        if (e < ks1) {
-          const bool live = slot[e] >= 0;
-          const int zoff = (live ? slot[e] : 0) * ZS + i;
-#pragma unroll
-          for (int nt = 0; nt < NT; ++nt) {
-            float v = Z[zoff + 16 * nt];
-            v = norm_fn<KIND>(v, p0[e], p1[e], p2[e], p3[e]);
-            if (live) Z[zoff + 16 * nt] = v;
-            ZB[(e * NT + nt) * 64 + lane] = live ? v : 0.0f;
-          }
-        }
+      for (int nt = 0; nt < NT; ++nt) {
+        float v = Z[zoff + 16 * nt];
+        v = norm_fn<KIND>(v, tin.p0[e], tin.p1[e], tin.p2[e], tin.p3[e]);
+        if (live) Z[zoff + 16 * nt] = v;
+        zb[e][nt] = live ? v : 0.0f;
       }
     }
 
     // ---- coupling network(s) on the matrix cores
+    st.mark(0);
     f32x4 outA[OT][NT];
-    coupling_net<HT, KSL, OT, NT, LMID, ACTA>(sp + SMALL_WORDS, ZB, ks1, lane, g, outA);
+    coupling_net<HT, KSL, KS1, OT, NT, LMID, ACTA>(sp + SMALL_WORDS, zb, lane, g, outA, st);
     f32x4 outB[OT][NT];
     if constexpr (KIND == GBNF_KIND_REALNVP) {
-      coupling_net<HT, KSL, OT, NT, LMID, ACTB>(sp + SMALL_WORDS + L::NET_WORDS, ZB, ks1, lane, g, outB);
+      coupling_net<HT, KSL, KS1, OT, NT, LMID, ACTB>(sp + SMALL_WORDS + L.NET_WORDS, zb, lane, g, outB, st);
     }
 
     // ---- coupling transform of the other half, in place, + per-lane log-det partials
-    {
-      const uint32_t* otab = tab + 160;
-      int slot[NENT];
-      float p0[NENT], p1[NENT], p2[NENT], p3[NENT];
+    if (KIND == GBNF_KIND_GLOW && !p.additive) {
+      // affine, "cross" split: rows 2j / 2j+1 of the last Linear are (shift_j, raw_j) and sit
+      // in adjacent accumulator registers of the same lane.  models/glow.py:331-338.
 #pragma unroll
-      for (int h = 0; h < 2; ++h) {
-        i32x4 s4 = *reinterpret_cast<const i32x4*>(otab + h * 4);
-        f32x4 a4 = *reinterpret_cast<const f32x4*>(otab + 32 + h * 4);
-        f32x4 b4 = *reinterpret_cast<const f32x4*>(otab + 64 + h * 4);
-        f32x4 c4 = *reinterpret_cast<const f32x4*>(otab + 96 + h * 4);
-        f32x4 d4 = *reinterpret_cast<const f32x4*>(otab + 128 + h * 4);
+      for (int e = 0; e < 2 * OT && e < NENT; ++e) {
+        const int o = e >> 1, pp = e & 1;
+        const bool live = tout.slot[e] >= 0;
+        const int zoff = (live ? tout.slot[e] : 0) * ZS + i;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          slot[h * 4 + e] = s4[e]; p0[h * 4 + e] = a4[e]; p1[h * 4 + e] = b4[e];
-          p2[h * 4 + e] = c4[e]; p3[h * 4 + e] = d4[e];
-        }
-      }
-      if (KIND == GBNF_KIND_GLOW && !p.additive) {
-        // affine, "cross" split: rows 2j / 2j+1 of the last Linear are (shift_j, raw_j) and sit
-        // in adjacent accumulator registers of the same lane.  models/glow.py:331-338.
-#pragma unroll
-        for (int e = 0; e < 2 * OT && e < NENT; ++e) {
-          const int o = e >> 1, pp = e & 1;
-          const bool live = slot[e] >= 0;
-          const int zoff = (live ? slot[e] : 0) * ZS + i;
-#pragma unroll
-          for (int nt = 0; nt < NT; ++nt) {
-            float v = Z[zoff + 16 * nt];
-            v = norm_fn<KIND>(v, p0[e], p1[e], p2[e], p3[e]);
-            const float shift = outA[o][nt][2 * pp], raw = outA[o][nt][2 * pp + 1];
-            const float sc = sigmoid_acc(raw + 2.0f);
-            v = (v + shift) * sc;
-            if (live) {
-              Z[zoff + 16 * nt] = v;
-              ld[nt] += logf(sc);
-            }
+        for (int nt = 0; nt < NT; ++nt) {
+          float v = Z[zoff + 16 * nt];
+          v = norm_fn<KIND>(v, tout.p0[e], tout.p1[e], tout.p2[e], tout.p3[e]);
+          const float shift = outA[o][nt][2 * pp], raw = outA[o][nt][2 * pp + 1];
+          float sc, lsc;
+          sigmoid_logsigmoid(raw + 2.0f, sc, lsc);
+          v = (v + shift) * sc;
+          if (live) {
+            Z[zoff + 16 * nt] = v;
+            ld[nt] += lsc;
           }
         }
-      } else {
+      }
+    } else {
 #pragma unroll
-        for (int e = 0; e < 4 * OT && e < NENT; ++e) {
-          const int o = e >> 2, r = e & 3;
-          const bool live = slot[e] >= 0;
-          const int zoff = (live ? slot[e] : 0) * ZS + i;
+      for (int e = 0; e < 4 * OT && e < NENT; ++e) {
+        const int o = e >> 2, r = e & 3;
+        const bool live = tout.slot[e] >= 0;
+        const int zoff = (live ? tout.slot[e] : 0) * ZS + i;
 #pragma unroll
-          for (int nt = 0; nt < NT; ++nt) {
-            float v = Z[zoff + 16 * nt];
-            v = norm_fn<KIND>(v, p0[e], p1[e], p2[e], p3[e]);
-            if constexpr (KIND == GBNF_KIND_GLOW) {
-              v = v + outA[o][nt][r];                       // additive, models/glow.py:328-329
-              if (live) Z[zoff + 16 * nt] = v;
-            } else {
-              const float shift = outA[o][nt][r], scale = outB[o][nt][r];
-              v = shift + v * expf(scale);                  // models/transformations.py:575
-              if (live) {
-                Z[zoff + 16 * nt] = v;
-                ld[nt] += scale;                            // models/transformations.py:577
-              }
+        for (int nt = 0; nt < NT; ++nt) {
+          float v = Z[zoff + 16 * nt];
+          v = norm_fn<KIND>(v, tout.p0[e], tout.p1[e], tout.p2[e], tout.p3[e]);
+          if constexpr (KIND == GBNF_KIND_GLOW) {
+            v = v + outA[o][nt][r];                       // additive, models/glow.py:328-329
+            if (live) Z[zoff + 16 * nt] = v;
+          } else {
+            const float shift = outA[o][nt][r], scale = outB[o][nt][r];
+            v = shift + v * exp_fast(scale);              // models/transformations.py:575
+            if (live) {
+              Z[zoff + 16 * nt] = v;
+              ld[nt] += scale;                            // models/transformations.py:577
             }
           }
         }
       }
     }
     __syncthreads();
+    st.mark(5);
   }
 
   // ---- base log-density + log|det J|, folded over the 4 lane groups
@@ -510,35 +687,48 @@ __global__ void __launch_bounds__(64) flow_kernel(const FlowLaunch p) {
       if (n < p.n) zo[n * d + lane] = Z[slot * ZS + r];
     }
   }
+#ifdef GBNF_STAMPS
+  st.mark(6);
+  if (p.dbg != nullptr && lane == 0) {
+#pragma unroll
+    for (int k = 0; k < 8; ++k) p.dbg[(size_t)blockIdx.x * 8 + k] = st.acc[k];
+  }
+#endif
+}
+
+// dynamic LDS bytes a launch needs (tables for K steps when they fit + Z)
+inline size_t flow_lds_bytes(int n_steps, int nt) {
+  const size_t tables = n_steps <= LDS_TABLE_STEPS ? (size_t)n_steps * SMALL_WORDS : 0;
+  return (tables + (size_t)ZSLOTS * (16 * nt + 1)) * 4;
 }
 
 // ---------------------------------------------------------------------------------
-// variant registry: each variants/*.hip instantiates one kernel and registers a launcher
+// variant registry: each variant translation unit instantiates one kernel and registers a launcher
 // ---------------------------------------------------------------------------------
 struct VariantKey {
-  int kind, ht, ksl, ot, nt, lmid, act_a, act_b;
+  int kind, ht, ksl, ks1, ot, nt, lmid, act_a, act_b;
   bool operator==(const VariantKey& o) const {
-    return kind == o.kind && ht == o.ht && ksl == o.ksl && ot == o.ot && nt == o.nt &&
+    return kind == o.kind && ht == o.ht && ksl == o.ksl && ks1 == o.ks1 && ot == o.ot && nt == o.nt &&
            lmid == o.lmid && act_a == o.act_a && act_b == o.act_b;
   }
 };
 using LaunchFn = hipError_t (*)(const FlowLaunch&, unsigned grid, hipStream_t);
 void register_variant(const VariantKey& key, LaunchFn fn, const char* name);
 
-#define GBNF_INSTANTIATE(KIND, HT, KSL, OT, NT, LMID, ACTA, ACTB)                                   \
-  namespace gbnf {                                                                                  \
-  static hipError_t launch_##KIND##_##HT##_##KSL##_##OT##_##NT##_##LMID##_##ACTA##_##ACTB(          \
-      const FlowLaunch& p, unsigned grid, hipStream_t s) {                                          \
-    hipLaunchKernelGGL((flow_kernel<KIND, HT, KSL, OT, NT, LMID, ACTA, ACTB>), dim3(grid), dim3(64), \
-                       0, s, p);                                                                    \
-    return hipGetLastError();                                                                       \
-  }                                                                                                 \
-  static const int reg_##KIND##_##HT##_##KSL##_##OT##_##NT##_##LMID##_##ACTA##_##ACTB =             \
-      (register_variant(VariantKey{KIND, HT, KSL, OT, NT, LMID, ACTA, ACTB},                        \
-                        launch_##KIND##_##HT##_##KSL##_##OT##_##NT##_##LMID##_##ACTA##_##ACTB,      \
-                        "flow_kernel<" #KIND "," #HT "," #KSL "," #OT "," #NT "," #LMID "," #ACTA   \
-                        "," #ACTB ">"),                                                             \
-       0);                                                                                          \
+#define GBNF_INSTANTIATE(KIND, HT, KSL, KS1, OT, NT, LMID, ACTA, ACTB)                                      \
+  namespace gbnf {                                                                                          \
+  static hipError_t launch_##KIND##_##HT##_##KSL##_##KS1##_##OT##_##NT##_##LMID##_##ACTA##_##ACTB(          \
+      const FlowLaunch& p, unsigned grid, hipStream_t s) {                                                  \
+    hipLaunchKernelGGL((flow_kernel<KIND, HT, KSL, KS1, OT, NT, LMID, ACTA, ACTB>), dim3(grid), dim3(64),   \
+                       flow_lds_bytes(p.n_steps, NT), s, p);                                                \
+    return hipGetLastError();                                                                               \
+  }                                                                                                         \
+  static const int reg_##KIND##_##HT##_##KSL##_##KS1##_##OT##_##NT##_##LMID##_##ACTA##_##ACTB =             \
+      (register_variant(VariantKey{KIND, HT, KSL, KS1, OT, NT, LMID, ACTA, ACTB},                           \
+                        launch_##KIND##_##HT##_##KSL##_##KS1##_##OT##_##NT##_##LMID##_##ACTA##_##ACTB,      \
+                        "flow_kernel<" #KIND "," #HT "," #KSL "," #KS1 "," #OT "," #NT "," #LMID "," #ACTA  \
+                        "," #ACTB ">"),                                                                     \
+       0);                                                                                                  \
   }
 
 }  // namespace gbnf

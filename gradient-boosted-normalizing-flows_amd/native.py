@@ -12,7 +12,8 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libgbnf_hip.so")
+# GBNF_LIB_PATH: diagnostic builds only (e.g. the -DGBNF_STAMPS library of tools/build_stamps.sh)
+LIB_PATH = os.environ.get("GBNF_LIB_PATH") or os.path.join(_HERE, "libgbnf_hip.so")
 
 KIND = {"glow": 0, "realnvp": 1}
 ACT = {"tanh": 0, "relu": 1}
