@@ -1,0 +1,494 @@
+"""Host-side mirror of the reference's ``BoostedFlow`` (models/boosted_flow.py) for the density path.
+
+Same constructor (``BoostedFlow(args)`` reading the same Namespace fields), same attribute
+surface (``flows``, ``rho``, ``component``, ``all_trained``, ``num_components``,
+``increment_component``, ``update_rho``, ``_sample_component``), same parameter / buffer names
+(``flows.<c>.flow.layers.<k>.actnorm.bias`` ..., so reference ``state_dict``s load and
+optimization/optimizers.py:29-35's name parsing keeps working) and the same call:
+
+    z, z_mu, z_var, ldj, y_logits = model(x=x, components=c)        # models/boosted_flow.py:224-228
+
+but the arithmetic of ``self.flows[c](x)`` runs in the HIP kernels behind ``include/gbnf.h``.
+The sub-modules below only HOLD parameters; they have no math of their own and there is no
+CPU / eager fallback: calling the model without the built library or with CPU tensors raises.
+
+Additions named in BASELINE.json / SURVEY.md section 8(b): ``component_forward``,
+``component_log_prob``, ``log_prob`` and the permutation side-car (``permutation_state`` /
+``load_permutation_state``) that fixes the reference's loss of ``PermuteNd.indices`` on checkpointing.
+
+Out of scope here: backward pass / training, sampling (the reference's
+``decode`` is dead code: models/boosted_flow.py:216 passes a misspelt kwarg), ActNorm data-dependent
+initialisation, image inputs.
+"""
+from __future__ import annotations
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from . import native
+from . import spec as gspec
+
+
+# ----------------------------------------------------------------------------- parameter holders
+class _CouplingNet(nn.Module):
+    """TanhNet / ReLUNet parameter layout: ``network`` = Linear, [act, Linear] x depth, act, Linear
+    (models/layers.py:208-243).  nn.Linear's default init is what the reference uses."""
+
+    def __init__(self, in_dim, out_dim, hidden_dim, num_layers, act):
+        super().__init__()
+        act_cls = nn.Tanh if act == "tanh" else nn.ReLU
+        layers = [nn.Linear(in_dim, hidden_dim)]
+        for _ in range(num_layers):
+            layers += [act_cls(), nn.Linear(hidden_dim, hidden_dim)]
+        layers += [act_cls(), nn.Linear(hidden_dim, out_dim)]
+        self.network = nn.Sequential(*layers)
+
+    def forward(self, *a, **k):
+        raise RuntimeError("coupling networks are evaluated by the fused HIP kernel, not module by module")
+
+
+class TanhNet(_CouplingNet):
+    def __init__(self, in_dim, out_dim, hidden_dim, num_layers=1):
+        super().__init__(in_dim, out_dim, hidden_dim, num_layers, "tanh")
+
+
+class ReLUNet(_CouplingNet):
+    def __init__(self, in_dim, out_dim, hidden_dim, num_layers=1):
+        super().__init__(in_dim, out_dim, hidden_dim, num_layers, "relu")
+
+
+def _coupling_cls(name):
+    if name == "tanh":
+        return TanhNet
+    if name == "relu":
+        return ReLUNet
+    if name == "random":   # models/glow.py:295-296 draws from numpy's global RNG
+        return [TanhNet, ReLUNet][np.random.randint(2)]
+    raise NotImplementedError(
+        f"coupling_network={name!r}: only tanh / relu (and mixed for RealNVP) are on the supported path")
+
+
+class ActNorm1d(nn.Module):
+    """Parameter holder for _ActNorm/ActNorm1d (models/layers.py:453-545): bias, logs (1,d) and
+    the ``inited`` flag (a plain attribute in the reference too)."""
+
+    def __init__(self, num_features, scale=1.0):
+        super().__init__()
+        self.bias = nn.Parameter(torch.zeros(1, num_features))
+        self.logs = nn.Parameter(torch.zeros(1, num_features))
+        self.num_features = num_features
+        self.scale = scale
+        self.inited = False
+        self.image_input = False
+
+
+class Permute1d(nn.Module):
+    """PermuteNd/Permute1d (models/layers.py:633-668): ``indices`` / ``indices_inverse`` are plain
+    tensors, not buffers (hence absent from state_dict -- see BoostedFlow.permutation_state)."""
+
+    def __init__(self, num_dim, shuffle):
+        super().__init__()
+        self.num_dim = num_dim
+        self.indices = torch.arange(num_dim - 1, -1, -1, dtype=torch.long)
+        self.indices_inverse = torch.zeros(num_dim, dtype=torch.long)
+        if shuffle:
+            self.indices = self.indices[torch.randperm(num_dim)]
+        self._rebuild_inverse()
+
+    def _rebuild_inverse(self):
+        self.indices_inverse = torch.empty(self.num_dim, dtype=torch.long)
+        self.indices_inverse[self.indices] = torch.arange(self.num_dim, dtype=torch.long)
+
+    def set_indices(self, indices):
+        idx = torch.as_tensor(np.asarray(indices), dtype=torch.long).clone()
+        if idx.shape != (self.num_dim,) or sorted(idx.tolist()) != list(range(self.num_dim)):
+            raise ValueError("indices must be a permutation of range(num_dim)")
+        self.indices = idx
+        self._rebuild_inverse()
+
+
+class FlowStep(nn.Module):
+    """Tabular FlowStep parameter layout (models/glow.py:264-308): actnorm, shuffle|reverse, block."""
+
+    def __init__(self, in_dim, hidden_dim, actnorm_scale, flow_permutation, flow_coupling, args):
+        super().__init__()
+        self.image_input = False
+        self.flow_coupling = flow_coupling
+        self.actnorm = ActNorm1d(in_dim, actnorm_scale)
+        if flow_permutation == "shuffle":
+            self.shuffle = Permute1d(in_dim, shuffle=True)
+        elif flow_permutation == "invconv":
+            raise NotImplementedError("invconv is image-only in the reference (models/layers.py:750 unpacks 4 dims)")
+        else:
+            self.reverse = Permute1d(in_dim, shuffle=False)
+        net = _coupling_cls(args.coupling_network)
+        d1 = in_dim // 2
+        d2 = in_dim - d1
+        if flow_coupling == "additive":
+            self.block = net(d1, d2, hidden_dim, args.coupling_network_depth)
+        elif flow_coupling == "affine":
+            self.block = net(d1, d2 * 2, hidden_dim, args.coupling_network_depth)
+        else:
+            raise ValueError(f"flow_coupling={flow_coupling!r}")
+
+    @property
+    def permutation(self):
+        return self.shuffle if hasattr(self, "shuffle") else self.reverse
+
+
+class FlowNet(nn.Module):
+    def __init__(self, args):
+        super().__init__()
+        if len(args.input_size) > 1:
+            raise NotImplementedError("image inputs are outside the supported path (SURVEY.md section 8f, N4)")
+        self.image_input = False
+        self.K = args.num_flows
+        self.L = args.num_blocks
+        self.output_shapes = [[-1, args.input_size[0]]]
+        self.layers = nn.ModuleList([
+            FlowStep(args.input_size[0], args.h_size, args.actnorm_scale, args.flow_permutation,
+                     args.flow_coupling, args) for _ in range(args.num_flows)])
+
+
+class Glow(nn.Module):
+    """Parameter layout of the tabular Glow component (models/glow.py:12-58): flow, prior_h, bounds."""
+
+    def __init__(self, args):
+        super().__init__()
+        if getattr(args, "learn_top", False) or getattr(args, "y_condition", False):
+            raise NotImplementedError("learn_top / y_condition are image-path options")
+        self.learn_top = False
+        self.y_condition = False
+        self.y_classes = args.y_classes
+        self.sample_size = args.sample_size
+        self.image_input = False
+        self.flow = FlowNet(args)
+        self.register_buffer("prior_h", torch.zeros([1, args.z_size * 2]))
+        self.register_buffer("bounds", torch.tensor([0.9], dtype=torch.float32))
+        self.dequant_flows = None
+        self.z_size = args.z_size
+
+    def set_actnorm_init(self):
+        """Mark ActNorm layers initialised ("Use if given a loaded model", models/glow.py:181-187)."""
+        for layer in self.flow.layers:
+            layer.actnorm.inited = True
+
+
+class BatchNorm(nn.Module):
+    """RealNVP BatchNorm parameter layout (models/layers.py:320-335)."""
+
+    def __init__(self, input_size, momentum=0.9, eps=1e-5):
+        super().__init__()
+        self.momentum = momentum
+        self.eps = eps
+        self.log_gamma = nn.Parameter(torch.zeros(input_size))
+        self.beta = nn.Parameter(torch.zeros(input_size))
+        self.register_buffer("running_mean", torch.zeros(input_size))
+        self.register_buffer("running_var", torch.ones(input_size))
+        self.register_buffer("batch_mean", torch.zeros(input_size))
+        self.register_buffer("batch_var", torch.zeros(input_size))
+
+
+class RealNVPFlow(nn.Module):
+    """Parameter layout of RealNVPFlow (models/realnvp.py:18-78): flow_param[k] = [t_net, s_net, bn|None]."""
+
+    def __init__(self, args, flip_init=0):
+        super().__init__()
+        self.num_flows = args.num_flows
+        self.z_size = args.z_size
+        self.flip_init = flip_init
+        self.sample_size = args.sample_size
+        self.register_buffer("base_dist_mean", torch.randn(self.z_size).normal_(0, 0.1))
+        self.register_buffer("base_dist_var", 3.0 * torch.ones(self.z_size))
+        self.flow_param = nn.ModuleList()
+        for k in range(self.num_flows):
+            flipped = ((k + flip_init) % 2) > 0
+            if flipped:
+                out_dim, in_dim = self.z_size // 2, self.z_size - self.z_size // 2
+            else:
+                in_dim, out_dim = self.z_size // 2, self.z_size - self.z_size // 2
+            if args.coupling_network == "mixed":
+                nets = [ReLUNet(in_dim, out_dim, args.h_size, args.coupling_network_depth),
+                        TanhNet(in_dim, out_dim, args.h_size, args.coupling_network_depth)]
+            else:
+                nets = [_coupling_cls(args.coupling_network)(in_dim, out_dim, args.h_size, args.coupling_network_depth)
+                        for _ in range(2)]
+            bn = BatchNorm(self.z_size) if (args.batch_norm and k < self.num_flows - 1) else None
+            self.flow_param.append(nn.ModuleList(nets + [bn]))
+        self.register_buffer("prior_h", torch.zeros([1, 2 * self.z_size]))
+
+
+# ----------------------------------------------------------------------------- the boosted model
+class BoostedFlow(nn.Module):
+    """Drop-in for models/boosted_flow.py:BoostedFlow on the density-evaluation path."""
+
+    def __init__(self, args):
+        super().__init__()
+        self.args = args
+        self.num_flows = args.num_flows
+        self.z_size = args.z_size
+        self.density_evaluation = args.density_evaluation
+        self.amortized = not args.density_evaluation
+        self.all_trained = False
+        self.component_type = args.component_type
+        self.num_components = args.num_components
+        self.component = 0
+        # GenerativeFlow buffers (models/generative_flow.py:22-23)
+        self.register_buffer("base_dist_mean", torch.randn(self.z_size).normal_(0, 0.1))
+        self.register_buffer("base_dist_var", 3.0 * torch.ones(self.z_size))
+        # rho (models/boosted_flow.py:32-39)
+        if args.rho_init == "decreasing":
+            rho = torch.clamp(1.0 / torch.pow(2.0, torch.arange(self.num_components * 1.0)), min=0.05)
+        else:
+            rho = torch.full((self.num_components,), 1.0 / self.num_components)
+        self.register_buffer("rho", rho.float())
+        self.flows = nn.ModuleList()
+        for c in range(self.num_components):
+            if args.component_type == "realnvp":
+                self.flows.append(RealNVPFlow(args, flip_init=c))
+            elif args.component_type == "glow":
+                self.flows.append(Glow(args))
+            else:
+                raise NotImplementedError("Only glow and realnvp components are currently implemented")
+        self._handles = {}      # c -> (version key, NativeFlow)
+        self._mixture = None    # (version key, NativeMixture)
+        dev = getattr(args, "device", None)
+        if dev is not None:
+            self.to(dev)
+
+    # ------------------------------------------------------------------ reference API
+    @property
+    def base_dist(self):
+        import torch.distributions as D
+        return D.Normal(self.base_dist_mean, self.base_dist_var)
+
+    def increment_component(self):
+        """models/boosted_flow.py:52-59."""
+        if self.component == self.num_components - 1:
+            self.component = 0
+            self.all_trained = True
+        else:
+            self.component = min(self.component + 1, self.num_components - 1)
+
+    def _sample_component(self, sampling_components):
+        """models/boosted_flow.py:61-96: "c" | "1:c" | "1:c-1" | "-c" -> component id (draws
+        torch.multinomial over rho for the ranged forms)."""
+        if sampling_components == "c":
+            return min(self.component, self.num_components - 1)
+        if sampling_components in ("1:c", "1:c-1"):
+            if sampling_components == "1:c-1":
+                n = self.component
+            else:
+                n = self.num_components if self.all_trained else self.component + 1
+            n = min(max(n, 1), self.num_components)
+            simplex = self.rho[0:n] / torch.sum(self.rho[0:n])
+            return int(torch.multinomial(simplex, 1, replacement=True).item())
+        if sampling_components == "-c":
+            simplex = self.rho.clone().detach()
+            simplex[self.component] = 0.0
+            simplex = simplex / simplex.sum()
+            return int(torch.multinomial(simplex, 1, replacement=True).item())
+        raise ValueError("z_k can only be sampled from ['c', '1:c-1', '1:c', '-c'] "
+                         "(corresponding to 'new', 'fixed', or new+fixed components)")
+
+    def encode(self, x, y_onehot, components):
+        c = self._sample_component(components) if isinstance(components, str) else int(components)
+        z, ldj = self.component_forward(x, c)
+        flow = self.flows[c]
+        h = flow.prior_h.repeat(x.shape[0], 1)     # Glow.prior / RealNVPFlow.prior: zeros, returned as-is
+        z_mu, z_var = h[:, : self.z_size], h[:, self.z_size:]
+        return z, z_mu, z_var, ldj, None
+
+    def decode(self, z, y_onehot, temperature, components):
+        raise NotImplementedError(
+            "reverse / sampling is not on the supported path: the reference's own BoostedFlow.decode always "
+            "raises TypeError (models/boosted_flow.py:216 passes y_onhot=) -- SURVEY.md S3")
+
+    def forward(self, x=None, y_onehot=None, z=None, temperature=None, components=None, reverse=False):
+        if reverse:
+            return self.decode(z, y_onehot, temperature, components)
+        return self.encode(x, y_onehot, components)
+
+    @torch.no_grad()
+    def _rho_gradients(self, x):
+        """models/boosted_flow.py:119-139 (note: un-normalised rho in this recursion, as in the reference)."""
+        full_ll = fixed_ll = new_ll = None
+        for c in range(self.component + 1):
+            z, ldj = self.component_forward(x, c)
+            ll = torch.sum(-0.5 * np.log(2 * np.pi) - 0.5 * z * z, dim=-1) + ldj
+            if c == 0:
+                full_ll = ll
+                new_ll = ll if new_ll is None else new_ll
+            else:
+                new_ll = ll
+                prev = torch.log(1 - self.rho[c]) + full_ll
+                nxt = torch.log(self.rho[c]) + new_ll
+                full_ll = torch.logsumexp(torch.stack([prev, nxt], dim=1), dim=1)
+            if c == self.component - 1:
+                fixed_ll = full_ll
+        return new_ll, fixed_ll, full_ll
+
+    def update_rho(self, data_loader):
+        """models/boosted_flow.py:141-207 (approximate branch).  The reference's log line references an
+        undefined ``g_nll`` and so raises NameError whenever rho_iters > 0; the update rule
+        itself is reproduced, the broken log message is not."""
+        if self.component == 0 and not self.all_trained:
+            return
+        if getattr(self.args, "rho_iters", 0) == 0:
+            return
+        self.eval()
+        with torch.no_grad():
+            tolerance, min_iters = 0.001, 10
+            init_step, max_iters = self.args.rho_lr, self.args.rho_iters
+            prev_rho = self.rho[self.component].item()
+            data_iter = iter(data_loader)
+            for batch_id in range(max_iters):
+                try:
+                    (x, _) = next(data_iter)
+                except StopIteration:
+                    data_iter = iter(data_loader)
+                    (x, _) = next(data_iter)
+                x = x.detach().to(self.rho.device)
+                g_ll, G_ll, _ = self._rho_gradients(x)
+                gradient = torch.mean((-g_ll) - (-G_ll)).item()
+                step = init_step / (0.05 * batch_id + 1)
+                rho = min(max(prev_rho - step * gradient, 0.01), 100.0)
+                self.rho[self.component] = rho
+                dif = abs(prev_rho - rho)
+                prev_rho = rho
+                if batch_id > min_iters and (batch_id > max_iters or dif < tolerance):
+                    break
+
+    # ------------------------------------------------------------------ native handles
+    def _component_key(self, c):
+        flow = self.flows[c]
+        key = [int(t._version) for t in list(flow.parameters()) + list(flow.buffers())]
+        key += [t.data_ptr() for t in flow.parameters()]
+        if self.component_type == "glow":
+            for layer in flow.flow.layers:
+                key.append(tuple(layer.permutation.indices.tolist()))
+                key.append(bool(layer.actnorm.inited))
+        return tuple(key)
+
+    def _check_ready(self, x):
+        if not isinstance(x, torch.Tensor) or not x.is_cuda:
+            raise native.GbnfError("x must live on the MI355X (cuda) device: this module has no CPU path")
+        if self.training and torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
+            raise RuntimeError(
+                "the HIP path is forward/density-evaluation only (no backward: SURVEY.md section 8f N3); call "
+                ".eval() or wrap the call in torch.no_grad()")
+        if self.component_type == "glow":
+            for flow in self.flows:
+                for layer in flow.flow.layers:
+                    if not layer.actnorm.inited:
+                        # the reference raises the same way in eval mode (models/layers.py:473-475)
+                        raise ValueError("In Eval mode, but ActNorm not initiated")
+
+    def native_flow(self, c):
+        key = self._component_key(c)
+        cached = self._handles.get(c)
+        if cached is None or cached[0] != key:
+            handle = native.NativeFlow(gspec.spec_from_component(self.flows[c]))
+            self._handles[c] = (key, handle)
+            self._mixture = None
+        return self._handles[c][1]
+
+    def native_mixture(self):
+        flows = [self.native_flow(c) for c in range(self.num_components)]
+        key = tuple(id(f) for f in flows)
+        if self._mixture is None or self._mixture[0] != key:
+            self._mixture = (key, native.NativeMixture(flows))
+        return self._mixture[1]
+
+    # ------------------------------------------------------------------ convenience API (BASELINE.json)
+    def component_forward(self, x, c):
+        """x (N,d) -> z (N,d), ldj (N,) of component c  ==  self.flows[c](x)[0], [3] of the reference."""
+        self._check_ready(x)
+        x = x.contiguous().float()
+        with torch.cuda.device(x.device):
+            z, ldj, _ = self.native_flow(int(c)).forward(x)
+        return z, ldj
+
+    def component_log_prob(self, x, n_used=None):
+        """(N, C_used): ll_c(x) = log N(z_c;0,I) + ldj_c for c < n_used, all in ONE launch
+        (density_experiment.py:562-565)."""
+        self._check_ready(x)
+        n_used = self._n_used(n_used)
+        x = x.contiguous().float()
+        with torch.cuda.device(x.device):
+            ll = self.native_mixture().component_log_prob(x, 0, n_used)
+        return ll.t()
+
+    def log_prob(self, x, n_used=None):
+        """(N,): mixture log-density over the first n_used components with the recursive
+        prefix-normalised weights of density_experiment.py:561-573.  Default n_used follows
+        ``evaluate``: ``self.component + 1`` (all components once ``all_trained``)."""
+        self._check_ready(x)
+        n_used = self._n_used(n_used)
+        x = x.contiguous().float()
+        with torch.cuda.device(x.device):
+            G, _ = self.native_mixture().log_prob(x, self.rho.contiguous().float(), n_used=n_used)
+        return G
+
+    def _n_used(self, n_used):
+        if n_used is None:
+            n_used = self.num_components if self.all_trained else self.component + 1
+        n_used = int(n_used)
+        if not 1 <= n_used <= self.num_components:
+            raise ValueError(f"n_used={n_used} outside [1, {self.num_components}]")
+        return n_used
+
+    # ------------------------------------------------------------------ checkpoint side-car (fixes S5)
+    def permutation_state(self):
+        """What the reference's checkpoints lose: permutation indices, ActNorm ``inited``,
+        ``component`` and ``all_trained``.  Save next to ``state_dict()``."""
+        st = {"component": self.component, "all_trained": self.all_trained, "indices": {}, "actnorm_inited": {}}
+        if self.component_type == "glow":
+            for c, flow in enumerate(self.flows):
+                for k, layer in enumerate(flow.flow.layers):
+                    st["indices"][f"{c}.{k}"] = layer.permutation.indices.clone()
+                    st["actnorm_inited"][f"{c}.{k}"] = bool(layer.actnorm.inited)
+        return st
+
+    def load_permutation_state(self, st):
+        self.component = int(st["component"])
+        self.all_trained = bool(st["all_trained"])
+        for name, idx in st["indices"].items():
+            c, k = (int(v) for v in name.split("."))
+            self.flows[c].flow.layers[k].permutation.set_indices(idx)
+        for name, flag in st["actnorm_inited"].items():
+            c, k = (int(v) for v in name.split("."))
+            self.flows[c].flow.layers[k].actnorm.inited = bool(flag)
+
+    def load_spec(self, c, spec):
+        """Install a flow spec's numbers (see spec.py) into component c's parameters."""
+        flow = self.flows[c]
+        dev = self.rho.device
+
+        def put(dst, src):
+            with torch.no_grad():
+                dst.copy_(torch.as_tensor(np.asarray(src)).reshape(dst.shape).to(dev))
+
+        def load_net(holder, net):
+            linears = [m for m in holder.network if isinstance(m, nn.Linear)]
+            if len(linears) != len(net["layers"]):
+                raise ValueError("coupling network depth mismatch")
+            for m, (w, b) in zip(linears, net["layers"]):
+                put(m.weight, w)
+                put(m.bias, b)
+
+        if spec["kind"] == "glow":
+            for layer, st in zip(flow.flow.layers, spec["steps"]):
+                put(layer.actnorm.bias, st["an_bias"])
+                put(layer.actnorm.logs, st["an_logs"])
+                layer.actnorm.inited = True
+                layer.permutation.set_indices(st["perm"])
+                load_net(layer.block, st["net"])
+        else:
+            for mods, st in zip(flow.flow_param, spec["steps"]):
+                load_net(mods[0], st["t_net"])
+                load_net(mods[1], st["s_net"])
+                if st["bn"] is not None:
+                    for key in ("log_gamma", "beta", "running_mean", "running_var"):
+                        put(getattr(mods[2], key), st["bn"][key])

@@ -224,8 +224,27 @@ def toy_case(name, N=64):
     print(f"{name}: ll[0,:3]={ll[0, :3]}  G[:3]={G[:3]}")
 
 
+def state_dict_layout_case():
+    """Names + shapes of the reference's state_dict for both component kinds (the host mirror must
+    expose exactly these so reference checkpoints load and optimizers.py:29-35's name parsing works)."""
+    out = {}
+    for kind, kw in (("glow", {}), ("realnvp", {}), ("realnvp_mixed", dict(coupling_network="mixed")),
+                     ("glow_depth2_additive", dict(depth=2, coupling="additive", permutation="reverse"))):
+        base = kind.split("_")[0]
+        m = RefBoostedFlow(ref_args(base, 7, 12, 3, 2, **kw))
+        out[kind] = {k: list(v.shape) for k, v in m.state_dict().items()}
+        out[kind + "::named_parameters"] = [n for n, _ in m.named_parameters()]
+    with open(os.path.join(HERE, "state_dict_layout.json"), "w") as f:
+        json.dump(out, f, indent=1, sort_keys=True)
+    print("state_dict_layout.json:", {k: len(v) for k, v in out.items()})
+
+
 def main():
     torch.set_num_threads(4)
+    if "--layout-only" in sys.argv:
+        state_dict_layout_case()
+        return
+    state_dict_layout_case()
     toy_case("g1_toy_realnvp_c2")
     native_glow_case("g2_glow_native_d43_h32_c3")
     # G3: MINIBOONE full width (BASELINE.json metric config), synthetic weights
