@@ -27,10 +27,15 @@ def read_variants():
             line = line.split("#")[0].strip()
             if not line:
                 continue
+            if line.startswith("hx3"):
+                kind, ht, ot, acta, actb = (int(v) for v in line.split()[1:])
+                for nt in (1, 2):
+                    out.append(("hx3", kind, ht, ot, nt, acta, actb))
+                continue
             kind, ht, ksl, ks1, ot, lmid, acta, actb = (int(v) for v in line.split())
             for nt in (1, 2):
                 out.append((kind, ht, ksl, ks1, ot, nt, lmid, acta, actb))
-    return sorted(set(out))
+    return sorted(set(out), key=str)
 
 
 def newer(target, deps):
@@ -53,7 +58,8 @@ def main(argv=None):
     ap.add_argument("--force", action="store_true")
     args = ap.parse_args(argv)
     os.makedirs(OBJ, exist_ok=True)
-    hdr = [os.path.join(HERE, "gbnf_flow_kernel.hip.h"), os.path.join(PKG, "..", "include", "gbnf.h")]
+    hdr = [os.path.join(HERE, "gbnf_flow_kernel.hip.h"), os.path.join(HERE, "gbnf_flow_kernel_hx3.hip.h"),
+           os.path.join(PKG, "..", "include", "gbnf.h")]
     jobs = []
     objs = []
     api_o = os.path.join(OBJ, "gbnf_api.o")
@@ -61,12 +67,15 @@ def main(argv=None):
     api_src = os.path.join(HERE, "gbnf_api.hip")
     if args.force or not newer(api_o, [api_src] + hdr):
         jobs.append([HIPCC] + FLAGS + ["-c", api_src, "-o", api_o])
-    vsrc = os.path.join(HERE, "variant.hip")
     for v in read_variants():
         o = os.path.join(OBJ, "v_" + "_".join(str(a) for a in v) + ".o")
         objs.append(o)
+        if v[0] == "hx3":
+            vsrc, vargs = os.path.join(HERE, "variant_hx3.hip"), v[1:]
+        else:
+            vsrc, vargs = os.path.join(HERE, "variant.hip"), v
         if args.force or not newer(o, [vsrc] + hdr):
-            jobs.append([HIPCC] + FLAGS + ["-DGBNF_V_ARGS=" + ",".join(str(a) for a in v), "-c", vsrc, "-o", o])
+            jobs.append([HIPCC] + FLAGS + ["-DGBNF_V_ARGS=" + ",".join(str(a) for a in vargs), "-c", vsrc, "-o", o])
     keep = set(objs)
     for fn in os.listdir(OBJ):      # drop objects of variants that left the list
         p = os.path.join(OBJ, fn)

@@ -7,11 +7,12 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <string.h>
 #include <mutex>
 #include <string>
 #include <vector>
 
-#include "gbnf_flow_kernel.hip.h"
+#include "gbnf_flow_kernel_hx3.hip.h"
 
 namespace gbnf {
 
@@ -56,6 +57,7 @@ struct NetDims {
 }  // namespace gbnf
 
 struct gbnf_flow {
+  int math_mode = 0;   // GBNF_MATH_*
   int kind = 0, d = 0, n_steps = 0, additive = 0;
   int hidden = 0, depth = 0, act_a = 0, act_b = 0;
   int ht = 0, ksl = 0, ot = 0;     // tile geometry (exact)
@@ -182,6 +184,100 @@ static void pack_net(std::vector<uint32_t>& blob, size_t base, const gbnf_net& n
 
 static size_t net_words(int HT, int KS1, int OT, int LMID) { return (size_t)NetLayoutRT(HT, KS1, OT, LMID).NET_WORDS; }
 
+// ---- f16x3 packing --------------------------------------------------------------------------------
+static uint16_t f16_bits(float x) {
+  const _Float16 h = static_cast<_Float16>(x);      // round to nearest even
+  uint16_t b;
+  std::memcpy(&b, &h, 2);
+  return b;
+}
+static float f16_to_f32(uint16_t b) {
+  _Float16 h;
+  std::memcpy(&h, &b, 2);
+  return static_cast<float>(h);
+}
+
+// One (hi, mid) fragment pair at word offset `off`: 16 rows x 32 k-slots.  elem(i, g, j) returns the f32
+// weight of row i and k-slot (g, j); lane (i,g) stores its 8 f16 as 4 words, element 2q in the low half.
+template <typename F>
+static void put_frag_pair(std::vector<uint32_t>& blob, size_t off, F elem) {
+  for (int lane = 0; lane < 64; ++lane) {
+    const int i = lane & 15, gg = lane >> 4;
+    for (int q = 0; q < 4; ++q) {
+      uint32_t whi = 0, wmid = 0;
+      for (int e = 0; e < 2; ++e) {
+        const float v = elem(i, gg, 2 * q + e);
+        const uint16_t hi = f16_bits(v);
+        const uint16_t mid = f16_bits(v - f16_to_f32(hi));
+        whi |= (uint32_t)hi << (16 * e);
+        wmid |= (uint32_t)mid << (16 * e);
+      }
+      blob[off + (size_t)lane * 4 + q] = whi;
+      blob[off + 256 + (size_t)lane * 4 + q] = wmid;
+    }
+  }
+}
+
+// k-slot (g, j) of hidden chunk c  <->  hidden unit 16*(2c + (j>>2)) + 4g + (j&3): the D-register layout of two
+// consecutive 16-unit accumulator tiles read as one k = 32 B operand
+static int hx3_hidden_unit(int c, int gg, int j) { return 16 * (2 * c + (j >> 2)) + 4 * gg + (j & 3); }
+
+static void pack_net_hx3(std::vector<uint32_t>& blob, size_t base, const gbnf_net& net, int HT, int OT, int in_f,
+                         int h, int out_f) {
+  const Hx3Layout L(HT, OT);
+  auto put = [&](size_t off, float v) { std::memcpy(&blob[base + off], &v, 4); };
+  const gbnf_linear& l0 = net.layers[0];
+  const gbnf_linear& l1 = net.layers[1];
+  const gbnf_linear& l2 = net.layers[2];
+  // layers whose output goes through tanh carry the 2*log2(e) of tanh(x) = 1 - 2/(2^(2 log2(e) x) + 1)
+  const float T = net.activation == GBNF_ACT_TANH ? 2.8853900817779268f : 1.0f;
+  for (int t = 0; t < HT; ++t)
+    for (int k = 0; k < 16; ++k) {
+      const int u = 16 * t + k;
+      put((size_t)t * 16 + k, u < h ? T * l0.bias[u] : 0.0f);
+      put((size_t)(HT + t) * 16 + k, u < h ? T * l1.bias[u] : 0.0f);
+    }
+  for (int o = 0; o < OT; ++o)
+    for (int k = 0; k < 16; ++k) {
+      const int r = 16 * o + k;
+      put((size_t)(2 * HT + o) * 16 + k, r < out_f ? l2.bias[r] : 0.0f);
+    }
+  int s = 0;
+  for (int i0 = 0; i0 < L.N_L0; ++i0, ++s) {               // layer 0: k-slot (g,j) = input feature 8g + j
+    const int t0 = i0 * HX3_L0_TILES;
+    for (int tl = 0; tl < L.nf[s] / 2; ++tl) {
+      const int t = t0 + tl;
+      put_frag_pair(blob, base + L.off[s] + (size_t)tl * 512, [&](int i, int gg, int j) {
+        const int u = 16 * t + i, k = 8 * gg + j;
+        return (u < h && k < in_f) ? T * l0.weight[(size_t)u * in_f + k] : 0.0f;
+      });
+    }
+  }
+  for (int u = 0; u < HT; ++u, ++s) {                         // hidden row u (+ output chunk (u-2)/2)
+    for (int c = 0; c < L.HC; ++c)
+      put_frag_pair(blob, base + L.off[s] + (size_t)c * 512, [&](int i, int gg, int j) {
+        const int uo = 16 * u + i, ui = hx3_hidden_unit(c, gg, j);
+        return (uo < h && ui < h) ? T * l1.weight[(size_t)uo * h + ui] : 0.0f;
+      });
+    if (u % 2 == 0 && u >= 2) {
+      const int c = (u - 2) / 2;
+      for (int o = 0; o < OT; ++o)
+        put_frag_pair(blob, base + L.off[s] + (size_t)(L.HC + o) * 512, [&](int i, int gg, int j) {
+          const int row = 16 * o + i, ui = hx3_hidden_unit(c, gg, j);
+          return (row < out_f && ui < h) ? l2.weight[(size_t)row * h + ui] : 0.0f;
+        });
+    }
+  }
+  {                                                            // drain: output chunk HC-1
+    const int c = L.HC - 1;
+    for (int o = 0; o < OT; ++o)
+      put_frag_pair(blob, base + L.off[s] + (size_t)o * 512, [&](int i, int gg, int j) {
+        const int row = 16 * o + i, ui = hx3_hidden_unit(c, gg, j);
+        return (row < out_f && ui < h) ? l2.weight[(size_t)row * h + ui] : 0.0f;
+      });
+  }
+}
+
 static const Variant* find_variant(const VariantKey& k) {
   for (const Variant& v : variants())
     if (v.key == k) return &v;
@@ -198,7 +294,21 @@ int gbnf_version(void) { return GBNF_ABI_VERSION; }
 
 const char* gbnf_last_error(void) { return g_err.c_str(); }
 
+static int default_math_mode() {
+  static const int mode = [] {
+    const char* e = getenv("GBNF_MATH");          // "f32" | "f16x3": tuning / test knob
+    if (e && !strcmp(e, "f32")) return (int)GBNF_MATH_F32;
+    if (e && !strcmp(e, "f16x3")) return (int)GBNF_MATH_F16X3;
+    return (int)GBNF_MATH_DEFAULT;
+  }();
+  return mode;
+}
+
 int gbnf_flow_create(const gbnf_flow_desc* desc, gbnf_flow** out) {
+  return gbnf_flow_create_mode(desc, default_math_mode(), out);
+}
+
+int gbnf_flow_create_mode(const gbnf_flow_desc* desc, int32_t math_mode, gbnf_flow** out) {
   if (out == nullptr) return fail(GBNF_ERR_INVALID, "gbnf_flow_create: out is null");
   *out = nullptr;
   if (desc == nullptr) return fail(GBNF_ERR_INVALID, "gbnf_flow_create: desc is null");
@@ -274,15 +384,49 @@ int gbnf_flow_create(const gbnf_flow_desc* desc, gbnf_flow** out) {
     return fail(GBNF_ERR_UNSUPPORTED, "coupled half of %d features exceeds the per-lane table (%d)", max_out, NENT);
 
   // ---- pick compiled variants (exact geometry first, then the cheapest zero-padded superset)
+  if (math_mode != GBNF_MATH_F32 && math_mode != GBNF_MATH_F16X3 && math_mode != GBNF_MATH_DEFAULT)
+    return fail(GBNF_ERR_INVALID, "unknown math mode %d", math_mode);
   gbnf_flow* f = new gbnf_flow();
   f->kind = desc->kind; f->d = d; f->n_steps = K; f->additive = additive ? 1 : 0;
   f->hidden = h; f->depth = depth; f->act_a = act_a; f->act_b = act_b;
   const int ks1 = ceil_div(max_in, 4);
   f->ht = ht; f->ksl = ksl; f->ot = ot; f->ks1 = ks1;
-  {
+  bool hx3 = false;
+  if (math_mode != GBNF_MATH_F32 && depth == 1) {
+    // split-f16 kernel: hidden tiles in natural order (no k-step skipping), any zero-padded superset works
+    const int ht_b = ceil_div(h, 16);
+    long best = -1;
+    for (const Variant& v : variants()) {
+      const VariantKey& k = v.key;
+      if (k.ksl != -3 || k.kind != desc->kind || k.act_a != act_a || k.act_b != act_b) continue;
+      if (k.ht < ht_b || k.ot < ot) continue;
+      const Variant* v1 = find_variant(VariantKey{k.kind, k.ht, -3, 0, k.ot, 1, 1, k.act_a, k.act_b});
+      const Variant* v2 = find_variant(VariantKey{k.kind, k.ht, -3, 0, k.ot, 2, 1, k.act_a, k.act_b});
+      if (!v1 || !v2) continue;
+      const long cost = (long)k.ht * (k.ht + 1) / 2 * 2 + k.ht * k.ot;
+      if (best < 0 || cost < best) {
+        best = cost;
+        f->var_ht = k.ht; f->var_ksl = -3; f->var_ks1 = 0; f->var_ot = k.ot;
+        f->launch_nt[1] = v1->fn; f->name_nt[1] = v1->name;
+        f->launch_nt[2] = v2->fn; f->name_nt[2] = v2->name;
+      }
+    }
+    hx3 = best >= 0;
+    if (!hx3 && math_mode == GBNF_MATH_F16X3) {
+      delete f;
+      return fail(GBNF_ERR_UNSUPPORTED, "no compiled f16x3 kernel variant for kind=%d hidden=%d out_tiles=%d act=(%d,%d); "
+                  "add it to csrc/variants.list", desc->kind, h, ot, act_a, act_b);
+    }
+  } else if (math_mode == GBNF_MATH_F16X3) {
+    delete f;
+    return fail(GBNF_ERR_UNSUPPORTED, "the f16x3 kernel supports coupling_network_depth == 1 only (got %d)", depth);
+  }
+  f->math_mode = hx3 ? GBNF_MATH_F16X3 : GBNF_MATH_F32;
+  if (!hx3) {
     long best_cost = -1;
     for (const Variant& v : variants()) {
       const VariantKey& k = v.key;
+      if (k.ksl < 0) continue;
       if (k.kind != desc->kind || k.lmid != depth || k.act_a != act_a || k.act_b != act_b) continue;
       if (k.ot < ot || k.ks1 < ks1) continue;
       // a variant processes hidden k-steps [0, 4(k.ht-1)+k.ksl); ours are [0, 4(ht-1)+ksl); extra ones
@@ -312,7 +456,7 @@ int gbnf_flow_create(const gbnf_flow_desc* desc, gbnf_flow** out) {
   const int HT = f->var_ht, OT = f->var_ot, KS1V = f->var_ks1;
 
   const int nnets = glow ? 1 : 2;
-  const size_t NW = net_words(HT, KS1V, OT, depth);
+  const size_t NW = hx3 ? (size_t)Hx3Layout(HT, OT).NET_WORDS : net_words(HT, KS1V, OT, depth);
   const size_t step_words = SMALL_WORDS + nnets * NW;
   const size_t total_words = step_words * K + 64;
   std::vector<uint32_t> blob(total_words, 0u);
@@ -378,10 +522,10 @@ int gbnf_flow_create(const gbnf_flow_desc* desc, gbnf_flow** out) {
     }
     put_i(sb + 0, ceil_div(in_f, 4));
     put_f(sb + 1, ld_const);
-    // in tables [g][e]: k = 4e + g
+    // in tables [g][e]: f32 kernel k = 4e + g (k-step e, lane group g); f16x3 kernel k = 8g + e
     for (int gg = 0; gg < 4; ++gg)
       for (int e = 0; e < NENT; ++e) {
-        const int k = 4 * e + gg;
+        const int k = hx3 ? 8 * gg + e : 4 * e + gg;
         const size_t o = sb + SMALL_HDR + gg * NENT + e;
         if (k < in_f) {
           const int j = in_feat[k];
@@ -406,15 +550,27 @@ int gbnf_flow_create(const gbnf_flow_desc* desc, gbnf_flow** out) {
         }
       }
     const int net_out = paired ? 2 * out_f : out_f;
-    if (glow) {
+    if (hx3) {
+      if (glow) {
+        pack_net_hx3(blob, sb + SMALL_WORDS, desc->glow_steps[s].block, HT, OT, in_f, h, net_out);
+      } else {
+        pack_net_hx3(blob, sb + SMALL_WORDS, desc->realnvp_steps[s].t_net, HT, OT, in_f, h, net_out);
+        pack_net_hx3(blob, sb + SMALL_WORDS + NW, desc->realnvp_steps[s].s_net, HT, OT, in_f, h, net_out);
+      }
+    } else if (glow) {
       pack_net(blob, sb + SMALL_WORDS, desc->glow_steps[s].block, HT, KS1V, OT, depth, in_f, h, net_out);
     } else {
       pack_net(blob, sb + SMALL_WORDS, desc->realnvp_steps[s].t_net, HT, KS1V, OT, depth, in_f, h, net_out);
       pack_net(blob, sb + SMALL_WORDS + NW, desc->realnvp_steps[s].s_net, HT, KS1V, OT, depth, in_f, h, net_out);
     }
     macs += (double)nnets * ((double)in_f * h + (double)depth * h * h + (double)h * net_out);
-    const double kh = 4.0 * (HT - 1) + f->var_ksl;  // live hidden k-steps in the variant
-    padded += (double)nnets * (16.0 * HT * 4 * KS1V + depth * 16.0 * HT * 4 * kh + 16.0 * OT * 4 * kh);
+    if (hx3) {   // executed f16 MACs / 3 (each f32 product = 3 f16 products), k padded to 32
+      const double hc = (HT + 1) / 2;
+      padded += (double)nnets * (16.0 * HT * 32 + 16.0 * HT * 32 * hc + 16.0 * OT * 32 * hc);
+    } else {
+      const double kh = 4.0 * (HT - 1) + f->var_ksl;  // live hidden k-steps in the variant
+      padded += (double)nnets * (16.0 * HT * 4 * KS1V + depth * 16.0 * HT * 4 * kh + 16.0 * OT * 4 * kh);
+    }
   }
   for (int j = 0; j < d; ++j) put_i(step_words * K + j, sigma[j]);
   f->macs = macs; f->padded_macs = padded;
@@ -447,6 +603,7 @@ int gbnf_flow_info(const gbnf_flow* flow, gbnf_kernel_info* info) {
   info->hidden_tiles = flow->var_ht;
   info->out_tiles = flow->var_ot;
   info->samples_per_wave = 32;
+  info->math_mode = flow->math_mode;
   info->n_steps = flow->n_steps;
   info->macs_per_sample = flow->macs;
   info->padded_macs_per_sample = flow->padded_macs;
@@ -479,7 +636,8 @@ static int launch_flow(const gbnf_flow* f, const uint32_t* const* table, int c_b
   if (n == 0 || n_comp == 0) return GBNF_OK;
   const int nt = pick_nt(n, n_comp);
   const int64_t tiles = (n + 16 * nt - 1) / (16 * nt);
-  const int64_t grid = tiles * n_comp;
+  // f32 kernel: one wave (= block) per tile; f16x3 kernel: one 4-wave block per group of 4 tiles
+  const int64_t grid = (f->math_mode == GBNF_MATH_F16X3 ? (tiles + HX3_WAVES - 1) / HX3_WAVES : tiles) * n_comp;
   if (grid > 0x7fffffffLL) return fail(GBNF_ERR_UNSUPPORTED, "batch too large for one launch (%lld tiles)", (long long)grid);
   FlowLaunch p{};
   p.blobs = table; p.x = x; p.z_out = z; p.ldj_out = ldj; p.ll_out = ll;
@@ -542,7 +700,7 @@ int gbnf_mixture_create(gbnf_flow* const* flows, int32_t n_flows, gbnf_mixture**
   for (int c = 0; c < n_flows; ++c) {
     const gbnf_flow* f = flows[c];
     if (!f) return fail(GBNF_ERR_INVALID, "gbnf_mixture_create: flow %d is null", c);
-    if (f->kind != f0->kind || f->d != f0->d || f->n_steps != f0->n_steps || f->additive != f0->additive ||
+    if (f->math_mode != f0->math_mode || f->kind != f0->kind || f->d != f0->d || f->n_steps != f0->n_steps || f->additive != f0->additive ||
         f->hidden != f0->hidden || f->depth != f0->depth || f->act_a != f0->act_a || f->act_b != f0->act_b ||
         f->var_ht != f0->var_ht || f->var_ksl != f0->var_ksl || f->var_ks1 != f0->var_ks1 || f->var_ot != f0->var_ot)
       return fail(GBNF_ERR_INVALID, "gbnf_mixture_create: flow %d has a different architecture than flow 0", c);

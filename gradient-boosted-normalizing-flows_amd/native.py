@@ -18,11 +18,12 @@ LIB_PATH = os.environ.get("GBNF_LIB_PATH") or os.path.join(_HERE, "libgbnf_hip.s
 KIND = {"glow": 0, "realnvp": 1}
 ACT = {"tanh": 0, "relu": 1}
 COUPLING = {"affine": 0, "additive": 1}
+MATH = {"default": -1, "f32": 0, "f16x3": 1}
 
 # every symbol include/gbnf.h declares (tests check the library exports exactly these)
 ABI_SYMBOLS = (
     "gbnf_version", "gbnf_last_error",
-    "gbnf_flow_create", "gbnf_flow_destroy", "gbnf_flow_info", "gbnf_flow_forward",
+    "gbnf_flow_create", "gbnf_flow_create_mode", "gbnf_flow_destroy", "gbnf_flow_info", "gbnf_flow_forward",
     "gbnf_mixture_create", "gbnf_mixture_destroy", "gbnf_mixture_set_base",
     "gbnf_mixture_component_log_prob", "gbnf_mixture_lse", "gbnf_mixture_log_prob",
 )
@@ -61,7 +62,8 @@ class _FlowDesc(C.Structure):
 class KernelInfo(C.Structure):
     _fields_ = [("hidden_tiles", C.c_int32), ("out_tiles", C.c_int32), ("samples_per_wave", C.c_int32),
                 ("n_steps", C.c_int32), ("macs_per_sample", C.c_double),
-                ("padded_macs_per_sample", C.c_double), ("packed_bytes", C.c_int64)]
+                ("padded_macs_per_sample", C.c_double), ("packed_bytes", C.c_int64),
+                ("math_mode", C.c_int32), ("reserved", C.c_int32)]
 
 
 _lib = None
@@ -81,6 +83,7 @@ def lib():
     L.gbnf_version.restype = C.c_int
     L.gbnf_last_error.restype = C.c_char_p
     L.gbnf_flow_create.argtypes = [C.POINTER(_FlowDesc), C.POINTER(vp)]
+    L.gbnf_flow_create_mode.argtypes = [C.POINTER(_FlowDesc), i32, C.POINTER(vp)]
     L.gbnf_flow_destroy.argtypes = [vp]
     L.gbnf_flow_info.argtypes = [vp, C.POINTER(KernelInfo)]
     L.gbnf_flow_forward.argtypes = [vp, vp, i64, vp, vp, vp, vp]
@@ -184,10 +187,10 @@ def _stream_ptr():
 class NativeFlow:
     """One packed component on the device (gbnf_flow)."""
 
-    def __init__(self, spec):
+    def __init__(self, spec, math="default"):
         desc, keep = flow_desc_from_spec(spec)
         h = C.c_void_p()
-        _check(lib().gbnf_flow_create(C.byref(desc), C.byref(h)))
+        _check(lib().gbnf_flow_create_mode(C.byref(desc), MATH[math], C.byref(h)))
         del keep
         self.handle = h
         self.d = int(spec["d"])

@@ -44,6 +44,12 @@ typedef enum gbnf_status {
 enum { GBNF_KIND_GLOW = 0, GBNF_KIND_REALNVP = 1 };
 enum { GBNF_ACT_TANH = 0, GBNF_ACT_RELU = 1 };
 enum { GBNF_COUPLING_AFFINE = 0, GBNF_COUPLING_ADDITIVE = 1 };
+/* How the coupling-network matrix products are evaluated (results agree to ~1e-6 relative in log-likelihood):
+ *   F32     exact f32 MFMA (v_mfma_f32_16x16x4_f32), bitwise an ordered fmaf chain;
+ *   F16X3   each f32 operand split into two fp16 pieces (22 significand bits); a.b = a_mid.b_hi + a_hi.b_mid +
+ *           a_hi.b_hi on the f16 matrix pipe with f32 accumulation (coupling_network_depth == 1 only);
+ *   DEFAULT F16X3 where a compiled variant exists, else F32. */
+enum { GBNF_MATH_DEFAULT = -1, GBNF_MATH_F32 = 0, GBNF_MATH_F16X3 = 1 };
 
 /* nn.Linear: y = x W^T + b, W row-major (out_features, in_features).
  * TanhNet / ReLUNet layers, models/layers.py:208-243. */
@@ -105,6 +111,8 @@ typedef struct gbnf_kernel_info {
   double macs_per_sample;        /* algorithmic multiply-adds per sample per component */
   double padded_macs_per_sample; /* what the MFMA tiles actually execute          */
   int64_t packed_bytes;          /* device bytes of packed parameters per component */
+  int32_t math_mode;             /* GBNF_MATH_F32 or GBNF_MATH_F16X3 actually used */
+  int32_t reserved;
 } gbnf_kernel_info;
 
 int gbnf_version(void);
@@ -113,6 +121,8 @@ const char* gbnf_last_error(void);
 /* Replaces: constructing flows[c] + .to(device)  (models/boosted_flow.py:42-50).
  * Packs (pads, tiles, folds slot maps) and uploads the parameters. */
 int gbnf_flow_create(const gbnf_flow_desc* desc, gbnf_flow** out);
+/* Same with an explicit GBNF_MATH_* mode (gbnf_flow_create uses GBNF_MATH_DEFAULT, or env GBNF_MATH=f32|f16x3). */
+int gbnf_flow_create_mode(const gbnf_flow_desc* desc, int32_t math_mode, gbnf_flow** out);
 int gbnf_flow_destroy(gbnf_flow* flow);
 int gbnf_flow_info(const gbnf_flow* flow, gbnf_kernel_info* info);
 

@@ -33,14 +33,16 @@ def test_ctypes_structs_match_header_layout():
     assert ctypes.sizeof(native._GlowStep) == 40
     assert ctypes.sizeof(native._RealNVPStep) == 8 + 4 * 8 + 8 + 16 + 16
     assert ctypes.sizeof(native._FlowDesc) == 32
-    assert ctypes.sizeof(native.KernelInfo) == 16 + 8 + 8 + 8
+    assert ctypes.sizeof(native.KernelInfo) == 16 + 8 + 8 + 8 + 8
 
 
 def test_variant_list_covers_baseline_configs():
     """Every BASELINE.json config geometry has an exact compiled variant (not a padded superset)."""
     lines = [ln.split("#")[0].split() for ln in open(os.path.join(
         REPO, "gradient-boosted-normalizing-flows_amd", "csrc", "variants.list"))]
-    keys = {tuple(int(v) for v in ln) for ln in lines if ln}
-    assert (0, 14, 2, 6, 3, 1, 0, 0) in keys      # MINIBOONE d=43 h=215 Glow tanh depth 1
-    assert (1, 7, 3, 3, 1, 1, 0, 0) in keys       # HEPMASS d=21 h=105 RealNVP tanh depth 1
-    assert (1, 4, 4, 3, 1, 1, 0, 0) in keys       # toy / small RealNVP
+    keys = {tuple(ln) for ln in lines if ln}
+    assert tuple("0 14 2 6 3 1 0 0".split()) in keys      # MINIBOONE d=43 h=215 Glow tanh depth 1, exact f32
+    assert tuple("1 7 3 3 1 1 0 0".split()) in keys       # HEPMASS d=21 h=105 RealNVP tanh depth 1, exact f32
+    assert tuple("1 4 4 3 1 1 0 0".split()) in keys       # toy / small RealNVP
+    assert tuple("hx3 0 14 3 0 0".split()) in keys        # MINIBOONE, split-f16 kernel
+    assert tuple("hx3 1 7 1 0 0".split()) in keys         # HEPMASS, split-f16 kernel

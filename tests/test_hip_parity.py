@@ -20,17 +20,24 @@ def dev():
     return torch.device("cuda:0")
 
 
-def _mixture(specs):
+def _mixture(specs, math="default"):
     from gbnf_amd import native
-    flows = [native.NativeFlow(s) for s in specs]
+    flows = [native.NativeFlow(s, math=math) for s in specs]
     return native.NativeMixture(flows), flows
 
 
+@pytest.mark.parametrize("math", ["f32", "f16x3"])
 @pytest.mark.parametrize("name", golden_names())
-def test_hip_matches_reference_golden(name, golden_case, dev):
+def test_hip_matches_reference_golden(name, math, golden_case, dev):
+    """Every fixture in both math modes: exact-f32 MFMA and the split-f16 (3 product) matrix path."""
     import torch
+    from gbnf_amd import native
     g = golden_case(name)
-    mix, flows = _mixture(g.specs)
+    try:
+        mix, flows = _mixture(g.specs, math)
+    except native.GbnfError:
+        assert math == "f16x3" and g.cfg.get("synth_kw", {}).get("depth", 1) != 1   # depth 0 / 2: f32 kernel only
+        pytest.skip("split-f16 kernel is depth-1 only; this fixture runs on the exact-f32 kernel")
     if g.base is not None:
         mix.set_base(*g.base)
     x = torch.from_numpy(g.x).to(dev)
@@ -138,6 +145,24 @@ def test_mixture_lse_edge_cases(dev):
     # C = 1 is the identity
     one = native.mixture_lse(torch.from_numpy(ll[:1].copy()).to(dev), torch.from_numpy(rho).to(dev)).cpu().numpy()
     assert np.array_equal(one, ll[0])
+
+
+def test_default_math_mode_and_mode_agreement(dev):
+    """Default = split-f16 kernel where compiled (depth 1); both modes agree to ~1e-6 on the BASELINE shape."""
+    import torch
+    from gbnf_amd import native, synth
+    spec = synth.synth_glow_spec(43, 215, 5, seed=1000)
+    assert native.NativeFlow(spec).info().math_mode == native.MATH["f16x3"]
+    assert native.NativeFlow(spec, math="f32").info().math_mode == native.MATH["f32"]
+    deep = synth.synth_glow_spec(43, 64, 3, depth=2, seed=3)
+    assert native.NativeFlow(deep).info().math_mode == native.MATH["f32"]        # falls back loudly-documented
+    with pytest.raises(native.GbnfError):
+        native.NativeFlow(deep, math="f16x3")
+    x = torch.from_numpy(synth.synth_batch(4096, 43, seed=9)).to(dev)
+    a = native.NativeFlow(spec, math="f32").forward(x, want_ll=True)
+    b = native.NativeFlow(spec, math="f16x3").forward(x, want_ll=True)
+    assert rel_err(b[2].cpu().numpy(), a[2].cpu().numpy()) < 2e-6
+    np.testing.assert_allclose(b[0].cpu().numpy(), a[0].cpu().numpy(), rtol=0, atol=1e-5)
 
 
 def test_empty_batch_and_errors(dev):
