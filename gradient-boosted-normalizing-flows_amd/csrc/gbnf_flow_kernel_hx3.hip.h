@@ -145,29 +145,33 @@ __global__ void __launch_bounds__(64 * HX3_WAVES) flow_kernel_hx3(const FlowLaun
   const int d = p.d;
   const int64_t row0 = ((int64_t)grp * HX3_WAVES + wave) * (16 * NT);    // rows >= n are masked everywhere
 
-  // ---- weight staging: stage index -> DMA burst into staging buffer (gs & 1); wave w moves fragments
-  //      w, w+4, ...; the LDS destination of a wave-instruction is base + lane*16 = the fragment itself
-  auto issue_stage = [&](int step, int net, int ls, int gs) {
-    const uint32_t* src = blob + (size_t)step * STEP_WORDS + SMALL_WORDS + net * L.NET_WORDS + L.off[ls];
-    uint32_t* dst = STG + (gs & 1) * STAGE_WORDS;
-    const int nf = L.nf[ls];
-    for (int f = wave; f < nf; f += HX3_WAVES) {
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + f * 256 + lane * 4),
-                                       (__attribute__((address_space(3))) void*)(dst + f * 256), 16, 0, 0);
+  // ---- weight staging.  The blob is laid out in consumption order, so "the next stage" is a running
+  //      pointer; every call site knows the next stage's fragment count at compile time.  Wave w moves
+  //      fragments w, w+4, ...; the LDS destination of a wave-instruction is base + lane*16 = the fragment.
+  using gwords = const __attribute__((address_space(1))) uint32_t*;
+  gwords next_src = (gwords)blob + SMALL_WORDS + L.BIAS_WORDS;   // first stage of step 0, net 0
+  int gs = 0;                                                      // stage counter: buffer = gs & 1
+  const unsigned lane_b16 = (unsigned)lane * 16u;
+  auto issue = [&](auto nf_c, int into) {
+    constexpr int NF = decltype(nf_c)::value;
+    uint32_t* dst = STG + (into & 1) * STAGE_WORDS;
+#pragma unroll
+    for (int k = 0; 4 * k < NF; ++k) {
+      const int f = wave + 4 * k;
+      if (4 * k + 3 < NF || f < NF) {
+        // uniform base + 32-bit per-lane offset -> saddr form, no 64-bit VALU address arithmetic
+        const __attribute__((address_space(1))) char* base =
+            reinterpret_cast<const __attribute__((address_space(1))) char*>(next_src + f * 256);
+        __builtin_amdgcn_global_load_lds(base + lane_b16, (__attribute__((address_space(3))) void*)(dst + f * 256),
+                                         16, 0, 0);
+      }
     }
+    next_src += NF * 256;
   };
-  // (step, net, ls) of the stage after the given one; returns false at the very end
-  auto next_stage = [&](int& step, int& net, int& ls) -> bool {
-    if (++ls < L.NS) return true;
-    ls = 0;
-    if (++net < NNETS) return true;
-    net = 0;
-    return ++step < p.n_steps;
-  };
+  constexpr int NF_L0_FIRST = 2 * (HT < HX3_L0_TILES ? HT : HX3_L0_TILES);
 
   // ---- per-step tables -> LDS, x tile -> Z, first weight stage in flight
-  int gs = 0;                    // global stage counter (uniform)
-  issue_stage(0, 0, 0, 0);
+  issue(std::integral_constant<int, NF_L0_FIRST>{}, 0);
   if (lds_tables) {
     for (int s = 0; s < p.n_steps; ++s) {
       const uint32_t* src = blob + (size_t)s * STEP_WORDS;
@@ -193,22 +197,12 @@ __global__ void __launch_bounds__(64 * HX3_WAVES) flow_kernel_hx3(const FlowLaun
   Stamps st;
   st.start();
 
-  int pf_step = 0, pf_net = 0, pf_ls = 0;   // the stage currently in buffer gs & 1
-
-  // begin a stage: put the NEXT stage's DMA in flight (into the other buffer, which every wave has
-  // finished reading: the previous stage ended with a barrier)
-  auto stage_begin = [&]() -> const uint32_t* {
-    int s2 = pf_step, n2 = pf_net, l2 = pf_ls;
-    if (next_stage(s2, n2, l2)) issue_stage(s2, n2, l2, gs + 1);
-    return STG + (gs & 1) * STAGE_WORDS;
-  };
-  auto stage_end = [&]() {
-    __syncthreads();             // all waves done with this buffer; next stage's DMA landed (vmcnt drained)
-    next_stage(pf_step, pf_net, pf_ls);
-    ++gs;
-  };
   auto frag = [&](const uint32_t* buf, int f) -> u32x4 {
     return *reinterpret_cast<const u32x4*>(buf + f * 256 + lane * 4);
+  };
+  auto stage_end = [&]() {
+    __syncthreads();             // all waves done with this buffer; the next stage's DMA has landed
+    ++gs;
   };
 
   for (int step = 0; step < p.n_steps; ++step) {
@@ -253,15 +247,23 @@ __global__ void __launch_bounds__(64 * HX3_WAVES) flow_kernel_hx3(const FlowLaun
     for (int net = 0; net < NNETS; ++net) {
       f32x4 (&out)[OT][NT] = (net == 0) ? outA : outB;
       const int ACT = (net == 0) ? ACTA : ACTB;
-      const uint32_t* nb = sp + SMALL_WORDS + net * L.NET_WORDS;
-      const f32x4* b1 = reinterpret_cast<const f32x4*>(nb) + g;
-      const f32x4* b2 = reinterpret_cast<const f32x4*>(nb + HT * 16) + g;
-      const f32x4* b3 = reinterpret_cast<const f32x4*>(nb + 2 * HT * 16) + g;
+      using gf4 = const __attribute__((address_space(1))) f32x4*;
+      gwords nb = (gwords)blob + (size_t)step * STEP_WORDS + SMALL_WORDS + net * L.NET_WORDS;
+      gf4 b1 = (gf4)nb + g;
+      gf4 b2 = (gf4)(nb + HT * 16) + g;
+      gf4 b3 = (gf4)(nb + 2 * HT * 16) + g;
       auto act = [&](float v) { return ACT == GBNF_ACT_TANH ? act_hx3<GBNF_ACT_TANH>(v) : act_hx3<GBNF_ACT_RELU>(v); };
+      // activate + split one register pair (values 2hp, 2hp+1 of a raw accumulator tile)
+      // (the empty asm pins the computation HERE: without it LLVM sinks the whole tanh + split into the later
+      //  block that first consumes the operand, un-interleaving it from this region's MFMAs)
+      auto act_split = [&](const f32x4& raw, int hp, unsigned& h, unsigned& m) {
+        split_pair(act(raw[2 * hp]), act(raw[2 * hp + 1]), h, m);
+        asm volatile("" : "+v"(h), "+v"(m));
+      };
 
       u32x4 hBhi[HC][NT], hBmid[HC][NT];     // layer-0 output = B operands of the hidden layer
 #pragma unroll
-      for (int nt = 0; nt < NT; ++nt) {       // phantom half of an odd tile count is zero
+      for (int nt = 0; nt < NT; ++nt) {       // phantom half of an odd tile count stays zero
         hBhi[HC - 1][nt] = u32x4{0, 0, 0, 0};
         hBmid[HC - 1][nt] = u32x4{0, 0, 0, 0};
       }
@@ -272,95 +274,165 @@ __global__ void __launch_bounds__(64 * HX3_WAVES) flow_kernel_hx3(const FlowLaun
         for (int nt = 0; nt < NT; ++nt) out[o][nt] = b;
       }
 
-      // ---- layer 0: tile t = W1[tile t] . z  (one k = 32 chunk); tanh + split of tile t-1 rides along
+      // ---- layer 0: tile t = W1[tile t] . z  (one k = 32 chunk); the tanh + split of tile t-1 shares its region
       {
         f32x4 raw[NT];
         f32x4 bias = b1[0];
 #pragma unroll
         for (int sI = 0; sI < L.N_L0; ++sI) {
-          const uint32_t* buf = stage_begin();
+          const uint32_t* buf = STG + (gs & 1) * STAGE_WORDS;
+          constexpr int NF_PASS0 = 2 * HC;
           const int t0 = sI * HX3_L0_TILES;
+          // next stage: another layer-0 stage or the first hidden pass
+          if (sI + 1 < L.N_L0) {
+            if (HT - (sI + 1) * HX3_L0_TILES >= HX3_L0_TILES) issue(std::integral_constant<int, 2 * HX3_L0_TILES>{}, gs + 1);
+            else issue(std::integral_constant<int, 2 * (HT % HX3_L0_TILES == 0 ? HX3_L0_TILES : HT % HX3_L0_TILES)>{}, gs + 1);
+          } else {
+            issue(std::integral_constant<int, NF_PASS0>{}, gs + 1);
+          }
+          u32x4 AL[2 * HX3_L0_TILES];
+#pragma unroll
+          for (int tl = 0; tl < HX3_L0_TILES; ++tl)
+            if (t0 + tl < HT) {
+              AL[2 * tl] = frag(buf, 2 * tl);
+              AL[2 * tl + 1] = frag(buf, 2 * tl + 1);
+            }
 #pragma unroll
           for (int tl = 0; tl < HX3_L0_TILES; ++tl) {
             const int t = t0 + tl;
             if (t < HT) {
-              const u32x4 a_hi = frag(buf, 2 * tl), a_mid = frag(buf, 2 * tl + 1);
-              f32x4 cur[NT];
+              const u32x4 c_hi = AL[2 * tl], c_mid = AL[2 * tl + 1];
               const f32x4 bias_next = b1[(t + 1 < HT ? t + 1 : t) * 4];
+              f32x4 cur[NT];
 #pragma unroll
-              for (int nt = 0; nt < NT; ++nt) cur[nt] = mfma_x3(a_hi, a_mid, zhi[nt], zmid[nt], bias);
+              for (int nt = 0; nt < NT; ++nt) {
+                cur[nt] = mfma_f16(c_mid, zhi[nt], bias);
+                MFMA_ORDER_FENCE();
+              }
               if (t > 0) {
+                const int c = (t - 1) >> 1, hf = (t - 1) & 1;
 #pragma unroll
-                for (int nt = 0; nt < NT; ++nt) {
-                  const int c = (t - 1) >> 1, hf = (t - 1) & 1;
-                  unsigned h0, m0, h1, m1;
-                  split_pair(act(raw[nt][0]), act(raw[nt][1]), h0, m0);
-                  split_pair(act(raw[nt][2]), act(raw[nt][3]), h1, m1);
-                  hBhi[c][nt][2 * hf] = h0; hBmid[c][nt][2 * hf] = m0;
-                  hBhi[c][nt][2 * hf + 1] = h1; hBmid[c][nt][2 * hf + 1] = m1;
-                }
+                for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                  for (int hp = 0; hp < 2; ++hp) {
+                    unsigned h, m;
+                    act_split(raw[nt], hp, h, m);
+                    hBhi[c][nt][2 * hf + hp] = h;
+                    hBmid[c][nt][2 * hf + hp] = m;
+                  }
+              }
+#pragma unroll
+              for (int nt = 0; nt < NT; ++nt) {
+                cur[nt] = mfma_f16(c_hi, zmid[nt], cur[nt]);
+                MFMA_ORDER_FENCE();
+              }
+#pragma unroll
+              for (int nt = 0; nt < NT; ++nt) {
+                cur[nt] = mfma_f16(c_hi, zhi[nt], cur[nt]);
+                MFMA_ORDER_FENCE();
               }
 #pragma unroll
               for (int nt = 0; nt < NT; ++nt) raw[nt] = cur[nt];
               bias = bias_next;
+              __builtin_amdgcn_sched_barrier(0);
             }
           }
           stage_end();
         }
-#pragma unroll
-        for (int nt = 0; nt < NT; ++nt) {
+        {
           const int c = (HT - 1) >> 1, hf = (HT - 1) & 1;
-          unsigned h0, m0, h1, m1;
-          split_pair(act(raw[nt][0]), act(raw[nt][1]), h0, m0);
-          split_pair(act(raw[nt][2]), act(raw[nt][3]), h1, m1);
-          hBhi[c][nt][2 * hf] = h0; hBmid[c][nt][2 * hf] = m0;
-          hBhi[c][nt][2 * hf + 1] = h1; hBmid[c][nt][2 * hf + 1] = m1;
+#pragma unroll
+          for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+            for (int hp = 0; hp < 2; ++hp) {
+              unsigned h, m;
+              act_split(raw[nt], hp, h, m);
+              hBhi[c][nt][2 * hf + hp] = h;
+              hBmid[c][nt][2 * hf + hp] = m;
+            }
         }
       }
       st.mark(1);
 
-      // ---- hidden layer, one output tile per stage; tile u-1 is activated/split during pass u and an
-      //      output-layer chunk (two hidden tiles = k 32) is consumed as soon as it is complete
+      // ---- hidden layer, one 16-unit output tile per stage.  Tile u-1 is activated/split during pass u
+      //      (one register pair per chunk region); an output-layer chunk (two hidden tiles = k 32) is
+      //      consumed in the pass after its second tile.
       {
         f32x4 pre[NT];
         u32x4 hOhi[NT], hOmid[NT];
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+          hOhi[nt] = u32x4{0, 0, 0, 0};
+          hOmid[nt] = u32x4{0, 0, 0, 0};
+        }
         f32x4 bias = b2[0];
-        // PREV: 0 = no previous tile (u = 0), 1 = tile u-1 is the FIRST half of its output-layer chunk
-        // (u odd), 2 = it is the SECOND half and the chunk (u-2)/2 is consumed in this pass (u even >= 2)
-        auto pass = [&](int u, auto prev_c) {
+        // PREV: 0 = no previous tile (u = 0); 1 = tile u-1 is the FIRST half of its output-layer chunk
+        // (u odd); 2 = it is the SECOND half and chunk (u-2)/2 is consumed at the end of this pass (u even >= 2)
+        auto pass = [&](int u, auto prev_c, auto last_c) {
           constexpr int PREV = decltype(prev_c)::value;
-          const uint32_t* buf = stage_begin();
+          constexpr bool LAST = decltype(last_c)::value;
+          constexpr int NF_CUR = 2 * HC + (PREV == 2 ? 2 * OT : 0);
+          constexpr int NF_NEXT = LAST ? 2 * OT : (PREV == 1 ? 2 * HC + 2 * OT : 2 * HC);
+          const uint32_t* buf = STG + (gs & 1) * STAGE_WORDS;
+          issue(std::integral_constant<int, NF_NEXT>{}, gs + 1);
+          u32x4 A[NF_CUR];
+#pragma unroll
+          for (int f = 0; f < NF_CUR; ++f) A[f] = frag(buf, f);
           const f32x4 bias_next = b2[(u + 1 < HT ? u + 1 : u) * 4];
           f32x4 acc[NT];
 #pragma unroll
           for (int nt = 0; nt < NT; ++nt) acc[nt] = bias;
+          __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
           for (int c = 0; c < HC; ++c) {
-            const u32x4 a_hi = frag(buf, 2 * c), a_mid = frag(buf, 2 * c + 1);
+            if (PREV != 0) {
+              // register pairs q = c, c + HC, ... of the previous tile (2*NT pairs in all); issued ahead of the
+              // region's MFMAs so that the first region covers the LDS latency of the fragment reads
 #pragma unroll
-            for (int nt = 0; nt < NT; ++nt) acc[nt] = mfma_x3(a_hi, a_mid, hBhi[c][nt], hBmid[c][nt], acc[nt]);
-            if (c == 0 && PREV != 0) {
-#pragma unroll
-              for (int nt = 0; nt < NT; ++nt) {
-                unsigned h0, m0, h1, m1;
-                split_pair(act(pre[nt][0]), act(pre[nt][1]), h0, m0);
-                split_pair(act(pre[nt][2]), act(pre[nt][3]), h1, m1);
-                if (PREV == 2) {
-                  hOhi[nt][2] = h0; hOhi[nt][3] = h1; hOmid[nt][2] = m0; hOmid[nt][3] = m1;
-                } else {
-                  hOhi[nt] = u32x4{h0, h1, 0, 0};
-                  hOmid[nt] = u32x4{m0, m1, 0, 0};
-                }
+              for (int q = c; q < 2 * NT; q += HC) {
+                const int nt = q >> 1, hp = q & 1;
+                unsigned h, m;
+                act_split(pre[nt], hp, h, m);
+                hOhi[nt][(PREV == 2 ? 2 : 0) + hp] = h;
+                hOmid[nt][(PREV == 2 ? 2 : 0) + hp] = m;
               }
             }
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+              acc[nt] = mfma_f16(A[2 * c + 1], hBhi[c][nt], acc[nt]);
+              MFMA_ORDER_FENCE();
+            }
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+              acc[nt] = mfma_f16(A[2 * c], hBmid[c][nt], acc[nt]);
+              MFMA_ORDER_FENCE();
+            }
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+              acc[nt] = mfma_f16(A[2 * c], hBhi[c][nt], acc[nt]);
+              MFMA_ORDER_FENCE();
+            }
+            __builtin_amdgcn_sched_barrier(0);
           }
           if (PREV == 2) {
             // output-layer chunk (u-2)/2 = hidden tiles (u-2, u-1): its fragments follow the hidden row
 #pragma unroll
             for (int o = 0; o < OT; ++o) {
-              const u32x4 a_hi = frag(buf, 2 * HC + 2 * o), a_mid = frag(buf, 2 * HC + 2 * o + 1);
 #pragma unroll
-              for (int nt = 0; nt < NT; ++nt) out[o][nt] = mfma_x3(a_hi, a_mid, hOhi[nt], hOmid[nt], out[o][nt]);
+              for (int nt = 0; nt < NT; ++nt) {
+                out[o][nt] = mfma_f16(A[2 * HC + 2 * o + 1], hOhi[nt], out[o][nt]);
+                MFMA_ORDER_FENCE();
+              }
+#pragma unroll
+              for (int nt = 0; nt < NT; ++nt) {
+                out[o][nt] = mfma_f16(A[2 * HC + 2 * o], hOmid[nt], out[o][nt]);
+                MFMA_ORDER_FENCE();
+              }
+#pragma unroll
+              for (int nt = 0; nt < NT; ++nt) {
+                out[o][nt] = mfma_f16(A[2 * HC + 2 * o], hOhi[nt], out[o][nt]);
+                MFMA_ORDER_FENCE();
+              }
             }
           }
 #pragma unroll
@@ -368,38 +440,58 @@ __global__ void __launch_bounds__(64 * HX3_WAVES) flow_kernel_hx3(const FlowLaun
           bias = bias_next;
           stage_end();
         };
-        pass(0, std::integral_constant<int, 0>{});
-        {
+        using I0 = std::integral_constant<int, 0>;
+        using I1 = std::integral_constant<int, 1>;
+        using I2 = std::integral_constant<int, 2>;
+        using BF = std::false_type;
+        using BT = std::true_type;
+        if constexpr (HT == 1) {
+          pass(0, I0{}, BT{});
+        } else {
+          pass(0, I0{}, BF{});
           int u = 1;
 #pragma unroll 1
-          for (; u + 1 < HT; u += 2) {
-            pass(u, std::integral_constant<int, 1>{});
-            pass(u + 1, std::integral_constant<int, 2>{});
+          for (; u + 2 < HT; u += 2) {
+            pass(u, I1{}, BF{});
+            pass(u + 1, I2{}, BF{});
           }
-          if (u < HT) pass(u, std::integral_constant<int, 1>{});
+          if constexpr (HT % 2 == 1) {       // two passes left: HT-2 (odd), HT-1 (even, last)
+            pass(u, I1{}, BF{});
+            pass(u + 1, I2{}, BT{});
+          } else {                           // one pass left: HT-1 (odd, last)
+            pass(u, I1{}, BT{});
+          }
         }
         st.mark(3);
-        // ---- drain: last tile, last output-layer chunk (HC-1)
+        // ---- drain: last tile, last output-layer chunk (HC-1); put the next net's / step's first stage in flight
         {
-          const uint32_t* buf = stage_begin();
+          const uint32_t* buf = STG + (gs & 1) * STAGE_WORDS;
+          const bool more = (net + 1 < NNETS) || (step + 1 < p.n_steps);
+          if (more) {
+            next_src += (net + 1 < NNETS) ? L.BIAS_WORDS : SMALL_WORDS + L.BIAS_WORDS;
+            issue(std::integral_constant<int, NF_L0_FIRST>{}, gs + 1);
+          }
+          u32x4 A[2 * OT];
+#pragma unroll
+          for (int f = 0; f < 2 * OT; ++f) A[f] = frag(buf, f);
           constexpr bool odd_last = ((HT - 1) & 1) != 0;
 #pragma unroll
           for (int nt = 0; nt < NT; ++nt) {
-            unsigned h0, m0, h1, m1;
-            split_pair(act(pre[nt][0]), act(pre[nt][1]), h0, m0);
-            split_pair(act(pre[nt][2]), act(pre[nt][3]), h1, m1);
-            if (odd_last) {
-              hOhi[nt][2] = h0; hOhi[nt][3] = h1; hOmid[nt][2] = m0; hOmid[nt][3] = m1;
-            } else {
-              hOhi[nt] = u32x4{h0, h1, 0, 0};
-              hOmid[nt] = u32x4{m0, m1, 0, 0};
+#pragma unroll
+            for (int hp = 0; hp < 2; ++hp) {
+              unsigned h, m;
+              act_split(pre[nt], hp, h, m);
+              hOhi[nt][(odd_last ? 2 : 0) + hp] = h;
+              hOmid[nt][(odd_last ? 2 : 0) + hp] = m;
+            }
+            if (!odd_last) {
+              hOhi[nt][2] = 0; hOhi[nt][3] = 0; hOmid[nt][2] = 0; hOmid[nt][3] = 0;
             }
           }
 #pragma unroll
           for (int o = 0; o < OT; ++o) {
-            const u32x4 a_hi = frag(buf, 2 * o), a_mid = frag(buf, 2 * o + 1);
 #pragma unroll
-            for (int nt = 0; nt < NT; ++nt) out[o][nt] = mfma_x3(a_hi, a_mid, hOhi[nt], hOmid[nt], out[o][nt]);
+            for (int nt = 0; nt < NT; ++nt) out[o][nt] = mfma_x3(A[2 * o], A[2 * o + 1], hOhi[nt], hOmid[nt], out[o][nt]);
           }
           stage_end();
         }

@@ -1,14 +1,15 @@
 #!/bin/bash
-# Diagnostic build: the flow kernel with in-kernel s_memtime phase stamps (-DGBNF_STAMPS).
+# Diagnostic build: both flow kernels with in-kernel s_memtime phase stamps (-DGBNF_STAMPS).
 # Never shipped, never timed end to end; read the SHARES it prints, not its run time.
 set -e
 cd "$(dirname "$0")/../gradient-boosted-normalizing-flows_amd/csrc"
 OUT=/tmp/gbnf_stamps; mkdir -p $OUT
-ARGS="${1:-0,14,2,6,3,NT,1,0,0}"
+F="--offload-arch=gfx950 -O3 -fPIC -std=c++17 -DGBNF_STAMPS"
 for nt in 1 2; do
-  hipcc --offload-arch=gfx950 -O3 -fPIC -std=c++17 -DGBNF_STAMPS -DGBNF_V_ARGS=${ARGS/NT/$nt} -c variant.hip -o $OUT/v_$nt.o &
+  hipcc $F -DGBNF_V_ARGS=0,14,2,6,3,$nt,1,0,0 -c variant.hip -o $OUT/v_$nt.o &
+  hipcc $F -DGBNF_V_ARGS=0,14,3,$nt,0,0 -c variant_hx3.hip -o $OUT/h_$nt.o &
 done
-hipcc --offload-arch=gfx950 -O3 -fPIC -std=c++17 -DGBNF_STAMPS -c gbnf_api.hip -o $OUT/api.o
+hipcc $F -c gbnf_api.hip -o $OUT/api.o
 wait
-hipcc --offload-arch=gfx950 -shared -fPIC -o ../../tools/libgbnf_hip_stamps.so $OUT/api.o $OUT/v_1.o $OUT/v_2.o
+hipcc --offload-arch=gfx950 -shared -fPIC -o ../../tools/libgbnf_hip_stamps.so $OUT/api.o $OUT/v_1.o $OUT/v_2.o $OUT/h_1.o $OUT/h_2.o
 echo "built tools/libgbnf_hip_stamps.so"
