@@ -28,6 +28,7 @@ REPO = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, REPO)
 
 F32_MFMA_PEAK_TFLOPS = 157.3   # /opt/skills/guides/MI355X_MICROARCH.md: dense f32 matrix peak
+F16_MFMA_PEAK_TFLOPS = 2500.0  # same guide: dense bf16/f16 matrix peak (no sparsity)
 HBM_PEAK_GBS = 8000.0          # same guide: HBM3E spec peak
 
 CONFIGS = {
@@ -95,6 +96,11 @@ def main():
     ap.add_argument("--batch", type=int, default=None)
     ap.add_argument("--components", type=int, default=None)
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the CPU baseline leg (0 = skip)")
+    ap.add_argument("--math", default="default", choices=["default", "f32", "f16x3"],
+                    help="matrix path: exact-f32 MFMA or split-f16 (3 f16 MFMAs per f32 product)")
+    ap.add_argument("--streams", type=int, default=0,
+                    help="HIP streams over which consecutive (independent) batches are pipelined "
+                         "(0 = auto: 1 on a single GPU, 4 when components are sharded)")
     args = ap.parse_args()
 
     import numpy as np
@@ -125,44 +131,42 @@ def main():
     rho_np = np.maximum(1.0 / np.power(2.0, np.arange(C)), 0.05).astype(np.float32)   # "decreasing"
     parts = sharded.partition(C, world)
     c0, c1 = parts[rank]
-    flows = [native.NativeFlow(specs[c]) for c in range(c0, c1)]
+    flows = [native.NativeFlow(specs[c], math=args.math) for c in range(c0, c1)]
     mix = native.NativeMixture(flows)
     info = flows[0].info()
     x = torch.from_numpy(x_np).to(dev)
     rho = torch.from_numpy(rho_np).to(dev)
 
-    nbuf = 2
+    # N = 1: one stream, the flow kernel fills the chip.  N > 1: every rank holds C/N components, so one
+    # batch occupies only a fraction of its GPU and the exchange is latency-bound: consecutive batches are
+    # independent, so they are pipelined over a few streams (kernel of batch i+1 under the all-gather of i).
+    nstream = args.streams if args.streams > 0 else (1 if world == 1 else 4)
+    nbuf = max(2, nstream)
     ll_local = [torch.empty((c1 - c0, B), dtype=torch.float32, device=dev) for _ in range(nbuf)]
     ll_full = [torch.empty((C, B), dtype=torch.float32, device=dev) for _ in range(nbuf)]
     G = [torch.empty(B, dtype=torch.float32, device=dev) for _ in range(nbuf)]
     ev0 = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
     ev1 = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
+    streams = [torch.cuda.current_stream()] if nstream == 1 else [torch.cuda.Stream() for _ in range(nstream)]
 
     def run(n_steps, timed):
-        pending = None
         for i in range(n_steps):
             b = i % nbuf
-            if timed:
-                ev0[i].record()
-            mix.component_log_prob(x, out=ll_local[b])
-            if timed:
-                ev1[i].record()
-            if world == 1:
-                native.mixture_lse(ll_local[b], rho, out=G[b])
-            else:
-                # all-gather of step i stays in flight under the flow kernel of step i+1
-                work = dist.all_gather_into_tensor(ll_full[b], ll_local[b], async_op=True)
-                if pending is not None:
-                    pb, pw = pending
-                    pw.wait()
-                    native.mixture_lse(ll_full[pb], rho, out=G[pb])
-                pending = (b, work)
-        if pending is not None:
-            pb, pw = pending
-            pw.wait()
-            native.mixture_lse(ll_full[pb], rho, out=G[pb])
+            with torch.cuda.stream(streams[i % nstream]):
+                if timed:
+                    ev0[i].record()
+                mix.component_log_prob(x, out=ll_local[b])
+                if timed:
+                    ev1[i].record()
+                if world == 1:
+                    native.mixture_lse(ll_local[b], rho, out=G[b])
+                else:
+                    # RCCL orders the gathers on its own stream; this stream only waits for ITS gather
+                    dist.all_gather_into_tensor(ll_full[b], ll_local[b])
+                    native.mixture_lse(ll_full[b], rho, out=G[b])
 
     def barrier():
+        torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
@@ -183,8 +187,12 @@ def main():
 
     if rank == 0:
         value = B * args.steps / elapsed
+        f16x3 = info.math_mode == native.MATH["f16x3"]
         flops_per_launch = 2.0 * info.macs_per_sample * (c1 - c0) * B
         achieved_tf = flops_per_launch / (kern_ms * 1e-3) / 1e12
+        # what the matrix pipe executes: tile padding, and 3 f16 products per f32 product on the split path
+        executed_tf = achieved_tf * info.padded_macs_per_sample / info.macs_per_sample * (3.0 if f16x3 else 1.0)
+        peak = F16_MFMA_PEAK_TFLOPS if f16x3 else F32_MFMA_PEAK_TFLOPS
         alg_bytes = (4.0 * d + 4.0 * (c1 - c0)) * B          # read x once, write ll per component
         out = {
             "metric": "density-eval samples/sec, Boosted-Glow C=8 MINIBOONE d=43" if args.config == "miniboone_glow"
@@ -194,16 +202,22 @@ def main():
             "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"{args.config}: d={d} h={h} K={K} C={C} batch={B}, x ~ N(0,1), synthetic weights",
                        "global_batch": B, "components": C,
+                       "math": "f16x3: f32 operands split into two fp16 pieces, 3 f16 MFMAs per product, f32 accumulate"
+                               if f16x3 else "f32: exact f32-input MFMA",
                        "parallelism": "single GPU, all components in one launch" if world == 1
-                       else f"components sharded {C // world}/GPU + RCCL all-gather of ll"},
+                       else f"components sharded {C // world}/GPU + RCCL all-gather of ll, {nstream} streams"},
             "roofline": {
-                "kernel": "gbnf::flow_kernel (fused K-step flow + coupling nets + log-det + base density)",
-                "bound": "mfma", "achieved": achieved_tf, "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                "frac": achieved_tf / F32_MFMA_PEAK_TFLOPS, "traffic": None,
+                "kernel": "gbnf::flow_kernel_hx3" if f16x3 else "gbnf::flow_kernel",
+                "bound": "mfma", "achieved": achieved_tf, "peak": peak, "unit": "TFLOP/s",
+                "frac": achieved_tf / peak, "traffic": None,
                 "launch_ms": kern_ms, "flops_per_launch": flops_per_launch,
-                "padded_mfma_frac": achieved_tf / F32_MFMA_PEAK_TFLOPS * info.padded_macs_per_sample / info.macs_per_sample,
+                "executed_mfma_tflops": executed_tf, "executed_frac": executed_tf / peak,
+                "vs_f32_mfma_peak": achieved_tf / F32_MFMA_PEAK_TFLOPS,
                 "hbm_algorithmic_GBs": alg_bytes / (kern_ms * 1e-3) / 1e9,
                 "hbm_frac": alg_bytes / (kern_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                "note": "achieved = ALGORITHMIC f32 flops / launch time; the split path runs 3x (+padding) that on "
+                        "the f16 pipe. The binding limit is instruction issue: VALU (tanh, hi/mid split) and MFMA "
+                        "serialise on a SIMD (tools/ubench), see DESIGN.md section 4",
             },
         }
         if args.cpu_seconds > 0 and world == 1:
