@@ -16,9 +16,11 @@ Additions named in BASELINE.json / SURVEY.md section 8(b): ``component_forward``
 ``component_log_prob``, ``log_prob`` and the permutation side-car (``permutation_state`` /
 ``load_permutation_state``) that fixes the reference's loss of ``PermuteNd.indices`` on checkpointing.
 
+ActNorm's data-dependent initialisation (train mode, first batch: models/layers.py:473-486) is reproduced with
+the statistics kernel ``gbnf_actnorm_init``.
+
 Out of scope here: backward pass / training, sampling (the reference's
-``decode`` is dead code: models/boosted_flow.py:216 passes a misspelt kwarg), ActNorm data-dependent
-initialisation, image inputs.
+``decode`` is dead code: models/boosted_flow.py:216 passes a misspelt kwarg), image inputs.
 """
 from __future__ import annotations
 
@@ -378,12 +380,32 @@ class BoostedFlow(nn.Module):
             raise RuntimeError(
                 "the HIP path is forward/density-evaluation only (no backward: SURVEY.md section 8f N3); call "
                 ".eval() or wrap the call in torch.no_grad()")
-        if self.component_type == "glow":
-            for flow in self.flows:
-                for layer in flow.flow.layers:
-                    if not layer.actnorm.inited:
-                        # the reference raises the same way in eval mode (models/layers.py:473-475)
-                        raise ValueError("In Eval mode, but ActNorm not initiated")
+
+    def _ensure_actnorm(self, x, c):
+        """_ActNorm.forward initialises itself from the first batch it sees in TRAIN mode and raises in eval mode
+        (models/layers.py:473-486, 524-525).  Here: layer k of component c is initialised from the output of the
+        first k (already initialised) steps, computed by the HIP path, with the statistics kernel
+        gbnf_actnorm_init."""
+        if self.component_type != "glow":
+            return
+        layers = self.flows[c].flow.layers
+        if all(bool(l.actnorm.inited) for l in layers):
+            return
+        if not self.training:
+            raise ValueError("In Eval mode, but ActNorm not initiated")
+        with torch.no_grad(), torch.cuda.device(x.device):
+            for k, layer in enumerate(layers):
+                if layer.actnorm.inited:
+                    continue
+                if k == 0:
+                    zk = x
+                else:
+                    head = gspec.spec_from_glow_module(self.flows[c], upto=k)
+                    zk, _, _ = native.NativeFlow(head).forward(x, want_ldj=False)
+                bias, logs = native.actnorm_init(zk.contiguous(), layer.actnorm.scale)
+                layer.actnorm.bias.copy_(bias.view(1, -1))
+                layer.actnorm.logs.copy_(logs.view(1, -1))
+                layer.actnorm.inited = True
 
     def native_flow(self, c):
         key = self._component_key(c)
@@ -406,6 +428,7 @@ class BoostedFlow(nn.Module):
         """x (N,d) -> z (N,d), ldj (N,) of component c  ==  self.flows[c](x)[0], [3] of the reference."""
         self._check_ready(x)
         x = x.contiguous().float()
+        self._ensure_actnorm(x, int(c))
         with torch.cuda.device(x.device):
             z, ldj, _ = self.native_flow(int(c)).forward(x)
         return z, ldj
@@ -416,6 +439,8 @@ class BoostedFlow(nn.Module):
         self._check_ready(x)
         n_used = self._n_used(n_used)
         x = x.contiguous().float()
+        for c in range(self.num_components):
+            self._ensure_actnorm(x, c)
         with torch.cuda.device(x.device):
             ll = self.native_mixture().component_log_prob(x, 0, n_used)
         return ll.t()
@@ -427,6 +452,8 @@ class BoostedFlow(nn.Module):
         self._check_ready(x)
         n_used = self._n_used(n_used)
         x = x.contiguous().float()
+        for c in range(self.num_components):
+            self._ensure_actnorm(x, c)
         with torch.cuda.device(x.device):
             G, _ = self.native_mixture().log_prob(x, self.rho.contiguous().float(), n_used=n_used)
         return G

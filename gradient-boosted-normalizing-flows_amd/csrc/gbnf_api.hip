@@ -676,6 +676,54 @@ __global__ void __launch_bounds__(256) mixture_lse_kernel(const float* __restric
 
 }  // namespace gbnf
 
+// ---- ActNorm data-dependent initialisation (models/layers.py:473-486): per-feature statistics of a batch.
+//   bias = -mean_0(z);  var = mean_0((z + bias)^2);  logs = log(scale / (sqrt(var) + 1e-6))
+// HBM-bound column reduction, two passes like the reference (centred second moment).  A wave reads one row
+// segment (d <= 64 consecutive floats) per load; the 4 waves of a block take rows r, r+1, r+2, r+3; block
+// partials go to a workspace and are combined in a fixed order (bit-reproducible, no atomics).
+constexpr int AN_MAX_BLOCKS = 256;
+
+__global__ void __launch_bounds__(256) actnorm_partial_kernel(const float* __restrict__ z, int64_t n, int d,
+                                                              const float* __restrict__ prev_partial, int pass,
+                                                              float* __restrict__ partial) {
+  __shared__ float red[4][64];
+  const int c = threadIdx.x & 63, w = threadIdx.x >> 6;
+  float shift = 0.0f;
+  if (pass == 2 && c < d) {            // bias = -mean from the first pass's partials (fixed order)
+    float s = 0.0f;
+    for (int b = 0; b < (int)gridDim.x; ++b) s += prev_partial[b * 64 + c];
+    shift = -(s / (float)n);
+  }
+  float acc = 0.0f;
+  if (c < d) {
+    for (int64_t r = (int64_t)blockIdx.x * 4 + w; r < n; r += (int64_t)gridDim.x * 4) {
+      const float v = z[r * d + c] + shift;
+      acc += (pass == 2) ? v * v : v;
+    }
+  }
+  red[w][c] = acc;
+  __syncthreads();
+  if (w == 0) partial[blockIdx.x * 64 + c] = (red[0][c] + red[1][c]) + (red[2][c] + red[3][c]);
+}
+
+__global__ void __launch_bounds__(64) actnorm_finalize_kernel(const float* __restrict__ p1, const float* __restrict__ p2,
+                                                              int nb, int64_t n, int d, float scale,
+                                                              float* __restrict__ bias, float* __restrict__ logs) {
+  const int c = threadIdx.x;
+  if (c >= d) return;
+  float s1 = 0.0f, s2 = 0.0f;
+  for (int b = 0; b < nb; ++b) {
+    s1 += p1[b * 64 + c];
+    s2 += p2[b * 64 + c];
+  }
+  const float mean = s1 / (float)n, var = s2 / (float)n;
+  bias[c] = -mean;
+  logs[c] = logf(scale / (sqrtf(var) + 1e-6f));
+}
+
+static float* g_actnorm_ws = nullptr;   // 2 x AN_MAX_BLOCKS x 64 floats, allocated on first use, never freed
+static std::mutex g_actnorm_mu;
+
 #ifdef GBNF_STAMPS
 // diagnostic builds only (not part of include/gbnf.h): device buffer of 8 u64 per block
 extern "C" int gbnf_debug_set_stamp_buffer(void* dev) { gbnf::g_stamp_buf = (unsigned long long*)dev; return 0; }
@@ -778,6 +826,29 @@ int gbnf_mixture_log_prob(const gbnf_mixture* mix, const float* x, int64_t n, in
   int rc = gbnf_mixture_component_log_prob(mix, x, n, 0, n_used, ll_workspace, stream);
   if (rc) return rc;
   return gbnf_mixture_lse(ll_workspace, n, rho_dev, n_used, n, out, stream);
+}
+
+int gbnf_actnorm_init(const float* z, int64_t n, int32_t d, float scale, float* bias_out, float* logs_out,
+                      void* stream) {
+  if (!z || !bias_out || !logs_out) return fail(GBNF_ERR_INVALID, "gbnf_actnorm_init: null pointer");
+  if (n < 1) return fail(GBNF_ERR_INVALID, "gbnf_actnorm_init: needs at least one row");
+  if (d < 1 || d > ZSLOTS) return fail(GBNF_ERR_UNSUPPORTED, "gbnf_actnorm_init: d=%d outside [1,%d]", d, ZSLOTS);
+  {
+    std::lock_guard<std::mutex> lk(g_actnorm_mu);
+    if (!g_actnorm_ws) GBNF_HIP(hipMalloc((void**)&g_actnorm_ws, sizeof(float) * 2 * AN_MAX_BLOCKS * 64));
+  }
+  int nb = (int)((n + 63) / 64);
+  if (nb > AN_MAX_BLOCKS) nb = AN_MAX_BLOCKS;
+  float* p1 = g_actnorm_ws;
+  float* p2 = g_actnorm_ws + AN_MAX_BLOCKS * 64;
+  hipStream_t s = (hipStream_t)stream;
+  hipLaunchKernelGGL(actnorm_partial_kernel, dim3(nb), dim3(256), 0, s, z, n, d, (const float*)nullptr, 1, p1);
+  hipLaunchKernelGGL(actnorm_partial_kernel, dim3(nb), dim3(256), 0, s, z, n, d, (const float*)p1, 2, p2);
+  hipLaunchKernelGGL(actnorm_finalize_kernel, dim3(1), dim3(64), 0, s, (const float*)p1, (const float*)p2, nb, n, d,
+                     scale, bias_out, logs_out);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return fail(GBNF_ERR_HIP, "gbnf_actnorm_init launch failed: %s", hipGetErrorString(e));
+  return GBNF_OK;
 }
 
 }  // extern "C"

@@ -26,6 +26,7 @@ ABI_SYMBOLS = (
     "gbnf_flow_create", "gbnf_flow_create_mode", "gbnf_flow_destroy", "gbnf_flow_info", "gbnf_flow_forward",
     "gbnf_mixture_create", "gbnf_mixture_destroy", "gbnf_mixture_set_base",
     "gbnf_mixture_component_log_prob", "gbnf_mixture_lse", "gbnf_mixture_log_prob",
+    "gbnf_actnorm_init",
 )
 
 
@@ -93,6 +94,7 @@ def lib():
     L.gbnf_mixture_component_log_prob.argtypes = [vp, vp, i64, i32, i32, vp, vp]
     L.gbnf_mixture_lse.argtypes = [vp, i64, vp, i32, i64, vp, vp]
     L.gbnf_mixture_log_prob.argtypes = [vp, vp, i64, i32, vp, vp, vp, vp]
+    L.gbnf_actnorm_init.argtypes = [vp, i64, i32, C.c_float, vp, vp, vp]
     for name in ABI_SYMBOLS:
         if name not in ("gbnf_version", "gbnf_last_error"):
             getattr(L, name).restype = C.c_int
@@ -316,3 +318,17 @@ def mixture_lse(ll, rho, out=None):
     _check(lib().gbnf_mixture_lse(C.c_void_p(ll.data_ptr() if n else 0), n, C.c_void_p(rho.data_ptr()), c, n,
                                   C.c_void_p(out.data_ptr() if n else 0), _stream_ptr()))
     return out
+
+
+def actnorm_init(z, scale=1.0):
+    """ActNorm data-dependent initialisation statistics of a device batch z (n,d) -> (bias (d,), logs (d,))."""
+    import torch
+    _require_device_f32(z, "z")
+    if z.dim() != 2 or z.shape[0] < 1:
+        raise GbnfError("z must be (n,d) with n >= 1")
+    n, d = z.shape
+    bias = torch.empty(d, dtype=torch.float32, device=z.device)
+    logs = torch.empty(d, dtype=torch.float32, device=z.device)
+    _check(lib().gbnf_actnorm_init(C.c_void_p(z.data_ptr()), n, d, float(scale), C.c_void_p(bias.data_ptr()),
+                                   C.c_void_p(logs.data_ptr()), _stream_ptr()))
+    return bias, logs

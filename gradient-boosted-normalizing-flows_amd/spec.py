@@ -51,7 +51,7 @@ def _mixed_act_error():
     raise NotImplementedError("coupling network mixes activations inside one net")
 
 
-def spec_from_glow_module(glow, coupling=None):
+def spec_from_glow_module(glow, coupling=None, upto=None):
     """Export a tabular Glow component (this package's or the reference's module).
 
     Permutation indices are read from the LIVE module because the reference keeps
@@ -59,7 +59,9 @@ def spec_from_glow_module(glow, coupling=None):
     """
     steps = []
     d = None
-    for layer in glow.flow.layers:
+    for k, layer in enumerate(glow.flow.layers):
+        if upto is not None and k >= upto:
+            break
         an = layer.actnorm
         if not bool(an.inited):
             raise ValueError("ActNorm not initialised (models/layers.py:473-475 raises in eval mode too)")

@@ -162,6 +162,14 @@ int gbnf_mixture_lse(const float* ll, int64_t ll_row_stride, const float* rho_de
 int gbnf_mixture_log_prob(const gbnf_mixture* mix, const float* x, int64_t n, int32_t n_used,
                           const float* rho_dev, float* ll_workspace, float* out, void* stream);
 
+/* Replaces: _ActNorm.initialize_parameters (models/layers.py:473-486), the data-dependent initialisation the
+ * reference runs on the first training batches (density_experiment.py:346-356):
+ *   bias = -mean_0(z);  logs = log(scale / (sqrt(mean_0((z + bias)^2)) + 1e-6)).
+ * z is the (n,d) DEVICE input of the ActNorm layer (the output of the preceding flow steps); bias_out / logs_out
+ * are (d,) DEVICE buffers.  The first call allocates a small internal workspace. */
+int gbnf_actnorm_init(const float* z, int64_t n, int32_t d, float scale, float* bias_out, float* logs_out,
+                      void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -298,6 +298,28 @@ def mixture_log_prob(specs, rho, x, n_used=None, backend="torch", base=None):
     return ll, mixture_recursion(ll, rho, backend)
 
 
+def actnorm_data_init(spec, x, scale=1.0, backend="torch"):
+    """ActNorm data-dependent initialisation of every step of a Glow component, the way the reference does it
+    when the un-initialised model sees its first batch in train mode (_ActNorm.initialize_parameters,
+    models/layers.py:473-486, reached through FlowStep.encode models/glow.py:320-321):
+        bias = -mean_0(z_k);  logs = log(scale / (sqrt(mean_0((z_k + bias)^2)) + 1e-6))
+    where z_k is the output of the first k (already initialised) steps.  Returns a NEW spec (an_bias / an_logs
+    replaced) and leaves the input untouched."""
+    import copy
+    ops = _ops(backend)
+    out = copy.deepcopy(spec)
+    z = ops.arr(x)
+    ld = ops.zeros(z.shape[0])
+    for st in out["steps"]:
+        bias = -z.mean(0)
+        var = ((z + bias) * (z + bias)).mean(0)
+        logs = ops.log(scale / (ops.sqrt(var) + 1e-6))
+        st["an_bias"] = ops.to_numpy(bias).astype(np.float32)
+        st["an_logs"] = ops.to_numpy(logs).astype(np.float32)
+        z, ld = glow_step(ops, out, st, z, ld)
+    return out
+
+
 def rho_init(num_components, kind="decreasing"):
     """BoostedFlow.__init__ rho buffer: models/boosted_flow.py:32-39."""
     if kind == "decreasing":

@@ -18,7 +18,18 @@ def pytest_configure(config):
 
 
 def golden_names():
-    return sorted(os.path.splitext(os.path.basename(p))[0] for p in glob.glob(os.path.join(GOLDEN_DIR, "*.npz")))
+    """Forward/mixture fixtures (g1..g6).  g7 (ActNorm data-dependent init) has its own tests."""
+    names = sorted(os.path.splitext(os.path.basename(p))[0] for p in glob.glob(os.path.join(GOLDEN_DIR, "*.npz")))
+    return [n for n in names if not n.startswith("g7_")]
+
+
+def load_actnorm_init_case():
+    from gbnf_amd import synth
+    data = dict(np.load(os.path.join(GOLDEN_DIR, "g7_glow_actnorm_data_init.npz")))
+    cfg = json.loads(bytes(data["config"]).decode())
+    specs = synth.synth_boosted_specs("glow", cfg["C"], cfg["d"], cfg["h"], cfg["K"], seed=cfg["w_seed"])
+    x = synth.synth_batch(cfg["N"], cfg["d"], seed=cfg["x_seed"], scale=cfg["x_scale"]) + np.float32(cfg["x_shift"])
+    return cfg, data, specs, x.astype(np.float32)
 
 
 class GoldenCase:

@@ -239,12 +239,46 @@ def state_dict_layout_case():
     print("state_dict_layout.json:", {k: len(v) for k, v in out.items()})
 
 
+def actnorm_init_case(name, d=43, h=64, K=4, C=2, N=300):
+    """G7: ActNorm data-dependent initialisation by the reference itself: synthetic Linear weights and
+    permutations installed, ActNorm left un-initialised, one train-mode forward per component under no_grad
+    (density_experiment.py:346-356).  Stores the resulting bias/logs of every layer + the eval outputs."""
+    torch.manual_seed(5)
+    model = RefBoostedFlow(ref_args("glow", d, h, K, C))
+    specs = synth.synth_boosted_specs("glow", C, d, h, K, seed=21)
+    for c in range(C):
+        install_spec(model.flows[c], specs[c])
+        for layer in model.flows[c].flow.layers:
+            layer.actnorm.inited = False
+            layer.actnorm.bias.data.zero_()
+            layer.actnorm.logs.data.zero_()
+    x = synth.synth_batch(N, d, seed=13, scale=1.7) + 0.4
+    model.train()
+    with torch.no_grad():
+        for c in range(C):
+            model(x=torch.from_numpy(x).clone(), components=c)
+    bias = np.stack([np.stack([l.actnorm.bias.detach().numpy().reshape(-1) for l in f.flow.layers]) for f in model.flows])
+    logs = np.stack([np.stack([l.actnorm.logs.detach().numpy().reshape(-1) for l in f.flow.layers]) for f in model.flows])
+    assert all(l.actnorm.inited for f in model.flows for l in f.flow.layers)
+    z, ldj, ll, G = run_reference(model, x, C)
+    cfg = dict(case="actnorm_init", kind="glow", d=d, h=h, K=K, C=C, N=N, w_seed=21, x_seed=13, x_scale=1.7, x_shift=0.4,
+               synth_kw=dict())
+    np.savez_compressed(os.path.join(HERE, name + ".npz"),
+                        config=np.frombuffer(json.dumps(cfg).encode(), dtype=np.uint8),
+                        rho=model.rho.numpy().copy(), an_bias=bias, an_logs=logs, ldj=ldj, ll=ll, G=G)
+    print(f"{name}: logs[0,0,:3]={logs[0, 0, :3]} ll[0,:3]={ll[0, :3]}")
+
+
 def main():
     torch.set_num_threads(4)
+    if "--actnorm-only" in sys.argv:
+        actnorm_init_case("g7_glow_actnorm_data_init")
+        return
     if "--layout-only" in sys.argv:
         state_dict_layout_case()
         return
     state_dict_layout_case()
+    actnorm_init_case("g7_glow_actnorm_data_init")
     toy_case("g1_toy_realnvp_c2")
     native_glow_case("g2_glow_native_d43_h32_c3")
     # G3: MINIBOONE full width (BASELINE.json metric config), synthetic weights

@@ -141,3 +141,47 @@ def test_sharded_single_rank_equals_mixture(golden_case):
     outs = sm.log_prob_pipelined([x, x], rho)
     assert all(torch.equal(o, G2) for o in outs)
     assert rel_err(G.cpu().numpy(), g.G) < LL_RTOL
+
+
+def test_actnorm_data_dependent_init_matches_reference():
+    """G7: un-initialised model, train mode, first batch under no_grad -- as
+    density_experiment.py:346-356 drives the reference -- must reproduce the reference's ActNorm parameters."""
+    import torch
+    from conftest import load_actnorm_init_case
+    from gbnf_amd import BoostedFlow, native
+    dev = torch.device("cuda:0")
+    cfg, data, specs, x = load_actnorm_init_case()
+    m = BoostedFlow(_args(cfg, dev))
+    for c, spec in enumerate(specs):
+        m.load_spec(c, spec)
+        for layer in m.flows[c].flow.layers:
+            layer.actnorm.inited = False
+            with torch.no_grad():
+                layer.actnorm.bias.zero_()
+                layer.actnorm.logs.zero_()
+    xd = torch.from_numpy(x).to(dev)
+    m.eval()
+    with pytest.raises(ValueError):                 # eval mode + un-initialised: the reference raises too
+        m(x=xd, components=0)
+    m.train()
+    with torch.no_grad():
+        for c in range(cfg["C"]):
+            m(x=xd, components=c)
+    for c in range(cfg["C"]):
+        for k, layer in enumerate(m.flows[c].flow.layers):
+            assert layer.actnorm.inited
+            np.testing.assert_allclose(layer.actnorm.bias.detach().cpu().numpy().reshape(-1), data["an_bias"][c, k],
+                                       rtol=0, atol=5e-6)
+            np.testing.assert_allclose(layer.actnorm.logs.detach().cpu().numpy().reshape(-1), data["an_logs"][c, k],
+                                       rtol=0, atol=5e-6)
+    m.eval()
+    m.component = cfg["C"] - 1
+    assert rel_err(m.log_prob(xd).cpu().numpy(), data["G"]) < LL_RTOL
+    # the statistics kernel on its own, incl. a single row and many blocks
+    big = torch.randn(70000, 21, device=dev) * 3 + 1
+    b, l = native.actnorm_init(big, 1.0)
+    np.testing.assert_allclose(b.cpu().numpy(), -big.mean(0).cpu().numpy(), rtol=0, atol=2e-5)
+    ref_logs = torch.log(1.0 / (torch.sqrt(((big - big.mean(0)) ** 2).mean(0)) + 1e-6)).cpu().numpy()
+    np.testing.assert_allclose(l.cpu().numpy(), ref_logs, rtol=0, atol=2e-5)
+    b2, l2 = native.actnorm_init(big, 1.0)
+    assert torch.equal(b, b2) and torch.equal(l, l2)      # fixed-order reduction: bit-reproducible

@@ -165,6 +165,24 @@ def test_default_math_mode_and_mode_agreement(dev):
     np.testing.assert_allclose(b[0].cpu().numpy(), a[0].cpu().numpy(), rtol=0, atol=1e-5)
 
 
+@pytest.mark.parametrize("math", ["f32", "f16x3"])
+@pytest.mark.parametrize("kind,d,h,K", [("glow", 43, 64, 13), ("realnvp", 21, 64, 14), ("glow", 6, 30, 1)])
+def test_many_and_few_steps_against_oracle(kind, d, h, K, math, dev):
+    """K > 12 takes the per-step tables from global memory instead of LDS; K = 1 is the minimum."""
+    import torch
+    from gbnf_amd import native, synth
+    from oracle import gbnf_oracle as oracle
+    spec = (synth.synth_glow_spec(d, h, K, seed=7) if kind == "glow"
+            else synth.synth_realnvp_spec(d, h, K, flip_init=1, seed=7))
+    x = synth.synth_batch(300, d, seed=8)
+    z, ldj, ll = native.NativeFlow(spec, math=math).forward(torch.from_numpy(x).to(dev), want_ll=True)
+    zr, lr = oracle.component_forward(spec, x)
+    llr = oracle.component_log_prob(spec, x)
+    assert rel_err(ll.cpu().numpy(), llr) < LL_RTOL
+    assert rel_err(ldj.cpu().numpy(), lr) < LL_RTOL
+    np.testing.assert_allclose(z.cpu().numpy(), zr, rtol=0, atol=2e-5 * max(1.0, np.abs(zr).max()))
+
+
 def test_empty_batch_and_errors(dev):
     import torch
     from gbnf_amd import native, synth

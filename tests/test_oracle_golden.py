@@ -2,7 +2,7 @@
 import numpy as np
 import pytest
 
-from conftest import golden_names, rel_err
+from conftest import golden_names, load_actnorm_init_case, rel_err
 from oracle import gbnf_oracle as oracle
 
 LL_RTOL = 1e-5     # BASELINE.json: log-likelihood within 1e-5 relative
@@ -60,3 +60,15 @@ def test_rho_init_and_permutations():
     np.testing.assert_array_equal(idx, [4, 3, 2, 1, 0])
     inv = oracle.permute_inverse(np.array([2, 0, 3, 1]))
     np.testing.assert_array_equal(inv, [1, 3, 0, 2])
+
+
+def test_actnorm_data_init_matches_reference():
+    """G7: the oracle's restatement of ActNorm's data-dependent init against the reference's own."""
+    cfg, data, specs, x = load_actnorm_init_case()
+    inited = [oracle.actnorm_data_init(s, x) for s in specs]
+    for c, spec in enumerate(inited):
+        for k, st in enumerate(spec["steps"]):
+            np.testing.assert_allclose(st["an_bias"], data["an_bias"][c, k], rtol=0, atol=2e-6)
+            np.testing.assert_allclose(st["an_logs"], data["an_logs"][c, k], rtol=0, atol=2e-6)
+    ll, G = oracle.mixture_log_prob(inited, data["rho"], x)
+    assert rel_err(ll, data["ll"]) < 5e-6 and rel_err(G, data["G"]) < 5e-6
