@@ -19,6 +19,7 @@ Prints ONE JSON line on rank 0 (see the driver contract), including
   "cpu_baseline": the torch-CPU oracle ("port" of the reference path) timed on this box's cores.
 """
 import argparse
+import ctypes
 import json
 import os
 import sys
@@ -98,9 +99,10 @@ def main():
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the CPU baseline leg (0 = skip)")
     ap.add_argument("--math", default="default", choices=["default", "f32", "f16x3"],
                     help="matrix path: exact-f32 MFMA or split-f16 (3 f16 MFMAs per f32 product)")
-    ap.add_argument("--streams", type=int, default=0,
-                    help="HIP streams over which consecutive (independent) batches are pipelined "
-                         "(0 = auto: 1 on a single GPU, 4 when components are sharded)")
+    ap.add_argument("--force-gather", action="store_true",
+                    help="testing aid: run the RCCL all-gather leg even with one rank")
+    ap.add_argument("--group", type=int, default=0,
+                    help="batches served per launch / per all-gather (0 = auto: 4 on one GPU, 8 when sharded; max 8)")
     args = ap.parse_args()
 
     import numpy as np
@@ -137,33 +139,72 @@ def main():
     x = torch.from_numpy(x_np).to(dev)
     rho = torch.from_numpy(rho_np).to(dev)
 
-    # N = 1: one stream, the flow kernel fills the chip.  N > 1: every rank holds C/N components, so one
-    # batch occupies only a fraction of its GPU and the exchange is latency-bound: consecutive batches are
-    # independent, so they are pipelined over a few streams (kernel of batch i+1 under the all-gather of i).
-    nstream = args.streams if args.streams > 0 else (1 if world == 1 else 4)
-    nbuf = max(2, nstream)
-    ll_local = [torch.empty((c1 - c0, B), dtype=torch.float32, device=dev) for _ in range(nbuf)]
-    ll_full = [torch.empty((C, B), dtype=torch.float32, device=dev) for _ in range(nbuf)]
-    G = [torch.empty(B, dtype=torch.float32, device=dev) for _ in range(nbuf)]
-    ev0 = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
-    ev1 = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
-    streams = [torch.cuda.current_stream()] if nstream == 1 else [torch.cuda.Stream() for _ in range(nstream)]
+    # ---- pipeline.  Consecutive steps (batches) are independent, so they are served in GROUPS of S: one flow
+    # launch covers the S batches of a group (for a rank holding C/N components a single batch fills only 1/N
+    # of its GPU), ONE RCCL all-gather rebuilds the (C, S*B) table of the group and ONE recursion launch
+    # finishes it -- "bigger, fewer collectives".  The flow kernels run on one stream, gather + recursion on a
+    # second one, double-buffered, so the exchange of group g overlaps the kernel of group g+1.
+    gather = world > 1 or args.force_gather
+    S = args.group if args.group > 0 else (4 if world == 1 else 8)
+    S = max(1, min(S, 8, args.steps))
+    xs_np = [x_np] + [synth.synth_batch(B, d, seed=100 + s) for s in range(1, S)]   # S distinct resident batches
+    xs = [x] + [torch.from_numpy(a).to(dev) for a in xs_np[1:]]
+    NBUF = 2
+    main = torch.cuda.current_stream()
+    post = torch.cuda.Stream() if gather else main
+    mptr, pptr = ctypes.c_void_p(main.cuda_stream), ctypes.c_void_p(post.cuda_stream)
+    flow_done = [torch.cuda.Event() for _ in range(NBUF)]
+    post_done = [torch.cuda.Event() for _ in range(NBUF)]
+
+    class Group:
+        """Buffers + pre-bound launches for groups of `size` batches (double-buffered).  Every argument is bound
+        once: per group the host does two ctypes calls (+ one RCCL call when sharded)."""
+
+        def __init__(self, size):
+            self.size = size
+            self.local = [torch.empty((c1 - c0, size * B), dtype=torch.float32, device=dev) for _ in range(NBUF)]
+            self.full = ([torch.empty((C, size * B), dtype=torch.float32, device=dev) for _ in range(NBUF)]
+                         if gather else self.local)
+            self.G = [torch.empty(size * B, dtype=torch.float32, device=dev) for _ in range(NBUF)]
+            self.flow = [mix.prepared_group_log_prob(xs[:size], self.local[q]) for q in range(NBUF)]
+            self.lse = [native.prepared_mixture_lse(self.full[q], rho, self.G[q]) for q in range(NBUF)]
+
+    groups = {S: Group(S)}
+    for t in {args.steps % S, args.warmup % S} - {0}:       # ragged last group of the timed / warm-up run
+        groups[t] = Group(t)
+    n_timed_groups = (args.steps + S - 1) // S
+    ev0 = [torch.cuda.Event(enable_timing=True) for _ in range(n_timed_groups)]
+    ev1 = [torch.cuda.Event(enable_timing=True) for _ in range(n_timed_groups)]
+    if gather and not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
 
     def run(n_steps, timed):
-        for i in range(n_steps):
-            b = i % nbuf
-            with torch.cuda.stream(streams[i % nstream]):
-                if timed:
-                    ev0[i].record()
-                mix.component_log_prob(x, out=ll_local[b])
-                if timed:
-                    ev1[i].record()
-                if world == 1:
-                    native.mixture_lse(ll_local[b], rho, out=G[b])
-                else:
-                    # RCCL orders the gathers on its own stream; this stream only waits for ITS gather
-                    dist.all_gather_into_tensor(ll_full[b], ll_local[b])
-                    native.mixture_lse(ll_full[b], rho, out=G[b])
+        """n_steps batches in ceil(n_steps / S) groups; every batch gets its flow pass, exchange and recursion."""
+        gi = 0
+        done = 0
+        while done < n_steps:
+            q = gi % NBUF
+            grp = groups[min(S, n_steps - done)]
+            if gather and gi >= NBUF:
+                main.wait_event(post_done[q])          # group gi-2 has released this buffer pair
+            if timed:
+                ev0[gi].record(main)
+            grp.flow[q](mptr)
+            if timed:
+                ev1[gi].record(main)
+            if gather:
+                flow_done[q].record(main)
+                post.wait_event(flow_done[q])
+                with torch.cuda.stream(post):
+                    dist.all_gather_into_tensor(grp.full[q], grp.local[q])
+                grp.lse[q](pptr)
+                post_done[q].record(post)
+            else:
+                grp.lse[q](mptr)
+            done += grp.size
+            gi += 1
 
     def barrier():
         torch.cuda.synchronize()
@@ -182,18 +223,19 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
-    kern_ms = sum(a.elapsed_time(b) for a, b in zip(ev0, ev1)) / args.steps
-    G_gpu = G[(args.steps - 1) % nbuf].cpu().numpy()
+    full_groups = args.steps // S
+    kern_ms = sum(ev0[i].elapsed_time(ev1[i]) for i in range(full_groups)) / max(1, full_groups)   # per GROUP launch
+    G_gpu = groups[S].G[(full_groups - 1) % NBUF][:B].cpu().numpy()      # batch 0 of the last full group
 
     if rank == 0:
         value = B * args.steps / elapsed
         f16x3 = info.math_mode == native.MATH["f16x3"]
-        flops_per_launch = 2.0 * info.macs_per_sample * (c1 - c0) * B
+        flops_per_launch = 2.0 * info.macs_per_sample * (c1 - c0) * B * S      # one launch serves S batches
         achieved_tf = flops_per_launch / (kern_ms * 1e-3) / 1e12
         # what the matrix pipe executes: tile padding, and 3 f16 products per f32 product on the split path
         executed_tf = achieved_tf * info.padded_macs_per_sample / info.macs_per_sample * (3.0 if f16x3 else 1.0)
         peak = F16_MFMA_PEAK_TFLOPS if f16x3 else F32_MFMA_PEAK_TFLOPS
-        alg_bytes = (4.0 * d + 4.0 * (c1 - c0)) * B          # read x once, write ll per component
+        alg_bytes = (4.0 * d + 4.0 * (c1 - c0)) * B * S      # read x once, write ll per component
         out = {
             "metric": "density-eval samples/sec, Boosted-Glow C=8 MINIBOONE d=43" if args.config == "miniboone_glow"
                       else f"density-eval samples/sec, {args.config}",
@@ -205,7 +247,8 @@ def main():
                        "math": "f16x3: f32 operands split into two fp16 pieces, 3 f16 MFMAs per product, f32 accumulate"
                                if f16x3 else "f32: exact f32-input MFMA",
                        "parallelism": "single GPU, all components in one launch" if world == 1
-                       else f"components sharded {C // world}/GPU + RCCL all-gather of ll, {nstream} streams"},
+                       else f"components sharded {C // world}/GPU + one RCCL all-gather of ll per group",
+                       "group": f"{S} batches per flow launch / all-gather / recursion launch"},
             "roofline": {
                 "kernel": "gbnf::flow_kernel_hx3" if f16x3 else "gbnf::flow_kernel",
                 "bound": "mfma", "achieved": achieved_tf, "peak": peak, "unit": "TFLOP/s",
@@ -230,7 +273,7 @@ def main():
             out["cpu_baseline"] = None     # reported on the N=1 run only
         print(json.dumps(out), flush=True)
 
-    if world > 1:
+    if dist.is_initialized():
         dist.destroy_process_group()
 
 

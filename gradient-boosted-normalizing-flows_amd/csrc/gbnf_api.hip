@@ -632,17 +632,21 @@ static unsigned long long* g_stamp_buf = nullptr;
 #endif
 
 static int launch_flow(const gbnf_flow* f, const uint32_t* const* table, int c_begin, int n_comp, const float* x,
-                       int64_t n, float* z, float* ldj, float* ll, const float* base, hipStream_t stream) {
-  if (n == 0 || n_comp == 0) return GBNF_OK;
-  const int nt = pick_nt(n, n_comp);
+                       int64_t n, float* z, float* ldj, float* ll, const float* base, hipStream_t stream,
+                       int64_t out_stride = -1, const float* const* xs = nullptr, int n_batches = 1) {
+  if (n == 0 || n_comp == 0 || n_batches == 0) return GBNF_OK;
+  const int nt = pick_nt(n * n_batches, n_comp);
   const int64_t tiles = (n + 16 * nt - 1) / (16 * nt);
   // f32 kernel: one wave (= block) per tile; f16x3 kernel: one 4-wave block per group of 4 tiles
-  const int64_t grid = (f->math_mode == GBNF_MATH_F16X3 ? (tiles + HX3_WAVES - 1) / HX3_WAVES : tiles) * n_comp;
+  const int64_t grid =
+      (f->math_mode == GBNF_MATH_F16X3 ? (tiles + HX3_WAVES - 1) / HX3_WAVES : tiles) * n_comp * n_batches;
   if (grid > 0x7fffffffLL) return fail(GBNF_ERR_UNSUPPORTED, "batch too large for one launch (%lld tiles)", (long long)grid);
   FlowLaunch p{};
-  p.blobs = table; p.x = x; p.z_out = z; p.ldj_out = ldj; p.ll_out = ll;
+  p.blobs = table; p.z_out = z; p.ldj_out = ldj; p.ll_out = ll;
+  p.n_batches = n_batches;
+  for (int b = 0; b < n_batches; ++b) p.xs[b] = xs ? xs[b] : x;
   p.base_mean = base; p.base_std = base ? base + f->d : nullptr;
-  p.n = n; p.d = f->d; p.n_steps = f->n_steps; p.c_begin = c_begin; p.n_comp = n_comp;
+  p.n = n; p.out_stride = out_stride < 0 ? n * n_batches : out_stride; p.d = f->d; p.n_steps = f->n_steps; p.c_begin = c_begin; p.n_comp = n_comp;
   p.n_tiles = (int32_t)tiles; p.additive = f->additive;
 #ifdef GBNF_STAMPS
   p.dbg = g_stamp_buf;
@@ -793,14 +797,34 @@ int gbnf_mixture_set_base(gbnf_mixture* mix, const float* mean, const float* std
 
 int gbnf_mixture_component_log_prob(const gbnf_mixture* mix, const float* x, int64_t n, int32_t c_begin,
                                     int32_t c_end, float* ll, void* stream) {
+  return gbnf_mixture_component_log_prob_strided(mix, x, n, c_begin, c_end, ll, n, stream);
+}
+
+int gbnf_mixture_component_log_prob_strided(const gbnf_mixture* mix, const float* x, int64_t n, int32_t c_begin,
+                                            int32_t c_end, float* ll, int64_t ll_row_stride, void* stream) {
+  const float* xs[1] = {x};
+  return gbnf_mixture_component_log_prob_multi(mix, xs, 1, n, c_begin, c_end, ll, ll_row_stride, stream);
+}
+
+int gbnf_mixture_component_log_prob_multi(const gbnf_mixture* mix, const float* const* xs, int32_t n_batches, int64_t n,
+                                          int32_t c_begin, int32_t c_end, float* ll, int64_t ll_row_stride,
+                                          void* stream) {
   if (!mix) return fail(GBNF_ERR_INVALID, "gbnf_mixture_component_log_prob: mix is null");
+  if (n_batches < 1 || n_batches > MAX_BATCHES)
+    return fail(GBNF_ERR_INVALID, "n_batches=%d outside [1,%d]", n_batches, MAX_BATCHES);
+  if (!xs) return fail(GBNF_ERR_INVALID, "xs is null");
+  if (ll_row_stride < n * n_batches)
+    return fail(GBNF_ERR_INVALID, "gbnf_mixture_component_log_prob: ll_row_stride < n_batches * n");
+  const float* x = xs[0];
+  for (int b = 0; b < n_batches; ++b)
+    if (n > 0 && !xs[b]) return fail(GBNF_ERR_INVALID, "xs[%d] is null", b);
   const int C = (int)mix->flows.size();
   if (c_begin < 0 || c_end > C || c_begin > c_end)
     return fail(GBNF_ERR_INVALID, "component range [%d,%d) outside [0,%d)", c_begin, c_end, C);
   if (n < 0) return fail(GBNF_ERR_INVALID, "n < 0");
   if (n > 0 && c_end > c_begin && (!x || !ll)) return fail(GBNF_ERR_INVALID, "x / ll is null");
   return launch_flow(mix->flows[0], mix->table_dev, c_begin, c_end - c_begin, x, n, nullptr, nullptr, ll,
-                     mix->base_dev, (hipStream_t)stream);
+                     mix->base_dev, (hipStream_t)stream, ll_row_stride, xs, n_batches);
 }
 
 int gbnf_mixture_lse(const float* ll, int64_t ll_row_stride, const float* rho_dev, int32_t n_components, int64_t n,

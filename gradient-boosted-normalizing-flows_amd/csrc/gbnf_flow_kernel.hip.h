@@ -67,21 +67,25 @@ struct NetLayoutRT {
         NET_WORDS(B3 + OT * 16) {}
 };
 
+constexpr int MAX_BATCHES = 8;   // batches one launch can serve
+
 struct FlowLaunch {
   const uint32_t* const* blobs;  // device array: packed parameter blob per component
-  const float* x;                // (n, d)
+  const float* xs[MAX_BATCHES];  // n_batches inputs of (n, d) each; log-densities of batch b go to columns [b*n, (b+1)*n)
   float* z_out;                  // (n_comp, n, d) or null
   float* ldj_out;                // (n_comp, n)    or null
   float* ll_out;                 // (n_comp, n)    or null
   const float* base_mean;        // (d,) or null  -> N(0,1)
   const float* base_std;         // (d,) or null
   int64_t n;
+  int64_t out_stride;              // floats between consecutive components' rows of ldj_out / ll_out (>= n)
   int32_t d;
   int32_t n_steps;
   int32_t c_begin;
   int32_t n_comp;
   int32_t n_tiles;               // ceil(n / (16*NT))
   int32_t additive;              // glow: additive coupling
+  int32_t n_batches;             // 1..MAX_BATCHES (z_out / ldj_out only with 1)
   unsigned long long* dbg;       // diagnostic builds (-DGBNF_STAMPS) only: per-block phase cycle sums
 };
 
@@ -514,19 +518,23 @@ __global__ void __launch_bounds__(64) flow_kernel(const FlowLaunch p) {
   // ---- XCD-aware block -> (component, sample tile).  Blocks are dealt round-robin over the
   //      8 XCDs; give each XCD a contiguous run of the (component-major) work list so one
   //      component's weights stay in one XCD's L2.  Bijective for any grid size.
-  int comp, tile;
+  int comp, tile, batch;
   {
     const int total = gridDim.x;
     const int b = blockIdx.x;
     const int xcd = b & 7, j = b >> 3;
     const int base = total >> 3, rem = total & 7;
     const int q = xcd * base + (xcd < rem ? xcd : rem) + j;
-    comp = q / p.n_tiles;
-    tile = q - comp * p.n_tiles;
+    const int per_comp = p.n_tiles * p.n_batches;   // work list: component-major, then batch, then tile
+    comp = q / per_comp;
+    const int r = q - comp * per_comp;
+    batch = r / p.n_tiles;
+    tile = r - batch * p.n_tiles;
   }
   const uint32_t* __restrict__ blob = p.blobs[p.c_begin + comp];
   const int d = p.d;
   const int64_t row0 = (int64_t)tile * (16 * NT);
+  const float* __restrict__ xin = p.xs[batch];
 
   // ---- per-step index/normalisation tables -> LDS (1.3 KB per step), x tile -> Z[feature][sample]
   if (lds_tables) {
@@ -541,7 +549,7 @@ __global__ void __launch_bounds__(64) flow_kernel(const FlowLaunch p) {
     for (int r = 0; r < 16 * NT; ++r) {
       const int64_t n = row0 + r;
       float v = 0.0f;
-      if (n < p.n) v = p.x[n * d + lane];
+      if (n < p.n) v = xin[n * d + lane];
       Z[lane * ZS + r] = v;
     }
   }
@@ -671,7 +679,7 @@ __global__ void __launch_bounds__(64) flow_kernel(const FlowLaunch p) {
     const int64_t n = row0 + 16 * nt + i;
     if (g == 0 && n < p.n) {
       const float ldj = l + ld_const;
-      const int64_t o = (int64_t)comp * p.n + n;
+      const int64_t o = (int64_t)comp * p.out_stride + (int64_t)batch * p.n + n;
       if (p.ldj_out) p.ldj_out[o] = ldj;
       if (p.ll_out) p.ll_out[o] = (q - 0.91893853320467274f * (float)d) + ldj;   // -d/2 log(2 pi)
     }

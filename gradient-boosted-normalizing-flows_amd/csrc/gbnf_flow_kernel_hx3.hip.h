@@ -131,19 +131,23 @@ __global__ void __launch_bounds__(64 * HX3_WAVES) flow_kernel_hx3(const FlowLaun
 
   // ---- XCD-aware block -> (component, group of 4 sample tiles)
   const int n_groups = (p.n_tiles + HX3_WAVES - 1) / HX3_WAVES;
-  int comp, grp;
+  int comp, grp, batch;
   {
     const int total = gridDim.x;
     const int b = blockIdx.x;
     const int xcd = b & 7, j = b >> 3;
     const int base = total >> 3, rem = total & 7;
     const int q = xcd * base + (xcd < rem ? xcd : rem) + j;
-    comp = q / n_groups;
-    grp = q - comp * n_groups;
+    const int per_comp = n_groups * p.n_batches;    // work list: component-major, then batch, then tile group
+    comp = q / per_comp;
+    const int r = q - comp * per_comp;
+    batch = r / n_groups;
+    grp = r - batch * n_groups;
   }
   const uint32_t* __restrict__ blob = p.blobs[p.c_begin + comp];
   const int d = p.d;
   const int64_t row0 = ((int64_t)grp * HX3_WAVES + wave) * (16 * NT);    // rows >= n are masked everywhere
+  const float* __restrict__ xin = p.xs[batch];
 
   // ---- weight staging.  The blob is laid out in consumption order, so "the next stage" is a running
   //      pointer; every call site knows the next stage's fragment count at compile time.  Wave w moves
@@ -184,7 +188,7 @@ __global__ void __launch_bounds__(64 * HX3_WAVES) flow_kernel_hx3(const FlowLaun
     for (int r = 0; r < 16 * NT; ++r) {
       const int64_t n = row0 + r;
       float v = 0.0f;
-      if (n < p.n) v = p.x[n * d + lane];
+      if (n < p.n) v = xin[n * d + lane];
       Z[lane * ZS + r] = v;
     }
   }
@@ -584,7 +588,7 @@ __global__ void __launch_bounds__(64 * HX3_WAVES) flow_kernel_hx3(const FlowLaun
     const int64_t n = row0 + 16 * nt + i;
     if (g == 0 && n < p.n) {
       const float ldj = l + ld_const;
-      const int64_t o = (int64_t)comp * p.n + n;
+      const int64_t o = (int64_t)comp * p.out_stride + (int64_t)batch * p.n + n;
       if (p.ldj_out) p.ldj_out[o] = ldj;
       if (p.ll_out) p.ll_out[o] = (q - 0.91893853320467274f * (float)d) + ldj;
     }

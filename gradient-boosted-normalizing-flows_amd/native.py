@@ -25,7 +25,9 @@ ABI_SYMBOLS = (
     "gbnf_version", "gbnf_last_error",
     "gbnf_flow_create", "gbnf_flow_create_mode", "gbnf_flow_destroy", "gbnf_flow_info", "gbnf_flow_forward",
     "gbnf_mixture_create", "gbnf_mixture_destroy", "gbnf_mixture_set_base",
-    "gbnf_mixture_component_log_prob", "gbnf_mixture_lse", "gbnf_mixture_log_prob",
+    "gbnf_mixture_component_log_prob", "gbnf_mixture_component_log_prob_strided",
+    "gbnf_mixture_component_log_prob_multi", "gbnf_mixture_lse",
+    "gbnf_mixture_log_prob",
     "gbnf_actnorm_init",
 )
 
@@ -92,6 +94,8 @@ def lib():
     L.gbnf_mixture_destroy.argtypes = [vp]
     L.gbnf_mixture_set_base.argtypes = [vp, C.POINTER(C.c_float), C.POINTER(C.c_float)]
     L.gbnf_mixture_component_log_prob.argtypes = [vp, vp, i64, i32, i32, vp, vp]
+    L.gbnf_mixture_component_log_prob_strided.argtypes = [vp, vp, i64, i32, i32, vp, i64, vp]
+    L.gbnf_mixture_component_log_prob_multi.argtypes = [vp, C.POINTER(vp), i32, i64, i32, i32, vp, i64, vp]
     L.gbnf_mixture_lse.argtypes = [vp, i64, vp, i32, i64, vp, vp]
     L.gbnf_mixture_log_prob.argtypes = [vp, vp, i64, i32, vp, vp, vp, vp]
     L.gbnf_actnorm_init.argtypes = [vp, i64, i32, C.c_float, vp, vp, vp]
@@ -272,6 +276,52 @@ class NativeMixture:
             C.c_void_p(out.data_ptr() if out.numel() else 0), _stream_ptr()))
         return out
 
+    def prepared_component_log_prob(self, x, out, c_begin=0, c_end=None, col_offset=0):
+        """Bind every argument once and return ``launch(stream_ptr)``: the per-call host cost is then one ctypes
+        call (for latency-sensitive loops such as bench.py's pipeline).  ``out`` is a (c_end-c_begin, >= n) table;
+        this batch's log-densities go to columns [col_offset, col_offset + n) (rows keep out's row stride)."""
+        _require_device_f32(x, "x")
+        if not out.is_cuda or out.dtype.is_floating_point is False or out.stride(1) != 1:
+            raise GbnfError("out must be a float32 device table with unit column stride")
+        c_end = self.n_components if c_end is None else c_end
+        n = x.shape[0]
+        if out.shape[0] != c_end - c_begin or out.shape[1] < col_offset + n or x.shape[1] != self.d:
+            raise GbnfError("prepared_component_log_prob: shape mismatch")
+        fn, h = lib().gbnf_mixture_component_log_prob_strided, self.handle
+        stride = out.stride(0) if out.shape[0] > 1 else max(out.shape[1], n)
+        xp = C.c_void_p(x.data_ptr())
+        op = C.c_void_p(out.data_ptr() + 4 * col_offset)
+        keep = (x, out)
+
+        def launch(stream_ptr, _keep=keep):
+            rc = fn(h, xp, n, c_begin, c_end, op, stride, stream_ptr)
+            if rc:
+                _check(rc)
+        return launch
+
+    def prepared_group_log_prob(self, xs, out, c_begin=0, c_end=None):
+        """Bound launch of ONE kernel over a group of batches: xs = list of (n,d) device tensors (same n), ``out`` a
+        (c_end-c_begin, len(xs)*n) table; batch b lands in columns [b*n, (b+1)*n).  Returns ``launch(stream_ptr)``."""
+        c_end = self.n_components if c_end is None else c_end
+        n = xs[0].shape[0]
+        for t in xs:
+            _require_device_f32(t, "x")
+            if tuple(t.shape) != (n, self.d):
+                raise GbnfError("all batches of a group must be (n, d) with the same n")
+        _require_device_f32(out, "out")
+        if tuple(out.shape) != (c_end - c_begin, len(xs) * n):
+            raise GbnfError("out must be (components, len(xs) * n)")
+        fn, h = lib().gbnf_mixture_component_log_prob_multi, self.handle
+        arr = (C.c_void_p * len(xs))(*[t.data_ptr() for t in xs])
+        nb, stride, op = len(xs), len(xs) * n, C.c_void_p(out.data_ptr())
+        keep = (list(xs), out, arr)
+
+        def launch(stream_ptr, _keep=keep):
+            rc = fn(h, arr, nb, n, c_begin, c_end, op, stride, stream_ptr)
+            if rc:
+                _check(rc)
+        return launch
+
     def log_prob(self, x, rho, n_used=None, ll_out=None, out=None):
         """The measured path: G (n,) = mixture log-density over components [0, n_used)."""
         import torch
@@ -318,6 +368,25 @@ def mixture_lse(ll, rho, out=None):
     _check(lib().gbnf_mixture_lse(C.c_void_p(ll.data_ptr() if n else 0), n, C.c_void_p(rho.data_ptr()), c, n,
                                   C.c_void_p(out.data_ptr() if n else 0), _stream_ptr()))
     return out
+
+
+def prepared_mixture_lse(ll, rho, out):
+    """Bound form of mixture_lse: returns ``launch(stream_ptr)``."""
+    _require_device_f32(ll, "ll")
+    _require_device_f32(rho, "rho")
+    _require_device_f32(out, "out")
+    c, n = ll.shape
+    if rho.numel() < c or out.numel() != n:
+        raise GbnfError("prepared_mixture_lse: shape mismatch")
+    fn = lib().gbnf_mixture_lse
+    lp, rp, op = C.c_void_p(ll.data_ptr()), C.c_void_p(rho.data_ptr()), C.c_void_p(out.data_ptr())
+    keep = (ll, rho, out)
+
+    def launch(stream_ptr, _keep=keep):
+        rc = fn(lp, n, rp, c, n, op, stream_ptr)
+        if rc:
+            _check(rc)
+    return launch
 
 
 def actnorm_init(z, scale=1.0):

@@ -59,6 +59,19 @@ class ShardedMixture:
         ll, _ = self.gather(ll_local)
         return self.lse(ll, rho), ll
 
+    def log_prob_group(self, xs, rho, compute_local_group):
+        """A GROUP of independent batches behind one exchange: ``compute_local_group(xs) -> (C_local, S*n)`` is ONE
+        launch over the S batches (NativeMixture.prepared_group_log_prob / gbnf_mixture_component_log_prob_multi;
+        batch b in columns [b*n, (b+1)*n)); one all-gather rebuilds the (C, S*n) table, one recursion launch
+        finishes all S batches.  Returns [G_0, ..., G_{S-1}]."""
+        n = xs[0].shape[0]
+        ll_local = compute_local_group(xs)
+        if tuple(ll_local.shape) != (self.c_end - self.c_begin, len(xs) * n):
+            raise ValueError("compute_local_group must return (C_local, len(xs) * n)")
+        ll, _ = self.gather(ll_local)
+        G = self.lse(ll, rho)
+        return [G[b * n:(b + 1) * n] for b in range(len(xs))]
+
     def log_prob_pipelined(self, batches, rho):
         """Throughput form: batches are independent, so the all-gather of batch i overlaps the
         flow kernel of batch i+1 (the recursion for batch i is enqueued after kernel i+1)."""

@@ -149,6 +149,18 @@ int gbnf_mixture_set_base(gbnf_mixture* mix, const float* mean, const float* std
  * ll is (c_end - c_begin, n) row-major. */
 int gbnf_mixture_component_log_prob(const gbnf_mixture* mix, const float* x, int64_t n,
                                     int32_t c_begin, int32_t c_end, float* ll, void* stream);
+/* Same, writing row c of ll at ll + (c - c_begin) * ll_row_stride (>= n): lets several batches share one
+ * (components, batches*n) table so that ONE all-gather / ONE recursion launch serves a group of batches. */
+int gbnf_mixture_component_log_prob_strided(const gbnf_mixture* mix, const float* x, int64_t n,
+                                            int32_t c_begin, int32_t c_end, float* ll, int64_t ll_row_stride,
+                                            void* stream);
+/* Same for a GROUP of up to 8 independent batches in ONE launch: xs is a HOST array of n_batches DEVICE pointers to
+ * (n,d) inputs; batch b's log-densities go to columns [b*n, (b+1)*n) of the (c_end-c_begin, >= n_batches*n) table.
+ * (A rank that holds few components does not fill the GPU with one batch; serving several batches per launch does,
+ * and one all-gather + one recursion launch then cover the whole group.) */
+int gbnf_mixture_component_log_prob_multi(const gbnf_mixture* mix, const float* const* xs, int32_t n_batches,
+                                          int64_t n, int32_t c_begin, int32_t c_end, float* ll,
+                                          int64_t ll_row_stride, void* stream);
 
 /* Replaces: the recursive prefix-normalised 2-way logsumexp (density_experiment.py:567-571):
  *   G_0 = ll_0;  r_c = rho_c / sum(rho[0..c]);  G_c = LSE(log(1-r_c)+G_{c-1}, log(r_c)+ll_c).

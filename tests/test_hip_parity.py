@@ -74,6 +74,32 @@ def test_single_launch_equals_per_component(golden_case, dev):
     assert torch.equal(part, ll_all[2:5])
 
 
+@pytest.mark.parametrize("math", ["f32", "f16x3"])
+def test_group_launch_equals_per_batch_launches(math, golden_case, dev):
+    """One launch over a group of batches (gbnf_mixture_component_log_prob_multi) == one launch per batch, bit for
+    bit, incl. ragged batch sizes; the strided single-batch form writes only its column block."""
+    import torch
+    from gbnf_amd import native, synth
+    g = golden_case("g3_glow_d43_h215_c8")
+    mix, _ = _mixture(g.specs, math)
+    for n in (4096, 77):
+        xs = [torch.from_numpy(synth.synth_batch(n, 43, seed=40 + b)).to(dev) for b in range(5)]
+        table = torch.full((8, 5 * n), float("nan"), device=dev)
+        mix.prepared_group_log_prob(xs, table)(native._stream_ptr())
+        for b, xb in enumerate(xs):
+            single = mix.component_log_prob(xb)
+            if n == 4096:     # same 32-sample wave tiles in both launches -> identical bits
+                assert torch.equal(table[:, b * n:(b + 1) * n], single)
+            else:             # the lone small batch runs on 16-sample tiles: same math, other instantiation
+                assert rel_err(table[:, b * n:(b + 1) * n].cpu().numpy(), single.cpu().numpy()) < 2e-6
+        part = torch.full((3, 5 * n), float("nan"), device=dev)
+        mix.prepared_component_log_prob(xs[2], part, 2, 5, col_offset=3 * n)(native._stream_ptr())
+        assert torch.equal(part[:, 3 * n:4 * n], mix.component_log_prob(xs[2], 2, 5))
+        assert torch.isnan(part[:, :3 * n]).all() and torch.isnan(part[:, 4 * n:]).all()
+    with pytest.raises(native.GbnfError):
+        mix.prepared_group_log_prob(xs + xs, torch.empty((8, 10 * 77), device=dev))(native._stream_ptr())   # > 8 batches
+
+
 def test_deterministic_and_tile_independent(golden_case, dev):
     """Run twice -> identical bits; a row's result does not depend on the batch around it
     (16- vs 32-sample wave tiles, tails)."""

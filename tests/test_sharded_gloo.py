@@ -52,7 +52,14 @@ def _worker(rank, world, port, ll_all, rho, ret):
         x = torch.zeros(n, 3)
         G, ll = sm.log_prob(x, torch.from_numpy(rho))
         outs = sm.log_prob_pipelined([x, x, x], torch.from_numpy(rho))
-        ret[rank] = (G.numpy(), ll.numpy(), [o.numpy() for o in outs], calls, (sm.c_begin, sm.c_end))
+
+        def compute_group(xs_):   # one "launch" over a group: batch b in columns [b*n, (b+1)*n), scaled to tell them apart
+            c0, c1 = sharded.partition(C, world)[rank]
+            return torch.cat([torch.from_numpy(ll_all[c0:c1]) - float(b) for b in range(len(xs_))], dim=1)
+
+        grouped = sm.log_prob_group([x, x, x], torch.from_numpy(rho), compute_group)
+        ret[rank] = (G.numpy(), ll.numpy(), [o.numpy() for o in outs], calls, (sm.c_begin, sm.c_end),
+                     [g.numpy() for g in grouped])
     finally:
         dist.destroy_process_group()
 
@@ -69,7 +76,7 @@ def test_two_rank_component_sharding_gloo():
     port = _free_port()
     mp.spawn(_worker, args=(world, port, ll_all, rho, ret), nprocs=world, join=True)
     for rank in range(world):
-        G, ll, outs, calls, part = ret[rank]
+        G, ll, outs, calls, part, grouped = ret[rank]
         assert part == (rank * 2, rank * 2 + 2)
         assert all(c == part for c in calls)                      # each rank computed only its block
         np.testing.assert_array_equal(ll, ll_all)                 # (C, n) rebuilt in component order
@@ -77,3 +84,6 @@ def test_two_rank_component_sharding_gloo():
         assert len(outs) == 3
         for o in outs:
             np.testing.assert_array_equal(o, expect)
+        assert len(grouped) == 3                                  # grouped exchange: batch b == recursion(ll - b)
+        for b, gb in enumerate(grouped):
+            np.testing.assert_allclose(gb, oracle.mixture_recursion(ll_all - np.float32(b), rho), rtol=0, atol=0)
