@@ -111,7 +111,7 @@ __device__ __forceinline__ f32x4 mfma_x3(u32x4 w_hi, u32x4 w_mid, u32x4 x_hi, u3
 }
 
 template <int KIND, int HT, int OT, int NT, int ACTA, int ACTB>
-__global__ void __launch_bounds__(64 * HX3_WAVES) flow_kernel_hx3(const FlowLaunch p) {
+__global__ void __launch_bounds__(64 * HX3_WAVES, (NT == 1) ? 2 : 1) flow_kernel_hx3(const FlowLaunch p) {
   constexpr int ZS = 16 * NT + 1;
   constexpr int NNETS = (KIND == GBNF_KIND_REALNVP) ? 2 : 1;
   constexpr const Hx3Layout& L = Hx3LayoutOf<HT, OT>::value;
@@ -125,7 +125,7 @@ __global__ void __launch_bounds__(64 * HX3_WAVES) flow_kernel_hx3(const FlowLaun
   uint32_t* STG = lds + (lds_tables ? p.n_steps * SMALL_WORDS : 0);       // 2 staging buffers
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-  float* Z = reinterpret_cast<float*>(STG + 2 * STAGE_WORDS) + wave * (ZSLOTS * ZS);   // wave-private
+  float* Z = reinterpret_cast<float*>(STG + 2 * STAGE_WORDS) + wave * (p.d * ZS);   // wave-private, d slots
   const int i = lane & 15;
   const int g = lane >> 4;
 
@@ -379,9 +379,7 @@ __global__ void __launch_bounds__(64 * HX3_WAVES) flow_kernel_hx3(const FlowLaun
           constexpr int NF_NEXT = LAST ? 2 * OT : (PREV == 1 ? 2 * HC + 2 * OT : 2 * HC);
           const uint32_t* buf = STG + (gs & 1) * STAGE_WORDS;
           issue(std::integral_constant<int, NF_NEXT>{}, gs + 1);
-          u32x4 A[NF_CUR];
-#pragma unroll
-          for (int f = 0; f < NF_CUR; ++f) A[f] = frag(buf, f);
+          u32x4 a_hi = frag(buf, 0), a_mid = frag(buf, 1);
           const f32x4 bias_next = b2[(u + 1 < HT ? u + 1 : u) * 4];
           f32x4 acc[NT];
 #pragma unroll
@@ -389,6 +387,11 @@ __global__ void __launch_bounds__(64 * HX3_WAVES) flow_kernel_hx3(const FlowLaun
           __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
           for (int c = 0; c < HC; ++c) {
+            const u32x4 c_hi = a_hi, c_mid = a_mid;
+            if (c + 1 < HC || PREV == 2) {      // next chunk's fragments (or the first output-layer tile's)
+              a_hi = frag(buf, 2 * c + 2);
+              a_mid = frag(buf, 2 * c + 3);
+            }
             if (PREV != 0) {
               // register pairs q = c, c + HC, ... of the previous tile (2*NT pairs in all); issued ahead of the
               // region's MFMAs so that the first region covers the LDS latency of the fragment reads
@@ -403,17 +406,17 @@ __global__ void __launch_bounds__(64 * HX3_WAVES) flow_kernel_hx3(const FlowLaun
             }
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt) {
-              acc[nt] = mfma_f16(A[2 * c + 1], hBhi[c][nt], acc[nt]);
+              acc[nt] = mfma_f16(c_mid, hBhi[c][nt], acc[nt]);
               MFMA_ORDER_FENCE();
             }
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt) {
-              acc[nt] = mfma_f16(A[2 * c], hBmid[c][nt], acc[nt]);
+              acc[nt] = mfma_f16(c_hi, hBmid[c][nt], acc[nt]);
               MFMA_ORDER_FENCE();
             }
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt) {
-              acc[nt] = mfma_f16(A[2 * c], hBhi[c][nt], acc[nt]);
+              acc[nt] = mfma_f16(c_hi, hBhi[c][nt], acc[nt]);
               MFMA_ORDER_FENCE();
             }
             __builtin_amdgcn_sched_barrier(0);
@@ -422,19 +425,24 @@ __global__ void __launch_bounds__(64 * HX3_WAVES) flow_kernel_hx3(const FlowLaun
             // output-layer chunk (u-2)/2 = hidden tiles (u-2, u-1): its fragments follow the hidden row
 #pragma unroll
             for (int o = 0; o < OT; ++o) {
+              const u32x4 c_hi = a_hi, c_mid = a_mid;
+              if (o + 1 < OT) {
+                a_hi = frag(buf, 2 * HC + 2 * o + 2);
+                a_mid = frag(buf, 2 * HC + 2 * o + 3);
+              }
 #pragma unroll
               for (int nt = 0; nt < NT; ++nt) {
-                out[o][nt] = mfma_f16(A[2 * HC + 2 * o + 1], hOhi[nt], out[o][nt]);
+                out[o][nt] = mfma_f16(c_mid, hOhi[nt], out[o][nt]);
                 MFMA_ORDER_FENCE();
               }
 #pragma unroll
               for (int nt = 0; nt < NT; ++nt) {
-                out[o][nt] = mfma_f16(A[2 * HC + 2 * o], hOmid[nt], out[o][nt]);
+                out[o][nt] = mfma_f16(c_hi, hOmid[nt], out[o][nt]);
                 MFMA_ORDER_FENCE();
               }
 #pragma unroll
               for (int nt = 0; nt < NT; ++nt) {
-                out[o][nt] = mfma_f16(A[2 * HC + 2 * o], hOhi[nt], out[o][nt]);
+                out[o][nt] = mfma_f16(c_hi, hOhi[nt], out[o][nt]);
                 MFMA_ORDER_FENCE();
               }
             }
@@ -611,9 +619,9 @@ __global__ void __launch_bounds__(64 * HX3_WAVES) flow_kernel_hx3(const FlowLaun
 #endif
 }
 
-inline size_t flow_hx3_lds_bytes(int n_steps, int nt, int stage_frags) {
+inline size_t flow_hx3_lds_bytes(int n_steps, int nt, int stage_frags, int d) {
   const size_t tables = n_steps <= LDS_TABLE_STEPS ? (size_t)n_steps * SMALL_WORDS : 0;
-  return (tables + 2 * (size_t)stage_frags * 256 + (size_t)HX3_WAVES * ZSLOTS * (16 * nt + 1)) * 4;
+  return (tables + 2 * (size_t)stage_frags * 256 + (size_t)HX3_WAVES * d * (16 * nt + 1)) * 4;
 }
 
 // hx3 variants are keyed like the f32 ones with ksl = ks1 = lmid-independent fields fixed:
@@ -623,7 +631,7 @@ inline size_t flow_hx3_lds_bytes(int n_steps, int nt, int stage_frags) {
   static hipError_t launch_hx3_##KIND##_##HT##_##OT##_##NT##_##ACTA##_##ACTB(const FlowLaunch& p,           \
                                                                              unsigned grid, hipStream_t s) { \
     constexpr Hx3Layout L(HT, OT);                                                                          \
-    const size_t lds = flow_hx3_lds_bytes(p.n_steps, NT, L.STAGE_FRAGS);                                    \
+    const size_t lds = flow_hx3_lds_bytes(p.n_steps, NT, L.STAGE_FRAGS, p.d);                                    \
     static bool attr_set = false;                                                                           \
     if (!attr_set) {                                                                                        \
       hipError_t e = hipFuncSetAttribute((const void*)flow_kernel_hx3<KIND, HT, OT, NT, ACTA, ACTB>,        \
