@@ -70,12 +70,15 @@ def main(argv=None):
     for v in read_variants():
         o = os.path.join(OBJ, "v_" + "_".join(str(a) for a in v) + ".o")
         objs.append(o)
+        extra = []
         if v[0] == "hx3":
             vsrc, vargs = os.path.join(HERE, "variant_hx3.hip"), v[1:]
+            # keep MFMA accumulators in VGPRs: the tanh/split reads them directly (no v_accvgpr_read per value)
+            extra = ["-mllvm", "-amdgpu-mfma-vgpr-form=1"]
         else:
             vsrc, vargs = os.path.join(HERE, "variant.hip"), v
         if args.force or not newer(o, [vsrc] + hdr):
-            jobs.append([HIPCC] + FLAGS + ["-DGBNF_V_ARGS=" + ",".join(str(a) for a in vargs), "-c", vsrc, "-o", o])
+            jobs.append([HIPCC] + FLAGS + extra + ["-DGBNF_V_ARGS=" + ",".join(str(a) for a in vargs), "-c", vsrc, "-o", o])
     keep = set(objs)
     for fn in os.listdir(OBJ):      # drop objects of variants that left the list
         p = os.path.join(OBJ, fn)
