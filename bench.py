@@ -102,7 +102,7 @@ def main():
     ap.add_argument("--force-gather", action="store_true",
                     help="testing aid: run the RCCL all-gather leg even with one rank")
     ap.add_argument("--group", type=int, default=0,
-                    help="batches served per launch / per all-gather (0 = auto = 8, the maximum)")
+                    help="batches served per launch / per all-gather (0 = auto: 8..16, max 16)")
     args = ap.parse_args()
 
     import numpy as np
@@ -145,8 +145,9 @@ def main():
     # finishes it -- "bigger, fewer collectives".  The flow kernels run on one stream, gather + recursion on a
     # second one, double-buffered, so the exchange of group g overlaps the kernel of group g+1.
     gather = world > 1 or args.force_gather
-    S = args.group if args.group > 0 else 8
-    S = max(1, min(S, 8, args.steps))
+    # auto: at least 8, and enough batches per launch for two co-resident workgroups per CU (>= 512 workgroups)
+    S = args.group if args.group > 0 else max(8, (16 * world + C - 1) // C)
+    S = max(1, min(S, 16, args.steps))
     xs_np = [x_np] + [synth.synth_batch(B, d, seed=100 + s) for s in range(1, S)]   # S distinct resident batches
     xs = [x] + [torch.from_numpy(a).to(dev) for a in xs_np[1:]]
     NBUF = 2

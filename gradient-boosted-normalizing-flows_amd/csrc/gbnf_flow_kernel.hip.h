@@ -67,7 +67,7 @@ struct NetLayoutRT {
         NET_WORDS(B3 + OT * 16) {}
 };
 
-constexpr int MAX_BATCHES = 8;   // batches one launch can serve
+constexpr int MAX_BATCHES = 16;  // batches one launch can serve
 
 struct FlowLaunch {
   const uint32_t* const* blobs;  // device array: packed parameter blob per component

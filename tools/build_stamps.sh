@@ -7,7 +7,7 @@ OUT=/tmp/gbnf_stamps; mkdir -p $OUT
 F="--offload-arch=gfx950 -O3 -fPIC -std=c++17 -DGBNF_STAMPS"
 for nt in 1 2; do
   hipcc $F -DGBNF_V_ARGS=0,14,2,6,3,$nt,1,0,0 -c variant.hip -o $OUT/v_$nt.o &
-  hipcc $F -DGBNF_V_ARGS=0,14,3,$nt,0,0 -c variant_hx3.hip -o $OUT/h_$nt.o &
+  hipcc $F -mllvm -amdgpu-mfma-vgpr-form=1 -DGBNF_V_ARGS=0,14,3,$nt,0,0 -c variant_hx3.hip -o $OUT/h_$nt.o &
 done
 hipcc $F -c gbnf_api.hip -o $OUT/api.o
 wait
