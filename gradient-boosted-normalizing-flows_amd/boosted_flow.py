@@ -316,9 +316,12 @@ class BoostedFlow(nn.Module):
     def _rho_gradients(self, x):
         """models/boosted_flow.py:119-139 (note: un-normalised rho in this recursion, as in the reference)."""
         full_ll = fixed_ll = new_ll = None
+        x = x.contiguous().float()
         for c in range(self.component + 1):
-            z, ldj = self.component_forward(x, c)
-            ll = torch.sum(-0.5 * np.log(2 * np.pi) - 0.5 * z * z, dim=-1) + ldj
+            self._check_ready(x)
+            self._ensure_actnorm(x, c)
+            with torch.cuda.device(x.device):     # ll_c = log N(z;0,I) + ldj straight from the flow kernel
+                _, _, ll = self.native_flow(c).forward(x, want_z=False, want_ldj=False, want_ll=True)
             if c == 0:
                 full_ll = ll
                 new_ll = ll if new_ll is None else new_ll

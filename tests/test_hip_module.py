@@ -185,3 +185,25 @@ def test_actnorm_data_dependent_init_matches_reference():
     np.testing.assert_allclose(l.cpu().numpy(), ref_logs, rtol=0, atol=2e-5)
     b2, l2 = native.actnorm_init(big, 1.0)
     assert torch.equal(b, b2) and torch.equal(l, l2)      # fixed-order reduction: bit-reproducible
+
+
+def test_update_rho_runs_on_the_device_path(golden_case):
+    """update_rho (models/boosted_flow.py:141-207) driven like the reference: rho of the current component moves
+    by SGD on mean(g_nll - G_nll); rho_iters == 0 is a no-op."""
+    import torch
+    dev = torch.device("cuda:0")
+    g = golden_case("g6_glow_d43_h64_c3_rho")
+    m = _model_from_case(g, dev)
+    m.component = 1
+    m.args.rho_iters, m.args.rho_lr = 0, 0.1
+    before = m.rho.clone()
+    loader = [(torch.from_numpy(g.x), None)]
+    m.update_rho(loader)
+    assert torch.equal(m.rho, before)
+    m.args.rho_iters = 12
+    m.update_rho(loader)
+    assert not torch.equal(m.rho, before) and 0.01 <= float(m.rho[1]) <= 100.0
+    assert torch.equal(m.rho[0], before[0]) and torch.equal(m.rho[2], before[2])
+    new_ll, fixed_ll, full_ll = m._rho_gradients(torch.from_numpy(g.x).to(dev))
+    assert rel_err(new_ll.cpu().numpy(), g.ll[1]) < LL_RTOL          # g^c of the reference's recursion
+    assert rel_err(fixed_ll.cpu().numpy(), g.ll[0]) < LL_RTOL         # G^(c-1) with one fixed component = ll_0
