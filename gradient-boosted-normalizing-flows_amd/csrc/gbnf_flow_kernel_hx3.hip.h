@@ -99,7 +99,12 @@ __device__ __forceinline__ float act_hx3(float y) {
 }
 
 __device__ __forceinline__ f32x4 mfma_f16(u32x4 a, u32x4 b, f32x4 c) {
+#ifdef GBNF_ABLATE_MFMA           // diagnostic: one cheap VALU op instead of the MFMA (keeps every value live)
+  c[0] += __builtin_bit_cast(float, a[0] ^ b[0]);
+  return c;
+#else
   return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+#endif
 }
 
 // acc += W.x with W = (w_hi, w_mid), x = (x_hi, x_mid): small terms first
@@ -261,7 +266,15 @@ __global__ void __launch_bounds__(64 * HX3_WAVES, (NT == 1) ? 2 : 1) flow_kernel
       // (the empty asm pins the computation HERE: without it LLVM sinks the whole tanh + split into the later
       //  block that first consumes the operand, un-interleaving it from this region's MFMAs)
       auto act_split = [&](const f32x4& raw, int hp, unsigned& h, unsigned& m) {
+#if defined(GBNF_ABLATE_ACT)      // diagnostic: no tanh, no split (results wrong, timing only)
+        h = __builtin_bit_cast(unsigned, raw[2 * hp]);
+        m = __builtin_bit_cast(unsigned, raw[2 * hp + 1]);
+#elif defined(GBNF_ABLATE_SPLIT)  // diagnostic: tanh but no split
+        h = __builtin_bit_cast(unsigned, act(raw[2 * hp]));
+        m = __builtin_bit_cast(unsigned, act(raw[2 * hp + 1]));
+#else
         split_pair(act(raw[2 * hp]), act(raw[2 * hp + 1]), h, m);
+#endif
         asm volatile("" : "+v"(h), "+v"(m));
       };
 
