@@ -461,6 +461,18 @@ class BoostedFlow(nn.Module):
             G, _ = self.native_mixture().log_prob(x, self.rho.contiguous().float(), n_used=n_used)
         return G
 
+    def boosting_weights(self, x, beta=1.0):
+        """Step 1-2 of compute_kl_pq_loss (density_experiment.py:612-640) for training component ``self.component``:
+        G = mixture log-density of the ``self.component`` FIXED components (recursion of :614-622), then
+        w = softmax(-G), w^beta, clamp to [0.01, 0.1] when max(w) > 0.1, renormalise.  Returns (w (N,), G (N,)).
+        The caller resamples with its own RNG: ``idx = torch.multinomial(w, N, replacement=True)`` (:642)."""
+        if not (self.all_trained or self.component > 0):
+            raise ValueError("the first component is trained without boosting weights (density_experiment.py:660-666)")
+        G = self.log_prob(x, n_used=self.component)
+        with torch.cuda.device(x.device):
+            w = native.boosting_weights(G, beta)
+        return w, G
+
     def _n_used(self, n_used):
         if n_used is None:
             n_used = self.num_components if self.all_trained else self.component + 1

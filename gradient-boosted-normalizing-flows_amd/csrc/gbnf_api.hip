@@ -680,6 +680,55 @@ __global__ void __launch_bounds__(256) mixture_lse_kernel(const float* __restric
 
 }  // namespace gbnf
 
+// ---- boosting sample weights (density_experiment.py:624-640): how much each training sample matters to the NEXT
+// component, from the mixture log-density G of the fixed components:
+//   w = softmax(-G);  w = w^beta;  if max(w) > 0.1: w = clamp(w, 0.01, 0.1);  if sum(w) != 1: w /= sum(w)
+// One workgroup walks the batch four times (max, sum of exp, max/sum of w, final scale): n*4 bytes read per pass,
+// launch-latency sized; fixed-order tree reductions => bit-reproducible.
+__device__ __forceinline__ float block_reduce(float v, bool is_max, float* red) {
+  for (int off = 32; off > 0; off >>= 1) {
+    const float o = __shfl_xor(v, off);
+    v = is_max ? fmaxf(v, o) : v + o;
+  }
+  const int w = threadIdx.x >> 6;
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) red[w] = v;
+  __syncthreads();
+  float r = red[0];
+  for (int k = 1; k < (int)(blockDim.x >> 6); ++k) r = is_max ? fmaxf(r, red[k]) : r + red[k];
+  return r;
+}
+
+__global__ void __launch_bounds__(1024) boosting_weights_kernel(const float* __restrict__ G, int64_t n, float beta,
+                                                                float* __restrict__ w) {
+  __shared__ float red[16];
+  float m = -INFINITY;
+  for (int64_t i = threadIdx.x; i < n; i += blockDim.x) m = fmaxf(m, -G[i]);
+  m = block_reduce(m, true, red);
+  float s = 0.0f;
+  for (int64_t i = threadIdx.x; i < n; i += blockDim.x) s += expf(-G[i] - m);
+  s = block_reduce(s, false, red);
+  float wmax = 0.0f;
+  for (int64_t i = threadIdx.x; i < n; i += blockDim.x) {
+    float v = expf(-G[i] - m) / s;
+    if (beta != 1.0f) v = powf(v, beta);
+    w[i] = v;
+    wmax = fmaxf(wmax, v);
+  }
+  wmax = block_reduce(wmax, true, red);
+  const bool clamp = wmax > 0.1f;
+  float tot = 0.0f;
+  for (int64_t i = threadIdx.x; i < n; i += blockDim.x) {
+    float v = w[i];
+    if (clamp) v = fmaxf(fminf(v, 0.1f), 0.01f);
+    w[i] = v;
+    tot += v;
+  }
+  tot = block_reduce(tot, false, red);
+  if (tot != 1.0f)
+    for (int64_t i = threadIdx.x; i < n; i += blockDim.x) w[i] = w[i] / tot;
+}
+
 // ---- ActNorm data-dependent initialisation (models/layers.py:473-486): per-feature statistics of a batch.
 //   bias = -mean_0(z);  var = mean_0((z + bias)^2);  logs = log(scale / (sqrt(var) + 1e-6))
 // HBM-bound column reduction, two passes like the reference (centred second moment).  A wave reads one row
@@ -872,6 +921,15 @@ int gbnf_actnorm_init(const float* z, int64_t n, int32_t d, float scale, float* 
                      scale, bias_out, logs_out);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return fail(GBNF_ERR_HIP, "gbnf_actnorm_init launch failed: %s", hipGetErrorString(e));
+  return GBNF_OK;
+}
+
+int gbnf_boosting_weights(const float* G, int64_t n, float beta, float* w_out, void* stream) {
+  if (!G || !w_out) return fail(GBNF_ERR_INVALID, "gbnf_boosting_weights: null pointer");
+  if (n < 1) return fail(GBNF_ERR_INVALID, "gbnf_boosting_weights: needs at least one sample");
+  hipLaunchKernelGGL(boosting_weights_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, G, n, beta, w_out);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return fail(GBNF_ERR_HIP, "gbnf_boosting_weights launch failed: %s", hipGetErrorString(e));
   return GBNF_OK;
 }
 

@@ -28,7 +28,7 @@ ABI_SYMBOLS = (
     "gbnf_mixture_component_log_prob", "gbnf_mixture_component_log_prob_strided",
     "gbnf_mixture_component_log_prob_multi", "gbnf_mixture_lse",
     "gbnf_mixture_log_prob",
-    "gbnf_actnorm_init",
+    "gbnf_actnorm_init", "gbnf_boosting_weights",
 )
 
 
@@ -99,6 +99,7 @@ def lib():
     L.gbnf_mixture_lse.argtypes = [vp, i64, vp, i32, i64, vp, vp]
     L.gbnf_mixture_log_prob.argtypes = [vp, vp, i64, i32, vp, vp, vp, vp]
     L.gbnf_actnorm_init.argtypes = [vp, i64, i32, C.c_float, vp, vp, vp]
+    L.gbnf_boosting_weights.argtypes = [vp, i64, C.c_float, vp, vp]
     for name in ABI_SYMBOLS:
         if name not in ("gbnf_version", "gbnf_last_error"):
             getattr(L, name).restype = C.c_int
@@ -401,3 +402,15 @@ def actnorm_init(z, scale=1.0):
     _check(lib().gbnf_actnorm_init(C.c_void_p(z.data_ptr()), n, d, float(scale), C.c_void_p(bias.data_ptr()),
                                    C.c_void_p(logs.data_ptr()), _stream_ptr()))
     return bias, logs
+
+
+def boosting_weights(G, beta=1.0):
+    """Boosting sample weights from the fixed components' mixture log-density G (n,) on the device."""
+    import torch
+    _require_device_f32(G, "G")
+    if G.dim() != 1 or G.numel() < 1:
+        raise GbnfError("G must be (n,) with n >= 1")
+    w = torch.empty_like(G)
+    _check(lib().gbnf_boosting_weights(C.c_void_p(G.data_ptr()), G.numel(), float(beta), C.c_void_p(w.data_ptr()),
+                                       _stream_ptr()))
+    return w

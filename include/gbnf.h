@@ -182,6 +182,13 @@ int gbnf_mixture_log_prob(const gbnf_mixture* mix, const float* x, int64_t n, in
 int gbnf_actnorm_init(const float* z, int64_t n, int32_t d, float scale, float* bias_out, float* logs_out,
                       void* stream);
 
+/* Replaces: the boosting sample weights of compute_kl_pq_loss (density_experiment.py:624-640), computed from the
+ * mixture log-density G (n,) of the fixed components:
+ *   w = softmax(-G) (utils/utilities.py:12-14);  w = w^beta;  if max(w) > 0.1: w = clamp(w, 0.01, 0.1);
+ *   if sum(w) != 1: w /= sum(w).
+ * G and w_out are DEVICE buffers of n floats.  (The multinomial resampling that follows stays with the caller's RNG.) */
+int gbnf_boosting_weights(const float* G, int64_t n, float beta, float* w_out, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -320,6 +320,21 @@ def actnorm_data_init(spec, x, scale=1.0, backend="torch"):
     return out
 
 
+def boosting_weights(G, beta=1.0):
+    """Sample weights of compute_kl_pq_loss (density_experiment.py:624-640) in torch float32:
+    softmax(G_nll) with utils/utilities.py:12-14's max-shifted softmax, ^beta, clamp to [0.01, 0.1] when the
+    largest weight exceeds 0.1, renormalise when the sum is not exactly 1."""
+    G_nll = -torch.as_tensor(np.asarray(G), dtype=torch.float32)
+    e = torch.exp(G_nll - torch.max(G_nll))
+    w = e / torch.sum(e)
+    w = torch.pow(w, beta)
+    if w.max() > 0.1:
+        w = torch.max(torch.min(w, torch.tensor([0.1])), torch.tensor([0.01]))
+    if w.sum() != 1.0:
+        w = w / torch.sum(w)
+    return w.numpy()
+
+
 def rho_init(num_components, kind="decreasing"):
     """BoostedFlow.__init__ rho buffer: models/boosted_flow.py:32-39."""
     if kind == "decreasing":

@@ -18,9 +18,10 @@ def pytest_configure(config):
 
 
 def golden_names():
-    """Forward/mixture fixtures (g1..g6).  g7 (ActNorm data-dependent init) has its own tests."""
+    """Forward/mixture fixtures (g1..g6).  g7 (ActNorm data-dependent init) and g8 (boosting weights) have their
+    own tests."""
     names = sorted(os.path.splitext(os.path.basename(p))[0] for p in glob.glob(os.path.join(GOLDEN_DIR, "*.npz")))
-    return [n for n in names if not n.startswith("g7_")]
+    return [n for n in names if not n.startswith(("g7_", "g8_"))]
 
 
 def load_actnorm_init_case():

@@ -269,8 +269,38 @@ def actnorm_init_case(name, d=43, h=64, K=4, C=2, N=300):
     print(f"{name}: logs[0,0,:3]={logs[0, 0, :3]} ll[0,:3]={ll[0, :3]}")
 
 
+def boosting_weights_case(name):
+    """G8: the sample weights of compute_kl_pq_loss (density_experiment.py:624-640), produced with the reference's
+    own ``utils.utilities.softmax`` and the very statements of that function, for several G shapes: a peaked one
+    (max weight > 0.1 -> clamp branch), a flat one (no clamp), and beta != 1."""
+    from utils.utilities import softmax as ref_softmax
+    rng = np.random.RandomState(3)
+    out = {}
+    cases = {"flat": (-60 + 0.5 * rng.standard_normal(4096)).astype(np.float32),
+             "peaked": (-60 + 6.0 * rng.standard_normal(512)).astype(np.float32),
+             "tiny": np.array([-3.0, -2.5], dtype=np.float32),
+             "beta": (-40 + 2.0 * rng.standard_normal(1000)).astype(np.float32)}
+    for key, G_ll in cases.items():
+        beta = 0.5 if key == "beta" else 1.0
+        G_nll = -1.0 * torch.from_numpy(G_ll)
+        weights = ref_softmax(G_nll)
+        weights = torch.pow(weights, beta)
+        if weights.max() > 0.1:
+            weights = torch.max(torch.min(weights, torch.tensor([0.1])), torch.tensor([0.01]))
+        if weights.sum() != 1.0:
+            weights = weights / torch.sum(weights)
+        out[key + ".G"] = G_ll
+        out[key + ".w"] = weights.numpy().copy()
+        out[key + ".beta"] = np.float32(beta)
+    np.savez_compressed(os.path.join(HERE, name + ".npz"), **out)
+    print(name, {k: float(v.max()) for k, v in out.items() if k.endswith(".w")})
+
+
 def main():
     torch.set_num_threads(4)
+    if "--boosting-only" in sys.argv:
+        boosting_weights_case("g8_boosting_weights")
+        return
     if "--actnorm-only" in sys.argv:
         actnorm_init_case("g7_glow_actnorm_data_init")
         return
@@ -279,6 +309,7 @@ def main():
         return
     state_dict_layout_case()
     actnorm_init_case("g7_glow_actnorm_data_init")
+    boosting_weights_case("g8_boosting_weights")
     toy_case("g1_toy_realnvp_c2")
     native_glow_case("g2_glow_native_d43_h32_c3")
     # G3: MINIBOONE full width (BASELINE.json metric config), synthetic weights

@@ -207,3 +207,32 @@ def test_update_rho_runs_on_the_device_path(golden_case):
     new_ll, fixed_ll, full_ll = m._rho_gradients(torch.from_numpy(g.x).to(dev))
     assert rel_err(new_ll.cpu().numpy(), g.ll[1]) < LL_RTOL          # g^c of the reference's recursion
     assert rel_err(fixed_ll.cpu().numpy(), g.ll[0]) < LL_RTOL         # G^(c-1) with one fixed component = ll_0
+
+
+def test_boosting_weights_match_reference(golden_case):
+    """G8: sample weights for the next component; kernel vs the reference's own statements, and the
+    module method on top of the fixed components' mixture density."""
+    import os
+    import torch
+    from conftest import GOLDEN_DIR
+    from gbnf_amd import native
+    dev = torch.device("cuda:0")
+    data = dict(np.load(os.path.join(GOLDEN_DIR, "g8_boosting_weights.npz")))
+    for key in ("flat", "peaked", "tiny", "beta"):
+        w = native.boosting_weights(torch.from_numpy(data[key + ".G"]).to(dev), float(data[key + ".beta"]))
+        np.testing.assert_allclose(w.cpu().numpy(), data[key + ".w"], rtol=2e-5, atol=0)
+        w2 = native.boosting_weights(torch.from_numpy(data[key + ".G"]).to(dev), float(data[key + ".beta"]))
+        assert torch.equal(w, w2)
+    g = golden_case("g3_glow_d43_h215_c8")
+    m = _model_from_case(g, dev)
+    x = torch.from_numpy(g.x).to(dev)
+    with pytest.raises(ValueError):
+        m.boosting_weights(x)                     # component 0 trains without weights
+    m.component = 3
+    w, G = m.boosting_weights(x)
+    from oracle import gbnf_oracle as oracle
+    ll_ref, G_ref = oracle.mixture_log_prob(g.specs, g.rho, g.x, n_used=3)
+    assert rel_err(G.cpu().numpy(), G_ref) < LL_RTOL
+    np.testing.assert_allclose(w.cpu().numpy(), oracle.boosting_weights(G_ref), rtol=2e-4, atol=1e-9)
+    idx = torch.multinomial(w, x.shape[0], replacement=True)           # the caller's resampling step works on it
+    assert idx.shape == (x.shape[0],) and abs(float(w.sum()) - 1.0) < 1e-5

@@ -72,3 +72,14 @@ def test_actnorm_data_init_matches_reference():
             np.testing.assert_allclose(st["an_logs"], data["an_logs"][c, k], rtol=0, atol=2e-6)
     ll, G = oracle.mixture_log_prob(inited, data["rho"], x)
     assert rel_err(ll, data["ll"]) < 5e-6 and rel_err(G, data["G"]) < 5e-6
+
+
+def test_boosting_weights_match_reference():
+    """G8: density_experiment.py:624-640 restated, against weights produced by the reference's own statements."""
+    import os
+    from conftest import GOLDEN_DIR
+    data = dict(np.load(os.path.join(GOLDEN_DIR, "g8_boosting_weights.npz")))
+    for key in ("flat", "peaked", "tiny", "beta"):
+        w = oracle.boosting_weights(data[key + ".G"], float(data[key + ".beta"]))
+        np.testing.assert_allclose(w, data[key + ".w"], rtol=1e-6, atol=0)
+        assert abs(float(w.sum()) - 1.0) < 1e-5
