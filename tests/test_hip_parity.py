@@ -227,3 +227,34 @@ def test_empty_batch_and_errors(dev):
     wide = synth.synth_glow_spec(43, 300, 1, seed=0)          # h > 256: no compiled variant
     with pytest.raises(native.GbnfError):
         native.NativeFlow(wide)
+
+
+def test_new_entry_points_reject_bad_arguments(dev):
+    import ctypes as C
+    import torch
+    from gbnf_amd import native, synth
+    L = native.lib()
+    spec = synth.synth_glow_spec(43, 64, 2, seed=0)
+    f = native.NativeFlow(spec)
+    mix = native.NativeMixture([f])
+    x = torch.zeros((64, 43), device=dev)
+    out = torch.zeros((1, 64), device=dev)
+    vp = C.c_void_p
+    arr = (vp * 1)(x.data_ptr())
+    s = native._stream_ptr()
+    assert L.gbnf_mixture_component_log_prob_multi(mix.handle, arr, 0, 64, 0, 1, vp(out.data_ptr()), 64, s) < 0     # n_batches < 1
+    assert L.gbnf_mixture_component_log_prob_multi(mix.handle, arr, 17, 64, 0, 1, vp(out.data_ptr()), 64 * 17, s) < 0
+    assert L.gbnf_mixture_component_log_prob_multi(mix.handle, arr, 1, 64, 0, 1, vp(out.data_ptr()), 63, s) < 0    # stride < n
+    assert L.gbnf_mixture_component_log_prob_strided(mix.handle, vp(x.data_ptr()), 64, 0, 2, vp(out.data_ptr()), 64, s) < 0
+    assert b"component range" in L.gbnf_last_error()
+    assert L.gbnf_actnorm_init(vp(x.data_ptr()), 0, 43, 1.0, vp(out.data_ptr()), vp(out.data_ptr()), s) < 0
+    assert L.gbnf_actnorm_init(vp(x.data_ptr()), 64, 65, 1.0, vp(out.data_ptr()), vp(out.data_ptr()), s) < 0
+    assert L.gbnf_boosting_weights(vp(out.data_ptr()), 0, 1.0, vp(out.data_ptr()), s) < 0
+    assert L.gbnf_boosting_weights(None, 4, 1.0, vp(out.data_ptr()), s) < 0
+    with pytest.raises(native.GbnfError):
+        native.actnorm_init(torch.zeros((0, 43), device=dev))
+    with pytest.raises(native.GbnfError):
+        native.boosting_weights(torch.zeros((4,)))          # CPU tensor
+    # a correct call still works afterwards
+    mix.prepared_group_log_prob([x], out)(s)
+    assert torch.isfinite(out).all()
