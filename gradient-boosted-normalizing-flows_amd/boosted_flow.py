@@ -254,6 +254,7 @@ class BoostedFlow(nn.Module):
             else:
                 raise NotImplementedError("Only glow and realnvp components are currently implemented")
         self._handles = {}      # c -> (version key, NativeFlow)
+        self._handles_exact = {}   # c -> (version key, exact-f32 NativeFlow), inverse direction only
         self._mixture = None    # (version key, NativeMixture)
         dev = getattr(args, "device", None)
         if dev is not None:
@@ -302,10 +303,19 @@ class BoostedFlow(nn.Module):
         z_mu, z_var = h[:, : self.z_size], h[:, self.z_size:]
         return z, z_mu, z_var, ldj, None
 
+    @torch.no_grad()
     def decode(self, z, y_onehot, temperature, components):
-        raise NotImplementedError(
-            "reverse / sampling is not on the supported path: the reference's own BoostedFlow.decode always "
-            "raises TypeError (models/boosted_flow.py:216 passes y_onhot=) -- SURVEY.md S3")
+        """z -> x through ONE (given or sampled) component: what models/boosted_flow.py:209-218 is meant to do (the
+        reference's own call raises TypeError: :216 passes ``y_onhot=``).  ``z is None`` draws ``sample_size`` rows from
+        the prior, N(0, temperature) as Glow.decode / RealNVPFlow.decode do (models/glow.py:114-116,
+        models/realnvp.py:99-101: prior mean 0, "z_var" 0 -> std = exp(0) * temperature)."""
+        c = self._sample_component(components) if isinstance(components, str) else int(components)
+        if z is None:
+            t = 1.0 if temperature is None else float(temperature)
+            dev = self.rho.device
+            z = torch.randn(int(self.args.sample_size), self.z_size, device=dev, dtype=torch.float32) * t
+        x, _ = self.component_inverse(z, c)
+        return x
 
     def forward(self, x=None, y_onehot=None, z=None, temperature=None, components=None, reverse=False):
         if reverse:
@@ -419,6 +429,14 @@ class BoostedFlow(nn.Module):
             self._mixture = None
         return self._handles[c][1]
 
+    def native_flow_exact(self, c):
+        """The exact-f32 handle of component c: the inverse direction runs on that kernel only."""
+        key = self._component_key(c)
+        cached = self._handles_exact.get(c)
+        if cached is None or cached[0] != key:
+            self._handles_exact[c] = (key, native.NativeFlow(gspec.spec_from_component(self.flows[c]), math="f32"))
+        return self._handles_exact[c][1]
+
     def native_mixture(self):
         flows = [self.native_flow(c) for c in range(self.num_components)]
         key = tuple(id(f) for f in flows)
@@ -435,6 +453,15 @@ class BoostedFlow(nn.Module):
         with torch.cuda.device(x.device):
             z, ldj, _ = self.native_flow(int(c)).forward(x)
         return z, ldj
+
+    def component_inverse(self, z, c):
+        """z (N,d) -> x (N,d), log|det dx/dz| (N,) of component c: inverse of ``component_forward``."""
+        self._check_ready(z)
+        z = z.contiguous().float()
+        if not all(bool(l.actnorm.inited) for l in getattr(getattr(self.flows[int(c)], "flow", None), "layers", [])):
+            raise ValueError("ActNorm not initiated: run a forward pass on data first (models/layers.py:473-475)")
+        with torch.cuda.device(z.device):
+            return self.native_flow_exact(int(c)).inverse(z)
 
     def component_log_prob(self, x, n_used=None):
         """(N, C_used): ll_c(x) = log N(z_c;0,I) + ldj_c for c < n_used, all in ONE launch

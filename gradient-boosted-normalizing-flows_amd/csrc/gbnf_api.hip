@@ -488,6 +488,7 @@ int gbnf_flow_create_mode(const gbnf_flow_desc* desc, int32_t math_mode, gbnf_fl
         sigma[j] = prev[m];
         P0[j] = st.actnorm_bias[m];
         P1[j] = expf(st.actnorm_logs[m]);
+        P2[j] = expf(-st.actnorm_logs[m]);      // for the inverse flow (ActNorm reverse multiplies by exp(-logs))
       }
       in_f = d1; out_f = d2;
       for (int j = 0; j < d1; ++j) in_feat.push_back(j);
@@ -633,7 +634,8 @@ static unsigned long long* g_stamp_buf = nullptr;
 
 static int launch_flow(const gbnf_flow* f, const uint32_t* const* table, int c_begin, int n_comp, const float* x,
                        int64_t n, float* z, float* ldj, float* ll, const float* base, hipStream_t stream,
-                       int64_t out_stride = -1, const float* const* xs = nullptr, int n_batches = 1) {
+                       int64_t out_stride = -1, const float* const* xs = nullptr, int n_batches = 1,
+                       int inverse = 0) {
   if (n == 0 || n_comp == 0 || n_batches == 0) return GBNF_OK;
   const int nt = pick_nt(n * n_batches, n_comp);
   const int64_t tiles = (n + 16 * nt - 1) / (16 * nt);
@@ -644,6 +646,7 @@ static int launch_flow(const gbnf_flow* f, const uint32_t* const* table, int c_b
   FlowLaunch p{};
   p.blobs = table; p.z_out = z; p.ldj_out = ldj; p.ll_out = ll;
   p.n_batches = n_batches;
+  p.inverse = inverse;
   for (int b = 0; b < n_batches; ++b) p.xs[b] = xs ? xs[b] : x;
   p.base_mean = base; p.base_std = base ? base + f->d : nullptr;
   p.n = n; p.out_stride = out_stride < 0 ? n * n_batches : out_stride; p.d = f->d; p.n_steps = f->n_steps; p.c_begin = c_begin; p.n_comp = n_comp;
@@ -790,6 +793,16 @@ int gbnf_flow_forward(const gbnf_flow* flow, const float* x, int64_t n, float* z
   if (n < 0) return fail(GBNF_ERR_INVALID, "gbnf_flow_forward: n < 0");
   if (n > 0 && !x) return fail(GBNF_ERR_INVALID, "gbnf_flow_forward: x is null");
   return launch_flow(flow, flow->self_table_dev, 0, 1, x, n, z, ldj, ll, nullptr, (hipStream_t)stream);
+}
+
+int gbnf_flow_inverse(const gbnf_flow* flow, const float* z, int64_t n, float* x, float* ldj, void* stream) {
+  if (!flow) return fail(GBNF_ERR_INVALID, "gbnf_flow_inverse: flow is null");
+  if (flow->math_mode != GBNF_MATH_F32)
+    return fail(GBNF_ERR_UNSUPPORTED, "gbnf_flow_inverse runs on the exact-f32 kernel: create the handle with GBNF_MATH_F32");
+  if (n < 0) return fail(GBNF_ERR_INVALID, "gbnf_flow_inverse: n < 0");
+  if (n > 0 && (!z || !x)) return fail(GBNF_ERR_INVALID, "gbnf_flow_inverse: z / x is null");
+  return launch_flow(flow, flow->self_table_dev, 0, 1, z, n, x, ldj, nullptr, nullptr, (hipStream_t)stream, -1,
+                     nullptr, 1, 1);
 }
 
 int gbnf_mixture_create(gbnf_flow* const* flows, int32_t n_flows, gbnf_mixture** out) {

@@ -86,6 +86,7 @@ struct FlowLaunch {
   int32_t n_tiles;               // ceil(n / (16*NT))
   int32_t additive;              // glow: additive coupling
   int32_t n_batches;             // 1..MAX_BATCHES (z_out / ldj_out only with 1)
+  int32_t inverse;               // f32 kernel only: run the flow backwards (xs = z in, z_out = x out, ldj_out = log|det dx/dz|)
   unsigned long long* dbg;       // diagnostic builds (-DGBNF_STAMPS) only: per-block phase cycle sums
 };
 
@@ -449,6 +450,17 @@ __device__ __forceinline__ float norm_fn(float v, float p0, float p1, float p2, 
   }
 }
 
+// x = norm^-1(y).  ActNorm reverse: y * exp(-logs) - bias (models/layers.py:493-533, the packer stores exp(-logs) in
+// p2); BatchNorm.inverse: (y - beta) * exp(-log_gamma) * sqrt(var + eps) + mean (models/layers.py:360-372).
+template <int KIND>
+__device__ __forceinline__ float invnorm_fn(float y, float p0, float p1, float p2, float p3) {
+  if constexpr (KIND == GBNF_KIND_GLOW) {
+    return y * p2 - p0;
+  } else {
+    return ((y - p3) / p2) * p1 + p0;
+  }
+}
+
 // scale = sigmoid(v) and log(scale) from one exp: e = exp(-v); scale = 1/(1+e); log scale = -log(1+e).
 // (the reference takes log() of the rounded sigmoid, models/glow.py:333-338; both are within an ulp or
 // two of the exact value).  v_exp_f32 / v_rcp_f32 / v_log_f32 are 1-ulp instructions.
@@ -535,8 +547,11 @@ __global__ void __launch_bounds__(64) flow_kernel(const FlowLaunch p) {
   const int d = p.d;
   const int64_t row0 = (int64_t)tile * (16 * NT);
   const float* __restrict__ xin = p.xs[batch];
+  const uint32_t* tail = blob + (size_t)p.n_steps * STEP_WORDS;   // final slot of logical feature j
+  const bool inv = p.inverse != 0;
 
   // ---- per-step index/normalisation tables -> LDS (1.3 KB per step), x tile -> Z[feature][sample]
+  //      (inverse: the input is z in the reference's output order, so feature j starts in its FINAL slot)
   if (lds_tables) {
     for (int s = 0; s < p.n_steps; ++s) {
       const uint32_t* src = blob + (size_t)s * STEP_WORDS;
@@ -545,12 +560,13 @@ __global__ void __launch_bounds__(64) flow_kernel(const FlowLaunch p) {
     }
   }
   if (lane < d) {
+    const int zslot = inv ? (int)tail[lane] : lane;
 #pragma unroll 8
     for (int r = 0; r < 16 * NT; ++r) {
       const int64_t n = row0 + r;
       float v = 0.0f;
       if (n < p.n) v = xin[n * d + lane];
-      Z[lane * ZS + r] = v;
+      Z[zslot * ZS + r] = v;
     }
   }
   __syncthreads();
@@ -562,19 +578,22 @@ __global__ void __launch_bounds__(64) flow_kernel(const FlowLaunch p) {
   Stamps st;
   st.start();
 
-  for (int step = 0; step < p.n_steps; ++step) {
+  for (int it = 0; it < p.n_steps; ++it) {
+    const int step = inv ? p.n_steps - 1 - it : it;      // the inverse undoes the steps last to first
     const uint32_t* __restrict__ sp = blob + (size_t)step * STEP_WORDS;
     LaneTable tin, tout;
+    float step_ld;
     if (lds_tables) {
       const uint32_t* sm = SM + step * SMALL_WORDS;
-      ld_const += as_f32(sm[1]);
+      step_ld = as_f32(sm[1]);
       tin.load(sm + SMALL_HDR + g * NENT);
       tout.load(sm + SMALL_HDR + 160 + g * NENT);
     } else {
-      ld_const += as_f32(sp[1]);
+      step_ld = as_f32(sp[1]);
       tin.load(sp + SMALL_HDR + g * NENT);
       tout.load(sp + SMALL_HDR + 160 + g * NENT);
     }
+    ld_const += inv ? -step_ld : step_ld;
 
     // ---- normalise the coupling net's inputs in place; they are the first layer's B operands
     float zb[KS1][NT];
@@ -585,8 +604,13 @@ __global__ void __launch_bounds__(64) flow_kernel(const FlowLaunch p) {
 #pragma unroll
       for (int nt = 0; nt < NT; ++nt) {
         float v = Z[zoff + 16 * nt];
-        v = norm_fn<KIND>(v, tin.p0[e], tin.p1[e], tin.p2[e], tin.p3[e]);
-        if (live) Z[zoff + 16 * nt] = v;
+        if (!inv) {
+          v = norm_fn<KIND>(v, tin.p0[e], tin.p1[e], tin.p2[e], tin.p3[e]);
+          if (live) Z[zoff + 16 * nt] = v;
+        } else if (live) {
+          // the stored value IS the normalised input of the net; un-normalise it for the preceding step
+          Z[zoff + 16 * nt] = invnorm_fn<KIND>(v, tin.p0[e], tin.p1[e], tin.p2[e], tin.p3[e]);
+        }
         zb[e][nt] = live ? v : 0.0f;
       }
     }
@@ -612,11 +636,17 @@ __global__ void __launch_bounds__(64) flow_kernel(const FlowLaunch p) {
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) {
           float v = Z[zoff + 16 * nt];
-          v = norm_fn<KIND>(v, tout.p0[e], tout.p1[e], tout.p2[e], tout.p3[e]);
           const float shift = outA[o][nt][2 * pp], raw = outA[o][nt][2 * pp + 1];
           float sc, lsc;
           sigmoid_logsigmoid(raw + 2.0f, sc, lsc);
-          v = (v + shift) * sc;
+          if (!inv) {
+            v = norm_fn<KIND>(v, tout.p0[e], tout.p1[e], tout.p2[e], tout.p3[e]);
+            v = (v + shift) * sc;
+          } else {
+            v = v / sc - shift;                                   // FlowStep.decode, models/glow.py:352-355
+            v = invnorm_fn<KIND>(v, tout.p0[e], tout.p1[e], tout.p2[e], tout.p3[e]);
+            lsc = -lsc;
+          }
           if (live) {
             Z[zoff + 16 * nt] = v;
             ld[nt] += lsc;
@@ -632,16 +662,22 @@ __global__ void __launch_bounds__(64) flow_kernel(const FlowLaunch p) {
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) {
           float v = Z[zoff + 16 * nt];
-          v = norm_fn<KIND>(v, tout.p0[e], tout.p1[e], tout.p2[e], tout.p3[e]);
+          if (!inv) v = norm_fn<KIND>(v, tout.p0[e], tout.p1[e], tout.p2[e], tout.p3[e]);
           if constexpr (KIND == GBNF_KIND_GLOW) {
-            v = v + outA[o][nt][r];                       // additive, models/glow.py:328-329
+            v = inv ? v - outA[o][nt][r] : v + outA[o][nt][r];      // additive, models/glow.py:328-329 / 349-350
+            if (inv) v = invnorm_fn<KIND>(v, tout.p0[e], tout.p1[e], tout.p2[e], tout.p3[e]);
             if (live) Z[zoff + 16 * nt] = v;
           } else {
             const float shift = outA[o][nt][r], scale = outB[o][nt][r];
-            v = shift + v * exp_fast(scale);              // models/transformations.py:575
+            if (!inv) {
+              v = shift + v * exp_fast(scale);            // models/transformations.py:575
+            } else {
+              v = (v - shift) * exp_fast(-scale);         // the true inverse of :575 (the reference's own
+              v = invnorm_fn<KIND>(v, tout.p0[e], tout.p1[e], tout.p2[e], tout.p3[e]);   // .inverse is not: SURVEY S3)
+            }
             if (live) {
               Z[zoff + 16 * nt] = v;
-              ld[nt] += scale;                            // models/transformations.py:577
+              ld[nt] += inv ? -scale : scale;             // models/transformations.py:577
             }
           }
         }
@@ -652,7 +688,6 @@ __global__ void __launch_bounds__(64) flow_kernel(const FlowLaunch p) {
   }
 
   // ---- base log-density + log|det J|, folded over the 4 lane groups
-  const uint32_t* tail = blob + (size_t)p.n_steps * STEP_WORDS;   // final slot of logical feature j
   float quad[NT];
 #pragma unroll
   for (int nt = 0; nt < NT; ++nt) quad[nt] = 0.0f;
@@ -685,9 +720,9 @@ __global__ void __launch_bounds__(64) flow_kernel(const FlowLaunch p) {
     }
   }
 
-  // ---- z in the reference's feature order (post-permutation, post-swap)
+  // ---- z in the reference's feature order (post-permutation, post-swap); inverse: x, feature j sits in slot j
   if (p.z_out != nullptr && lane < d) {
-    const int slot = (int)tail[lane];
+    const int slot = inv ? lane : (int)tail[lane];
     float* zo = p.z_out + (int64_t)comp * p.n * d;
 #pragma unroll 8
     for (int r = 0; r < 16 * NT; ++r) {

@@ -24,6 +24,7 @@ MATH = {"default": -1, "f32": 0, "f16x3": 1}
 ABI_SYMBOLS = (
     "gbnf_version", "gbnf_last_error",
     "gbnf_flow_create", "gbnf_flow_create_mode", "gbnf_flow_destroy", "gbnf_flow_info", "gbnf_flow_forward",
+    "gbnf_flow_inverse",
     "gbnf_mixture_create", "gbnf_mixture_destroy", "gbnf_mixture_set_base",
     "gbnf_mixture_component_log_prob", "gbnf_mixture_component_log_prob_strided",
     "gbnf_mixture_component_log_prob_multi", "gbnf_mixture_lse",
@@ -90,6 +91,7 @@ def lib():
     L.gbnf_flow_destroy.argtypes = [vp]
     L.gbnf_flow_info.argtypes = [vp, C.POINTER(KernelInfo)]
     L.gbnf_flow_forward.argtypes = [vp, vp, i64, vp, vp, vp, vp]
+    L.gbnf_flow_inverse.argtypes = [vp, vp, i64, vp, vp, vp]
     L.gbnf_mixture_create.argtypes = [C.POINTER(vp), i32, C.POINTER(vp)]
     L.gbnf_mixture_destroy.argtypes = [vp]
     L.gbnf_mixture_set_base.argtypes = [vp, C.POINTER(C.c_float), C.POINTER(C.c_float)]
@@ -220,6 +222,19 @@ class NativeFlow:
         ptr = lambda t: C.c_void_p(t.data_ptr()) if t is not None and t.numel() else C.c_void_p(0)
         _check(lib().gbnf_flow_forward(self.handle, ptr(x), n, ptr(z), ptr(ldj), ptr(ll), _stream_ptr()))
         return z, ldj, ll
+
+    def inverse(self, z, want_ldj=True):
+        """z (n,d) -> (x (n,d), log|det dx/dz| (n,) | None).  Needs a handle created with math="f32"."""
+        import torch
+        _require_device_f32(z, "z")
+        if z.dim() != 2 or z.shape[1] != self.d:
+            raise GbnfError(f"z must be (n,{self.d}), got {tuple(z.shape)}")
+        n = z.shape[0]
+        x = torch.empty_like(z)
+        ldj = torch.empty(n, dtype=torch.float32, device=z.device) if want_ldj else None
+        ptr = lambda t: C.c_void_p(t.data_ptr()) if t is not None and t.numel() else C.c_void_p(0)
+        _check(lib().gbnf_flow_inverse(self.handle, ptr(z), n, ptr(x), ptr(ldj), _stream_ptr()))
+        return x, ldj
 
     def close(self):
         if getattr(self, "handle", None):

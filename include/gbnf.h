@@ -133,6 +133,12 @@ int gbnf_flow_info(const gbnf_flow* flow, gbnf_kernel_info* info);
 int gbnf_flow_forward(const gbnf_flow* flow, const float* x, int64_t n,
                       float* z, float* ldj, float* ll, void* stream);
 
+/* The flow backwards, z (n,d) -> x (n,d) and log|det dx/dz| (n,) (= -ldj of the forward pass at x): what
+ * BoostedFlow.decode / Glow.decode / FlowStep.decode (models/boosted_flow.py:209-218, models/glow.py:112-123, 344-366)
+ * and RealNVPFlow.decode (models/realnvp.py:97-113) are meant to do.  In the reference this direction is dead or wrong
+ * on tabular data, so parity is defined by inverse(forward(x)) == x.  Needs a GBNF_MATH_F32 handle. */
+int gbnf_flow_inverse(const gbnf_flow* flow, const float* z, int64_t n, float* x, float* ldj, void* stream);
+
 /* Replaces: the nn.ModuleList of components (models/boosted_flow.py:42).  All flows must
  * share one architecture (they do: every component is built from the same args).
  * The mixture does NOT take ownership of the flows; they must outlive it. */

@@ -240,6 +240,72 @@ def component_forward(spec, x, backend="torch", return_steps=False):
     return ops.to_numpy(z), ops.to_numpy(ld)
 
 
+# --------------------------------------------------------------------------
+# the z -> x direction
+# --------------------------------------------------------------------------
+def glow_step_inverse(ops, spec, step, z, ld):
+    """FlowStep.decode, models/glow.py:344-366: coupling^-1, permutation^-1 (Permute1d reverse, models/layers.py:661-668:
+    x[:, perm[j]] = z[:, j]), ActNorm reverse (models/layers.py:493-533: x * exp(-logs) - bias, logdet -= sum(logs)).
+    The reference's affine branch cannot run on 2-D input (its logdet sums over dims [1,2,3], :357); the arithmetic of
+    :352-355 is restated here with the sum over features."""
+    d = spec["d"]
+    z1, z2 = z[:, : d // 2], z[:, d // 2:]
+    h = coupling_net(ops, step["net"], z1)
+    if spec["coupling"] == "additive":
+        z2 = z2 - h
+    else:
+        shift, raw = h[:, 0::2], h[:, 1::2]
+        scale = ops.sigmoid(raw + 2.0)
+        z2 = z2 / scale
+        z2 = z2 - shift
+        ld = ld - ops.sum1(ops.log(scale))
+    y = ops.cat([z1, z2])
+    perm = np.asarray(step["perm"], dtype=np.int64)
+    inv = np.empty_like(perm)
+    inv[perm] = np.arange(perm.size)
+    y = y[:, ops.idx(inv)]
+    bias = ops.arr(step["an_bias"]).reshape(1, -1)
+    logs = ops.arr(step["an_logs"]).reshape(1, -1)
+    x = y * ops.exp(-logs) - bias
+    return x, ld - logs.sum()
+
+
+def realnvp_step_inverse(ops, spec, step, z):
+    """The true inverse of RealNVP.forward (models/transformations.py:560-579) followed by BatchNorm.inverse
+    (models/layers.py:360-372, running statistics).  NOT a restatement of models/transformations.py:581-599, which
+    feeds the transformed half to the nets and therefore does not invert ``forward``."""
+    d = spec["d"]
+    n1 = d - d // 2 if step["flipped"] else d // 2          # forward emits cat[z1, z2] with z1 = the upper half when flipped
+    z1, z2 = z[:, :n1], z[:, n1:]
+    shift = coupling_net(ops, step["t_net"], z1)
+    scale = coupling_net(ops, step["s_net"], z1)
+    x2 = (z2 - shift) * ops.exp(-scale)
+    x = ops.cat([x2, z1]) if step["flipped"] else ops.cat([z1, x2])
+    ld = -ops.sum1(scale)
+    bn = step["bn"]
+    if bn is not None:
+        mean, var = ops.arr(bn["running_mean"]), ops.arr(bn["running_var"])
+        log_gamma, beta = ops.arr(bn["log_gamma"]), ops.arr(bn["beta"])
+        x = (x - beta) * ops.exp(-log_gamma) * ops.sqrt(var + bn["eps"]) + mean
+        ld = ld + (0.5 * ops.log(var + bn["eps"]) - log_gamma).sum()
+    return x, ld
+
+
+def component_inverse(spec, z, backend="torch"):
+    """z (N,d) -> x (N,d), log|det dx/dz| (N,): FlowNet.decode (models/glow.py:254-260) / RealNVPFlow.decode
+    (models/realnvp.py:97-113) with the steps undone last to first."""
+    ops = _ops(backend)
+    x = ops.arr(z)
+    ld = ops.zeros(x.shape[0])
+    for step in reversed(spec["steps"]):
+        if spec["kind"] == "glow":
+            x, ld = glow_step_inverse(ops, spec, step, x, ld)
+        else:
+            x, step_ld = realnvp_step_inverse(ops, spec, step, x)
+            ld = ld + step_ld
+    return ops.to_numpy(x), ops.to_numpy(ld)
+
+
 def log_normal_standard_sum(ops, z):
     """log_normal_standard(z, reduce=True, dim=-1): utils/distributions.py:44-60."""
     log_norm = (-0.5 * LOG_2PI) - (0.5 * z * z)

@@ -18,10 +18,20 @@ def pytest_configure(config):
 
 
 def golden_names():
-    """Forward/mixture fixtures (g1..g6).  g7 (ActNorm data-dependent init) and g8 (boosting weights) have their
-    own tests."""
+    """Forward/mixture fixtures (g1..g6).  g7 (ActNorm data-dependent init), g8 (boosting weights) and g9 (decode)
+    have their own tests."""
     names = sorted(os.path.splitext(os.path.basename(p))[0] for p in glob.glob(os.path.join(GOLDEN_DIR, "*.npz")))
-    return [n for n in names if not n.startswith(("g7_", "g8_"))]
+    return [n for n in names if not n.startswith(("g7_", "g8_", "g9_"))]
+
+
+def load_decode_case():
+    """g9: (specs, z, x_ref (C,N,d)) -- the reference's own Glow.decode on additive tabular components."""
+    from gbnf_amd import synth
+    data = dict(np.load(os.path.join(GOLDEN_DIR, "g9_glow_additive_decode.npz")))
+    cfg = json.loads(bytes(data["config"]).decode())
+    specs = synth.synth_boosted_specs("glow", cfg["C"], cfg["d"], cfg["h"], cfg["K"], seed=cfg["w_seed"], **cfg["synth_kw"])
+    z = synth.synth_batch(cfg["N"], cfg["d"], seed=cfg["z_seed"], scale=cfg["z_scale"])
+    return specs, z, data["x"]
 
 
 def load_actnorm_init_case():

@@ -296,8 +296,34 @@ def boosting_weights_case(name):
     print(name, {k: float(v.max()) for k, v in out.items() if k.endswith(".w")})
 
 
+def decode_case(name, d=43, h=64, K=5, C=2, N=96):
+    """G9: the z -> x direction, by the reference itself.  On tabular data only ``Glow.decode`` with ADDITIVE coupling
+    runs in the reference: the affine branch sums its log-scale over image dims (models/glow.py:357 -> IndexError on
+    2-D input), ``RealNVP.inverse`` conditions on the wrong half (models/transformations.py:581-599: it is not the
+    inverse of ``forward``), and ``BoostedFlow.decode`` passes a misspelt keyword (models/boosted_flow.py:216).  So the
+    fixture calls ``model.flows[c].decode(z, None, None)`` (models/glow.py:112-123) on additive components; the other
+    kinds are pinned by the round trip inverse(forward(x)) == x in the tests."""
+    specs = synth.synth_boosted_specs("glow", C, d, h, K, seed=31, coupling="additive")
+    model = RefBoostedFlow(ref_args("glow", d, h, K, C, coupling="additive")).eval()
+    for c in range(C):
+        install_spec(model.flows[c], specs[c])
+    z = synth.synth_batch(N, d, seed=17, scale=1.3)
+    xs = []
+    with torch.no_grad():
+        for c in range(C):
+            xs.append(model.flows[c].decode(torch.from_numpy(z).clone(), None, None).numpy().copy())
+    cfg = dict(case="decode", kind="glow", d=d, h=h, K=K, C=C, N=N, w_seed=31, z_seed=17, z_scale=1.3,
+               synth_kw=dict(coupling="additive"))
+    np.savez_compressed(os.path.join(HERE, name + ".npz"),
+                        config=np.frombuffer(json.dumps(cfg).encode(), dtype=np.uint8), x=np.stack(xs))
+    print(f"{name}: x[0,0,:3]={xs[0][0, :3]}")
+
+
 def main():
     torch.set_num_threads(4)
+    if "--decode-only" in sys.argv:
+        decode_case("g9_glow_additive_decode")
+        return
     if "--boosting-only" in sys.argv:
         boosting_weights_case("g8_boosting_weights")
         return
@@ -310,6 +336,7 @@ def main():
     state_dict_layout_case()
     actnorm_init_case("g7_glow_actnorm_data_init")
     boosting_weights_case("g8_boosting_weights")
+    decode_case("g9_glow_additive_decode")
     toy_case("g1_toy_realnvp_c2")
     native_glow_case("g2_glow_native_d43_h32_c3")
     # G3: MINIBOONE full width (BASELINE.json metric config), synthetic weights

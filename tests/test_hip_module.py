@@ -236,3 +236,20 @@ def test_boosting_weights_match_reference(golden_case):
     np.testing.assert_allclose(w.cpu().numpy(), oracle.boosting_weights(G_ref), rtol=2e-4, atol=1e-9)
     idx = torch.multinomial(w, x.shape[0], replacement=True)           # the caller's resampling step works on it
     assert idx.shape == (x.shape[0],) and abs(float(w.sum()) - 1.0) < 1e-5
+
+
+def test_decode_inverts_encode(golden_case):
+    """model(z=..., reverse=True) undoes model(x=...) for a fixed component; z=None samples sample_size rows."""
+    import torch
+    dev = torch.device("cuda:0")
+    for name in ("g2_glow_native_d43_h32_c3", "g4_realnvp_d21_h105_c8"):
+        g = golden_case(name)
+        m = _model_from_case(g, dev)
+        x = torch.from_numpy(g.x).to(dev)
+        for c in (0, g.cfg["C"] - 1):
+            z = m(x=x, components=c)[0]
+            xr = m(z=z, temperature=1.0, components=c, reverse=True)
+            assert (xr - x).abs().max().item() <= 2e-5 * max(1.0, float(x.abs().max()))
+        m.component = g.cfg["C"] - 1
+        s = m(z=None, temperature=0.7, components="1:c", reverse=True)
+        assert s.shape == (4, g.cfg["d"]) and torch.isfinite(s).all()

@@ -258,3 +258,63 @@ def test_new_entry_points_reject_bad_arguments(dev):
     # a correct call still works afterwards
     mix.prepared_group_log_prob([x], out)(s)
     assert torch.isfinite(out).all()
+
+
+# ------------------------------------------------------------------ z -> x
+INV_NAMES = ["g3_glow_d43_h215_c8", "g4_realnvp_d21_h105_c8", "g5_glow_d43_h64_c2_additive",
+             "g5_glow_d43_h64_c2_reverse_relu", "g5_glow_d43_h64_c2_depth2", "g5_glow_d43_h64_c2_depth0",
+             "g4_realnvp_d21_h105_c2_relu_nobn", "g5_realnvp_d6_h30_c3", "g6_glow_d43_h64_n77", "g6_glow_d43_h64_n1",
+             "g5_glow_d63_h128_c2", "g6_realnvp_d21_h64_n33"]
+
+
+@pytest.mark.parametrize("name", INV_NAMES)
+def test_inverse_matches_oracle_and_round_trips(name, golden_case):
+    """gbnf_flow_inverse against the float64 oracle on the reference's z, plus inverse(forward(x)) == x through the
+    device kernels alone.  x tolerance 2e-5 of the data scale (f32 coupling nets on both legs)."""
+    import torch
+    from gbnf_amd import native
+    from oracle import gbnf_oracle as oracle
+    g = golden_case(name)
+    for c, spec in enumerate(g.specs[:3]):
+        flow = native.NativeFlow(spec, math="f32")
+        z_ref = g.z(c)                      # the reference's own z where the fixture holds it
+        if z_ref is None:
+            z_ref = oracle.component_forward(spec, g.x, backend="numpy64")[0]
+        z_ref = np.ascontiguousarray(z_ref, dtype=np.float32)
+        x_or, ild_or = oracle.component_inverse(spec, z_ref, backend="numpy64")
+        x, ild = flow.inverse(torch.from_numpy(z_ref).cuda())
+        scale = max(1.0, float(np.abs(x_or).max()))
+        assert np.abs(x.cpu().numpy() - x_or).max() <= 2e-5 * scale
+        assert np.abs(ild.cpu().numpy() - ild_or).max() <= 1e-5 * max(1.0, float(np.abs(ild_or).max()))
+        xd = torch.from_numpy(g.x).cuda()
+        z, ldj, _ = flow.forward(xd)
+        xr, ild2 = flow.inverse(z)
+        assert (xr - xd).abs().max().item() <= 2e-5 * max(1.0, float(np.abs(g.x).max()))
+        assert (ild2 + ldj).abs().max().item() <= 1e-5 * max(1.0, float(ldj.abs().max()))
+
+
+def test_inverse_matches_reference_decode():
+    """g9: the reference's own Glow.decode output (additive coupling)."""
+    import torch
+    from conftest import load_decode_case
+    from gbnf_amd import native
+    specs, z, x_ref = load_decode_case()
+    for c, spec in enumerate(specs):
+        x, _ = native.NativeFlow(spec, math="f32").inverse(torch.from_numpy(z).cuda())
+        assert np.abs(x.cpu().numpy() - x_ref[c]).max() <= 2e-5 * max(1.0, float(np.abs(x_ref[c]).max()))
+
+
+def test_inverse_needs_exact_handle_and_large_n(golden_case):
+    import torch
+    from gbnf_amd import native
+    g = golden_case("g3_glow_d43_h215_c8")
+    with pytest.raises(native.GbnfError):
+        native.NativeFlow(g.specs[0], math="f16x3").inverse(torch.zeros(4, 43, device="cuda"))
+    flow = native.NativeFlow(g.specs[0], math="f32")
+    x = torch.randn(20001, 43, device="cuda") * 1.5
+    z, ldj, _ = flow.forward(x)
+    xr, ild = flow.inverse(z)
+    assert (xr - x).abs().max().item() <= 5e-5 * float(x.abs().max())
+    assert (ild + ldj).abs().max().item() <= 1e-5 * float(ldj.abs().max())
+    xe, _ = flow.inverse(torch.zeros(0, 43, device="cuda"))
+    assert xe.shape == (0, 43)

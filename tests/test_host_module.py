@@ -86,7 +86,7 @@ def test_no_cpu_fallback_and_guards():
         m(x=x, components=0)
     with pytest.raises(native.GbnfError):
         m.log_prob(x)
-    with pytest.raises(NotImplementedError):   # the reference's decode is dead code (S3)
+    with pytest.raises(native.GbnfError):      # the inverse direction has no CPU path either
         m(z=x, components=0, reverse=True)
     with pytest.raises(NotImplementedError):
         BoostedFlow(make_args(coupling_network="residual"))

@@ -2,7 +2,7 @@
 import numpy as np
 import pytest
 
-from conftest import golden_names, load_actnorm_init_case, rel_err
+from conftest import golden_names, load_actnorm_init_case, load_decode_case, rel_err
 from oracle import gbnf_oracle as oracle
 
 LL_RTOL = 1e-5     # BASELINE.json: log-likelihood within 1e-5 relative
@@ -83,3 +83,26 @@ def test_boosting_weights_match_reference():
         w = oracle.boosting_weights(data[key + ".G"], float(data[key + ".beta"]))
         np.testing.assert_allclose(w, data[key + ".w"], rtol=1e-6, atol=0)
         assert abs(float(w.sum()) - 1.0) < 1e-5
+
+
+def test_inverse_matches_reference_decode():
+    """g9: the reference's own Glow.decode (additive coupling, the one tabular z->x branch it can run)."""
+    specs, z, x_ref = load_decode_case()
+    for c, spec in enumerate(specs):
+        x, ld = oracle.component_inverse(spec, z)
+        assert np.abs(x - x_ref[c]).max() <= 2e-5 * max(1.0, np.abs(x_ref[c]).max())
+        x64, _ = oracle.component_inverse(spec, z, backend="numpy64")
+        assert np.abs(x64 - x_ref[c]).max() <= 2e-5 * max(1.0, np.abs(x_ref[c]).max())
+
+
+@pytest.mark.parametrize("name", ["g3_glow_d43_h215_c8", "g4_realnvp_d21_h105_c8", "g5_glow_d43_h64_c2_additive",
+                                  "g5_glow_d43_h64_c2_reverse_relu", "g5_glow_d43_h64_c2_depth2",
+                                  "g4_realnvp_d21_h105_c2_relu_nobn", "g5_realnvp_d6_h30_c3"])
+def test_inverse_round_trip(name, golden_case):
+    """inverse(forward(x)) == x and ldj_inverse == -ldj_forward, in float64 (kinds the reference cannot decode)."""
+    g = golden_case(name)
+    for c, spec in enumerate(g.specs[:2]):
+        z, ldj = oracle.component_forward(spec, g.x, backend="numpy64")
+        x, ild = oracle.component_inverse(spec, z, backend="numpy64")
+        assert np.abs(x - g.x).max() <= 1e-9 * max(1.0, np.abs(g.x).max())
+        assert np.abs(ild + ldj).max() <= 1e-9 * max(1.0, np.abs(ldj).max())
