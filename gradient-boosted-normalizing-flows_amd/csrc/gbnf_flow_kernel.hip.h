@@ -624,6 +624,13 @@ __global__ void __launch_bounds__(64) flow_kernel(const FlowLaunch p) {
       coupling_net<HT, KSL, KS1, OT, NT, LMID, ACTB>(sp + SMALL_WORDS + L.NET_WORDS, zb, lane, g, outB, st);
     }
 
+    // The epilogue's first accumulator reads may sit directly behind a (direction) branch, 2-3 issue slots after the
+    // last MFMA; the compiler's MFMA-result hazard padding was seen to miss that path (gfx950, ROCm 7.2: the inverse
+    // direction read the last output row one k-step short).  16 wait states cover an 8-pass MFMA on every path.
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_nop 7\n\ts_nop 7");
+    __builtin_amdgcn_sched_barrier(0);
+
     // ---- coupling transform of the other half, in place, + per-lane log-det partials
     if (KIND == GBNF_KIND_GLOW && !p.additive) {
       // affine, "cross" split: rows 2j / 2j+1 of the last Linear are (shift_j, raw_j) and sit
