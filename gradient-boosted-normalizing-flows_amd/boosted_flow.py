@@ -222,6 +222,30 @@ class RealNVPFlow(nn.Module):
 
 
 # ----------------------------------------------------------------------------- the boosted model
+class _FlowFunction(torch.autograd.Function):
+    """(z, ldj) = flows[c](x) recorded for autograd: forward and backward both run in libgbnf_hip.so on the live
+    parameter tensors (native.NativeTrainer); activations are recomputed in the backward kernel, so only x is kept."""
+
+    @staticmethod
+    def forward(ctx, trainer, x, *params):
+        z, ldj = trainer.forward(x)
+        ctx.trainer = trainer
+        ctx.save_for_backward(x, *params)      # params: autograd's in-place-modification check only
+        return z, ldj
+
+    @staticmethod
+    def backward(ctx, g_z, g_ldj):
+        x = ctx.saved_tensors[0]
+        trainer = ctx.trainer
+        g_z = None if g_z is None else g_z.contiguous().float()
+        g_ldj = None if g_ldj is None else g_ldj.contiguous().float()
+        with torch.cuda.device(x.device):
+            g_x, grads = trainer.backward(x, g_z, g_ldj, want_gx=ctx.needs_input_grad[1])
+        out = [g for t, g in zip(trainer.params, grads) if t is not None]
+        out = [g if need else None for g, need in zip(out, ctx.needs_input_grad[2:])]
+        return (None, g_x) + tuple(out)
+
+
 class BoostedFlow(nn.Module):
     """Drop-in for models/boosted_flow.py:BoostedFlow on the density-evaluation path."""
 
@@ -255,6 +279,7 @@ class BoostedFlow(nn.Module):
                 raise NotImplementedError("Only glow and realnvp components are currently implemented")
         self._handles = {}      # c -> (version key, NativeFlow)
         self._handles_exact = {}   # c -> (version key, exact-f32 NativeFlow), inverse direction only
+        self._trainers = {}        # c -> (address key, NativeTrainer), calls recorded by autograd
         self._mixture = None    # (version key, NativeMixture)
         dev = getattr(args, "device", None)
         if dev is not None:
@@ -389,10 +414,30 @@ class BoostedFlow(nn.Module):
     def _check_ready(self, x):
         if not isinstance(x, torch.Tensor) or not x.is_cuda:
             raise native.GbnfError("x must live on the MI355X (cuda) device: this module has no CPU path")
-        if self.training and torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
-            raise RuntimeError(
-                "the HIP path is forward/density-evaluation only (no backward: SURVEY.md section 8f N3); call "
-                ".eval() or wrap the call in torch.no_grad()")
+
+    def _needs_grad(self, x, c):
+        """True when the call must be recorded by autograd: gradients enabled and the input or a parameter of
+        component c asks for one (the training step of density_experiment.py:366-374)."""
+        if not torch.is_grad_enabled():
+            return False
+        return bool(x.requires_grad) or any(p.requires_grad for p in self.flows[c].parameters())
+
+    def native_trainer(self, c):
+        """The training-path handle of component c: bound to the parameter tensors' device addresses, re-created only
+        when a tensor is re-allocated or a permutation changes (in-place optimiser updates need nothing)."""
+        flow = self.flows[c]
+        if self.component_type != "glow" and self.training and any(len(m) > 2 for m in flow.flow_param):
+            raise NotImplementedError(
+                "train-mode BatchNorm (batch statistics, models/layers.py:339-346) is not on the supported path; "
+                "differentiate RealNVP components in eval() mode (running statistics) or build them without batch_norm")
+        key = [t.data_ptr() for t in list(flow.parameters()) + list(flow.buffers())]
+        if self.component_type == "glow":
+            key += [tuple(layer.permutation.indices.tolist()) for layer in flow.flow.layers]
+        key = tuple(key)
+        cached = self._trainers.get(c)
+        if cached is None or cached[0] != key:
+            self._trainers[c] = (key, native.NativeTrainer(gspec.device_spec_from_component(flow)))
+        return self._trainers[c][1]
 
     def _ensure_actnorm(self, x, c):
         """_ActNorm.forward initialises itself from the first batch it sees in TRAIN mode and raises in eval mode
@@ -451,6 +496,10 @@ class BoostedFlow(nn.Module):
         x = x.contiguous().float()
         self._ensure_actnorm(x, int(c))
         with torch.cuda.device(x.device):
+            if self._needs_grad(x, int(c)):
+                trainer = self.native_trainer(int(c))
+                params = [t for t in trainer.params if t is not None]
+                return _FlowFunction.apply(trainer, x, *params)
             z, ldj, _ = self.native_flow(int(c)).forward(x)
         return z, ldj
 

@@ -65,8 +65,13 @@ def main(argv=None):
     api_o = os.path.join(OBJ, "gbnf_api.o")
     objs.append(api_o)
     api_src = os.path.join(HERE, "gbnf_api.hip")
+    hdr.append(os.path.join(HERE, "gbnf_internal.h"))
     if args.force or not newer(api_o, [api_src] + hdr):
         jobs.append([HIPCC] + FLAGS + ["-c", api_src, "-o", api_o])
+    train_o, train_src = os.path.join(OBJ, "gbnf_train.o"), os.path.join(HERE, "gbnf_train.hip")
+    objs.append(train_o)
+    if args.force or not newer(train_o, [train_src, hdr[2], hdr[3]]):
+        jobs.append([HIPCC] + FLAGS + ["-c", train_src, "-o", train_o])
     for v in read_variants():
         o = os.path.join(OBJ, "v_" + "_".join(str(a) for a in v) + ".o")
         objs.append(o)

@@ -13,13 +13,14 @@
 #include <vector>
 
 #include "gbnf_flow_kernel_hx3.hip.h"
+#include "gbnf_internal.h"
 
 namespace gbnf {
 
 // ------------------------------------------------------------------ error reporting
 static thread_local std::string g_err;
 
-static int fail(int code, const char* fmt, ...) {
+int fail(int code, const char* fmt, ...) {
   char buf[512];
   va_list ap;
   va_start(ap, fmt);
@@ -308,9 +309,14 @@ int gbnf_flow_create(const gbnf_flow_desc* desc, gbnf_flow** out) {
   return gbnf_flow_create_mode(desc, default_math_mode(), out);
 }
 
-int gbnf_flow_create_mode(const gbnf_flow_desc* desc, int32_t math_mode, gbnf_flow** out) {
-  if (out == nullptr) return fail(GBNF_ERR_INVALID, "gbnf_flow_create: out is null");
-  *out = nullptr;
+// Shape / consistency rules of a component descriptor; reads the descriptor's HOST fields and the permutation indices,
+// never the parameter arrays themselves (so the trainer can validate a descriptor whose parameters live on the device).
+struct DescInfo {
+  NetDims ref{};
+  int act_a = 0, act_b = 0, ht = 0, ksl = 0, ot = 0, ks1 = 0;
+};
+
+static int validate_desc(const gbnf_flow_desc* desc, DescInfo* info) {
   if (desc == nullptr) return fail(GBNF_ERR_INVALID, "gbnf_flow_create: desc is null");
   const int d = desc->d, K = desc->n_steps;
   if (d < 2 || d > ZSLOTS) return fail(GBNF_ERR_UNSUPPORTED, "d=%d outside the supported range [2,%d]", d, ZSLOTS);
@@ -324,7 +330,6 @@ int gbnf_flow_create_mode(const gbnf_flow_desc* desc, int32_t math_mode, gbnf_fl
   if (glow && desc->coupling != GBNF_COUPLING_AFFINE && desc->coupling != GBNF_COUPLING_ADDITIVE)
     return fail(GBNF_ERR_INVALID, "unknown coupling %d", desc->coupling);
   const int d1 = d / 2, d2 = d - d1;
-
   // ---- validate every step, collect the common network geometry
   NetDims ref{};
   int act_a = 0, act_b = 0;
@@ -383,13 +388,41 @@ int gbnf_flow_create_mode(const gbnf_flow_desc* desc, int32_t math_mode, gbnf_fl
   if (max_out_entries > NENT || ot > 4)
     return fail(GBNF_ERR_UNSUPPORTED, "coupled half of %d features exceeds the per-lane table (%d)", max_out, NENT);
 
+  info->ref = ref; info->act_a = act_a; info->act_b = act_b;
+  info->ht = ht; info->ksl = ksl; info->ot = ot; info->ks1 = ceil_div(max_in, 4);
+  return GBNF_OK;
+}
+
+int gbnf_flow_validate(const gbnf_flow_desc* desc) {
+  DescInfo info;
+  return validate_desc(desc, &info);
+}
+
+int gbnf_flow_create_mode(const gbnf_flow_desc* desc, int32_t math_mode, gbnf_flow** out) {
+  if (out == nullptr) return fail(GBNF_ERR_INVALID, "gbnf_flow_create: out is null");
+  *out = nullptr;
+  DescInfo info;
+  {
+    const int rc = validate_desc(desc, &info);
+    if (rc) return rc;
+  }
+  const int d = desc->d, K = desc->n_steps;
+  const bool glow = desc->kind == GBNF_KIND_GLOW;
+  const bool additive = glow && desc->coupling == GBNF_COUPLING_ADDITIVE;
+  const int d1 = d / 2, d2 = d - d1;
+  const NetDims ref = info.ref;
+  const int act_a = info.act_a, act_b = info.act_b;
+  const int h = ref.hidden, depth = ref.depth;
+  const int ht = info.ht, ksl = info.ksl, ot = info.ot;
+  (void)d1; (void)d2;
+
   // ---- pick compiled variants (exact geometry first, then the cheapest zero-padded superset)
   if (math_mode != GBNF_MATH_F32 && math_mode != GBNF_MATH_F16X3 && math_mode != GBNF_MATH_DEFAULT)
     return fail(GBNF_ERR_INVALID, "unknown math mode %d", math_mode);
   gbnf_flow* f = new gbnf_flow();
   f->kind = desc->kind; f->d = d; f->n_steps = K; f->additive = additive ? 1 : 0;
   f->hidden = h; f->depth = depth; f->act_a = act_a; f->act_b = act_b;
-  const int ks1 = ceil_div(max_in, 4);
+  const int ks1 = info.ks1;
   f->ht = ht; f->ksl = ksl; f->ot = ot; f->ks1 = ks1;
   bool hx3 = false;
   if (math_mode != GBNF_MATH_F32 && depth == 1) {

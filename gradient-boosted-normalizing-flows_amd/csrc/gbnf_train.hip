@@ -1,0 +1,683 @@
+// gbnf_train.hip -- the training path of one boosted component: forward on the LIVE
+// parameters and the backward pass (recompute-in-backward), for gfx950.
+//
+// Why a second kernel family: the evaluation kernels read parameters from a packed, immutable blob -- right for
+// density evaluation, wrong for training, where every optimiser step changes every weight.  The trainer therefore
+// binds the DEVICE addresses of the caller's parameter tensors once and reads them in their natural nn.Linear
+// (out, in) row-major layout; an optimiser that updates in place needs no repacking at all.
+//
+//   train_kernel<KIND>   one wave = 16 samples of one component.  Activations are LDS-resident as
+//                        [unit][sample] (row stride 17): they are the B operand of v_mfma_f32_16x16x4_f32 read
+//                        straight from LDS, the weights are the A operand read from global/L2 (forward: W rows,
+//                        one 16-byte load per lane per 4 k-steps; backward: W^T, i.e. columns of W).
+//                        MODE 0: x -> z, ldj.   MODE 1: forward through all K steps keeping every step's
+//                        normalised state in LDS, then the steps in reverse: recompute the nets, coupling /
+//                        normalisation backward, net backward (dgrad chain in place of the activations), emit the
+//                        two operands of every weight gradient to a workspace, atomically accumulate the
+//                        ActNorm / BatchNorm parameter gradients.
+//   wgrad_kernel         all weight/bias gradients of a component in ONE launch: dW = D . A^T contracted over
+//                        the samples on the matrix cores (split over sample chunks, atomic accumulation).
+//
+// Reference semantics differentiated (the forward is the one of gbnf_flow_kernel.hip.h):
+//   FlowStep.encode models/glow.py:317-342, _ActNorm.forward models/layers.py:488-533, TanhNet/ReLUNet
+//   models/layers.py:208-243, RealNVP.forward models/transformations.py:560-579, BatchNorm.forward (running
+//   statistics) models/layers.py:337-358.  Caller: loss.backward() of density_experiment.py:366-374 through
+//   compute_kl_pq_loss (density_experiment.py:606-660).
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdint>
+#include <cstring>
+#include <vector>
+
+#include "../../include/gbnf.h"
+#include "gbnf_internal.h"
+
+namespace gbnf {
+
+using f32x4 = __attribute__((ext_vector_type(4))) float;
+typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));
+
+constexpr int TR_S = 17;            // LDS row stride (floats): 16 samples + 1 pad
+constexpr int TR_MAX_LAYERS = 4;    // Linear layers per coupling net (depth <= 2)
+constexpr int TR_MAX_IN = 32;       // coupling-net input / coupled-half width
+constexpr int TR_LDS_BYTES = 160 * 1024;
+
+struct TrLayer {
+  const float* W;      // (rows, cols) row-major = nn.Linear.weight (out, in)
+  const float* b;      // (rows,)
+  int64_t gW, gb;      // float offsets into the flat gradient buffer
+  int rows, cols;
+};
+struct TrNet {
+  TrLayer layer[TR_MAX_LAYERS];
+  int n_layers, act;
+};
+struct TrStep {
+  int in_f, out_f, has_norm, pad0;
+  const float* na;     // glow: actnorm bias   | realnvp: bn log_gamma
+  const float* nb;     // glow: actnorm logs   | realnvp: bn beta
+  const float* mean;   // realnvp: bn running_mean
+  const float* var;    // realnvp: bn running_var
+  float eps;
+  int pad1;
+  int64_t g_na, g_nb;  // float offsets into the flat gradient buffer
+  int in_slot[TR_MAX_IN], out_slot[TR_MAX_IN];
+  int feat[64];        // feat[slot] = index into na/nb/mean/var of the feature that lives in that slot at this step
+  TrNet net[2];        // glow: net[0] = block; realnvp: net[0] = t_net (shift), net[1] = s_net (log-scale)
+};
+
+struct TrainLaunch {
+  const TrStep* steps;
+  const int* tail;     // final slot of logical feature j
+  const float* x;      // (n, d)
+  float* z_out;        // MODE 0
+  float* ldj_out;      // MODE 0
+  const float* g_z;    // MODE 1 (n, d) or null
+  const float* g_ldj;  // MODE 1 (n,) or null
+  float* g_x;          // MODE 1 (n, d) or null
+  float* grads;        // MODE 1 flat parameter-gradient buffer
+  float* ws;           // MODE 1 workspace
+  int64_t n, np;       // samples, samples rounded up to 16
+  int d, K, kind, additive;
+  int n_hidden;        // hidden layers per net = depth + 1
+  int hp, ip, op;      // padded hidden / net-input / net-output rows (multiples of 16)
+  int64_t net_rows;    // workspace rows (of np floats) per (step, net)
+};
+
+__device__ __forceinline__ float tr_tanh(float x) {
+  const float e = __builtin_amdgcn_exp2f(x * 2.8853900817779268f);
+  return __builtin_fmaf(-2.0f, __builtin_amdgcn_rcpf(e + 1.0f), 1.0f);
+}
+__device__ __forceinline__ float tr_act(int act, float v) { return act == GBNF_ACT_TANH ? tr_tanh(v) : fmaxf(v, 0.0f); }
+// derivative of the activation expressed through its OUTPUT h
+__device__ __forceinline__ float tr_dact(int act, float h) {
+  return act == GBNF_ACT_TANH ? __builtin_fmaf(-h, h, 1.0f) : (h > 0.0f ? 1.0f : 0.0f);
+}
+__device__ __forceinline__ f32x4 tr_mfma(float a, float b, f32x4 c) {
+  return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+}
+
+// A fragment of W (rows x cols, row-major): lane (i,g) gets W[row0+i][col0+4g .. +3]  (k-step r <-> k = col0+4g+r)
+__device__ __forceinline__ f32x4 tr_load_a(const float* __restrict__ W, int rows, int cols, int row, int col) {
+  f32x4 a = {0.f, 0.f, 0.f, 0.f};
+  if (row < rows) {
+    const float* p = W + (size_t)row * cols + col;
+    if (col + 3 < cols) {
+      const f32x4u v = *reinterpret_cast<const f32x4u*>(p);
+      a[0] = v[0]; a[1] = v[1]; a[2] = v[2]; a[3] = v[3];
+    } else {
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        if (col + r < cols) a[r] = p[r];
+    }
+  }
+  return a;
+}
+// A fragment of W^T: lane (i,g) gets W[k0+4g+r][row0+i], r = 0..3
+__device__ __forceinline__ f32x4 tr_load_at(const float* __restrict__ W, int rows, int cols, int trow, int k) {
+  f32x4 a = {0.f, 0.f, 0.f, 0.f};
+  if (trow < cols) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+      if (k + r < rows) a[r] = W[(size_t)(k + r) * cols + trow];
+  }
+  return a;
+}
+
+// out[u][s] = epi(u, sum_k A[u][k] in[k][s] + bias[u]) for u in [0, 16*out_tiles), LDS in/out with row stride TR_S.
+// TRANS = false: A = W (out units = W rows, k = W cols).  TRANS = true: A = W^T (out units = W cols, k = W rows).
+template <bool TRANS, class Epi>
+__device__ __forceinline__ void tr_dense(const TrLayer& L, bool use_bias, const float* in, int out_tiles, int lane,
+                                         Epi epi) {
+  const int i = lane & 15, g = lane >> 4;
+  const int rows = L.rows, cols = L.cols;
+  const int kdim = TRANS ? rows : cols;
+  const int udim = TRANS ? cols : rows;
+  const int kc = (kdim + 15) >> 4;
+  for (int o = 0; o < out_tiles; o += 2) {
+    const bool two = o + 1 < out_tiles;
+    f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+    if (use_bias) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int u0 = 16 * o + 4 * g + r, u1 = u0 + 16;
+        if (u0 < udim) acc0[r] = L.b[u0];
+        if (two && u1 < udim) acc1[r] = L.b[u1];
+      }
+    }
+    for (int c = 0; c < kc; ++c) {
+      const int k = 16 * c + 4 * g;
+      f32x4 a0, a1 = {0.f, 0.f, 0.f, 0.f};
+      if constexpr (TRANS) {
+        a0 = tr_load_at(L.W, rows, cols, 16 * o + i, k);
+        if (two) a1 = tr_load_at(L.W, rows, cols, 16 * o + 16 + i, k);
+      } else {
+        a0 = tr_load_a(L.W, rows, cols, 16 * o + i, k);
+        if (two) a1 = tr_load_a(L.W, rows, cols, 16 * o + 16 + i, k);
+      }
+      float b[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) b[r] = in[(k + r) * TR_S + i];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        acc0 = tr_mfma(a0[r], b[r], acc0);
+        if (two) acc1 = tr_mfma(a1[r], b[r], acc1);
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      epi(16 * o + 4 * g + r, acc0[r]);
+      if (two) epi(16 * o + 16 + 4 * g + r, acc1[r]);
+    }
+  }
+}
+
+__device__ __forceinline__ float tr_group_sum(float v) {   // sum over the 16 lanes of a lane group (all active)
+  v += __shfl_xor(v, 1);
+  v += __shfl_xor(v, 2);
+  v += __shfl_xor(v, 4);
+  v += __shfl_xor(v, 8);
+  return v;
+}
+
+template <int KIND, int MODE>
+__global__ void __launch_bounds__(64) train_kernel(const TrainLaunch p) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  constexpr int S = TR_S;
+  const int lane = threadIdx.x, i = lane & 15, g = lane >> 4;
+  const int d = p.d, K = p.K;
+  const int64_t row0 = (int64_t)blockIdx.x * 16;
+  const int64_t ni = row0 + i;
+  const bool valid = ni < p.n;
+
+  float* Y = lds;                                         // [K*d] normalised state of every step (MODE 1)
+  float* Zc = Y + (MODE == 1 ? (size_t)K * d * S : 0);    // [d]   running state (forward) / gradient state (backward)
+  float* X = Zc + (size_t)d * S;                          // [ip]  coupling-net input
+  float* GX = X + (size_t)p.ip * S;                       // [ip]  gradient w.r.t. the coupling-net input
+  float* H = GX + (size_t)p.ip * S;                       // [n_hidden][hp] hidden activations, then their gradients
+  float* O = H + (size_t)p.n_hidden * p.hp * S;           // [op]  net output, then its gradient
+  float* O2 = O + (size_t)p.op * S;                       // [op]  realnvp: shift output / shift gradient
+
+  const int hid_tiles = p.hp >> 4, out_tiles = p.op >> 4, in_tiles = p.ip >> 4;
+
+  // ---- normalisation of slot s at a step (ActNorm / eval-mode BatchNorm)
+  auto norm_fwd = [&](const TrStep& st, int s, float v, float& logdet) -> float {
+    const int f = st.feat[s];
+    if constexpr (KIND == GBNF_KIND_GLOW) {
+      const float logs = st.nb[f];
+      logdet += logs;                                      // models/layers.py:506-512
+      return (v + st.na[f]) * __expf(logs);
+    } else {
+      if (!st.has_norm) return v;
+      const float ve = st.var[f] + st.eps, lg = st.na[f];
+      logdet += lg - 0.5f * __logf(ve);                    // models/layers.py:357-358
+      return __expf(lg) * (v - st.mean[f]) / sqrtf(ve) + st.nb[f];
+    }
+  };
+
+  // ---- coupling net forward from X: hidden layers into H (+ emit), last layer into `out` (or skipped)
+  auto net_forward = [&](const TrNet& net, float* out, float* ws_net) {
+    const float* in = X;
+    const int nl = net.n_layers;
+    for (int l = 0; l + 1 < nl; ++l) {
+      float* Hl = H + (size_t)l * p.hp * S;
+      float* ws_h = (MODE == 1) ? ws_net + ((size_t)p.ip + (size_t)l * p.hp) * p.np + row0 + i : nullptr;
+      const int act = net.act;
+      tr_dense<false>(net.layer[l], true, in, hid_tiles, lane, [&](int u, float v) {
+        const float h = tr_act(act, v);
+        Hl[u * S + i] = h;
+        if (MODE == 1) ws_h[(size_t)u * p.np] = h;
+      });
+      in = Hl;
+    }
+    if (out != nullptr)
+      tr_dense<false>(net.layer[nl - 1], true, in, out_tiles, lane, [&](int u, float v) { out[u * S + i] = v; });
+  };
+
+  // ---- coupling net backward: cur = gradient w.r.t. the net output (LDS, [op]); leaves d(loss)/d(net input) in GX
+  auto net_backward = [&](const TrNet& net, const float* cur, float* ws_net, bool accumulate) {
+    const int nl = net.n_layers, nh = p.n_hidden;
+    // gradient-side operand of the last layer's weight gradient
+    {
+      float* ws_d = ws_net + ((size_t)p.ip + 2 * (size_t)nh * p.hp) * p.np + row0 + i;
+      for (int u = g; u < p.op; u += 4) ws_d[(size_t)u * p.np] = cur[u * S + i];
+    }
+    for (int l = nl - 1; l >= 1; --l) {
+      float* Hl = H + (size_t)(l - 1) * p.hp * S;           // activations of hidden layer l-1 -> overwritten by its gradient
+      float* ws_d = ws_net + ((size_t)p.ip + (size_t)nh * p.hp + (size_t)(l - 1) * p.hp) * p.np + row0 + i;
+      const int act = net.act;
+      tr_dense<true>(net.layer[l], false, cur, hid_tiles, lane, [&](int u, float v) {
+        const float gpre = v * tr_dact(act, Hl[u * S + i]);
+        Hl[u * S + i] = gpre;
+        ws_d[(size_t)u * p.np] = gpre;
+      });
+      cur = Hl;
+    }
+    tr_dense<true>(net.layer[0], false, cur, in_tiles, lane, [&](int u, float v) {
+      GX[u * S + i] = accumulate ? GX[u * S + i] + v : v;
+    });
+  };
+
+  // ---- x tile -> Zc (slot j = feature j)
+  for (int j = g; j < d; j += 4) Zc[j * S + i] = valid ? p.x[ni * d + j] : 0.0f;
+
+  // =============================== forward through all steps
+  float ld = 0.0f;   // per-lane partial of log|det J| (lane group g adds its own slots / features)
+  for (int k = 0; k < K; ++k) {
+    const TrStep& st = p.steps[k];
+    for (int s = g; s < d; s += 4) {
+      const float y = norm_fwd(st, s, Zc[s * S + i], ld);
+      Zc[s * S + i] = y;
+      if (MODE == 1) Y[((size_t)k * d + s) * S + i] = y;
+    }
+    if (MODE == 1 && k == K - 1) break;                    // the last step's outputs are not needed for the backward
+    for (int kk = g; kk < p.ip; kk += 4) X[kk * S + i] = kk < st.in_f ? Zc[st.in_slot[kk] * S + i] : 0.0f;
+    if constexpr (KIND == GBNF_KIND_GLOW) {
+      net_forward(st.net[0], O, nullptr);
+      for (int j = g; j < st.out_f; j += 4) {
+        const int slot = st.out_slot[j];
+        const float y2 = Zc[slot * S + i];
+        if (p.additive) {
+          Zc[slot * S + i] = y2 + O[j * S + i];                                  // models/glow.py:328-329
+        } else {
+          const float e = __expf(-(O[(2 * j + 1) * S + i] + 2.0f));              // scale = sigmoid(raw + 2)
+          const float sc = 1.0f / (1.0f + e);
+          Zc[slot * S + i] = (y2 + O[(2 * j) * S + i]) * sc;                     // models/glow.py:333-336
+          ld += -log1pf(e);                                                      // log(scale), models/glow.py:338
+        }
+      }
+    } else {
+      net_forward(st.net[0], O2, nullptr);
+      net_forward(st.net[1], O, nullptr);
+      for (int j = g; j < st.out_f; j += 4) {
+        const int slot = st.out_slot[j];
+        const float scale = O[j * S + i];
+        Zc[slot * S + i] = O2[j * S + i] + Zc[slot * S + i] * __expf(scale);      // models/transformations.py:575
+        ld += scale;                                                             // models/transformations.py:577
+      }
+    }
+  }
+
+  if constexpr (MODE == 0) {
+    ld += __shfl_xor(ld, 16);
+    ld += __shfl_xor(ld, 32);
+    if (valid) {
+      if (p.ldj_out != nullptr && g == 0) p.ldj_out[ni] = ld;
+      if (p.z_out != nullptr)
+        for (int j = g; j < d; j += 4) p.z_out[ni * d + j] = Zc[p.tail[j] * S + i];
+    }
+    return;
+  } else {
+    // =============================== backward
+    const float gl = (valid && p.g_ldj != nullptr) ? p.g_ldj[ni] : 0.0f;
+    for (int j = g; j < d; j += 4) Zc[p.tail[j] * S + i] = (valid && p.g_z != nullptr) ? p.g_z[ni * d + j] : 0.0f;
+    float* G = Zc;
+    const int nnets = (KIND == GBNF_KIND_GLOW) ? 1 : 2;
+
+    // normalisation backward for one slot: returns d(loss)/d(pre-norm value); accumulates the parameter gradients
+    auto norm_bwd = [&](const TrStep& st, int s, float gy, float y) -> float {
+      const int f = st.feat[s];
+      float ga, gb, gx;
+      if constexpr (KIND == GBNF_KIND_GLOW) {
+        const float e = __expf(st.nb[f]);
+        gx = gy * e;
+        ga = gx;                  // d/d bias
+        gb = gy * y + gl;         // d/d logs: y = (x + bias) e^logs, and logdet += logs for every sample
+      } else {
+        if (!st.has_norm) return gy;
+        const float a = __expf(st.na[f]) / sqrtf(st.var[f] + st.eps);
+        gx = gy * a;
+        ga = gy * (y - st.nb[f]) + gl;   // d/d log_gamma
+        gb = gy;                         // d/d beta
+      }
+      ga = tr_group_sum(ga);
+      gb = tr_group_sum(gb);
+      if (i == 0) {
+        atomicAdd(p.grads + st.g_na + f, ga);
+        atomicAdd(p.grads + st.g_nb + f, gb);
+      }
+      return gx;
+    };
+
+    for (int k = K - 1; k >= 0; --k) {
+      const TrStep& st = p.steps[k];
+      const float* Yk = Y + (size_t)k * d * S;
+      float* ws_step = p.ws + (size_t)k * nnets * p.net_rows * p.np;
+      // net input (also the activation-side operand of the first layer's weight gradient)
+      for (int kk = g; kk < p.ip; kk += 4) {
+        const float v = kk < st.in_f ? Yk[st.in_slot[kk] * S + i] : 0.0f;
+        X[kk * S + i] = v;
+        for (int q = 0; q < nnets; ++q) (ws_step + (size_t)q * p.net_rows * p.np)[(size_t)kk * p.np + row0 + i] = v;
+      }
+      if constexpr (KIND == GBNF_KIND_GLOW) {
+        net_forward(st.net[0], O, ws_step);
+        for (int j = g; j < st.out_f; j += 4) {
+          const int slot = st.out_slot[j];
+          const float y2 = Yk[slot * S + i], g2 = G[slot * S + i];
+          float gy;
+          if (p.additive) {
+            gy = g2;
+            O[j * S + i] = g2;
+          } else {
+            const float shift = O[(2 * j) * S + i];
+            const float e = __expf(-(O[(2 * j + 1) * S + i] + 2.0f));
+            const float sc = 1.0f / (1.0f + e);
+            const float omsc = e < 1e30f ? e * sc : 1.0f;               // 1 - scale
+            gy = g2 * sc;
+            O[(2 * j) * S + i] = gy;                                     // d/d shift
+            O[(2 * j + 1) * S + i] = (g2 * (y2 + shift) * sc + gl) * omsc;   // d/d raw: z2' = (y2+shift) s, ld += log s
+          }
+          G[slot * S + i] = norm_bwd(st, slot, gy, y2);
+        }
+        net_backward(st.net[0], O, ws_step, false);
+      } else {
+        float* ws_t = ws_step;
+        float* ws_s = ws_step + (size_t)p.net_rows * p.np;
+        net_forward(st.net[1], O, ws_s);                                 // log-scale net
+        for (int u = g; u < p.op; u += 4) O2[u * S + i] = 0.0f;
+        for (int j = g; j < st.out_f; j += 4) {
+          const int slot = st.out_slot[j];
+          const float y2 = Yk[slot * S + i], g2 = G[slot * S + i];
+          const float es = __expf(O[j * S + i]);
+          O2[j * S + i] = g2;                                            // d/d shift
+          O[j * S + i] = g2 * y2 * es + gl;                              // d/d scale: z2' = shift + y2 e^scale, ld += scale
+          G[slot * S + i] = norm_bwd(st, slot, g2 * es, y2);
+        }
+        net_backward(st.net[1], O, ws_s, false);
+        net_forward(st.net[0], nullptr, ws_t);                           // shift net: only its activations are needed
+        net_backward(st.net[0], O2, ws_t, true);
+      }
+      for (int kk = g; kk < st.in_f; kk += 4) {
+        const int slot = st.in_slot[kk];
+        G[slot * S + i] = norm_bwd(st, slot, G[slot * S + i] + GX[kk * S + i], Yk[slot * S + i]);
+      }
+    }
+    if (valid && p.g_x != nullptr)
+      for (int j = g; j < d; j += 4) p.g_x[ni * d + j] = G[j * S + i];
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Weight / bias gradients: C (M x N, row-major) += D (M rows of np samples) . A (N rows of np samples)^T, bias += row sums of D.
+// One wave = one 32 x 32 block of C over one chunk of samples; k-step r of a 16-sample group uses samples s0+4g+r.
+// ---------------------------------------------------------------------------------------------------------------
+struct WgProblem {
+  int64_t d_row, a_row;   // first row (of np floats) of the two operands in the workspace
+  int64_t c_off, b_off;   // float offsets of dW / db in the flat gradient buffer
+  int M, N, blk_begin, nb;
+};
+constexpr int WG_CHUNK = 512;   // samples per block
+
+__global__ void __launch_bounds__(64) wgrad_kernel(const WgProblem* __restrict__ probs, int n_probs,
+                                                   const float* __restrict__ ws, float* __restrict__ grads, int64_t np) {
+  const int lane = threadIdx.x, i = lane & 15, g = lane >> 4;
+  int pi = 0;
+  while (pi + 1 < n_probs && (int)blockIdx.x >= probs[pi + 1].blk_begin) ++pi;
+  const WgProblem P = probs[pi];
+  const int blk = blockIdx.x - P.blk_begin;
+  const int m0 = (blk / P.nb) * 32, n0 = (blk % P.nb) * 32;
+  const int64_t s_begin = (int64_t)blockIdx.y * WG_CHUNK;
+  const int64_t s_end = (s_begin + WG_CHUNK < np) ? s_begin + WG_CHUNK : np;
+  const float* D0 = ws + (P.d_row + m0 + i) * np + 4 * g;
+  const float* D1 = D0 + 16 * np;
+  const float* A0 = ws + (P.a_row + n0 + i) * np + 4 * g;
+  const float* A1 = A0 + 16 * np;
+  const bool m1 = m0 + 16 < P.M, n1 = n0 + 16 < P.N;    // second tile row / column live (operand rows exist up to the padded size)
+  const bool want_bias = (n0 == 0);
+  f32x4 c00 = {0.f, 0.f, 0.f, 0.f}, c01 = c00, c10 = c00, c11 = c00, cb0 = c00, cb1 = c00;
+  for (int64_t s = s_begin; s < s_end; s += 16) {
+    const f32x4 d0 = *reinterpret_cast<const f32x4*>(D0 + s);
+    const f32x4 a0 = *reinterpret_cast<const f32x4*>(A0 + s);
+    f32x4 d1 = {0.f, 0.f, 0.f, 0.f}, a1 = d1;
+    if (m1) d1 = *reinterpret_cast<const f32x4*>(D1 + s);
+    if (n1) a1 = *reinterpret_cast<const f32x4*>(A1 + s);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      c00 = tr_mfma(d0[r], a0[r], c00);
+      c01 = tr_mfma(d0[r], a1[r], c01);
+      c10 = tr_mfma(d1[r], a0[r], c10);
+      c11 = tr_mfma(d1[r], a1[r], c11);
+      if (want_bias) {
+        cb0 = tr_mfma(d0[r], 1.0f, cb0);
+        cb1 = tr_mfma(d1[r], 1.0f, cb1);
+      }
+    }
+  }
+  float* C = grads + P.c_off;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int ma = m0 + 4 * g + r, mb = ma + 16;
+    const int na = n0 + i, nb = na + 16;
+    if (ma < P.M && na < P.N) atomicAdd(C + (size_t)ma * P.N + na, c00[r]);
+    if (ma < P.M && nb < P.N) atomicAdd(C + (size_t)ma * P.N + nb, c01[r]);
+    if (mb < P.M && na < P.N) atomicAdd(C + (size_t)mb * P.N + na, c10[r]);
+    if (mb < P.M && nb < P.N) atomicAdd(C + (size_t)mb * P.N + nb, c11[r]);
+    if (want_bias && i == 0) {
+      if (ma < P.M) atomicAdd(grads + P.b_off + ma, cb0[r]);
+      if (mb < P.M) atomicAdd(grads + P.b_off + mb, cb1[r]);
+    }
+  }
+}
+
+}  // namespace gbnf
+
+using namespace gbnf;
+
+struct gbnf_trainer {
+  int kind = 0, d = 0, K = 0, additive = 0, n_hidden = 0, hp = 0, ip = 0, op = 0, nnets = 1;
+  int64_t net_rows = 0, grad_floats = 0;
+  size_t lds_fwd = 0, lds_bwd = 0;
+  TrStep* steps_dev = nullptr;
+  int* tail_dev = nullptr;
+  WgProblem* probs_dev = nullptr;
+  int n_probs = 0, wg_blocks = 0;
+};
+
+static int ceil16(int v) { return (v + 15) / 16 * 16; }
+
+extern "C" {
+
+int gbnf_trainer_create(const gbnf_flow_desc* desc, gbnf_trainer** out) {
+  if (out == nullptr) return fail(GBNF_ERR_INVALID, "gbnf_trainer_create: out is null");
+  *out = nullptr;
+  // Validate the descriptor with the evaluation path's own checks (shape rules are identical); that call dereferences
+  // only the HOST fields (perm_indices, sizes), never the parameter arrays, when asked to validate only.
+  int rc = gbnf_flow_validate(desc);
+  if (rc) return rc;
+  const int d = desc->d, K = desc->n_steps;
+  const bool glow = desc->kind == GBNF_KIND_GLOW;
+  const bool additive = glow && desc->coupling == GBNF_COUPLING_ADDITIVE;
+  const int d1 = d / 2, d2 = d - d1;
+  const gbnf_net& n0 = glow ? desc->glow_steps[0].block : desc->realnvp_steps[0].t_net;
+  const int h = n0.layers[0].out_features, nl = n0.n_layers;
+  if (nl > TR_MAX_LAYERS) return fail(GBNF_ERR_UNSUPPORTED, "gbnf_trainer_create: %d Linear layers per net > %d", nl, TR_MAX_LAYERS);
+  if (d2 > TR_MAX_IN) return fail(GBNF_ERR_UNSUPPORTED, "gbnf_trainer_create: half width %d > %d", d2, TR_MAX_IN);
+
+  gbnf_trainer* t = new gbnf_trainer();
+  t->kind = desc->kind; t->d = d; t->K = K; t->additive = additive ? 1 : 0;
+  t->nnets = glow ? 1 : 2;
+  t->n_hidden = nl - 1;
+  t->hp = ceil16(h);
+  t->ip = ceil16(d2);
+  t->op = ceil16(glow && !additive ? 2 * d2 : d2);
+  t->net_rows = (int64_t)t->ip + 2LL * t->n_hidden * t->hp + t->op;
+  const size_t common = (size_t)d + 2 * (size_t)t->ip + (size_t)t->n_hidden * t->hp + 2 * (size_t)t->op;
+  t->lds_fwd = common * TR_S * 4;
+  t->lds_bwd = (common + (size_t)K * d) * TR_S * 4;
+  if (t->lds_bwd > (size_t)TR_LDS_BYTES) {
+    const size_t need = t->lds_bwd;
+    delete t;
+    return fail(GBNF_ERR_UNSUPPORTED, "gbnf_trainer_create: K*d = %d needs %zu bytes of LDS per wave (> %d)", K * d, need,
+                TR_LDS_BYTES);
+  }
+
+  std::vector<TrStep> steps(K);
+  std::vector<WgProblem> probs;
+  std::vector<int> sigma(d), prev(d);
+  for (int j = 0; j < d; ++j) sigma[j] = j;
+  int64_t goff = 0;
+  int blocks = 0;
+  for (int s = 0; s < K; ++s) {
+    TrStep& st = steps[s];
+    std::memset(&st, 0, sizeof(st));
+    prev = sigma;
+    int in_f, out_f;
+    st.g_na = goff; goff += d;
+    st.g_nb = goff; goff += d;
+    const gbnf_net* nets[2] = {nullptr, nullptr};
+    if (glow) {
+      const gbnf_glow_step& g = desc->glow_steps[s];
+      st.has_norm = 1;
+      st.na = g.actnorm_bias; st.nb = g.actnorm_logs;
+      for (int j = 0; j < d; ++j) {
+        const int m = (int)g.perm_indices[j];       // z = actnorm(x)[:, perm]
+        sigma[j] = prev[m];
+        st.feat[sigma[j]] = m;
+      }
+      in_f = d1; out_f = d2;
+      nets[0] = &g.block;
+    } else {
+      const gbnf_realnvp_step& r = desc->realnvp_steps[s];
+      st.has_norm = r.has_batch_norm ? 1 : 0;
+      st.na = r.bn_log_gamma; st.nb = r.bn_beta; st.mean = r.bn_running_mean; st.var = r.bn_running_var;
+      st.eps = r.bn_eps;
+      for (int j = 0; j < d; ++j) {
+        const int m = r.flipped ? ((j < d2) ? d1 + j : j - d2) : j;
+        sigma[j] = prev[m];
+        st.feat[sigma[j]] = m;
+      }
+      in_f = r.flipped ? d2 : d1; out_f = r.flipped ? d1 : d2;
+      nets[0] = &r.t_net; nets[1] = &r.s_net;
+    }
+    st.in_f = in_f; st.out_f = out_f;
+    for (int j = 0; j < in_f; ++j) st.in_slot[j] = sigma[j];
+    for (int j = 0; j < out_f; ++j) st.out_slot[j] = sigma[in_f + j];
+    for (int q = 0; q < t->nnets; ++q) {
+      TrNet& net = st.net[q];
+      net.n_layers = nl; net.act = nets[q]->activation;
+      const int64_t base_row = ((int64_t)s * t->nnets + q) * t->net_rows;
+      for (int l = 0; l < nl; ++l) {
+        const gbnf_linear& lin = nets[q]->layers[l];
+        TrLayer& L = net.layer[l];
+        L.W = lin.weight; L.b = lin.bias; L.rows = lin.out_features; L.cols = lin.in_features;
+        L.gW = goff; goff += (int64_t)L.rows * L.cols;
+        L.gb = goff; goff += L.rows;
+        WgProblem P{};
+        P.M = L.rows; P.N = L.cols;
+        // gradient-side operand: D of this layer's output; activation-side operand: this layer's input
+        P.d_row = base_row + (l == nl - 1 ? (int64_t)t->ip + 2LL * t->n_hidden * t->hp
+                                          : (int64_t)t->ip + (int64_t)t->n_hidden * t->hp + (int64_t)l * t->hp);
+        P.a_row = base_row + (l == 0 ? 0 : (int64_t)t->ip + (int64_t)(l - 1) * t->hp);
+        P.c_off = L.gW; P.b_off = L.gb;
+        P.nb = (P.N + 31) / 32;
+        P.blk_begin = blocks;
+        blocks += ((P.M + 31) / 32) * P.nb;
+        probs.push_back(P);
+      }
+    }
+  }
+  t->grad_floats = goff;
+  t->n_probs = (int)probs.size();
+  t->wg_blocks = blocks;
+  std::vector<int> tail(64, 0);
+  for (int j = 0; j < d; ++j) tail[j] = sigma[j];
+
+  hipError_t e = hipMalloc((void**)&t->steps_dev, sizeof(TrStep) * K);
+  if (e == hipSuccess) e = hipMemcpy(t->steps_dev, steps.data(), sizeof(TrStep) * K, hipMemcpyHostToDevice);
+  if (e == hipSuccess) e = hipMalloc((void**)&t->tail_dev, sizeof(int) * 64);
+  if (e == hipSuccess) e = hipMemcpy(t->tail_dev, tail.data(), sizeof(int) * 64, hipMemcpyHostToDevice);
+  if (e == hipSuccess) e = hipMalloc((void**)&t->probs_dev, sizeof(WgProblem) * probs.size());
+  if (e == hipSuccess) e = hipMemcpy(t->probs_dev, probs.data(), sizeof(WgProblem) * probs.size(), hipMemcpyHostToDevice);
+  if (e == hipSuccess) {
+    const void* fns[4] = {(const void*)train_kernel<GBNF_KIND_GLOW, 0>, (const void*)train_kernel<GBNF_KIND_GLOW, 1>,
+                          (const void*)train_kernel<GBNF_KIND_REALNVP, 0>, (const void*)train_kernel<GBNF_KIND_REALNVP, 1>};
+    for (int k = 0; k < 4 && e == hipSuccess; ++k)
+      e = hipFuncSetAttribute(fns[k], hipFuncAttributeMaxDynamicSharedMemorySize, TR_LDS_BYTES);
+  }
+  if (e != hipSuccess) {
+    gbnf_trainer_destroy(t);
+    return fail(GBNF_ERR_HIP, "gbnf_trainer_create: %s", hipGetErrorString(e));
+  }
+  *out = t;
+  return GBNF_OK;
+}
+
+int gbnf_trainer_destroy(gbnf_trainer* t) {
+  if (t == nullptr) return GBNF_OK;
+  if (t->steps_dev) (void)hipFree(t->steps_dev);
+  if (t->tail_dev) (void)hipFree(t->tail_dev);
+  if (t->probs_dev) (void)hipFree(t->probs_dev);
+  delete t;
+  return GBNF_OK;
+}
+
+int gbnf_trainer_grad_floats(const gbnf_trainer* t, int64_t* n_floats) {
+  if (!t || !n_floats) return fail(GBNF_ERR_INVALID, "gbnf_trainer_grad_floats: null argument");
+  *n_floats = t->grad_floats;
+  return GBNF_OK;
+}
+
+int gbnf_trainer_workspace_bytes(const gbnf_trainer* t, int64_t n, int64_t* bytes) {
+  if (!t || !bytes || n < 0) return fail(GBNF_ERR_INVALID, "gbnf_trainer_workspace_bytes: bad argument");
+  const int64_t np = (n + 15) / 16 * 16;
+  *bytes = (int64_t)t->K * t->nnets * t->net_rows * np * 4;
+  return GBNF_OK;
+}
+
+static void fill_launch(const gbnf_trainer* t, TrainLaunch& p, const float* x, int64_t n) {
+  std::memset(&p, 0, sizeof(p));
+  p.steps = t->steps_dev; p.tail = t->tail_dev; p.x = x;
+  p.n = n; p.np = (n + 15) / 16 * 16;
+  p.d = t->d; p.K = t->K; p.kind = t->kind; p.additive = t->additive;
+  p.n_hidden = t->n_hidden; p.hp = t->hp; p.ip = t->ip; p.op = t->op; p.net_rows = t->net_rows;
+}
+
+int gbnf_trainer_forward(const gbnf_trainer* t, const float* x, int64_t n, float* z, float* ldj, void* stream) {
+  if (!t) return fail(GBNF_ERR_INVALID, "gbnf_trainer_forward: trainer is null");
+  if (n < 0) return fail(GBNF_ERR_INVALID, "gbnf_trainer_forward: n < 0");
+  if (n == 0) return GBNF_OK;
+  if (!x) return fail(GBNF_ERR_INVALID, "gbnf_trainer_forward: x is null");
+  TrainLaunch p;
+  fill_launch(t, p, x, n);
+  p.z_out = z; p.ldj_out = ldj;
+  const dim3 grid((unsigned)(p.np / 16));
+  if (t->kind == GBNF_KIND_GLOW)
+    hipLaunchKernelGGL((train_kernel<GBNF_KIND_GLOW, 0>), grid, dim3(64), t->lds_fwd, (hipStream_t)stream, p);
+  else
+    hipLaunchKernelGGL((train_kernel<GBNF_KIND_REALNVP, 0>), grid, dim3(64), t->lds_fwd, (hipStream_t)stream, p);
+  const hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return fail(GBNF_ERR_HIP, "gbnf_trainer_forward launch: %s", hipGetErrorString(e));
+  return GBNF_OK;
+}
+
+int gbnf_trainer_backward(const gbnf_trainer* t, const float* x, int64_t n, const float* g_z, const float* g_ldj,
+                          float* g_x, float* grads, void* workspace, int64_t workspace_bytes, void* stream) {
+  if (!t) return fail(GBNF_ERR_INVALID, "gbnf_trainer_backward: trainer is null");
+  if (n < 0) return fail(GBNF_ERR_INVALID, "gbnf_trainer_backward: n < 0");
+  if (n == 0) return GBNF_OK;
+  if (!x || !grads || !workspace) return fail(GBNF_ERR_INVALID, "gbnf_trainer_backward: x / grads / workspace is null");
+  int64_t need = 0;
+  gbnf_trainer_workspace_bytes(t, n, &need);
+  if (workspace_bytes < need)
+    return fail(GBNF_ERR_INVALID, "gbnf_trainer_backward: workspace of %lld bytes < %lld", (long long)workspace_bytes,
+                (long long)need);
+  TrainLaunch p;
+  fill_launch(t, p, x, n);
+  p.g_z = g_z; p.g_ldj = g_ldj; p.g_x = g_x; p.grads = grads; p.ws = (float*)workspace;
+  const dim3 grid((unsigned)(p.np / 16));
+  hipStream_t s = (hipStream_t)stream;
+  if (t->kind == GBNF_KIND_GLOW)
+    hipLaunchKernelGGL((train_kernel<GBNF_KIND_GLOW, 1>), grid, dim3(64), t->lds_bwd, s, p);
+  else
+    hipLaunchKernelGGL((train_kernel<GBNF_KIND_REALNVP, 1>), grid, dim3(64), t->lds_bwd, s, p);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return fail(GBNF_ERR_HIP, "gbnf_trainer_backward launch: %s", hipGetErrorString(e));
+  const dim3 wgrid((unsigned)t->wg_blocks, (unsigned)((p.np + WG_CHUNK - 1) / WG_CHUNK));
+  hipLaunchKernelGGL(wgrad_kernel, wgrid, dim3(64), 0, s, t->probs_dev, t->n_probs, (const float*)workspace, grads, p.np);
+  e = hipGetLastError();
+  if (e != hipSuccess) return fail(GBNF_ERR_HIP, "gbnf_trainer_backward wgrad launch: %s", hipGetErrorString(e));
+  return GBNF_OK;
+}
+
+}  // extern "C"

@@ -30,6 +30,8 @@ ABI_SYMBOLS = (
     "gbnf_mixture_component_log_prob_multi", "gbnf_mixture_lse",
     "gbnf_mixture_log_prob",
     "gbnf_actnorm_init", "gbnf_boosting_weights",
+    "gbnf_flow_validate", "gbnf_trainer_create", "gbnf_trainer_destroy", "gbnf_trainer_forward",
+    "gbnf_trainer_grad_floats", "gbnf_trainer_workspace_bytes", "gbnf_trainer_backward",
 )
 
 
@@ -102,6 +104,13 @@ def lib():
     L.gbnf_mixture_log_prob.argtypes = [vp, vp, i64, i32, vp, vp, vp, vp]
     L.gbnf_actnorm_init.argtypes = [vp, i64, i32, C.c_float, vp, vp, vp]
     L.gbnf_boosting_weights.argtypes = [vp, i64, C.c_float, vp, vp]
+    L.gbnf_flow_validate.argtypes = [C.POINTER(_FlowDesc)]
+    L.gbnf_trainer_create.argtypes = [C.POINTER(_FlowDesc), C.POINTER(vp)]
+    L.gbnf_trainer_destroy.argtypes = [vp]
+    L.gbnf_trainer_forward.argtypes = [vp, vp, i64, vp, vp, vp]
+    L.gbnf_trainer_grad_floats.argtypes = [vp, C.POINTER(i64)]
+    L.gbnf_trainer_workspace_bytes.argtypes = [vp, i64, C.POINTER(i64)]
+    L.gbnf_trainer_backward.argtypes = [vp, vp, i64, vp, vp, vp, vp, vp, i64, vp]
     for name in ABI_SYMBOLS:
         if name not in ("gbnf_version", "gbnf_last_error"):
             getattr(L, name).restype = C.c_int
@@ -239,6 +248,141 @@ class NativeFlow:
     def close(self):
         if getattr(self, "handle", None):
             lib().gbnf_flow_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class NativeTrainer:
+    """Training path of one component (gbnf_trainer): forward on the LIVE device parameters and the backward pass.
+
+    ``dev_spec`` has the shape of a flow spec (spec.py) but every float array is a contiguous float32 CUDA tensor --
+    the caller's parameter / buffer storage itself (``perm`` stays a host int64 array).  Nothing is copied: the
+    library keeps the addresses, this object keeps the tensors alive."""
+
+    def __init__(self, dev_spec):
+        import torch
+        self._tensors = []        # keep-alive; also the identity check for re-creation
+        self.params = []          # tensors in the order of the flat gradient buffer (None = reserved, unused region)
+        self._sizes = []
+        keep = []
+        K = len(dev_spec["steps"])
+        self.d = d = int(dev_spec["d"])
+        fp = C.POINTER(C.c_float)
+
+        def dptr(t, numel):
+            _require_device_f32(t, "parameter")
+            if t.numel() != numel:
+                raise GbnfError(f"parameter has {t.numel()} elements, expected {numel}")
+            self._tensors.append(t)
+            return C.cast(C.c_void_p(t.data_ptr()), fp)
+
+        def region(t, numel):
+            self.params.append(t)
+            self._sizes.append(numel)
+
+        def net(n):
+            arr = (_Linear * len(n["layers"]))()
+            for k, (w, b) in enumerate(n["layers"]):
+                out_f, in_f = int(w.shape[0]), int(w.shape[1])
+                arr[k] = _Linear(dptr(w, out_f * in_f), dptr(b, out_f), out_f, in_f)
+                region(w, out_f * in_f)
+                region(b, out_f)
+            keep.append(arr)
+            return _Net(ACT[n["act"]], len(n["layers"]), arr)
+
+        desc = _FlowDesc()
+        desc.kind = KIND[dev_spec["kind"]]
+        desc.d = d
+        desc.n_steps = K
+        desc.coupling = COUPLING[dev_spec.get("coupling") or "affine"]
+        hk = _Keep()
+        if dev_spec["kind"] == "glow":
+            steps = (_GlowStep * K)()
+            for k, st in enumerate(dev_spec["steps"]):
+                region(st["an_bias"], d)
+                region(st["an_logs"], d)
+                steps[k] = _GlowStep(dptr(st["an_bias"], d), dptr(st["an_logs"], d), hk.i64(st["perm"]), net(st["net"]))
+            desc.glow_steps = steps
+        else:
+            steps = (_RealNVPStep * K)()
+            for k, st in enumerate(dev_spec["steps"]):
+                s = _RealNVPStep()
+                s.flipped = int(bool(st["flipped"]))
+                bn = st["bn"]
+                s.has_batch_norm = int(bn is not None)
+                if bn is not None:
+                    s.bn_log_gamma = dptr(bn["log_gamma"], d)
+                    s.bn_beta = dptr(bn["beta"], d)
+                    s.bn_running_mean = dptr(bn["running_mean"], d)
+                    s.bn_running_var = dptr(bn["running_var"], d)
+                    s.bn_eps = float(bn["eps"])
+                    region(bn["log_gamma"], d)
+                    region(bn["beta"], d)
+                else:
+                    region(None, d)
+                    region(None, d)
+                s.t_net = net(st["t_net"])
+                s.s_net = net(st["s_net"])
+                steps[k] = s
+            desc.realnvp_steps = steps
+        h = C.c_void_p()
+        _check(lib().gbnf_trainer_create(C.byref(desc), C.byref(h)))
+        self.handle = h
+        nf = C.c_int64()
+        _check(lib().gbnf_trainer_grad_floats(h, C.byref(nf)))
+        self.grad_floats = int(nf.value)
+        if self.grad_floats != sum(self._sizes):
+            raise GbnfError("gradient-buffer layout mismatch between the library and the binding")
+        self._ws = None
+
+    def key(self):
+        return tuple(t.data_ptr() for t in self._tensors)
+
+    def forward(self, x):
+        import torch
+        _require_device_f32(x, "x")
+        if x.dim() != 2 or x.shape[1] != self.d:
+            raise GbnfError(f"x must be (n,{self.d}), got {tuple(x.shape)}")
+        n = x.shape[0]
+        z = torch.empty_like(x)
+        ldj = torch.empty(n, dtype=torch.float32, device=x.device)
+        if n:
+            _check(lib().gbnf_trainer_forward(self.handle, C.c_void_p(x.data_ptr()), n, C.c_void_p(z.data_ptr()),
+                                              C.c_void_p(ldj.data_ptr()), _stream_ptr()))
+        return z, ldj
+
+    def backward(self, x, g_z=None, g_ldj=None, want_gx=False):
+        """-> (g_x | None, [gradient per entry of ``self.params`` (views of one flat buffer; None for reserved regions)])."""
+        import torch
+        _require_device_f32(x, "x")
+        n = x.shape[0]
+        for t, name in ((g_z, "g_z"), (g_ldj, "g_ldj")):
+            if t is not None:
+                _require_device_f32(t, name)
+        flat = torch.zeros(self.grad_floats, dtype=torch.float32, device=x.device)
+        g_x = torch.empty_like(x) if want_gx else None
+        if n:
+            nb = C.c_int64()
+            _check(lib().gbnf_trainer_workspace_bytes(self.handle, n, C.byref(nb)))
+            if self._ws is None or self._ws.numel() * 4 < nb.value or self._ws.device != x.device:
+                self._ws = torch.empty((nb.value + 3) // 4, dtype=torch.float32, device=x.device)
+            ptr = lambda t: C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
+            _check(lib().gbnf_trainer_backward(self.handle, ptr(x), n, ptr(g_z), ptr(g_ldj), ptr(g_x), ptr(flat),
+                                               ptr(self._ws), self._ws.numel() * 4, _stream_ptr()))
+        grads, off = [], 0
+        for t, size in zip(self.params, self._sizes):
+            grads.append(None if t is None else flat[off:off + size].view(t.shape))
+            off += size
+        return g_x, grads
+
+    def close(self):
+        if getattr(self, "handle", None):
+            lib().gbnf_trainer_destroy(self.handle)
             self.handle = None
 
     def __del__(self):

@@ -112,6 +112,48 @@ def spec_from_component(module):
     raise TypeError(f"not a boosted-flow component: {type(module).__name__}")
 
 
+# ------------------------------------------------------------------ live (device) view for the training path
+def _dev_net(seq_owner):
+    layers, act = [], None
+    for m in seq_owner.network:
+        cls = type(m).__name__
+        if cls == "Linear":
+            layers.append((m.weight, m.bias))
+        elif cls in ("Tanh", "ReLU"):
+            a = cls.lower()
+            act = a if act in (None, a) else _mixed_act_error()
+        else:
+            raise NotImplementedError(f"unsupported coupling-network module {cls}")
+    return {"act": act or "tanh", "layers": layers}
+
+
+def device_spec_from_component(module):
+    """Like ``spec_from_component`` but the float arrays are the module's own parameter / buffer TENSORS (no copy):
+    the input of ``native.NativeTrainer``, which binds their device addresses."""
+    if hasattr(module, "flow_param"):
+        steps = []
+        for k, mods in enumerate(module.flow_param):
+            bn = mods[2] if len(mods) > 2 else None
+            steps.append({
+                "flipped": bool(((k + int(module.flip_init)) % 2) > 0),
+                "bn": None if bn is None else {"log_gamma": bn.log_gamma, "beta": bn.beta, "running_mean": bn.running_mean,
+                                               "running_var": bn.running_var, "eps": float(bn.eps)},
+                "t_net": _dev_net(mods[0]), "s_net": _dev_net(mods[1])})
+        return {"kind": "realnvp", "d": int(module.z_size), "steps": steps}
+    steps, coupling, d = [], None, None
+    for layer in module.flow.layers:
+        an = layer.actnorm
+        if not bool(an.inited):
+            raise ValueError("ActNorm not initialised (models/layers.py:473-475 raises in eval mode too)")
+        d = int(an.bias.numel())
+        perm = layer.shuffle.indices if hasattr(layer, "shuffle") else layer.reverse.indices
+        steps.append({"an_bias": an.bias, "an_logs": an.logs,
+                      "perm": np.asarray(perm.detach().cpu().numpy() if hasattr(perm, "detach") else perm, dtype=np.int64),
+                      "net": _dev_net(layer.block)})
+        coupling = coupling or layer.flow_coupling
+    return {"kind": "glow", "d": d, "coupling": coupling, "steps": steps}
+
+
 # ------------------------------------------------------------------ (de)serialisation
 def flatten_spec(spec, prefix=""):
     """spec -> {name: ndarray} (+ a json header) for ``np.savez``."""

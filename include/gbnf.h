@@ -195,6 +195,41 @@ int gbnf_actnorm_init(const float* z, int64_t n, int32_t d, float scale, float* 
  * G and w_out are DEVICE buffers of n floats.  (The multinomial resampling that follows stays with the caller's RNG.) */
 int gbnf_boosting_weights(const float* G, int64_t n, float beta, float* w_out, void* stream);
 
+/* ---------------------------------------------------------------------------------------------------------------
+ * Training path: what loss.backward() / optimizer.step() of density_experiment.py:366-374 do
+ * to ONE component -- the forward on the LIVE parameters and its backward pass.
+ *
+ * A trainer binds the DEVICE addresses of the caller's parameter tensors: the descriptor has the same shape as for
+ * gbnf_flow_create, but every float pointer (weights, biases, ActNorm / BatchNorm arrays) is a DEVICE pointer to the
+ * tensor in its reference layout (nn.Linear.weight (out,in) row-major, ...) and stays owned by the caller;
+ * perm_indices stay HOST pointers.  Nothing is packed or copied, so parameters updated in place by an optimiser are
+ * seen by the next call; re-create the trainer only when a tensor is re-allocated.  RealNVP BatchNorm is differentiated
+ * in its running-statistics (eval) form, models/layers.py:347-358.
+ * --------------------------------------------------------------------------------------------------------------- */
+typedef struct gbnf_trainer gbnf_trainer;
+
+/* The descriptor checks gbnf_flow_create applies (reads sizes and perm_indices, never the parameter arrays). */
+int gbnf_flow_validate(const gbnf_flow_desc* desc);
+
+int gbnf_trainer_create(const gbnf_flow_desc* desc_device_params, gbnf_trainer** out);
+int gbnf_trainer_destroy(gbnf_trainer* trainer);
+
+/* z, ldj = flows[c](x) on the live parameters (same semantics and outputs as gbnf_flow_forward). */
+int gbnf_trainer_forward(const gbnf_trainer* trainer, const float* x, int64_t n, float* z, float* ldj, void* stream);
+
+/* Size of the flat parameter-gradient buffer, in floats.  Layout, step by step in descriptor order:
+ *   glow:    [actnorm bias (d)] [actnorm logs (d)]  then per Linear of the block:   [weight (out*in)] [bias (out)]
+ *   realnvp: [bn log_gamma (d)] [bn beta (d)]  (left zero without batch norm)  then t_net's Linears, then s_net's. */
+int gbnf_trainer_grad_floats(const gbnf_trainer* trainer, int64_t* n_floats);
+/* Bytes of caller-owned DEVICE scratch one backward call over n samples needs. */
+int gbnf_trainer_workspace_bytes(const gbnf_trainer* trainer, int64_t n, int64_t* bytes);
+
+/* Backward of (z, ldj) = flows[c](x): given g_z = dL/dz (n,d) and g_ldj = dL/dldj (n,) (either may be NULL = zero),
+ * ACCUMULATES dL/dparameters into `grads` (the caller zeroes it; layout above) and writes dL/dx to g_x (n,d) unless
+ * NULL.  Activations are recomputed from x (nothing is kept from the forward call). */
+int gbnf_trainer_backward(const gbnf_trainer* trainer, const float* x, int64_t n, const float* g_z, const float* g_ldj,
+                          float* g_x, float* grads, void* workspace, int64_t workspace_bytes, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -306,6 +306,71 @@ def component_inverse(spec, z, backend="torch"):
     return ops.to_numpy(x), ops.to_numpy(ld)
 
 
+# --------------------------------------------------------------------------
+# gradients: torch autograd in float64 over the SAME restatement of the forward
+# --------------------------------------------------------------------------
+class _TorchGradOps(_TorchOps):
+    """float64 torch ops whose ``arr`` hands out ONE leaf tensor per source array, so that the forward restatement
+    above builds an autograd graph on the parameters (what loss.backward() does in density_experiment.py:366-374)."""
+    name = "torch64-grad"
+
+    def __init__(self):
+        self.leaves = {}
+
+    def arr(self, a):
+        if torch.is_tensor(a):
+            return a
+        key = id(a)
+        if key not in self.leaves:
+            t = torch.tensor(np.asarray(a, dtype=np.float64), dtype=torch.float64, requires_grad=True)
+            self.leaves[key] = (a, t)
+        return self.leaves[key][1]
+
+    def zeros(self, n):
+        return torch.zeros(n, dtype=torch.float64)
+
+    def grad_of(self, a):
+        g = self.leaves[id(a)][1].grad
+        return np.zeros(np.shape(a)) if g is None else g.numpy().copy()
+
+
+def param_arrays(spec):
+    """The parameter arrays of a spec in the order of the library's flat gradient buffer (include/gbnf.h,
+    gbnf_trainer_grad_floats): per step [norm a][norm b] then every Linear's [weight][bias] (realnvp: t_net, s_net;
+    without batch norm the two norm regions are reserved: None)."""
+    out = []
+    for st in spec["steps"]:
+        if spec["kind"] == "glow":
+            out += [st["an_bias"], st["an_logs"]]
+            nets = [st["net"]]
+        else:
+            out += [None, None] if st["bn"] is None else [st["bn"]["log_gamma"], st["bn"]["beta"]]
+            nets = [st["t_net"], st["s_net"]]
+        for net in nets:
+            for w, b in net["layers"]:
+                out += [w, b]
+    return out
+
+
+def component_grads(spec, x, g_z, g_ldj):
+    """d(sum(z * g_z) + sum(ldj * g_ldj)) / d(x, parameters) in float64: the vector-Jacobian product a backward pass
+    with upstream gradients (g_z, g_ldj) must return.  -> (g_x (N,d), [gradient per entry of param_arrays(spec)])."""
+    ops = _TorchGradOps()
+    xt = torch.tensor(np.asarray(x, dtype=np.float64), dtype=torch.float64, requires_grad=True)
+    z, ld = xt, ops.zeros(xt.shape[0])
+    for step in spec["steps"]:
+        if spec["kind"] == "glow":
+            z, ld = glow_step(ops, spec, step, z, ld)
+        else:
+            z, step_ld = realnvp_step(ops, spec, step, z)
+            ld = ld + step_ld
+    loss = (z * torch.as_tensor(np.asarray(g_z, dtype=np.float64))).sum() + \
+           (ld * torch.as_tensor(np.asarray(g_ldj, dtype=np.float64))).sum()
+    loss.backward()
+    grads = [None if a is None else ops.grad_of(a) for a in param_arrays(spec)]
+    return xt.grad.numpy().copy(), grads
+
+
 def log_normal_standard_sum(ops, z):
     """log_normal_standard(z, reduce=True, dim=-1): utils/distributions.py:44-60."""
     log_norm = (-0.5 * LOG_2PI) - (0.5 * z * z)

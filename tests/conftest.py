@@ -21,7 +21,20 @@ def golden_names():
     """Forward/mixture fixtures (g1..g6).  g7 (ActNorm data-dependent init), g8 (boosting weights) and g9 (decode)
     have their own tests."""
     names = sorted(os.path.splitext(os.path.basename(p))[0] for p in glob.glob(os.path.join(GOLDEN_DIR, "*.npz")))
-    return [n for n in names if not n.startswith(("g7_", "g8_", "g9_"))]
+    return [n for n in names if not n.startswith(("g7_", "g8_", "g9_", "g10_"))]
+
+
+GRADS_CASES = ("g10_glow_grads_d43_h64", "g10_glow_grads_additive_relu_d8", "g10_realnvp_grads_d21_h32")
+
+
+def load_grads_case(name):
+    """g10: (cfg, spec, x, nll, flat parameter gradients, g_x) -- the reference's own nll.backward()."""
+    from gbnf_amd import synth
+    data = dict(np.load(os.path.join(GOLDEN_DIR, name + ".npz")))
+    cfg = json.loads(bytes(data["config"]).decode())
+    spec = synth.synth_boosted_specs(cfg["kind"], 1, cfg["d"], cfg["h"], cfg["K"], seed=cfg["w_seed"], **cfg["synth_kw"])[0]
+    x = synth.synth_batch(cfg["N"], cfg["d"], seed=cfg["x_seed"], scale=cfg["x_scale"])
+    return cfg, spec, x, float(data["nll"]), data["grads"], data["g_x"]
 
 
 def load_decode_case():

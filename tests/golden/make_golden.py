@@ -319,8 +319,64 @@ def decode_case(name, d=43, h=64, K=5, C=2, N=96):
     print(f"{name}: x[0,0,:3]={xs[0][0, :3]}")
 
 
+def _ref_params_in_flat_order(component, kind):
+    """Reference parameters of one component in the order of the library's flat gradient buffer (include/gbnf.h)."""
+    out = []
+    if kind == "glow":
+        for layer in component.flow.layers:
+            out += [layer.actnorm.bias, layer.actnorm.logs]
+            for m in layer.block.network:
+                if isinstance(m, torch.nn.Linear):
+                    out += [m.weight, m.bias]
+    else:
+        for mods in component.flow_param:
+            bn = mods[2] if len(mods) > 2 else None
+            out += [None, None] if bn is None else [bn.log_gamma, bn.beta]
+            for net in (mods[0], mods[1]):
+                for m in net.network:
+                    if isinstance(m, torch.nn.Linear):
+                        out += [m.weight, m.bias]
+    return out
+
+
+def grads_case(name, kind, d, h, K, N, **synth_kw):
+    """G10: the training step's gradients by the reference itself: nll = mean(-(log_normal_standard(z) + ldj)) of ONE
+    component (density_experiment.py:655-659, the non-boosted / first-component branch of compute_kl_pq_loss), then
+    nll.backward() (density_experiment.py:366-368).  The model is in eval() mode so that RealNVP's BatchNorm uses its
+    running statistics (the form the build differentiates); ActNorm is initialised.  Stores nll and every parameter
+    gradient, concatenated in the order of the library's flat gradient buffer, plus d nll / d x."""
+    C = 1
+    specs = synth.synth_boosted_specs(kind, C, d, h, K, seed=41, **synth_kw)
+    ref_kw = dict(depth=synth_kw.get("depth", 1), coupling=synth_kw.get("coupling", "affine"),
+                  batch_norm=synth_kw.get("batch_norm", True),
+                  coupling_network=synth_kw.get("act", synth_kw.get("coupling_network", "tanh")))
+    model = RefBoostedFlow(ref_args(kind, d, h, K, C, **ref_kw)).eval()
+    install_spec(model.flows[0], specs[0])
+    x = torch.from_numpy(synth.synth_batch(N, d, seed=23, scale=1.2)).requires_grad_(True)
+    z, _, _, ldj, _ = model(x=x, components=0)
+    g_nll = -1.0 * (log_normal_standard(z, reduce=True, dim=-1) + ldj)
+    nll = torch.mean(g_nll)
+    nll.backward()
+    flat = []
+    for p in _ref_params_in_flat_order(model.flows[0], kind):
+        if p is None:
+            flat.append(np.zeros(d, dtype=np.float32))
+        else:
+            flat.append(p.grad.detach().numpy().reshape(-1).astype(np.float32))
+    cfg = dict(case="grads", kind=kind, d=d, h=h, K=K, C=C, N=N, w_seed=41, x_seed=23, x_scale=1.2, synth_kw=synth_kw)
+    np.savez_compressed(os.path.join(HERE, name + ".npz"),
+                        config=np.frombuffer(json.dumps(cfg).encode(), dtype=np.uint8),
+                        nll=np.float32(nll.item()), grads=np.concatenate(flat), g_x=x.grad.numpy().copy())
+    print(f"{name}: nll={nll.item():.5f} |grads|={np.abs(np.concatenate(flat)).max():.4f} n={sum(f.size for f in flat)}")
+
+
 def main():
     torch.set_num_threads(4)
+    if "--grads-only" in sys.argv:
+        grads_case("g10_glow_grads_d43_h64", "glow", 43, 64, 3, 96)
+        grads_case("g10_glow_grads_additive_relu_d8", "glow", 8, 40, 3, 50, coupling="additive", act="relu")
+        grads_case("g10_realnvp_grads_d21_h32", "realnvp", 21, 32, 4, 80)
+        return
     if "--decode-only" in sys.argv:
         decode_case("g9_glow_additive_decode")
         return
@@ -337,6 +393,9 @@ def main():
     actnorm_init_case("g7_glow_actnorm_data_init")
     boosting_weights_case("g8_boosting_weights")
     decode_case("g9_glow_additive_decode")
+    grads_case("g10_glow_grads_d43_h64", "glow", 43, 64, 3, 96)
+    grads_case("g10_glow_grads_additive_relu_d8", "glow", 8, 40, 3, 50, coupling="additive", act="relu")
+    grads_case("g10_realnvp_grads_d21_h32", "realnvp", 21, 32, 4, 80)
     toy_case("g1_toy_realnvp_c2")
     native_glow_case("g2_glow_native_d43_h32_c3")
     # G3: MINIBOONE full width (BASELINE.json metric config), synthetic weights

@@ -110,18 +110,22 @@ def test_handles_follow_parameter_updates(golden_case):
     assert torch.equal(m2.log_prob(x), m.log_prob(x))
 
 
-def test_training_mode_with_grad_is_refused(golden_case):
+def test_training_mode_with_grad_is_recorded(golden_case):
+    """Train mode with gradients enabled goes through the training path (autograd-recorded, live parameters); the
+    no-grad loops of the reference keep using the packed evaluation kernels.  Same numbers either way."""
     import torch
     dev = torch.device("cuda:0")
     g = golden_case("g6_glow_d43_h64_n77")
     m = _model_from_case(g, dev)
     x = torch.from_numpy(g.x).to(dev)
     m.train()
-    with pytest.raises(RuntimeError):
-        m(x=x, components=0)
+    z, _, _, ldj, _ = m(x=x, components=0)
+    assert z.requires_grad and ldj.requires_grad
+    assert rel_err(ldj.detach().cpu().numpy(), g.ldj[0]) < LL_RTOL
     with torch.no_grad():
-        z, _, _, ldj, _ = m(x=x, components=0)       # the no-grad loops of the reference still work
-    assert rel_err(ldj.cpu().numpy(), g.ldj[0]) < LL_RTOL
+        z2, _, _, ldj2, _ = m(x=x, components=0)
+    assert not ldj2.requires_grad
+    assert rel_err(ldj2.cpu().numpy(), g.ldj[0]) < LL_RTOL
 
 
 def test_sharded_single_rank_equals_mixture(golden_case):

@@ -1,0 +1,186 @@
+"""GPU: the training path (gbnf_trainer_*) against the float64 oracle and the reference's own
+nll.backward() (fixtures g10_*).  Tolerances: forward as the evaluation path (1e-5 relative on ldj); gradients 2e-4 of the
+largest entry of each tensor (f32 dot products over up to N samples, atomically accumulated in no fixed order)."""
+import argparse
+
+import numpy as np
+import pytest
+
+from conftest import GRADS_CASES, load_grads_case, rel_err
+
+pytestmark = pytest.mark.gpu
+G_RTOL = 2e-4
+
+
+def _dev_spec(spec, dev):
+    """flow spec (numpy) -> device spec (CUDA tensors) for native.NativeTrainer."""
+    import torch
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).to(dev)
+    net = lambda n: {"act": n["act"], "layers": [(t(w), t(b)) for w, b in n["layers"]]}
+    out = {"kind": spec["kind"], "d": spec["d"], "coupling": spec.get("coupling"), "steps": []}
+    for st in spec["steps"]:
+        if spec["kind"] == "glow":
+            out["steps"].append({"an_bias": t(st["an_bias"]), "an_logs": t(st["an_logs"]), "perm": st["perm"],
+                                 "net": net(st["net"])})
+        else:
+            bn = st["bn"]
+            out["steps"].append({"flipped": st["flipped"],
+                                 "bn": None if bn is None else {**{k: t(bn[k]) for k in ("log_gamma", "beta", "running_mean",
+                                                                                         "running_var")}, "eps": bn["eps"]},
+                                 "t_net": net(st["t_net"]), "s_net": net(st["s_net"])})
+    return out
+
+
+def _check_grads(dev_grads, ref_grads, what):
+    assert len(dev_grads) == len(ref_grads)
+    for k, (a, b) in enumerate(zip(dev_grads, ref_grads)):
+        if b is None:
+            assert a is None
+            continue
+        a = a.detach().cpu().numpy().reshape(b.shape)
+        scale = max(float(np.abs(b).max()), 1e-3)
+        assert np.abs(a - b).max() <= G_RTOL * scale, f"{what}: gradient {k} shape {b.shape}: {np.abs(a - b).max()} vs scale {scale}"
+
+
+TRAIN_CASES = ["g3_glow_d43_h215_c8", "g5_glow_d43_h64_c2_additive", "g5_glow_d43_h64_c2_reverse_relu",
+               "g5_glow_d43_h64_c2_depth2", "g5_glow_d43_h64_c2_depth0", "g5_glow_d6_h30_c2", "g5_glow_d63_h128_c2",
+               "g4_realnvp_d21_h105_c8", "g4_realnvp_d21_h105_c2_mixed", "g4_realnvp_d21_h105_c2_relu_nobn",
+               "g5_realnvp_d6_h30_c3", "g6_glow_d43_h64_n77", "g6_glow_d43_h64_n1", "g6_realnvp_d21_h64_n33",
+               "g1_toy_realnvp_c2"]
+
+
+@pytest.mark.parametrize("name", TRAIN_CASES)
+def test_trainer_forward_and_backward_match_oracle(name, golden_case):
+    import torch
+    from gbnf_amd import native
+    from oracle import gbnf_oracle as oracle
+    dev = torch.device("cuda:0")
+    g = golden_case(name)
+    rng = np.random.RandomState(7)
+    for c in sorted({0, len(g.specs) - 1}):
+        spec = g.specs[c]
+        tr = native.NativeTrainer(_dev_spec(spec, dev))
+        x = torch.from_numpy(g.x).to(dev)
+        z, ldj = tr.forward(x)
+        z64, ldj64 = oracle.component_forward(spec, g.x, backend="numpy64")
+        assert rel_err(ldj.cpu().numpy(), ldj64) < 1e-5
+        assert np.abs(z.cpu().numpy() - z64).max() <= 1e-5 * max(1.0, float(np.abs(z64).max()))
+        g_z = rng.standard_normal(g.x.shape).astype(np.float32)
+        g_l = rng.standard_normal(g.x.shape[0]).astype(np.float32)
+        gx64, grads64 = oracle.component_grads(spec, g.x, g_z, g_l)
+        gx, grads = tr.backward(x, torch.from_numpy(g_z).to(dev), torch.from_numpy(g_l).to(dev), want_gx=True)
+        _check_grads(grads, grads64, f"{name}[{c}]")
+        assert np.abs(gx.cpu().numpy() - gx64).max() <= G_RTOL * float(np.abs(gx64).max())
+        # null upstream gradients are zeros
+        _, only_l = tr.backward(x, None, torch.from_numpy(g_l).to(dev))
+        _, l64 = oracle.component_grads(spec, g.x, np.zeros_like(g_z), g_l)
+        _check_grads(only_l, l64, f"{name}[{c}] g_z=None")
+
+
+@pytest.mark.parametrize("name", GRADS_CASES)
+def test_trainer_matches_reference_backward(name):
+    """g10: the reference's own nll.backward()."""
+    import torch
+    from gbnf_amd import native
+    dev = torch.device("cuda:0")
+    cfg, spec, x, nll, flat, g_x = load_grads_case(name)
+    tr = native.NativeTrainer(_dev_spec(spec, dev))
+    xd = torch.from_numpy(x).to(dev)
+    z, ldj = tr.forward(xd)
+    n = x.shape[0]
+    my_nll = float(torch.mean(-(torch.sum(-0.5 * np.log(2 * np.pi) - 0.5 * z * z, dim=1) + ldj)))
+    assert abs(my_nll - nll) <= 1e-5 * abs(nll)
+    gx, grads = tr.backward(xd, (z / n).contiguous(), torch.full((n,), -1.0 / n, device=dev), want_gx=True)
+    mine = np.concatenate([np.zeros(cfg["d"], np.float32) if gr is None else gr.cpu().numpy().reshape(-1) for gr in grads])
+    assert np.abs(mine - flat).max() <= G_RTOL * float(np.abs(flat).max())
+    assert np.abs(gx.cpu().numpy() - g_x).max() <= G_RTOL * float(np.abs(g_x).max())
+
+
+def _args(kind, d, h, K, C, dev, **kw):
+    return argparse.Namespace(
+        num_flows=K, z_size=d, density_evaluation=True, device=dev, cuda=True, component_type=kind, num_components=C,
+        rho_init="decreasing", learn_top=False, y_classes=0, y_condition=False, sample_size=4, input_size=[d], h_size=h,
+        num_blocks=1, actnorm_scale=1.0, flow_permutation=kw.get("permutation", "shuffle"),
+        flow_coupling=kw.get("coupling", "affine"), LU_decomposed=False, num_dequant_blocks=0,
+        coupling_network=kw.get("act", "tanh"), coupling_network_depth=kw.get("depth", 1),
+        batch_norm=kw.get("batch_norm", True))
+
+
+@pytest.mark.parametrize("name", GRADS_CASES)
+def test_module_autograd_matches_reference(name):
+    """The drop-in module in the reference's training step: nll of component 0, nll.backward(), p.grad vs the fixture."""
+    import torch
+    from gbnf_amd import BoostedFlow
+    dev = torch.device("cuda:0")
+    cfg, spec, x, nll, flat, g_x = load_grads_case(name)
+    m = BoostedFlow(_args(cfg["kind"], cfg["d"], cfg["h"], cfg["K"], 1, dev, **cfg["synth_kw"]))
+    m.load_spec(0, spec)
+    m.train(cfg["kind"] == "glow")          # RealNVP: running-statistics BatchNorm, as in the fixture
+    xd = torch.from_numpy(x).to(dev).requires_grad_(True)
+    z, _, _, ldj, _ = m(x=xd, components=0)
+    loss = torch.mean(-(torch.sum(-0.5 * np.log(2 * np.pi) - 0.5 * z.pow(2), dim=-1) + ldj))
+    assert abs(loss.item() - nll) <= 1e-5 * abs(nll)
+    loss.backward()
+    from gbnf_amd import spec as gspec
+    tr_params = [t for t in m.native_trainer(0).params]
+    mine = np.concatenate([np.zeros(cfg["d"], np.float32) if t is None else t.grad.cpu().numpy().reshape(-1) for t in tr_params])
+    assert np.abs(mine - flat).max() <= G_RTOL * float(np.abs(flat).max())
+    assert np.abs(xd.grad.cpu().numpy() - g_x).max() <= G_RTOL * float(np.abs(g_x).max())
+
+
+def test_training_steps_lower_the_nll_without_rebinding():
+    """A few Adam steps on the HIP path: the trainer is created once (in-place updates need no repacking), the loss goes
+    down, and the evaluation path afterwards sees the updated parameters."""
+    import torch
+    from gbnf_amd import BoostedFlow
+    dev = torch.device("cuda:0")
+    torch.manual_seed(0)
+    m = BoostedFlow(_args("glow", 8, 32, 3, 2, dev)).to(dev)
+    m.train()
+    x = torch.randn(512, 8, device=dev) * torch.linspace(0.5, 2.0, 8, device=dev) + 0.3
+    opt = torch.optim.Adam(m.flows[0].parameters(), lr=5e-3)
+    losses = []
+    trainer_ids = set()
+    for it in range(30):
+        opt.zero_grad()
+        z, _, _, ldj, _ = m(x=x, components=0)
+        loss = torch.mean(-(torch.sum(-0.5 * np.log(2 * np.pi) - 0.5 * z.pow(2), dim=-1) + ldj))
+        loss.backward()
+        opt.step()
+        losses.append(loss.item())
+        trainer_ids.add(id(m.native_trainer(0)))
+    assert len(trainer_ids) == 1
+    assert losses[-1] < losses[0] - 0.2
+    m.eval()
+    with torch.no_grad():
+        z, _, _, ldj, _ = m(x=x, components=0)           # packed evaluation kernel, re-packed from the new parameters
+        after = torch.mean(-(torch.sum(-0.5 * np.log(2 * np.pi) - 0.5 * z.pow(2), dim=-1) + ldj)).item()
+    assert after < losses[-1] + 0.05
+
+
+def test_in_place_change_between_forward_and_backward_is_caught():
+    import torch
+    from gbnf_amd import BoostedFlow
+    dev = torch.device("cuda:0")
+    m = BoostedFlow(_args("glow", 8, 32, 2, 1, dev)).to(dev)
+    m.train()
+    x = torch.randn(64, 8, device=dev)
+    z, _, _, ldj, _ = m(x=x, components=0)
+    with torch.no_grad():
+        next(m.flows[0].parameters()).add_(1.0)
+    with pytest.raises(RuntimeError):
+        (z.sum() + ldj.sum()).backward()
+
+
+def test_trainer_argument_validation():
+    import ctypes as C
+    import torch
+    from gbnf_amd import native
+    L = native.lib()
+    assert L.gbnf_trainer_forward(None, None, 4, None, None, None) == -1
+    assert L.gbnf_trainer_backward(None, None, 4, None, None, None, None, None, 0, None) == -1
+    assert L.gbnf_trainer_destroy(None) == 0
+    with pytest.raises(native.GbnfError):          # CPU tensors: no CPU path
+        native.NativeTrainer({"kind": "glow", "d": 4, "coupling": "affine", "steps": [
+            {"an_bias": torch.zeros(4), "an_logs": torch.zeros(4), "perm": np.arange(4),
+             "net": {"act": "tanh", "layers": [(torch.zeros(8, 2), torch.zeros(8)), (torch.zeros(4, 8), torch.zeros(4))]}}]})

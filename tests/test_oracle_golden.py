@@ -2,7 +2,7 @@
 import numpy as np
 import pytest
 
-from conftest import golden_names, load_actnorm_init_case, load_decode_case, rel_err
+from conftest import GRADS_CASES, golden_names, load_actnorm_init_case, load_decode_case, load_grads_case, rel_err
 from oracle import gbnf_oracle as oracle
 
 LL_RTOL = 1e-5     # BASELINE.json: log-likelihood within 1e-5 relative
@@ -106,3 +106,19 @@ def test_inverse_round_trip(name, golden_case):
         x, ild = oracle.component_inverse(spec, z, backend="numpy64")
         assert np.abs(x - g.x).max() <= 1e-9 * max(1.0, np.abs(g.x).max())
         assert np.abs(ild + ldj).max() <= 1e-9 * max(1.0, np.abs(ldj).max())
+
+
+@pytest.mark.parametrize("name", GRADS_CASES)
+def test_oracle_gradients_match_reference_backward(name):
+    """g10: nll = mean(-(log N(z;0,I) + ldj)); nll.backward() by the reference  vs  the oracle's float64 autograd with the
+    upstream gradients of that loss (d nll/dz = z/N, d nll/dldj = -1/N)."""
+    cfg, spec, x, nll, flat, g_x = load_grads_case(name)
+    z, ldj = oracle.component_forward(spec, x, backend="numpy64")
+    n = x.shape[0]
+    my_nll = float(np.mean(-(np.sum(-0.5 * np.log(2 * np.pi) - 0.5 * z * z, axis=1) + ldj)))
+    assert abs(my_nll - nll) <= 1e-5 * abs(nll)
+    gx, grads = oracle.component_grads(spec, x, z / n, -np.ones(n) / n)
+    mine = np.concatenate([np.zeros(cfg["d"]) if g is None else g.reshape(-1) for g in grads])
+    assert mine.shape == flat.shape
+    assert np.abs(mine - flat).max() <= 2e-5 * np.abs(flat).max()
+    assert np.abs(gx - g_x).max() <= 2e-5 * np.abs(g_x).max()
