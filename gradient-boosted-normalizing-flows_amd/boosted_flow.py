@@ -416,9 +416,12 @@ class BoostedFlow(nn.Module):
             raise native.GbnfError("x must live on the MI355X (cuda) device: this module has no CPU path")
 
     def _needs_grad(self, x, c):
-        """True when the call must be recorded by autograd: gradients enabled and the input or a parameter of
-        component c asks for one (the training step of density_experiment.py:366-374)."""
-        if not torch.is_grad_enabled():
+        """True when the call must be recorded by autograd: TRAIN mode, gradients enabled and the input or a parameter
+        of component c asks for one (the training step of density_experiment.py:366-374).  In eval() mode the module
+        is a density evaluator: calls run on the packed kernels and return tensors without autograd history (the
+        reference's evaluate() detaches them anyway, density_experiment.py:558-603); ask for a recorded call in eval
+        mode explicitly with ``component_forward(x, c, differentiable=True)``."""
+        if not (self.training and torch.is_grad_enabled()):
             return False
         return bool(x.requires_grad) or any(p.requires_grad for p in self.flows[c].parameters())
 
@@ -490,13 +493,14 @@ class BoostedFlow(nn.Module):
         return self._mixture[1]
 
     # ------------------------------------------------------------------ convenience API (BASELINE.json)
-    def component_forward(self, x, c):
-        """x (N,d) -> z (N,d), ldj (N,) of component c  ==  self.flows[c](x)[0], [3] of the reference."""
+    def component_forward(self, x, c, differentiable=None):
+        """x (N,d) -> z (N,d), ldj (N,) of component c  ==  self.flows[c](x)[0], [3] of the reference.
+        ``differentiable``: None = recorded by autograd in train mode only (see ``_needs_grad``); True / False force it."""
         self._check_ready(x)
         x = x.contiguous().float()
         self._ensure_actnorm(x, int(c))
         with torch.cuda.device(x.device):
-            if self._needs_grad(x, int(c)):
+            if self._needs_grad(x, int(c)) if differentiable is None else bool(differentiable):
                 trainer = self.native_trainer(int(c))
                 params = [t for t in trainer.params if t is not None]
                 return _FlowFunction.apply(trainer, x, *params)

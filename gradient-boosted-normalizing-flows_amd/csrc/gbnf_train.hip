@@ -222,12 +222,13 @@ __global__ void __launch_bounds__(64) train_kernel(const TrainLaunch p) {
     const int nl = net.n_layers;
     for (int l = 0; l + 1 < nl; ++l) {
       float* Hl = H + (size_t)l * p.hp * S;
-      float* ws_h = (MODE == 1) ? ws_net + ((size_t)p.ip + (size_t)l * p.hp) * p.np + row0 + i : nullptr;
+      const bool emit = (MODE == 1) && ws_net != nullptr;    // backward sweep only: activation-side operand of dW
+      float* ws_h = emit ? ws_net + ((size_t)p.ip + (size_t)l * p.hp) * p.np + row0 + i : nullptr;
       const int act = net.act;
       tr_dense<false>(net.layer[l], true, in, hid_tiles, lane, [&](int u, float v) {
         const float h = tr_act(act, v);
         Hl[u * S + i] = h;
-        if (MODE == 1) ws_h[(size_t)u * p.np] = h;
+        if (emit) ws_h[(size_t)u * p.np] = h;
       });
       in = Hl;
     }

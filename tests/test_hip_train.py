@@ -115,9 +115,17 @@ def test_module_autograd_matches_reference(name):
     cfg, spec, x, nll, flat, g_x = load_grads_case(name)
     m = BoostedFlow(_args(cfg["kind"], cfg["d"], cfg["h"], cfg["K"], 1, dev, **cfg["synth_kw"]))
     m.load_spec(0, spec)
-    m.train(cfg["kind"] == "glow")          # RealNVP: running-statistics BatchNorm, as in the fixture
     xd = torch.from_numpy(x).to(dev).requires_grad_(True)
-    z, _, _, ldj, _ = m(x=xd, components=0)
+    if cfg["kind"] == "glow":
+        m.train()
+        z, _, _, ldj, _ = m(x=xd, components=0)
+    else:                                   # RealNVP: running-statistics BatchNorm, as in the fixture
+        m.eval()
+        with pytest.raises(NotImplementedError):
+            m.train()
+            m(x=xd, components=0)
+        m.eval()
+        z, ldj = m.component_forward(xd, 0, differentiable=True)
     loss = torch.mean(-(torch.sum(-0.5 * np.log(2 * np.pi) - 0.5 * z.pow(2), dim=-1) + ldj))
     assert abs(loss.item() - nll) <= 1e-5 * abs(nll)
     loss.backward()
