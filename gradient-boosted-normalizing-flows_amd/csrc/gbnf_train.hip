@@ -42,6 +42,10 @@ constexpr int TR_S = 17;            // LDS row stride (floats): 16 samples + 1 p
 constexpr int TR_MAX_LAYERS = 4;    // Linear layers per coupling net (depth <= 2)
 constexpr int TR_MAX_IN = 32;       // coupling-net input / coupled-half width
 constexpr int TR_LDS_BYTES = 160 * 1024;
+#ifndef GBNF_TR_WAVES
+#define GBNF_TR_WAVES 4
+#endif
+constexpr int TR_WAVES = GBNF_TR_WAVES;         // waves per workgroup; they share one 16-sample tile and split every layer's tiles
 
 struct TrLayer {
   const float* W;      // (rows, cols) row-major = nn.Linear.weight (out, in)
@@ -97,6 +101,12 @@ __device__ __forceinline__ float tr_dact(int act, float h) {
 __device__ __forceinline__ f32x4 tr_mfma(float a, float b, f32x4 c) {
   return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
 }
+// Accumulators are read right behind a loop exit: the compiler's MFMA-result hazard padding does not look across that
+// branch on gfx950 / ROCm 7.2 (same finding as in gbnf_flow_kernel.hip.h: the last k-step went missing), so pad by hand.
+// The accumulators are operands of the padding ("+a": they stay in AGPRs), so every read of them is ordered behind it.
+__device__ __forceinline__ void tr_mfma_drain(f32x4& c0, f32x4& c1) {
+  asm volatile("s_nop 7\n\ts_nop 7" : "+a"(c0), "+a"(c1));
+}
 
 // A fragment of W (rows x cols, row-major): lane (i,g) gets W[row0+i][col0+4g .. +3]  (k-step r <-> k = col0+4g+r)
 __device__ __forceinline__ f32x4 tr_load_a(const float* __restrict__ W, int rows, int cols, int row, int col) {
@@ -129,13 +139,19 @@ __device__ __forceinline__ f32x4 tr_load_at(const float* __restrict__ W, int row
 // TRANS = false: A = W (out units = W rows, k = W cols).  TRANS = true: A = W^T (out units = W cols, k = W rows).
 template <bool TRANS, class Epi>
 __device__ __forceinline__ void tr_dense(const TrLayer& L, bool use_bias, const float* in, int out_tiles, int lane,
-                                         Epi epi) {
+                                         int wave, Epi epi) {
   const int i = lane & 15, g = lane >> 4;
   const int rows = L.rows, cols = L.cols;
+  const float* __restrict__ W = L.W;
   const int kdim = TRANS ? rows : cols;
   const int udim = TRANS ? cols : rows;
   const int kc = (kdim + 15) >> 4;
-  for (int o = 0; o < out_tiles; o += 2) {
+  auto load = [&](int o, int c) -> f32x4 {
+    if constexpr (TRANS) return tr_load_at(W, rows, cols, 16 * o + i, 16 * c + 4 * g);
+    else return tr_load_a(W, rows, cols, 16 * o + i, 16 * c + 4 * g);
+  };
+  // wave w owns the tile pairs (2w, 2w+1), (2w + 2*TR_WAVES, ...): the waves of a workgroup split one layer
+  for (int o = 2 * wave; o < out_tiles; o += 2 * TR_WAVES) {
     const bool two = o + 1 < out_tiles;
     f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
     if (use_bias) {
@@ -146,31 +162,32 @@ __device__ __forceinline__ void tr_dense(const TrLayer& L, bool use_bias, const 
         if (two && u1 < udim) acc1[r] = L.b[u1];
       }
     }
+    const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+    f32x4 a0n = load(o, 0), a1n = two ? load(o + 1, 0) : zero;
     for (int c = 0; c < kc; ++c) {
-      const int k = 16 * c + 4 * g;
-      f32x4 a0, a1 = {0.f, 0.f, 0.f, 0.f};
-      if constexpr (TRANS) {
-        a0 = tr_load_at(L.W, rows, cols, 16 * o + i, k);
-        if (two) a1 = tr_load_at(L.W, rows, cols, 16 * o + 16 + i, k);
-      } else {
-        a0 = tr_load_a(L.W, rows, cols, 16 * o + i, k);
-        if (two) a1 = tr_load_a(L.W, rows, cols, 16 * o + 16 + i, k);
+      const f32x4 a0 = a0n, a1 = a1n;
+      if (c + 1 < kc) {                      // next chunk's weights are in flight under this chunk's MFMAs
+        a0n = load(o, c + 1);
+        if (two) a1n = load(o + 1, c + 1);
       }
+      const int k = 16 * c + 4 * g;
       float b[4];
 #pragma unroll
       for (int r = 0; r < 4; ++r) b[r] = in[(k + r) * TR_S + i];
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
+      for (int r = 0; r < 4; ++r) {           // (an odd last tile multiplies zeros: no branch, accumulators stay in AGPRs)
         acc0 = tr_mfma(a0[r], b[r], acc0);
-        if (two) acc1 = tr_mfma(a1[r], b[r], acc1);
+        acc1 = tr_mfma(a1[r], b[r], acc1);
       }
     }
+    tr_mfma_drain(acc0, acc1);
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       epi(16 * o + 4 * g + r, acc0[r]);
       if (two) epi(16 * o + 16 + 4 * g + r, acc1[r]);
     }
   }
+  __syncthreads();     // the layer's output (LDS) is complete for every wave
 }
 
 __device__ __forceinline__ float tr_group_sum(float v) {   // sum over the 16 lanes of a lane group (all active)
@@ -182,10 +199,12 @@ __device__ __forceinline__ float tr_group_sum(float v) {   // sum over the 16 la
 }
 
 template <int KIND, int MODE>
-__global__ void __launch_bounds__(64) train_kernel(const TrainLaunch p) {
+__global__ void __launch_bounds__(64 * TR_WAVES) train_kernel(const TrainLaunch p) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   constexpr int S = TR_S;
-  const int lane = threadIdx.x, i = lane & 15, g = lane >> 4;
+  constexpr int GS = 4 * TR_WAVES;                       // lane groups of 16 in the workgroup: elementwise loop stride
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, i = lane & 15;
+  const int g = 4 * wave + (lane >> 4);                  // lane-group index (elementwise work); MFMA code uses lane, wave
   const int d = p.d, K = p.K;
   const int64_t row0 = (int64_t)blockIdx.x * 16;
   const int64_t ni = row0 + i;
@@ -225,7 +244,7 @@ __global__ void __launch_bounds__(64) train_kernel(const TrainLaunch p) {
       const bool emit = (MODE == 1) && ws_net != nullptr;    // backward sweep only: activation-side operand of dW
       float* ws_h = emit ? ws_net + ((size_t)p.ip + (size_t)l * p.hp) * p.np + row0 + i : nullptr;
       const int act = net.act;
-      tr_dense<false>(net.layer[l], true, in, hid_tiles, lane, [&](int u, float v) {
+      tr_dense<false>(net.layer[l], true, in, hid_tiles, lane, wave, [&](int u, float v) {
         const float h = tr_act(act, v);
         Hl[u * S + i] = h;
         if (emit) ws_h[(size_t)u * p.np] = h;
@@ -233,7 +252,7 @@ __global__ void __launch_bounds__(64) train_kernel(const TrainLaunch p) {
       in = Hl;
     }
     if (out != nullptr)
-      tr_dense<false>(net.layer[nl - 1], true, in, out_tiles, lane, [&](int u, float v) { out[u * S + i] = v; });
+      tr_dense<false>(net.layer[nl - 1], true, in, out_tiles, lane, wave, [&](int u, float v) { out[u * S + i] = v; });
   };
 
   // ---- coupling net backward: cur = gradient w.r.t. the net output (LDS, [op]); leaves d(loss)/d(net input) in GX
@@ -242,41 +261,44 @@ __global__ void __launch_bounds__(64) train_kernel(const TrainLaunch p) {
     // gradient-side operand of the last layer's weight gradient
     {
       float* ws_d = ws_net + ((size_t)p.ip + 2 * (size_t)nh * p.hp) * p.np + row0 + i;
-      for (int u = g; u < p.op; u += 4) ws_d[(size_t)u * p.np] = cur[u * S + i];
+      for (int u = g; u < p.op; u += GS) ws_d[(size_t)u * p.np] = cur[u * S + i];
     }
     for (int l = nl - 1; l >= 1; --l) {
       float* Hl = H + (size_t)(l - 1) * p.hp * S;           // activations of hidden layer l-1 -> overwritten by its gradient
       float* ws_d = ws_net + ((size_t)p.ip + (size_t)nh * p.hp + (size_t)(l - 1) * p.hp) * p.np + row0 + i;
       const int act = net.act;
-      tr_dense<true>(net.layer[l], false, cur, hid_tiles, lane, [&](int u, float v) {
+      tr_dense<true>(net.layer[l], false, cur, hid_tiles, lane, wave, [&](int u, float v) {
         const float gpre = v * tr_dact(act, Hl[u * S + i]);
         Hl[u * S + i] = gpre;
         ws_d[(size_t)u * p.np] = gpre;
       });
       cur = Hl;
     }
-    tr_dense<true>(net.layer[0], false, cur, in_tiles, lane, [&](int u, float v) {
+    tr_dense<true>(net.layer[0], false, cur, in_tiles, lane, wave, [&](int u, float v) {
       GX[u * S + i] = accumulate ? GX[u * S + i] + v : v;
     });
   };
 
   // ---- x tile -> Zc (slot j = feature j)
-  for (int j = g; j < d; j += 4) Zc[j * S + i] = valid ? p.x[ni * d + j] : 0.0f;
+  for (int j = g; j < d; j += GS) Zc[j * S + i] = valid ? p.x[ni * d + j] : 0.0f;
+  __syncthreads();
 
   // =============================== forward through all steps
-  float ld = 0.0f;   // per-lane partial of log|det J| (lane group g adds its own slots / features)
+  float ld = 0.0f;   // per-lane partial of log|det J| (every lane group adds its own slots / features)
   for (int k = 0; k < K; ++k) {
     const TrStep& st = p.steps[k];
-    for (int s = g; s < d; s += 4) {
+    for (int s = g; s < d; s += GS) {
       const float y = norm_fwd(st, s, Zc[s * S + i], ld);
       Zc[s * S + i] = y;
       if (MODE == 1) Y[((size_t)k * d + s) * S + i] = y;
     }
     if (MODE == 1 && k == K - 1) break;                    // the last step's outputs are not needed for the backward
-    for (int kk = g; kk < p.ip; kk += 4) X[kk * S + i] = kk < st.in_f ? Zc[st.in_slot[kk] * S + i] : 0.0f;
+    __syncthreads();
+    for (int kk = g; kk < p.ip; kk += GS) X[kk * S + i] = kk < st.in_f ? Zc[st.in_slot[kk] * S + i] : 0.0f;
+    __syncthreads();
     if constexpr (KIND == GBNF_KIND_GLOW) {
       net_forward(st.net[0], O, nullptr);
-      for (int j = g; j < st.out_f; j += 4) {
+      for (int j = g; j < st.out_f; j += GS) {
         const int slot = st.out_slot[j];
         const float y2 = Zc[slot * S + i];
         if (p.additive) {
@@ -291,28 +313,37 @@ __global__ void __launch_bounds__(64) train_kernel(const TrainLaunch p) {
     } else {
       net_forward(st.net[0], O2, nullptr);
       net_forward(st.net[1], O, nullptr);
-      for (int j = g; j < st.out_f; j += 4) {
+      for (int j = g; j < st.out_f; j += GS) {
         const int slot = st.out_slot[j];
         const float scale = O[j * S + i];
         Zc[slot * S + i] = O2[j * S + i] + Zc[slot * S + i] * __expf(scale);      // models/transformations.py:575
         ld += scale;                                                             // models/transformations.py:577
       }
     }
+    __syncthreads();
   }
 
   if constexpr (MODE == 0) {
     ld += __shfl_xor(ld, 16);
     ld += __shfl_xor(ld, 32);
+    if ((lane >> 4) == 0) X[wave * 16 + i] = ld;          // X is free: fold the waves' partial sums through it
+    __syncthreads();
     if (valid) {
-      if (p.ldj_out != nullptr && g == 0) p.ldj_out[ni] = ld;
+      if (p.ldj_out != nullptr && g == 0) {
+        float t = 0.0f;
+        for (int w = 0; w < TR_WAVES; ++w) t += X[w * 16 + i];
+        p.ldj_out[ni] = t;
+      }
       if (p.z_out != nullptr)
-        for (int j = g; j < d; j += 4) p.z_out[ni * d + j] = Zc[p.tail[j] * S + i];
+        for (int j = g; j < d; j += GS) p.z_out[ni * d + j] = Zc[p.tail[j] * S + i];
     }
     return;
   } else {
     // =============================== backward
+    __syncthreads();
     const float gl = (valid && p.g_ldj != nullptr) ? p.g_ldj[ni] : 0.0f;
-    for (int j = g; j < d; j += 4) Zc[p.tail[j] * S + i] = (valid && p.g_z != nullptr) ? p.g_z[ni * d + j] : 0.0f;
+    for (int j = g; j < d; j += GS) Zc[p.tail[j] * S + i] = (valid && p.g_z != nullptr) ? p.g_z[ni * d + j] : 0.0f;
+    __syncthreads();
     float* G = Zc;
     const int nnets = (KIND == GBNF_KIND_GLOW) ? 1 : 2;
 
@@ -346,14 +377,15 @@ __global__ void __launch_bounds__(64) train_kernel(const TrainLaunch p) {
       const float* Yk = Y + (size_t)k * d * S;
       float* ws_step = p.ws + (size_t)k * nnets * p.net_rows * p.np;
       // net input (also the activation-side operand of the first layer's weight gradient)
-      for (int kk = g; kk < p.ip; kk += 4) {
+      for (int kk = g; kk < p.ip; kk += GS) {
         const float v = kk < st.in_f ? Yk[st.in_slot[kk] * S + i] : 0.0f;
         X[kk * S + i] = v;
         for (int q = 0; q < nnets; ++q) (ws_step + (size_t)q * p.net_rows * p.np)[(size_t)kk * p.np + row0 + i] = v;
       }
+      __syncthreads();
       if constexpr (KIND == GBNF_KIND_GLOW) {
         net_forward(st.net[0], O, ws_step);
-        for (int j = g; j < st.out_f; j += 4) {
+        for (int j = g; j < st.out_f; j += GS) {
           const int slot = st.out_slot[j];
           const float y2 = Yk[slot * S + i], g2 = G[slot * S + i];
           float gy;
@@ -371,13 +403,15 @@ __global__ void __launch_bounds__(64) train_kernel(const TrainLaunch p) {
           }
           G[slot * S + i] = norm_bwd(st, slot, gy, y2);
         }
+        __syncthreads();
         net_backward(st.net[0], O, ws_step, false);
       } else {
         float* ws_t = ws_step;
         float* ws_s = ws_step + (size_t)p.net_rows * p.np;
         net_forward(st.net[1], O, ws_s);                                 // log-scale net
-        for (int u = g; u < p.op; u += 4) O2[u * S + i] = 0.0f;
-        for (int j = g; j < st.out_f; j += 4) {
+        for (int u = g; u < p.op; u += GS) O2[u * S + i] = 0.0f;
+        __syncthreads();
+        for (int j = g; j < st.out_f; j += GS) {
           const int slot = st.out_slot[j];
           const float y2 = Yk[slot * S + i], g2 = G[slot * S + i];
           const float es = __expf(O[j * S + i]);
@@ -385,17 +419,19 @@ __global__ void __launch_bounds__(64) train_kernel(const TrainLaunch p) {
           O[j * S + i] = g2 * y2 * es + gl;                              // d/d scale: z2' = shift + y2 e^scale, ld += scale
           G[slot * S + i] = norm_bwd(st, slot, g2 * es, y2);
         }
+        __syncthreads();
         net_backward(st.net[1], O, ws_s, false);
         net_forward(st.net[0], nullptr, ws_t);                           // shift net: only its activations are needed
         net_backward(st.net[0], O2, ws_t, true);
       }
-      for (int kk = g; kk < st.in_f; kk += 4) {
+      for (int kk = g; kk < st.in_f; kk += GS) {
         const int slot = st.in_slot[kk];
         G[slot * S + i] = norm_bwd(st, slot, G[slot * S + i] + GX[kk * S + i], Yk[slot * S + i]);
       }
+      __syncthreads();
     }
     if (valid && p.g_x != nullptr)
-      for (int j = g; j < d; j += 4) p.g_x[ni * d + j] = G[j * S + i];
+      for (int j = g; j < d; j += GS) p.g_x[ni * d + j] = G[j * S + i];
   }
 }
 
@@ -445,6 +481,9 @@ __global__ void __launch_bounds__(64) wgrad_kernel(const WgProblem* __restrict__
       }
     }
   }
+  tr_mfma_drain(c00, c01);
+  tr_mfma_drain(c10, c11);
+  tr_mfma_drain(cb0, cb1);
   float* C = grads + P.c_off;
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
@@ -644,9 +683,9 @@ int gbnf_trainer_forward(const gbnf_trainer* t, const float* x, int64_t n, float
   p.z_out = z; p.ldj_out = ldj;
   const dim3 grid((unsigned)(p.np / 16));
   if (t->kind == GBNF_KIND_GLOW)
-    hipLaunchKernelGGL((train_kernel<GBNF_KIND_GLOW, 0>), grid, dim3(64), t->lds_fwd, (hipStream_t)stream, p);
+    hipLaunchKernelGGL((train_kernel<GBNF_KIND_GLOW, 0>), grid, dim3(64 * TR_WAVES), t->lds_fwd, (hipStream_t)stream, p);
   else
-    hipLaunchKernelGGL((train_kernel<GBNF_KIND_REALNVP, 0>), grid, dim3(64), t->lds_fwd, (hipStream_t)stream, p);
+    hipLaunchKernelGGL((train_kernel<GBNF_KIND_REALNVP, 0>), grid, dim3(64 * TR_WAVES), t->lds_fwd, (hipStream_t)stream, p);
   const hipError_t e = hipGetLastError();
   if (e != hipSuccess) return fail(GBNF_ERR_HIP, "gbnf_trainer_forward launch: %s", hipGetErrorString(e));
   return GBNF_OK;
@@ -669,9 +708,9 @@ int gbnf_trainer_backward(const gbnf_trainer* t, const float* x, int64_t n, cons
   const dim3 grid((unsigned)(p.np / 16));
   hipStream_t s = (hipStream_t)stream;
   if (t->kind == GBNF_KIND_GLOW)
-    hipLaunchKernelGGL((train_kernel<GBNF_KIND_GLOW, 1>), grid, dim3(64), t->lds_bwd, s, p);
+    hipLaunchKernelGGL((train_kernel<GBNF_KIND_GLOW, 1>), grid, dim3(64 * TR_WAVES), t->lds_bwd, s, p);
   else
-    hipLaunchKernelGGL((train_kernel<GBNF_KIND_REALNVP, 1>), grid, dim3(64), t->lds_bwd, s, p);
+    hipLaunchKernelGGL((train_kernel<GBNF_KIND_REALNVP, 1>), grid, dim3(64 * TR_WAVES), t->lds_bwd, s, p);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return fail(GBNF_ERR_HIP, "gbnf_trainer_backward launch: %s", hipGetErrorString(e));
   const dim3 wgrid((unsigned)t->wg_blocks, (unsigned)((p.np + WG_CHUNK - 1) / WG_CHUNK));

@@ -1,0 +1,130 @@
+#!/usr/bin/env python3
+"""Training-step timing of ONE component on the HIP training path: forward + backward
+(gbnf_trainer_forward / gbnf_trainer_backward) on synthetic data, next to (a) the same step in plain PyTorch on the GPU
+(eager autograd over the oracle's op order) and (b) the torch-CPU oracle.  Prints one JSON line.
+
+    python tools/bench_train.py [--config miniboone_glow|hepmass_realnvp] [--batch N] [--steps K] [--warmup W]
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+import numpy as np
+import torch
+
+CONFIGS = {"miniboone_glow": dict(kind="glow", d=43, h=215, K=5, kw={}),
+           "hepmass_realnvp": dict(kind="realnvp", d=21, h=105, K=5, kw={})}
+
+
+def torch_step(spec, x, dev, dtype=torch.float32):
+    """One forward+backward of the same component in eager PyTorch (oracle op order) on `dev`."""
+    from oracle import gbnf_oracle as oracle
+
+    class Ops(oracle._TorchGradOps):
+        def arr(self, a):
+            if torch.is_tensor(a):
+                return a
+            key = id(a)
+            if key not in self.leaves:
+                self.leaves[key] = (a, torch.tensor(np.asarray(a), dtype=dtype, device=dev, requires_grad=True))
+            return self.leaves[key][1]
+
+        def idx(self, a):
+            return torch.as_tensor(np.asarray(a), dtype=torch.long, device=dev)
+
+        def zeros(self, n):
+            return torch.zeros(n, dtype=dtype, device=dev)
+
+    ops = Ops()
+
+    def step():
+        z, ld = x, ops.zeros(x.shape[0])
+        for st in spec["steps"]:
+            if spec["kind"] == "glow":
+                z, ld = oracle.glow_step(ops, spec, st, z, ld)
+            else:
+                z, sld = oracle.realnvp_step(ops, spec, st, z)
+                ld = ld + sld
+        loss = torch.mean(-(torch.sum(-0.5 * np.log(2 * np.pi) - 0.5 * z * z, dim=1) + ld))
+        for _, t in ops.leaves.values():
+            t.grad = None
+        loss.backward()
+        return loss
+    return step
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--config", default="miniboone_glow")
+    ap.add_argument("--batch", type=int, default=4096)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--cpu-steps", type=int, default=3)
+    a = ap.parse_args()
+    cfg = CONFIGS[a.config]
+    from gbnf_amd import native, synth
+    from test_hip_train import _dev_spec
+    dev = torch.device("cuda:0")
+    spec = synth.synth_boosted_specs(cfg["kind"], 1, cfg["d"], cfg["h"], cfg["K"], seed=1, **cfg["kw"])[0]
+    tr = native.NativeTrainer(_dev_spec(spec, dev))
+    x = torch.from_numpy(synth.synth_batch(a.batch, cfg["d"], seed=0)).to(dev)
+    n = a.batch
+
+    def hip_step():
+        z, ldj = tr.forward(x)
+        g_z = z / n
+        g_l = torch.full((n,), -1.0 / n, device=dev)
+        return tr.backward(x, g_z, g_l)
+
+    def timed(fn, steps, warmup):
+        for _ in range(warmup):
+            fn()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            fn()
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / steps
+
+    t_hip = timed(hip_step, a.steps, a.warmup)
+    # kernel-only: events around forward, backward
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
+    z, ldj = tr.forward(x)
+    g_z = (z / n).contiguous(); g_l = torch.full((n,), -1.0 / n, device=dev)
+    torch.cuda.synchronize()
+    fw = bw = 0.0
+    for _ in range(a.steps):
+        ev[0].record(); tr.forward(x); ev[1].record(); tr.backward(x, g_z, g_l); ev[2].record()
+        torch.cuda.synchronize()
+        fw += ev[0].elapsed_time(ev[1]); bw += ev[1].elapsed_time(ev[2])
+    fw /= a.steps; bw /= a.steps
+    t_gpu_torch = timed(torch_step(spec, x, dev), a.steps, a.warmup)
+    torch.set_num_threads(min(8, os.cpu_count() or 1))
+    xc = x.cpu()
+    cpu_fn = torch_step(spec, xc, torch.device("cpu"))
+    cpu_fn()
+    t0 = time.perf_counter()
+    for _ in range(a.cpu_steps):
+        cpu_fn()
+    t_cpu = (time.perf_counter() - t0) / a.cpu_steps
+    macs = sum((w.shape[0] * w.shape[1]) for st in spec["steps"] for net in ([st["net"]] if cfg["kind"] == "glow" else [st["t_net"], st["s_net"]]) for w, _ in net["layers"])
+    flops = 2.0 * macs * n * 3        # forward + dgrad + wgrad
+    print(json.dumps({
+        "metric": f"training step (forward+backward) samples/sec, one component, {a.config}", "unit": "samples/s",
+        "value": n / t_hip, "ms_per_step": t_hip * 1e3, "batch": n,
+        "forward_kernel_ms": fw, "backward_kernels_ms": bw,
+        "algorithmic_tflops": flops / t_hip / 1e12, "algorithmic_tflops_kernels_only": flops / ((fw + bw) * 1e-3) / 1e12,
+        "torch_gpu_eager": {"value": n / t_gpu_torch, "ms_per_step": t_gpu_torch * 1e3},
+        "cpu_baseline": {"value": n / t_cpu, "ms_per_step": t_cpu * 1e3, "threads": torch.get_num_threads(),
+                         "kind": "port (torch-CPU autograd over the oracle's op order)"},
+        "speedup_vs_torch_gpu_eager": t_gpu_torch / t_hip, "speedup_vs_cpu": t_cpu / t_hip}))
+
+
+if __name__ == "__main__":
+    main()
