@@ -45,12 +45,14 @@ constexpr int TR_LDS_BYTES = 160 * 1024;
 #ifndef GBNF_TR_WAVES
 #define GBNF_TR_WAVES 4
 #endif
+constexpr int TR_PD = 4;            // weight-prefetch distance of the dense layers, in k-chunks
 constexpr int TR_WAVES = GBNF_TR_WAVES;         // waves per workgroup; they share one 16-sample tile and split every layer's tiles
 
 struct TrLayer {
   const float* W;      // (rows, cols) row-major = nn.Linear.weight (out, in)
   const float* b;      // (rows,)
   int64_t gW, gb;      // float offsets into the flat gradient buffer
+  int64_t wt;          // float offset of the transposed copy (cols x rows) in the workspace's weight region
   int rows, cols;
 };
 struct TrNet {
@@ -81,7 +83,9 @@ struct TrainLaunch {
   const float* g_ldj;  // MODE 1 (n,) or null
   float* g_x;          // MODE 1 (n, d) or null
   float* grads;        // MODE 1 flat parameter-gradient buffer
-  float* ws;           // MODE 1 workspace
+  unsigned long long* dbg;   // diagnostic builds only
+  float* ws;           // MODE 1 workspace: operands of the weight gradients ...
+  const float* wt;     // ... followed by the transposed copies of the weights (made by transpose_kernel)
   int64_t n, np;       // samples, samples rounded up to 16
   int d, K, kind, additive;
   int n_hidden;        // hidden layers per net = depth + 1
@@ -107,87 +111,198 @@ __device__ __forceinline__ f32x4 tr_mfma(float a, float b, f32x4 c) {
 __device__ __forceinline__ void tr_mfma_drain(f32x4& c0, f32x4& c1) {
   asm volatile("s_nop 7\n\ts_nop 7" : "+a"(c0), "+a"(c1));
 }
+// ... and the other direction: freshly written accumulators feed an MFMA in the next basic block.
+__device__ __forceinline__ void tr_acc_settle(f32x4& c0, f32x4& c1) {
+  asm volatile("s_nop 3" : "+a"(c0), "+a"(c1));
+}
 
-// A fragment of W (rows x cols, row-major): lane (i,g) gets W[row0+i][col0+4g .. +3]  (k-step r <-> k = col0+4g+r)
-__device__ __forceinline__ f32x4 tr_load_a(const float* __restrict__ W, int rows, int cols, int row, int col) {
-  f32x4 a = {0.f, 0.f, 0.f, 0.f};
-  if (row < rows) {
-    const float* p = W + (size_t)row * cols + col;
-    if (col + 3 < cols) {
-      const f32x4u v = *reinterpret_cast<const f32x4u*>(p);
-      a[0] = v[0]; a[1] = v[1]; a[2] = v[2]; a[3] = v[3];
-    } else {
+// Parameter tensors are global memory: say so, or every load is a flat_load that also counts against lgkmcnt.
+typedef const float __attribute__((address_space(1)))* gptr;
+__device__ __forceinline__ gptr tr_global(const float* p) { return (gptr)(p); }
+
+// In-kernel phase stamps, diagnostic builds only (-DGBNF_TRAIN_STAMPS; tools/train_stamps.py).
+struct TrStamps {
+#ifdef GBNF_TRAIN_STAMPS
+  unsigned long long last = 0, acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#endif
+  __device__ __forceinline__ void mark(int k) {
+#ifdef GBNF_TRAIN_STAMPS
+    unsigned long long t;
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
+    __builtin_amdgcn_sched_barrier(0);
+    if (k >= 0) acc[k] += t - last;
+    last = t;
+#else
+    (void)k;
+#endif
+  }
+};
+
+__device__ __forceinline__ int tr_uniform(int v) { return __builtin_amdgcn_readfirstlane(v); }
+// A pointer that is the same in every lane, moved to scalar registers: address arithmetic on it then does not depend
+// on the vector-memory load that fetched it from the step table (which would drag a vmcnt(0) into every prefetch).
+__device__ __forceinline__ gptr tr_uniform(gptr p) {
+  const unsigned long long v = (unsigned long long)p;
+  const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
+  return (gptr)(((unsigned long long)hi << 32) | lo);
+}
+
+// A fragment of A (urows x kcols, row-major): lane (i,g) wants A[row][col .. col+3]  (k-step r <-> k = col + r).
+// The MFMA blocks the vector ALU of its SIMD, so every VALU instruction in the stream costs its full issue time:
+//   * rows >= urows are loaded from the clamped last row and simply never stored (the epilogue drops them);
+//   * columns >= kcols meet B rows that are exactly zero (padded units of the LDS activations are kept at zero),
+//     so a chunk that lies fully inside the row needs NO fix-up at all;
+//   * only the last chunk of a row whose length is not a multiple of 16 is fixed (its 16-byte load is shifted left to
+//     stay inside the row; tr_fix_tail shifts it back) -- a uniform branch, taken once per tile pair.
+// tr_load_raw touches nothing it loads (any ALU on the result would wait for the load on the spot).
+template <bool VEC>
+__device__ __forceinline__ f32x4 tr_load_raw(gptr row_ptr, int kcols, int col) {
+  f32x4 a;
+  if constexpr (VEC) {
+    const int cc = col < kcols - 4 ? col : kcols - 4;
+    a = __builtin_bit_cast(f32x4, *reinterpret_cast<const f32x4u __attribute__((address_space(1)))*>(row_ptr + cc));
+  } else {
 #pragma unroll
-      for (int r = 0; r < 4; ++r)
-        if (col + r < cols) a[r] = p[r];
+    for (int r = 0; r < 4; ++r) a[r] = row_ptr[col + r < kcols ? col + r : kcols - 1];
+  }
+  return a;
+}
+template <bool VEC>
+__device__ __forceinline__ f32x4 tr_fix_tail(f32x4 raw, int kcols, int col) {
+  f32x4 a;
+  const int sh = VEC ? col - (col < kcols - 4 ? col : kcols - 4) : 0;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    float v = raw[r];
+    if (VEC) {
+      if (r + 1 < 4) v = sh == 1 ? raw[r + 1] : v;
+      if (r + 2 < 4) v = sh == 2 ? raw[r + 2] : v;
+      if (r + 3 < 4) v = sh == 3 ? raw[r + 3] : v;
     }
-  }
-  return a;
-}
-// A fragment of W^T: lane (i,g) gets W[k0+4g+r][row0+i], r = 0..3
-__device__ __forceinline__ f32x4 tr_load_at(const float* __restrict__ W, int rows, int cols, int trow, int k) {
-  f32x4 a = {0.f, 0.f, 0.f, 0.f};
-  if (trow < cols) {
-#pragma unroll
-    for (int r = 0; r < 4; ++r)
-      if (k + r < rows) a[r] = W[(size_t)(k + r) * cols + trow];
+    a[r] = (r + sh < 4 && col + r < kcols) ? v : 0.0f;
   }
   return a;
 }
 
-// out[u][s] = epi(u, sum_k A[u][k] in[k][s] + bias[u]) for u in [0, 16*out_tiles), LDS in/out with row stride TR_S.
-// TRANS = false: A = W (out units = W rows, k = W cols).  TRANS = true: A = W^T (out units = W cols, k = W rows).
-template <bool TRANS, class Epi>
-__device__ __forceinline__ void tr_dense(const TrLayer& L, bool use_bias, const float* in, int out_tiles, int lane,
-                                         int wave, Epi epi) {
+// out[u][s] = epi(u, sum_k A[u][k] in[k][s] + bias[u]) for u in [0, 16*out_tiles): A is a (urows x kcols) row-major
+// matrix in global memory (a Linear's weight for the forward, its transposed copy for the backward), `in` / the
+// epilogue's targets are LDS arrays [unit][sample] with row stride TR_S.
+// The waves of the workgroup split the output tiles in pairs: wave w owns pairs w, w + TR_WAVES, ...  Its
+// (pair, k-chunk) iterations form ONE software-pipelined stream: TR_PD iterations of weights are in flight under the
+// MFMAs, also across pair boundaries; a pair's bias is requested at its first chunk and added in its epilogue.
+template <bool VEC, class Epi>
+__device__ __forceinline__ void tr_dense_impl(gptr A, gptr bias, int urows, int kcols, const float* in, int out_tiles,
+                                              int lane, int wave, TrStamps& stamps, Epi epi) {
   const int i = lane & 15, g = lane >> 4;
-  const int rows = L.rows, cols = L.cols;
-  const float* __restrict__ W = L.W;
-  const int kdim = TRANS ? rows : cols;
-  const int udim = TRANS ? cols : rows;
-  const int kc = (kdim + 15) >> 4;
-  auto load = [&](int o, int c) -> f32x4 {
-    if constexpr (TRANS) return tr_load_at(W, rows, cols, 16 * o + i, 16 * c + 4 * g);
-    else return tr_load_a(W, rows, cols, 16 * o + i, 16 * c + 4 * g);
+  const int kc = (kcols + 15) >> 4;
+  const int n_pairs = (out_tiles + 1) >> 1;
+  const int my_pairs = wave < n_pairs ? (n_pairs - wave + TR_WAVES - 1) / TR_WAVES : 0;
+  const int T = my_pairs * kc;
+  auto row_ptr = [&](int o) -> gptr {          // start of row 16 o + i of A, clamped into the matrix
+    const int row = 16 * o + i;
+    return A + (size_t)(row < urows ? row : urows - 1) * kcols;
   };
-  // wave w owns the tile pairs (2w, 2w+1), (2w + 2*TR_WAVES, ...): the waves of a workgroup split one layer
-  for (int o = 2 * wave; o < out_tiles; o += 2 * TR_WAVES) {
-    const bool two = o + 1 < out_tiles;
-    f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
-    if (use_bias) {
+  auto load_bias = [&](int o) -> f32x4 {
+    f32x4 b = {0.f, 0.f, 0.f, 0.f};
+    if (bias != nullptr) {
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const int u0 = 16 * o + 4 * g + r, u1 = u0 + 16;
-        if (u0 < udim) acc0[r] = L.b[u0];
-        if (two && u1 < udim) acc1[r] = L.b[u1];
+        const int u = 16 * o + 4 * g + r;
+        b[r] = bias[u < urows ? u : urows - 1];       // raw; rows >= urows are never stored
       }
     }
-    const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
-    f32x4 a0n = load(o, 0), a1n = two ? load(o + 1, 0) : zero;
-    for (int c = 0; c < kc; ++c) {
-      const f32x4 a0 = a0n, a1 = a1n;
-      if (c + 1 < kc) {                      // next chunk's weights are in flight under this chunk's MFMAs
-        a0n = load(o, c + 1);
-        if (two) a1n = load(o + 1, c + 1);
-      }
-      const int k = 16 * c + 4 * g;
-      float b[4];
-#pragma unroll
-      for (int r = 0; r < 4; ++r) b[r] = in[(k + r) * TR_S + i];
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {           // (an odd last tile multiplies zeros: no branch, accumulators stay in AGPRs)
-        acc0 = tr_mfma(a0[r], b[r], acc0);
-        acc1 = tr_mfma(a1[r], b[r], acc1);
-      }
+    return b;
+  };
+  // Ring of TR_PD iterations of weights in flight (an L2 round trip is several iterations of 8 MFMAs long).  Every
+  // load below is UNCONDITIONAL and its registers are only read by the iteration that consumes them: a conditional
+  // definition would make the compiler copy the freshly loaded registers at the join, i.e. wait for the load at once.
+  // Loads past the end re-read the clamped last row (harmless).
+  f32x4 ra0[TR_PD], ra1[TR_PD];
+  int pl = wave, cl = 0;                       // load cursor (pair, chunk)
+  gptr rp0 = row_ptr(2 * pl), rp1 = row_ptr(2 * pl + 1);
+  auto issue = [&](f32x4& d0, f32x4& d1) {
+    const int col = 16 * cl + 4 * g;
+    d0 = tr_load_raw<VEC>(rp0, kcols, col);
+    d1 = tr_load_raw<VEC>(rp1, kcols, col);
+    if (++cl == kc) {
+      cl = 0; pl += TR_WAVES;
+      rp0 = row_ptr(2 * pl); rp1 = row_ptr(2 * pl + 1);
     }
-    tr_mfma_drain(acc0, acc1);
+  };
+  constexpr int MAXP = (8 + TR_WAVES - 1) / TR_WAVES;   // pairs per wave (<= 16 output tiles)
+  f32x4 bq0[MAXP], bq1[MAXP];                           // every pair's bias, requested up front, used in the epilogues
+#pragma unroll
+  for (int q = 0; q < MAXP; ++q) {
+    bq0[q] = load_bias(2 * (wave + q * TR_WAVES));
+    bq1[q] = load_bias(2 * (wave + q * TR_WAVES) + 1);
+  }
+#pragma unroll
+  for (int j = 0; j < TR_PD; ++j) issue(ra0[j], ra1[j]);
+  stamps.mark(5);
+  int pair = wave, c = 0, q = 0;
+  const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+  f32x4 acc0 = zero, acc1 = zero;
+  auto body = [&](const f32x4& r0, const f32x4& r1) {
+    const int k = 16 * c + 4 * g;
+    f32x4 a0 = r0, a1 = r1;
+    if (16 * c + 15 >= kcols) {                // uniform: the row's ragged last chunk
+      a0 = tr_fix_tail<VEC>(r0, kcols, k);
+      a1 = tr_fix_tail<VEC>(r1, kcols, k);
+    }
+    float b[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) b[r] = in[(k + r) * TR_S + i];
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-      epi(16 * o + 4 * g + r, acc0[r]);
-      if (two) epi(16 * o + 16 + 4 * g + r, acc1[r]);
+      acc0 = tr_mfma(a0[r], b[r], acc0);
+      acc1 = tr_mfma(a1[r], b[r], acc1);
+    }
+    if (++c == kc) {
+      tr_mfma_drain(acc0, acc1);
+      f32x4 bias0 = bq0[0], bias1 = bq1[0];
+#pragma unroll
+      for (int qq = 1; qq < MAXP; ++qq) {
+        bias0 = q == qq ? bq0[qq] : bias0;
+        bias1 = q == qq ? bq1[qq] : bias1;
+      }
+      const int o = 2 * pair;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int u0 = 16 * o + 4 * g + r, u1 = u0 + 16;          // padded units (>= urows) stay exactly zero
+        epi(u0, u0 < urows ? acc0[r] + bias0[r] : 0.0f);
+        if (o + 1 < out_tiles) epi(u1, u1 < urows ? acc1[r] + bias1[r] : 0.0f);
+      }
+      acc0 = zero; acc1 = zero;
+      tr_acc_settle(acc0, acc1);
+      c = 0; pair += TR_WAVES; ++q;
+    }
+  };
+  int t = 0;
+  for (; t + TR_PD <= T; t += TR_PD) {
+#pragma unroll
+    for (int j = 0; j < TR_PD; ++j) {
+      body(ra0[j], ra1[j]);
+      issue(ra0[j], ra1[j]);
     }
   }
+#pragma unroll
+  for (int j = 0; j < TR_PD - 1; ++j)
+    if (t + j < T) body(ra0[j], ra1[j]);
+  stamps.mark(6);
   __syncthreads();     // the layer's output (LDS) is complete for every wave
+  stamps.mark(7);
+}
+
+template <class Epi>
+__device__ __forceinline__ void tr_dense(gptr A, gptr bias, int urows, int kcols, const float* in, int out_tiles,
+                                         int lane, int wave, TrStamps& stamps, Epi epi) {
+  A = tr_uniform(A);
+  if (bias != nullptr) bias = tr_uniform(bias);
+  urows = tr_uniform(urows);
+  kcols = tr_uniform(kcols);
+  if (kcols >= 4) tr_dense_impl<true>(A, bias, urows, kcols, in, out_tiles, lane, wave, stamps, epi);
+  else tr_dense_impl<false>(A, bias, urows, kcols, in, out_tiles, lane, wave, stamps, epi);
 }
 
 __device__ __forceinline__ float tr_group_sum(float v) {   // sum over the 16 lanes of a lane group (all active)
@@ -203,14 +318,46 @@ __global__ void __launch_bounds__(64 * TR_WAVES) train_kernel(const TrainLaunch 
   extern __shared__ __attribute__((aligned(16))) float lds[];
   constexpr int S = TR_S;
   constexpr int GS = 4 * TR_WAVES;                       // lane groups of 16 in the workgroup: elementwise loop stride
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, i = lane & 15;
+  const int lane = threadIdx.x & 63, i = lane & 15;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);    // scalar: tile loops / branches on it are uniform
   const int g = 4 * wave + (lane >> 4);                  // lane-group index (elementwise work); MFMA code uses lane, wave
   const int d = p.d, K = p.K;
   const int64_t row0 = (int64_t)blockIdx.x * 16;
   const int64_t ni = row0 + i;
   const bool valid = ni < p.n;
 
-  float* Y = lds;                                         // [K*d] normalised state of every step (MODE 1)
+  TrStamps stamps;
+  stamps.mark(-1);
+  // per-step tables, staged once: slot maps and the normalisation constants of every slot
+  int* TI = reinterpret_cast<int*>(lds);                   // [K][64]: in_slot[32], out_slot[32]
+  float* TP = lds + (size_t)K * 64;                        // [K][4][64]: p0..p3 per slot
+  for (int k = 0; k < K; ++k) {
+    const TrStep& st = p.steps[k];
+    for (int t = threadIdx.x; t < 128; t += 64 * TR_WAVES)
+    if (t < 32) TI[k * 64 + t] = st.in_slot[t];
+    else if (t < 64) TI[k * 64 + t] = st.out_slot[t - 32];
+    else {
+      const int sl = t - 64;
+      float p0 = 0.f, p1 = 1.f, p2 = 0.f, p3 = 0.f;
+      if (sl < d) {
+        const int f = st.feat[sl];
+        if constexpr (KIND == GBNF_KIND_GLOW) {
+          p3 = st.nb[f];                                   // logs: per-sample logdet term, models/layers.py:506-512
+          p0 = st.na[f];                                   // y = (x + bias) * exp(logs)
+          p1 = __expf(p3);
+        } else if (st.has_norm) {
+          const float ve = st.var[f] + st.eps, lg = st.na[f];
+          p0 = st.mean[f];                                 // y = (x - mean) * [exp(log_gamma) / sqrt(var + eps)] + beta
+          p1 = __expf(lg) / sqrtf(ve);
+          p2 = st.nb[f];
+          p3 = lg - 0.5f * __logf(ve);                     // models/layers.py:357-358
+        }
+      }
+      float* tp = TP + (size_t)k * 256 + sl;
+      tp[0] = p0; tp[64] = p1; tp[128] = p2; tp[192] = p3;
+    }
+  }
+  float* Y = lds + (size_t)K * 320;                       // [K*d] normalised state of every step (MODE 1)
   float* Zc = Y + (MODE == 1 ? (size_t)K * d * S : 0);    // [d]   running state (forward) / gradient state (backward)
   float* X = Zc + (size_t)d * S;                          // [ip]  coupling-net input
   float* GX = X + (size_t)p.ip * S;                       // [ip]  gradient w.r.t. the coupling-net input
@@ -221,18 +368,11 @@ __global__ void __launch_bounds__(64 * TR_WAVES) train_kernel(const TrainLaunch 
   const int hid_tiles = p.hp >> 4, out_tiles = p.op >> 4, in_tiles = p.ip >> 4;
 
   // ---- normalisation of slot s at a step (ActNorm / eval-mode BatchNorm)
-  auto norm_fwd = [&](const TrStep& st, int s, float v, float& logdet) -> float {
-    const int f = st.feat[s];
-    if constexpr (KIND == GBNF_KIND_GLOW) {
-      const float logs = st.nb[f];
-      logdet += logs;                                      // models/layers.py:506-512
-      return (v + st.na[f]) * __expf(logs);
-    } else {
-      if (!st.has_norm) return v;
-      const float ve = st.var[f] + st.eps, lg = st.na[f];
-      logdet += lg - 0.5f * __logf(ve);                    // models/layers.py:357-358
-      return __expf(lg) * (v - st.mean[f]) / sqrtf(ve) + st.nb[f];
-    }
+  auto norm_fwd = [&](int k, int s, float v, float& logdet) -> float {
+    const float* tp = TP + (size_t)k * 256 + s;
+    logdet += tp[192];
+    if constexpr (KIND == GBNF_KIND_GLOW) return (v + tp[0]) * tp[64];
+    else return (v - tp[0]) * tp[64] + tp[128];
   };
 
   // ---- coupling net forward from X: hidden layers into H (+ emit), last layer into `out` (or skipped)
@@ -244,15 +384,19 @@ __global__ void __launch_bounds__(64 * TR_WAVES) train_kernel(const TrainLaunch 
       const bool emit = (MODE == 1) && ws_net != nullptr;    // backward sweep only: activation-side operand of dW
       float* ws_h = emit ? ws_net + ((size_t)p.ip + (size_t)l * p.hp) * p.np + row0 + i : nullptr;
       const int act = net.act;
-      tr_dense<false>(net.layer[l], true, in, hid_tiles, lane, wave, [&](int u, float v) {
+      const TrLayer& L = net.layer[l];
+      tr_dense(tr_global(L.W), tr_global(L.b), L.rows, L.cols, in, hid_tiles, lane, wave, stamps, [&](int u, float v) {
         const float h = tr_act(act, v);
         Hl[u * S + i] = h;
         if (emit) ws_h[(size_t)u * p.np] = h;
       });
       in = Hl;
     }
-    if (out != nullptr)
-      tr_dense<false>(net.layer[nl - 1], true, in, out_tiles, lane, wave, [&](int u, float v) { out[u * S + i] = v; });
+    if (out != nullptr) {
+      const TrLayer& L = net.layer[nl - 1];
+      tr_dense(tr_global(L.W), tr_global(L.b), L.rows, L.cols, in, out_tiles, lane, wave, stamps,
+               [&](int u, float v) { out[u * S + i] = v; });
+    }
   };
 
   // ---- coupling net backward: cur = gradient w.r.t. the net output (LDS, [op]); leaves d(loss)/d(net input) in GX
@@ -267,39 +411,45 @@ __global__ void __launch_bounds__(64 * TR_WAVES) train_kernel(const TrainLaunch 
       float* Hl = H + (size_t)(l - 1) * p.hp * S;           // activations of hidden layer l-1 -> overwritten by its gradient
       float* ws_d = ws_net + ((size_t)p.ip + (size_t)nh * p.hp + (size_t)(l - 1) * p.hp) * p.np + row0 + i;
       const int act = net.act;
-      tr_dense<true>(net.layer[l], false, cur, hid_tiles, lane, wave, [&](int u, float v) {
+      const TrLayer& L = net.layer[l];      // W^T (cols x rows), copied by transpose_kernel: same 16-byte row loads
+      tr_dense(tr_global(p.wt + L.wt), gptr(nullptr), L.cols, L.rows, cur, hid_tiles, lane, wave, stamps, [&](int u, float v) {
         const float gpre = v * tr_dact(act, Hl[u * S + i]);
         Hl[u * S + i] = gpre;
         ws_d[(size_t)u * p.np] = gpre;
       });
       cur = Hl;
     }
-    tr_dense<true>(net.layer[0], false, cur, in_tiles, lane, wave, [&](int u, float v) {
+    const TrLayer& L0 = net.layer[0];
+    tr_dense(tr_global(p.wt + L0.wt), gptr(nullptr), L0.cols, L0.rows, cur, in_tiles, lane, wave, stamps, [&](int u, float v) {
       GX[u * S + i] = accumulate ? GX[u * S + i] + v : v;
     });
   };
 
   // ---- x tile -> Zc (slot j = feature j)
   for (int j = g; j < d; j += GS) Zc[j * S + i] = valid ? p.x[ni * d + j] : 0.0f;
-  __syncthreads();
+  __syncthreads();    // (also: the tables are complete)
+  stamps.mark(0);
 
   // =============================== forward through all steps
   float ld = 0.0f;   // per-lane partial of log|det J| (every lane group adds its own slots / features)
   for (int k = 0; k < K; ++k) {
     const TrStep& st = p.steps[k];
     for (int s = g; s < d; s += GS) {
-      const float y = norm_fwd(st, s, Zc[s * S + i], ld);
+      const float y = norm_fwd(k, s, Zc[s * S + i], ld);
       Zc[s * S + i] = y;
       if (MODE == 1) Y[((size_t)k * d + s) * S + i] = y;
     }
     if (MODE == 1 && k == K - 1) break;                    // the last step's outputs are not needed for the backward
     __syncthreads();
-    for (int kk = g; kk < p.ip; kk += GS) X[kk * S + i] = kk < st.in_f ? Zc[st.in_slot[kk] * S + i] : 0.0f;
+    const int* ti = TI + k * 64;
+    for (int kk = g; kk < p.ip; kk += GS) X[kk * S + i] = kk < st.in_f ? Zc[ti[kk] * S + i] : 0.0f;
     __syncthreads();
+    stamps.mark(1);
     if constexpr (KIND == GBNF_KIND_GLOW) {
       net_forward(st.net[0], O, nullptr);
+      stamps.mark(-1);
       for (int j = g; j < st.out_f; j += GS) {
-        const int slot = st.out_slot[j];
+        const int slot = ti[32 + j];
         const float y2 = Zc[slot * S + i];
         if (p.additive) {
           Zc[slot * S + i] = y2 + O[j * S + i];                                  // models/glow.py:328-329
@@ -314,13 +464,14 @@ __global__ void __launch_bounds__(64 * TR_WAVES) train_kernel(const TrainLaunch 
       net_forward(st.net[0], O2, nullptr);
       net_forward(st.net[1], O, nullptr);
       for (int j = g; j < st.out_f; j += GS) {
-        const int slot = st.out_slot[j];
+        const int slot = ti[32 + j];
         const float scale = O[j * S + i];
         Zc[slot * S + i] = O2[j * S + i] + Zc[slot * S + i] * __expf(scale);      // models/transformations.py:575
         ld += scale;                                                             // models/transformations.py:577
       }
     }
     __syncthreads();
+    stamps.mark(3);
   }
 
   if constexpr (MODE == 0) {
@@ -337,6 +488,11 @@ __global__ void __launch_bounds__(64 * TR_WAVES) train_kernel(const TrainLaunch 
       if (p.z_out != nullptr)
         for (int j = g; j < d; j += GS) p.z_out[ni * d + j] = Zc[p.tail[j] * S + i];
     }
+    stamps.mark(4);
+#ifdef GBNF_TRAIN_STAMPS
+    if (p.dbg != nullptr && threadIdx.x == 0)
+      for (int q = 0; q < 8; ++q) p.dbg[(size_t)blockIdx.x * 8 + q] = stamps.acc[q];
+#endif
     return;
   } else {
     // =============================== backward
@@ -348,19 +504,17 @@ __global__ void __launch_bounds__(64 * TR_WAVES) train_kernel(const TrainLaunch 
     const int nnets = (KIND == GBNF_KIND_GLOW) ? 1 : 2;
 
     // normalisation backward for one slot: returns d(loss)/d(pre-norm value); accumulates the parameter gradients
-    auto norm_bwd = [&](const TrStep& st, int s, float gy, float y) -> float {
+    auto norm_bwd = [&](const TrStep& st, int k, int s, float gy, float y) -> float {
       const int f = st.feat[s];
-      float ga, gb, gx;
+      const float* tp = TP + (size_t)k * 256 + s;
+      float ga, gb;
+      const float gx = gy * tp[64];
       if constexpr (KIND == GBNF_KIND_GLOW) {
-        const float e = __expf(st.nb[f]);
-        gx = gy * e;
         ga = gx;                  // d/d bias
         gb = gy * y + gl;         // d/d logs: y = (x + bias) e^logs, and logdet += logs for every sample
       } else {
         if (!st.has_norm) return gy;
-        const float a = __expf(st.na[f]) / sqrtf(st.var[f] + st.eps);
-        gx = gy * a;
-        ga = gy * (y - st.nb[f]) + gl;   // d/d log_gamma
+        ga = gy * (y - tp[128]) + gl;    // d/d log_gamma
         gb = gy;                         // d/d beta
       }
       ga = tr_group_sum(ga);
@@ -376,9 +530,10 @@ __global__ void __launch_bounds__(64 * TR_WAVES) train_kernel(const TrainLaunch 
       const TrStep& st = p.steps[k];
       const float* Yk = Y + (size_t)k * d * S;
       float* ws_step = p.ws + (size_t)k * nnets * p.net_rows * p.np;
+      const int* ti = TI + k * 64;
       // net input (also the activation-side operand of the first layer's weight gradient)
       for (int kk = g; kk < p.ip; kk += GS) {
-        const float v = kk < st.in_f ? Yk[st.in_slot[kk] * S + i] : 0.0f;
+        const float v = kk < st.in_f ? Yk[ti[kk] * S + i] : 0.0f;
         X[kk * S + i] = v;
         for (int q = 0; q < nnets; ++q) (ws_step + (size_t)q * p.net_rows * p.np)[(size_t)kk * p.np + row0 + i] = v;
       }
@@ -386,7 +541,7 @@ __global__ void __launch_bounds__(64 * TR_WAVES) train_kernel(const TrainLaunch 
       if constexpr (KIND == GBNF_KIND_GLOW) {
         net_forward(st.net[0], O, ws_step);
         for (int j = g; j < st.out_f; j += GS) {
-          const int slot = st.out_slot[j];
+          const int slot = ti[32 + j];
           const float y2 = Yk[slot * S + i], g2 = G[slot * S + i];
           float gy;
           if (p.additive) {
@@ -401,7 +556,7 @@ __global__ void __launch_bounds__(64 * TR_WAVES) train_kernel(const TrainLaunch 
             O[(2 * j) * S + i] = gy;                                     // d/d shift
             O[(2 * j + 1) * S + i] = (g2 * (y2 + shift) * sc + gl) * omsc;   // d/d raw: z2' = (y2+shift) s, ld += log s
           }
-          G[slot * S + i] = norm_bwd(st, slot, gy, y2);
+          G[slot * S + i] = norm_bwd(st, k, slot, gy, y2);
         }
         __syncthreads();
         net_backward(st.net[0], O, ws_step, false);
@@ -412,12 +567,12 @@ __global__ void __launch_bounds__(64 * TR_WAVES) train_kernel(const TrainLaunch 
         for (int u = g; u < p.op; u += GS) O2[u * S + i] = 0.0f;
         __syncthreads();
         for (int j = g; j < st.out_f; j += GS) {
-          const int slot = st.out_slot[j];
+          const int slot = ti[32 + j];
           const float y2 = Yk[slot * S + i], g2 = G[slot * S + i];
           const float es = __expf(O[j * S + i]);
           O2[j * S + i] = g2;                                            // d/d shift
           O[j * S + i] = g2 * y2 * es + gl;                              // d/d scale: z2' = shift + y2 e^scale, ld += scale
-          G[slot * S + i] = norm_bwd(st, slot, g2 * es, y2);
+          G[slot * S + i] = norm_bwd(st, k, slot, g2 * es, y2);
         }
         __syncthreads();
         net_backward(st.net[1], O, ws_s, false);
@@ -425,8 +580,8 @@ __global__ void __launch_bounds__(64 * TR_WAVES) train_kernel(const TrainLaunch 
         net_backward(st.net[0], O2, ws_t, true);
       }
       for (int kk = g; kk < st.in_f; kk += GS) {
-        const int slot = st.in_slot[kk];
-        G[slot * S + i] = norm_bwd(st, slot, G[slot * S + i] + GX[kk * S + i], Yk[slot * S + i]);
+        const int slot = ti[kk];
+        G[slot * S + i] = norm_bwd(st, k, slot, G[slot * S + i] + GX[kk * S + i], Yk[slot * S + i]);
       }
       __syncthreads();
     }
@@ -500,6 +655,35 @@ __global__ void __launch_bounds__(64) wgrad_kernel(const WgProblem* __restrict__
   }
 }
 
+// W (rows x cols) -> W^T (cols x rows) for every Linear of the component, one launch (32 x 32 tiles through LDS).
+struct TpProblem {
+  const float* W;
+  int64_t wt;          // float offset in the workspace's weight region
+  int rows, cols, blk_begin, nbx;
+};
+
+__global__ void __launch_bounds__(256) transpose_kernel(const TpProblem* __restrict__ probs, int n_probs, float* __restrict__ wt) {
+  __shared__ float tile[32][33];
+  int pi = 0;
+  while (pi + 1 < n_probs && (int)blockIdx.x >= probs[pi + 1].blk_begin) ++pi;
+  const TpProblem P = probs[pi];
+  const int blk = blockIdx.x - P.blk_begin;
+  const int r0 = (blk / P.nbx) * 32, c0 = (blk % P.nbx) * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int r = r0 + ty + 8 * j, c = c0 + tx;
+    tile[ty + 8 * j][tx] = (r < P.rows && c < P.cols) ? P.W[(size_t)r * P.cols + c] : 0.0f;
+  }
+  __syncthreads();
+  float* out = wt + P.wt;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int c = c0 + ty + 8 * j, r = r0 + tx;
+    if (c < P.cols && r < P.rows) out[(size_t)c * P.rows + r] = tile[tx][ty + 8 * j];
+  }
+}
+
 }  // namespace gbnf
 
 using namespace gbnf;
@@ -511,7 +695,9 @@ struct gbnf_trainer {
   TrStep* steps_dev = nullptr;
   int* tail_dev = nullptr;
   WgProblem* probs_dev = nullptr;
-  int n_probs = 0, wg_blocks = 0;
+  TpProblem* tp_dev = nullptr;
+  int n_probs = 0, wg_blocks = 0, tp_blocks = 0;
+  int64_t wt_floats = 0;
 };
 
 static int ceil16(int v) { return (v + 15) / 16 * 16; }
@@ -543,8 +729,9 @@ int gbnf_trainer_create(const gbnf_flow_desc* desc, gbnf_trainer** out) {
   t->op = ceil16(glow && !additive ? 2 * d2 : d2);
   t->net_rows = (int64_t)t->ip + 2LL * t->n_hidden * t->hp + t->op;
   const size_t common = (size_t)d + 2 * (size_t)t->ip + (size_t)t->n_hidden * t->hp + 2 * (size_t)t->op;
-  t->lds_fwd = common * TR_S * 4;
-  t->lds_bwd = (common + (size_t)K * d) * TR_S * 4;
+  const size_t tables = (size_t)K * 320 * 4;
+  t->lds_fwd = tables + common * TR_S * 4;
+  t->lds_bwd = tables + (common + (size_t)K * d) * TR_S * 4;
   if (t->lds_bwd > (size_t)TR_LDS_BYTES) {
     const size_t need = t->lds_bwd;
     delete t;
@@ -554,6 +741,9 @@ int gbnf_trainer_create(const gbnf_flow_desc* desc, gbnf_trainer** out) {
 
   std::vector<TrStep> steps(K);
   std::vector<WgProblem> probs;
+  std::vector<TpProblem> tps;
+  int64_t wt_off = 0;
+  int tp_blocks = 0;
   std::vector<int> sigma(d), prev(d);
   for (int j = 0; j < d; ++j) sigma[j] = j;
   int64_t goff = 0;
@@ -603,6 +793,13 @@ int gbnf_trainer_create(const gbnf_flow_desc* desc, gbnf_trainer** out) {
         L.W = lin.weight; L.b = lin.bias; L.rows = lin.out_features; L.cols = lin.in_features;
         L.gW = goff; goff += (int64_t)L.rows * L.cols;
         L.gb = goff; goff += L.rows;
+        L.wt = wt_off; wt_off += ((int64_t)L.rows * L.cols + 3) / 4 * 4;
+        TpProblem T{};
+        T.W = L.W; T.wt = L.wt; T.rows = L.rows; T.cols = L.cols;
+        T.nbx = (L.cols + 31) / 32;
+        T.blk_begin = tp_blocks;
+        tp_blocks += ((L.rows + 31) / 32) * T.nbx;
+        tps.push_back(T);
         WgProblem P{};
         P.M = L.rows; P.N = L.cols;
         // gradient-side operand: D of this layer's output; activation-side operand: this layer's input
@@ -620,6 +817,8 @@ int gbnf_trainer_create(const gbnf_flow_desc* desc, gbnf_trainer** out) {
   t->grad_floats = goff;
   t->n_probs = (int)probs.size();
   t->wg_blocks = blocks;
+  t->tp_blocks = tp_blocks;
+  t->wt_floats = wt_off + 16;
   std::vector<int> tail(64, 0);
   for (int j = 0; j < d; ++j) tail[j] = sigma[j];
 
@@ -629,6 +828,8 @@ int gbnf_trainer_create(const gbnf_flow_desc* desc, gbnf_trainer** out) {
   if (e == hipSuccess) e = hipMemcpy(t->tail_dev, tail.data(), sizeof(int) * 64, hipMemcpyHostToDevice);
   if (e == hipSuccess) e = hipMalloc((void**)&t->probs_dev, sizeof(WgProblem) * probs.size());
   if (e == hipSuccess) e = hipMemcpy(t->probs_dev, probs.data(), sizeof(WgProblem) * probs.size(), hipMemcpyHostToDevice);
+  if (e == hipSuccess) e = hipMalloc((void**)&t->tp_dev, sizeof(TpProblem) * tps.size());
+  if (e == hipSuccess) e = hipMemcpy(t->tp_dev, tps.data(), sizeof(TpProblem) * tps.size(), hipMemcpyHostToDevice);
   if (e == hipSuccess) {
     const void* fns[4] = {(const void*)train_kernel<GBNF_KIND_GLOW, 0>, (const void*)train_kernel<GBNF_KIND_GLOW, 1>,
                           (const void*)train_kernel<GBNF_KIND_REALNVP, 0>, (const void*)train_kernel<GBNF_KIND_REALNVP, 1>};
@@ -648,6 +849,7 @@ int gbnf_trainer_destroy(gbnf_trainer* t) {
   if (t->steps_dev) (void)hipFree(t->steps_dev);
   if (t->tail_dev) (void)hipFree(t->tail_dev);
   if (t->probs_dev) (void)hipFree(t->probs_dev);
+  if (t->tp_dev) (void)hipFree(t->tp_dev);
   delete t;
   return GBNF_OK;
 }
@@ -661,12 +863,20 @@ int gbnf_trainer_grad_floats(const gbnf_trainer* t, int64_t* n_floats) {
 int gbnf_trainer_workspace_bytes(const gbnf_trainer* t, int64_t n, int64_t* bytes) {
   if (!t || !bytes || n < 0) return fail(GBNF_ERR_INVALID, "gbnf_trainer_workspace_bytes: bad argument");
   const int64_t np = (n + 15) / 16 * 16;
-  *bytes = (int64_t)t->K * t->nnets * t->net_rows * np * 4;
+  *bytes = ((int64_t)t->K * t->nnets * t->net_rows * np + t->wt_floats) * 4;
   return GBNF_OK;
 }
 
+#ifdef GBNF_TRAIN_STAMPS
+static unsigned long long* g_train_stamp_buf = nullptr;
+extern "C" void gbnf_debug_set_train_stamp_buffer(unsigned long long* p) { g_train_stamp_buf = p; }
+#endif
+
 static void fill_launch(const gbnf_trainer* t, TrainLaunch& p, const float* x, int64_t n) {
   std::memset(&p, 0, sizeof(p));
+#ifdef GBNF_TRAIN_STAMPS
+  p.dbg = g_train_stamp_buf;
+#endif
   p.steps = t->steps_dev; p.tail = t->tail_dev; p.x = x;
   p.n = n; p.np = (n + 15) / 16 * 16;
   p.d = t->d; p.K = t->K; p.kind = t->kind; p.additive = t->additive;
@@ -705,8 +915,11 @@ int gbnf_trainer_backward(const gbnf_trainer* t, const float* x, int64_t n, cons
   TrainLaunch p;
   fill_launch(t, p, x, n);
   p.g_z = g_z; p.g_ldj = g_ldj; p.g_x = g_x; p.grads = grads; p.ws = (float*)workspace;
+  float* wt = (float*)workspace + (int64_t)t->K * t->nnets * t->net_rows * p.np;
+  p.wt = wt;
   const dim3 grid((unsigned)(p.np / 16));
   hipStream_t s = (hipStream_t)stream;
+  hipLaunchKernelGGL(transpose_kernel, dim3((unsigned)t->tp_blocks), dim3(256), 0, s, t->tp_dev, (int)(t->n_probs), wt);
   if (t->kind == GBNF_KIND_GLOW)
     hipLaunchKernelGGL((train_kernel<GBNF_KIND_GLOW, 1>), grid, dim3(64 * TR_WAVES), t->lds_bwd, s, p);
   else
