@@ -45,7 +45,8 @@ constexpr int TR_LDS_BYTES = 160 * 1024;
 #ifndef GBNF_TR_WAVES
 #define GBNF_TR_WAVES 4
 #endif
-constexpr int TR_PD = 4;            // weight-prefetch distance of the dense layers, in k-chunks
+constexpr int TR_PD = 4;            // weight-prefetch distance of the dense layers, in k-chunks (even: B ping-pong)
+static_assert(TR_PD % 2 == 0, "the LDS operand ping-pong follows the ring index");
 constexpr int TR_WAVES = GBNF_TR_WAVES;         // waves per workgroup; they share one 16-sample tile and split every layer's tiles
 
 struct TrLayer {
@@ -243,16 +244,22 @@ __device__ __forceinline__ void tr_dense_impl(gptr A, gptr bias, int urows, int 
   int pair = wave, c = 0, q = 0;
   const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
   f32x4 acc0 = zero, acc1 = zero;
-  auto body = [&](const f32x4& r0, const f32x4& r1) {
+  // B operands (LDS) one iteration ahead, ping-pong registers: the read of chunk c+1 is in flight under chunk c's MFMAs
+  float bb[2][4];
+  const float* inl = in + (4 * g) * TR_S + i;
+  auto read_b = [&](float (&b)[4], int chunk) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) b[r] = inl[(16 * chunk + r) * TR_S];
+  };
+  read_b(bb[0], 0);
+  auto body = [&](const f32x4& r0, const f32x4& r1, const float (&b)[4], float (&bn)[4]) {
     const int k = 16 * c + 4 * g;
+    read_b(bn, c + 1 == kc ? 0 : c + 1);       // (past the end: chunk 0 again, never used)
     f32x4 a0 = r0, a1 = r1;
     if (16 * c + 15 >= kcols) {                // uniform: the row's ragged last chunk
       a0 = tr_fix_tail<VEC>(r0, kcols, k);
       a1 = tr_fix_tail<VEC>(r1, kcols, k);
     }
-    float b[4];
-#pragma unroll
-    for (int r = 0; r < 4; ++r) b[r] = in[(k + r) * TR_S + i];
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       acc0 = tr_mfma(a0[r], b[r], acc0);
@@ -282,13 +289,13 @@ __device__ __forceinline__ void tr_dense_impl(gptr A, gptr bias, int urows, int 
   for (; t + TR_PD <= T; t += TR_PD) {
 #pragma unroll
     for (int j = 0; j < TR_PD; ++j) {
-      body(ra0[j], ra1[j]);
+      body(ra0[j], ra1[j], bb[j & 1], bb[(j + 1) & 1]);
       issue(ra0[j], ra1[j]);
     }
   }
 #pragma unroll
   for (int j = 0; j < TR_PD - 1; ++j)
-    if (t + j < T) body(ra0[j], ra1[j]);
+    if (t + j < T) body(ra0[j], ra1[j], bb[j & 1], bb[(j + 1) & 1]);
   stamps.mark(6);
   __syncthreads();     // the layer's output (LDS) is complete for every wave
   stamps.mark(7);
