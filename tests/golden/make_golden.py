@@ -370,8 +370,36 @@ def grads_case(name, kind, d, h, K, N, **synth_kw):
     print(f"{name}: nll={nll.item():.5f} |grads|={np.abs(np.concatenate(flat)).max():.4f} n={sum(f.size for f in flat)}")
 
 
+def checkpoint_case(name, d=6, h=8, K=2, C=2, N=16):
+    """G11: a checkpoint FILE written by the reference's own utils.utilities.save (utils/utilities.py:78-93) from a
+    reference model + Adam optimiser, together with what the file does not hold (the permutation indices of the live
+    model) and the model's outputs on a batch.  The .pt file is data: tensors and python scalars."""
+    from utils.utilities import save as ref_save
+    torch.manual_seed(3)
+    model = RefBoostedFlow(ref_args("glow", d, h, K, C))
+    specs = synth.synth_boosted_specs("glow", C, d, h, K, seed=51)
+    for c in range(C):
+        install_spec(model.flows[c], specs[c])
+    model.component = 1
+    model.all_trained = False
+    model.eval()
+    opt = torch.optim.Adam(model.parameters(), lr=1e-3)
+    ref_save(model, opt, os.path.join(HERE, name + ".pt"))
+    x = synth.synth_batch(N, d, seed=29)
+    z, ldj, ll, G = run_reference(model, x, C)
+    np.savez_compressed(os.path.join(HERE, name + ".npz"),
+                        config=np.frombuffer(json.dumps(dict(case="checkpoint", kind="glow", d=d, h=h, K=K, C=C, N=N, x_seed=29,
+                                                             component=1, all_trained=False)).encode(), dtype=np.uint8),
+                        indices=np.stack([np.stack([l.shuffle.indices.numpy() for l in f.flow.layers]) for f in model.flows]),
+                        ll=ll, G=G)
+    print(f"{name}: ll[0,:3]={ll[0, :3]} file={os.path.getsize(os.path.join(HERE, name + '.pt'))} bytes")
+
+
 def main():
     torch.set_num_threads(4)
+    if "--checkpoint-only" in sys.argv:
+        checkpoint_case("g11_reference_checkpoint")
+        return
     if "--grads-only" in sys.argv:
         grads_case("g10_glow_grads_d43_h64", "glow", 43, 64, 3, 96)
         grads_case("g10_glow_grads_additive_relu_d8", "glow", 8, 40, 3, 50, coupling="additive", act="relu")
@@ -393,6 +421,7 @@ def main():
     actnorm_init_case("g7_glow_actnorm_data_init")
     boosting_weights_case("g8_boosting_weights")
     decode_case("g9_glow_additive_decode")
+    checkpoint_case("g11_reference_checkpoint")
     grads_case("g10_glow_grads_d43_h64", "glow", 43, 64, 3, 96)
     grads_case("g10_glow_grads_additive_relu_d8", "glow", 8, 40, 3, 50, coupling="additive", act="relu")
     grads_case("g10_realnvp_grads_d21_h32", "realnvp", 21, 32, 4, 80)

@@ -257,3 +257,25 @@ def test_decode_inverts_encode(golden_case):
         m.component = g.cfg["C"] - 1
         s = m(z=None, temperature=0.7, components="1:c", reverse=True)
         assert s.shape == (4, g.cfg["d"]) and torch.isfinite(s).all()
+
+
+def test_reference_checkpoint_evaluates_like_the_reference():
+    """g11: load the reference-written checkpoint + the exported indices, evaluate on the device, compare with the outputs
+    the reference produced from the very model it saved."""
+    import json, os
+    import torch
+    from conftest import GOLDEN_DIR
+    from gbnf_amd import BoostedFlow, checkpoint, synth
+    dev = torch.device("cuda:0")
+    data = dict(np.load(os.path.join(GOLDEN_DIR, "g11_reference_checkpoint.npz")))
+    cfg = json.loads(bytes(data["config"]).decode())
+    args = _args(dict(cfg, synth_kw={}), dev)
+    m = BoostedFlow(args)
+    side = {"component": cfg["component"], "all_trained": cfg["all_trained"],
+            "indices": {f"{c}.{k}": torch.from_numpy(data["indices"][c, k]) for c in range(cfg["C"]) for k in range(cfg["K"])},
+            "actnorm_inited": {f"{c}.{k}": True for c in range(cfg["C"]) for k in range(cfg["K"])}}
+    checkpoint.load(m, None, os.path.join(GOLDEN_DIR, "g11_reference_checkpoint.pt"), args, side_car=side)
+    m.eval()
+    x = torch.from_numpy(synth.synth_batch(cfg["N"], cfg["d"], seed=cfg["x_seed"])).to(dev)
+    assert rel_err(m.component_log_prob(x).cpu().numpy().T, data["ll"]) < LL_RTOL
+    assert rel_err(m.log_prob(x).cpu().numpy(), data["G"]) < LL_RTOL

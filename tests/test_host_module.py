@@ -159,3 +159,67 @@ def test_default_permutation_is_reversed_arange():
     for f in m.flows:
         for layer in f.flow.layers:
             assert layer.permutation.indices.tolist() == [4, 3, 2, 1, 0]   # models/layers.py:636
+
+
+# ------------------------------------------------------------------ checkpoint files
+def _ckpt_fixture():
+    data = dict(np.load(os.path.join(GOLDEN_DIR, "g11_reference_checkpoint.npz")))
+    cfg = json.loads(bytes(data["config"]).decode())
+    return cfg, data, os.path.join(GOLDEN_DIR, "g11_reference_checkpoint.pt")
+
+
+def test_loads_a_checkpoint_written_by_the_reference():
+    """g11: a file written by the reference's utils.utilities.save.  Parameters, component and all_trained come back;
+    the file has no permutation indices (S5) -> a warning, unless the caller supplies the side-car."""
+    import warnings
+    from gbnf_amd import checkpoint
+    cfg, data, path = _ckpt_fixture()
+    args = make_args(kind="glow", d=cfg["d"], h=cfg["h"], K=cfg["K"], C=cfg["C"])
+    m = BoostedFlow(args)
+    opt = torch.optim.Adam(m.parameters(), lr=1e-3)
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        ckpt = checkpoint.load(m, opt, path, args)
+    assert any("permutation" in str(x.message) for x in w)
+    assert m.component == cfg["component"] and m.all_trained == cfg["all_trained"]
+    for k, v in ckpt["model"].items():
+        assert torch.equal(m.state_dict()[k], v), k
+    # with the indices exported from the live reference model: no warning, indices installed
+    side = {"component": cfg["component"], "all_trained": cfg["all_trained"],
+            "indices": {f"{c}.{k}": torch.from_numpy(data["indices"][c, k]) for c in range(cfg["C"]) for k in range(cfg["K"])},
+            "actnorm_inited": {f"{c}.{k}": True for c in range(cfg["C"]) for k in range(cfg["K"])}}
+    m2 = BoostedFlow(args)
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        checkpoint.load(m2, None, path, args, side_car=side)
+    assert not any("permutation" in str(x.message) for x in w)
+    for c in range(cfg["C"]):
+        for k in range(cfg["K"]):
+            assert m2.flows[c].flow.layers[k].permutation.indices.tolist() == data["indices"][c, k].tolist()
+
+
+def test_checkpoint_round_trip_keeps_permutations(tmp_path):
+    from gbnf_amd import checkpoint
+    args = make_args(kind="glow", d=7, h=12, K=3, C=2)
+    m = BoostedFlow(args)
+    for f in m.flows:
+        f.set_actnorm_init()
+    m.component, m.all_trained = 1, True
+    opt = torch.optim.Adam(m.parameters(), lr=1e-3)
+    sched = torch.optim.lr_scheduler.StepLR(opt, 3)
+    path = str(tmp_path / "ck.pt")
+    checkpoint.save(m, opt, path, scheduler=sched)
+    raw = torch.load(path)
+    assert {"model", "optimizer", "scheduler", "all_trained", "component"} <= set(raw)      # the reference's keys
+    m2 = BoostedFlow(args)
+    checkpoint.load(m2, torch.optim.Adam(m2.parameters(), lr=1e-3), path, args)
+    assert m2.component == 1 and m2.all_trained is True
+    for (k1, v1), (k2, v2) in zip(m.state_dict().items(), m2.state_dict().items()):
+        assert k1 == k2 and torch.equal(v1, v2)
+    for f1, f2 in zip(m.flows, m2.flows):
+        for l1, l2 in zip(f1.flow.layers, f2.flow.layers):
+            assert torch.equal(l1.permutation.indices, l2.permutation.indices) and bool(l2.actnorm.inited)
+    # the reference's "initialise from arguments" branch (utils/utilities.py:53-64)
+    args.boosted, args.loaded_init_component, args.loaded_all_trained, args.loaded_num_components = True, 0, False, None
+    checkpoint.load(m2, None, path, args, init_with_args=True)
+    assert m2.component == 0 and m2.all_trained is False
