@@ -106,3 +106,68 @@ def synth_batch(N, d, seed=0, scale=1.0):
     """z-scored-like N(0,1) inputs (the loaders z-score the data: utils/miniboone.py:57-67)."""
     rng = np.random.RandomState(seed)
     return (scale * rng.standard_normal((N, d))).astype(np.float32)
+
+
+# ------------------------------------------------------------------ image Glow (multi-scale, conv coupling nets)
+def _conv(rng, out_ch, in_ch, k, std, bias=False, actnorm=False, zeros_logs=False):
+    """One Conv2d / Conv2dZeros of models/layers.py:577-630 as plain data:
+    w (out,in,k,k); b (out,) | None; an_bias/an_logs (out,) | None (the ActNorm2d behind a Conv2d);
+    logs (out,) | None (Conv2dZeros' output scale exp(3*logs))."""
+    c = {"w": (std * rng.standard_normal((out_ch, in_ch, k, k))).astype(np.float32), "b": None,
+         "an_bias": None, "an_logs": None, "logs": None}
+    if bias:
+        c["b"] = (0.05 * rng.standard_normal(out_ch)).astype(np.float32)
+    if actnorm:
+        c["an_bias"] = (0.1 * rng.standard_normal(out_ch)).astype(np.float32)
+        c["an_logs"] = (0.1 * rng.standard_normal(out_ch)).astype(np.float32)
+    if zeros_logs:
+        c["logs"] = (0.05 * rng.standard_normal(out_ch)).astype(np.float32)
+    return c
+
+
+def synth_image_glow_spec(input_size=(3, 32, 32), h=32, K=2, L=2, depth=1, coupling="affine", permutation="invconv",
+                          learn_top=True, seed=0, gain=1.0):
+    """One image Glow component (models/glow.py:192-233 FlowNet image branch: L x [squeeze, K FlowSteps, Split2d])
+    with synthetic parameters.  ``permutation``: "invconv" (a random well-conditioned C x C matrix: what
+    InvertibleConv1x1.get_weight returns for either parameterisation), "shuffle" or "reverse"."""
+    rng = np.random.RandomState(seed)
+    C, H, W = input_size
+    levels = []
+    for lvl in range(L):
+        C, H, W = C * 4, H // 2, W // 2
+        steps = []
+        for _ in range(K):
+            st = {"an_bias": (0.1 * rng.standard_normal(C)).astype(np.float32),
+                  "an_logs": (0.1 * rng.standard_normal(C)).astype(np.float32), "perm_w": None, "perm": None}
+            if permutation == "invconv":
+                q, _ = np.linalg.qr(rng.standard_normal((C, C)))
+                st["perm_w"] = (q * np.exp(0.1 * rng.standard_normal(C))[None, :]).astype(np.float32)
+            else:
+                perm = np.arange(C - 1, -1, -1, dtype=np.int64)
+                st["perm"] = perm[rng.permutation(C)] if permutation == "shuffle" else perm
+            cin, cout = C // 2, C - C // 2
+            out_ch = 2 * cout if coupling == "affine" else cout
+            convs = [_conv(rng, h, cin, 3, gain * 0.6 / np.sqrt(9 * cin), actnorm=True)]
+            for _ in range(depth):
+                convs.append(_conv(rng, h, h, 1, gain * 1.0 / np.sqrt(h), actnorm=True))
+            convs.append(_conv(rng, out_ch, h, 3, gain * 0.5 / np.sqrt(9 * h), bias=True, zeros_logs=True))
+            st["convs"] = convs
+            steps.append(st)
+        split = None
+        if lvl < L - 1:
+            split = _conv(rng, C, C // 2, 3, gain * 0.3 / np.sqrt(9 * (C // 2)), bias=True, zeros_logs=True)
+            C = C // 2
+        levels.append({"steps": steps, "split": split})
+    top = None
+    if learn_top:
+        top = _conv(rng, 2 * C, 2 * C, 3, 0.05, bias=True, zeros_logs=True)
+    return {"kind": "glow_image", "input_size": [int(v) for v in input_size], "hidden": int(h), "coupling": coupling,
+            "bounds": 0.9, "levels": levels, "learn_top": top}
+
+
+def synth_image_batch(N, input_size=(3, 32, 32), seed=0):
+    """Images in [0, 1] quantised to 256 levels (what the CIFAR loader hands over) + the dequantisation noise."""
+    rng = np.random.RandomState(seed)
+    x = rng.randint(0, 256, size=(N,) + tuple(input_size)).astype(np.float32) / 255.0
+    noise = rng.uniform(0.0, 1.0, size=x.shape).astype(np.float32)
+    return x, noise

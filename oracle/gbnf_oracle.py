@@ -371,6 +371,98 @@ def component_grads(spec, x, g_z, g_ldj):
     return xt.grad.numpy().copy(), grads
 
 
+# --------------------------------------------------------------------------
+# image Glow: torch restatement (conv2d is the primitive here, as nn.Linear is above)
+# --------------------------------------------------------------------------
+def _t(a, dtype):
+    return torch.as_tensor(np.asarray(a), dtype=dtype)
+
+
+def image_conv(c, x, dtype):
+    """Conv2d (+ActNorm2d) or Conv2dZeros, models/layers.py:577-630: 'same' padding, stride 1."""
+    w = _t(c["w"], dtype)
+    k = w.shape[-1]
+    y = torch.nn.functional.conv2d(x, w, None if c["b"] is None else _t(c["b"], dtype), padding=k // 2)
+    if c["an_bias"] is not None:                       # ActNorm2d, models/layers.py:488-533 (no logdet here)
+        y = (y + _t(c["an_bias"], dtype).view(1, -1, 1, 1)) * torch.exp(_t(c["an_logs"], dtype).view(1, -1, 1, 1))
+    if c["logs"] is not None:                          # Conv2dZeros: * exp(logs * 3), models/layers.py:629-630
+        y = y * torch.exp(_t(c["logs"], dtype).view(1, -1, 1, 1) * 3.0)
+    return y
+
+
+def image_squeeze(x, factor=2):
+    """squeeze2d, utils/utilities.py:107-119."""
+    B, C, H, W = x.shape
+    x = x.view(B, C, H // factor, factor, W // factor, factor).permute(0, 1, 3, 5, 2, 4).contiguous()
+    return x.view(B, C * factor * factor, H // factor, W // factor)
+
+
+def image_flow_step(spec, st, z, ld, dtype):
+    """FlowStep.encode, image branch (models/glow.py:317-342): ActNorm2d (logdet x H*W), invconv 1x1 / Permute2d,
+    ConvNet coupling."""
+    B, C, H, W = z.shape
+    logs = _t(st["an_logs"], dtype).view(1, -1, 1, 1)
+    z = (z + _t(st["an_bias"], dtype).view(1, -1, 1, 1)) * torch.exp(logs)
+    ld = ld + logs.sum() * H * W                                        # models/layers.py:506-508
+    if st["perm_w"] is not None:                                        # InvertibleConv1x1, models/layers.py:786-790
+        w = _t(st["perm_w"], dtype)
+        z = torch.nn.functional.conv2d(z, w.view(C, C, 1, 1))
+        ld = ld + torch.slogdet(w.double())[1].to(dtype) * H * W
+    else:
+        z = z[:, torch.as_tensor(np.asarray(st["perm"]), dtype=torch.long)]   # Permute2d, models/layers.py:675-677
+    z1, z2 = z[:, : C // 2], z[:, C // 2:]
+    h = z1
+    n = len(st["convs"])
+    for k, c in enumerate(st["convs"]):                                 # ConvNet, models/layers.py:304-317
+        h = image_conv(c, h, dtype)
+        if k < n - 1:
+            h = torch.relu(h)
+    if spec["coupling"] == "additive":
+        z2 = z2 + h
+    else:
+        shift, raw = h[:, 0::2], h[:, 1::2]
+        scale = torch.sigmoid(raw + 2.0)
+        z2 = (z2 + shift) * scale
+        ld = ld + torch.log(scale).sum(dim=[1, 2, 3])
+    return torch.cat([z1, z2], dim=1), ld
+
+
+def image_component_forward(spec, x, noise, dtype=None):
+    """Glow.encode for image input (models/glow.py:92-110): dequantise (:125-140, noise injected), to_logits (:142-179),
+    FlowNet.encode (:249-252) with Split2d priors (models/layers.py:685-705), then the prior of Glow.prior (:62-84).
+    -> z (N,Cz,Hz,Wz), z_mu, z_var, logdet (N,), ll (N,) = log_normal_diag(z, z_mu, z_var) + logdet
+    (image_experiment.py:227; log_normal_diag has no 2 pi term, utils/distributions.py:13-21)."""
+    dtype = dtype or torch.float32
+    x = _t(x, dtype).clone()
+    B, C, H, W = x.shape
+    x = (255.0 * x + _t(noise, dtype)) / 256.0
+    ld = torch.full((B,), -math.log(256.0) * C * H * W, dtype=dtype)
+    bounds = torch.tensor(spec["bounds"], dtype=dtype)
+    x = ((x * 2.0 - 1.0) * bounds + 1.0) / 2.0
+    logit = torch.log(x) - torch.log(1.0 - x)
+    sp = torch.nn.functional.softplus
+    ld = ld + (sp(logit) + sp(-logit) - sp((1.0 - bounds).log() - bounds.log())).flatten(1).sum(-1)
+    z = logit
+    for lvl in spec["levels"]:
+        z = image_squeeze(z)
+        for st in lvl["steps"]:
+            z, ld = image_flow_step(spec, st, z, ld, dtype)
+        if lvl["split"] is not None:
+            Cz = z.shape[1]
+            z1, z2 = z[:, : Cz // 2], z[:, Cz // 2:]
+            hh = image_conv(lvl["split"], z1, dtype)
+            mu, lv = hh[:, 0::2], hh[:, 1::2]
+            ld = ld + (-0.5 * (lv + (z2 - mu) ** 2 * torch.exp(-lv))).sum(dim=[1, 2, 3])
+            z = z1
+    Cz = z.shape[1]
+    hprior = torch.zeros((B, 2 * Cz) + tuple(z.shape[2:]), dtype=dtype)
+    if spec["learn_top"] is not None:
+        hprior = image_conv(spec["learn_top"], hprior, dtype)
+    z_mu, z_var = hprior[:, :Cz], hprior[:, Cz:]
+    ll = (-0.5 * (z_var + (z - z_mu) ** 2 * torch.exp(-z_var))).sum(dim=[1, 2, 3]) + ld
+    return z.numpy(), z_mu.numpy(), z_var.numpy(), ld.numpy(), ll.numpy()
+
+
 def log_normal_standard_sum(ops, z):
     """log_normal_standard(z, reduce=True, dim=-1): utils/distributions.py:44-60."""
     log_norm = (-0.5 * LOG_2PI) - (0.5 * z * z)

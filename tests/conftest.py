@@ -21,7 +21,28 @@ def golden_names():
     """Forward/mixture fixtures (g1..g6).  g7 (ActNorm data-dependent init), g8 (boosting weights) and g9 (decode)
     have their own tests."""
     names = sorted(os.path.splitext(os.path.basename(p))[0] for p in glob.glob(os.path.join(GOLDEN_DIR, "*.npz")))
-    return [n for n in names if not n.startswith(("g7_", "g8_", "g9_", "g10_", "g11_"))]
+    return [n for n in names if not n.startswith(("g7_", "g8_", "g9_", "g10_", "g11_", "g12_"))]
+
+
+IMAGE_CASES = ("g12_image_glow_invconv_affine", "g12_image_glow_shuffle_additive", "g12_image_glow_lu")
+
+
+def load_image_case(name):
+    """g12: (cfg, specs, x, noise, data) -- the reference's image Glow outputs."""
+    from gbnf_amd import synth
+    data = dict(np.load(os.path.join(GOLDEN_DIR, name + ".npz")))
+    cfg = json.loads(bytes(data["config"]).decode())
+    specs = [synth.synth_image_glow_spec((3, 32, 32), cfg["h"], cfg["K"], cfg["L"], depth=cfg["depth"], coupling=cfg["coupling"],
+                                         permutation=cfg["permutation"], learn_top=cfg["learn_top"], seed=cfg["w_seed"] + c)
+             for c in range(cfg["C"])]
+    if cfg["LU"]:
+        for c, sp in enumerate(specs):
+            k = 0
+            for lvl in sp["levels"]:
+                for st in lvl["steps"]:
+                    st["perm_w"] = data[f"c{c}.perm_w.{k}"]; k += 1
+    x, noise = synth.synth_image_batch(cfg["N"], (3, 32, 32), seed=cfg["x_seed"])
+    return cfg, specs, x, noise, data
 
 
 GRADS_CASES = ("g10_glow_grads_d43_h64", "g10_glow_grads_additive_relu_d8", "g10_realnvp_grads_d21_h32")

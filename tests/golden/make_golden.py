@@ -395,8 +395,113 @@ def checkpoint_case(name, d=6, h=8, K=2, C=2, N=16):
     print(f"{name}: ll[0,:3]={ll[0, :3]} file={os.path.getsize(os.path.join(HERE, name + '.pt'))} bytes")
 
 
+def _install_conv(ref_conv, c):
+    """Conv2d (+ActNorm2d) / Conv2dZeros of the reference <- conv dict of the image spec."""
+    ref_conv.conv.weight.data.copy_(torch.from_numpy(c["w"]))
+    if c["b"] is not None:
+        ref_conv.conv.bias.data.copy_(torch.from_numpy(c["b"]))
+    if c["an_bias"] is not None:
+        ref_conv.actnorm.bias.data.copy_(torch.from_numpy(c["an_bias"]).view(1, -1, 1, 1))
+        ref_conv.actnorm.logs.data.copy_(torch.from_numpy(c["an_logs"]).view(1, -1, 1, 1))
+        ref_conv.actnorm.inited = True
+    if c["logs"] is not None:
+        ref_conv.logs.data.copy_(torch.from_numpy(c["logs"]).view(-1, 1, 1))
+
+
+def install_image_spec(ref_glow, spec, keep_invconv=False):
+    from models.glow import FlowStep
+    from models.layers import Split2d
+    layers = list(ref_glow.flow.layers)
+    steps = [st for lvl in spec["levels"] for st in lvl["steps"]]
+    splits = [lvl["split"] for lvl in spec["levels"] if lvl["split"] is not None]
+    si = pi = 0
+    for layer in layers:
+        if isinstance(layer, FlowStep):
+            st = steps[si]; si += 1
+            layer.actnorm.bias.data.copy_(torch.from_numpy(st["an_bias"]).view(1, -1, 1, 1))
+            layer.actnorm.logs.data.copy_(torch.from_numpy(st["an_logs"]).view(1, -1, 1, 1))
+            layer.actnorm.inited = True
+            if hasattr(layer, "invconv"):
+                if keep_invconv:     # LU parameterisation: keep the reference's own factors, export the composed matrix
+                    w, _ = layer.invconv.get_weight(torch.zeros(1, layer.invconv.w_shape[0], 1, 1), False)
+                    st["perm_w"] = w.detach().view(*layer.invconv.w_shape).numpy().copy()
+                else:
+                    layer.invconv.weight.data.copy_(torch.from_numpy(st["perm_w"]))
+            else:
+                pm = layer.shuffle if hasattr(layer, "shuffle") else layer.reverse
+                pm.indices = torch.from_numpy(st["perm"]).long()
+                for i in range(pm.num_dim):
+                    pm.indices_inverse[pm.indices[i]] = i
+            convs = [m for m in layer.block.network if not isinstance(m, torch.nn.ReLU)]
+            assert len(convs) == len(st["convs"])
+            for m, c in zip(convs, st["convs"]):
+                _install_conv(m, c)
+        elif isinstance(layer, Split2d):
+            _install_conv(layer.conv, splits[pi]); pi += 1
+    if spec["learn_top"] is not None:
+        _install_conv(ref_glow.learn_top_fn, spec["learn_top"])
+
+
+def image_case(name, h=32, K=2, L=2, C=2, N=4, depth=1, coupling="affine", permutation="invconv", learn_top=True,
+               LU=False):
+    """G12: the image path (BASELINE.json configs[3] at toy size) by the reference itself:
+    BoostedFlow with input_size (3,32,32) -> Glow.encode (dequantise with the fixture's noise injected through
+    Tensor.uniform_, to_logits, squeeze / FlowStep / Split2d levels, learned top prior), then
+    ll_c = log_normal_diag(z, z_mu, z_var) + logdet (image_experiment.py:227) and the boosted recursion over c."""
+    from utils.distributions import log_normal_diag
+    input_size = (3, 32, 32)
+    a = ref_args("glow", 3 * 32 * 32, h, K, C, depth=depth, coupling=coupling, permutation=permutation)
+    a.input_size = list(input_size); a.num_blocks = L; a.learn_top = learn_top; a.LU_decomposed = LU
+    torch.manual_seed(7)
+    model = RefBoostedFlow(a).eval()
+    specs = [synth.synth_image_glow_spec(input_size, h, K, L, depth=depth, coupling=coupling, permutation=permutation,
+                                         learn_top=learn_top, seed=61 + c) for c in range(C)]
+    for c in range(C):
+        install_image_spec(model.flows[c], specs[c], keep_invconv=LU)
+    x, noise = synth.synth_image_batch(N, input_size, seed=31)
+    orig = torch.Tensor.uniform_
+    noise_t = torch.from_numpy(noise)
+
+    def injected(self, a=0.0, b=1.0):
+        self.copy_(noise_t)
+        return self
+    lls, zs, ldjs = [], [], []
+    G = None
+    try:
+        torch.Tensor.uniform_ = injected
+        with torch.no_grad():
+            for c in range(C):
+                z, mu, var, ldj, _ = model(x=torch.from_numpy(x).clone(), components=c)
+                ll = log_normal_diag(z, mu, var, dim=[1, 2, 3]) + ldj
+                zs.append(z.numpy().copy()); ldjs.append(ldj.numpy().copy()); lls.append(ll.numpy().copy())
+                if c == 0:
+                    G = ll
+                else:
+                    r = model.rho[0:(c + 1)] / torch.sum(model.rho[0:(c + 1)])
+                    G = torch.logsumexp(torch.stack([torch.log(1 - r[c]) + G, torch.log(r[c]) + ll], dim=1), dim=1)
+    finally:
+        torch.Tensor.uniform_ = orig
+    out = dict(config=np.frombuffer(json.dumps(dict(case="image", h=h, K=K, L=L, C=C, N=N, depth=depth, coupling=coupling,
+                                                    permutation=permutation, learn_top=learn_top, LU=LU, w_seed=61,
+                                                    x_seed=31)).encode(), dtype=np.uint8),
+               rho=model.rho.numpy().copy(), z=np.stack(zs), ldj=np.stack(ldjs), ll=np.stack(lls), G=G.numpy().copy())
+    if LU:   # the composed invconv matrices of the reference's own LU factors (not reproducible from the generator)
+        for c in range(C):
+            k = 0
+            for lvl in specs[c]["levels"]:
+                for st in lvl["steps"]:
+                    out[f"c{c}.perm_w.{k}"] = st["perm_w"]; k += 1
+    np.savez_compressed(os.path.join(HERE, name + ".npz"), **out)
+    print(f"{name}: ll[:, :2]={np.stack(lls)[:, :2]} bpd={-np.stack(lls).mean() / (np.log(2) * 3072):.4f}")
+
+
 def main():
     torch.set_num_threads(4)
+    if "--image-only" in sys.argv:
+        image_case("g12_image_glow_invconv_affine")
+        image_case("g12_image_glow_shuffle_additive", coupling="additive", permutation="shuffle", learn_top=False, depth=2)
+        image_case("g12_image_glow_lu", LU=True, K=1, h=16)
+        return
     if "--checkpoint-only" in sys.argv:
         checkpoint_case("g11_reference_checkpoint")
         return
@@ -422,6 +527,9 @@ def main():
     boosting_weights_case("g8_boosting_weights")
     decode_case("g9_glow_additive_decode")
     checkpoint_case("g11_reference_checkpoint")
+    image_case("g12_image_glow_invconv_affine")
+    image_case("g12_image_glow_shuffle_additive", coupling="additive", permutation="shuffle", learn_top=False, depth=2)
+    image_case("g12_image_glow_lu", LU=True, K=1, h=16)
     grads_case("g10_glow_grads_d43_h64", "glow", 43, 64, 3, 96)
     grads_case("g10_glow_grads_additive_relu_d8", "glow", 8, 40, 3, 50, coupling="additive", act="relu")
     grads_case("g10_realnvp_grads_d21_h32", "realnvp", 21, 32, 4, 80)

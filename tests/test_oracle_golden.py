@@ -122,3 +122,25 @@ def test_oracle_gradients_match_reference_backward(name):
     assert mine.shape == flat.shape
     assert np.abs(mine - flat).max() <= 2e-5 * np.abs(flat).max()
     assert np.abs(gx - g_x).max() <= 2e-5 * np.abs(g_x).max()
+
+
+from conftest import IMAGE_CASES, load_image_case  # noqa: E402
+
+
+@pytest.mark.parametrize("name", IMAGE_CASES)
+def test_oracle_image_path_matches_reference(name):
+    """g12: the reference's image Glow (dequantise with injected noise, logits, squeeze / FlowStep / Split2d levels, top
+    prior) vs the oracle restatement, per component, and the boosted recursion on top."""
+    import torch
+    cfg, specs, x, noise, data = load_image_case(name)
+    lls = []
+    for c, sp in enumerate(specs):
+        z, mu, var, ld, ll = oracle.image_component_forward(sp, x, noise)
+        assert rel_err(ld, data["ldj"][c]) < 1e-5
+        assert rel_err(ll, data["ll"][c]) < 1e-5
+        assert np.abs(z - data["z"][c]).max() <= 2e-4 * max(1.0, np.abs(data["z"][c]).max())
+        z64, _, _, ld64, ll64 = oracle.image_component_forward(sp, x, noise, dtype=torch.float64)
+        assert rel_err(ll64, data["ll"][c]) < 1e-5
+        lls.append(ll)
+    G = oracle.mixture_recursion(np.stack(lls), data["rho"])
+    assert rel_err(G, data["G"]) < 1e-5
