@@ -1,0 +1,672 @@
+// gbnf_image.hip -- density evaluation of ONE image Glow component (BASELINE.json
+// configs[3]: CIFAR-10 3x32x32 multi-scale Boosted-Glow) for gfx950.
+//
+//   x (n,3,H,W) in [0,1]  --dequantise, logit-->  L levels of { squeeze, K x FlowStep, Split2d }  -->  z, log|det|, ll
+//
+// Every convolution is an implicit GEMM on the matrix cores (exact-f32 v_mfma_f32_16x16x4_f32), "transposed" like the
+// tabular path:  OUT(channels x pixels) = sum_tap W_tap(out x in) . IN_tap(in x pixels).  One workgroup (4 waves) owns a
+// strip of IMG_R rows of one image: the strip plus its halo, all input channels, is staged ONCE in LDS with the zero
+// 'same' padding materialised, and is the B operand of every tap straight from LDS (a tap is an address offset); the
+// weights are the A operand, pre-tiled at pack time into lane order (one 16-byte load per lane per 4 k-steps) with the
+// per-channel scales of ActNorm2d / Conv2dZeros folded in, streamed from L2 through a ring of loads in flight.
+//   * ActNorm2d + InvertibleConv1x1 / Permute2d of a FlowStep collapse into ONE 1x1 convolution
+//     (W_eff = W_perm . diag(exp(logs)), b_eff = W_eff . bias); its log-determinant is a per-handle constant.
+//   * the coupling (shift/scale "cross" rows are adjacent accumulator registers), the Split2d prior density and the
+//     ReLU / bias epilogues are fused into the producing convolution; log-det partials are reduced with wave shuffles.
+//   * convolutions with fewer output tiles than waves (the last 3x3 of a coupling net: 256 -> 12/24 channels) split
+//     their contraction (taps x channel chunks) over the 4 waves and fold the partial tiles through LDS.
+//
+// Reference semantics (file:line):  Glow.encode / dequantize / to_logits models/glow.py:92-110, 125-179;  FlowNet image
+// branch :192-252;  FlowStep.encode :317-342;  _ActNorm (x H*W log-det) models/layers.py:488-533;  InvertibleConv1x1
+// :722-796;  Permute2d :671-680;  ConvNet :304-317;  Conv2d / Conv2dZeros :577-630;  Split2d :685-705;  squeeze2d
+// utils/utilities.py:107-119;  Glow.prior models/glow.py:62-84;  log_normal_diag utils/distributions.py:13-21;
+// ll = log_normal_diag(z, mu, var) + logdet image_experiment.py:227.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdint>
+#include <cstring>
+#include <vector>
+
+#include "../../include/gbnf.h"
+#include "gbnf_internal.h"
+
+namespace gbnf {
+
+using f32x4 = __attribute__((ext_vector_type(4))) float;
+
+constexpr int IMG_R = 4;          // rows of one image per workgroup
+constexpr int IMG_WAVES = 4;
+constexpr int IMG_PD = 4;         // weight-prefetch distance (iterations of 4 k-steps)
+constexpr int IMG_MAX_PT = 4;     // pixel tiles of 16 per strip (IMG_R * W / 16, W <= 16)
+
+enum { EPI_RELU = 0, EPI_STORE = 1, EPI_COUPLE_AFFINE = 2, EPI_COUPLE_ADD = 3, EPI_SPLIT = 4 };
+
+struct ConvLaunch {
+  const float* in;        // (n, *, H, W): first input channel of image 0
+  int64_t in_img;         // floats between images
+  const float* wp;        // packed weights [OT][taps][KC][64][4]
+  const float* bias;      // [OT*16]
+  float* out;             // EPI_RELU / EPI_STORE: (n, *, H, W) first output channel of image 0
+  int64_t out_img;
+  float* st;              // EPI_COUPLE_* / EPI_SPLIT: the coupled half z2 (n, *, H, W), first channel of image 0
+  int64_t st_img;
+  float* ldj;             // (n,) accumulated with atomics (EPI_COUPLE_AFFINE / EPI_SPLIT)
+  int cin, cout, H, W, ks, n_strips;
+};
+
+__device__ __forceinline__ f32x4 img_mfma(float a, float b, f32x4 c) {
+  return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+}
+// see gbnf_train.hip: the compiler's MFMA-result hazard padding does not look across branches on this toolchain
+template <int N>
+__device__ __forceinline__ void img_drain(f32x4 (&c)[N]) {
+#pragma unroll
+  for (int k = 0; k < N; ++k) asm volatile("s_nop 7\n\ts_nop 7" : "+a"(c[k]));
+}
+
+// EPI: see enum.  PT: pixel tiles per strip (2 or 4).
+template <int EPI, int PT>
+__global__ void __launch_bounds__(64 * IMG_WAVES) img_conv_kernel(const ConvLaunch p) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  typedef const float __attribute__((address_space(1)))* gptr;
+  const int lane = threadIdx.x & 63, i = lane & 15, g = lane >> 4;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int n = blockIdx.x / p.n_strips, strip = blockIdx.x % p.n_strips;
+  constexpr int W = 16 * PT / IMG_R;                        // the strip is IMG_R full rows: W = 16 (PT = 4) or 8 (PT = 2)
+  constexpr int WP = W + 2, CS = (IMG_R + 2) * WP;          // padded row / channel stride in LDS
+  const int H = p.H, r0 = strip * IMG_R;
+  const int kc = (p.cin + 15) >> 4, cin_pad = kc * 16;
+  const int taps = p.ks * p.ks, half = p.ks >> 1;
+  const int OT = (p.cout + 15) >> 4;
+
+  // ---- stage the strip (+ halo, zero padded) of every input channel
+  {
+    const float* src = p.in + (int64_t)n * p.in_img;
+    const int per_ch = (IMG_R + 2) * WP;
+    for (int e = threadIdx.x; e < cin_pad * per_ch; e += 64 * IMG_WAVES) {
+      const int ci = e / per_ch, rem = e % per_ch, rr = rem / WP, cc = rem % WP;
+      const int row = r0 + rr - 1, col = cc - 1;
+      float v = 0.0f;
+      if (ci < p.cin && row >= 0 && row < H && col >= 0 && col < W) v = src[((int64_t)ci * H + row) * W + col];
+      lds[e] = v;
+    }
+  }
+  __syncthreads();
+
+  // pixel of lane i in tile pt: linear index 16 pt + i inside the strip (row-major over IMG_R x W)
+  int boff[PT];
+#pragma unroll
+  for (int pt = 0; pt < PT; ++pt) {
+    const int lin = 16 * pt + i, pr = lin / W, pc = lin % W;
+    boff[pt] = (4 * g) * CS + (pr + 1) * WP + pc + 1;
+  }
+
+  const bool splitk = OT < IMG_WAVES;                        // few output tiles: the waves split the contraction instead
+  const int T_all = taps * kc;                               // iterations (tap, chunk) of one output tile
+  gptr wp = (gptr)p.wp;
+  const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+
+  // one output tile over the iterations [t_begin, t_end) with stride t_step: acc[pt] += ...
+  auto run_tile = [&](int o, int t_begin, int t_end, int t_step, f32x4 (&acc)[PT]) {
+    const gptr wo = wp + ((size_t)o * T_all) * 256 + lane * 4;
+    f32x4 ring[IMG_PD];
+    int tl = t_begin;
+#pragma unroll
+    for (int j = 0; j < IMG_PD; ++j) {                       // unconditional: past the end re-reads the last fragment
+      const int tt = tl < t_end ? tl : 0;
+      ring[j] = *reinterpret_cast<const f32x4 __attribute__((address_space(1)))*>(wo + (size_t)tt * 256);
+      tl += t_step;
+    }
+    auto body = [&](const f32x4& a, int t) {
+      const int tap = t / kc, c = t - tap * kc;
+      const int dy = tap / p.ks - half, dx = tap % p.ks - half;
+      const float* b0 = lds + (16 * c) * CS + dy * WP + dx;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+#pragma unroll
+        for (int pt = 0; pt < PT; ++pt) acc[pt] = img_mfma(a[r], b0[boff[pt] + r * CS], acc[pt]);
+      }
+    };
+    int t = t_begin;
+    for (; t + (IMG_PD - 1) * t_step < t_end; ) {
+#pragma unroll
+      for (int j = 0; j < IMG_PD; ++j) {
+        body(ring[j], t);
+        const int tt = tl < t_end ? tl : 0;
+        ring[j] = *reinterpret_cast<const f32x4 __attribute__((address_space(1)))*>(wo + (size_t)tt * 256);
+        tl += t_step;
+        t += t_step;
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < IMG_PD - 1; ++j) {
+      if (t < t_end) {
+        body(ring[j], t);
+        t += t_step;
+      }
+    }
+  };
+
+  float ld = 0.0f;
+  // epilogue of one (output tile o, pixel tile pt): lane (i,g) holds channels 16o+4g+r of pixel 16pt+i
+  auto epilogue = [&](int o, int pt, const f32x4& acc) {
+    gptr bias = (gptr)p.bias;
+    const int lin = 16 * pt + i, pr = lin / W, pc = lin % W;
+    const int row = r0 + pr;
+    const bool in_img = row < H;
+    const int64_t pix = (int64_t)row * W + pc;
+    if constexpr (EPI == EPI_RELU || EPI == EPI_STORE) {
+      float* out = p.out + (int64_t)n * p.out_img;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int co = 16 * o + 4 * g + r;
+        float v = acc[r] + bias[co];
+        if (EPI == EPI_RELU) v = fmaxf(v, 0.0f);
+        if (co < p.cout && in_img) out[(int64_t)co * H * W + pix] = v;
+      }
+    } else if constexpr (EPI == EPI_COUPLE_ADD) {
+      float* st = p.st + (int64_t)n * p.st_img;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int co = 16 * o + 4 * g + r;
+        if (co < p.cout && in_img) st[(int64_t)co * H * W + pix] += acc[r] + bias[co];   // models/glow.py:328-329
+      }
+    } else {
+      // "cross" rows: (2j, 2j+1) = (shift_j, raw_j) for the coupling, (mean_j, log-var_j) for the Split2d prior
+      float* st = p.st + (int64_t)n * p.st_img;
+#pragma unroll
+      for (int q = 0; q < 2; ++q) {
+        const int co = 16 * o + 4 * g + 2 * q, j = co >> 1;
+        if (co + 1 < p.cout && in_img) {
+          const float h0 = acc[2 * q] + bias[co], h1 = acc[2 * q + 1] + bias[co + 1];
+          float* zp = st + (int64_t)j * H * W + pix;
+          const float z2 = *zp;
+          if constexpr (EPI == EPI_COUPLE_AFFINE) {
+            const float e = __expf(-(h1 + 2.0f));                   // scale = sigmoid(raw + 2), models/glow.py:333
+            const float sc = 1.0f / (1.0f + e);
+            *zp = (z2 + h0) * sc;                                   // models/glow.py:334-335
+            ld += -log1pf(e);                                       // log(scale), models/glow.py:338
+          } else {                                                  // Split2d: log_normal_diag(z2; mean, log-var)
+            const float dlt = z2 - h0;
+            ld += -0.5f * (h1 + dlt * dlt * __expf(-h1));           // utils/distributions.py:14, models/layers.py:703
+          }
+        }
+      }
+    }
+  };
+
+  if (!splitk) {
+    for (int o = wave; o < OT; o += IMG_WAVES) {
+      f32x4 acc[PT];
+#pragma unroll
+      for (int pt = 0; pt < PT; ++pt) acc[pt] = zero;
+      run_tile(o, 0, T_all, 1, acc);
+      img_drain(acc);
+#pragma unroll
+      for (int pt = 0; pt < PT; ++pt) epilogue(o, pt, acc[pt]);
+    }
+  } else {
+    // every wave: ALL (<= 3) output tiles over its share of the (tap, chunk) iterations; the partial tiles meet in LDS
+    // once the strip is dead, and the (tile, pixel tile) epilogues are dealt round-robin to the waves
+    constexpr int MAXO = IMG_WAVES - 1;
+    f32x4 part[MAXO][PT];
+#pragma unroll
+    for (int o = 0; o < MAXO; ++o) {
+#pragma unroll
+      for (int pt = 0; pt < PT; ++pt) part[o][pt] = zero;
+      if (o < OT) {
+        run_tile(o, wave, T_all, IMG_WAVES, part[o]);
+        img_drain(part[o]);
+      }
+    }
+    __syncthreads();                                         // nobody reads the strip any more
+    f32x4* red = reinterpret_cast<f32x4*>(lds);              // [wave][o][pt][64]
+#pragma unroll
+    for (int o = 0; o < MAXO; ++o)
+#pragma unroll
+      for (int pt = 0; pt < PT; ++pt)
+        if (o < OT) red[((wave * MAXO + o) * PT + pt) * 64 + lane] = part[o][pt];
+    __syncthreads();
+    for (int q = wave; q < OT * PT; q += IMG_WAVES) {
+      const int o = q / PT, pt = q % PT;
+      f32x4 acc = zero;
+#pragma unroll
+      for (int w = 0; w < IMG_WAVES; ++w) {
+        const f32x4 v = red[((w * MAXO + o) * PT + pt) * 64 + lane];
+        acc += v;
+      }
+      epilogue(o, pt, acc);
+    }
+  }
+
+  if constexpr (EPI == EPI_COUPLE_AFFINE || EPI == EPI_SPLIT) {
+#pragma unroll
+    for (int m = 1; m < 64; m <<= 1) ld += __shfl_xor(ld, m);
+    if (lane == 0) atomicAdd(p.ldj + n, ld);
+  }
+}
+
+// ---- dequantise + logit + first squeeze (models/glow.py:125-179; utils/utilities.py:107-119) -------------------
+// x (n, C, H, W) in [0,1] (+ uniform noise or null) -> squeezed logits (n, 4C, H/2, W/2); ldj[n] = its log-det.
+__global__ void __launch_bounds__(256) img_pre_kernel(const float* __restrict__ x, const float* __restrict__ noise, float* __restrict__ out,
+                                                      float* __restrict__ ldj, int C, int H, int W, float bounds, float ld_const) {
+  const int n = blockIdx.x, chw = C * H * W;
+  const float* xi = x + (int64_t)n * chw;
+  float* oi = out + (int64_t)n * chw;
+  const float soft_c = log1pf((1.0f - bounds) / bounds);     // softplus(log(1-b) - log(b))
+  float ld = 0.0f;
+  for (int e = threadIdx.x; e < chw; e += 256) {
+    const int c = e / (H * W), rem = e % (H * W), y = rem / W, xx = rem % W;
+    float v = xi[e];
+    v = (255.0f * v + (noise ? noise[(int64_t)n * chw + e] : 0.0f)) / 256.0f;      // models/glow.py:136
+    v = ((v * 2.0f - 1.0f) * bounds + 1.0f) * 0.5f;                                   // models/glow.py:164-168
+    const float logit = logf(v) - logf(1.0f - v);                                     // :171
+    // softplus(l) + softplus(-l) = -log(v) - log(1-v) for l = logit(v)
+    ld += -logf(v) - logf(1.0f - v) - soft_c;                                         // :174-175
+    const int oc = c * 4 + (y & 1) * 2 + (xx & 1);
+    oi[((int64_t)oc * (H / 2) + (y >> 1)) * (W / 2) + (xx >> 1)] = logit;
+  }
+  __shared__ float red[256];
+  red[threadIdx.x] = ld;
+  __syncthreads();
+  for (int s = 128; s > 0; s >>= 1) {
+    if ((int)threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) ldj[n] = red[0] + ld_const;
+}
+
+// squeeze2d of the first `C` channels of (n, Cin_total, H, W) -> (n, 4C, H/2, W/2)
+__global__ void __launch_bounds__(256) img_squeeze_kernel(const float* __restrict__ in, int64_t in_img, float* __restrict__ out, int C, int H,
+                                                          int W) {
+  const int n = blockIdx.x, chw = C * H * W;
+  const float* xi = in + (int64_t)n * in_img;
+  float* oi = out + (int64_t)n * chw;
+  for (int e = threadIdx.x; e < chw; e += 256) {
+    const int c = e / (H * W), rem = e % (H * W), y = rem / W, xx = rem % W;
+    const int oc = c * 4 + (y & 1) * 2 + (xx & 1);
+    oi[((int64_t)oc * (H / 2) + (y >> 1)) * (W / 2) + (xx >> 1)] = xi[e];
+  }
+}
+
+// ll[n] = sum -0.5 (log-var + (z - mean)^2 exp(-log-var)) + ldj[n]  with per-channel prior constants (Glow.prior on zeros:
+// Conv2dZeros(0) = bias * exp(3 logs), models/glow.py:62-84); optional copies of z / mean / log-var.
+__global__ void __launch_bounds__(256) img_final_kernel(const float* __restrict__ z, int64_t z_img, const float* __restrict__ prior /* [2C] */,
+                                                        const float* __restrict__ ldj, float* __restrict__ ll, float* __restrict__ z_out,
+                                                        int C, int HW) {
+  const int n = blockIdx.x;
+  const float* zi = z + (int64_t)n * z_img;
+  float acc = 0.0f;
+  for (int e = threadIdx.x; e < C * HW; e += 256) {
+    const int c = e / HW;
+    const float mu = prior[c], lv = prior[C + c], v = zi[e], dlt = v - mu;
+    acc += -0.5f * (lv + dlt * dlt * __expf(-lv));
+    if (z_out) z_out[(int64_t)n * C * HW + e] = v;
+  }
+  __shared__ float red[256];
+  red[threadIdx.x] = acc;
+  __syncthreads();
+  for (int s = 128; s > 0; s >>= 1) {
+    if ((int)threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0 && ll) ll[n] = red[0] + ldj[n];
+}
+
+
+// ---------------------------------------------------------------------------------------------------------------
+// host side: packing + launch sequence
+// ---------------------------------------------------------------------------------------------------------------
+struct PackedConv {
+  int cin = 0, cout = 0, ks = 1;
+  size_t w_off = 0, b_off = 0;   // float offsets into the handle's parameter blob
+};
+
+}  // namespace gbnf
+
+using namespace gbnf;
+
+struct gbnf_image_flow {
+  int C = 0, H = 0, W = 0, L = 0, K = 0, hidden = 0, additive = 0, depth = 0;
+  float bounds = 0.9f;
+  double ld_const = 0;                       // dequantisation + every ActNorm2d / invconv log-det (per image)
+  std::vector<int> level_steps;              // FlowSteps per level
+  std::vector<PackedConv> mix, split;        // [sum steps] / [L-1]
+  std::vector<std::vector<PackedConv>> net;  // [L*K][depth + 2]
+  size_t prior_off = 0;                      // [2 Cz] top prior (mean, log-var per channel)
+  float* blob_dev = nullptr;
+  int zC = 0, zH = 0, zW = 0;
+  double macs = 0;                           // multiply-adds per image
+};
+
+namespace {
+
+struct Packer {
+  std::vector<float> blob;
+  // weight w[co][ci][ky][kx] * row_scale[co] -> fragments [OT][taps][KC][64 lanes][4]; bias[co] -> [OT*16]
+  PackedConv add(const float* w, int cout, int cin, int ks, const std::vector<double>& row_scale, const std::vector<double>& bias) {
+    PackedConv pc;
+    pc.cin = cin; pc.cout = cout; pc.ks = ks;
+    const int OT = (cout + 15) / 16, KC = (cin + 15) / 16, taps = ks * ks;
+    pc.w_off = blob.size();
+    blob.resize(blob.size() + (size_t)OT * taps * KC * 256, 0.0f);
+    for (int o = 0; o < OT; ++o)
+      for (int tap = 0; tap < taps; ++tap)
+        for (int c = 0; c < KC; ++c)
+          for (int lane = 0; lane < 64; ++lane)
+            for (int r = 0; r < 4; ++r) {
+              const int co = 16 * o + (lane & 15), ci = 16 * c + 4 * (lane >> 4) + r;
+              float v = 0.0f;
+              if (co < cout && ci < cin) v = (float)(row_scale[co] * (double)w[((size_t)co * cin + ci) * taps + tap]);
+              blob[pc.w_off + ((((size_t)o * taps + tap) * KC + c) * 64 + lane) * 4 + r] = v;
+            }
+    pc.b_off = blob.size();
+    blob.resize(blob.size() + (size_t)OT * 16, 0.0f);
+    for (int co = 0; co < cout; ++co) blob[pc.b_off + co] = (float)bias[co];
+    return pc;
+  }
+};
+
+// log|det A| of an n x n matrix (double, partial pivoting)
+double logabsdet(std::vector<double> a, int n) {
+  double acc = 0;
+  for (int k = 0; k < n; ++k) {
+    int piv = k;
+    for (int r = k + 1; r < n; ++r)
+      if (std::fabs(a[r * n + k]) > std::fabs(a[piv * n + k])) piv = r;
+    if (a[piv * n + k] == 0.0) return -INFINITY;
+    if (piv != k)
+      for (int c = 0; c < n; ++c) std::swap(a[k * n + c], a[piv * n + c]);
+    acc += std::log(std::fabs(a[k * n + k]));
+    for (int r = k + 1; r < n; ++r) {
+      const double f = a[r * n + k] / a[k * n + k];
+      for (int c = k; c < n; ++c) a[r * n + c] -= f * a[k * n + c];
+    }
+  }
+  return acc;
+}
+
+int check_conv(const gbnf_conv& c, int cin, int cout, int ks, bool want_an, bool want_zeros, const char* what) {
+  if (!c.weight) return fail(GBNF_ERR_INVALID, "%s: null weight", what);
+  if (c.in_channels != cin || c.out_channels != cout || c.kernel_size != ks)
+    return fail(GBNF_ERR_INVALID, "%s: is %dx%d k=%d, expected %dx%d k=%d", what, c.out_channels, c.in_channels, c.kernel_size,
+                cout, cin, ks);
+  if (want_an && (!c.actnorm_bias || !c.actnorm_logs)) return fail(GBNF_ERR_INVALID, "%s: needs its ActNorm2d arrays", what);
+  if (want_zeros && (!c.bias || !c.logs)) return fail(GBNF_ERR_INVALID, "%s: Conv2dZeros needs bias and logs", what);
+  return GBNF_OK;
+}
+
+// Conv2d + ActNorm2d: (conv + an_bias) * exp(an_logs);  Conv2dZeros: (conv + bias) * exp(3 logs)
+PackedConv pack_conv(Packer& P, const gbnf_conv& c) {
+  std::vector<double> scale(c.out_channels, 1.0), bias(c.out_channels, 0.0);
+  for (int co = 0; co < c.out_channels; ++co) {
+    double b = c.bias ? c.bias[co] : 0.0;
+    if (c.actnorm_bias) {
+      scale[co] = std::exp((double)c.actnorm_logs[co]);
+      b = (b + c.actnorm_bias[co]) * scale[co];
+    }
+    if (c.logs) {
+      const double s3 = std::exp(3.0 * (double)c.logs[co]);
+      scale[co] *= s3;
+      b *= s3;
+    }
+    bias[co] = b;
+  }
+  return P.add(c.weight, c.out_channels, c.in_channels, c.kernel_size, scale, bias);
+}
+
+template <int EPI>
+void launch_conv(const ConvLaunch& p, int n, hipStream_t s) {
+  const int per_ch = (IMG_R + 2) * (p.W + 2);
+  const int kc = (p.cin + 15) / 16, OT = (p.cout + 15) / 16, PT = IMG_R * p.W / 16;
+  size_t lds = (size_t)kc * 16 * per_ch * 4;
+  if (OT < IMG_WAVES) lds = std::max(lds, (size_t)IMG_WAVES * (IMG_WAVES - 1) * PT * 64 * 16);
+  const dim3 grid((unsigned)(n * p.n_strips));
+  if (PT == 4) hipLaunchKernelGGL((img_conv_kernel<EPI, 4>), grid, dim3(64 * IMG_WAVES), lds, s, p);
+  else hipLaunchKernelGGL((img_conv_kernel<EPI, 2>), grid, dim3(64 * IMG_WAVES), lds, s, p);
+}
+
+template <int EPI, int PT>
+hipError_t allow_lds() {
+  return hipFuncSetAttribute((const void*)img_conv_kernel<EPI, PT>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+}
+
+}  // namespace
+
+extern "C" {
+
+int gbnf_image_flow_create(const gbnf_image_flow_desc* d, gbnf_image_flow** out) {
+  if (!out) return fail(GBNF_ERR_INVALID, "gbnf_image_flow_create: out is null");
+  *out = nullptr;
+  if (!d || !d->levels) return fail(GBNF_ERR_INVALID, "gbnf_image_flow_create: null descriptor");
+  if (d->n_levels < 1 || d->n_levels > 4) return fail(GBNF_ERR_UNSUPPORTED, "n_levels=%d outside [1,4]", d->n_levels);
+  if (d->coupling != GBNF_COUPLING_AFFINE && d->coupling != GBNF_COUPLING_ADDITIVE)
+    return fail(GBNF_ERR_INVALID, "unknown coupling %d", d->coupling);
+  int C = d->channels, H = d->height, W = d->width;
+  if (C < 1 || H != W) return fail(GBNF_ERR_UNSUPPORTED, "input %dx%dx%d: square images only", C, H, W);
+  if (!(d->bounds > 0.5f && d->bounds < 1.0f)) return fail(GBNF_ERR_INVALID, "bounds must be in (0.5, 1)");
+  auto* f = new gbnf_image_flow();
+  f->C = C; f->H = H; f->W = W; f->L = d->n_levels; f->additive = d->coupling == GBNF_COUPLING_ADDITIVE;
+  f->bounds = d->bounds; f->hidden = d->hidden;
+  Packer P;
+  double ld_const = -std::log(256.0) * C * H * W;              // dequantisation, models/glow.py:137
+  char what[96];
+  int rc = GBNF_OK;
+  for (int l = 0; l < d->n_levels && rc == GBNF_OK; ++l) {
+    const gbnf_image_level& lv = d->levels[l];
+    if (H % 2 || W % 2) { rc = fail(GBNF_ERR_INVALID, "level %d: odd spatial size", l); break; }
+    C *= 4; H /= 2; W /= 2;
+    if (W != 16 && W != 8) { rc = fail(GBNF_ERR_UNSUPPORTED, "level %d works on %dx%d maps; compiled for widths 16 and 8 (32x32 input, <= 2 levels)", l, H, W); break; }
+    if (H % IMG_R) { rc = fail(GBNF_ERR_UNSUPPORTED, "level %d: height %d not a multiple of %d", l, H, IMG_R); break; }
+    if (C > 64) { rc = fail(GBNF_ERR_UNSUPPORTED, "level %d: %d channels > 64", l, C); break; }
+    f->level_steps.push_back(lv.n_steps);
+    if (lv.n_steps < 1 || !lv.steps) { rc = fail(GBNF_ERR_INVALID, "level %d: no steps", l); break; }
+    const int c1 = C / 2, c2 = C - c1;
+    for (int k = 0; k < lv.n_steps && rc == GBNF_OK; ++k) {
+      const gbnf_image_step& st = lv.steps[k];
+      if (!st.actnorm_bias || !st.actnorm_logs || (!st.perm_weight && !st.perm_indices)) {
+        rc = fail(GBNF_ERR_INVALID, "level %d step %d: null actnorm / permutation", l, k); break;
+      }
+      // ActNorm2d then invconv / Permute2d as one C x C matrix
+      std::vector<double> wperm((size_t)C * C, 0.0);
+      if (st.perm_weight) {
+        for (int e = 0; e < C * C; ++e) wperm[e] = st.perm_weight[e];
+        ld_const += logabsdet(wperm, C) * H * W;                 // models/layers.py:756, 790
+      } else {
+        std::vector<char> seen(C, 0);
+        for (int j = 0; j < C; ++j) {
+          const int64_t m = st.perm_indices[j];
+          if (m < 0 || m >= C || seen[m]) { rc = fail(GBNF_ERR_INVALID, "level %d step %d: perm_indices is not a permutation", l, k); break; }
+          seen[m] = 1;
+          wperm[(size_t)j * C + m] = 1.0;                        // z[:, j] = y[:, indices[j]], models/layers.py:675-677
+        }
+        if (rc) break;
+      }
+      std::vector<float> weff((size_t)C * C);
+      std::vector<double> ones(C, 1.0), beff(C, 0.0);
+      for (int j = 0; j < C; ++j) {
+        double b = 0;
+        for (int m = 0; m < C; ++m) {
+          const double e = std::exp((double)st.actnorm_logs[m]);
+          const double v = wperm[(size_t)j * C + m] * e;
+          weff[(size_t)j * C + m] = (float)v;
+          b += v * st.actnorm_bias[m];
+        }
+        beff[j] = b;
+      }
+      for (int m = 0; m < C; ++m) ld_const += (double)st.actnorm_logs[m] * H * W;      // models/layers.py:506-508
+      f->mix.push_back(P.add(weff.data(), C, C, 1, ones, beff));
+      // ConvNet: Conv2d 3x3 (+ActNorm2d), [Conv2d 1x1 (+ActNorm2d)] x depth, Conv2dZeros 3x3
+      if (st.n_convs < 2 || st.n_convs > 5 || !st.convs) { rc = fail(GBNF_ERR_INVALID, "level %d step %d: needs 2..5 convolutions", l, k); break; }
+      const int hdim = st.convs[0].out_channels;
+      if (hdim < 1 || hdim > 256) { rc = fail(GBNF_ERR_UNSUPPORTED, "hidden width %d outside [1,256]", hdim); break; }
+      std::vector<PackedConv> net;
+      for (int q = 0; q < st.n_convs && rc == GBNF_OK; ++q) {
+        const bool first = q == 0, last = q == st.n_convs - 1;
+        snprintf(what, sizeof(what), "level %d step %d conv %d", l, k, q);
+        rc = check_conv(st.convs[q], first ? c1 : hdim, last ? (f->additive ? c2 : 2 * c2) : hdim, (first || last) ? 3 : 1, !last, last, what);
+        if (rc == GBNF_OK) {
+          net.push_back(pack_conv(P, st.convs[q]));
+          f->macs += (double)st.convs[q].in_channels * st.convs[q].out_channels * st.convs[q].kernel_size * st.convs[q].kernel_size * H * W;
+        }
+      }
+      f->net.push_back(net);
+      f->depth = st.n_convs - 2;
+      f->macs += (double)C * C * H * W;
+    }
+    if (rc) break;
+    if (l < d->n_levels - 1) {
+      if (!lv.split_prior) { rc = fail(GBNF_ERR_INVALID, "level %d: missing Split2d prior", l); break; }
+      snprintf(what, sizeof(what), "level %d split prior", l);
+      rc = check_conv(*lv.split_prior, C / 2, C, 3, false, true, what);
+      if (rc) break;
+      if (C % 2) { rc = fail(GBNF_ERR_UNSUPPORTED, "Split2d on an odd channel count"); break; }
+      f->split.push_back(pack_conv(P, *lv.split_prior));
+      f->macs += (double)(C / 2) * C * 9 * H * W;
+      C /= 2;
+    }
+  }
+  if (rc == GBNF_OK) {
+    f->zC = C; f->zH = H; f->zW = W;
+    // top prior: Conv2dZeros applied to zeros = bias * exp(3 logs) per channel (models/glow.py:62-84); else zeros
+    f->prior_off = P.blob.size();
+    P.blob.resize(P.blob.size() + 2 * (size_t)C, 0.0f);
+    if (d->learn_top) {
+      const gbnf_conv& t = *d->learn_top;
+      if (t.out_channels != 2 * C || !t.bias || !t.logs) rc = fail(GBNF_ERR_INVALID, "learn_top must be a Conv2dZeros with %d outputs", 2 * C);
+      else
+        for (int c = 0; c < 2 * C; ++c) P.blob[f->prior_off + c] = (float)((double)t.bias[c] * std::exp(3.0 * (double)t.logs[c]));
+    }
+  }
+  if (rc == GBNF_OK) {
+    f->ld_const = ld_const;
+    hipError_t e = hipMalloc((void**)&f->blob_dev, P.blob.size() * 4);
+    if (e == hipSuccess) e = hipMemcpy(f->blob_dev, P.blob.data(), P.blob.size() * 4, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = allow_lds<EPI_RELU, 4>();
+    if (e == hipSuccess) e = allow_lds<EPI_RELU, 2>();
+    if (e == hipSuccess) e = allow_lds<EPI_STORE, 4>();
+    if (e == hipSuccess) e = allow_lds<EPI_STORE, 2>();
+    if (e == hipSuccess) e = allow_lds<EPI_COUPLE_AFFINE, 4>();
+    if (e == hipSuccess) e = allow_lds<EPI_COUPLE_AFFINE, 2>();
+    if (e == hipSuccess) e = allow_lds<EPI_COUPLE_ADD, 4>();
+    if (e == hipSuccess) e = allow_lds<EPI_COUPLE_ADD, 2>();
+    if (e == hipSuccess) e = allow_lds<EPI_SPLIT, 4>();
+    if (e == hipSuccess) e = allow_lds<EPI_SPLIT, 2>();
+    if (e != hipSuccess) rc = fail(GBNF_ERR_HIP, "gbnf_image_flow_create: %s", hipGetErrorString(e));
+  }
+  if (rc != GBNF_OK) {
+    gbnf_image_flow_destroy(f);
+    return rc;
+  }
+  *out = f;
+  return GBNF_OK;
+}
+
+int gbnf_image_flow_destroy(gbnf_image_flow* f) {
+  if (!f) return GBNF_OK;
+  if (f->blob_dev) (void)hipFree(f->blob_dev);
+  delete f;
+  return GBNF_OK;
+}
+
+int gbnf_image_flow_info(const gbnf_image_flow* f, int32_t* z_channels, int32_t* z_height, int32_t* z_width, double* macs_per_image) {
+  if (!f) return fail(GBNF_ERR_INVALID, "gbnf_image_flow_info: flow is null");
+  if (z_channels) *z_channels = f->zC;
+  if (z_height) *z_height = f->zH;
+  if (z_width) *z_width = f->zW;
+  if (macs_per_image) *macs_per_image = f->macs;
+  return GBNF_OK;
+}
+
+int gbnf_image_flow_prior(const gbnf_image_flow* f, float* host) {
+  if (!f || !host) return fail(GBNF_ERR_INVALID, "gbnf_image_flow_prior: null argument");
+  const hipError_t e = hipMemcpy(host, f->blob_dev + f->prior_off, 2 * (size_t)f->zC * 4, hipMemcpyDeviceToHost);
+  if (e != hipSuccess) return fail(GBNF_ERR_HIP, "gbnf_image_flow_prior: %s", hipGetErrorString(e));
+  return GBNF_OK;
+}
+
+int gbnf_image_flow_workspace_bytes(const gbnf_image_flow* f, int64_t n, int64_t* bytes) {
+  if (!f || !bytes || n < 0) return fail(GBNF_ERR_INVALID, "gbnf_image_flow_workspace_bytes: bad argument");
+  const int64_t chw = (int64_t)f->C * f->H * f->W;
+  const int64_t hid = (int64_t)f->hidden * (f->H / 2) * (f->W / 2);
+  *bytes = (2 * chw + 2 * hid) * n * 4 + 256;
+  return GBNF_OK;
+}
+
+int gbnf_image_flow_forward(const gbnf_image_flow* f, const float* x, const float* noise, int64_t n, float* z, float* ldj,
+                            float* ll, void* workspace, int64_t workspace_bytes, void* stream) {
+  if (!f) return fail(GBNF_ERR_INVALID, "gbnf_image_flow_forward: flow is null");
+  if (n < 0) return fail(GBNF_ERR_INVALID, "gbnf_image_flow_forward: n < 0");
+  if (n == 0) return GBNF_OK;
+  if (!x || !ldj || !workspace) return fail(GBNF_ERR_INVALID, "gbnf_image_flow_forward: x / ldj / workspace is null");
+  int64_t need = 0;
+  gbnf_image_flow_workspace_bytes(f, n, &need);
+  if (workspace_bytes < need) return fail(GBNF_ERR_INVALID, "gbnf_image_flow_forward: workspace of %lld bytes < %lld", (long long)workspace_bytes, (long long)need);
+  hipStream_t s = (hipStream_t)stream;
+  const int64_t chw = (int64_t)f->C * f->H * f->W;
+  const int64_t hid = (int64_t)f->hidden * (f->H / 2) * (f->W / 2);
+  float* SA = (float*)workspace;
+  float* SB = SA + chw * n;
+  float* H1 = SB + chw * n;
+  float* H2 = H1 + hid * n;
+  const float* blob = f->blob_dev;
+
+  int C = f->C * 4, H = f->H / 2, W = f->W / 2;
+  hipLaunchKernelGGL(img_pre_kernel, dim3((unsigned)n), dim3(256), 0, s, x, noise, SA, ldj, f->C, f->H, f->W, f->bounds, (float)f->ld_const);
+  float* cur = SA;      // current state (n, C, H, W), image stride = C*H*W
+  float* oth = SB;
+  size_t step = 0;
+  for (int l = 0; l < f->L; ++l) {
+    const int64_t img = (int64_t)C * H * W;
+    const int n_strips = H / IMG_R;
+    const int c1 = C / 2;
+    const int K = f->level_steps[l];
+    for (int k = 0; k < K; ++k, ++step) {
+      ConvLaunch p{};
+      p.H = H; p.W = W; p.n_strips = n_strips; p.ldj = ldj;
+      // ActNorm2d + permutation: cur -> oth
+      const PackedConv& m = f->mix[step];
+      p.in = cur; p.in_img = img; p.wp = blob + m.w_off; p.bias = blob + m.b_off; p.out = oth; p.out_img = img;
+      p.cin = C; p.cout = C; p.ks = 1;
+      launch_conv<EPI_STORE>(p, (int)n, s);
+      std::swap(cur, oth);
+      // coupling net on the first half
+      const std::vector<PackedConv>& net = f->net[step];
+      const float* hin = cur;
+      int64_t hin_img = img;
+      float* hb[2] = {H1, H2};
+      for (size_t q = 0; q + 1 < net.size(); ++q) {
+        const PackedConv& c = net[q];
+        p.in = hin; p.in_img = hin_img; p.wp = blob + c.w_off; p.bias = blob + c.b_off;
+        p.out = hb[q & 1]; p.out_img = (int64_t)c.cout * H * W; p.cin = c.cin; p.cout = c.cout; p.ks = c.ks;
+        launch_conv<EPI_RELU>(p, (int)n, s);
+        hin = hb[q & 1]; hin_img = p.out_img;
+      }
+      const PackedConv& c = net.back();
+      p.in = hin; p.in_img = hin_img; p.wp = blob + c.w_off; p.bias = blob + c.b_off; p.out = nullptr;
+      p.st = cur + (int64_t)c1 * H * W; p.st_img = img; p.cin = c.cin; p.cout = c.cout; p.ks = c.ks;
+      if (f->additive) launch_conv<EPI_COUPLE_ADD>(p, (int)n, s);
+      else launch_conv<EPI_COUPLE_AFFINE>(p, (int)n, s);
+    }
+    if (l < f->L - 1) {
+      ConvLaunch p{};
+      const PackedConv& c = f->split[l];
+      p.H = H; p.W = W; p.n_strips = n_strips; p.ldj = ldj;
+      p.in = cur; p.in_img = img; p.wp = blob + c.w_off; p.bias = blob + c.b_off;
+      p.st = cur + (int64_t)c1 * H * W; p.st_img = img; p.cin = c.cin; p.cout = c.cout; p.ks = c.ks;
+      launch_conv<EPI_SPLIT>(p, (int)n, s);
+      hipLaunchKernelGGL(img_squeeze_kernel, dim3((unsigned)n), dim3(256), 0, s, (const float*)cur, img, oth, c1, H, W);
+      std::swap(cur, oth);
+      C = c1 * 4; H /= 2; W /= 2;
+    }
+  }
+  hipLaunchKernelGGL(img_final_kernel, dim3((unsigned)n), dim3(256), 0, s, (const float*)cur, (int64_t)C * H * W,
+                     blob + f->prior_off, (const float*)ldj, ll, z, C, H * W);
+  const hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return fail(GBNF_ERR_HIP, "gbnf_image_flow_forward: %s", hipGetErrorString(e));
+  return GBNF_OK;
+}
+
+}  // extern "C"

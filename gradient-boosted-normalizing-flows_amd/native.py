@@ -32,6 +32,8 @@ ABI_SYMBOLS = (
     "gbnf_actnorm_init", "gbnf_boosting_weights",
     "gbnf_flow_validate", "gbnf_trainer_create", "gbnf_trainer_destroy", "gbnf_trainer_forward",
     "gbnf_trainer_grad_floats", "gbnf_trainer_workspace_bytes", "gbnf_trainer_backward",
+    "gbnf_image_flow_create", "gbnf_image_flow_destroy", "gbnf_image_flow_info", "gbnf_image_flow_workspace_bytes",
+    "gbnf_image_flow_forward", "gbnf_image_flow_prior",
 )
 
 
@@ -63,6 +65,29 @@ class _RealNVPStep(C.Structure):
 class _FlowDesc(C.Structure):
     _fields_ = [("kind", C.c_int32), ("d", C.c_int32), ("n_steps", C.c_int32), ("coupling", C.c_int32),
                 ("glow_steps", C.POINTER(_GlowStep)), ("realnvp_steps", C.POINTER(_RealNVPStep))]
+
+
+class _Conv(C.Structure):
+    _fields_ = [("weight", C.POINTER(C.c_float)), ("bias", C.POINTER(C.c_float)),
+                ("actnorm_bias", C.POINTER(C.c_float)), ("actnorm_logs", C.POINTER(C.c_float)),
+                ("logs", C.POINTER(C.c_float)),
+                ("out_channels", C.c_int32), ("in_channels", C.c_int32), ("kernel_size", C.c_int32)]
+
+
+class _ImageStep(C.Structure):
+    _fields_ = [("actnorm_bias", C.POINTER(C.c_float)), ("actnorm_logs", C.POINTER(C.c_float)),
+                ("perm_weight", C.POINTER(C.c_float)), ("perm_indices", C.POINTER(C.c_int64)),
+                ("n_convs", C.c_int32), ("convs", C.POINTER(_Conv))]
+
+
+class _ImageLevel(C.Structure):
+    _fields_ = [("n_steps", C.c_int32), ("steps", C.POINTER(_ImageStep)), ("split_prior", C.POINTER(_Conv))]
+
+
+class _ImageFlowDesc(C.Structure):
+    _fields_ = [("channels", C.c_int32), ("height", C.c_int32), ("width", C.c_int32), ("n_levels", C.c_int32),
+                ("coupling", C.c_int32), ("hidden", C.c_int32), ("bounds", C.c_float),
+                ("levels", C.POINTER(_ImageLevel)), ("learn_top", C.POINTER(_Conv))]
 
 
 class KernelInfo(C.Structure):
@@ -111,6 +136,12 @@ def lib():
     L.gbnf_trainer_grad_floats.argtypes = [vp, C.POINTER(i64)]
     L.gbnf_trainer_workspace_bytes.argtypes = [vp, i64, C.POINTER(i64)]
     L.gbnf_trainer_backward.argtypes = [vp, vp, i64, vp, vp, vp, vp, vp, i64, vp]
+    L.gbnf_image_flow_create.argtypes = [C.POINTER(_ImageFlowDesc), C.POINTER(vp)]
+    L.gbnf_image_flow_destroy.argtypes = [vp]
+    L.gbnf_image_flow_info.argtypes = [vp, C.POINTER(i32), C.POINTER(i32), C.POINTER(i32), C.POINTER(C.c_double)]
+    L.gbnf_image_flow_workspace_bytes.argtypes = [vp, i64, C.POINTER(i64)]
+    L.gbnf_image_flow_forward.argtypes = [vp, vp, vp, i64, vp, vp, vp, vp, i64, vp]
+    L.gbnf_image_flow_prior.argtypes = [vp, C.POINTER(C.c_float)]
     for name in ABI_SYMBOLS:
         if name not in ("gbnf_version", "gbnf_last_error"):
             getattr(L, name).restype = C.c_int
@@ -248,6 +279,109 @@ class NativeFlow:
     def close(self):
         if getattr(self, "handle", None):
             lib().gbnf_flow_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class NativeImageFlow:
+    """One packed image Glow component (gbnf_image_flow).  ``spec``: the image flow spec of ``synth.synth_image_glow_spec``
+    / ``spec.image_spec_from_glow_module`` (numpy arrays)."""
+
+    def __init__(self, spec):
+        keep = _Keep()
+
+        def conv(c):
+            w = np.asarray(c["w"])
+            cc = _Conv()
+            cc.weight = keep.f32(w)
+            for field, key in (("bias", "b"), ("actnorm_bias", "an_bias"), ("actnorm_logs", "an_logs"), ("logs", "logs")):
+                if c[key] is not None:
+                    setattr(cc, field, keep.f32(np.asarray(c[key]).reshape(-1)))
+            cc.out_channels, cc.in_channels, cc.kernel_size = int(w.shape[0]), int(w.shape[1]), int(w.shape[2])
+            return cc
+
+        desc = _ImageFlowDesc()
+        desc.channels, desc.height, desc.width = (int(v) for v in spec["input_size"])
+        desc.n_levels = len(spec["levels"])
+        desc.coupling = COUPLING[spec.get("coupling") or "affine"]
+        desc.hidden = int(spec["hidden"])
+        desc.bounds = float(spec.get("bounds", 0.9))
+        levels = (_ImageLevel * desc.n_levels)()
+        for l, lv in enumerate(spec["levels"]):
+            steps = (_ImageStep * len(lv["steps"]))()
+            for k, st in enumerate(lv["steps"]):
+                s_ = _ImageStep()
+                s_.actnorm_bias = keep.f32(np.asarray(st["an_bias"]).reshape(-1))
+                s_.actnorm_logs = keep.f32(np.asarray(st["an_logs"]).reshape(-1))
+                if st.get("perm_w") is not None:
+                    s_.perm_weight = keep.f32(st["perm_w"])
+                else:
+                    s_.perm_indices = keep.i64(st["perm"])
+                arr = (_Conv * len(st["convs"]))(*[conv(c) for c in st["convs"]])
+                keep.refs.append(arr)
+                s_.n_convs, s_.convs = len(st["convs"]), arr
+                steps[k] = s_
+            keep.refs.append(steps)
+            levels[l].n_steps, levels[l].steps = len(lv["steps"]), steps
+            if lv["split"] is not None:
+                sp = conv(lv["split"])
+                keep.refs.append(sp)
+                levels[l].split_prior = C.pointer(sp)
+        desc.levels = levels
+        if spec.get("learn_top") is not None:
+            top = conv(spec["learn_top"])
+            keep.refs.append(top)
+            desc.learn_top = C.pointer(top)
+        h = C.c_void_p()
+        _check(lib().gbnf_image_flow_create(C.byref(desc), C.byref(h)))
+        del keep
+        self.handle = h
+        self.input_size = tuple(int(v) for v in spec["input_size"])
+        zc, zh, zw, macs = C.c_int32(), C.c_int32(), C.c_int32(), C.c_double()
+        _check(lib().gbnf_image_flow_info(h, C.byref(zc), C.byref(zh), C.byref(zw), C.byref(macs)))
+        self.z_shape = (zc.value, zh.value, zw.value)
+        self.macs_per_image = macs.value
+        self._ws = None
+
+    def prior(self):
+        """(mean (Cz,), log-variance (Cz,)) of the top prior, numpy."""
+        buf = (C.c_float * (2 * self.z_shape[0]))()
+        _check(lib().gbnf_image_flow_prior(self.handle, buf))
+        a = np.frombuffer(buf, dtype=np.float32).copy()
+        return a[: self.z_shape[0]], a[self.z_shape[0]:]
+
+    def forward(self, x, noise=None, want_z=True):
+        """x (n,C,H,W) in [0,1] (+ dequantisation noise) -> (z | None, ldj (n,), ll (n,)); current stream."""
+        import torch
+        _require_device_f32(x, "x")
+        if x.dim() != 4 or tuple(x.shape[1:]) != self.input_size:
+            raise GbnfError(f"x must be (n,{self.input_size}), got {tuple(x.shape)}")
+        if noise is not None:
+            _require_device_f32(noise, "noise")
+            if noise.shape != x.shape:
+                raise GbnfError("noise must have the shape of x")
+        n = x.shape[0]
+        z = torch.empty((n,) + self.z_shape, dtype=torch.float32, device=x.device) if want_z else None
+        ldj = torch.empty(n, dtype=torch.float32, device=x.device)
+        ll = torch.empty(n, dtype=torch.float32, device=x.device)
+        if n:
+            nb = C.c_int64()
+            _check(lib().gbnf_image_flow_workspace_bytes(self.handle, n, C.byref(nb)))
+            if self._ws is None or self._ws.numel() * 4 < nb.value or self._ws.device != x.device:
+                self._ws = torch.empty((nb.value + 3) // 4, dtype=torch.float32, device=x.device)
+            ptr = lambda t: C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
+            _check(lib().gbnf_image_flow_forward(self.handle, ptr(x), ptr(noise), n, ptr(z), ptr(ldj), ptr(ll),
+                                                 ptr(self._ws), self._ws.numel() * 4, _stream_ptr()))
+        return z, ldj, ll
+
+    def close(self):
+        if getattr(self, "handle", None):
+            lib().gbnf_image_flow_destroy(self.handle)
             self.handle = None
 
     def __del__(self):

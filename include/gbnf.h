@@ -230,6 +230,65 @@ int gbnf_trainer_workspace_bytes(const gbnf_trainer* trainer, int64_t n, int64_t
 int gbnf_trainer_backward(const gbnf_trainer* trainer, const float* x, int64_t n, const float* g_z, const float* g_ldj,
                           float* g_x, float* grads, void* workspace, int64_t workspace_bytes, void* stream);
 
+/* ---------------------------------------------------------------------------------------------------------------
+ * Image components (BASELINE.json configs[3]): density evaluation of one multi-scale image
+ * Glow, models/glow.py:92-110 with the image branches of FlowNet / FlowStep (:192-252, :317-342).  All arrays are HOST
+ * pointers read at creation (the handle is immutable, like gbnf_flow).
+ * --------------------------------------------------------------------------------------------------------------- */
+/* Conv2d (+ its ActNorm2d) or Conv2dZeros, models/layers.py:577-630: stride 1, 'same' zero padding. */
+typedef struct gbnf_conv {
+  const float* weight;        /* (out, in, k, k) = nn.Conv2d.weight                                      */
+  const float* bias;          /* (out,) or NULL (a Conv2d followed by ActNorm2d has none)                 */
+  const float* actnorm_bias;  /* (out,) ActNorm2d.bias after the convolution, or NULL                     */
+  const float* actnorm_logs;  /* (out,)                                                                   */
+  const float* logs;          /* (out,) Conv2dZeros.logs (output scale exp(3 logs)), or NULL              */
+  int32_t out_channels, in_channels, kernel_size;
+} gbnf_conv;
+
+/* One image FlowStep: ActNorm2d -> InvertibleConv1x1 | Permute2d -> ConvNet coupling. */
+typedef struct gbnf_image_step {
+  const float* actnorm_bias;    /* (C,) */
+  const float* actnorm_logs;    /* (C,) */
+  const float* perm_weight;     /* (C,C) the matrix InvertibleConv1x1.get_weight returns (models/layers.py:751-776,
+                                   either parameterisation), or NULL for a channel permutation */
+  const int64_t* perm_indices;  /* (C,) Permute2d.indices when perm_weight is NULL */
+  int32_t n_convs;              /* coupling_network_depth + 2: 3x3 (+ActNorm2d), 1x1 (+ActNorm2d) x depth, Conv2dZeros 3x3 */
+  const gbnf_conv* convs;
+} gbnf_image_step;
+
+typedef struct gbnf_image_level {   /* SqueezeLayer(2), n_steps FlowSteps, Split2d (all levels but the last) */
+  int32_t n_steps;
+  const gbnf_image_step* steps;
+  const gbnf_conv* split_prior;     /* Split2d.conv (Conv2dZeros C/2 -> C), NULL on the last level */
+} gbnf_image_level;
+
+typedef struct gbnf_image_flow_desc {
+  int32_t channels, height, width;  /* input_size, e.g. 3, 32, 32 */
+  int32_t n_levels;                 /* L = num_blocks */
+  int32_t coupling;                 /* GBNF_COUPLING_* */
+  int32_t hidden;                   /* h_size (width of the coupling ConvNets) */
+  float bounds;                     /* Glow.bounds, models/glow.py:50 (0.9) */
+  const gbnf_image_level* levels;
+  const gbnf_conv* learn_top;       /* Glow.learn_top_fn (Conv2dZeros 2Cz -> 2Cz) or NULL: zero-mean unit-variance prior */
+} gbnf_image_flow_desc;
+
+typedef struct gbnf_image_flow gbnf_image_flow;
+
+int gbnf_image_flow_create(const gbnf_image_flow_desc* desc, gbnf_image_flow** out);
+int gbnf_image_flow_destroy(gbnf_image_flow* flow);
+/* Shape of z (per image) and the algorithmic multiply-adds per image; any pointer may be NULL. */
+int gbnf_image_flow_info(const gbnf_image_flow* flow, int32_t* z_channels, int32_t* z_height, int32_t* z_width,
+                         double* macs_per_image);
+int gbnf_image_flow_workspace_bytes(const gbnf_image_flow* flow, int64_t n, int64_t* bytes);
+/* Replaces: z, z_mu, z_var, logdet, _ = self.flows[c](x) for image input (models/glow.py:92-110) and
+ * ll = log_normal_diag(z, z_mu, z_var) + logdet (image_experiment.py:227).  x (n,C,H,W) in [0,1]; noise (n,C,H,W) is the
+ * U(0,1) dequantisation noise of models/glow.py:135 (NULL = none); z (n,Cz,Hz,Wz) and ll (n,) may be NULL; ldj (n,) is
+ * required (it is also the accumulator).  z_mu / z_var are per-channel constants: gbnf_image_flow_prior. */
+int gbnf_image_flow_forward(const gbnf_image_flow* flow, const float* x, const float* noise, int64_t n, float* z,
+                            float* ldj, float* ll, void* workspace, int64_t workspace_bytes, void* stream);
+/* The top prior per channel: mean (Cz,) then log-variance (Cz,) into a HOST buffer of 2 Cz floats. */
+int gbnf_image_flow_prior(const gbnf_image_flow* flow, float* mean_logvar_host);
+
 #ifdef __cplusplus
 }
 #endif

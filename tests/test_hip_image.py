@@ -1,0 +1,66 @@
+"""GPU: the image path (gbnf_image_flow_*, SURVEY.md section 8a a14 / BASELINE.json configs[3]) against the reference's own
+image Glow outputs (fixtures g12_*) and the oracle.  Tolerance: 1e-5 relative on the log-likelihood (north star)."""
+import numpy as np
+import pytest
+
+from conftest import IMAGE_CASES, load_image_case, rel_err
+
+pytestmark = pytest.mark.gpu
+LL_RTOL = 1e-5
+
+
+@pytest.mark.parametrize("name", IMAGE_CASES)
+def test_image_flow_matches_reference(name):
+    import torch
+    from gbnf_amd import native
+    cfg, specs, x, noise, data = load_image_case(name)
+    dev = torch.device("cuda:0")
+    xd, nd = torch.from_numpy(x).to(dev), torch.from_numpy(noise).to(dev)
+    lls = []
+    for c, sp in enumerate(specs):
+        flow = native.NativeImageFlow(sp)
+        z, ldj, ll = flow.forward(xd, nd)
+        assert rel_err(ldj.cpu().numpy(), data["ldj"][c]) < LL_RTOL
+        assert rel_err(ll.cpu().numpy(), data["ll"][c]) < LL_RTOL
+        zr = data["z"][c]
+        assert np.abs(z.cpu().numpy() - zr).max() <= 2e-4 * max(1.0, float(np.abs(zr).max()))
+        lls.append(ll)
+    G = native.mixture_lse(torch.stack(lls), torch.from_numpy(data["rho"]).to(dev))
+    assert rel_err(G.cpu().numpy(), data["G"]) < LL_RTOL
+
+
+def test_image_flow_full_width_matches_oracle():
+    """BASELINE.json configs[3] geometry: 3x32x32, L = 2, h = 256 (K reduced to 2 to keep the CPU oracle quick)."""
+    import torch
+    from gbnf_amd import native, synth
+    from oracle import gbnf_oracle as oracle
+    sp = synth.synth_image_glow_spec((3, 32, 32), h=256, K=2, L=2, seed=5)
+    x, noise = synth.synth_image_batch(6, seed=9)
+    z64, _, _, ld64, ll64 = oracle.image_component_forward(sp, x, noise, dtype=torch.float64)
+    dev = torch.device("cuda:0")
+    flow = native.NativeImageFlow(sp)
+    z, ldj, ll = flow.forward(torch.from_numpy(x).to(dev), torch.from_numpy(noise).to(dev))
+    assert rel_err(ll.cpu().numpy(), ll64) < LL_RTOL
+    assert rel_err(ldj.cpu().numpy(), ld64) < LL_RTOL
+    assert np.abs(z.cpu().numpy() - z64).max() <= 2e-4 * max(1.0, float(np.abs(z64).max()))
+    # no noise, odd batch, no z
+    _, ldj1, ll1 = flow.forward(torch.from_numpy(x[:1]).to(dev), None, want_z=False)
+    _, _, _, _, ll1_ref = oracle.image_component_forward(sp, x[:1], np.zeros_like(x[:1]), dtype=torch.float64)
+    assert rel_err(ll1.cpu().numpy(), ll1_ref) < LL_RTOL
+    mu, lv = flow.prior()
+    assert mu.shape == (24,) and lv.shape == (24,)
+
+
+def test_image_flow_argument_validation():
+    import torch
+    from gbnf_amd import native, synth
+    sp = synth.synth_image_glow_spec((3, 32, 32), h=16, K=1, L=2, seed=1)
+    flow = native.NativeImageFlow(sp)
+    with pytest.raises(native.GbnfError):
+        flow.forward(torch.zeros(2, 3, 32, 32))                    # CPU tensor: no CPU path
+    with pytest.raises(native.GbnfError):
+        flow.forward(torch.zeros(2, 3, 16, 16, device="cuda"))
+    bad = synth.synth_image_glow_spec((3, 64, 64), h=16, K=1, L=1, seed=1)
+    with pytest.raises(native.GbnfError):                          # 32-wide maps are not compiled
+        native.NativeImageFlow(bad)
+    assert native.lib().gbnf_image_flow_forward(None, None, None, 1, None, None, None, None, 0, None) == -1
