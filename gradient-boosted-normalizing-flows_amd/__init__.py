@@ -19,7 +19,7 @@ def __getattr__(name):
     # lazy so that ``import gbnf_amd`` works on a box where torch / the .so are absent;
     # anything that computes fails loudly inside ``native``.
     import importlib
-    if name in ("native", "boosted_flow", "sharded", "checkpoint"):
+    if name in ("native", "boosted_flow", "sharded", "checkpoint", "image_glow"):
         return importlib.import_module(__name__ + "." + name)
     if name == "BoostedFlow":
         return importlib.import_module(__name__ + ".boosted_flow").BoostedFlow

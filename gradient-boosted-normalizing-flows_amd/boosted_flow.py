@@ -249,6 +249,13 @@ class _FlowFunction(torch.autograd.Function):
 class BoostedFlow(nn.Module):
     """Drop-in for models/boosted_flow.py:BoostedFlow on the density-evaluation path."""
 
+    def __new__(cls, args=None, *a, **k):
+        # image components (len(input_size) > 1, BASELINE.json configs[3]) live in image_glow.BoostedImageFlow
+        if cls is BoostedFlow and args is not None and len(getattr(args, "input_size", [0])) > 1:
+            from .image_glow import BoostedImageFlow
+            return BoostedImageFlow(args)
+        return super().__new__(cls)
+
     def __init__(self, args):
         super().__init__()
         self.args = args

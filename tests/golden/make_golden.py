@@ -234,6 +234,16 @@ def state_dict_layout_case():
         m = RefBoostedFlow(ref_args(base, 7, 12, 3, 2, **kw))
         out[kind] = {k: list(v.shape) for k, v in m.state_dict().items()}
         out[kind + "::named_parameters"] = [n for n, _ in m.named_parameters()]
+    for kind, kw in (("image_invconv", dict(permutation="invconv", LU=False, learn_top=True)),
+                     ("image_lu", dict(permutation="invconv", LU=True, learn_top=True)),
+                     ("image_shuffle_additive", dict(permutation="shuffle", LU=False, learn_top=False, coupling="additive",
+                                                     depth=2))):
+        a = ref_args("glow", 3 * 32 * 32, 8, 2, 2, depth=kw.get("depth", 1), coupling=kw.get("coupling", "affine"),
+                     permutation=kw["permutation"])
+        a.input_size = [3, 32, 32]; a.num_blocks = 2; a.learn_top = kw["learn_top"]; a.LU_decomposed = kw["LU"]
+        m = RefBoostedFlow(a)
+        out[kind] = {k: list(v.shape) for k, v in m.state_dict().items()}
+        out[kind + "::named_parameters"] = [n for n, _ in m.named_parameters()]
     with open(os.path.join(HERE, "state_dict_layout.json"), "w") as f:
         json.dump(out, f, indent=1, sort_keys=True)
     print("state_dict_layout.json:", {k: len(v) for k, v in out.items()})

@@ -64,3 +64,32 @@ def test_image_flow_argument_validation():
     with pytest.raises(native.GbnfError):                          # 32-wide maps are not compiled
         native.NativeImageFlow(bad)
     assert native.lib().gbnf_image_flow_forward(None, None, None, 1, None, None, None, None, 0, None) == -1
+
+
+def test_image_module_dropin_matches_reference():
+    """BoostedFlow(args) with image input_size: model(x=x, components=c) and log_prob against the reference's outputs
+    (fixture g12, noise injected) -- the drop-in module end to end."""
+    import argparse
+    import torch
+    from gbnf_amd import BoostedFlow, image_glow
+    cfg, specs, x, noise, data = load_image_case("g12_image_glow_invconv_affine")
+    dev = torch.device("cuda:0")
+    args = argparse.Namespace(
+        num_flows=cfg["K"], z_size=3072, density_evaluation=True, device=dev, cuda=True, component_type="glow",
+        num_components=cfg["C"], rho_init="decreasing", learn_top=cfg["learn_top"], y_classes=0, y_condition=False,
+        sample_size=4, input_size=[3, 32, 32], h_size=cfg["h"], num_blocks=cfg["L"], actnorm_scale=1.0,
+        flow_permutation=cfg["permutation"], flow_coupling=cfg["coupling"], LU_decomposed=False, num_dequant_blocks=0,
+        coupling_network="tanh", coupling_network_depth=cfg["depth"], batch_norm=False)
+    m = BoostedFlow(args)
+    assert isinstance(m, image_glow.BoostedImageFlow)
+    for c, sp in enumerate(specs):
+        image_glow.load_image_spec(m.flows[c], sp)
+    m.eval()
+    xd, nd = torch.from_numpy(x).to(dev), torch.from_numpy(noise).to(dev)
+    with torch.no_grad():
+        ll = m.component_log_prob(xd, noise=nd)
+        assert rel_err(ll.cpu().numpy().T, data["ll"]) < LL_RTOL
+        assert rel_err(m.log_prob(xd, noise=nd).cpu().numpy(), data["G"]) < LL_RTOL
+        z, z_mu, z_var, ldj, y = m(x=xd, components=1)              # fresh noise: shapes and the constant prior only
+        assert y is None and z.shape == (cfg["N"], 24, 8, 8) and z_mu.shape == z.shape and z_var.shape == z.shape
+        assert torch.isfinite(ldj).all()

@@ -223,3 +223,49 @@ def test_checkpoint_round_trip_keeps_permutations(tmp_path):
     args.boosted, args.loaded_init_component, args.loaded_all_trained, args.loaded_num_components = True, 0, False, None
     checkpoint.load(m2, None, path, args, init_with_args=True)
     assert m2.component == 0 and m2.all_trained is False
+
+
+# ------------------------------------------------------------------ image components (BASELINE.json configs[3])
+def _image_args(permutation="invconv", LU=False, learn_top=True, coupling="affine", depth=1, h=8, K=2, L=2, C=2,
+                device=torch.device("cpu")):
+    a = make_args(kind="glow", d=3 * 32 * 32, h=h, K=K, C=C, depth=depth, coupling=coupling, permutation=permutation)
+    a.input_size = [3, 32, 32]; a.num_blocks = L; a.learn_top = learn_top; a.LU_decomposed = LU; a.device = device
+    return a
+
+
+@pytest.mark.parametrize("case,kw", [("image_invconv", dict(permutation="invconv", LU=False, learn_top=True)),
+                                     ("image_lu", dict(permutation="invconv", LU=True, learn_top=True)),
+                                     ("image_shuffle_additive", dict(permutation="shuffle", learn_top=False,
+                                                                     coupling="additive", depth=2))])
+def test_image_state_dict_layout_matches_reference(case, kw):
+    """BoostedFlow(args) with a 3-d input_size builds the image mirror with the reference's parameter names/shapes."""
+    from gbnf_amd import image_glow
+    m = BoostedFlow(_image_args(**kw))
+    assert isinstance(m, image_glow.BoostedImageFlow)
+    got = {k: list(v.shape) for k, v in m.state_dict().items()}
+    assert got == LAYOUT[case]
+    assert [n for n, _ in m.named_parameters()] == LAYOUT[case + "::named_parameters"]
+
+
+def test_image_spec_export_round_trips_synthetic_parameters():
+    """Install a synthetic image spec into the mirror module by module and export it again."""
+    from gbnf_amd import image_glow, synth
+    sp = synth.synth_image_glow_spec((3, 32, 32), h=8, K=2, L=2, seed=3)
+    m = BoostedFlow(_image_args(h=8, K=2, L=2, C=1))
+    g = m.flows[0]
+    with pytest.raises(ValueError):                 # ActNorm not initialised
+        image_glow.image_spec_from_glow_module(g)
+    image_glow.load_image_spec(g, sp)
+    out = image_glow.image_spec_from_glow_module(g)
+    for lv_a, lv_b in zip(sp["levels"], out["levels"]):
+        for a, b in zip(lv_a["steps"], lv_b["steps"]):
+            np.testing.assert_allclose(a["perm_w"], b["perm_w"], rtol=0, atol=1e-7)
+            np.testing.assert_array_equal(a["an_logs"], b["an_logs"])
+            for ca, cb in zip(a["convs"], b["convs"]):
+                np.testing.assert_array_equal(ca["w"], cb["w"])
+                assert (ca["logs"] is None) == (cb["logs"] is None)
+        assert (lv_a["split"] is None) == (lv_b["split"] is None)
+    np.testing.assert_array_equal(sp["learn_top"]["b"], out["learn_top"]["b"])
+    with pytest.raises(native.GbnfError):           # CPU tensor: no CPU path
+        m.eval()
+        m(x=torch.zeros(2, 3, 32, 32), components=0)
