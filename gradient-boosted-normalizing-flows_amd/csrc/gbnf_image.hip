@@ -66,8 +66,9 @@ __device__ __forceinline__ void img_drain(f32x4 (&c)[N]) {
   for (int k = 0; k < N; ++k) asm volatile("s_nop 7\n\ts_nop 7" : "+a"(c[k]));
 }
 
-// EPI: see enum.  PT: pixel tiles per strip (2 or 4).
-template <int EPI, int PT>
+// EPI: see enum.  PT: pixel tiles per strip (2 or 4).  KS: 1 or 3 (a 1x1 convolution stages no halo: half the LDS,
+// two workgroups per CU).
+template <int EPI, int PT, int KS>
 __global__ void __launch_bounds__(64 * IMG_WAVES) img_conv_kernel(const ConvLaunch p) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   typedef const float __attribute__((address_space(1)))* gptr;
@@ -75,22 +76,28 @@ __global__ void __launch_bounds__(64 * IMG_WAVES) img_conv_kernel(const ConvLaun
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int n = blockIdx.x / p.n_strips, strip = blockIdx.x % p.n_strips;
   constexpr int W = 16 * PT / IMG_R;                        // the strip is IMG_R full rows: W = 16 (PT = 4) or 8 (PT = 2)
-  constexpr int WP = W + 2, CS = (IMG_R + 2) * WP;          // padded row / channel stride in LDS
+  constexpr int HALO = KS >> 1;
+  constexpr int WP = W + 2 * HALO, RP = IMG_R + 2 * HALO, CS = RP * WP;   // padded row / rows / channel stride in LDS
   const int H = p.H, r0 = strip * IMG_R;
   const int kc = (p.cin + 15) >> 4, cin_pad = kc * 16;
-  const int taps = p.ks * p.ks, half = p.ks >> 1;
+  constexpr int taps = KS * KS, half = HALO;
   const int OT = (p.cout + 15) >> 4;
 
-  // ---- stage the strip (+ halo, zero padded) of every input channel
+  // ---- stage the strip (+ halo, zero padded) of every input channel: one image row = W/4 16-byte loads
   {
     const float* src = p.in + (int64_t)n * p.in_img;
-    const int per_ch = (IMG_R + 2) * WP;
-    for (int e = threadIdx.x; e < cin_pad * per_ch; e += 64 * IMG_WAVES) {
-      const int ci = e / per_ch, rem = e % per_ch, rr = rem / WP, cc = rem % WP;
-      const int row = r0 + rr - 1, col = cc - 1;
-      float v = 0.0f;
-      if (ci < p.cin && row >= 0 && row < H && col >= 0 && col < W) v = src[((int64_t)ci * H + row) * W + col];
-      lds[e] = v;
+    constexpr int Q = W / 4;                                 // float4s per image row
+    const int q = threadIdx.x % Q, rid = threadIdx.x / Q;
+    constexpr int ROWS_PER_PASS = 64 * IMG_WAVES / Q;
+    for (int idx = rid; idx < cin_pad * RP; idx += ROWS_PER_PASS) {
+      const int ci = idx / RP, rr = idx - ci * RP;
+      const int row = r0 + rr - HALO;
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (ci < p.cin && row >= 0 && row < H) v = *reinterpret_cast<const f32x4*>(src + ((int64_t)ci * H + row) * W + 4 * q);
+      float* dst = lds + ci * CS + rr * WP + HALO + 4 * q;
+      dst[0] = v[0]; dst[1] = v[1]; dst[2] = v[2]; dst[3] = v[3];
+      if (HALO && q == 0) dst[-1] = 0.0f;                    // left / right zero columns
+      if (HALO && q == Q - 1) dst[4] = 0.0f;
     }
   }
   __syncthreads();
@@ -100,7 +107,7 @@ __global__ void __launch_bounds__(64 * IMG_WAVES) img_conv_kernel(const ConvLaun
 #pragma unroll
   for (int pt = 0; pt < PT; ++pt) {
     const int lin = 16 * pt + i, pr = lin / W, pc = lin % W;
-    boff[pt] = (4 * g) * CS + (pr + 1) * WP + pc + 1;
+    boff[pt] = (4 * g) * CS + (pr + HALO) * WP + pc + HALO;
   }
 
   const bool splitk = OT < IMG_WAVES;                        // few output tiles: the waves split the contraction instead
@@ -121,7 +128,7 @@ __global__ void __launch_bounds__(64 * IMG_WAVES) img_conv_kernel(const ConvLaun
     }
     auto body = [&](const f32x4& a, int t) {
       const int tap = t / kc, c = t - tap * kc;
-      const int dy = tap / p.ks - half, dx = tap % p.ks - half;
+      const int dy = tap / KS - half, dx = tap % KS - half;
       const float* b0 = lds + (16 * c) * CS + dy * WP + dx;
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
@@ -419,18 +426,26 @@ PackedConv pack_conv(Packer& P, const gbnf_conv& c) {
 
 template <int EPI>
 void launch_conv(const ConvLaunch& p, int n, hipStream_t s) {
-  const int per_ch = (IMG_R + 2) * (p.W + 2);
+  const int halo = p.ks >> 1;
+  const int per_ch = (IMG_R + 2 * halo) * (p.W + 2 * halo);
   const int kc = (p.cin + 15) / 16, OT = (p.cout + 15) / 16, PT = IMG_R * p.W / 16;
   size_t lds = (size_t)kc * 16 * per_ch * 4;
   if (OT < IMG_WAVES) lds = std::max(lds, (size_t)IMG_WAVES * (IMG_WAVES - 1) * PT * 64 * 16);
-  const dim3 grid((unsigned)(n * p.n_strips));
-  if (PT == 4) hipLaunchKernelGGL((img_conv_kernel<EPI, 4>), grid, dim3(64 * IMG_WAVES), lds, s, p);
-  else hipLaunchKernelGGL((img_conv_kernel<EPI, 2>), grid, dim3(64 * IMG_WAVES), lds, s, p);
+  const dim3 grid((unsigned)(n * p.n_strips)), blk(64 * IMG_WAVES);
+  if (PT == 4 && p.ks == 3) hipLaunchKernelGGL((img_conv_kernel<EPI, 4, 3>), grid, blk, lds, s, p);
+  else if (PT == 4) hipLaunchKernelGGL((img_conv_kernel<EPI, 4, 1>), grid, blk, lds, s, p);
+  else if (p.ks == 3) hipLaunchKernelGGL((img_conv_kernel<EPI, 2, 3>), grid, blk, lds, s, p);
+  else hipLaunchKernelGGL((img_conv_kernel<EPI, 2, 1>), grid, blk, lds, s, p);
 }
 
-template <int EPI, int PT>
+template <int EPI>
 hipError_t allow_lds() {
-  return hipFuncSetAttribute((const void*)img_conv_kernel<EPI, PT>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  hipError_t e = hipSuccess;
+  const void* fns[4] = {(const void*)img_conv_kernel<EPI, 4, 3>, (const void*)img_conv_kernel<EPI, 4, 1>,
+                        (const void*)img_conv_kernel<EPI, 2, 3>, (const void*)img_conv_kernel<EPI, 2, 1>};
+  for (int k = 0; k < 4 && e == hipSuccess; ++k)
+    e = hipFuncSetAttribute(fns[k], hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  return e;
 }
 
 }  // namespace
@@ -544,16 +559,11 @@ int gbnf_image_flow_create(const gbnf_image_flow_desc* d, gbnf_image_flow** out)
     f->ld_const = ld_const;
     hipError_t e = hipMalloc((void**)&f->blob_dev, P.blob.size() * 4);
     if (e == hipSuccess) e = hipMemcpy(f->blob_dev, P.blob.data(), P.blob.size() * 4, hipMemcpyHostToDevice);
-    if (e == hipSuccess) e = allow_lds<EPI_RELU, 4>();
-    if (e == hipSuccess) e = allow_lds<EPI_RELU, 2>();
-    if (e == hipSuccess) e = allow_lds<EPI_STORE, 4>();
-    if (e == hipSuccess) e = allow_lds<EPI_STORE, 2>();
-    if (e == hipSuccess) e = allow_lds<EPI_COUPLE_AFFINE, 4>();
-    if (e == hipSuccess) e = allow_lds<EPI_COUPLE_AFFINE, 2>();
-    if (e == hipSuccess) e = allow_lds<EPI_COUPLE_ADD, 4>();
-    if (e == hipSuccess) e = allow_lds<EPI_COUPLE_ADD, 2>();
-    if (e == hipSuccess) e = allow_lds<EPI_SPLIT, 4>();
-    if (e == hipSuccess) e = allow_lds<EPI_SPLIT, 2>();
+    if (e == hipSuccess) e = allow_lds<EPI_RELU>();
+    if (e == hipSuccess) e = allow_lds<EPI_STORE>();
+    if (e == hipSuccess) e = allow_lds<EPI_COUPLE_AFFINE>();
+    if (e == hipSuccess) e = allow_lds<EPI_COUPLE_ADD>();
+    if (e == hipSuccess) e = allow_lds<EPI_SPLIT>();
     if (e != hipSuccess) rc = fail(GBNF_ERR_HIP, "gbnf_image_flow_create: %s", hipGetErrorString(e));
   }
   if (rc != GBNF_OK) {

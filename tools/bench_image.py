@@ -1,0 +1,94 @@
+#!/usr/bin/env python3
+"""BASELINE.json configs[3]: CIFAR-10 3x32x32 multi-scale Boosted-Glow C=4 (K=8 steps per level, L=2 levels, h=256,
+invconv, affine, learned top prior), density evaluation of a batch of synthetic images already resident in HBM:
+all C components + the mixture log-sum-exp -> G (N,).  Prints one JSON line (same fields as bench.py).
+
+    python tools/bench_image.py [--batch 64 --components 4 --K 8 --hidden 256 --steps 20 --warmup 3 --cpu-seconds 15]
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+import numpy as np
+import torch
+
+F32_MFMA_PEAK_TFLOPS = 157.3
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--batch", type=int, default=64)
+    ap.add_argument("--components", type=int, default=4)
+    ap.add_argument("--K", type=int, default=8)
+    ap.add_argument("--L", type=int, default=2)
+    ap.add_argument("--hidden", type=int, default=256)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--cpu-seconds", type=float, default=15.0)
+    a = ap.parse_args()
+    from gbnf_amd import native, synth
+    from oracle import gbnf_oracle as oracle
+    dev = torch.device("cuda:0")
+    specs = [synth.synth_image_glow_spec((3, 32, 32), a.hidden, a.K, a.L, seed=100 + c) for c in range(a.components)]
+    flows = [native.NativeImageFlow(sp) for sp in specs]
+    x_np, noise_np = synth.synth_image_batch(a.batch, seed=0)
+    x, noise = torch.from_numpy(x_np).to(dev), torch.from_numpy(noise_np).to(dev)
+    rho = torch.clamp(1.0 / torch.pow(2.0, torch.arange(a.components * 1.0)), min=0.05).to(dev)
+    ll = torch.empty((a.components, a.batch), dtype=torch.float32, device=dev)
+
+    def step():
+        for c, f in enumerate(flows):
+            ll[c] = f.forward(x, noise, want_z=False)[2]
+        return native.mixture_lse(ll, rho)
+
+    for _ in range(a.warmup):
+        G = step()
+    torch.cuda.synchronize()
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t0 = time.perf_counter()
+    ev0.record()
+    for _ in range(a.steps):
+        G = step()
+    ev1.record()
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / a.steps
+    gpu_ms = ev0.elapsed_time(ev1) / a.steps
+    flops = 2.0 * sum(f.macs_per_image for f in flows) * a.batch
+    # CPU baseline: the oracle (torch CPU, reference op order) on a bounded sample of the same images
+    torch.set_num_threads(min(8, os.cpu_count() or 1))
+    ns = min(a.batch, 4)
+    with torch.no_grad():
+        oracle.image_component_forward(specs[0], x_np[:1], noise_np[:1])
+        t0 = time.perf_counter()
+        passes = 0
+        G_cpu = None
+        while True:
+            lls = [oracle.image_component_forward(sp, x_np[:ns], noise_np[:ns])[4] for sp in specs]
+            G_cpu = oracle.mixture_recursion(np.stack(lls), rho.cpu().numpy())
+            passes += 1
+            if time.perf_counter() - t0 > a.cpu_seconds:
+                break
+        cpu_dt = (time.perf_counter() - t0) / passes
+    err = float(np.abs(G.cpu().numpy()[:ns] - G_cpu).max() / np.abs(G_cpu).max())
+    print(json.dumps({
+        "metric": "density-eval images/sec, CIFAR-10 3x32x32 multi-scale Boosted-Glow", "value": a.batch / dt, "unit": "images/s",
+        "n_gpus": 1, "steps": a.steps, "warmup": a.warmup, "ms_per_step": dt * 1e3, "higher_is_better": True,
+        "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": f"cifar_glow: 3x32x32, C={a.components} components, K={a.K} steps x L={a.L} levels, h={a.hidden}, "
+                               f"invconv, affine, learn_top, batch={a.batch}, synthetic images + weights"},
+        "roofline": {"kernel": "gbnf::img_conv_kernel (all convolutions)", "bound": "mfma", "achieved": flops / (gpu_ms * 1e-3) / 1e12,
+                     "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": flops / (gpu_ms * 1e-3) / 1e12 / F32_MFMA_PEAK_TFLOPS,
+                     "traffic": None, "gpu_ms_per_step": gpu_ms, "flops_per_step": flops},
+        "cpu_baseline": {"value": ns / cpu_dt, "unit": "images/s", "cores": torch.get_num_threads(), "kind": "port",
+                         "sample": f"{passes} pass(es) over {ns} of the {a.batch} images, all {a.components} components + recursion, "
+                                   f"torch-CPU oracle in the reference's op order"},
+        "speedup_vs_cpu": (a.batch / dt) / (ns / cpu_dt), "max_rel_err_vs_cpu": err}))
+
+
+if __name__ == "__main__":
+    main()
