@@ -53,6 +53,7 @@ def cpu_baseline(specs, rho, x_np, budget_s):
     cands = [t for t in (1, 4, 8, 16, 32, 64) if t <= host_cores] or [1]
     probe_x = x_np[: min(512, x_np.shape[0])]
     best_t, best_dt = cands[0], None
+    one_thread = None
     with torch.no_grad():
         for t in cands:
             torch.set_num_threads(t)
@@ -60,6 +61,8 @@ def cpu_baseline(specs, rho, x_np, budget_s):
             t0 = time.perf_counter()
             oracle.component_log_prob(specs[0], probe_x)
             dt = time.perf_counter() - t0
+            if t == 1:      # the reference scripts' own default is one worker: record that figure too (probe-sized sample)
+                one_thread = probe_x.shape[0] / (dt * len(specs))
             if best_dt is None or dt < best_dt:
                 best_t, best_dt = t, dt
             if dt > 2.0:
@@ -81,7 +84,7 @@ def cpu_baseline(specs, rho, x_np, budget_s):
                 break
     return {
         "value": n * passes / el, "unit": "samples/s", "cores": best_t, "kind": "port",
-        "host_cores": host_cores,
+        "host_cores": host_cores, "one_thread_value": one_thread,
         "sample": f"{passes} pass(es) over {n} of the {x_np.shape[0]} rows, all {len(specs)} components + mixture "
                   f"recursion, torch-CPU oracle in the reference's op order, {best_t} threads "
                   f"(fastest of {cands}), {el:.1f} s",

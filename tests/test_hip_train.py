@@ -192,3 +192,64 @@ def test_trainer_argument_validation():
         native.NativeTrainer({"kind": "glow", "d": 4, "coupling": "affine", "steps": [
             {"an_bias": torch.zeros(4), "an_logs": torch.zeros(4), "perm": np.arange(4),
              "net": {"act": "tanh", "layers": [(torch.zeros(8, 2), torch.zeros(8)), (torch.zeros(4, 8), torch.zeros(4))]}}]})
+
+
+def test_boosted_training_loop_like_the_reference():
+    """The reference's boosted training step (compute_kl_pq_loss, density_experiment.py:606-660) on the device path, both
+    ways: the reference's own statement sequence through model(x=, components=) and the fused shortcuts
+    (boosting_weights + one recorded forward).  Component 0 is trained first, then component 1 on re-weighted samples;
+    the mixture's NLL on fresh data must improve over component 0 alone."""
+    import math
+    import torch
+    from gbnf_amd import BoostedFlow
+    dev = torch.device("cuda:0")
+    torch.manual_seed(1)
+    d = 6
+    m = BoostedFlow(_args("glow", d, 32, 3, 2, dev)).to(dev)
+
+    def sample(n):          # two well separated blobs: one component cannot fit both equally well
+        a = torch.randn(n, d, device=dev) * 0.5 + 2.0
+        b = torch.randn(n, d, device=dev) * 0.8 - 1.5
+        return torch.where(torch.rand(n, 1, device=dev) < 0.5, a, b)
+
+    def lns(z):             # log_normal_standard(z, reduce=True, dim=-1)
+        return torch.sum(-0.5 * math.log(2 * math.pi) - 0.5 * z.pow(2), dim=-1)
+
+    m.train()
+    opt = torch.optim.Adam(m.flows[0].parameters(), lr=3e-3)
+    for _ in range(60):     # first component: trained like a non-boosted model (:655-659)
+        x = sample(512)
+        opt.zero_grad()
+        z, _, _, ldj, _ = m(x=x, components="c")
+        loss = torch.mean(-(lns(z) + ldj))
+        loss.backward()
+        opt.step()
+    m.increment_component()
+    assert m.component == 1
+    opt = torch.optim.Adam(m.flows[1].parameters(), lr=3e-3)
+    for it in range(60):
+        x = sample(512)
+        opt.zero_grad()
+        if it % 2 == 0:     # the reference's statements (:612-651)
+            with torch.no_grad():
+                z_G, _, _, ldj_G, _ = m(x=x, components=0)
+                G_nll = -1.0 * (lns(z_G) + ldj_G)
+                w = torch.softmax(G_nll, dim=0)
+                if w.max() > 0.1:
+                    w = torch.max(torch.min(w, torch.tensor([0.1], device=dev)), torch.tensor([0.01], device=dev))
+                w = w / w.sum()
+        else:               # the fused form of the same two steps
+            with torch.no_grad():
+                w, _ = m.boosting_weights(x)
+        xr = x[torch.multinomial(w, x.size(0), replacement=True)]
+        z_g, _, _, ldj_g, _ = m(x=xr, components="c")
+        loss = torch.mean(-(lns(z_g) + ldj_g))
+        loss.backward()
+        opt.step()
+    m.eval()
+    with torch.no_grad():
+        xt = sample(4096)
+        nll_first = -m.log_prob(xt, n_used=1).mean().item()
+        m.rho[1] = 0.5
+        nll_mix = -m.log_prob(xt, n_used=2).mean().item()
+    assert math.isfinite(nll_mix) and nll_mix < nll_first + 0.05, (nll_first, nll_mix)
