@@ -228,8 +228,9 @@ class _FlowFunction(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, trainer, x, *params):
-        z, ldj = trainer.forward(x)
+        z, ldj, trace = trainer.forward(x, want_trace=True)
         ctx.trainer = trainer
+        ctx.trace = trace                       # every step's normalised state: spares the backward its forward sweep
         ctx.save_for_backward(x, *params)      # params: autograd's in-place-modification check only
         return z, ldj
 
@@ -240,7 +241,7 @@ class _FlowFunction(torch.autograd.Function):
         g_z = None if g_z is None else g_z.contiguous().float()
         g_ldj = None if g_ldj is None else g_ldj.contiguous().float()
         with torch.cuda.device(x.device):
-            g_x, grads = trainer.backward(x, g_z, g_ldj, want_gx=ctx.needs_input_grad[1])
+            g_x, grads = trainer.backward(x, g_z, g_ldj, want_gx=ctx.needs_input_grad[1], trace=ctx.trace)
         out = [g for t, g in zip(trainer.params, grads) if t is not None]
         out = [g if need else None for g, need in zip(out, ctx.needs_input_grad[2:])]
         return (None, g_x) + tuple(out)

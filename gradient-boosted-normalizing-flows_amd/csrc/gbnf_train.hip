@@ -80,6 +80,8 @@ struct TrainLaunch {
   const float* x;      // (n, d)
   float* z_out;        // MODE 0
   float* ldj_out;      // MODE 0
+  float* trace_out;    // MODE 0, optional: every step's normalised state [K][d][np], saved for the backward
+  const float* trace;  // MODE 1, optional: that buffer (else the forward sweep is recomputed)
   const float* g_z;    // MODE 1 (n, d) or null
   const float* g_ldj;  // MODE 1 (n,) or null
   float* g_x;          // MODE 1 (n, d) or null
@@ -439,12 +441,17 @@ __global__ void __launch_bounds__(64 * TR_WAVES) train_kernel(const TrainLaunch 
 
   // =============================== forward through all steps
   float ld = 0.0f;   // per-lane partial of log|det J| (every lane group adds its own slots / features)
-  for (int k = 0; k < K; ++k) {
+  const bool have_trace = (MODE == 1) && p.trace != nullptr;
+  if (have_trace) {  // the forward call saved every step's normalised state: just bring this tile's columns in
+    for (int e = g; e < K * d; e += GS) Y[(size_t)e * S + i] = p.trace[(size_t)e * p.np + row0 + i];
+  }
+  for (int k = 0; k < (have_trace ? 0 : K); ++k) {
     const TrStep& st = p.steps[k];
     for (int s = g; s < d; s += GS) {
       const float y = norm_fwd(k, s, Zc[s * S + i], ld);
       Zc[s * S + i] = y;
       if (MODE == 1) Y[((size_t)k * d + s) * S + i] = y;
+      if (MODE == 0 && p.trace_out != nullptr) p.trace_out[((size_t)k * d + s) * p.np + row0 + i] = y;
     }
     if (MODE == 1 && k == K - 1) break;                    // the last step's outputs are not needed for the backward
     __syncthreads();
@@ -599,7 +606,9 @@ __global__ void __launch_bounds__(64 * TR_WAVES) train_kernel(const TrainLaunch 
 
 // ---------------------------------------------------------------------------------------------------------------
 // Weight / bias gradients: C (M x N, row-major) += D (M rows of np samples) . A (N rows of np samples)^T, bias += row sums of D.
-// One wave = one 32 x 32 block of C over one chunk of samples; k-step r of a 16-sample group uses samples s0+4g+r.
+// One wave = one 64 x 64 block of C (16 accumulator tiles) over one chunk of samples; k-step r of a 16-sample group
+// uses samples s0+4g+r, so each operand fragment is ONE 16-byte load per lane.  Branch-free: operand rows past the
+// padded matrix belong to the next workspace region (finite numbers) and only feed output rows that are never stored.
 // ---------------------------------------------------------------------------------------------------------------
 struct WgProblem {
   int64_t d_row, a_row;   // first row (of np floats) of the two operands in the workspace
@@ -607,57 +616,90 @@ struct WgProblem {
   int M, N, blk_begin, nb;
 };
 constexpr int WG_CHUNK = 512;   // samples per block
+constexpr int WG_PD = 2;        // 16-sample groups of operand loads in flight
 
 __global__ void __launch_bounds__(64) wgrad_kernel(const WgProblem* __restrict__ probs, int n_probs,
                                                    const float* __restrict__ ws, float* __restrict__ grads, int64_t np) {
+  typedef const f32x4 __attribute__((address_space(1)))* gv4;
   const int lane = threadIdx.x, i = lane & 15, g = lane >> 4;
   int pi = 0;
   while (pi + 1 < n_probs && (int)blockIdx.x >= probs[pi + 1].blk_begin) ++pi;
   const WgProblem P = probs[pi];
   const int blk = blockIdx.x - P.blk_begin;
-  const int m0 = (blk / P.nb) * 32, n0 = (blk % P.nb) * 32;
+  const int m0 = (blk / P.nb) * 64, n0 = (blk % P.nb) * 64;
   const int64_t s_begin = (int64_t)blockIdx.y * WG_CHUNK;
   const int64_t s_end = (s_begin + WG_CHUNK < np) ? s_begin + WG_CHUNK : np;
-  const float* D0 = ws + (P.d_row + m0 + i) * np + 4 * g;
-  const float* D1 = D0 + 16 * np;
-  const float* A0 = ws + (P.a_row + n0 + i) * np + 4 * g;
-  const float* A1 = A0 + 16 * np;
-  const bool m1 = m0 + 16 < P.M, n1 = n0 + 16 < P.N;    // second tile row / column live (operand rows exist up to the padded size)
-  const bool want_bias = (n0 == 0);
-  f32x4 c00 = {0.f, 0.f, 0.f, 0.f}, c01 = c00, c10 = c00, c11 = c00, cb0 = c00, cb1 = c00;
-  for (int64_t s = s_begin; s < s_end; s += 16) {
-    const f32x4 d0 = *reinterpret_cast<const f32x4*>(D0 + s);
-    const f32x4 a0 = *reinterpret_cast<const f32x4*>(A0 + s);
-    f32x4 d1 = {0.f, 0.f, 0.f, 0.f}, a1 = d1;
-    if (m1) d1 = *reinterpret_cast<const f32x4*>(D1 + s);
-    if (n1) a1 = *reinterpret_cast<const f32x4*>(A1 + s);
+  const float* Db = ws + (P.d_row + m0 + i) * np + 4 * g;
+  const float* Ab = ws + (P.a_row + n0 + i) * np + 4 * g;
+  const int64_t t16 = 16 * np;
+  f32x4 acc[4][4];
+  f32x4 bsum[4];
+  const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      c00 = tr_mfma(d0[r], a0[r], c00);
-      c01 = tr_mfma(d0[r], a1[r], c01);
-      c10 = tr_mfma(d1[r], a0[r], c10);
-      c11 = tr_mfma(d1[r], a1[r], c11);
-      if (want_bias) {
-        cb0 = tr_mfma(d0[r], 1.0f, cb0);
-        cb1 = tr_mfma(d1[r], 1.0f, cb1);
-      }
+  for (int a = 0; a < 4; ++a) {
+    bsum[a] = zero;
+#pragma unroll
+    for (int b = 0; b < 4; ++b) acc[a][b] = zero;
+  }
+  f32x4 rd[WG_PD][4], ra[WG_PD][4];
+  int64_t sl = s_begin;
+  auto issue = [&](f32x4 (&d)[4], f32x4 (&a)[4]) {
+    const int64_t s = sl < s_end ? sl : s_begin;       // past the end: a valid (unused) group again
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      d[t] = *(gv4)(Db + t * t16 + s);
+      a[t] = *(gv4)(Ab + t * t16 + s);
+    }
+    sl += 16;
+  };
+#pragma unroll
+  for (int j = 0; j < WG_PD; ++j) issue(rd[j], ra[j]);
+  auto body = [&](const f32x4 (&d)[4], const f32x4 (&a)[4]) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+      for (int x = 0; x < 4; ++x)
+#pragma unroll
+        for (int y = 0; y < 4; ++y) acc[x][y] = tr_mfma(d[x][r], a[y][r], acc[x][y]);
+#pragma unroll
+    for (int x = 0; x < 4; ++x) bsum[x] += d[x];
+  };
+  int64_t s = s_begin;
+  for (; s + 16 * WG_PD <= s_end; s += 16 * WG_PD) {
+#pragma unroll
+    for (int j = 0; j < WG_PD; ++j) {
+      body(rd[j], ra[j]);
+      issue(rd[j], ra[j]);
     }
   }
-  tr_mfma_drain(c00, c01);
-  tr_mfma_drain(c10, c11);
-  tr_mfma_drain(cb0, cb1);
+#pragma unroll
+  for (int j = 0; j < WG_PD - 1; ++j)
+    if (s + 16 * j < s_end) body(rd[j], ra[j]);
+#pragma unroll
+  for (int x = 0; x < 4; ++x) {
+    tr_mfma_drain(acc[x][0], acc[x][1]);
+    tr_mfma_drain(acc[x][2], acc[x][3]);
+  }
   float* C = grads + P.c_off;
 #pragma unroll
-  for (int r = 0; r < 4; ++r) {
-    const int ma = m0 + 4 * g + r, mb = ma + 16;
-    const int na = n0 + i, nb = na + 16;
-    if (ma < P.M && na < P.N) atomicAdd(C + (size_t)ma * P.N + na, c00[r]);
-    if (ma < P.M && nb < P.N) atomicAdd(C + (size_t)ma * P.N + nb, c01[r]);
-    if (mb < P.M && na < P.N) atomicAdd(C + (size_t)mb * P.N + na, c10[r]);
-    if (mb < P.M && nb < P.N) atomicAdd(C + (size_t)mb * P.N + nb, c11[r]);
-    if (want_bias && i == 0) {
-      if (ma < P.M) atomicAdd(grads + P.b_off + ma, cb0[r]);
-      if (mb < P.M) atomicAdd(grads + P.b_off + mb, cb1[r]);
+  for (int x = 0; x < 4; ++x)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int m = m0 + 16 * x + 4 * g + r;
+#pragma unroll
+      for (int y = 0; y < 4; ++y) {
+        const int n = n0 + 16 * y + i;
+        if (m < P.M && n < P.N) atomicAdd(C + (size_t)m * P.N + n, acc[x][y][r]);
+      }
+    }
+  if (n0 == 0) {     // db[m] = sum over samples of D[m][.]: lane (i,g) holds row m0+16x+i, fold r, then the 4 lane groups
+#pragma unroll
+    for (int x = 0; x < 4; ++x) {
+      float v = bsum[x][0] + bsum[x][1] + bsum[x][2] + bsum[x][3];
+      v += __shfl_xor(v, 16);
+      v += __shfl_xor(v, 32);
+      const int m = m0 + 16 * x + i;
+      if (g == 0 && m < P.M) atomicAdd(grads + P.b_off + m, v);
     }
   }
 }
@@ -814,9 +856,9 @@ int gbnf_trainer_create(const gbnf_flow_desc* desc, gbnf_trainer** out) {
                                           : (int64_t)t->ip + (int64_t)t->n_hidden * t->hp + (int64_t)l * t->hp);
         P.a_row = base_row + (l == 0 ? 0 : (int64_t)t->ip + (int64_t)(l - 1) * t->hp);
         P.c_off = L.gW; P.b_off = L.gb;
-        P.nb = (P.N + 31) / 32;
+        P.nb = (P.N + 63) / 64;
         P.blk_begin = blocks;
-        blocks += ((P.M + 31) / 32) * P.nb;
+        blocks += ((P.M + 63) / 64) * P.nb;
         probs.push_back(P);
       }
     }
@@ -870,7 +912,8 @@ int gbnf_trainer_grad_floats(const gbnf_trainer* t, int64_t* n_floats) {
 int gbnf_trainer_workspace_bytes(const gbnf_trainer* t, int64_t n, int64_t* bytes) {
   if (!t || !bytes || n < 0) return fail(GBNF_ERR_INVALID, "gbnf_trainer_workspace_bytes: bad argument");
   const int64_t np = (n + 15) / 16 * 16;
-  *bytes = ((int64_t)t->K * t->nnets * t->net_rows * np + t->wt_floats) * 4;
+  // operand regions + 64 slack rows (a 64-row block of wgrad_kernel may run past the last region) + transposed weights
+  *bytes = (((int64_t)t->K * t->nnets * t->net_rows + 64) * np + t->wt_floats) * 4;
   return GBNF_OK;
 }
 
@@ -890,14 +933,21 @@ static void fill_launch(const gbnf_trainer* t, TrainLaunch& p, const float* x, i
   p.n_hidden = t->n_hidden; p.hp = t->hp; p.ip = t->ip; p.op = t->op; p.net_rows = t->net_rows;
 }
 
-int gbnf_trainer_forward(const gbnf_trainer* t, const float* x, int64_t n, float* z, float* ldj, void* stream) {
+int gbnf_trainer_trace_floats(const gbnf_trainer* t, int64_t n, int64_t* n_floats) {
+  if (!t || !n_floats || n < 0) return fail(GBNF_ERR_INVALID, "gbnf_trainer_trace_floats: bad argument");
+  *n_floats = (int64_t)t->K * t->d * ((n + 15) / 16 * 16);
+  return GBNF_OK;
+}
+
+int gbnf_trainer_forward(const gbnf_trainer* t, const float* x, int64_t n, float* z, float* ldj, float* trace,
+                         void* stream) {
   if (!t) return fail(GBNF_ERR_INVALID, "gbnf_trainer_forward: trainer is null");
   if (n < 0) return fail(GBNF_ERR_INVALID, "gbnf_trainer_forward: n < 0");
   if (n == 0) return GBNF_OK;
   if (!x) return fail(GBNF_ERR_INVALID, "gbnf_trainer_forward: x is null");
   TrainLaunch p;
   fill_launch(t, p, x, n);
-  p.z_out = z; p.ldj_out = ldj;
+  p.z_out = z; p.ldj_out = ldj; p.trace_out = trace;
   const dim3 grid((unsigned)(p.np / 16));
   if (t->kind == GBNF_KIND_GLOW)
     hipLaunchKernelGGL((train_kernel<GBNF_KIND_GLOW, 0>), grid, dim3(64 * TR_WAVES), t->lds_fwd, (hipStream_t)stream, p);
@@ -908,8 +958,9 @@ int gbnf_trainer_forward(const gbnf_trainer* t, const float* x, int64_t n, float
   return GBNF_OK;
 }
 
-int gbnf_trainer_backward(const gbnf_trainer* t, const float* x, int64_t n, const float* g_z, const float* g_ldj,
-                          float* g_x, float* grads, void* workspace, int64_t workspace_bytes, void* stream) {
+int gbnf_trainer_backward(const gbnf_trainer* t, const float* x, int64_t n, const float* trace, const float* g_z,
+                          const float* g_ldj, float* g_x, float* grads, void* workspace, int64_t workspace_bytes,
+                          void* stream) {
   if (!t) return fail(GBNF_ERR_INVALID, "gbnf_trainer_backward: trainer is null");
   if (n < 0) return fail(GBNF_ERR_INVALID, "gbnf_trainer_backward: n < 0");
   if (n == 0) return GBNF_OK;
@@ -921,8 +972,8 @@ int gbnf_trainer_backward(const gbnf_trainer* t, const float* x, int64_t n, cons
                 (long long)need);
   TrainLaunch p;
   fill_launch(t, p, x, n);
-  p.g_z = g_z; p.g_ldj = g_ldj; p.g_x = g_x; p.grads = grads; p.ws = (float*)workspace;
-  float* wt = (float*)workspace + (int64_t)t->K * t->nnets * t->net_rows * p.np;
+  p.g_z = g_z; p.g_ldj = g_ldj; p.g_x = g_x; p.grads = grads; p.ws = (float*)workspace; p.trace = trace;
+  float* wt = (float*)workspace + ((int64_t)t->K * t->nnets * t->net_rows + 64) * p.np;
   p.wt = wt;
   const dim3 grid((unsigned)(p.np / 16));
   hipStream_t s = (hipStream_t)stream;

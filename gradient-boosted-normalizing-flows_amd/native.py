@@ -31,7 +31,7 @@ ABI_SYMBOLS = (
     "gbnf_mixture_log_prob",
     "gbnf_actnorm_init", "gbnf_boosting_weights",
     "gbnf_flow_validate", "gbnf_trainer_create", "gbnf_trainer_destroy", "gbnf_trainer_forward",
-    "gbnf_trainer_grad_floats", "gbnf_trainer_workspace_bytes", "gbnf_trainer_backward",
+    "gbnf_trainer_grad_floats", "gbnf_trainer_workspace_bytes", "gbnf_trainer_backward", "gbnf_trainer_trace_floats",
     "gbnf_image_flow_create", "gbnf_image_flow_destroy", "gbnf_image_flow_info", "gbnf_image_flow_workspace_bytes",
     "gbnf_image_flow_forward", "gbnf_image_flow_prior",
 )
@@ -132,10 +132,11 @@ def lib():
     L.gbnf_flow_validate.argtypes = [C.POINTER(_FlowDesc)]
     L.gbnf_trainer_create.argtypes = [C.POINTER(_FlowDesc), C.POINTER(vp)]
     L.gbnf_trainer_destroy.argtypes = [vp]
-    L.gbnf_trainer_forward.argtypes = [vp, vp, i64, vp, vp, vp]
+    L.gbnf_trainer_forward.argtypes = [vp, vp, i64, vp, vp, vp, vp]
+    L.gbnf_trainer_trace_floats.argtypes = [vp, i64, C.POINTER(i64)]
     L.gbnf_trainer_grad_floats.argtypes = [vp, C.POINTER(i64)]
     L.gbnf_trainer_workspace_bytes.argtypes = [vp, i64, C.POINTER(i64)]
-    L.gbnf_trainer_backward.argtypes = [vp, vp, i64, vp, vp, vp, vp, vp, i64, vp]
+    L.gbnf_trainer_backward.argtypes = [vp, vp, i64, vp, vp, vp, vp, vp, vp, i64, vp]
     L.gbnf_image_flow_create.argtypes = [C.POINTER(_ImageFlowDesc), C.POINTER(vp)]
     L.gbnf_image_flow_destroy.argtypes = [vp]
     L.gbnf_image_flow_info.argtypes = [vp, C.POINTER(i32), C.POINTER(i32), C.POINTER(i32), C.POINTER(C.c_double)]
@@ -477,7 +478,9 @@ class NativeTrainer:
     def key(self):
         return tuple(t.data_ptr() for t in self._tensors)
 
-    def forward(self, x):
+    def forward(self, x, want_trace=False):
+        """-> (z, ldj) or (z, ldj, trace): ``trace`` holds every step's normalised state; passing it to ``backward``
+        saves that call the forward sweep (valid while the parameters are unchanged)."""
         import torch
         _require_device_f32(x, "x")
         if x.dim() != 2 or x.shape[1] != self.d:
@@ -485,12 +488,18 @@ class NativeTrainer:
         n = x.shape[0]
         z = torch.empty_like(x)
         ldj = torch.empty(n, dtype=torch.float32, device=x.device)
+        trace = None
+        if want_trace:
+            nf = C.c_int64()
+            _check(lib().gbnf_trainer_trace_floats(self.handle, n, C.byref(nf)))
+            trace = torch.empty(nf.value, dtype=torch.float32, device=x.device)
         if n:
             _check(lib().gbnf_trainer_forward(self.handle, C.c_void_p(x.data_ptr()), n, C.c_void_p(z.data_ptr()),
-                                              C.c_void_p(ldj.data_ptr()), _stream_ptr()))
-        return z, ldj
+                                              C.c_void_p(ldj.data_ptr()),
+                                              C.c_void_p(trace.data_ptr() if trace is not None else 0), _stream_ptr()))
+        return (z, ldj, trace) if want_trace else (z, ldj)
 
-    def backward(self, x, g_z=None, g_ldj=None, want_gx=False):
+    def backward(self, x, g_z=None, g_ldj=None, want_gx=False, trace=None):
         """-> (g_x | None, [gradient per entry of ``self.params`` (views of one flat buffer; None for reserved regions)])."""
         import torch
         _require_device_f32(x, "x")
@@ -506,7 +515,7 @@ class NativeTrainer:
             if self._ws is None or self._ws.numel() * 4 < nb.value or self._ws.device != x.device:
                 self._ws = torch.empty((nb.value + 3) // 4, dtype=torch.float32, device=x.device)
             ptr = lambda t: C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
-            _check(lib().gbnf_trainer_backward(self.handle, ptr(x), n, ptr(g_z), ptr(g_ldj), ptr(g_x), ptr(flat),
+            _check(lib().gbnf_trainer_backward(self.handle, ptr(x), n, ptr(trace), ptr(g_z), ptr(g_ldj), ptr(g_x), ptr(flat),
                                                ptr(self._ws), self._ws.numel() * 4, _stream_ptr()))
         grads, off = [], 0
         for t, size in zip(self.params, self._sizes):

@@ -214,8 +214,12 @@ int gbnf_flow_validate(const gbnf_flow_desc* desc);
 int gbnf_trainer_create(const gbnf_flow_desc* desc_device_params, gbnf_trainer** out);
 int gbnf_trainer_destroy(gbnf_trainer* trainer);
 
-/* z, ldj = flows[c](x) on the live parameters (same semantics and outputs as gbnf_flow_forward). */
-int gbnf_trainer_forward(const gbnf_trainer* trainer, const float* x, int64_t n, float* z, float* ldj, void* stream);
+/* z, ldj = flows[c](x) on the live parameters (same semantics and outputs as gbnf_flow_forward).  `trace` (optional,
+ * gbnf_trainer_trace_floats(n) floats of DEVICE memory) receives every step's normalised state; handing it to
+ * gbnf_trainer_backward saves that call the forward sweep (valid only while the parameters are unchanged). */
+int gbnf_trainer_trace_floats(const gbnf_trainer* trainer, int64_t n, int64_t* n_floats);
+int gbnf_trainer_forward(const gbnf_trainer* trainer, const float* x, int64_t n, float* z, float* ldj, float* trace,
+                         void* stream);
 
 /* Size of the flat parameter-gradient buffer, in floats.  Layout, step by step in descriptor order:
  *   glow:    [actnorm bias (d)] [actnorm logs (d)]  then per Linear of the block:   [weight (out*in)] [bias (out)]
@@ -226,9 +230,11 @@ int gbnf_trainer_workspace_bytes(const gbnf_trainer* trainer, int64_t n, int64_t
 
 /* Backward of (z, ldj) = flows[c](x): given g_z = dL/dz (n,d) and g_ldj = dL/dldj (n,) (either may be NULL = zero),
  * ACCUMULATES dL/dparameters into `grads` (the caller zeroes it; layout above) and writes dL/dx to g_x (n,d) unless
- * NULL.  Activations are recomputed from x (nothing is kept from the forward call). */
-int gbnf_trainer_backward(const gbnf_trainer* trainer, const float* x, int64_t n, const float* g_z, const float* g_ldj,
-                          float* g_x, float* grads, void* workspace, int64_t workspace_bytes, void* stream);
+ * NULL.  The coupling nets' activations are recomputed; `trace` is the forward call's trace buffer or NULL (then the
+ * whole forward sweep is recomputed from x as well). */
+int gbnf_trainer_backward(const gbnf_trainer* trainer, const float* x, int64_t n, const float* trace, const float* g_z,
+                          const float* g_ldj, float* g_x, float* grads, void* workspace, int64_t workspace_bytes,
+                          void* stream);
 
 /* ---------------------------------------------------------------------------------------------------------------
  * Image components (BASELINE.json configs[3]): density evaluation of one multi-scale image

@@ -71,6 +71,12 @@ def test_trainer_forward_and_backward_match_oracle(name, golden_case):
         gx, grads = tr.backward(x, torch.from_numpy(g_z).to(dev), torch.from_numpy(g_l).to(dev), want_gx=True)
         _check_grads(grads, grads64, f"{name}[{c}]")
         assert np.abs(gx.cpu().numpy() - gx64).max() <= G_RTOL * float(np.abs(gx64).max())
+        # the same with the forward call's trace (no forward sweep inside the backward kernel): identical state
+        z2, ldj2, trace = tr.forward(x, want_trace=True)
+        assert torch.equal(z2, z) and torch.equal(ldj2, ldj)
+        gx_t, grads_t = tr.backward(x, torch.from_numpy(g_z).to(dev), torch.from_numpy(g_l).to(dev), want_gx=True, trace=trace)
+        _check_grads(grads_t, grads64, f"{name}[{c}] traced")
+        assert np.abs(gx_t.cpu().numpy() - gx64).max() <= G_RTOL * float(np.abs(gx64).max())
         # null upstream gradients are zeros
         _, only_l = tr.backward(x, None, torch.from_numpy(g_l).to(dev))
         _, l64 = oracle.component_grads(spec, g.x, np.zeros_like(g_z), g_l)
@@ -185,8 +191,8 @@ def test_trainer_argument_validation():
     import torch
     from gbnf_amd import native
     L = native.lib()
-    assert L.gbnf_trainer_forward(None, None, 4, None, None, None) == -1
-    assert L.gbnf_trainer_backward(None, None, 4, None, None, None, None, None, 0, None) == -1
+    assert L.gbnf_trainer_forward(None, None, 4, None, None, None, None) == -1
+    assert L.gbnf_trainer_backward(None, None, 4, None, None, None, None, None, None, 0, None) == -1
     assert L.gbnf_trainer_destroy(None) == 0
     with pytest.raises(native.GbnfError):          # CPU tensors: no CPU path
         native.NativeTrainer({"kind": "glow", "d": 4, "coupling": "affine", "steps": [

@@ -77,10 +77,10 @@ def main():
     n = a.batch
 
     def hip_step():
-        z, ldj = tr.forward(x)
+        z, ldj, trace = tr.forward(x, want_trace=True)
         g_z = z / n
         g_l = torch.full((n,), -1.0 / n, device=dev)
-        return tr.backward(x, g_z, g_l)
+        return tr.backward(x, g_z, g_l, trace=trace)
 
     def timed(fn, steps, warmup):
         for _ in range(warmup):
@@ -95,12 +95,12 @@ def main():
     t_hip = timed(hip_step, a.steps, a.warmup)
     # kernel-only: events around forward, backward
     ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
-    z, ldj = tr.forward(x)
+    z, ldj, trace = tr.forward(x, want_trace=True)
     g_z = (z / n).contiguous(); g_l = torch.full((n,), -1.0 / n, device=dev)
     torch.cuda.synchronize()
     fw = bw = 0.0
     for _ in range(a.steps):
-        ev[0].record(); tr.forward(x); ev[1].record(); tr.backward(x, g_z, g_l); ev[2].record()
+        ev[0].record(); tr.forward(x, want_trace=True); ev[1].record(); tr.backward(x, g_z, g_l, trace=trace); ev[2].record()
         torch.cuda.synchronize()
         fw += ev[0].elapsed_time(ev[1]); bw += ev[1].elapsed_time(ev[2])
     fw /= a.steps; bw /= a.steps
