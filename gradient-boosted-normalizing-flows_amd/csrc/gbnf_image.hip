@@ -54,6 +54,7 @@ struct ConvLaunch {
   int64_t st_img;
   float* ldj;             // (n,) accumulated with atomics (EPI_COUPLE_AFFINE / EPI_SPLIT)
   int cin, cout, H, W, ks, n_strips;
+  int o_split;            // workgroups sharing one strip, each with 1/o_split of the output tiles (fills the chip at small batch)
 };
 
 __device__ __forceinline__ f32x4 img_mfma(float a, float b, f32x4 c) {
@@ -74,7 +75,8 @@ __global__ void __launch_bounds__(64 * IMG_WAVES) img_conv_kernel(const ConvLaun
   typedef const float __attribute__((address_space(1)))* gptr;
   const int lane = threadIdx.x & 63, i = lane & 15, g = lane >> 4;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int n = blockIdx.x / p.n_strips, strip = blockIdx.x % p.n_strips;
+  const int osp = blockIdx.x % p.o_split, bid = blockIdx.x / p.o_split;
+  const int n = bid / p.n_strips, strip = bid % p.n_strips;
   constexpr int W = 16 * PT / IMG_R;                        // the strip is IMG_R full rows: W = 16 (PT = 4) or 8 (PT = 2)
   constexpr int HALO = KS >> 1;
   constexpr int WP = W + 2 * HALO, RP = IMG_R + 2 * HALO, CS = RP * WP;   // padded row / rows / channel stride in LDS
@@ -205,7 +207,8 @@ __global__ void __launch_bounds__(64 * IMG_WAVES) img_conv_kernel(const ConvLaun
   };
 
   if (!splitk) {
-    for (int o = wave; o < OT; o += IMG_WAVES) {
+    const int o_per = (OT + p.o_split - 1) / p.o_split, o_end = min(OT, (osp + 1) * o_per);
+    for (int o = osp * o_per + wave; o < o_end; o += IMG_WAVES) {
       f32x4 acc[PT];
 #pragma unroll
       for (int pt = 0; pt < PT; ++pt) acc[pt] = zero;
@@ -431,11 +434,15 @@ void launch_conv(const ConvLaunch& p, int n, hipStream_t s) {
   const int kc = (p.cin + 15) / 16, OT = (p.cout + 15) / 16, PT = IMG_R * p.W / 16;
   size_t lds = (size_t)kc * 16 * per_ch * 4;
   if (OT < IMG_WAVES) lds = std::max(lds, (size_t)IMG_WAVES * (IMG_WAVES - 1) * PT * 64 * 16);
-  const dim3 grid((unsigned)(n * p.n_strips)), blk(64 * IMG_WAVES);
-  if (PT == 4 && p.ks == 3) hipLaunchKernelGGL((img_conv_kernel<EPI, 4, 3>), grid, blk, lds, s, p);
-  else if (PT == 4) hipLaunchKernelGGL((img_conv_kernel<EPI, 4, 1>), grid, blk, lds, s, p);
-  else if (p.ks == 3) hipLaunchKernelGGL((img_conv_kernel<EPI, 2, 3>), grid, blk, lds, s, p);
-  else hipLaunchKernelGGL((img_conv_kernel<EPI, 2, 1>), grid, blk, lds, s, p);
+  ConvLaunch q = p;
+  q.o_split = 1;
+  if (OT >= 2 * IMG_WAVES && (int64_t)n * p.n_strips < 512) q.o_split = 2;      // < 2 workgroups per CU otherwise
+  if (OT >= 4 * IMG_WAVES && (int64_t)n * p.n_strips < 256) q.o_split = 4;
+  const dim3 grid((unsigned)(n * p.n_strips * q.o_split)), blk(64 * IMG_WAVES);
+  if (PT == 4 && p.ks == 3) hipLaunchKernelGGL((img_conv_kernel<EPI, 4, 3>), grid, blk, lds, s, q);
+  else if (PT == 4) hipLaunchKernelGGL((img_conv_kernel<EPI, 4, 1>), grid, blk, lds, s, q);
+  else if (p.ks == 3) hipLaunchKernelGGL((img_conv_kernel<EPI, 2, 3>), grid, blk, lds, s, q);
+  else hipLaunchKernelGGL((img_conv_kernel<EPI, 2, 1>), grid, blk, lds, s, q);
 }
 
 template <int EPI>
