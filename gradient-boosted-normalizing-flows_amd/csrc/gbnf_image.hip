@@ -55,6 +55,13 @@ struct ConvLaunch {
   float* ldj;             // (n,) accumulated with atomics (EPI_COUPLE_AFFINE / EPI_SPLIT)
   int cin, cout, H, W, ks, n_strips;
   int o_split;            // workgroups sharing one strip, each with 1/o_split of the output tiles (fills the chip at small batch)
+  // fused producer (1x1 convolutions only): the input of this convolution is relu(conv3x3(pre_in) + pre_bias), computed
+  // for the strip straight into LDS instead of being read from `in` (the ConvNet's first layer never touches HBM)
+  const float* pre_in;    // (n, *, H, W) first input channel of image 0, or null
+  int64_t pre_in_img;
+  const float* pre_wp;    // packed 3x3 weights [cin/16 tiles][9][pre_kc][64][4]
+  const float* pre_bias;
+  int pre_cin;
 };
 
 __device__ __forceinline__ f32x4 img_mfma(float a, float b, f32x4 c) {
@@ -85,6 +92,79 @@ __global__ void __launch_bounds__(64 * IMG_WAVES) img_conv_kernel(const ConvLaun
   constexpr int taps = KS * KS, half = HALO;
   const int OT = (p.cout + 15) >> 4;
 
+  if (KS == 1 && p.pre_in != nullptr) {
+    // ---- fused first layer: stage its small input with a halo behind the main buffer, run the 3x3 on the matrix cores,
+    //      leave relu(. + bias) in the main buffer as this convolution's input
+    constexpr int WPz = W + 2, RPz = IMG_R + 2, CSz = RPz * WPz;
+    float* zin = lds + cin_pad * CS;
+    const int pkc = (p.pre_cin + 15) >> 4;
+    {
+      const float* src = p.pre_in + (int64_t)n * p.pre_in_img;
+      constexpr int Q = W / 4;
+      const int q = threadIdx.x % Q, rid = threadIdx.x / Q;
+      constexpr int ROWS_PER_PASS = 64 * IMG_WAVES / Q;
+      for (int idx = rid; idx < pkc * 16 * RPz; idx += ROWS_PER_PASS) {
+        const int ci = idx / RPz, rr = idx - ci * RPz;
+        const int row = r0 + rr - 1;
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (ci < p.pre_cin && row >= 0 && row < H) v = *reinterpret_cast<const f32x4*>(src + ((int64_t)ci * H + row) * W + 4 * q);
+        float* dst = zin + ci * CSz + rr * WPz + 1 + 4 * q;
+        dst[0] = v[0]; dst[1] = v[1]; dst[2] = v[2]; dst[3] = v[3];
+        if (q == 0) dst[-1] = 0.0f;
+        if (q == Q - 1) dst[4] = 0.0f;
+      }
+    }
+    __syncthreads();
+    typedef const float __attribute__((address_space(1)))* gptr0;
+    gptr0 pw = (gptr0)p.pre_wp, pb = (gptr0)p.pre_bias;
+    // (pre_cin <= 16: one k-chunk, 9 taps.)  All 9 tap fragments of a tile are requested at once, the next tile's while
+    // this tile's MFMAs run.
+    auto load9 = [&](int o, f32x4 (&af)[9]) {
+      const int oo = o < kc ? o : wave;                       // past the end: a valid tile again (unused)
+#pragma unroll
+      for (int t = 0; t < 9; ++t)
+        af[t] = *reinterpret_cast<const f32x4 __attribute__((address_space(1)))*>(pw + ((size_t)oo * 9 + t) * 256 + lane * 4);
+    };
+    int zoff[PT];
+#pragma unroll
+    for (int pt = 0; pt < PT; ++pt) {
+      const int lin = 16 * pt + i, pr = lin / W, pc = lin % W;
+      zoff[pt] = (4 * g) * CSz + (pr + 1) * WPz + pc + 1;
+    }
+    f32x4 af[2][9];
+    load9(wave, af[0]);
+    auto pre_tile = [&](int o, const f32x4 (&a)[9]) {
+      f32x4 acc[PT];
+#pragma unroll
+      for (int pt = 0; pt < PT; ++pt) acc[pt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int t = 0; t < 9; ++t) {
+        const int dy = t / 3 - 1, dx = t % 3 - 1;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+#pragma unroll
+          for (int pt = 0; pt < PT; ++pt) acc[pt] = img_mfma(a[t][r], zin[zoff[pt] + r * CSz + dy * WPz + dx], acc[pt]);
+        }
+      }
+      img_drain(acc);
+#pragma unroll
+      for (int pt = 0; pt < PT; ++pt) {
+        const int lin = 16 * pt + i;                         // main buffer (no halo): [channel][IMG_R * W]
+        const bool in_img = r0 + lin / W < H;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int co = 16 * o + 4 * g + r;
+          lds[co * CS + lin] = (co < p.cin && in_img) ? fmaxf(acc[pt][r] + pb[co < p.cin ? co : 0], 0.0f) : 0.0f;
+        }
+      }
+    };
+    for (int o = wave; o < kc; o += 2 * IMG_WAVES) {         // the main convolution's input tiles, two per round
+      load9(o + IMG_WAVES, af[1]);
+      pre_tile(o, af[0]);
+      load9(o + 2 * IMG_WAVES, af[0]);
+      if (o + IMG_WAVES < kc) pre_tile(o + IMG_WAVES, af[1]);
+    }
+  } else
   // ---- stage the strip (+ halo, zero padded) of every input channel: one image row = W/4 16-byte loads
   {
     const float* src = p.in + (int64_t)n * p.in_img;
@@ -433,6 +513,7 @@ void launch_conv(const ConvLaunch& p, int n, hipStream_t s) {
   const int per_ch = (IMG_R + 2 * halo) * (p.W + 2 * halo);
   const int kc = (p.cin + 15) / 16, OT = (p.cout + 15) / 16, PT = IMG_R * p.W / 16;
   size_t lds = (size_t)kc * 16 * per_ch * 4;
+  if (p.pre_in != nullptr) lds += (size_t)((p.pre_cin + 15) / 16) * 16 * (IMG_R + 2) * (p.W + 2) * 4;
   if (OT < IMG_WAVES) lds = std::max(lds, (size_t)IMG_WAVES * (IMG_WAVES - 1) * PT * 64 * 16);
   ConvLaunch q = p;
   q.o_split = 1;
@@ -656,9 +737,16 @@ int gbnf_image_flow_forward(const gbnf_image_flow* f, const float* x, const floa
       float* hb[2] = {H1, H2};
       for (size_t q = 0; q + 1 < net.size(); ++q) {
         const PackedConv& c = net[q];
+        if (q == 0 && net.size() >= 3 && c.cin <= 16) continue;     // fused into the 1x1 that follows
         p.in = hin; p.in_img = hin_img; p.wp = blob + c.w_off; p.bias = blob + c.b_off;
         p.out = hb[q & 1]; p.out_img = (int64_t)c.cout * H * W; p.cin = c.cin; p.cout = c.cout; p.ks = c.ks;
+        p.pre_in = nullptr;
+        if (q == 1 && net.size() >= 3 && net[0].cin <= 16) {
+          p.pre_in = cur; p.pre_in_img = img; p.pre_wp = blob + net[0].w_off; p.pre_bias = blob + net[0].b_off;
+          p.pre_cin = net[0].cin;
+        }
         launch_conv<EPI_RELU>(p, (int)n, s);
+        p.pre_in = nullptr;
         hin = hb[q & 1]; hin_img = p.out_img;
       }
       const PackedConv& c = net.back();
