@@ -92,3 +92,47 @@ class ShardedMixture:
                 p_work.wait()
             outs.append(self.lse(p_ll, rho))
         return outs
+
+
+def row_partition(n, world_size):
+    """Batch-row replicas: rank r evaluates rows [begin, end) with ALL components.  The alternative to component sharding
+    when the component count does not divide over the ranks (e.g. C = 4 on 8 GPUs)."""
+    base, rem = divmod(n, world_size)
+    out, begin = [], 0
+    for r in range(world_size):
+        end = begin + base + (1 if r < rem else 0)
+        out.append((begin, end))
+        begin = end
+    return out
+
+
+class ReplicatedMixture:
+    """Every rank holds every component and evaluates its own slice of the batch: NO collective on the data path
+    (``log_prob_local``); ``log_prob`` optionally reassembles the (n,) result on every rank with one all-gather of the
+    row slices (padded to the largest slice).  ``log_prob_fn(x_rows) -> (rows,)`` is the single-GPU path
+    (``BoostedFlow.log_prob`` / ``NativeMixture.log_prob``)."""
+
+    def __init__(self, log_prob_fn, group=None):
+        import torch.distributed as dist
+        self.dist, self.group = dist, group
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.rank = dist.get_rank(group) if dist.is_initialized() else 0
+        self.log_prob_fn = log_prob_fn
+
+    def log_prob_local(self, x):
+        b, e = row_partition(x.shape[0], self.world)[self.rank]
+        return self.log_prob_fn(x[b:e]), (b, e)
+
+    def log_prob(self, x):
+        import torch
+        n = x.shape[0]
+        parts = row_partition(n, self.world)
+        local, (b, e) = self.log_prob_local(x)
+        if self.world == 1:
+            return local
+        width = max(pe - pb for pb, pe in parts)
+        buf = torch.zeros(width, dtype=local.dtype, device=local.device)
+        buf[: e - b] = local
+        out = torch.empty(self.world * width, dtype=local.dtype, device=local.device)
+        self.dist.all_gather_into_tensor(out, buf, group=self.group)
+        return torch.cat([out[r * width: r * width + (pe - pb)] for r, (pb, pe) in enumerate(parts)])

@@ -58,8 +58,15 @@ def _worker(rank, world, port, ll_all, rho, ret):
             return torch.cat([torch.from_numpy(ll_all[c0:c1]) - float(b) for b in range(len(xs_))], dim=1)
 
         grouped = sm.log_prob_group([x, x, x], torch.from_numpy(rho), compute_group)
+        # batch-row replicas (no data-path collective): every rank evaluates its rows with all components
+        def full_log_prob(rows):
+            idx = rows[:, 0].long().numpy()
+            return torch.from_numpy(oracle.mixture_recursion(ll_all[:, idx], rho))
+        xr = torch.arange(n, dtype=torch.float32).view(-1, 1).repeat(1, 3)      # column 0 carries the row id
+        rm = sharded.ReplicatedMixture(full_log_prob)
+        local, rows = rm.log_prob_local(xr)
         ret[rank] = (G.numpy(), ll.numpy(), [o.numpy() for o in outs], calls, (sm.c_begin, sm.c_end),
-                     [g.numpy() for g in grouped])
+                     [g.numpy() for g in grouped], (rm.log_prob(xr).numpy(), rows, local.numpy()))
     finally:
         dist.destroy_process_group()
 
@@ -76,7 +83,10 @@ def test_two_rank_component_sharding_gloo():
     port = _free_port()
     mp.spawn(_worker, args=(world, port, ll_all, rho, ret), nprocs=world, join=True)
     for rank in range(world):
-        G, ll, outs, calls, part, grouped = ret[rank]
+        G, ll, outs, calls, part, grouped, replica = ret[rank]
+        rep_G, rep_rows, rep_local = replica       # replicas: own rows only, reassembled result identical on every rank
+        assert rep_rows == sharded.row_partition(n, world)[rank] and rep_local.shape == (rep_rows[1] - rep_rows[0],)
+        np.testing.assert_array_equal(rep_G, expect)
         assert part == (rank * 2, rank * 2 + 2)
         assert all(c == part for c in calls)                      # each rank computed only its block
         np.testing.assert_array_equal(ll, ll_all)                 # (C, n) rebuilt in component order
@@ -87,3 +97,9 @@ def test_two_rank_component_sharding_gloo():
         assert len(grouped) == 3                                  # grouped exchange: batch b == recursion(ll - b)
         for b, gb in enumerate(grouped):
             np.testing.assert_allclose(gb, oracle.mixture_recursion(ll_all - np.float32(b), rho), rtol=0, atol=0)
+
+
+def test_row_partition_covers_ragged_batches():
+    assert sharded.row_partition(10, 4) == [(0, 3), (3, 6), (6, 8), (8, 10)]
+    assert sharded.row_partition(3, 4) == [(0, 1), (1, 2), (2, 3), (3, 3)]
+    assert sharded.row_partition(8, 1) == [(0, 8)]
