@@ -39,6 +39,17 @@ CONFIGS = {
 }
 
 
+def _cpu_model():
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.lower().startswith("model name"):
+                    return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
 def cpu_baseline(specs, rho, x_np, budget_s):
     """Times the oracle (torch CPU, the reference's op order) on a bounded sample of the SAME workload.
 
@@ -84,7 +95,7 @@ def cpu_baseline(specs, rho, x_np, budget_s):
                 break
     return {
         "value": n * passes / el, "unit": "samples/s", "cores": best_t, "kind": "port",
-        "host_cores": host_cores, "one_thread_value": one_thread,
+        "host_cores": host_cores, "cpu_model": _cpu_model(), "one_thread_value": one_thread,
         "sample": f"{passes} pass(es) over {n} of the {x_np.shape[0]} rows, all {len(specs)} components + mixture "
                   f"recursion, torch-CPU oracle in the reference's op order, {best_t} threads "
                   f"(fastest of {cands}), {el:.1f} s",
