@@ -86,7 +86,7 @@ def main(argv=None):
             jobs.append([HIPCC] + FLAGS + extra + ["-DGBNF_V_ARGS=" + ",".join(str(a) for a in vargs), "-c", vsrc, "-o", o])
     img_o, img_src = os.path.join(OBJ, "gbnf_image.o"), os.path.join(HERE, "gbnf_image.hip")
     objs.append(img_o)
-    if args.force or not newer(img_o, [img_src, hdr[2], hdr[3]]):
+    if args.force or not newer(img_o, [img_src, os.path.join(HERE, "gbnf_image_hx3.hip.h"), hdr[2], hdr[3]]):
         jobs.append([HIPCC] + FLAGS + ["-c", img_src, "-o", img_o])
     keep = set(objs)
     for fn in os.listdir(OBJ):      # drop objects of variants that left the list

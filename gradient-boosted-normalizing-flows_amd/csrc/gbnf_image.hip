@@ -26,6 +26,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdint>
+#include <cstdlib>
 #include <cstring>
 #include <vector>
 
@@ -120,7 +121,7 @@ __global__ void __launch_bounds__(64 * IMG_WAVES) img_conv_kernel(const ConvLaun
     // (pre_cin <= 16: one k-chunk, 9 taps.)  All 9 tap fragments of a tile are requested at once, the next tile's while
     // this tile's MFMAs run.
     auto load9 = [&](int o, f32x4 (&af)[9]) {
-      const int oo = o < kc ? o : wave;                       // past the end: a valid tile again (unused)
+      const int oo = o < kc ? o : 0;                          // past the end: a valid tile again (unused)
 #pragma unroll
       for (int t = 0; t < 9; ++t)
         af[t] = *reinterpret_cast<const f32x4 __attribute__((address_space(1)))*>(pw + ((size_t)oo * 9 + t) * 256 + lane * 4);
@@ -406,12 +407,19 @@ __global__ void __launch_bounds__(256) img_final_kernel(const float* __restrict_
 }
 
 
+}  // namespace gbnf
+
+#include "gbnf_image_hx3.hip.h"
+
+namespace gbnf {
+
 // ---------------------------------------------------------------------------------------------------------------
 // host side: packing + launch sequence
 // ---------------------------------------------------------------------------------------------------------------
 struct PackedConv {
   int cin = 0, cout = 0, ks = 1;
   size_t w_off = 0, b_off = 0;   // float offsets into the handle's parameter blob
+  size_t x_off = 0;              // f16x3 fragments (wide convolutions) / compact fragments (first 3x3), 0 = none
 };
 
 }  // namespace gbnf
@@ -429,6 +437,8 @@ struct gbnf_image_flow {
   float* blob_dev = nullptr;
   int zC = 0, zH = 0, zW = 0;
   double macs = 0;                           // multiply-adds per image
+  int math_mode = 0;                         // GBNF_MATH_F32 or GBNF_MATH_F16X3 (the coupling nets' two wide convolutions)
+  int chp = 0;                               // hidden width padded to 32 (split-f16 activation layout)
 };
 
 namespace {
@@ -458,6 +468,55 @@ struct Packer {
     return pc;
   }
 };
+
+unsigned short f16_bits(float x) {
+  const _Float16 h = static_cast<_Float16>(x);      // round to nearest even
+  unsigned short b;
+  std::memcpy(&b, &h, 2);
+  return b;
+}
+
+// f16x3 A fragments of a convolution: [o][tap][c][hi|mid][64 lanes][8 halfs], k = 32c + 8g + j; returns the float offset
+size_t pack_hx3(Packer& P, const float* w, int cout, int cin, int ks, const std::vector<double>& row_scale) {
+  const int OT = (cout + 15) / 16, KC = (cin + 31) / 32, taps = ks * ks;
+  while (P.blob.size() % 4) P.blob.push_back(0.0f);                     // 16-byte aligned fragments
+  const size_t off = P.blob.size();
+  P.blob.resize(off + (size_t)OT * taps * KC * 2 * 64 * 4, 0.0f);
+  unsigned short* dst = reinterpret_cast<unsigned short*>(P.blob.data() + off);
+  for (int o = 0; o < OT; ++o)
+    for (int tap = 0; tap < taps; ++tap)
+      for (int c = 0; c < KC; ++c)
+        for (int lane = 0; lane < 64; ++lane)
+          for (int j = 0; j < 8; ++j) {
+            const int co = 16 * o + (lane & 15), ci = 32 * c + 8 * (lane >> 4) + j;
+            float v = 0.0f;
+            if (co < cout && ci < cin) v = (float)(row_scale[co] * (double)w[((size_t)co * cin + ci) * taps + tap]);
+            const _Float16 hi = static_cast<_Float16>(v);
+            const float mid = v - (float)hi;
+            const size_t base = ((((size_t)o * taps + tap) * KC + c) * 2) * 64 * 8;
+            dst[base + (size_t)lane * 8 + j] = f16_bits((float)hi);
+            dst[base + 64 * 8 + (size_t)lane * 8 + j] = f16_bits(mid);
+          }
+  return off;
+}
+
+// compact f32 fragments of a 3x3 with <= 16 input channels: [tile][9][64 lanes][4], k-step r <-> input channel 4r + g
+size_t pack_compact(Packer& P, const float* w, int cout_pad16, int cout, int cin, const std::vector<double>& row_scale) {
+  while (P.blob.size() % 4) P.blob.push_back(0.0f);
+  const size_t off = P.blob.size();
+  const int tiles = cout_pad16 / 16;
+  P.blob.resize(off + (size_t)tiles * 9 * 256, 0.0f);
+  for (int o = 0; o < tiles; ++o)
+    for (int tap = 0; tap < 9; ++tap)
+      for (int lane = 0; lane < 64; ++lane)
+        for (int r = 0; r < 4; ++r) {
+          const int co = 16 * o + (lane & 15), ci = 4 * r + (lane >> 4);
+          float v = 0.0f;
+          if (co < cout && ci < cin) v = (float)(row_scale[co] * (double)w[((size_t)co * cin + ci) * 9 + tap]);
+          P.blob[off + (((size_t)o * 9 + tap) * 64 + lane) * 4 + r] = v;
+        }
+  return off;
+}
 
 // log|det A| of an n x n matrix (double, partial pivoting)
 double logabsdet(std::vector<double> a, int n) {
@@ -489,7 +548,7 @@ int check_conv(const gbnf_conv& c, int cin, int cout, int ks, bool want_an, bool
 }
 
 // Conv2d + ActNorm2d: (conv + an_bias) * exp(an_logs);  Conv2dZeros: (conv + bias) * exp(3 logs)
-PackedConv pack_conv(Packer& P, const gbnf_conv& c) {
+PackedConv pack_conv(Packer& P, const gbnf_conv& c, std::vector<double>* scale_out = nullptr) {
   std::vector<double> scale(c.out_channels, 1.0), bias(c.out_channels, 0.0);
   for (int co = 0; co < c.out_channels; ++co) {
     double b = c.bias ? c.bias[co] : 0.0;
@@ -504,6 +563,7 @@ PackedConv pack_conv(Packer& P, const gbnf_conv& c) {
     }
     bias[co] = b;
   }
+  if (scale_out) *scale_out = scale;
   return P.add(c.weight, c.out_channels, c.in_channels, c.kernel_size, scale, bias);
 }
 
@@ -553,6 +613,10 @@ int gbnf_image_flow_create(const gbnf_image_flow_desc* d, gbnf_image_flow** out)
   auto* f = new gbnf_image_flow();
   f->C = C; f->H = H; f->W = W; f->L = d->n_levels; f->additive = d->coupling == GBNF_COUPLING_ADDITIVE;
   f->bounds = d->bounds; f->hidden = d->hidden;
+  const char* env_math = getenv("GBNF_MATH");                // "f32": exact-f32 MFMA everywhere (tuning / test knob)
+  const bool use_hx3 = !(env_math && !strcmp(env_math, "f32"));
+  f->math_mode = use_hx3 ? GBNF_MATH_F16X3 : GBNF_MATH_F32;
+  f->chp = (d->hidden + 31) / 32 * 32;
   Packer P;
   double ld_const = -std::log(256.0) * C * H * W;              // dequantisation, models/glow.py:137
   char what[96];
@@ -611,7 +675,16 @@ int gbnf_image_flow_create(const gbnf_image_flow_desc* d, gbnf_image_flow** out)
         snprintf(what, sizeof(what), "level %d step %d conv %d", l, k, q);
         rc = check_conv(st.convs[q], first ? c1 : hdim, last ? (f->additive ? c2 : 2 * c2) : hdim, (first || last) ? 3 : 1, !last, last, what);
         if (rc == GBNF_OK) {
-          net.push_back(pack_conv(P, st.convs[q]));
+          std::vector<double> sc;
+          PackedConv pc = pack_conv(P, st.convs[q], &sc);
+          // split-f16 path (coupling_network_depth == 1, first 3x3 with <= 16 input channels): extra fragment sets
+          if (use_hx3 && st.n_convs == 3 && c1 <= 16) {
+            const int chp = (hdim + 31) / 32 * 32;
+            if (q == 0) pc.x_off = pack_compact(P, st.convs[q].weight, chp, hdim, c1, sc);
+            else pc.x_off = pack_hx3(P, st.convs[q].weight, st.convs[q].out_channels, st.convs[q].in_channels,
+                                     st.convs[q].kernel_size, sc);
+          }
+          net.push_back(pc);
           f->macs += (double)st.convs[q].in_channels * st.convs[q].out_channels * st.convs[q].kernel_size * st.convs[q].kernel_size * H * W;
         }
       }
@@ -652,6 +725,13 @@ int gbnf_image_flow_create(const gbnf_image_flow_desc* d, gbnf_image_flow** out)
     if (e == hipSuccess) e = allow_lds<EPI_COUPLE_AFFINE>();
     if (e == hipSuccess) e = allow_lds<EPI_COUPLE_ADD>();
     if (e == hipSuccess) e = allow_lds<EPI_SPLIT>();
+    {
+      const void* fns[6] = {(const void*)img_mid_hx3_kernel<4>, (const void*)img_mid_hx3_kernel<2>,
+                            (const void*)img_last_hx3_kernel<EPI_COUPLE_AFFINE, 4>, (const void*)img_last_hx3_kernel<EPI_COUPLE_AFFINE, 2>,
+                            (const void*)img_last_hx3_kernel<EPI_COUPLE_ADD, 4>, (const void*)img_last_hx3_kernel<EPI_COUPLE_ADD, 2>};
+      for (int k = 0; k < 6 && e == hipSuccess; ++k)
+        e = hipFuncSetAttribute(fns[k], hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    }
     if (e != hipSuccess) rc = fail(GBNF_ERR_HIP, "gbnf_image_flow_create: %s", hipGetErrorString(e));
   }
   if (rc != GBNF_OK) {
@@ -688,7 +768,7 @@ int gbnf_image_flow_prior(const gbnf_image_flow* f, float* host) {
 int gbnf_image_flow_workspace_bytes(const gbnf_image_flow* f, int64_t n, int64_t* bytes) {
   if (!f || !bytes || n < 0) return fail(GBNF_ERR_INVALID, "gbnf_image_flow_workspace_bytes: bad argument");
   const int64_t chw = (int64_t)f->C * f->H * f->W;
-  const int64_t hid = (int64_t)f->hidden * (f->H / 2) * (f->W / 2);
+  const int64_t hid = (int64_t)f->chp * (f->H / 2) * (f->W / 2);
   *bytes = (2 * chw + 2 * hid) * n * 4 + 256;
   return GBNF_OK;
 }
@@ -704,7 +784,7 @@ int gbnf_image_flow_forward(const gbnf_image_flow* f, const float* x, const floa
   if (workspace_bytes < need) return fail(GBNF_ERR_INVALID, "gbnf_image_flow_forward: workspace of %lld bytes < %lld", (long long)workspace_bytes, (long long)need);
   hipStream_t s = (hipStream_t)stream;
   const int64_t chw = (int64_t)f->C * f->H * f->W;
-  const int64_t hid = (int64_t)f->hidden * (f->H / 2) * (f->W / 2);
+  const int64_t hid = (int64_t)f->chp * (f->H / 2) * (f->W / 2);
   float* SA = (float*)workspace;
   float* SB = SA + chw * n;
   float* H1 = SB + chw * n;
@@ -732,6 +812,38 @@ int gbnf_image_flow_forward(const gbnf_image_flow* f, const float* x, const floa
       std::swap(cur, oth);
       // coupling net on the first half
       const std::vector<PackedConv>& net = f->net[step];
+      if (net.size() == 3 && net[1].x_off != 0) {
+        // split-f16 path: [first 3x3 -> relu -> split] + 1x1 in one kernel, the last 3x3 + coupling in the second
+        const int PT = IMG_R * W / 16, OT = (net[1].cout + 15) / 16;
+        MidLaunch m1{};
+        m1.pre_in = cur; m1.pre_in_img = img; m1.pre_wp = blob + net[0].x_off; m1.pre_bias = blob + net[0].b_off;
+        m1.wp = reinterpret_cast<const unsigned*>(blob + net[1].x_off); m1.bias = blob + net[1].b_off;
+        m1.h2 = reinterpret_cast<unsigned*>(H1); m1.pre_cin = net[0].cin; m1.hid = net[1].cout; m1.chp = f->chp;
+        m1.H = H; m1.n_strips = n_strips;
+        m1.o_split = 1;
+        if (OT >= 2 * IMG_WAVES && (int64_t)n * n_strips < 512) m1.o_split = 2;
+        if (OT >= 4 * IMG_WAVES && (int64_t)n * n_strips < 256) m1.o_split = 4;
+        const int pixb = 4 * f->chp + 16;
+        const size_t lds1 = (size_t)IMG_R * W * pixb + 16 * (IMG_R + 2) * (W + 2) * 4;
+        const dim3 g1((unsigned)(n * n_strips * m1.o_split)), blk(64 * IMG_WAVES);
+        if (16 * OT != f->chp) (void)hipMemsetAsync(H1, 0, (size_t)hid * n * 4, s);      // pad channels of the split layout
+        if (PT == 4) hipLaunchKernelGGL((img_mid_hx3_kernel<4>), g1, blk, lds1, s, m1);
+        else hipLaunchKernelGGL((img_mid_hx3_kernel<2>), g1, blk, lds1, s, m1);
+        LastLaunch m2{};
+        m2.h2 = reinterpret_cast<const unsigned*>(H1); m2.wp = reinterpret_cast<const unsigned*>(blob + net[2].x_off);
+        m2.bias = blob + net[2].b_off; m2.st = cur + (int64_t)c1 * H * W; m2.st_img = img; m2.ldj = ldj;
+        m2.chp = f->chp; m2.cout = net[2].cout; m2.H = H; m2.n_strips = n_strips;
+        const size_t lds2 = std::max((size_t)(IMG_R + 2) * (W + 2) * pixb, (size_t)IMG_WAVES * (IMG_WAVES - 1) * PT * 64 * 16);
+        const dim3 g2((unsigned)(n * n_strips));
+        if (f->additive) {
+          if (PT == 4) hipLaunchKernelGGL((img_last_hx3_kernel<EPI_COUPLE_ADD, 4>), g2, blk, lds2, s, m2);
+          else hipLaunchKernelGGL((img_last_hx3_kernel<EPI_COUPLE_ADD, 2>), g2, blk, lds2, s, m2);
+        } else {
+          if (PT == 4) hipLaunchKernelGGL((img_last_hx3_kernel<EPI_COUPLE_AFFINE, 4>), g2, blk, lds2, s, m2);
+          else hipLaunchKernelGGL((img_last_hx3_kernel<EPI_COUPLE_AFFINE, 2>), g2, blk, lds2, s, m2);
+        }
+        continue;
+      }
       const float* hin = cur;
       int64_t hin_img = img;
       float* hb[2] = {H1, H2};

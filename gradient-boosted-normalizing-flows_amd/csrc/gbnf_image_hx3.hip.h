@@ -1,0 +1,382 @@
+// gbnf_image_hx3.hip.h -- split-f16 ("f16x3") versions of the two wide convolutions of an image
+// coupling net (the 1x1 hidden -> hidden and the last 3x3 hidden -> shift/scale), included by gbnf_image.hip.
+//
+// An f32 operand is two fp16 pieces x ~ hi + mid; a product is three v_mfma_f32_16x16x32_f16 with f32 accumulation
+// (a_hi b_hi + a_hi b_mid + a_mid b_hi), 4.9x the f32-MFMA rate per FLOP, same accuracy to ~2^-22.  Unlike the tabular
+// coupling nets (tanh + split in the MFMA stream), a ReLU ConvNet splits each activation ONCE where it is produced:
+//   * weights: split at pack time (round to nearest), A fragments [o][tap][c][hi|mid][64 lanes][8 halfs];
+//   * activations between the two kernels live in HBM as "NHWC split-f16": per pixel [hi: CHP halfs][mid: CHP halfs]
+//     (CHP = hidden width padded to 32), so the consumer stages a pixel with plain 16-byte copies and a lane's B operand
+//     (8 consecutive channels of one pixel, k = 32c + 8g + j) is ONE ds_read_b128; the pixel stride is padded by 16 B,
+//     which makes the 16 lanes of a group hit 16 different bank quads.
+//   img_mid_hx3_kernel : [first 3x3 (f32 MFMA, small input) -> relu -> split -> LDS] -> 1x1 (f16x3) -> relu -> split -> HBM
+//   img_last_hx3_kernel: stage strip + halo -> 3x3 (f16x3, contraction split over the 4 waves) -> coupling epilogue (f32)
+#pragma once
+
+namespace gbnf {
+
+using u32x4 = __attribute__((ext_vector_type(4))) unsigned;
+using u32x2 = __attribute__((ext_vector_type(2))) unsigned;
+using f16x8 = __attribute__((ext_vector_type(8))) _Float16;
+
+__device__ __forceinline__ f32x4 img_mfma16(u32x4 a, u32x4 b, f32x4 c) {
+  return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+}
+// hi = f16(x) (toward zero), mid = f16(x - hi) for a pair; x is clamped to the fp16 range first
+__device__ __forceinline__ void img_split_pair(float x0, float x1, unsigned& hi, unsigned& mid) {
+  x0 = __builtin_amdgcn_fmed3f(x0, -65504.0f, 65504.0f);
+  x1 = __builtin_amdgcn_fmed3f(x1, -65504.0f, 65504.0f);
+  const auto h = __builtin_amdgcn_cvt_pkrtz(x0, x1);
+  hi = __builtin_bit_cast(unsigned, h);
+  const auto m = __builtin_amdgcn_cvt_pkrtz(x0 - (float)h[0], x1 - (float)h[1]);
+  mid = __builtin_bit_cast(unsigned, m);
+}
+
+struct MidLaunch {
+  const float* pre_in;      // (n, *, H, W) f32: the coupling net's input z1
+  int64_t pre_in_img;
+  const float* pre_wp;      // compact f32 fragments of the first 3x3: [tile][9][64 lanes][4], k-step r <-> input channel 4r+g
+  const float* pre_bias;    // [16 * tiles]
+  const unsigned* wp;       // f16x3 fragments of the 1x1: [o][c][hi|mid][64][4 u32]
+  const float* bias;        // [16 * OT]
+  unsigned* h2;             // out: NHWC split-f16 (n, H, W, 2 * chp halfs)
+  int pre_cin, hid, chp, H, n_strips, o_split;
+};
+
+template <int PT>
+__global__ void __launch_bounds__(64 * IMG_WAVES) img_mid_hx3_kernel(const MidLaunch p) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+  typedef const float __attribute__((address_space(1)))* gptr;
+  typedef const u32x4 __attribute__((address_space(1)))* gv4;
+  constexpr int W = 16 * PT / IMG_R, WPz = W + 2, RPz = IMG_R + 2, CSz = RPz * WPz, NPIX = IMG_R * W;
+  const int lane = threadIdx.x & 63, i = lane & 15, g = lane >> 4;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int osp = blockIdx.x % p.o_split, bid = blockIdx.x / p.o_split;
+  const int n = bid / p.n_strips, strip = bid % p.n_strips;
+  const int H = p.H, r0 = strip * IMG_R;
+  const int chp = p.chp, pixb = 4 * chp + 16;               // bytes per pixel in LDS: hi[chp] mid[chp] halfs + pad
+  const int OT = (p.hid + 15) >> 4, KC = chp >> 5;
+  unsigned char* HB = lds_raw;                              // [NPIX][pixb]
+  float* zin = reinterpret_cast<float*>(lds_raw + (size_t)NPIX * pixb);   // [16][RPz][WPz]
+
+  // ---- stage z1 (strip + halo, zero padded)
+  {
+    const float* src = p.pre_in + (int64_t)n * p.pre_in_img;
+    constexpr int Q = W / 4;
+    const int q = threadIdx.x % Q, rid = threadIdx.x / Q;
+    constexpr int ROWS_PER_PASS = 64 * IMG_WAVES / Q;
+    for (int idx = rid; idx < 16 * RPz; idx += ROWS_PER_PASS) {
+      const int ci = idx / RPz, rr = idx - ci * RPz;
+      const int row = r0 + rr - 1;
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (ci < p.pre_cin && row >= 0 && row < H) v = *reinterpret_cast<const f32x4*>(src + ((int64_t)ci * H + row) * W + 4 * q);
+      float* dst = zin + ci * CSz + rr * WPz + 1 + 4 * q;
+      dst[0] = v[0]; dst[1] = v[1]; dst[2] = v[2]; dst[3] = v[3];
+      if (q == 0) dst[-1] = 0.0f;
+      if (q == Q - 1) dst[4] = 0.0f;
+    }
+  }
+  __syncthreads();
+
+  // ---- first 3x3 on f32 MFMA (k-step r covers input channels 4r..4r+3: ceil(cin/4) k-steps), relu, split -> HB
+  {
+    gptr pw = (gptr)p.pre_wp, pb = (gptr)p.pre_bias;
+    const int ks4 = (p.pre_cin + 3) >> 2;
+    const int kt = chp >> 4;                                // 16-channel tiles of the padded hidden width
+    int zoff[PT];
+#pragma unroll
+    for (int pt = 0; pt < PT; ++pt) {
+      const int lin = 16 * pt + i, pr = lin / W, pc = lin % W;
+      zoff[pt] = g * CSz + (pr + 1) * WPz + pc + 1;
+    }
+    auto load9 = [&](int o, f32x4 (&af)[9]) {
+      const int oo = o < kt ? o : 0;
+#pragma unroll
+      for (int t = 0; t < 9; ++t)
+        af[t] = *reinterpret_cast<const f32x4 __attribute__((address_space(1)))*>(pw + ((size_t)oo * 9 + t) * 256 + lane * 4);
+    };
+    f32x4 af[2][9];
+    load9(wave, af[0]);
+    auto pre_tile = [&](int o, const f32x4 (&a)[9]) {
+      f32x4 acc[PT];
+#pragma unroll
+      for (int pt = 0; pt < PT; ++pt) acc[pt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int t = 0; t < 9; ++t) {
+        const int dy = t / 3 - 1, dx = t % 3 - 1;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          if (r < ks4) {
+#pragma unroll
+            for (int pt = 0; pt < PT; ++pt) acc[pt] = img_mfma(a[t][r], zin[zoff[pt] + (4 * r) * CSz + dy * WPz + dx], acc[pt]);
+          }
+        }
+      }
+      img_drain(acc);
+#pragma unroll
+      for (int pt = 0; pt < PT; ++pt) {
+        const int lin = 16 * pt + i;
+        const bool in_img = r0 + lin / W < H;
+        float v[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int co = 16 * o + 4 * g + r;
+          v[r] = (co < p.hid && in_img) ? fmaxf(acc[pt][r] + pb[co < p.hid ? co : 0], 0.0f) : 0.0f;
+        }
+        unsigned h01, m01, h23, m23;
+        img_split_pair(v[0], v[1], h01, m01);
+        img_split_pair(v[2], v[3], h23, m23);
+        const u32x2 hi = {h01, h23}, mid = {m01, m23};
+        unsigned char* px = HB + (size_t)lin * pixb + 2 * (16 * o + 4 * g);
+        *reinterpret_cast<u32x2*>(px) = hi;
+        *reinterpret_cast<u32x2*>(px + 2 * chp) = mid;
+      }
+    };
+    for (int o = wave; o < kt; o += 2 * IMG_WAVES) {
+      load9(o + IMG_WAVES, af[1]);
+      pre_tile(o, af[0]);
+      load9(o + 2 * IMG_WAVES, af[0]);
+      if (o + IMG_WAVES < kt) pre_tile(o + IMG_WAVES, af[1]);
+    }
+  }
+  __syncthreads();
+
+  // ---- 1x1 hidden -> hidden, f16x3: this wave's (<= 4) output tiles x PT pixel tiles, B operands shared by the tiles
+  constexpr int MAXO = 4;
+  const int o_per = (OT + p.o_split - 1) / p.o_split;
+  const int o_begin = osp * o_per, o_end = min(OT, o_begin + o_per);
+  int ow[MAXO];
+#pragma unroll
+  for (int q = 0; q < MAXO; ++q) ow[q] = o_begin + wave + q * IMG_WAVES;       // tile of slot q (>= o_end: idle)
+  f32x4 acc[MAXO][PT];
+#pragma unroll
+  for (int q = 0; q < MAXO; ++q)
+#pragma unroll
+    for (int pt = 0; pt < PT; ++pt) acc[q][pt] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const gv4 wp = (gv4)p.wp;
+  auto load_a = [&](int c, u32x4 (&ah)[MAXO], u32x4 (&am)[MAXO]) {
+    const int cc = c < KC ? c : 0;
+#pragma unroll
+    for (int q = 0; q < MAXO; ++q) {
+      const int o = ow[q] < o_end ? ow[q] : o_begin;          // idle slots re-read a valid fragment
+      const gv4 f = wp + ((size_t)o * KC + cc) * 128 + lane;
+      ah[q] = f[0];
+      am[q] = f[64];
+    }
+  };
+  const unsigned char* bbase = HB + (size_t)i * pixb + 16 * g;
+  auto chunk = [&](int c, const u32x4 (&ah)[MAXO], const u32x4 (&am)[MAXO]) {
+    u32x4 bh[PT], bm[PT];
+#pragma unroll
+    for (int pt = 0; pt < PT; ++pt) {
+      const unsigned char* px = bbase + (size_t)(16 * pt) * pixb + 64 * c;
+      bh[pt] = *reinterpret_cast<const u32x4*>(px);
+      bm[pt] = *reinterpret_cast<const u32x4*>(px + 2 * chp);
+    }
+#pragma unroll
+    for (int q = 0; q < MAXO; ++q) {
+      if (ow[q] < o_end) {
+#pragma unroll
+        for (int pt = 0; pt < PT; ++pt) {
+          acc[q][pt] = img_mfma16(am[q], bh[pt], acc[q][pt]);
+          acc[q][pt] = img_mfma16(ah[q], bm[pt], acc[q][pt]);
+          acc[q][pt] = img_mfma16(ah[q], bh[pt], acc[q][pt]);
+        }
+      }
+    }
+  };
+  {
+    u32x4 ah[2][MAXO], am[2][MAXO];
+    load_a(0, ah[0], am[0]);
+    int c = 0;
+    for (; c + 2 <= KC; c += 2) {
+      load_a(c + 1, ah[1], am[1]);
+      chunk(c, ah[0], am[0]);
+      load_a(c + 2, ah[0], am[0]);
+      chunk(c + 1, ah[1], am[1]);
+    }
+    if (c < KC) chunk(c, ah[0], am[0]);
+  }
+#pragma unroll
+  for (int q = 0; q < MAXO; ++q) img_drain(acc[q]);
+
+  // ---- relu(. + bias) -> split -> HBM (NHWC split-f16)
+  gptr bias = (gptr)p.bias;
+#pragma unroll
+  for (int q = 0; q < MAXO; ++q) {
+    if (ow[q] < o_end) {
+      const int o = ow[q];
+#pragma unroll
+      for (int pt = 0; pt < PT; ++pt) {
+        const int lin = 16 * pt + i, row = r0 + lin / W, col = lin % W;
+        if (row < H) {
+          float v[4];
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int co = 16 * o + 4 * g + r;
+            v[r] = co < p.hid ? fmaxf(acc[q][pt][r] + bias[co], 0.0f) : 0.0f;
+          }
+          unsigned h01, m01, h23, m23;
+          img_split_pair(v[0], v[1], h01, m01);
+          img_split_pair(v[2], v[3], h23, m23);
+          const u32x2 hi = {h01, h23}, mid = {m01, m23};
+          unsigned char* px = reinterpret_cast<unsigned char*>(p.h2) + (((int64_t)n * H + row) * W + col) * (int64_t)(4 * chp)
+                              + 2 * (16 * o + 4 * g);
+          *reinterpret_cast<u32x2*>(px) = hi;
+          *reinterpret_cast<u32x2*>(px + 2 * chp) = mid;
+        }
+      }
+    }
+  }
+}
+
+struct LastLaunch {
+  const unsigned* h2;       // NHWC split-f16 input (n, H, W, 2 * chp halfs)
+  const unsigned* wp;       // f16x3 fragments [o][tap][c][hi|mid][64][4 u32]
+  const float* bias;        // [16 * OT]
+  float* st;                // coupled half z2 (n, *, H, W) f32, first channel of image 0
+  int64_t st_img;
+  float* ldj;
+  int chp, cout, H, n_strips;
+};
+
+// EPI: EPI_COUPLE_AFFINE or EPI_COUPLE_ADD
+template <int EPI, int PT>
+__global__ void __launch_bounds__(64 * IMG_WAVES) img_last_hx3_kernel(const LastLaunch p) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+  typedef const float __attribute__((address_space(1)))* gptr;
+  typedef const u32x4 __attribute__((address_space(1)))* gv4;
+  constexpr int W = 16 * PT / IMG_R, WP = W + 2, RP = IMG_R + 2;
+  const int lane = threadIdx.x & 63, i = lane & 15, g = lane >> 4;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int n = blockIdx.x / p.n_strips, strip = blockIdx.x % p.n_strips;
+  const int H = p.H, r0 = strip * IMG_R;
+  const int chp = p.chp, pixb = 4 * chp + 16, KC = chp >> 5;
+  const int OT = (p.cout + 15) >> 4;                        // <= 3
+  unsigned char* HB = lds_raw;                              // [RP * WP][pixb]
+
+  // ---- stage strip + halo: a pixel is 4*chp contiguous bytes in HBM; outside the image: zeros
+  {
+    const int units = chp >> 2;                             // 16-byte units per pixel
+    const int total = RP * WP * units;
+    const unsigned char* src = reinterpret_cast<const unsigned char*>(p.h2) + (int64_t)n * H * W * (int64_t)(4 * chp);
+    for (int e = threadIdx.x; e < total; e += 64 * IMG_WAVES) {
+      const int px = e / units, u = e - px * units;
+      const int rr = px / WP, cc = px - rr * WP;
+      const int row = r0 + rr - 1, col = cc - 1;
+      u32x4 v = {0u, 0u, 0u, 0u};
+      if (row >= 0 && row < H && col >= 0 && col < W)
+        v = *reinterpret_cast<const u32x4*>(src + ((int64_t)row * W + col) * (int64_t)(4 * chp) + 16 * u);
+      *reinterpret_cast<u32x4*>(HB + (size_t)px * pixb + 16 * u) = v;
+    }
+  }
+  __syncthreads();
+
+  constexpr int MAXO = IMG_WAVES - 1;
+  f32x4 part[MAXO][PT];
+#pragma unroll
+  for (int o = 0; o < MAXO; ++o)
+#pragma unroll
+    for (int pt = 0; pt < PT; ++pt) part[o][pt] = f32x4{0.f, 0.f, 0.f, 0.f};
+  int boff[PT];
+#pragma unroll
+  for (int pt = 0; pt < PT; ++pt) {
+    const int lin = 16 * pt + i, pr = lin / W, pc = lin % W;
+    boff[pt] = ((pr + 1) * WP + pc + 1) * pixb + 16 * g;
+  }
+  const int T_all = 9 * KC;
+  const gv4 wp = (gv4)p.wp;
+  auto load_a = [&](int t, u32x4 (&ah)[MAXO], u32x4 (&am)[MAXO]) {
+    const int tt = t < T_all ? t : 0;
+#pragma unroll
+    for (int o = 0; o < MAXO; ++o) {
+      const gv4 f = wp + ((size_t)(o < OT ? o : 0) * T_all + tt) * 128 + lane;
+      ah[o] = f[0];
+      am[o] = f[64];
+    }
+  };
+  auto iter = [&](int t, const u32x4 (&ah)[MAXO], const u32x4 (&am)[MAXO]) {
+    const int tap = t / KC, c = t - tap * KC;
+    const int dy = tap / 3 - 1, dx = tap % 3 - 1;
+    const unsigned char* b0 = HB + (dy * WP + dx) * pixb + 64 * c;
+    u32x4 bh[PT], bm[PT];
+#pragma unroll
+    for (int pt = 0; pt < PT; ++pt) {
+      bh[pt] = *reinterpret_cast<const u32x4*>(b0 + boff[pt]);
+      bm[pt] = *reinterpret_cast<const u32x4*>(b0 + boff[pt] + 2 * chp);
+    }
+#pragma unroll
+    for (int o = 0; o < MAXO; ++o) {
+      if (o < OT) {
+#pragma unroll
+        for (int pt = 0; pt < PT; ++pt) {
+          part[o][pt] = img_mfma16(am[o], bh[pt], part[o][pt]);
+          part[o][pt] = img_mfma16(ah[o], bm[pt], part[o][pt]);
+          part[o][pt] = img_mfma16(ah[o], bh[pt], part[o][pt]);
+        }
+      }
+    }
+  };
+  {
+    u32x4 ah[2][MAXO], am[2][MAXO];
+    int t = wave;
+    load_a(t, ah[0], am[0]);
+    for (; t + IMG_WAVES < T_all; t += 2 * IMG_WAVES) {
+      load_a(t + IMG_WAVES, ah[1], am[1]);
+      iter(t, ah[0], am[0]);
+      load_a(t + 2 * IMG_WAVES, ah[0], am[0]);
+      iter(t + IMG_WAVES, ah[1], am[1]);
+    }
+    if (t < T_all) iter(t, ah[0], am[0]);
+  }
+#pragma unroll
+  for (int o = 0; o < MAXO; ++o) img_drain(part[o]);
+  __syncthreads();                                         // nobody reads the strip any more
+  f32x4* red = reinterpret_cast<f32x4*>(lds_raw);          // [wave][o][pt][64]
+#pragma unroll
+  for (int o = 0; o < MAXO; ++o)
+#pragma unroll
+    for (int pt = 0; pt < PT; ++pt)
+      if (o < OT) red[((wave * MAXO + o) * PT + pt) * 64 + lane] = part[o][pt];
+  __syncthreads();
+
+  float ld = 0.0f;
+  gptr bias = (gptr)p.bias;
+  float* st = p.st + (int64_t)n * p.st_img;
+  for (int q = wave; q < OT * PT; q += IMG_WAVES) {
+    const int o = q / PT, pt = q % PT;
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int w = 0; w < IMG_WAVES; ++w) acc += red[((w * MAXO + o) * PT + pt) * 64 + lane];
+    const int lin = 16 * pt + i, row = r0 + lin / W, pc = lin % W;
+    const bool in_img = row < H;
+    const int64_t pix = (int64_t)row * W + pc;
+    if constexpr (EPI == EPI_COUPLE_ADD) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int co = 16 * o + 4 * g + r;
+        if (co < p.cout && in_img) st[(int64_t)co * H * W + pix] += acc[r] + bias[co];        // models/glow.py:328-329
+      }
+    } else {
+#pragma unroll
+      for (int qq = 0; qq < 2; ++qq) {
+        const int co = 16 * o + 4 * g + 2 * qq, j = co >> 1;
+        if (co + 1 < p.cout && in_img) {
+          const float h0 = acc[2 * qq] + bias[co], h1 = acc[2 * qq + 1] + bias[co + 1];
+          float* zp = st + (int64_t)j * H * W + pix;
+          const float e = __expf(-(h1 + 2.0f));                     // scale = sigmoid(raw + 2), models/glow.py:333
+          const float sc = 1.0f / (1.0f + e);
+          *zp = (*zp + h0) * sc;                                    // models/glow.py:334-335
+          ld += -log1pf(e);                                         // log(scale), models/glow.py:338
+        }
+      }
+    }
+  }
+  if constexpr (EPI == EPI_COUPLE_AFFINE) {
+#pragma unroll
+    for (int m = 1; m < 64; m <<= 1) ld += __shfl_xor(ld, m);
+    if (lane == 0) atomicAdd(p.ldj + n, ld);
+  }
+}
+
+}  // namespace gbnf
