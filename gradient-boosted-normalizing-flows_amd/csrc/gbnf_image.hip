@@ -419,7 +419,9 @@ namespace gbnf {
 struct PackedConv {
   int cin = 0, cout = 0, ks = 1;
   size_t w_off = 0, b_off = 0;   // float offsets into the handle's parameter blob
-  size_t x_off = 0;              // f16x3 fragments (wide convolutions) / compact fragments (first 3x3), 0 = none
+  size_t x_off = 0;              // f16x3 fragments (wide convolutions; first 3x3: taps folded into k), 0 = none
+  size_t k_off = 0;              // first 3x3: im2col offset table
+  int kc = 0;                    // first 3x3: 32-wide chunks of the folded contraction
 };
 
 }  // namespace gbnf
@@ -500,21 +502,44 @@ size_t pack_hx3(Packer& P, const float* w, int cout, int cin, int ks, const std:
   return off;
 }
 
-// compact f32 fragments of a 3x3 with <= 16 input channels: [tile][9][64 lanes][4], k-step r <-> input channel 4r + g
-size_t pack_compact(Packer& P, const float* w, int cout_pad16, int cout, int cin, const std::vector<double>& row_scale) {
+// The first 3x3 (<= 16 input channels) as one GEMM with its taps folded into the contraction, k = tap * cin + ci:
+// f16x3 A fragments [tile][kc][hi|mid][64 lanes][8 halfs] followed by the im2col offset table int[32 * kc]
+// (float offset ci * CSz + (dy+1) * WPz + (dx+1) from the corner of the pixel's 3x3 window in the staged strip; -1 = padding).
+size_t pack_folded(Packer& P, const float* w, int cout_pad16, int cout, int cin, int W, const std::vector<double>& row_scale,
+                   size_t* koff_out, int* kc_out) {
+  const int tiles = cout_pad16 / 16, K = 9 * cin, KC = (K + 31) / 32;
   while (P.blob.size() % 4) P.blob.push_back(0.0f);
   const size_t off = P.blob.size();
-  const int tiles = cout_pad16 / 16;
-  P.blob.resize(off + (size_t)tiles * 9 * 256, 0.0f);
+  P.blob.resize(off + (size_t)tiles * KC * 2 * 64 * 4, 0.0f);
+  unsigned short* dst = reinterpret_cast<unsigned short*>(P.blob.data() + off);
   for (int o = 0; o < tiles; ++o)
-    for (int tap = 0; tap < 9; ++tap)
+    for (int c = 0; c < KC; ++c)
       for (int lane = 0; lane < 64; ++lane)
-        for (int r = 0; r < 4; ++r) {
-          const int co = 16 * o + (lane & 15), ci = 4 * r + (lane >> 4);
+        for (int j = 0; j < 8; ++j) {
+          const int co = 16 * o + (lane & 15), k = 32 * c + 8 * (lane >> 4) + j;
           float v = 0.0f;
-          if (co < cout && ci < cin) v = (float)(row_scale[co] * (double)w[((size_t)co * cin + ci) * 9 + tap]);
-          P.blob[off + (((size_t)o * 9 + tap) * 64 + lane) * 4 + r] = v;
+          if (co < cout && k < K) {
+            const int tap = k / cin, ci = k % cin;
+            v = (float)(row_scale[co] * (double)w[((size_t)co * cin + ci) * 9 + tap]);
+          }
+          const _Float16 hi = static_cast<_Float16>(v);
+          const size_t base = (((size_t)o * KC + c) * 2) * 64 * 8;
+          dst[base + (size_t)lane * 8 + j] = f16_bits((float)hi);
+          dst[base + 64 * 8 + (size_t)lane * 8 + j] = f16_bits(v - (float)hi);
         }
+  const size_t koff = P.blob.size();
+  P.blob.resize(koff + (size_t)32 * KC, 0.0f);
+  const int WPz = W + 2, CSz = (IMG_R + 2) * WPz;
+  for (int k = 0; k < 32 * KC; ++k) {
+    int v = -1;
+    if (k < K) {
+      const int tap = k / cin, ci = k % cin;
+      v = ci * CSz + (tap / 3) * WPz + (tap % 3);
+    }
+    std::memcpy(&P.blob[koff + k], &v, 4);
+  }
+  *koff_out = koff;
+  *kc_out = KC;
   return off;
 }
 
@@ -567,6 +592,10 @@ PackedConv pack_conv(Packer& P, const gbnf_conv& c, std::vector<double>* scale_o
   return P.add(c.weight, c.out_channels, c.in_channels, c.kernel_size, scale, bias);
 }
 
+#ifdef GBNF_IMG_STAMPS
+unsigned long long* g_img_stamp_buf = nullptr;
+#endif
+
 template <int EPI>
 void launch_conv(const ConvLaunch& p, int n, hipStream_t s) {
   const int halo = p.ks >> 1;
@@ -599,6 +628,10 @@ hipError_t allow_lds() {
 }  // namespace
 
 extern "C" {
+
+#ifdef GBNF_IMG_STAMPS
+void gbnf_debug_set_image_stamp_buffer(unsigned long long* p) { g_img_stamp_buf = p; }
+#endif
 
 int gbnf_image_flow_create(const gbnf_image_flow_desc* d, gbnf_image_flow** out) {
   if (!out) return fail(GBNF_ERR_INVALID, "gbnf_image_flow_create: out is null");
@@ -680,7 +713,7 @@ int gbnf_image_flow_create(const gbnf_image_flow_desc* d, gbnf_image_flow** out)
           // split-f16 path (coupling_network_depth == 1, first 3x3 with <= 16 input channels): extra fragment sets
           if (use_hx3 && st.n_convs == 3 && c1 <= 16) {
             const int chp = (hdim + 31) / 32 * 32;
-            if (q == 0) pc.x_off = pack_compact(P, st.convs[q].weight, chp, hdim, c1, sc);
+            if (q == 0) pc.x_off = pack_folded(P, st.convs[q].weight, chp, hdim, c1, W, sc, &pc.k_off, &pc.kc);
             else pc.x_off = pack_hx3(P, st.convs[q].weight, st.convs[q].out_channels, st.convs[q].in_channels,
                                      st.convs[q].kernel_size, sc);
           }
@@ -726,10 +759,12 @@ int gbnf_image_flow_create(const gbnf_image_flow_desc* d, gbnf_image_flow** out)
     if (e == hipSuccess) e = allow_lds<EPI_COUPLE_ADD>();
     if (e == hipSuccess) e = allow_lds<EPI_SPLIT>();
     {
-      const void* fns[6] = {(const void*)img_mid_hx3_kernel<4>, (const void*)img_mid_hx3_kernel<2>,
-                            (const void*)img_last_hx3_kernel<EPI_COUPLE_AFFINE, 4>, (const void*)img_last_hx3_kernel<EPI_COUPLE_AFFINE, 2>,
-                            (const void*)img_last_hx3_kernel<EPI_COUPLE_ADD, 4>, (const void*)img_last_hx3_kernel<EPI_COUPLE_ADD, 2>};
-      for (int k = 0; k < 6 && e == hipSuccess; ++k)
+      const void* fns[10] = {(const void*)img_mid_hx3_kernel<4, 2>, (const void*)img_mid_hx3_kernel<4, 4>,
+                             (const void*)img_mid_hx3_kernel<4, 5>, (const void*)img_mid_hx3_kernel<2, 2>,
+                             (const void*)img_mid_hx3_kernel<2, 4>, (const void*)img_mid_hx3_kernel<2, 5>,
+                             (const void*)img_last_hx3_kernel<EPI_COUPLE_AFFINE, 4>, (const void*)img_last_hx3_kernel<EPI_COUPLE_AFFINE, 2>,
+                             (const void*)img_last_hx3_kernel<EPI_COUPLE_ADD, 4>, (const void*)img_last_hx3_kernel<EPI_COUPLE_ADD, 2>};
+      for (int k = 0; k < 10 && e == hipSuccess; ++k)
         e = hipFuncSetAttribute(fns[k], hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     }
     if (e != hipSuccess) rc = fail(GBNF_ERR_HIP, "gbnf_image_flow_create: %s", hipGetErrorString(e));
@@ -816,10 +851,15 @@ int gbnf_image_flow_forward(const gbnf_image_flow* f, const float* x, const floa
         // split-f16 path: [first 3x3 -> relu -> split] + 1x1 in one kernel, the last 3x3 + coupling in the second
         const int PT = IMG_R * W / 16, OT = (net[1].cout + 15) / 16;
         MidLaunch m1{};
-        m1.pre_in = cur; m1.pre_in_img = img; m1.pre_wp = blob + net[0].x_off; m1.pre_bias = blob + net[0].b_off;
+        m1.pre_in = cur; m1.pre_in_img = img; m1.pre_wp = reinterpret_cast<const unsigned*>(blob + net[0].x_off);
+        m1.pre_koff = reinterpret_cast<const int*>(blob + net[0].k_off); m1.pre_kc = net[0].kc;
+        m1.pre_bias = blob + net[0].b_off;
         m1.wp = reinterpret_cast<const unsigned*>(blob + net[1].x_off); m1.bias = blob + net[1].b_off;
         m1.h2 = reinterpret_cast<unsigned*>(H1); m1.pre_cin = net[0].cin; m1.hid = net[1].cout; m1.chp = f->chp;
         m1.H = H; m1.n_strips = n_strips;
+#ifdef GBNF_IMG_STAMPS
+        m1.dbg = (PT == 4) ? g_img_stamp_buf : nullptr;
+#endif
         m1.o_split = 1;
         if (OT >= 2 * IMG_WAVES && (int64_t)n * n_strips < 512) m1.o_split = 2;
         if (OT >= 4 * IMG_WAVES && (int64_t)n * n_strips < 256) m1.o_split = 4;
@@ -827,8 +867,13 @@ int gbnf_image_flow_forward(const gbnf_image_flow* f, const float* x, const floa
         const size_t lds1 = (size_t)IMG_R * W * pixb + 16 * (IMG_R + 2) * (W + 2) * 4;
         const dim3 g1((unsigned)(n * n_strips * m1.o_split)), blk(64 * IMG_WAVES);
         if (16 * OT != f->chp) (void)hipMemsetAsync(H1, 0, (size_t)hid * n * 4, s);      // pad channels of the split layout
-        if (PT == 4) hipLaunchKernelGGL((img_mid_hx3_kernel<4>), g1, blk, lds1, s, m1);
-        else hipLaunchKernelGGL((img_mid_hx3_kernel<2>), g1, blk, lds1, s, m1);
+        const int pk = m1.pre_kc <= 2 ? 2 : (m1.pre_kc <= 4 ? 4 : 5);
+        if (PT == 4 && pk == 2) hipLaunchKernelGGL((img_mid_hx3_kernel<4, 2>), g1, blk, lds1, s, m1);
+        else if (PT == 4 && pk == 4) hipLaunchKernelGGL((img_mid_hx3_kernel<4, 4>), g1, blk, lds1, s, m1);
+        else if (PT == 4) hipLaunchKernelGGL((img_mid_hx3_kernel<4, 5>), g1, blk, lds1, s, m1);
+        else if (pk == 2) hipLaunchKernelGGL((img_mid_hx3_kernel<2, 2>), g1, blk, lds1, s, m1);
+        else if (pk == 4) hipLaunchKernelGGL((img_mid_hx3_kernel<2, 4>), g1, blk, lds1, s, m1);
+        else hipLaunchKernelGGL((img_mid_hx3_kernel<2, 5>), g1, blk, lds1, s, m1);
         LastLaunch m2{};
         m2.h2 = reinterpret_cast<const unsigned*>(H1); m2.wp = reinterpret_cast<const unsigned*>(blob + net[2].x_off);
         m2.bias = blob + net[2].b_off; m2.st = cur + (int64_t)c1 * H * W; m2.st_img = img; m2.ldj = ldj;

@@ -32,18 +32,38 @@ __device__ __forceinline__ void img_split_pair(float x0, float x1, unsigned& hi,
   mid = __builtin_bit_cast(unsigned, m);
 }
 
+// IMG_PRE_KC (template parameter of the mid kernel): 32-wide chunks of the first 3x3's folded contraction that are kept
+// in registers: 2 (cin <= 7), 4 (cin <= 14) or 5 (cin <= 16)
+
 struct MidLaunch {
   const float* pre_in;      // (n, *, H, W) f32: the coupling net's input z1
   int64_t pre_in_img;
-  const float* pre_wp;      // compact f32 fragments of the first 3x3: [tile][9][64 lanes][4], k-step r <-> input channel 4r+g
+  const unsigned* pre_wp;   // f16x3 fragments of the first 3x3 with taps folded into k: [tile][pre_kc][hi|mid][64][4 u32]
+  const int* pre_koff;      // [32 * pre_kc] im2col offsets: k -> float offset ci * CSz + (dy+1) * WPz + (dx+1) from the window's corner, -1 = pad
   const float* pre_bias;    // [16 * tiles]
+  int pre_kc;
   const unsigned* wp;       // f16x3 fragments of the 1x1: [o][c][hi|mid][64][4 u32]
   const float* bias;        // [16 * OT]
   unsigned* h2;             // out: NHWC split-f16 (n, H, W, 2 * chp halfs)
   int pre_cin, hid, chp, H, n_strips, o_split;
+  unsigned long long* dbg;  // diagnostic builds (-DGBNF_IMG_STAMPS) only
 };
 
-template <int PT>
+#ifdef GBNF_IMG_STAMPS
+#define IMG_STAMP(k)                                                                         \
+  do {                                                                                       \
+    unsigned long long t_;                                                                   \
+    __builtin_amdgcn_sched_barrier(0);                                                       \
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");              \
+    __builtin_amdgcn_sched_barrier(0);                                                       \
+    if ((k) >= 0) stamp_acc[(k)] += t_ - stamp_last;                                         \
+    stamp_last = t_;                                                                         \
+  } while (0)
+#else
+#define IMG_STAMP(k) do { } while (0)
+#endif
+
+template <int PT, int IMG_PRE_KC>
 __global__ void __launch_bounds__(64 * IMG_WAVES) img_mid_hx3_kernel(const MidLaunch p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
   typedef const float __attribute__((address_space(1)))* gptr;
@@ -58,6 +78,10 @@ __global__ void __launch_bounds__(64 * IMG_WAVES) img_mid_hx3_kernel(const MidLa
   const int OT = (p.hid + 15) >> 4, KC = chp >> 5;
   unsigned char* HB = lds_raw;                              // [NPIX][pixb]
   float* zin = reinterpret_cast<float*>(lds_raw + (size_t)NPIX * pixb);   // [16][RPz][WPz]
+#ifdef GBNF_IMG_STAMPS
+  unsigned long long stamp_last = 0, stamp_acc[6] = {0, 0, 0, 0, 0, 0};
+#endif
+  IMG_STAMP(-1);
 
   // ---- stage z1 (strip + halo, zero padded)
   {
@@ -77,38 +101,60 @@ __global__ void __launch_bounds__(64 * IMG_WAVES) img_mid_hx3_kernel(const MidLa
     }
   }
   __syncthreads();
+  IMG_STAMP(0);
 
-  // ---- first 3x3 on f32 MFMA (k-step r covers input channels 4r..4r+3: ceil(cin/4) k-steps), relu, split -> HB
+  // ---- first 3x3 as ONE small f16x3 GEMM: its 9 taps x cin input channels are folded into the contraction
+  //      (k = tap * cin + ci, padded to 32 * pre_kc), so a lane's B operand is an im2col gather of 8 values of its pixel
+  //      -- built ONCE per pixel tile from a host-made offset table and reused by every output tile; relu, split -> HB
   {
-    gptr pw = (gptr)p.pre_wp, pb = (gptr)p.pre_bias;
-    const int ks4 = (p.pre_cin + 3) >> 2;
+    gptr pb = (gptr)p.pre_bias;
+    const gv4 pw = (gv4)p.pre_wp;
+    const int kcp = p.pre_kc;                               // 32-wide chunks of the folded contraction (<= IMG_PRE_KC)
     const int kt = chp >> 4;                                // 16-channel tiles of the padded hidden width
-    int zoff[PT];
+    u32x4 bh[IMG_PRE_KC][PT], bm[IMG_PRE_KC][PT];
 #pragma unroll
-    for (int pt = 0; pt < PT; ++pt) {
-      const int lin = 16 * pt + i, pr = lin / W, pc = lin % W;
-      zoff[pt] = g * CSz + (pr + 1) * WPz + pc + 1;
+    for (int c = 0; c < IMG_PRE_KC; ++c) {
+      if (c < kcp) {
+        const int* ko = p.pre_koff + 32 * c + 8 * g;        // float offsets from the 3x3 window's corner; < 0: padding
+        int off[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) off[j] = ko[j];
+#pragma unroll
+        for (int pt = 0; pt < PT; ++pt) {
+          const int lin = 16 * pt + i, pr = lin / W, pc = lin % W;
+          const float* ctr = zin + pr * WPz + pc;             // top-left corner of the pixel's 3x3 window (offsets >= 0)
+          float v[8];
+#pragma unroll
+          for (int j = 0; j < 8; ++j) v[j] = off[j] >= 0 ? ctr[off[j]] : 0.0f;
+          unsigned h[4], m[4];
+#pragma unroll
+          for (int q = 0; q < 4; ++q) img_split_pair(v[2 * q], v[2 * q + 1], h[q], m[q]);
+          bh[c][pt] = u32x4{h[0], h[1], h[2], h[3]};
+          bm[c][pt] = u32x4{m[0], m[1], m[2], m[3]};
+        }
+      }
     }
-    auto load9 = [&](int o, f32x4 (&af)[9]) {
-      const int oo = o < kt ? o : 0;
+    auto load_pa = [&](int o, u32x4 (&ah)[IMG_PRE_KC], u32x4 (&am)[IMG_PRE_KC]) {
+      const int oo = o < kt ? o : 0;                          // past the end: a valid tile again (unused)
 #pragma unroll
-      for (int t = 0; t < 9; ++t)
-        af[t] = *reinterpret_cast<const f32x4 __attribute__((address_space(1)))*>(pw + ((size_t)oo * 9 + t) * 256 + lane * 4);
+      for (int c = 0; c < IMG_PRE_KC; ++c) {
+        const gv4 f = pw + ((size_t)oo * kcp + (c < kcp ? c : 0)) * 128 + lane;
+        ah[c] = f[0];
+        am[c] = f[64];
+      }
     };
-    f32x4 af[2][9];
-    load9(wave, af[0]);
-    auto pre_tile = [&](int o, const f32x4 (&a)[9]) {
+    auto pre_tile = [&](int o, const u32x4 (&ah)[IMG_PRE_KC], const u32x4 (&am)[IMG_PRE_KC]) {
       f32x4 acc[PT];
 #pragma unroll
       for (int pt = 0; pt < PT; ++pt) acc[pt] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-      for (int t = 0; t < 9; ++t) {
-        const int dy = t / 3 - 1, dx = t % 3 - 1;
+      for (int c = 0; c < IMG_PRE_KC; ++c) {
+        if (c < kcp) {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          if (r < ks4) {
-#pragma unroll
-            for (int pt = 0; pt < PT; ++pt) acc[pt] = img_mfma(a[t][r], zin[zoff[pt] + (4 * r) * CSz + dy * WPz + dx], acc[pt]);
+          for (int pt = 0; pt < PT; ++pt) {
+            acc[pt] = img_mfma16(am[c], bh[c][pt], acc[pt]);
+            acc[pt] = img_mfma16(ah[c], bm[c][pt], acc[pt]);
+            acc[pt] = img_mfma16(ah[c], bh[c][pt], acc[pt]);
           }
         }
       }
@@ -132,14 +178,17 @@ __global__ void __launch_bounds__(64 * IMG_WAVES) img_mid_hx3_kernel(const MidLa
         *reinterpret_cast<u32x2*>(px + 2 * chp) = mid;
       }
     };
+    u32x4 ah[2][IMG_PRE_KC], am[2][IMG_PRE_KC];
+    load_pa(wave, ah[0], am[0]);
     for (int o = wave; o < kt; o += 2 * IMG_WAVES) {
-      load9(o + IMG_WAVES, af[1]);
-      pre_tile(o, af[0]);
-      load9(o + 2 * IMG_WAVES, af[0]);
-      if (o + IMG_WAVES < kt) pre_tile(o + IMG_WAVES, af[1]);
+      load_pa(o + IMG_WAVES, ah[1], am[1]);
+      pre_tile(o, ah[0], am[0]);
+      load_pa(o + 2 * IMG_WAVES, ah[0], am[0]);
+      if (o + IMG_WAVES < kt) pre_tile(o + IMG_WAVES, ah[1], am[1]);
     }
   }
   __syncthreads();
+  IMG_STAMP(1);
 
   // ---- 1x1 hidden -> hidden, f16x3: this wave's (<= 4) output tiles x PT pixel tiles, B operands shared by the tiles
   constexpr int MAXO = 4;
@@ -199,6 +248,7 @@ __global__ void __launch_bounds__(64 * IMG_WAVES) img_mid_hx3_kernel(const MidLa
   }
 #pragma unroll
   for (int q = 0; q < MAXO; ++q) img_drain(acc[q]);
+  IMG_STAMP(2);
 
   // ---- relu(. + bias) -> split -> HBM (NHWC split-f16)
   gptr bias = (gptr)p.bias;
@@ -228,6 +278,11 @@ __global__ void __launch_bounds__(64 * IMG_WAVES) img_mid_hx3_kernel(const MidLa
       }
     }
   }
+  IMG_STAMP(3);
+#ifdef GBNF_IMG_STAMPS
+  if (p.dbg != nullptr && threadIdx.x == 0)
+    for (int k = 0; k < 6; ++k) p.dbg[(size_t)blockIdx.x * 6 + k] = stamp_acc[k];
+#endif
 }
 
 struct LastLaunch {
