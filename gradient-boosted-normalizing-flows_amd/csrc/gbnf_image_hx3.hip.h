@@ -250,7 +250,9 @@ __global__ void __launch_bounds__(64 * IMG_WAVES) img_mid_hx3_kernel(const MidLa
   for (int q = 0; q < MAXO; ++q) img_drain(acc[q]);
   IMG_STAMP(2);
 
-  // ---- relu(. + bias) -> split -> HBM (NHWC split-f16)
+  // ---- relu(. + bias) -> split -> back into HB (its input role is over) -> HBM as NHWC split-f16 with 16-byte, fully
+  //      coalesced copies (a lane's own 8-byte pieces would reach HBM as 32-byte fragments)
+  __syncthreads();                                         // every wave is done reading HB as the 1x1's input
   gptr bias = (gptr)p.bias;
 #pragma unroll
   for (int q = 0; q < MAXO; ++q) {
@@ -258,24 +260,34 @@ __global__ void __launch_bounds__(64 * IMG_WAVES) img_mid_hx3_kernel(const MidLa
       const int o = ow[q];
 #pragma unroll
       for (int pt = 0; pt < PT; ++pt) {
-        const int lin = 16 * pt + i, row = r0 + lin / W, col = lin % W;
-        if (row < H) {
-          float v[4];
+        const int lin = 16 * pt + i;
+        float v[4];
 #pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            const int co = 16 * o + 4 * g + r;
-            v[r] = co < p.hid ? fmaxf(acc[q][pt][r] + bias[co], 0.0f) : 0.0f;
-          }
-          unsigned h01, m01, h23, m23;
-          img_split_pair(v[0], v[1], h01, m01);
-          img_split_pair(v[2], v[3], h23, m23);
-          const u32x2 hi = {h01, h23}, mid = {m01, m23};
-          unsigned char* px = reinterpret_cast<unsigned char*>(p.h2) + (((int64_t)n * H + row) * W + col) * (int64_t)(4 * chp)
-                              + 2 * (16 * o + 4 * g);
-          *reinterpret_cast<u32x2*>(px) = hi;
-          *reinterpret_cast<u32x2*>(px + 2 * chp) = mid;
+        for (int r = 0; r < 4; ++r) {
+          const int co = 16 * o + 4 * g + r;
+          v[r] = co < p.hid ? fmaxf(acc[q][pt][r] + bias[co], 0.0f) : 0.0f;
         }
+        unsigned h01, m01, h23, m23;
+        img_split_pair(v[0], v[1], h01, m01);
+        img_split_pair(v[2], v[3], h23, m23);
+        unsigned char* px = HB + (size_t)lin * pixb + 2 * (16 * o + 4 * g);
+        *reinterpret_cast<u32x2*>(px) = u32x2{h01, h23};
+        *reinterpret_cast<u32x2*>(px + 2 * chp) = u32x2{m01, m23};
       }
+    }
+  }
+  __syncthreads();
+  {
+    // this workgroup's channels [16 o_begin, 16 o_end): per pixel one run in the hi half and one in the mid half
+    const int run_units = (o_end - o_begin) * 2;            // 16-byte units per run (a tile = 16 halfs = 32 B)
+    const int per_pix = 2 * run_units;
+    unsigned char* dst0 = reinterpret_cast<unsigned char*>(p.h2) + ((int64_t)n * H + r0) * W * (int64_t)(4 * chp);
+    const int rows = min(IMG_R, H - r0);
+    for (int e = threadIdx.x; e < rows * W * per_pix; e += 64 * IMG_WAVES) {
+      const int px = e / per_pix, u = e - px * per_pix;
+      const int half = u / run_units, k = u - half * run_units;
+      const int boff = half * 2 * chp + 32 * o_begin + 16 * k;
+      *reinterpret_cast<u32x4*>(dst0 + (int64_t)px * (4 * chp) + boff) = *reinterpret_cast<const u32x4*>(HB + (size_t)px * pixb + boff);
     }
   }
   IMG_STAMP(3);
