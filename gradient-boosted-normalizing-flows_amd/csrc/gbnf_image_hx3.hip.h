@@ -322,19 +322,21 @@ __global__ void __launch_bounds__(64 * IMG_WAVES) img_last_hx3_kernel(const Last
   const int OT = (p.cout + 15) >> 4;                        // <= 3
   unsigned char* HB = lds_raw;                              // [RP * WP][pixb]
 
-  // ---- stage strip + halo: a pixel is 4*chp contiguous bytes in HBM; outside the image: zeros
+  // ---- stage strip + halo: a pixel is 4*chp contiguous bytes in HBM (a wave moves one pixel per pass, lane = 16-byte
+  //      unit: fully coalesced, no index arithmetic beyond the pixel's row / column); outside the image: zeros
   {
     const int units = chp >> 2;                             // 16-byte units per pixel
-    const int total = RP * WP * units;
     const unsigned char* src = reinterpret_cast<const unsigned char*>(p.h2) + (int64_t)n * H * W * (int64_t)(4 * chp);
-    for (int e = threadIdx.x; e < total; e += 64 * IMG_WAVES) {
-      const int px = e / units, u = e - px * units;
+    for (int px = wave; px < RP * WP; px += IMG_WAVES) {
       const int rr = px / WP, cc = px - rr * WP;
       const int row = r0 + rr - 1, col = cc - 1;
-      u32x4 v = {0u, 0u, 0u, 0u};
-      if (row >= 0 && row < H && col >= 0 && col < W)
-        v = *reinterpret_cast<const u32x4*>(src + ((int64_t)row * W + col) * (int64_t)(4 * chp) + 16 * u);
-      *reinterpret_cast<u32x4*>(HB + (size_t)px * pixb + 16 * u) = v;
+      const bool inside = row >= 0 && row < H && col >= 0 && col < W;
+      const unsigned char* s0 = src + ((int64_t)row * W + col) * (int64_t)(4 * chp);
+      for (int u = lane; u < units; u += 64) {
+        u32x4 v = {0u, 0u, 0u, 0u};
+        if (inside) v = *reinterpret_cast<const u32x4*>(s0 + 16 * u);
+        *reinterpret_cast<u32x4*>(HB + (size_t)px * pixb + 16 * u) = v;
+      }
     }
   }
   __syncthreads();

@@ -30,6 +30,7 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
+    ap.add_argument("--graph", action="store_true", help="capture one step in a HIP graph and replay it")
     a = ap.parse_args()
     from gbnf_amd import native, synth
     from oracle import gbnf_oracle as oracle
@@ -49,11 +50,27 @@ def main():
     for _ in range(a.warmup):
         G = step()
     torch.cuda.synchronize()
+    run = step
+    if a.graph:      # the ~50 launches per component replayed as one HIP graph (same kernels, same buffers)
+        graph = torch.cuda.CUDAGraph()
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            step()
+        torch.cuda.current_stream().wait_stream(side)
+        with torch.cuda.graph(graph):
+            G_static = step()
+
+        def run():
+            graph.replay()
+            return G_static
+        run()
+        torch.cuda.synchronize()
     ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     t0 = time.perf_counter()
     ev0.record()
     for _ in range(a.steps):
-        G = step()
+        G = run()
     ev1.record()
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / a.steps
@@ -80,7 +97,8 @@ def main():
         "n_gpus": 1, "steps": a.steps, "warmup": a.warmup, "ms_per_step": dt * 1e3, "higher_is_better": True,
         "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": f"cifar_glow: 3x32x32, C={a.components} components, K={a.K} steps x L={a.L} levels, h={a.hidden}, "
-                               f"invconv, affine, learn_top, batch={a.batch}, synthetic images + weights"},
+                               f"invconv, affine, learn_top, batch={a.batch}, synthetic images + weights",
+                   "launch": "HIP graph replay" if a.graph else "stream launches"},
         "roofline": {"kernel": "gbnf::img_conv_kernel (all convolutions)", "bound": "mfma", "achieved": flops / (gpu_ms * 1e-3) / 1e12,
                      "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": flops / (gpu_ms * 1e-3) / 1e12 / F32_MFMA_PEAK_TFLOPS,
                      "traffic": None, "gpu_ms_per_step": gpu_ms, "flops_per_step": flops},
