@@ -259,3 +259,49 @@ def test_boosted_training_loop_like_the_reference():
         m.rho[1] = 0.5
         nll_mix = -m.log_prob(xt, n_used=2).mean().item()
     assert math.isfinite(nll_mix) and nll_mix < nll_first + 0.05, (nll_first, nll_mix)
+
+
+def _random_train_cases():
+    rng = np.random.RandomState(77)
+    cases = []
+    for k in range(14):
+        kind = "glow" if k % 3 else "realnvp"
+        d = int(rng.choice([2, 3, 5, 8, 13, 21, 43, 50, 64]))
+        h = int(rng.choice([7, 16, 33, 64, 105, 129, 215, 256]))
+        K = int(rng.randint(1, 5))
+        n = int(rng.choice([1, 15, 17, 33, 100, 257]))
+        depth = int(rng.choice([0, 1, 1, 2]))
+        if kind == "glow":
+            extra = dict(act=str(rng.choice(["tanh", "relu"])), coupling=str(rng.choice(["affine", "additive"])),
+                         permutation=str(rng.choice(["shuffle", "reverse"])), depth=depth)
+        else:
+            extra = dict(coupling_network=str(rng.choice(["tanh", "relu", "mixed"])), batch_norm=bool(rng.randint(2)),
+                         flip_init=int(rng.randint(2)), depth=depth)
+        cases.append((kind, d, h, K, n, extra, 900 + k))
+    return cases
+
+
+@pytest.mark.parametrize("kind,d,h,K,n,extra,seed", _random_train_cases())
+def test_trainer_random_shapes_against_oracle(kind, d, h, K, n, extra, seed):
+    """Randomised geometry sweep of the training kernels (ragged rows / columns of every Linear, odd d, 1..4 steps,
+    depth 0..2, ragged batches) against the float64 autograd oracle."""
+    import torch
+    from gbnf_amd import native, synth
+    from oracle import gbnf_oracle as oracle
+    dev = torch.device("cuda:0")
+    spec = (synth.synth_glow_spec(d, h, K, seed=seed, **extra) if kind == "glow"
+            else synth.synth_realnvp_spec(d, h, K, seed=seed, **extra))
+    x = synth.synth_batch(n, d, seed=seed + 1)
+    rng = np.random.RandomState(seed)
+    g_z = rng.standard_normal(x.shape).astype(np.float32)
+    g_l = rng.standard_normal(n).astype(np.float32)
+    tr = native.NativeTrainer(_dev_spec(spec, dev))
+    xd = torch.from_numpy(x).to(dev)
+    z, ldj, trace = tr.forward(xd, want_trace=True)
+    z64, ldj64 = oracle.component_forward(spec, x, backend="numpy64")
+    assert np.abs(ldj.cpu().numpy() - ldj64).max() <= 1e-5 * max(1.0, float(np.abs(ldj64).max()))
+    assert np.abs(z.cpu().numpy() - z64).max() <= 2e-5 * max(1.0, float(np.abs(z64).max()))
+    gx64, grads64 = oracle.component_grads(spec, x, g_z, g_l)
+    gx, grads = tr.backward(xd, torch.from_numpy(g_z).to(dev), torch.from_numpy(g_l).to(dev), want_gx=True, trace=trace)
+    _check_grads(grads, grads64, f"{kind} d={d} h={h} K={K} n={n} {extra}")
+    assert np.abs(gx.cpu().numpy() - gx64).max() <= G_RTOL * max(float(np.abs(gx64).max()), 1e-3)
