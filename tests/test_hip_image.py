@@ -93,3 +93,33 @@ def test_image_module_dropin_matches_reference():
         z, z_mu, z_var, ldj, y = m(x=xd, components=1)              # fresh noise: shapes and the constant prior only
         assert y is None and z.shape == (cfg["N"], 24, 8, 8) and z_mu.shape == z.shape and z_var.shape == z.shape
         assert torch.isfinite(ldj).all()
+
+
+def _random_image_cases():
+    rng = np.random.RandomState(11)
+    cases = []
+    for k in range(10):
+        cases.append(dict(h=int(rng.choice([8, 16, 24, 32, 48, 100])), K=int(rng.randint(1, 3)), L=int(rng.choice([1, 2])),
+                          depth=int(rng.choice([0, 1, 1, 2])), coupling=str(rng.choice(["affine", "additive"])),
+                          permutation=str(rng.choice(["invconv", "shuffle", "reverse"])), learn_top=bool(rng.randint(2)),
+                          n=int(rng.choice([1, 3, 5])), seed=300 + k))
+    return cases
+
+
+@pytest.mark.parametrize("case", _random_image_cases(), ids=lambda c: f"h{c['h']}K{c['K']}L{c['L']}d{c['depth']}{c['coupling'][:3]}{c['permutation'][:3]}")
+def test_image_random_geometry_against_oracle(case):
+    """Hidden widths that are not multiples of 32 (padded split-f16 layout), depth 0 / 2 (exact-f32 kernels), one level
+    (16x16 maps only), every permutation kind, both couplings -- against the float64 oracle."""
+    import torch
+    from gbnf_amd import native, synth
+    from oracle import gbnf_oracle as oracle
+    c = dict(case)
+    n, seed = c.pop("n"), c.pop("seed")
+    sp = synth.synth_image_glow_spec((3, 32, 32), seed=seed, **c)
+    x, noise = synth.synth_image_batch(n, seed=seed + 1)
+    z64, _, _, ld64, ll64 = oracle.image_component_forward(sp, x, noise, dtype=torch.float64)
+    dev = torch.device("cuda:0")
+    z, ldj, ll = native.NativeImageFlow(sp).forward(torch.from_numpy(x).to(dev), torch.from_numpy(noise).to(dev))
+    assert rel_err(ll.cpu().numpy(), ll64) < LL_RTOL
+    assert rel_err(ldj.cpu().numpy(), ld64) < LL_RTOL
+    assert np.abs(z.cpu().numpy() - z64).max() <= 2e-4 * max(1.0, float(np.abs(z64).max()))
