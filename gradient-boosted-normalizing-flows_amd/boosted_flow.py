@@ -437,10 +437,6 @@ class BoostedFlow(nn.Module):
         """The training-path handle of component c: bound to the parameter tensors' device addresses, re-created only
         when a tensor is re-allocated or a permutation changes (in-place optimiser updates need nothing)."""
         flow = self.flows[c]
-        if self.component_type != "glow" and self.training and any(len(m) > 2 for m in flow.flow_param):
-            raise NotImplementedError(
-                "train-mode BatchNorm (batch statistics, models/layers.py:339-346) is not on the supported path; "
-                "differentiate RealNVP components in eval() mode (running statistics) or build them without batch_norm")
         key = [t.data_ptr() for t in list(flow.parameters()) + list(flow.buffers())]
         if self.component_type == "glow":
             key += [tuple(layer.permutation.indices.tolist()) for layer in flow.flow.layers]
@@ -510,8 +506,19 @@ class BoostedFlow(nn.Module):
         with torch.cuda.device(x.device):
             if self._needs_grad(x, int(c)) if differentiable is None else bool(differentiable):
                 trainer = self.native_trainer(int(c))
+                # train(): BatchNorm normalises with the batch statistics and updates its running ones (models/layers.py:338-346)
+                batch_stats = bool(self.training and trainer.has_batch_stats)
+                trainer.set_batch_stats(batch_stats)
                 params = [t for t in trainer.params if t is not None]
-                return _FlowFunction.apply(trainer, x, *params)
+                out = _FlowFunction.apply(trainer, x, *params)
+                if batch_stats:
+                    with torch.no_grad():
+                        for mods in self.flows[int(c)].flow_param:
+                            bn = mods[2] if len(mods) > 2 else None
+                            if bn is not None:
+                                bn.running_mean.mul_(bn.momentum).add_(bn.batch_mean * (1 - bn.momentum))
+                                bn.running_var.mul_(bn.momentum).add_(bn.batch_var * (1 - bn.momentum))
+                return out
             z, ldj, _ = self.native_flow(int(c)).forward(x)
         return z, ldj
 

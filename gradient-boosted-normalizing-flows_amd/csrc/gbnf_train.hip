@@ -26,6 +26,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cmath>
+#include <cstddef>
 #include <cstdint>
 #include <cstring>
 #include <vector>
@@ -66,6 +67,8 @@ struct TrStep {
   const float* nb;     // glow: actnorm logs   | realnvp: bn beta
   const float* mean;   // realnvp: bn running_mean
   const float* var;    // realnvp: bn running_var
+  float* bmean;        // realnvp: batch statistics of this step's input (batch-statistics mode), (d,) each
+  float* bvar;
   float eps;
   int pad1;
   int64_t g_na, g_nb;  // float offsets into the flat gradient buffer
@@ -82,6 +85,15 @@ struct TrainLaunch {
   float* ldj_out;      // MODE 0
   float* trace_out;    // MODE 0, optional: every step's normalised state [K][d][np], saved for the backward
   const float* trace;  // MODE 1, optional: that buffer (else the forward sweep is recomputed)
+  // step-range launches (batch-statistics BatchNorm needs a grid-wide reduction between steps): the state / its gradient
+  // travel between launches in slot layout [d][np]
+  int k_begin, k_end;        // steps [k_begin, k_end) of the K
+  int batch_stats;           // BatchNorm normalises with TrStep::bmean / bvar instead of the running statistics
+  int ldj_accumulate;        // MODE 0: ldj_out += instead of =
+  const float* state_in;     // MODE 0: state before step k_begin (null: x, row-major)
+  float* state_out;          // MODE 0: state after step k_end - 1 (null: z_out / none)
+  const float* gstate_in;    // MODE 1: gradient w.r.t. the state after step k_end - 1 (null: g_z through the final map)
+  float* gstate_out;         // MODE 1: gradient w.r.t. the state before step k_begin (null: g_x, row-major)
   const float* g_z;    // MODE 1 (n, d) or null
   const float* g_ldj;  // MODE 1 (n,) or null
   float* g_x;          // MODE 1 (n, d) or null
@@ -355,8 +367,10 @@ __global__ void __launch_bounds__(64 * TR_WAVES) train_kernel(const TrainLaunch 
           p0 = st.na[f];                                   // y = (x + bias) * exp(logs)
           p1 = __expf(p3);
         } else if (st.has_norm) {
-          const float ve = st.var[f] + st.eps, lg = st.na[f];
-          p0 = st.mean[f];                                 // y = (x - mean) * [exp(log_gamma) / sqrt(var + eps)] + beta
+          const float* mu = p.batch_stats ? st.bmean : st.mean;
+          const float* vr = p.batch_stats ? st.bvar : st.var;
+          const float ve = vr[f] + st.eps, lg = st.na[f];
+          p0 = mu[f];                                      // y = (x - mean) * [exp(log_gamma) / sqrt(var + eps)] + beta
           p1 = __expf(lg) / sqrtf(ve);
           p2 = st.nb[f];
           p3 = lg - 0.5f * __logf(ve);                     // models/layers.py:357-358
@@ -434,18 +448,23 @@ __global__ void __launch_bounds__(64 * TR_WAVES) train_kernel(const TrainLaunch 
     });
   };
 
-  // ---- x tile -> Zc (slot j = feature j)
-  for (int j = g; j < d; j += GS) Zc[j * S + i] = valid ? p.x[ni * d + j] : 0.0f;
+  // ---- x tile -> Zc (slot j = feature j), or the state a previous step-range launch left in slot layout
+  if (MODE == 0 && p.state_in != nullptr) {
+    for (int s = g; s < d; s += GS) Zc[s * S + i] = p.state_in[(size_t)s * p.np + row0 + i];
+  } else {
+    for (int j = g; j < d; j += GS) Zc[j * S + i] = valid ? p.x[ni * d + j] : 0.0f;
+  }
   __syncthreads();    // (also: the tables are complete)
   stamps.mark(0);
 
   // =============================== forward through all steps
   float ld = 0.0f;   // per-lane partial of log|det J| (every lane group adds its own slots / features)
   const bool have_trace = (MODE == 1) && p.trace != nullptr;
+  const int kb = p.k_begin, ke = p.k_end;
   if (have_trace) {  // the forward call saved every step's normalised state: just bring this tile's columns in
-    for (int e = g; e < K * d; e += GS) Y[(size_t)e * S + i] = p.trace[(size_t)e * p.np + row0 + i];
+    for (int e = g + kb * d; e < ke * d; e += GS) Y[(size_t)e * S + i] = p.trace[(size_t)e * p.np + row0 + i];
   }
-  for (int k = 0; k < (have_trace ? 0 : K); ++k) {
+  for (int k = kb; k < (have_trace ? kb : ke); ++k) {
     const TrStep& st = p.steps[k];
     for (int s = g; s < d; s += GS) {
       const float y = norm_fwd(k, s, Zc[s * S + i], ld);
@@ -453,7 +472,7 @@ __global__ void __launch_bounds__(64 * TR_WAVES) train_kernel(const TrainLaunch 
       if (MODE == 1) Y[((size_t)k * d + s) * S + i] = y;
       if (MODE == 0 && p.trace_out != nullptr) p.trace_out[((size_t)k * d + s) * p.np + row0 + i] = y;
     }
-    if (MODE == 1 && k == K - 1) break;                    // the last step's outputs are not needed for the backward
+    if (MODE == 1 && k == ke - 1) break;                   // the last step's outputs are not needed for the backward
     __syncthreads();
     const int* ti = TI + k * 64;
     for (int kk = g; kk < p.ip; kk += GS) X[kk * S + i] = kk < st.in_f ? Zc[ti[kk] * S + i] : 0.0f;
@@ -495,13 +514,15 @@ __global__ void __launch_bounds__(64 * TR_WAVES) train_kernel(const TrainLaunch 
     __syncthreads();
     if (valid) {
       if (p.ldj_out != nullptr && g == 0) {
-        float t = 0.0f;
+        float t = p.ldj_accumulate ? p.ldj_out[ni] : 0.0f;
         for (int w = 0; w < TR_WAVES; ++w) t += X[w * 16 + i];
         p.ldj_out[ni] = t;
       }
-      if (p.z_out != nullptr)
+      if (p.z_out != nullptr && ke == K)
         for (int j = g; j < d; j += GS) p.z_out[ni * d + j] = Zc[p.tail[j] * S + i];
     }
+    if (p.state_out != nullptr)
+      for (int s = g; s < d; s += GS) p.state_out[(size_t)s * p.np + row0 + i] = Zc[s * S + i];
     stamps.mark(4);
 #ifdef GBNF_TRAIN_STAMPS
     if (p.dbg != nullptr && threadIdx.x == 0)
@@ -512,7 +533,11 @@ __global__ void __launch_bounds__(64 * TR_WAVES) train_kernel(const TrainLaunch 
     // =============================== backward
     __syncthreads();
     const float gl = (valid && p.g_ldj != nullptr) ? p.g_ldj[ni] : 0.0f;
-    for (int j = g; j < d; j += GS) Zc[p.tail[j] * S + i] = (valid && p.g_z != nullptr) ? p.g_z[ni * d + j] : 0.0f;
+    if (p.gstate_in != nullptr) {
+      for (int s = g; s < d; s += GS) Zc[s * S + i] = p.gstate_in[(size_t)s * p.np + row0 + i];
+    } else {
+      for (int j = g; j < d; j += GS) Zc[p.tail[j] * S + i] = (valid && p.g_z != nullptr) ? p.g_z[ni * d + j] : 0.0f;
+    }
     __syncthreads();
     float* G = Zc;
     const int nnets = (KIND == GBNF_KIND_GLOW) ? 1 : 2;
@@ -540,7 +565,7 @@ __global__ void __launch_bounds__(64 * TR_WAVES) train_kernel(const TrainLaunch 
       return gx;
     };
 
-    for (int k = K - 1; k >= 0; --k) {
+    for (int k = ke - 1; k >= kb; --k) {
       const TrStep& st = p.steps[k];
       const float* Yk = Y + (size_t)k * d * S;
       float* ws_step = p.ws + (size_t)k * nnets * p.net_rows * p.np;
@@ -599,8 +624,11 @@ __global__ void __launch_bounds__(64 * TR_WAVES) train_kernel(const TrainLaunch 
       }
       __syncthreads();
     }
-    if (valid && p.g_x != nullptr)
+    if (p.gstate_out != nullptr) {
+      for (int s = g; s < d; s += GS) p.gstate_out[(size_t)s * p.np + row0 + i] = G[s * S + i];
+    } else if (valid && p.g_x != nullptr) {
       for (int j = g; j < d; j += GS) p.g_x[ni * d + j] = G[j * S + i];
+    }
   }
 }
 
@@ -704,6 +732,64 @@ __global__ void __launch_bounds__(64) wgrad_kernel(const WgProblem* __restrict__
   }
 }
 
+// ---- batch-statistics BatchNorm (models/layers.py:338-358 in train mode): the pieces that need the whole batch ----------
+// (n, d) row-major <-> slot layout [d][np] (slot j = feature j at the input of step 0)
+__global__ void __launch_bounds__(256) rows_to_slots_kernel(const float* __restrict__ x, float* __restrict__ st, int64_t n, int64_t np, int d) {
+  const int64_t s = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (s >= np) return;
+  for (int j = 0; j < d; ++j) st[(size_t)j * np + s] = s < n ? x[s * d + j] : 0.0f;
+}
+__global__ void __launch_bounds__(256) slots_to_rows_kernel(const float* __restrict__ st, float* __restrict__ x, int64_t n, int64_t np, int d) {
+  const int64_t s = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (s >= n) return;
+  for (int j = 0; j < d; ++j) x[s * d + j] = st[(size_t)j * np + s];
+}
+
+__device__ __forceinline__ float tr_block_sum(float v, float* red) {
+#pragma unroll
+  for (int m = 1; m < 64; m <<= 1) v += __shfl_xor(v, m);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+  __syncthreads();
+  return red[0] + red[1] + red[2] + red[3];
+}
+
+// One block per slot: mean and UNBIASED variance over the n valid samples of the state (two passes, fixed order).
+__global__ void __launch_bounds__(256) bn_stats_kernel(const TrStep* __restrict__ steps, int k, const float* __restrict__ st, int64_t n, int64_t np) {
+  __shared__ float red[4];
+  const TrStep& S = steps[k];
+  const int slot = blockIdx.x, f = S.feat[slot];
+  const float* col = st + (size_t)slot * np;
+  float a = 0.0f;
+  for (int64_t s = threadIdx.x; s < n; s += 256) a += col[s];
+  const float mean = tr_block_sum(a, red) / (float)n;
+  float b = 0.0f;
+  for (int64_t s = threadIdx.x; s < n; s += 256) {
+    const float c = col[s] - mean;
+    b += c * c;
+  }
+  const float var = tr_block_sum(b, red) / (float)(n - 1);
+  if (threadIdx.x == 0) {
+    S.bmean[f] = mean;
+    S.bvar[f] = var;
+  }
+}
+
+// Backward through the batch statistics of step k, applied to the gradient state the step's backward launch left behind
+// (which treated mean / var as constants):   g_x -= (gamma / sigma) * S1 / n  +  x_hat / (sigma (n - 1)) * S2,
+// S1 = sum g_y = d/d beta,  S2 = gamma sum g_y x_hat + sum g_ldj = d/d log_gamma -- both already in `grads`.
+__global__ void __launch_bounds__(256) bn_bwd_fix_kernel(const TrStep* __restrict__ steps, int k, int d, const float* __restrict__ trace, const float* __restrict__ grads,
+                                                         float* __restrict__ gst, int64_t n, int64_t np) {
+  const TrStep& S = steps[k];
+  const int slot = blockIdx.y, f = S.feat[slot];
+  const int64_t s = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (s >= n) return;
+  const float gamma = __expf(S.na[f]), beta = S.nb[f], sigma = sqrtf(S.bvar[f] + S.eps);
+  const float s1 = grads[S.g_nb + f], s2 = grads[S.g_na + f];
+  const float xhat = (trace[((size_t)k * d + slot) * np + s] - beta) / gamma;
+  gst[(size_t)slot * np + s] -= gamma / sigma * s1 / (float)n + xhat / (sigma * (float)(n - 1)) * s2;
+}
+
 // W (rows x cols) -> W^T (cols x rows) for every Linear of the component, one launch (32 x 32 tiles through LDS).
 struct TpProblem {
   const float* W;
@@ -747,9 +833,21 @@ struct gbnf_trainer {
   TpProblem* tp_dev = nullptr;
   int n_probs = 0, wg_blocks = 0, tp_blocks = 0;
   int64_t wt_floats = 0;
+  int batch_stats = 0;                 // BatchNorm on batch statistics (the reference's train() mode)
+  std::vector<int> has_norm;           // per step
+  std::vector<char> stats_bound;       // per step: bmean / bvar bound by the caller
 };
 
 static int ceil16(int v) { return (v + 15) / 16 * 16; }
+
+template <int MODE>
+static void launch_train(const gbnf_trainer* t, const TrainLaunch& p, hipStream_t s) {
+  const dim3 grid((unsigned)(p.np / 16)), blk(64 * TR_WAVES);
+  const size_t lds = MODE == 0 ? t->lds_fwd : t->lds_bwd;
+  if (t->kind == GBNF_KIND_GLOW) hipLaunchKernelGGL((train_kernel<GBNF_KIND_GLOW, MODE>), grid, blk, lds, s, p);
+  else hipLaunchKernelGGL((train_kernel<GBNF_KIND_REALNVP, MODE>), grid, blk, lds, s, p);
+}
+
 
 extern "C" {
 
@@ -829,6 +927,8 @@ int gbnf_trainer_create(const gbnf_flow_desc* desc, gbnf_trainer** out) {
       in_f = r.flipped ? d2 : d1; out_f = r.flipped ? d1 : d2;
       nets[0] = &r.t_net; nets[1] = &r.s_net;
     }
+    t->has_norm.push_back(st.has_norm);
+    t->stats_bound.push_back(0);
     st.in_f = in_f; st.out_f = out_f;
     for (int j = 0; j < in_f; ++j) st.in_slot[j] = sigma[j];
     for (int j = 0; j < out_f; ++j) st.out_slot[j] = sigma[in_f + j];
@@ -913,7 +1013,8 @@ int gbnf_trainer_workspace_bytes(const gbnf_trainer* t, int64_t n, int64_t* byte
   if (!t || !bytes || n < 0) return fail(GBNF_ERR_INVALID, "gbnf_trainer_workspace_bytes: bad argument");
   const int64_t np = (n + 15) / 16 * 16;
   // operand regions + 64 slack rows (a 64-row block of wgrad_kernel may run past the last region) + transposed weights
-  *bytes = (((int64_t)t->K * t->nnets * t->net_rows + 64) * np + t->wt_floats) * 4;
+  // ... + the gradient state of step-by-step launches (batch-statistics BatchNorm)
+  *bytes = (((int64_t)t->K * t->nnets * t->net_rows + 64) * np + t->wt_floats + (int64_t)t->d * np) * 4;
   return GBNF_OK;
 }
 
@@ -931,11 +1032,44 @@ static void fill_launch(const gbnf_trainer* t, TrainLaunch& p, const float* x, i
   p.n = n; p.np = (n + 15) / 16 * 16;
   p.d = t->d; p.K = t->K; p.kind = t->kind; p.additive = t->additive;
   p.n_hidden = t->n_hidden; p.hp = t->hp; p.ip = t->ip; p.op = t->op; p.net_rows = t->net_rows;
+  p.k_begin = 0; p.k_end = t->K;
+}
+
+// batch-statistics mode is on and some step has a BatchNorm whose statistics must come from the batch
+static bool needs_step_launches(const gbnf_trainer* t) {
+  if (!t->batch_stats) return false;
+  for (int v : t->has_norm)
+    if (v) return true;
+  return false;
+}
+
+int gbnf_trainer_set_batch_stats(gbnf_trainer* t, int32_t on) {
+  if (!t) return fail(GBNF_ERR_INVALID, "gbnf_trainer_set_batch_stats: trainer is null");
+  if (on && t->kind == GBNF_KIND_REALNVP)
+    for (size_t k = 0; k < t->has_norm.size(); ++k)
+      if (t->has_norm[k] && !t->stats_bound[k])
+        return fail(GBNF_ERR_INVALID, "gbnf_trainer_set_batch_stats: step %d has a BatchNorm but no batch-statistics buffers "
+                    "(gbnf_trainer_bind_batch_stats)", (int)k);
+  t->batch_stats = on ? 1 : 0;
+  return GBNF_OK;
+}
+
+int gbnf_trainer_bind_batch_stats(gbnf_trainer* t, int32_t step, float* mean_dev, float* var_dev) {
+  if (!t || step < 0 || step >= t->K || !mean_dev || !var_dev)
+    return fail(GBNF_ERR_INVALID, "gbnf_trainer_bind_batch_stats: bad argument");
+  if (!t->has_norm[step] || t->kind != GBNF_KIND_REALNVP)
+    return fail(GBNF_ERR_INVALID, "gbnf_trainer_bind_batch_stats: step %d has no BatchNorm", step);
+  float* ptrs[2] = {mean_dev, var_dev};
+  const hipError_t e = hipMemcpy(reinterpret_cast<char*>(t->steps_dev + step) + offsetof(TrStep, bmean), ptrs, sizeof(ptrs),
+                                 hipMemcpyHostToDevice);
+  if (e != hipSuccess) return fail(GBNF_ERR_HIP, "gbnf_trainer_bind_batch_stats: %s", hipGetErrorString(e));
+  t->stats_bound[step] = 1;
+  return GBNF_OK;
 }
 
 int gbnf_trainer_trace_floats(const gbnf_trainer* t, int64_t n, int64_t* n_floats) {
   if (!t || !n_floats || n < 0) return fail(GBNF_ERR_INVALID, "gbnf_trainer_trace_floats: bad argument");
-  *n_floats = (int64_t)t->K * t->d * ((n + 15) / 16 * 16);
+  *n_floats = ((int64_t)t->K + 1) * t->d * ((n + 15) / 16 * 16);     // K normalised states + the running state
   return GBNF_OK;
 }
 
@@ -948,11 +1082,28 @@ int gbnf_trainer_forward(const gbnf_trainer* t, const float* x, int64_t n, float
   TrainLaunch p;
   fill_launch(t, p, x, n);
   p.z_out = z; p.ldj_out = ldj; p.trace_out = trace;
-  const dim3 grid((unsigned)(p.np / 16));
-  if (t->kind == GBNF_KIND_GLOW)
-    hipLaunchKernelGGL((train_kernel<GBNF_KIND_GLOW, 0>), grid, dim3(64 * TR_WAVES), t->lds_fwd, (hipStream_t)stream, p);
-  else
-    hipLaunchKernelGGL((train_kernel<GBNF_KIND_REALNVP, 0>), grid, dim3(64 * TR_WAVES), t->lds_fwd, (hipStream_t)stream, p);
+  p.batch_stats = t->batch_stats;
+  hipStream_t s = (hipStream_t)stream;
+  if (!needs_step_launches(t)) {
+    launch_train<0>(t, p, s);
+  } else {
+    // BatchNorm on batch statistics: a step's statistics need the whole batch, so the steps run one launch at a time
+    // with the state parked in HBM in slot layout (the last d*np floats of the trace buffer)
+    if (!trace || !ldj) return fail(GBNF_ERR_INVALID, "gbnf_trainer_forward: batch-statistics mode needs the trace buffer and ldj");
+    if (n < 2) return fail(GBNF_ERR_INVALID, "gbnf_trainer_forward: batch statistics need n >= 2");
+    float* state = trace + (int64_t)t->K * t->d * p.np;
+    const unsigned nb = (unsigned)((p.np + 255) / 256);
+    hipLaunchKernelGGL(rows_to_slots_kernel, dim3(nb), dim3(256), 0, s, x, state, n, p.np, t->d);
+    for (int k = 0; k < t->K; ++k) {
+      if (t->has_norm[k])
+        hipLaunchKernelGGL(bn_stats_kernel, dim3((unsigned)t->d), dim3(256), 0, s, (const TrStep*)t->steps_dev, k, (const float*)state, n, p.np);
+      TrainLaunch q = p;
+      q.k_begin = k; q.k_end = k + 1;
+      q.state_in = state; q.state_out = state;
+      q.ldj_accumulate = k > 0;
+      launch_train<0>(t, q, s);
+    }
+  }
   const hipError_t e = hipGetLastError();
   if (e != hipSuccess) return fail(GBNF_ERR_HIP, "gbnf_trainer_forward launch: %s", hipGetErrorString(e));
   return GBNF_OK;
@@ -973,15 +1124,33 @@ int gbnf_trainer_backward(const gbnf_trainer* t, const float* x, int64_t n, cons
   TrainLaunch p;
   fill_launch(t, p, x, n);
   p.g_z = g_z; p.g_ldj = g_ldj; p.g_x = g_x; p.grads = grads; p.ws = (float*)workspace; p.trace = trace;
+  p.batch_stats = t->batch_stats;
   float* wt = (float*)workspace + ((int64_t)t->K * t->nnets * t->net_rows + 64) * p.np;
+  float* gstate = wt + t->wt_floats;                       // [d][np]: gradient state between step launches
   p.wt = wt;
-  const dim3 grid((unsigned)(p.np / 16));
   hipStream_t s = (hipStream_t)stream;
   hipLaunchKernelGGL(transpose_kernel, dim3((unsigned)t->tp_blocks), dim3(256), 0, s, t->tp_dev, (int)(t->n_probs), wt);
-  if (t->kind == GBNF_KIND_GLOW)
-    hipLaunchKernelGGL((train_kernel<GBNF_KIND_GLOW, 1>), grid, dim3(64 * TR_WAVES), t->lds_bwd, s, p);
-  else
-    hipLaunchKernelGGL((train_kernel<GBNF_KIND_REALNVP, 1>), grid, dim3(64 * TR_WAVES), t->lds_bwd, s, p);
+  if (!needs_step_launches(t)) {
+    launch_train<1>(t, p, s);
+  } else {
+    // the mirror image of the forward: one launch per step; after a BatchNorm step the gradient state is corrected for
+    // the dependence of the batch statistics on every sample (its two batch sums are that step's d/d beta, d/d log_gamma)
+    if (!trace) return fail(GBNF_ERR_INVALID, "gbnf_trainer_backward: batch-statistics mode needs the forward call's trace");
+    for (int k = t->K - 1; k >= 0; --k) {
+      TrainLaunch q = p;
+      q.k_begin = k; q.k_end = k + 1;
+      q.gstate_in = (k == t->K - 1) ? nullptr : gstate;
+      q.gstate_out = gstate;
+      launch_train<1>(t, q, s);
+      if (t->has_norm[k]) {
+        const dim3 fg((unsigned)((n + 255) / 256), (unsigned)t->d);
+        hipLaunchKernelGGL(bn_bwd_fix_kernel, fg, dim3(256), 0, s, (const TrStep*)t->steps_dev, k, t->d, trace, (const float*)grads,
+                           gstate, n, p.np);
+      }
+    }
+    if (g_x != nullptr)
+      hipLaunchKernelGGL(slots_to_rows_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, (const float*)gstate, g_x, n, p.np, t->d);
+  }
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return fail(GBNF_ERR_HIP, "gbnf_trainer_backward launch: %s", hipGetErrorString(e));
   const dim3 wgrid((unsigned)t->wg_blocks, (unsigned)((p.np + WG_CHUNK - 1) / WG_CHUNK));

@@ -32,6 +32,7 @@ ABI_SYMBOLS = (
     "gbnf_actnorm_init", "gbnf_boosting_weights",
     "gbnf_flow_validate", "gbnf_trainer_create", "gbnf_trainer_destroy", "gbnf_trainer_forward",
     "gbnf_trainer_grad_floats", "gbnf_trainer_workspace_bytes", "gbnf_trainer_backward", "gbnf_trainer_trace_floats",
+    "gbnf_trainer_bind_batch_stats", "gbnf_trainer_set_batch_stats",
     "gbnf_image_flow_create", "gbnf_image_flow_destroy", "gbnf_image_flow_info", "gbnf_image_flow_workspace_bytes",
     "gbnf_image_flow_forward", "gbnf_image_flow_prior",
 )
@@ -134,6 +135,8 @@ def lib():
     L.gbnf_trainer_destroy.argtypes = [vp]
     L.gbnf_trainer_forward.argtypes = [vp, vp, i64, vp, vp, vp, vp]
     L.gbnf_trainer_trace_floats.argtypes = [vp, i64, C.POINTER(i64)]
+    L.gbnf_trainer_bind_batch_stats.argtypes = [vp, i32, vp, vp]
+    L.gbnf_trainer_set_batch_stats.argtypes = [vp, i32]
     L.gbnf_trainer_grad_floats.argtypes = [vp, C.POINTER(i64)]
     L.gbnf_trainer_workspace_bytes.argtypes = [vp, i64, C.POINTER(i64)]
     L.gbnf_trainer_backward.argtypes = [vp, vp, i64, vp, vp, vp, vp, vp, vp, i64, vp]
@@ -468,6 +471,22 @@ class NativeTrainer:
         h = C.c_void_p()
         _check(lib().gbnf_trainer_create(C.byref(desc), C.byref(h)))
         self.handle = h
+        # BatchNorm on batch statistics (the reference's train() mode): bind the buffers that receive them
+        self.has_batch_stats = False
+        if dev_spec["kind"] == "realnvp":
+            bound = 0
+            for k, st in enumerate(dev_spec["steps"]):
+                bn = st["bn"]
+                if bn is not None and bn.get("batch_mean") is not None:
+                    for t in (bn["batch_mean"], bn["batch_var"]):
+                        _require_device_f32(t, "batch statistics buffer")
+                        self._tensors.append(t)
+                    _check(lib().gbnf_trainer_bind_batch_stats(h, k, C.c_void_p(bn["batch_mean"].data_ptr()),
+                                                               C.c_void_p(bn["batch_var"].data_ptr())))
+                    bound += 1
+            n_bn = sum(1 for st in dev_spec["steps"] if st["bn"] is not None)
+            self.has_batch_stats = bound == n_bn and n_bn > 0
+        self.batch_stats = False
         nf = C.c_int64()
         _check(lib().gbnf_trainer_grad_floats(h, C.byref(nf)))
         self.grad_floats = int(nf.value)
@@ -477,6 +496,13 @@ class NativeTrainer:
 
     def key(self):
         return tuple(t.data_ptr() for t in self._tensors)
+
+    def set_batch_stats(self, on):
+        """RealNVP BatchNorm on batch statistics (True = the reference's train() mode) or running statistics (False)."""
+        on = bool(on)
+        if on != self.batch_stats:
+            _check(lib().gbnf_trainer_set_batch_stats(self.handle, int(on)))
+            self.batch_stats = on
 
     def forward(self, x, want_trace=False):
         """-> (z, ldj) or (z, ldj, trace): ``trace`` holds every step's normalised state; passing it to ``backward``

@@ -137,7 +137,9 @@ def device_spec_from_component(module):
             steps.append({
                 "flipped": bool(((k + int(module.flip_init)) % 2) > 0),
                 "bn": None if bn is None else {"log_gamma": bn.log_gamma, "beta": bn.beta, "running_mean": bn.running_mean,
-                                               "running_var": bn.running_var, "eps": float(bn.eps)},
+                                               "running_var": bn.running_var, "eps": float(bn.eps),
+                                               "batch_mean": getattr(bn, "batch_mean", None),
+                                               "batch_var": getattr(bn, "batch_var", None)},
                 "t_net": _dev_net(mods[0]), "s_net": _dev_net(mods[1])})
         return {"kind": "realnvp", "d": int(module.z_size), "steps": steps}
     steps, coupling, d = [], None, None

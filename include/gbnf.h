@@ -204,7 +204,7 @@ int gbnf_boosting_weights(const float* G, int64_t n, float beta, float* w_out, v
  * tensor in its reference layout (nn.Linear.weight (out,in) row-major, ...) and stays owned by the caller;
  * perm_indices stay HOST pointers.  Nothing is packed or copied, so parameters updated in place by an optimiser are
  * seen by the next call; re-create the trainer only when a tensor is re-allocated.  RealNVP BatchNorm is differentiated
- * in its running-statistics (eval) form, models/layers.py:347-358.
+ * in its running-statistics (eval) form, models/layers.py:347-358, unless gbnf_trainer_set_batch_stats(1).
  * --------------------------------------------------------------------------------------------------------------- */
 typedef struct gbnf_trainer gbnf_trainer;
 
@@ -220,6 +220,14 @@ int gbnf_trainer_destroy(gbnf_trainer* trainer);
 int gbnf_trainer_trace_floats(const gbnf_trainer* trainer, int64_t n, int64_t* n_floats);
 int gbnf_trainer_forward(const gbnf_trainer* trainer, const float* x, int64_t n, float* z, float* ldj, float* trace,
                          void* stream);
+
+/* RealNVP BatchNorm in the reference's train() form (models/layers.py:338-346): normalise with the BATCH mean and the
+ * unbiased batch variance of every step's input, differentiate through them.  bind: DEVICE (d,) buffers that receive a
+ * step's batch mean / variance at every forward call (the reference keeps them as BatchNorm.batch_mean / batch_var; the
+ * running-statistics update with momentum stays with the caller).  set(1) switches forward / backward to one launch per
+ * step (the statistics need the whole batch); it requires the trace buffer in both calls and n >= 2. */
+int gbnf_trainer_bind_batch_stats(gbnf_trainer* trainer, int32_t step, float* mean_dev, float* var_dev);
+int gbnf_trainer_set_batch_stats(gbnf_trainer* trainer, int32_t on);
 
 /* Size of the flat parameter-gradient buffer, in floats.  Layout, step by step in descriptor order:
  *   glow:    [actnorm bias (d)] [actnorm logs (d)]  then per Linear of the block:   [weight (out*in)] [bias (out)]

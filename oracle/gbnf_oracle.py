@@ -193,10 +193,30 @@ def batch_norm_eval(ops, bn, x):
     return y, ladj.sum()
 
 
-def realnvp_step(ops, spec, step, x):
-    """RealNVP.forward: models/transformations.py:560-579 (note the half swap when flipped)."""
+def batch_norm_train(ops, bn, x, stats_out=None):
+    """BatchNorm.forward in TRAIN mode (models/layers.py:338-358): batch mean, UNBIASED batch variance (x.var(0)), the
+    log-det uses the batch variance too; the statistics are part of the autograd graph.  ``stats_out`` collects
+    (batch_mean, batch_var) for the running-statistics update of :343-344."""
+    n = x.shape[0]
+    mean = x.sum(0) / n
+    var = ((x - mean) * (x - mean)).sum(0) / (n - 1)
+    log_gamma = ops.arr(bn["log_gamma"])
+    beta = ops.arr(bn["beta"])
+    x_hat = (x - mean) / ops.sqrt(var + bn["eps"])
+    y = ops.exp(log_gamma) * x_hat + beta
+    ladj = log_gamma - 0.5 * ops.log(var + bn["eps"])
+    if stats_out is not None:
+        stats_out.append((ops.to_numpy(mean), ops.to_numpy(var)))
+    return y, ladj.sum()
+
+
+def realnvp_step(ops, spec, step, x, train=False, stats_out=None):
+    """RealNVP.forward: models/transformations.py:560-579 (note the half swap when flipped).  ``train``: BatchNorm with
+    batch statistics (model.train())."""
     d = spec["d"]
-    if step["bn"] is not None:
+    if step["bn"] is not None and train:
+        x, bn_ld = batch_norm_train(ops, step["bn"], x, stats_out)
+    elif step["bn"] is not None:
         x, bn_ld = batch_norm_eval(ops, step["bn"], x)
     else:
         bn_ld = 0.0
@@ -214,6 +234,18 @@ def realnvp_step(ops, spec, step, x):
 # --------------------------------------------------------------------------
 # component / mixture level
 # --------------------------------------------------------------------------
+def component_forward_train(spec, x, backend="numpy64"):
+    """RealNVP component in train() mode (BatchNorm on batch statistics): -> z, ldj, [(batch_mean, batch_var) per BN step]."""
+    ops = _ops(backend)
+    z = ops.arr(x)
+    ld = ops.zeros(z.shape[0])
+    stats = []
+    for step in spec["steps"]:
+        z, step_ld = realnvp_step(ops, spec, step, z, train=True, stats_out=stats)
+        ld = ld + step_ld
+    return ops.to_numpy(z), ops.to_numpy(ld), stats
+
+
 def component_forward(spec, x, backend="torch", return_steps=False):
     """One boosted component: x (N,d) -> z (N,d), ldj (N,).
 
@@ -352,9 +384,10 @@ def param_arrays(spec):
     return out
 
 
-def component_grads(spec, x, g_z, g_ldj):
+def component_grads(spec, x, g_z, g_ldj, train=False):
     """d(sum(z * g_z) + sum(ldj * g_ldj)) / d(x, parameters) in float64: the vector-Jacobian product a backward pass
-    with upstream gradients (g_z, g_ldj) must return.  -> (g_x (N,d), [gradient per entry of param_arrays(spec)])."""
+    with upstream gradients (g_z, g_ldj) must return.  -> (g_x (N,d), [gradient per entry of param_arrays(spec)]).
+    ``train``: RealNVP BatchNorm on batch statistics (gradients flow through the statistics)."""
     ops = _TorchGradOps()
     xt = torch.tensor(np.asarray(x, dtype=np.float64), dtype=torch.float64, requires_grad=True)
     z, ld = xt, ops.zeros(xt.shape[0])
@@ -362,7 +395,7 @@ def component_grads(spec, x, g_z, g_ldj):
         if spec["kind"] == "glow":
             z, ld = glow_step(ops, spec, step, z, ld)
         else:
-            z, step_ld = realnvp_step(ops, spec, step, z)
+            z, step_ld = realnvp_step(ops, spec, step, z, train=train)
             ld = ld + step_ld
     loss = (z * torch.as_tensor(np.asarray(g_z, dtype=np.float64))).sum() + \
            (ld * torch.as_tensor(np.asarray(g_ldj, dtype=np.float64))).sum()

@@ -48,6 +48,16 @@ def load_image_case(name):
 GRADS_CASES = ("g10_glow_grads_d43_h64", "g10_glow_grads_additive_relu_d8", "g10_realnvp_grads_d21_h32")
 
 
+def load_train_bn_case():
+    """g10 (train-mode BatchNorm): (cfg, spec, x, data)."""
+    from gbnf_amd import synth
+    data = dict(np.load(os.path.join(GOLDEN_DIR, "g10_realnvp_grads_train_bn_d21_h32.npz")))
+    cfg = json.loads(bytes(data["config"]).decode())
+    spec = synth.synth_boosted_specs("realnvp", 1, cfg["d"], cfg["h"], cfg["K"], seed=cfg["w_seed"])[0]
+    x = synth.synth_batch(cfg["N"], cfg["d"], seed=cfg["x_seed"], scale=cfg["x_scale"])
+    return cfg, spec, x, data
+
+
 def load_grads_case(name):
     """g10: (cfg, spec, x, nll, flat parameter gradients, g_x) -- the reference's own nll.backward()."""
     from gbnf_amd import synth

@@ -349,6 +349,32 @@ def _ref_params_in_flat_order(component, kind):
     return out
 
 
+def grads_train_bn_case(name, d=21, h=32, K=4, N=80):
+    """G10b: RealNVP in TRAIN mode (the reference's default batch_norm=True while training): BatchNorm normalises with the
+    batch statistics, the log-det uses them, nll.backward() differentiates through them, and the running statistics are
+    updated with momentum 0.9 (models/layers.py:338-358).  Stores nll, the gradients and the updated running statistics."""
+    specs = synth.synth_boosted_specs("realnvp", 1, d, h, K, seed=43)
+    model = RefBoostedFlow(ref_args("realnvp", d, h, K, 1))
+    install_spec(model.flows[0], specs[0])
+    model.train()
+    x = torch.from_numpy(synth.synth_batch(N, d, seed=27, scale=1.2)).requires_grad_(True)
+    z, _, _, ldj, _ = model(x=x, components=0)
+    nll = torch.mean(-1.0 * (log_normal_standard(z, reduce=True, dim=-1) + ldj))
+    nll.backward()
+    flat = []
+    for p in _ref_params_in_flat_order(model.flows[0], "realnvp"):
+        flat.append(np.zeros(d, dtype=np.float32) if p is None else p.grad.detach().numpy().reshape(-1).astype(np.float32))
+    bns = [mods[2] for mods in model.flows[0].flow_param if len(mods) > 2 and mods[2] is not None]
+    cfg = dict(case="grads_train_bn", kind="realnvp", d=d, h=h, K=K, C=1, N=N, w_seed=43, x_seed=27, x_scale=1.2, synth_kw={})
+    np.savez_compressed(os.path.join(HERE, name + ".npz"),
+                        config=np.frombuffer(json.dumps(cfg).encode(), dtype=np.uint8),
+                        nll=np.float32(nll.item()), grads=np.concatenate(flat), g_x=x.grad.numpy().copy(),
+                        z=z.detach().numpy().copy(), ldj=ldj.detach().numpy().copy(),
+                        running_mean=np.stack([b.running_mean.numpy() for b in bns]),
+                        running_var=np.stack([b.running_var.numpy() for b in bns]))
+    print(f"{name}: nll={nll.item():.5f} |grads|={np.abs(np.concatenate(flat)).max():.4f}")
+
+
 def grads_case(name, kind, d, h, K, N, **synth_kw):
     """G10: the training step's gradients by the reference itself: nll = mean(-(log_normal_standard(z) + ldj)) of ONE
     component (density_experiment.py:655-659, the non-boosted / first-component branch of compute_kl_pq_loss), then
@@ -515,6 +541,9 @@ def main():
     if "--checkpoint-only" in sys.argv:
         checkpoint_case("g11_reference_checkpoint")
         return
+    if "--train-bn-only" in sys.argv:
+        grads_train_bn_case("g10_realnvp_grads_train_bn_d21_h32")
+        return
     if "--grads-only" in sys.argv:
         grads_case("g10_glow_grads_d43_h64", "glow", 43, 64, 3, 96)
         grads_case("g10_glow_grads_additive_relu_d8", "glow", 8, 40, 3, 50, coupling="additive", act="relu")
@@ -543,6 +572,7 @@ def main():
     grads_case("g10_glow_grads_d43_h64", "glow", 43, 64, 3, 96)
     grads_case("g10_glow_grads_additive_relu_d8", "glow", 8, 40, 3, 50, coupling="additive", act="relu")
     grads_case("g10_realnvp_grads_d21_h32", "realnvp", 21, 32, 4, 80)
+    grads_train_bn_case("g10_realnvp_grads_train_bn_d21_h32")
     toy_case("g1_toy_realnvp_c2")
     native_glow_case("g2_glow_native_d43_h32_c3")
     # G3: MINIBOONE full width (BASELINE.json metric config), synthetic weights

@@ -31,14 +31,16 @@ def _dev_spec(spec, dev):
     return out
 
 
-def _check_grads(dev_grads, ref_grads, what):
+def _check_grads(dev_grads, ref_grads, what, floor=1e-3):
+    """``floor``: smallest scale a tensor is judged on (a gradient that is exactly zero by symmetry -- e.g. a bias in front of
+    a batch-statistics BatchNorm -- comes out as f32 summation noise of the terms that cancel)."""
     assert len(dev_grads) == len(ref_grads)
     for k, (a, b) in enumerate(zip(dev_grads, ref_grads)):
         if b is None:
             assert a is None
             continue
         a = a.detach().cpu().numpy().reshape(b.shape)
-        scale = max(float(np.abs(b).max()), 1e-3)
+        scale = max(float(np.abs(b).max()), floor)
         assert np.abs(a - b).max() <= G_RTOL * scale, f"{what}: gradient {k} shape {b.shape}: {np.abs(a - b).max()} vs scale {scale}"
 
 
@@ -126,10 +128,6 @@ def test_module_autograd_matches_reference(name):
         m.train()
         z, _, _, ldj, _ = m(x=xd, components=0)
     else:                                   # RealNVP: running-statistics BatchNorm, as in the fixture
-        m.eval()
-        with pytest.raises(NotImplementedError):
-            m.train()
-            m(x=xd, components=0)
         m.eval()
         z, ldj = m.component_forward(xd, 0, differentiable=True)
     loss = torch.mean(-(torch.sum(-0.5 * np.log(2 * np.pi) - 0.5 * z.pow(2), dim=-1) + ldj))
@@ -305,3 +303,78 @@ def test_trainer_random_shapes_against_oracle(kind, d, h, K, n, extra, seed):
     gx, grads = tr.backward(xd, torch.from_numpy(g_z).to(dev), torch.from_numpy(g_l).to(dev), want_gx=True, trace=trace)
     _check_grads(grads, grads64, f"{kind} d={d} h={h} K={K} n={n} {extra}")
     assert np.abs(gx.cpu().numpy() - gx64).max() <= G_RTOL * max(float(np.abs(gx64).max()), 1e-3)
+
+
+def test_train_mode_batch_norm_matches_reference():
+    """g10 (train-mode BatchNorm): RealNVP in train() like the reference's default configuration -- BatchNorm on batch
+    statistics (one launch per step), nll.backward() through the statistics, running statistics updated."""
+    import torch
+    from conftest import load_train_bn_case
+    from gbnf_amd import BoostedFlow
+    dev = torch.device("cuda:0")
+    cfg, spec, x, data = load_train_bn_case()
+    m = BoostedFlow(_args("realnvp", cfg["d"], cfg["h"], cfg["K"], 1, dev))
+    m.load_spec(0, spec)
+    m.train()
+    xd = torch.from_numpy(x).to(dev).requires_grad_(True)
+    z, _, _, ldj, _ = m(x=xd, components=0)
+    assert np.abs(z.detach().cpu().numpy() - data["z"]).max() <= 2e-5 * float(np.abs(data["z"]).max())
+    assert rel_err(ldj.detach().cpu().numpy(), data["ldj"]) < 1e-5
+    loss = torch.mean(-(torch.sum(-0.5 * np.log(2 * np.pi) - 0.5 * z.pow(2), dim=-1) + ldj))
+    assert abs(loss.item() - float(data["nll"])) <= 1e-5 * abs(float(data["nll"]))
+    loss.backward()
+    tr = m.native_trainer(0)
+    mine = np.concatenate([np.zeros(cfg["d"], np.float32) if t is None else t.grad.cpu().numpy().reshape(-1) for t in tr.params])
+    assert np.abs(mine - data["grads"]).max() <= G_RTOL * float(np.abs(data["grads"]).max())
+    assert np.abs(xd.grad.cpu().numpy() - data["g_x"]).max() <= G_RTOL * float(np.abs(data["g_x"]).max())
+    bns = [mods[2] for mods in m.flows[0].flow_param if len(mods) > 2 and mods[2] is not None]
+    for k, bn in enumerate(bns):
+        np.testing.assert_allclose(bn.running_mean.cpu().numpy(), data["running_mean"][k], rtol=0, atol=2e-6)
+        np.testing.assert_allclose(bn.running_var.cpu().numpy(), data["running_var"][k], rtol=0, atol=2e-6)
+    # eval() afterwards: running statistics, single fused launch, packed kernels see the updated buffers
+    m.eval()
+    with torch.no_grad():
+        z2, _, _, ldj2, _ = m(x=xd.detach(), components=0)
+    assert torch.isfinite(ldj2).all() and not torch.allclose(ldj2, ldj.detach())
+
+
+@pytest.mark.parametrize("d,h,K,n,seed", [(21, 33, 3, 100, 1), (6, 16, 4, 17, 2), (43, 64, 2, 257, 3)])
+def test_trainer_batch_stats_against_oracle(d, h, K, n, seed):
+    import torch
+    from gbnf_amd import native, synth
+    from oracle import gbnf_oracle as oracle
+    dev = torch.device("cuda:0")
+    spec = synth.synth_realnvp_spec(d, h, K, seed=seed, flip_init=seed % 2)
+    dv = _dev_spec(spec, dev)
+    for st in dv["steps"]:
+        if st["bn"] is not None:
+            st["bn"]["batch_mean"] = torch.zeros(d, device=dev)
+            st["bn"]["batch_var"] = torch.zeros(d, device=dev)
+    tr = native.NativeTrainer(dv)
+    assert tr.has_batch_stats
+    tr.set_batch_stats(True)
+    x = synth.synth_batch(n, d, seed=seed + 5)
+    xd = torch.from_numpy(x).to(dev)
+    z, ldj, trace = tr.forward(xd, want_trace=True)
+    z64, ldj64, stats = oracle.component_forward_train(spec, x)
+    assert np.abs(z.cpu().numpy() - z64).max() <= 2e-5 * max(1.0, float(np.abs(z64).max()))
+    assert np.abs(ldj.cpu().numpy() - ldj64).max() <= 1e-5 * max(1.0, float(np.abs(ldj64).max()))
+    k = 0
+    for st in dv["steps"]:
+        if st["bn"] is not None:
+            np.testing.assert_allclose(st["bn"]["batch_mean"].cpu().numpy(), stats[k][0], rtol=0, atol=2e-6)
+            np.testing.assert_allclose(st["bn"]["batch_var"].cpu().numpy(), stats[k][1], rtol=1e-5, atol=1e-6)
+            k += 1
+    rng = np.random.RandomState(seed)
+    g_z = rng.standard_normal(x.shape).astype(np.float32)
+    g_l = rng.standard_normal(n).astype(np.float32)
+    gx64, grads64 = oracle.component_grads(spec, x, g_z, g_l, train=True)
+    gx, grads = tr.backward(xd, torch.from_numpy(g_z).to(dev), torch.from_numpy(g_l).to(dev), want_gx=True, trace=trace)
+    _check_grads(grads, grads64, "batch-stats", floor=0.05 * max(float(np.abs(g).max()) for g in grads64 if g is not None))
+    assert np.abs(gx.cpu().numpy() - gx64).max() <= G_RTOL * float(np.abs(gx64).max())
+    with pytest.raises(native.GbnfError):          # the statistics need the forward call's trace
+        tr.backward(xd, torch.from_numpy(g_z).to(dev), torch.from_numpy(g_l).to(dev))
+    tr.set_batch_stats(False)                      # back to running statistics: the fused single launch
+    z_e, ldj_e = tr.forward(xd)
+    z_r, ldj_r = oracle.component_forward(spec, x, backend="numpy64")
+    assert np.abs(ldj_e.cpu().numpy() - ldj_r).max() <= 1e-5 * max(1.0, float(np.abs(ldj_r).max()))

@@ -144,3 +144,26 @@ def test_oracle_image_path_matches_reference(name):
         lls.append(ll)
     G = oracle.mixture_recursion(np.stack(lls), data["rho"])
     assert rel_err(G, data["G"]) < 1e-5
+
+
+def test_oracle_train_mode_batch_norm_matches_reference():
+    """g10 (train-mode BatchNorm): the reference's RealNVP in train(): forward on batch statistics, nll.backward() through
+    them, running statistics updated with momentum 0.9."""
+    from conftest import load_train_bn_case
+    cfg, spec, x, data = load_train_bn_case()
+    z, ldj, stats = oracle.component_forward_train(spec, x)
+    assert np.abs(z - data["z"]).max() <= 1e-5 * np.abs(data["z"]).max()
+    assert rel_err(ldj, data["ldj"]) < 1e-5
+    n = x.shape[0]
+    gx, grads = oracle.component_grads(spec, x, z / n, -np.ones(n) / n, train=True)
+    mine = np.concatenate([np.zeros(cfg["d"]) if g is None else g.reshape(-1) for g in grads])
+    assert np.abs(mine - data["grads"]).max() <= 2e-5 * np.abs(data["grads"]).max()
+    assert np.abs(gx - data["g_x"]).max() <= 2e-5 * np.abs(data["g_x"]).max()
+    k = 0
+    for st in spec["steps"]:
+        if st["bn"] is None:
+            continue
+        m, v = stats[k]
+        np.testing.assert_allclose(0.9 * st["bn"]["running_mean"] + 0.1 * m, data["running_mean"][k], rtol=0, atol=1e-6)
+        np.testing.assert_allclose(0.9 * st["bn"]["running_var"] + 0.1 * v, data["running_var"][k], rtol=0, atol=1e-6)
+        k += 1
