@@ -198,7 +198,8 @@ def test_trainer_argument_validation():
              "net": {"act": "tanh", "layers": [(torch.zeros(8, 2), torch.zeros(8)), (torch.zeros(4, 8), torch.zeros(4))]}}]})
 
 
-def test_boosted_training_loop_like_the_reference():
+@pytest.mark.parametrize("kind", ["glow", "realnvp"])
+def test_boosted_training_loop_like_the_reference(kind):
     """The reference's boosted training step (compute_kl_pq_loss, density_experiment.py:606-660) on the device path, both
     ways: the reference's own statement sequence through model(x=, components=) and the fused shortcuts
     (boosting_weights + one recorded forward).  Component 0 is trained first, then component 1 on re-weighted samples;
@@ -209,7 +210,7 @@ def test_boosted_training_loop_like_the_reference():
     dev = torch.device("cuda:0")
     torch.manual_seed(1)
     d = 6
-    m = BoostedFlow(_args("glow", d, 32, 3, 2, dev)).to(dev)
+    m = BoostedFlow(_args(kind, d, 32, 3, 2, dev)).to(dev)     # realnvp: default batch_norm=True, batch statistics in train()
 
     def sample(n):          # two well separated blobs: one component cannot fit both equally well
         a = torch.randn(n, d, device=dev) * 0.5 + 2.0
