@@ -37,7 +37,9 @@
 namespace gbnf {
 
 using f32x4 = __attribute__((ext_vector_type(4))) float;
-typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));
+using u32x4 = __attribute__((ext_vector_type(4))) unsigned;
+using u32x2 = __attribute__((ext_vector_type(2))) unsigned;
+using f16x8 = __attribute__((ext_vector_type(8))) _Float16;
 
 constexpr int TR_S = 17;            // LDS row stride (floats): 16 samples + 1 pad
 constexpr int TR_MAX_LAYERS = 4;    // Linear layers per coupling net (depth <= 2)
@@ -54,7 +56,7 @@ struct TrLayer {
   const float* W;      // (rows, cols) row-major = nn.Linear.weight (out, in)
   const float* b;      // (rows,)
   int64_t gW, gb;      // float offsets into the flat gradient buffer
-  int64_t wt;          // float offset of the transposed copy (cols x rows) in the workspace's weight region
+  int64_t fw, bw;      // u32x4 offsets of the split fragments of W (forward) / W^T (backward) in the trainer's fragment buffer
   int rows, cols;
 };
 struct TrNet {
@@ -99,12 +101,13 @@ struct TrainLaunch {
   float* g_x;          // MODE 1 (n, d) or null
   float* grads;        // MODE 1 flat parameter-gradient buffer
   unsigned long long* dbg;   // diagnostic builds only
-  float* ws;           // MODE 1 workspace: operands of the weight gradients ...
-  const float* wt;     // ... followed by the transposed copies of the weights (made by transpose_kernel)
+  float* ws;           // MODE 1 workspace: operands of the weight gradients
+  const u32x4* frag;   // split-f16 weight fragments of this call (prep_kernel)
   int64_t n, np;       // samples, samples rounded up to 16
   int d, K, kind, additive;
   int n_hidden;        // hidden layers per net = depth + 1
   int hp, ip, op;      // padded hidden / net-input / net-output rows (multiples of 16)
+  int hw, xw, ow;      // the same padded to 32: widths of the split activation rows
   int64_t net_rows;    // workspace rows (of np floats) per (step, net)
 };
 
@@ -155,6 +158,12 @@ struct TrStamps {
 };
 
 __device__ __forceinline__ int tr_uniform(int v) { return __builtin_amdgcn_readfirstlane(v); }
+template <class P>
+__device__ __forceinline__ P tr_uniform_ptr(P p) {          // same, for any pointer type
+  const unsigned long long v = (unsigned long long)p;
+  const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
+  return (P)(((unsigned long long)hi << 32) | lo);
+}
 // A pointer that is the same in every lane, moved to scalar registers: address arithmetic on it then does not depend
 // on the vector-memory load that fetched it from the step table (which would drag a vmcnt(0) into every prefetch).
 __device__ __forceinline__ gptr tr_uniform(gptr p) {
@@ -163,123 +172,120 @@ __device__ __forceinline__ gptr tr_uniform(gptr p) {
   return (gptr)(((unsigned long long)hi << 32) | lo);
 }
 
-// A fragment of A (urows x kcols, row-major): lane (i,g) wants A[row][col .. col+3]  (k-step r <-> k = col + r).
-// The MFMA blocks the vector ALU of its SIMD, so every VALU instruction in the stream costs its full issue time:
-//   * rows >= urows are loaded from the clamped last row and simply never stored (the epilogue drops them);
-//   * columns >= kcols meet B rows that are exactly zero (padded units of the LDS activations are kept at zero),
-//     so a chunk that lies fully inside the row needs NO fix-up at all;
-//   * only the last chunk of a row whose length is not a multiple of 16 is fixed (its 16-byte load is shifted left to
-//     stay inside the row; tr_fix_tail shifts it back) -- a uniform branch, taken once per tile pair.
-// tr_load_raw touches nothing it loads (any ALU on the result would wait for the load on the spot).
-template <bool VEC>
-__device__ __forceinline__ f32x4 tr_load_raw(gptr row_ptr, int kcols, int col) {
-  f32x4 a;
-  if constexpr (VEC) {
-    const int cc = col < kcols - 4 ? col : kcols - 4;
-    a = __builtin_bit_cast(f32x4, *reinterpret_cast<const f32x4u __attribute__((address_space(1)))*>(row_ptr + cc));
-  } else {
-#pragma unroll
-    for (int r = 0; r < 4; ++r) a[r] = row_ptr[col + r < kcols ? col + r : kcols - 1];
-  }
-  return a;
-}
-template <bool VEC>
-__device__ __forceinline__ f32x4 tr_fix_tail(f32x4 raw, int kcols, int col) {
-  f32x4 a;
-  const int sh = VEC ? col - (col < kcols - 4 ? col : kcols - 4) : 0;
-#pragma unroll
-  for (int r = 0; r < 4; ++r) {
-    float v = raw[r];
-    if (VEC) {
-      if (r + 1 < 4) v = sh == 1 ? raw[r + 1] : v;
-      if (r + 2 < 4) v = sh == 2 ? raw[r + 2] : v;
-      if (r + 3 < 4) v = sh == 3 ? raw[r + 3] : v;
-    }
-    a[r] = (r + sh < 4 && col + r < kcols) ? v : 0.0f;
-  }
-  return a;
-}
+// ---- split-f16 dense layers: an f32 operand is two fp16 pieces x ~ hi + mid and a product
+// is three v_mfma_f32_16x16x32_f16 with f32 accumulation.  Weights: prep_kernel splits the LIVE f32 parameter tensors
+// into MFMA A fragments ([o][c][hi|mid][64 lanes][8 halfs], k = 32c + 8g + j, zero padded: no edge handling in the
+// stream at all) at the start of every call -- both orientations (W for the forward, W^T for the backward), 5 us.
+// Activations that feed a dense layer live in LDS as rows [sample][hi: width halfs | mid: width halfs] (+16 B pad: the 16
+// lanes of a group hit 16 different bank quads), so a lane's B operand (8 consecutive units of its sample) is ONE
+// ds_read_b128; they are split where they are produced (layer epilogues, the element-wise stages), never in the stream.
+typedef const u32x4 __attribute__((address_space(1)))* gfrag;
 
-// out[u][s] = epi(u, sum_k A[u][k] in[k][s] + bias[u]) for u in [0, 16*out_tiles): A is a (urows x kcols) row-major
-// matrix in global memory (a Linear's weight for the forward, its transposed copy for the backward), `in` / the
-// epilogue's targets are LDS arrays [unit][sample] with row stride TR_S.
-// The waves of the workgroup split the output tiles in pairs: wave w owns pairs w, w + TR_WAVES, ...  Its
-// (pair, k-chunk) iterations form ONE software-pipelined stream: TR_PD iterations of weights are in flight under the
-// MFMAs, also across pair boundaries; a pair's bias is requested at its first chunk and added in its epilogue.
-template <bool VEC, class Epi>
-__device__ __forceinline__ void tr_dense_impl(gptr A, gptr bias, int urows, int kcols, const float* in, int out_tiles,
-                                              int lane, int wave, TrStamps& stamps, Epi epi) {
+__device__ __forceinline__ f32x4 tr_mfma16(u32x4 a, u32x4 b, f32x4 c) {
+  return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+}
+// hi = f16(x) (toward zero), mid = f16(x - hi) for a pair, clamped to the fp16 range
+__device__ __forceinline__ void tr_split_pair(float x0, float x1, unsigned& hi, unsigned& mid) {
+  x0 = __builtin_amdgcn_fmed3f(x0, -65504.0f, 65504.0f);
+  x1 = __builtin_amdgcn_fmed3f(x1, -65504.0f, 65504.0f);
+  const auto h = __builtin_amdgcn_cvt_pkrtz(x0, x1);
+  hi = __builtin_bit_cast(unsigned, h);
+  const auto m = __builtin_amdgcn_cvt_pkrtz(x0 - (float)h[0], x1 - (float)h[1]);
+  mid = __builtin_bit_cast(unsigned, m);
+}
+// a split activation buffer in LDS: 16 rows (samples) of [hi: w halfs][mid: w halfs] + 16 B
+struct TrSplit {
+  unsigned char* base;
+  int w;                                                  // channels (multiple of 32)
+  __device__ __forceinline__ int rs() const { return 4 * w + 16; }
+  __device__ __forceinline__ void put1(int i, int ch, float v) const {       // one element (element-wise stages)
+    unsigned h, m;
+    tr_split_pair(v, 0.0f, h, m);
+    unsigned char* q = base + (size_t)i * rs() + 2 * ch;
+    *reinterpret_cast<unsigned short*>(q) = (unsigned short)h;
+    *reinterpret_cast<unsigned short*>(q + 2 * w) = (unsigned short)m;
+  }
+  __device__ __forceinline__ void put4(int i, int ch0, f32x4 v) const {       // 4 consecutive channels (dense epilogues)
+    unsigned h01, m01, h23, m23;
+    tr_split_pair(v[0], v[1], h01, m01);
+    tr_split_pair(v[2], v[3], h23, m23);
+    unsigned char* q = base + (size_t)i * rs() + 2 * ch0;
+    *reinterpret_cast<u32x2*>(q) = u32x2{h01, h23};
+    *reinterpret_cast<u32x2*>(q + 2 * w) = u32x2{m01, m23};
+  }
+  __device__ __forceinline__ f32x4 get4(int i, int ch0) const {
+    typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+    const unsigned* qh = reinterpret_cast<const unsigned*>(base + (size_t)i * rs() + 2 * ch0);
+    const unsigned* qm = reinterpret_cast<const unsigned*>(base + (size_t)i * rs() + 2 * ch0 + 2 * w);
+    const unsigned h0 = qh[0], h1 = qh[1], m0 = qm[0], m1 = qm[1];
+    const h2 h01 = __builtin_bit_cast(h2, h0), h23 = __builtin_bit_cast(h2, h1);
+    const h2 m01 = __builtin_bit_cast(h2, m0), m23 = __builtin_bit_cast(h2, m1);
+    f32x4 r;
+    r[0] = (float)h01[0] + (float)m01[0];
+    r[1] = (float)h01[1] + (float)m01[1];
+    r[2] = (float)h23[0] + (float)m23[0];
+    r[3] = (float)h23[1] + (float)m23[1];
+    return r;
+  }
+};
+
+// out[u][s] = epi(u0, acc + bias) for the 16*out_tiles output units: A = pre-split fragments (kc32 chunks of 32 k per
+// output tile), `in` = split activation rows.  The waves of the workgroup split the output tiles in pairs (wave w owns
+// pairs w, w + TR_WAVES, ...); a wave's (pair, chunk) iterations form ONE software-pipelined stream with TR_PD
+// iterations of fragments in flight (unconditional loads, static ring indices); a pair's bias is requested up front and
+// added in its epilogue.  epi(u0, v): units u0..u0+3 of sample i; units >= urows arrive as exact zeros.
+template <class Epi>
+__device__ __forceinline__ void tr_dense(gfrag A, gptr bias, int urows, int kc32, int frag_tiles, const TrSplit in,
+                                         int out_tiles, int lane, int wave, TrStamps& stamps, Epi epi) {
   const int i = lane & 15, g = lane >> 4;
-  const int kc = (kcols + 15) >> 4;
   const int n_pairs = (out_tiles + 1) >> 1;
   const int my_pairs = wave < n_pairs ? (n_pairs - wave + TR_WAVES - 1) / TR_WAVES : 0;
-  const int T = my_pairs * kc;
-  auto row_ptr = [&](int o) -> gptr {          // start of row 16 o + i of A, clamped into the matrix
-    const int row = 16 * o + i;
-    return A + (size_t)(row < urows ? row : urows - 1) * kcols;
-  };
+  const int T = my_pairs * kc32;
   auto load_bias = [&](int o) -> f32x4 {
     f32x4 b = {0.f, 0.f, 0.f, 0.f};
     if (bias != nullptr) {
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int u = 16 * o + 4 * g + r;
-        b[r] = bias[u < urows ? u : urows - 1];       // raw; rows >= urows are never stored
+        b[r] = bias[u < urows ? u : urows - 1];       // raw; rows >= urows are zeroed in the epilogue
       }
     }
     return b;
   };
-  // Ring of TR_PD iterations of weights in flight (an L2 round trip is several iterations of 8 MFMAs long).  Every
-  // load below is UNCONDITIONAL and its registers are only read by the iteration that consumes them: a conditional
-  // definition would make the compiler copy the freshly loaded registers at the join, i.e. wait for the load at once.
-  // Loads past the end re-read the clamped last row (harmless).
-  f32x4 ra0[TR_PD], ra1[TR_PD];
+  u32x4 r0h[TR_PD], r0m[TR_PD], r1h[TR_PD], r1m[TR_PD];
   int pl = wave, cl = 0;                       // load cursor (pair, chunk)
-  gptr rp0 = row_ptr(2 * pl), rp1 = row_ptr(2 * pl + 1);
-  auto issue = [&](f32x4& d0, f32x4& d1) {
-    const int col = 16 * cl + 4 * g;
-    d0 = tr_load_raw<VEC>(rp0, kcols, col);
-    d1 = tr_load_raw<VEC>(rp1, kcols, col);
-    if (++cl == kc) {
-      cl = 0; pl += TR_WAVES;
-      rp0 = row_ptr(2 * pl); rp1 = row_ptr(2 * pl + 1);
-    }
+  auto issue = [&](u32x4& a0h, u32x4& a0m, u32x4& a1h, u32x4& a1m) {
+    const int o0 = 2 * pl < frag_tiles ? 2 * pl : 0, o1 = 2 * pl + 1 < frag_tiles ? 2 * pl + 1 : 0;   // past the end: tile 0 again
+    const gfrag f0 = A + ((size_t)o0 * kc32 + cl) * 128 + lane, f1 = A + ((size_t)o1 * kc32 + cl) * 128 + lane;
+    a0h = f0[0]; a0m = f0[64];
+    a1h = f1[0]; a1m = f1[64];
+    if (++cl == kc32) { cl = 0; pl += TR_WAVES; }
   };
   constexpr int MAXP = (8 + TR_WAVES - 1) / TR_WAVES;   // pairs per wave (<= 16 output tiles)
-  f32x4 bq0[MAXP], bq1[MAXP];                           // every pair's bias, requested up front, used in the epilogues
+  f32x4 bq0[MAXP], bq1[MAXP];
 #pragma unroll
   for (int q = 0; q < MAXP; ++q) {
     bq0[q] = load_bias(2 * (wave + q * TR_WAVES));
     bq1[q] = load_bias(2 * (wave + q * TR_WAVES) + 1);
   }
 #pragma unroll
-  for (int j = 0; j < TR_PD; ++j) issue(ra0[j], ra1[j]);
+  for (int j = 0; j < TR_PD; ++j) issue(r0h[j], r0m[j], r1h[j], r1m[j]);
   stamps.mark(5);
   int pair = wave, c = 0, q = 0;
   const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
   f32x4 acc0 = zero, acc1 = zero;
-  // B operands (LDS) one iteration ahead, ping-pong registers: the read of chunk c+1 is in flight under chunk c's MFMAs
-  float bb[2][4];
-  const float* inl = in + (4 * g) * TR_S + i;
-  auto read_b = [&](float (&b)[4], int chunk) {
-#pragma unroll
-    for (int r = 0; r < 4; ++r) b[r] = inl[(16 * chunk + r) * TR_S];
-  };
-  read_b(bb[0], 0);
-  auto body = [&](const f32x4& r0, const f32x4& r1, const float (&b)[4], float (&bn)[4]) {
-    const int k = 16 * c + 4 * g;
-    read_b(bn, c + 1 == kc ? 0 : c + 1);       // (past the end: chunk 0 again, never used)
-    f32x4 a0 = r0, a1 = r1;
-    if (16 * c + 15 >= kcols) {                // uniform: the row's ragged last chunk
-      a0 = tr_fix_tail<VEC>(r0, kcols, k);
-      a1 = tr_fix_tail<VEC>(r1, kcols, k);
-    }
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      acc0 = tr_mfma(a0[r], b[r], acc0);
-      acc1 = tr_mfma(a1[r], b[r], acc1);
-    }
-    if (++c == kc) {
+  const unsigned char* inl = in.base + (size_t)i * in.rs() + 16 * g;
+  const int mid_off = 2 * in.w;
+  auto body = [&](const u32x4& a0h, const u32x4& a0m, const u32x4& a1h, const u32x4& a1m) {
+    const u32x4 bh = *reinterpret_cast<const u32x4*>(inl + 64 * c);
+    const u32x4 bm = *reinterpret_cast<const u32x4*>(inl + 64 * c + mid_off);
+    acc0 = tr_mfma16(a0m, bh, acc0);
+    acc1 = tr_mfma16(a1m, bh, acc1);
+    acc0 = tr_mfma16(a0h, bm, acc0);
+    acc1 = tr_mfma16(a1h, bm, acc1);
+    acc0 = tr_mfma16(a0h, bh, acc0);
+    acc1 = tr_mfma16(a1h, bh, acc1);
+    if (++c == kc32) {
       tr_mfma_drain(acc0, acc1);
       f32x4 bias0 = bq0[0], bias1 = bq1[0];
 #pragma unroll
@@ -288,12 +294,15 @@ __device__ __forceinline__ void tr_dense_impl(gptr A, gptr bias, int urows, int 
         bias1 = q == qq ? bq1[qq] : bias1;
       }
       const int o = 2 * pair;
+      f32x4 v0, v1;
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int u0 = 16 * o + 4 * g + r, u1 = u0 + 16;          // padded units (>= urows) stay exactly zero
-        epi(u0, u0 < urows ? acc0[r] + bias0[r] : 0.0f);
-        if (o + 1 < out_tiles) epi(u1, u1 < urows ? acc1[r] + bias1[r] : 0.0f);
+        v0[r] = u0 < urows ? acc0[r] + bias0[r] : 0.0f;
+        v1[r] = u1 < urows ? acc1[r] + bias1[r] : 0.0f;
       }
+      epi(16 * o + 4 * g, v0);
+      if (o + 1 < out_tiles) epi(16 * o + 16 + 4 * g, v1);
       acc0 = zero; acc1 = zero;
       tr_acc_settle(acc0, acc1);
       c = 0; pair += TR_WAVES; ++q;
@@ -303,27 +312,16 @@ __device__ __forceinline__ void tr_dense_impl(gptr A, gptr bias, int urows, int 
   for (; t + TR_PD <= T; t += TR_PD) {
 #pragma unroll
     for (int j = 0; j < TR_PD; ++j) {
-      body(ra0[j], ra1[j], bb[j & 1], bb[(j + 1) & 1]);
-      issue(ra0[j], ra1[j]);
+      body(r0h[j], r0m[j], r1h[j], r1m[j]);
+      issue(r0h[j], r0m[j], r1h[j], r1m[j]);
     }
   }
 #pragma unroll
   for (int j = 0; j < TR_PD - 1; ++j)
-    if (t + j < T) body(ra0[j], ra1[j], bb[j & 1], bb[(j + 1) & 1]);
+    if (t + j < T) body(r0h[j], r0m[j], r1h[j], r1m[j]);
   stamps.mark(6);
   __syncthreads();     // the layer's output (LDS) is complete for every wave
   stamps.mark(7);
-}
-
-template <class Epi>
-__device__ __forceinline__ void tr_dense(gptr A, gptr bias, int urows, int kcols, const float* in, int out_tiles,
-                                         int lane, int wave, TrStamps& stamps, Epi epi) {
-  A = tr_uniform(A);
-  if (bias != nullptr) bias = tr_uniform(bias);
-  urows = tr_uniform(urows);
-  kcols = tr_uniform(kcols);
-  if (kcols >= 4) tr_dense_impl<true>(A, bias, urows, kcols, in, out_tiles, lane, wave, stamps, epi);
-  else tr_dense_impl<false>(A, bias, urows, kcols, in, out_tiles, lane, wave, stamps, epi);
 }
 
 __device__ __forceinline__ float tr_group_sum(float v) {   // sum over the 16 lanes of a lane group (all active)
@@ -382,11 +380,28 @@ __global__ void __launch_bounds__(64 * TR_WAVES) train_kernel(const TrainLaunch 
   }
   float* Y = lds + (size_t)K * 320;                       // [K*d] normalised state of every step (MODE 1)
   float* Zc = Y + (MODE == 1 ? (size_t)K * d * S : 0);    // [d]   running state (forward) / gradient state (backward)
-  float* X = Zc + (size_t)d * S;                          // [ip]  coupling-net input
-  float* GX = X + (size_t)p.ip * S;                       // [ip]  gradient w.r.t. the coupling-net input
-  float* H = GX + (size_t)p.ip * S;                       // [n_hidden][hp] hidden activations, then their gradients
-  float* O = H + (size_t)p.n_hidden * p.hp * S;           // [op]  net output, then its gradient
+  float* GX = Zc + (size_t)d * S;                         // [ip]  gradient w.r.t. the coupling-net input
+  float* O = GX + (size_t)p.ip * S;                       // [op]  net output, then its gradient
   float* O2 = O + (size_t)p.op * S;                       // [op]  realnvp: shift output / shift gradient
+  float* RED = O2 + (size_t)p.op * S;                     // [64]  cross-wave scratch
+  // split-f16 rows (B operands of the dense layers): net input, hidden activations (then their gradients), output gradient
+  unsigned char* sp = reinterpret_cast<unsigned char*>(lds) +
+                      (((reinterpret_cast<unsigned char*>(RED + 64) - reinterpret_cast<unsigned char*>(lds)) + 15) & ~15);   // 16-byte aligned
+  const TrSplit XS{sp, p.xw};
+  sp += 16 * XS.rs();
+  TrSplit HS[TR_MAX_LAYERS - 1];
+#pragma unroll
+  for (int l = 0; l < TR_MAX_LAYERS - 1; ++l) {
+    HS[l] = TrSplit{sp, p.hw};
+    if (l < p.n_hidden) sp += 16 * HS[l].rs();
+  }
+  const TrSplit GOS{sp, p.ow};
+  // channels between the 16-padded and the 32-padded widths are never written by an epilogue: zero the split rows once
+  {
+    unsigned char* s0 = const_cast<unsigned char*>(XS.base);
+    const int bytes = (int)((sp + 16 * GOS.rs()) - s0);
+    for (int e = 16 * threadIdx.x; e < bytes; e += 16 * 64 * TR_WAVES) *reinterpret_cast<u32x4*>(s0 + e) = u32x4{0u, 0u, 0u, 0u};
+  }
 
   const int hid_tiles = p.hp >> 4, out_tiles = p.op >> 4, in_tiles = p.ip >> 4;
 
@@ -398,53 +413,75 @@ __global__ void __launch_bounds__(64 * TR_WAVES) train_kernel(const TrainLaunch 
     else return (v - tp[0]) * tp[64] + tp[128];
   };
 
-  // ---- coupling net forward from X: hidden layers into H (+ emit), last layer into `out` (or skipped)
+  // ---- coupling net forward from XS: hidden layers into HS (+ emit f32), last layer into `out` (f32; or skipped)
   auto net_forward = [&](const TrNet& net, float* out, float* ws_net) {
-    const float* in = X;
+    TrSplit in = XS;
     const int nl = net.n_layers;
     for (int l = 0; l + 1 < nl; ++l) {
-      float* Hl = H + (size_t)l * p.hp * S;
+      const TrSplit Hl = HS[l];
       const bool emit = (MODE == 1) && ws_net != nullptr;    // backward sweep only: activation-side operand of dW
       float* ws_h = emit ? ws_net + ((size_t)p.ip + (size_t)l * p.hp) * p.np + row0 + i : nullptr;
       const int act = net.act;
       const TrLayer& L = net.layer[l];
-      tr_dense(tr_global(L.W), tr_global(L.b), L.rows, L.cols, in, hid_tiles, lane, wave, stamps, [&](int u, float v) {
-        const float h = tr_act(act, v);
-        Hl[u * S + i] = h;
-        if (emit) ws_h[(size_t)u * p.np] = h;
+      tr_dense(tr_uniform_ptr((gfrag)(p.frag + L.fw)), tr_uniform(tr_global(L.b)), tr_uniform(L.rows), in.w >> 5, hid_tiles, in, hid_tiles, lane, wave,
+               stamps, [&](int u0, f32x4 v) {
+        f32x4 h;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) h[r] = tr_act(act, v[r]);
+        Hl.put4(i, u0, h);
+        if (emit) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) ws_h[(size_t)(u0 + r) * p.np] = h[r];
+        }
       });
       in = Hl;
     }
     if (out != nullptr) {
       const TrLayer& L = net.layer[nl - 1];
-      tr_dense(tr_global(L.W), tr_global(L.b), L.rows, L.cols, in, out_tiles, lane, wave, stamps,
-               [&](int u, float v) { out[u * S + i] = v; });
+      tr_dense(tr_uniform_ptr((gfrag)(p.frag + L.fw)), tr_uniform(tr_global(L.b)), tr_uniform(L.rows), in.w >> 5, out_tiles, in, out_tiles, lane, wave,
+               stamps, [&](int u0, f32x4 v) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) out[(u0 + r) * S + i] = v[r];
+      });
     }
   };
 
-  // ---- coupling net backward: cur = gradient w.r.t. the net output (LDS, [op]); leaves d(loss)/d(net input) in GX
+  // ---- coupling net backward: cur = gradient w.r.t. the net output (LDS f32, [op]); leaves d(loss)/d(net input) in GX
   auto net_backward = [&](const TrNet& net, const float* cur, float* ws_net, bool accumulate) {
     const int nl = net.n_layers, nh = p.n_hidden;
-    // gradient-side operand of the last layer's weight gradient
+    // gradient-side operand of the last layer's weight gradient (f32 to the workspace) + its split copy for the dense chain
     {
       float* ws_d = ws_net + ((size_t)p.ip + 2 * (size_t)nh * p.hp) * p.np + row0 + i;
-      for (int u = g; u < p.op; u += GS) ws_d[(size_t)u * p.np] = cur[u * S + i];
+      for (int u = g; u < p.ow; u += GS) {
+        const float v = u < p.op ? cur[u * S + i] : 0.0f;
+        if (u < p.op) ws_d[(size_t)u * p.np] = v;
+        GOS.put1(i, u, v);
+      }
     }
+    __syncthreads();
+    TrSplit in = GOS;
     for (int l = nl - 1; l >= 1; --l) {
-      float* Hl = H + (size_t)(l - 1) * p.hp * S;           // activations of hidden layer l-1 -> overwritten by its gradient
+      const TrSplit Hl = HS[l - 1];                          // activations of hidden layer l-1 -> overwritten by its gradient
       float* ws_d = ws_net + ((size_t)p.ip + (size_t)nh * p.hp + (size_t)(l - 1) * p.hp) * p.np + row0 + i;
       const int act = net.act;
-      const TrLayer& L = net.layer[l];      // W^T (cols x rows), copied by transpose_kernel: same 16-byte row loads
-      tr_dense(tr_global(p.wt + L.wt), gptr(nullptr), L.cols, L.rows, cur, hid_tiles, lane, wave, stamps, [&](int u, float v) {
-        const float gpre = v * tr_dact(act, Hl[u * S + i]);
-        Hl[u * S + i] = gpre;
-        ws_d[(size_t)u * p.np] = gpre;
+      const TrLayer& L = net.layer[l];                       // A = W^T: output units = cols, k = rows
+      tr_dense(tr_uniform_ptr((gfrag)(p.frag + L.bw)), gptr(nullptr), tr_uniform(L.cols), in.w >> 5, hid_tiles, in, hid_tiles, lane, wave, stamps,
+               [&](int u0, f32x4 v) {
+        const f32x4 h = Hl.get4(i, u0);
+        f32x4 gpre;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) gpre[r] = v[r] * tr_dact(act, h[r]);
+        Hl.put4(i, u0, gpre);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) ws_d[(size_t)(u0 + r) * p.np] = gpre[r];
       });
-      cur = Hl;
+      in = Hl;
     }
     const TrLayer& L0 = net.layer[0];
-    tr_dense(tr_global(p.wt + L0.wt), gptr(nullptr), L0.cols, L0.rows, cur, in_tiles, lane, wave, stamps, [&](int u, float v) {
-      GX[u * S + i] = accumulate ? GX[u * S + i] + v : v;
+    tr_dense(tr_uniform_ptr((gfrag)(p.frag + L0.bw)), gptr(nullptr), tr_uniform(L0.cols), in.w >> 5, in_tiles, in, in_tiles, lane, wave, stamps,
+             [&](int u0, f32x4 v) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) GX[(u0 + r) * S + i] = accumulate ? GX[(u0 + r) * S + i] + v[r] : v[r];
     });
   };
 
@@ -475,7 +512,7 @@ __global__ void __launch_bounds__(64 * TR_WAVES) train_kernel(const TrainLaunch 
     if (MODE == 1 && k == ke - 1) break;                   // the last step's outputs are not needed for the backward
     __syncthreads();
     const int* ti = TI + k * 64;
-    for (int kk = g; kk < p.ip; kk += GS) X[kk * S + i] = kk < st.in_f ? Zc[ti[kk] * S + i] : 0.0f;
+    for (int kk = g; kk < p.xw; kk += GS) XS.put1(i, kk, kk < st.in_f ? Zc[ti[kk] * S + i] : 0.0f);
     __syncthreads();
     stamps.mark(1);
     if constexpr (KIND == GBNF_KIND_GLOW) {
@@ -510,12 +547,12 @@ __global__ void __launch_bounds__(64 * TR_WAVES) train_kernel(const TrainLaunch 
   if constexpr (MODE == 0) {
     ld += __shfl_xor(ld, 16);
     ld += __shfl_xor(ld, 32);
-    if ((lane >> 4) == 0) X[wave * 16 + i] = ld;          // X is free: fold the waves' partial sums through it
+    if ((lane >> 4) == 0) RED[wave * 16 + i] = ld;        // fold the waves' partial sums
     __syncthreads();
     if (valid) {
       if (p.ldj_out != nullptr && g == 0) {
         float t = p.ldj_accumulate ? p.ldj_out[ni] : 0.0f;
-        for (int w = 0; w < TR_WAVES; ++w) t += X[w * 16 + i];
+        for (int w = 0; w < TR_WAVES; ++w) t += RED[w * 16 + i];
         p.ldj_out[ni] = t;
       }
       if (p.z_out != nullptr && ke == K)
@@ -571,10 +608,11 @@ __global__ void __launch_bounds__(64 * TR_WAVES) train_kernel(const TrainLaunch 
       float* ws_step = p.ws + (size_t)k * nnets * p.net_rows * p.np;
       const int* ti = TI + k * 64;
       // net input (also the activation-side operand of the first layer's weight gradient)
-      for (int kk = g; kk < p.ip; kk += GS) {
+      for (int kk = g; kk < p.xw; kk += GS) {
         const float v = kk < st.in_f ? Yk[ti[kk] * S + i] : 0.0f;
-        X[kk * S + i] = v;
-        for (int q = 0; q < nnets; ++q) (ws_step + (size_t)q * p.net_rows * p.np)[(size_t)kk * p.np + row0 + i] = v;
+        XS.put1(i, kk, v);
+        if (kk < p.ip)
+          for (int q = 0; q < nnets; ++q) (ws_step + (size_t)q * p.net_rows * p.np)[(size_t)kk * p.np + row0 + i] = v;
       }
       __syncthreads();
       if constexpr (KIND == GBNF_KIND_GLOW) {
@@ -790,33 +828,49 @@ __global__ void __launch_bounds__(256) bn_bwd_fix_kernel(const TrStep* __restric
   gst[(size_t)slot * np + s] -= gamma / sigma * s1 / (float)n + xhat / (sigma * (float)(n - 1)) * s2;
 }
 
-// W (rows x cols) -> W^T (cols x rows) for every Linear of the component, one launch (32 x 32 tiles through LDS).
-struct TpProblem {
-  const float* W;
-  int64_t wt;          // float offset in the workspace's weight region
-  int rows, cols, blk_begin, nbx;
+// Split every Linear's LIVE f32 weight into f16x3 MFMA A fragments, both orientations, one launch: a 64-thread block
+// = one fragment pair (hi, mid) of [o][c]; lane (i,g) element j = M[16 o + i][32 c + 8 g + j], zero outside the matrix.
+struct PrepProblem {
+  const float* W;      // (rows, cols) row-major
+  int64_t off;         // u32x4 offset of this orientation's fragments
+  int rows, cols;      // of W
+  int trans;           // 0: M = W (out units = rows, k = cols); 1: M = W^T
+  int tiles, kc;       // fragment grid: output tiles x 32-wide k chunks
+  int blk_begin;
 };
 
-__global__ void __launch_bounds__(256) transpose_kernel(const TpProblem* __restrict__ probs, int n_probs, float* __restrict__ wt) {
-  __shared__ float tile[32][33];
+__global__ void __launch_bounds__(64) prep_kernel(const PrepProblem* __restrict__ probs, int n_probs, u32x4* __restrict__ frag) {
   int pi = 0;
   while (pi + 1 < n_probs && (int)blockIdx.x >= probs[pi + 1].blk_begin) ++pi;
-  const TpProblem P = probs[pi];
+  const PrepProblem P = probs[pi];
   const int blk = blockIdx.x - P.blk_begin;
-  const int r0 = (blk / P.nbx) * 32, c0 = (blk % P.nbx) * 32;
-  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  const int o = blk / P.kc, c = blk - o * P.kc;
+  const int lane = threadIdx.x, i = lane & 15, g = lane >> 4;
+  const int m = 16 * o + i;
+  float v[8];
 #pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    const int r = r0 + ty + 8 * j, c = c0 + tx;
-    tile[ty + 8 * j][tx] = (r < P.rows && c < P.cols) ? P.W[(size_t)r * P.cols + c] : 0.0f;
+  for (int j = 0; j < 8; ++j) {
+    const int k = 32 * c + 8 * g + j;
+    float x = 0.0f;
+    if (!P.trans) {
+      if (m < P.rows && k < P.cols) x = P.W[(size_t)m * P.cols + k];
+    } else {
+      if (m < P.cols && k < P.rows) x = P.W[(size_t)k * P.cols + m];
+    }
+    v[j] = x;
   }
-  __syncthreads();
-  float* out = wt + P.wt;
+  unsigned h[4], md[4];
 #pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    const int c = c0 + ty + 8 * j, r = r0 + tx;
-    if (c < P.cols && r < P.rows) out[(size_t)c * P.rows + r] = tile[tx][ty + 8 * j];
+  for (int q = 0; q < 4; ++q) {       // weights: hi rounded to nearest, mid = f16(x - hi)
+    typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+    const h2 hh = {(_Float16)v[2 * q], (_Float16)v[2 * q + 1]};
+    const h2 mm = {(_Float16)(v[2 * q] - (float)hh[0]), (_Float16)(v[2 * q + 1] - (float)hh[1])};
+    h[q] = __builtin_bit_cast(unsigned, hh);
+    md[q] = __builtin_bit_cast(unsigned, mm);
   }
+  u32x4* dst = frag + P.off + ((size_t)o * P.kc + c) * 128 + lane;
+  dst[0] = u32x4{h[0], h[1], h[2], h[3]};
+  dst[64] = u32x4{md[0], md[1], md[2], md[3]};
 }
 
 }  // namespace gbnf
@@ -830,9 +884,10 @@ struct gbnf_trainer {
   TrStep* steps_dev = nullptr;
   int* tail_dev = nullptr;
   WgProblem* probs_dev = nullptr;
-  TpProblem* tp_dev = nullptr;
-  int n_probs = 0, wg_blocks = 0, tp_blocks = 0;
-  int64_t wt_floats = 0;
+  PrepProblem* prep_dev = nullptr;
+  u32x4* frag_dev = nullptr;           // split-f16 weight fragments, rebuilt by prep_kernel at the start of every call
+  int n_probs = 0, wg_blocks = 0, n_prep = 0, prep_blocks = 0;
+  int hw = 0, xw = 0, ow = 0;
   int batch_stats = 0;                 // BatchNorm on batch statistics (the reference's train() mode)
   std::vector<int> has_norm;           // per step
   std::vector<char> stats_bound;       // per step: bmean / bvar bound by the caller
@@ -875,10 +930,12 @@ int gbnf_trainer_create(const gbnf_flow_desc* desc, gbnf_trainer** out) {
   t->ip = ceil16(d2);
   t->op = ceil16(glow && !additive ? 2 * d2 : d2);
   t->net_rows = (int64_t)t->ip + 2LL * t->n_hidden * t->hp + t->op;
-  const size_t common = (size_t)d + 2 * (size_t)t->ip + (size_t)t->n_hidden * t->hp + 2 * (size_t)t->op;
+  t->hw = (h + 31) / 32 * 32; t->xw = (d2 + 31) / 32 * 32; t->ow = ((glow && !additive ? 2 * d2 : d2) + 31) / 32 * 32;
+  const size_t common = (size_t)d + (size_t)t->ip + 2 * (size_t)t->op;            // f32 rows: state, GX, O, O2
+  const size_t split = 16 * ((size_t)(4 * t->xw + 16) + (size_t)t->n_hidden * (4 * t->hw + 16) + (size_t)(4 * t->ow + 16));
   const size_t tables = (size_t)K * 320 * 4;
-  t->lds_fwd = tables + common * TR_S * 4;
-  t->lds_bwd = tables + (common + (size_t)K * d) * TR_S * 4;
+  t->lds_fwd = tables + common * TR_S * 4 + 256 + 16 + split;
+  t->lds_bwd = tables + (common + (size_t)K * d) * TR_S * 4 + 256 + 16 + split;
   if (t->lds_bwd > (size_t)TR_LDS_BYTES) {
     const size_t need = t->lds_bwd;
     delete t;
@@ -888,9 +945,9 @@ int gbnf_trainer_create(const gbnf_flow_desc* desc, gbnf_trainer** out) {
 
   std::vector<TrStep> steps(K);
   std::vector<WgProblem> probs;
-  std::vector<TpProblem> tps;
-  int64_t wt_off = 0;
-  int tp_blocks = 0;
+  std::vector<PrepProblem> preps;
+  int64_t frag_off = 0;
+  int prep_blocks = 0;
   std::vector<int> sigma(d), prev(d);
   for (int j = 0; j < d; ++j) sigma[j] = j;
   int64_t goff = 0;
@@ -942,13 +999,27 @@ int gbnf_trainer_create(const gbnf_flow_desc* desc, gbnf_trainer** out) {
         L.W = lin.weight; L.b = lin.bias; L.rows = lin.out_features; L.cols = lin.in_features;
         L.gW = goff; goff += (int64_t)L.rows * L.cols;
         L.gb = goff; goff += L.rows;
-        L.wt = wt_off; wt_off += ((int64_t)L.rows * L.cols + 3) / 4 * 4;
-        TpProblem T{};
-        T.W = L.W; T.wt = L.wt; T.rows = L.rows; T.cols = L.cols;
-        T.nbx = (L.cols + 31) / 32;
-        T.blk_begin = tp_blocks;
-        tp_blocks += ((L.rows + 31) / 32) * T.nbx;
-        tps.push_back(T);
+        // fragment grids follow the LDS buffers the layer reads / writes: output tiles of the destination buffer, k chunks of
+        // the (32-padded) source rows
+        const bool first = l == 0, last = l == nl - 1;
+        for (int trans = 0; trans < 2; ++trans) {
+          PrepProblem P{};
+          P.W = L.W; P.rows = L.rows; P.cols = L.cols; P.trans = trans;
+          if (!trans) {            // forward: out = rows, k = cols
+            P.tiles = (last ? t->op : t->hp) / 16;
+            P.kc = (first ? t->xw : t->hw) / 32;
+            L.fw = frag_off;
+          } else {                 // backward: out = cols, k = rows
+            P.tiles = (first ? t->ip : t->hp) / 16;
+            P.kc = (last ? t->ow : t->hw) / 32;
+            L.bw = frag_off;
+          }
+          P.off = frag_off;
+          P.blk_begin = prep_blocks;
+          prep_blocks += P.tiles * P.kc;
+          frag_off += (int64_t)P.tiles * P.kc * 128;
+          preps.push_back(P);
+        }
         WgProblem P{};
         P.M = L.rows; P.N = L.cols;
         // gradient-side operand: D of this layer's output; activation-side operand: this layer's input
@@ -966,8 +1037,8 @@ int gbnf_trainer_create(const gbnf_flow_desc* desc, gbnf_trainer** out) {
   t->grad_floats = goff;
   t->n_probs = (int)probs.size();
   t->wg_blocks = blocks;
-  t->tp_blocks = tp_blocks;
-  t->wt_floats = wt_off + 16;
+  t->n_prep = (int)preps.size();
+  t->prep_blocks = prep_blocks;
   std::vector<int> tail(64, 0);
   for (int j = 0; j < d; ++j) tail[j] = sigma[j];
 
@@ -977,8 +1048,9 @@ int gbnf_trainer_create(const gbnf_flow_desc* desc, gbnf_trainer** out) {
   if (e == hipSuccess) e = hipMemcpy(t->tail_dev, tail.data(), sizeof(int) * 64, hipMemcpyHostToDevice);
   if (e == hipSuccess) e = hipMalloc((void**)&t->probs_dev, sizeof(WgProblem) * probs.size());
   if (e == hipSuccess) e = hipMemcpy(t->probs_dev, probs.data(), sizeof(WgProblem) * probs.size(), hipMemcpyHostToDevice);
-  if (e == hipSuccess) e = hipMalloc((void**)&t->tp_dev, sizeof(TpProblem) * tps.size());
-  if (e == hipSuccess) e = hipMemcpy(t->tp_dev, tps.data(), sizeof(TpProblem) * tps.size(), hipMemcpyHostToDevice);
+  if (e == hipSuccess) e = hipMalloc((void**)&t->prep_dev, sizeof(PrepProblem) * preps.size());
+  if (e == hipSuccess) e = hipMemcpy(t->prep_dev, preps.data(), sizeof(PrepProblem) * preps.size(), hipMemcpyHostToDevice);
+  if (e == hipSuccess) e = hipMalloc((void**)&t->frag_dev, (size_t)frag_off * 16);
   if (e == hipSuccess) {
     const void* fns[4] = {(const void*)train_kernel<GBNF_KIND_GLOW, 0>, (const void*)train_kernel<GBNF_KIND_GLOW, 1>,
                           (const void*)train_kernel<GBNF_KIND_REALNVP, 0>, (const void*)train_kernel<GBNF_KIND_REALNVP, 1>};
@@ -998,7 +1070,8 @@ int gbnf_trainer_destroy(gbnf_trainer* t) {
   if (t->steps_dev) (void)hipFree(t->steps_dev);
   if (t->tail_dev) (void)hipFree(t->tail_dev);
   if (t->probs_dev) (void)hipFree(t->probs_dev);
-  if (t->tp_dev) (void)hipFree(t->tp_dev);
+  if (t->prep_dev) (void)hipFree(t->prep_dev);
+  if (t->frag_dev) (void)hipFree(t->frag_dev);
   delete t;
   return GBNF_OK;
 }
@@ -1012,9 +1085,9 @@ int gbnf_trainer_grad_floats(const gbnf_trainer* t, int64_t* n_floats) {
 int gbnf_trainer_workspace_bytes(const gbnf_trainer* t, int64_t n, int64_t* bytes) {
   if (!t || !bytes || n < 0) return fail(GBNF_ERR_INVALID, "gbnf_trainer_workspace_bytes: bad argument");
   const int64_t np = (n + 15) / 16 * 16;
-  // operand regions + 64 slack rows (a 64-row block of wgrad_kernel may run past the last region) + transposed weights
+  // operand regions + 64 slack rows (a 64-row block of wgrad_kernel may run past the last region)
   // ... + the gradient state of step-by-step launches (batch-statistics BatchNorm)
-  *bytes = (((int64_t)t->K * t->nnets * t->net_rows + 64) * np + t->wt_floats + (int64_t)t->d * np) * 4;
+  *bytes = (((int64_t)t->K * t->nnets * t->net_rows + 64) * np + (int64_t)t->d * np) * 4;
   return GBNF_OK;
 }
 
@@ -1032,6 +1105,7 @@ static void fill_launch(const gbnf_trainer* t, TrainLaunch& p, const float* x, i
   p.n = n; p.np = (n + 15) / 16 * 16;
   p.d = t->d; p.K = t->K; p.kind = t->kind; p.additive = t->additive;
   p.n_hidden = t->n_hidden; p.hp = t->hp; p.ip = t->ip; p.op = t->op; p.net_rows = t->net_rows;
+  p.hw = t->hw; p.xw = t->xw; p.ow = t->ow; p.frag = t->frag_dev;
   p.k_begin = 0; p.k_end = t->K;
 }
 
@@ -1084,6 +1158,8 @@ int gbnf_trainer_forward(const gbnf_trainer* t, const float* x, int64_t n, float
   p.z_out = z; p.ldj_out = ldj; p.trace_out = trace;
   p.batch_stats = t->batch_stats;
   hipStream_t s = (hipStream_t)stream;
+  // the parameters may have changed since the last call: split them into this call's MFMA fragments
+  hipLaunchKernelGGL(prep_kernel, dim3((unsigned)t->prep_blocks), dim3(64), 0, s, (const PrepProblem*)t->prep_dev, t->n_prep, t->frag_dev);
   if (!needs_step_launches(t)) {
     launch_train<0>(t, p, s);
   } else {
@@ -1125,11 +1201,9 @@ int gbnf_trainer_backward(const gbnf_trainer* t, const float* x, int64_t n, cons
   fill_launch(t, p, x, n);
   p.g_z = g_z; p.g_ldj = g_ldj; p.g_x = g_x; p.grads = grads; p.ws = (float*)workspace; p.trace = trace;
   p.batch_stats = t->batch_stats;
-  float* wt = (float*)workspace + ((int64_t)t->K * t->nnets * t->net_rows + 64) * p.np;
-  float* gstate = wt + t->wt_floats;                       // [d][np]: gradient state between step launches
-  p.wt = wt;
+  float* gstate = (float*)workspace + ((int64_t)t->K * t->nnets * t->net_rows + 64) * p.np;   // [d][np]: gradient state between step launches
   hipStream_t s = (hipStream_t)stream;
-  hipLaunchKernelGGL(transpose_kernel, dim3((unsigned)t->tp_blocks), dim3(256), 0, s, t->tp_dev, (int)(t->n_probs), wt);
+  hipLaunchKernelGGL(prep_kernel, dim3((unsigned)t->prep_blocks), dim3(64), 0, s, (const PrepProblem*)t->prep_dev, t->n_prep, t->frag_dev);
   if (!needs_step_launches(t)) {
     launch_train<1>(t, p, s);
   } else {
