@@ -193,6 +193,12 @@ __device__ __forceinline__ void tr_split_pair(float x0, float x1, unsigned& hi, 
   const auto m = __builtin_amdgcn_cvt_pkrtz(x0 - (float)h[0], x1 - (float)h[1]);
   mid = __builtin_bit_cast(unsigned, m);
 }
+// Workgroup barrier that publishes LDS traffic only: the epilogues' global stores (weight-gradient operands) and the
+// fragment prefetches stay in flight across it -- __syncthreads() would drain them (vmcnt(0)) at the end of every layer.
+__device__ __forceinline__ void tr_lds_barrier() {
+  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
 // a split activation buffer in LDS: 16 rows (samples) of [hi: w halfs][mid: w halfs] + 16 B
 struct TrSplit {
   unsigned char* base;
@@ -320,7 +326,7 @@ __device__ __forceinline__ void tr_dense(gfrag A, gptr bias, int urows, int kc32
   for (int j = 0; j < TR_PD - 1; ++j)
     if (t + j < T) body(r0h[j], r0m[j], r1h[j], r1m[j]);
   stamps.mark(6);
-  __syncthreads();     // the layer's output (LDS) is complete for every wave
+  tr_lds_barrier();    // the layer's output (LDS) is complete for every wave
   stamps.mark(7);
 }
 
@@ -378,7 +384,19 @@ __global__ void __launch_bounds__(64 * TR_WAVES) train_kernel(const TrainLaunch 
       tp[0] = p0; tp[64] = p1; tp[128] = p2; tp[192] = p3;
     }
   }
-  float* Y = lds + (size_t)K * 320;                       // [K*d] normalised state of every step (MODE 1)
+  // ... and the per-layer descriptors (bias address, fragment offsets, rows, cols): 8 words per (step, net, layer)
+  unsigned* TL = reinterpret_cast<unsigned*>(lds + (size_t)K * 320);
+  for (int e = threadIdx.x; e < K * 2 * TR_MAX_LAYERS; e += 64 * TR_WAVES) {
+    const int k = e / (2 * TR_MAX_LAYERS), q = (e / TR_MAX_LAYERS) & 1, l = e % TR_MAX_LAYERS;
+    const TrLayer& L = p.steps[k].net[q].layer[l];
+    unsigned* t = TL + (size_t)e * 8;
+    const unsigned long long b = (unsigned long long)L.b;
+    t[0] = (unsigned)b; t[1] = (unsigned)(b >> 32);
+    t[2] = (unsigned)L.fw; t[3] = (unsigned)(L.fw >> 32);
+    t[4] = (unsigned)L.bw; t[5] = (unsigned)(L.bw >> 32);
+    t[6] = (unsigned)L.rows; t[7] = (unsigned)L.cols;
+  }
+  float* Y = lds + (size_t)K * 320 + (size_t)K * 2 * TR_MAX_LAYERS * 8;   // [K*d] normalised state of every step (MODE 1)
   float* Zc = Y + (MODE == 1 ? (size_t)K * d * S : 0);    // [d]   running state (forward) / gradient state (backward)
   float* GX = Zc + (size_t)d * S;                         // [ip]  gradient w.r.t. the coupling-net input
   float* O = GX + (size_t)p.ip * S;                       // [op]  net output, then its gradient
@@ -413,17 +431,34 @@ __global__ void __launch_bounds__(64 * TR_WAVES) train_kernel(const TrainLaunch 
     else return (v - tp[0]) * tp[64] + tp[128];
   };
 
+  struct LayerD { gptr b; long long fw, bw; int rows, cols; };
+  auto layer_desc = [&](int k, int q, int l) -> LayerD {     // from the LDS table, moved to scalar registers
+    const unsigned* t = TL + ((size_t)(k * 2 + q) * TR_MAX_LAYERS + l) * 8;
+    unsigned w[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) w[e] = __builtin_amdgcn_readfirstlane(t[e]);
+    LayerD D;
+    D.b = (gptr)(((unsigned long long)w[1] << 32) | w[0]);
+    D.fw = (long long)(((unsigned long long)w[3] << 32) | w[2]);
+    D.bw = (long long)(((unsigned long long)w[5] << 32) | w[4]);
+    D.rows = (int)w[6]; D.cols = (int)w[7];
+    return D;
+  };
+  const int nl = tr_uniform(p.steps[0].net[0].n_layers);
+  const int act_a = tr_uniform(p.steps[0].net[0].act), act_b = tr_uniform(p.steps[0].net[KIND == GBNF_KIND_GLOW ? 0 : 1].act);
+
   // ---- coupling net forward from XS: hidden layers into HS (+ emit f32), last layer into `out` (f32; or skipped)
-  auto net_forward = [&](const TrNet& net, float* out, float* ws_net) {
+  auto net_forward = [&](int k, int q, float* out, float* ws_net) {
     TrSplit in = XS;
-    const int nl = net.n_layers;
+    const int act = q == 0 ? act_a : act_b;
     for (int l = 0; l + 1 < nl; ++l) {
       const TrSplit Hl = HS[l];
       const bool emit = (MODE == 1) && ws_net != nullptr;    // backward sweep only: activation-side operand of dW
-      float* ws_h = emit ? ws_net + ((size_t)p.ip + (size_t)l * p.hp) * p.np + row0 + i : nullptr;
-      const int act = net.act;
-      const TrLayer& L = net.layer[l];
-      tr_dense(tr_uniform_ptr((gfrag)(p.frag + L.fw)), tr_uniform(tr_global(L.b)), tr_uniform(L.rows), in.w >> 5, hid_tiles, in, hid_tiles, lane, wave,
+      // operand sub-regions are tiled: [tile of 16 samples][unit][16] -- a workgroup's rows of one operand are one
+      // contiguous block, and a unit's 16 samples one 64-byte run (wgrad_kernel reads 16 units x 64 B per wave load)
+      float* ws_h = emit ? ws_net + ((size_t)p.ip + (size_t)l * p.hp) * p.np + (size_t)blockIdx.x * p.hp * 16 + i : nullptr;
+      const LayerD L = layer_desc(k, q, l);
+      tr_dense((gfrag)(p.frag + L.fw), L.b, L.rows, in.w >> 5, hid_tiles, in, hid_tiles, lane, wave,
                stamps, [&](int u0, f32x4 v) {
         f32x4 h;
 #pragma unroll
@@ -431,14 +466,14 @@ __global__ void __launch_bounds__(64 * TR_WAVES) train_kernel(const TrainLaunch 
         Hl.put4(i, u0, h);
         if (emit) {
 #pragma unroll
-          for (int r = 0; r < 4; ++r) ws_h[(size_t)(u0 + r) * p.np] = h[r];
+          for (int r = 0; r < 4; ++r) ws_h[(size_t)(u0 + r) * 16] = h[r];
         }
       });
       in = Hl;
     }
     if (out != nullptr) {
-      const TrLayer& L = net.layer[nl - 1];
-      tr_dense(tr_uniform_ptr((gfrag)(p.frag + L.fw)), tr_uniform(tr_global(L.b)), tr_uniform(L.rows), in.w >> 5, out_tiles, in, out_tiles, lane, wave,
+      const LayerD L = layer_desc(k, q, nl - 1);
+      tr_dense((gfrag)(p.frag + L.fw), L.b, L.rows, in.w >> 5, out_tiles, in, out_tiles, lane, wave,
                stamps, [&](int u0, f32x4 v) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) out[(u0 + r) * S + i] = v[r];
@@ -447,25 +482,25 @@ __global__ void __launch_bounds__(64 * TR_WAVES) train_kernel(const TrainLaunch 
   };
 
   // ---- coupling net backward: cur = gradient w.r.t. the net output (LDS f32, [op]); leaves d(loss)/d(net input) in GX
-  auto net_backward = [&](const TrNet& net, const float* cur, float* ws_net, bool accumulate) {
-    const int nl = net.n_layers, nh = p.n_hidden;
+  auto net_backward = [&](int k, int q, const float* cur, float* ws_net, bool accumulate) {
+    const int nh = p.n_hidden;
+    const int act = q == 0 ? act_a : act_b;
     // gradient-side operand of the last layer's weight gradient (f32 to the workspace) + its split copy for the dense chain
     {
-      float* ws_d = ws_net + ((size_t)p.ip + 2 * (size_t)nh * p.hp) * p.np + row0 + i;
+      float* ws_d = ws_net + ((size_t)p.ip + 2 * (size_t)nh * p.hp) * p.np + (size_t)blockIdx.x * p.op * 16 + i;
       for (int u = g; u < p.ow; u += GS) {
         const float v = u < p.op ? cur[u * S + i] : 0.0f;
-        if (u < p.op) ws_d[(size_t)u * p.np] = v;
+        if (u < p.op) ws_d[(size_t)u * 16] = v;
         GOS.put1(i, u, v);
       }
     }
-    __syncthreads();
+    tr_lds_barrier();
     TrSplit in = GOS;
     for (int l = nl - 1; l >= 1; --l) {
       const TrSplit Hl = HS[l - 1];                          // activations of hidden layer l-1 -> overwritten by its gradient
-      float* ws_d = ws_net + ((size_t)p.ip + (size_t)nh * p.hp + (size_t)(l - 1) * p.hp) * p.np + row0 + i;
-      const int act = net.act;
-      const TrLayer& L = net.layer[l];                       // A = W^T: output units = cols, k = rows
-      tr_dense(tr_uniform_ptr((gfrag)(p.frag + L.bw)), gptr(nullptr), tr_uniform(L.cols), in.w >> 5, hid_tiles, in, hid_tiles, lane, wave, stamps,
+      float* ws_d = ws_net + ((size_t)p.ip + (size_t)nh * p.hp + (size_t)(l - 1) * p.hp) * p.np + (size_t)blockIdx.x * p.hp * 16 + i;
+      const LayerD L = layer_desc(k, q, l);                  // A = W^T: output units = cols, k = rows
+      tr_dense((gfrag)(p.frag + L.bw), gptr(nullptr), L.cols, in.w >> 5, hid_tiles, in, hid_tiles, lane, wave, stamps,
                [&](int u0, f32x4 v) {
         const f32x4 h = Hl.get4(i, u0);
         f32x4 gpre;
@@ -473,12 +508,12 @@ __global__ void __launch_bounds__(64 * TR_WAVES) train_kernel(const TrainLaunch 
         for (int r = 0; r < 4; ++r) gpre[r] = v[r] * tr_dact(act, h[r]);
         Hl.put4(i, u0, gpre);
 #pragma unroll
-        for (int r = 0; r < 4; ++r) ws_d[(size_t)(u0 + r) * p.np] = gpre[r];
+        for (int r = 0; r < 4; ++r) ws_d[(size_t)(u0 + r) * 16] = gpre[r];
       });
       in = Hl;
     }
-    const TrLayer& L0 = net.layer[0];
-    tr_dense(tr_uniform_ptr((gfrag)(p.frag + L0.bw)), gptr(nullptr), tr_uniform(L0.cols), in.w >> 5, in_tiles, in, in_tiles, lane, wave, stamps,
+    const LayerD L0 = layer_desc(k, q, 0);
+    tr_dense((gfrag)(p.frag + L0.bw), gptr(nullptr), L0.cols, in.w >> 5, in_tiles, in, in_tiles, lane, wave, stamps,
              [&](int u0, f32x4 v) {
 #pragma unroll
       for (int r = 0; r < 4; ++r) GX[(u0 + r) * S + i] = accumulate ? GX[(u0 + r) * S + i] + v[r] : v[r];
@@ -491,7 +526,7 @@ __global__ void __launch_bounds__(64 * TR_WAVES) train_kernel(const TrainLaunch 
   } else {
     for (int j = g; j < d; j += GS) Zc[j * S + i] = valid ? p.x[ni * d + j] : 0.0f;
   }
-  __syncthreads();    // (also: the tables are complete)
+  tr_lds_barrier();    // (also: the tables are complete)
   stamps.mark(0);
 
   // =============================== forward through all steps
@@ -510,13 +545,13 @@ __global__ void __launch_bounds__(64 * TR_WAVES) train_kernel(const TrainLaunch 
       if (MODE == 0 && p.trace_out != nullptr) p.trace_out[((size_t)k * d + s) * p.np + row0 + i] = y;
     }
     if (MODE == 1 && k == ke - 1) break;                   // the last step's outputs are not needed for the backward
-    __syncthreads();
+    tr_lds_barrier();
     const int* ti = TI + k * 64;
     for (int kk = g; kk < p.xw; kk += GS) XS.put1(i, kk, kk < st.in_f ? Zc[ti[kk] * S + i] : 0.0f);
-    __syncthreads();
+    tr_lds_barrier();
     stamps.mark(1);
     if constexpr (KIND == GBNF_KIND_GLOW) {
-      net_forward(st.net[0], O, nullptr);
+      net_forward(k, 0, O, nullptr);
       stamps.mark(-1);
       for (int j = g; j < st.out_f; j += GS) {
         const int slot = ti[32 + j];
@@ -531,8 +566,8 @@ __global__ void __launch_bounds__(64 * TR_WAVES) train_kernel(const TrainLaunch 
         }
       }
     } else {
-      net_forward(st.net[0], O2, nullptr);
-      net_forward(st.net[1], O, nullptr);
+      net_forward(k, 0, O2, nullptr);
+      net_forward(k, 1, O, nullptr);
       for (int j = g; j < st.out_f; j += GS) {
         const int slot = ti[32 + j];
         const float scale = O[j * S + i];
@@ -540,7 +575,7 @@ __global__ void __launch_bounds__(64 * TR_WAVES) train_kernel(const TrainLaunch 
         ld += scale;                                                             // models/transformations.py:577
       }
     }
-    __syncthreads();
+    tr_lds_barrier();
     stamps.mark(3);
   }
 
@@ -548,7 +583,7 @@ __global__ void __launch_bounds__(64 * TR_WAVES) train_kernel(const TrainLaunch 
     ld += __shfl_xor(ld, 16);
     ld += __shfl_xor(ld, 32);
     if ((lane >> 4) == 0) RED[wave * 16 + i] = ld;        // fold the waves' partial sums
-    __syncthreads();
+    tr_lds_barrier();
     if (valid) {
       if (p.ldj_out != nullptr && g == 0) {
         float t = p.ldj_accumulate ? p.ldj_out[ni] : 0.0f;
@@ -568,14 +603,14 @@ __global__ void __launch_bounds__(64 * TR_WAVES) train_kernel(const TrainLaunch 
     return;
   } else {
     // =============================== backward
-    __syncthreads();
+    tr_lds_barrier();
     const float gl = (valid && p.g_ldj != nullptr) ? p.g_ldj[ni] : 0.0f;
     if (p.gstate_in != nullptr) {
       for (int s = g; s < d; s += GS) Zc[s * S + i] = p.gstate_in[(size_t)s * p.np + row0 + i];
     } else {
       for (int j = g; j < d; j += GS) Zc[p.tail[j] * S + i] = (valid && p.g_z != nullptr) ? p.g_z[ni * d + j] : 0.0f;
     }
-    __syncthreads();
+    tr_lds_barrier();
     float* G = Zc;
     const int nnets = (KIND == GBNF_KIND_GLOW) ? 1 : 2;
 
@@ -612,11 +647,12 @@ __global__ void __launch_bounds__(64 * TR_WAVES) train_kernel(const TrainLaunch 
         const float v = kk < st.in_f ? Yk[ti[kk] * S + i] : 0.0f;
         XS.put1(i, kk, v);
         if (kk < p.ip)
-          for (int q = 0; q < nnets; ++q) (ws_step + (size_t)q * p.net_rows * p.np)[(size_t)kk * p.np + row0 + i] = v;
+          for (int q = 0; q < nnets; ++q)
+            (ws_step + (size_t)q * p.net_rows * p.np)[((size_t)blockIdx.x * p.ip + kk) * 16 + i] = v;
       }
-      __syncthreads();
+      tr_lds_barrier();
       if constexpr (KIND == GBNF_KIND_GLOW) {
-        net_forward(st.net[0], O, ws_step);
+        net_forward(k, 0, O, ws_step);
         for (int j = g; j < st.out_f; j += GS) {
           const int slot = ti[32 + j];
           const float y2 = Yk[slot * S + i], g2 = G[slot * S + i];
@@ -635,14 +671,14 @@ __global__ void __launch_bounds__(64 * TR_WAVES) train_kernel(const TrainLaunch 
           }
           G[slot * S + i] = norm_bwd(st, k, slot, gy, y2);
         }
-        __syncthreads();
-        net_backward(st.net[0], O, ws_step, false);
+        tr_lds_barrier();
+        net_backward(k, 0, O, ws_step, false);
       } else {
         float* ws_t = ws_step;
         float* ws_s = ws_step + (size_t)p.net_rows * p.np;
-        net_forward(st.net[1], O, ws_s);                                 // log-scale net
+        net_forward(k, 1, O, ws_s);                                 // log-scale net
         for (int u = g; u < p.op; u += GS) O2[u * S + i] = 0.0f;
-        __syncthreads();
+        tr_lds_barrier();
         for (int j = g; j < st.out_f; j += GS) {
           const int slot = ti[32 + j];
           const float y2 = Yk[slot * S + i], g2 = G[slot * S + i];
@@ -651,16 +687,16 @@ __global__ void __launch_bounds__(64 * TR_WAVES) train_kernel(const TrainLaunch 
           O[j * S + i] = g2 * y2 * es + gl;                              // d/d scale: z2' = shift + y2 e^scale, ld += scale
           G[slot * S + i] = norm_bwd(st, k, slot, g2 * es, y2);
         }
-        __syncthreads();
-        net_backward(st.net[1], O, ws_s, false);
-        net_forward(st.net[0], nullptr, ws_t);                           // shift net: only its activations are needed
-        net_backward(st.net[0], O2, ws_t, true);
+        tr_lds_barrier();
+        net_backward(k, 1, O, ws_s, false);
+        net_forward(k, 0, nullptr, ws_t);                           // shift net: only its activations are needed
+        net_backward(k, 0, O2, ws_t, true);
       }
       for (int kk = g; kk < st.in_f; kk += GS) {
         const int slot = ti[kk];
         G[slot * S + i] = norm_bwd(st, k, slot, G[slot * S + i] + GX[kk * S + i], Yk[slot * S + i]);
       }
-      __syncthreads();
+      tr_lds_barrier();
     }
     if (p.gstate_out != nullptr) {
       for (int s = g; s < d; s += GS) p.gstate_out[(size_t)s * p.np + row0 + i] = G[s * S + i];
@@ -677,9 +713,10 @@ __global__ void __launch_bounds__(64 * TR_WAVES) train_kernel(const TrainLaunch 
 // padded matrix belong to the next workspace region (finite numbers) and only feed output rows that are never stored.
 // ---------------------------------------------------------------------------------------------------------------
 struct WgProblem {
-  int64_t d_row, a_row;   // first row (of np floats) of the two operands in the workspace
+  int64_t d_row, a_row;   // first row (of np floats) of the two operands' sub-regions in the workspace
   int64_t c_off, b_off;   // float offsets of dW / db in the flat gradient buffer
   int M, N, blk_begin, nb;
+  int d_rows, a_rows;     // rows of the two sub-regions (tiled as [tile][row][16 samples])
 };
 constexpr int WG_CHUNK = 512;   // samples per block
 constexpr int WG_PD = 2;        // 16-sample groups of operand loads in flight
@@ -695,9 +732,10 @@ __global__ void __launch_bounds__(64) wgrad_kernel(const WgProblem* __restrict__
   const int m0 = (blk / P.nb) * 64, n0 = (blk % P.nb) * 64;
   const int64_t s_begin = (int64_t)blockIdx.y * WG_CHUNK;
   const int64_t s_end = (s_begin + WG_CHUNK < np) ? s_begin + WG_CHUNK : np;
-  const float* Db = ws + (P.d_row + m0 + i) * np + 4 * g;
-  const float* Ab = ws + (P.a_row + n0 + i) * np + 4 * g;
-  const int64_t t16 = 16 * np;
+  // element (row, sample s) of a sub-region with R rows: base + ((s / 16) * R + row) * 16 + s % 16
+  const float* Db = ws + P.d_row * np + (int64_t)(m0 + i) * 16 + 4 * g;
+  const float* Ab = ws + P.a_row * np + (int64_t)(n0 + i) * 16 + 4 * g;
+  const int64_t dstep = (int64_t)P.d_rows, astep = (int64_t)P.a_rows;      // floats per sample when walking tiles (R * 16 / 16)
   f32x4 acc[4][4];
   f32x4 bsum[4];
   const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
@@ -713,8 +751,8 @@ __global__ void __launch_bounds__(64) wgrad_kernel(const WgProblem* __restrict__
     const int64_t s = sl < s_end ? sl : s_begin;       // past the end: a valid (unused) group again
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
-      d[t] = *(gv4)(Db + t * t16 + s);
-      a[t] = *(gv4)(Ab + t * t16 + s);
+      d[t] = *(gv4)(Db + s * dstep + t * 256);         // 16 rows further = 256 floats inside the tile
+      a[t] = *(gv4)(Ab + s * astep + t * 256);
     }
     sl += 16;
   };
@@ -933,7 +971,7 @@ int gbnf_trainer_create(const gbnf_flow_desc* desc, gbnf_trainer** out) {
   t->hw = (h + 31) / 32 * 32; t->xw = (d2 + 31) / 32 * 32; t->ow = ((glow && !additive ? 2 * d2 : d2) + 31) / 32 * 32;
   const size_t common = (size_t)d + (size_t)t->ip + 2 * (size_t)t->op;            // f32 rows: state, GX, O, O2
   const size_t split = 16 * ((size_t)(4 * t->xw + 16) + (size_t)t->n_hidden * (4 * t->hw + 16) + (size_t)(4 * t->ow + 16));
-  const size_t tables = (size_t)K * 320 * 4;
+  const size_t tables = (size_t)K * (320 + 2 * TR_MAX_LAYERS * 8) * 4;
   t->lds_fwd = tables + common * TR_S * 4 + 256 + 16 + split;
   t->lds_bwd = tables + (common + (size_t)K * d) * TR_S * 4 + 256 + 16 + split;
   if (t->lds_bwd > (size_t)TR_LDS_BYTES) {
@@ -1027,6 +1065,8 @@ int gbnf_trainer_create(const gbnf_flow_desc* desc, gbnf_trainer** out) {
                                           : (int64_t)t->ip + (int64_t)t->n_hidden * t->hp + (int64_t)l * t->hp);
         P.a_row = base_row + (l == 0 ? 0 : (int64_t)t->ip + (int64_t)(l - 1) * t->hp);
         P.c_off = L.gW; P.b_off = L.gb;
+        P.d_rows = (l == nl - 1) ? t->op : t->hp;
+        P.a_rows = (l == 0) ? t->ip : t->hp;
         P.nb = (P.N + 63) / 64;
         P.blk_begin = blocks;
         blocks += ((P.M + 63) / 64) * P.nb;
