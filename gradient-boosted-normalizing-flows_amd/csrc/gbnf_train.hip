@@ -28,6 +28,7 @@
 #include <cmath>
 #include <cstddef>
 #include <cstdint>
+#include <cstdlib>
 #include <cstring>
 #include <vector>
 
@@ -41,22 +42,23 @@ using u32x4 = __attribute__((ext_vector_type(4))) unsigned;
 using u32x2 = __attribute__((ext_vector_type(2))) unsigned;
 using f16x8 = __attribute__((ext_vector_type(8))) _Float16;
 
-constexpr int TR_S = 17;            // LDS row stride (floats): 16 samples + 1 pad
+constexpr int TR_MAX_NT = 2;        // 16-sample tiles per workgroup (they share every weight fragment a wave loads)
 constexpr int TR_MAX_LAYERS = 4;    // Linear layers per coupling net (depth <= 2)
 constexpr int TR_MAX_IN = 32;       // coupling-net input / coupled-half width
 constexpr int TR_LDS_BYTES = 160 * 1024;
 #ifndef GBNF_TR_WAVES
-#define GBNF_TR_WAVES 4
+#define GBNF_TR_WAVES 8
 #endif
 constexpr int TR_PD = 4;            // weight-prefetch distance of the dense layers, in k-chunks (even: B ping-pong)
 static_assert(TR_PD % 2 == 0, "the LDS operand ping-pong follows the ring index");
-constexpr int TR_WAVES = GBNF_TR_WAVES;         // waves per workgroup; they share one 16-sample tile and split every layer's tiles
+constexpr int TR_WAVES = GBNF_TR_WAVES;         // waves per workgroup; they share the workgroup's sample tiles and split every layer's output tiles
 
 struct TrLayer {
   const float* W;      // (rows, cols) row-major = nn.Linear.weight (out, in)
   const float* b;      // (rows,)
   int64_t gW, gb;      // float offsets into the flat gradient buffer
   int64_t fw, bw;      // u32x4 offsets of the split fragments of W (forward) / W^T (backward) in the trainer's fragment buffer
+  int64_t fb;          // float offset (same buffer) of the bias, zero-padded to whole 16-unit tiles
   int rows, cols;
 };
 struct TrNet {
@@ -103,7 +105,7 @@ struct TrainLaunch {
   unsigned long long* dbg;   // diagnostic builds only
   float* ws;           // MODE 1 workspace: operands of the weight gradients
   const u32x4* frag;   // split-f16 weight fragments of this call (prep_kernel)
-  int64_t n, np;       // samples, samples rounded up to 16
+  int64_t n, np;       // samples, samples rounded up to whole workgroups (16 * TR_MAX_NT)
   int d, K, kind, additive;
   int n_hidden;        // hidden layers per net = depth + 1
   int hp, ip, op;      // padded hidden / net-input / net-output rows (multiples of 16)
@@ -115,10 +117,28 @@ __device__ __forceinline__ float tr_tanh(float x) {
   const float e = __builtin_amdgcn_exp2f(x * 2.8853900817779268f);
   return __builtin_fmaf(-2.0f, __builtin_amdgcn_rcpf(e + 1.0f), 1.0f);
 }
-__device__ __forceinline__ float tr_act(int act, float v) { return act == GBNF_ACT_TANH ? tr_tanh(v) : fmaxf(v, 0.0f); }
-// derivative of the activation expressed through its OUTPUT h
-__device__ __forceinline__ float tr_dact(int act, float h) {
-  return act == GBNF_ACT_TANH ? __builtin_fmaf(-h, h, 1.0f) : (h > 0.0f ? 1.0f : 0.0f);
+// four values at a time: `act` is uniform, so this is one scalar branch around straight-line code
+__device__ __forceinline__ f32x4 tr_act4(int act, f32x4 v) {
+  f32x4 h;
+  if (act == GBNF_ACT_TANH) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) h[r] = tr_tanh(v[r]);
+  } else {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) h[r] = fmaxf(v[r], 0.0f);
+  }
+  return h;
+}
+__device__ __forceinline__ f32x4 tr_dact4_mul(int act, f32x4 h, f32x4 v) {   // v * act'(pre-activation), through the output h
+  f32x4 o;
+  if (act == GBNF_ACT_TANH) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) o[r] = v[r] * __builtin_fmaf(-h[r], h[r], 1.0f);
+  } else {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) o[r] = h[r] > 0.0f ? v[r] : 0.0f;
+  }
+  return o;
 }
 __device__ __forceinline__ f32x4 tr_mfma(float a, float b, f32x4 c) {
   return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
@@ -132,6 +152,16 @@ __device__ __forceinline__ void tr_mfma_drain(f32x4& c0, f32x4& c1) {
 // ... and the other direction: freshly written accumulators feed an MFMA in the next basic block.
 __device__ __forceinline__ void tr_acc_settle(f32x4& c0, f32x4& c1) {
   asm volatile("s_nop 3" : "+a"(c0), "+a"(c1));
+}
+template <int NT>
+__device__ __forceinline__ void tr_mfma_drain(f32x4 (&c0)[NT], f32x4 (&c1)[NT]) {
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) tr_mfma_drain(c0[nt], c1[nt]);
+}
+template <int NT>
+__device__ __forceinline__ void tr_acc_settle(f32x4 (&c0)[NT], f32x4 (&c1)[NT]) {
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) tr_acc_settle(c0[nt], c1[nt]);
 }
 
 // Parameter tensors are global memory: say so, or every load is a flat_load that also counts against lgkmcnt.
@@ -199,30 +229,40 @@ __device__ __forceinline__ void tr_lds_barrier() {
   asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 }
 
-// a split activation buffer in LDS: 16 rows (samples) of [hi: w halfs][mid: w halfs] + 16 B
+// LDS pointers carry their address space: through a generic pointer every access is a flat_load / flat_store, which
+// counts against vmcnt AND lgkmcnt -- the B-operand reads of the dense stream would then wait for every weight fragment
+// in flight (s_waitcnt vmcnt(0) per iteration: no prefetch at all).
+#define TR_LDS __attribute__((address_space(3)))
+typedef float TR_LDS* lfp;
+typedef const float TR_LDS* lcfp;
+typedef int TR_LDS* lip;
+typedef unsigned TR_LDS* lup;
+typedef unsigned char TR_LDS* lbp;
+
+// a split activation buffer in LDS: 16 NT rows (samples) of [hi: w halfs][mid: w halfs] + 16 B
 struct TrSplit {
-  unsigned char* base;
+  lbp base;
   int w;                                                  // channels (multiple of 32)
   __device__ __forceinline__ int rs() const { return 4 * w + 16; }
   __device__ __forceinline__ void put1(int i, int ch, float v) const {       // one element (element-wise stages)
     unsigned h, m;
     tr_split_pair(v, 0.0f, h, m);
-    unsigned char* q = base + (size_t)i * rs() + 2 * ch;
-    *reinterpret_cast<unsigned short*>(q) = (unsigned short)h;
-    *reinterpret_cast<unsigned short*>(q + 2 * w) = (unsigned short)m;
+    lbp q = base + i * rs() + 2 * ch;
+    *reinterpret_cast<unsigned short TR_LDS*>(q) = (unsigned short)h;
+    *reinterpret_cast<unsigned short TR_LDS*>(q + 2 * w) = (unsigned short)m;
   }
   __device__ __forceinline__ void put4(int i, int ch0, f32x4 v) const {       // 4 consecutive channels (dense epilogues)
     unsigned h01, m01, h23, m23;
     tr_split_pair(v[0], v[1], h01, m01);
     tr_split_pair(v[2], v[3], h23, m23);
-    unsigned char* q = base + (size_t)i * rs() + 2 * ch0;
-    *reinterpret_cast<u32x2*>(q) = u32x2{h01, h23};
-    *reinterpret_cast<u32x2*>(q + 2 * w) = u32x2{m01, m23};
+    lbp q = base + i * rs() + 2 * ch0;
+    *reinterpret_cast<u32x2 TR_LDS*>(q) = u32x2{h01, h23};
+    *reinterpret_cast<u32x2 TR_LDS*>(q + 2 * w) = u32x2{m01, m23};
   }
   __device__ __forceinline__ f32x4 get4(int i, int ch0) const {
     typedef _Float16 h2 __attribute__((ext_vector_type(2)));
-    const unsigned* qh = reinterpret_cast<const unsigned*>(base + (size_t)i * rs() + 2 * ch0);
-    const unsigned* qm = reinterpret_cast<const unsigned*>(base + (size_t)i * rs() + 2 * ch0 + 2 * w);
+    const unsigned TR_LDS* qh = reinterpret_cast<const unsigned TR_LDS*>(base + i * rs() + 2 * ch0);
+    const unsigned TR_LDS* qm = reinterpret_cast<const unsigned TR_LDS*>(base + i * rs() + 2 * ch0 + 2 * w);
     const unsigned h0 = qh[0], h1 = qh[1], m0 = qm[0], m1 = qm[1];
     const h2 h01 = __builtin_bit_cast(h2, h0), h23 = __builtin_bit_cast(h2, h1);
     const h2 m01 = __builtin_bit_cast(h2, m0), m23 = __builtin_bit_cast(h2, m1);
@@ -239,24 +279,19 @@ struct TrSplit {
 // output tile), `in` = split activation rows.  The waves of the workgroup split the output tiles in pairs (wave w owns
 // pairs w, w + TR_WAVES, ...); a wave's (pair, chunk) iterations form ONE software-pipelined stream with TR_PD
 // iterations of fragments in flight (unconditional loads, static ring indices); a pair's bias is requested up front and
-// added in its epilogue.  epi(u0, v): units u0..u0+3 of sample i; units >= urows arrive as exact zeros.
-template <class Epi>
-__device__ __forceinline__ void tr_dense(gfrag A, gptr bias, int urows, int kc32, int frag_tiles, const TrSplit in,
+// added in its epilogue (`bias`: the zero-padded copy in the fragment buffer, or null).  A fragment is used for all NT sample tiles of the workgroup (rows i + 16 nt of `in`).
+// epi(u0, nt, v): units u0..u0+3 of sample i of tile nt; units past the layer's width arrive as exact zeros.
+template <int NT, class Epi>
+__device__ __forceinline__ void tr_dense(gfrag A, gptr bias, int kc32, int frag_tiles, const TrSplit in,
                                          int out_tiles, int lane, int wave, TrStamps& stamps, Epi epi) {
   const int i = lane & 15, g = lane >> 4;
   const int n_pairs = (out_tiles + 1) >> 1;
   const int my_pairs = wave < n_pairs ? (n_pairs - wave + TR_WAVES - 1) / TR_WAVES : 0;
   const int T = my_pairs * kc32;
-  auto load_bias = [&](int o) -> f32x4 {
-    f32x4 b = {0.f, 0.f, 0.f, 0.f};
-    if (bias != nullptr) {
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int u = 16 * o + 4 * g + r;
-        b[r] = bias[u < urows ? u : urows - 1];       // raw; rows >= urows are zeroed in the epilogue
-      }
-    }
-    return b;
+  typedef const f32x4 __attribute__((address_space(1)))* gv4;
+  auto load_bias = [&](int o) -> f32x4 {          // the padded copy prep_kernel wrote: units past the layer are zeros
+    if (bias == nullptr) return f32x4{0.f, 0.f, 0.f, 0.f};
+    return *(gv4)(bias + 16 * (o < out_tiles ? o : 0) + 4 * g);
   };
   u32x4 r0h[TR_PD], r0m[TR_PD], r1h[TR_PD], r1m[TR_PD];
   int pl = wave, cl = 0;                       // load cursor (pair, chunk)
@@ -279,18 +314,33 @@ __device__ __forceinline__ void tr_dense(gfrag A, gptr bias, int urows, int kc32
   stamps.mark(5);
   int pair = wave, c = 0, q = 0;
   const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
-  f32x4 acc0 = zero, acc1 = zero;
-  const unsigned char* inl = in.base + (size_t)i * in.rs() + 16 * g;
-  const int mid_off = 2 * in.w;
+  f32x4 acc0[NT], acc1[NT];
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) { acc0[nt] = zero; acc1[nt] = zero; }
+  const lbp inl = in.base + i * in.rs() + 16 * g;
+  const int mid_off = 2 * in.w, tile_off = 16 * in.rs();
   auto body = [&](const u32x4& a0h, const u32x4& a0m, const u32x4& a1h, const u32x4& a1m) {
-    const u32x4 bh = *reinterpret_cast<const u32x4*>(inl + 64 * c);
-    const u32x4 bm = *reinterpret_cast<const u32x4*>(inl + 64 * c + mid_off);
-    acc0 = tr_mfma16(a0m, bh, acc0);
-    acc1 = tr_mfma16(a1m, bh, acc1);
-    acc0 = tr_mfma16(a0h, bm, acc0);
-    acc1 = tr_mfma16(a1h, bm, acc1);
-    acc0 = tr_mfma16(a0h, bh, acc0);
-    acc1 = tr_mfma16(a1h, bh, acc1);
+    u32x4 bh[NT], bm[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+      bh[nt] = *reinterpret_cast<const u32x4 TR_LDS*>(inl + nt * tile_off + 64 * c);
+      bm[nt] = *reinterpret_cast<const u32x4 TR_LDS*>(inl + nt * tile_off + 64 * c + mid_off);
+    }
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+      acc0[nt] = tr_mfma16(a0m, bh[nt], acc0[nt]);
+      acc1[nt] = tr_mfma16(a1m, bh[nt], acc1[nt]);
+    }
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+      acc0[nt] = tr_mfma16(a0h, bm[nt], acc0[nt]);
+      acc1[nt] = tr_mfma16(a1h, bm[nt], acc1[nt]);
+    }
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+      acc0[nt] = tr_mfma16(a0h, bh[nt], acc0[nt]);
+      acc1[nt] = tr_mfma16(a1h, bh[nt], acc1[nt]);
+    }
     if (++c == kc32) {
       tr_mfma_drain(acc0, acc1);
       f32x4 bias0 = bq0[0], bias1 = bq1[0];
@@ -300,16 +350,18 @@ __device__ __forceinline__ void tr_dense(gfrag A, gptr bias, int urows, int kc32
         bias1 = q == qq ? bq1[qq] : bias1;
       }
       const int o = 2 * pair;
-      f32x4 v0, v1;
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int u0 = 16 * o + 4 * g + r, u1 = u0 + 16;          // padded units (>= urows) stay exactly zero
-        v0[r] = u0 < urows ? acc0[r] + bias0[r] : 0.0f;
-        v1[r] = u1 < urows ? acc1[r] + bias1[r] : 0.0f;
+      for (int nt = 0; nt < NT; ++nt) {
+        f32x4 v0, v1;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          v0[r] = acc0[nt][r] + bias0[r];             // padded units: zero fragments + zero bias = exactly zero
+          v1[r] = acc1[nt][r] + bias1[r];
+        }
+        epi(16 * o + 4 * g, nt, v0);
+        if (o + 1 < out_tiles) epi(16 * o + 16 + 4 * g, nt, v1);
+        acc0[nt] = zero; acc1[nt] = zero;
       }
-      epi(16 * o + 4 * g, v0);
-      if (o + 1 < out_tiles) epi(16 * o + 16 + 4 * g, v1);
-      acc0 = zero; acc1 = zero;
       tr_acc_settle(acc0, acc1);
       c = 0; pair += TR_WAVES; ++q;
     }
@@ -338,24 +390,27 @@ __device__ __forceinline__ float tr_group_sum(float v) {   // sum over the 16 la
   return v;
 }
 
-template <int KIND, int MODE>
+template <int KIND, int MODE, int NT>
 __global__ void __launch_bounds__(64 * TR_WAVES) train_kernel(const TrainLaunch p) {
-  extern __shared__ __attribute__((aligned(16))) float lds[];
-  constexpr int S = TR_S;
+  extern __shared__ __attribute__((aligned(16))) float lds_raw[];
+  const lfp lds = (lfp)lds_raw;
+  constexpr int TS = 16 * NT;                            // samples per workgroup
+  constexpr int S = TS + 1;                              // LDS row stride (floats) of the f32 arrays: samples + 1 pad
   constexpr int GS = 4 * TR_WAVES;                       // lane groups of 16 in the workgroup: elementwise loop stride
   const int lane = threadIdx.x & 63, i = lane & 15;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);    // scalar: tile loops / branches on it are uniform
   const int g = 4 * wave + (lane >> 4);                  // lane-group index (elementwise work); MFMA code uses lane, wave
   const int d = p.d, K = p.K;
-  const int64_t row0 = (int64_t)blockIdx.x * 16;
-  const int64_t ni = row0 + i;
-  const bool valid = ni < p.n;
+  const int64_t row0 = (int64_t)blockIdx.x * TS;
+  const int64_t tile0 = (int64_t)blockIdx.x * NT;        // first 16-sample tile (the workspace is tiled by 16 samples)
+  // a lane works on sample i of each of the NT tiles: local row ii = i + 16 nt, global row row0 + ii
+#define TR_NT _Pragma("unroll") for (int nt = 0; nt < NT; ++nt)
 
   TrStamps stamps;
   stamps.mark(-1);
   // per-step tables, staged once: slot maps and the normalisation constants of every slot
-  int* TI = reinterpret_cast<int*>(lds);                   // [K][64]: in_slot[32], out_slot[32]
-  float* TP = lds + (size_t)K * 64;                        // [K][4][64]: p0..p3 per slot
+  const lip TI = reinterpret_cast<lip>(lds);               // [K][64]: in_slot[32], out_slot[32]
+  const lfp TP = lds + K * 64;                        // [K][4][64]: p0..p3 per slot
   for (int k = 0; k < K; ++k) {
     const TrStep& st = p.steps[k];
     for (int t = threadIdx.x; t < 128; t += 64 * TR_WAVES)
@@ -380,52 +435,50 @@ __global__ void __launch_bounds__(64 * TR_WAVES) train_kernel(const TrainLaunch 
           p3 = lg - 0.5f * __logf(ve);                     // models/layers.py:357-358
         }
       }
-      float* tp = TP + (size_t)k * 256 + sl;
+      const lfp tp = TP + k * 256 + sl;
       tp[0] = p0; tp[64] = p1; tp[128] = p2; tp[192] = p3;
     }
   }
-  // ... and the per-layer descriptors (bias address, fragment offsets, rows, cols): 8 words per (step, net, layer)
-  unsigned* TL = reinterpret_cast<unsigned*>(lds + (size_t)K * 320);
+  // ... and the per-layer descriptors (padded-bias offset, fragment offsets, rows, cols): 8 words per (step, net, layer)
+  const lup TL = reinterpret_cast<lup>(lds + K * 320);
   for (int e = threadIdx.x; e < K * 2 * TR_MAX_LAYERS; e += 64 * TR_WAVES) {
     const int k = e / (2 * TR_MAX_LAYERS), q = (e / TR_MAX_LAYERS) & 1, l = e % TR_MAX_LAYERS;
     const TrLayer& L = p.steps[k].net[q].layer[l];
-    unsigned* t = TL + (size_t)e * 8;
-    const unsigned long long b = (unsigned long long)L.b;
-    t[0] = (unsigned)b; t[1] = (unsigned)(b >> 32);
+    const lup t = TL + e * 8;
+    t[0] = (unsigned)L.fb; t[1] = (unsigned)(L.fb >> 32);
     t[2] = (unsigned)L.fw; t[3] = (unsigned)(L.fw >> 32);
     t[4] = (unsigned)L.bw; t[5] = (unsigned)(L.bw >> 32);
     t[6] = (unsigned)L.rows; t[7] = (unsigned)L.cols;
   }
-  float* Y = lds + (size_t)K * 320 + (size_t)K * 2 * TR_MAX_LAYERS * 8;   // [K*d] normalised state of every step (MODE 1)
-  float* Zc = Y + (MODE == 1 ? (size_t)K * d * S : 0);    // [d]   running state (forward) / gradient state (backward)
-  float* GX = Zc + (size_t)d * S;                         // [ip]  gradient w.r.t. the coupling-net input
-  float* O = GX + (size_t)p.ip * S;                       // [op]  net output, then its gradient
-  float* O2 = O + (size_t)p.op * S;                       // [op]  realnvp: shift output / shift gradient
-  float* RED = O2 + (size_t)p.op * S;                     // [64]  cross-wave scratch
+  const lfp Y = lds + K * 320 + K * 2 * TR_MAX_LAYERS * 8;   // [K*d] normalised state of every step (MODE 1)
+  const lfp Zc = Y + (MODE == 1 ? K * d * S : 0);         // [d]   running state (forward) / gradient state (backward)
+  const lfp GX = Zc + d * S;                              // [ip]  gradient w.r.t. the coupling-net input
+  const lfp O = GX + p.ip * S;                            // [op]  net output, then its gradient
+  const lfp O2 = O + p.op * S;                            // [op]  realnvp: shift output / shift gradient
+  const lfp RED = O2 + p.op * S;                          // [waves][NT][16]  cross-wave scratch
   // split-f16 rows (B operands of the dense layers): net input, hidden activations (then their gradients), output gradient
-  unsigned char* sp = reinterpret_cast<unsigned char*>(lds) +
-                      (((reinterpret_cast<unsigned char*>(RED + 64) - reinterpret_cast<unsigned char*>(lds)) + 15) & ~15);   // 16-byte aligned
+  lbp sp = reinterpret_cast<lbp>(lds) + ((((RED + 16 * TR_WAVES * NT) - lds) * 4 + 15) & ~15);   // 16-byte aligned
   const TrSplit XS{sp, p.xw};
-  sp += 16 * XS.rs();
+  sp += TS * XS.rs();
   TrSplit HS[TR_MAX_LAYERS - 1];
 #pragma unroll
   for (int l = 0; l < TR_MAX_LAYERS - 1; ++l) {
     HS[l] = TrSplit{sp, p.hw};
-    if (l < p.n_hidden) sp += 16 * HS[l].rs();
+    if (l < p.n_hidden) sp += TS * HS[l].rs();
   }
   const TrSplit GOS{sp, p.ow};
   // channels between the 16-padded and the 32-padded widths are never written by an epilogue: zero the split rows once
   {
-    unsigned char* s0 = const_cast<unsigned char*>(XS.base);
-    const int bytes = (int)((sp + 16 * GOS.rs()) - s0);
-    for (int e = 16 * threadIdx.x; e < bytes; e += 16 * 64 * TR_WAVES) *reinterpret_cast<u32x4*>(s0 + e) = u32x4{0u, 0u, 0u, 0u};
+    const lbp s0 = XS.base;
+    const int bytes = (int)((sp + TS * GOS.rs()) - s0);
+    for (int e = 16 * threadIdx.x; e < bytes; e += 16 * 64 * TR_WAVES) *reinterpret_cast<u32x4 TR_LDS*>(s0 + e) = u32x4{0u, 0u, 0u, 0u};
   }
 
   const int hid_tiles = p.hp >> 4, out_tiles = p.op >> 4, in_tiles = p.ip >> 4;
 
   // ---- normalisation of slot s at a step (ActNorm / eval-mode BatchNorm)
   auto norm_fwd = [&](int k, int s, float v, float& logdet) -> float {
-    const float* tp = TP + (size_t)k * 256 + s;
+    const lcfp tp = TP + k * 256 + s;
     logdet += tp[192];
     if constexpr (KIND == GBNF_KIND_GLOW) return (v + tp[0]) * tp[64];
     else return (v - tp[0]) * tp[64] + tp[128];
@@ -433,12 +486,12 @@ __global__ void __launch_bounds__(64 * TR_WAVES) train_kernel(const TrainLaunch 
 
   struct LayerD { gptr b; long long fw, bw; int rows, cols; };
   auto layer_desc = [&](int k, int q, int l) -> LayerD {     // from the LDS table, moved to scalar registers
-    const unsigned* t = TL + ((size_t)(k * 2 + q) * TR_MAX_LAYERS + l) * 8;
+    const lup t = TL + ((k * 2 + q) * TR_MAX_LAYERS + l) * 8;
     unsigned w[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) w[e] = __builtin_amdgcn_readfirstlane(t[e]);
     LayerD D;
-    D.b = (gptr)(((unsigned long long)w[1] << 32) | w[0]);
+    D.b = (gptr)(reinterpret_cast<const float*>(p.frag) + (long long)(((unsigned long long)w[1] << 32) | w[0]));
     D.fw = (long long)(((unsigned long long)w[3] << 32) | w[2]);
     D.bw = (long long)(((unsigned long long)w[5] << 32) | w[4]);
     D.rows = (int)w[6]; D.cols = (int)w[7];
@@ -448,7 +501,7 @@ __global__ void __launch_bounds__(64 * TR_WAVES) train_kernel(const TrainLaunch 
   const int act_a = tr_uniform(p.steps[0].net[0].act), act_b = tr_uniform(p.steps[0].net[KIND == GBNF_KIND_GLOW ? 0 : 1].act);
 
   // ---- coupling net forward from XS: hidden layers into HS (+ emit f32), last layer into `out` (f32; or skipped)
-  auto net_forward = [&](int k, int q, float* out, float* ws_net) {
+  auto net_forward = [&](int k, int q, lfp out, float* ws_net) {
     TrSplit in = XS;
     const int act = q == 0 ? act_a : act_b;
     for (int l = 0; l + 1 < nl; ++l) {
@@ -456,98 +509,104 @@ __global__ void __launch_bounds__(64 * TR_WAVES) train_kernel(const TrainLaunch 
       const bool emit = (MODE == 1) && ws_net != nullptr;    // backward sweep only: activation-side operand of dW
       // operand sub-regions are tiled: [tile of 16 samples][unit][16] -- a workgroup's rows of one operand are one
       // contiguous block, and a unit's 16 samples one 64-byte run (wgrad_kernel reads 16 units x 64 B per wave load)
-      float* ws_h = emit ? ws_net + ((size_t)p.ip + (size_t)l * p.hp) * p.np + (size_t)blockIdx.x * p.hp * 16 + i : nullptr;
+      float* ws_h = emit ? ws_net + ((size_t)p.ip + (size_t)l * p.hp) * p.np + (size_t)tile0 * p.hp * 16 + i : nullptr;
       const LayerD L = layer_desc(k, q, l);
-      tr_dense((gfrag)(p.frag + L.fw), L.b, L.rows, in.w >> 5, hid_tiles, in, hid_tiles, lane, wave,
-               stamps, [&](int u0, f32x4 v) {
-        f32x4 h;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) h[r] = tr_act(act, v[r]);
-        Hl.put4(i, u0, h);
+      tr_dense<NT>((gfrag)(p.frag + L.fw), L.b, in.w >> 5, hid_tiles, in, hid_tiles, lane, wave,
+                   stamps, [&](int u0, int nt, f32x4 v) {
+        const f32x4 h = tr_act4(act, v);
+        Hl.put4(i + 16 * nt, u0, h);
         if (emit) {
 #pragma unroll
-          for (int r = 0; r < 4; ++r) ws_h[(size_t)(u0 + r) * 16] = h[r];
+          for (int r = 0; r < 4; ++r) ws_h[((size_t)nt * p.hp + u0 + r) * 16] = h[r];
         }
       });
       in = Hl;
     }
     if (out != nullptr) {
       const LayerD L = layer_desc(k, q, nl - 1);
-      tr_dense((gfrag)(p.frag + L.fw), L.b, L.rows, in.w >> 5, out_tiles, in, out_tiles, lane, wave,
-               stamps, [&](int u0, f32x4 v) {
+      tr_dense<NT>((gfrag)(p.frag + L.fw), L.b, in.w >> 5, out_tiles, in, out_tiles, lane, wave,
+                   stamps, [&](int u0, int nt, f32x4 v) {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) out[(u0 + r) * S + i] = v[r];
+        for (int r = 0; r < 4; ++r) out[(u0 + r) * S + i + 16 * nt] = v[r];
       });
     }
   };
 
   // ---- coupling net backward: cur = gradient w.r.t. the net output (LDS f32, [op]); leaves d(loss)/d(net input) in GX
-  auto net_backward = [&](int k, int q, const float* cur, float* ws_net, bool accumulate) {
+  auto net_backward = [&](int k, int q, lcfp cur, float* ws_net, bool accumulate) {
     const int nh = p.n_hidden;
     const int act = q == 0 ? act_a : act_b;
     // gradient-side operand of the last layer's weight gradient (f32 to the workspace) + its split copy for the dense chain
     {
-      float* ws_d = ws_net + ((size_t)p.ip + 2 * (size_t)nh * p.hp) * p.np + (size_t)blockIdx.x * p.op * 16 + i;
+      float* ws_d = ws_net + ((size_t)p.ip + 2 * (size_t)nh * p.hp) * p.np + (size_t)tile0 * p.op * 16 + i;
       for (int u = g; u < p.ow; u += GS) {
-        const float v = u < p.op ? cur[u * S + i] : 0.0f;
-        if (u < p.op) ws_d[(size_t)u * 16] = v;
-        GOS.put1(i, u, v);
+        TR_NT {
+          const float v = u < p.op ? cur[u * S + i + 16 * nt] : 0.0f;
+          if (u < p.op) ws_d[((size_t)nt * p.op + u) * 16] = v;
+          GOS.put1(i + 16 * nt, u, v);
+        }
       }
     }
     tr_lds_barrier();
     TrSplit in = GOS;
     for (int l = nl - 1; l >= 1; --l) {
       const TrSplit Hl = HS[l - 1];                          // activations of hidden layer l-1 -> overwritten by its gradient
-      float* ws_d = ws_net + ((size_t)p.ip + (size_t)nh * p.hp + (size_t)(l - 1) * p.hp) * p.np + (size_t)blockIdx.x * p.hp * 16 + i;
+      float* ws_d = ws_net + ((size_t)p.ip + (size_t)nh * p.hp + (size_t)(l - 1) * p.hp) * p.np + (size_t)tile0 * p.hp * 16 + i;
       const LayerD L = layer_desc(k, q, l);                  // A = W^T: output units = cols, k = rows
-      tr_dense((gfrag)(p.frag + L.bw), gptr(nullptr), L.cols, in.w >> 5, hid_tiles, in, hid_tiles, lane, wave, stamps,
-               [&](int u0, f32x4 v) {
-        const f32x4 h = Hl.get4(i, u0);
-        f32x4 gpre;
+      tr_dense<NT>((gfrag)(p.frag + L.bw), gptr(nullptr), in.w >> 5, hid_tiles, in, hid_tiles, lane, wave, stamps,
+                   [&](int u0, int nt, f32x4 v) {
+        const f32x4 h = Hl.get4(i + 16 * nt, u0);
+        const f32x4 gpre = tr_dact4_mul(act, h, v);
+        Hl.put4(i + 16 * nt, u0, gpre);
 #pragma unroll
-        for (int r = 0; r < 4; ++r) gpre[r] = v[r] * tr_dact(act, h[r]);
-        Hl.put4(i, u0, gpre);
-#pragma unroll
-        for (int r = 0; r < 4; ++r) ws_d[(size_t)(u0 + r) * 16] = gpre[r];
+        for (int r = 0; r < 4; ++r) ws_d[((size_t)nt * p.hp + u0 + r) * 16] = gpre[r];
       });
       in = Hl;
     }
     const LayerD L0 = layer_desc(k, q, 0);
-    tr_dense((gfrag)(p.frag + L0.bw), gptr(nullptr), L0.cols, in.w >> 5, in_tiles, in, in_tiles, lane, wave, stamps,
-             [&](int u0, f32x4 v) {
+    tr_dense<NT>((gfrag)(p.frag + L0.bw), gptr(nullptr), in.w >> 5, in_tiles, in, in_tiles, lane, wave, stamps,
+                 [&](int u0, int nt, f32x4 v) {
 #pragma unroll
-      for (int r = 0; r < 4; ++r) GX[(u0 + r) * S + i] = accumulate ? GX[(u0 + r) * S + i] + v[r] : v[r];
+      for (int r = 0; r < 4; ++r) {
+        const lfp gx = GX + (u0 + r) * S + i + 16 * nt;
+        *gx = accumulate ? *gx + v[r] : v[r];
+      }
     });
   };
 
   // ---- x tile -> Zc (slot j = feature j), or the state a previous step-range launch left in slot layout
   if (MODE == 0 && p.state_in != nullptr) {
-    for (int s = g; s < d; s += GS) Zc[s * S + i] = p.state_in[(size_t)s * p.np + row0 + i];
+    for (int s = g; s < d; s += GS) TR_NT Zc[s * S + i + 16 * nt] = p.state_in[(size_t)s * p.np + row0 + i + 16 * nt];
   } else {
-    for (int j = g; j < d; j += GS) Zc[j * S + i] = valid ? p.x[ni * d + j] : 0.0f;
+    for (int j = g; j < d; j += GS) TR_NT {
+      const int64_t r = row0 + i + 16 * nt;
+      Zc[j * S + i + 16 * nt] = r < p.n ? p.x[r * d + j] : 0.0f;
+    }
   }
   tr_lds_barrier();    // (also: the tables are complete)
   stamps.mark(0);
 
   // =============================== forward through all steps
-  float ld = 0.0f;   // per-lane partial of log|det J| (every lane group adds its own slots / features)
+  float ld[NT];      // per-lane partials of log|det J| (every lane group adds its own slots / features)
+  TR_NT ld[nt] = 0.0f;
   const bool have_trace = (MODE == 1) && p.trace != nullptr;
   const int kb = p.k_begin, ke = p.k_end;
   if (have_trace) {  // the forward call saved every step's normalised state: just bring this tile's columns in
-    for (int e = g + kb * d; e < ke * d; e += GS) Y[(size_t)e * S + i] = p.trace[(size_t)e * p.np + row0 + i];
+    for (int e = g + kb * d; e < ke * d; e += GS) TR_NT Y[e * S + i + 16 * nt] = p.trace[(size_t)e * p.np + row0 + i + 16 * nt];
   }
   for (int k = kb; k < (have_trace ? kb : ke); ++k) {
     const TrStep& st = p.steps[k];
-    for (int s = g; s < d; s += GS) {
-      const float y = norm_fwd(k, s, Zc[s * S + i], ld);
-      Zc[s * S + i] = y;
-      if (MODE == 1) Y[((size_t)k * d + s) * S + i] = y;
-      if (MODE == 0 && p.trace_out != nullptr) p.trace_out[((size_t)k * d + s) * p.np + row0 + i] = y;
+    for (int s = g; s < d; s += GS) TR_NT {
+      const int ii = i + 16 * nt;
+      const float y = norm_fwd(k, s, Zc[s * S + ii], ld[nt]);
+      Zc[s * S + ii] = y;
+      if (MODE == 1) Y[(k * d + s) * S + ii] = y;
+      if (MODE == 0 && p.trace_out != nullptr) p.trace_out[((size_t)k * d + s) * p.np + row0 + ii] = y;
     }
     if (MODE == 1 && k == ke - 1) break;                   // the last step's outputs are not needed for the backward
     tr_lds_barrier();
-    const int* ti = TI + k * 64;
-    for (int kk = g; kk < p.xw; kk += GS) XS.put1(i, kk, kk < st.in_f ? Zc[ti[kk] * S + i] : 0.0f);
+    const lip ti = TI + k * 64;
+    for (int kk = g; kk < p.xw; kk += GS) TR_NT XS.put1(i + 16 * nt, kk, kk < st.in_f ? Zc[ti[kk] * S + i + 16 * nt] : 0.0f);
     tr_lds_barrier();
     stamps.mark(1);
     if constexpr (KIND == GBNF_KIND_GLOW) {
@@ -555,14 +614,17 @@ __global__ void __launch_bounds__(64 * TR_WAVES) train_kernel(const TrainLaunch 
       stamps.mark(-1);
       for (int j = g; j < st.out_f; j += GS) {
         const int slot = ti[32 + j];
-        const float y2 = Zc[slot * S + i];
-        if (p.additive) {
-          Zc[slot * S + i] = y2 + O[j * S + i];                                  // models/glow.py:328-329
-        } else {
-          const float e = __expf(-(O[(2 * j + 1) * S + i] + 2.0f));              // scale = sigmoid(raw + 2)
-          const float sc = 1.0f / (1.0f + e);
-          Zc[slot * S + i] = (y2 + O[(2 * j) * S + i]) * sc;                     // models/glow.py:333-336
-          ld += -log1pf(e);                                                      // log(scale), models/glow.py:338
+        TR_NT {
+          const int ii = i + 16 * nt;
+          const float y2 = Zc[slot * S + ii];
+          if (p.additive) {
+            Zc[slot * S + ii] = y2 + O[j * S + ii];                                  // models/glow.py:328-329
+          } else {
+            const float e = __expf(-(O[(2 * j + 1) * S + ii] + 2.0f));              // scale = sigmoid(raw + 2)
+            const float sc = 1.0f / (1.0f + e);
+            Zc[slot * S + ii] = (y2 + O[(2 * j) * S + ii]) * sc;                     // models/glow.py:333-336
+            ld[nt] += -log1pf(e);                                                    // log(scale), models/glow.py:338
+          }
         }
       }
     } else {
@@ -570,9 +632,12 @@ __global__ void __launch_bounds__(64 * TR_WAVES) train_kernel(const TrainLaunch 
       net_forward(k, 1, O, nullptr);
       for (int j = g; j < st.out_f; j += GS) {
         const int slot = ti[32 + j];
-        const float scale = O[j * S + i];
-        Zc[slot * S + i] = O2[j * S + i] + Zc[slot * S + i] * __expf(scale);      // models/transformations.py:575
-        ld += scale;                                                             // models/transformations.py:577
+        TR_NT {
+          const int ii = i + 16 * nt;
+          const float scale = O[j * S + ii];
+          Zc[slot * S + ii] = O2[j * S + ii] + Zc[slot * S + ii] * __expf(scale);     // models/transformations.py:575
+          ld[nt] += scale;                                                           // models/transformations.py:577
+        }
       }
     }
     tr_lds_barrier();
@@ -580,21 +645,27 @@ __global__ void __launch_bounds__(64 * TR_WAVES) train_kernel(const TrainLaunch 
   }
 
   if constexpr (MODE == 0) {
-    ld += __shfl_xor(ld, 16);
-    ld += __shfl_xor(ld, 32);
-    if ((lane >> 4) == 0) RED[wave * 16 + i] = ld;        // fold the waves' partial sums
-    tr_lds_barrier();
-    if (valid) {
-      if (p.ldj_out != nullptr && g == 0) {
-        float t = p.ldj_accumulate ? p.ldj_out[ni] : 0.0f;
-        for (int w = 0; w < TR_WAVES; ++w) t += RED[w * 16 + i];
-        p.ldj_out[ni] = t;
-      }
-      if (p.z_out != nullptr && ke == K)
-        for (int j = g; j < d; j += GS) p.z_out[ni * d + j] = Zc[p.tail[j] * S + i];
+    TR_NT {
+      ld[nt] += __shfl_xor(ld[nt], 16);
+      ld[nt] += __shfl_xor(ld[nt], 32);
+      if ((lane >> 4) == 0) RED[(wave * NT + nt) * 16 + i] = ld[nt];        // fold the waves' partial sums
     }
-    if (p.state_out != nullptr)
-      for (int s = g; s < d; s += GS) p.state_out[(size_t)s * p.np + row0 + i] = Zc[s * S + i];
+    tr_lds_barrier();
+    TR_NT {
+      const int ii = i + 16 * nt;
+      const int64_t r = row0 + ii;
+      if (r < p.n) {
+        if (p.ldj_out != nullptr && g == 0) {
+          float t = p.ldj_accumulate ? p.ldj_out[r] : 0.0f;
+          for (int w = 0; w < TR_WAVES; ++w) t += RED[(w * NT + nt) * 16 + i];
+          p.ldj_out[r] = t;
+        }
+        if (p.z_out != nullptr && ke == K)
+          for (int j = g; j < d; j += GS) p.z_out[r * d + j] = Zc[p.tail[j] * S + ii];
+      }
+      if (p.state_out != nullptr)
+        for (int s = g; s < d; s += GS) p.state_out[(size_t)s * p.np + r] = Zc[s * S + ii];
+    }
     stamps.mark(4);
 #ifdef GBNF_TRAIN_STAMPS
     if (p.dbg != nullptr && threadIdx.x == 0)
@@ -604,72 +675,88 @@ __global__ void __launch_bounds__(64 * TR_WAVES) train_kernel(const TrainLaunch 
   } else {
     // =============================== backward
     tr_lds_barrier();
-    const float gl = (valid && p.g_ldj != nullptr) ? p.g_ldj[ni] : 0.0f;
+    float gl[NT];
+    TR_NT {
+      const int64_t r = row0 + i + 16 * nt;
+      gl[nt] = (r < p.n && p.g_ldj != nullptr) ? p.g_ldj[r] : 0.0f;
+    }
     if (p.gstate_in != nullptr) {
-      for (int s = g; s < d; s += GS) Zc[s * S + i] = p.gstate_in[(size_t)s * p.np + row0 + i];
+      for (int s = g; s < d; s += GS) TR_NT Zc[s * S + i + 16 * nt] = p.gstate_in[(size_t)s * p.np + row0 + i + 16 * nt];
     } else {
-      for (int j = g; j < d; j += GS) Zc[p.tail[j] * S + i] = (valid && p.g_z != nullptr) ? p.g_z[ni * d + j] : 0.0f;
+      for (int j = g; j < d; j += GS) TR_NT {
+        const int64_t r = row0 + i + 16 * nt;
+        Zc[p.tail[j] * S + i + 16 * nt] = (r < p.n && p.g_z != nullptr) ? p.g_z[r * d + j] : 0.0f;
+      }
     }
     tr_lds_barrier();
-    float* G = Zc;
+    const lfp G = Zc;
     const int nnets = (KIND == GBNF_KIND_GLOW) ? 1 : 2;
 
-    // normalisation backward for one slot: returns d(loss)/d(pre-norm value); accumulates the parameter gradients
-    auto norm_bwd = [&](const TrStep& st, int k, int s, float gy, float y) -> float {
-      const int f = st.feat[s];
-      const float* tp = TP + (size_t)k * 256 + s;
-      float ga, gb;
+    // normalisation backward for one slot and one sample: returns d(loss)/d(pre-norm value) and adds the sample's terms
+    // of the two parameter gradients to ga / gb; norm_commit folds them over the workgroup's samples of that slot
+    auto norm_bwd = [&](const TrStep& st, int k, int s, float gy, float y, float gldj, float& ga, float& gb) -> float {
+      const lcfp tp = TP + k * 256 + s;
       const float gx = gy * tp[64];
       if constexpr (KIND == GBNF_KIND_GLOW) {
-        ga = gx;                  // d/d bias
-        gb = gy * y + gl;         // d/d logs: y = (x + bias) e^logs, and logdet += logs for every sample
+        ga += gx;                   // d/d bias
+        gb += gy * y + gldj;        // d/d logs: y = (x + bias) e^logs, and logdet += logs for every sample
       } else {
         if (!st.has_norm) return gy;
-        ga = gy * (y - tp[128]) + gl;    // d/d log_gamma
-        gb = gy;                         // d/d beta
+        ga += gy * (y - tp[128]) + gldj;   // d/d log_gamma
+        gb += gy;                          // d/d beta
       }
+      return gx;
+    };
+    auto norm_commit = [&](const TrStep& st, int s, float ga, float gb) {
+      if (KIND != GBNF_KIND_GLOW && !st.has_norm) return;
+      const int f = st.feat[s];
       ga = tr_group_sum(ga);
       gb = tr_group_sum(gb);
       if (i == 0) {
         atomicAdd(p.grads + st.g_na + f, ga);
         atomicAdd(p.grads + st.g_nb + f, gb);
       }
-      return gx;
     };
 
     for (int k = ke - 1; k >= kb; --k) {
       const TrStep& st = p.steps[k];
-      const float* Yk = Y + (size_t)k * d * S;
+      const lcfp Yk = Y + k * d * S;
       float* ws_step = p.ws + (size_t)k * nnets * p.net_rows * p.np;
-      const int* ti = TI + k * 64;
+      const lip ti = TI + k * 64;
       // net input (also the activation-side operand of the first layer's weight gradient)
-      for (int kk = g; kk < p.xw; kk += GS) {
-        const float v = kk < st.in_f ? Yk[ti[kk] * S + i] : 0.0f;
-        XS.put1(i, kk, v);
+      for (int kk = g; kk < p.xw; kk += GS) TR_NT {
+        const int ii = i + 16 * nt;
+        const float v = kk < st.in_f ? Yk[ti[kk] * S + ii] : 0.0f;
+        XS.put1(ii, kk, v);
         if (kk < p.ip)
           for (int q = 0; q < nnets; ++q)
-            (ws_step + (size_t)q * p.net_rows * p.np)[((size_t)blockIdx.x * p.ip + kk) * 16 + i] = v;
+            (ws_step + (size_t)q * p.net_rows * p.np)[((size_t)(tile0 + nt) * p.ip + kk) * 16 + i] = v;
       }
       tr_lds_barrier();
       if constexpr (KIND == GBNF_KIND_GLOW) {
         net_forward(k, 0, O, ws_step);
         for (int j = g; j < st.out_f; j += GS) {
           const int slot = ti[32 + j];
-          const float y2 = Yk[slot * S + i], g2 = G[slot * S + i];
-          float gy;
-          if (p.additive) {
-            gy = g2;
-            O[j * S + i] = g2;
-          } else {
-            const float shift = O[(2 * j) * S + i];
-            const float e = __expf(-(O[(2 * j + 1) * S + i] + 2.0f));
-            const float sc = 1.0f / (1.0f + e);
-            const float omsc = e < 1e30f ? e * sc : 1.0f;               // 1 - scale
-            gy = g2 * sc;
-            O[(2 * j) * S + i] = gy;                                     // d/d shift
-            O[(2 * j + 1) * S + i] = (g2 * (y2 + shift) * sc + gl) * omsc;   // d/d raw: z2' = (y2+shift) s, ld += log s
+          float ga = 0.0f, gb = 0.0f;
+          TR_NT {
+            const int ii = i + 16 * nt;
+            const float y2 = Yk[slot * S + ii], g2 = G[slot * S + ii];
+            float gy;
+            if (p.additive) {
+              gy = g2;
+              O[j * S + ii] = g2;
+            } else {
+              const float shift = O[(2 * j) * S + ii];
+              const float e = __expf(-(O[(2 * j + 1) * S + ii] + 2.0f));
+              const float sc = 1.0f / (1.0f + e);
+              const float omsc = e < 1e30f ? e * sc : 1.0f;               // 1 - scale
+              gy = g2 * sc;
+              O[(2 * j) * S + ii] = gy;                                     // d/d shift
+              O[(2 * j + 1) * S + ii] = (g2 * (y2 + shift) * sc + gl[nt]) * omsc;   // d/d raw: z2' = (y2+shift) s, ld += log s
+            }
+            G[slot * S + ii] = norm_bwd(st, k, slot, gy, y2, gl[nt], ga, gb);
           }
-          G[slot * S + i] = norm_bwd(st, k, slot, gy, y2);
+          norm_commit(st, slot, ga, gb);
         }
         tr_lds_barrier();
         net_backward(k, 0, O, ws_step, false);
@@ -677,15 +764,20 @@ __global__ void __launch_bounds__(64 * TR_WAVES) train_kernel(const TrainLaunch 
         float* ws_t = ws_step;
         float* ws_s = ws_step + (size_t)p.net_rows * p.np;
         net_forward(k, 1, O, ws_s);                                 // log-scale net
-        for (int u = g; u < p.op; u += GS) O2[u * S + i] = 0.0f;
+        for (int u = g; u < p.op; u += GS) TR_NT O2[u * S + i + 16 * nt] = 0.0f;
         tr_lds_barrier();
         for (int j = g; j < st.out_f; j += GS) {
           const int slot = ti[32 + j];
-          const float y2 = Yk[slot * S + i], g2 = G[slot * S + i];
-          const float es = __expf(O[j * S + i]);
-          O2[j * S + i] = g2;                                            // d/d shift
-          O[j * S + i] = g2 * y2 * es + gl;                              // d/d scale: z2' = shift + y2 e^scale, ld += scale
-          G[slot * S + i] = norm_bwd(st, k, slot, g2 * es, y2);
+          float ga = 0.0f, gb = 0.0f;
+          TR_NT {
+            const int ii = i + 16 * nt;
+            const float y2 = Yk[slot * S + ii], g2 = G[slot * S + ii];
+            const float es = __expf(O[j * S + ii]);
+            O2[j * S + ii] = g2;                                            // d/d shift
+            O[j * S + ii] = g2 * y2 * es + gl[nt];                          // d/d scale: z2' = shift + y2 e^scale, ld += scale
+            G[slot * S + ii] = norm_bwd(st, k, slot, g2 * es, y2, gl[nt], ga, gb);
+          }
+          norm_commit(st, slot, ga, gb);
         }
         tr_lds_barrier();
         net_backward(k, 1, O, ws_s, false);
@@ -694,16 +786,26 @@ __global__ void __launch_bounds__(64 * TR_WAVES) train_kernel(const TrainLaunch 
       }
       for (int kk = g; kk < st.in_f; kk += GS) {
         const int slot = ti[kk];
-        G[slot * S + i] = norm_bwd(st, k, slot, G[slot * S + i] + GX[kk * S + i], Yk[slot * S + i]);
+        float ga = 0.0f, gb = 0.0f;
+        TR_NT {
+          const int ii = i + 16 * nt;
+          G[slot * S + ii] = norm_bwd(st, k, slot, G[slot * S + ii] + GX[kk * S + ii], Yk[slot * S + ii], gl[nt], ga, gb);
+        }
+        norm_commit(st, slot, ga, gb);
       }
       tr_lds_barrier();
     }
-    if (p.gstate_out != nullptr) {
-      for (int s = g; s < d; s += GS) p.gstate_out[(size_t)s * p.np + row0 + i] = G[s * S + i];
-    } else if (valid && p.g_x != nullptr) {
-      for (int j = g; j < d; j += GS) p.g_x[ni * d + j] = G[j * S + i];
+    TR_NT {
+      const int ii = i + 16 * nt;
+      const int64_t r = row0 + ii;
+      if (p.gstate_out != nullptr) {
+        for (int s = g; s < d; s += GS) p.gstate_out[(size_t)s * p.np + r] = G[s * S + ii];
+      } else if (r < p.n && p.g_x != nullptr) {
+        for (int j = g; j < d; j += GS) p.g_x[r * d + j] = G[j * S + ii];
+      }
     }
   }
+#undef TR_NT
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -875,6 +977,8 @@ struct PrepProblem {
   int trans;           // 0: M = W (out units = rows, k = cols); 1: M = W^T
   int tiles, kc;       // fragment grid: output tiles x 32-wide k chunks
   int blk_begin;
+  const float* bias;   // forward orientation only: (rows,) -> zero-padded copy at float offset boff of the fragment buffer
+  int64_t boff;
 };
 
 __global__ void __launch_bounds__(64) prep_kernel(const PrepProblem* __restrict__ probs, int n_probs, u32x4* __restrict__ frag) {
@@ -909,6 +1013,8 @@ __global__ void __launch_bounds__(64) prep_kernel(const PrepProblem* __restrict_
   u32x4* dst = frag + P.off + ((size_t)o * P.kc + c) * 128 + lane;
   dst[0] = u32x4{h[0], h[1], h[2], h[3]};
   dst[64] = u32x4{md[0], md[1], md[2], md[3]};
+  if (P.bias != nullptr && c == 0 && lane < 16)
+    reinterpret_cast<float*>(frag)[P.boff + m] = m < P.rows ? P.bias[m] : 0.0f;
 }
 
 }  // namespace gbnf
@@ -918,7 +1024,7 @@ using namespace gbnf;
 struct gbnf_trainer {
   int kind = 0, d = 0, K = 0, additive = 0, n_hidden = 0, hp = 0, ip = 0, op = 0, nnets = 1;
   int64_t net_rows = 0, grad_floats = 0;
-  size_t lds_fwd = 0, lds_bwd = 0;
+  size_t lds_fwd[TR_MAX_NT + 1] = {0, 0, 0}, lds_bwd[TR_MAX_NT + 1] = {0, 0, 0};   // dynamic LDS bytes by tiles per workgroup
   TrStep* steps_dev = nullptr;
   int* tail_dev = nullptr;
   WgProblem* probs_dev = nullptr;
@@ -932,13 +1038,33 @@ struct gbnf_trainer {
 };
 
 static int ceil16(int v) { return (v + 15) / 16 * 16; }
+static int64_t tr_padded(int64_t n) { return (n + 16 * TR_MAX_NT - 1) / (16 * TR_MAX_NT) * (16 * TR_MAX_NT); }   // np: whole workgroups for every NT
+
+// 16-sample tiles per workgroup.  Two tiles halve the weight-fragment traffic per sample (the bound of these kernels,
+// DESIGN.md section 4.7) at twice the LDS per workgroup: worth it once there are enough workgroups to cover the chip.
+static int pick_nt(const gbnf_trainer* t, int64_t np, int mode) {
+  static const int forced = [] { const char* e = getenv("GBNF_TRAIN_NT"); return e ? atoi(e) : 0; }();
+  const size_t* lds = mode == 0 ? t->lds_fwd : t->lds_bwd;
+  int nt = TR_MAX_NT;      // measured: two tiles win at every batch size, even when they leave CUs without a workgroup
+  (void)np;
+  if (forced >= 1 && forced <= TR_MAX_NT) nt = forced;
+  while (nt > 1 && lds[nt] > (size_t)TR_LDS_BYTES) --nt;
+  return nt;
+}
 
 template <int MODE>
 static void launch_train(const gbnf_trainer* t, const TrainLaunch& p, hipStream_t s) {
-  const dim3 grid((unsigned)(p.np / 16)), blk(64 * TR_WAVES);
-  const size_t lds = MODE == 0 ? t->lds_fwd : t->lds_bwd;
-  if (t->kind == GBNF_KIND_GLOW) hipLaunchKernelGGL((train_kernel<GBNF_KIND_GLOW, MODE>), grid, blk, lds, s, p);
-  else hipLaunchKernelGGL((train_kernel<GBNF_KIND_REALNVP, MODE>), grid, blk, lds, s, p);
+  const int nt = pick_nt(t, p.np, MODE);
+  const dim3 grid((unsigned)(p.np / (16 * nt))), blk(64 * TR_WAVES);
+  const size_t lds = MODE == 0 ? t->lds_fwd[nt] : t->lds_bwd[nt];
+  const bool glow = t->kind == GBNF_KIND_GLOW;
+  if (nt == 2) {
+    if (glow) hipLaunchKernelGGL((train_kernel<GBNF_KIND_GLOW, MODE, 2>), grid, blk, lds, s, p);
+    else hipLaunchKernelGGL((train_kernel<GBNF_KIND_REALNVP, MODE, 2>), grid, blk, lds, s, p);
+  } else {
+    if (glow) hipLaunchKernelGGL((train_kernel<GBNF_KIND_GLOW, MODE, 1>), grid, blk, lds, s, p);
+    else hipLaunchKernelGGL((train_kernel<GBNF_KIND_REALNVP, MODE, 1>), grid, blk, lds, s, p);
+  }
 }
 
 
@@ -969,15 +1095,22 @@ int gbnf_trainer_create(const gbnf_flow_desc* desc, gbnf_trainer** out) {
   t->op = ceil16(glow && !additive ? 2 * d2 : d2);
   t->net_rows = (int64_t)t->ip + 2LL * t->n_hidden * t->hp + t->op;
   t->hw = (h + 31) / 32 * 32; t->xw = (d2 + 31) / 32 * 32; t->ow = ((glow && !additive ? 2 * d2 : d2) + 31) / 32 * 32;
-  const size_t common = (size_t)d + (size_t)t->ip + 2 * (size_t)t->op;            // f32 rows: state, GX, O, O2
-  const size_t split = 16 * ((size_t)(4 * t->xw + 16) + (size_t)t->n_hidden * (4 * t->hw + 16) + (size_t)(4 * t->ow + 16));
-  const size_t tables = (size_t)K * (320 + 2 * TR_MAX_LAYERS * 8) * 4;
-  t->lds_fwd = tables + common * TR_S * 4 + 256 + 16 + split;
-  t->lds_bwd = tables + (common + (size_t)K * d) * TR_S * 4 + 256 + 16 + split;
-  if (t->lds_bwd > (size_t)TR_LDS_BYTES) {
-    const size_t need = t->lds_bwd;
+  if (t->hp > 256) {
     delete t;
-    return fail(GBNF_ERR_UNSUPPORTED, "gbnf_trainer_create: K*d = %d needs %zu bytes of LDS per wave (> %d)", K * d, need,
+    return fail(GBNF_ERR_UNSUPPORTED, "gbnf_trainer_create: hidden width %d > 256", h);
+  }
+  const size_t common = (size_t)d + (size_t)t->ip + 2 * (size_t)t->op;            // f32 rows: state, GX, O, O2
+  const size_t tables = (size_t)K * (320 + 2 * TR_MAX_LAYERS * 8) * 4;
+  for (int nt = 1; nt <= TR_MAX_NT; ++nt) {
+    const size_t S = 16 * nt + 1;
+    const size_t split = 16 * nt * ((size_t)(4 * t->xw + 16) + (size_t)t->n_hidden * (4 * t->hw + 16) + (size_t)(4 * t->ow + 16));
+    t->lds_fwd[nt] = tables + common * S * 4 + 64 * TR_WAVES * nt + 16 + split;
+    t->lds_bwd[nt] = tables + (common + (size_t)K * d) * S * 4 + 64 * TR_WAVES * nt + 16 + split;
+  }
+  if (t->lds_bwd[1] > (size_t)TR_LDS_BYTES) {
+    const size_t need = t->lds_bwd[1];
+    delete t;
+    return fail(GBNF_ERR_UNSUPPORTED, "gbnf_trainer_create: K*d = %d needs %zu bytes of LDS per workgroup (> %d)", K * d, need,
                 TR_LDS_BYTES);
   }
 
@@ -1047,6 +1180,9 @@ int gbnf_trainer_create(const gbnf_flow_desc* desc, gbnf_trainer** out) {
             P.tiles = (last ? t->op : t->hp) / 16;
             P.kc = (first ? t->xw : t->hw) / 32;
             L.fw = frag_off;
+            P.bias = L.b;
+            P.boff = (frag_off + (int64_t)P.tiles * P.kc * 128) * 4;      // right behind this orientation's fragments
+            L.fb = P.boff;
           } else {                 // backward: out = cols, k = rows
             P.tiles = (first ? t->ip : t->hp) / 16;
             P.kc = (last ? t->ow : t->hw) / 32;
@@ -1055,7 +1191,7 @@ int gbnf_trainer_create(const gbnf_flow_desc* desc, gbnf_trainer** out) {
           P.off = frag_off;
           P.blk_begin = prep_blocks;
           prep_blocks += P.tiles * P.kc;
-          frag_off += (int64_t)P.tiles * P.kc * 128;
+          frag_off += (int64_t)P.tiles * P.kc * 128 + (trans ? 0 : P.tiles * 4);   // (+ 16 bias floats per tile)
           preps.push_back(P);
         }
         WgProblem P{};
@@ -1092,9 +1228,11 @@ int gbnf_trainer_create(const gbnf_flow_desc* desc, gbnf_trainer** out) {
   if (e == hipSuccess) e = hipMemcpy(t->prep_dev, preps.data(), sizeof(PrepProblem) * preps.size(), hipMemcpyHostToDevice);
   if (e == hipSuccess) e = hipMalloc((void**)&t->frag_dev, (size_t)frag_off * 16);
   if (e == hipSuccess) {
-    const void* fns[4] = {(const void*)train_kernel<GBNF_KIND_GLOW, 0>, (const void*)train_kernel<GBNF_KIND_GLOW, 1>,
-                          (const void*)train_kernel<GBNF_KIND_REALNVP, 0>, (const void*)train_kernel<GBNF_KIND_REALNVP, 1>};
-    for (int k = 0; k < 4 && e == hipSuccess; ++k)
+    const void* fns[8] = {(const void*)train_kernel<GBNF_KIND_GLOW, 0, 1>, (const void*)train_kernel<GBNF_KIND_GLOW, 1, 1>,
+                          (const void*)train_kernel<GBNF_KIND_REALNVP, 0, 1>, (const void*)train_kernel<GBNF_KIND_REALNVP, 1, 1>,
+                          (const void*)train_kernel<GBNF_KIND_GLOW, 0, 2>, (const void*)train_kernel<GBNF_KIND_GLOW, 1, 2>,
+                          (const void*)train_kernel<GBNF_KIND_REALNVP, 0, 2>, (const void*)train_kernel<GBNF_KIND_REALNVP, 1, 2>};
+    for (int k = 0; k < 8 && e == hipSuccess; ++k)
       e = hipFuncSetAttribute(fns[k], hipFuncAttributeMaxDynamicSharedMemorySize, TR_LDS_BYTES);
   }
   if (e != hipSuccess) {
@@ -1124,7 +1262,7 @@ int gbnf_trainer_grad_floats(const gbnf_trainer* t, int64_t* n_floats) {
 
 int gbnf_trainer_workspace_bytes(const gbnf_trainer* t, int64_t n, int64_t* bytes) {
   if (!t || !bytes || n < 0) return fail(GBNF_ERR_INVALID, "gbnf_trainer_workspace_bytes: bad argument");
-  const int64_t np = (n + 15) / 16 * 16;
+  const int64_t np = tr_padded(n);
   // operand regions + 64 slack rows (a 64-row block of wgrad_kernel may run past the last region)
   // ... + the gradient state of step-by-step launches (batch-statistics BatchNorm)
   *bytes = (((int64_t)t->K * t->nnets * t->net_rows + 64) * np + (int64_t)t->d * np) * 4;
@@ -1142,7 +1280,7 @@ static void fill_launch(const gbnf_trainer* t, TrainLaunch& p, const float* x, i
   p.dbg = g_train_stamp_buf;
 #endif
   p.steps = t->steps_dev; p.tail = t->tail_dev; p.x = x;
-  p.n = n; p.np = (n + 15) / 16 * 16;
+  p.n = n; p.np = tr_padded(n);
   p.d = t->d; p.K = t->K; p.kind = t->kind; p.additive = t->additive;
   p.n_hidden = t->n_hidden; p.hp = t->hp; p.ip = t->ip; p.op = t->op; p.net_rows = t->net_rows;
   p.hw = t->hw; p.xw = t->xw; p.ow = t->ow; p.frag = t->frag_dev;
@@ -1183,7 +1321,7 @@ int gbnf_trainer_bind_batch_stats(gbnf_trainer* t, int32_t step, float* mean_dev
 
 int gbnf_trainer_trace_floats(const gbnf_trainer* t, int64_t n, int64_t* n_floats) {
   if (!t || !n_floats || n < 0) return fail(GBNF_ERR_INVALID, "gbnf_trainer_trace_floats: bad argument");
-  *n_floats = ((int64_t)t->K + 1) * t->d * ((n + 15) / 16 * 16);     // K normalised states + the running state
+  *n_floats = ((int64_t)t->K + 1) * t->d * tr_padded(n);     // K normalised states + the running state
   return GBNF_OK;
 }
 
