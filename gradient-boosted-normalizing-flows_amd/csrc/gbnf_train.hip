@@ -119,6 +119,9 @@ __device__ __forceinline__ float tr_tanh(float x) {
 }
 // four values at a time: `act` is uniform, so this is one scalar branch around straight-line code
 __device__ __forceinline__ f32x4 tr_act4(int act, f32x4 v) {
+#ifdef GBNF_TR_ABLATE_ACT           // diagnostic: no activation
+  return v;
+#endif
   f32x4 h;
   if (act == GBNF_ACT_TANH) {
 #pragma unroll
@@ -212,6 +215,10 @@ __device__ __forceinline__ gptr tr_uniform(gptr p) {
 typedef const u32x4 __attribute__((address_space(1)))* gfrag;
 
 __device__ __forceinline__ f32x4 tr_mfma16(u32x4 a, u32x4 b, f32x4 c) {
+#ifdef GBNF_TR_ABLATE_MFMA          // diagnostic: one cheap VALU op instead of the MFMA (keeps every value live)
+  c[0] += __builtin_bit_cast(float, a[0] ^ b[0]);
+  return c;
+#endif
   return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
 }
 // hi = f16(x) (toward zero), mid = f16(x - hi) for a pair, clamped to the fp16 range
@@ -298,8 +305,12 @@ __device__ __forceinline__ void tr_dense(gfrag A, gptr bias, int kc32, int frag_
   auto issue = [&](u32x4& a0h, u32x4& a0m, u32x4& a1h, u32x4& a1m) {
     const int o0 = 2 * pl < frag_tiles ? 2 * pl : 0, o1 = 2 * pl + 1 < frag_tiles ? 2 * pl + 1 : 0;   // past the end: tile 0 again
     const gfrag f0 = A + ((size_t)o0 * kc32 + cl) * 128 + lane, f1 = A + ((size_t)o1 * kc32 + cl) * 128 + lane;
+#ifndef GBNF_TR_ABLATE_LOADS        // (diagnostic builds: tools/build_train_ablations.sh -- timing only, results wrong)
     a0h = f0[0]; a0m = f0[64];
     a1h = f1[0]; a1m = f1[64];
+#else
+    (void)f0; (void)f1;
+#endif
     if (++cl == kc32) { cl = 0; pl += TR_WAVES; }
   };
   constexpr int MAXP = (8 + TR_WAVES - 1) / TR_WAVES;   // pairs per wave (<= 16 output tiles)
@@ -409,13 +420,16 @@ __global__ void __launch_bounds__(64 * TR_WAVES) train_kernel(const TrainLaunch 
   TrStamps stamps;
   stamps.mark(-1);
   // per-step tables, staged once: slot maps and the normalisation constants of every slot
-  const lip TI = reinterpret_cast<lip>(lds);               // [K][64]: in_slot[32], out_slot[32]
-  const lfp TP = lds + K * 64;                        // [K][4][64]: p0..p3 per slot
+  // (everything a step needs lives in LDS from here on: a read of the step table in global memory inside the step loop
+  // is a vector-memory load, and waiting for it drains the weight prefetch)
+  const lip TI = reinterpret_cast<lip>(lds);               // [K][128]: in_slot[32], out_slot[32], feat[64]
+  const lfp TP = lds + K * 128;                       // [K][4][64]: p0..p3 per slot
   for (int k = 0; k < K; ++k) {
     const TrStep& st = p.steps[k];
-    for (int t = threadIdx.x; t < 128; t += 64 * TR_WAVES)
-    if (t < 32) TI[k * 64 + t] = st.in_slot[t];
-    else if (t < 64) TI[k * 64 + t] = st.out_slot[t - 32];
+    for (int t = threadIdx.x; t < 192; t += 64 * TR_WAVES)
+    if (t < 32) TI[k * 128 + t] = st.in_slot[t];
+    else if (t < 64) TI[k * 128 + t] = st.out_slot[t - 32];
+    else if (t >= 128) TI[k * 128 + t - 64] = st.feat[t - 128];
     else {
       const int sl = t - 64;
       float p0 = 0.f, p1 = 1.f, p2 = 0.f, p3 = 0.f;
@@ -440,7 +454,7 @@ __global__ void __launch_bounds__(64 * TR_WAVES) train_kernel(const TrainLaunch 
     }
   }
   // ... and the per-layer descriptors (padded-bias offset, fragment offsets, rows, cols): 8 words per (step, net, layer)
-  const lup TL = reinterpret_cast<lup>(lds + K * 320);
+  const lup TL = reinterpret_cast<lup>(lds + K * 384);
   for (int e = threadIdx.x; e < K * 2 * TR_MAX_LAYERS; e += 64 * TR_WAVES) {
     const int k = e / (2 * TR_MAX_LAYERS), q = (e / TR_MAX_LAYERS) & 1, l = e % TR_MAX_LAYERS;
     const TrLayer& L = p.steps[k].net[q].layer[l];
@@ -450,7 +464,28 @@ __global__ void __launch_bounds__(64 * TR_WAVES) train_kernel(const TrainLaunch 
     t[4] = (unsigned)L.bw; t[5] = (unsigned)(L.bw >> 32);
     t[6] = (unsigned)L.rows; t[7] = (unsigned)L.cols;
   }
-  const lfp Y = lds + K * 320 + K * 2 * TR_MAX_LAYERS * 8;   // [K*d] normalised state of every step (MODE 1)
+  // ... and the per-step scalars: in_f, out_f, has_norm, -, g_na, g_nb (two words each)
+  const lup TSC = TL + K * 2 * TR_MAX_LAYERS * 8;
+  for (int k = threadIdx.x; k < K; k += 64 * TR_WAVES) {
+    const TrStep& st = p.steps[k];
+    const lup t = TSC + k * 8;
+    t[0] = (unsigned)st.in_f; t[1] = (unsigned)st.out_f; t[2] = (unsigned)st.has_norm; t[3] = 0u;
+    t[4] = (unsigned)st.g_na; t[5] = (unsigned)((unsigned long long)st.g_na >> 32);
+    t[6] = (unsigned)st.g_nb; t[7] = (unsigned)((unsigned long long)st.g_nb >> 32);
+  }
+  struct StepD { int in_f, out_f, has_norm; long long g_na, g_nb; };
+  auto step_desc = [&](int k) -> StepD {                 // from the LDS table, moved to scalar registers
+    const lup t = TSC + k * 8;
+    unsigned w[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) w[e] = __builtin_amdgcn_readfirstlane(t[e]);
+    StepD D;
+    D.in_f = (int)w[0]; D.out_f = (int)w[1]; D.has_norm = (int)w[2];
+    D.g_na = (long long)(((unsigned long long)w[5] << 32) | w[4]);
+    D.g_nb = (long long)(((unsigned long long)w[7] << 32) | w[6]);
+    return D;
+  };
+  const lfp Y = lds + K * 384 + K * 2 * TR_MAX_LAYERS * 8 + K * 8;   // [K*d] normalised state of every step (MODE 1)
   const lfp Zc = Y + (MODE == 1 ? K * d * S : 0);         // [d]   running state (forward) / gradient state (backward)
   const lfp GX = Zc + d * S;                              // [ip]  gradient w.r.t. the coupling-net input
   const lfp O = GX + p.ip * S;                            // [op]  net output, then its gradient
@@ -460,12 +495,12 @@ __global__ void __launch_bounds__(64 * TR_WAVES) train_kernel(const TrainLaunch 
   lbp sp = reinterpret_cast<lbp>(lds) + ((((RED + 16 * TR_WAVES * NT) - lds) * 4 + 15) & ~15);   // 16-byte aligned
   const TrSplit XS{sp, p.xw};
   sp += TS * XS.rs();
-  TrSplit HS[TR_MAX_LAYERS - 1];
-#pragma unroll
-  for (int l = 0; l < TR_MAX_LAYERS - 1; ++l) {
-    HS[l] = TrSplit{sp, p.hw};
-    if (l < p.n_hidden) sp += TS * HS[l].rs();
-  }
+  // hidden layer l's rows: computed, not an array (a dynamically indexed local array lives in scratch memory, and a
+  // scratch load is a vector-memory load: waiting for it drains the weight prefetch)
+  const lbp hs0 = sp;
+  const int hs_bytes = TS * (4 * p.hw + 16);
+  auto HS = [&](int l) -> TrSplit { return TrSplit{hs0 + l * hs_bytes, p.hw}; };
+  sp += p.n_hidden * hs_bytes;
   const TrSplit GOS{sp, p.ow};
   // channels between the 16-padded and the 32-padded widths are never written by an epilogue: zero the split rows once
   {
@@ -505,7 +540,7 @@ __global__ void __launch_bounds__(64 * TR_WAVES) train_kernel(const TrainLaunch 
     TrSplit in = XS;
     const int act = q == 0 ? act_a : act_b;
     for (int l = 0; l + 1 < nl; ++l) {
-      const TrSplit Hl = HS[l];
+      const TrSplit Hl = HS(l);
       const bool emit = (MODE == 1) && ws_net != nullptr;    // backward sweep only: activation-side operand of dW
       // operand sub-regions are tiled: [tile of 16 samples][unit][16] -- a workgroup's rows of one operand are one
       // contiguous block, and a unit's 16 samples one 64-byte run (wgrad_kernel reads 16 units x 64 B per wave load)
@@ -550,7 +585,7 @@ __global__ void __launch_bounds__(64 * TR_WAVES) train_kernel(const TrainLaunch 
     tr_lds_barrier();
     TrSplit in = GOS;
     for (int l = nl - 1; l >= 1; --l) {
-      const TrSplit Hl = HS[l - 1];                          // activations of hidden layer l-1 -> overwritten by its gradient
+      const TrSplit Hl = HS(l - 1);                          // activations of hidden layer l-1 -> overwritten by its gradient
       float* ws_d = ws_net + ((size_t)p.ip + (size_t)nh * p.hp + (size_t)(l - 1) * p.hp) * p.np + (size_t)tile0 * p.hp * 16 + i;
       const LayerD L = layer_desc(k, q, l);                  // A = W^T: output units = cols, k = rows
       tr_dense<NT>((gfrag)(p.frag + L.bw), gptr(nullptr), in.w >> 5, hid_tiles, in, hid_tiles, lane, wave, stamps,
@@ -595,7 +630,7 @@ __global__ void __launch_bounds__(64 * TR_WAVES) train_kernel(const TrainLaunch 
     for (int e = g + kb * d; e < ke * d; e += GS) TR_NT Y[e * S + i + 16 * nt] = p.trace[(size_t)e * p.np + row0 + i + 16 * nt];
   }
   for (int k = kb; k < (have_trace ? kb : ke); ++k) {
-    const TrStep& st = p.steps[k];
+    const StepD st = step_desc(k);
     for (int s = g; s < d; s += GS) TR_NT {
       const int ii = i + 16 * nt;
       const float y = norm_fwd(k, s, Zc[s * S + ii], ld[nt]);
@@ -605,7 +640,7 @@ __global__ void __launch_bounds__(64 * TR_WAVES) train_kernel(const TrainLaunch 
     }
     if (MODE == 1 && k == ke - 1) break;                   // the last step's outputs are not needed for the backward
     tr_lds_barrier();
-    const lip ti = TI + k * 64;
+    const lip ti = TI + k * 128;
     for (int kk = g; kk < p.xw; kk += GS) TR_NT XS.put1(i + 16 * nt, kk, kk < st.in_f ? Zc[ti[kk] * S + i + 16 * nt] : 0.0f);
     tr_lds_barrier();
     stamps.mark(1);
@@ -694,7 +729,7 @@ __global__ void __launch_bounds__(64 * TR_WAVES) train_kernel(const TrainLaunch 
 
     // normalisation backward for one slot and one sample: returns d(loss)/d(pre-norm value) and adds the sample's terms
     // of the two parameter gradients to ga / gb; norm_commit folds them over the workgroup's samples of that slot
-    auto norm_bwd = [&](const TrStep& st, int k, int s, float gy, float y, float gldj, float& ga, float& gb) -> float {
+    auto norm_bwd = [&](const StepD& st, int k, int s, float gy, float y, float gldj, float& ga, float& gb) -> float {
       const lcfp tp = TP + k * 256 + s;
       const float gx = gy * tp[64];
       if constexpr (KIND == GBNF_KIND_GLOW) {
@@ -707,9 +742,9 @@ __global__ void __launch_bounds__(64 * TR_WAVES) train_kernel(const TrainLaunch 
       }
       return gx;
     };
-    auto norm_commit = [&](const TrStep& st, int s, float ga, float gb) {
+    auto norm_commit = [&](const StepD& st, int k, int s, float ga, float gb) {
       if (KIND != GBNF_KIND_GLOW && !st.has_norm) return;
-      const int f = st.feat[s];
+      const int f = TI[k * 128 + 64 + s];
       ga = tr_group_sum(ga);
       gb = tr_group_sum(gb);
       if (i == 0) {
@@ -719,10 +754,10 @@ __global__ void __launch_bounds__(64 * TR_WAVES) train_kernel(const TrainLaunch 
     };
 
     for (int k = ke - 1; k >= kb; --k) {
-      const TrStep& st = p.steps[k];
+      const StepD st = step_desc(k);
       const lcfp Yk = Y + k * d * S;
       float* ws_step = p.ws + (size_t)k * nnets * p.net_rows * p.np;
-      const lip ti = TI + k * 64;
+      const lip ti = TI + k * 128;
       // net input (also the activation-side operand of the first layer's weight gradient)
       for (int kk = g; kk < p.xw; kk += GS) TR_NT {
         const int ii = i + 16 * nt;
@@ -756,7 +791,7 @@ __global__ void __launch_bounds__(64 * TR_WAVES) train_kernel(const TrainLaunch 
             }
             G[slot * S + ii] = norm_bwd(st, k, slot, gy, y2, gl[nt], ga, gb);
           }
-          norm_commit(st, slot, ga, gb);
+          norm_commit(st, k, slot, ga, gb);
         }
         tr_lds_barrier();
         net_backward(k, 0, O, ws_step, false);
@@ -777,7 +812,7 @@ __global__ void __launch_bounds__(64 * TR_WAVES) train_kernel(const TrainLaunch 
             O[j * S + ii] = g2 * y2 * es + gl[nt];                          // d/d scale: z2' = shift + y2 e^scale, ld += scale
             G[slot * S + ii] = norm_bwd(st, k, slot, g2 * es, y2, gl[nt], ga, gb);
           }
-          norm_commit(st, slot, ga, gb);
+          norm_commit(st, k, slot, ga, gb);
         }
         tr_lds_barrier();
         net_backward(k, 1, O, ws_s, false);
@@ -791,7 +826,7 @@ __global__ void __launch_bounds__(64 * TR_WAVES) train_kernel(const TrainLaunch 
           const int ii = i + 16 * nt;
           G[slot * S + ii] = norm_bwd(st, k, slot, G[slot * S + ii] + GX[kk * S + ii], Yk[slot * S + ii], gl[nt], ga, gb);
         }
-        norm_commit(st, slot, ga, gb);
+        norm_commit(st, k, slot, ga, gb);
       }
       tr_lds_barrier();
     }
@@ -1100,7 +1135,7 @@ int gbnf_trainer_create(const gbnf_flow_desc* desc, gbnf_trainer** out) {
     return fail(GBNF_ERR_UNSUPPORTED, "gbnf_trainer_create: hidden width %d > 256", h);
   }
   const size_t common = (size_t)d + (size_t)t->ip + 2 * (size_t)t->op;            // f32 rows: state, GX, O, O2
-  const size_t tables = (size_t)K * (320 + 2 * TR_MAX_LAYERS * 8) * 4;
+  const size_t tables = (size_t)K * (384 + 2 * TR_MAX_LAYERS * 8 + 8) * 4;
   for (int nt = 1; nt <= TR_MAX_NT; ++nt) {
     const size_t S = 16 * nt + 1;
     const size_t split = 16 * nt * ((size_t)(4 * t->xw + 16) + (size_t)t->n_hidden * (4 * t->hw + 16) + (size_t)(4 * t->ow + 16));

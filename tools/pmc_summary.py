@@ -1,0 +1,17 @@
+#!/usr/bin/env python3
+"""Sum rocprofv3 --pmc counters per kernel name from the counter_collection CSVs under a directory."""
+import csv, glob, sys, collections
+root = sys.argv[1]
+acc = collections.defaultdict(lambda: collections.defaultdict(float))
+cnt = collections.defaultdict(set)
+for f in glob.glob(root + "/**/*counter_collection.csv", recursive=True):
+    for r in csv.DictReader(open(f)):
+        k = r["Kernel_Name"][:70]
+        acc[k][r["Counter_Name"]] += float(r["Counter_Value"])
+        cnt[k].add(r["Dispatch_Id"])
+for k, d in sorted(acc.items(), key=lambda kv: -kv[1].get("SQ_WAVE_CYCLES", 0)):
+    n = len(cnt[k])
+    print(f"{k}  dispatches={n}")
+    wc = d.get("SQ_WAVE_CYCLES", 0) or 1
+    for c, v in sorted(d.items()):
+        print(f"    {c:32s} {v / n:16.0f} per dispatch   {100 * v / wc / n * n:6.1f} % of wave cycles")

@@ -3,7 +3,7 @@
 Read the SHARES, not the absolute time (the stamps serialise the wave)."""
 import ctypes as C, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-os.environ["GBNF_LIB_PATH"] = os.path.join(ROOT, "tools", "libgbnf_train_stamps.so")
+os.environ.setdefault("GBNF_LIB_PATH", os.path.join(ROOT, "tools", "libgbnf_train_stamps.so"))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np, torch
 from gbnf_amd import native, synth
