@@ -112,7 +112,7 @@ def main():
     t0 = time.perf_counter()
     for _ in range(a.cpu_steps):
         cpu_fn()
-    t_cpu = (time.perf_counter() - t0) / a.cpu_steps
+    t_cpu = (time.perf_counter() - t0) / a.cpu_steps if a.cpu_steps > 0 else float("inf")   # --cpu-steps 0: GPU legs only
     macs = sum((w.shape[0] * w.shape[1]) for st in spec["steps"] for net in ([st["net"]] if cfg["kind"] == "glow" else [st["t_net"], st["s_net"]]) for w, _ in net["layers"])
     flops = 2.0 * macs * n * 3        # forward + dgrad + wgrad
     print(json.dumps({
