@@ -855,11 +855,28 @@ struct WgProblem {
   int M, N, blk_begin, nb;
   int d_rows, a_rows;     // rows of the two sub-regions (tiled as [tile][row][16 samples])
 };
-constexpr int WG_CHUNK = 512;   // samples per block
-constexpr int WG_PD = 2;        // 16-sample groups of operand loads in flight
+constexpr int WG_PD = 2;        // 32-sample groups of operand loads in flight
 
+// hi = f16(x) toward zero, mid = f16(x - hi) for 8 consecutive samples of one operand row -> one MFMA operand each.
+// No clamp: toward-zero conversion saturates at the largest finite fp16, so a value beyond the fp16 range degrades to
+// a finite wrong number (<= 131008) instead of an infinity -- the forward path saturates such values anyway.
+__device__ __forceinline__ void wg_split8(f32x4 lo, f32x4 hi4, u32x4& h, u32x4& m) {
+#pragma unroll
+  for (int q = 0; q < 2; ++q) {
+    const auto a = __builtin_amdgcn_cvt_pkrtz(lo[2 * q], lo[2 * q + 1]);
+    const auto b = __builtin_amdgcn_cvt_pkrtz(hi4[2 * q], hi4[2 * q + 1]);
+    h[q] = __builtin_bit_cast(unsigned, a);
+    h[2 + q] = __builtin_bit_cast(unsigned, b);
+    m[q] = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(lo[2 * q] - (float)a[0], lo[2 * q + 1] - (float)a[1]));
+    m[2 + q] = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(hi4[2 * q] - (float)b[0], hi4[2 * q + 1] - (float)b[1]));
+  }
+}
+
+// The contraction runs on the f16 pipe with split operands (section 4.1: three v_mfma_f32_16x16x32_f16 per product, f32
+// accumulation): one k = 32 step = 32 samples = two 16-sample tiles of the workspace; lane (i, g) of an operand
+// fragment holds samples 8 (g & 1) .. + 7 of tile (g >> 1) of row i -- 32 contiguous bytes, split in registers.
 __global__ void __launch_bounds__(64) wgrad_kernel(const WgProblem* __restrict__ probs, int n_probs,
-                                                   const float* __restrict__ ws, float* __restrict__ grads, int64_t np) {
+                                                   const float* __restrict__ ws, float* __restrict__ grads, int64_t np, int chunk) {
   typedef const f32x4 __attribute__((address_space(1)))* gv4;
   const int lane = threadIdx.x, i = lane & 15, g = lane >> 4;
   int pi = 0;
@@ -867,12 +884,12 @@ __global__ void __launch_bounds__(64) wgrad_kernel(const WgProblem* __restrict__
   const WgProblem P = probs[pi];
   const int blk = blockIdx.x - P.blk_begin;
   const int m0 = (blk / P.nb) * 64, n0 = (blk % P.nb) * 64;
-  const int64_t s_begin = (int64_t)blockIdx.y * WG_CHUNK;
-  const int64_t s_end = (s_begin + WG_CHUNK < np) ? s_begin + WG_CHUNK : np;
+  const int64_t s_begin = (int64_t)blockIdx.y * chunk;       // `chunk` samples per block (a multiple of 32)
+  const int64_t s_end = (s_begin + chunk < np) ? s_begin + chunk : np;
   // element (row, sample s) of a sub-region with R rows: base + ((s / 16) * R + row) * 16 + s % 16
-  const float* Db = ws + P.d_row * np + (int64_t)(m0 + i) * 16 + 4 * g;
-  const float* Ab = ws + P.a_row * np + (int64_t)(n0 + i) * 16 + 4 * g;
   const int64_t dstep = (int64_t)P.d_rows, astep = (int64_t)P.a_rows;      // floats per sample when walking tiles (R * 16 / 16)
+  const float* Db = ws + P.d_row * np + (int64_t)(m0 + i) * 16 + 8 * (g & 1) + (g >> 1) * 16 * dstep;
+  const float* Ab = ws + P.a_row * np + (int64_t)(n0 + i) * 16 + 8 * (g & 1) + (g >> 1) * 16 * astep;
   f32x4 acc[4][4];
   f32x4 bsum[4];
   const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
@@ -882,31 +899,43 @@ __global__ void __launch_bounds__(64) wgrad_kernel(const WgProblem* __restrict__
 #pragma unroll
     for (int b = 0; b < 4; ++b) acc[a][b] = zero;
   }
-  f32x4 rd[WG_PD][4], ra[WG_PD][4];
+  f32x4 rd[WG_PD][4][2], ra[WG_PD][4][2];
   int64_t sl = s_begin;
-  auto issue = [&](f32x4 (&d)[4], f32x4 (&a)[4]) {
+  auto issue = [&](f32x4 (&d)[4][2], f32x4 (&a)[4][2]) {
     const int64_t s = sl < s_end ? sl : s_begin;       // past the end: a valid (unused) group again
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
-      d[t] = *(gv4)(Db + s * dstep + t * 256);         // 16 rows further = 256 floats inside the tile
-      a[t] = *(gv4)(Ab + s * astep + t * 256);
+      const gv4 dp = (gv4)(Db + s * dstep + t * 256), ap = (gv4)(Ab + s * astep + t * 256);   // 16 rows further = 256 floats inside the tile
+      d[t][0] = dp[0]; d[t][1] = dp[1];
+      a[t][0] = ap[0]; a[t][1] = ap[1];
     }
-    sl += 16;
+    sl += 32;
   };
 #pragma unroll
   for (int j = 0; j < WG_PD; ++j) issue(rd[j], ra[j]);
-  auto body = [&](const f32x4 (&d)[4], const f32x4 (&a)[4]) {
+  auto body = [&](const f32x4 (&d)[4][2], const f32x4 (&a)[4][2]) {
+    u32x4 dh[4], dm[4], ah[4], am[4];
 #pragma unroll
-    for (int r = 0; r < 4; ++r)
+    for (int x = 0; x < 4; ++x) {
+      wg_split8(d[x][0], d[x][1], dh[x], dm[x]);
+      wg_split8(a[x][0], a[x][1], ah[x], am[x]);
+      bsum[x] += d[x][0] + d[x][1];
+    }
 #pragma unroll
-      for (int x = 0; x < 4; ++x)
+    for (int x = 0; x < 4; ++x)
 #pragma unroll
-        for (int y = 0; y < 4; ++y) acc[x][y] = tr_mfma(d[x][r], a[y][r], acc[x][y]);
+      for (int y = 0; y < 4; ++y) acc[x][y] = tr_mfma16(dm[x], ah[y], acc[x][y]);
 #pragma unroll
-    for (int x = 0; x < 4; ++x) bsum[x] += d[x];
+    for (int x = 0; x < 4; ++x)
+#pragma unroll
+      for (int y = 0; y < 4; ++y) acc[x][y] = tr_mfma16(dh[x], am[y], acc[x][y]);
+#pragma unroll
+    for (int x = 0; x < 4; ++x)
+#pragma unroll
+      for (int y = 0; y < 4; ++y) acc[x][y] = tr_mfma16(dh[x], ah[y], acc[x][y]);
   };
   int64_t s = s_begin;
-  for (; s + 16 * WG_PD <= s_end; s += 16 * WG_PD) {
+  for (; s + 32 * WG_PD <= s_end; s += 32 * WG_PD) {
 #pragma unroll
     for (int j = 0; j < WG_PD; ++j) {
       body(rd[j], ra[j]);
@@ -915,7 +944,7 @@ __global__ void __launch_bounds__(64) wgrad_kernel(const WgProblem* __restrict__
   }
 #pragma unroll
   for (int j = 0; j < WG_PD - 1; ++j)
-    if (s + 16 * j < s_end) body(rd[j], ra[j]);
+    if (s + 32 * j < s_end) body(rd[j], ra[j]);
 #pragma unroll
   for (int x = 0; x < 4; ++x) {
     tr_mfma_drain(acc[x][0], acc[x][1]);
@@ -1440,8 +1469,13 @@ int gbnf_trainer_backward(const gbnf_trainer* t, const float* x, int64_t n, cons
   }
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return fail(GBNF_ERR_HIP, "gbnf_trainer_backward launch: %s", hipGetErrorString(e));
-  const dim3 wgrid((unsigned)t->wg_blocks, (unsigned)((p.np + WG_CHUNK - 1) / WG_CHUNK));
-  hipLaunchKernelGGL(wgrad_kernel, wgrid, dim3(64), 0, s, t->probs_dev, t->n_probs, (const float*)workspace, grads, p.np);
+  // samples per block: every block ends in 4096 atomic adds, so as many samples as still leave a few thousand waves
+  static const int forced_chunk = [] { const char* e = getenv("GBNF_WGRAD_CHUNK"); return e ? atoi(e) : 0; }();
+  int chunk = 512;
+  while (chunk < 4096 && (int64_t)t->wg_blocks * (p.np / (2 * chunk)) >= 3072) chunk *= 2;
+  if (forced_chunk >= 32 && forced_chunk % 32 == 0) chunk = forced_chunk;
+  const dim3 wgrid((unsigned)t->wg_blocks, (unsigned)((p.np + chunk - 1) / chunk));
+  hipLaunchKernelGGL(wgrad_kernel, wgrid, dim3(64), 0, s, t->probs_dev, t->n_probs, (const float*)workspace, grads, p.np, chunk);
   e = hipGetLastError();
   if (e != hipSuccess) return fail(GBNF_ERR_HIP, "gbnf_trainer_backward wgrad launch: %s", hipGetErrorString(e));
   return GBNF_OK;
