@@ -45,6 +45,7 @@ using f16x8 = __attribute__((ext_vector_type(8))) _Float16;
 constexpr int TR_MAX_NT = 2;        // 16-sample tiles per workgroup (they share every weight fragment a wave loads)
 constexpr int TR_MAX_LAYERS = 4;    // Linear layers per coupling net (depth <= 2)
 constexpr int TR_MAX_IN = 32;       // coupling-net input / coupled-half width
+constexpr int TR_MAX_HIDDEN = 512;  // hidden width (32 output tiles = 16 tile pairs per layer)
 constexpr int TR_LDS_BYTES = 160 * 1024;
 #ifndef GBNF_TR_WAVES
 #define GBNF_TR_WAVES 8
@@ -313,7 +314,7 @@ __device__ __forceinline__ void tr_dense(gfrag A, gptr bias, int kc32, int frag_
 #endif
     if (++cl == kc32) { cl = 0; pl += TR_WAVES; }
   };
-  constexpr int MAXP = (8 + TR_WAVES - 1) / TR_WAVES;   // pairs per wave (<= 16 output tiles)
+  constexpr int MAXP = (TR_MAX_HIDDEN / 32 + TR_WAVES - 1) / TR_WAVES;   // tile pairs per wave
   f32x4 bq0[MAXP], bq1[MAXP];
 #pragma unroll
   for (int q = 0; q < MAXP; ++q) {
@@ -1159,9 +1160,9 @@ int gbnf_trainer_create(const gbnf_flow_desc* desc, gbnf_trainer** out) {
   t->op = ceil16(glow && !additive ? 2 * d2 : d2);
   t->net_rows = (int64_t)t->ip + 2LL * t->n_hidden * t->hp + t->op;
   t->hw = (h + 31) / 32 * 32; t->xw = (d2 + 31) / 32 * 32; t->ow = ((glow && !additive ? 2 * d2 : d2) + 31) / 32 * 32;
-  if (t->hp > 256) {
+  if (t->hp > TR_MAX_HIDDEN) {
     delete t;
-    return fail(GBNF_ERR_UNSUPPORTED, "gbnf_trainer_create: hidden width %d > 256", h);
+    return fail(GBNF_ERR_UNSUPPORTED, "gbnf_trainer_create: hidden width %d > %d", h, TR_MAX_HIDDEN);
   }
   const size_t common = (size_t)d + (size_t)t->ip + 2 * (size_t)t->op;            // f32 rows: state, GX, O, O2
   const size_t tables = (size_t)K * (384 + 2 * TR_MAX_LAYERS * 8 + 8) * 4;

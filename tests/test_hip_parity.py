@@ -115,6 +115,26 @@ def test_deterministic_and_tile_independent(golden_case, dev):
     assert rel_err(small.cpu().numpy(), a[:, :77].cpu().numpy()) < 2e-6
 
 
+@pytest.mark.parametrize("kind,d,h,act", [("glow", 63, 315, "tanh"), ("glow", 43, 430, "tanh"), ("glow", 21, 512, "relu"),
+                                          ("realnvp", 21, 300, "tanh"), ("realnvp", 63, 512, "relu")])
+def test_wide_hidden_layers(kind, d, h, act, dev):
+    """Hidden widths above 256 (the reference sets h = h_size_factor * D: 5 x 63 = 315, 10 x 43 = 430):
+    the 24- and 32-tile variants of the split-f16 kernel, 16- and 32-sample wave tiles, ragged tail."""
+    import torch
+    from gbnf_amd import synth
+    from oracle import gbnf_oracle as oracle
+    kw = {"act": act} if kind == "glow" else {"coupling_network": act}
+    specs = synth.synth_boosted_specs(kind, 2, d, h, 3, seed=7, **kw)
+    mix, _ = _mixture(specs)
+    rho = oracle.rho_init(2)
+    for n in (333, 4096):
+        xs = synth.synth_batch(n, d, seed=n)
+        ll_ref, G_ref = oracle.mixture_log_prob(specs, rho, xs)
+        G, ll = mix.log_prob(torch.from_numpy(xs).to(dev), torch.from_numpy(rho).to(dev))
+        assert rel_err(ll.cpu().numpy(), ll_ref) < LL_RTOL
+        assert rel_err(G.cpu().numpy(), G_ref) < LL_RTOL
+
+
 def test_full_size_against_oracle(dev):
     """BASELINE config: MINIBOONE d=43 h=215 K=5 C=8, N=4096 -- HIP vs the torch-CPU oracle."""
     import torch

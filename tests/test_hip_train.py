@@ -277,6 +277,12 @@ def _random_train_cases():
             extra = dict(coupling_network=str(rng.choice(["tanh", "relu", "mixed"])), batch_norm=bool(rng.randint(2)),
                          flip_init=int(rng.randint(2)), depth=depth)
         cases.append((kind, d, h, K, n, extra, 900 + k))
+    # hidden widths above 256 (h = h_size_factor * D in the reference: 5 x 63 = 315, 10 x 43 = 430), one or two
+    # 16-sample tiles per workgroup depending on what fits the LDS
+    cases.append(("glow", 63, 315, 2, 100, dict(act="tanh", coupling="affine", permutation="shuffle", depth=1), 950))
+    cases.append(("glow", 43, 430, 2, 77, dict(act="relu", coupling="affine", permutation="shuffle", depth=1), 951))
+    cases.append(("realnvp", 21, 512, 2, 65, dict(coupling_network="tanh", batch_norm=True, flip_init=1, depth=1), 952))
+    cases.append(("glow", 8, 300, 1, 33, dict(act="tanh", coupling="additive", permutation="reverse", depth=2), 953))
     return cases
 
 
