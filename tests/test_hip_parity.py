@@ -244,7 +244,7 @@ def test_empty_batch_and_errors(dev):
     bad["steps"][0]["perm"] = np.zeros(43, dtype=np.int64)    # not a permutation
     with pytest.raises(native.GbnfError):
         native.NativeFlow(bad)
-    wide = synth.synth_glow_spec(43, 300, 1, seed=0)          # h > 256: no compiled variant
+    wide = synth.synth_glow_spec(43, 600, 1, seed=0)          # h > 512: no compiled variant
     with pytest.raises(native.GbnfError):
         native.NativeFlow(wide)
 
