@@ -102,6 +102,20 @@ def cpu_baseline(specs, rho, x_np, budget_s):
     }, G, n
 
 
+def measured_traffic(config, B, C, S, f16x3, world):
+    """HBM-side bytes per launch of the dominant kernel from the PMC passes committed under profiles/ (FETCH_SIZE x 2
+    + WRITE_SIZE, collected as MI355X_MICROARCH.md prescribes) -- only for the exact workload they were taken on."""
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "headline_traffic.json")
+    try:
+        rec = json.load(open(path))
+    except (OSError, ValueError):
+        return None
+    w = rec.get("workload", {})
+    same = (w.get("config") == config and w.get("batch") == B and w.get("components") == C and w.get("group") == S
+            and w.get("math") == ("f16x3" if f16x3 else "f32") and w.get("n_gpus") == world)
+    return float(rec["traffic_bytes_per_launch"]) if same else None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -267,7 +281,7 @@ def main():
             "roofline": {
                 "kernel": "gbnf::flow_kernel_hx3" if f16x3 else "gbnf::flow_kernel",
                 "bound": "mfma", "achieved": achieved_tf, "peak": peak, "unit": "TFLOP/s",
-                "frac": achieved_tf / peak, "traffic": None,
+                "frac": achieved_tf / peak, "traffic": measured_traffic(args.config, B, C, S, f16x3, world),
                 "launch_ms": kern_ms, "flops_per_launch": flops_per_launch,
                 "executed_mfma_tflops": executed_tf, "executed_frac": executed_tf / peak,
                 "vs_f32_mfma_peak": achieved_tf / F32_MFMA_PEAK_TFLOPS,
