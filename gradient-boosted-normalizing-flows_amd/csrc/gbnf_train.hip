@@ -1110,8 +1110,9 @@ static int64_t tr_padded(int64_t n) { return (n + 16 * TR_MAX_NT - 1) / (16 * TR
 static int pick_nt(const gbnf_trainer* t, int64_t np, int mode) {
   static const int forced = [] { const char* e = getenv("GBNF_TRAIN_NT"); return e ? atoi(e) : 0; }();
   const size_t* lds = mode == 0 ? t->lds_fwd : t->lds_bwd;
-  int nt = TR_MAX_NT;      // measured: two tiles win at every batch size, even when they leave CUs without a workgroup
-  (void)np;
+  // measured (MINIBOONE Glow): one tile per workgroup is the faster of the two up to 1024 samples (a lone workgroup's
+  // pass through the layers is the whole latency there), two tiles from 2048 on even while they leave CUs idle
+  int nt = np / 16 > 96 ? TR_MAX_NT : 1;
   if (forced >= 1 && forced <= TR_MAX_NT) nt = forced;
   while (nt > 1 && lds[nt] > (size_t)TR_LDS_BYTES) --nt;
   return nt;
