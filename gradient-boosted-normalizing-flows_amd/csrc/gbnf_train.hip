@@ -331,13 +331,21 @@ __device__ __forceinline__ void tr_dense(gfrag A, gptr bias, int kc32, int frag_
   for (int nt = 0; nt < NT; ++nt) { acc0[nt] = zero; acc1[nt] = zero; }
   const lbp inl = in.base + i * in.rs() + 16 * g;
   const int mid_off = 2 * in.w, tile_off = 16 * in.rs();
-  auto body = [&](const u32x4& a0h, const u32x4& a0m, const u32x4& a1h, const u32x4& a1m) {
-    u32x4 bh[NT], bm[NT];
+  // B operands are read one iteration ahead (ping-pong on the ring index): a chunk's ds_read_b128s are issued behind
+  // the previous chunk's MFMAs instead of in front of its own (the LDS round trip was exposed in every iteration).
+  // B depends on the chunk only, not on the output tile: after a pair's last chunk comes chunk 0 again.
+  u32x4 Bh[2][NT], Bm[2][NT];
+  auto load_b = [&](int cc, u32x4 (&h)[NT], u32x4 (&m)[NT]) {
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
-      bh[nt] = *reinterpret_cast<const u32x4 TR_LDS*>(inl + nt * tile_off + 64 * c);
-      bm[nt] = *reinterpret_cast<const u32x4 TR_LDS*>(inl + nt * tile_off + 64 * c + mid_off);
+      h[nt] = *reinterpret_cast<const u32x4 TR_LDS*>(inl + nt * tile_off + 64 * cc);
+      m[nt] = *reinterpret_cast<const u32x4 TR_LDS*>(inl + nt * tile_off + 64 * cc + mid_off);
     }
+  };
+  load_b(0, Bh[0], Bm[0]);
+  auto body = [&](const u32x4& a0h, const u32x4& a0m, const u32x4& a1h, const u32x4& a1m, const u32x4 (&bh)[NT],
+                  const u32x4 (&bm)[NT], u32x4 (&nh)[NT], u32x4 (&nm)[NT]) {
+    load_b(c + 1 == kc32 ? 0 : c + 1, nh, nm);
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
       acc0[nt] = tr_mfma16(a0m, bh[nt], acc0[nt]);
@@ -382,13 +390,13 @@ __device__ __forceinline__ void tr_dense(gfrag A, gptr bias, int kc32, int frag_
   for (; t + TR_PD <= T; t += TR_PD) {
 #pragma unroll
     for (int j = 0; j < TR_PD; ++j) {
-      body(r0h[j], r0m[j], r1h[j], r1m[j]);
+      body(r0h[j], r0m[j], r1h[j], r1m[j], Bh[j & 1], Bm[j & 1], Bh[(j + 1) & 1], Bm[(j + 1) & 1]);
       issue(r0h[j], r0m[j], r1h[j], r1m[j]);
     }
   }
 #pragma unroll
   for (int j = 0; j < TR_PD - 1; ++j)
-    if (t + j < T) body(r0h[j], r0m[j], r1h[j], r1m[j]);
+    if (t + j < T) body(r0h[j], r0m[j], r1h[j], r1m[j], Bh[j & 1], Bm[j & 1], Bh[(j + 1) & 1], Bm[(j + 1) & 1]);
   stamps.mark(6);
   tr_lds_barrier();    // the layer's output (LDS) is complete for every wave
   stamps.mark(7);
