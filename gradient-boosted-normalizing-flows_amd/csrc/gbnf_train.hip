@@ -6,17 +6,23 @@
 // binds the DEVICE addresses of the caller's parameter tensors once and reads them in their natural nn.Linear
 // (out, in) row-major layout; an optimiser that updates in place needs no repacking at all.
 //
-//   train_kernel<KIND>   one wave = 16 samples of one component.  Activations are LDS-resident as
-//                        [unit][sample] (row stride 17): they are the B operand of v_mfma_f32_16x16x4_f32 read
-//                        straight from LDS, the weights are the A operand read from global/L2 (forward: W rows,
-//                        one 16-byte load per lane per 4 k-steps; backward: W^T, i.e. columns of W).
-//                        MODE 0: x -> z, ldj.   MODE 1: forward through all K steps keeping every step's
-//                        normalised state in LDS, then the steps in reverse: recompute the nets, coupling /
-//                        normalisation backward, net backward (dgrad chain in place of the activations), emit the
-//                        two operands of every weight gradient to a workspace, atomically accumulate the
-//                        ActNorm / BatchNorm parameter gradients.
+//   prep_kernel          at the start of every call: the LIVE f32 weights -> split-f16 MFMA A fragments (hi, mid), both
+//                        orientations (W forward, W^T backward), zero padded, plus zero-padded bias copies.
+//   train_kernel<KIND, MODE, NT>
+//                        one workgroup of 8 waves = NT 16-sample tiles of one component.  Activations that feed a
+//                        dense layer are LDS-resident as split rows [sample][hi | mid] (the B operand of
+//                        v_mfma_f32_16x16x32_f16 is one ds_read_b128); the waves split a layer's output tiles in
+//                        pairs and stream the fragments from L2 through a register ring (three MFMAs per product,
+//                        f32 accumulation).
+//                        MODE 0: x -> z, ldj (+ the trace of every step's normalised state).   MODE 1: the steps in
+//                        reverse: recompute the nets, coupling / normalisation backward, net backward (dgrad chain
+//                        in place of the activations), emit the two operands of every weight gradient to a
+//                        workspace, atomically accumulate the ActNorm / BatchNorm parameter gradients.
 //   wgrad_kernel         all weight/bias gradients of a component in ONE launch: dW = D . A^T contracted over
-//                        the samples on the matrix cores (split over sample chunks, atomic accumulation).
+//                        the samples on the f16 pipe (operands split in registers; split over sample chunks,
+//                        atomic accumulation).
+//   bn_stats_kernel, bn_bwd_fix_kernel, rows_to_slots_kernel, slots_to_rows_kernel
+//                        train-mode BatchNorm (batch statistics need the whole batch: one launch per step).
 //
 // Reference semantics differentiated (the forward is the one of gbnf_flow_kernel.hip.h):
 //   FlowStep.encode models/glow.py:317-342, _ActNorm.forward models/layers.py:488-533, TanhNet/ReLUNet
