@@ -384,11 +384,16 @@ def param_arrays(spec):
     return out
 
 
-def component_grads(spec, x, g_z, g_ldj, train=False):
+def component_grads(spec, x, g_z, g_ldj, train=False, relu_shift=0.0):
     """d(sum(z * g_z) + sum(ldj * g_ldj)) / d(x, parameters) in float64: the vector-Jacobian product a backward pass
     with upstream gradients (g_z, g_ldj) must return.  -> (g_x (N,d), [gradient per entry of param_arrays(spec)]).
-    ``train``: RealNVP BatchNorm on batch statistics (gradients flow through the statistics)."""
+    ``train``: RealNVP BatchNorm on batch statistics (gradients flow through the statistics).
+    ``relu_shift``: a ReLU passes a pre-activation only above this threshold instead of 0 -- with +-(f32 round-off of a
+    pre-activation) the two results bracket what any float32 implementation may return for pre-activations that close
+    to zero (tools/stress_train.py uses it to tell a kernel error from the kink of the ReLU)."""
     ops = _TorchGradOps()
+    if relu_shift != 0.0:
+        ops.relu = lambda a: torch.where(a > relu_shift, a, torch.zeros_like(a))
     xt = torch.tensor(np.asarray(x, dtype=np.float64), dtype=torch.float64, requires_grad=True)
     z, ld = xt, ops.zeros(xt.shape[0])
     for step in spec["steps"]:
