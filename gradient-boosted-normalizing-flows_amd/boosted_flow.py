@@ -476,10 +476,19 @@ class BoostedFlow(nn.Module):
         key = self._component_key(c)
         cached = self._handles.get(c)
         if cached is None or cached[0] != key:
-            handle = native.NativeFlow(gspec.spec_from_component(self.flows[c]))
+            handle = native.NativeFlow(gspec.spec_from_component(self.flows[c]),
+                                       per_step_activation=self._per_step_activation())
             self._handles[c] = (key, handle)
             self._mixture = None
         return self._handles[c][1]
+
+    def _per_step_activation(self):
+        """`--coupling_network random`: components (or the steps of one) differ in activation, so every handle is packed
+        for the kernel variants that read it per step and all of them still share one mixture launch."""
+        if getattr(self, "_per_step_act", None) is None:
+            pats = {gspec.activation_pattern_of_component(self.flows[c]) for c in range(self.num_components)}
+            self._per_step_act = len(pats) > 1 or any(len(set(p)) > 1 for p in pats)
+        return self._per_step_act
 
     def native_flow_exact(self, c):
         """The exact-f32 handle of component c: the inverse direction runs on that kernel only."""

@@ -369,8 +369,12 @@ static int validate_desc(const gbnf_flow_desc* desc, DescInfo* info) {
     }
     if (s == 0) {
       ref = a; act_a = a.act; act_b = b.act;
-    } else if (a.hidden != ref.hidden || a.depth != ref.depth || a.act != act_a || b.act != act_b) {
-      return fail(GBNF_ERR_UNSUPPORTED, "step %d: coupling-network width/depth/activation differs from step 0", s);
+    } else if (a.hidden != ref.hidden || a.depth != ref.depth) {
+      return fail(GBNF_ERR_UNSUPPORTED, "step %d: coupling-network width/depth differs from step 0", s);
+    } else if (a.act != act_a || b.act != act_b) {
+      // the reference's `--coupling_network random` draws tanh / relu per step (glow.py:295-296) or per net
+      // (realnvp.py:59-60): the kernels then pick the activation per step and net from the step header
+      act_a = act_b = GBNF_ACT_PER_STEP;
     }
     if (a.in_f > 4 * KS1MAX)
       return fail(GBNF_ERR_UNSUPPORTED, "coupling-net input width %d > %d", a.in_f, 4 * KS1MAX);
@@ -399,13 +403,19 @@ int gbnf_flow_validate(const gbnf_flow_desc* desc) {
 }
 
 int gbnf_flow_create_mode(const gbnf_flow_desc* desc, int32_t math_mode, gbnf_flow** out) {
+  return gbnf_flow_create_ex(desc, math_mode, 0, out);
+}
+
+int gbnf_flow_create_ex(const gbnf_flow_desc* desc, int32_t math_mode, int32_t flags, gbnf_flow** out) {
   if (out == nullptr) return fail(GBNF_ERR_INVALID, "gbnf_flow_create: out is null");
   *out = nullptr;
+  if (flags & ~GBNF_CREATE_PER_STEP_ACTIVATION) return fail(GBNF_ERR_INVALID, "gbnf_flow_create_ex: unknown flags 0x%x", flags);
   DescInfo info;
   {
     const int rc = validate_desc(desc, &info);
     if (rc) return rc;
   }
+  if (flags & GBNF_CREATE_PER_STEP_ACTIVATION) info.act_a = info.act_b = GBNF_ACT_PER_STEP;
   const int d = desc->d, K = desc->n_steps;
   const bool glow = desc->kind == GBNF_KIND_GLOW;
   const bool additive = glow && desc->coupling == GBNF_COUPLING_ADDITIVE;
@@ -556,6 +566,12 @@ int gbnf_flow_create_mode(const gbnf_flow_desc* desc, int32_t math_mode, gbnf_fl
     }
     put_i(sb + 0, ceil_div(in_f, 4));
     put_f(sb + 1, ld_const);
+    {   // activation of the step's net(s): 1 = relu (read by the per-step-activation kernel variants only)
+      const gbnf_net& na = glow ? desc->glow_steps[s].block : desc->realnvp_steps[s].t_net;
+      const gbnf_net& nb = glow ? desc->glow_steps[s].block : desc->realnvp_steps[s].s_net;
+      put_i(sb + 2, na.activation == GBNF_ACT_RELU ? 1 : 0);
+      put_i(sb + 3, nb.activation == GBNF_ACT_RELU ? 1 : 0);
+    }
     // in tables [g][e]: f32 kernel k = 4e + g (k-step e, lane group g); f16x3 kernel k = 8g + e
     for (int gg = 0; gg < 4; ++gg)
       for (int e = 0; e < NENT; ++e) {

@@ -133,12 +133,17 @@ __device__ __forceinline__ float tanh_act(float x) {
 #endif
 }
 
+// ACT: GBNF_ACT_TANH, GBNF_ACT_RELU, or 2 = chosen per step and net (`relu`, uniform): both are computed and one is
+// selected -- straight-line code, the interleaving with the MFMAs stays what it is
 template <int ACT>
-__device__ __forceinline__ float act_fn(float v) {
+__device__ __forceinline__ float act_fn(float v, bool relu) {
   if constexpr (ACT == GBNF_ACT_TANH) {
     return tanh_act(v);
-  } else {
+  } else if constexpr (ACT == GBNF_ACT_RELU) {
     return __builtin_fmaxf(v, 0.0f);
+  } else {
+    const float t = tanh_act(v), r = __builtin_fmaxf(v, 0.0f);
+    return relu ? r : t;
   }
 }
 
@@ -161,7 +166,7 @@ __device__ __forceinline__ f32x4 mfma4(float a, float b, f32x4 c) {
 // ---------------------------------------------------------------------------------
 template <int HT, int KSL, int KS1, int OT, int NT, int LMID, int ACT>
 __device__ __forceinline__ void coupling_net(const uint32_t* __restrict__ net, const float (&zb)[KS1][NT],
-                                             int lane, int g, f32x4 (&out)[OT][NT], Stamps& st) {
+                                             int lane, int g, f32x4 (&out)[OT][NT], Stamps& st, bool relu) {
   constexpr NetLayoutRT L(HT, KS1, OT, LMID);
   constexpr int KQ = L.KQ;
   const f32x4* w1 = reinterpret_cast<const f32x4*>(net + L.W1) + lane * KQ;   // + t*64*KQ
@@ -204,7 +209,7 @@ __device__ __forceinline__ void coupling_net(const uint32_t* __restrict__ net, c
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
-          for (int r = 0; r < 4; ++r) hA[t][nt][r] = act_fn<ACT>(hA[t][nt][r]);
+          for (int r = 0; r < 4; ++r) hA[t][nt][r] = act_fn<ACT>(hA[t][nt][r], relu);
       }
     }
     st.mark(1);
@@ -235,7 +240,7 @@ __device__ __forceinline__ void coupling_net(const uint32_t* __restrict__ net, c
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
-          for (int r = 0; r < 4; ++r) hA[t][nt][r] = act_fn<ACT>(hB[t][nt][r]);
+          for (int r = 0; r < 4; ++r) hA[t][nt][r] = act_fn<ACT>(hB[t][nt][r], relu);
     }
     st.mark(2);
 #pragma unroll
@@ -360,7 +365,7 @@ __device__ __forceinline__ void coupling_net(const uint32_t* __restrict__ net, c
         if (t >= R0 && t - R0 < NTR) {
 #pragma unroll
           for (int v = (t - R0) * VPT; v < (t - R0 + 1) * VPT && v < NV; ++v)
-            hb[v >> 2][v & 3] = act_fn<ACT>(pre[v >> 2][v & 3]);
+            hb[v >> 2][v & 3] = act_fn<ACT>(pre[v >> 2][v & 3], relu);
         }
         if (t == TG) out_chunk(w3 + u * OT * 64, 4);
         __builtin_amdgcn_sched_barrier(0);
@@ -388,7 +393,7 @@ __device__ __forceinline__ void coupling_net(const uint32_t* __restrict__ net, c
 #pragma unroll
       for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) hA[0][nt][r] = act_fn<ACT>(h0[nt][r]);
+        for (int r = 0; r < 4; ++r) hA[0][nt][r] = act_fn<ACT>(h0[nt][r], relu);
     }
     __builtin_amdgcn_sched_barrier(0);
     st.mark(1);
@@ -413,7 +418,7 @@ __device__ __forceinline__ void coupling_net(const uint32_t* __restrict__ net, c
 #pragma unroll
           for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) hA[t + 1][nt][r] = act_fn<ACT>(hraw[(t + 1) & 1][nt][r]);
+            for (int r = 0; r < 4; ++r) hA[t + 1][nt][r] = act_fn<ACT>(hraw[(t + 1) & 1][nt][r], relu);
         }
         __builtin_amdgcn_sched_barrier(0);
       }
@@ -433,7 +438,7 @@ __device__ __forceinline__ void coupling_net(const uint32_t* __restrict__ net, c
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) hb[nt][r] = act_fn<ACT>(pre[nt][r]);
+      for (int r = 0; r < 4; ++r) hb[nt][r] = act_fn<ACT>(pre[nt][r], relu);
     out_chunk(w3 + HT * OT * 64, KSL);
     st.mark(4);
   }
@@ -583,6 +588,9 @@ __global__ void __launch_bounds__(64) flow_kernel(const FlowLaunch p) {
     const uint32_t* __restrict__ sp = blob + (size_t)step * STEP_WORDS;
     LaneTable tin, tout;
     float step_ld;
+    // per-step activation variants only: 1 = relu, from the step header (uniform)
+    const bool relu_a = ACTA == 2 && __builtin_amdgcn_readfirstlane(sp[2]) != 0;
+    const bool relu_b = ACTB == 2 && __builtin_amdgcn_readfirstlane(sp[3]) != 0;
     if (lds_tables) {
       const uint32_t* sm = SM + step * SMALL_WORDS;
       step_ld = as_f32(sm[1]);
@@ -618,10 +626,10 @@ __global__ void __launch_bounds__(64) flow_kernel(const FlowLaunch p) {
     // ---- coupling network(s) on the matrix cores
     st.mark(0);
     f32x4 outA[OT][NT];
-    coupling_net<HT, KSL, KS1, OT, NT, LMID, ACTA>(sp + SMALL_WORDS, zb, lane, g, outA, st);
+    coupling_net<HT, KSL, KS1, OT, NT, LMID, ACTA>(sp + SMALL_WORDS, zb, lane, g, outA, st, relu_a);
     f32x4 outB[OT][NT];
     if constexpr (KIND == GBNF_KIND_REALNVP) {
-      coupling_net<HT, KSL, KS1, OT, NT, LMID, ACTB>(sp + SMALL_WORDS + L.NET_WORDS, zb, lane, g, outB, st);
+      coupling_net<HT, KSL, KS1, OT, NT, LMID, ACTB>(sp + SMALL_WORDS + L.NET_WORDS, zb, lane, g, outB, st, relu_b);
     }
 
     // The epilogue's first accumulator reads may sit directly behind a (direction) branch, 2-3 issue slots after the

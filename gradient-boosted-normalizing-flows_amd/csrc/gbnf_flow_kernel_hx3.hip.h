@@ -261,7 +261,15 @@ __global__ void __launch_bounds__(64 * HX3_WAVES, (NT == 1) ? 2 : 1) flow_kernel
       gf4 b1 = (gf4)nb + g;
       gf4 b2 = (gf4)(nb + HT * 16) + g;
       gf4 b3 = (gf4)(nb + 2 * HT * 16) + g;
-      auto act = [&](float v) { return ACT == GBNF_ACT_TANH ? act_hx3<GBNF_ACT_TANH>(v) : act_hx3<GBNF_ACT_RELU>(v); };
+      // ACT == 2: the activation of this step's net comes from the step header (`--coupling_network random`): both are
+      // computed and one is selected (the packer folded the tanh pre-scale into this net's layers only if it is a tanh net)
+      const bool relu_rt = ACT == 2 && __builtin_amdgcn_readfirstlane(sp[2 + net]) != 0;
+      auto act = [&](float v) {
+        if (ACT == GBNF_ACT_TANH) return act_hx3<GBNF_ACT_TANH>(v);
+        if (ACT == GBNF_ACT_RELU) return act_hx3<GBNF_ACT_RELU>(v);
+        const float t = act_hx3<GBNF_ACT_TANH>(v), r = act_hx3<GBNF_ACT_RELU>(v);
+        return relu_rt ? r : t;
+      };
       // activate + split one register pair (values 2hp, 2hp+1 of a raw accumulator tile)
       // (the empty asm pins the computation HERE: without it LLVM sinks the whole tanh + split into the later
       //  block that first consumes the operand, un-interleaving it from this region's MFMAs)

@@ -479,16 +479,17 @@ __global__ void __launch_bounds__(64 * TR_WAVES) train_kernel(const TrainLaunch 
     t[4] = (unsigned)L.bw; t[5] = (unsigned)(L.bw >> 32);
     t[6] = (unsigned)L.rows; t[7] = (unsigned)L.cols;
   }
-  // ... and the per-step scalars: in_f, out_f, has_norm, -, g_na, g_nb (two words each)
+  // ... and the per-step scalars: in_f, out_f, has_norm, activations, g_na, g_nb (two words each)
   const lup TSC = TL + K * 2 * TR_MAX_LAYERS * 8;
   for (int k = threadIdx.x; k < K; k += 64 * TR_WAVES) {
     const TrStep& st = p.steps[k];
     const lup t = TSC + k * 8;
-    t[0] = (unsigned)st.in_f; t[1] = (unsigned)st.out_f; t[2] = (unsigned)st.has_norm; t[3] = 0u;
+    t[0] = (unsigned)st.in_f; t[1] = (unsigned)st.out_f; t[2] = (unsigned)st.has_norm;
+    t[3] = (unsigned)st.net[0].act | ((unsigned)st.net[KIND == GBNF_KIND_GLOW ? 0 : 1].act << 8);   // per step and net
     t[4] = (unsigned)st.g_na; t[5] = (unsigned)((unsigned long long)st.g_na >> 32);
     t[6] = (unsigned)st.g_nb; t[7] = (unsigned)((unsigned long long)st.g_nb >> 32);
   }
-  struct StepD { int in_f, out_f, has_norm; long long g_na, g_nb; };
+  struct StepD { int in_f, out_f, has_norm, act[2]; long long g_na, g_nb; };
   auto step_desc = [&](int k) -> StepD {                 // from the LDS table, moved to scalar registers
     const lup t = TSC + k * 8;
     unsigned w[8];
@@ -496,6 +497,7 @@ __global__ void __launch_bounds__(64 * TR_WAVES) train_kernel(const TrainLaunch 
     for (int e = 0; e < 8; ++e) w[e] = __builtin_amdgcn_readfirstlane(t[e]);
     StepD D;
     D.in_f = (int)w[0]; D.out_f = (int)w[1]; D.has_norm = (int)w[2];
+    D.act[0] = (int)(w[3] & 255u); D.act[1] = (int)(w[3] >> 8);
     D.g_na = (long long)(((unsigned long long)w[5] << 32) | w[4]);
     D.g_nb = (long long)(((unsigned long long)w[7] << 32) | w[6]);
     return D;
@@ -548,12 +550,10 @@ __global__ void __launch_bounds__(64 * TR_WAVES) train_kernel(const TrainLaunch 
     return D;
   };
   const int nl = tr_uniform(p.steps[0].net[0].n_layers);
-  const int act_a = tr_uniform(p.steps[0].net[0].act), act_b = tr_uniform(p.steps[0].net[KIND == GBNF_KIND_GLOW ? 0 : 1].act);
 
   // ---- coupling net forward from XS: hidden layers into HS (+ emit f32), last layer into `out` (f32; or skipped)
-  auto net_forward = [&](int k, int q, lfp out, float* ws_net) {
+  auto net_forward = [&](int k, int q, int act, lfp out, float* ws_net) {
     TrSplit in = XS;
-    const int act = q == 0 ? act_a : act_b;
     for (int l = 0; l + 1 < nl; ++l) {
       const TrSplit Hl = HS(l);
       const bool emit = (MODE == 1) && ws_net != nullptr;    // backward sweep only: activation-side operand of dW
@@ -583,9 +583,8 @@ __global__ void __launch_bounds__(64 * TR_WAVES) train_kernel(const TrainLaunch 
   };
 
   // ---- coupling net backward: cur = gradient w.r.t. the net output (LDS f32, [op]); leaves d(loss)/d(net input) in GX
-  auto net_backward = [&](int k, int q, lcfp cur, float* ws_net, bool accumulate) {
+  auto net_backward = [&](int k, int q, int act, lcfp cur, float* ws_net, bool accumulate) {
     const int nh = p.n_hidden;
-    const int act = q == 0 ? act_a : act_b;
     // gradient-side operand of the last layer's weight gradient (f32 to the workspace) + its split copy for the dense chain
     {
       float* ws_d = ws_net + ((size_t)p.ip + 2 * (size_t)nh * p.hp) * p.np + (size_t)tile0 * p.op * 16 + i;
@@ -660,7 +659,7 @@ __global__ void __launch_bounds__(64 * TR_WAVES) train_kernel(const TrainLaunch 
     tr_lds_barrier();
     stamps.mark(1);
     if constexpr (KIND == GBNF_KIND_GLOW) {
-      net_forward(k, 0, O, nullptr);
+      net_forward(k, 0, st.act[0], O, nullptr);
       stamps.mark(-1);
       for (int j = g; j < st.out_f; j += GS) {
         const int slot = ti[32 + j];
@@ -678,8 +677,8 @@ __global__ void __launch_bounds__(64 * TR_WAVES) train_kernel(const TrainLaunch 
         }
       }
     } else {
-      net_forward(k, 0, O2, nullptr);
-      net_forward(k, 1, O, nullptr);
+      net_forward(k, 0, st.act[0], O2, nullptr);
+      net_forward(k, 1, st.act[1], O, nullptr);
       for (int j = g; j < st.out_f; j += GS) {
         const int slot = ti[32 + j];
         TR_NT {
@@ -784,7 +783,7 @@ __global__ void __launch_bounds__(64 * TR_WAVES) train_kernel(const TrainLaunch 
       }
       tr_lds_barrier();
       if constexpr (KIND == GBNF_KIND_GLOW) {
-        net_forward(k, 0, O, ws_step);
+        net_forward(k, 0, st.act[0], O, ws_step);
         for (int j = g; j < st.out_f; j += GS) {
           const int slot = ti[32 + j];
           float ga = 0.0f, gb = 0.0f;
@@ -809,11 +808,11 @@ __global__ void __launch_bounds__(64 * TR_WAVES) train_kernel(const TrainLaunch 
           norm_commit(st, k, slot, ga, gb);
         }
         tr_lds_barrier();
-        net_backward(k, 0, O, ws_step, false);
+        net_backward(k, 0, st.act[0], O, ws_step, false);
       } else {
         float* ws_t = ws_step;
         float* ws_s = ws_step + (size_t)p.net_rows * p.np;
-        net_forward(k, 1, O, ws_s);                                 // log-scale net
+        net_forward(k, 1, st.act[1], O, ws_s);                                 // log-scale net
         for (int u = g; u < p.op; u += GS) TR_NT O2[u * S + i + 16 * nt] = 0.0f;
         tr_lds_barrier();
         for (int j = g; j < st.out_f; j += GS) {
@@ -830,9 +829,9 @@ __global__ void __launch_bounds__(64 * TR_WAVES) train_kernel(const TrainLaunch 
           norm_commit(st, k, slot, ga, gb);
         }
         tr_lds_barrier();
-        net_backward(k, 1, O, ws_s, false);
-        net_forward(k, 0, nullptr, ws_t);                           // shift net: only its activations are needed
-        net_backward(k, 0, O2, ws_t, true);
+        net_backward(k, 1, st.act[1], O, ws_s, false);
+        net_forward(k, 0, st.act[0], nullptr, ws_t);                           // shift net: only its activations are needed
+        net_backward(k, 0, st.act[0], O2, ws_t, true);
       }
       for (int kk = g; kk < st.in_f; kk += GS) {
         const int slot = ti[kk];

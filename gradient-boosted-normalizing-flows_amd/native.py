@@ -23,7 +23,7 @@ MATH = {"default": -1, "f32": 0, "f16x3": 1}
 # every symbol include/gbnf.h declares (tests check the library exports exactly these)
 ABI_SYMBOLS = (
     "gbnf_version", "gbnf_last_error",
-    "gbnf_flow_create", "gbnf_flow_create_mode", "gbnf_flow_destroy", "gbnf_flow_info", "gbnf_flow_forward",
+    "gbnf_flow_create", "gbnf_flow_create_mode", "gbnf_flow_create_ex", "gbnf_flow_destroy", "gbnf_flow_info", "gbnf_flow_forward",
     "gbnf_flow_inverse",
     "gbnf_mixture_create", "gbnf_mixture_destroy", "gbnf_mixture_set_base",
     "gbnf_mixture_component_log_prob", "gbnf_mixture_component_log_prob_strided",
@@ -116,6 +116,7 @@ def lib():
     L.gbnf_last_error.restype = C.c_char_p
     L.gbnf_flow_create.argtypes = [C.POINTER(_FlowDesc), C.POINTER(vp)]
     L.gbnf_flow_create_mode.argtypes = [C.POINTER(_FlowDesc), i32, C.POINTER(vp)]
+    L.gbnf_flow_create_ex.argtypes = [C.POINTER(_FlowDesc), i32, i32, C.POINTER(vp)]
     L.gbnf_flow_destroy.argtypes = [vp]
     L.gbnf_flow_info.argtypes = [vp, C.POINTER(KernelInfo)]
     L.gbnf_flow_forward.argtypes = [vp, vp, i64, vp, vp, vp, vp]
@@ -240,10 +241,13 @@ def _stream_ptr():
 class NativeFlow:
     """One packed component on the device (gbnf_flow)."""
 
-    def __init__(self, spec, math="default"):
+    def __init__(self, spec, math="default", per_step_activation=False):
+        """``per_step_activation``: pack for the kernel variants that read the activation per step although this
+        component uses one activation throughout (GBNF_CREATE_PER_STEP_ACTIVATION): lets it share a NativeMixture with
+        components that do not (`--coupling_network random`); see ``flows_for_mixture``."""
         desc, keep = flow_desc_from_spec(spec)
         h = C.c_void_p()
-        _check(lib().gbnf_flow_create_mode(C.byref(desc), MATH[math], C.byref(h)))
+        _check(lib().gbnf_flow_create_ex(C.byref(desc), MATH[math], 1 if per_step_activation else 0, C.byref(h)))
         del keep
         self.handle = h
         self.d = int(spec["d"])
@@ -559,6 +563,26 @@ class NativeTrainer:
             self.close()
         except Exception:
             pass
+
+
+def activation_pattern(spec):
+    """The activations of a component's coupling nets, step by step (a hashable)."""
+    if spec["kind"] == "glow":
+        return tuple(st["net"]["act"] for st in spec["steps"])
+    return tuple((st["t_net"]["act"], st["s_net"]["act"]) for st in spec["steps"])
+
+
+def needs_per_step_activation(specs):
+    """True when the components cannot share one uniform-activation kernel: some component mixes activations, or two
+    components use different ones (the reference's `--coupling_network random`, models/glow.py:295-296)."""
+    pats = {activation_pattern(s) for s in specs}
+    return len(pats) > 1 or any(len(set(p)) > 1 for p in pats)
+
+
+def flows_for_mixture(specs, math="default"):
+    """NativeFlow handles of `specs` that are guaranteed to fit one NativeMixture."""
+    per_step = needs_per_step_activation(specs)
+    return [NativeFlow(s, math=math, per_step_activation=per_step) for s in specs]
 
 
 class NativeMixture:

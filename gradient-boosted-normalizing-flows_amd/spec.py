@@ -112,6 +112,22 @@ def spec_from_component(module):
     raise TypeError(f"not a boosted-flow component: {type(module).__name__}")
 
 
+def activation_pattern_of_component(module):
+    """The activations of a component's coupling nets, step by step, read from the module STRUCTURE only (no parameter
+    is touched: usable before ActNorm's data-dependent initialisation).  Same value as
+    ``native.activation_pattern(spec_from_component(module))``."""
+    def act_of(seq_owner):
+        acts = {type(m).__name__.lower() for m in seq_owner.network if type(m).__name__ in ("Tanh", "ReLU")}
+        if len(acts) > 1:
+            _mixed_act_error()
+        return acts.pop() if acts else "tanh"
+    if hasattr(module, "flow_param"):
+        return tuple((act_of(mods[0]), act_of(mods[1])) for mods in module.flow_param)
+    if hasattr(module, "flow"):
+        return tuple(act_of(layer.block) for layer in module.flow.layers)
+    raise TypeError(f"not a boosted-flow component: {type(module).__name__}")
+
+
 # ------------------------------------------------------------------ live (device) view for the training path
 def _dev_net(seq_owner):
     layers, act = [], None

@@ -34,8 +34,10 @@ def _net(rng, in_f, out_f, h, depth, act, gain):
 
 def synth_glow_spec(d, h, K, depth=1, act="tanh", coupling="affine", permutation="shuffle",
                     seed=0, gain=1.0):
-    """One tabular Glow component (models/glow.py FlowStep x K) with synthetic parameters."""
+    """One tabular Glow component (models/glow.py FlowStep x K) with synthetic parameters.
+    ``act``: "tanh" | "relu" | "random" (each step draws one of the two, models/glow.py:295-296)."""
     rng = np.random.RandomState(seed)
+    act_rng = np.random.RandomState(seed + 7919)
     d1 = d // 2
     d2 = d - d1
     steps = []
@@ -48,7 +50,7 @@ def synth_glow_spec(d, h, K, depth=1, act="tanh", coupling="affine", permutation
             "an_bias": (0.1 * rng.standard_normal(d)).astype(np.float32),
             "an_logs": (0.1 * rng.standard_normal(d)).astype(np.float32),
             "perm": perm.astype(np.int64),
-            "net": _net(rng, d1, out_f, h, depth, act, gain),
+            "net": _net(rng, d1, out_f, h, depth, ["tanh", "relu"][act_rng.randint(2)] if act == "random" else act, gain),
         })
     return {"kind": "glow", "d": int(d), "coupling": coupling, "steps": steps}
 
@@ -57,10 +59,12 @@ def synth_realnvp_spec(d, h, K, depth=1, coupling_network="tanh", batch_norm=Tru
                        seed=0, gain=1.0):
     """One RealNVPFlow component (models/realnvp.py:34-78) with synthetic parameters.
 
-    ``coupling_network``: "tanh" | "relu" | "mixed" (t_net ReLU, s_net Tanh, realnvp.py:47-51).
+    ``coupling_network``: "tanh" | "relu" | "mixed" (t_net ReLU, s_net Tanh, realnvp.py:47-51) | "random" (every net
+    of every step draws one of the two, realnvp.py:59-60).
     BatchNorm is present on every step but the last when ``batch_norm`` (realnvp.py:71-74).
     """
     rng = np.random.RandomState(seed)
+    act_rng = np.random.RandomState(seed + 7919)
     steps = []
     for k in range(K):
         flipped = ((k + flip_init) % 2) > 0
@@ -70,6 +74,8 @@ def synth_realnvp_spec(d, h, K, depth=1, coupling_network="tanh", batch_norm=Tru
             in_f, out_f = d // 2, d - d // 2
         if coupling_network == "mixed":
             t_act, s_act = "relu", "tanh"
+        elif coupling_network == "random":
+            t_act, s_act = (["tanh", "relu"][act_rng.randint(2)] for _ in range(2))
         else:
             t_act = s_act = coupling_network
         t_net = _net(rng, in_f, out_f, h, depth, t_act, gain)

@@ -123,6 +123,13 @@ const char* gbnf_last_error(void);
 int gbnf_flow_create(const gbnf_flow_desc* desc, gbnf_flow** out);
 /* Same with an explicit GBNF_MATH_* mode (gbnf_flow_create uses GBNF_MATH_DEFAULT, or env GBNF_MATH=f32|f16x3). */
 int gbnf_flow_create_mode(const gbnf_flow_desc* desc, int32_t math_mode, gbnf_flow** out);
+/* ... and creation flags.  A component whose coupling nets do not all use the same activation (the reference's
+ * `--coupling_network random` draws TanhNet / ReLUNet per step, models/glow.py:295-296, or per net,
+ * models/realnvp.py:59-60) runs on kernel variants that read the activation per step from the packed blob; that choice
+ * is automatic.  GBNF_CREATE_PER_STEP_ACTIVATION asks for those variants although this component is uniform, so that it
+ * can share a mixture (one launch, gbnf_mixture_create wants one kernel for all components) with components that are not. */
+enum { GBNF_CREATE_PER_STEP_ACTIVATION = 1 };
+int gbnf_flow_create_ex(const gbnf_flow_desc* desc, int32_t math_mode, int32_t flags, gbnf_flow** out);
 int gbnf_flow_destroy(gbnf_flow* flow);
 int gbnf_flow_info(const gbnf_flow* flow, gbnf_kernel_info* info);
 

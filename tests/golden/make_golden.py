@@ -203,6 +203,40 @@ def native_glow_case(name, d=43, h=32, K=5, C=3, N=256):
     print(f"{name}: ll[0,:3]={ll[0, :3]}  G[:3]={G[:3]}")
 
 
+def native_random_case(name, kind, d, h, K, C, N=96):
+    """G13: `--coupling_network random` -- the reference draws TanhNet / ReLUNet per step (Glow, glow.py:295-296) or per
+    net (RealNVP, realnvp.py:59-60) from numpy's global RNG; it initialises itself, the parameters are perturbed."""
+    torch.manual_seed(13)
+    np.random.seed(13)
+    model = RefBoostedFlow(ref_args(kind, d, h, K, C, coupling_network="random"))
+    x = synth.synth_batch(N, d, seed=13)
+    model.train()
+    with torch.no_grad():
+        if kind == "glow":
+            for c in range(C):   # ActNorm data-dependent init, density_experiment.py:346-356
+                model(x=torch.from_numpy(x).clone(), components=c)
+        for p in model.parameters():
+            p.add_(0.05 * torch.randn_like(p))
+        for b_name, b in model.named_buffers():
+            if b_name.endswith("running_var"):
+                b.mul_(1.0 + 0.3 * torch.rand_like(b))
+            elif b_name.endswith("running_mean"):
+                b.add_(0.1 * torch.randn_like(b))
+    model.eval()
+    specs = [gspec.spec_from_component(model.flows[c]) for c in range(C)]
+    acts = [[(st["net"]["act"],) if kind == "glow" else (st["t_net"]["act"], st["s_net"]["act"]) for st in sp["steps"]]
+            for sp in specs]
+    assert any(len({a for st in comp for a in st}) == 2 for comp in acts), "the draw gave no mixed component: change the seed"
+    z, ldj, ll, G = run_reference(model, x, C)
+    cfg = dict(case="native", kind=kind, d=d, h=h, K=K, C=C, N=N, x_seed=13, activations=acts)
+    out = dict(config=np.frombuffer(json.dumps(cfg).encode(), dtype=np.uint8),
+               rho=model.rho.numpy().copy(), x=x, z=z, ldj=ldj, ll=ll, G=G)
+    for c in range(C):
+        out.update(gspec.flatten_spec(specs[c], prefix=f"c{c}."))
+    np.savez_compressed(os.path.join(HERE, name + ".npz"), **out)
+    print(f"{name}: activations {acts}  ll[0,:3]={ll[0, :3]}  G[:3]={G[:3]}")
+
+
 def toy_case(name, N=64):
     """G1: 8-Gaussians-shaped toy config: d=2 RealNVP C=2 K=1 h=64, uniform rho,
     base density = model.base_dist = Normal(base_dist_mean, 3.0) (toy_experiment.py:413-429)."""
@@ -549,6 +583,10 @@ def main():
         grads_case("g10_glow_grads_additive_relu_d8", "glow", 8, 40, 3, 50, coupling="additive", act="relu")
         grads_case("g10_realnvp_grads_d21_h32", "realnvp", 21, 32, 4, 80)
         return
+    if "--random-only" in sys.argv:
+        native_random_case("g13_glow_random_d43_h64", "glow", 43, 64, 6, 2)
+        native_random_case("g13_realnvp_random_d21_h32", "realnvp", 21, 32, 5, 2)
+        return
     if "--decode-only" in sys.argv:
         decode_case("g9_glow_additive_decode")
         return
@@ -575,6 +613,8 @@ def main():
     grads_train_bn_case("g10_realnvp_grads_train_bn_d21_h32")
     toy_case("g1_toy_realnvp_c2")
     native_glow_case("g2_glow_native_d43_h32_c3")
+    native_random_case("g13_glow_random_d43_h64", "glow", 43, 64, 6, 2)
+    native_random_case("g13_realnvp_random_d21_h32", "realnvp", 21, 32, 5, 2)
     # G3: MINIBOONE full width (BASELINE.json metric config), synthetic weights
     synth_case("g3_glow_d43_h215_c8", "glow", 43, 215, 5, 8, 256)
     # G4: HEPMASS RealNVP, flip_init 0..7, BN with non-trivial running stats

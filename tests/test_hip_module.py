@@ -22,13 +22,15 @@ def _args(cfg, dev):
         y_condition=False, sample_size=4, input_size=[cfg["d"]], h_size=cfg["h"], num_blocks=1,
         actnorm_scale=1.0, flow_permutation=skw.get("permutation", "shuffle"),
         flow_coupling=skw.get("coupling", "affine"), LU_decomposed=False, num_dequant_blocks=0,
-        coupling_network=skw.get("act", skw.get("coupling_network", "tanh")),
+        coupling_network="random" if "activations" in cfg else skw.get("act", skw.get("coupling_network", "tanh")),
         coupling_network_depth=skw.get("depth", 1), batch_norm=skw.get("batch_norm", True))
 
 
 def _model_from_case(g, dev):
     import torch
     from gbnf_amd import BoostedFlow
+    if "activations" in g.cfg:     # `--coupling_network random`: the constructor draws from numpy's global RNG like the
+        np.random.seed(13)         # reference does (tests/golden/make_golden.py native_random_case seeds it with 13)
     m = BoostedFlow(_args(g.cfg, dev))
     for c, spec in enumerate(g.specs):
         m.load_spec(c, spec)
@@ -56,7 +58,8 @@ def _evaluate_like_reference(model, x):
 
 
 @pytest.mark.parametrize("name", ["g2_glow_native_d43_h32_c3", "g4_realnvp_d21_h105_c8",
-                                  "g5_glow_d43_h64_c2_additive", "g4_realnvp_d21_h105_c2_mixed"])
+                                  "g5_glow_d43_h64_c2_additive", "g4_realnvp_d21_h105_c2_mixed",
+                                  "g13_glow_random_d43_h64", "g13_realnvp_random_d21_h32"])
 def test_module_dropin_matches_reference(name, golden_case):
     import torch
     dev = torch.device("cuda:0")

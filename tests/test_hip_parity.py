@@ -22,7 +22,7 @@ def dev():
 
 def _mixture(specs, math="default"):
     from gbnf_amd import native
-    flows = [native.NativeFlow(s, math=math) for s in specs]
+    flows = native.flows_for_mixture(specs, math=math)    # (per-step activation kernels when the components need them)
     return native.NativeMixture(flows), flows
 
 
@@ -133,6 +133,38 @@ def test_wide_hidden_layers(kind, d, h, act, dev):
         G, ll = mix.log_prob(torch.from_numpy(xs).to(dev), torch.from_numpy(rho).to(dev))
         assert rel_err(ll.cpu().numpy(), ll_ref) < LL_RTOL
         assert rel_err(G.cpu().numpy(), G_ref) < LL_RTOL
+
+
+@pytest.mark.parametrize("math", ["f32", "f16x3"])
+@pytest.mark.parametrize("kind,d,h,K", [("glow", 43, 64, 7), ("glow", 21, 300, 6), ("realnvp", 21, 105, 6), ("realnvp", 6, 30, 8)])
+def test_activation_drawn_per_step(kind, d, h, K, math, dev):
+    """`--coupling_network random` (models/glow.py:295-296, models/realnvp.py:59-60): tanh / relu per step (Glow) or per
+    net (RealNVP), different per component -- the per-step-activation kernel variants, forward and inverse."""
+    import torch
+    from gbnf_amd import native, synth
+    from oracle import gbnf_oracle as oracle
+    if math == "f32" and h > 256:
+        pytest.skip("hidden widths above 256 run on the split-f16 kernel only")
+    kw = {"act": "random"} if kind == "glow" else {"coupling_network": "random"}
+    specs = synth.synth_boosted_specs(kind, 3, d, h, K, seed=21, **kw)
+    assert native.needs_per_step_activation(specs)
+    assert any(len(set(native.activation_pattern(s))) > 1 for s in specs)
+    mix, flows = _mixture(specs, math)
+    rho = oracle.rho_init(3)
+    for n in (77, 2048):
+        xs = synth.synth_batch(n, d, seed=n)
+        ll_ref, G_ref = oracle.mixture_log_prob(specs, rho, xs)
+        G, ll = mix.log_prob(torch.from_numpy(xs).to(dev), torch.from_numpy(rho).to(dev))
+        assert rel_err(ll.cpu().numpy(), ll_ref) < LL_RTOL
+        assert rel_err(G.cpu().numpy(), G_ref) < LL_RTOL
+    if math == "f32":            # the inverse direction runs on the exact-f32 kernel
+        x = synth.synth_batch(200, d, seed=3)
+        xd = torch.from_numpy(x).to(dev)
+        z, _, _ = flows[1].forward(xd)
+        xr, _ = flows[1].inverse(z)
+        assert np.abs(xr.cpu().numpy() - x).max() < 5e-4
+    # a uniform component created on its own keeps its uniform kernel; with the flag it joins the others
+    assert native.NativeFlow(specs[0], math=math, per_step_activation=True).info().math_mode == flows[0].info().math_mode
 
 
 def test_full_size_against_oracle(dev):

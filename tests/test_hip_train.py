@@ -283,6 +283,9 @@ def _random_train_cases():
     cases.append(("glow", 43, 430, 2, 77, dict(act="relu", coupling="affine", permutation="shuffle", depth=1), 951))
     cases.append(("realnvp", 21, 512, 2, 65, dict(coupling_network="tanh", batch_norm=True, flip_init=1, depth=1), 952))
     cases.append(("glow", 8, 300, 1, 33, dict(act="tanh", coupling="additive", permutation="reverse", depth=2), 953))
+    # `--coupling_network random`: the activation changes from step to step (Glow) / net to net (RealNVP)
+    cases.append(("glow", 21, 64, 6, 100, dict(act="random", coupling="affine", permutation="shuffle", depth=1), 954))
+    cases.append(("realnvp", 13, 33, 6, 65, dict(coupling_network="random", batch_norm=True, flip_init=0, depth=1), 955))
     return cases
 
 

@@ -44,6 +44,28 @@ def test_state_dict_layout_matches_reference(case, kw):
         assert n.startswith("flows.") and n.split(".")[1].isdigit()
 
 
+@pytest.mark.parametrize("name,kind,d,h,K", [("g13_glow_random_d43_h64", "glow", 43, 64, 6),
+                                              ("g13_realnvp_random_d21_h32", "realnvp", 21, 32, 5)])
+def test_random_coupling_network_draws_like_the_reference(name, kind, d, h, K):
+    """`--coupling_network random`: the constructor draws TanhNet / ReLUNet from numpy's global RNG in the reference's
+    order (per step for Glow, models/glow.py:295-296; per net for RealNVP, models/realnvp.py:59-60), so the same seed
+    builds the same architecture -- the fixture records what the reference drew with seed 13."""
+    g = np.load(os.path.join(GOLDEN_DIR, name + ".npz"))
+    cfg = json.loads(bytes(g["config"]).decode())
+    np.random.seed(13)
+    m = BoostedFlow(make_args(kind=kind, d=d, h=h, K=K, C=2, coupling_network="random"))
+    got = [gspec.activation_pattern_of_component(m.flows[c]) for c in range(2)]
+    want = [tuple(tuple(st) if kind == "realnvp" else st[0] for st in comp) for comp in cfg["activations"]]
+    assert got == want
+    assert any(len(set(p)) > 1 for p in got)                  # a mixed component exists
+    assert m._per_step_activation()                            # -> the per-step-activation kernel variants
+    specs = [gspec.unflatten_spec(g, prefix=f"c{c}.") for c in range(2)]
+    assert [native.activation_pattern(sp) for sp in specs] == got
+    assert native.needs_per_step_activation(specs)
+    if kind == "glow":        # its first component happened to draw tanh six times: uniform on its own
+        assert not native.needs_per_step_activation(specs[:1] * 2)
+
+
 def test_rho_init_and_increment():
     m = BoostedFlow(make_args(C=8))
     np.testing.assert_array_equal(m.rho.numpy(), np.array([1, .5, .25, .125, .0625, .05, .05, .05], np.float32))

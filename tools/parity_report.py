@@ -13,7 +13,7 @@ for name in golden_names():
     g = GoldenCase(name)
     for mode in ("f32", "f16x3"):
         try:
-            flows = [native.NativeFlow(s, math=mode) for s in g.specs]
+            flows = native.flows_for_mixture(g.specs, math=mode)
         except native.GbnfError as e:
             print(f"{name:38s} {mode:7s} n/a ({str(e)[:60]})")
             continue
