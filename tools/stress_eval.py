@@ -20,14 +20,14 @@ for k in range(cases):
     C = int(rng.randint(1, 5))
     n = int(rng.choice([1, 17, 33, 100, 333, 1000, 4096, 5000]))
     if kind == "glow":
-        kw = dict(act=str(rng.choice(["tanh", "relu"])), coupling=str(rng.choice(["affine", "additive"])),
+        kw = dict(act=str(rng.choice(["tanh", "relu", "random"])), coupling=str(rng.choice(["affine", "additive"])),
                   permutation=str(rng.choice(["shuffle", "reverse"])))
     else:
-        kw = dict(coupling_network=str(rng.choice(["tanh", "relu", "mixed"])), batch_norm=bool(rng.randint(2)))
+        kw = dict(coupling_network=str(rng.choice(["tanh", "relu", "mixed", "random"])), batch_norm=bool(rng.randint(2)))
     tag = f"{kind} C={C} d={d} h={h} K={K} n={n} {kw}"
     specs = synth.synth_boosted_specs(kind, C, d, h, K, seed=300 + k, **kw)
     try:
-        mix = native.NativeMixture([native.NativeFlow(sp) for sp in specs])
+        mix = native.NativeMixture(native.flows_for_mixture(specs))
     except native.GbnfError as e:
         print("skip (unsupported):", tag, "|", str(e)[:90]); continue
     x = synth.synth_batch(n, d, seed=k)

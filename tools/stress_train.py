@@ -26,11 +26,11 @@ for k in range(cases):
     n = int(rng.choice([1, 2, 15, 16, 17, 31, 32, 33, 100, 257, 1000, 1537, 2049, 3000]))
     depth = int(rng.choice([0, 1, 1, 1, 2]))
     if kind == "glow":
-        extra = dict(act=str(rng.choice(["tanh", "relu"])), coupling=str(rng.choice(["affine", "additive"])),
+        extra = dict(act=str(rng.choice(["tanh", "relu", "random"])), coupling=str(rng.choice(["affine", "additive"])),
                      permutation=str(rng.choice(["shuffle", "reverse"])), depth=depth)
         spec = synth.synth_glow_spec(d, h, K, seed=5000 + k, **extra)
     else:
-        extra = dict(coupling_network=str(rng.choice(["tanh", "relu", "mixed"])), batch_norm=bool(rng.randint(2)),
+        extra = dict(coupling_network=str(rng.choice(["tanh", "relu", "mixed", "random"])), batch_norm=bool(rng.randint(2)),
                      flip_init=int(rng.randint(2)), depth=depth)
         spec = synth.synth_realnvp_spec(d, h, K, seed=5000 + k, **extra)
     tag = f"{kind} d={d} h={h} K={K} n={n} {extra}"
