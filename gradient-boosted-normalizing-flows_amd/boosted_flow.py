@@ -60,15 +60,47 @@ class ReLUNet(_CouplingNet):
         super().__init__(in_dim, out_dim, hidden_dim, num_layers, "relu")
 
 
-def _coupling_cls(name):
+class ResidualBlock(nn.Module):
+    """Parameter layout (and initialisation order) of models/layers.py:246-273: two Linear(h, h), the second one
+    re-initialised uniformly in +-1e-3."""
+
+    def __init__(self, hidden_dim):
+        super().__init__()
+        self.activation = nn.ReLU()
+        self.linear_layers = nn.ModuleList([nn.Linear(hidden_dim, hidden_dim) for _ in range(2)])
+        nn.init.uniform_(self.linear_layers[-1].weight, -1e-3, 1e-3)
+        nn.init.uniform_(self.linear_layers[-1].bias, -1e-3, 1e-3)
+
+
+class ResidualNet(nn.Module):
+    """ResidualNet parameter layout (models/layers.py:276-301): ``initial_layer``, ``blocks`` (num_layers of them),
+    ``final_layer``.  Evaluation only; RealNVP only (the reference's glow.py never imports it)."""
+
+    def __init__(self, in_dim, out_dim, hidden_dim, num_layers=2):
+        super().__init__()
+        self.hidden_dim = hidden_dim
+        self.initial_layer = nn.Linear(in_dim, hidden_dim)
+        self.blocks = nn.ModuleList([ResidualBlock(hidden_dim) for _ in range(num_layers)])
+        self.final_layer = nn.Linear(hidden_dim, out_dim)
+
+    def forward(self, *a, **k):
+        raise RuntimeError("coupling networks are evaluated by the fused HIP kernel, not module by module")
+
+
+def _coupling_cls(name, realnvp=False):
+    if name == "residual" and realnvp:
+        return ResidualNet
     if name == "tanh":
         return TanhNet
     if name == "relu":
         return ReLUNet
     if name == "random":   # models/glow.py:295-296 draws from numpy's global RNG
         return [TanhNet, ReLUNet][np.random.randint(2)]
+    if name == "residual":
+        raise NotImplementedError("coupling_network='residual' with Glow: the reference's glow.py does not import "
+                                  "ResidualNet (NameError there); it is available for component_type='realnvp'")
     raise NotImplementedError(
-        f"coupling_network={name!r}: only tanh / relu (and mixed for RealNVP) are on the supported path")
+        f"coupling_network={name!r}: tanh / relu / random (and mixed / residual for RealNVP) are on the supported path")
 
 
 class ActNorm1d(nn.Module):
@@ -214,7 +246,8 @@ class RealNVPFlow(nn.Module):
                 nets = [ReLUNet(in_dim, out_dim, args.h_size, args.coupling_network_depth),
                         TanhNet(in_dim, out_dim, args.h_size, args.coupling_network_depth)]
             else:
-                nets = [_coupling_cls(args.coupling_network)(in_dim, out_dim, args.h_size, args.coupling_network_depth)
+                nets = [_coupling_cls(args.coupling_network, realnvp=True)(in_dim, out_dim, args.h_size,
+                                                                           args.coupling_network_depth)
                         for _ in range(2)]
             bn = BatchNorm(self.z_size) if (args.batch_norm and k < self.num_flows - 1) else None
             self.flow_param.append(nn.ModuleList(nets + [bn]))
@@ -617,7 +650,7 @@ class BoostedFlow(nn.Module):
                 dst.copy_(torch.as_tensor(np.asarray(src)).reshape(dst.shape).to(dev))
 
         def load_net(holder, net):
-            linears = [m for m in holder.network if isinstance(m, nn.Linear)]
+            linears = gspec.linears_of(holder)
             if len(linears) != len(net["layers"]):
                 raise ValueError("coupling network depth mismatch")
             for m, (w, b) in zip(linears, net["layers"]):

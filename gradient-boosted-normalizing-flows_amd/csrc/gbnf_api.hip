@@ -52,7 +52,7 @@ void register_variant(const VariantKey& key, LaunchFn fn, const char* name) {
 
 // ------------------------------------------------------------------ handles
 struct NetDims {
-  int in_f = 0, hidden = 0, out_f = 0, depth = 0, act = 0;
+  int in_f = 0, hidden = 0, out_f = 0, depth = 0, act = 0, residual = 0;
 };
 
 }  // namespace gbnf
@@ -60,7 +60,7 @@ struct NetDims {
 struct gbnf_flow {
   int math_mode = 0;   // GBNF_MATH_*
   int kind = 0, d = 0, n_steps = 0, additive = 0;
-  int hidden = 0, depth = 0, act_a = 0, act_b = 0;
+  int hidden = 0, depth = 0, act_a = 0, act_b = 0, residual = 0;
   int ht = 0, ksl = 0, ot = 0;     // tile geometry (exact)
   int ks1 = 0;
   int var_ht = 0, var_ksl = 0, var_ks1 = 0, var_ot = 0;  // geometry of the compiled variant the blob was packed for
@@ -92,9 +92,11 @@ static int phys_to_logical(int p, int h) {
 static int check_net(const gbnf_net& net, int in_f, int out_f, NetDims* dims, const char* what) {
   if (net.n_layers < 2 || net.layers == nullptr)
     return fail(GBNF_ERR_INVALID, "%s: coupling network needs >= 2 Linear layers", what);
-  if (net.activation != GBNF_ACT_TANH && net.activation != GBNF_ACT_RELU)
-    return fail(GBNF_ERR_UNSUPPORTED, "%s: activation %d not supported (tanh / relu only; the reference's "
-                "ResidualNet is not on the supported path)", what, net.activation);
+  const bool residual = net.activation == GBNF_ACT_RESIDUAL_RELU;
+  if (net.activation != GBNF_ACT_TANH && net.activation != GBNF_ACT_RELU && !residual)
+    return fail(GBNF_ERR_UNSUPPORTED, "%s: activation %d not supported (tanh / relu / residual-relu)", what, net.activation);
+  if (residual && (net.n_layers < 4 || net.n_layers % 2 != 0))
+    return fail(GBNF_ERR_INVALID, "%s: a ResidualNet has 2 + 2 B Linear layers (got %d)", what, net.n_layers);
   const int h = net.layers[0].out_features;
   for (int l = 0; l < net.n_layers; ++l) {
     const gbnf_linear& lin = net.layers[l];
@@ -107,7 +109,9 @@ static int check_net(const gbnf_net& net, int in_f, int out_f, NetDims* dims, co
                   lin.in_features, want_out, want_in);
   }
   dims->in_f = in_f; dims->hidden = h; dims->out_f = out_f;
-  dims->depth = net.n_layers - 2; dims->act = net.activation;
+  dims->depth = net.n_layers - 2;                 // hidden -> hidden Linear layers (a ResidualNet of B blocks: 2 B)
+  dims->act = residual ? GBNF_ACT_RELU : net.activation;
+  dims->residual = residual ? 1 : 0;
   return GBNF_OK;
 }
 
@@ -364,13 +368,13 @@ static int validate_desc(const gbnf_flow_desc* desc, DescInfo* info) {
       snprintf(what, sizeof(what), "realnvp step %d s_net", s);
       rc = check_net(st.s_net, in_f, out_f, &b, what);
       if (rc) return rc;
-      if (a.hidden != b.hidden || a.depth != b.depth)
-        return fail(GBNF_ERR_UNSUPPORTED, "realnvp step %d: t_net and s_net differ in width/depth", s);
+      if (a.hidden != b.hidden || a.depth != b.depth || a.residual != b.residual)
+        return fail(GBNF_ERR_UNSUPPORTED, "realnvp step %d: t_net and s_net differ in width/depth/architecture", s);
     }
     if (s == 0) {
       ref = a; act_a = a.act; act_b = b.act;
-    } else if (a.hidden != ref.hidden || a.depth != ref.depth) {
-      return fail(GBNF_ERR_UNSUPPORTED, "step %d: coupling-network width/depth differs from step 0", s);
+    } else if (a.hidden != ref.hidden || a.depth != ref.depth || a.residual != ref.residual) {
+      return fail(GBNF_ERR_UNSUPPORTED, "step %d: coupling-network width/depth/architecture differs from step 0", s);
     } else if (a.act != act_a || b.act != act_b) {
       // the reference's `--coupling_network random` draws tanh / relu per step (glow.py:295-296) or per net
       // (realnvp.py:59-60): the kernels then pick the activation per step and net from the step header
@@ -383,7 +387,8 @@ static int validate_desc(const gbnf_flow_desc* desc, DescInfo* info) {
     if (entries > max_out_entries) max_out_entries = entries;
   }
   const int h = ref.hidden, depth = ref.depth;
-  if (depth > 2) return fail(GBNF_ERR_UNSUPPORTED, "coupling_network_depth=%d > 2 has no compiled variant", depth);
+  if (ref.residual ? depth > 4 : depth > 2)
+    return fail(GBNF_ERR_UNSUPPORTED, "coupling_network_depth=%d > 2 has no compiled variant", ref.residual ? depth / 2 : depth);
   const int ksh = ceil_div(h, 4);
   const int ht = ceil_div(ksh, 4), ksl = ksh - 4 * (ht - 1);
   // out tiles: glow affine -> pairs (shift_j, raw_j): 8 pairs per 16-row tile; else 16 rows per tile
@@ -431,11 +436,12 @@ int gbnf_flow_create_ex(const gbnf_flow_desc* desc, int32_t math_mode, int32_t f
     return fail(GBNF_ERR_INVALID, "unknown math mode %d", math_mode);
   gbnf_flow* f = new gbnf_flow();
   f->kind = desc->kind; f->d = d; f->n_steps = K; f->additive = additive ? 1 : 0;
-  f->hidden = h; f->depth = depth; f->act_a = act_a; f->act_b = act_b;
+  f->hidden = h; f->depth = depth; f->act_a = act_a; f->act_b = act_b; f->residual = ref.residual;
+  const int lmid_key = ref.residual ? 10 + depth / 2 : depth;      // the LMID field of the variant key (gbnf_flow_kernel.hip.h)
   const int ks1 = info.ks1;
   f->ht = ht; f->ksl = ksl; f->ot = ot; f->ks1 = ks1;
   bool hx3 = false;
-  if (math_mode != GBNF_MATH_F32 && depth == 1) {
+  if (math_mode != GBNF_MATH_F32 && depth == 1 && !ref.residual) {
     // split-f16 kernel: hidden tiles in natural order (no k-step skipping), any zero-padded superset works
     const int ht_b = ceil_div(h, 16);
     long best = -1;
@@ -462,7 +468,8 @@ int gbnf_flow_create_ex(const gbnf_flow_desc* desc, int32_t math_mode, int32_t f
     }
   } else if (math_mode == GBNF_MATH_F16X3) {
     delete f;
-    return fail(GBNF_ERR_UNSUPPORTED, "the f16x3 kernel supports coupling_network_depth == 1 only (got %d)", depth);
+    return fail(GBNF_ERR_UNSUPPORTED, "the f16x3 kernel supports TanhNet / ReLUNet of coupling_network_depth == 1 only (got %s%d)",
+                ref.residual ? "a ResidualNet, hidden layers " : "", depth);
   }
   f->math_mode = hx3 ? GBNF_MATH_F16X3 : GBNF_MATH_F32;
   if (!hx3) {
@@ -470,7 +477,7 @@ int gbnf_flow_create_ex(const gbnf_flow_desc* desc, int32_t math_mode, int32_t f
     for (const Variant& v : variants()) {
       const VariantKey& k = v.key;
       if (k.ksl < 0) continue;
-      if (k.kind != desc->kind || k.lmid != depth || k.act_a != act_a || k.act_b != act_b) continue;
+      if (k.kind != desc->kind || k.lmid != lmid_key || k.act_a != act_a || k.act_b != act_b) continue;
       if (k.ot < ot || k.ks1 < ks1) continue;
       // a variant processes hidden k-steps [0, 4(k.ht-1)+k.ksl); ours are [0, 4(ht-1)+ksl); extra ones
       // multiply zero padding, so any superset is exact (just slower)
@@ -864,7 +871,7 @@ int gbnf_mixture_create(gbnf_flow* const* flows, int32_t n_flows, gbnf_mixture**
     const gbnf_flow* f = flows[c];
     if (!f) return fail(GBNF_ERR_INVALID, "gbnf_mixture_create: flow %d is null", c);
     if (f->math_mode != f0->math_mode || f->kind != f0->kind || f->d != f0->d || f->n_steps != f0->n_steps || f->additive != f0->additive ||
-        f->hidden != f0->hidden || f->depth != f0->depth || f->act_a != f0->act_a || f->act_b != f0->act_b ||
+        f->hidden != f0->hidden || f->depth != f0->depth || f->act_a != f0->act_a || f->act_b != f0->act_b || f->residual != f0->residual ||
         f->var_ht != f0->var_ht || f->var_ksl != f0->var_ksl || f->var_ks1 != f0->var_ks1 || f->var_ot != f0->var_ot)
       return fail(GBNF_ERR_INVALID, "gbnf_mixture_create: flow %d has a different architecture than flow 0", c);
     table[c] = f->blob_dev;

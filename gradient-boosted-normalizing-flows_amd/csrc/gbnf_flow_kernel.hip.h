@@ -67,6 +67,12 @@ struct NetLayoutRT {
         NET_WORDS(B3 + OT * 16) {}
 };
 
+// The LMID template / variant-key field: 0..2 = coupling_network_depth of a TanhNet / ReLUNet; 10 + B = a ResidualNet of
+// B blocks (models/layers.py:246-301: Linear, B x [x + Linear(relu(Linear(relu(x))))], Linear -- the same Linear shapes
+// as a plain net of depth 2B, other activation placement and a skip connection).
+constexpr bool lmid_is_residual(int lmid) { return lmid >= 10; }
+constexpr int lmid_mid_layers(int lmid) { return lmid >= 10 ? 2 * (lmid - 10) : lmid; }
+
 constexpr int MAX_BATCHES = 16;  // batches one launch can serve
 
 struct FlowLaunch {
@@ -133,7 +139,7 @@ __device__ __forceinline__ float tanh_act(float x) {
 #endif
 }
 
-// ACT: GBNF_ACT_TANH, GBNF_ACT_RELU, or 2 = chosen per step and net (`relu`, uniform): both are computed and one is
+// ACT: GBNF_ACT_TANH, GBNF_ACT_RELU, or 3 (GBNF_ACT_PER_STEP, gbnf_internal.h) = chosen per step and net (`relu`, uniform): both are computed and one is
 // selected -- straight-line code, the interleaving with the MFMAs stays what it is
 template <int ACT>
 __device__ __forceinline__ float act_fn(float v, bool relu) {
@@ -167,7 +173,9 @@ __device__ __forceinline__ f32x4 mfma4(float a, float b, f32x4 c) {
 template <int HT, int KSL, int KS1, int OT, int NT, int LMID, int ACT>
 __device__ __forceinline__ void coupling_net(const uint32_t* __restrict__ net, const float (&zb)[KS1][NT],
                                              int lane, int g, f32x4 (&out)[OT][NT], Stamps& st, bool relu) {
-  constexpr NetLayoutRT L(HT, KS1, OT, LMID);
+  constexpr NetLayoutRT L(HT, KS1, OT, lmid_mid_layers(LMID));
+  constexpr bool RES = lmid_is_residual(LMID);
+  constexpr int MIDS = lmid_mid_layers(LMID);
   constexpr int KQ = L.KQ;
   const f32x4* w1 = reinterpret_cast<const f32x4*>(net + L.W1) + lane * KQ;   // + t*64*KQ
   const f32x4* b1 = reinterpret_cast<const f32x4*>(net + L.B1) + g;           // + t*4
@@ -206,15 +214,71 @@ __device__ __forceinline__ void coupling_net(const uint32_t* __restrict__ net, c
         load_w1(t + 1, wq[(t + 1) & 1]);
         bq[(t + 1) & 1] = b1[(t + 1) * 4];
         layer0_tile(wq[t & 1], bq[t & 1], hA[t]);
+        if constexpr (!RES) {
 #pragma unroll
-        for (int nt = 0; nt < NT; ++nt)
+          for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
-          for (int r = 0; r < 4; ++r) hA[t][nt][r] = act_fn<ACT>(hA[t][nt][r], relu);
+            for (int r = 0; r < 4; ++r) hA[t][nt][r] = act_fn<ACT>(hA[t][nt][r], relu);
+        }
       }
     }
     st.mark(1);
+    if constexpr (RES) {
+      // ---- residual blocks: hA is the running (un-activated) state; block = hA += W_b . relu(W_a . relu(hA) + b_a) + b_b
 #pragma unroll
-    for (int m = 0; m < LMID; ++m) {
+      for (int blk = 0; blk < MIDS / 2; ++blk) {
+        const f32x4* wa = reinterpret_cast<const f32x4*>(net + L.MID0 + (2 * blk) * L.MID_STRIDE) + lane;
+        const f32x4* ba = reinterpret_cast<const f32x4*>(net + L.MID0 + (2 * blk) * L.MID_STRIDE + L.MID_W) + g;
+        const f32x4* wb = reinterpret_cast<const f32x4*>(net + L.MID0 + (2 * blk + 1) * L.MID_STRIDE) + lane;
+        const f32x4* bb = reinterpret_cast<const f32x4*>(net + L.MID0 + (2 * blk + 1) * L.MID_STRIDE + L.MID_W) + g;
+        f32x4 hB[HT][NT];
+#pragma unroll
+        for (int u = 0; u < HT; ++u) {
+          const f32x4 bias = ba[u * 4];
+#pragma unroll
+          for (int nt = 0; nt < NT; ++nt) hB[u][nt] = bias;
+#pragma unroll
+          for (int t = 0; t < HT; ++t) {
+            const f32x4 a = wa[(u * HT + t) * 64];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              if (t < HT - 1 || r < KSL) {
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) hB[u][nt] = mfma4(a[r], __builtin_fmaxf(hA[t][nt][r], 0.0f), hB[u][nt]);
+              }
+            }
+          }
+        }
+#pragma unroll
+        for (int t = 0; t < HT; ++t)
+#pragma unroll
+          for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) hB[t][nt][r] = __builtin_fmaxf(hB[t][nt][r], 0.0f);
+#pragma unroll
+        for (int u = 0; u < HT; ++u) {
+          f32x4 acc[NT];
+          const f32x4 bias = bb[u * 4];
+#pragma unroll
+          for (int nt = 0; nt < NT; ++nt) acc[nt] = bias;
+#pragma unroll
+          for (int t = 0; t < HT; ++t) {
+            const f32x4 a = wb[(u * HT + t) * 64];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              if (t < HT - 1 || r < KSL) {
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) acc[nt] = mfma4(a[r], hB[t][nt][r], acc[nt]);
+              }
+            }
+          }
+#pragma unroll
+          for (int nt = 0; nt < NT; ++nt) hA[u][nt] += acc[nt];      // the skip connection (hA[u] is no input of this layer)
+        }
+      }
+    }
+#pragma unroll
+    for (int m = 0; m < (RES ? 0 : MIDS); ++m) {
       const f32x4* w = reinterpret_cast<const f32x4*>(net + L.MID0 + m * L.MID_STRIDE) + lane;
       const f32x4* b = reinterpret_cast<const f32x4*>(net + L.MID0 + m * L.MID_STRIDE + L.MID_W) + g;
       f32x4 hB[HT][NT];
@@ -519,7 +583,7 @@ template <int KIND, int HT, int KSL, int KS1, int OT, int NT, int LMID, int ACTA
 __global__ void __launch_bounds__(64) flow_kernel(const FlowLaunch p) {
   constexpr int ZS = 16 * NT + 1;   // +1: conflict-free transposed x load / z store
   constexpr int NNETS = (KIND == GBNF_KIND_REALNVP) ? 2 : 1;
-  constexpr NetLayoutRT L(HT, KS1, OT, LMID);
+  constexpr NetLayoutRT L(HT, KS1, OT, lmid_mid_layers(LMID));
   constexpr int STEP_WORDS = SMALL_WORDS + NNETS * L.NET_WORDS;
 
   // one dynamic LDS block (16-byte aligned base): [ per-step tables | Z ]
@@ -589,8 +653,8 @@ __global__ void __launch_bounds__(64) flow_kernel(const FlowLaunch p) {
     LaneTable tin, tout;
     float step_ld;
     // per-step activation variants only: 1 = relu, from the step header (uniform)
-    const bool relu_a = ACTA == 2 && __builtin_amdgcn_readfirstlane(sp[2]) != 0;
-    const bool relu_b = ACTB == 2 && __builtin_amdgcn_readfirstlane(sp[3]) != 0;
+    const bool relu_a = ACTA == 3 && __builtin_amdgcn_readfirstlane(sp[2]) != 0;
+    const bool relu_b = ACTB == 3 && __builtin_amdgcn_readfirstlane(sp[3]) != 0;
     if (lds_tables) {
       const uint32_t* sm = SM + step * SMALL_WORDS;
       step_ld = as_f32(sm[1]);

@@ -261,9 +261,9 @@ __global__ void __launch_bounds__(64 * HX3_WAVES, (NT == 1) ? 2 : 1) flow_kernel
       gf4 b1 = (gf4)nb + g;
       gf4 b2 = (gf4)(nb + HT * 16) + g;
       gf4 b3 = (gf4)(nb + 2 * HT * 16) + g;
-      // ACT == 2: the activation of this step's net comes from the step header (`--coupling_network random`): both are
+      // ACT == 3 (GBNF_ACT_PER_STEP): the activation of this step's net comes from the step header (`--coupling_network random`): both are
       // computed and one is selected (the packer folded the tanh pre-scale into this net's layers only if it is a tanh net)
-      const bool relu_rt = ACT == 2 && __builtin_amdgcn_readfirstlane(sp[2 + net]) != 0;
+      const bool relu_rt = ACT == 3 && __builtin_amdgcn_readfirstlane(sp[2 + net]) != 0;
       auto act = [&](float v) {
         if (ACT == GBNF_ACT_TANH) return act_hx3<GBNF_ACT_TANH>(v);
         if (ACT == GBNF_ACT_RELU) return act_hx3<GBNF_ACT_RELU>(v);

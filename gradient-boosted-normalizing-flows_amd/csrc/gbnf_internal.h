@@ -8,6 +8,6 @@ int fail(int code, const char* fmt, ...);
 
 // Kernel-variant key only (not a descriptor value): the activation differs between the steps / nets of a component
 // (`--coupling_network random` in the reference); the kernel reads it per step and net from the step header.
-constexpr int GBNF_ACT_PER_STEP = 2;
+constexpr int GBNF_ACT_PER_STEP = 3;
 
 }  // namespace gbnf

@@ -1162,6 +1162,8 @@ int gbnf_trainer_create(const gbnf_flow_desc* desc, gbnf_trainer** out) {
   const int d1 = d / 2, d2 = d - d1;
   const gbnf_net& n0 = glow ? desc->glow_steps[0].block : desc->realnvp_steps[0].t_net;
   const int h = n0.layers[0].out_features, nl = n0.n_layers;
+  if (n0.activation == GBNF_ACT_RESIDUAL_RELU)
+    return fail(GBNF_ERR_UNSUPPORTED, "gbnf_trainer_create: ResidualNet coupling networks are evaluation-only");
   if (nl > TR_MAX_LAYERS) return fail(GBNF_ERR_UNSUPPORTED, "gbnf_trainer_create: %d Linear layers per net > %d", nl, TR_MAX_LAYERS);
   if (d2 > TR_MAX_IN) return fail(GBNF_ERR_UNSUPPORTED, "gbnf_trainer_create: half width %d > %d", d2, TR_MAX_IN);
 

@@ -29,9 +29,21 @@ def _np32(t):
     return np.ascontiguousarray(t.detach().cpu().numpy().astype(np.float32))
 
 
+def linears_of(net_module):
+    """The Linear modules of a coupling network in evaluation order: TanhNet / ReLUNet keep them in ``network``
+    (models/layers.py:208-243), a ResidualNet in ``initial_layer``, ``blocks[b].linear_layers[0..1]``, ``final_layer``
+    (models/layers.py:246-301)."""
+    if hasattr(net_module, "initial_layer"):
+        return ([net_module.initial_layer] + [lin for blk in net_module.blocks for lin in blk.linear_layers]
+                + [net_module.final_layer])
+    return [m for m in net_module.network if type(m).__name__ == "Linear"]
+
+
 def _net_from_module(seq_owner):
-    """TanhNet / ReLUNet -> net dict.  ``seq_owner.network`` is an nn.Sequential of
+    """TanhNet / ReLUNet / ResidualNet -> net dict.  ``seq_owner.network`` is an nn.Sequential of
     Linear / activation modules (models/layers.py:208-243)."""
+    if hasattr(seq_owner, "initial_layer"):
+        return {"act": "residual", "layers": [(_np32(m.weight), _np32(m.bias)) for m in linears_of(seq_owner)]}
     layers = []
     act = None
     for m in seq_owner.network:
@@ -117,6 +129,8 @@ def activation_pattern_of_component(module):
     is touched: usable before ActNorm's data-dependent initialisation).  Same value as
     ``native.activation_pattern(spec_from_component(module))``."""
     def act_of(seq_owner):
+        if hasattr(seq_owner, "initial_layer"):
+            return "residual"
         acts = {type(m).__name__.lower() for m in seq_owner.network if type(m).__name__ in ("Tanh", "ReLU")}
         if len(acts) > 1:
             _mixed_act_error()
@@ -130,6 +144,8 @@ def activation_pattern_of_component(module):
 
 # ------------------------------------------------------------------ live (device) view for the training path
 def _dev_net(seq_owner):
+    if hasattr(seq_owner, "initial_layer"):
+        raise NotImplementedError("ResidualNet coupling networks are evaluation-only (no training kernels)")
     layers, act = [], None
     for m in seq_owner.network:
         cls = type(m).__name__

@@ -32,6 +32,16 @@ def _net(rng, in_f, out_f, h, depth, act, gain):
     return {"act": act, "layers": layers}
 
 
+def _res_net(rng, in_f, out_f, h, blocks, gain):
+    """ResidualNet (models/layers.py:276-301): initial, `blocks` x (Linear, Linear), final."""
+    layers = [_linear(rng, h, in_f, gain)]
+    for _ in range(blocks):
+        layers.append(_linear(rng, h, h, gain))
+        layers.append(_linear(rng, h, h, 0.3 * gain))
+    layers.append(_linear(rng, out_f, h, gain))
+    return {"act": "residual", "layers": layers}
+
+
 def synth_glow_spec(d, h, K, depth=1, act="tanh", coupling="affine", permutation="shuffle",
                     seed=0, gain=1.0):
     """One tabular Glow component (models/glow.py FlowStep x K) with synthetic parameters.
@@ -60,7 +70,7 @@ def synth_realnvp_spec(d, h, K, depth=1, coupling_network="tanh", batch_norm=Tru
     """One RealNVPFlow component (models/realnvp.py:34-78) with synthetic parameters.
 
     ``coupling_network``: "tanh" | "relu" | "mixed" (t_net ReLU, s_net Tanh, realnvp.py:47-51) | "random" (every net
-    of every step draws one of the two, realnvp.py:59-60).
+    of every step draws one of the two, realnvp.py:59-60) | "residual" (ResidualNet of ``depth`` blocks, realnvp.py:57).
     BatchNorm is present on every step but the last when ``batch_norm`` (realnvp.py:71-74).
     """
     rng = np.random.RandomState(seed)
@@ -78,9 +88,13 @@ def synth_realnvp_spec(d, h, K, depth=1, coupling_network="tanh", batch_norm=Tru
             t_act, s_act = (["tanh", "relu"][act_rng.randint(2)] for _ in range(2))
         else:
             t_act = s_act = coupling_network
-        t_net = _net(rng, in_f, out_f, h, depth, t_act, gain)
-        # keep log-scales tame: the s-net's last layer is scaled down a little
-        s_net = _net(rng, in_f, out_f, h, depth, s_act, gain)
+        if coupling_network == "residual":       # depth = number of residual blocks (realnvp.py:62-65)
+            t_net = _res_net(rng, in_f, out_f, h, depth, gain)
+            s_net = _res_net(rng, in_f, out_f, h, depth, 0.5 * gain)
+        else:
+            t_net = _net(rng, in_f, out_f, h, depth, t_act, gain)
+            # keep log-scales tame: the s-net's last layer is scaled down a little
+            s_net = _net(rng, in_f, out_f, h, depth, s_act, gain)
         bn = None
         if batch_norm and k < K - 1:
             bn = {

@@ -42,7 +42,12 @@ typedef enum gbnf_status {
 } gbnf_status;
 
 enum { GBNF_KIND_GLOW = 0, GBNF_KIND_REALNVP = 1 };
-enum { GBNF_ACT_TANH = 0, GBNF_ACT_RELU = 1 };
+/* TANH / RELU: TanhNet / ReLUNet (models/layers.py:208-243), n_layers = coupling_network_depth + 2 Linear layers.
+ * RESIDUAL_RELU: ResidualNet (models/layers.py:246-301) of B = coupling_network_depth blocks, n_layers = 2 + 2 B Linear
+ * layers in the order initial_layer, (blocks[b].linear_layers[0], blocks[b].linear_layers[1]) for b < B, final_layer:
+ *     t = initial(x);  t += lin1_b(relu(lin0_b(relu(t)))) for every block;  out = final(t)
+ * Evaluation and the inverse direction (exact-f32 kernel, B <= 2); not the training entry points. */
+enum { GBNF_ACT_TANH = 0, GBNF_ACT_RELU = 1, GBNF_ACT_RESIDUAL_RELU = 2 };
 enum { GBNF_COUPLING_AFFINE = 0, GBNF_COUPLING_ADDITIVE = 1 };
 /* How the coupling-network matrix products are evaluated (results agree to ~1e-6 relative in log-likelihood):
  *   F32     exact f32 MFMA (v_mfma_f32_16x16x4_f32), bitwise an ordered fmaf chain;

@@ -143,8 +143,17 @@ def coupling_net(ops, net, x):
 
     Follows models/layers.py:208-243 (nn.Linear: y = x W^T + b, W is (out,in)).
     """
-    act = ops.tanh if net["act"] == "tanh" else ops.relu
     layers = net["layers"]
+    if net["act"] == "residual":
+        # ResidualNet (models/layers.py:246-301): initial_layer, B x ResidualBlock, final_layer;
+        # block: inputs + linear_layers[1](relu(linear_layers[0](relu(inputs))))  (layers.py:267-273)
+        h = ops.linear(x, ops.arr(layers[0][0]), ops.arr(layers[0][1]))
+        for b in range((len(layers) - 2) // 2):
+            (w0, b0), (w1, b1) = layers[1 + 2 * b], layers[2 + 2 * b]
+            t = ops.linear(ops.relu(h), ops.arr(w0), ops.arr(b0))
+            h = h + ops.linear(ops.relu(t), ops.arr(w1), ops.arr(b1))
+        return ops.linear(h, ops.arr(layers[-1][0]), ops.arr(layers[-1][1]))
+    act = ops.tanh if net["act"] == "tanh" else ops.relu
     h = ops.linear(x, ops.arr(layers[0][0]), ops.arr(layers[0][1]))
     for w, b in layers[1:]:
         h = ops.linear(act(h), ops.arr(w), ops.arr(b))

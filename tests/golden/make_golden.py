@@ -54,7 +54,7 @@ def ref_args(kind, d, h, K, C, depth=1, coupling_network="tanh", coupling="affin
 
 
 def _load_net(ref_net, net):
-    linears = [m for m in ref_net.network if isinstance(m, torch.nn.Linear)]
+    linears = gspec.linears_of(ref_net)
     assert len(linears) == len(net["layers"])
     for m, (w, b) in zip(linears, net["layers"]):
         assert tuple(m.weight.shape) == w.shape, (m.weight.shape, w.shape)
@@ -263,6 +263,7 @@ def state_dict_layout_case():
     expose exactly these so reference checkpoints load and optimizers.py:29-35's name parsing works)."""
     out = {}
     for kind, kw in (("glow", {}), ("realnvp", {}), ("realnvp_mixed", dict(coupling_network="mixed")),
+                     ("realnvp_residual", dict(coupling_network="residual", depth=2)),
                      ("glow_depth2_additive", dict(depth=2, coupling="additive", permutation="reverse"))):
         base = kind.split("_")[0]
         m = RefBoostedFlow(ref_args(base, 7, 12, 3, 2, **kw))
@@ -583,6 +584,11 @@ def main():
         grads_case("g10_glow_grads_additive_relu_d8", "glow", 8, 40, 3, 50, coupling="additive", act="relu")
         grads_case("g10_realnvp_grads_d21_h32", "realnvp", 21, 32, 4, 80)
         return
+    if "--residual-only" in sys.argv:
+        synth_case("g14_realnvp_residual_d21_h64_c2", "realnvp", 21, 64, 4, 2, 128, coupling_network="residual")
+        synth_case("g14_realnvp_residual2_d8_h40_c2", "realnvp", 8, 40, 3, 2, 96, coupling_network="residual", depth=2,
+                   batch_norm=False)
+        return
     if "--random-only" in sys.argv:
         native_random_case("g13_glow_random_d43_h64", "glow", 43, 64, 6, 2)
         native_random_case("g13_realnvp_random_d21_h32", "realnvp", 21, 32, 5, 2)
@@ -620,6 +626,10 @@ def main():
     # G4: HEPMASS RealNVP, flip_init 0..7, BN with non-trivial running stats
     synth_case("g4_realnvp_d21_h105_c8", "realnvp", 21, 105, 5, 8, 256)
     synth_case("g4_realnvp_d21_h105_c2_mixed", "realnvp", 21, 105, 5, 2, 128, coupling_network="mixed")
+    # G14: ResidualNet coupling networks (RealNVP only: models/realnvp.py:57, models/layers.py:246-301)
+    synth_case("g14_realnvp_residual_d21_h64_c2", "realnvp", 21, 64, 4, 2, 128, coupling_network="residual")
+    synth_case("g14_realnvp_residual2_d8_h40_c2", "realnvp", 8, 40, 3, 2, 96, coupling_network="residual", depth=2,
+               batch_norm=False)
     synth_case("g4_realnvp_d21_h105_c2_relu_nobn", "realnvp", 21, 105, 3, 2, 128,
                coupling_network="relu", batch_norm=False)
     # G5: variants

@@ -59,7 +59,8 @@ def _evaluate_like_reference(model, x):
 
 @pytest.mark.parametrize("name", ["g2_glow_native_d43_h32_c3", "g4_realnvp_d21_h105_c8",
                                   "g5_glow_d43_h64_c2_additive", "g4_realnvp_d21_h105_c2_mixed",
-                                  "g13_glow_random_d43_h64", "g13_realnvp_random_d21_h32"])
+                                  "g13_glow_random_d43_h64", "g13_realnvp_random_d21_h32",
+                                  "g14_realnvp_residual_d21_h64_c2", "g14_realnvp_residual2_d8_h40_c2"])
 def test_module_dropin_matches_reference(name, golden_case):
     import torch
     dev = torch.device("cuda:0")

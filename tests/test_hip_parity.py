@@ -36,8 +36,9 @@ def test_hip_matches_reference_golden(name, math, golden_case, dev):
     try:
         mix, flows = _mixture(g.specs, math)
     except native.GbnfError:
-        assert math == "f16x3" and g.cfg.get("synth_kw", {}).get("depth", 1) != 1   # depth 0 / 2: f32 kernel only
-        pytest.skip("split-f16 kernel is depth-1 only; this fixture runs on the exact-f32 kernel")
+        skw = g.cfg.get("synth_kw", {})    # depth 0 / 2 and ResidualNets: exact-f32 kernel only
+        assert math == "f16x3" and (skw.get("depth", 1) != 1 or skw.get("coupling_network") == "residual")
+        pytest.skip("split-f16 kernel: TanhNet / ReLUNet of depth 1 only; this fixture runs on the exact-f32 kernel")
     if g.base is not None:
         mix.set_base(*g.base)
     x = torch.from_numpy(g.x).to(dev)
@@ -165,6 +166,33 @@ def test_activation_drawn_per_step(kind, d, h, K, math, dev):
         assert np.abs(xr.cpu().numpy() - x).max() < 5e-4
     # a uniform component created on its own keeps its uniform kernel; with the flag it joins the others
     assert native.NativeFlow(specs[0], math=math, per_step_activation=True).info().math_mode == flows[0].info().math_mode
+
+
+@pytest.mark.parametrize("blocks", [1, 2])
+def test_residual_coupling_networks(blocks, dev):
+    """`--coupling_network residual` (RealNVP: models/realnvp.py:57, ResidualNet models/layers.py:246-301): forward at
+    16- and 32-sample wave tiles, the inverse direction, and the loud refusals (f16x3 math, training)."""
+    import torch
+    from gbnf_amd import native, synth
+    from oracle import gbnf_oracle as oracle
+    d, h, K = 21, 105, 4
+    specs = synth.synth_boosted_specs("realnvp", 3, d, h, K, seed=33, coupling_network="residual", depth=blocks)
+    mix, flows = _mixture(specs)
+    assert flows[0].info().math_mode == native.MATH["f32"]
+    rho = oracle.rho_init(3)
+    for n in (50, 5000):
+        xs = synth.synth_batch(n, d, seed=n)
+        ll_ref, G_ref = oracle.mixture_log_prob(specs, rho, xs)
+        G, ll = mix.log_prob(torch.from_numpy(xs).to(dev), torch.from_numpy(rho).to(dev))
+        assert rel_err(ll.cpu().numpy(), ll_ref) < LL_RTOL
+        assert rel_err(G.cpu().numpy(), G_ref) < LL_RTOL
+    x = synth.synth_batch(300, d, seed=4)
+    z, ldj, _ = flows[2].forward(torch.from_numpy(x).to(dev))
+    xr, ldj_inv = flows[2].inverse(z)
+    assert np.abs(xr.cpu().numpy() - x).max() < 5e-4
+    assert np.abs((ldj + ldj_inv).cpu().numpy()).max() < 1e-3
+    with pytest.raises(native.GbnfError):
+        native.NativeFlow(specs[0], math="f16x3")
 
 
 def test_full_size_against_oracle(dev):

@@ -31,6 +31,7 @@ LAYOUT = json.load(open(os.path.join(GOLDEN_DIR, "state_dict_layout.json")))
     ("glow", dict(kind="glow")),
     ("realnvp", dict(kind="realnvp")),
     ("realnvp_mixed", dict(kind="realnvp", coupling_network="mixed")),
+    ("realnvp_residual", dict(kind="realnvp", coupling_network="residual", depth=2)),
     ("glow_depth2_additive", dict(kind="glow", depth=2, coupling="additive", permutation="reverse")),
 ])
 def test_state_dict_layout_matches_reference(case, kw):
