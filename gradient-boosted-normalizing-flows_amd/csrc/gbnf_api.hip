@@ -421,6 +421,13 @@ int gbnf_flow_create_ex(const gbnf_flow_desc* desc, int32_t math_mode, int32_t f
     if (rc) return rc;
   }
   if (flags & GBNF_CREATE_PER_STEP_ACTIVATION) info.act_a = info.act_b = GBNF_ACT_PER_STEP;
+  {   // an activation pair nobody compiled a kernel for (`random` can draw a tanh shift net with a relu scale net for
+      // every step): the per-step variants cover it
+    bool compiled = false;
+    for (const Variant& v : variants())
+      compiled = compiled || (v.key.kind == desc->kind && v.key.act_a == info.act_a && v.key.act_b == info.act_b);
+    if (!compiled) info.act_a = info.act_b = GBNF_ACT_PER_STEP;
+  }
   const int d = desc->d, K = desc->n_steps;
   const bool glow = desc->kind == GBNF_KIND_GLOW;
   const bool additive = glow && desc->coupling == GBNF_COUPLING_ADDITIVE;

@@ -164,6 +164,13 @@ def test_activation_drawn_per_step(kind, d, h, K, math, dev):
         z, _, _ = flows[1].forward(xd)
         xr, _ = flows[1].inverse(z)
         assert np.abs(xr.cpu().numpy() - x).max() < 5e-4
+    if kind == "realnvp":      # a pair nobody compiled (tanh shift net, relu scale net, every step) runs on the per-step kernels
+        odd = synth.synth_realnvp_spec(d, h, 3, seed=5, coupling_network="tanh")
+        for st in odd["steps"]:
+            st["s_net"]["act"] = "relu"
+        xs = synth.synth_batch(64, d, seed=1)
+        ll = native.NativeFlow(odd, math=math).forward(torch.from_numpy(xs).to(dev), want_ll=True)[2]
+        assert rel_err(ll.cpu().numpy(), oracle.component_log_prob(odd, xs)) < LL_RTOL
     # a uniform component created on its own keeps its uniform kernel; with the flag it joins the others
     assert native.NativeFlow(specs[0], math=math, per_step_activation=True).info().math_mode == flows[0].info().math_mode
 
