@@ -535,7 +535,18 @@ class BoostedFlow(nn.Module):
         flows = [self.native_flow(c) for c in range(self.num_components)]
         key = tuple(id(f) for f in flows)
         if self._mixture is None or self._mixture[0] != key:
-            self._mixture = (key, native.NativeMixture(flows))
+            try:
+                mix = native.NativeMixture(flows)
+            except native.GbnfError:
+                if self._per_step_activation():
+                    raise
+                # components ended up on different kernel variants: put all of them on the per-step-activation supersets
+                self._per_step_act = True
+                self._handles = {}
+                flows = [self.native_flow(c) for c in range(self.num_components)]
+                key = tuple(id(f) for f in flows)
+                mix = native.NativeMixture(flows)
+            self._mixture = (key, mix)
         return self._mixture[1]
 
     # ------------------------------------------------------------------ convenience API (BASELINE.json)

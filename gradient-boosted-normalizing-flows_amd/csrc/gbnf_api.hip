@@ -470,6 +470,8 @@ int gbnf_flow_create_ex(const gbnf_flow_desc* desc, int32_t math_mode, int32_t f
     hx3 = best >= 0;
     if (!hx3 && math_mode == GBNF_MATH_F16X3) {
       delete f;
+      if (act_a != GBNF_ACT_PER_STEP && !ref.residual)     // the per-step-activation variants are generic supersets
+        return gbnf_flow_create_ex(desc, math_mode, flags | GBNF_CREATE_PER_STEP_ACTIVATION, out);
       return fail(GBNF_ERR_UNSUPPORTED, "no compiled f16x3 kernel variant for kind=%d hidden=%d out_tiles=%d act=(%d,%d); "
                   "add it to csrc/variants.list", desc->kind, h, ot, act_a, act_b);
     }
@@ -504,6 +506,8 @@ int gbnf_flow_create_ex(const gbnf_flow_desc* desc, int32_t math_mode, int32_t f
     }
     if (best_cost < 0) {
       delete f;
+      if (act_a != GBNF_ACT_PER_STEP && !ref.residual)     // the per-step-activation variants are generic supersets
+        return gbnf_flow_create_ex(desc, math_mode, flags | GBNF_CREATE_PER_STEP_ACTIVATION, out);
       return fail(GBNF_ERR_UNSUPPORTED,
                   "no compiled kernel variant for kind=%d hidden=%d (tiles=%d,last k-steps=%d) in k-steps=%d out_tiles=%d "
                   "depth=%d act=(%d,%d); add it to csrc/variants.list", desc->kind, h, ht, ksl, ks1, ot, depth, act_a,

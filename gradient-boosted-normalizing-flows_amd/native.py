@@ -585,6 +585,18 @@ def flows_for_mixture(specs, math="default"):
     return [NativeFlow(s, math=math, per_step_activation=per_step) for s in specs]
 
 
+def mixture_from_specs(specs, math="default"):
+    """(NativeMixture, [NativeFlow]) of `specs`.  A mixture is one launch on ONE kernel variant; when the components
+    would individually end up on different variants (different activations, or a geometry only the per-step-activation
+    supersets cover) all of them are created for those supersets."""
+    flows = flows_for_mixture(specs, math=math)
+    try:
+        return NativeMixture(flows), flows
+    except GbnfError:
+        flows = [NativeFlow(s, math=math, per_step_activation=True) for s in specs]
+        return NativeMixture(flows), flows
+
+
 class NativeMixture:
     """C same-architecture components behind one launch (gbnf_mixture)."""
 

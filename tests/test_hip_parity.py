@@ -22,8 +22,7 @@ def dev():
 
 def _mixture(specs, math="default"):
     from gbnf_amd import native
-    flows = native.flows_for_mixture(specs, math=math)    # (per-step activation kernels when the components need them)
-    return native.NativeMixture(flows), flows
+    return native.mixture_from_specs(specs, math=math)    # (per-step activation kernels when the components need them)
 
 
 @pytest.mark.parametrize("math", ["f32", "f16x3"])
