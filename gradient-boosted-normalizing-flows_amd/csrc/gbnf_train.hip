@@ -49,7 +49,7 @@ using u32x2 = __attribute__((ext_vector_type(2))) unsigned;
 using f16x8 = __attribute__((ext_vector_type(8))) _Float16;
 
 constexpr int TR_MAX_NT = 2;        // 16-sample tiles per workgroup (they share every weight fragment a wave loads)
-constexpr int TR_MAX_LAYERS = 4;    // Linear layers per coupling net (depth <= 2)
+constexpr int TR_MAX_LAYERS = 6;    // Linear layers per coupling net (depth <= 2; a ResidualNet of 2 blocks has 6)
 constexpr int TR_MAX_IN = 32;       // coupling-net input / coupled-half width
 constexpr int TR_MAX_HIDDEN = 512;  // hidden width (32 output tiles = 16 tile pairs per layer)
 constexpr int TR_LDS_BYTES = 160 * 1024;
@@ -114,6 +114,7 @@ struct TrainLaunch {
   const u32x4* frag;   // split-f16 weight fragments of this call (prep_kernel)
   int64_t n, np;       // samples, samples rounded up to whole workgroups (16 * TR_MAX_NT)
   int d, K, kind, additive;
+  int residual;        // coupling nets are ResidualNets (models/layers.py:246-301): n_hidden = 2 blocks + 1
   int n_hidden;        // hidden layers per net = depth + 1
   int hp, ip, op;      // padded hidden / net-input / net-output rows (multiples of 16)
   int hw, xw, ow;      // the same padded to 32: widths of the split activation rows
@@ -507,7 +508,8 @@ __global__ void __launch_bounds__(64 * TR_WAVES) train_kernel(const TrainLaunch 
   const lfp GX = Zc + d * S;                              // [ip]  gradient w.r.t. the coupling-net input
   const lfp O = GX + p.ip * S;                            // [op]  net output, then its gradient
   const lfp O2 = O + p.op * S;                            // [op]  realnvp: shift output / shift gradient
-  const lfp RED = O2 + p.op * S;                          // [waves][NT][16]  cross-wave scratch
+  const lfp RT = O2 + p.op * S;                           // [hp]  ResidualNets: running state t (forward) / its gradient (backward)
+  const lfp RED = RT + (p.residual ? p.hp * S : 0);       // [waves][NT][16]  cross-wave scratch
   // split-f16 rows (B operands of the dense layers): net input, hidden activations (then their gradients), output gradient
   lbp sp = reinterpret_cast<lbp>(lds) + ((((RED + 16 * TR_WAVES * NT) - lds) * 4 + 15) & ~15);   // 16-byte aligned
   const TrSplit XS{sp, p.xw};
@@ -563,7 +565,26 @@ __global__ void __launch_bounds__(64 * TR_WAVES) train_kernel(const TrainLaunch 
       const LayerD L = layer_desc(k, q, l);
       tr_dense<NT>((gfrag)(p.frag + L.fw), L.b, in.w >> 5, hid_tiles, in, hid_tiles, lane, wave,
                    stamps, [&](int u0, int nt, f32x4 v) {
-        const f32x4 h = tr_act4(act, v);
+        f32x4 h;
+        if (!p.residual) {
+          h = tr_act4(act, v);
+        } else {
+          // ResidualNet: layer 0 = initial_layer, odd layers = first Linear of a block, even ones = second (+ skip).
+          // Hl receives the INPUT of the next Linear: relu(t) in front of a block, relu(m) inside it, t itself in front
+          // of final_layer (models/layers.py:267-273, 296-300)
+          if (l & 1) {
+            h = tr_act4(GBNF_ACT_RELU, v);
+          } else {
+            f32x4 t = v;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              const lfp rt = RT + (u0 + r) * S + i + 16 * nt;
+              if (l > 0) t[r] += *rt;
+              *rt = t[r];
+            }
+            h = l == nl - 2 ? t : tr_act4(GBNF_ACT_RELU, t);
+          }
+        }
         Hl.put4(i + 16 * nt, u0, h);
         if (emit) {
 #pragma unroll
@@ -605,7 +626,24 @@ __global__ void __launch_bounds__(64 * TR_WAVES) train_kernel(const TrainLaunch 
       tr_dense<NT>((gfrag)(p.frag + L.bw), gptr(nullptr), in.w >> 5, hid_tiles, in, hid_tiles, lane, wave, stamps,
                    [&](int u0, int nt, f32x4 v) {
         const f32x4 h = Hl.get4(i + 16 * nt, u0);
-        const f32x4 gpre = tr_dact4_mul(act, h, v);
+        f32x4 gpre;
+        if (!p.residual) {
+          gpre = tr_dact4_mul(act, h, v);
+        } else if (l == nl - 1) {
+          gpre = v;                                  // d/dt behind the last block: final_layer's input is t itself
+#pragma unroll
+          for (int r = 0; r < 4; ++r) RT[(u0 + r) * S + i + 16 * nt] = v[r];
+        } else if (!(l & 1)) {
+          gpre = tr_dact4_mul(GBNF_ACT_RELU, h, v);   // through the relu between a block's two Linears
+        } else {
+          // through a block's entry relu, plus the skip connection: d/dt in front of the block
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const lfp rt = RT + (u0 + r) * S + i + 16 * nt;
+            gpre[r] = *rt + (h[r] > 0.0f ? v[r] : 0.0f);
+            *rt = gpre[r];
+          }
+        }
         Hl.put4(i + 16 * nt, u0, gpre);
 #pragma unroll
         for (int r = 0; r < 4; ++r) ws_d[((size_t)nt * p.hp + u0 + r) * 16] = gpre[r];
@@ -1110,6 +1148,7 @@ struct gbnf_trainer {
   u32x4* frag_dev = nullptr;           // split-f16 weight fragments, rebuilt by prep_kernel at the start of every call
   int n_probs = 0, wg_blocks = 0, n_prep = 0, prep_blocks = 0;
   int hw = 0, xw = 0, ow = 0;
+  int residual = 0;                    // ResidualNet coupling networks
   int batch_stats = 0;                 // BatchNorm on batch statistics (the reference's train() mode)
   std::vector<int> has_norm;           // per step
   std::vector<char> stats_bound;       // per step: bmean / bvar bound by the caller
@@ -1162,14 +1201,14 @@ int gbnf_trainer_create(const gbnf_flow_desc* desc, gbnf_trainer** out) {
   const int d1 = d / 2, d2 = d - d1;
   const gbnf_net& n0 = glow ? desc->glow_steps[0].block : desc->realnvp_steps[0].t_net;
   const int h = n0.layers[0].out_features, nl = n0.n_layers;
-  if (n0.activation == GBNF_ACT_RESIDUAL_RELU)
-    return fail(GBNF_ERR_UNSUPPORTED, "gbnf_trainer_create: ResidualNet coupling networks are evaluation-only");
+  const bool residual = n0.activation == GBNF_ACT_RESIDUAL_RELU;
   if (nl > TR_MAX_LAYERS) return fail(GBNF_ERR_UNSUPPORTED, "gbnf_trainer_create: %d Linear layers per net > %d", nl, TR_MAX_LAYERS);
   if (d2 > TR_MAX_IN) return fail(GBNF_ERR_UNSUPPORTED, "gbnf_trainer_create: half width %d > %d", d2, TR_MAX_IN);
 
   gbnf_trainer* t = new gbnf_trainer();
   t->kind = desc->kind; t->d = d; t->K = K; t->additive = additive ? 1 : 0;
   t->nnets = glow ? 1 : 2;
+  t->residual = residual ? 1 : 0;
   t->n_hidden = nl - 1;
   t->hp = ceil16(h);
   t->ip = ceil16(d2);
@@ -1180,7 +1219,7 @@ int gbnf_trainer_create(const gbnf_flow_desc* desc, gbnf_trainer** out) {
     delete t;
     return fail(GBNF_ERR_UNSUPPORTED, "gbnf_trainer_create: hidden width %d > %d", h, TR_MAX_HIDDEN);
   }
-  const size_t common = (size_t)d + (size_t)t->ip + 2 * (size_t)t->op;            // f32 rows: state, GX, O, O2
+  const size_t common = (size_t)d + (size_t)t->ip + 2 * (size_t)t->op + (residual ? t->hp : 0);   // f32 rows: state, GX, O, O2, (RT)
   const size_t tables = (size_t)K * (384 + 2 * TR_MAX_LAYERS * 8 + 8) * 4;
   for (int nt = 1; nt <= TR_MAX_NT; ++nt) {
     const size_t S = 16 * nt + 1;
@@ -1243,7 +1282,7 @@ int gbnf_trainer_create(const gbnf_flow_desc* desc, gbnf_trainer** out) {
     for (int j = 0; j < out_f; ++j) st.out_slot[j] = sigma[in_f + j];
     for (int q = 0; q < t->nnets; ++q) {
       TrNet& net = st.net[q];
-      net.n_layers = nl; net.act = nets[q]->activation;
+      net.n_layers = nl; net.act = residual ? GBNF_ACT_RELU : nets[q]->activation;
       const int64_t base_row = ((int64_t)s * t->nnets + q) * t->net_rows;
       for (int l = 0; l < nl; ++l) {
         const gbnf_linear& lin = nets[q]->layers[l];
@@ -1363,6 +1402,7 @@ static void fill_launch(const gbnf_trainer* t, TrainLaunch& p, const float* x, i
   p.steps = t->steps_dev; p.tail = t->tail_dev; p.x = x;
   p.n = n; p.np = tr_padded(n);
   p.d = t->d; p.K = t->K; p.kind = t->kind; p.additive = t->additive;
+  p.residual = t->residual;
   p.n_hidden = t->n_hidden; p.hp = t->hp; p.ip = t->ip; p.op = t->op; p.net_rows = t->net_rows;
   p.hw = t->hw; p.xw = t->xw; p.ow = t->ow; p.frag = t->frag_dev;
   p.k_begin = 0; p.k_end = t->K;

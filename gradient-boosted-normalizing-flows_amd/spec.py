@@ -145,7 +145,7 @@ def activation_pattern_of_component(module):
 # ------------------------------------------------------------------ live (device) view for the training path
 def _dev_net(seq_owner):
     if hasattr(seq_owner, "initial_layer"):
-        raise NotImplementedError("ResidualNet coupling networks are evaluation-only (no training kernels)")
+        return {"act": "residual", "layers": [(m.weight, m.bias) for m in linears_of(seq_owner)]}
     layers, act = [], None
     for m in seq_owner.network:
         cls = type(m).__name__

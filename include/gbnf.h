@@ -46,7 +46,7 @@ enum { GBNF_KIND_GLOW = 0, GBNF_KIND_REALNVP = 1 };
  * RESIDUAL_RELU: ResidualNet (models/layers.py:246-301) of B = coupling_network_depth blocks, n_layers = 2 + 2 B Linear
  * layers in the order initial_layer, (blocks[b].linear_layers[0], blocks[b].linear_layers[1]) for b < B, final_layer:
  *     t = initial(x);  t += lin1_b(relu(lin0_b(relu(t)))) for every block;  out = final(t)
- * Evaluation and the inverse direction (exact-f32 kernel, B <= 2); not the training entry points. */
+ * Evaluation and the inverse direction on the exact-f32 kernel, training on gbnf_trainer_* (B <= 2). */
 enum { GBNF_ACT_TANH = 0, GBNF_ACT_RELU = 1, GBNF_ACT_RESIDUAL_RELU = 2 };
 enum { GBNF_COUPLING_AFFINE = 0, GBNF_COUPLING_ADDITIVE = 1 };
 /* How the coupling-network matrix products are evaluated (results agree to ~1e-6 relative in log-likelihood):

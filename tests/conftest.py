@@ -45,7 +45,8 @@ def load_image_case(name):
     return cfg, specs, x, noise, data
 
 
-GRADS_CASES = ("g10_glow_grads_d43_h64", "g10_glow_grads_additive_relu_d8", "g10_realnvp_grads_d21_h32")
+GRADS_CASES = ("g10_glow_grads_d43_h64", "g10_glow_grads_additive_relu_d8", "g10_realnvp_grads_d21_h32",
+               "g10_realnvp_residual_grads_d21_h32")
 
 
 def load_train_bn_case():

@@ -378,9 +378,8 @@ def _ref_params_in_flat_order(component, kind):
             bn = mods[2] if len(mods) > 2 else None
             out += [None, None] if bn is None else [bn.log_gamma, bn.beta]
             for net in (mods[0], mods[1]):
-                for m in net.network:
-                    if isinstance(m, torch.nn.Linear):
-                        out += [m.weight, m.bias]
+                for m in gspec.linears_of(net):
+                    out += [m.weight, m.bias]
     return out
 
 
@@ -583,6 +582,7 @@ def main():
         grads_case("g10_glow_grads_d43_h64", "glow", 43, 64, 3, 96)
         grads_case("g10_glow_grads_additive_relu_d8", "glow", 8, 40, 3, 50, coupling="additive", act="relu")
         grads_case("g10_realnvp_grads_d21_h32", "realnvp", 21, 32, 4, 80)
+        grads_case("g10_realnvp_residual_grads_d21_h32", "realnvp", 21, 32, 3, 80, coupling_network="residual")
         return
     if "--residual-only" in sys.argv:
         synth_case("g14_realnvp_residual_d21_h64_c2", "realnvp", 21, 64, 4, 2, 128, coupling_network="residual")
@@ -616,6 +616,7 @@ def main():
     grads_case("g10_glow_grads_d43_h64", "glow", 43, 64, 3, 96)
     grads_case("g10_glow_grads_additive_relu_d8", "glow", 8, 40, 3, 50, coupling="additive", act="relu")
     grads_case("g10_realnvp_grads_d21_h32", "realnvp", 21, 32, 4, 80)
+    grads_case("g10_realnvp_residual_grads_d21_h32", "realnvp", 21, 32, 3, 80, coupling_network="residual")
     grads_train_bn_case("g10_realnvp_grads_train_bn_d21_h32")
     toy_case("g1_toy_realnvp_c2")
     native_glow_case("g2_glow_native_d43_h32_c3")

@@ -110,7 +110,7 @@ def _args(kind, d, h, K, C, dev, **kw):
         rho_init="decreasing", learn_top=False, y_classes=0, y_condition=False, sample_size=4, input_size=[d], h_size=h,
         num_blocks=1, actnorm_scale=1.0, flow_permutation=kw.get("permutation", "shuffle"),
         flow_coupling=kw.get("coupling", "affine"), LU_decomposed=False, num_dequant_blocks=0,
-        coupling_network=kw.get("act", "tanh"), coupling_network_depth=kw.get("depth", 1),
+        coupling_network=kw.get("act", kw.get("coupling_network", "tanh")), coupling_network_depth=kw.get("depth", 1),
         batch_norm=kw.get("batch_norm", True))
 
 
@@ -286,6 +286,10 @@ def _random_train_cases():
     # `--coupling_network random`: the activation changes from step to step (Glow) / net to net (RealNVP)
     cases.append(("glow", 21, 64, 6, 100, dict(act="random", coupling="affine", permutation="shuffle", depth=1), 954))
     cases.append(("realnvp", 13, 33, 6, 65, dict(coupling_network="random", batch_norm=True, flip_init=0, depth=1), 955))
+    # ResidualNet coupling networks (1 and 2 blocks)
+    cases.append(("realnvp", 21, 64, 3, 100, dict(coupling_network="residual", batch_norm=True, flip_init=1, depth=1), 956))
+    cases.append(("realnvp", 21, 215, 2, 2049, dict(coupling_network="residual", batch_norm=False, flip_init=0, depth=1), 957))
+    cases.append(("realnvp", 8, 40, 3, 77, dict(coupling_network="residual", batch_norm=True, flip_init=0, depth=2), 958))
     return cases
 
 
