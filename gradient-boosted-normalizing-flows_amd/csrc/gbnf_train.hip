@@ -151,9 +151,6 @@ __device__ __forceinline__ f32x4 tr_dact4_mul(int act, f32x4 h, f32x4 v) {   // 
   }
   return o;
 }
-__device__ __forceinline__ f32x4 tr_mfma(float a, float b, f32x4 c) {
-  return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
-}
 // Accumulators are read right behind a loop exit: the compiler's MFMA-result hazard padding does not look across that
 // branch on gfx950 / ROCm 7.2 (same finding as in gbnf_flow_kernel.hip.h: the last k-step went missing), so pad by hand.
 // The accumulators are operands of the padding ("+a": they stay in AGPRs), so every read of them is ordered behind it.
@@ -897,9 +894,9 @@ __global__ void __launch_bounds__(64 * TR_WAVES) train_kernel(const TrainLaunch 
 
 // ---------------------------------------------------------------------------------------------------------------
 // Weight / bias gradients: C (M x N, row-major) += D (M rows of np samples) . A (N rows of np samples)^T, bias += row sums of D.
-// One wave = one 64 x 64 block of C (16 accumulator tiles) over one chunk of samples; k-step r of a 16-sample group
-// uses samples s0+4g+r, so each operand fragment is ONE 16-byte load per lane.  Branch-free: operand rows past the
-// padded matrix belong to the next workspace region (finite numbers) and only feed output rows that are never stored.
+// One wave = one 64 x 64 block of C (16 accumulator tiles) over one chunk of samples (see wgrad_kernel below for the
+// operand layout).  Branch-free: operand rows past the padded matrix belong to the next workspace region and only feed
+// output rows / columns that are never stored.
 // ---------------------------------------------------------------------------------------------------------------
 struct WgProblem {
   int64_t d_row, a_row;   // first row (of np floats) of the two operands' sub-regions in the workspace
