@@ -370,7 +370,9 @@ class BoostedFlow(nn.Module):
         c = self._sample_component(components) if isinstance(components, str) else int(components)
         z, ldj = self.component_forward(x, c)
         flow = self.flows[c]
-        h = flow.prior_h.repeat(x.shape[0], 1)     # Glow.prior / RealNVPFlow.prior: zeros, returned as-is
+        # Glow.prior / RealNVPFlow.prior: prior_h (zeros) repeated over the batch, returned as-is -- as a broadcast VIEW
+        # here (same values and shapes, no copy kernel per call)
+        h = flow.prior_h.expand(x.shape[0], -1)
         z_mu, z_var = h[:, : self.z_size], h[:, self.z_size:]
         return z, z_mu, z_var, ldj, None
 
