@@ -81,6 +81,11 @@ class Permute2d(nn.Module):
         if shuffle:
             self.indices = self.indices[torch.randperm(num_dim)]
 
+    def __setattr__(self, name, value):
+        if name == "indices":        # every (re)assignment gets a new serial number: the handle keys use it
+            object.__setattr__(self, "indices_serial", getattr(self, "indices_serial", 0) + 1)
+        super().__setattr__(name, value)
+
     def set_indices(self, indices):
         idx = torch.as_tensor(np.asarray(indices), dtype=torch.long).clone()
         if idx.shape != (self.num_dim,) or sorted(idx.tolist()) != list(range(self.num_dim)):
@@ -336,12 +341,27 @@ class BoostedImageFlow(nn.Module):
             return int(torch.multinomial(simplex / simplex.sum(), 1, replacement=True).item())
         raise ValueError("z_k can only be sampled from ['c', '1:c-1', '1:c', '-c']")
 
+    def _component_tensors(self, c):
+        """(parameters, buffers, Permute2d modules, ActNorm modules) of component c, collected once: walking the module
+        tree per call costs about as much as a small launch.  `_apply` (.to / .cuda / .float) drops the cache."""
+        cache = self.__dict__.setdefault("_tensor_cache", {})
+        if c not in cache:
+            flow = self.flows[c]
+            cache[c] = (list(flow.parameters()), list(flow.buffers()),
+                        [m for m in flow.modules() if isinstance(m, Permute2d)], list(flow._actnorms()))
+        return cache[c]
+
+    def _apply(self, fn, *a, **k):
+        self.__dict__.pop("_tensor_cache", None)
+        return super()._apply(fn, *a, **k)
+
     def native_flow(self, c):
         flow = self.flows[c]
-        key = tuple(int(t._version) for t in list(flow.parameters()) + list(flow.buffers())) + \
-            tuple(t.data_ptr() for t in flow.parameters()) + \
-            tuple(tuple(m.indices.tolist()) for m in flow.modules() if isinstance(m, Permute2d)) + \
-            tuple(bool(m.inited) for m in flow._actnorms())
+        params, buffers, perms, actnorms = self._component_tensors(c)
+        key = tuple(int(t._version) for t in params) + tuple(int(t._version) for t in buffers) + \
+            tuple(t.data_ptr() for t in params) + \
+            tuple((m.indices_serial, int(m.indices._version)) for m in perms) + \
+            tuple(bool(m.inited) for m in actnorms)
         cached = self._handles.get(c)
         if cached is None or cached[0] != key:
             self._handles[c] = (key, native.NativeImageFlow(image_spec_from_glow_module(flow)))
@@ -368,11 +388,14 @@ class BoostedImageFlow(nn.Module):
             raise NotImplementedError("sampling from image components is not on the supported path")
         c = self._sample_component(components) if isinstance(components, str) else int(components)
         zz, ldj, _ = self.component_forward(x, c)
-        mu, lv = self.native_flow(c).prior()
+        handle = self.native_flow(c)
+        prior = handle.__dict__.get("_prior_dev")            # (mean, logvar) of the top prior on the device, per handle
+        if prior is None or prior[0].device != x.device:
+            mu, lv = handle.prior()
+            prior = (torch.from_numpy(mu).to(x.device).view(1, -1, 1, 1), torch.from_numpy(lv).to(x.device).view(1, -1, 1, 1))
+            handle.__dict__["_prior_dev"] = prior
         shape = (x.shape[0],) + tuple(zz.shape[1:])
-        z_mu = torch.from_numpy(mu).to(x.device).view(1, -1, 1, 1).expand(shape).contiguous()
-        z_var = torch.from_numpy(lv).to(x.device).view(1, -1, 1, 1).expand(shape).contiguous()
-        return zz, z_mu, z_var, ldj, None
+        return zz, prior[0].expand(shape), prior[1].expand(shape), ldj, None      # broadcast views: same values, no copies
 
     def component_log_prob(self, x, n_used=None, noise=None):
         """(N, C_used): ll_c = log_normal_diag(z, z_mu, z_var) + logdet (image_experiment.py:227); the SAME noise for every
