@@ -1499,7 +1499,10 @@ int gbnf_trainer_backward(const gbnf_trainer* t, const float* x, int64_t n, cons
   p.batch_stats = t->batch_stats;
   float* gstate = (float*)workspace + ((int64_t)t->K * t->nnets * t->net_rows + 64) * p.np;   // [d][np]: gradient state between step launches
   hipStream_t s = (hipStream_t)stream;
-  hipLaunchKernelGGL(prep_kernel, dim3((unsigned)t->prep_blocks), dim3(64), 0, s, (const PrepProblem*)t->prep_dev, t->n_prep, t->frag_dev);
+  // a trace is valid only while the parameters are what they were in the forward call that wrote it (include/gbnf.h):
+  // that call split them into this trainer's fragment buffer, so the fragments are still the right ones
+  if (trace == nullptr)
+    hipLaunchKernelGGL(prep_kernel, dim3((unsigned)t->prep_blocks), dim3(64), 0, s, (const PrepProblem*)t->prep_dev, t->n_prep, t->frag_dev);
   if (!needs_step_launches(t)) {
     launch_train<1>(t, p, s);
   } else {

@@ -228,7 +228,8 @@ int gbnf_trainer_destroy(gbnf_trainer* trainer);
 
 /* z, ldj = flows[c](x) on the live parameters (same semantics and outputs as gbnf_flow_forward).  `trace` (optional,
  * gbnf_trainer_trace_floats(n) floats of DEVICE memory) receives every step's normalised state; handing it to
- * gbnf_trainer_backward saves that call the forward sweep (valid only while the parameters are unchanged). */
+ * gbnf_trainer_backward saves that call the forward sweep and the re-splitting of the weights (valid only while the
+ * parameters are unchanged and no other forward call of this trainer ran on changed parameters in between). */
 int gbnf_trainer_trace_floats(const gbnf_trainer* trainer, int64_t n, int64_t* n_floats);
 int gbnf_trainer_forward(const gbnf_trainer* trainer, const float* x, int64_t n, float* z, float* ldj, float* trace,
                          void* stream);
