@@ -704,10 +704,13 @@ __global__ void __launch_bounds__(64 * TR_WAVES) train_kernel(const TrainLaunch 
           if (p.additive) {
             Zc[slot * S + ii] = y2 + O[j * S + ii];                                  // models/glow.py:328-329
           } else {
-            const float e = __expf(-(O[(2 * j + 1) * S + ii] + 2.0f));              // scale = sigmoid(raw + 2)
-            const float sc = 1.0f / (1.0f + e);
+            // scale = sigmoid(raw + 2) and log(scale) from one exponential, as the evaluation kernels do
+            // (sigmoid_logsigmoid in gbnf_flow_kernel.hip.h): e = exp(-(raw + 2)), scale = 1 / (1 + e), log = -log(1 + e)
+            const float e = __builtin_amdgcn_exp2f((O[(2 * j + 1) * S + ii] + 2.0f) * -1.4426950408889634f);
+            const float s1 = 1.0f + e;
+            const float sc = __builtin_amdgcn_rcpf(s1);
             Zc[slot * S + ii] = (y2 + O[(2 * j) * S + ii]) * sc;                     // models/glow.py:333-336
-            ld[nt] += -log1pf(e);                                                    // log(scale), models/glow.py:338
+            ld[nt] += -0.69314718055994531f * __builtin_amdgcn_logf(s1);             // log(scale), models/glow.py:338
           }
         }
       }
