@@ -119,8 +119,8 @@ def measured_traffic(config, B, C, S, f16x3, world):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=200)
-    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--steps", type=int, default=1000)
+    ap.add_argument("--warmup", type=int, default=50)
     ap.add_argument("--config", default="miniboone_glow", choices=sorted(CONFIGS))
     ap.add_argument("--batch", type=int, default=None)
     ap.add_argument("--components", type=int, default=None)
