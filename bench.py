@@ -14,8 +14,8 @@ N > 1: the C components are sharded over the ranks (contiguous blocks, C/N each)
 one RCCL all-gather of float32[C/N, batch] per rank per step rebuilds (C, batch) before the
 recursion; total work is fixed => "scaling": "strong".
 
-Timing: `--prewarm` seconds (default 0.3, reported as "prewarm_s") of untimed launches let the clocks of a cold GPU
-settle, then W untimed warm-up steps, then exactly K timed steps between barriers + device synchronisations.
+Timing: 2000 x `--prewarm` (default 0.3, reported as "prewarm_s": about that many seconds on one GPU) untimed steps let
+the clocks of a cold GPU settle, then W untimed warm-up steps, then exactly K timed steps between barriers + device synchronisations.
 
 Prints ONE JSON line on rank 0 (see the driver contract), including
   "roofline":     dominant kernel (the fused flow kernel) against the dense f32-MFMA peak
@@ -124,7 +124,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=1000)
     ap.add_argument("--warmup", type=int, default=50)
-    ap.add_argument("--prewarm", type=float, default=0.3, help="seconds of untimed launches before the warm-up steps (clock ramp)")
+    ap.add_argument("--prewarm", type=float, default=0.3, help="untimed launches before the warm-up steps (clock ramp): 2000 steps per unit, i.e. about this many seconds on one GPU")
     ap.add_argument("--config", default="miniboone_glow", choices=sorted(CONFIGS))
     ap.add_argument("--batch", type=int, default=None)
     ap.add_argument("--components", type=int, default=None)
@@ -145,6 +145,8 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if rank != 0:          # only rank 0 reports: nothing another rank (or a library it loads) writes may follow the JSON line
+        os.dup2(os.open(os.devnull, os.O_WRONLY), 1)
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
     if not torch.cuda.is_available():
@@ -247,10 +249,8 @@ def main():
 
     # clock settle phase (untimed, on top of the W warm-up steps, reported as "prewarm_s"): a cold MI355X runs the first
     # few hundred steps ~10 % slower while its clocks ramp up; the timed region is meant to see the steady state
-    t_pre = time.perf_counter()
-    while time.perf_counter() - t_pre < args.prewarm:
-        run(S, False)
-        torch.cuda.synchronize()
+    # (a FIXED number of steps: every rank must issue the same collectives)
+    run(int(args.prewarm * 2000) // S * S, False)
     run(args.warmup, False)
     barrier()
     t0 = time.perf_counter()
@@ -310,10 +310,22 @@ def main():
             out["max_rel_err_vs_cpu"] = err
         elif args.cpu_seconds > 0:
             out["cpu_baseline"] = None     # reported on the N=1 run only
-        print(json.dumps(out), flush=True)
+        line = json.dumps(out)
+    else:
+        line = None
 
+    # RCCL writes a version banner to (C-level, buffered) stdout: tear the process group down and flush that buffer first,
+    # so that the JSON line is the LAST line on stdout
     if dist.is_initialized():
+        dist.barrier()
         dist.destroy_process_group()
+    sys.stdout.flush()
+    try:
+        ctypes.CDLL(None).fflush(None)       # ... its banner sits in the C library's stdout buffer until then
+    except OSError:
+        pass
+    if line is not None:
+        print(line, flush=True)
 
 
 if __name__ == "__main__":
