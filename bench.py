@@ -137,6 +137,8 @@ def main():
                     help="batches served per launch / per all-gather (0 = auto: 8..16, max 16)")
     args = ap.parse_args()
 
+    # dmabuf IPC is the only form the host driver supports (without it RCCL fails with hipIpcGetMemHandle: invalid argument)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     import numpy as np
     import torch
     import torch.distributed as dist
