@@ -107,6 +107,7 @@ struct TrainLaunch {
   float* gstate_out;         // MODE 1: gradient w.r.t. the state before step k_begin (null: g_x, row-major)
   const float* g_z;    // MODE 1 (n, d) or null
   const float* g_ldj;  // MODE 1 (n,) or null
+  const unsigned* gmax;  // MODE 1: bits of max(|g_z|, |g_ldj|) over the batch (gmax_kernel): fixes the gradient scale
   float* g_x;          // MODE 1 (n, d) or null
   float* grads;        // MODE 1 flat parameter-gradient buffer
   unsigned long long* dbg;   // diagnostic builds only
@@ -404,6 +405,34 @@ __device__ __forceinline__ void tr_dense(gfrag A, gptr bias, int kc32, int frag_
   stamps.mark(6);
   tr_lds_barrier();    // the layer's output (LDS) is complete for every wave
   stamps.mark(7);
+}
+
+// ---- gradient scaling.  The split-f16 operands carry f32 accuracy only for magnitudes between ~0.1 and 65504 (the mid
+// piece of a smaller value is an fp16 subnormal: absolute floor 2^-24).  Activations are O(1) by construction; gradients
+// are as large as the caller's loss makes them (a mean over 65536 samples hands in 1.5e-5 per sample).  The backward
+// pass is linear in the upstream gradient, so it runs on alpha * gradient with alpha = the power of two that puts the
+// largest upstream entry of the batch at 2^8, and every result (g_x, parameter gradients) is multiplied by 1 / alpha --
+// exact scalings.  gmax_kernel finds that largest entry (non-negative floats order like their bit patterns).
+__device__ __forceinline__ void tr_grad_scale(unsigned max_bits, float& alpha, float& inv_alpha) {
+  const int e = (int)((max_bits >> 23) & 255u);          // biased exponent of the largest |upstream gradient|
+  if (max_bits == 0u || e == 255) { alpha = 1.0f; inv_alpha = 1.0f; return; }
+  int k = 8 - (e - 127);                                   // alpha = 2^k
+  k = k > 100 ? 100 : (k < -100 ? -100 : k);
+  alpha = __builtin_bit_cast(float, (unsigned)(k + 127) << 23);
+  inv_alpha = __builtin_bit_cast(float, (unsigned)(127 - k) << 23);
+}
+
+__global__ void __launch_bounds__(256) gmax_kernel(const float* __restrict__ g_z, const float* __restrict__ g_ldj, int64_t n, int d,
+                                                   unsigned* __restrict__ out) {
+  unsigned m = 0u;
+  const int64_t stride = (int64_t)gridDim.x * 256, t0 = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (g_z != nullptr)
+    for (int64_t e = t0; e < n * d; e += stride) m = max(m, __builtin_bit_cast(unsigned, g_z[e]) & 0x7fffffffu);
+  if (g_ldj != nullptr)
+    for (int64_t e = t0; e < n; e += stride) m = max(m, __builtin_bit_cast(unsigned, g_ldj[e]) & 0x7fffffffu);
+#pragma unroll
+  for (int s = 1; s < 64; s <<= 1) m = max(m, (unsigned)__shfl_xor((int)m, s));
+  if ((threadIdx.x & 63) == 0 && m != 0u) atomicMax(out, m);
 }
 
 __device__ __forceinline__ float tr_group_sum(float v) {   // sum over the 16 lanes of a lane group (all active)
@@ -760,19 +789,21 @@ __global__ void __launch_bounds__(64 * TR_WAVES) train_kernel(const TrainLaunch 
 #endif
     return;
   } else {
-    // =============================== backward
+    // =============================== backward (on alpha * the upstream gradient, see tr_grad_scale)
     tr_lds_barrier();
+    float alpha = 1.0f, inv_alpha = 1.0f;
+    if (p.gmax != nullptr) tr_grad_scale(__builtin_amdgcn_readfirstlane(*p.gmax), alpha, inv_alpha);
     float gl[NT];
     TR_NT {
       const int64_t r = row0 + i + 16 * nt;
-      gl[nt] = (r < p.n && p.g_ldj != nullptr) ? p.g_ldj[r] : 0.0f;
+      gl[nt] = (r < p.n && p.g_ldj != nullptr) ? p.g_ldj[r] * alpha : 0.0f;
     }
     if (p.gstate_in != nullptr) {
       for (int s = g; s < d; s += GS) TR_NT Zc[s * S + i + 16 * nt] = p.gstate_in[(size_t)s * p.np + row0 + i + 16 * nt];
     } else {
       for (int j = g; j < d; j += GS) TR_NT {
         const int64_t r = row0 + i + 16 * nt;
-        Zc[p.tail[j] * S + i + 16 * nt] = (r < p.n && p.g_z != nullptr) ? p.g_z[r * d + j] : 0.0f;
+        Zc[p.tail[j] * S + i + 16 * nt] = (r < p.n && p.g_z != nullptr) ? p.g_z[r * d + j] * alpha : 0.0f;
       }
     }
     tr_lds_barrier();
@@ -800,8 +831,8 @@ __global__ void __launch_bounds__(64 * TR_WAVES) train_kernel(const TrainLaunch 
       ga = tr_group_sum(ga);
       gb = tr_group_sum(gb);
       if (i == 0) {
-        atomicAdd(p.grads + st.g_na + f, ga);
-        atomicAdd(p.grads + st.g_nb + f, gb);
+        atomicAdd(p.grads + st.g_na + f, ga * inv_alpha);
+        atomicAdd(p.grads + st.g_nb + f, gb * inv_alpha);
       }
     };
 
@@ -888,7 +919,7 @@ __global__ void __launch_bounds__(64 * TR_WAVES) train_kernel(const TrainLaunch 
       if (p.gstate_out != nullptr) {
         for (int s = g; s < d; s += GS) p.gstate_out[(size_t)s * p.np + r] = G[s * S + ii];
       } else if (r < p.n && p.g_x != nullptr) {
-        for (int j = g; j < d; j += GS) p.g_x[r * d + j] = G[j * S + ii];
+        for (int j = g; j < d; j += GS) p.g_x[r * d + j] = G[j * S + ii] * inv_alpha;
       }
     }
   }
@@ -928,8 +959,11 @@ __device__ __forceinline__ void wg_split8(f32x4 lo, f32x4 hi4, u32x4& h, u32x4& 
 // accumulation): one k = 32 step = 32 samples = two 16-sample tiles of the workspace; lane (i, g) of an operand
 // fragment holds samples 8 (g & 1) .. + 7 of tile (g >> 1) of row i -- 32 contiguous bytes, split in registers.
 __global__ void __launch_bounds__(64) wgrad_kernel(const WgProblem* __restrict__ probs, int n_probs,
-                                                   const float* __restrict__ ws, float* __restrict__ grads, int64_t np, int chunk) {
+                                                   const float* __restrict__ ws, float* __restrict__ grads, int64_t np, int chunk,
+                                                   const unsigned* __restrict__ gmax) {
   typedef const f32x4 __attribute__((address_space(1)))* gv4;
+  float alpha = 1.0f, inv_alpha = 1.0f;          // the gradient-side operands were emitted on the scaled gradient
+  if (gmax != nullptr) tr_grad_scale(__builtin_amdgcn_readfirstlane(*gmax), alpha, inv_alpha);
   const int lane = threadIdx.x, i = lane & 15, g = lane >> 4;
   int pi = 0;
   while (pi + 1 < n_probs && (int)blockIdx.x >= probs[pi + 1].blk_begin) ++pi;
@@ -1011,7 +1045,7 @@ __global__ void __launch_bounds__(64) wgrad_kernel(const WgProblem* __restrict__
 #pragma unroll
       for (int y = 0; y < 4; ++y) {
         const int n = n0 + 16 * y + i;
-        if (m < P.M && n < P.N) atomicAdd(C + (size_t)m * P.N + n, acc[x][y][r]);
+        if (m < P.M && n < P.N) atomicAdd(C + (size_t)m * P.N + n, acc[x][y][r] * inv_alpha);
       }
     }
   if (n0 == 0) {     // db[m] = sum over samples of D[m][.]: lane (i,g) holds row m0+16x+i, fold r, then the 4 lane groups
@@ -1021,7 +1055,7 @@ __global__ void __launch_bounds__(64) wgrad_kernel(const WgProblem* __restrict__
       v += __shfl_xor(v, 16);
       v += __shfl_xor(v, 32);
       const int m = m0 + 16 * x + i;
-      if (g == 0 && m < P.M) atomicAdd(grads + P.b_off + m, v);
+      if (g == 0 && m < P.M) atomicAdd(grads + P.b_off + m, v * inv_alpha);
     }
   }
 }
@@ -1033,10 +1067,13 @@ __global__ void __launch_bounds__(256) rows_to_slots_kernel(const float* __restr
   if (s >= np) return;
   for (int j = 0; j < d; ++j) st[(size_t)j * np + s] = s < n ? x[s * d + j] : 0.0f;
 }
-__global__ void __launch_bounds__(256) slots_to_rows_kernel(const float* __restrict__ st, float* __restrict__ x, int64_t n, int64_t np, int d) {
+__global__ void __launch_bounds__(256) slots_to_rows_kernel(const float* __restrict__ st, float* __restrict__ x, int64_t n, int64_t np, int d,
+                                                            const unsigned* __restrict__ gmax) {
   const int64_t s = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (s >= n) return;
-  for (int j = 0; j < d; ++j) x[s * d + j] = st[(size_t)j * np + s];
+  float alpha = 1.0f, inv_alpha = 1.0f;          // the gradient state travels scaled (tr_grad_scale)
+  if (gmax != nullptr) tr_grad_scale(*gmax, alpha, inv_alpha);
+  for (int j = 0; j < d; ++j) x[s * d + j] = st[(size_t)j * np + s] * inv_alpha;
 }
 
 __device__ __forceinline__ float tr_block_sum(float v, float* red) {
@@ -1073,7 +1110,9 @@ __global__ void __launch_bounds__(256) bn_stats_kernel(const TrStep* __restrict_
 // (which treated mean / var as constants):   g_x -= (gamma / sigma) * S1 / n  +  x_hat / (sigma (n - 1)) * S2,
 // S1 = sum g_y = d/d beta,  S2 = gamma sum g_y x_hat + sum g_ldj = d/d log_gamma -- both already in `grads`.
 __global__ void __launch_bounds__(256) bn_bwd_fix_kernel(const TrStep* __restrict__ steps, int k, int d, const float* __restrict__ trace, const float* __restrict__ grads,
-                                                         float* __restrict__ gst, int64_t n, int64_t np) {
+                                                         float* __restrict__ gst, int64_t n, int64_t np, const unsigned* __restrict__ gmax) {
+  float alpha = 1.0f, inv_alpha = 1.0f;          // gst is the SCALED gradient state, S1 / S2 come from the (unscaled) gradient buffer
+  if (gmax != nullptr) tr_grad_scale(*gmax, alpha, inv_alpha);
   const TrStep& S = steps[k];
   const int slot = blockIdx.y, f = S.feat[slot];
   const int64_t s = (int64_t)blockIdx.x * 256 + threadIdx.x;
@@ -1081,7 +1120,7 @@ __global__ void __launch_bounds__(256) bn_bwd_fix_kernel(const TrStep* __restric
   const float gamma = __expf(S.na[f]), beta = S.nb[f], sigma = sqrtf(S.bvar[f] + S.eps);
   const float s1 = grads[S.g_nb + f], s2 = grads[S.g_na + f];
   const float xhat = (trace[((size_t)k * d + slot) * np + s] - beta) / gamma;
-  gst[(size_t)slot * np + s] -= gamma / sigma * s1 / (float)n + xhat / (sigma * (float)(n - 1)) * s2;
+  gst[(size_t)slot * np + s] -= alpha * (gamma / sigma * s1 / (float)n + xhat / (sigma * (float)(n - 1)) * s2);
 }
 
 // Split every Linear's LIVE f32 weight into f16x3 MFMA A fragments, both orientations, one launch: a 64-thread block
@@ -1149,6 +1188,7 @@ struct gbnf_trainer {
   int n_probs = 0, wg_blocks = 0, n_prep = 0, prep_blocks = 0;
   int hw = 0, xw = 0, ow = 0;
   int residual = 0;                    // ResidualNet coupling networks
+  unsigned* gmax_dev = nullptr;        // bits of the largest |upstream gradient| of the current backward call (gradient scaling)
   int batch_stats = 0;                 // BatchNorm on batch statistics (the reference's train() mode)
   std::vector<int> has_norm;           // per step
   std::vector<char> stats_bound;       // per step: bmean / bvar bound by the caller
@@ -1347,6 +1387,7 @@ int gbnf_trainer_create(const gbnf_flow_desc* desc, gbnf_trainer** out) {
   if (e == hipSuccess) e = hipMalloc((void**)&t->prep_dev, sizeof(PrepProblem) * preps.size());
   if (e == hipSuccess) e = hipMemcpy(t->prep_dev, preps.data(), sizeof(PrepProblem) * preps.size(), hipMemcpyHostToDevice);
   if (e == hipSuccess) e = hipMalloc((void**)&t->frag_dev, (size_t)frag_off * 16);
+  if (e == hipSuccess) e = hipMalloc((void**)&t->gmax_dev, sizeof(unsigned));
   if (e == hipSuccess) {
     const void* fns[8] = {(const void*)train_kernel<GBNF_KIND_GLOW, 0, 1>, (const void*)train_kernel<GBNF_KIND_GLOW, 1, 1>,
                           (const void*)train_kernel<GBNF_KIND_REALNVP, 0, 1>, (const void*)train_kernel<GBNF_KIND_REALNVP, 1, 1>,
@@ -1370,6 +1411,7 @@ int gbnf_trainer_destroy(gbnf_trainer* t) {
   if (t->probs_dev) (void)hipFree(t->probs_dev);
   if (t->prep_dev) (void)hipFree(t->prep_dev);
   if (t->frag_dev) (void)hipFree(t->frag_dev);
+  if (t->gmax_dev) (void)hipFree(t->gmax_dev);
   delete t;
   return GBNF_OK;
 }
@@ -1502,6 +1544,14 @@ int gbnf_trainer_backward(const gbnf_trainer* t, const float* x, int64_t n, cons
   p.batch_stats = t->batch_stats;
   float* gstate = (float*)workspace + ((int64_t)t->K * t->nnets * t->net_rows + 64) * p.np;   // [d][np]: gradient state between step launches
   hipStream_t s = (hipStream_t)stream;
+  // the scale of this call's gradients: the largest upstream entry (tr_grad_scale)
+  (void)hipMemsetAsync(t->gmax_dev, 0, sizeof(unsigned), s);
+  {
+    const int64_t work = n * (g_z ? t->d : 1);
+    const unsigned gb = (unsigned)((work + 256 * 16 - 1) / (256 * 16) < 1024 ? (work + 256 * 16 - 1) / (256 * 16) : 1024);
+    hipLaunchKernelGGL(gmax_kernel, dim3(gb ? gb : 1), dim3(256), 0, s, g_z, g_ldj, n, t->d, t->gmax_dev);
+  }
+  p.gmax = t->gmax_dev;
   // a trace is valid only while the parameters are what they were in the forward call that wrote it (include/gbnf.h):
   // that call split them into this trainer's fragment buffer, so the fragments are still the right ones
   if (trace == nullptr)
@@ -1521,11 +1571,12 @@ int gbnf_trainer_backward(const gbnf_trainer* t, const float* x, int64_t n, cons
       if (t->has_norm[k]) {
         const dim3 fg((unsigned)((n + 255) / 256), (unsigned)t->d);
         hipLaunchKernelGGL(bn_bwd_fix_kernel, fg, dim3(256), 0, s, (const TrStep*)t->steps_dev, k, t->d, trace, (const float*)grads,
-                           gstate, n, p.np);
+                           gstate, n, p.np, (const unsigned*)t->gmax_dev);
       }
     }
     if (g_x != nullptr)
-      hipLaunchKernelGGL(slots_to_rows_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, (const float*)gstate, g_x, n, p.np, t->d);
+      hipLaunchKernelGGL(slots_to_rows_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, (const float*)gstate, g_x, n, p.np, t->d,
+                         (const unsigned*)t->gmax_dev);
   }
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return fail(GBNF_ERR_HIP, "gbnf_trainer_backward launch: %s", hipGetErrorString(e));
@@ -1535,7 +1586,8 @@ int gbnf_trainer_backward(const gbnf_trainer* t, const float* x, int64_t n, cons
   while (chunk < 4096 && (int64_t)t->wg_blocks * (p.np / (2 * chunk)) >= 3072) chunk *= 2;
   if (forced_chunk >= 32 && forced_chunk % 32 == 0) chunk = forced_chunk;
   const dim3 wgrid((unsigned)t->wg_blocks, (unsigned)((p.np + chunk - 1) / chunk));
-  hipLaunchKernelGGL(wgrad_kernel, wgrid, dim3(64), 0, s, t->probs_dev, t->n_probs, (const float*)workspace, grads, p.np, chunk);
+  hipLaunchKernelGGL(wgrad_kernel, wgrid, dim3(64), 0, s, t->probs_dev, t->n_probs, (const float*)workspace, grads, p.np, chunk,
+                     (const unsigned*)t->gmax_dev);
   e = hipGetLastError();
   if (e != hipSuccess) return fail(GBNF_ERR_HIP, "gbnf_trainer_backward wgrad launch: %s", hipGetErrorString(e));
   return GBNF_OK;

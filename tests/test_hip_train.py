@@ -319,6 +319,45 @@ def test_trainer_random_shapes_against_oracle(kind, d, h, K, n, extra, seed):
     assert np.abs(gx.cpu().numpy() - gx64).max() <= G_RTOL * max(float(np.abs(gx64).max()), 1e-3)
 
 
+@pytest.mark.parametrize("kind,batch_stats", [("glow", False), ("realnvp", False), ("realnvp", True)])
+def test_backward_is_invariant_to_the_scale_of_the_loss(kind, batch_stats):
+    """The backward pass is linear in the upstream gradient, and its accuracy must not depend on that gradient's
+    magnitude: a mean over 65536 samples hands in 1.5e-5 per sample, a summed loss 1e4 times more.  (The split-f16
+    operands only carry f32 accuracy for magnitudes around 1: the kernels rescale by a power of two per call.)"""
+    import torch
+    from gbnf_amd import native, synth
+    from oracle import gbnf_oracle as oracle
+    dev = torch.device("cuda:0")
+    d, h, K, n = 21, 105, 4, 700
+    spec = (synth.synth_glow_spec(d, h, K, seed=71) if kind == "glow"
+            else synth.synth_realnvp_spec(d, h, K, seed=71, batch_norm=True))
+    x = synth.synth_batch(n, d, seed=72)
+    rng = np.random.RandomState(73)
+    g_z = rng.standard_normal(x.shape).astype(np.float32)
+    g_l = rng.standard_normal(n).astype(np.float32)
+    gx64, gr64 = oracle.component_grads(spec, x, g_z, g_l, train=batch_stats)
+    dev_spec = _dev_spec(spec, dev)
+    if batch_stats:
+        for st in dev_spec["steps"]:
+            if st["bn"] is not None:
+                st["bn"]["batch_mean"] = torch.zeros(d, device=dev)
+                st["bn"]["batch_var"] = torch.zeros(d, device=dev)
+    tr = native.NativeTrainer(dev_spec)
+    if batch_stats:
+        tr.set_batch_stats(True)
+    xd = torch.from_numpy(x).to(dev)
+    _, _, trace = tr.forward(xd, want_trace=True)
+    floor = 0.05 * max(float(np.abs(g).max()) for g in gr64 if g is not None) if batch_stats else 1e-3
+    for scale in (1.0, 1.5e-5, 1e-7, 3e4):
+        sc = np.float32(scale)
+        gx, gr = tr.backward(xd, torch.from_numpy(g_z * sc).to(dev), torch.from_numpy(g_l * sc).to(dev), want_gx=True, trace=trace)
+        for a, b in zip(gr, gr64):
+            if b is not None:
+                got = a.cpu().numpy().reshape(b.shape).astype(np.float64) / float(sc)
+                assert np.abs(got - b).max() <= G_RTOL * max(float(np.abs(b).max()), floor), scale
+        assert np.abs(gx.cpu().numpy().astype(np.float64) / float(sc) - gx64).max() <= G_RTOL * float(np.abs(gx64).max()), scale
+
+
 def test_train_mode_batch_norm_matches_reference():
     """g10 (train-mode BatchNorm): RealNVP in train() like the reference's default configuration -- BatchNorm on batch
     statistics (one launch per step), nll.backward() through the statistics, running statistics updated."""

@@ -14,11 +14,8 @@ from gbnf_amd import native, synth
 from oracle import gbnf_oracle as oracle
 from test_hip_train import _dev_spec, _check_grads, G_RTOL
 
-cases = int(sys.argv[1]) if len(sys.argv) > 1 else 60
-rng = np.random.RandomState(int(sys.argv[2]) if len(sys.argv) > 2 else 2024)
-dev = torch.device("cuda:0")
-bad = 0
-for k in range(cases):
+def gen_case(rng, k):
+    """Case k of the stream `rng` (the draw order is part of the tool: tools/debug_train_case.py replays it)."""
     kind = "glow" if rng.randint(3) else "realnvp"
     d = int(rng.choice([2, 3, 5, 6, 8, 13, 21, 33, 43, 50, 63, 64]))
     h = int(rng.choice([5, 16, 30, 33, 64, 105, 129, 215, 256, 257, 315, 430, 512]))
@@ -33,51 +30,65 @@ for k in range(cases):
         extra = dict(coupling_network=str(rng.choice(["tanh", "relu", "mixed", "random"])), batch_norm=bool(rng.randint(2)),
                      flip_init=int(rng.randint(2)), depth=depth)
         spec = synth.synth_realnvp_spec(d, h, K, seed=5000 + k, **extra)
-    tag = f"{kind} d={d} h={h} K={K} n={n} {extra}"
-    try:
-        tr = native.NativeTrainer(_dev_spec(spec, dev))
-    except native.GbnfError as e:
-        print("skip (unsupported):", tag, "|", str(e)[:80])
-        continue
-    x = synth.synth_batch(n, d, seed=k)
-    g_z = rng.standard_normal(x.shape).astype(np.float32)
-    g_l = rng.standard_normal(n).astype(np.float32)
-    xd = torch.from_numpy(x).to(dev)
-    try:
-        z, ldj, trace = tr.forward(xd, want_trace=True)
-        z64, ldj64 = oracle.component_forward(spec, x, backend="numpy64")
-        assert np.abs(ldj.cpu().numpy() - ldj64).max() <= 1e-5 * max(1.0, float(np.abs(ldj64).max())), "ldj"
-        assert np.abs(z.cpu().numpy() - z64).max() <= 2e-5 * max(1.0, float(np.abs(z64).max())), "z"
-        gx64, grads64 = oracle.component_grads(spec, x, g_z, g_l)
-        gx, grads = tr.backward(xd, torch.from_numpy(g_z).to(dev), torch.from_numpy(g_l).to(dev), want_gx=True, trace=trace)
-        _check_grads(grads, grads64, tag)
-        assert np.abs(gx.cpu().numpy() - gx64).max() <= G_RTOL * max(float(np.abs(gx64).max()), 1e-3), "gx"
-        gx2, grads2 = tr.backward(xd, torch.from_numpy(g_z).to(dev), torch.from_numpy(g_l).to(dev), want_gx=True, trace=None)
-        assert np.abs(gx2.cpu().numpy() - gx64).max() <= G_RTOL * max(float(np.abs(gx64).max()), 1e-3), "gx (no trace)"
-        print("ok  ", tag)
-    except AssertionError as e:
-        # is it the kernels or the problem?  A ReLU net's gradient jumps when a pre-activation crosses zero, and f32
-        # round-off (~1e-6 absolute on a sum of h products) decides the side for the few pre-activations that close to
-        # zero (expected count ~ 1e-6 * n * h * layers * K).  Bracket: the oracle with the ReLU threshold at -tol and
-        # +tol; an entry of a gradient is fine if it lies in the interval those two and the plain oracle span.
-        tol = 5e-6
-        _, g_lo = oracle.component_grads(spec, x, g_z, g_l, relu_shift=-tol)
-        _, g_hi = oracle.component_grads(spec, x, g_z, g_l, relu_shift=+tol)
-        worst_out, errs = 0.0, []
-        for i, (a, b) in enumerate(zip(grads, grads64)):
-            if b is None:
-                continue
-            a = a.cpu().numpy().reshape(b.shape).astype(np.float64)
-            lo = np.minimum(np.minimum(g_lo[i], g_hi[i]), b); hi = np.maximum(np.maximum(g_lo[i], g_hi[i]), b)
-            out = np.maximum(np.maximum(lo - a, a - hi), 0.0).max() / max(np.abs(b).max(), 1e-3)
-            worst_out = max(worst_out, float(out))
-            errs.append((float(np.abs(a - b).max() / max(np.abs(b).max(), 1e-3)), i, b.shape))
-        errs = sorted(errs, reverse=True)[:3]
-        # (the bracket moves ALL near-zero units together, round-off moves an arbitrary subset: entries that several
-        # of them touch may stay a little outside -- a kink explains the case if most of the deviation is gone)
-        kink = worst_out <= max(G_RTOL, 0.2 * errs[0][0])
-        bad += 0 if kink else 1
-        print("KINK" if kink else "FAIL", tag, "| worst tensors", [(f"{e:.1e}", i, sh) for e, i, sh in errs],
-              f"| outside the ReLU-threshold bracket by {worst_out:.1e}")
-print(f"{cases} cases, {bad} failures")
-sys.exit(1 if bad else 0)
+    return kind, d, h, K, n, extra, spec
+
+
+def main():
+    cases = int(sys.argv[1]) if len(sys.argv) > 1 else 60
+    rng = np.random.RandomState(int(sys.argv[2]) if len(sys.argv) > 2 else 2024)
+    dev = torch.device("cuda:0")
+    bad = 0
+    for k in range(cases):
+        kind, d, h, K, n, extra, spec = gen_case(rng, k)
+        tag = f"{kind} d={d} h={h} K={K} n={n} {extra}"
+        try:
+            tr = native.NativeTrainer(_dev_spec(spec, dev))
+        except native.GbnfError as e:
+            print("skip (unsupported):", tag, "|", str(e)[:80])
+            continue
+        x = synth.synth_batch(n, d, seed=k)
+        g_z = rng.standard_normal(x.shape).astype(np.float32)
+        g_l = rng.standard_normal(n).astype(np.float32)
+        xd = torch.from_numpy(x).to(dev)
+        try:
+            z, ldj, trace = tr.forward(xd, want_trace=True)
+            z64, ldj64 = oracle.component_forward(spec, x, backend="numpy64")
+            assert np.abs(ldj.cpu().numpy() - ldj64).max() <= 1e-5 * max(1.0, float(np.abs(ldj64).max())), "ldj"
+            assert np.abs(z.cpu().numpy() - z64).max() <= 2e-5 * max(1.0, float(np.abs(z64).max())), "z"
+            gx64, grads64 = oracle.component_grads(spec, x, g_z, g_l)
+            gx, grads = tr.backward(xd, torch.from_numpy(g_z).to(dev), torch.from_numpy(g_l).to(dev), want_gx=True, trace=trace)
+            _check_grads(grads, grads64, tag)
+            assert np.abs(gx.cpu().numpy() - gx64).max() <= G_RTOL * max(float(np.abs(gx64).max()), 1e-3), "gx"
+            gx2, grads2 = tr.backward(xd, torch.from_numpy(g_z).to(dev), torch.from_numpy(g_l).to(dev), want_gx=True, trace=None)
+            assert np.abs(gx2.cpu().numpy() - gx64).max() <= G_RTOL * max(float(np.abs(gx64).max()), 1e-3), "gx (no trace)"
+            print("ok  ", tag)
+        except AssertionError as e:
+            # is it the kernels or the problem?  A ReLU net's gradient jumps when a pre-activation crosses zero, and f32
+            # round-off (~1e-6 absolute on a sum of h products) decides the side for the few pre-activations that close to
+            # zero (expected count ~ 1e-6 * n * h * layers * K).  Bracket: the oracle with the ReLU threshold at -tol and
+            # +tol; an entry of a gradient is fine if it lies in the interval those two and the plain oracle span.
+            tol = 5e-6
+            _, g_lo = oracle.component_grads(spec, x, g_z, g_l, relu_shift=-tol)
+            _, g_hi = oracle.component_grads(spec, x, g_z, g_l, relu_shift=+tol)
+            worst_out, errs = 0.0, []
+            for i, (a, b) in enumerate(zip(grads, grads64)):
+                if b is None:
+                    continue
+                a = a.cpu().numpy().reshape(b.shape).astype(np.float64)
+                lo = np.minimum(np.minimum(g_lo[i], g_hi[i]), b); hi = np.maximum(np.maximum(g_lo[i], g_hi[i]), b)
+                out = np.maximum(np.maximum(lo - a, a - hi), 0.0).max() / max(np.abs(b).max(), 1e-3)
+                worst_out = max(worst_out, float(out))
+                errs.append((float(np.abs(a - b).max() / max(np.abs(b).max(), 1e-3)), i, b.shape))
+            errs = sorted(errs, reverse=True)[:3]
+            # (the bracket moves ALL near-zero units together, round-off moves an arbitrary subset: entries that several
+            # of them touch may stay a little outside -- a kink explains the case if most of the deviation is gone)
+            kink = worst_out <= max(G_RTOL, 0.2 * errs[0][0])
+            bad += 0 if kink else 1
+            print("KINK" if kink else "FAIL", tag, "| worst tensors", [(f"{e:.1e}", i, sh) for e, i, sh in errs],
+                  f"| outside the ReLU-threshold bracket by {worst_out:.1e}")
+    print(f"{cases} cases, {bad} failures")
+    sys.exit(1 if bad else 0)
+
+
+if __name__ == "__main__":
+    main()
