@@ -27,8 +27,9 @@ for k in range(want + 1):
     except native.GbnfError:
         continue                       # (the stress tool draws g_z, g_l only for supported cases)
     x = synth.synth_batch(n, d, seed=k)
-    g_z = rng.standard_normal(x.shape).astype(np.float32)
-    g_l = rng.standard_normal(n).astype(np.float32)
+    gscale = np.float32(10.0 ** rng.uniform(-6, 4))
+    g_z = rng.standard_normal(x.shape).astype(np.float32) * gscale
+    g_l = rng.standard_normal(n).astype(np.float32) * gscale
     if k == want:
         break
 print("case", k, kind, d, h, K, n, extra, "activations:", native.activation_pattern(spec))
