@@ -31,7 +31,8 @@ for k in range(cases):
         mix, _ = native.mixture_from_specs(specs)
     except native.GbnfError as e:
         print("skip (unsupported):", tag, "|", str(e)[:90]); continue
-    x = synth.synth_batch(n, d, seed=k)
+    x = synth.synth_batch(n, d, seed=k, scale=float(10.0 ** rng.uniform(-1, 0.5)))      # the data need not be exactly z-scored
+    # (beyond ~3x the unit scale random ReLU RealNVPs without BatchNorm overflow exp(scale) in float32 -- oracle and kernels alike)
     rho = oracle.rho_init(C)
     ll_ref, G_ref = oracle.mixture_log_prob(specs, rho, x)
     G, ll = mix.log_prob(torch.from_numpy(x).to(dev), torch.from_numpy(rho).to(dev))
