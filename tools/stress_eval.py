@@ -53,7 +53,23 @@ for k in range(cases):
         # the component's density; summation order decides who is luckier -- the mixture G must still meet the bar)
         ok = e_gpu <= max(1e-5, 3.0 * e_ref) or (e2 < 1e-5 and e_gpu < 3e-5)
         note = f" | vs float64: kernels {e_gpu:.1e}, the f32 oracle itself {e_ref:.1e}"
+    # the z -> x direction (exact-f32 kernel, hidden <= 256): x -> z -> x must come back, log-dets must cancel
+    inv_note = ""
+    if h <= 256:
+        try:
+            f32 = native.NativeFlow(specs[C - 1], math="f32")
+            xd = torch.from_numpy(x).to(dev)
+            z, ldj, _ = f32.forward(xd)
+            xr, ldj_inv = f32.inverse(z)
+            ex = float((xr - xd).abs().max() / max(1.0, float(xd.abs().max())))
+            el = float((ldj + ldj_inv).abs().max() / max(1.0, float(ldj.abs().max())))
+            zmax = float(z.abs().max())
+            inv_ok = (ex < 2e-4 and el < 1e-4) or not np.isfinite(zmax) or zmax > 1e4     # (exploded nets cannot round-trip in f32)
+            inv_note = f" | inverse: x {ex:.1e} ldj {el:.1e}"
+            ok = ok and inv_ok
+        except native.GbnfError as e:
+            inv_note = " | inverse: unsupported"
     bad += 0 if ok else 1
-    print(("ok  " if ok and not note else "COND" if ok else "FAIL"), tag, f"| ll {e1:.1e} G {e2:.1e}" + note)
+    print(("ok  " if ok and not note else "COND" if ok else "FAIL"), tag, f"| ll {e1:.1e} G {e2:.1e}" + note + inv_note)
 print(f"{cases} cases, {bad} failures")
 sys.exit(1 if bad else 0)
