@@ -23,6 +23,9 @@ def main():
     ap.add_argument("--batch", type=int, default=512)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--components", type=int, default=4)
+    ap.add_argument("--reference-style", action="store_true",
+                    help="the reference's own statement sequence (one model(x, components=c) call per fixed component + the "
+                         "recursion and the weights in torch ops, density_experiment.py:612-644) instead of boosting_weights()")
     a = ap.parse_args()
     dev = torch.device("cuda:0")
     torch.manual_seed(0)
@@ -37,10 +40,33 @@ def main():
     m.component = C - 1                          # train the last component against the C-1 fixed ones
     opt = torch.optim.Adam(m.flows[C - 1].parameters(), lr=1e-3)
 
+    for name, p_ in m.named_parameters():                                   # init_boosted_lr, density_experiment.py:537-538
+        p_.requires_grad = name.startswith(f"flows.{m.component}")
+    lo, hi = torch.tensor([0.01], device=dev), torch.tensor([0.1], device=dev)
+
+    def reference_weights():
+        G_ll = None
+        for c in range(m.component):
+            z_G, _, _, ldj_G, _ = m(x=x, components=c)
+            ll = lns(z_G) + ldj_G
+            if c == 0:
+                G_ll = ll
+            else:
+                rs = m.rho[0:(c + 1)] / torch.sum(m.rho[0:(c + 1)])
+                G_ll = torch.logsumexp(torch.cat([(torch.log(1 - rs[c]) + G_ll).view(-1, 1),
+                                                  (torch.log(rs[c]) + ll).view(-1, 1)], dim=1), dim=1)
+        w = torch.softmax(-1.0 * G_ll, dim=0)
+        if w.max() > 0.1:
+            w = torch.max(torch.min(w, hi), lo)
+        return w / torch.sum(w)
+
     def step():
         opt.zero_grad(set_to_none=False)
-        with torch.no_grad():
-            w, _ = m.boosting_weights(x)                                    # softmax(-G) clamped, :624-640
+        if a.reference_style:
+            w = reference_weights()
+        else:
+            with torch.no_grad():
+                w, _ = m.boosting_weights(x)                                # softmax(-G) clamped, :624-640
         xr = x[torch.multinomial(w, x.size(0), replacement=True)]           # :642-644
         z, _, _, ldj, _ = m(x=xr, components="c")
         loss = torch.mean(-(lns(z) + ldj))
@@ -65,7 +91,7 @@ def main():
     gpu = ev[0].elapsed_time(ev[1]) / a.steps * 1e-3
     prof_note = "GPU-side time between events around the loop (the stream is never empty if host < GPU)"
     print(json.dumps({"metric": "boosted training step (weights + resample + forward + backward + Adam), MINIBOONE Glow",
-                      "batch": a.batch, "components": C, "ms_per_step_wall": wall * 1e3, "ms_per_step_gpu_events": gpu * 1e3,
+                      "batch": a.batch, "components": C, "reference_style": a.reference_style, "ms_per_step_wall": wall * 1e3, "ms_per_step_gpu_events": gpu * 1e3,
                       "samples_per_s": a.batch / wall, "note": prof_note}))
 
 
