@@ -662,8 +662,12 @@ class BoostedFlow(nn.Module):
     # ------------------------------------------------------------------ checkpoint side-car (fixes S5)
     def permutation_state(self):
         """What the reference's checkpoints lose: permutation indices, ActNorm ``inited``,
-        ``component`` and ``all_trained``.  Save next to ``state_dict()``."""
-        st = {"component": self.component, "all_trained": self.all_trained, "indices": {}, "actnorm_inited": {}}
+        ``component`` and ``all_trained`` -- and, for `--coupling_network random`, WHICH activation every coupling net
+        drew at construction time (the state_dict of a TanhNet and of a ReLUNet look the same).  Save next to
+        ``state_dict()``."""
+        st = {"component": self.component, "all_trained": self.all_trained, "indices": {}, "actnorm_inited": {},
+              "activations": [[list(a) if isinstance(a, tuple) else a for a in gspec.activation_pattern_of_component(f)]
+                              for f in self.flows]}
         if self.component_type == "glow":
             for c, flow in enumerate(self.flows):
                 for k, layer in enumerate(flow.flow.layers):
@@ -674,12 +678,34 @@ class BoostedFlow(nn.Module):
     def load_permutation_state(self, st):
         self.component = int(st["component"])
         self.all_trained = bool(st["all_trained"])
+        if st.get("activations") is not None:
+            self._set_activations(st["activations"])
         for name, idx in st["indices"].items():
             c, k = (int(v) for v in name.split("."))
             self.flows[c].flow.layers[k].permutation.set_indices(idx)
         for name, flag in st["actnorm_inited"].items():
             c, k = (int(v) for v in name.split("."))
             self.flows[c].flow.layers[k].actnorm.inited = bool(flag)
+
+    def _set_activations(self, patterns):
+        """Make every TanhNet / ReLUNet use the recorded activation (a model built with `--coupling_network random`
+        draws them anew on every construction)."""
+        changed = False
+        for flow, pat in zip(self.flows, patterns):
+            nets = ([layer.block for layer in flow.flow.layers] if self.component_type == "glow"
+                    else [n for mods in flow.flow_param for n in (mods[0], mods[1])])
+            acts = [a for step in pat for a in (step if isinstance(step, (list, tuple)) else [step])]
+            for net, act in zip(nets, acts):
+                if act == "residual" or not hasattr(net, "network"):
+                    continue
+                want = nn.Tanh if act == "tanh" else nn.ReLU
+                for i, mod in enumerate(net.network):
+                    if isinstance(mod, (nn.Tanh, nn.ReLU)) and not isinstance(mod, want):
+                        net.network[i] = want()
+                        changed = True
+        if changed:                 # handles and trainers were built for the old architecture
+            self._handles, self._handles_exact, self._trainers, self._mixture = {}, {}, {}, None
+            self._per_step_act = None
 
     def load_spec(self, c, spec):
         """Install a flow spec's numbers (see spec.py) into component c's parameters."""

@@ -67,6 +67,26 @@ def test_random_coupling_network_draws_like_the_reference(name, kind, d, h, K):
         assert not native.needs_per_step_activation(specs[:1] * 2)
 
 
+def test_side_car_restores_randomly_drawn_activations():
+    """A `--coupling_network random` model draws its activations at construction: the side-car records them and a freshly
+    built model (other draws) takes them over together with the state_dict."""
+    np.random.seed(5)
+    a = BoostedFlow(make_args(kind="glow", d=9, h=10, K=6, C=2, coupling_network="random"))
+    np.random.seed(6)
+    b = BoostedFlow(make_args(kind="glow", d=9, h=10, K=6, C=2, coupling_network="random"))
+    pa = [gspec.activation_pattern_of_component(f) for f in a.flows]
+    assert pa != [gspec.activation_pattern_of_component(f) for f in b.flows]
+    b.load_state_dict(a.state_dict())
+    b.load_permutation_state(a.permutation_state())
+    assert [gspec.activation_pattern_of_component(f) for f in b.flows] == pa
+    np.random.seed(7)
+    r = BoostedFlow(make_args(kind="realnvp", d=9, h=10, K=5, C=2, coupling_network="random"))
+    np.random.seed(8)
+    r2 = BoostedFlow(make_args(kind="realnvp", d=9, h=10, K=5, C=2, coupling_network="random"))
+    r2.load_permutation_state(r.permutation_state())
+    assert [gspec.activation_pattern_of_component(f) for f in r2.flows] == [gspec.activation_pattern_of_component(f) for f in r.flows]
+
+
 def test_rho_init_and_increment():
     m = BoostedFlow(make_args(C=8))
     np.testing.assert_array_equal(m.rho.numpy(), np.array([1, .5, .25, .125, .0625, .05, .05, .05], np.float32))
