@@ -1,0 +1,42 @@
+#!/usr/bin/env python3
+"""Randomised stress of the image path (multi-scale Glow on 3x32x32) against the float64 oracle (opt-in, GPU).
+usage: python tools/stress_image.py [cases] [seed]"""
+import os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+import numpy as np, torch
+from gbnf_amd import native, synth
+from oracle import gbnf_oracle as oracle
+
+
+def main():
+    cases = int(sys.argv[1]) if len(sys.argv) > 1 else 30
+    rng = np.random.RandomState(int(sys.argv[2]) if len(sys.argv) > 2 else 17)
+    dev = torch.device("cuda:0")
+    bad = 0
+    for k in range(cases):
+        c = dict(h=int(rng.choice([8, 16, 24, 32, 48, 64, 100, 128, 200, 256])), K=int(rng.randint(1, 5)), L=int(rng.choice([1, 2])),
+                 depth=int(rng.choice([0, 1, 1, 1, 2])), coupling=str(rng.choice(["affine", "additive"])),
+                 permutation=str(rng.choice(["invconv", "shuffle", "reverse"])), learn_top=bool(rng.randint(2)))
+        n = int(rng.choice([1, 2, 3, 5, 16, 33, 64]))
+        tag = f"n={n} {c}"
+        sp = synth.synth_image_glow_spec((3, 32, 32), seed=900 + k, **c)
+        x, noise = synth.synth_image_batch(n, seed=901 + k)
+        try:
+            flow = native.NativeImageFlow(sp)
+        except native.GbnfError as e:
+            print("skip (unsupported):", tag, "|", str(e)[:80]); continue
+        z64, _, _, ld64, ll64 = oracle.image_component_forward(sp, x, noise, dtype=torch.float64)
+        z, ldj, ll = flow.forward(torch.from_numpy(x).to(dev), torch.from_numpy(noise).to(dev))
+        e_ll = float(np.max(np.abs(ll.cpu().numpy() - ll64) / np.maximum(np.abs(ll64), 1.0)))
+        e_ld = float(np.max(np.abs(ldj.cpu().numpy() - ld64) / np.maximum(np.abs(ld64), 1.0)))
+        e_z = float(np.abs(z.cpu().numpy() - z64).max() / max(1.0, float(np.abs(z64).max())))
+        ok = e_ll < 1e-5 and e_ld < 1e-5 and e_z < 2e-4
+        bad += 0 if ok else 1
+        print("ok  " if ok else "FAIL", tag, f"| ll {e_ll:.1e} ldj {e_ld:.1e} z {e_z:.1e}")
+    print(f"{cases} cases, {bad} failures")
+    sys.exit(1 if bad else 0)
+
+
+if __name__ == "__main__":
+    main()
