@@ -411,12 +411,14 @@ __device__ __forceinline__ void tr_dense(gfrag A, gptr bias, int kc32, int frag_
 // piece of a smaller value is an fp16 subnormal: absolute floor 2^-24).  Activations are O(1) by construction; gradients
 // are as large as the caller's loss makes them (a mean over 65536 samples hands in 1.5e-5 per sample).  The backward
 // pass is linear in the upstream gradient, so it runs on alpha * gradient with alpha = the power of two that puts the
-// largest upstream entry of the batch at 2^8, and every result (g_x, parameter gradients) is multiplied by 1 / alpha --
-// exact scalings.  gmax_kernel finds that largest entry (non-negative floats order like their bit patterns).
+// largest upstream entry of the batch at 2^2, and every result (g_x, parameter gradients) is multiplied by 1 / alpha --
+// exact scalings.  2^2 leaves a factor 16 000 of headroom for what the chain multiplies a sample's gradient by (RealNVP:
+// exp(scale)) before the fp16 range saturates; entries far below the largest one keep an ABSOLUTE accuracy of 2^-24 * 4
+// relative to it, i.e. what f32 rounding of the large entries costs anyway.  gmax_kernel finds that largest entry (non-negative floats order like their bit patterns).
 __device__ __forceinline__ void tr_grad_scale(unsigned max_bits, float& alpha, float& inv_alpha) {
   const int e = (int)((max_bits >> 23) & 255u);          // biased exponent of the largest |upstream gradient|
   if (max_bits == 0u || e == 255) { alpha = 1.0f; inv_alpha = 1.0f; return; }
-  int k = 8 - (e - 127);                                   // alpha = 2^k
+  int k = 2 - (e - 127);                                   // alpha = 2^k: the largest upstream entry lands in [4, 8)
   k = k > 100 ? 100 : (k < -100 ? -100 : k);
   alpha = __builtin_bit_cast(float, (unsigned)(k + 127) << 23);
   inv_alpha = __builtin_bit_cast(float, (unsigned)(127 - k) << 23);
