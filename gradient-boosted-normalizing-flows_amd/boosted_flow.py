@@ -651,6 +651,16 @@ class BoostedFlow(nn.Module):
             w = native.boosting_weights(G, beta)
         return w, G
 
+    @staticmethod
+    def check_numerics(reset=True):
+        """Raise if any kernel since the last check stored a split-f16 operand beyond the fp16 range (+-65504), where it
+        saturates: inputs far outside the scale the flow was fitted on, or an exploding model.
+        Synchronises with the device; call it once per epoch, not per step."""
+        n = native.saturation_count(reset=reset)
+        if n:
+            raise FloatingPointError(f"{n} wave(s) saturated a split-f16 operand at +-65504: results for those samples are "
+                                     "wrong; evaluate with GBNF_MATH=f32 or normalise the inputs")
+
     def _n_used(self, n_used):
         if n_used is None:
             n_used = self.num_components if self.all_trained else self.component + 1

@@ -82,6 +82,16 @@ namespace gbnf {
 
 static int ceil_div(int a, int b) { return (a + b - 1) / b; }
 
+unsigned* saturation_counter() {
+  static unsigned* dev = [] {
+    unsigned* p = nullptr;
+    if (hipMalloc((void**)&p, sizeof(unsigned)) != hipSuccess) return (unsigned*)nullptr;
+    if (hipMemset(p, 0, sizeof(unsigned)) != hipSuccess) { (void)hipFree(p); return (unsigned*)nullptr; }
+    return p;
+  }();
+  return dev;
+}
+
 // physical hidden position p = 16 t + 4 g + r  <->  logical unit 4*(4t + r) + g
 static int phys_to_logical(int p, int h) {
   const int t = p / 16, gg = (p % 16) / 4, r = p % 4;
@@ -296,6 +306,19 @@ using namespace gbnf;
 extern "C" {
 
 int gbnf_version(void) { return GBNF_ABI_VERSION; }
+
+int gbnf_saturation_count(int64_t* count, int32_t reset) {
+  if (count == nullptr) return fail(GBNF_ERR_INVALID, "gbnf_saturation_count: count is null");
+  *count = 0;
+  unsigned* dev = gbnf::saturation_counter();
+  if (dev == nullptr) return GBNF_OK;
+  unsigned host = 0;
+  hipError_t e = hipMemcpy(&host, dev, sizeof(host), hipMemcpyDeviceToHost);      // (synchronises with the device)
+  if (e == hipSuccess && reset) e = hipMemset(dev, 0, sizeof(host));
+  if (e != hipSuccess) return fail(GBNF_ERR_HIP, "gbnf_saturation_count: %s", hipGetErrorString(e));
+  *count = (int64_t)host;
+  return GBNF_OK;
+}
 
 const char* gbnf_last_error(void) { return g_err.c_str(); }
 
@@ -721,6 +744,7 @@ static int launch_flow(const gbnf_flow* f, const uint32_t* const* table, int c_b
 #ifdef GBNF_STAMPS
   p.dbg = g_stamp_buf;
 #endif
+  p.sat = saturation_counter();
   hipError_t e = f->launch_nt[nt](p, (unsigned)grid, stream);
   if (e != hipSuccess) return fail(GBNF_ERR_HIP, "launch of %s failed: %s", f->name_nt[nt], hipGetErrorString(e));
   return GBNF_OK;

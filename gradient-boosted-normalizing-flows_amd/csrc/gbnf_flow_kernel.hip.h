@@ -94,6 +94,7 @@ struct FlowLaunch {
   int32_t n_batches;             // 1..MAX_BATCHES (z_out / ldj_out only with 1)
   int32_t inverse;               // f32 kernel only: run the flow backwards (xs = z in, z_out = x out, ldj_out = log|det dx/dz|)
   unsigned long long* dbg;       // diagnostic builds (-DGBNF_STAMPS) only: per-block phase cycle sums
+  unsigned* sat;                 // split-f16 kernel: counter of waves whose coupling-net inputs left the fp16 range (they saturate)
 };
 
 __device__ __forceinline__ float as_f32(uint32_t u) { return __builtin_bit_cast(float, u); }

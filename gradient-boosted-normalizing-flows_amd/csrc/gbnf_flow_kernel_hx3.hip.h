@@ -203,6 +203,7 @@ __global__ void __launch_bounds__(64 * HX3_WAVES, (NT == 1) ? 2 : 1) flow_kernel
 #pragma unroll
   for (int nt = 0; nt < NT; ++nt) ld[nt] = 0.0f;
   float ld_const = 0.0f;
+  bool sat = false;
   Stamps st;
   st.start();
 
@@ -238,6 +239,7 @@ __global__ void __launch_bounds__(64 * HX3_WAVES, (NT == 1) ? 2 : 1) flow_kernel
           float t = Z[zoff];
           t = norm_fn<KIND>(t, tin.p0[e], tin.p1[e], tin.p2[e], tin.p3[e]);
           if (live) Z[zoff] = t;
+          sat = sat || (live && !(__builtin_fabsf(t) <= 65504.0f));       // beyond the fp16 range the operand saturates
           v[e] = live ? __builtin_amdgcn_fmed3f(t, -65504.0f, 65504.0f) : 0.0f;
         }
 #pragma unroll
@@ -622,6 +624,7 @@ __global__ void __launch_bounds__(64 * HX3_WAVES, (NT == 1) ? 2 : 1) flow_kernel
       if (p.ll_out) p.ll_out[o] = (q - 0.91893853320467274f * (float)d) + ldj;
     }
   }
+  if (p.sat != nullptr && __any(sat) && lane == 0) atomicAdd(p.sat, 1u);
   if (p.z_out != nullptr && lane < d) {
     const int slot = (int)tail[lane];
     float* zo = p.z_out + (int64_t)comp * p.n * d;

@@ -111,6 +111,7 @@ struct TrainLaunch {
   float* g_x;          // MODE 1 (n, d) or null
   float* grads;        // MODE 1 flat parameter-gradient buffer
   unsigned long long* dbg;   // diagnostic builds only
+  unsigned* sat;             // library-wide counter: waves that stored a split operand beyond the fp16 range (it saturates)
   float* ws;           // MODE 1 workspace: operands of the weight gradients
   const u32x4* frag;   // split-f16 weight fragments of this call (prep_kernel)
   int64_t n, np;       // samples, samples rounded up to whole workgroups (16 * TR_MAX_NT)
@@ -463,6 +464,13 @@ __global__ void __launch_bounds__(64 * TR_WAVES) train_kernel(const TrainLaunch 
 
   TrStamps stamps;
   stamps.mark(-1);
+  // a split operand saturates at +-65504: remember it, count the wave once at the end
+  bool sat = false;
+  auto watch = [&](float v) { sat = sat || !(__builtin_fabsf(v) <= 65504.0f); };
+  auto watch4 = [&](f32x4 v) { watch(v[0]); watch(v[1]); watch(v[2]); watch(v[3]); };
+  auto report = [&]() {
+    if (p.sat != nullptr && __any(sat) && lane == 0) atomicAdd(p.sat, 1u);
+  };
   // per-step tables, staged once: slot maps and the normalisation constants of every slot
   // (everything a step needs lives in LDS from here on: a read of the step table in global memory inside the step loop
   // is a vector-memory load, and waiting for it drains the weight prefetch)
@@ -613,6 +621,7 @@ __global__ void __launch_bounds__(64 * TR_WAVES) train_kernel(const TrainLaunch 
             h = l == nl - 2 ? t : tr_act4(GBNF_ACT_RELU, t);
           }
         }
+        watch4(h);
         Hl.put4(i + 16 * nt, u0, h);
         if (emit) {
 #pragma unroll
@@ -641,6 +650,7 @@ __global__ void __launch_bounds__(64 * TR_WAVES) train_kernel(const TrainLaunch 
         TR_NT {
           const float v = u < p.op ? cur[u * S + i + 16 * nt] : 0.0f;
           if (u < p.op) ws_d[((size_t)nt * p.op + u) * 16] = v;
+          watch(v);
           GOS.put1(i + 16 * nt, u, v);
         }
       }
@@ -672,6 +682,7 @@ __global__ void __launch_bounds__(64 * TR_WAVES) train_kernel(const TrainLaunch 
             *rt = gpre[r];
           }
         }
+        watch4(gpre);
         Hl.put4(i + 16 * nt, u0, gpre);
 #pragma unroll
         for (int r = 0; r < 4; ++r) ws_d[((size_t)nt * p.hp + u0 + r) * 16] = gpre[r];
@@ -721,7 +732,11 @@ __global__ void __launch_bounds__(64 * TR_WAVES) train_kernel(const TrainLaunch 
     if (MODE == 1 && k == ke - 1) break;                   // the last step's outputs are not needed for the backward
     tr_lds_barrier();
     const lip ti = TI + k * 128;
-    for (int kk = g; kk < p.xw; kk += GS) TR_NT XS.put1(i + 16 * nt, kk, kk < st.in_f ? Zc[ti[kk] * S + i + 16 * nt] : 0.0f);
+    for (int kk = g; kk < p.xw; kk += GS) TR_NT {
+      const float v = kk < st.in_f ? Zc[ti[kk] * S + i + 16 * nt] : 0.0f;
+      watch(v);
+      XS.put1(i + 16 * nt, kk, v);
+    }
     tr_lds_barrier();
     stamps.mark(1);
     if constexpr (KIND == GBNF_KIND_GLOW) {
@@ -785,6 +800,7 @@ __global__ void __launch_bounds__(64 * TR_WAVES) train_kernel(const TrainLaunch 
         for (int s = g; s < d; s += GS) p.state_out[(size_t)s * p.np + r] = Zc[s * S + ii];
     }
     stamps.mark(4);
+    report();
 #ifdef GBNF_TRAIN_STAMPS
     if (p.dbg != nullptr && threadIdx.x == 0)
       for (int q = 0; q < 8; ++q) p.dbg[(size_t)blockIdx.x * 8 + q] = stamps.acc[q];
@@ -847,6 +863,7 @@ __global__ void __launch_bounds__(64 * TR_WAVES) train_kernel(const TrainLaunch 
       for (int kk = g; kk < p.xw; kk += GS) TR_NT {
         const int ii = i + 16 * nt;
         const float v = kk < st.in_f ? Yk[ti[kk] * S + ii] : 0.0f;
+        watch(v);
         XS.put1(ii, kk, v);
         if (kk < p.ip)
           for (int q = 0; q < nnets; ++q)
@@ -924,6 +941,7 @@ __global__ void __launch_bounds__(64 * TR_WAVES) train_kernel(const TrainLaunch 
         for (int j = g; j < d; j += GS) p.g_x[r * d + j] = G[j * S + ii] * inv_alpha;
       }
     }
+    report();
   }
 #undef TR_NT
 }
@@ -1444,6 +1462,7 @@ static void fill_launch(const gbnf_trainer* t, TrainLaunch& p, const float* x, i
   p.dbg = g_train_stamp_buf;
 #endif
   p.steps = t->steps_dev; p.tail = t->tail_dev; p.x = x;
+  p.sat = saturation_counter();
   p.n = n; p.np = tr_padded(n);
   p.d = t->d; p.K = t->K; p.kind = t->kind; p.additive = t->additive;
   p.residual = t->residual;

@@ -22,7 +22,7 @@ MATH = {"default": -1, "f32": 0, "f16x3": 1}
 
 # every symbol include/gbnf.h declares (tests check the library exports exactly these)
 ABI_SYMBOLS = (
-    "gbnf_version", "gbnf_last_error",
+    "gbnf_version", "gbnf_last_error", "gbnf_saturation_count",
     "gbnf_flow_create", "gbnf_flow_create_mode", "gbnf_flow_create_ex", "gbnf_flow_destroy", "gbnf_flow_info", "gbnf_flow_forward",
     "gbnf_flow_inverse",
     "gbnf_mixture_create", "gbnf_mixture_destroy", "gbnf_mixture_set_base",
@@ -115,6 +115,7 @@ def lib():
     L.gbnf_version.restype = C.c_int
     L.gbnf_last_error.restype = C.c_char_p
     L.gbnf_flow_create.argtypes = [C.POINTER(_FlowDesc), C.POINTER(vp)]
+    L.gbnf_saturation_count.argtypes = [C.POINTER(C.c_int64), i32]
     L.gbnf_flow_create_mode.argtypes = [C.POINTER(_FlowDesc), i32, C.POINTER(vp)]
     L.gbnf_flow_create_ex.argtypes = [C.POINTER(_FlowDesc), i32, i32, C.POINTER(vp)]
     L.gbnf_flow_destroy.argtypes = [vp]
@@ -563,6 +564,14 @@ class NativeTrainer:
             self.close()
         except Exception:
             pass
+
+
+def saturation_count(reset=False):
+    """How many waves stored a split-f16 operand beyond +-65504 (it saturates there) since the last reset: 0 for
+    z-scored data on a trained flow.  Synchronises with the device (gbnf_saturation_count)."""
+    n = C.c_int64(0)
+    _check(lib().gbnf_saturation_count(C.byref(n), 1 if reset else 0))
+    return int(n.value)
 
 
 def activation_pattern(spec):

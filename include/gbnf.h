@@ -123,6 +123,12 @@ typedef struct gbnf_kernel_info {
 int gbnf_version(void);
 const char* gbnf_last_error(void);
 
+/* The split-f16 kernels (evaluation default, training) represent an f32 operand by two fp16 pieces: beyond +-65504 it
+ * saturates silently (the normalised input of a coupling net; in training also activations and scaled gradients).  This
+ * returns how many waves ran into that since the last reset -- 0 for z-scored data on a trained flow -- and optionally
+ * resets the counter.  Library-wide; synchronises with the device. */
+int gbnf_saturation_count(int64_t* count, int32_t reset);
+
 /* Replaces: constructing flows[c] + .to(device)  (models/boosted_flow.py:42-50).
  * Packs (pads, tiles, folds slot maps) and uploads the parameters. */
 int gbnf_flow_create(const gbnf_flow_desc* desc, gbnf_flow** out);

@@ -201,6 +201,24 @@ def test_residual_coupling_networks(blocks, dev):
         native.NativeFlow(specs[0], math="f16x3")
 
 
+def test_saturation_is_counted(dev):
+    """Beyond +-65504 a split-f16 operand saturates silently; the library counts the waves it happened to."""
+    import torch
+    from gbnf_amd import native, synth
+    native.saturation_count(reset=True)
+    spec = synth.synth_realnvp_spec(6, 30, 3, seed=1, coupling_network="relu", batch_norm=False)
+    flow = native.NativeFlow(spec)
+    assert flow.info().math_mode == native.MATH["f16x3"]
+    x = synth.synth_batch(256, 6, seed=2)
+    flow.forward(torch.from_numpy(x).to(dev), want_ll=True)
+    assert native.saturation_count() == 0
+    flow.forward(torch.from_numpy(x * np.float32(1e7)).to(dev), want_ll=True)
+    assert native.saturation_count(reset=True) > 0
+    assert native.saturation_count() == 0
+    native.NativeFlow(spec, math="f32").forward(torch.from_numpy(x * np.float32(1e7)).to(dev), want_ll=True)
+    assert native.saturation_count() == 0                      # the exact-f32 kernel has no such bound
+
+
 def test_full_size_against_oracle(dev):
     """BASELINE config: MINIBOONE d=43 h=215 K=5 C=8, N=4096 -- HIP vs the torch-CPU oracle."""
     import torch

@@ -358,6 +358,22 @@ def test_backward_is_invariant_to_the_scale_of_the_loss(kind, batch_stats):
         assert np.abs(gx.cpu().numpy().astype(np.float64) / float(sc) - gx64).max() <= G_RTOL * float(np.abs(gx64).max()), scale
 
 
+def test_trainer_counts_saturated_operands():
+    import torch
+    from gbnf_amd import native, synth
+    dev = torch.device("cuda:0")
+    native.saturation_count(reset=True)
+    spec = synth.synth_glow_spec(8, 16, 2, seed=3, act="relu")
+    tr = native.NativeTrainer(_dev_spec(spec, dev))
+    x = synth.synth_batch(64, 8, seed=4)
+    xd = torch.from_numpy(x).to(dev)
+    z, ldj, trace = tr.forward(xd, want_trace=True)
+    tr.backward(xd, torch.ones_like(z) * 1e-9, torch.ones_like(ldj) * 1e9, want_gx=True, trace=trace)   # any loss scale is fine
+    assert native.saturation_count() == 0
+    tr.forward(torch.from_numpy(x * np.float32(1e8)).to(dev))
+    assert native.saturation_count(reset=True) > 0
+
+
 def test_train_mode_batch_norm_matches_reference():
     """g10 (train-mode BatchNorm): RealNVP in train() like the reference's default configuration -- BatchNorm on batch
     statistics (one launch per step), nll.backward() through the statistics, running statistics updated."""
