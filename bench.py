@@ -5,26 +5,35 @@
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
 
+`python bench.py --gpus N` with N > 1 and no WORLD_SIZE in the environment starts that launcher itself as a child
+process (before anything here touches torch or the GPU) and relays rank 0's JSON line.
+
 Workload (BASELINE.json metric): MINIBOONE-shaped d=43, Boosted-Glow C=8 (K=5 flow steps, coupling
 net 21->215->215->44 tanh, shuffle permutation, affine coupling), batch 4096 synthetic N(0,1) rows
 already resident in HBM, random-init synthetic weights.  One "step" = one pass of the hot path over
 one batch: all C component flows + the mixture log-sum-exp  ->  G (N,).
 
-N > 1: the C components are sharded over the ranks (contiguous blocks, C/N each), x is replicated,
-one RCCL all-gather of float32[C/N, batch] per rank per step rebuilds (C, batch) before the
-recursion; total work is fixed => "scaling": "strong".
+Consecutive batches are independent, so they are served in groups of S = 16 (the same S for every N: one flow launch,
+one all-gather, one recursion launch per group -- gbnf_amd.sharded.GroupPipeline, the class the GPU tests exercise).
+N > 1: the C components are sharded over the ranks (contiguous blocks, C/N each), x is replicated, one RCCL all-gather
+of float32[C/N, S*batch] per rank per group rebuilds (C, S*batch) before the recursion; total work is fixed =>
+"scaling": "strong".
 
-Timing: 2000 x `--prewarm` (default 0.3, reported as "prewarm_s": about that many seconds on one GPU) untimed steps let
-the clocks of a cold GPU settle, then W untimed warm-up steps, then exactly K timed steps between barriers + device synchronisations.
+Timing: 2000 x `--prewarm` untimed steps let the clocks of a cold GPU settle, then W untimed warm-up steps, then exactly
+K timed steps between barriers + device synchronisations, MAX over ranks.
 
 Prints ONE JSON line on rank 0 (see the driver contract), including
-  "roofline":     dominant kernel (the fused flow kernel) against the dense f32-MFMA peak
+  "dtype":        the arithmetic the timed kernel computes in ("f16x3" = f32 operands split into two fp16 pieces, three
+                  f16 MFMAs per product, f32 accumulate; "bf16x6"; "f32" = exact f32-input MFMA)
+  "roofline":     dominant kernel (the fused flow kernel) against the dense MFMA peak of the pipe it runs on
+  "legs":         (N = 1) the same workload on the exact-f32 kernel, and one batch per launch (group 1)
   "cpu_baseline": the torch-CPU oracle ("port" of the reference path) timed on this box's cores.
 """
 import argparse
 import ctypes
 import json
 import os
+import subprocess
 import sys
 import time
 
@@ -34,12 +43,20 @@ sys.path.insert(0, REPO)
 F32_MFMA_PEAK_TFLOPS = 157.3   # /opt/skills/guides/MI355X_MICROARCH.md: dense f32 matrix peak
 F16_MFMA_PEAK_TFLOPS = 2500.0  # same guide: dense bf16/f16 matrix peak (no sparsity)
 HBM_PEAK_GBS = 8000.0          # same guide: HBM3E spec peak
+GROUP = 16                     # batches per flow launch / all-gather / recursion launch, for every N
 
 CONFIGS = {
     # name: (kind, d, h, K, default C, default batch)
     "miniboone_glow": ("glow", 43, 215, 5, 8, 4096),
     "hepmass_realnvp": ("realnvp", 21, 105, 5, 8, 65536),
 }
+MATH_NAME = {0: "f32", 1: "f16x3", 2: "bf16x6"}
+MATH_TEXT = {
+    "f32": "f32: exact f32-input MFMA (v_mfma_f32_16x16x4_f32)",
+    "f16x3": "f16x3: f32 operands split into two fp16 pieces, 3 f16 MFMAs per product, f32 accumulate",
+    "bf16x6": "bf16x6: f32 operands split into three bf16 pieces, 6 bf16 MFMAs per product, f32 accumulate",
+}
+PRODUCTS = {"f32": 1.0, "f16x3": 3.0, "bf16x6": 6.0}
 
 
 def _cpu_model():
@@ -60,14 +77,14 @@ def cpu_baseline(specs, rho, x_np, budget_s):
     which is pathological on a many-core host for these small GEMMs (256 threads: ~100 s per pass), so
     the baseline is given its best setting: a quick probe over {1, 4, 8, 16, 32, 64} picks the fastest,
     and `cores` reports the threads actually used.  Then whole passes (all components + recursion) are
-    timed until ~budget_s seconds are spent (first pass untimed)."""
+    timed until ~budget_s seconds are spent (first pass untimed).  `one_thread_value` is the same whole pass (all
+    components + recursion) on ONE thread over a bounded row sample (the reference scripts' own default is one worker)."""
     import torch
     from oracle import gbnf_oracle as oracle
     host_cores = os.cpu_count() or 1
     cands = [t for t in (1, 4, 8, 16, 32, 64) if t <= host_cores] or [1]
     probe_x = x_np[: min(512, x_np.shape[0])]
     best_t, best_dt = cands[0], None
-    one_thread = None
     with torch.no_grad():
         for t in cands:
             torch.set_num_threads(t)
@@ -75,12 +92,17 @@ def cpu_baseline(specs, rho, x_np, budget_s):
             t0 = time.perf_counter()
             oracle.component_log_prob(specs[0], probe_x)
             dt = time.perf_counter() - t0
-            if t == 1:      # the reference scripts' own default is one worker: record that figure too (probe-sized sample)
-                one_thread = probe_x.shape[0] / (dt * len(specs))
             if best_dt is None or dt < best_dt:
                 best_t, best_dt = t, dt
             if dt > 2.0:
                 break
+        # one thread, the stated workload (all components + the recursion) on a row sample worth ~2 s
+        torch.set_num_threads(1)
+        n1 = min(x_np.shape[0], 1024)
+        oracle.mixture_log_prob(specs, rho, x_np[:64])
+        t0 = time.perf_counter()
+        oracle.mixture_log_prob(specs, rho, x_np[:n1])
+        one_thread = n1 / (time.perf_counter() - t0)
         torch.set_num_threads(best_t)
         est = best_dt * len(specs) * x_np.shape[0] / probe_x.shape[0]
         n = x_np.shape[0]
@@ -99,24 +121,47 @@ def cpu_baseline(specs, rho, x_np, budget_s):
     return {
         "value": n * passes / el, "unit": "samples/s", "cores": best_t, "kind": "port",
         "host_cores": host_cores, "cpu_model": _cpu_model(), "one_thread_value": one_thread,
+        "one_thread_sample": f"one pass over {n1} rows, all {len(specs)} components + mixture recursion, 1 thread",
         "sample": f"{passes} pass(es) over {n} of the {x_np.shape[0]} rows, all {len(specs)} components + mixture "
                   f"recursion, torch-CPU oracle in the reference's op order, {best_t} threads "
                   f"(fastest of {cands}), {el:.1f} s",
     }, G, n
 
 
-def measured_traffic(config, B, C, S, f16x3, world):
+def measured_traffic(config, B, C, S, math, world):
     """HBM-side bytes per launch of the dominant kernel from the PMC passes committed under profiles/ (FETCH_SIZE x 2
     + WRITE_SIZE, collected as MI355X_MICROARCH.md prescribes) -- only for the exact workload they were taken on."""
-    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "headline_traffic.json")
+    path = os.path.join(REPO, "profiles", "headline_traffic.json")
     try:
         rec = json.load(open(path))
     except (OSError, ValueError):
         return None
     w = rec.get("workload", {})
     same = (w.get("config") == config and w.get("batch") == B and w.get("components") == C and w.get("group") == S
-            and w.get("math") == ("f16x3" if f16x3 else "f32") and w.get("n_gpus") == world)
+            and w.get("math") == math and w.get("n_gpus") == world)
     return float(rec["traffic_bytes_per_launch"]) if same else None
+
+
+def self_launch(args):
+    """`python bench.py --gpus N` as the driver may invoke it: start the one-process-per-GPU job as a CHILD (this parent
+    has not imported torch or touched the GPU, and never replaces itself) and relay rank 0's JSON line."""
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    proc = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    lines = [l for l in proc.stdout.splitlines() if l.startswith("{")]
+    for l in proc.stdout.splitlines():
+        if not l.startswith("{"):
+            print(l, file=sys.stderr)
+    if lines:
+        print(lines[-1], flush=True)
+    return proc.returncode if proc.returncode != 0 or lines else 1
 
 
 def main():
@@ -129,13 +174,17 @@ def main():
     ap.add_argument("--batch", type=int, default=None)
     ap.add_argument("--components", type=int, default=None)
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the CPU baseline leg (0 = skip)")
-    ap.add_argument("--math", default="default", choices=["default", "f32", "f16x3"],
-                    help="matrix path: exact-f32 MFMA or split-f16 (3 f16 MFMAs per f32 product)")
+    ap.add_argument("--math", default="default", choices=["default", "f32", "f16x3", "bf16x6"],
+                    help="matrix path: default = chosen by the library per model (probe at create time)")
     ap.add_argument("--force-gather", action="store_true",
-                    help="testing aid: run the RCCL all-gather leg even with one rank")
-    ap.add_argument("--group", type=int, default=0,
-                    help="batches served per launch / per all-gather (0 = auto: 8..16, max 16)")
+                    help="EMULATION aid: run the RCCL all-gather leg with one rank (with --components k: the per-rank load "
+                         "of an 8/k-GPU run on one GPU; the cross-GPU hop itself is not exercised)")
+    ap.add_argument("--group", type=int, default=GROUP, help=f"batches per launch / all-gather (default {GROUP}, max 16)")
+    ap.add_argument("--no-extra-legs", action="store_true", help="skip the f32-exact and group-1 legs of the N=1 line")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(self_launch(args))
 
     # dmabuf IPC is the only form the host driver supports (without it RCCL fails with hipIpcGetMemHandle: invalid argument)
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
@@ -150,14 +199,19 @@ def main():
     if rank != 0:          # only rank 0 reports: nothing another rank (or a library it loads) writes may follow the JSON line
         os.dup2(os.open(os.devnull, os.O_WRONLY), 1)
     if world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: there is no CPU fallback for the product path")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    gather = world > 1 or args.force_gather
+    if gather:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        os.environ.setdefault("MASTER_PORT", "29533")
+        if world > 1:
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
 
     kind, d, h, K, C_def, B_def = CONFIGS[args.config]
     C = args.components or C_def
@@ -169,79 +223,10 @@ def main():
     rho_np = np.maximum(1.0 / np.power(2.0, np.arange(C)), 0.05).astype(np.float32)   # "decreasing"
     parts = sharded.partition(C, world)
     c0, c1 = parts[rank]
-    flows = [native.NativeFlow(specs[c], math=args.math) for c in range(c0, c1)]
-    mix = native.NativeMixture(flows)
-    info = flows[0].info()
-    x = torch.from_numpy(x_np).to(dev)
     rho = torch.from_numpy(rho_np).to(dev)
-
-    # ---- pipeline.  Consecutive steps (batches) are independent, so they are served in GROUPS of S: one flow
-    # launch covers the S batches of a group (for a rank holding C/N components a single batch fills only 1/N
-    # of its GPU), ONE RCCL all-gather rebuilds the (C, S*B) table of the group and ONE recursion launch
-    # finishes it -- "bigger, fewer collectives".  The flow kernels run on one stream, gather + recursion on a
-    # second one, double-buffered, so the exchange of group g overlaps the kernel of group g+1.
-    gather = world > 1 or args.force_gather
-    # auto: at least 8, and enough batches per launch for two co-resident workgroups per CU (>= 512 workgroups)
-    S = args.group if args.group > 0 else max(8, (16 * world + C - 1) // C)
-    S = max(1, min(S, 16, args.steps))
+    S = max(1, min(args.group, 16))
     xs_np = [x_np] + [synth.synth_batch(B, d, seed=100 + s) for s in range(1, S)]   # S distinct resident batches
-    xs = [x] + [torch.from_numpy(a).to(dev) for a in xs_np[1:]]
-    NBUF = 2
-    main = torch.cuda.current_stream()
-    post = torch.cuda.Stream() if gather else main
-    mptr, pptr = ctypes.c_void_p(main.cuda_stream), ctypes.c_void_p(post.cuda_stream)
-    flow_done = [torch.cuda.Event() for _ in range(NBUF)]
-    post_done = [torch.cuda.Event() for _ in range(NBUF)]
-
-    class Group:
-        """Buffers + pre-bound launches for groups of `size` batches (double-buffered).  Every argument is bound
-        once: per group the host does two ctypes calls (+ one RCCL call when sharded)."""
-
-        def __init__(self, size):
-            self.size = size
-            self.local = [torch.empty((c1 - c0, size * B), dtype=torch.float32, device=dev) for _ in range(NBUF)]
-            self.full = ([torch.empty((C, size * B), dtype=torch.float32, device=dev) for _ in range(NBUF)]
-                         if gather else self.local)
-            self.G = [torch.empty(size * B, dtype=torch.float32, device=dev) for _ in range(NBUF)]
-            self.flow = [mix.prepared_group_log_prob(xs[:size], self.local[q]) for q in range(NBUF)]
-            self.lse = [native.prepared_mixture_lse(self.full[q], rho, self.G[q]) for q in range(NBUF)]
-
-    groups = {S: Group(S)}
-    for t in {args.steps % S, args.warmup % S} - {0}:       # ragged last group of the timed / warm-up run
-        groups[t] = Group(t)
-    n_timed_groups = (args.steps + S - 1) // S
-    ev0 = [torch.cuda.Event(enable_timing=True) for _ in range(n_timed_groups)]
-    ev1 = [torch.cuda.Event(enable_timing=True) for _ in range(n_timed_groups)]
-    if gather and not dist.is_initialized():
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("MASTER_PORT", "29533")
-        dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
-
-    def run(n_steps, timed):
-        """n_steps batches in ceil(n_steps / S) groups; every batch gets its flow pass, exchange and recursion."""
-        gi = 0
-        done = 0
-        while done < n_steps:
-            q = gi % NBUF
-            grp = groups[min(S, n_steps - done)]
-            if gather and gi >= NBUF:
-                main.wait_event(post_done[q])          # group gi-2 has released this buffer pair
-            if timed:
-                ev0[gi].record(main)
-            grp.flow[q](mptr)
-            if timed:
-                ev1[gi].record(main)
-            if gather:
-                flow_done[q].record(main)
-                post.wait_event(flow_done[q])
-                with torch.cuda.stream(post):
-                    dist.all_gather_into_tensor(grp.full[q], grp.local[q])
-                grp.lse[q](pptr)
-                post_done[q].record(post)
-            else:
-                grp.lse[q](mptr)
-            done += grp.size
-            gi += 1
+    xs = [torch.from_numpy(a).to(dev) for a in xs_np]
 
     def barrier():
         torch.cuda.synchronize()
@@ -249,67 +234,131 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    # clock settle phase (untimed, on top of the W warm-up steps, reported as "prewarm_s"): a cold MI355X runs the first
-    # few hundred steps ~10 % slower while its clocks ramp up; the timed region is meant to see the steady state
-    # (a FIXED number of steps: every rank must issue the same collectives)
-    run(int(args.prewarm * 2000) // S * S, False)
-    run(args.warmup, False)
-    barrier()
-    t0 = time.perf_counter()
-    run(args.steps, True)
-    barrier()
-    elapsed = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    def timed_run(math, group, steps, warmup, prewarm, want_gather_times=False):
+        """The pipeline on this rank's components in `math` mode, groups of `group` batches: returns timing + the handles' info."""
+        flows = [native.NativeFlow(specs[c], math=math) for c in range(c0, c1)]
+        mix = native.NativeMixture(flows)
+        info = flows[0].info()
+        pipe = sharded.GroupPipeline(mix, C, c0, c1, rho, B, group, gather)
 
-    full_groups = args.steps // S
-    kern_ms = sum(ev0[i].elapsed_time(ev1[i]) for i in range(full_groups)) / max(1, full_groups)   # per GROUP launch
-    G_gpu = groups[S].G[(full_groups - 1) % NBUF][:B].cpu().numpy()      # batch 0 of the last full group
+        def run(n_steps, events=None):
+            done = gi = 0
+            last = None
+            while done < n_steps:
+                k = min(group, n_steps - done)
+                ev = None
+                if events is not None and k == group:
+                    ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+                    events.append(ev)
+                last = pipe.submit(xs[:k], ev)
+                done += k
+                gi += 1
+            return last
+
+        # clock settle phase (untimed, on top of the W warm-up steps, reported as "prewarm_s"): a cold MI355X runs the
+        # first few hundred steps ~10 % slower while its clocks ramp up (a FIXED number of steps: every rank must issue
+        # the same collectives)
+        run(int(prewarm * 2000) // group * group)
+        run(warmup)
+        barrier()
+        events = []
+        if want_gather_times and gather:
+            pipe.gather_events = []
+        t0 = time.perf_counter()
+        run(steps, events)
+        barrier()
+        elapsed = time.perf_counter() - t0
+        if world > 1:
+            t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            elapsed = float(t.item())
+        kern_ms = sum(a.elapsed_time(b) for a, b in events) / max(1, len(events))      # per full-group launch
+        gather_us = None
+        if pipe.gather_events:
+            gather_us = 1e3 * sum(a.elapsed_time(b) for a, b in pipe.gather_events) / len(pipe.gather_events)
+        # batch 0 of a full group (slot 0 was written by an even group; any slot holds a complete group's result)
+        G0 = pipe._buffers(group)[2][0][:B].cpu().numpy() if steps >= group else None
+        return {"elapsed": elapsed, "kern_ms": kern_ms, "info": info, "G0": G0, "gather_us": gather_us,
+                "name": MATH_NAME[info.math_mode], "keep": (flows, mix, pipe)}
+
+    def roofline(r, group):
+        info, math = r["info"], r["name"]
+        flops = 2.0 * info.macs_per_sample * (c1 - c0) * B * group            # one launch serves `group` batches
+        achieved = flops / (r["kern_ms"] * 1e-3) / 1e12
+        executed = achieved * info.padded_macs_per_sample / info.macs_per_sample * PRODUCTS[math]
+        peak = F32_MFMA_PEAK_TFLOPS if math == "f32" else F16_MFMA_PEAK_TFLOPS
+        alg_bytes = (4.0 * d + 4.0 * (c1 - c0)) * B * group                   # read x once, write ll per component
+        return {
+            "kernel": "gbnf::flow_kernel" if math == "f32" else "gbnf::flow_kernel_hx3",
+            "bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
+            "traffic": measured_traffic(args.config, B, C, group, math, world),
+            "launch_ms": r["kern_ms"], "flops_per_launch": flops, "batches_per_launch": group,
+            "executed_mfma_tflops": executed, "executed_frac": executed / peak,
+            "vs_f32_mfma_peak": achieved / F32_MFMA_PEAK_TFLOPS,
+            "hbm_algorithmic_bytes_per_launch": alg_bytes,
+            "hbm_algorithmic_GBs": alg_bytes / (r["kern_ms"] * 1e-3) / 1e9,
+            "hbm_frac": alg_bytes / (r["kern_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS,
+        }
+
+    main_run = timed_run(args.math, S, args.steps, args.warmup, args.prewarm, want_gather_times=True)
+    ranks_seen = None
+    if dist.is_initialized():
+        seen = torch.zeros(world, dtype=torch.int32, device=dev)
+        seen[rank] = 1 + torch.cuda.current_device()
+        dist.all_reduce(seen)
+        ranks_seen = [int(v) - 1 for v in seen.cpu()]       # local device index of every rank, -1 = a rank that did not answer
 
     if rank == 0:
-        value = B * args.steps / elapsed
-        f16x3 = info.math_mode == native.MATH["f16x3"]
-        flops_per_launch = 2.0 * info.macs_per_sample * (c1 - c0) * B * S      # one launch serves S batches
-        achieved_tf = flops_per_launch / (kern_ms * 1e-3) / 1e12
-        # what the matrix pipe executes: tile padding, and 3 f16 products per f32 product on the split path
-        executed_tf = achieved_tf * info.padded_macs_per_sample / info.macs_per_sample * (3.0 if f16x3 else 1.0)
-        peak = F16_MFMA_PEAK_TFLOPS if f16x3 else F32_MFMA_PEAK_TFLOPS
-        alg_bytes = (4.0 * d + 4.0 * (c1 - c0)) * B * S      # read x once, write ll per component
+        value = B * args.steps / main_run["elapsed"]
+        math = main_run["name"]
+        rl = roofline(main_run, S)
+        rl["note"] = ("achieved = ALGORITHMIC f32 flops / launch time (HIP events around the launch); the split paths run "
+                      "3x / 6x (+padding) that on the f16 pipe (executed_*). The binding limit is instruction issue: VALU "
+                      "(tanh, hi/mid split) and MFMA serialise on a SIMD (tools/ubench), see DESIGN.md section 4")
         out = {
             "metric": "density-eval samples/sec, Boosted-Glow C=8 MINIBOONE d=43" if args.config == "miniboone_glow"
                       else f"density-eval samples/sec, {args.config}",
             "value": value, "unit": "samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": 1e3 * elapsed / args.steps, "prewarm_s": args.prewarm, "higher_is_better": True,
-            "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "ms_per_step": 1e3 * main_run["elapsed"] / args.steps, "prewarm_s": args.prewarm, "higher_is_better": True,
+            "scaling": "strong", "vs_baseline": None, "dtype": math, "data": "synthetic",
             "config": {"workload": f"{args.config}: d={d} h={h} K={K} C={C} batch={B}, x ~ N(0,1), synthetic weights",
-                       "global_batch": B, "components": C,
-                       "math": "f16x3: f32 operands split into two fp16 pieces, 3 f16 MFMAs per product, f32 accumulate"
-                               if f16x3 else "f32: exact f32-input MFMA",
-                       "parallelism": "single GPU, all components in one launch" if world == 1
-                       else f"components sharded {C // world}/GPU + one RCCL all-gather of ll per group",
-                       "group": f"{S} batches per flow launch / all-gather / recursion launch"},
-            "roofline": {
-                "kernel": "gbnf::flow_kernel_hx3" if f16x3 else "gbnf::flow_kernel",
-                "bound": "mfma", "achieved": achieved_tf, "peak": peak, "unit": "TFLOP/s",
-                "frac": achieved_tf / peak, "traffic": measured_traffic(args.config, B, C, S, f16x3, world),
-                "launch_ms": kern_ms, "flops_per_launch": flops_per_launch,
-                "executed_mfma_tflops": executed_tf, "executed_frac": executed_tf / peak,
-                "vs_f32_mfma_peak": achieved_tf / F32_MFMA_PEAK_TFLOPS,
-                "hbm_algorithmic_GBs": alg_bytes / (kern_ms * 1e-3) / 1e9,
-                "hbm_frac": alg_bytes / (kern_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                "note": "achieved = ALGORITHMIC f32 flops / launch time; the split path runs 3x (+padding) that on "
-                        "the f16 pipe. The binding limit is instruction issue: VALU (tanh, hi/mid split) and MFMA "
-                        "serialise on a SIMD (tools/ubench), see DESIGN.md section 4",
-            },
+                       "global_batch": B, "components": C, "math": MATH_TEXT[math], "group": S,
+                       "group_note": f"{S} batches per flow launch / all-gather / recursion launch (same for every N)",
+                       "parallelism": ("single GPU, all components in one launch" if world == 1 and not gather else
+                                       f"components sharded {C // world}/GPU + one RCCL all-gather of ll per group"),
+                       "emulated": bool(args.force_gather and world == 1)},
+            "roofline": rl,
         }
+        if gather:
+            out["rccl"] = {"ranks_seen": ranks_seen, "allgather_us": main_run["gather_us"],
+                           "allgather_bytes_per_rank": 4 * (c1 - c0) * S * B}
+        if world == 1 and not args.no_extra_legs:
+            legs = {}
+            n_leg = max(2 * S, min(args.steps, 320))
+            try:
+                r = timed_run("f32", S, n_leg, 2 * S, 0.0)
+                rf = roofline(r, S)
+                legs["f32_exact"] = {"value": B * n_leg / r["elapsed"], "unit": "samples/s", "dtype": "f32", "steps": n_leg,
+                                     "launch_ms": r["kern_ms"], "achieved_tflops": rf["achieved"], "peak": rf["peak"],
+                                     "frac": rf["frac"], "group": S}
+                del r
+            except native.GbnfError as e:
+                legs["f32_exact"] = {"error": str(e)}
+            r = timed_run(args.math, 1, n_leg, 16, 0.0)
+            rg = roofline(r, 1)
+            legs["group1"] = {"value": B * n_leg / r["elapsed"], "unit": "samples/s", "dtype": r["name"], "steps": n_leg,
+                              "launch_ms": r["kern_ms"], "ms_per_batch": 1e3 * r["elapsed"] / n_leg,
+                              "achieved_tflops": rg["achieved"], "frac": rg["frac"], "group": 1,
+                              "note": "one batch per flow launch + one recursion launch (per-call latency form)"}
+            del r
+            out["legs"] = legs
         if args.cpu_seconds > 0 and world == 1:
             cb, G_cpu, n_cpu = cpu_baseline(specs, rho_np, x_np, args.cpu_seconds)
             out["cpu_baseline"] = cb
             out["speedup_vs_cpu"] = value / cb["value"]
-            err = float(np.max(np.abs(G_gpu[:n_cpu].astype(np.float64) - G_cpu) / np.maximum(np.abs(G_cpu), 1.0)))
-            out["max_rel_err_vs_cpu"] = err
+            if main_run["G0"] is not None:
+                err = float(np.max(np.abs(main_run["G0"][:n_cpu].astype(np.float64) - G_cpu) / np.maximum(np.abs(G_cpu), 1.0)))
+                out["max_rel_err_vs_cpu"] = err
         elif args.cpu_seconds > 0:
             out["cpu_baseline"] = None     # reported on the N=1 run only
         line = json.dumps(out)

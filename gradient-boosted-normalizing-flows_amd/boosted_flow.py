@@ -19,8 +19,10 @@ Additions named in BASELINE.json / SURVEY.md section 8(b): ``component_forward``
 ActNorm's data-dependent initialisation (train mode, first batch: models/layers.py:473-486) is reproduced with
 the statistics kernel ``gbnf_actnorm_init``.
 
-Out of scope here: backward pass / training, sampling (the reference's
-``decode`` is dead code: models/boosted_flow.py:216 passes a misspelt kwarg), image inputs.
+Also here: the training step -- ``model.train(); model(x=x, components=c)`` is recorded by autograd
+and both directions run in the library (``_FlowFunction`` / ``native.NativeTrainer``); the inverse direction / sampling
+(``decode``, ``model(z=, reverse=True)``; the reference's own ``decode`` is dead code: models/boosted_flow.py:216 passes a
+misspelt kwarg); image inputs dispatch to ``image_glow.BoostedImageFlow`` (``BoostedFlow.__new__``).
 """
 from __future__ import annotations
 
@@ -180,7 +182,7 @@ class FlowNet(nn.Module):
     def __init__(self, args):
         super().__init__()
         if len(args.input_size) > 1:
-            raise NotImplementedError("image inputs are outside the supported path (SURVEY.md section 8f, N4)")
+            raise NotImplementedError("image inputs are built by image_glow.BoostedImageFlow (BoostedFlow(args) dispatches there)")
         self.image_input = False
         self.K = args.num_flows
         self.L = args.num_blocks
@@ -269,6 +271,10 @@ class _FlowFunction(torch.autograd.Function):
         z, ldj, trace = trainer.forward(x, want_trace=True)
         ctx.trainer = trainer
         ctx.trace = trace                       # every step's normalised state: spares the backward its forward sweep
+        # batch-statistics BatchNorm: the step statistics live in the trainer's bound buffers (bn.batch_mean / batch_var),
+        # which the NEXT recorded forward of this component overwrites -- remember which call they belong to
+        trainer.forward_serial = getattr(trainer, "forward_serial", 0) + 1
+        ctx.forward_serial = trainer.forward_serial
         ctx.save_for_backward(x, *params)      # params: autograd's in-place-modification check only
         return z, ldj
 
@@ -276,6 +282,11 @@ class _FlowFunction(torch.autograd.Function):
     def backward(ctx, g_z, g_ldj):
         x = ctx.saved_tensors[0]
         trainer = ctx.trainer
+        if trainer.batch_stats and ctx.forward_serial != trainer.forward_serial:
+            raise RuntimeError(
+                "backward of a train-mode RealNVP component after ANOTHER recorded forward of the same component: the batch "
+                "statistics of this call were overwritten (one forward -> one backward per component in batch-statistics "
+                "mode; evaluate extra batches under torch.no_grad() or in eval())")
         g_z = None if g_z is None else g_z.contiguous().float()
         g_ldj = None if g_ldj is None else g_ldj.contiguous().float()
         with torch.cuda.device(x.device):
@@ -398,16 +409,19 @@ class BoostedFlow(nn.Module):
     @torch.no_grad()
     def _rho_gradients(self, x):
         """models/boosted_flow.py:119-139 (note: un-normalised rho in this recursion, as in the reference)."""
-        full_ll = fixed_ll = new_ll = None
+        self._check_ready(x)
         x = x.contiguous().float()
+        # the reference starts all three at zeros (:120-122): with component == 0 (second boosting pass, all_trained)
+        # new_ll and fixed_ll stay zero, the gradient is 0 and rho[0] is left where it is
+        full_ll = torch.zeros(x.shape[0], dtype=torch.float32, device=x.device)
+        fixed_ll = torch.zeros_like(full_ll)
+        new_ll = torch.zeros_like(full_ll)
         for c in range(self.component + 1):
-            self._check_ready(x)
             self._ensure_actnorm(x, c)
             with torch.cuda.device(x.device):     # ll_c = log N(z;0,I) + ldj straight from the flow kernel
                 _, _, ll = self.native_flow(c).forward(x, want_z=False, want_ldj=False, want_ll=True)
             if c == 0:
                 full_ll = ll
-                new_ll = ll if new_ll is None else new_ll
             else:
                 new_ll = ll
                 prev = torch.log(1 - self.rho[c]) + full_ll
@@ -628,8 +642,10 @@ class BoostedFlow(nn.Module):
 
     def log_prob(self, x, n_used=None):
         """(N,): mixture log-density over the first n_used components with the recursive
-        prefix-normalised weights of density_experiment.py:561-573.  Default n_used follows
-        ``evaluate``: ``self.component + 1`` (all components once ``all_trained``)."""
+        prefix-normalised weights of density_experiment.py:561-573.  Default n_used: ``self.component + 1`` as the
+        reference's ``evaluate`` (density_experiment.py:562), and ALL components once ``all_trained`` -- a deliberate
+        divergence: the reference keeps ``range(self.component + 1)`` there too, which after the last boosting pass
+        (component reset to 0) evaluates only the first component; pass ``n_used`` to reproduce that."""
         self._check_ready(x)
         n_used = self._n_used(n_used)
         x = x.contiguous().float()

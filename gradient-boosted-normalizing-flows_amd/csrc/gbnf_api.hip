@@ -82,14 +82,23 @@ namespace gbnf {
 
 static int ceil_div(int a, int b) { return (a + b - 1) / b; }
 
+// One counter per device (a kernel may only touch memory of the device it runs on): allocated on first use by a launch
+// on that device, never freed.
+constexpr int MAX_DEVICES = 64;
+static std::mutex g_dev_mu;
+static unsigned* g_sat_counter[MAX_DEVICES] = {};
+
 unsigned* saturation_counter() {
-  static unsigned* dev = [] {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= MAX_DEVICES) return nullptr;
+  std::lock_guard<std::mutex> lk(g_dev_mu);
+  if (g_sat_counter[dev] == nullptr) {
     unsigned* p = nullptr;
-    if (hipMalloc((void**)&p, sizeof(unsigned)) != hipSuccess) return (unsigned*)nullptr;
-    if (hipMemset(p, 0, sizeof(unsigned)) != hipSuccess) { (void)hipFree(p); return (unsigned*)nullptr; }
-    return p;
-  }();
-  return dev;
+    if (hipMalloc((void**)&p, sizeof(unsigned)) != hipSuccess) return nullptr;
+    if (hipMemset(p, 0, sizeof(unsigned)) != hipSuccess) { (void)hipFree(p); return nullptr; }
+    g_sat_counter[dev] = p;
+  }
+  return g_sat_counter[dev];
 }
 
 // physical hidden position p = 16 t + 4 g + r  <->  logical unit 4*(4t + r) + g
@@ -310,10 +319,13 @@ int gbnf_version(void) { return GBNF_ABI_VERSION; }
 int gbnf_saturation_count(int64_t* count, int32_t reset) {
   if (count == nullptr) return fail(GBNF_ERR_INVALID, "gbnf_saturation_count: count is null");
   *count = 0;
-  unsigned* dev = gbnf::saturation_counter();
+  unsigned* dev = gbnf::saturation_counter();                // the CURRENT device's counter
   if (dev == nullptr) return GBNF_OK;
   unsigned host = 0;
-  hipError_t e = hipMemcpy(&host, dev, sizeof(host), hipMemcpyDeviceToHost);      // (synchronises with the device)
+  // every stream of the device (torch's side streams are non-blocking ones: the null-stream copy alone would not
+  // order against their kernels)
+  hipError_t e = hipDeviceSynchronize();
+  if (e == hipSuccess) e = hipMemcpy(&host, dev, sizeof(host), hipMemcpyDeviceToHost);
   if (e == hipSuccess && reset) e = hipMemset(dev, 0, sizeof(host));
   if (e != hipSuccess) return fail(GBNF_ERR_HIP, "gbnf_saturation_count: %s", hipGetErrorString(e));
   *count = (int64_t)host;
@@ -868,7 +880,7 @@ __global__ void __launch_bounds__(64) actnorm_finalize_kernel(const float* __res
   logs[c] = logf(scale / (sqrtf(var) + 1e-6f));
 }
 
-static float* g_actnorm_ws = nullptr;   // 2 x AN_MAX_BLOCKS x 64 floats, allocated on first use, never freed
+static float* g_actnorm_ws[gbnf::MAX_DEVICES] = {};   // per device: 2 x AN_MAX_BLOCKS x 64 floats, allocated on first use, never freed
 static std::mutex g_actnorm_mu;
 
 #ifdef GBNF_STAMPS
@@ -1010,14 +1022,19 @@ int gbnf_actnorm_init(const float* z, int64_t n, int32_t d, float scale, float* 
   if (!z || !bias_out || !logs_out) return fail(GBNF_ERR_INVALID, "gbnf_actnorm_init: null pointer");
   if (n < 1) return fail(GBNF_ERR_INVALID, "gbnf_actnorm_init: needs at least one row");
   if (d < 1 || d > ZSLOTS) return fail(GBNF_ERR_UNSUPPORTED, "gbnf_actnorm_init: d=%d outside [1,%d]", d, ZSLOTS);
+  float* ws = nullptr;
   {
+    int dev = 0;
+    GBNF_HIP(hipGetDevice(&dev));
+    if (dev < 0 || dev >= gbnf::MAX_DEVICES) return fail(GBNF_ERR_UNSUPPORTED, "gbnf_actnorm_init: device index %d", dev);
     std::lock_guard<std::mutex> lk(g_actnorm_mu);
-    if (!g_actnorm_ws) GBNF_HIP(hipMalloc((void**)&g_actnorm_ws, sizeof(float) * 2 * AN_MAX_BLOCKS * 64));
+    if (!g_actnorm_ws[dev]) GBNF_HIP(hipMalloc((void**)&g_actnorm_ws[dev], sizeof(float) * 2 * AN_MAX_BLOCKS * 64));
+    ws = g_actnorm_ws[dev];
   }
   int nb = (int)((n + 63) / 64);
   if (nb > AN_MAX_BLOCKS) nb = AN_MAX_BLOCKS;
-  float* p1 = g_actnorm_ws;
-  float* p2 = g_actnorm_ws + AN_MAX_BLOCKS * 64;
+  float* p1 = ws;
+  float* p2 = ws + AN_MAX_BLOCKS * 64;
   hipStream_t s = (hipStream_t)stream;
   hipLaunchKernelGGL(actnorm_partial_kernel, dim3(nb), dim3(256), 0, s, z, n, d, (const float*)nullptr, 1, p1);
   hipLaunchKernelGGL(actnorm_partial_kernel, dim3(nb), dim3(256), 0, s, z, n, d, (const float*)p1, 2, p2);

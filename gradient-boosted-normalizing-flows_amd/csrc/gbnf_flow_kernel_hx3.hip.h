@@ -171,8 +171,12 @@ __global__ void __launch_bounds__(64 * HX3_WAVES, (NT == 1) ? 2 : 1) flow_kernel
         // uniform base + 32-bit per-lane offset -> saddr form, no 64-bit VALU address arithmetic
         const __attribute__((address_space(1))) char* base =
             reinterpret_cast<const __attribute__((address_space(1))) char*>(next_src + f * 256);
+#ifndef GBNF_ABLATE_DMA          // diagnostic: no weight staging at all (stale LDS contents, timing only)
         __builtin_amdgcn_global_load_lds(base + lane_b16, (__attribute__((address_space(3))) void*)(dst + f * 256),
                                          16, 0, 0);
+#else
+        (void)base; (void)dst;
+#endif
       }
     }
     next_src += NF * 256;
@@ -207,11 +211,19 @@ __global__ void __launch_bounds__(64 * HX3_WAVES, (NT == 1) ? 2 : 1) flow_kernel
   Stamps st;
   st.start();
 
+#ifdef GBNF_ABLATE_FRAG            // diagnostic: one fragment read per kernel, reused for every MFMA (timing only)
+  u32x4 frag_dummy = *reinterpret_cast<const u32x4*>(STG + lane * 4);
+  asm volatile("" : "+v"(frag_dummy));
+  auto frag = [&](const uint32_t*, int) -> u32x4 { return frag_dummy; };
+#else
   auto frag = [&](const uint32_t* buf, int f) -> u32x4 {
     return *reinterpret_cast<const u32x4*>(buf + f * 256 + lane * 4);
   };
+#endif
   auto stage_end = [&]() {
+#ifndef GBNF_ABLATE_BARRIER       // diagnostic: no per-stage rendezvous (races on the staging buffers, timing only)
     __syncthreads();             // all waves done with this buffer; the next stage's DMA has landed
+#endif
     ++gs;
   };
 
@@ -263,6 +275,11 @@ __global__ void __launch_bounds__(64 * HX3_WAVES, (NT == 1) ? 2 : 1) flow_kernel
       gf4 b1 = (gf4)nb + g;
       gf4 b2 = (gf4)(nb + HT * 16) + g;
       gf4 b3 = (gf4)(nb + 2 * HT * 16) + g;
+#ifdef GBNF_ABLATE_BIAS            // diagnostic: no bias loads from global memory (timing only)
+      auto ldb = [&](gf4, int) { return f32x4{0.01f, 0.02f, 0.03f, 0.04f}; };
+#else
+      auto ldb = [&](gf4 b, int idx) { return b[idx]; };
+#endif
       // ACT == 3 (GBNF_ACT_PER_STEP): the activation of this step's net comes from the step header (`--coupling_network random`): both are
       // computed and one is selected (the packer folded the tanh pre-scale into this net's layers only if it is a tanh net)
       const bool relu_rt = ACT == 3 && __builtin_amdgcn_readfirstlane(sp[2 + net]) != 0;
@@ -296,7 +313,7 @@ __global__ void __launch_bounds__(64 * HX3_WAVES, (NT == 1) ? 2 : 1) flow_kernel
       }
 #pragma unroll
       for (int o = 0; o < OT; ++o) {
-        const f32x4 b = b3[o * 4];
+        const f32x4 b = ldb(b3, o * 4);
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) out[o][nt] = b;
       }
@@ -304,7 +321,7 @@ __global__ void __launch_bounds__(64 * HX3_WAVES, (NT == 1) ? 2 : 1) flow_kernel
       // ---- layer 0: tile t = W1[tile t] . z  (one k = 32 chunk); the tanh + split of tile t-1 shares its region
       {
         f32x4 raw[NT];
-        f32x4 bias = b1[0];
+        f32x4 bias = ldb(b1, 0);
 #pragma unroll
         for (int sI = 0; sI < L.N_L0; ++sI) {
           const uint32_t* buf = STG + (gs & 1) * STAGE_WORDS;
@@ -329,7 +346,7 @@ __global__ void __launch_bounds__(64 * HX3_WAVES, (NT == 1) ? 2 : 1) flow_kernel
             const int t = t0 + tl;
             if (t < HT) {
               const u32x4 c_hi = AL[2 * tl], c_mid = AL[2 * tl + 1];
-              const f32x4 bias_next = b1[(t + 1 < HT ? t + 1 : t) * 4];
+              const f32x4 bias_next = ldb(b1, (t + 1 < HT ? t + 1 : t) * 4);
               f32x4 cur[NT];
 #pragma unroll
               for (int nt = 0; nt < NT; ++nt) {
@@ -392,7 +409,7 @@ __global__ void __launch_bounds__(64 * HX3_WAVES, (NT == 1) ? 2 : 1) flow_kernel
           hOhi[nt] = u32x4{0, 0, 0, 0};
           hOmid[nt] = u32x4{0, 0, 0, 0};
         }
-        f32x4 bias = b2[0];
+        f32x4 bias = ldb(b2, 0);
         // PREV: 0 = no previous tile (u = 0); 1 = tile u-1 is the FIRST half of its output-layer chunk
         // (u odd); 2 = it is the SECOND half and chunk (u-2)/2 is consumed at the end of this pass (u even >= 2)
         auto pass = [&](int u, auto prev_c, auto last_c) {
@@ -403,7 +420,7 @@ __global__ void __launch_bounds__(64 * HX3_WAVES, (NT == 1) ? 2 : 1) flow_kernel
           const uint32_t* buf = STG + (gs & 1) * STAGE_WORDS;
           issue(std::integral_constant<int, NF_NEXT>{}, gs + 1);
           u32x4 a_hi = frag(buf, 0), a_mid = frag(buf, 1);
-          const f32x4 bias_next = b2[(u + 1 < HT ? u + 1 : u) * 4];
+          const f32x4 bias_next = ldb(b2, (u + 1 < HT ? u + 1 : u) * 4);
           f32x4 acc[NT];
 #pragma unroll
           for (int nt = 0; nt < NT; ++nt) acc[nt] = bias;

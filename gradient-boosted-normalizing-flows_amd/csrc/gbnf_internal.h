@@ -6,8 +6,9 @@ namespace gbnf {
 // Records the message behind gbnf_last_error() (thread-local) and returns `code`.
 int fail(int code, const char* fmt, ...);
 
-// Device counter of waves that stored a split-f16 operand beyond +-65504 (it saturates there); null if it could not be
-// allocated.  Read and reset by gbnf_saturation_count().
+// The CURRENT device's counter of waves that stored a split-f16 operand beyond +-65504 (it saturates there); null if it
+// could not be allocated.  Call it at launch time, with the launch's device current.  Read and reset by
+// gbnf_saturation_count().
 unsigned* saturation_counter();
 
 // Kernel-variant key only (not a descriptor value): the activation differs between the steps / nets of a component

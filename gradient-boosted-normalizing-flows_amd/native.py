@@ -18,7 +18,7 @@ LIB_PATH = os.environ.get("GBNF_LIB_PATH") or os.path.join(_HERE, "libgbnf_hip.s
 KIND = {"glow": 0, "realnvp": 1}
 ACT = {"tanh": 0, "relu": 1, "residual": 2}     # GBNF_ACT_TANH / _RELU / _RESIDUAL_RELU
 COUPLING = {"affine": 0, "additive": 1}
-MATH = {"default": -1, "f32": 0, "f16x3": 1}
+MATH = {"default": -1, "f32": 0, "f16x3": 1, "bf16x6": 2}
 
 # every symbol include/gbnf.h declares (tests check the library exports exactly these)
 ABI_SYMBOLS = (

@@ -7,8 +7,11 @@ launch, and a single ``all_gather`` of ``float32[C_local, n]`` per rank rebuilds
 ``(C, n)`` table on every rank before the (replicated, cheap) mixture recursion.
 
 No other collective exists on the path.  The exchange is latency-bound (4*n bytes per
-component), so ``ShardedMixture.log_prob_pipelined`` keeps the all-gather of batch i in
-flight under the flow kernel of batch i+1.
+component), so consecutive (independent) batches are served in GROUPS: ``GroupPipeline`` runs one flow
+launch per group on one HIP stream and the group's all-gather + recursion on a second one,
+double-buffered, so the exchange of group g overlaps the kernel of group g+1 (this is the
+pipeline ``bench.py`` times and ``tests/test_sharded_gpu.py`` checks on RCCL);
+``ShardedMixture.log_prob_pipelined`` is the single-stream form of the same idea.
 """
 from __future__ import annotations
 
@@ -136,3 +139,128 @@ class ReplicatedMixture:
         out = torch.empty(self.world * width, dtype=local.dtype, device=local.device)
         self.dist.all_gather_into_tensor(out, buf, group=self.group)
         return torch.cat([out[r * width: r * width + (pe - pb)] for r, (pb, pe) in enumerate(parts)])
+
+
+class GroupPipeline:
+    """The measured multi-GPU pipeline: groups of S independent batches, two HIP streams.
+
+        main stream:  flow kernel of group g     (ONE launch: rank's components x S batches, gbnf_mixture_component_log_prob_multi)
+        post stream:  all-gather of the (C_local, S*n) table  ->  (C, S*n)   (RCCL, one collective per group)
+                      mixture recursion over the whole table   ->  G (S*n,)  (one launch)
+
+    NBUF = 2 buffer sets: the flow kernel of group g+1 runs while group g is exchanged and finished; a buffer set is
+    re-used only after its recursion has completed (event-ordered, no host synchronisation anywhere).  Every launch is
+    bound once per distinct group of input tensors (``NativeMixture.prepared_group_log_prob`` /
+    ``native.prepared_mixture_lse``): per group the host does two ctypes calls and one RCCL call.
+
+    ``mix``: the rank's ``native.NativeMixture`` (its components [c_begin, c_end) of ``n_components``); ``gather`` False
+    (one rank, no collective forced) skips the second stream and the exchange.  ``submit(xs)`` returns the device tensor
+    that will hold G of the group's batches (batch b in [b*n, (b+1)*n)) once ``post_done`` of that slot has fired;
+    ``drain()`` makes the current stream wait for everything submitted."""
+
+    NBUF = 2
+
+    def __init__(self, mix, n_components, c_begin, c_end, rho, rows, group_size, gather, process_group=None):
+        import torch
+        from . import native
+        self.torch, self.native = torch, native
+        self.mix, self.C, self.c0, self.c1 = mix, int(n_components), int(c_begin), int(c_end)
+        self.rho, self.rows, self.S = rho, int(rows), int(group_size)
+        self.gather = bool(gather)
+        self.pg = process_group
+        self.dev = rho.device
+        self.main = torch.cuda.current_stream(self.dev)
+        self.post = torch.cuda.Stream(self.dev) if self.gather else self.main
+        self.flow_done = [torch.cuda.Event() for _ in range(self.NBUF)]
+        self.post_done = [torch.cuda.Event() for _ in range(self.NBUF)]
+        self._bufs = {}        # group size -> per-slot (local, full, G)
+        self._bound = {}       # (slot, data_ptrs of the group's inputs) -> (flow launch, recursion launch)
+        self.gi = 0            # groups submitted so far
+        self.gather_events = None     # optional [(start, end)] timing events around the all-gathers (bench.py)
+        if self.gather:
+            import torch.distributed as dist
+            self.dist = dist
+            if not dist.is_initialized():
+                raise RuntimeError("GroupPipeline(gather=True) needs an initialised process group (backend nccl = RCCL)")
+
+    def _buffers(self, size):
+        torch = self.torch
+        if size not in self._bufs:
+            n = size * self.rows
+            local = [torch.empty((self.c1 - self.c0, n), dtype=torch.float32, device=self.dev) for _ in range(self.NBUF)]
+            full = ([torch.empty((self.C, n), dtype=torch.float32, device=self.dev) for _ in range(self.NBUF)]
+                    if self.gather else local)
+            G = [torch.empty(n, dtype=torch.float32, device=self.dev) for _ in range(self.NBUF)]
+            self._bufs[size] = (local, full, G)
+        return self._bufs[size]
+
+    def _launches(self, q, xs):
+        key = (q,) + tuple(t.data_ptr() for t in xs)
+        if key not in self._bound:
+            local, full, G = self._buffers(len(xs))
+            self._bound[key] = (self.mix.prepared_group_log_prob(list(xs), local[q]),
+                                self.native.prepared_mixture_lse(full[q], self.rho, G[q]))
+        return self._bound[key]
+
+    def submit(self, xs, kernel_events=None):
+        """Enqueue one group (1..S batches of (rows, d)); ``kernel_events`` = (start, end) timing events recorded around
+        the flow launch on the main stream.  Returns (G tensor of the slot, slot index)."""
+        import ctypes
+        torch = self.torch
+        if not 1 <= len(xs) <= self.S:
+            raise ValueError(f"a group holds 1..{self.S} batches")
+        q = self.gi % self.NBUF
+        local, full, G = self._buffers(len(xs))
+        flow, lse = self._launches(q, xs)
+        mptr = ctypes.c_void_p(self.main.cuda_stream)
+        if self.gather and self.gi >= self.NBUF:
+            self.main.wait_event(self.post_done[q])          # group gi-NBUF has released this buffer set
+        if kernel_events is not None:
+            kernel_events[0].record(self.main)
+        flow(mptr)
+        if kernel_events is not None:
+            kernel_events[1].record(self.main)
+        if self.gather:
+            self.flow_done[q].record(self.main)
+            self.post.wait_event(self.flow_done[q])
+            with torch.cuda.stream(self.post):
+                ev = None
+                if self.gather_events is not None:
+                    ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+                    ev[0].record(self.post)
+                self.dist.all_gather_into_tensor(full[q], local[q], group=self.pg)
+                if ev is not None:
+                    ev[1].record(self.post)
+                    self.gather_events.append(ev)
+            lse(ctypes.c_void_p(self.post.cuda_stream))
+            self.post_done[q].record(self.post)
+        else:
+            lse(mptr)
+        self.gi += 1
+        return G[q], q
+
+    def drain(self):
+        """The main stream waits for every exchange / recursion submitted so far."""
+        if self.gather:
+            for ev in self.post_done[: min(self.gi, self.NBUF)]:
+                self.main.wait_event(ev)
+
+    def log_prob_groups(self, groups):
+        """Convenience form: [[x, ...], ...] -> [G per batch] (cloned out of the slot buffers as each slot completes)."""
+        outs = []
+        pending = []
+        for xs in groups:
+            if len(pending) == self.NBUF:      # the slot about to be re-used: copy its result out first (stream-ordered)
+                self._collect(pending.pop(0), outs)
+            G, q = self.submit(xs)
+            pending.append((G, q, len(xs)))
+        for item in pending:
+            self._collect(item, outs)
+        return outs
+
+    def _collect(self, item, outs):
+        G, q, k = item
+        if self.gather:
+            self.main.wait_event(self.post_done[q])
+        n = self.rows
+        outs.extend(G[b * n:(b + 1) * n].clone() for b in range(k))

@@ -126,7 +126,8 @@ const char* gbnf_last_error(void);
 /* The split-f16 kernels (evaluation default, training) represent an f32 operand by two fp16 pieces: beyond +-65504 it
  * saturates silently (the normalised input of a coupling net; in training also activations and scaled gradients).  This
  * returns how many waves ran into that since the last reset -- 0 for z-scored data on a trained flow -- and optionally
- * resets the counter.  Library-wide; synchronises with the device. */
+ * resets the counter.  One counter per device: this reports (and resets) the CURRENT device's, after a
+ * hipDeviceSynchronize() (every stream of that device). */
 int gbnf_saturation_count(int64_t* count, int32_t reset);
 
 /* Replaces: constructing flows[c] + .to(device)  (models/boosted_flow.py:42-50).

@@ -217,6 +217,23 @@ def test_update_rho_runs_on_the_device_path(golden_case):
     assert rel_err(fixed_ll.cpu().numpy(), g.ll[0]) < LL_RTOL         # G^(c-1) with one fixed component = ll_0
 
 
+def test_update_rho_second_boosting_pass_component_zero(golden_case):
+    """component == 0 with all_trained (the second pass over the components): the reference's recursion leaves
+    new_ll = fixed_ll = zeros (models/boosted_flow.py:120-122), so the gradient is 0 and rho[0] does not move."""
+    import torch
+    dev = torch.device("cuda:0")
+    g = golden_case("g6_glow_d43_h64_c3_rho")
+    m = _model_from_case(g, dev)
+    m.component, m.all_trained = 0, True
+    m.args.rho_iters, m.args.rho_lr = 12, 0.1
+    before = m.rho.clone()
+    new_ll, fixed_ll, full_ll = m._rho_gradients(torch.from_numpy(g.x).to(dev))
+    assert float(new_ll.abs().max()) == 0.0 and float(fixed_ll.abs().max()) == 0.0
+    assert rel_err(full_ll.cpu().numpy(), g.ll[0]) < LL_RTOL
+    m.update_rho([(torch.from_numpy(g.x), None)])
+    assert torch.equal(m.rho, before)
+
+
 def test_boosting_weights_match_reference(golden_case):
     """G8: sample weights for the next component; kernel vs the reference's own statements, and the
     module method on top of the fixed components' mixture density."""

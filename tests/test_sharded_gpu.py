@@ -73,3 +73,57 @@ def test_two_ranks_one_gpu_matches_reference(name):
         for t in Gs:
             assert np.array_equal(t, G)
     assert np.array_equal(ret[0][0], ret[1][0])          # both ranks hold the same mixture density
+
+
+def _nccl_pipeline_worker(rank, world, port, name, ret):
+    """world_size = 1 on the real RCCL backend: the two-stream group pipeline bench.py times (GroupPipeline)."""
+    import torch
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    dev = torch.device("cuda:0")
+    torch.cuda.set_device(dev)
+    dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    try:
+        from conftest import GoldenCase
+        from gbnf_amd import native, sharded, synth
+        g = GoldenCase(name)
+        C, d, n = len(g.specs), g.cfg["d"], g.x.shape[0]
+        mix, flows = native.mixture_from_specs(g.specs)
+        rho = torch.from_numpy(g.rho).to(dev)
+        S = 3
+        batches = [g.x] + [synth.synth_batch(n, d, seed=50 + b) for b in range(1, 7)]      # 7 batches: groups of 3, 3, 1
+        xs = [torch.from_numpy(b).to(dev) for b in batches]
+        pipe = sharded.GroupPipeline(mix, C, 0, C, rho, n, S, gather=True)
+        pipe.gather_events = []
+        outs = pipe.log_prob_groups([xs[0:3], xs[3:6], xs[6:7]])
+        pipe.drain()
+        torch.cuda.synchronize()
+        # the same groups again: every launch is already bound, buffers are re-used across the two slots
+        outs2 = pipe.log_prob_groups([xs[0:3], xs[3:6], xs[6:7]])
+        torch.cuda.synchronize()
+        ref = [mix.log_prob(x, rho)[0] for x in xs]                                      # per-batch launches, no exchange
+        torch.cuda.synchronize()
+        ret[rank] = ([o.cpu().numpy() for o in outs], [o.cpu().numpy() for o in outs2], [r.cpu().numpy() for r in ref],
+                     len(pipe.gather_events))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_group_pipeline_on_rccl_world_size_one():
+    """The measured pipeline class on the `nccl` (= RCCL) backend: flow launches on one stream, all_gather_into_tensor +
+    recursion on a second one, double-buffered; results bit-identical to per-batch launches and within 1e-5 of the
+    reference fixture."""
+    import torch.multiprocessing as mp
+    from conftest import GoldenCase, rel_err
+    name = "g3_glow_d43_h215_c8"
+    g = GoldenCase(name)
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_nccl_pipeline_worker, args=(1, _free_port(), name, ret), nprocs=1, join=True)
+    outs, outs2, ref, n_gathers = ret[0]
+    assert len(outs) == 7 and n_gathers == 3
+    assert rel_err(outs[0], g.G) < 1e-5
+    for a, b, c in zip(outs, outs2, ref):
+        assert np.array_equal(a, c) and np.array_equal(b, c)
