@@ -38,12 +38,14 @@ def test_miniboone_glow_c4_batch_4096_against_oracle():
     G, ll = mix.log_prob(torch.from_numpy(xs).to(dev), torch.from_numpy(rho).to(dev))
     assert rel_err(ll.cpu().numpy(), ll_ref) < LL_RTOL
     assert rel_err(G.cpu().numpy(), G_ref) < LL_RTOL
-    # the group form bench.py times (16 batches in one launch): batch 0 identical to the single launch
+    # the group form bench.py times (16 batches in one launch): batch 0 agrees with the single launch (bit-identical
+    # when both use the same samples-per-wave tile; here the single launch runs 16-sample tiles, the group 32-sample ones)
     table = torch.empty((4, 16 * 4096), dtype=torch.float32, device=dev)
     xb = [torch.from_numpy(xs).to(dev)] + [torch.from_numpy(synth.synth_batch(4096, 43, seed=100 + s)).to(dev) for s in range(1, 16)]
     mix.prepared_group_log_prob(xb, table)(native._stream_ptr())
     torch.cuda.synchronize()
-    assert np.array_equal(table[:, :4096].cpu().numpy(), ll.cpu().numpy())
+    assert rel_err(table[:, :4096].cpu().numpy(), ll.cpu().numpy()) < 2e-6
+    assert rel_err(table[:, :4096].cpu().numpy(), ll_ref) < LL_RTOL
     Gg = native.mixture_lse(table, torch.from_numpy(rho).to(dev)).cpu().numpy()
     assert rel_err(Gg, _lse64(table.cpu().numpy(), rho)) < 5e-6     # all 16 batches: G == LSE(ll + log w) in float64
 
