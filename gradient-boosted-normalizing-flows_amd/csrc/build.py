@@ -27,10 +27,11 @@ def read_variants():
             line = line.split("#")[0].strip()
             if not line:
                 continue
-            if line.startswith("hx3"):
+            if line.startswith("hx3"):     # both split precisions: 0 = f16x3, 1 = bf16x6 (its repair pass / safe mode)
                 kind, ht, ot, acta, actb = (int(v) for v in line.split()[1:])
                 for nt in (1, 2):
-                    out.append(("hx3", kind, ht, ot, nt, acta, actb))
+                    for prec in (0, 1):
+                        out.append(("hx3", kind, ht, ot, nt, acta, actb, prec))
                 continue
             kind, ht, ksl, ks1, ot, lmid, acta, actb = (int(v) for v in line.split())
             for nt in (1, 2):
@@ -50,6 +51,48 @@ def run(cmd):
     if r.returncode != 0:
         raise RuntimeError("command failed: %s\n%s" % (" ".join(cmd), r.stdout))
     return r.stdout
+
+
+LLVM_BIN = "/opt/rocm/lib/llvm/bin"
+VGPR_FORM = ["-mllvm", "-amdgpu-mfma-vgpr-form=1"]
+
+
+def scratch_bytes(obj):
+    """Private-segment (scratch) bytes per lane of the gfx950 kernel inside a host object, or None if it cannot be read."""
+    import tempfile
+    with tempfile.TemporaryDirectory() as t:
+        fb, co = os.path.join(t, "fb.bin"), os.path.join(t, "dev.co")
+        try:
+            run([os.path.join(LLVM_BIN, "llvm-objcopy"), "--dump-section", ".hip_fatbin=" + fb, obj])
+            run([os.path.join(LLVM_BIN, "clang-offload-bundler"), "--type=o", "--input=" + fb,
+                 "--targets=hipv4-amdgcn-amd-amdhsa--gfx950", "--unbundle", "--output=" + co])
+            notes = run([os.path.join(LLVM_BIN, "llvm-readelf"), "--notes", co])
+        except RuntimeError:
+            return None
+    worst = 0
+    for line in notes.splitlines():
+        if ".private_segment_fixed_size:" in line:
+            worst = max(worst, int(line.split(":")[1]))
+    return worst
+
+
+def compile_hx3(cmd):
+    """A split-kernel variant: accumulators in VGPRs (the activation + split reads them directly, no v_accvgpr_read per
+    value) -- unless that build spills: one wave per SIMD has 512 registers only as 256 VGPRs + 256 AGPRs, and the
+    VGPR form cannot use the second half; such variants are rebuilt with the default (AGPR) accumulator placement."""
+    run(cmd)
+    obj = cmd[-1]
+    sb = scratch_bytes(obj)
+    if sb:
+        plain = [a for a in cmd if a not in VGPR_FORM]
+        run(plain)
+        sb2 = scratch_bytes(obj)
+        if sb2 is not None and sb2 > sb:
+            run(cmd)          # the VGPR form was the smaller evil
+            sb2 = sb
+        if sb2:
+            print(f"[gbnf build] note: {os.path.basename(obj)} uses {sb2} bytes of scratch per lane", flush=True)
+    return ""
 
 
 def main(argv=None):
@@ -79,7 +122,7 @@ def main(argv=None):
         if v[0] == "hx3":
             vsrc, vargs = os.path.join(HERE, "variant_hx3.hip"), v[1:]
             # keep MFMA accumulators in VGPRs: the tanh/split reads them directly (no v_accvgpr_read per value)
-            extra = ["-mllvm", "-amdgpu-mfma-vgpr-form=1"]
+            extra = list(VGPR_FORM)
         else:
             vsrc, vargs = os.path.join(HERE, "variant.hip"), v
         if args.force or not newer(o, [vsrc] + hdr):
@@ -96,7 +139,7 @@ def main(argv=None):
     if jobs:
         print(f"[gbnf build] compiling {len(jobs)} object(s) with -j{args.j}", flush=True)
         with cf.ThreadPoolExecutor(max_workers=args.j) as ex:
-            for _ in ex.map(run, jobs):
+            for _ in ex.map(lambda c: compile_hx3(c) if "variant_hx3.hip" in " ".join(c) else run(c), jobs):
                 pass
     if jobs or not os.path.exists(LIB):
         run([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs)

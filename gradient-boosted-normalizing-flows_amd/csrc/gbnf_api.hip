@@ -58,7 +58,9 @@ struct NetDims {
 }  // namespace gbnf
 
 struct gbnf_flow {
-  int math_mode = 0;   // GBNF_MATH_*
+  int math_mode = 0;   // GBNF_MATH_* actually in use (F32, F16X3 or BF16X6)
+  int requested_mode = 0;     // what the caller asked for (GBNF_MATH_DEFAULT = chosen by the probe)
+  float probe_rel_err = -1.0f;   // DEFAULT mode: largest relative log-likelihood difference f16x3 vs bf16x6 on the probe batch
   int kind = 0, d = 0, n_steps = 0, additive = 0;
   int hidden = 0, depth = 0, act_a = 0, act_b = 0, residual = 0;
   int ht = 0, ksl = 0, ot = 0;     // tile geometry (exact)
@@ -70,17 +72,34 @@ struct gbnf_flow {
   const uint32_t** self_table_dev = nullptr;  // 1-entry blob table for single-flow launches
   size_t blob_words = 0;
   double macs = 0, padded_macs = 0;
+  // split kernels: `blob_dev` / `launch_nt` belong to `math_mode`; an f16x3 handle also carries the bf16x6 packing of the
+  // same parameters: the repair pass behind every f16x3 launch (samples that left the fp16 range) and the mode a
+  // mixture falls back to when its components were created in different split modes
+  gbnf::LaunchFn launch2_nt[3] = {nullptr, nullptr, nullptr};
+  const char* name2_nt[3] = {nullptr, nullptr, nullptr};
+  uint32_t* blob2_dev = nullptr;
+  const uint32_t** self_table2_dev = nullptr;
+  size_t blob2_words = 0;
+  double padded_macs2 = 0;
+  int var2_ht = 0, var2_ot = 0;
 };
 
 struct gbnf_mixture {
   std::vector<gbnf_flow*> flows;
+  int math_mode = 0;                    // the mode every component runs in
+  bool use_blob2 = false;               // components were created as f16x3 but the mixture runs their bf16x6 packing
   const uint32_t** table_dev = nullptr;
+  const uint32_t** table2_dev = nullptr;   // bf16x6 packings for the repair pass of an f16x3 mixture (or null)
   float* base_dev = nullptr;  // [2][d] mean, std or null
 };
 
 namespace gbnf {
 
 static int ceil_div(int a, int b) { return (a + b - 1) / b; }
+
+// DEFAULT math mode keeps a component on f16x3 when its probe agrees with bf16x6 to this relative log-likelihood error
+// (a quarter of the 1e-5 bar: headroom for data that is harder than the probe batch)
+constexpr float PROBE_MAX_REL_ERR = 2.5e-6f;
 
 // One counter per device (a kernel may only touch memory of the device it runs on): allocated on first use by a launch
 // on that device, never freed.
@@ -208,7 +227,7 @@ static void pack_net(std::vector<uint32_t>& blob, size_t base, const gbnf_net& n
 
 static size_t net_words(int HT, int KS1, int OT, int LMID) { return (size_t)NetLayoutRT(HT, KS1, OT, LMID).NET_WORDS; }
 
-// ---- f16x3 packing --------------------------------------------------------------------------------
+// ---- split-operand packing (f16x3 / bf16x6) ------------------------------------------------------------------
 static uint16_t f16_bits(float x) {
   const _Float16 h = static_cast<_Float16>(x);      // round to nearest even
   uint16_t b;
@@ -220,58 +239,87 @@ static float f16_to_f32(uint16_t b) {
   std::memcpy(&h, &b, 2);
   return static_cast<float>(h);
 }
+static uint16_t bf16_bits(float x) {                  // round to nearest even (finite inputs)
+  uint32_t u;
+  std::memcpy(&u, &x, 4);
+  u += 0x7fffu + ((u >> 16) & 1u);
+  return (uint16_t)(u >> 16);
+}
+static float bf16_to_f32(uint16_t b) {
+  const uint32_t u = (uint32_t)b << 16;
+  float f;
+  std::memcpy(&f, &u, 4);
+  return f;
+}
 
-// One (hi, mid) fragment pair at word offset `off`: 16 rows x 32 k-slots.  elem(i, g, j) returns the f32
-// weight of row i and k-slot (g, j); lane (i,g) stores its 8 f16 as 4 words, element 2q in the low half.
+// The NP pieces of one weight tile at word offset `off` (NP consecutive fragments, largest piece first): 16 rows x 32
+// k-slots.  elem(i, g, j) returns the f32 weight of row i and k-slot (g, j); lane (i,g) stores its 8 narrow values as
+// 4 words, element 2q in the low half.  NP = 2: fp16 (hi, mid); NP = 3: bf16 (p0, p1, p2); every piece rounded to nearest.
+// Returns false if a weight does not fit the narrow type's range (fp16: |w| > 65504).
 template <typename F>
-static void put_frag_pair(std::vector<uint32_t>& blob, size_t off, F elem) {
+static bool put_tile(std::vector<uint32_t>& blob, size_t off, int NP, F elem) {
+  bool ok = true;
   for (int lane = 0; lane < 64; ++lane) {
     const int i = lane & 15, gg = lane >> 4;
     for (int q = 0; q < 4; ++q) {
-      uint32_t whi = 0, wmid = 0;
+      uint32_t w[3] = {0, 0, 0};
       for (int e = 0; e < 2; ++e) {
-        const float v = elem(i, gg, 2 * q + e);
-        const uint16_t hi = f16_bits(v);
-        const uint16_t mid = f16_bits(v - f16_to_f32(hi));
-        whi |= (uint32_t)hi << (16 * e);
-        wmid |= (uint32_t)mid << (16 * e);
+        float r = elem(i, gg, 2 * q + e);
+        if (NP == 2 && !(std::fabs(r) <= 65504.0f)) ok = false;
+        for (int k = 0; k < NP; ++k) {
+          const uint16_t b = NP == 2 ? f16_bits(r) : bf16_bits(r);
+          w[k] |= (uint32_t)b << (16 * e);
+          r -= NP == 2 ? f16_to_f32(b) : bf16_to_f32(b);
+        }
       }
-      blob[off + (size_t)lane * 4 + q] = whi;
-      blob[off + 256 + (size_t)lane * 4 + q] = wmid;
+      for (int k = 0; k < NP; ++k) blob[off + (size_t)k * 256 + (size_t)lane * 4 + q] = w[k];
     }
   }
+  return ok;
 }
 
 // k-slot (g, j) of hidden chunk c  <->  hidden unit 16*(2c + (j>>2)) + 4g + (j&3): the D-register layout of two
 // consecutive 16-unit accumulator tiles read as one k = 32 B operand
 static int hx3_hidden_unit(int c, int gg, int j) { return 16 * (2 * c + (j >> 2)) + 4 * gg + (j & 3); }
 
-static void pack_net_hx3(std::vector<uint32_t>& blob, size_t base, const gbnf_net& net, int HT, int OT, int in_f,
+static bool pack_net_hx3(std::vector<uint32_t>& blob, size_t base, const gbnf_net& net, int HT, int OT, int NP, int in_f,
                          int h, int out_f) {
-  const Hx3Layout L(HT, OT);
+  const Hx3Layout L(HT, OT, NP);
   auto put = [&](size_t off, float v) { std::memcpy(&blob[base + off], &v, 4); };
   const gbnf_linear& l0 = net.layers[0];
   const gbnf_linear& l1 = net.layers[1];
   const gbnf_linear& l2 = net.layers[2];
-  // layers whose output goes through tanh carry the 2*log2(e) of tanh(x) = 1 - 2/(2^(2 log2(e) x) + 1)
-  const float T = net.activation == GBNF_ACT_TANH ? 2.8853900817779268f : 1.0f;
+  bool ok = true;
+  // tanh networks (gbnf_flow_kernel_hx3.hip.h, tanh_hx3): a layer whose output goes through tanh carries the factor
+  // T = 2*log2(e) of tanh(x) = 1 - 2/(2^(T x) + 1); the kernel hands on r = 1/(2^(T x) + 1), and the layer that
+  // consumes t = 1 - 2 r folds the affine map:  W.t + b = (-2 W).r + (b + W.1)   (row sums in double)
+  const bool tanh_net = net.activation == GBNF_ACT_TANH;
+  const float T = tanh_net ? 2.8853900817779268f : 1.0f;
+  const float R = tanh_net ? -2.0f : 1.0f;                  // factor on the weights of a layer fed by an activation
+  auto folded_bias = [&](const gbnf_linear& l, int row, int n_in) {
+    double b = l.bias[row];
+    if (tanh_net)
+      for (int k = 0; k < n_in; ++k) b += (double)l.weight[(size_t)row * n_in + k];
+    return (float)b;
+  };
   for (int t = 0; t < HT; ++t)
     for (int k = 0; k < 16; ++k) {
       const int u = 16 * t + k;
       put((size_t)t * 16 + k, u < h ? T * l0.bias[u] : 0.0f);
-      put((size_t)(HT + t) * 16 + k, u < h ? T * l1.bias[u] : 0.0f);
+      put((size_t)(HT + t) * 16 + k, u < h ? T * folded_bias(l1, u, h) : 0.0f);
     }
   for (int o = 0; o < OT; ++o)
     for (int k = 0; k < 16; ++k) {
       const int r = 16 * o + k;
-      put((size_t)(2 * HT + o) * 16 + k, r < out_f ? l2.bias[r] : 0.0f);
+      put((size_t)(2 * HT + o) * 16 + k, r < out_f ? folded_bias(l2, r, h) : 0.0f);
     }
+  const size_t TW = (size_t)NP * 256;                        // words per weight tile
   int s = 0;
   for (int i0 = 0; i0 < L.N_L0; ++i0, ++s) {               // layer 0: k-slot (g,j) = input feature 8g + j
-    const int t0 = i0 * HX3_L0_TILES;
-    for (int tl = 0; tl < L.nf[s] / 2; ++tl) {
+    const int t0 = i0 * L.TL0;
+    for (int tl = 0; tl < L.nf[s] / NP; ++tl) {
       const int t = t0 + tl;
-      put_frag_pair(blob, base + L.off[s] + (size_t)tl * 512, [&](int i, int gg, int j) {
+      ok &= put_tile(blob, base + L.off[s] + (size_t)tl * TW, NP, [&](int i, int gg, int j) {
         const int u = 16 * t + i, k = 8 * gg + j;
         return (u < h && k < in_f) ? T * l0.weight[(size_t)u * in_f + k] : 0.0f;
       });
@@ -279,27 +327,28 @@ static void pack_net_hx3(std::vector<uint32_t>& blob, size_t base, const gbnf_ne
   }
   for (int u = 0; u < HT; ++u, ++s) {                         // hidden row u (+ output chunk (u-2)/2)
     for (int c = 0; c < L.HC; ++c)
-      put_frag_pair(blob, base + L.off[s] + (size_t)c * 512, [&](int i, int gg, int j) {
+      ok &= put_tile(blob, base + L.off[s] + (size_t)c * TW, NP, [&](int i, int gg, int j) {
         const int uo = 16 * u + i, ui = hx3_hidden_unit(c, gg, j);
-        return (uo < h && ui < h) ? T * l1.weight[(size_t)uo * h + ui] : 0.0f;
+        return (uo < h && ui < h) ? T * R * l1.weight[(size_t)uo * h + ui] : 0.0f;
       });
     if (u % 2 == 0 && u >= 2) {
       const int c = (u - 2) / 2;
       for (int o = 0; o < OT; ++o)
-        put_frag_pair(blob, base + L.off[s] + (size_t)(L.HC + o) * 512, [&](int i, int gg, int j) {
+        ok &= put_tile(blob, base + L.off[s] + (size_t)(L.HC + o) * TW, NP, [&](int i, int gg, int j) {
           const int row = 16 * o + i, ui = hx3_hidden_unit(c, gg, j);
-          return (row < out_f && ui < h) ? l2.weight[(size_t)row * h + ui] : 0.0f;
+          return (row < out_f && ui < h) ? R * l2.weight[(size_t)row * h + ui] : 0.0f;
         });
     }
   }
   {                                                            // drain: output chunk HC-1
     const int c = L.HC - 1;
     for (int o = 0; o < OT; ++o)
-      put_frag_pair(blob, base + L.off[s] + (size_t)o * 512, [&](int i, int gg, int j) {
+      ok &= put_tile(blob, base + L.off[s] + (size_t)o * TW, NP, [&](int i, int gg, int j) {
         const int row = 16 * o + i, ui = hx3_hidden_unit(c, gg, j);
-        return (row < out_f && ui < h) ? l2.weight[(size_t)row * h + ui] : 0.0f;
+        return (row < out_f && ui < h) ? R * l2.weight[(size_t)row * h + ui] : 0.0f;
       });
   }
+  return ok;
 }
 
 static const Variant* find_variant(const VariantKey& k) {
@@ -339,6 +388,7 @@ static int default_math_mode() {
     const char* e = getenv("GBNF_MATH");          // "f32" | "f16x3": tuning / test knob
     if (e && !strcmp(e, "f32")) return (int)GBNF_MATH_F32;
     if (e && !strcmp(e, "f16x3")) return (int)GBNF_MATH_F16X3;
+    if (e && !strcmp(e, "bf16x6")) return (int)GBNF_MATH_BF16X6;
     return (int)GBNF_MATH_DEFAULT;
   }();
   return mode;
@@ -446,116 +496,87 @@ int gbnf_flow_create_mode(const gbnf_flow_desc* desc, int32_t math_mode, gbnf_fl
   return gbnf_flow_create_ex(desc, math_mode, 0, out);
 }
 
-int gbnf_flow_create_ex(const gbnf_flow_desc* desc, int32_t math_mode, int32_t flags, gbnf_flow** out) {
-  if (out == nullptr) return fail(GBNF_ERR_INVALID, "gbnf_flow_create: out is null");
-  *out = nullptr;
-  if (flags & ~GBNF_CREATE_PER_STEP_ACTIVATION) return fail(GBNF_ERR_INVALID, "gbnf_flow_create_ex: unknown flags 0x%x", flags);
-  DescInfo info;
-  {
-    const int rc = validate_desc(desc, &info);
-    if (rc) return rc;
+// ---- host-side blob of one component for one kernel variant ---------------------------------------------------
+struct VariantChoice {
+  bool hx3 = false;
+  int np = 0;                         // split kernels: pieces per operand (2 = f16x3, 3 = bf16x6)
+  int ht = 0, ksl = 0, ks1 = 0, ot = 0;
+  gbnf::LaunchFn launch_nt[3] = {nullptr, nullptr, nullptr};
+  const char* name_nt[3] = {nullptr, nullptr, nullptr};
+};
+
+struct PackedBlob {
+  std::vector<uint32_t> words;
+  double macs = 0, padded = 0;
+  bool in_range = true;               // f16x3: every (pre-scaled) weight fits the fp16 range
+};
+
+// the cheapest compiled split-kernel variant (key.ksl = -3 f16x3 / -6 bf16x6) that covers hidden width h and `ot` output tiles
+static bool choose_hx3(int kind, int h, int ot, int act_a, int act_b, int ksl_key, VariantChoice* vc) {
+  const int ht_b = ceil_div(h, 16);
+  long best = -1;
+  for (const Variant& v : variants()) {
+    const VariantKey& k = v.key;
+    if (k.ksl != ksl_key || k.kind != kind || k.act_a != act_a || k.act_b != act_b) continue;
+    if (k.ht < ht_b || k.ot < ot) continue;
+    const Variant* v1 = find_variant(VariantKey{k.kind, k.ht, ksl_key, 0, k.ot, 1, 1, k.act_a, k.act_b});
+    const Variant* v2 = find_variant(VariantKey{k.kind, k.ht, ksl_key, 0, k.ot, 2, 1, k.act_a, k.act_b});
+    if (!v1 || !v2) continue;
+    const long cost = (long)k.ht * (k.ht + 1) / 2 * 2 + k.ht * k.ot;
+    if (best < 0 || cost < best) {
+      best = cost;
+      vc->hx3 = true; vc->np = ksl_key == -3 ? 2 : 3;
+      vc->ht = k.ht; vc->ksl = ksl_key; vc->ks1 = 0; vc->ot = k.ot;
+      vc->launch_nt[1] = v1->fn; vc->name_nt[1] = v1->name;
+      vc->launch_nt[2] = v2->fn; vc->name_nt[2] = v2->name;
+    }
   }
-  if (flags & GBNF_CREATE_PER_STEP_ACTIVATION) info.act_a = info.act_b = GBNF_ACT_PER_STEP;
-  {   // an activation pair nobody compiled a kernel for (`random` can draw a tanh shift net with a relu scale net for
-      // every step): the per-step variants cover it
-    bool compiled = false;
-    for (const Variant& v : variants())
-      compiled = compiled || (v.key.kind == desc->kind && v.key.act_a == info.act_a && v.key.act_b == info.act_b);
-    if (!compiled) info.act_a = info.act_b = GBNF_ACT_PER_STEP;
+  return best >= 0;
+}
+
+static bool choose_f32(int kind, int ht, int ksl, int ks1, int ot, int depth, int lmid_key, int act_a, int act_b,
+                       VariantChoice* vc) {
+  long best_cost = -1;
+  for (const Variant& v : variants()) {
+    const VariantKey& k = v.key;
+    if (k.ksl < 0) continue;
+    if (k.kind != kind || k.lmid != lmid_key || k.act_a != act_a || k.act_b != act_b) continue;
+    if (k.ot < ot || k.ks1 < ks1) continue;
+    // a variant processes hidden k-steps [0, 4(k.ht-1)+k.ksl); ours are [0, 4(ht-1)+ksl); extra ones
+    // multiply zero padding, so any superset is exact (just slower)
+    const bool covers_h = (k.ht > ht) || (k.ht == ht && k.ksl >= ksl);
+    if (!covers_h) continue;
+    // both NT=1 and NT=2 of the same geometry must exist
+    const Variant* v1 = find_variant(VariantKey{k.kind, k.ht, k.ksl, k.ks1, k.ot, 1, k.lmid, k.act_a, k.act_b});
+    const Variant* v2 = find_variant(VariantKey{k.kind, k.ht, k.ksl, k.ks1, k.ot, 2, k.lmid, k.act_a, k.act_b});
+    if (!v1 || !v2) continue;
+    const long cost = (long)(4 * (k.ht - 1) + k.ksl) * (k.ht * 16L * depth + k.ot * 16L) + k.ht * 16L * 4 * k.ks1;
+    if (best_cost < 0 || cost < best_cost) {
+      best_cost = cost;
+      vc->hx3 = false; vc->np = 0;
+      vc->ht = k.ht; vc->ksl = k.ksl; vc->ks1 = k.ks1; vc->ot = k.ot;
+      vc->launch_nt[1] = v1->fn; vc->name_nt[1] = v1->name;
+      vc->launch_nt[2] = v2->fn; vc->name_nt[2] = v2->name;
+    }
   }
+  return best_cost >= 0;
+}
+
+// Pads, tiles and folds the slot maps of `desc` for the kernel variant `vc` (host memory only).
+static void pack_component(const gbnf_flow_desc* desc, const DescInfo& info, const VariantChoice& vc, PackedBlob* pb) {
   const int d = desc->d, K = desc->n_steps;
   const bool glow = desc->kind == GBNF_KIND_GLOW;
   const bool additive = glow && desc->coupling == GBNF_COUPLING_ADDITIVE;
   const int d1 = d / 2, d2 = d - d1;
-  const NetDims ref = info.ref;
-  const int act_a = info.act_a, act_b = info.act_b;
-  const int h = ref.hidden, depth = ref.depth;
-  const int ht = info.ht, ksl = info.ksl, ot = info.ot;
-  (void)d1; (void)d2;
-
-  // ---- pick compiled variants (exact geometry first, then the cheapest zero-padded superset)
-  if (math_mode != GBNF_MATH_F32 && math_mode != GBNF_MATH_F16X3 && math_mode != GBNF_MATH_DEFAULT)
-    return fail(GBNF_ERR_INVALID, "unknown math mode %d", math_mode);
-  gbnf_flow* f = new gbnf_flow();
-  f->kind = desc->kind; f->d = d; f->n_steps = K; f->additive = additive ? 1 : 0;
-  f->hidden = h; f->depth = depth; f->act_a = act_a; f->act_b = act_b; f->residual = ref.residual;
-  const int lmid_key = ref.residual ? 10 + depth / 2 : depth;      // the LMID field of the variant key (gbnf_flow_kernel.hip.h)
-  const int ks1 = info.ks1;
-  f->ht = ht; f->ksl = ksl; f->ot = ot; f->ks1 = ks1;
-  bool hx3 = false;
-  if (math_mode != GBNF_MATH_F32 && depth == 1 && !ref.residual) {
-    // split-f16 kernel: hidden tiles in natural order (no k-step skipping), any zero-padded superset works
-    const int ht_b = ceil_div(h, 16);
-    long best = -1;
-    for (const Variant& v : variants()) {
-      const VariantKey& k = v.key;
-      if (k.ksl != -3 || k.kind != desc->kind || k.act_a != act_a || k.act_b != act_b) continue;
-      if (k.ht < ht_b || k.ot < ot) continue;
-      const Variant* v1 = find_variant(VariantKey{k.kind, k.ht, -3, 0, k.ot, 1, 1, k.act_a, k.act_b});
-      const Variant* v2 = find_variant(VariantKey{k.kind, k.ht, -3, 0, k.ot, 2, 1, k.act_a, k.act_b});
-      if (!v1 || !v2) continue;
-      const long cost = (long)k.ht * (k.ht + 1) / 2 * 2 + k.ht * k.ot;
-      if (best < 0 || cost < best) {
-        best = cost;
-        f->var_ht = k.ht; f->var_ksl = -3; f->var_ks1 = 0; f->var_ot = k.ot;
-        f->launch_nt[1] = v1->fn; f->name_nt[1] = v1->name;
-        f->launch_nt[2] = v2->fn; f->name_nt[2] = v2->name;
-      }
-    }
-    hx3 = best >= 0;
-    if (!hx3 && math_mode == GBNF_MATH_F16X3) {
-      delete f;
-      if (act_a != GBNF_ACT_PER_STEP && !ref.residual)     // the per-step-activation variants are generic supersets
-        return gbnf_flow_create_ex(desc, math_mode, flags | GBNF_CREATE_PER_STEP_ACTIVATION, out);
-      return fail(GBNF_ERR_UNSUPPORTED, "no compiled f16x3 kernel variant for kind=%d hidden=%d out_tiles=%d act=(%d,%d); "
-                  "add it to csrc/variants.list", desc->kind, h, ot, act_a, act_b);
-    }
-  } else if (math_mode == GBNF_MATH_F16X3) {
-    delete f;
-    return fail(GBNF_ERR_UNSUPPORTED, "the f16x3 kernel supports TanhNet / ReLUNet of coupling_network_depth == 1 only (got %s%d)",
-                ref.residual ? "a ResidualNet, hidden layers " : "", depth);
-  }
-  f->math_mode = hx3 ? GBNF_MATH_F16X3 : GBNF_MATH_F32;
-  if (!hx3) {
-    long best_cost = -1;
-    for (const Variant& v : variants()) {
-      const VariantKey& k = v.key;
-      if (k.ksl < 0) continue;
-      if (k.kind != desc->kind || k.lmid != lmid_key || k.act_a != act_a || k.act_b != act_b) continue;
-      if (k.ot < ot || k.ks1 < ks1) continue;
-      // a variant processes hidden k-steps [0, 4(k.ht-1)+k.ksl); ours are [0, 4(ht-1)+ksl); extra ones
-      // multiply zero padding, so any superset is exact (just slower)
-      const bool covers_h = (k.ht > ht) || (k.ht == ht && k.ksl >= ksl);
-      if (!covers_h) continue;
-      // both NT=1 and NT=2 of the same geometry must exist
-      const Variant* v1 = find_variant(VariantKey{k.kind, k.ht, k.ksl, k.ks1, k.ot, 1, k.lmid, k.act_a, k.act_b});
-      const Variant* v2 = find_variant(VariantKey{k.kind, k.ht, k.ksl, k.ks1, k.ot, 2, k.lmid, k.act_a, k.act_b});
-      if (!v1 || !v2) continue;
-      const long cost = (long)(4 * (k.ht - 1) + k.ksl) * (k.ht * 16L * depth + k.ot * 16L) + k.ht * 16L * 4 * k.ks1;
-      if (best_cost < 0 || cost < best_cost) {
-        best_cost = cost;
-        f->var_ht = k.ht; f->var_ksl = k.ksl; f->var_ks1 = k.ks1; f->var_ot = k.ot;
-        f->launch_nt[1] = v1->fn; f->name_nt[1] = v1->name;
-        f->launch_nt[2] = v2->fn; f->name_nt[2] = v2->name;
-      }
-    }
-    if (best_cost < 0) {
-      delete f;
-      if (act_a != GBNF_ACT_PER_STEP && !ref.residual)     // the per-step-activation variants are generic supersets
-        return gbnf_flow_create_ex(desc, math_mode, flags | GBNF_CREATE_PER_STEP_ACTIVATION, out);
-      return fail(GBNF_ERR_UNSUPPORTED,
-                  "no compiled kernel variant for kind=%d hidden=%d (tiles=%d,last k-steps=%d) in k-steps=%d out_tiles=%d "
-                  "depth=%d act=(%d,%d); add it to csrc/variants.list", desc->kind, h, ht, ksl, ks1, ot, depth, act_a,
-                  act_b);
-    }
-  }
-  const int HT = f->var_ht, OT = f->var_ot, KS1V = f->var_ks1;
-
+  const int h = info.ref.hidden, depth = info.ref.depth;
+  const bool hx3 = vc.hx3;
+  const int HT = vc.ht, OT = vc.ot, KS1V = vc.ks1;
   const int nnets = glow ? 1 : 2;
-  const size_t NW = hx3 ? (size_t)Hx3Layout(HT, OT).NET_WORDS : net_words(HT, KS1V, OT, depth);
+  const size_t NW = hx3 ? (size_t)Hx3Layout(HT, OT, vc.np).NET_WORDS : net_words(HT, KS1V, OT, depth);
   const size_t step_words = SMALL_WORDS + nnets * NW;
   const size_t total_words = step_words * K + 64;
-  std::vector<uint32_t> blob(total_words, 0u);
+  std::vector<uint32_t>& blob = pb->words;
+  blob.assign(total_words, 0u);
 
   // slot map: sigma[j] = LDS slot of logical feature j at the current step
   std::vector<int> sigma(d), prev(d);
@@ -625,7 +646,7 @@ int gbnf_flow_create_ex(const gbnf_flow_desc* desc, int32_t math_mode, int32_t f
       put_i(sb + 2, na.activation == GBNF_ACT_RELU ? 1 : 0);
       put_i(sb + 3, nb.activation == GBNF_ACT_RELU ? 1 : 0);
     }
-    // in tables [g][e]: f32 kernel k = 4e + g (k-step e, lane group g); f16x3 kernel k = 8g + e
+    // in tables [g][e]: f32 kernel k = 4e + g (k-step e, lane group g); split kernels k = 8g + e
     for (int gg = 0; gg < 4; ++gg)
       for (int e = 0; e < NENT; ++e) {
         const int k = hx3 ? 8 * gg + e : 4 * e + gg;
@@ -655,10 +676,10 @@ int gbnf_flow_create_ex(const gbnf_flow_desc* desc, int32_t math_mode, int32_t f
     const int net_out = paired ? 2 * out_f : out_f;
     if (hx3) {
       if (glow) {
-        pack_net_hx3(blob, sb + SMALL_WORDS, desc->glow_steps[s].block, HT, OT, in_f, h, net_out);
+        pb->in_range &= pack_net_hx3(blob, sb + SMALL_WORDS, desc->glow_steps[s].block, HT, OT, vc.np, in_f, h, net_out);
       } else {
-        pack_net_hx3(blob, sb + SMALL_WORDS, desc->realnvp_steps[s].t_net, HT, OT, in_f, h, net_out);
-        pack_net_hx3(blob, sb + SMALL_WORDS + NW, desc->realnvp_steps[s].s_net, HT, OT, in_f, h, net_out);
+        pb->in_range &= pack_net_hx3(blob, sb + SMALL_WORDS, desc->realnvp_steps[s].t_net, HT, OT, vc.np, in_f, h, net_out);
+        pb->in_range &= pack_net_hx3(blob, sb + SMALL_WORDS + NW, desc->realnvp_steps[s].s_net, HT, OT, vc.np, in_f, h, net_out);
       }
     } else if (glow) {
       pack_net(blob, sb + SMALL_WORDS, desc->glow_steps[s].block, HT, KS1V, OT, depth, in_f, h, net_out);
@@ -667,37 +688,176 @@ int gbnf_flow_create_ex(const gbnf_flow_desc* desc, int32_t math_mode, int32_t f
       pack_net(blob, sb + SMALL_WORDS + NW, desc->realnvp_steps[s].s_net, HT, KS1V, OT, depth, in_f, h, net_out);
     }
     macs += (double)nnets * ((double)in_f * h + (double)depth * h * h + (double)h * net_out);
-    if (hx3) {   // executed f16 MACs / 3 (each f32 product = 3 f16 products), k padded to 32
+    if (hx3) {   // executed narrow MACs / products per f32 product, k padded to 32
       const double hc = (HT + 1) / 2;
       padded += (double)nnets * (16.0 * HT * 32 + 16.0 * HT * 32 * hc + 16.0 * OT * 32 * hc);
     } else {
-      const double kh = 4.0 * (HT - 1) + f->var_ksl;  // live hidden k-steps in the variant
+      const double kh = 4.0 * (HT - 1) + vc.ksl;  // live hidden k-steps in the variant
       padded += (double)nnets * (16.0 * HT * 4 * KS1V + depth * 16.0 * HT * 4 * kh + 16.0 * OT * 4 * kh);
     }
   }
   for (int j = 0; j < d; ++j) put_i(step_words * K + j, sigma[j]);
-  f->macs = macs; f->padded_macs = padded;
-  f->blob_words = total_words;
+  pb->macs = macs; pb->padded = padded;
+}
 
-  hipError_t e = hipMalloc((void**)&f->blob_dev, total_words * 4);
-  if (e == hipSuccess) e = hipMemcpy(f->blob_dev, blob.data(), total_words * 4, hipMemcpyHostToDevice);
-  if (e == hipSuccess) e = hipMalloc((void**)&f->self_table_dev, sizeof(uint32_t*));
-  if (e == hipSuccess) e = hipMemcpy(f->self_table_dev, &f->blob_dev, sizeof(uint32_t*), hipMemcpyHostToDevice);
+static hipError_t upload_blob(const std::vector<uint32_t>& words, uint32_t** blob_dev, const uint32_t*** table_dev) {
+  hipError_t e = hipMalloc((void**)blob_dev, words.size() * 4);
+  if (e == hipSuccess) e = hipMemcpy(*blob_dev, words.data(), words.size() * 4, hipMemcpyHostToDevice);
+  if (e == hipSuccess) e = hipMalloc((void**)table_dev, sizeof(uint32_t*));
+  if (e == hipSuccess) e = hipMemcpy(*table_dev, blob_dev, sizeof(uint32_t*), hipMemcpyHostToDevice);
+  return e;
+}
+
+static void free_flow(gbnf_flow* f) {
+  if (!f) return;
+  if (f->blob_dev) (void)hipFree(f->blob_dev);
+  if (f->self_table_dev) (void)hipFree(f->self_table_dev);
+  if (f->blob2_dev) (void)hipFree(f->blob2_dev);
+  if (f->self_table2_dev) (void)hipFree(f->self_table2_dev);
+  delete f;
+}
+
+}  // extern "C"  (the probe needs launch_flow, defined below in namespace gbnf)
+
+namespace gbnf {
+static int probe_split_modes(gbnf_flow* f, float* rel_err);
+}
+
+extern "C" {
+
+int gbnf_flow_create_ex(const gbnf_flow_desc* desc, int32_t math_mode, int32_t flags, gbnf_flow** out) {
+  if (out == nullptr) return fail(GBNF_ERR_INVALID, "gbnf_flow_create: out is null");
+  *out = nullptr;
+  if (flags & ~GBNF_CREATE_PER_STEP_ACTIVATION) return fail(GBNF_ERR_INVALID, "gbnf_flow_create_ex: unknown flags 0x%x", flags);
+  DescInfo info;
+  {
+    const int rc = validate_desc(desc, &info);
+    if (rc) return rc;
+  }
+  if (flags & GBNF_CREATE_PER_STEP_ACTIVATION) info.act_a = info.act_b = GBNF_ACT_PER_STEP;
+  {   // an activation pair nobody compiled a kernel for (`random` can draw a tanh shift net with a relu scale net for
+      // every step): the per-step variants cover it
+    bool compiled = false;
+    for (const Variant& v : variants())
+      compiled = compiled || (v.key.kind == desc->kind && v.key.act_a == info.act_a && v.key.act_b == info.act_b);
+    if (!compiled) info.act_a = info.act_b = GBNF_ACT_PER_STEP;
+  }
+  const int d = desc->d, K = desc->n_steps;
+  const bool glow = desc->kind == GBNF_KIND_GLOW;
+  const bool additive = glow && desc->coupling == GBNF_COUPLING_ADDITIVE;
+  const NetDims ref = info.ref;
+  const int act_a = info.act_a, act_b = info.act_b;
+  const int h = ref.hidden, depth = ref.depth;
+  const int ht = info.ht, ksl = info.ksl, ot = info.ot;
+
+  if (math_mode != GBNF_MATH_F32 && math_mode != GBNF_MATH_F16X3 && math_mode != GBNF_MATH_BF16X6 && math_mode != GBNF_MATH_DEFAULT)
+    return fail(GBNF_ERR_INVALID, "unknown math mode %d", math_mode);
+  const bool split_shape = depth == 1 && !ref.residual;      // what the split kernels take: TanhNet / ReLUNet of depth 1
+  if (!split_shape && (math_mode == GBNF_MATH_F16X3 || math_mode == GBNF_MATH_BF16X6))
+    return fail(GBNF_ERR_UNSUPPORTED, "the split kernels (f16x3 / bf16x6) support TanhNet / ReLUNet of coupling_network_depth == 1 only (got %s%d)",
+                ref.residual ? "a ResidualNet, hidden layers " : "", depth);
+
+  // ---- pick compiled variants (exact geometry first, then the cheapest zero-padded superset)
+  VariantChoice fast, safe, exact;
+  const bool want_split = split_shape && math_mode != GBNF_MATH_F32;
+  const bool have_fast = want_split && math_mode != GBNF_MATH_BF16X6 && choose_hx3(desc->kind, h, ot, act_a, act_b, -3, &fast);
+  const bool have_safe = want_split && choose_hx3(desc->kind, h, ot, act_a, act_b, -6, &safe);
+  const bool retry_per_step = act_a != GBNF_ACT_PER_STEP && !ref.residual;   // the per-step-activation variants are generic supersets
+  if (math_mode == GBNF_MATH_F16X3 && !have_fast) {
+    if (retry_per_step) return gbnf_flow_create_ex(desc, math_mode, flags | GBNF_CREATE_PER_STEP_ACTIVATION, out);
+    return fail(GBNF_ERR_UNSUPPORTED, "no compiled f16x3 kernel variant for kind=%d hidden=%d out_tiles=%d act=(%d,%d); "
+                "add it to csrc/variants.list", desc->kind, h, ot, act_a, act_b);
+  }
+  if (math_mode == GBNF_MATH_BF16X6 && !have_safe) {
+    if (retry_per_step) return gbnf_flow_create_ex(desc, math_mode, flags | GBNF_CREATE_PER_STEP_ACTIVATION, out);
+    return fail(GBNF_ERR_UNSUPPORTED, "no compiled bf16x6 kernel variant for kind=%d hidden=%d out_tiles=%d act=(%d,%d); "
+                "add it to csrc/variants.list", desc->kind, h, ot, act_a, act_b);
+  }
+  const bool use_split = have_fast || (have_safe && math_mode != GBNF_MATH_F16X3);
+  if (!use_split) {
+    const int lmid_key = ref.residual ? 10 + depth / 2 : depth;      // the LMID field of the variant key (gbnf_flow_kernel.hip.h)
+    if (!choose_f32(desc->kind, ht, ksl, info.ks1, ot, depth, lmid_key, act_a, act_b, &exact)) {
+      if (retry_per_step) return gbnf_flow_create_ex(desc, math_mode, flags | GBNF_CREATE_PER_STEP_ACTIVATION, out);
+      return fail(GBNF_ERR_UNSUPPORTED,
+                  "no compiled kernel variant for kind=%d hidden=%d (tiles=%d,last k-steps=%d) in k-steps=%d out_tiles=%d "
+                  "depth=%d act=(%d,%d); add it to csrc/variants.list", desc->kind, h, ht, ksl, info.ks1, ot, depth, act_a,
+                  act_b);
+    }
+  }
+
+  gbnf_flow* f = new gbnf_flow();
+  f->requested_mode = math_mode;
+  f->kind = desc->kind; f->d = d; f->n_steps = K; f->additive = additive ? 1 : 0;
+  f->hidden = h; f->depth = depth; f->act_a = act_a; f->act_b = act_b; f->residual = ref.residual;
+  f->ht = ht; f->ksl = ksl; f->ot = ot; f->ks1 = info.ks1;
+
+  auto install_primary = [&](const VariantChoice& vc, const PackedBlob& pb, int mode) -> hipError_t {
+    f->math_mode = mode;
+    f->var_ht = vc.ht; f->var_ksl = vc.ksl; f->var_ks1 = vc.ks1; f->var_ot = vc.ot;
+    for (int nt = 1; nt <= 2; ++nt) { f->launch_nt[nt] = vc.launch_nt[nt]; f->name_nt[nt] = vc.name_nt[nt]; }
+    f->macs = pb.macs; f->padded_macs = pb.padded; f->blob_words = pb.words.size();
+    return upload_blob(pb.words, &f->blob_dev, &f->self_table_dev);
+  };
+  auto install_secondary = [&](const VariantChoice& vc, const PackedBlob& pb) -> hipError_t {
+    f->var2_ht = vc.ht; f->var2_ot = vc.ot;
+    for (int nt = 1; nt <= 2; ++nt) { f->launch2_nt[nt] = vc.launch_nt[nt]; f->name2_nt[nt] = vc.name_nt[nt]; }
+    f->padded_macs2 = pb.padded; f->blob2_words = pb.words.size();
+    return upload_blob(pb.words, &f->blob2_dev, &f->self_table2_dev);
+  };
+
+  hipError_t e = hipSuccess;
+  if (!use_split) {
+    PackedBlob pb;
+    pack_component(desc, info, exact, &pb);
+    e = install_primary(exact, pb, GBNF_MATH_F32);
+  } else {
+    PackedBlob pf, ps;
+    if (have_fast) pack_component(desc, info, fast, &pf);
+    if (have_safe) pack_component(desc, info, safe, &ps);
+    if (have_fast && !pf.in_range) {       // a (pre-scaled) weight beyond +-65504: the f16x3 packing cannot represent this model
+      if (math_mode == GBNF_MATH_F16X3 || !have_safe) {
+        free_flow(f);
+        return fail(GBNF_ERR_UNSUPPORTED, "a coupling-network weight exceeds the fp16 range (|w| > 65504): evaluate this model "
+                    "with GBNF_MATH_BF16X6 or GBNF_MATH_F32");
+      }
+      e = install_primary(safe, ps, GBNF_MATH_BF16X6);
+    } else if (have_fast) {
+      e = install_primary(fast, pf, GBNF_MATH_F16X3);
+      if (e == hipSuccess && have_safe) e = install_secondary(safe, ps);
+    } else {
+      e = install_primary(safe, ps, GBNF_MATH_BF16X6);
+    }
+  }
   if (e != hipSuccess) {
-    if (f->blob_dev) (void)hipFree(f->blob_dev);
-    if (f->self_table_dev) (void)hipFree(f->self_table_dev);
-    delete f;
+    free_flow(f);
     return fail(GBNF_ERR_HIP, "uploading packed parameters failed: %s", hipGetErrorString(e));
+  }
+  // ---- DEFAULT: the probe decides between the fast and the f32-faithful split mode
+  if (math_mode == GBNF_MATH_DEFAULT && f->math_mode == GBNF_MATH_F16X3 && f->blob2_dev != nullptr) {
+    float err = 0.0f;
+    const int rc = probe_split_modes(f, &err);
+    if (rc) { free_flow(f); return rc; }
+    f->probe_rel_err = err;
+    if (!(err <= PROBE_MAX_REL_ERR)) {      // (a NaN difference fails the test too): run this component on its bf16x6 packing
+      std::swap(f->blob_dev, f->blob2_dev);
+      std::swap(f->self_table_dev, f->self_table2_dev);
+      std::swap(f->blob_words, f->blob2_words);
+      for (int nt = 1; nt <= 2; ++nt) { f->launch_nt[nt] = f->launch2_nt[nt]; f->name_nt[nt] = f->name2_nt[nt]; }
+      f->padded_macs = f->padded_macs2;
+      f->var_ht = f->var2_ht; f->var_ot = f->var2_ot; f->var_ksl = -6;
+      f->math_mode = GBNF_MATH_BF16X6;
+      // the f16x3 packing is of no further use
+      (void)hipFree(f->blob2_dev); (void)hipFree(f->self_table2_dev);
+      f->blob2_dev = nullptr; f->self_table2_dev = nullptr; f->blob2_words = 0;
+      for (int nt = 1; nt <= 2; ++nt) { f->launch2_nt[nt] = nullptr; f->name2_nt[nt] = nullptr; }
+    }
   }
   *out = f;
   return GBNF_OK;
 }
 
 int gbnf_flow_destroy(gbnf_flow* flow) {
-  if (flow == nullptr) return GBNF_OK;
-  if (flow->blob_dev) (void)hipFree(flow->blob_dev);
-  if (flow->self_table_dev) (void)hipFree(flow->self_table_dev);
-  delete flow;
+  free_flow(flow);
   return GBNF_OK;
 }
 
@@ -710,7 +870,8 @@ int gbnf_flow_info(const gbnf_flow* flow, gbnf_kernel_info* info) {
   info->n_steps = flow->n_steps;
   info->macs_per_sample = flow->macs;
   info->padded_macs_per_sample = flow->padded_macs;
-  info->packed_bytes = (int64_t)flow->blob_words * 4;
+  info->packed_bytes = (int64_t)(flow->blob_words + flow->blob2_words) * 4;
+  info->probe_rel_err = flow->probe_rel_err;
   return GBNF_OK;
 }
 
@@ -718,8 +879,8 @@ int gbnf_flow_info(const gbnf_flow* flow, gbnf_kernel_info* info) {
 
 namespace gbnf {
 
-// samples per wave: 32 (NT=2) once there is enough work to give every SIMD of the chip a
-// wave that way (256 CUs x 4 SIMDs), otherwise 16 (NT=1) to expose more waves.
+// samples per wave: 32 (NT=2) once there is enough work to give every SIMD of the chip two
+// waves that way (256 CUs x 4 SIMDs x 2), otherwise 16 (NT=1) to expose more waves.
 static int pick_nt(int64_t n, int n_comp) {
   static const int forced = [] {
     const char* e = getenv("GBNF_FORCE_NT");   // tuning / test knob: 1 or 2
@@ -727,23 +888,36 @@ static int pick_nt(int64_t n, int n_comp) {
   }();
   if (forced == 1 || forced == 2) return forced;
   const int64_t waves32 = ((n + 31) / 32) * n_comp;
-  return waves32 >= 1024 ? 2 : 1;
+  return waves32 >= 2048 ? 2 : 1;
 }
 
 #ifdef GBNF_STAMPS
 static unsigned long long* g_stamp_buf = nullptr;
 #endif
 
-static int launch_flow(const gbnf_flow* f, const uint32_t* const* table, int c_begin, int n_comp, const float* x,
+static bool repair_enabled() {
+  static const bool on = [] {
+    const char* e = getenv("GBNF_NO_REPAIR");   // diagnostic knob: time the bare f16x3 launch
+    return !(e && atoi(e) != 0);
+  }();
+  return on;
+}
+
+// One launch of the flow kernel of `f` (all components of `table` share its variant).  `table2` (or null): the bf16x6
+// packings of the same components -- an f16x3 launch is followed by the repair launch over the same grid.
+static int launch_flow(const gbnf_flow* f, const uint32_t* const* table, const uint32_t* const* table2, bool use_second,
+                       int c_begin, int n_comp, const float* x,
                        int64_t n, float* z, float* ldj, float* ll, const float* base, hipStream_t stream,
                        int64_t out_stride = -1, const float* const* xs = nullptr, int n_batches = 1,
                        int inverse = 0) {
   if (n == 0 || n_comp == 0 || n_batches == 0) return GBNF_OK;
+  const int mode = use_second ? GBNF_MATH_BF16X6 : f->math_mode;
+  const LaunchFn* launch = use_second ? f->launch2_nt : f->launch_nt;
+  const char* const* names = use_second ? f->name2_nt : f->name_nt;
   const int nt = pick_nt(n * n_batches, n_comp);
   const int64_t tiles = (n + 16 * nt - 1) / (16 * nt);
-  // f32 kernel: one wave (= block) per tile; f16x3 kernel: one 4-wave block per group of 4 tiles
-  const int64_t grid =
-      (f->math_mode == GBNF_MATH_F16X3 ? (tiles + HX3_WAVES - 1) / HX3_WAVES : tiles) * n_comp * n_batches;
+  // f32 kernel: one wave (= block) per tile; the split kernels size their own grid
+  const int64_t grid = tiles * n_comp * n_batches;
   if (grid > 0x7fffffffLL) return fail(GBNF_ERR_UNSUPPORTED, "batch too large for one launch (%lld tiles)", (long long)grid);
   FlowLaunch p{};
   p.blobs = table; p.z_out = z; p.ldj_out = ldj; p.ll_out = ll;
@@ -757,8 +931,68 @@ static int launch_flow(const gbnf_flow* f, const uint32_t* const* table, int c_b
   p.dbg = g_stamp_buf;
 #endif
   p.sat = saturation_counter();
-  hipError_t e = f->launch_nt[nt](p, (unsigned)grid, stream);
-  if (e != hipSuccess) return fail(GBNF_ERR_HIP, "launch of %s failed: %s", f->name_nt[nt], hipGetErrorString(e));
+  hipError_t e = launch[nt](p, (unsigned)grid, stream);
+  if (e != hipSuccess) return fail(GBNF_ERR_HIP, "launch of %s failed: %s", names[nt], hipGetErrorString(e));
+  if (mode == GBNF_MATH_F16X3 && table2 != nullptr && f->launch2_nt[nt] != nullptr && repair_enabled()) {
+    p.blobs = table2;
+    p.repair = 1;
+    p.sat = nullptr;
+    e = f->launch2_nt[nt](p, (unsigned)grid, stream);
+    if (e != hipSuccess) return fail(GBNF_ERR_HIP, "repair launch of %s failed: %s", f->name2_nt[nt], hipGetErrorString(e));
+  }
+  return GBNF_OK;
+}
+
+// DEFAULT math mode: the same probe batch (rows ~ N(0,1), and N(0, 2^2) for the second half: what z-scored data looks
+// like, tails included) through the f16x3 and the bf16x6 packing of a new component; the largest relative
+// log-likelihood difference decides which one the handle runs on.  Synchronises (create does anyway).
+constexpr int PROBE_ROWS = 128;
+static int probe_split_modes(gbnf_flow* f, float* rel_err) {
+  const int d = f->d;
+  std::vector<float> x((size_t)PROBE_ROWS * d);
+  uint64_t st = 0x9E3779B97F4A7C15ull;
+  auto next_u = [&]() {                        // splitmix64 -> (0,1)
+    st += 0x9E3779B97F4A7C15ull;
+    uint64_t zz = st;
+    zz = (zz ^ (zz >> 30)) * 0xBF58476D1CE4E5B9ull;
+    zz = (zz ^ (zz >> 27)) * 0x94D049BB133111EBull;
+    zz ^= zz >> 31;
+    return ((double)(zz >> 11) + 0.5) / 9007199254740992.0;
+  };
+  for (int r = 0; r < PROBE_ROWS; ++r)
+    for (int j = 0; j < d; ++j) {
+      const double u1 = next_u(), u2 = next_u();
+      const double g0 = std::sqrt(-2.0 * std::log(u1)) * std::cos(6.283185307179586 * u2);
+      x[(size_t)r * d + j] = (float)(g0 * (r < PROBE_ROWS / 2 ? 1.0 : 2.0));
+    }
+  float *x_dev = nullptr, *ll_dev = nullptr;
+  GBNF_HIP(hipMalloc((void**)&x_dev, x.size() * 4));
+  hipError_t e = hipMalloc((void**)&ll_dev, 2 * PROBE_ROWS * 4);
+  if (e == hipSuccess) e = hipMemcpy(x_dev, x.data(), x.size() * 4, hipMemcpyHostToDevice);
+  int rc = GBNF_OK;
+  if (e == hipSuccess) {
+    rc = launch_flow(f, f->self_table_dev, nullptr, false, 0, 1, x_dev, PROBE_ROWS, nullptr, nullptr, ll_dev, nullptr, nullptr);
+    if (!rc) rc = launch_flow(f, f->self_table2_dev, nullptr, true, 0, 1, x_dev, PROBE_ROWS, nullptr, nullptr, ll_dev + PROBE_ROWS, nullptr, nullptr);
+  }
+  std::vector<float> ll(2 * PROBE_ROWS, 0.0f);
+  if (e == hipSuccess && !rc) e = hipMemcpy(ll.data(), ll_dev, ll.size() * 4, hipMemcpyDeviceToHost);   // (synchronises)
+  (void)hipFree(x_dev);
+  (void)hipFree(ll_dev);
+  if (rc) return rc;
+  if (e != hipSuccess) return fail(GBNF_ERR_HIP, "probing the split modes failed: %s", hipGetErrorString(e));
+  float worst = 0.0f;
+  for (int r = 0; r < PROBE_ROWS; ++r) {
+    const float a = ll[r], b = ll[PROBE_ROWS + r];
+    if (a == b) continue;                                   // (equal infinities included)
+    if (!(std::isfinite(a) && std::isfinite(b))) {
+      if (a != a && b != b) continue;                       // both NaN: the model explodes on this row either way
+      worst = INFINITY;
+      break;
+    }
+    const float rel = std::fabs(a - b) / std::fmax(std::fabs(b), 1.0f);
+    if (rel > worst) worst = rel;
+  }
+  *rel_err = worst;
   return GBNF_OK;
 }
 
@@ -895,7 +1129,7 @@ int gbnf_flow_forward(const gbnf_flow* flow, const float* x, int64_t n, float* z
   if (!flow) return fail(GBNF_ERR_INVALID, "gbnf_flow_forward: flow is null");
   if (n < 0) return fail(GBNF_ERR_INVALID, "gbnf_flow_forward: n < 0");
   if (n > 0 && !x) return fail(GBNF_ERR_INVALID, "gbnf_flow_forward: x is null");
-  return launch_flow(flow, flow->self_table_dev, 0, 1, x, n, z, ldj, ll, nullptr, (hipStream_t)stream);
+  return launch_flow(flow, flow->self_table_dev, flow->self_table2_dev, false, 0, 1, x, n, z, ldj, ll, nullptr, (hipStream_t)stream);
 }
 
 int gbnf_flow_inverse(const gbnf_flow* flow, const float* z, int64_t n, float* x, float* ldj, void* stream) {
@@ -904,7 +1138,7 @@ int gbnf_flow_inverse(const gbnf_flow* flow, const float* z, int64_t n, float* x
     return fail(GBNF_ERR_UNSUPPORTED, "gbnf_flow_inverse runs on the exact-f32 kernel: create the handle with GBNF_MATH_F32");
   if (n < 0) return fail(GBNF_ERR_INVALID, "gbnf_flow_inverse: n < 0");
   if (n > 0 && (!z || !x)) return fail(GBNF_ERR_INVALID, "gbnf_flow_inverse: z / x is null");
-  return launch_flow(flow, flow->self_table_dev, 0, 1, z, n, x, ldj, nullptr, nullptr, (hipStream_t)stream, -1,
+  return launch_flow(flow, flow->self_table_dev, nullptr, false, 0, 1, z, n, x, ldj, nullptr, nullptr, (hipStream_t)stream, -1,
                      nullptr, 1, 1);
 }
 
@@ -913,22 +1147,59 @@ int gbnf_mixture_create(gbnf_flow* const* flows, int32_t n_flows, gbnf_mixture**
   *out = nullptr;
   if (!flows || n_flows < 1) return fail(GBNF_ERR_INVALID, "gbnf_mixture_create: need >= 1 flow");
   const gbnf_flow* f0 = flows[0];
-  std::vector<const uint32_t*> table(n_flows);
+  // One launch = one kernel variant.  Components created in DEFAULT mode may have come out of their probes in different
+  // split modes: the mixture then runs all of them as bf16x6 (an f16x3 handle carries that packing too).
+  bool all_same = true, any_safe = false, all_have_safe = true;
   for (int c = 0; c < n_flows; ++c) {
     const gbnf_flow* f = flows[c];
     if (!f) return fail(GBNF_ERR_INVALID, "gbnf_mixture_create: flow %d is null", c);
-    if (f->math_mode != f0->math_mode || f->kind != f0->kind || f->d != f0->d || f->n_steps != f0->n_steps || f->additive != f0->additive ||
-        f->hidden != f0->hidden || f->depth != f0->depth || f->act_a != f0->act_a || f->act_b != f0->act_b || f->residual != f0->residual ||
-        f->var_ht != f0->var_ht || f->var_ksl != f0->var_ksl || f->var_ks1 != f0->var_ks1 || f->var_ot != f0->var_ot)
+    if (f->kind != f0->kind || f->d != f0->d || f->n_steps != f0->n_steps || f->additive != f0->additive ||
+        f->hidden != f0->hidden || f->depth != f0->depth || f->act_a != f0->act_a || f->act_b != f0->act_b || f->residual != f0->residual)
       return fail(GBNF_ERR_INVALID, "gbnf_mixture_create: flow %d has a different architecture than flow 0", c);
-    table[c] = f->blob_dev;
+    all_same = all_same && f->math_mode == f0->math_mode;
+    any_safe = any_safe || f->math_mode == GBNF_MATH_BF16X6;
+    all_have_safe = all_have_safe && (f->math_mode == GBNF_MATH_BF16X6 || (f->math_mode == GBNF_MATH_F16X3 && f->blob2_dev != nullptr));
+  }
+  const bool promote = !all_same && any_safe && all_have_safe;      // mixed f16x3 / bf16x6 -> everything on bf16x6
+  if (!all_same && !promote)
+    return fail(GBNF_ERR_INVALID, "gbnf_mixture_create: the flows were created in different math modes (%d vs %d)",
+                f0->math_mode, GBNF_MATH_BF16X6);
+  std::vector<const uint32_t*> table(n_flows), table2(n_flows, nullptr);
+  bool have2 = !promote && f0->math_mode == GBNF_MATH_F16X3;
+  const gbnf_flow* lead = f0;            // the flow whose launch table the mixture uses
+  for (int c = 0; c < n_flows; ++c) {
+    const gbnf_flow* f = flows[c];
+    if (promote) {
+      table[c] = f->math_mode == GBNF_MATH_BF16X6 ? f->blob_dev : f->blob2_dev;
+      if (f->math_mode == GBNF_MATH_BF16X6) lead = f;
+    } else {
+      table[c] = f->blob_dev;
+      table2[c] = f->blob2_dev;
+      have2 = have2 && f->blob2_dev != nullptr;
+    }
+    const int vht = (promote && f->math_mode == GBNF_MATH_F16X3) ? f->var2_ht : f->var_ht;
+    const int vot = (promote && f->math_mode == GBNF_MATH_F16X3) ? f->var2_ot : f->var_ot;
+    const int lht = (promote && f0->math_mode == GBNF_MATH_F16X3) ? f0->var2_ht : f0->var_ht;
+    const int lot = (promote && f0->math_mode == GBNF_MATH_F16X3) ? f0->var2_ot : f0->var_ot;
+    if (vht != lht || vot != lot || (!promote && (f->var_ksl != f0->var_ksl || f->var_ks1 != f0->var_ks1)))
+      return fail(GBNF_ERR_INVALID, "gbnf_mixture_create: flow %d runs on a different kernel variant than flow 0", c);
   }
   gbnf_mixture* m = new gbnf_mixture();
   m->flows.assign(flows, flows + n_flows);
+  // the launch table comes from flows[0]: when the mixture is promoted and flows[0] is an f16x3 handle, its second
+  // (bf16x6) launch table is used (launch_flow's use_second)
+  m->use_blob2 = promote && f0->math_mode == GBNF_MATH_F16X3;
+  m->math_mode = promote ? GBNF_MATH_BF16X6 : f0->math_mode;
+  (void)lead;
   hipError_t e = hipMalloc((void**)&m->table_dev, sizeof(uint32_t*) * n_flows);
   if (e == hipSuccess) e = hipMemcpy(m->table_dev, table.data(), sizeof(uint32_t*) * n_flows, hipMemcpyHostToDevice);
+  if (e == hipSuccess && have2) {
+    e = hipMalloc((void**)&m->table2_dev, sizeof(uint32_t*) * n_flows);
+    if (e == hipSuccess) e = hipMemcpy(m->table2_dev, table2.data(), sizeof(uint32_t*) * n_flows, hipMemcpyHostToDevice);
+  }
   if (e != hipSuccess) {
     if (m->table_dev) (void)hipFree(m->table_dev);
+    if (m->table2_dev) (void)hipFree(m->table2_dev);
     delete m;
     return fail(GBNF_ERR_HIP, "gbnf_mixture_create: %s", hipGetErrorString(e));
   }
@@ -939,6 +1210,7 @@ int gbnf_mixture_create(gbnf_flow* const* flows, int32_t n_flows, gbnf_mixture**
 int gbnf_mixture_destroy(gbnf_mixture* mix) {
   if (!mix) return GBNF_OK;
   if (mix->table_dev) (void)hipFree(mix->table_dev);
+  if (mix->table2_dev) (void)hipFree(mix->table2_dev);
   if (mix->base_dev) (void)hipFree(mix->base_dev);
   delete mix;
   return GBNF_OK;
@@ -988,7 +1260,7 @@ int gbnf_mixture_component_log_prob_multi(const gbnf_mixture* mix, const float* 
     return fail(GBNF_ERR_INVALID, "component range [%d,%d) outside [0,%d)", c_begin, c_end, C);
   if (n < 0) return fail(GBNF_ERR_INVALID, "n < 0");
   if (n > 0 && c_end > c_begin && (!x || !ll)) return fail(GBNF_ERR_INVALID, "x / ll is null");
-  return launch_flow(mix->flows[0], mix->table_dev, c_begin, c_end - c_begin, x, n, nullptr, nullptr, ll,
+  return launch_flow(mix->flows[0], mix->table_dev, mix->table2_dev, mix->use_blob2, c_begin, c_end - c_begin, x, n, nullptr, nullptr, ll,
                      mix->base_dev, (hipStream_t)stream, ll_row_stride, xs, n_batches);
 }
 

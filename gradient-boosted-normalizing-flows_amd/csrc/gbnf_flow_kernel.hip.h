@@ -94,7 +94,12 @@ struct FlowLaunch {
   int32_t n_batches;             // 1..MAX_BATCHES (z_out / ldj_out only with 1)
   int32_t inverse;               // f32 kernel only: run the flow backwards (xs = z in, z_out = x out, ldj_out = log|det dx/dz|)
   unsigned long long* dbg;       // diagnostic builds (-DGBNF_STAMPS) only: per-block phase cycle sums
-  unsigned* sat;                 // split-f16 kernel: counter of waves whose coupling-net inputs left the fp16 range (they saturate)
+  unsigned* sat;                 // split-f16 kernel: counter of waves that stored an operand beyond the fp16 range
+  int32_t ring;                  // hx3 kernels: stage slots of the LDS weight ring (2..HX3_MAX_RING), set by the launcher
+  int32_t repair;                // hx3 kernels: 1 = only workgroups owning a sample whose outputs are NaN run (the bf16x6 pass
+                                 //   behind an f16x3 launch that marked out-of-range samples)
+  int32_t lds_tables;            // hx3 kernels: per-step tables staged in LDS (else read from the blob), set by the launcher
+  int32_t reserved_;
 };
 
 __device__ __forceinline__ float as_f32(uint32_t u) { return __builtin_bit_cast(float, u); }
@@ -105,7 +110,15 @@ struct Stamps {
 #ifdef GBNF_STAMPS
   unsigned long long last = 0;
   unsigned long long acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  int cur = 0;                   // bucket of the phase in progress (split kernels: stage_end books its wait separately)
 #endif
+  __device__ __forceinline__ void set(int k) {
+#ifdef GBNF_STAMPS
+    cur = k;
+#else
+    (void)k;
+#endif
+  }
   __device__ __forceinline__ void start() {
 #ifdef GBNF_STAMPS
     __builtin_amdgcn_sched_barrier(0);

@@ -1,30 +1,34 @@
-// gbnf_flow_kernel_hx3.hip.h -- the fused flow kernel on the f16 matrix pipe with split-f32 operands.
+// gbnf_flow_kernel_hx3.hip.h -- the fused flow kernel on the f16 / bf16 matrix pipe with split-f32 operands.
 //
 // Why: on gfx950 the f32-input MFMA (v_mfma_f32_16x16x4_f32) runs at the f32 VECTOR rate and blocks the
 // vector ALU for its whole duration (tools/ubench/mfma_f32_issue.hip: 32 cycles per 2048 FLOP, VALU fully
-// additive).  v_mfma_f32_16x16x32_f16 delivers 16384 FLOP in ~17 cycles and ~8 of those cycles accept
-// VALU work (tools/ubench/mfma_bf16_issue.hip; the f16 forms take the same cycles).  An f32 value x is
-// split into two fp16 pieces
-//      x ~= hi + mid,   hi = f16(x), mid = f16(x - hi)            (x - hi is exact in f32)
-// which carry 22 of its 24 significand bits (absolute floor 2^-25 from fp16 subnormals), and a product is
-// evaluated as  a_mid.b_hi + a_hi.b_mid + a_hi.b_hi : three f16 MFMAs with f32 accumulation, every
-// f16 x f16 product being exact in f32.  The dropped a_mid.b_mid term is 2^-22 relative, i.e. the result
-// is within a few ulp of the f32 dot product; end to end the log-likelihood agrees with float64 to ~1e-7
-// relative, the same as the torch-f32 reference itself (tests/test_hip_parity.py runs every fixture in
-// both math modes).  Range: tanh outputs are in [-1,1]; ReLU outputs and the network inputs are clamped to
-// the fp16 range (|v| <= 65504) with one v_med3 -- such values do not occur in a normalising flow.
-// For tanh networks 2*log2(e) is folded into the packed weights and biases of the layers that feed a tanh
-// (the split is as accurate for c*w as for w), so tanh(y) = 1 - 2/(2^y + 1) costs exp, add, rcp, fma.
+// additive).  v_mfma_f32_16x16x32_{f16,bf16} delivers 16384 FLOP in ~17 cycles.  An f32 value x is split into
+// pieces of the narrow type and a product is evaluated as a sum of narrow MFMAs with f32 accumulation (every
+// narrow x narrow product is exact in f32):
 //
-// Structure (differences to gbnf_flow_kernel.hip.h, whose register-resident chain idea is kept):
-//   * a workgroup is 4 waves; each wave owns 16*NT samples and its own LDS feature tile Z, all four work
-//     on the SAME component, so the weight stream is fetched once per workgroup: the packed f16 fragments
-//     go L2 -> LDS by direct-to-LDS DMA (global_load_lds_dwordx4, 1 KiB per wave-instruction, issued a
-//     full stage ahead into the other of two staging buffers) and every wave reads its A operands with
-//     conflict-free lane-linear ds_read_b128.  One s_barrier per stage (= per 16-unit output tile).
-//   * D layout == B layout still holds: two consecutive 16-unit accumulator tiles, after tanh and the
-//     hi/mid split, ARE the B operand (k = 32) of the next layer's chunk; nothing is shuffled or stored.
-//   * the tanh + split of tile u-1 (VALU) is issued between the MFMAs of tile u.
+//   PREC 0, "f16x3":  x ~= hi + mid, hi = f16(x), mid = f16(x - hi)   (22 of 24 significand bits, fp16 RANGE)
+//                     a.b = a_mid.b_hi + a_hi.b_mid + a_hi.b_hi                             (3 MFMAs)
+//   PREC 1, "bf16x6": x ~= p0 + p1 + p2, p_k = bf16_rne(x - p_0 - .. - p_{k-1})   (>= 24 bits, f32 RANGE)
+//                     a.b = a2.b0 + a0.b2 + a1.b1 + a1.b0 + a0.b1 + a0.b0; the dropped terms are < 2^-25 |a.b|  (6 MFMAs)
+//
+// f16x3 is the fast path (end to end ~1e-7 relative in the log-likelihood on well-conditioned models); bf16x6 is
+// f32-faithful for any finite input and any model the f32 reference itself evaluates accurately.  A f16x3 launch
+// marks every sample whose operands left the fp16 range (NaN in its outputs); the library follows it with a bf16x6
+// "repair" launch of the same grid whose workgroups exit at once unless they own a marked sample (gbnf_api.hip).
+// For tanh networks 2*log2(e) is folded into the packed weights and biases of the layers that feed a tanh, and
+// t = 1 - 2 r into the layer that consumes it: a tanh costs exp, add, rcp (tanh_hx3 below).
+//
+// Structure:
+//   * a workgroup is WAVES (8, or 4 when a wave needs more than 256 registers) waves; each wave owns 16*NT samples and
+//     its own LDS feature tile Z; all work on the SAME component, so the weight stream is fetched once per
+//     workgroup: the packed fragments go L2 -> LDS by direct-to-LDS DMA (global_load_lds_dwordx4, 1 KiB per
+//     wave-instruction) one stage ahead into the other of two staging slots (the blob is laid out in consumption order,
+//     so "the next stage" is a running pointer with a compile-time size; a deeper ring was measured and bought nothing:
+//     profiles/r2_*); every wave reads its A operands with conflict-free lane-linear ds_read_b128, two consumption units
+//     ahead.  One s_barrier per stage.  Biases travel with a net's first stage into a double-buffered LDS area.
+//   * D layout == B layout: two consecutive 16-unit accumulator tiles, after the activation and the split, ARE the
+//     B operand (k = 32) of the next layer's chunk; nothing is shuffled or stored.
+//   * the activation + split of tile u-1 (VALU) is issued between the MFMAs of tile u.
 #pragma once
 
 #include <type_traits>
@@ -34,108 +38,191 @@
 namespace gbnf {
 
 using f16x8 = __attribute__((ext_vector_type(8))) _Float16;
+using bf16x8 = __attribute__((ext_vector_type(8))) __bf16;
+using bf16x2 = __attribute__((ext_vector_type(2))) __bf16;
+using f32x2 = __attribute__((ext_vector_type(2))) float;
 using u32x4 = __attribute__((ext_vector_type(4))) unsigned;
 
-constexpr int HX3_WAVES = 4;
-constexpr int HX3_L0_TILES = 10;   // layer-0 tiles per staging stage
+constexpr int HX3_RING = 2;         // stage slots in LDS: the stage in use and the next one
 
-// Packed layout of one coupling network for the hx3 kernel, in 32-bit words.  A "fragment" is the A
-// operand of one v_mfma_f32_16x16x32_f16 for one 16-row tile: [64 lanes][8 f16] = 256 words; every
-// weight tile is a (hi, mid) fragment pair.  Stages are contiguous so one stage = one DMA burst:
-//   biases   : B1 [HT][16] | B2 [HT][16] | B3 [OT][16]                                   (f32)
-//   L0 stages: tiles [0,10), [10,20)...  each tile (hi, mid)
-//   PASS u   : hidden row u, chunks c = 0..HC-1 each (hi, mid); then, if u is even and u >= 2, the
-//              output-layer chunk (u-2)/2: tiles o = 0..OT-1 each (hi, mid)   (it is consumed in pass u)
+constexpr int hx3_pieces(int prec) { return prec == 0 ? 2 : 3; }
+
+// Packed layout of one coupling network for the hx3 kernel, in 32-bit words.  A "fragment" is the A operand of one
+// v_mfma_f32_16x16x32_* for one 16-row tile: [64 lanes][8 narrow values] = 256 words; every weight tile is NP
+// consecutive fragments (its pieces, largest first).  Stages are contiguous and in consumption order:
+//   biases   : B1 [HT][16] | B2 [HT][16] | B3 [OT][16] (f32), padded to whole fragments (BIAS_FRAGS)
+//   L0 stages: layer-0 tiles [0,TL0), [TL0,2 TL0) ...                                  TL0 = HC + OT tiles per stage
+//   PASS u   : hidden row u, chunks c = 0..HC-1; then, if u is even and u >= 2, the output-layer chunk (u-2)/2:
+//              tiles o = 0..OT-1 (it is consumed in pass u)
 //   DRAIN    : output-layer chunk HC-1
 struct Hx3Layout {
-  static constexpr int MAXS = 40;
-  int HC, N_L0, NS, BIAS_WORDS, NET_WORDS, STAGE_FRAGS;
+  static constexpr int MAXS = 44;
+  int NP, HC, TL0, N_L0, NS, BIAS_FRAGS, BIAS_WORDS, NET_WORDS, STAGE_FRAGS;
   int off[MAXS];   // word offset of stage s from the start of the net block
   int nf[MAXS];    // fragments in stage s
-  constexpr Hx3Layout(int HT, int OT)
-      : HC((HT + 1) / 2), N_L0((HT + HX3_L0_TILES - 1) / HX3_L0_TILES), NS(0), BIAS_WORDS((2 * HT + OT) * 16),
-        NET_WORDS(0), STAGE_FRAGS(0), off{}, nf{} {
+  constexpr Hx3Layout(int HT, int OT, int np)
+      : NP(np), HC((HT + 1) / 2), TL0((HT + 1) / 2 + OT), N_L0(0), NS(0), BIAS_FRAGS(((2 * HT + OT) * 16 + 255) / 256),
+        BIAS_WORDS(0), NET_WORDS(0), STAGE_FRAGS(0), off{}, nf{} {
+    BIAS_WORDS = BIAS_FRAGS * 256;
+    N_L0 = (HT + TL0 - 1) / TL0;
     int s = 0, w = BIAS_WORDS;
     for (int i = 0; i < N_L0; ++i) {
-      const int t0 = i * HX3_L0_TILES;
-      const int cnt = (HT - t0 < HX3_L0_TILES) ? HT - t0 : HX3_L0_TILES;
-      off[s] = w; nf[s] = 2 * cnt; w += nf[s] * 256; ++s;
+      const int t0 = i * TL0;
+      const int cnt = (HT - t0 < TL0) ? HT - t0 : TL0;
+      off[s] = w; nf[s] = NP * cnt; w += nf[s] * 256; ++s;
     }
     for (int u = 0; u < HT; ++u) {
-      off[s] = w; nf[s] = 2 * HC + ((u % 2 == 0 && u >= 2) ? 2 * OT : 0); w += nf[s] * 256; ++s;
+      off[s] = w; nf[s] = NP * HC + ((u % 2 == 0 && u >= 2) ? NP * OT : 0); w += nf[s] * 256; ++s;
     }
-    off[s] = w; nf[s] = 2 * OT; w += nf[s] * 256; ++s;
+    off[s] = w; nf[s] = NP * OT; w += nf[s] * 256; ++s;
     NS = s;
     NET_WORDS = w;
     for (int k = 0; k < s; ++k) STAGE_FRAGS = nf[k] > STAGE_FRAGS ? nf[k] : STAGE_FRAGS;
   }
 };
 
-template <int HT, int OT>
+template <int HT, int OT, int NP>
 struct Hx3LayoutOf {
-  static constexpr Hx3Layout value = Hx3Layout(HT, OT);
+  static constexpr Hx3Layout value = Hx3Layout(HT, OT, NP);
 };
 
-// 2-piece fp16 split of a pair of f32 values: hi = f16(x) (toward zero), mid = f16(x - hi); 6 VALU ops
-__device__ __forceinline__ void split_pair(float x0, float x1, unsigned& hi, unsigned& mid) {
+// Waves per workgroup: 8 (two per SIMD, 256 registers each) unless the register-resident hidden layer of a wave
+// (HC chunks x NT tiles x NP pieces x 4 registers) needs the 512-register budget of one wave per SIMD.
+constexpr int hx3_reg_estimate(int HT, int OT, int NT, int prec, int kind, int act_a, int act_b) {
+  const int np = hx3_pieces(prec);
+  const int hc = (HT + 1) / 2;
+  const int nn = kind == GBNF_KIND_REALNVP ? 2 : 1;
+  const int relu = (act_a != GBNF_ACT_TANH || act_b != GBNF_ACT_TANH) ? 28 : 0;   // measured: ReLU / per-step variants keep more values live
+  const int accs = np == 3 ? 3 : 1;                    // running sums per output tile (Products<NP>::NACC)
+  return hc * NT * np * 4 + (nn + accs - 1) * OT * NT * 4 + NT * 4 * (1 + accs) + 2 * NT * np * 4 + 3 * np * 4 + 36 + relu;
+}
+constexpr int hx3_waves(int HT, int OT, int NT, int prec, int kind, int act_a, int act_b) {
+#ifdef GBNF_HX3_FORCE_WAVES       // experiment knob: 4 = two independent 4-wave workgroups per CU (where registers and LDS allow)
+  return hx3_reg_estimate(HT, OT, NT, prec, kind, act_a, act_b) <= 248 ? GBNF_HX3_FORCE_WAVES : 4;
+#else
+  return hx3_reg_estimate(HT, OT, NT, prec, kind, act_a, act_b) <= 248 ? 8 : 4;
+#endif
+}
+// minimum waves per SIMD the kernel is compiled for (the register budget): 2 (256 registers) or 1 (512)
+constexpr int hx3_waves_per_simd(int HT, int OT, int NT, int prec, int kind, int act_a, int act_b) {
+  return hx3_reg_estimate(HT, OT, NT, prec, kind, act_a, act_b) <= 248 ? 2 : 1;
+}
+// Samples per wave actually compiled for a requested NT: 32-sample waves (NT = 2) of the widest geometries would
+// spill even with one wave per SIMD; their NT = 2 entry runs the 16-sample kernel.
+constexpr int hx3_eff_nt(int HT, int OT, int NT, int prec, int kind, int act_a, int act_b) {
+  return (NT == 2 && hx3_reg_estimate(HT, OT, 2, prec, kind, act_a, act_b) > 300) ? 1 : NT;
+}
+
+// ---- operand splitting ----------------------------------------------------------------------------------------
+// f16: hi = f16(x) (toward zero), mid = f16(x - hi); 4 VALU ops per register pair: the residual x - hi is ONE
+// v_fma_mix_f32 per value (the f16 half is widened inside the instruction; LLVM itself would emit v_cvt_f32_f16 + v_sub_f32)
+__device__ __forceinline__ void split_pair_f16(float x0, float x1, unsigned (&p)[2]) {
   const auto h = __builtin_amdgcn_cvt_pkrtz(x0, x1);
-  hi = __builtin_bit_cast(unsigned, h);
-  const float h0 = (float)h[0], h1 = (float)h[1];
-  const auto m = __builtin_amdgcn_cvt_pkrtz(x0 - h0, x1 - h1);
-  mid = __builtin_bit_cast(unsigned, m);
+  const unsigned hw = __builtin_bit_cast(unsigned, h);
+  p[0] = hw;
+  float r0, r1;
+  asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(r0) : "v"(hw), "v"(x0));
+  asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(r1) : "v"(hw), "v"(x1));
+  const auto m = __builtin_amdgcn_cvt_pkrtz(r0, r1);
+  p[1] = __builtin_bit_cast(unsigned, m);
+}
+// bf16: three round-to-nearest pieces (v_cvt_pk_bf16_f32); 11 VALU ops per register pair
+__device__ __forceinline__ void split_pair_bf16(float x0, float x1, unsigned (&p)[3]) {
+  const unsigned w0 = __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2{x0, x1}, bf16x2));
+  p[0] = w0;
+  const float r0 = x0 - __builtin_bit_cast(float, w0 << 16), r1 = x1 - __builtin_bit_cast(float, w0 & 0xffff0000u);
+  const unsigned w1 = __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2{r0, r1}, bf16x2));
+  p[1] = w1;
+  const float s0 = r0 - __builtin_bit_cast(float, w1 << 16), s1 = r1 - __builtin_bit_cast(float, w1 & 0xffff0000u);
+  p[2] = __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2{s0, s1}, bf16x2));
+}
+template <int NP>
+__device__ __forceinline__ void split_pair(float x0, float x1, unsigned (&p)[NP]) {
+  if constexpr (NP == 2) split_pair_f16(x0, x1, p);
+  else split_pair_bf16(x0, x1, p);
 }
 
-// activations on PRE-SCALED sums: for tanh the packer folded 2*log2(e) into the layer, so
-// tanh = 1 - 2/(2^y + 1); ReLU is clamped to the fp16 range in the same instruction
-template <int ACT>
-__device__ __forceinline__ float act_hx3(float y) {
-  if constexpr (ACT == GBNF_ACT_TANH) {
-    const float e = __builtin_amdgcn_exp2f(y);
-    const float r = __builtin_amdgcn_rcpf(e + 1.0f);
-    return __builtin_fmaf(-2.0f, r, 1.0f);
-  } else {
-    return __builtin_amdgcn_fmed3f(y, 0.0f, 65504.0f);
-  }
+// tanh networks: the packer folds 2*log2(e) into every layer that feeds a tanh and the affine map t = 1 - 2 r into the
+// layer that consumes it (W.t + b = (-2W).r + (b + W.1)), so the value handed on is r = 1/(2^y + 1), tanh(y') = 1 - 2 r:
+// v_exp_f32, v_add_f32, v_rcp_f32
+__device__ __forceinline__ float tanh_hx3(float y) {
+  const float e = __builtin_amdgcn_exp2f(y);
+  return __builtin_amdgcn_rcpf(e + 1.0f);
 }
 
-__device__ __forceinline__ f32x4 mfma_f16(u32x4 a, u32x4 b, f32x4 c) {
+template <int PREC>
+__device__ __forceinline__ f32x4 mfma_narrow(u32x4 a, u32x4 b, f32x4 c) {
 #ifdef GBNF_ABLATE_MFMA           // diagnostic: one cheap VALU op instead of the MFMA (keeps every value live)
   c[0] += __builtin_bit_cast(float, a[0] ^ b[0]);
   return c;
 #else
-  return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+  if constexpr (PREC == 0)
+    return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+  else
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
 #endif
 }
 
-// acc += W.x with W = (w_hi, w_mid), x = (x_hi, x_mid): small terms first
-__device__ __forceinline__ f32x4 mfma_x3(u32x4 w_hi, u32x4 w_mid, u32x4 x_hi, u32x4 x_mid, f32x4 acc) {
-  acc = mfma_f16(w_mid, x_hi, acc);
-  acc = mfma_f16(w_hi, x_mid, acc);
-  acc = mfma_f16(w_hi, x_hi, acc);
-  return acc;
+// the products of one f32 product, (weight piece, activation piece), smallest terms first
+template <int NP> struct Products;
+// ACC: which running sum a product goes to.  bf16x6 keeps one sum per magnitude class (a0.b0 | 2^-9 terms | 2^-18 terms) and
+// adds them once per output tile: an MFMA adds its 32 products to the accumulator at the accumulator's scale, which would
+// cost the small classes most of their bits (measured: 1e-5 instead of 2e-6 on the ill-conditioned fixture g15).
+template <> struct Products<2> { static constexpr int N = 3, NACC = 1; static constexpr int W[3] = {1, 0, 0}; static constexpr int X[3] = {0, 1, 0}; static constexpr int ACC[3] = {0, 0, 0}; };
+template <> struct Products<3> { static constexpr int N = 6, NACC = 3; static constexpr int W[6] = {2, 0, 1, 1, 0, 0}; static constexpr int X[6] = {0, 2, 1, 0, 1, 0}; static constexpr int ACC[6] = {2, 2, 2, 1, 1, 0}; };
+
+// the running sums of one 16x16 output tile
+template <int NACC>
+struct AccT {
+  f32x4 s[NACC];
+  __device__ __forceinline__ void init(f32x4 bias) {
+    s[0] = bias;
+#pragma unroll
+    for (int k = 1; k < NACC; ++k) s[k] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+  }
+  __device__ __forceinline__ f32x4 total() const {
+    if constexpr (NACC == 1) return s[0];
+    else return s[0] + (s[1] + s[2]);
+  }
+};
+
+// s_waitcnt vmcnt(n) for a run-time n (an immediate in the instruction): wait until at most n of this wave's
+// vector-memory operations are outstanding (in issue order), n clamped to [0, 8]
+__device__ __forceinline__ void wait_vmcnt(int n) {
+  if (n <= 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  else if (n == 1) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
+  else if (n == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+  else if (n == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+  else if (n == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+  else if (n == 5) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+  else if (n == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+  else if (n == 7) asm volatile("s_waitcnt vmcnt(7)" ::: "memory");
+  else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
 }
 
-template <int KIND, int HT, int OT, int NT, int ACTA, int ACTB>
-__global__ void __launch_bounds__(64 * HX3_WAVES, (NT == 1) ? 2 : 1) flow_kernel_hx3(const FlowLaunch p) {
+template <int KIND, int HT, int OT, int NT, int ACTA, int ACTB, int PREC>
+__global__ void __launch_bounds__(64 * hx3_waves(HT, OT, NT, PREC, KIND, ACTA, ACTB), hx3_waves_per_simd(HT, OT, NT, PREC, KIND, ACTA, ACTB))
+flow_kernel_hx3(const FlowLaunch p) {
+  constexpr int WAVES = hx3_waves(HT, OT, NT, PREC, KIND, ACTA, ACTB);
+  constexpr int NP = hx3_pieces(PREC);
+  constexpr int NPROD = Products<NP>::N;
+  using Acc = AccT<Products<NP>::NACC>;
   constexpr int ZS = 16 * NT + 1;
   constexpr int NNETS = (KIND == GBNF_KIND_REALNVP) ? 2 : 1;
-  constexpr const Hx3Layout& L = Hx3LayoutOf<HT, OT>::value;
-  constexpr int HC = L.HC;
-  constexpr int STEP_WORDS = SMALL_WORDS + NNETS * L.NET_WORDS;
-  constexpr int STAGE_WORDS = L.STAGE_FRAGS * 256;
+  using LT = Hx3LayoutOf<HT, OT, NP>;          // LT::value: the layout (a static member: usable inside the lambdas below)
+  constexpr int HC = LT::value.HC;
+  constexpr int STEP_WORDS = SMALL_WORDS + NNETS * LT::value.NET_WORDS;
+  constexpr int STAGE_WORDS = LT::value.STAGE_FRAGS * 256;
+  constexpr bool WATCH = PREC == 0;        // the fp16 range can be left; bf16 pieces have the range of f32
 
   extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
-  const bool lds_tables = p.n_steps <= LDS_TABLE_STEPS;
-  uint32_t* SM = lds;
-  uint32_t* STG = lds + (lds_tables ? p.n_steps * SMALL_WORDS : 0);       // 2 staging buffers
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-  float* Z = reinterpret_cast<float*>(STG + 2 * STAGE_WORDS) + wave * (p.d * ZS);   // wave-private, d slots
   const int i = lane & 15;
   const int g = lane >> 4;
 
-  // ---- XCD-aware block -> (component, group of 4 sample tiles)
-  const int n_groups = (p.n_tiles + HX3_WAVES - 1) / HX3_WAVES;
+  // ---- XCD-aware block -> (component, batch, group of WAVES sample tiles)
+  const int n_groups = (p.n_tiles + WAVES - 1) / WAVES;
   int comp, grp, batch;
   {
     const int total = gridDim.x;
@@ -151,44 +238,88 @@ __global__ void __launch_bounds__(64 * HX3_WAVES, (NT == 1) ? 2 : 1) flow_kernel
   }
   const uint32_t* __restrict__ blob = p.blobs[p.c_begin + comp];
   const int d = p.d;
-  const int64_t row0 = ((int64_t)grp * HX3_WAVES + wave) * (16 * NT);    // rows >= n are masked everywhere
+  const int64_t row0 = ((int64_t)grp * WAVES + wave) * (16 * NT);    // rows >= n are masked everywhere
   const float* __restrict__ xin = p.xs[batch];
+  const int64_t out_base = (int64_t)comp * p.out_stride + (int64_t)batch * p.n;
 
-  // ---- weight staging.  The blob is laid out in consumption order, so "the next stage" is a running
-  //      pointer; every call site knows the next stage's fragment count at compile time.  Wave w moves
-  //      fragments w, w+4, ...; the LDS destination of a wave-instruction is base + lane*16 = the fragment.
+  // ---- repair launch: only workgroups that own a sample marked by the f16x3 launch (NaN in its outputs) run
+  if (p.repair) {
+    bool need = false;
+    if (lane < 16 * NT) {
+      const int64_t n = row0 + lane;
+      if (n < p.n) {
+        float v;
+        if (p.ll_out) v = p.ll_out[out_base + n];
+        else if (p.ldj_out) v = p.ldj_out[out_base + n];
+        else v = p.z_out[((int64_t)comp * p.n + n) * d];
+        need = v != v;
+      }
+    }
+    // workgroup-wide OR through the first LDS word (no static LDS: the dynamic allocation may be all 160 KB)
+    if (threadIdx.x == 0) lds[0] = 0u;
+    __syncthreads();
+    if (__any(need) && lane == 0) lds[0] = 1u;
+    __syncthreads();
+    const bool any_need = lds[0] != 0u;
+    __syncthreads();             // before the word is re-used
+    if (!any_need) return;
+  }
+
+  // ---- LDS: per-step tables | 2 bias blocks | ring of stage slots | Z tiles
+  const bool lds_tables = p.lds_tables != 0;
+  constexpr int ring = 2;                                   // stage slots: the current stage and the next one
+  uint32_t* SM = lds;
+  uint32_t* BIAS = lds + (lds_tables ? p.n_steps * SMALL_WORDS : 0);
+  uint32_t* STG = BIAS + 2 * LT::value.BIAS_WORDS;
+  float* Z = reinterpret_cast<float*>(STG + ring * STAGE_WORDS) + wave * (d * ZS);   // wave-private, d slots
+
+  // ---- weight staging, one stage ahead into the other of two slots.  The blob is laid out in consumption order, so
+  //      "the next stage" is a running pointer; every call site knows the next stage's fragment count at compile time.
+  //      Wave w moves fragments w, w + WAVES, ...; the LDS destination of a wave-instruction is base + lane*16 = the
+  //      fragment.  A net's biases (BIAS_FRAGS fragments in front of its first stage) go to their own double-buffered area.
   using gwords = const __attribute__((address_space(1))) uint32_t*;
-  gwords next_src = (gwords)blob + SMALL_WORDS + L.BIAS_WORDS;   // first stage of step 0, net 0
-  int gs = 0;                                                      // stage counter: buffer = gs & 1
+  using lptr = __attribute__((address_space(3))) void*;
+  gwords next_src = (gwords)blob + SMALL_WORDS;    // bias block of step 0, net 0
+  int gs = 0;                                       // stage counter: slot = gs & 1
+  int nets_issued = 0;                              // nets whose first stage has been issued (bias buffer = & 1)
   const unsigned lane_b16 = (unsigned)lane * 16u;
-  auto issue = [&](auto nf_c, int into) {
+  auto dma = [&](gwords src, uint32_t* dst) {
+#ifndef GBNF_ABLATE_DMA          // diagnostic: no weight staging at all (stale LDS contents, timing only)
+    // uniform base + 32-bit per-lane offset -> saddr form, no 64-bit VALU address arithmetic
+    const __attribute__((address_space(1))) char* base = reinterpret_cast<const __attribute__((address_space(1))) char*>(src);
+    __builtin_amdgcn_global_load_lds(base + lane_b16, (lptr)dst, 16, 0, 0);
+#else
+    (void)src; (void)dst;
+#endif
+  };
+  auto issue = [&](auto nf_c, int into) {           // the next stage: NF fragments at next_src
     constexpr int NF = decltype(nf_c)::value;
     uint32_t* dst = STG + (into & 1) * STAGE_WORDS;
 #pragma unroll
-    for (int k = 0; 4 * k < NF; ++k) {
-      const int f = wave + 4 * k;
-      if (4 * k + 3 < NF || f < NF) {
-        // uniform base + 32-bit per-lane offset -> saddr form, no 64-bit VALU address arithmetic
-        const __attribute__((address_space(1))) char* base =
-            reinterpret_cast<const __attribute__((address_space(1))) char*>(next_src + f * 256);
-#ifndef GBNF_ABLATE_DMA          // diagnostic: no weight staging at all (stale LDS contents, timing only)
-        __builtin_amdgcn_global_load_lds(base + lane_b16, (__attribute__((address_space(3))) void*)(dst + f * 256),
-                                         16, 0, 0);
-#else
-        (void)base; (void)dst;
-#endif
-      }
+    for (int k = 0; k * WAVES < NF; ++k) {
+      const int f = wave + k * WAVES;
+      if ((k + 1) * WAVES <= NF || f < NF) dma(next_src + f * 256, dst + f * 256);
     }
     next_src += NF * 256;
   };
-  constexpr int NF_L0_FIRST = 2 * (HT < HX3_L0_TILES ? HT : HX3_L0_TILES);
+  auto issue_net_start = [&](int into) {            // next_src points at a net's bias block: biases + first L0 stage
+    uint32_t* bdst = BIAS + (nets_issued & 1) * LT::value.BIAS_WORDS;
+#pragma unroll
+    for (int k = 0; k * WAVES < LT::value.BIAS_FRAGS; ++k) {
+      const int f = wave + k * WAVES;
+      if ((k + 1) * WAVES <= LT::value.BIAS_FRAGS || f < LT::value.BIAS_FRAGS) dma(next_src + f * 256, bdst + f * 256);
+    }
+    next_src += LT::value.BIAS_WORDS;
+    ++nets_issued;
+    issue(std::integral_constant<int, LT::value.nf[0]>{}, into);
+  };
 
-  // ---- per-step tables -> LDS, x tile -> Z, first weight stage in flight
-  issue(std::integral_constant<int, NF_L0_FIRST>{}, 0);
+  // ---- per-step tables -> LDS, x tile -> Z, the first stage in flight
+  issue_net_start(0);
   if (lds_tables) {
     for (int s = 0; s < p.n_steps; ++s) {
       const uint32_t* src = blob + (size_t)s * STEP_WORDS;
-      for (int w = (int)threadIdx.x * 4; w < SMALL_WORDS; w += 256 * 4)
+      for (int w = (int)threadIdx.x * 4; w < SMALL_WORDS; w += 64 * WAVES * 4)
         *reinterpret_cast<i32x4*>(SM + s * SMALL_WORDS + w) = *reinterpret_cast<const i32x4*>(src + w);
     }
   }
@@ -201,37 +332,58 @@ __global__ void __launch_bounds__(64 * HX3_WAVES, (NT == 1) ? 2 : 1) flow_kernel
       Z[lane * ZS + r] = v;
     }
   }
-  __syncthreads();               // tables + Z visible, stage 0 landed (the barrier drains the DMA)
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this wave's pieces of the first stages have landed
+  __syncthreads();               // tables + Z visible, every wave's pieces landed
 
   float ld[NT];
 #pragma unroll
   for (int nt = 0; nt < NT; ++nt) ld[nt] = 0.0f;
   float ld_const = 0.0f;
-  bool sat = false;
+  bool sat[NT];                  // sample (i, nt) stored an operand beyond the fp16 range
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) sat[nt] = false;
   Stamps st;
   st.start();
 
+  // ---- consumer side: slot gs & 1 holds the current stage
+  int cnets = 0;                 // nets consumed so far (bias buffer = cnets & 1)
+  const uint32_t* buf = STG;
+  auto stage_begin = [&]() { buf = STG + (gs & 1) * STAGE_WORDS; };
+  auto stage_end = [&]() {
+#ifdef GBNF_STAMPS
+    const int phase_ = st.cur;
+    st.mark(phase_);             // compute time of the stage so far -> its phase bucket
+#endif
+#ifndef GBNF_ABLATE_BARRIER       // diagnostic: no per-stage rendezvous (races on the staging buffers, timing only)
+    // this wave's pieces of the next stage have landed, all waves are done with this slot
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+#endif
+#ifdef GBNF_STAMPS
+    st.mark(7);                  // bucket 7: time in the stage-end wait + barrier
+    st.cur = phase_;
+#endif
+    ++gs;
+  };
 #ifdef GBNF_ABLATE_FRAG            // diagnostic: one fragment read per kernel, reused for every MFMA (timing only)
   u32x4 frag_dummy = *reinterpret_cast<const u32x4*>(STG + lane * 4);
   asm volatile("" : "+v"(frag_dummy));
-  auto frag = [&](const uint32_t*, int) -> u32x4 { return frag_dummy; };
+  auto frag = [&](int) -> u32x4 { return frag_dummy; };
 #else
-  auto frag = [&](const uint32_t* buf, int f) -> u32x4 {
-    return *reinterpret_cast<const u32x4*>(buf + f * 256 + lane * 4);
-  };
+  auto frag = [&](int f) -> u32x4 { return *reinterpret_cast<const u32x4*>(buf + f * 256 + lane * 4); };
 #endif
-  auto stage_end = [&]() {
-#ifndef GBNF_ABLATE_BARRIER       // diagnostic: no per-stage rendezvous (races on the staging buffers, timing only)
-    __syncthreads();             // all waves done with this buffer; the next stage's DMA has landed
-#endif
-    ++gs;
+
+  // A consumption unit = one weight tile = NP fragments.  Units of a stage are read two ahead of their use.
+  struct Unit { u32x4 w[NP]; };
+  auto load_unit = [&](Unit& a, int n) {
+#pragma unroll
+    for (int q = 0; q < NP; ++q) a.w[q] = frag(n * NP + q);
   };
 
   for (int step = 0; step < p.n_steps; ++step) {
     const uint32_t* __restrict__ sp = blob + (size_t)step * STEP_WORDS;
     // ---- normalise the coupling net's inputs in place; split them into the first layer's B operand:
     //      lane (i,g), element j  <->  input feature 8g + j of sample i
-    u32x4 zhi[NT], zmid[NT];
+    u32x4 zp[NT][NP];
     {
       LaneTable tin;
       if (lds_tables) {
@@ -241,254 +393,229 @@ __global__ void __launch_bounds__(64 * HX3_WAVES, (NT == 1) ? 2 : 1) flow_kernel
         ld_const += as_f32(sp[1]);
         tin.load(sp + SMALL_HDR + g * NENT);
       }
+      float v[NT][NENT];
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt)            // every load first: the slots of a step are distinct
+#pragma unroll
+        for (int e = 0; e < NENT; ++e) v[nt][e] = Z[(tin.slot[e] >= 0 ? tin.slot[e] : 0) * ZS + i + 16 * nt];
 #pragma unroll
       for (int nt = 0; nt < NT; ++nt) {
-        float v[NENT];
 #pragma unroll
         for (int e = 0; e < NENT; ++e) {
           const bool live = tin.slot[e] >= 0;
-          const int zoff = (live ? tin.slot[e] : 0) * ZS + i + 16 * nt;
-          float t = Z[zoff];
-          t = norm_fn<KIND>(t, tin.p0[e], tin.p1[e], tin.p2[e], tin.p3[e]);
-          if (live) Z[zoff] = t;
-          sat = sat || (live && !(__builtin_fabsf(t) <= 65504.0f));       // beyond the fp16 range the operand saturates
-          v[e] = live ? __builtin_amdgcn_fmed3f(t, -65504.0f, 65504.0f) : 0.0f;
+          const float t = norm_fn<KIND>(v[nt][e], tin.p0[e], tin.p1[e], tin.p2[e], tin.p3[e]);
+          if (live) Z[tin.slot[e] * ZS + i + 16 * nt] = t;
+          if constexpr (WATCH) {
+            sat[nt] = sat[nt] || (live && !(__builtin_fabsf(t) <= 65504.0f));
+            v[nt][e] = live ? __builtin_amdgcn_fmed3f(t, -65504.0f, 65504.0f) : 0.0f;
+          } else {
+            v[nt][e] = live ? t : 0.0f;
+          }
         }
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-          unsigned hq, mq;
-          split_pair(v[2 * q], v[2 * q + 1], hq, mq);
-          zhi[nt][q] = hq;
-          zmid[nt][q] = mq;
+          unsigned pc[NP];
+          split_pair<NP>(v[nt][2 * q], v[nt][2 * q + 1], pc);
+#pragma unroll
+          for (int k = 0; k < NP; ++k) zp[nt][k][q] = pc[k];
         }
       }
     }
     st.mark(0);
+    st.set(1);
 
-    f32x4 outA[OT][NT], outB[OT][NT];
+    f32x4 outA[OT][NT], outB[OT][NT];       // the nets' outputs (all products summed)
 #pragma unroll
     for (int net = 0; net < NNETS; ++net) {
-      f32x4 (&out)[OT][NT] = (net == 0) ? outA : outB;
+      f32x4 (&outF)[OT][NT] = (net == 0) ? outA : outB;
+      Acc out[OT][NT];
       const int ACT = (net == 0) ? ACTA : ACTB;
-      using gf4 = const __attribute__((address_space(1))) f32x4*;
-      gwords nb = (gwords)blob + (size_t)step * STEP_WORDS + SMALL_WORDS + net * L.NET_WORDS;
-      gf4 b1 = (gf4)nb + g;
-      gf4 b2 = (gf4)(nb + HT * 16) + g;
-      gf4 b3 = (gf4)(nb + 2 * HT * 16) + g;
-#ifdef GBNF_ABLATE_BIAS            // diagnostic: no bias loads from global memory (timing only)
-      auto ldb = [&](gf4, int) { return f32x4{0.01f, 0.02f, 0.03f, 0.04f}; };
+      const uint32_t* bb = BIAS + (cnets & 1) * LT::value.BIAS_WORDS + g * 4;      // this net's biases (LDS)
+#ifdef GBNF_ABLATE_BIAS            // diagnostic: no bias reads (timing only)
+      auto ldb = [&](int) { return f32x4{0.01f, 0.02f, 0.03f, 0.04f}; };
 #else
-      auto ldb = [&](gf4 b, int idx) { return b[idx]; };
+      auto ldb = [&](int tile) { return *reinterpret_cast<const f32x4*>(bb + tile * 16); };
 #endif
       // ACT == 3 (GBNF_ACT_PER_STEP): the activation of this step's net comes from the step header (`--coupling_network random`): both are
       // computed and one is selected (the packer folded the tanh pre-scale into this net's layers only if it is a tanh net)
       const bool relu_rt = ACT == 3 && __builtin_amdgcn_readfirstlane(sp[2 + net]) != 0;
-      auto act = [&](float v) {
-        if (ACT == GBNF_ACT_TANH) return act_hx3<GBNF_ACT_TANH>(v);
-        if (ACT == GBNF_ACT_RELU) return act_hx3<GBNF_ACT_RELU>(v);
-        const float t = act_hx3<GBNF_ACT_TANH>(v), r = act_hx3<GBNF_ACT_RELU>(v);
+      float amax[NT];             // largest ReLU activation of sample (i, nt) in this net (fp16 range watch)
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) amax[nt] = 0.0f;
+      auto act1 = [&](float v, int nt) {
+        if (ACT == GBNF_ACT_TANH) return tanh_hx3(v);
+        float r = __builtin_fmaxf(v, 0.0f);
+        if constexpr (WATCH) {
+          if (ACT == GBNF_ACT_RELU) amax[nt] = __builtin_fmaxf(amax[nt], r);
+          else amax[nt] = __builtin_fmaxf(amax[nt], relu_rt ? r : 0.0f);
+          r = __builtin_fminf(r, 65504.0f);
+        }
+        if (ACT == GBNF_ACT_RELU) return r;
+        const float t = tanh_hx3(v);
         return relu_rt ? r : t;
       };
       // activate + split one register pair (values 2hp, 2hp+1 of a raw accumulator tile)
       // (the empty asm pins the computation HERE: without it LLVM sinks the whole tanh + split into the later
       //  block that first consumes the operand, un-interleaving it from this region's MFMAs)
-      auto act_split = [&](const f32x4& raw, int hp, unsigned& h, unsigned& m) {
-#if defined(GBNF_ABLATE_ACT)      // diagnostic: no tanh, no split (results wrong, timing only)
-        h = __builtin_bit_cast(unsigned, raw[2 * hp]);
-        m = __builtin_bit_cast(unsigned, raw[2 * hp + 1]);
-#elif defined(GBNF_ABLATE_SPLIT)  // diagnostic: tanh but no split
-        h = __builtin_bit_cast(unsigned, act(raw[2 * hp]));
-        m = __builtin_bit_cast(unsigned, act(raw[2 * hp + 1]));
+      auto act_split = [&](const f32x4& raw, int hp, int nt, unsigned (&pc)[NP]) {
+#if defined(GBNF_ABLATE_ACT)      // diagnostic: no activation, no split (results wrong, timing only)
+#pragma unroll
+        for (int k = 0; k < NP; ++k) pc[k] = __builtin_bit_cast(unsigned, raw[(2 * hp + k) & 3]);
+#elif defined(GBNF_ABLATE_SPLIT)  // diagnostic: activation but no split
+#pragma unroll
+        for (int k = 0; k < NP; ++k) pc[k] = __builtin_bit_cast(unsigned, act1(raw[(2 * hp + k) & 3], nt));
 #else
-        split_pair(act(raw[2 * hp]), act(raw[2 * hp + 1]), h, m);
+        split_pair<NP>(act1(raw[2 * hp], nt), act1(raw[2 * hp + 1], nt), pc);
 #endif
-        asm volatile("" : "+v"(h), "+v"(m));
+#pragma unroll
+        for (int k = 0; k < NP; ++k) asm volatile("" : "+v"(pc[k]));
+      };
+      // acc[nt] += W . X[nt] for one weight tile (NP pieces) and the B operands of the wave's NT sample tiles
+      auto mac = [&](const Unit& a, const u32x4 (&x)[NT][NP], Acc (&acc)[NT]) {
+#pragma unroll
+        for (int pr = 0; pr < NPROD; ++pr) {
+#pragma unroll
+          for (int nt = 0; nt < NT; ++nt) {
+            f32x4& t = acc[nt].s[Products<NP>::ACC[pr]];
+            t = mfma_narrow<PREC>(a.w[Products<NP>::W[pr]], x[nt][Products<NP>::X[pr]], t);
+            MFMA_ORDER_FENCE();
+          }
+        }
       };
 
-      u32x4 hBhi[HC][NT], hBmid[HC][NT];     // layer-0 output = B operands of the hidden layer
+      u32x4 hB[HC][NT][NP];       // layer-0 output = B operands of the hidden layer
 #pragma unroll
-      for (int nt = 0; nt < NT; ++nt) {       // phantom half of an odd tile count stays zero
-        hBhi[HC - 1][nt] = u32x4{0, 0, 0, 0};
-        hBmid[HC - 1][nt] = u32x4{0, 0, 0, 0};
-      }
+      for (int nt = 0; nt < NT; ++nt)         // phantom half of an odd tile count stays zero
 #pragma unroll
-      for (int o = 0; o < OT; ++o) {
-        const f32x4 b = ldb(b3, o * 4);
-#pragma unroll
-        for (int nt = 0; nt < NT; ++nt) out[o][nt] = b;
-      }
+        for (int k = 0; k < NP; ++k) hB[HC - 1][nt][k] = u32x4{0, 0, 0, 0};
 
-      // ---- layer 0: tile t = W1[tile t] . z  (one k = 32 chunk); the tanh + split of tile t-1 shares its region
+      // ---- layer 0: tile t = W1[tile t] . z  (one k = 32 chunk); the activation + split of tile t-1 shares its region
       {
         f32x4 raw[NT];
-        f32x4 bias = ldb(b1, 0);
+        auto finish_tile = [&](int t) {       // tile t (held in raw) -> its half of chunk t/2
+          const int c = t >> 1, hf = t & 1;
 #pragma unroll
-        for (int sI = 0; sI < L.N_L0; ++sI) {
-          const uint32_t* buf = STG + (gs & 1) * STAGE_WORDS;
-          constexpr int NF_PASS0 = 2 * HC;
-          const int t0 = sI * HX3_L0_TILES;
-          // next stage: another layer-0 stage or the first hidden pass
-          if (sI + 1 < L.N_L0) {
-            if (HT - (sI + 1) * HX3_L0_TILES >= HX3_L0_TILES) issue(std::integral_constant<int, 2 * HX3_L0_TILES>{}, gs + 1);
-            else issue(std::integral_constant<int, 2 * (HT % HX3_L0_TILES == 0 ? HX3_L0_TILES : HT % HX3_L0_TILES)>{}, gs + 1);
-          } else {
-            issue(std::integral_constant<int, NF_PASS0>{}, gs + 1);
-          }
-          u32x4 AL[2 * HX3_L0_TILES];
+          for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
-          for (int tl = 0; tl < HX3_L0_TILES; ++tl)
-            if (t0 + tl < HT) {
-              AL[2 * tl] = frag(buf, 2 * tl);
-              AL[2 * tl + 1] = frag(buf, 2 * tl + 1);
+            for (int hp = 0; hp < 2; ++hp) {
+              unsigned pc[NP];
+              act_split(raw[nt], hp, nt, pc);
+#pragma unroll
+              for (int k = 0; k < NP; ++k) hB[c][nt][k][2 * hf + hp] = pc[k];
             }
+        };
+        auto l0_stage = [&](auto sI_c) {
+          constexpr int sI = decltype(sI_c)::value;
+          stage_begin();
+          issue(std::integral_constant<int, LT::value.nf[sI + 1]>{}, gs + 1);     // the next layer-0 stage or the first hidden pass
+          constexpr int t0 = sI * LT::value.TL0;
+          constexpr int cnt = (HT - t0 < LT::value.TL0) ? HT - t0 : LT::value.TL0;
+          Unit A[3];
+          load_unit(A[0], 0);
+          if (cnt > 1) load_unit(A[1], 1);
+          f32x4 bias = ldb(t0);
+          if (sI == 0) {
 #pragma unroll
-          for (int tl = 0; tl < HX3_L0_TILES; ++tl) {
+            for (int o = 0; o < OT; ++o) {
+              const f32x4 b = ldb(2 * HT + o);
+#pragma unroll
+              for (int nt = 0; nt < NT; ++nt) out[o][nt].init(b);
+            }
+          }
+#pragma unroll
+          for (int tl = 0; tl < LT::value.TL0; ++tl) {
             const int t = t0 + tl;
-            if (t < HT) {
-              const u32x4 c_hi = AL[2 * tl], c_mid = AL[2 * tl + 1];
-              const f32x4 bias_next = ldb(b1, (t + 1 < HT ? t + 1 : t) * 4);
-              f32x4 cur[NT];
+            if (tl < cnt) {
+              if (tl + 2 < cnt) load_unit(A[(tl + 2) % 3], tl + 2);
+              const f32x4 bias_next = ldb(t + 1 < HT ? t + 1 : t);
+              Acc cur[NT];
+#pragma unroll
+              for (int nt = 0; nt < NT; ++nt) cur[nt].init(bias);
+              // first product, then the previous tile's activation + split, then the rest
 #pragma unroll
               for (int nt = 0; nt < NT; ++nt) {
-                cur[nt] = mfma_f16(c_mid, zhi[nt], bias);
+                f32x4& t0_ = cur[nt].s[Products<NP>::ACC[0]];
+                t0_ = mfma_narrow<PREC>(A[tl % 3].w[Products<NP>::W[0]], zp[nt][Products<NP>::X[0]], t0_);
                 MFMA_ORDER_FENCE();
               }
-              if (t > 0) {
-                const int c = (t - 1) >> 1, hf = (t - 1) & 1;
+              if (t > 0) finish_tile(t - 1);
 #pragma unroll
-                for (int nt = 0; nt < NT; ++nt)
+              for (int pr = 1; pr < NPROD; ++pr)
 #pragma unroll
-                  for (int hp = 0; hp < 2; ++hp) {
-                    unsigned h, m;
-                    act_split(raw[nt], hp, h, m);
-                    hBhi[c][nt][2 * hf + hp] = h;
-                    hBmid[c][nt][2 * hf + hp] = m;
-                  }
-              }
+                for (int nt = 0; nt < NT; ++nt) {
+                  f32x4& tp = cur[nt].s[Products<NP>::ACC[pr]];
+                  tp = mfma_narrow<PREC>(A[tl % 3].w[Products<NP>::W[pr]], zp[nt][Products<NP>::X[pr]], tp);
+                  MFMA_ORDER_FENCE();
+                }
 #pragma unroll
-              for (int nt = 0; nt < NT; ++nt) {
-                cur[nt] = mfma_f16(c_hi, zmid[nt], cur[nt]);
-                MFMA_ORDER_FENCE();
-              }
-#pragma unroll
-              for (int nt = 0; nt < NT; ++nt) {
-                cur[nt] = mfma_f16(c_hi, zhi[nt], cur[nt]);
-                MFMA_ORDER_FENCE();
-              }
-#pragma unroll
-              for (int nt = 0; nt < NT; ++nt) raw[nt] = cur[nt];
+              for (int nt = 0; nt < NT; ++nt) raw[nt] = cur[nt].total();
               bias = bias_next;
               __builtin_amdgcn_sched_barrier(0);
             }
           }
           stage_end();
-        }
-        {
-          const int c = (HT - 1) >> 1, hf = (HT - 1) & 1;
-#pragma unroll
-          for (int nt = 0; nt < NT; ++nt)
-#pragma unroll
-            for (int hp = 0; hp < 2; ++hp) {
-              unsigned h, m;
-              act_split(raw[nt], hp, h, m);
-              hBhi[c][nt][2 * hf + hp] = h;
-              hBmid[c][nt][2 * hf + hp] = m;
-            }
-        }
+        };
+        l0_stage(std::integral_constant<int, 0>{});
+        if constexpr (LT::value.N_L0 > 1) l0_stage(std::integral_constant<int, 1>{});
+        static_assert(LT::value.N_L0 <= 2, "layer 0 spans at most two stages");
+        finish_tile(HT - 1);
       }
       st.mark(1);
+      st.set(3);
 
       // ---- hidden layer, one 16-unit output tile per stage.  Tile u-1 is activated/split during pass u
       //      (one register pair per chunk region); an output-layer chunk (two hidden tiles = k 32) is
       //      consumed in the pass after its second tile.
       {
         f32x4 pre[NT];
-        u32x4 hOhi[NT], hOmid[NT];
+        u32x4 hO[NT][NP];
 #pragma unroll
-        for (int nt = 0; nt < NT; ++nt) {
-          hOhi[nt] = u32x4{0, 0, 0, 0};
-          hOmid[nt] = u32x4{0, 0, 0, 0};
-        }
-        f32x4 bias = ldb(b2, 0);
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+          for (int k = 0; k < NP; ++k) hO[nt][k] = u32x4{0, 0, 0, 0};
+        f32x4 bias = ldb(HT);
         // PREV: 0 = no previous tile (u = 0); 1 = tile u-1 is the FIRST half of its output-layer chunk
         // (u odd); 2 = it is the SECOND half and chunk (u-2)/2 is consumed at the end of this pass (u even >= 2)
         auto pass = [&](int u, auto prev_c, auto last_c) {
           constexpr int PREV = decltype(prev_c)::value;
           constexpr bool LAST = decltype(last_c)::value;
-          constexpr int NF_CUR = 2 * HC + (PREV == 2 ? 2 * OT : 0);
-          constexpr int NF_NEXT = LAST ? 2 * OT : (PREV == 1 ? 2 * HC + 2 * OT : 2 * HC);
-          const uint32_t* buf = STG + (gs & 1) * STAGE_WORDS;
+          constexpr int NU = HC + (PREV == 2 ? OT : 0);       // consumption units of this stage
+          // the stage after this one: the drain, a pass with an output-layer chunk (after an odd pass), or a plain pass
+          constexpr int NF_NEXT = LAST ? NP * OT : (PREV == 1 ? NP * (HC + OT) : NP * HC);
+          stage_begin();
           issue(std::integral_constant<int, NF_NEXT>{}, gs + 1);
-          u32x4 a_hi = frag(buf, 0), a_mid = frag(buf, 1);
-          const f32x4 bias_next = ldb(b2, (u + 1 < HT ? u + 1 : u) * 4);
-          f32x4 acc[NT];
+          Unit A[3];
+          load_unit(A[0], 0);
+          if (NU > 1) load_unit(A[1], 1);
+          const f32x4 bias_next = ldb(HT + (u + 1 < HT ? u + 1 : u));
+          Acc acc[NT];
 #pragma unroll
-          for (int nt = 0; nt < NT; ++nt) acc[nt] = bias;
+          for (int nt = 0; nt < NT; ++nt) acc[nt].init(bias);
           __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-          for (int c = 0; c < HC; ++c) {
-            const u32x4 c_hi = a_hi, c_mid = a_mid;
-            if (c + 1 < HC || PREV == 2) {      // next chunk's fragments (or the first output-layer tile's)
-              a_hi = frag(buf, 2 * c + 2);
-              a_mid = frag(buf, 2 * c + 3);
-            }
-            if (PREV != 0) {
-              // register pairs q = c, c + HC, ... of the previous tile (2*NT pairs in all); issued ahead of the
-              // region's MFMAs so that the first region covers the LDS latency of the fragment reads
+          for (int n = 0; n < NU; ++n) {
+            if (n + 2 < NU) load_unit(A[(n + 2) % 3], n + 2);
+            if (n < HC) {
+              if (PREV != 0) {
+                // register pairs q = n, n + HC, ... of the previous tile (2*NT pairs in all), ahead of the region's MFMAs
 #pragma unroll
-              for (int q = c; q < 2 * NT; q += HC) {
-                const int nt = q >> 1, hp = q & 1;
-                unsigned h, m;
-                act_split(pre[nt], hp, h, m);
-                hOhi[nt][(PREV == 2 ? 2 : 0) + hp] = h;
-                hOmid[nt][(PREV == 2 ? 2 : 0) + hp] = m;
+                for (int q = n; q < 2 * NT; q += HC) {
+                  const int nt = q >> 1, hp = q & 1;
+                  unsigned pc[NP];
+                  act_split(pre[nt], hp, nt, pc);
+#pragma unroll
+                  for (int k = 0; k < NP; ++k) hO[nt][k][(PREV == 2 ? 2 : 0) + hp] = pc[k];
+                }
               }
-            }
-#pragma unroll
-            for (int nt = 0; nt < NT; ++nt) {
-              acc[nt] = mfma_f16(c_mid, hBhi[c][nt], acc[nt]);
-              MFMA_ORDER_FENCE();
-            }
-#pragma unroll
-            for (int nt = 0; nt < NT; ++nt) {
-              acc[nt] = mfma_f16(c_hi, hBmid[c][nt], acc[nt]);
-              MFMA_ORDER_FENCE();
-            }
-#pragma unroll
-            for (int nt = 0; nt < NT; ++nt) {
-              acc[nt] = mfma_f16(c_hi, hBhi[c][nt], acc[nt]);
-              MFMA_ORDER_FENCE();
+              mac(A[n % 3], hB[n], acc);
+            } else {
+              // output-layer chunk (u-2)/2 = hidden tiles (u-2, u-1): its tiles follow the hidden row
+              mac(A[n % 3], hO, out[n - HC]);
             }
             __builtin_amdgcn_sched_barrier(0);
           }
-          if (PREV == 2) {
-            // output-layer chunk (u-2)/2 = hidden tiles (u-2, u-1): its fragments follow the hidden row
 #pragma unroll
-            for (int o = 0; o < OT; ++o) {
-              const u32x4 c_hi = a_hi, c_mid = a_mid;
-              if (o + 1 < OT) {
-                a_hi = frag(buf, 2 * HC + 2 * o + 2);
-                a_mid = frag(buf, 2 * HC + 2 * o + 3);
-              }
-#pragma unroll
-              for (int nt = 0; nt < NT; ++nt) {
-                out[o][nt] = mfma_f16(c_mid, hOhi[nt], out[o][nt]);
-                MFMA_ORDER_FENCE();
-              }
-#pragma unroll
-              for (int nt = 0; nt < NT; ++nt) {
-                out[o][nt] = mfma_f16(c_hi, hOmid[nt], out[o][nt]);
-                MFMA_ORDER_FENCE();
-              }
-#pragma unroll
-              for (int nt = 0; nt < NT; ++nt) {
-                out[o][nt] = mfma_f16(c_hi, hOhi[nt], out[o][nt]);
-                MFMA_ORDER_FENCE();
-              }
-            }
-          }
-#pragma unroll
-          for (int nt = 0; nt < NT; ++nt) pre[nt] = acc[nt];
+          for (int nt = 0; nt < NT; ++nt) pre[nt] = acc[nt].total();
           bias = bias_next;
           stage_end();
         };
@@ -515,40 +642,47 @@ __global__ void __launch_bounds__(64 * HX3_WAVES, (NT == 1) ? 2 : 1) flow_kernel
           }
         }
         st.mark(3);
-        // ---- drain: last tile, last output-layer chunk (HC-1); put the next net's / step's first stage in flight
+        st.set(4);
+        // ---- drain: last tile, last output-layer chunk (HC-1); the next net's / step's first stage goes in flight
         {
-          const uint32_t* buf = STG + (gs & 1) * STAGE_WORDS;
-          const bool more = (net + 1 < NNETS) || (step + 1 < p.n_steps);
-          if (more) {
-            next_src += (net + 1 < NNETS) ? L.BIAS_WORDS : SMALL_WORDS + L.BIAS_WORDS;
-            issue(std::integral_constant<int, NF_L0_FIRST>{}, gs + 1);
+          stage_begin();
+          if ((net + 1 < NNETS) || (step + 1 < p.n_steps)) {
+            if (net + 1 == NNETS) next_src += SMALL_WORDS;     // the next step's tables sit in front of its first net
+            issue_net_start(gs + 1);
           }
-          u32x4 A[2 * OT];
+          Unit A[OT];
 #pragma unroll
-          for (int f = 0; f < 2 * OT; ++f) A[f] = frag(buf, f);
+          for (int o = 0; o < OT; ++o) load_unit(A[o], o);
           constexpr bool odd_last = ((HT - 1) & 1) != 0;
 #pragma unroll
           for (int nt = 0; nt < NT; ++nt) {
 #pragma unroll
             for (int hp = 0; hp < 2; ++hp) {
-              unsigned h, m;
-              act_split(pre[nt], hp, h, m);
-              hOhi[nt][(odd_last ? 2 : 0) + hp] = h;
-              hOmid[nt][(odd_last ? 2 : 0) + hp] = m;
+              unsigned pc[NP];
+              act_split(pre[nt], hp, nt, pc);
+#pragma unroll
+              for (int k = 0; k < NP; ++k) hO[nt][k][(odd_last ? 2 : 0) + hp] = pc[k];
             }
             if (!odd_last) {
-              hOhi[nt][2] = 0; hOhi[nt][3] = 0; hOmid[nt][2] = 0; hOmid[nt][3] = 0;
+#pragma unroll
+              for (int k = 0; k < NP; ++k) { hO[nt][k][2] = 0; hO[nt][k][3] = 0; }
             }
           }
 #pragma unroll
-          for (int o = 0; o < OT; ++o) {
+          for (int o = 0; o < OT; ++o) mac(A[o], hO, out[o]);
 #pragma unroll
-            for (int nt = 0; nt < NT; ++nt) out[o][nt] = mfma_x3(A[2 * o], A[2 * o + 1], hOhi[nt], hOmid[nt], out[o][nt]);
-          }
+          for (int o = 0; o < OT; ++o)
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) outF[o][nt] = out[o][nt].total();
           stage_end();
         }
         st.mark(4);
       }
+      if constexpr (WATCH) {
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) sat[nt] = sat[nt] || !(amax[nt] <= 65504.0f);
+      }
+      ++cnets;
     }
 
     // ---- coupling transform of the other half, in place, + per-lane log-det partials
@@ -557,43 +691,51 @@ __global__ void __launch_bounds__(64 * HX3_WAVES, (NT == 1) ? 2 : 1) flow_kernel
       if (lds_tables) tout.load(SM + step * SMALL_WORDS + SMALL_HDR + 160 + g * NENT);
       else tout.load(sp + SMALL_HDR + 160 + g * NENT);
       if (KIND == GBNF_KIND_GLOW && !p.additive) {
+        constexpr int NE = (2 * OT < NENT) ? 2 * OT : NENT;
+        float v[NT][NE];
 #pragma unroll
-        for (int e = 0; e < 2 * OT && e < NENT; ++e) {
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+          for (int e = 0; e < NE; ++e) v[nt][e] = Z[(tout.slot[e] >= 0 ? tout.slot[e] : 0) * ZS + i + 16 * nt];
+#pragma unroll
+        for (int e = 0; e < NE; ++e) {
           const int o = e >> 1, pp = e & 1;
           const bool live = tout.slot[e] >= 0;
-          const int zoff = (live ? tout.slot[e] : 0) * ZS + i;
 #pragma unroll
           for (int nt = 0; nt < NT; ++nt) {
-            float v = Z[zoff + 16 * nt];
-            v = norm_fn<KIND>(v, tout.p0[e], tout.p1[e], tout.p2[e], tout.p3[e]);
+            float t = norm_fn<KIND>(v[nt][e], tout.p0[e], tout.p1[e], tout.p2[e], tout.p3[e]);
             const float shift = outA[o][nt][2 * pp], raw = outA[o][nt][2 * pp + 1];
             float sc, lsc;
             sigmoid_logsigmoid(raw + 2.0f, sc, lsc);
-            v = (v + shift) * sc;
+            t = (t + shift) * sc;
             if (live) {
-              Z[zoff + 16 * nt] = v;
+              Z[tout.slot[e] * ZS + i + 16 * nt] = t;
               ld[nt] += lsc;
             }
           }
         }
       } else {
+        constexpr int NE = (4 * OT < NENT) ? 4 * OT : NENT;
+        float v[NT][NE];
 #pragma unroll
-        for (int e = 0; e < 4 * OT && e < NENT; ++e) {
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+          for (int e = 0; e < NE; ++e) v[nt][e] = Z[(tout.slot[e] >= 0 ? tout.slot[e] : 0) * ZS + i + 16 * nt];
+#pragma unroll
+        for (int e = 0; e < NE; ++e) {
           const int o = e >> 2, r = e & 3;
           const bool live = tout.slot[e] >= 0;
-          const int zoff = (live ? tout.slot[e] : 0) * ZS + i;
 #pragma unroll
           for (int nt = 0; nt < NT; ++nt) {
-            float v = Z[zoff + 16 * nt];
-            v = norm_fn<KIND>(v, tout.p0[e], tout.p1[e], tout.p2[e], tout.p3[e]);
+            float t = norm_fn<KIND>(v[nt][e], tout.p0[e], tout.p1[e], tout.p2[e], tout.p3[e]);
             if constexpr (KIND == GBNF_KIND_GLOW) {
-              v = v + outA[o][nt][r];
-              if (live) Z[zoff + 16 * nt] = v;
+              t = t + outA[o][nt][r];
+              if (live) Z[tout.slot[e] * ZS + i + 16 * nt] = t;
             } else {
               const float shift = outA[o][nt][r], scale = outB[o][nt][r];
-              v = shift + v * exp_fast(scale);
+              t = shift + t * exp_fast(scale);
               if (live) {
-                Z[zoff + 16 * nt] = v;
+                Z[tout.slot[e] * ZS + i + 16 * nt] = t;
                 ld[nt] += scale;
               }
             }
@@ -628,66 +770,92 @@ __global__ void __launch_bounds__(64 * HX3_WAVES, (NT == 1) ? 2 : 1) flow_kernel
       quad[nt] += -0.5f * v * v - lsd;
     }
   }
+  bool any_sat = false;
+  unsigned long long bad_rows = 0;      // bit r: row r of the wave's tile left the fp16 range (its outputs are marked)
 #pragma unroll
   for (int nt = 0; nt < NT; ++nt) {
     float q = quad[nt], l = ld[nt];
     q += __shfl_xor(q, 16); q += __shfl_xor(q, 32);
     l += __shfl_xor(l, 16); l += __shfl_xor(l, 32);
+    bool bad = false;
+    if constexpr (WATCH) {
+      const unsigned long long m = __ballot(sat[nt]);          // bit (16 g + i): fold the 4 lane groups per sample
+      const unsigned rows = (unsigned)((m | (m >> 16) | (m >> 32) | (m >> 48)) & 0xffffull);
+      bad_rows |= (unsigned long long)rows << (16 * nt);
+      bad = (rows >> i) & 1u;
+      any_sat = any_sat || rows != 0;
+    }
     const int64_t n = row0 + 16 * nt + i;
     if (g == 0 && n < p.n) {
       const float ldj = l + ld_const;
-      const int64_t o = (int64_t)comp * p.out_stride + (int64_t)batch * p.n + n;
-      if (p.ldj_out) p.ldj_out[o] = ldj;
-      if (p.ll_out) p.ll_out[o] = (q - 0.91893853320467274f * (float)d) + ldj;
+      const float nanv = __builtin_nanf("");
+      if (p.ldj_out) p.ldj_out[out_base + n] = bad ? nanv : ldj;
+      if (p.ll_out) p.ll_out[out_base + n] = bad ? nanv : (q - 0.91893853320467274f * (float)d) + ldj;
     }
   }
-  if (p.sat != nullptr && __any(sat) && lane == 0) atomicAdd(p.sat, 1u);
+  if (WATCH && p.sat != nullptr && any_sat && lane == 0) atomicAdd(p.sat, 1u);
   if (p.z_out != nullptr && lane < d) {
     const int slot = (int)tail[lane];
     float* zo = p.z_out + (int64_t)comp * p.n * d;
 #pragma unroll 8
     for (int r = 0; r < 16 * NT; ++r) {
       const int64_t n = row0 + r;
-      if (n < p.n) zo[n * d + lane] = Z[slot * ZS + r];
+      float v = Z[slot * ZS + r];
+      if (WATCH && ((bad_rows >> r) & 1ull)) v = __builtin_nanf("");
+      if (n < p.n) zo[n * d + lane] = v;
     }
   }
 #ifdef GBNF_STAMPS
   st.mark(6);
   if (p.dbg != nullptr && lane == 0) {
 #pragma unroll
-    for (int k = 0; k < 8; ++k) p.dbg[((size_t)blockIdx.x * HX3_WAVES + wave) * 8 + k] = st.acc[k];
+    for (int k = 0; k < 8; ++k) p.dbg[((size_t)blockIdx.x * WAVES + wave) * 8 + k] = st.acc[k];
   }
 #endif
 }
 
-inline size_t flow_hx3_lds_bytes(int n_steps, int nt, int stage_frags, int d) {
-  const size_t tables = n_steps <= LDS_TABLE_STEPS ? (size_t)n_steps * SMALL_WORDS : 0;
-  return (tables + 2 * (size_t)stage_frags * 256 + (size_t)HX3_WAVES * d * (16 * nt + 1)) * 4;
+// LDS bytes of a launch with `ring` stage slots.
+inline size_t flow_hx3_lds_bytes(int n_steps, int nt, int waves, int stage_frags, int bias_frags, int d, int ring,
+                                 bool lds_tables) {
+  const size_t tables = lds_tables ? (size_t)n_steps * SMALL_WORDS : 0;
+  return (tables + 2 * (size_t)bias_frags * 256 + (size_t)ring * stage_frags * 256 + (size_t)waves * d * (16 * nt + 1)) * 4;
 }
-
-// hx3 variants are keyed like the f32 ones with ksl = ks1 = lmid-independent fields fixed:
-//   VariantKey{kind, ht, /*ksl*/ -3, /*ks1*/ 0, ot, nt, /*lmid*/ 1, act_a, act_b}
-#define GBNF_INSTANTIATE_HX3(KIND, HT, OT, NT, ACTA, ACTB)                                                  \
+// hx3 variants are keyed like the f32 ones with the lmid-independent fields fixed:
+//   VariantKey{kind, ht, /*ksl*/ -3 (f16x3) | -6 (bf16x6), /*ks1*/ 0, ot, nt, /*lmid*/ 1, act_a, act_b}
+// The launcher sizes its own grid (it knows its waves per workgroup) and ring; the `grid` argument is ignored.
+#define GBNF_INSTANTIATE_HX3(KIND, HT, OT, NT, ACTA, ACTB, PREC)                                            \
   namespace gbnf {                                                                                          \
-  static hipError_t launch_hx3_##KIND##_##HT##_##OT##_##NT##_##ACTA##_##ACTB(const FlowLaunch& p,           \
-                                                                             unsigned grid, hipStream_t s) { \
-    constexpr Hx3Layout L(HT, OT);                                                                          \
-    const size_t lds = flow_hx3_lds_bytes(p.n_steps, NT, L.STAGE_FRAGS, p.d);                                    \
+  static hipError_t launch_hx3_##KIND##_##HT##_##OT##_##NT##_##ACTA##_##ACTB##_##PREC(const FlowLaunch& p0, \
+                                                                                     unsigned, hipStream_t s) { \
+    constexpr Hx3Layout L(HT, OT, hx3_pieces(PREC));                                                        \
+    constexpr int ENT = hx3_eff_nt(HT, OT, NT, PREC, KIND, ACTA, ACTB);                                     \
+    constexpr int WAVES = hx3_waves(HT, OT, ENT, PREC, KIND, ACTA, ACTB);                                   \
+    FlowLaunch p = p0;                                                                                      \
+    p.n_tiles = (int32_t)((p.n + 16 * ENT - 1) / (16 * ENT));                                               \
+    /* per-step tables in LDS when they fit beside the staging slots and the Z tiles, else read from the blob */ \
+    p.lds_tables = p.n_steps <= LDS_TABLE_STEPS &&                                                          \
+        flow_hx3_lds_bytes(p.n_steps, ENT, WAVES, L.STAGE_FRAGS, L.BIAS_FRAGS, p.d, HX3_RING, true) <= 160 * 1024; \
+    p.ring = HX3_RING;                                                                                      \
+    const size_t lds = flow_hx3_lds_bytes(p.n_steps, ENT, WAVES, L.STAGE_FRAGS, L.BIAS_FRAGS, p.d, p.ring,  \
+                                          p.lds_tables != 0);                                               \
+    if (lds > 160 * 1024) return hipErrorInvalidValue;                                                      \
+    const long long grid = (long long)((p.n_tiles + WAVES - 1) / WAVES) * p.n_comp * p.n_batches;           \
+    if (grid > 0x7fffffffLL) return hipErrorInvalidValue;                                                   \
     static bool attr_set = false;                                                                           \
     if (!attr_set) {                                                                                        \
-      hipError_t e = hipFuncSetAttribute((const void*)flow_kernel_hx3<KIND, HT, OT, NT, ACTA, ACTB>,        \
+      hipError_t e = hipFuncSetAttribute((const void*)flow_kernel_hx3<KIND, HT, OT, ENT, ACTA, ACTB, PREC>, \
                                          hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);           \
       if (e != hipSuccess) return e;                                                                        \
       attr_set = true;                                                                                      \
     }                                                                                                       \
-    hipLaunchKernelGGL((flow_kernel_hx3<KIND, HT, OT, NT, ACTA, ACTB>), dim3(grid), dim3(64 * HX3_WAVES),   \
-                       lds, s, p);                                                                          \
+    hipLaunchKernelGGL((flow_kernel_hx3<KIND, HT, OT, ENT, ACTA, ACTB, PREC>), dim3((unsigned)grid),        \
+                       dim3(64 * WAVES), lds, s, p);                                                        \
     return hipGetLastError();                                                                               \
   }                                                                                                         \
-  static const int reg_hx3_##KIND##_##HT##_##OT##_##NT##_##ACTA##_##ACTB =                                  \
-      (register_variant(VariantKey{KIND, HT, -3, 0, OT, NT, 1, ACTA, ACTB},                                 \
-                        launch_hx3_##KIND##_##HT##_##OT##_##NT##_##ACTA##_##ACTB,                           \
-                        "flow_kernel_hx3<" #KIND "," #HT "," #OT "," #NT "," #ACTA "," #ACTB ">"),          \
+  static const int reg_hx3_##KIND##_##HT##_##OT##_##NT##_##ACTA##_##ACTB##_##PREC =                         \
+      (register_variant(VariantKey{KIND, HT, (PREC) == 0 ? -3 : -6, 0, OT, NT, 1, ACTA, ACTB},              \
+                        launch_hx3_##KIND##_##HT##_##OT##_##NT##_##ACTA##_##ACTB##_##PREC,                  \
+                        "flow_kernel_hx3<" #KIND "," #HT "," #OT "," #NT "," #ACTA "," #ACTB "," #PREC ">"),\
        0);                                                                                                  \
   }
 

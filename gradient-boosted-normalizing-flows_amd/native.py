@@ -95,7 +95,7 @@ class KernelInfo(C.Structure):
     _fields_ = [("hidden_tiles", C.c_int32), ("out_tiles", C.c_int32), ("samples_per_wave", C.c_int32),
                 ("n_steps", C.c_int32), ("macs_per_sample", C.c_double),
                 ("padded_macs_per_sample", C.c_double), ("packed_bytes", C.c_int64),
-                ("math_mode", C.c_int32), ("reserved", C.c_int32)]
+                ("math_mode", C.c_int32), ("probe_rel_err", C.c_float)]
 
 
 _lib = None

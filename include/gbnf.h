@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define GBNF_ABI_VERSION 1
+#define GBNF_ABI_VERSION 2
 
 typedef enum gbnf_status {
   GBNF_OK = 0,
@@ -49,12 +49,20 @@ enum { GBNF_KIND_GLOW = 0, GBNF_KIND_REALNVP = 1 };
  * Evaluation and the inverse direction on the exact-f32 kernel, training on gbnf_trainer_* (B <= 2). */
 enum { GBNF_ACT_TANH = 0, GBNF_ACT_RELU = 1, GBNF_ACT_RESIDUAL_RELU = 2 };
 enum { GBNF_COUPLING_AFFINE = 0, GBNF_COUPLING_ADDITIVE = 1 };
-/* How the coupling-network matrix products are evaluated (results agree to ~1e-6 relative in log-likelihood):
- *   F32     exact f32 MFMA (v_mfma_f32_16x16x4_f32), bitwise an ordered fmaf chain;
+/* How the coupling-network matrix products are evaluated:
+ *   F32     exact f32 MFMA (v_mfma_f32_16x16x4_f32), bitwise an ordered fmaf chain (any depth, ResidualNets; hidden <= 256);
  *   F16X3   each f32 operand split into two fp16 pieces (22 significand bits); a.b = a_mid.b_hi + a_hi.b_mid +
- *           a_hi.b_hi on the f16 matrix pipe with f32 accumulation (coupling_network_depth == 1 only);
- *   DEFAULT F16X3 where a compiled variant exists, else F32. */
-enum { GBNF_MATH_DEFAULT = -1, GBNF_MATH_F32 = 0, GBNF_MATH_F16X3 = 1 };
+ *           a_hi.b_hi on the f16 matrix pipe with f32 accumulation (coupling_network_depth == 1, hidden <= 512): the fast
+ *           path, ~1e-7 relative in the log-likelihood on well-conditioned models.  An operand beyond the fp16 range
+ *           (|v| > 65504) cannot be represented: the kernel marks such samples and a bf16x6 repair pass behind every
+ *           f16x3 launch re-evaluates them (same stream, no host synchronisation), so results are range-safe;
+ *   BF16X6  three bf16 pieces per operand (>= 24 bits, f32 range), six products: f32-faithful for every finite input;
+ *           ~2x the matrix work of F16X3 (same shapes as F16X3);
+ *   DEFAULT per component: both split packings are built and a probe batch (128 rows ~ N(0,1) / N(0,4)) is evaluated
+ *           on both at creation; F16X3 if they agree to 2.5e-6 relative in the log-likelihood, else BF16X6 (ill-conditioned
+ *           models: e.g. un-normalised ReLU RealNVPs); F32 where no split kernel applies (depth 0 / 2, ResidualNets).
+ *           Env GBNF_MATH=f32|f16x3|bf16x6 overrides DEFAULT in gbnf_flow_create. */
+enum { GBNF_MATH_DEFAULT = -1, GBNF_MATH_F32 = 0, GBNF_MATH_F16X3 = 1, GBNF_MATH_BF16X6 = 2 };
 
 /* nn.Linear: y = x W^T + b, W row-major (out_features, in_features).
  * TanhNet / ReLUNet layers, models/layers.py:208-243. */
@@ -116,15 +124,17 @@ typedef struct gbnf_kernel_info {
   double macs_per_sample;        /* algorithmic multiply-adds per sample per component */
   double padded_macs_per_sample; /* what the MFMA tiles actually execute          */
   int64_t packed_bytes;          /* device bytes of packed parameters per component */
-  int32_t math_mode;             /* GBNF_MATH_F32 or GBNF_MATH_F16X3 actually used */
-  int32_t reserved;
+  int32_t math_mode;             /* GBNF_MATH_F32, _F16X3 or _BF16X6 actually used */
+  float probe_rel_err;           /* DEFAULT mode: f16x3 vs bf16x6 on the creation-time probe batch (max relative
+                                    log-likelihood difference; inf = a probe row left the fp16 range); -1 = no probe ran */
 } gbnf_kernel_info;
 
 int gbnf_version(void);
 const char* gbnf_last_error(void);
 
-/* The split-f16 kernels (evaluation default, training) represent an f32 operand by two fp16 pieces: beyond +-65504 it
- * saturates silently (the normalised input of a coupling net; in training also activations and scaled gradients).  This
+/* The split-f16 kernels (evaluation, training) represent an f32 operand by two fp16 pieces: beyond +-65504 it cannot be
+ * stored (the normalised input of a coupling net, a ReLU activation; in training also scaled gradients).  The EVALUATION
+ * kernels repair such samples themselves (bf16x6 pass, see GBNF_MATH_F16X3); the training kernels saturate.  This
  * returns how many waves ran into that since the last reset -- 0 for z-scored data on a trained flow -- and optionally
  * resets the counter.  One counter per device: this reports (and resets) the CURRENT device's, after a
  * hipDeviceSynchronize() (every stream of that device). */
@@ -133,7 +143,7 @@ int gbnf_saturation_count(int64_t* count, int32_t reset);
 /* Replaces: constructing flows[c] + .to(device)  (models/boosted_flow.py:42-50).
  * Packs (pads, tiles, folds slot maps) and uploads the parameters. */
 int gbnf_flow_create(const gbnf_flow_desc* desc, gbnf_flow** out);
-/* Same with an explicit GBNF_MATH_* mode (gbnf_flow_create uses GBNF_MATH_DEFAULT, or env GBNF_MATH=f32|f16x3). */
+/* Same with an explicit GBNF_MATH_* mode (gbnf_flow_create uses GBNF_MATH_DEFAULT, or env GBNF_MATH=f32|f16x3|bf16x6). */
 int gbnf_flow_create_mode(const gbnf_flow_desc* desc, int32_t math_mode, gbnf_flow** out);
 /* ... and creation flags.  A component whose coupling nets do not all use the same activation (the reference's
  * `--coupling_network random` draws TanhNet / ReLUNet per step, models/glow.py:295-296, or per net,
@@ -159,7 +169,9 @@ int gbnf_flow_forward(const gbnf_flow* flow, const float* x, int64_t n,
 int gbnf_flow_inverse(const gbnf_flow* flow, const float* z, int64_t n, float* x, float* ldj, void* stream);
 
 /* Replaces: the nn.ModuleList of components (models/boosted_flow.py:42).  All flows must
- * share one architecture (they do: every component is built from the same args).
+ * share one architecture (they do: every component is built from the same args) and one math mode -- except that
+ * DEFAULT-created components which came out of their probes as a mix of F16X3 and BF16X6 are accepted: the mixture
+ * then runs every component on its bf16x6 packing.
  * The mixture does NOT take ownership of the flows; they must outlive it. */
 int gbnf_mixture_create(gbnf_flow* const* flows, int32_t n_flows, gbnf_mixture** out);
 int gbnf_mixture_destroy(gbnf_mixture* mix);

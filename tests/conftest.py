@@ -103,6 +103,10 @@ class GoldenCase:
         if cfg["case"] == "native":
             self.x = self.data["x"]
             self.specs = [gspec.unflatten_spec(self.data, prefix=f"c{c}.") for c in range(cfg["C"])]
+        elif cfg["case"] == "synth_specs":      # components given as generator calls (the stress offender g15)
+            self.x = synth.synth_batch(cfg["N"], cfg["d"], seed=cfg["x_seed"], scale=cfg.get("x_scale", 1.0))
+            self.specs = [getattr(synth, e["fn"])(**e["kwargs"]) for e in cfg["specs"]]
+            cfg.setdefault("synth_kw", {})
         else:
             self.x = synth.synth_batch(cfg["N"], cfg["d"], seed=cfg["x_seed"], scale=cfg.get("x_scale", 1.0))
             self.specs = synth.synth_boosted_specs(cfg["kind"], cfg["C"], cfg["d"], cfg["h"], cfg["K"],

@@ -177,6 +177,33 @@ def synth_case(name, kind, d, h, K, C, N, x_seed=0, w_seed=1, x_scale=1.0, n_use
     print(f"{name}: ll[0,:3]={ll[0, :3]}  G[:3]={G[:3]}  finite={np.isfinite(G).all()}")
 
 
+def specs_case(name, kind, entries, N, x_seed, x_scale=1.0, **ref_kw):
+    """Components given one by one as calls of this repo's generator (``entries`` = [(function name, kwargs)]): the
+    fixture stores the calls, x's seed and the reference's outputs.  Used for the stress offender found on the GPU
+    (tools/find_offender.py): an un-normalised ReLU RealNVP (no BatchNorm), K = 8, h = 500 -- ill-conditioned in f32."""
+    specs = [getattr(synth, fn)(**kw) for fn, kw in entries]
+    d, K, h = specs[0]["d"], len(specs[0]["steps"]), int(np.asarray(specs[0]["steps"][0]["t_net" if kind == "realnvp" else "net"]["layers"][0][0]).shape[0])
+    torch.manual_seed(1234)
+    model = RefBoostedFlow(ref_args(kind, d, h, K, len(specs), **ref_kw))
+    for c, sp in enumerate(specs):
+        install_spec(model.flows[c], sp)
+    x = synth.synth_batch(N, d, seed=x_seed, scale=x_scale)
+    z, ldj, ll, G = run_reference(model, x, len(specs))
+    cfg = dict(case="synth_specs", kind=kind, d=d, h=h, K=K, C=len(specs), N=N, x_seed=x_seed, x_scale=x_scale,
+               specs=[dict(fn=fn, kwargs=kw) for fn, kw in entries])
+    np.savez_compressed(os.path.join(HERE, name + ".npz"), config=np.frombuffer(json.dumps(cfg).encode(), dtype=np.uint8),
+                        rho=model.rho.numpy().copy(), ldj=ldj, ll=ll, G=G, z=z)
+    print(f"{name}: ll[:, :3]={ll[:, :3]}  G[:3]={G[:3]}  finite={np.isfinite(G).all()}  max|ll|={np.abs(ll).max():.1f}")
+
+
+def stress_cases():
+    common = dict(d=8, h=500, K=8, coupling_network="relu", batch_norm=False)
+    specs_case("g15_stress_realnvp_relu_nobn_d8_h500", "realnvp",
+               [("synth_realnvp_spec", dict(common, flip_init=0, seed=7004)),
+                ("synth_realnvp_spec", dict(common, flip_init=1, seed=7005))],     # tools/find_offender.py: d=8 h=500 K=8 seed=5 x_scale=2
+               N=512, x_seed=5, x_scale=2.0, coupling_network="relu", batch_norm=False)
+
+
 def native_glow_case(name, d=43, h=32, K=5, C=3, N=256):
     """G2: the reference initialises itself (ActNorm data init + perturbed Linear weights)."""
     torch.manual_seed(7)
@@ -567,6 +594,9 @@ def image_case(name, h=32, K=2, L=2, C=2, N=4, depth=1, coupling="affine", permu
 
 def main():
     torch.set_num_threads(4)
+    if "--stress-only" in sys.argv:
+        stress_cases()
+        return
     if "--image-only" in sys.argv:
         image_case("g12_image_glow_invconv_affine")
         image_case("g12_image_glow_shuffle_additive", coupling="additive", permutation="shuffle", learn_top=False, depth=2)
@@ -651,6 +681,7 @@ def main():
     synth_case("g6_glow_d43_h64_c4_used2", "glow", 43, 64, 5, 4, 64, n_used=2)           # loaded < C
     synth_case("g6_realnvp_d21_h64_n33", "realnvp", 21, 64, 5, 3, 33)
     synth_case("g6_glow_d43_h64_c3_rho", "glow", 43, 64, 5, 3, 64, rho_override=[0.7, 3.0, 0.01])
+    stress_cases()
 
 
 if __name__ == "__main__":

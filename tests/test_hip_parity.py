@@ -25,19 +25,28 @@ def _mixture(specs, math="default"):
     return native.mixture_from_specs(specs, math=math)    # (per-step activation kernels when the components need them)
 
 
-@pytest.mark.parametrize("math", ["f32", "f16x3"])
+@pytest.mark.parametrize("math", ["f32", "f16x3", "bf16x6", "default"])
 @pytest.mark.parametrize("name", golden_names())
 def test_hip_matches_reference_golden(name, math, golden_case, dev):
-    """Every fixture in both math modes: exact-f32 MFMA and the split-f16 (3 product) matrix path."""
+    """Every fixture in every math mode: exact-f32 MFMA, the split-f16 (3 product) and split-bf16 (6 product) matrix
+    paths, and the library's own choice (probe at creation)."""
     import torch
     from gbnf_amd import native
     g = golden_case(name)
+    stress = g.cfg["case"] == "synth_specs"      # g15: the ill-conditioned model tools/find_offender.py found (h = 500)
+    if stress and math == "f16x3":
+        pytest.skip("the explicit (unguarded) f16x3 mode misses 1e-5 on this model by design (1.5e-5): DEFAULT must "
+                    "pick bf16x6 for it, which the 'default' and 'bf16x6' cases of this fixture check")
     try:
         mix, flows = _mixture(g.specs, math)
     except native.GbnfError:
+        if stress and math == "f32":
+            pytest.skip("hidden width 500: beyond the exact-f32 kernel (h <= 256); the split kernels cover it")
         skw = g.cfg.get("synth_kw", {})    # depth 0 / 2 and ResidualNets: exact-f32 kernel only
-        assert math == "f16x3" and (skw.get("depth", 1) != 1 or skw.get("coupling_network") == "residual")
-        pytest.skip("split-f16 kernel: TanhNet / ReLUNet of depth 1 only; this fixture runs on the exact-f32 kernel")
+        assert math in ("f16x3", "bf16x6") and (skw.get("depth", 1) != 1 or skw.get("coupling_network") == "residual")
+        pytest.skip("split kernels: TanhNet / ReLUNet of depth 1 only; this fixture runs on the exact-f32 kernel")
+    if stress and math == "default":             # the probe must have moved the ill-conditioned component off f16x3
+        assert flows[1].info().math_mode == native.MATH["bf16x6"] and flows[1].info().probe_rel_err > 2.5e-6
     if g.base is not None:
         mix.set_base(*g.base)
     x = torch.from_numpy(g.x).to(dev)
@@ -74,7 +83,7 @@ def test_single_launch_equals_per_component(golden_case, dev):
     assert torch.equal(part, ll_all[2:5])
 
 
-@pytest.mark.parametrize("math", ["f32", "f16x3"])
+@pytest.mark.parametrize("math", ["f32", "f16x3", "bf16x6"])
 def test_group_launch_equals_per_batch_launches(math, golden_case, dev):
     """One launch over a group of batches (gbnf_mixture_component_log_prob_multi) == one launch per batch, bit for
     bit, incl. ragged batch sizes; the strided single-batch form writes only its column block."""
@@ -82,13 +91,13 @@ def test_group_launch_equals_per_batch_launches(math, golden_case, dev):
     from gbnf_amd import native, synth
     g = golden_case("g3_glow_d43_h215_c8")
     mix, _ = _mixture(g.specs, math)
-    for n in (4096, 77):
+    for n in (8192, 77):
         xs = [torch.from_numpy(synth.synth_batch(n, 43, seed=40 + b)).to(dev) for b in range(5)]
         table = torch.full((8, 5 * n), float("nan"), device=dev)
         mix.prepared_group_log_prob(xs, table)(native._stream_ptr())
         for b, xb in enumerate(xs):
             single = mix.component_log_prob(xb)
-            if n == 4096:     # same 32-sample wave tiles in both launches -> identical bits
+            if n == 8192:     # same 32-sample wave tiles in both launches -> identical bits
                 assert torch.equal(table[:, b * n:(b + 1) * n], single)
             else:             # the lone small batch runs on 16-sample tiles: same math, other instantiation
                 assert rel_err(table[:, b * n:(b + 1) * n].cpu().numpy(), single.cpu().numpy()) < 2e-6
@@ -201,22 +210,78 @@ def test_residual_coupling_networks(blocks, dev):
         native.NativeFlow(specs[0], math="f16x3")
 
 
-def test_saturation_is_counted(dev):
-    """Beyond +-65504 a split-f16 operand saturates silently; the library counts the waves it happened to."""
+def test_out_of_range_samples_are_repaired(dev):
+    """Beyond +-65504 a split-f16 operand cannot be stored: the f16x3 kernel marks such samples (and counts the waves),
+    and the bf16x6 repair pass behind every f16x3 launch re-evaluates them -- the results meet the bar for ANY finite
+    input, no host synchronisation involved."""
     import torch
     from gbnf_amd import native, synth
+    from oracle import gbnf_oracle as oracle
     native.saturation_count(reset=True)
-    spec = synth.synth_realnvp_spec(6, 30, 3, seed=1, coupling_network="relu", batch_norm=False)
-    flow = native.NativeFlow(spec)
-    assert flow.info().math_mode == native.MATH["f16x3"]
-    x = synth.synth_batch(256, 6, seed=2)
+    spec = synth.synth_glow_spec(6, 30, 3, seed=1)
+    flow = native.NativeFlow(spec, math="f16x3")
+    x = synth.synth_batch(300, 6, seed=2)
     flow.forward(torch.from_numpy(x).to(dev), want_ll=True)
     assert native.saturation_count() == 0
-    flow.forward(torch.from_numpy(x * np.float32(1e7)).to(dev), want_ll=True)
+    big = x.copy()
+    big[7] *= np.float32(1e6)           # one row far outside the fp16 range, the others untouched
+    big[130, 3] = np.float32(-4e5)
+    z, ldj, ll = flow.forward(torch.from_numpy(big).to(dev), want_ll=True)
     assert native.saturation_count(reset=True) > 0
     assert native.saturation_count() == 0
-    native.NativeFlow(spec, math="f32").forward(torch.from_numpy(x * np.float32(1e7)).to(dev), want_ll=True)
-    assert native.saturation_count() == 0                      # the exact-f32 kernel has no such bound
+    zr, lr = oracle.component_forward(spec, big)
+    llr = oracle.component_log_prob(spec, big)
+    assert np.isfinite(ll.cpu().numpy()).all()
+    assert rel_err(ll.cpu().numpy(), llr) < LL_RTOL and rel_err(ldj.cpu().numpy(), lr) < LL_RTOL
+    np.testing.assert_allclose(z.cpu().numpy(), zr, rtol=2e-5, atol=2e-5)
+    # outputs one at a time (the repair pass finds the marks in whichever output exists)
+    only_z = flow.forward(torch.from_numpy(big).to(dev), want_ldj=False)[0]
+    assert torch.equal(only_z, z)
+    only_ldj = flow.forward(torch.from_numpy(big).to(dev), want_z=False)[1]
+    assert torch.equal(only_ldj, ldj)
+    # a ReLU net: activations leave the range although the inputs do not
+    # (additive coupling, huge gain: 55 of the 256 rows drive a hidden activation beyond 65504, every ll stays finite)
+    rspec = synth.synth_glow_spec(6, 30, 1, act="relu", seed=5, gain=60.0, coupling="additive")
+    xr = synth.synth_batch(256, 6, seed=3, scale=30.0)
+    rflow = native.NativeFlow(rspec, math="f16x3")
+    _, _, llg = rflow.forward(torch.from_numpy(xr).to(dev), want_ll=True)
+    ref = oracle.component_log_prob(rspec, xr)
+    assert np.isfinite(ref).all() and rel_err(llg.cpu().numpy(), ref) < LL_RTOL
+    assert native.saturation_count(reset=True) > 0
+    # the mixture path repairs too
+    specs = synth.synth_boosted_specs("glow", 3, 6, 30, 3, seed=4)
+    mix, _ = native.mixture_from_specs(specs, math="f16x3")
+    rho = oracle.rho_init(3)
+    G, llm = mix.log_prob(torch.from_numpy(big).to(dev), torch.from_numpy(rho).to(dev))
+    ll_ref, G_ref = oracle.mixture_log_prob(specs, rho, big)
+    assert rel_err(llm.cpu().numpy(), ll_ref) < LL_RTOL and rel_err(G.cpu().numpy(), G_ref) < LL_RTOL
+    native.saturation_count(reset=True)
+
+
+def test_default_mode_probe_and_mixed_mixtures(dev):
+    """DEFAULT math mode: a well-conditioned component stays on f16x3 (probe error reported), an explicit bf16x6 handle
+    joins f16x3 handles in one mixture, which then runs every component on its bf16x6 packing."""
+    import torch
+    from gbnf_amd import native, synth
+    from oracle import gbnf_oracle as oracle
+    specs = synth.synth_boosted_specs("glow", 3, 43, 64, 4, seed=9)
+    auto = [native.NativeFlow(s) for s in specs]
+    for f in auto:
+        info = f.info()
+        assert info.math_mode == native.MATH["f16x3"] and 0.0 <= info.probe_rel_err < 2.5e-6
+    assert native.NativeFlow(specs[0], math="f16x3").info().probe_rel_err == -1.0
+    mixed = [auto[0], native.NativeFlow(specs[1], math="bf16x6"), auto[2]]
+    assert mixed[1].info().math_mode == native.MATH["bf16x6"]
+    mix = native.NativeMixture(mixed)
+    x = synth.synth_batch(500, 43, seed=1)
+    rho = oracle.rho_init(3)
+    G, ll = mix.log_prob(torch.from_numpy(x).to(dev), torch.from_numpy(rho).to(dev))
+    ll_ref, G_ref = oracle.mixture_log_prob(specs, rho, x)
+    assert rel_err(ll.cpu().numpy(), ll_ref) < LL_RTOL and rel_err(G.cpu().numpy(), G_ref) < LL_RTOL
+    safe_ll = torch.stack([native.NativeFlow(s, math="bf16x6").forward(torch.from_numpy(x).to(dev), want_ll=True)[2] for s in specs])
+    assert torch.equal(safe_ll, ll)                     # the promoted mixture IS the bf16x6 evaluation
+    with pytest.raises(native.GbnfError):               # an exact-f32 handle does not mix with split handles
+        native.NativeMixture([auto[0], native.NativeFlow(specs[1], math="f32")])
 
 
 def test_full_size_against_oracle(dev):

@@ -44,7 +44,7 @@ def test_random_shape_against_oracle(kind, d, h, K, n, act, extra, seed):
     zr, lr = oracle.component_forward(spec, x)
     llr = oracle.component_log_prob(spec, x)
     xd = torch.from_numpy(x).to(dev)
-    for math in ("f32", "f16x3"):
+    for math in ("f32", "f16x3", "bf16x6"):
         z, ldj, ll = native.NativeFlow(spec, math=math).forward(xd, want_ll=True)
         assert np.isfinite(ll.cpu().numpy()).all()
         assert rel_err(ll.cpu().numpy(), llr) < LL_RTOL, (math, rel_err(ll.cpu().numpy(), llr))

@@ -100,13 +100,14 @@ def _nccl_pipeline_worker(rank, world, port, name, ret):
         outs = pipe.log_prob_groups([xs[0:3], xs[3:6], xs[6:7]])
         pipe.drain()
         torch.cuda.synchronize()
+        n_gathers = len(pipe.gather_events)            # one all-gather per group
         # the same groups again: every launch is already bound, buffers are re-used across the two slots
         outs2 = pipe.log_prob_groups([xs[0:3], xs[3:6], xs[6:7]])
         torch.cuda.synchronize()
         ref = [mix.log_prob(x, rho)[0] for x in xs]                                      # per-batch launches, no exchange
         torch.cuda.synchronize()
         ret[rank] = ([o.cpu().numpy() for o in outs], [o.cpu().numpy() for o in outs2], [r.cpu().numpy() for r in ref],
-                     len(pipe.gather_events))
+                     n_gathers)
     finally:
         dist.destroy_process_group()
 

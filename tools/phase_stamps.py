@@ -17,7 +17,7 @@ NAMES = {
     "f32": ["0 tables+in-prep", "1 layer-0 tile 0", "2 fused pass u=0 (+layer 0)", "3 fused passes u>=1",
             "4 last tile+out", "5 coupling epilogue", "6 final ll/z store", "7 -"],
     "f16x3": ["0 tables+in-prep+split", "1 layer 0 (stages)", "2 -", "3 hidden passes (stages)", "4 drain stage",
-              "5 coupling epilogue", "6 final ll/z store", "7 -"],
+              "5 coupling epilogue", "6 final ll/z store", "7 stage-end wait + barrier"],
 }
 
 
@@ -26,11 +26,13 @@ def main():
     C_, B = 8, 4096
     specs = synth.synth_boosted_specs("glow", C_, 43, 215, 5, seed=1)
     dev = torch.device("cuda:0")
+    os.environ["GBNF_NO_REPAIR"] = "1"
     flows = [native.NativeFlow(s, math=mode) for s in specs]
     mix = native.NativeMixture(flows)
     x = torch.from_numpy(synth.synth_batch(B, 43, seed=0)).to(dev)
-    nwaves = C_ * ((B + 31) // 32)
-    buf = torch.zeros(nwaves * 2 * 8, dtype=torch.int64, device=dev)
+    nt = int(os.environ.get("GBNF_FORCE_NT", "1"))      # set GBNF_FORCE_NT=2 for the 32-sample waves of the grouped launches
+    nwaves = C_ * ((B + 16 * nt - 1) // (16 * nt))
+    buf = torch.zeros((nwaves + 64) * 2 * 8, dtype=torch.int64, device=dev)
     L = native.lib()
     L.gbnf_debug_set_stamp_buffer.argtypes = [C.c_void_p]
     L.gbnf_debug_set_stamp_buffer(C.c_void_p(buf.data_ptr()))
