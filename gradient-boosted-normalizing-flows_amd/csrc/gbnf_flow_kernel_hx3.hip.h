@@ -348,7 +348,6 @@ flow_kernel_hx3(const FlowLaunch p) {
   // ---- consumer side: slot gs & 1 holds the current stage
   int cnets = 0;                 // nets consumed so far (bias buffer = cnets & 1)
   const uint32_t* buf = STG;
-  auto stage_begin = [&]() { buf = STG + (gs & 1) * STAGE_WORDS; };
   auto stage_end = [&]() {
 #ifdef GBNF_STAMPS
     const int phase_ = st.cur;
@@ -372,12 +371,26 @@ flow_kernel_hx3(const FlowLaunch p) {
   auto frag = [&](int f) -> u32x4 { return *reinterpret_cast<const u32x4*>(buf + f * 256 + lane * 4); };
 #endif
 
-  // A consumption unit = one weight tile = NP fragments.  Units of a stage are read two ahead of their use.
+  // A consumption unit = one weight tile = NP fragments.  Units of a stage are read two ahead of their use; the first
+  // two units of the NEXT stage are read right behind the stage-end barrier, in front of the last unit's MFMAs of the
+  // stage that ends (N0, N1): all waves of a workgroup leave the barrier together, and without matrix work in hand every
+  // SIMD would idle for the LDS latency at the top of every stage.
   struct Unit { u32x4 w[NP]; };
   auto load_unit = [&](Unit& a, int n) {
 #pragma unroll
     for (int q = 0; q < NP; ++q) a.w[q] = frag(n * NP + q);
   };
+  Unit N0, N1;
+  auto preload = [&]() {
+    buf = STG + (gs & 1) * STAGE_WORDS;
+    load_unit(N0, 0);
+    load_unit(N1, 1);
+  };
+  auto stage_finish = [&]() {      // call it in front of the stage's last unit (all of the stage's fragments are in registers)
+    stage_end();
+    preload();
+  };
+  preload();                       // the very first stage (landed behind the prologue's barrier)
 
   for (int step = 0; step < p.n_steps; ++step) {
     const uint32_t* __restrict__ sp = blob + (size_t)step * STEP_WORDS;
@@ -506,13 +519,12 @@ flow_kernel_hx3(const FlowLaunch p) {
         };
         auto l0_stage = [&](auto sI_c) {
           constexpr int sI = decltype(sI_c)::value;
-          stage_begin();
           issue(std::integral_constant<int, LT::value.nf[sI + 1]>{}, gs + 1);     // the next layer-0 stage or the first hidden pass
           constexpr int t0 = sI * LT::value.TL0;
           constexpr int cnt = (HT - t0 < LT::value.TL0) ? HT - t0 : LT::value.TL0;
           Unit A[3];
-          load_unit(A[0], 0);
-          if (cnt > 1) load_unit(A[1], 1);
+          A[0] = N0;
+          A[1] = N1;
           f32x4 bias = ldb(t0);
           if (sI == 0) {
 #pragma unroll
@@ -528,6 +540,7 @@ flow_kernel_hx3(const FlowLaunch p) {
             if (tl < cnt) {
               if (tl + 2 < cnt) load_unit(A[(tl + 2) % 3], tl + 2);
               const f32x4 bias_next = ldb(t + 1 < HT ? t + 1 : t);
+              if (tl == cnt - 1) stage_finish();
               Acc cur[NT];
 #pragma unroll
               for (int nt = 0; nt < NT; ++nt) cur[nt].init(bias);
@@ -553,7 +566,6 @@ flow_kernel_hx3(const FlowLaunch p) {
               __builtin_amdgcn_sched_barrier(0);
             }
           }
-          stage_end();
         };
         l0_stage(std::integral_constant<int, 0>{});
         if constexpr (LT::value.N_L0 > 1) l0_stage(std::integral_constant<int, 1>{});
@@ -582,11 +594,10 @@ flow_kernel_hx3(const FlowLaunch p) {
           constexpr int NU = HC + (PREV == 2 ? OT : 0);       // consumption units of this stage
           // the stage after this one: the drain, a pass with an output-layer chunk (after an odd pass), or a plain pass
           constexpr int NF_NEXT = LAST ? NP * OT : (PREV == 1 ? NP * (HC + OT) : NP * HC);
-          stage_begin();
           issue(std::integral_constant<int, NF_NEXT>{}, gs + 1);
           Unit A[3];
-          load_unit(A[0], 0);
-          if (NU > 1) load_unit(A[1], 1);
+          A[0] = N0;
+          A[1] = N1;
           const f32x4 bias_next = ldb(HT + (u + 1 < HT ? u + 1 : u));
           Acc acc[NT];
 #pragma unroll
@@ -595,6 +606,7 @@ flow_kernel_hx3(const FlowLaunch p) {
 #pragma unroll
           for (int n = 0; n < NU; ++n) {
             if (n + 2 < NU) load_unit(A[(n + 2) % 3], n + 2);
+            if (n == NU - 1) stage_finish();
             if (n < HC) {
               if (PREV != 0) {
                 // register pairs q = n, n + HC, ... of the previous tile (2*NT pairs in all), ahead of the region's MFMAs
@@ -617,7 +629,6 @@ flow_kernel_hx3(const FlowLaunch p) {
 #pragma unroll
           for (int nt = 0; nt < NT; ++nt) pre[nt] = acc[nt].total();
           bias = bias_next;
-          stage_end();
         };
         using I0 = std::integral_constant<int, 0>;
         using I1 = std::integral_constant<int, 1>;
@@ -645,14 +656,15 @@ flow_kernel_hx3(const FlowLaunch p) {
         st.set(4);
         // ---- drain: last tile, last output-layer chunk (HC-1); the next net's / step's first stage goes in flight
         {
-          stage_begin();
           if ((net + 1 < NNETS) || (step + 1 < p.n_steps)) {
             if (net + 1 == NNETS) next_src += SMALL_WORDS;     // the next step's tables sit in front of its first net
             issue_net_start(gs + 1);
           }
           Unit A[OT];
+          A[0] = N0;
+          if (OT > 1) A[1] = N1;
 #pragma unroll
-          for (int o = 0; o < OT; ++o) load_unit(A[o], o);
+          for (int o = 2; o < OT; ++o) load_unit(A[o], o);
           constexpr bool odd_last = ((HT - 1) & 1) != 0;
 #pragma unroll
           for (int nt = 0; nt < NT; ++nt) {
@@ -669,12 +681,14 @@ flow_kernel_hx3(const FlowLaunch p) {
             }
           }
 #pragma unroll
-          for (int o = 0; o < OT; ++o) mac(A[o], hO, out[o]);
+          for (int o = 0; o < OT; ++o) {
+            if (o == OT - 1) stage_finish();
+            mac(A[o], hO, out[o]);
+          }
 #pragma unroll
           for (int o = 0; o < OT; ++o)
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt) outF[o][nt] = out[o][nt].total();
-          stage_end();
         }
         st.mark(4);
       }
