@@ -102,6 +102,7 @@ def main(argv=None):
     args = ap.parse_args(argv)
     os.makedirs(OBJ, exist_ok=True)
     hdr = [os.path.join(HERE, "gbnf_flow_kernel.hip.h"), os.path.join(HERE, "gbnf_flow_kernel_hx3.hip.h"),
+
            os.path.join(PKG, "..", "include", "gbnf.h")]
     jobs = []
     objs = []
@@ -139,7 +140,7 @@ def main(argv=None):
     if jobs:
         print(f"[gbnf build] compiling {len(jobs)} object(s) with -j{args.j}", flush=True)
         with cf.ThreadPoolExecutor(max_workers=args.j) as ex:
-            for _ in ex.map(lambda c: compile_hx3(c) if "variant_hx3.hip" in " ".join(c) else run(c), jobs):
+            for _ in ex.map(lambda c: compile_hx3(c) if "variant_hx3" in " ".join(c) else run(c), jobs):
                 pass
     if jobs or not os.path.exists(LIB):
         run([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs)

@@ -99,7 +99,7 @@ struct FlowLaunch {
   int32_t repair;                // hx3 kernels: 1 = only workgroups owning a sample whose outputs are NaN run (the bf16x6 pass
                                  //   behind an f16x3 launch that marked out-of-range samples)
   int32_t lds_tables;            // hx3 kernels: per-step tables staged in LDS (else read from the blob), set by the launcher
-  int32_t reserved_;
+  int32_t stagger;               // hx3 kernels, 4-wave workgroups in pairs per CU: sleeps of 2048 cycles for the one in the odd wave slots
 };
 
 __device__ __forceinline__ float as_f32(uint32_t u) { return __builtin_bit_cast(float, u); }

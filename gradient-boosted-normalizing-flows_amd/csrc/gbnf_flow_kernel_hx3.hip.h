@@ -200,10 +200,10 @@ __device__ __forceinline__ void wait_vmcnt(int n) {
   else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
 }
 
-template <int KIND, int HT, int OT, int NT, int ACTA, int ACTB, int PREC>
-__global__ void __launch_bounds__(64 * hx3_waves(HT, OT, NT, PREC, KIND, ACTA, ACTB), hx3_waves_per_simd(HT, OT, NT, PREC, KIND, ACTA, ACTB))
+template <int KIND, int HT, int OT, int NT, int ACTA, int ACTB, int PREC, int WV>
+__global__ void __launch_bounds__(64 * WV, hx3_waves_per_simd(HT, OT, NT, PREC, KIND, ACTA, ACTB))
 flow_kernel_hx3(const FlowLaunch p) {
-  constexpr int WAVES = hx3_waves(HT, OT, NT, PREC, KIND, ACTA, ACTB);
+  constexpr int WAVES = WV;
   constexpr int NP = hx3_pieces(PREC);
   constexpr int NPROD = Products<NP>::N;
   using Acc = AccT<Products<NP>::NACC>;
@@ -263,6 +263,21 @@ flow_kernel_hx3(const FlowLaunch p) {
     const bool any_need = lds[0] != 0u;
     __syncthreads();             // before the word is re-used
     if (!any_need) return;
+  }
+
+  // ---- experiment knob (FlowLaunch::stagger, off by default): of two 4-wave workgroups on a CU the one in the SIMDs' odd
+  //      wave slots starts late, so that its VALU-bound stretch at every step boundary (coupling epilogue, input
+  //      preparation, layer 0: ~1/3 of a step at < 30 % matrix-pipe use, profiles/r2_timeline_f16x3_8wave.txt) could
+  //      fall into the other one's MFMA-bound hidden passes.  Measured: no gain.
+  if (p.stagger > 0) {
+    unsigned hw;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+    if (threadIdx.x == 0) lds[0] = hw & 1u;             // WAVE_ID: the wave's slot on its SIMD
+    __syncthreads();
+    const bool late = lds[0] != 0u;
+    __syncthreads();
+    if (late)
+      for (int k = 0; k < p.stagger; ++k) __builtin_amdgcn_s_sleep(32);       // 32 x 64 cycles each
   }
 
   // ---- LDS: per-step tables | 2 bias blocks | ring of stage slots | Z tiles
@@ -349,6 +364,12 @@ flow_kernel_hx3(const FlowLaunch p) {
   int cnets = 0;                 // nets consumed so far (bias buffer = cnets & 1)
   const uint32_t* buf = STG;
   auto stage_end = [&]() {
+#ifdef GBNF_TIMELINE              // diagnostic: absolute s_memtime stamps of workgroup 0 per wave and stage: [wave][stage][before wait | after barrier]
+    unsigned long long tl0_ = 0, tl1_ = 0;
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tl0_)::"memory");
+    __builtin_amdgcn_sched_barrier(0);
+#endif
 #ifdef GBNF_STAMPS
     const int phase_ = st.cur;
     st.mark(phase_);             // compute time of the stage so far -> its phase bucket
@@ -360,6 +381,15 @@ flow_kernel_hx3(const FlowLaunch p) {
 #ifdef GBNF_STAMPS
     st.mark(7);                  // bucket 7: time in the stage-end wait + barrier
     st.cur = phase_;
+#endif
+#ifdef GBNF_TIMELINE
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tl1_)::"memory");
+    __builtin_amdgcn_sched_barrier(0);
+    if (p.dbg != nullptr && blockIdx.x == 0 && lane == 0 && gs < 128) {
+      p.dbg[(wave * 128 + gs) * 2 + 0] = tl0_;
+      p.dbg[(wave * 128 + gs) * 2 + 1] = tl1_;
+    }
 #endif
     ++gs;
   };
@@ -837,6 +867,38 @@ inline size_t flow_hx3_lds_bytes(int n_steps, int nt, int waves, int stage_frags
 // hx3 variants are keyed like the f32 ones with the lmid-independent fields fixed:
 //   VariantKey{kind, ht, /*ksl*/ -3 (f16x3) | -6 (bf16x6), /*ks1*/ 0, ot, nt, /*lmid*/ 1, act_a, act_b}
 // The launcher sizes its own grid (it knows its waves per workgroup) and ring; the `grid` argument is ignored.
+// An 8-wave kernel whose register budget is 256 also exists as a 4-wave workgroup: when two of those fit a CU's LDS
+// (small d / K / hidden width) they run instead, staggered by about half a flow step (FlowLaunch::stagger).
+template <int KIND, int HT, int OT, int ENT, int ACTA, int ACTB, int PREC, int WV>
+static hipError_t hx3_launch_wv(FlowLaunch p, bool staggered, hipStream_t s) {
+  constexpr Hx3Layout L(HT, OT, hx3_pieces(PREC));
+  p.n_tiles = (int32_t)((p.n + 16 * ENT - 1) / (16 * ENT));
+  /* per-step tables in LDS when they fit beside the staging slots and the Z tiles, else read from the blob */
+  const size_t budget = staggered ? 80 * 1024 : 160 * 1024;
+  p.lds_tables = p.n_steps <= LDS_TABLE_STEPS &&
+      flow_hx3_lds_bytes(p.n_steps, ENT, WV, L.STAGE_FRAGS, L.BIAS_FRAGS, p.d, HX3_RING, true) <= budget;
+  p.ring = HX3_RING;
+  const size_t lds = flow_hx3_lds_bytes(p.n_steps, ENT, WV, L.STAGE_FRAGS, L.BIAS_FRAGS, p.d, p.ring, p.lds_tables != 0);
+  if (lds > budget) return hipErrorInvalidValue;
+  const long long grid = (long long)((p.n_tiles + WV - 1) / WV) * p.n_comp * p.n_batches;
+  if (grid > 0x7fffffffLL) return hipErrorInvalidValue;
+  if (staggered) {
+    // A start offset between the two co-resident workgroups was measured and bought nothing
+    // (profiles/r2_wg_pairs_stagger_hx32.txt): off by default; GBNF_STAGGER = sleeps of 2048 cycles for experiments
+    static const int forced = [] { const char* e = getenv("GBNF_STAGGER"); return e ? atoi(e) : 0; }();
+    p.stagger = forced;
+  }
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute((const void*)flow_kernel_hx3<KIND, HT, OT, ENT, ACTA, ACTB, PREC, WV>,
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e != hipSuccess) return e;
+    attr_set = true;
+  }
+  hipLaunchKernelGGL((flow_kernel_hx3<KIND, HT, OT, ENT, ACTA, ACTB, PREC, WV>), dim3((unsigned)grid), dim3(64 * WV), lds, s, p);
+  return hipGetLastError();
+}
+
 #define GBNF_INSTANTIATE_HX3(KIND, HT, OT, NT, ACTA, ACTB, PREC)                                            \
   namespace gbnf {                                                                                          \
   static hipError_t launch_hx3_##KIND##_##HT##_##OT##_##NT##_##ACTA##_##ACTB##_##PREC(const FlowLaunch& p0, \
@@ -844,27 +906,16 @@ inline size_t flow_hx3_lds_bytes(int n_steps, int nt, int waves, int stage_frags
     constexpr Hx3Layout L(HT, OT, hx3_pieces(PREC));                                                        \
     constexpr int ENT = hx3_eff_nt(HT, OT, NT, PREC, KIND, ACTA, ACTB);                                     \
     constexpr int WAVES = hx3_waves(HT, OT, ENT, PREC, KIND, ACTA, ACTB);                                   \
-    FlowLaunch p = p0;                                                                                      \
-    p.n_tiles = (int32_t)((p.n + 16 * ENT - 1) / (16 * ENT));                                               \
-    /* per-step tables in LDS when they fit beside the staging slots and the Z tiles, else read from the blob */ \
-    p.lds_tables = p.n_steps <= LDS_TABLE_STEPS &&                                                          \
-        flow_hx3_lds_bytes(p.n_steps, ENT, WAVES, L.STAGE_FRAGS, L.BIAS_FRAGS, p.d, HX3_RING, true) <= 160 * 1024; \
-    p.ring = HX3_RING;                                                                                      \
-    const size_t lds = flow_hx3_lds_bytes(p.n_steps, ENT, WAVES, L.STAGE_FRAGS, L.BIAS_FRAGS, p.d, p.ring,  \
-                                          p.lds_tables != 0);                                               \
-    if (lds > 160 * 1024) return hipErrorInvalidValue;                                                      \
-    const long long grid = (long long)((p.n_tiles + WAVES - 1) / WAVES) * p.n_comp * p.n_batches;           \
-    if (grid > 0x7fffffffLL) return hipErrorInvalidValue;                                                   \
-    static bool attr_set = false;                                                                           \
-    if (!attr_set) {                                                                                        \
-      hipError_t e = hipFuncSetAttribute((const void*)flow_kernel_hx3<KIND, HT, OT, ENT, ACTA, ACTB, PREC>, \
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);           \
-      if (e != hipSuccess) return e;                                                                        \
-      attr_set = true;                                                                                      \
+    if constexpr (WAVES == 8) {                                                                             \
+      static const bool no_pairs = [] { const char* e = getenv("GBNF_NO_WG_PAIRS"); return e && atoi(e) != 0; }(); \
+      /* two 4-wave workgroups per CU where they fit: 80 KB each, tables included */                        \
+      const bool fits4 = flow_hx3_lds_bytes(p0.n_steps, ENT, 4, L.STAGE_FRAGS, L.BIAS_FRAGS, p0.d, HX3_RING,  \
+                                            p0.n_steps <= LDS_TABLE_STEPS) <= 80 * 1024;                    \
+      const long long waves_total = (long long)((p0.n + 16 * ENT - 1) / (16 * ENT)) * p0.n_comp * p0.n_batches; \
+      if (fits4 && !no_pairs && !p0.repair && waves_total >= 2048)                                          \
+        return hx3_launch_wv<KIND, HT, OT, ENT, ACTA, ACTB, PREC, 4>(p0, true, s);                          \
     }                                                                                                       \
-    hipLaunchKernelGGL((flow_kernel_hx3<KIND, HT, OT, ENT, ACTA, ACTB, PREC>), dim3((unsigned)grid),        \
-                       dim3(64 * WAVES), lds, s, p);                                                        \
-    return hipGetLastError();                                                                               \
+    return hx3_launch_wv<KIND, HT, OT, ENT, ACTA, ACTB, PREC, WAVES>(p0, false, s);                         \
   }                                                                                                         \
   static const int reg_hx3_##KIND##_##HT##_##OT##_##NT##_##ACTA##_##ACTB##_##PREC =                         \
       (register_variant(VariantKey{KIND, HT, (PREC) == 0 ? -3 : -6, 0, OT, NT, 1, ACTA, ACTB},              \
