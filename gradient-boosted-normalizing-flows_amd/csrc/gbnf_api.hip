@@ -8,6 +8,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <string.h>
+#include <atomic>
 #include <mutex>
 #include <string>
 #include <vector>
@@ -113,8 +114,9 @@ unsigned* saturation_counter() {
   std::lock_guard<std::mutex> lk(g_dev_mu);
   if (g_sat_counter[dev] == nullptr) {
     unsigned* p = nullptr;
-    if (hipMalloc((void**)&p, sizeof(unsigned)) != hipSuccess) return nullptr;
-    if (hipMemset(p, 0, sizeof(unsigned)) != hipSuccess) { (void)hipFree(p); return nullptr; }
+    const size_t bytes = sizeof(unsigned) * (SAT_MARKS + SAT_SLOTS);      // counter + the launch marks of the repair protocol
+    if (hipMalloc((void**)&p, bytes) != hipSuccess) return nullptr;
+    if (hipMemset(p, 0, bytes) != hipSuccess) { (void)hipFree(p); return nullptr; }
     g_sat_counter[dev] = p;
   }
   return g_sat_counter[dev];
@@ -931,12 +933,14 @@ static int launch_flow(const gbnf_flow* f, const uint32_t* const* table, const u
   p.dbg = g_stamp_buf;
 #endif
   p.sat = saturation_counter();
+  static std::atomic<uint32_t> launch_serial{1};
+  p.seq = launch_serial.fetch_add(1, std::memory_order_relaxed);
+  if (p.seq == 0) p.seq = launch_serial.fetch_add(1, std::memory_order_relaxed);      // 0 = the memset value of the marks
   hipError_t e = launch[nt](p, (unsigned)grid, stream);
   if (e != hipSuccess) return fail(GBNF_ERR_HIP, "launch of %s failed: %s", names[nt], hipGetErrorString(e));
   if (mode == GBNF_MATH_F16X3 && table2 != nullptr && f->launch2_nt[nt] != nullptr && repair_enabled()) {
     p.blobs = table2;
-    p.repair = 1;
-    p.sat = nullptr;
+    p.repair = 1;                      // (same seq: the launch it repairs; p.sat stays: the mark is read from there)
     e = f->launch2_nt[nt](p, (unsigned)grid, stream);
     if (e != hipSuccess) return fail(GBNF_ERR_HIP, "repair launch of %s failed: %s", f->name2_nt[nt], hipGetErrorString(e));
   }

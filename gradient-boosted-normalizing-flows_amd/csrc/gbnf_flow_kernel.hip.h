@@ -100,7 +100,13 @@ struct FlowLaunch {
                                  //   behind an f16x3 launch that marked out-of-range samples)
   int32_t lds_tables;            // hx3 kernels: per-step tables staged in LDS (else read from the blob), set by the launcher
   int32_t stagger;               // hx3 kernels, 4-wave workgroups in pairs per CU: sleeps of 2048 cycles for the one in the odd wave slots
+  uint32_t seq;                  // hx3 kernels: serial number of an f16x3 launch and its repair launch: the f16x3 launch writes it to
+                                 //   sat[SAT_MARKS + seq % SAT_SLOTS] when it marks a sample, the repair launch exits at once otherwise
+  int32_t n_items;               // hx3 kernels: work items (component, batch, tile group) of the launch; a repair launch walks them
+                                 //   with a grid of at most a few workgroups per CU
 };
+constexpr int SAT_MARKS = 2;     // layout of the per-device saturation words: [0] counter, [1] unused, [2 ..] launch marks
+constexpr int SAT_SLOTS = 64;
 
 __device__ __forceinline__ float as_f32(uint32_t u) { return __builtin_bit_cast(float, u); }
 

@@ -121,8 +121,13 @@ __device__ __forceinline__ void split_pair_f16(float x0, float x1, unsigned (&p)
   const unsigned hw = __builtin_bit_cast(unsigned, h);
   p[0] = hw;
   float r0, r1;
+#ifdef GBNF_HX3_NO_FMAMIX          // diagnostic: the residual as LLVM writes it (v_cvt_f32_f16 + v_sub_f32)
+  r0 = x0 - (float)h[0];
+  r1 = x1 - (float)h[1];
+#else
   asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(r0) : "v"(hw), "v"(x0));
   asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(r1) : "v"(hw), "v"(x1));
+#endif
   const auto m = __builtin_amdgcn_cvt_pkrtz(r0, r1);
   p[1] = __builtin_bit_cast(unsigned, m);
 }
@@ -221,12 +226,22 @@ flow_kernel_hx3(const FlowLaunch p) {
   const int i = lane & 15;
   const int g = lane >> 4;
 
-  // ---- XCD-aware block -> (component, batch, group of WAVES sample tiles)
+  // ---- a repair launch that has nothing to repair ends here: the f16x3 launch it follows left no mark
+  if (p.repair && p.sat != nullptr && p.sat[SAT_MARKS + p.seq % SAT_SLOTS] != p.seq) return;
+
+  // ---- work items: (component, batch, group of WAVES sample tiles).  A normal launch has one workgroup per item; a
+  //      repair launch walks the items with a small grid and skips those without a marked sample.
   const int n_groups = (p.n_tiles + WAVES - 1) / WAVES;
+  // (only the bf16x6 kernels serve repair launches: for the f16x3 instantiations the update is the constant -1, a single pass)
+  for (int item = blockIdx.x; item >= 0;
+       item = (PREC == 1 && p.repair && item + (int)gridDim.x < p.n_items) ? item + (int)gridDim.x : -1) {
+  if (item != (int)blockIdx.x) __syncthreads();      // the previous item's LDS contents are dead
   int comp, grp, batch;
   {
-    const int total = gridDim.x;
-    const int b = blockIdx.x;
+    // XCD-aware: items are dealt round-robin over the 8 XCDs (as the hardware deals workgroups); each XCD gets a
+    // contiguous run of the component-major work list
+    const int total = p.n_items;
+    const int b = item;
     const int xcd = b & 7, j = b >> 3;
     const int base = total >> 3, rem = total & 7;
     const int q = xcd * base + (xcd < rem ? xcd : rem) + j;
@@ -242,7 +257,7 @@ flow_kernel_hx3(const FlowLaunch p) {
   const float* __restrict__ xin = p.xs[batch];
   const int64_t out_base = (int64_t)comp * p.out_stride + (int64_t)batch * p.n;
 
-  // ---- repair launch: only workgroups that own a sample marked by the f16x3 launch (NaN in its outputs) run
+  // ---- repair launch: only items that own a sample marked by the f16x3 launch (NaN in its outputs) are evaluated
   if (p.repair) {
     bool need = false;
     if (lane < 16 * NT) {
@@ -262,7 +277,7 @@ flow_kernel_hx3(const FlowLaunch p) {
     __syncthreads();
     const bool any_need = lds[0] != 0u;
     __syncthreads();             // before the word is re-used
-    if (!any_need) return;
+    if (!any_need) continue;
   }
 
   // ---- experiment knob (FlowLaunch::stagger, off by default): of two 4-wave workgroups on a CU the one in the SIMDs' odd
@@ -416,7 +431,31 @@ flow_kernel_hx3(const FlowLaunch p) {
     load_unit(N0, 0);
     load_unit(N1, 1);
   };
-  auto stage_finish = [&]() {      // call it in front of the stage's last unit (all of the stage's fragments are in registers)
+  // The last unit of a pipelined stage runs behind the stage-end barrier and nothing reads its accumulators before the
+  // next stage's address arithmetic and staging instructions.  hipcc (VGPR-form MFMA, vDst != srcC) hands the registers
+  // the chain's last v_mfma still reads as source C to the first VALU result behind it, 7 wait states later.  That is
+  // not enough when the v_mfma is held up behind the one it depends on while a second wave of the workgroup, released by
+  // the same barrier, feeds the same SIMD's matrix pipe: the accumulator picks up the VALU result.  Seen on fixture
+  // g5_glow_d63_h128_c2 (8-wave workgroups, 12 MFMAs per stage): whole 16-sample tiles off by 5e-2, the set of tiles
+  // changing from launch to launch; 1 extra wait state does not cure it, 4 do, a late fragment read or a pause does, an
+  // extra barrier or a pause in front of the fragment reads does not (round 2, tools/ history).  Eight idle wait states
+  // behind the last unit close the window for every stage kind that ends early.
+  auto mfma_tail_guard = [&]() {
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_nop 7" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+  };
+#ifndef GBNF_HX3_PIPE_MASK
+#define GBNF_HX3_PIPE_MASK 7        // diagnostic: which stage kinds end early (1 layer-0 stages, 2 passes, 4 drain)
+#endif
+  // kind: 1 layer-0 stage, 2 pass, 4 drain.  `early`: in front of the stage's last unit (all of the stage's fragments
+  // are in registers); `late`: behind it (the stage kinds that are not pipelined)
+  auto stage_finish = [&](int kind, bool early) {
+    const bool pipelined = (GBNF_HX3_PIPE_MASK & kind) != 0;
+    if (pipelined != early) {
+      if (pipelined && !early) mfma_tail_guard();
+      return;
+    }
     stage_end();
     preload();
   };
@@ -570,7 +609,7 @@ flow_kernel_hx3(const FlowLaunch p) {
             if (tl < cnt) {
               if (tl + 2 < cnt) load_unit(A[(tl + 2) % 3], tl + 2);
               const f32x4 bias_next = ldb(t + 1 < HT ? t + 1 : t);
-              if (tl == cnt - 1) stage_finish();
+              if (tl == cnt - 1) stage_finish(1, true);
               Acc cur[NT];
 #pragma unroll
               for (int nt = 0; nt < NT; ++nt) cur[nt].init(bias);
@@ -596,6 +635,7 @@ flow_kernel_hx3(const FlowLaunch p) {
               __builtin_amdgcn_sched_barrier(0);
             }
           }
+          stage_finish(1, false);
         };
         l0_stage(std::integral_constant<int, 0>{});
         if constexpr (LT::value.N_L0 > 1) l0_stage(std::integral_constant<int, 1>{});
@@ -636,7 +676,7 @@ flow_kernel_hx3(const FlowLaunch p) {
 #pragma unroll
           for (int n = 0; n < NU; ++n) {
             if (n + 2 < NU) load_unit(A[(n + 2) % 3], n + 2);
-            if (n == NU - 1) stage_finish();
+            if (n == NU - 1) stage_finish(2, true);
             if (n < HC) {
               if (PREV != 0) {
                 // register pairs q = n, n + HC, ... of the previous tile (2*NT pairs in all), ahead of the region's MFMAs
@@ -659,6 +699,7 @@ flow_kernel_hx3(const FlowLaunch p) {
 #pragma unroll
           for (int nt = 0; nt < NT; ++nt) pre[nt] = acc[nt].total();
           bias = bias_next;
+          stage_finish(2, false);
         };
         using I0 = std::integral_constant<int, 0>;
         using I1 = std::integral_constant<int, 1>;
@@ -712,13 +753,14 @@ flow_kernel_hx3(const FlowLaunch p) {
           }
 #pragma unroll
           for (int o = 0; o < OT; ++o) {
-            if (o == OT - 1) stage_finish();
+            if (o == OT - 1) stage_finish(4, true);
             mac(A[o], hO, out[o]);
           }
 #pragma unroll
           for (int o = 0; o < OT; ++o)
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt) outF[o][nt] = out[o][nt].total();
+          stage_finish(4, false);
         }
         st.mark(4);
       }
@@ -837,7 +879,10 @@ flow_kernel_hx3(const FlowLaunch p) {
       if (p.ll_out) p.ll_out[out_base + n] = bad ? nanv : (q - 0.91893853320467274f * (float)d) + ldj;
     }
   }
-  if (WATCH && p.sat != nullptr && any_sat && lane == 0) atomicAdd(p.sat, 1u);
+  if (WATCH && p.sat != nullptr && any_sat && lane == 0) {
+    atomicAdd(p.sat, 1u);
+    p.sat[SAT_MARKS + p.seq % SAT_SLOTS] = p.seq;      // tells the repair launch behind this one that it has work
+  }
   if (p.z_out != nullptr && lane < d) {
     const int slot = (int)tail[lane];
     float* zo = p.z_out + (int64_t)comp * p.n * d;
@@ -856,6 +901,7 @@ flow_kernel_hx3(const FlowLaunch p) {
     for (int k = 0; k < 8; ++k) p.dbg[((size_t)blockIdx.x * WAVES + wave) * 8 + k] = st.acc[k];
   }
 #endif
+  }    // work items
 }
 
 // LDS bytes of a launch with `ring` stage slots.
@@ -880,8 +926,10 @@ static hipError_t hx3_launch_wv(FlowLaunch p, bool staggered, hipStream_t s) {
   p.ring = HX3_RING;
   const size_t lds = flow_hx3_lds_bytes(p.n_steps, ENT, WV, L.STAGE_FRAGS, L.BIAS_FRAGS, p.d, p.ring, p.lds_tables != 0);
   if (lds > budget) return hipErrorInvalidValue;
-  const long long grid = (long long)((p.n_tiles + WV - 1) / WV) * p.n_comp * p.n_batches;
+  long long grid = (long long)((p.n_tiles + WV - 1) / WV) * p.n_comp * p.n_batches;
   if (grid > 0x7fffffffLL) return hipErrorInvalidValue;
+  p.n_items = (int32_t)grid;
+  if (p.repair && grid > 512) grid = 512;           // a repair launch walks the items: one or two workgroups per CU
   if (staggered) {
     // A start offset between the two co-resident workgroups was measured and bought nothing
     // (profiles/r2_wg_pairs_stagger_hx32.txt): off by default; GBNF_STAGGER = sleeps of 2048 cycles for experiments
