@@ -431,15 +431,18 @@ flow_kernel_hx3(const FlowLaunch p) {
     load_unit(N0, 0);
     load_unit(N1, 1);
   };
-  // The last unit of a pipelined stage runs behind the stage-end barrier and nothing reads its accumulators before the
-  // next stage's address arithmetic and staging instructions.  hipcc (VGPR-form MFMA, vDst != srcC) hands the registers
-  // the chain's last v_mfma still reads as source C to the first VALU result behind it, 7 wait states later.  That is
-  // not enough when the v_mfma is held up behind the one it depends on while a second wave of the workgroup, released by
-  // the same barrier, feeds the same SIMD's matrix pipe: the accumulator picks up the VALU result.  Seen on fixture
-  // g5_glow_d63_h128_c2 (8-wave workgroups, 12 MFMAs per stage): whole 16-sample tiles off by 5e-2, the set of tiles
-  // changing from launch to launch; 1 extra wait state does not cure it, 4 do, a late fragment read or a pause does, an
-  // extra barrier or a pause in front of the fragment reads does not (round 2, tools/ history).  Eight idle wait states
-  // behind the last unit close the window for every stage kind that ends early.
+  // MFMA-tail guard.  The last unit of a stage that ended early runs behind the stage-end barrier; its last v_mfma is
+  // followed directly by the next stage's address arithmetic and staging DMA (hipcc reuses the chain's dead source-C
+  // registers for the DMA address, 7 wait states behind the v_mfma).  In that shape the 8-wave d=63 h=128 variant
+  // (12 MFMAs per stage, DMA-latency bound) returned whole 16-sample tiles off by 5e-2, another set of tiles on every
+  // launch (fixture g5_glow_d63_h128_c2).  Bisect on the GPU (profiles/r2_stage_boundary_bisect.txt): ending passes
+  // late cures it, so do 4-wave workgroups, fragment reads or a pause BEHIND the last unit, and 4 idle wait states
+  // there; 1 idle wait state, an extra barrier, a pause or an lgkmcnt(0) in FRONT of the last unit do not.  The weight
+  // fragments the waves consumed were identical in good and bad runs, so it is not a staging race.  The isolated
+  // sequences (dead-register overwrite, the 64-bit address add, the whole m0 / add / DMA / ds_read tail behind a dependent
+  // untied v_mfma chain: tools/ubench/mfma_tail_hazard.hip) are all handled correctly by the hardware at 0 wait states,
+  // with one and with two waves per SIMD, so the mechanism is NOT pinned down; the guard below is empirical: eight idle
+  // wait states behind the last unit of every stage kind that ends early (twice the measured need; no measurable cost).
   auto mfma_tail_guard = [&]() {
     __builtin_amdgcn_sched_barrier(0);
     asm volatile("s_nop 7" ::: "memory");
