@@ -33,8 +33,12 @@ def read_variants():
                     for prec in (0, 1):
                         out.append(("hx3", kind, ht, ot, nt, acta, actb, prec))
                 continue
-            kind, ht, ksl, ks1, ot, lmid, acta, actb = (int(v) for v in line.split())
-            for nt in (1, 2):
+            toks = line.split()
+            nts = (1, 2)
+            if toks[-1] == "nt1":          # 16-sample waves only (the 32-sample form of the widest geometries spills)
+                nts, toks = (1,), toks[:-1]
+            kind, ht, ksl, ks1, ot, lmid, acta, actb = (int(v) for v in toks)
+            for nt in nts:
                 out.append((kind, ht, ksl, ks1, ot, nt, lmid, acta, actb))
     return sorted(set(out), key=str)
 

@@ -548,17 +548,17 @@ static bool choose_f32(int kind, int ht, int ksl, int ks1, int ot, int depth, in
     // multiply zero padding, so any superset is exact (just slower)
     const bool covers_h = (k.ht > ht) || (k.ht == ht && k.ksl >= ksl);
     if (!covers_h) continue;
-    // both NT=1 and NT=2 of the same geometry must exist
+    // NT=1 must exist; a geometry built for 16-sample waves only (`nt1` in variants.list) has no NT=2 entry
     const Variant* v1 = find_variant(VariantKey{k.kind, k.ht, k.ksl, k.ks1, k.ot, 1, k.lmid, k.act_a, k.act_b});
     const Variant* v2 = find_variant(VariantKey{k.kind, k.ht, k.ksl, k.ks1, k.ot, 2, k.lmid, k.act_a, k.act_b});
-    if (!v1 || !v2) continue;
+    if (!v1) continue;
     const long cost = (long)(4 * (k.ht - 1) + k.ksl) * (k.ht * 16L * depth + k.ot * 16L) + k.ht * 16L * 4 * k.ks1;
     if (best_cost < 0 || cost < best_cost) {
       best_cost = cost;
       vc->hx3 = false; vc->np = 0;
       vc->ht = k.ht; vc->ksl = k.ksl; vc->ks1 = k.ks1; vc->ot = k.ot;
       vc->launch_nt[1] = v1->fn; vc->name_nt[1] = v1->name;
-      vc->launch_nt[2] = v2->fn; vc->name_nt[2] = v2->name;
+      vc->launch_nt[2] = v2 ? v2->fn : nullptr; vc->name_nt[2] = v2 ? v2->name : nullptr;
     }
   }
   return best_cost >= 0;
@@ -916,7 +916,8 @@ static int launch_flow(const gbnf_flow* f, const uint32_t* const* table, const u
   const int mode = use_second ? GBNF_MATH_BF16X6 : f->math_mode;
   const LaunchFn* launch = use_second ? f->launch2_nt : f->launch_nt;
   const char* const* names = use_second ? f->name2_nt : f->name_nt;
-  const int nt = pick_nt(n * n_batches, n_comp);
+  int nt = pick_nt(n * n_batches, n_comp);
+  if (launch[nt] == nullptr) nt = 1;                // geometry compiled for 16-sample waves only
   const int64_t tiles = (n + 16 * nt - 1) / (16 * nt);
   // f32 kernel: one wave (= block) per tile; the split kernels size their own grid
   const int64_t grid = tiles * n_comp * n_batches;

@@ -301,7 +301,7 @@ flow_kernel_hx3(const FlowLaunch p) {
   uint32_t* SM = lds;
   uint32_t* BIAS = lds + (lds_tables ? p.n_steps * SMALL_WORDS : 0);
   uint32_t* STG = BIAS + 2 * LT::value.BIAS_WORDS;
-  float* Z = reinterpret_cast<float*>(STG + ring * STAGE_WORDS) + wave * (d * ZS);   // wave-private, d slots
+  float* Z = reinterpret_cast<float*>(STG + ring * STAGE_WORDS) + wave * ((d + 1) * ZS);   // wave-private: d feature slots + a spare one (writes of dead table entries)
 
   // ---- weight staging, one stage ahead into the other of two slots.  The blob is laid out in consumption order, so
   //      "the next stage" is a running pointer; every call site knows the next stage's fragment count at compile time.
@@ -489,7 +489,7 @@ flow_kernel_hx3(const FlowLaunch p) {
         for (int e = 0; e < NENT; ++e) {
           const bool live = tin.slot[e] >= 0;
           const float t = norm_fn<KIND>(v[nt][e], tin.p0[e], tin.p1[e], tin.p2[e], tin.p3[e]);
-          if (live) Z[tin.slot[e] * ZS + i + 16 * nt] = t;
+          Z[(live ? tin.slot[e] : d) * ZS + i + 16 * nt] = t;         // dead entries go to the spare slot d: no exec masking
           if constexpr (WATCH) {
             sat[nt] = sat[nt] || (live && !(__builtin_fabsf(t) <= 65504.0f));
             v[nt][e] = live ? __builtin_amdgcn_fmed3f(t, -65504.0f, 65504.0f) : 0.0f;
@@ -797,10 +797,8 @@ flow_kernel_hx3(const FlowLaunch p) {
             float sc, lsc;
             sigmoid_logsigmoid(raw + 2.0f, sc, lsc);
             t = (t + shift) * sc;
-            if (live) {
-              Z[tout.slot[e] * ZS + i + 16 * nt] = t;
-              ld[nt] += lsc;
-            }
+            Z[(live ? tout.slot[e] : d) * ZS + i + 16 * nt] = t;
+            ld[nt] += live ? lsc : 0.0f;
           }
         }
       } else {
@@ -819,14 +817,12 @@ flow_kernel_hx3(const FlowLaunch p) {
             float t = norm_fn<KIND>(v[nt][e], tout.p0[e], tout.p1[e], tout.p2[e], tout.p3[e]);
             if constexpr (KIND == GBNF_KIND_GLOW) {
               t = t + outA[o][nt][r];
-              if (live) Z[tout.slot[e] * ZS + i + 16 * nt] = t;
+              Z[(live ? tout.slot[e] : d) * ZS + i + 16 * nt] = t;
             } else {
               const float shift = outA[o][nt][r], scale = outB[o][nt][r];
               t = shift + t * exp_fast(scale);
-              if (live) {
-                Z[tout.slot[e] * ZS + i + 16 * nt] = t;
-                ld[nt] += scale;
-              }
+              Z[(live ? tout.slot[e] : d) * ZS + i + 16 * nt] = t;
+              ld[nt] += live ? scale : 0.0f;
             }
           }
         }
@@ -911,7 +907,7 @@ flow_kernel_hx3(const FlowLaunch p) {
 inline size_t flow_hx3_lds_bytes(int n_steps, int nt, int waves, int stage_frags, int bias_frags, int d, int ring,
                                  bool lds_tables) {
   const size_t tables = lds_tables ? (size_t)n_steps * SMALL_WORDS : 0;
-  return (tables + 2 * (size_t)bias_frags * 256 + (size_t)ring * stage_frags * 256 + (size_t)waves * d * (16 * nt + 1)) * 4;
+  return (tables + 2 * (size_t)bias_frags * 256 + (size_t)ring * stage_frags * 256 + (size_t)waves * (d + 1) * (16 * nt + 1)) * 4;
 }
 // hx3 variants are keyed like the f32 ones with the lmid-independent fields fixed:
 //   VariantKey{kind, ht, /*ksl*/ -3 (f16x3) | -6 (bf16x6), /*ks1*/ 0, ot, nt, /*lmid*/ 1, act_a, act_b}

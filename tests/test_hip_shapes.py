@@ -51,3 +51,42 @@ def test_random_shape_against_oracle(kind, d, h, K, n, act, extra, seed):
         # ldj is a part of ll: judged on ll's scale
         assert float(np.max(np.abs(ldj.cpu().numpy() - lr) / np.maximum(np.abs(llr), 1.0))) < LL_RTOL, math
         np.testing.assert_allclose(z.cpu().numpy(), zr, rtol=0, atol=2e-5 * max(1.0, np.abs(zr).max()), err_msg=math)
+
+
+# 256 < h <= 512 beyond depth 1: the reference's CLI reaches these with --h_size_factor on MINIBOONE / BSDS300
+# (utils/load_data.py:64-65) together with --coupling_network_depth 0 / 2 or --coupling_network residual
+# (models/layers.py:208-301).  They run on the 32-tile exact-f32 variants (16-sample waves).
+WIDE_CASES = [
+    ("glow", 43, 430, 0, "tanh", dict(coupling="affine", permutation="shuffle")),
+    ("glow", 43, 430, 2, "tanh", dict(coupling="affine", permutation="shuffle")),
+    ("glow", 63, 315, 2, "relu", dict(coupling="additive", permutation="reverse")),
+    ("glow", 13, 300, 0, "random", dict(coupling="affine", permutation="shuffle")),
+    ("realnvp", 43, 385, 2, "random", dict(batch_norm=False)),
+    ("realnvp", 21, 400, 0, "mixed", dict(batch_norm=True)),
+    ("realnvp", 43, 430, 1, "residual", dict(batch_norm=True)),
+    ("realnvp", 8, 500, 2, "residual", dict(batch_norm=False)),
+]
+
+
+@pytest.mark.parametrize("kind,d,h,depth,act,extra", WIDE_CASES)
+def test_wide_hidden_layers_beyond_depth_one(kind, d, h, depth, act, extra):
+    import torch
+    from gbnf_amd import native, synth
+    from oracle import gbnf_oracle as oracle
+    dev = torch.device("cuda:0")
+    if kind == "glow":
+        spec = synth.synth_glow_spec(d, h, 3, depth=depth, act=act, seed=900 + h, **extra)
+    else:
+        spec = synth.synth_realnvp_spec(d, h, 3, depth=depth, coupling_network=act, seed=900 + h, **extra)
+    x = synth.synth_batch(100, d, seed=h)
+    zr, lr = oracle.component_forward(spec, x)
+    llr = oracle.component_log_prob(spec, x)
+    flow = native.NativeFlow(spec)                      # default mode: lands on the exact-f32 kernel here
+    assert flow.info().math_mode == native.MATH["f32"]
+    z, ldj, ll = flow.forward(torch.from_numpy(x).to(dev), want_ll=True)
+    assert rel_err(ll.cpu().numpy(), llr) < LL_RTOL
+    assert float(np.max(np.abs(ldj.cpu().numpy() - lr) / np.maximum(np.abs(llr), 1.0))) < LL_RTOL
+    np.testing.assert_allclose(z.cpu().numpy(), zr, rtol=0, atol=2e-5 * max(1.0, np.abs(zr).max()))
+    # and back: the z -> x direction runs on the same variants
+    xb, ldj_inv = flow.inverse(z)
+    np.testing.assert_allclose(xb.cpu().numpy(), x, rtol=0, atol=1e-4 * max(1.0, np.abs(x).max()))
