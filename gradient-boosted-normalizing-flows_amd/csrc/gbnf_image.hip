@@ -42,7 +42,9 @@ constexpr int IMG_WAVES = 4;
 constexpr int IMG_PD = 4;         // weight-prefetch distance (iterations of 4 k-steps)
 constexpr int IMG_MAX_PT = 4;     // pixel tiles of 16 per strip (IMG_R * W / 16, W <= 16)
 
-enum { EPI_RELU = 0, EPI_STORE = 1, EPI_COUPLE_AFFINE = 2, EPI_COUPLE_ADD = 3, EPI_SPLIT = 4 };
+enum { EPI_RELU = 0, EPI_STORE = 1, EPI_COUPLE_AFFINE = 2, EPI_COUPLE_ADD = 3, EPI_SPLIT = 4,
+       // the z -> x direction (gbnf_image_flow_inverse): coupling^-1 and Split2d's re-draw of the half it dropped
+       EPI_COUPLE_AFFINE_INV = 5, EPI_COUPLE_ADD_INV = 6, EPI_SPLIT_INV = 7 };
 
 struct ConvLaunch {
   const float* in;        // (n, *, H, W): first input channel of image 0
@@ -55,6 +57,7 @@ struct ConvLaunch {
   int64_t st_img;
   float* ldj;             // (n,) accumulated with atomics (EPI_COUPLE_AFFINE / EPI_SPLIT)
   int cin, cout, H, W, ks, n_strips;
+  float temperature;      // EPI_SPLIT_INV: z2 = mean + exp(log-var) * temperature * eps (models/layers.py:697)
   int o_split;            // workgroups sharing one strip, each with 1/o_split of the output tiles (fills the chip at small batch)
   // fused producer (1x1 convolutions only): the input of this convolution is relu(conv3x3(pre_in) + pre_bias), computed
   // for the strip straight into LDS instead of being read from `in` (the ConvNet's first layer never touches HBM)
@@ -256,12 +259,13 @@ __global__ void __launch_bounds__(64 * IMG_WAVES) img_conv_kernel(const ConvLaun
         if (EPI == EPI_RELU) v = fmaxf(v, 0.0f);
         if (co < p.cout && in_img) out[(int64_t)co * H * W + pix] = v;
       }
-    } else if constexpr (EPI == EPI_COUPLE_ADD) {
+    } else if constexpr (EPI == EPI_COUPLE_ADD || EPI == EPI_COUPLE_ADD_INV) {
       float* st = p.st + (int64_t)n * p.st_img;
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int co = 16 * o + 4 * g + r;
-        if (co < p.cout && in_img) st[(int64_t)co * H * W + pix] += acc[r] + bias[co];   // models/glow.py:328-329
+        const float h = acc[r] + bias[co];
+        if (co < p.cout && in_img) st[(int64_t)co * H * W + pix] += (EPI == EPI_COUPLE_ADD) ? h : -h;   // models/glow.py:328-329, :349-350
       }
     } else {
       // "cross" rows: (2j, 2j+1) = (shift_j, raw_j) for the coupling, (mean_j, log-var_j) for the Split2d prior
@@ -278,6 +282,11 @@ __global__ void __launch_bounds__(64 * IMG_WAVES) img_conv_kernel(const ConvLaun
             const float sc = 1.0f / (1.0f + e);
             *zp = (z2 + h0) * sc;                                   // models/glow.py:334-335
             ld += -log1pf(e);                                       // log(scale), models/glow.py:338
+          } else if constexpr (EPI == EPI_COUPLE_AFFINE_INV) {
+            const float e = __expf(-(h1 + 2.0f));                   // models/glow.py:352-355: z2 / scale - shift
+            *zp = z2 * (1.0f + e) - h0;
+          } else if constexpr (EPI == EPI_SPLIT_INV) {              // models/layers.py:695-699: the slot holds eps on entry
+            *zp = h0 + __expf(h1) * p.temperature * z2;
           } else {                                                  // Split2d: log_normal_diag(z2; mean, log-var)
             const float dlt = z2 - h0;
             ld += -0.5f * (h1 + dlt * dlt * __expf(-h1));           // utils/distributions.py:14, models/layers.py:703
@@ -382,6 +391,38 @@ __global__ void __launch_bounds__(256) img_squeeze_kernel(const float* __restric
   }
 }
 
+// unsqueeze2d (utils/utilities.py:121-135) of (n, 4C, H/2, W/2) into the first C channels of (n, Ctot, H, W); the next
+// `C_eps` channels are filled from eps (n, C_eps, H, W) (the standard-normal draws Split2d's reverse scales in place)
+__global__ void __launch_bounds__(256) img_unsqueeze_kernel(const float* __restrict__ in, float* __restrict__ out, int64_t out_img, int C, int H,
+                                                            int W, const float* __restrict__ eps, int C_eps) {
+  const int n = blockIdx.x, chw = C * H * W;
+  const float* xi = in + (int64_t)n * chw;
+  float* oi = out + (int64_t)n * out_img;
+  for (int e = threadIdx.x; e < chw; e += 256) {
+    const int c = e / (H * W), rem = e % (H * W), y = rem / W, xx = rem % W;
+    const int ic = c * 4 + (y & 1) * 2 + (xx & 1);
+    oi[e] = xi[((int64_t)ic * (H / 2) + (y >> 1)) * (W / 2) + (xx >> 1)];
+  }
+  if (eps != nullptr) {
+    const int ehw = C_eps * H * W;
+    for (int e = threadIdx.x; e < ehw; e += 256) oi[chw + e] = eps[(int64_t)n * ehw + e];
+  }
+}
+
+// the last unsqueeze + to_logits(reverse=True) (models/glow.py:151-158): (n, 4C, H/2, W/2) logits -> x (n, C, H, W)
+__global__ void __launch_bounds__(256) img_post_kernel(const float* __restrict__ in, float* __restrict__ x, int C, int H, int W, float bounds) {
+  const int n = blockIdx.x, chw = C * H * W;
+  const float* xi = in + (int64_t)n * chw;
+  float* oi = x + (int64_t)n * chw;
+  for (int e = threadIdx.x; e < chw; e += 256) {
+    const int c = e / (H * W), rem = e % (H * W), y = rem / W, xx = rem % W;
+    const int ic = c * 4 + (y & 1) * 2 + (xx & 1);
+    const float v = xi[((int64_t)ic * (H / 2) + (y >> 1)) * (W / 2) + (xx >> 1)];
+    const float sg = 1.0f / (__expf(-v) + 1.0f);
+    oi[e] = ((sg * 2.0f - 1.0f) / bounds + 1.0f) * 0.5f;
+  }
+}
+
 // ll[n] = sum -0.5 (log-var + (z - mean)^2 exp(-log-var)) + ldj[n]  with per-channel prior constants (Glow.prior on zeros:
 // Conv2dZeros(0) = bias * exp(3 logs), models/glow.py:62-84); optional copies of z / mean / log-var.
 __global__ void __launch_bounds__(256) img_final_kernel(const float* __restrict__ z, int64_t z_img, const float* __restrict__ prior /* [2C] */,
@@ -434,6 +475,7 @@ struct gbnf_image_flow {
   double ld_const = 0;                       // dequantisation + every ActNorm2d / invconv log-det (per image)
   std::vector<int> level_steps;              // FlowSteps per level
   std::vector<PackedConv> mix, split;        // [sum steps] / [L-1]
+  std::vector<PackedConv> mix_inv;           // [sum steps]: (invconv / Permute2d)^-1 then ActNorm2d reverse, as one C x C matrix
   std::vector<std::vector<PackedConv>> net;  // [L*K][depth + 2]
   size_t prior_off = 0;                      // [2 Cz] top prior (mean, log-var per channel)
   float* blob_dev = nullptr;
@@ -560,6 +602,30 @@ double logabsdet(std::vector<double> a, int n) {
     }
   }
   return acc;
+}
+
+// A^-1 of an n x n matrix (double, Gauss-Jordan with partial pivoting); false if singular
+bool invert(std::vector<double> a, int n, std::vector<double>* out) {
+  std::vector<double>& b = *out;
+  b.assign((size_t)n * n, 0.0);
+  for (int k = 0; k < n; ++k) b[(size_t)k * n + k] = 1.0;
+  for (int k = 0; k < n; ++k) {
+    int piv = k;
+    for (int r = k + 1; r < n; ++r)
+      if (std::fabs(a[r * n + k]) > std::fabs(a[piv * n + k])) piv = r;
+    if (a[piv * n + k] == 0.0) return false;
+    if (piv != k)
+      for (int c = 0; c < n; ++c) { std::swap(a[k * n + c], a[piv * n + c]); std::swap(b[k * n + c], b[piv * n + c]); }
+    const double d = 1.0 / a[k * n + k];
+    for (int c = 0; c < n; ++c) { a[k * n + c] *= d; b[k * n + c] *= d; }
+    for (int r = 0; r < n; ++r) {
+      if (r == k) continue;
+      const double f = a[r * n + k];
+      if (f == 0.0) continue;
+      for (int c = 0; c < n; ++c) { a[r * n + c] -= f * a[k * n + c]; b[r * n + c] -= f * b[k * n + c]; }
+    }
+  }
+  return true;
 }
 
 int check_conv(const gbnf_conv& c, int cin, int cout, int ks, bool want_an, bool want_zeros, const char* what) {
@@ -698,6 +764,19 @@ int gbnf_image_flow_create(const gbnf_image_flow_desc* d, gbnf_image_flow** out)
       }
       for (int m = 0; m < C; ++m) ld_const += (double)st.actnorm_logs[m] * H * W;      // models/layers.py:506-508
       f->mix.push_back(P.add(weff.data(), C, C, 1, ones, beff));
+      {
+        // the way back (FlowStep.decode, models/glow.py:360-364): x = exp(-logs) * (W^-1 y) - bias
+        std::vector<double> winv;
+        if (!invert(wperm, C, &winv)) { rc = fail(GBNF_ERR_INVALID, "level %d step %d: singular 1x1 convolution", l, k); break; }
+        std::vector<float> wi((size_t)C * C);
+        std::vector<double> rs(C), bi(C);
+        for (int m = 0; m < C; ++m) {
+          rs[m] = std::exp(-(double)st.actnorm_logs[m]);
+          bi[m] = -(double)st.actnorm_bias[m];
+          for (int j = 0; j < C; ++j) wi[(size_t)m * C + j] = (float)winv[(size_t)m * C + j];
+        }
+        f->mix_inv.push_back(P.add(wi.data(), C, C, 1, rs, bi));
+      }
       // ConvNet: Conv2d 3x3 (+ActNorm2d), [Conv2d 1x1 (+ActNorm2d)] x depth, Conv2dZeros 3x3
       if (st.n_convs < 2 || st.n_convs > 5 || !st.convs) { rc = fail(GBNF_ERR_INVALID, "level %d step %d: needs 2..5 convolutions", l, k); break; }
       const int hdim = st.convs[0].out_channels;
@@ -758,6 +837,9 @@ int gbnf_image_flow_create(const gbnf_image_flow_desc* d, gbnf_image_flow** out)
     if (e == hipSuccess) e = allow_lds<EPI_COUPLE_AFFINE>();
     if (e == hipSuccess) e = allow_lds<EPI_COUPLE_ADD>();
     if (e == hipSuccess) e = allow_lds<EPI_SPLIT>();
+    if (e == hipSuccess) e = allow_lds<EPI_COUPLE_AFFINE_INV>();
+    if (e == hipSuccess) e = allow_lds<EPI_COUPLE_ADD_INV>();
+    if (e == hipSuccess) e = allow_lds<EPI_SPLIT_INV>();
     {
       const void* fns[10] = {(const void*)img_mid_hx3_kernel<4, 2>, (const void*)img_mid_hx3_kernel<4, 4>,
                              (const void*)img_mid_hx3_kernel<4, 5>, (const void*)img_mid_hx3_kernel<2, 2>,
@@ -928,6 +1010,114 @@ int gbnf_image_flow_forward(const gbnf_image_flow* f, const float* x, const floa
                      blob + f->prior_off, (const float*)ldj, ll, z, C, H * W);
   const hipError_t e = hipGetLastError();
   if (e != hipSuccess) return fail(GBNF_ERR_HIP, "gbnf_image_flow_forward: %s", hipGetErrorString(e));
+  return GBNF_OK;
+}
+
+int gbnf_image_flow_eps_floats(const gbnf_image_flow* f, int64_t* per_image) {
+  if (!f || !per_image) return fail(GBNF_ERR_INVALID, "gbnf_image_flow_eps_floats: null argument");
+  *per_image = (int64_t)f->C * f->H * f->W - (int64_t)f->zC * f->zH * f->zW;
+  return GBNF_OK;
+}
+
+int gbnf_image_flow_inverse(const gbnf_image_flow* f, const float* z, const float* eps, float temperature, int64_t n, float* x,
+                            void* workspace, int64_t workspace_bytes, void* stream) {
+  if (!f) return fail(GBNF_ERR_INVALID, "gbnf_image_flow_inverse: flow is null");
+  if (n < 0) return fail(GBNF_ERR_INVALID, "gbnf_image_flow_inverse: n < 0");
+  if (n == 0) return GBNF_OK;
+  if (!z || !x || !workspace) return fail(GBNF_ERR_INVALID, "gbnf_image_flow_inverse: z / x / workspace is null");
+  if (f->L > 1 && !eps) return fail(GBNF_ERR_INVALID, "gbnf_image_flow_inverse: %d Split2d level(s) need eps", f->L - 1);
+  int64_t need = 0;
+  gbnf_image_flow_workspace_bytes(f, n, &need);
+  if (workspace_bytes < need) return fail(GBNF_ERR_INVALID, "gbnf_image_flow_inverse: workspace of %lld bytes < %lld", (long long)workspace_bytes, (long long)need);
+  hipStream_t s = (hipStream_t)stream;
+  const int64_t chw = (int64_t)f->C * f->H * f->W;
+  const int64_t hid = (int64_t)f->chp * (f->H / 2) * (f->W / 2);
+  float* SA = (float*)workspace;
+  float* SB = SA + chw * n;
+  float* H1 = SB + chw * n;
+  float* H2 = H1 + hid * n;
+  const float* blob = f->blob_dev;
+
+  // level shapes on the way in, and where each Split2d level's eps starts (level 0 first, each (n, C_l/2, H_l, W_l))
+  std::vector<int> LC(f->L), LH(f->L), LW(f->L);
+  std::vector<int64_t> eps_off(f->L, 0);
+  {
+    int C = f->C, H = f->H, W = f->W;
+    int64_t off = 0;
+    for (int l = 0; l < f->L; ++l) {
+      C *= 4; H /= 2; W /= 2;
+      LC[l] = C; LH[l] = H; LW[l] = W;
+      if (l < f->L - 1) {
+        eps_off[l] = off;
+        off += (int64_t)(C / 2) * H * W * n;
+        C /= 2;
+      }
+    }
+  }
+  size_t step_end = 0;
+  for (int l = 0; l < f->L; ++l) step_end += f->level_steps[l];
+
+  float* cur = SA;
+  float* oth = SB;
+  (void)hipMemcpyAsync(cur, z, (size_t)n * f->zC * f->zH * f->zW * 4, hipMemcpyDeviceToDevice, s);
+  for (int l = f->L - 1; l >= 0; --l) {
+    const int C = LC[l], H = LH[l], W = LW[l];
+    const int64_t img = (int64_t)C * H * W;
+    const int n_strips = H / IMG_R;
+    const int c1 = C / 2;
+    const int K = f->level_steps[l];
+    if (l < f->L - 1) {
+      // the state of level l+1 (n, 4 c1, H/2, W/2) -> first c1 channels of this level; eps into the other half; Split2d reverse
+      hipLaunchKernelGGL(img_unsqueeze_kernel, dim3((unsigned)n), dim3(256), 0, s, (const float*)cur, oth, img, c1, H, W,
+                         eps + eps_off[l], C - c1);
+      std::swap(cur, oth);
+      ConvLaunch p{};
+      const PackedConv& c = f->split[l];
+      p.H = H; p.W = W; p.n_strips = n_strips; p.ldj = nullptr; p.temperature = temperature;
+      p.in = cur; p.in_img = img; p.wp = blob + c.w_off; p.bias = blob + c.b_off;
+      p.st = cur + (int64_t)c1 * H * W; p.st_img = img; p.cin = c.cin; p.cout = c.cout; p.ks = c.ks;
+      launch_conv<EPI_SPLIT_INV>(p, (int)n, s);
+    }
+    for (int k = K - 1; k >= 0; --k) {
+      const size_t step = step_end - (size_t)(K - k);
+      ConvLaunch p{};
+      p.H = H; p.W = W; p.n_strips = n_strips; p.ldj = nullptr;
+      // coupling^-1: the net reads the first half (unchanged by the step), exact-f32 convolutions
+      const std::vector<PackedConv>& net = f->net[step];
+      const float* hin = cur;
+      int64_t hin_img = img;
+      float* hb[2] = {H1, H2};
+      for (size_t q = 0; q + 1 < net.size(); ++q) {
+        const PackedConv& c = net[q];
+        if (q == 0 && net.size() >= 3 && c.cin <= 16) continue;     // fused into the 1x1 that follows
+        p.in = hin; p.in_img = hin_img; p.wp = blob + c.w_off; p.bias = blob + c.b_off;
+        p.out = hb[q & 1]; p.out_img = (int64_t)c.cout * H * W; p.cin = c.cin; p.cout = c.cout; p.ks = c.ks;
+        p.pre_in = nullptr;
+        if (q == 1 && net.size() >= 3 && net[0].cin <= 16) {
+          p.pre_in = cur; p.pre_in_img = img; p.pre_wp = blob + net[0].w_off; p.pre_bias = blob + net[0].b_off;
+          p.pre_cin = net[0].cin;
+        }
+        launch_conv<EPI_RELU>(p, (int)n, s);
+        p.pre_in = nullptr;
+        hin = hb[q & 1]; hin_img = p.out_img;
+      }
+      const PackedConv& c = net.back();
+      p.in = hin; p.in_img = hin_img; p.wp = blob + c.w_off; p.bias = blob + c.b_off; p.out = nullptr;
+      p.st = cur + (int64_t)c1 * H * W; p.st_img = img; p.cin = c.cin; p.cout = c.cout; p.ks = c.ks;
+      if (f->additive) launch_conv<EPI_COUPLE_ADD_INV>(p, (int)n, s);
+      else launch_conv<EPI_COUPLE_AFFINE_INV>(p, (int)n, s);
+      // (invconv / Permute2d)^-1 + ActNorm2d reverse: cur -> oth
+      const PackedConv& m = f->mix_inv[step];
+      p.in = cur; p.in_img = img; p.wp = blob + m.w_off; p.bias = blob + m.b_off; p.out = oth; p.out_img = img; p.st = nullptr;
+      p.cin = C; p.cout = C; p.ks = 1;
+      launch_conv<EPI_STORE>(p, (int)n, s);
+      std::swap(cur, oth);
+    }
+    step_end -= (size_t)K;
+  }
+  hipLaunchKernelGGL(img_post_kernel, dim3((unsigned)n), dim3(256), 0, s, (const float*)cur, x, f->C, f->H, f->W, f->bounds);
+  const hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return fail(GBNF_ERR_HIP, "gbnf_image_flow_inverse: %s", hipGetErrorString(e));
   return GBNF_OK;
 }
 

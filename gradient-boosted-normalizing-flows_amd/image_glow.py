@@ -383,17 +383,39 @@ class BoostedImageFlow(nn.Module):
         with torch.cuda.device(x.device):
             return self.native_flow(int(c)).forward(x, noise.contiguous().float(), want_z=want_z)
 
+    def _prior_on(self, handle, device):
+        prior = handle.__dict__.get("_prior_dev")            # (mean, logvar) of the top prior on the device, per handle
+        if prior is None or prior[0].device != device:
+            mu, lv = handle.prior()
+            prior = (torch.from_numpy(mu).to(device).view(1, -1, 1, 1), torch.from_numpy(lv).to(device).view(1, -1, 1, 1))
+            handle.__dict__["_prior_dev"] = prior
+        return prior
+
+    def decode(self, z, y_onehot=None, temperature=1.0, components="c", eps=None):
+        """models/boosted_flow.py:208-218 -> Glow.decode (models/glow.py:112-123) of one component (the reference's own
+        BoostedFlow.decode dies on a misspelt keyword; the component-level decode is the parity target,
+        fixtures g16_*).  z None: ``sample_size`` draws from the top prior, z = Normal(z_mu, exp(z_var) * temperature) as the
+        reference writes it.  ``eps``: the standard-normal draws of the Split2d levels (native.NativeImageFlow.inverse)."""
+        c = self._sample_component(components) if isinstance(components, str) else int(components)
+        handle = self.native_flow(c)
+        temperature = 1.0 if temperature is None else float(temperature)
+        if z is None:
+            dev = self.rho.device
+            mu, lv = self._prior_on(handle, dev)
+            n = int(self.flows[c].sample_size)
+            z = mu + torch.exp(lv) * temperature * torch.randn((n,) + tuple(handle.z_shape), device=dev)
+        if not z.is_cuda:
+            raise native.GbnfError("z must live on the MI355X (cuda) device: this module has no CPU path")
+        with torch.cuda.device(z.device):
+            return handle.inverse(z.contiguous().float(), eps, temperature)
+
     def forward(self, x=None, y_onehot=None, z=None, temperature=None, components=None, reverse=False):
         if reverse:
-            raise NotImplementedError("sampling from image components is not on the supported path")
+            return self.decode(z, y_onehot, temperature, components)
         c = self._sample_component(components) if isinstance(components, str) else int(components)
         zz, ldj, _ = self.component_forward(x, c)
         handle = self.native_flow(c)
-        prior = handle.__dict__.get("_prior_dev")            # (mean, logvar) of the top prior on the device, per handle
-        if prior is None or prior[0].device != x.device:
-            mu, lv = handle.prior()
-            prior = (torch.from_numpy(mu).to(x.device).view(1, -1, 1, 1), torch.from_numpy(lv).to(x.device).view(1, -1, 1, 1))
-            handle.__dict__["_prior_dev"] = prior
+        prior = self._prior_on(handle, x.device)
         shape = (x.shape[0],) + tuple(zz.shape[1:])
         return zz, prior[0].expand(shape), prior[1].expand(shape), ldj, None      # broadcast views: same values, no copies
 

@@ -34,7 +34,7 @@ ABI_SYMBOLS = (
     "gbnf_trainer_grad_floats", "gbnf_trainer_workspace_bytes", "gbnf_trainer_backward", "gbnf_trainer_trace_floats",
     "gbnf_trainer_bind_batch_stats", "gbnf_trainer_set_batch_stats",
     "gbnf_image_flow_create", "gbnf_image_flow_destroy", "gbnf_image_flow_info", "gbnf_image_flow_workspace_bytes",
-    "gbnf_image_flow_forward", "gbnf_image_flow_prior",
+    "gbnf_image_flow_forward", "gbnf_image_flow_prior", "gbnf_image_flow_eps_floats", "gbnf_image_flow_inverse",
 )
 
 
@@ -148,6 +148,8 @@ def lib():
     L.gbnf_image_flow_workspace_bytes.argtypes = [vp, i64, C.POINTER(i64)]
     L.gbnf_image_flow_forward.argtypes = [vp, vp, vp, i64, vp, vp, vp, vp, i64, vp]
     L.gbnf_image_flow_prior.argtypes = [vp, C.POINTER(C.c_float)]
+    L.gbnf_image_flow_eps_floats.argtypes = [vp, C.POINTER(i64)]
+    L.gbnf_image_flow_inverse.argtypes = [vp, vp, vp, C.c_float, i64, vp, vp, i64, vp]
     for name in ABI_SYMBOLS:
         if name not in ("gbnf_version", "gbnf_last_error"):
             getattr(L, name).restype = C.c_int
@@ -351,6 +353,7 @@ class NativeImageFlow:
         del keep
         self.handle = h
         self.input_size = tuple(int(v) for v in spec["input_size"])
+        self.n_levels = len(spec["levels"])
         zc, zh, zw, macs = C.c_int32(), C.c_int32(), C.c_int32(), C.c_double()
         _check(lib().gbnf_image_flow_info(h, C.byref(zc), C.byref(zh), C.byref(zw), C.byref(macs)))
         self.z_shape = (zc.value, zh.value, zw.value)
@@ -387,6 +390,51 @@ class NativeImageFlow:
             _check(lib().gbnf_image_flow_forward(self.handle, ptr(x), ptr(noise), n, ptr(z), ptr(ldj), ptr(ll),
                                                  ptr(self._ws), self._ws.numel() * 4, _stream_ptr()))
         return z, ldj, ll
+
+    def split_shapes(self):
+        """(C_l/2, H_l, W_l) of the half each Split2d level drops (and re-draws on the way back), first level first."""
+        c, h, w = self.input_size
+        out = []
+        for l in range(self.n_levels):
+            c, h, w = c * 4, h // 2, w // 2
+            if l < self.n_levels - 1:
+                out.append((c // 2, h, w))
+                c //= 2
+        return out
+
+    def inverse(self, z, eps=None, temperature=1.0):
+        """z (n,Cz,Hz,Wz) -> x (n,C,H,W): the reference's Glow.decode(z, None, temperature) (gbnf_image_flow_inverse).
+        ``eps``: one standard-normal tensor (n, C_l/2, H_l, W_l) per Split2d level, first level first (``split_shapes``);
+        None draws them from torch's generator on z's device."""
+        import torch
+        _require_device_f32(z, "z")
+        if z.dim() != 4 or tuple(z.shape[1:]) != self.z_shape:
+            raise GbnfError(f"z must be (n,{self.z_shape}), got {tuple(z.shape)}")
+        n = z.shape[0]
+        shapes = self.split_shapes()
+        if eps is None:
+            eps = [torch.randn((n,) + sh, dtype=torch.float32, device=z.device) for sh in shapes]
+        if len(eps) != len(shapes):
+            raise GbnfError(f"eps needs {len(shapes)} tensors, got {len(eps)}")
+        for e, sh in zip(eps, shapes):
+            _require_device_f32(e, "eps")
+            if tuple(e.shape) != (n,) + sh:
+                raise GbnfError(f"eps tensor must be {(n,) + sh}, got {tuple(e.shape)}")
+        per = C.c_int64()
+        _check(lib().gbnf_image_flow_eps_floats(self.handle, C.byref(per)))
+        flat = torch.cat([e.reshape(-1) for e in eps]) if eps else None
+        if flat is not None and flat.numel() != per.value * n:
+            raise GbnfError("eps size disagrees with gbnf_image_flow_eps_floats")
+        x = torch.empty((n,) + self.input_size, dtype=torch.float32, device=z.device)
+        if n:
+            nb = C.c_int64()
+            _check(lib().gbnf_image_flow_workspace_bytes(self.handle, n, C.byref(nb)))
+            if self._ws is None or self._ws.numel() * 4 < nb.value or self._ws.device != z.device:
+                self._ws = torch.empty((nb.value + 3) // 4, dtype=torch.float32, device=z.device)
+            ptr = lambda t: C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
+            _check(lib().gbnf_image_flow_inverse(self.handle, ptr(z.contiguous()), ptr(flat), float(temperature), n, ptr(x),
+                                                 ptr(self._ws), self._ws.numel() * 4, _stream_ptr()))
+        return x
 
     def close(self):
         if getattr(self, "handle", None):

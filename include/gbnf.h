@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define GBNF_ABI_VERSION 2
+#define GBNF_ABI_VERSION 3
 
 typedef enum gbnf_status {
   GBNF_OK = 0,
@@ -334,6 +334,18 @@ int gbnf_image_flow_forward(const gbnf_image_flow* flow, const float* x, const f
                             float* ldj, float* ll, void* workspace, int64_t workspace_bytes, void* stream);
 /* The top prior per channel: mean (Cz,) then log-variance (Cz,) into a HOST buffer of 2 Cz floats. */
 int gbnf_image_flow_prior(const gbnf_image_flow* flow, float* mean_logvar_host);
+/* The z -> x direction.  Replaces: x = self.flows[c].decode(z, None, temperature) for image input (models/glow.py:112-123):
+ * FlowNet.decode (models/glow.py:254-260) = per level, last first: Split2d reverse (models/layers.py:695-699: the dropped
+ * half is re-drawn as Normal(mean, exp(log-var) * temperature) with (mean, log-var) = conv(z1)), the FlowSteps backwards
+ * (FlowStep.decode, models/glow.py:344-366: coupling^-1, torch.inverse of the 1x1 weight or indices_inverse, ActNorm2d
+ * reverse), unsqueeze2d (utils/utilities.py:121-135); then to_logits(reverse=True) (models/glow.py:151-158).
+ * z (n,Cz,Hz,Wz); x (n,C,H,W).  eps: the standard-normal draws behind Split2d's samples (the caller's RNG, so that
+ * sampling is reproducible and testable): level 0 first, each level a contiguous (n, C_l/2, H_l, W_l) array,
+ * gbnf_image_flow_eps_floats() floats per image in all (= C*H*W - Cz*Hz*Wz); may be NULL for a one-level flow.
+ * The coupling networks run on the exact-f32 convolution kernels.  workspace as for gbnf_image_flow_forward. */
+int gbnf_image_flow_eps_floats(const gbnf_image_flow* flow, int64_t* per_image);
+int gbnf_image_flow_inverse(const gbnf_image_flow* flow, const float* z, const float* eps, float temperature, int64_t n,
+                            float* x, void* workspace, int64_t workspace_bytes, void* stream);
 
 #ifdef __cplusplus
 }

@@ -510,6 +510,83 @@ def image_component_forward(spec, x, noise, dtype=None):
     return z.numpy(), z_mu.numpy(), z_var.numpy(), ld.numpy(), ll.numpy()
 
 
+def image_unsqueeze(x, factor=2):
+    """unsqueeze2d, utils/utilities.py:121-135."""
+    B, C, H, W = x.shape
+    f2 = factor * factor
+    x = x.view(B, C // f2, factor, factor, H, W).permute(0, 1, 4, 2, 5, 3).contiguous()
+    return x.view(B, C // f2, H * factor, W * factor)
+
+
+def image_flow_step_inverse(spec, st, z, dtype):
+    """FlowStep.decode, image branch (models/glow.py:344-366): coupling^-1, permutation^-1 (torch.inverse of the 1x1
+    weight, models/layers.py:756-758, or indices_inverse, :681-682), ActNorm2d reverse (scale by exp(-logs), then
+    minus bias: models/layers.py:488-533)."""
+    B, C, H, W = z.shape
+    z1, z2 = z[:, : C // 2], z[:, C // 2:]
+    h = z1
+    n = len(st["convs"])
+    for k, c in enumerate(st["convs"]):
+        h = image_conv(c, h, dtype)
+        if k < n - 1:
+            h = torch.relu(h)
+    if spec["coupling"] == "additive":
+        z2 = z2 - h
+    else:
+        shift, raw = h[:, 0::2], h[:, 1::2]
+        scale = torch.sigmoid(raw + 2.0)
+        z2 = z2 / scale - shift
+    z = torch.cat([z1, z2], dim=1)
+    if st["perm_w"] is not None:
+        w = torch.inverse(_t(st["perm_w"], dtype))
+        z = torch.nn.functional.conv2d(z, w.view(C, C, 1, 1))
+    else:
+        perm = np.asarray(st["perm"])
+        inv = np.empty_like(perm)
+        inv[perm] = np.arange(len(perm))
+        z = z[:, torch.as_tensor(inv, dtype=torch.long)]
+    z = z * torch.exp(-_t(st["an_logs"], dtype).view(1, -1, 1, 1)) - _t(st["an_bias"], dtype).view(1, -1, 1, 1)
+    return z
+
+
+def image_split_shapes(spec, input_size=(3, 32, 32)):
+    """(C/2, H, W) of the half each Split2d level re-draws on the way back, first level first."""
+    C, H, W = input_size
+    out = []
+    for lvl in spec["levels"]:
+        C, H, W = C * 4, H // 2, W // 2
+        if lvl["split"] is not None:
+            out.append((C // 2, H, W))
+            C //= 2
+    return out
+
+
+def image_component_inverse(spec, z, eps, temperature=1.0, dtype=None):
+    """Glow.decode for image input with z given (models/glow.py:112-123): FlowNet.decode (:254-260) walks the layers in
+    reverse; a Split2d level re-draws the half it dropped, z2 = Normal(mean, exp(log-var) * temperature) with
+    (mean, log-var) = conv(z1) (models/layers.py:695-699 -- the reference does pass exp(z_var), not its square root, as
+    the standard deviation); ``eps[l]`` (N, C_l/2, H_l, W_l) are the standard-normal draws behind those samples, first
+    level first.  Then to_logits(reverse=True) (:151-158).  -> x (N, C, H, W) in [0, 1]."""
+    dtype = dtype or torch.float32
+    z = _t(z, dtype).clone()
+    levels = spec["levels"]
+    n_split = sum(1 for lvl in levels if lvl["split"] is not None)
+    assert len(eps) == n_split
+    si = n_split
+    for lvl in reversed(levels):
+        if lvl["split"] is not None:
+            si -= 1
+            hh = image_conv(lvl["split"], z, dtype)
+            mu, lv = hh[:, 0::2], hh[:, 1::2]
+            z = torch.cat([z, mu + torch.exp(lv) * temperature * _t(eps[si], dtype)], dim=1)
+        for st in reversed(lvl["steps"]):
+            z = image_flow_step_inverse(spec, st, z, dtype)
+        z = image_unsqueeze(z)
+    x = 1.0 / (torch.exp(-z) + 1.0)
+    x = ((x * 2.0 - 1.0) / spec["bounds"] + 1.0) / 2.0
+    return x.numpy()
+
+
 def log_normal_standard_sum(ops, z):
     """log_normal_standard(z, reduce=True, dim=-1): utils/distributions.py:44-60."""
     log_norm = (-0.5 * LOG_2PI) - (0.5 * z * z)

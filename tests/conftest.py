@@ -21,7 +21,7 @@ def golden_names():
     """Forward/mixture fixtures (g1..g6).  g7 (ActNorm data-dependent init), g8 (boosting weights) and g9 (decode)
     have their own tests."""
     names = sorted(os.path.splitext(os.path.basename(p))[0] for p in glob.glob(os.path.join(GOLDEN_DIR, "*.npz")))
-    return [n for n in names if not n.startswith(("g7_", "g8_", "g9_", "g10_", "g11_", "g12_"))]
+    return [n for n in names if not n.startswith(("g7_", "g8_", "g9_", "g10_", "g11_", "g12_", "g16_"))]
 
 
 IMAGE_CASES = ("g12_image_glow_invconv_affine", "g12_image_glow_shuffle_additive", "g12_image_glow_lu")
@@ -43,6 +43,25 @@ def load_image_case(name):
                     st["perm_w"] = data[f"c{c}.perm_w.{k}"]; k += 1
     x, noise = synth.synth_image_batch(cfg["N"], (3, 32, 32), seed=cfg["x_seed"])
     return cfg, specs, x, noise, data
+
+
+IMAGE_DECODE_CASES = ("g16_image_decode_invconv_affine", "g16_image_decode_shuffle_additive", "g16_image_decode_lu")
+
+
+def load_image_decode_case(name):
+    """g16: (cfg, spec, z, eps list, x of the reference's Glow.decode)."""
+    from gbnf_amd import synth
+    data = dict(np.load(os.path.join(GOLDEN_DIR, name + ".npz")))
+    cfg = json.loads(bytes(data["config"]).decode())
+    spec = synth.synth_image_glow_spec((3, 32, 32), cfg["h"], cfg["K"], cfg["L"], depth=cfg["depth"], coupling=cfg["coupling"],
+                                       permutation=cfg["permutation"], learn_top=True, seed=cfg["w_seed"])
+    if cfg["LU"]:
+        k = 0
+        for lvl in spec["levels"]:
+            for st in lvl["steps"]:
+                st["perm_w"] = data[f"c0.perm_w.{k}"]; k += 1
+    eps = [data[f"eps.{l}"] for l in range(cfg["L"] - 1)]
+    return cfg, spec, data["z"], eps, data["x"]
 
 
 GRADS_CASES = ("g10_glow_grads_d43_h64", "g10_glow_grads_additive_relu_d8", "g10_realnvp_grads_d21_h32",

@@ -592,8 +592,70 @@ def image_case(name, h=32, K=2, L=2, C=2, N=4, depth=1, coupling="affine", permu
     print(f"{name}: ll[:, :2]={np.stack(lls)[:, :2]} bpd={-np.stack(lls).mean() / (np.log(2) * 3072):.4f}")
 
 
+def image_decode_case(name, h=32, K=2, L=2, N=3, depth=1, coupling="affine", permutation="invconv", LU=False,
+                      temperature=0.7):
+    """G16: the image z -> x direction by the reference itself: Glow.decode(z, None, temperature) (models/glow.py:112-123;
+    FlowNet.decode :254-260, FlowStep.decode :344-366, Split2d reverse models/layers.py:695-699, to_logits reverse
+    models/glow.py:151-158).  The draws of Split2d's torch.normal are injected (mean + std * eps with the fixture's eps),
+    so the result is a function of (z, eps, temperature)."""
+    input_size = (3, 32, 32)
+    a = ref_args("glow", 3 * 32 * 32, h, K, 1, depth=depth, coupling=coupling, permutation=permutation)
+    a.input_size = list(input_size); a.num_blocks = L; a.learn_top = True; a.LU_decomposed = LU
+    torch.manual_seed(11)
+    model = RefBoostedFlow(a).eval()
+    spec = synth.synth_image_glow_spec(input_size, h, K, L, depth=depth, coupling=coupling, permutation=permutation,
+                                       learn_top=True, seed=71)
+    install_image_spec(model.flows[0], spec, keep_invconv=LU)
+    rng = np.random.RandomState(17)
+    shapes = []                 # (C/2, H, W) of the half each Split2d drops, first level first
+    zc, zh, zw = input_size
+    for l in range(L):
+        zc, zh, zw = zc * 4, zh // 2, zw // 2
+        if l < L - 1:
+            shapes.append((zc // 2, zh, zw))
+            zc //= 2
+    z = (0.8 * rng.randn(N, zc, zh, zw)).astype(np.float32)
+    eps = [rng.randn(N, *sh).astype(np.float32) for sh in shapes]
+    queue = [torch.from_numpy(e) for e in eps]          # FlowNet.decode meets the deepest Split2d first
+    orig = torch.normal
+
+    def injected(mean, std, *args, **kw):
+        e = queue.pop()
+        assert tuple(e.shape) == tuple(mean.shape)
+        return mean + std * e
+    try:
+        torch.normal = injected
+        with torch.no_grad():
+            x = model.flows[0].decode(torch.from_numpy(z).clone(), None, temperature)
+    finally:
+        torch.normal = orig
+    assert not queue
+    out = dict(config=np.frombuffer(json.dumps(dict(case="image_decode", h=h, K=K, L=L, N=N, depth=depth, coupling=coupling,
+                                                    permutation=permutation, LU=LU, w_seed=71,
+                                                    temperature=temperature)).encode(), dtype=np.uint8),
+               z=z, x=x.numpy().copy())
+    for l, e in enumerate(eps):
+        out[f"eps.{l}"] = e
+    if LU:
+        k = 0
+        for lvl in spec["levels"]:
+            for st in lvl["steps"]:
+                out[f"c0.perm_w.{k}"] = st["perm_w"]; k += 1
+    np.savez_compressed(os.path.join(HERE, name + ".npz"), **out)
+    print(f"{name}: x[0,0,0,:4]={x.numpy()[0, 0, 0, :4]} range [{float(x.min()):.3f}, {float(x.max()):.3f}]")
+
+
+def image_decode_cases():
+    image_decode_case("g16_image_decode_invconv_affine")
+    image_decode_case("g16_image_decode_shuffle_additive", coupling="additive", permutation="shuffle", depth=2, temperature=1.0)
+    image_decode_case("g16_image_decode_lu", LU=True, K=1, h=16, temperature=0.5)
+
+
 def main():
     torch.set_num_threads(4)
+    if "--image-decode-only" in sys.argv:
+        image_decode_cases()
+        return
     if "--stress-only" in sys.argv:
         stress_cases()
         return
@@ -643,6 +705,7 @@ def main():
     image_case("g12_image_glow_invconv_affine")
     image_case("g12_image_glow_shuffle_additive", coupling="additive", permutation="shuffle", learn_top=False, depth=2)
     image_case("g12_image_glow_lu", LU=True, K=1, h=16)
+    image_decode_cases()
     grads_case("g10_glow_grads_d43_h64", "glow", 43, 64, 3, 96)
     grads_case("g10_glow_grads_additive_relu_d8", "glow", 8, 40, 3, 50, coupling="additive", act="relu")
     grads_case("g10_realnvp_grads_d21_h32", "realnvp", 21, 32, 4, 80)

@@ -123,3 +123,76 @@ def test_image_random_geometry_against_oracle(case):
     assert rel_err(ll.cpu().numpy(), ll64) < LL_RTOL
     assert rel_err(ldj.cpu().numpy(), ld64) < LL_RTOL
     assert np.abs(z.cpu().numpy() - z64).max() <= 2e-4 * max(1.0, float(np.abs(z64).max()))
+
+
+# ---- the z -> x direction (gbnf_image_flow_inverse) -------------------------------------------
+from conftest import IMAGE_DECODE_CASES, load_image_decode_case  # noqa: E402
+
+X_ATOL = 5e-5        # x is a pixel intensity in [0, 1] (sigmoid of the logits): absolute tolerance
+
+
+@pytest.mark.parametrize("name", IMAGE_DECODE_CASES)
+def test_image_inverse_matches_reference_decode(name):
+    """g16: the reference's Glow.decode(z, None, temperature) with Split2d's draws injected."""
+    import torch
+    from gbnf_amd import native
+    cfg, spec, z, eps, x_ref = load_image_decode_case(name)
+    dev = torch.device("cuda:0")
+    flow = native.NativeImageFlow(spec)
+    assert flow.split_shapes() == [tuple(e.shape[1:]) for e in eps]
+    x = flow.inverse(torch.from_numpy(z).to(dev), [torch.from_numpy(e).to(dev) for e in eps], cfg["temperature"])
+    torch.cuda.synchronize()
+    assert np.abs(x.cpu().numpy() - x_ref).max() <= X_ATOL, float(np.abs(x.cpu().numpy() - x_ref).max())
+
+
+def test_image_inverse_round_trip_at_config_size():
+    """BASELINE.json configs[3] geometry (3x32x32, K = 8, L = 2, h = 256), 64 images: decode, then encode the decoded image
+    (dequantisation noise chosen so that (255 x + noise) / 256 == x): z comes back.  Small batch also against the oracle."""
+    import torch
+    from gbnf_amd import native, synth
+    from oracle import gbnf_oracle as oracle
+    dev = torch.device("cuda:0")
+    sp = synth.synth_image_glow_spec((3, 32, 32), h=256, K=8, L=2, seed=44)
+    flow = native.NativeImageFlow(sp)
+    rng = np.random.RandomState(3)
+    n = 64
+    z = (0.7 * rng.randn(n, *flow.z_shape)).astype(np.float32)
+    eps = [rng.randn(n, *sh).astype(np.float32) for sh in flow.split_shapes()]
+    zd, ed = torch.from_numpy(z).to(dev), [torch.from_numpy(e).to(dev) for e in eps]
+    x = flow.inverse(zd, ed, 0.8)
+    assert torch.isfinite(x).all()
+    x_or = oracle.image_component_inverse(sp, z[:2], [e[:2] for e in eps], 0.8, dtype=torch.float64)
+    assert np.abs(x[:2].cpu().numpy() - x_or).max() <= X_ATOL
+    inside = (x > 0.02) & (x < 0.98)                 # pixels the logit of the forward direction can take back
+    xs = torch.where(inside, x, torch.full_like(x, 0.5))
+    z_back = flow.forward(xs, xs.clone())[0]
+    z_ref = torch.from_numpy(oracle.image_component_forward(sp, xs[:2].cpu().numpy(), xs[:2].cpu().numpy(), dtype=torch.float64)[0])
+    assert np.abs(z_back[:2].cpu().numpy() - z_ref.numpy()).max() <= 2e-4 * max(1.0, float(z_ref.abs().max()))
+    ok = inside.flatten(1).all(dim=1)                 # images decoded entirely inside the range: z must come back
+    if ok.any():
+        err = (z_back[ok] - zd[ok]).abs().max().item()
+        assert err <= 2e-3 * max(1.0, float(zd.abs().max())), err
+
+
+def test_image_module_decode_and_sampling():
+    """BoostedFlow(args) for images: model(z=z, components=c, reverse=True) == Glow.decode of the reference (g16), and
+    z = None draws sample_size images from the top prior."""
+    import argparse
+    import torch
+    from gbnf_amd import BoostedFlow, image_glow
+    cfg, spec, z, eps, x_ref = load_image_decode_case("g16_image_decode_invconv_affine")
+    dev = torch.device("cuda:0")
+    args = argparse.Namespace(
+        num_flows=cfg["K"], z_size=3072, density_evaluation=True, device=dev, cuda=True, component_type="glow",
+        num_components=2, rho_init="decreasing", learn_top=True, y_classes=0, y_condition=False,
+        sample_size=5, input_size=[3, 32, 32], h_size=cfg["h"], num_blocks=cfg["L"], actnorm_scale=1.0,
+        flow_permutation=cfg["permutation"], flow_coupling=cfg["coupling"], LU_decomposed=False, num_dequant_blocks=0,
+        coupling_network="tanh", coupling_network_depth=cfg["depth"], batch_norm=False)
+    m = BoostedFlow(args)
+    image_glow.load_image_spec(m.flows[1], spec)
+    m.eval()
+    with torch.no_grad():
+        x = m.decode(torch.from_numpy(z).to(dev), None, cfg["temperature"], 1, eps=[torch.from_numpy(e).to(dev) for e in eps])
+        assert np.abs(x.cpu().numpy() - x_ref).max() <= X_ATOL
+        xs = m(z=None, temperature=0.7, components=1, reverse=True)
+        assert xs.shape == (5, 3, 32, 32) and torch.isfinite(xs).all()

@@ -146,6 +146,24 @@ def test_oracle_image_path_matches_reference(name):
     assert rel_err(G, data["G"]) < 1e-5
 
 
+from conftest import IMAGE_DECODE_CASES, load_image_decode_case  # noqa: E402
+
+
+@pytest.mark.parametrize("name", IMAGE_DECODE_CASES)
+def test_oracle_image_decode_matches_reference(name):
+    """g16: the reference's Glow.decode(z, None, temperature) with Split2d's draws injected vs the oracle's inverse; and
+    the oracle's own round trip: encode(decode(z)) gives z back when the dropped halves are re-derived from it."""
+    import torch
+    cfg, spec, z, eps, x_ref = load_image_decode_case(name)
+    x = oracle.image_component_inverse(spec, z, eps, cfg["temperature"])
+    assert np.abs(x - x_ref).max() <= 2e-5
+    x64 = oracle.image_component_inverse(spec, z, eps, cfg["temperature"], dtype=torch.float64)
+    assert np.abs(x64 - x_ref).max() <= 2e-5
+    # forward of the decoded image: x = (255 x' + noise) / 256 with x' = x64, noise = x64 (then x = x64 exactly)
+    z_back = oracle.image_component_forward(spec, x64, x64, dtype=torch.float64)[0]
+    assert np.abs(z_back - z).max() <= 1e-6 * max(1.0, np.abs(z).max())
+
+
 def test_oracle_train_mode_batch_norm_matches_reference():
     """g10 (train-mode BatchNorm): the reference's RealNVP in train(): forward on batch statistics, nll.backward() through
     them, running statistics updated with momentum 0.9."""
