@@ -28,10 +28,12 @@ def read_variants():
             if not line:
                 continue
             if line.startswith("hx3"):     # both split precisions: 0 = f16x3, 1 = bf16x6 (its repair pass / safe mode)
-                kind, ht, ot, acta, actb = (int(v) for v in line.split()[1:])
+                vals = [int(v) for v in line.split()[1:]]
+                kind, ht, ot, acta, actb = vals[:5]
+                depth = vals[5] if len(vals) > 5 else 1          # coupling_network_depth: 0, 1 (default) or 2
                 for nt in (1, 2):
                     for prec in (0, 1):
-                        out.append(("hx3", kind, ht, ot, nt, acta, actb, prec))
+                        out.append(("hx3", kind, ht, ot, nt, acta, actb, prec, depth))
                 continue
             toks = line.split()
             nts = (1, 2)

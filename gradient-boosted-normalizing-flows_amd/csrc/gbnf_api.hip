@@ -284,13 +284,12 @@ static bool put_tile(std::vector<uint32_t>& blob, size_t off, int NP, F elem) {
 // consecutive 16-unit accumulator tiles read as one k = 32 B operand
 static int hx3_hidden_unit(int c, int gg, int j) { return 16 * (2 * c + (j >> 2)) + 4 * gg + (j & 3); }
 
-static bool pack_net_hx3(std::vector<uint32_t>& blob, size_t base, const gbnf_net& net, int HT, int OT, int NP, int in_f,
-                         int h, int out_f) {
-  const Hx3Layout L(HT, OT, NP);
+static bool pack_net_hx3(std::vector<uint32_t>& blob, size_t base, const gbnf_net& net, int HT, int OT, int NP, int depth,
+                         int in_f, int h, int out_f) {
+  const Hx3Layout L(HT, OT, NP, depth);
   auto put = [&](size_t off, float v) { std::memcpy(&blob[base + off], &v, 4); };
   const gbnf_linear& l0 = net.layers[0];
-  const gbnf_linear& l1 = net.layers[1];
-  const gbnf_linear& l2 = net.layers[2];
+  const gbnf_linear& lout = net.layers[depth + 1];
   bool ok = true;
   // tanh networks (gbnf_flow_kernel_hx3.hip.h, tanh_hx3): a layer whose output goes through tanh carries the factor
   // T = 2*log2(e) of tanh(x) = 1 - 2/(2^(T x) + 1); the kernel hands on r = 1/(2^(T x) + 1), and the layer that
@@ -308,14 +307,21 @@ static bool pack_net_hx3(std::vector<uint32_t>& blob, size_t base, const gbnf_ne
     for (int k = 0; k < 16; ++k) {
       const int u = 16 * t + k;
       put((size_t)t * 16 + k, u < h ? T * l0.bias[u] : 0.0f);
-      put((size_t)(HT + t) * 16 + k, u < h ? T * folded_bias(l1, u, h) : 0.0f);
+      for (int j = 1; j <= depth; ++j)
+        put((size_t)(j * HT + t) * 16 + k, u < h ? T * folded_bias(net.layers[j], u, h) : 0.0f);
     }
   for (int o = 0; o < OT; ++o)
     for (int k = 0; k < 16; ++k) {
       const int r = 16 * o + k;
-      put((size_t)(2 * HT + o) * 16 + k, r < out_f ? folded_bias(l2, r, h) : 0.0f);
+      put((size_t)((depth + 1) * HT + o) * 16 + k, r < out_f ? folded_bias(lout, r, h) : 0.0f);
     }
   const size_t TW = (size_t)NP * 256;                        // words per weight tile
+  auto out_tile = [&](size_t off, int c, int o) {             // output-layer tile o of hidden chunk c
+    ok &= put_tile(blob, off, NP, [&](int i, int gg, int j) {
+      const int row = 16 * o + i, ui = hx3_hidden_unit(c, gg, j);
+      return (row < out_f && ui < h) ? R * lout.weight[(size_t)row * h + ui] : 0.0f;
+    });
+  };
   int s = 0;
   for (int i0 = 0; i0 < L.N_L0; ++i0, ++s) {               // layer 0: k-slot (g,j) = input feature 8g + j
     const int t0 = i0 * L.TL0;
@@ -327,28 +333,26 @@ static bool pack_net_hx3(std::vector<uint32_t>& blob, size_t base, const gbnf_ne
       });
     }
   }
-  for (int u = 0; u < HT; ++u, ++s) {                         // hidden row u (+ output chunk (u-2)/2)
-    for (int c = 0; c < L.HC; ++c)
-      ok &= put_tile(blob, base + L.off[s] + (size_t)c * TW, NP, [&](int i, int gg, int j) {
-        const int uo = 16 * u + i, ui = hx3_hidden_unit(c, gg, j);
-        return (uo < h && ui < h) ? T * R * l1.weight[(size_t)uo * h + ui] : 0.0f;
-      });
-    if (u % 2 == 0 && u >= 2) {
-      const int c = (u - 2) / 2;
-      for (int o = 0; o < OT; ++o)
-        ok &= put_tile(blob, base + L.off[s] + (size_t)(L.HC + o) * TW, NP, [&](int i, int gg, int j) {
-          const int row = 16 * o + i, ui = hx3_hidden_unit(c, gg, j);
-          return (row < out_f && ui < h) ? R * l2.weight[(size_t)row * h + ui] : 0.0f;
+  for (int jl = 1; jl <= depth; ++jl) {
+    const gbnf_linear& lj = net.layers[jl];
+    for (int u = 0; u < HT; ++u, ++s) {                       // hidden row u (+ output chunk (u-2)/2 in the last hidden layer)
+      for (int c = 0; c < L.HC; ++c)
+        ok &= put_tile(blob, base + L.off[s] + (size_t)c * TW, NP, [&](int i, int gg, int j) {
+          const int uo = 16 * u + i, ui = hx3_hidden_unit(c, gg, j);
+          return (uo < h && ui < h) ? T * R * lj.weight[(size_t)uo * h + ui] : 0.0f;
         });
+      if (jl == depth && u % 2 == 0 && u >= 2)
+        for (int o = 0; o < OT; ++o) out_tile(base + L.off[s] + (size_t)(L.HC + o) * TW, (u - 2) / 2, o);
     }
   }
-  {                                                            // drain: output chunk HC-1
-    const int c = L.HC - 1;
-    for (int o = 0; o < OT; ++o)
-      ok &= put_tile(blob, base + L.off[s] + (size_t)o * TW, NP, [&](int i, int gg, int j) {
-        const int row = 16 * o + i, ui = hx3_hidden_unit(c, gg, j);
-        return (row < out_f && ui < h) ? R * l2.weight[(size_t)row * h + ui] : 0.0f;
-      });
+  if (depth >= 1) {                                            // drain: output chunk HC-1
+    for (int o = 0; o < OT; ++o) out_tile(base + L.off[s] + (size_t)o * TW, L.HC - 1, o);
+  } else {                                                     // no hidden layer: output stages of CG chunks
+    for (int k = 0; k < L.N_OUT; ++k, ++s) {
+      const int c0 = k * L.CG, cnt = std::min(L.CG, L.HC - c0);
+      for (int cc = 0; cc < cnt; ++cc)
+        for (int o = 0; o < OT; ++o) out_tile(base + L.off[s] + (size_t)(cc * OT + o) * TW, c0 + cc, o);
+    }
   }
   return ok;
 }
@@ -514,15 +518,15 @@ struct PackedBlob {
 };
 
 // the cheapest compiled split-kernel variant (key.ksl = -3 f16x3 / -6 bf16x6) that covers hidden width h and `ot` output tiles
-static bool choose_hx3(int kind, int h, int ot, int act_a, int act_b, int ksl_key, VariantChoice* vc) {
+static bool choose_hx3(int kind, int h, int ot, int depth, int act_a, int act_b, int ksl_key, VariantChoice* vc) {
   const int ht_b = ceil_div(h, 16);
   long best = -1;
   for (const Variant& v : variants()) {
     const VariantKey& k = v.key;
-    if (k.ksl != ksl_key || k.kind != kind || k.act_a != act_a || k.act_b != act_b) continue;
+    if (k.ksl != ksl_key || k.kind != kind || k.lmid != depth || k.act_a != act_a || k.act_b != act_b) continue;
     if (k.ht < ht_b || k.ot < ot) continue;
-    const Variant* v1 = find_variant(VariantKey{k.kind, k.ht, ksl_key, 0, k.ot, 1, 1, k.act_a, k.act_b});
-    const Variant* v2 = find_variant(VariantKey{k.kind, k.ht, ksl_key, 0, k.ot, 2, 1, k.act_a, k.act_b});
+    const Variant* v1 = find_variant(VariantKey{k.kind, k.ht, ksl_key, 0, k.ot, 1, depth, k.act_a, k.act_b});
+    const Variant* v2 = find_variant(VariantKey{k.kind, k.ht, ksl_key, 0, k.ot, 2, depth, k.act_a, k.act_b});
     if (!v1 || !v2) continue;
     const long cost = (long)k.ht * (k.ht + 1) / 2 * 2 + k.ht * k.ot;
     if (best < 0 || cost < best) {
@@ -574,7 +578,7 @@ static void pack_component(const gbnf_flow_desc* desc, const DescInfo& info, con
   const bool hx3 = vc.hx3;
   const int HT = vc.ht, OT = vc.ot, KS1V = vc.ks1;
   const int nnets = glow ? 1 : 2;
-  const size_t NW = hx3 ? (size_t)Hx3Layout(HT, OT, vc.np).NET_WORDS : net_words(HT, KS1V, OT, depth);
+  const size_t NW = hx3 ? (size_t)Hx3Layout(HT, OT, vc.np, depth).NET_WORDS : net_words(HT, KS1V, OT, depth);
   const size_t step_words = SMALL_WORDS + nnets * NW;
   const size_t total_words = step_words * K + 64;
   std::vector<uint32_t>& blob = pb->words;
@@ -678,10 +682,10 @@ static void pack_component(const gbnf_flow_desc* desc, const DescInfo& info, con
     const int net_out = paired ? 2 * out_f : out_f;
     if (hx3) {
       if (glow) {
-        pb->in_range &= pack_net_hx3(blob, sb + SMALL_WORDS, desc->glow_steps[s].block, HT, OT, vc.np, in_f, h, net_out);
+        pb->in_range &= pack_net_hx3(blob, sb + SMALL_WORDS, desc->glow_steps[s].block, HT, OT, vc.np, depth, in_f, h, net_out);
       } else {
-        pb->in_range &= pack_net_hx3(blob, sb + SMALL_WORDS, desc->realnvp_steps[s].t_net, HT, OT, vc.np, in_f, h, net_out);
-        pb->in_range &= pack_net_hx3(blob, sb + SMALL_WORDS + NW, desc->realnvp_steps[s].s_net, HT, OT, vc.np, in_f, h, net_out);
+        pb->in_range &= pack_net_hx3(blob, sb + SMALL_WORDS, desc->realnvp_steps[s].t_net, HT, OT, vc.np, depth, in_f, h, net_out);
+        pb->in_range &= pack_net_hx3(blob, sb + SMALL_WORDS + NW, desc->realnvp_steps[s].s_net, HT, OT, vc.np, depth, in_f, h, net_out);
       }
     } else if (glow) {
       pack_net(blob, sb + SMALL_WORDS, desc->glow_steps[s].block, HT, KS1V, OT, depth, in_f, h, net_out);
@@ -754,26 +758,26 @@ int gbnf_flow_create_ex(const gbnf_flow_desc* desc, int32_t math_mode, int32_t f
 
   if (math_mode != GBNF_MATH_F32 && math_mode != GBNF_MATH_F16X3 && math_mode != GBNF_MATH_BF16X6 && math_mode != GBNF_MATH_DEFAULT)
     return fail(GBNF_ERR_INVALID, "unknown math mode %d", math_mode);
-  const bool split_shape = depth == 1 && !ref.residual;      // what the split kernels take: TanhNet / ReLUNet of depth 1
+  const bool split_shape = depth <= 2 && !ref.residual;      // what the split kernels take: TanhNet / ReLUNet of depth 0, 1 or 2
   if (!split_shape && (math_mode == GBNF_MATH_F16X3 || math_mode == GBNF_MATH_BF16X6))
-    return fail(GBNF_ERR_UNSUPPORTED, "the split kernels (f16x3 / bf16x6) support TanhNet / ReLUNet of coupling_network_depth == 1 only (got %s%d)",
+    return fail(GBNF_ERR_UNSUPPORTED, "the split kernels (f16x3 / bf16x6) support TanhNet / ReLUNet of coupling_network_depth <= 2 only (got %s%d)",
                 ref.residual ? "a ResidualNet, hidden layers " : "", depth);
 
   // ---- pick compiled variants (exact geometry first, then the cheapest zero-padded superset)
   VariantChoice fast, safe, exact;
   const bool want_split = split_shape && math_mode != GBNF_MATH_F32;
-  const bool have_fast = want_split && math_mode != GBNF_MATH_BF16X6 && choose_hx3(desc->kind, h, ot, act_a, act_b, -3, &fast);
-  const bool have_safe = want_split && choose_hx3(desc->kind, h, ot, act_a, act_b, -6, &safe);
+  const bool have_fast = want_split && math_mode != GBNF_MATH_BF16X6 && choose_hx3(desc->kind, h, ot, depth, act_a, act_b, -3, &fast);
+  const bool have_safe = want_split && choose_hx3(desc->kind, h, ot, depth, act_a, act_b, -6, &safe);
   const bool retry_per_step = act_a != GBNF_ACT_PER_STEP && !ref.residual;   // the per-step-activation variants are generic supersets
   if (math_mode == GBNF_MATH_F16X3 && !have_fast) {
     if (retry_per_step) return gbnf_flow_create_ex(desc, math_mode, flags | GBNF_CREATE_PER_STEP_ACTIVATION, out);
-    return fail(GBNF_ERR_UNSUPPORTED, "no compiled f16x3 kernel variant for kind=%d hidden=%d out_tiles=%d act=(%d,%d); "
-                "add it to csrc/variants.list", desc->kind, h, ot, act_a, act_b);
+    return fail(GBNF_ERR_UNSUPPORTED, "no compiled f16x3 kernel variant for kind=%d hidden=%d out_tiles=%d depth=%d act=(%d,%d); "
+                "add it to csrc/variants.list", desc->kind, h, ot, depth, act_a, act_b);
   }
   if (math_mode == GBNF_MATH_BF16X6 && !have_safe) {
     if (retry_per_step) return gbnf_flow_create_ex(desc, math_mode, flags | GBNF_CREATE_PER_STEP_ACTIVATION, out);
-    return fail(GBNF_ERR_UNSUPPORTED, "no compiled bf16x6 kernel variant for kind=%d hidden=%d out_tiles=%d act=(%d,%d); "
-                "add it to csrc/variants.list", desc->kind, h, ot, act_a, act_b);
+    return fail(GBNF_ERR_UNSUPPORTED, "no compiled bf16x6 kernel variant for kind=%d hidden=%d out_tiles=%d depth=%d act=(%d,%d); "
+                "add it to csrc/variants.list", desc->kind, h, ot, depth, act_a, act_b);
   }
   const bool use_split = have_fast || (have_safe && math_mode != GBNF_MATH_F16X3);
   if (!use_split) {

@@ -50,67 +50,81 @@ constexpr int hx3_pieces(int prec) { return prec == 0 ? 2 : 3; }
 // Packed layout of one coupling network for the hx3 kernel, in 32-bit words.  A "fragment" is the A operand of one
 // v_mfma_f32_16x16x32_* for one 16-row tile: [64 lanes][8 narrow values] = 256 words; every weight tile is NP
 // consecutive fragments (its pieces, largest first).  Stages are contiguous and in consumption order:
-//   biases   : B1 [HT][16] | B2 [HT][16] | B3 [OT][16] (f32), padded to whole fragments (BIAS_FRAGS)
+//   biases   : layer 0 [HT][16] | hidden layer j = 1..DEPTH [HT][16] each | output layer [OT][16] (f32), padded to whole
+//              fragments (BIAS_FRAGS)
 //   L0 stages: layer-0 tiles [0,TL0), [TL0,2 TL0) ...                                  TL0 = HC + OT tiles per stage
-//   PASS u   : hidden row u, chunks c = 0..HC-1; then, if u is even and u >= 2, the output-layer chunk (u-2)/2:
-//              tiles o = 0..OT-1 (it is consumed in pass u)
-//   DRAIN    : output-layer chunk HC-1
+//   DEPTH >= 1, per hidden layer j:
+//     PASS u : hidden row u, chunks c = 0..HC-1; then, in the LAST hidden layer, if u is even and u >= 2, the output-layer
+//              chunk (u-2)/2: tiles o = 0..OT-1 (it is consumed in pass u)
+//     DRAIN  : output-layer chunk HC-1
+//   DEPTH == 0 (the output layer reads layer 0's activations): OUT stages of CG = TL0 / OT chunks, OT tiles each
 struct Hx3Layout {
-  static constexpr int MAXS = 44;
-  int NP, HC, TL0, N_L0, NS, BIAS_FRAGS, BIAS_WORDS, NET_WORDS, STAGE_FRAGS;
+  static constexpr int MAXS = 80;
+  int NP, HC, TL0, N_L0, NS, BIAS_FRAGS, BIAS_WORDS, NET_WORDS, STAGE_FRAGS, DEPTH, CG, N_OUT;
   int off[MAXS];   // word offset of stage s from the start of the net block
   int nf[MAXS];    // fragments in stage s
-  constexpr Hx3Layout(int HT, int OT, int np)
-      : NP(np), HC((HT + 1) / 2), TL0((HT + 1) / 2 + OT), N_L0(0), NS(0), BIAS_FRAGS(((2 * HT + OT) * 16 + 255) / 256),
-        BIAS_WORDS(0), NET_WORDS(0), STAGE_FRAGS(0), off{}, nf{} {
+  constexpr Hx3Layout(int HT, int OT, int np, int depth = 1)
+      : NP(np), HC((HT + 1) / 2), TL0((HT + 1) / 2 + OT), N_L0(0), NS(0), BIAS_FRAGS((((depth + 1) * HT + OT) * 16 + 255) / 256),
+        BIAS_WORDS(0), NET_WORDS(0), STAGE_FRAGS(0), DEPTH(depth), CG(1), N_OUT(0), off{}, nf{} {
     BIAS_WORDS = BIAS_FRAGS * 256;
     N_L0 = (HT + TL0 - 1) / TL0;
+    CG = TL0 / OT;
     int s = 0, w = BIAS_WORDS;
     for (int i = 0; i < N_L0; ++i) {
       const int t0 = i * TL0;
       const int cnt = (HT - t0 < TL0) ? HT - t0 : TL0;
       off[s] = w; nf[s] = NP * cnt; w += nf[s] * 256; ++s;
     }
-    for (int u = 0; u < HT; ++u) {
-      off[s] = w; nf[s] = NP * HC + ((u % 2 == 0 && u >= 2) ? NP * OT : 0); w += nf[s] * 256; ++s;
+    for (int j = 1; j <= depth; ++j)
+      for (int u = 0; u < HT; ++u) {
+        off[s] = w; nf[s] = NP * HC + ((j == depth && u % 2 == 0 && u >= 2) ? NP * OT : 0); w += nf[s] * 256; ++s;
+      }
+    if (depth >= 1) {
+      off[s] = w; nf[s] = NP * OT; w += nf[s] * 256; ++s;
+    } else {
+      N_OUT = (HC + CG - 1) / CG;
+      for (int k = 0; k < N_OUT; ++k) {
+        const int cnt = (HC - k * CG < CG) ? HC - k * CG : CG;
+        off[s] = w; nf[s] = NP * OT * cnt; w += nf[s] * 256; ++s;
+      }
     }
-    off[s] = w; nf[s] = NP * OT; w += nf[s] * 256; ++s;
     NS = s;
     NET_WORDS = w;
     for (int k = 0; k < s; ++k) STAGE_FRAGS = nf[k] > STAGE_FRAGS ? nf[k] : STAGE_FRAGS;
   }
 };
 
-template <int HT, int OT, int NP>
+template <int HT, int OT, int NP, int DEPTH>
 struct Hx3LayoutOf {
-  static constexpr Hx3Layout value = Hx3Layout(HT, OT, NP);
+  static constexpr Hx3Layout value = Hx3Layout(HT, OT, NP, DEPTH);
 };
 
 // Waves per workgroup: 8 (two per SIMD, 256 registers each) unless the register-resident hidden layer of a wave
 // (HC chunks x NT tiles x NP pieces x 4 registers) needs the 512-register budget of one wave per SIMD.
-constexpr int hx3_reg_estimate(int HT, int OT, int NT, int prec, int kind, int act_a, int act_b) {
+constexpr int hx3_reg_estimate(int HT, int OT, int NT, int prec, int kind, int act_a, int act_b, int depth = 1) {
   const int np = hx3_pieces(prec);
   const int hc = (HT + 1) / 2;
   const int nn = kind == GBNF_KIND_REALNVP ? 2 : 1;
   const int relu = (act_a != GBNF_ACT_TANH || act_b != GBNF_ACT_TANH) ? 28 : 0;   // measured: ReLU / per-step variants keep more values live
   const int accs = np == 3 ? 3 : 1;                    // running sums per output tile (Products<NP>::NACC)
-  return hc * NT * np * 4 + (nn + accs - 1) * OT * NT * 4 + NT * 4 * (1 + accs) + 2 * NT * np * 4 + 3 * np * 4 + 36 + relu;
+  // (a second hidden layer keeps the first one's activations AND its own, both as B operands)
+  return (depth == 2 ? 2 : 1) * hc * NT * np * 4 + (nn + accs - 1) * OT * NT * 4 + NT * 4 * (1 + accs) + 2 * NT * np * 4 + 3 * np * 4 + 36 + relu;
 }
-constexpr int hx3_waves(int HT, int OT, int NT, int prec, int kind, int act_a, int act_b) {
+constexpr int hx3_waves(int HT, int OT, int NT, int prec, int kind, int act_a, int act_b, int depth = 1) {
 #ifdef GBNF_HX3_FORCE_WAVES       // experiment knob: 4 = two independent 4-wave workgroups per CU (where registers and LDS allow)
-  return hx3_reg_estimate(HT, OT, NT, prec, kind, act_a, act_b) <= 248 ? GBNF_HX3_FORCE_WAVES : 4;
+  return hx3_reg_estimate(HT, OT, NT, prec, kind, act_a, act_b, depth) <= 248 ? GBNF_HX3_FORCE_WAVES : 4;
 #else
-  return hx3_reg_estimate(HT, OT, NT, prec, kind, act_a, act_b) <= 248 ? 8 : 4;
+  return hx3_reg_estimate(HT, OT, NT, prec, kind, act_a, act_b, depth) <= 248 ? 8 : 4;
 #endif
 }
 // minimum waves per SIMD the kernel is compiled for (the register budget): 2 (256 registers) or 1 (512)
-constexpr int hx3_waves_per_simd(int HT, int OT, int NT, int prec, int kind, int act_a, int act_b) {
-  return hx3_reg_estimate(HT, OT, NT, prec, kind, act_a, act_b) <= 248 ? 2 : 1;
+constexpr int hx3_waves_per_simd(int HT, int OT, int NT, int prec, int kind, int act_a, int act_b, int depth = 1) {
+  return hx3_reg_estimate(HT, OT, NT, prec, kind, act_a, act_b, depth) <= 248 ? 2 : 1;
 }
 // Samples per wave actually compiled for a requested NT: 32-sample waves (NT = 2) of the widest geometries would
 // spill even with one wave per SIMD; their NT = 2 entry runs the 16-sample kernel.
-constexpr int hx3_eff_nt(int HT, int OT, int NT, int prec, int kind, int act_a, int act_b) {
-  return (NT == 2 && hx3_reg_estimate(HT, OT, 2, prec, kind, act_a, act_b) > 300) ? 1 : NT;
+constexpr int hx3_eff_nt(int HT, int OT, int NT, int prec, int kind, int act_a, int act_b, int depth = 1) {
+  return (NT == 2 && hx3_reg_estimate(HT, OT, 2, prec, kind, act_a, act_b, depth) > 300) ? 1 : NT;
 }
 
 // ---- operand splitting ----------------------------------------------------------------------------------------
@@ -205,16 +219,17 @@ __device__ __forceinline__ void wait_vmcnt(int n) {
   else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
 }
 
-template <int KIND, int HT, int OT, int NT, int ACTA, int ACTB, int PREC, int WV>
-__global__ void __launch_bounds__(64 * WV, hx3_waves_per_simd(HT, OT, NT, PREC, KIND, ACTA, ACTB))
+template <int KIND, int HT, int OT, int NT, int ACTA, int ACTB, int PREC, int WV, int DEPTH>
+__global__ void __launch_bounds__(64 * WV, hx3_waves_per_simd(HT, OT, NT, PREC, KIND, ACTA, ACTB, DEPTH))
 flow_kernel_hx3(const FlowLaunch p) {
+  static_assert(DEPTH >= 0 && DEPTH <= 2, "coupling_network_depth 0, 1 or 2");
   constexpr int WAVES = WV;
   constexpr int NP = hx3_pieces(PREC);
   constexpr int NPROD = Products<NP>::N;
   using Acc = AccT<Products<NP>::NACC>;
   constexpr int ZS = 16 * NT + 1;
   constexpr int NNETS = (KIND == GBNF_KIND_REALNVP) ? 2 : 1;
-  using LT = Hx3LayoutOf<HT, OT, NP>;          // LT::value: the layout (a static member: usable inside the lambdas below)
+  using LT = Hx3LayoutOf<HT, OT, NP, DEPTH>;          // LT::value: the layout (a static member: usable inside the lambdas below)
   constexpr int HC = LT::value.HC;
   constexpr int STEP_WORDS = SMALL_WORDS + NNETS * LT::value.NET_WORDS;
   constexpr int STAGE_WORDS = LT::value.STAGE_FRAGS * 256;
@@ -568,11 +583,17 @@ flow_kernel_hx3(const FlowLaunch p) {
         }
       };
 
-      u32x4 hB[HC][NT][NP];       // layer-0 output = B operands of the hidden layer
+      // layer-0 output = B operands of the first hidden layer (DEPTH == 0: of the output layer); with two hidden layers
+      // the first one's output goes to the second set
+      constexpr int NHB = DEPTH == 2 ? 2 : 1;
+      u32x4 hBs[NHB][HC][NT][NP];
+      auto& hB = hBs[0];
 #pragma unroll
-      for (int nt = 0; nt < NT; ++nt)         // phantom half of an odd tile count stays zero
+      for (int b = 0; b < NHB; ++b)
 #pragma unroll
-        for (int k = 0; k < NP; ++k) hB[HC - 1][nt][k] = u32x4{0, 0, 0, 0};
+        for (int nt = 0; nt < NT; ++nt)         // phantom half of an odd tile count stays zero
+#pragma unroll
+          for (int k = 0; k < NP; ++k) hBs[b][HC - 1][nt][k] = u32x4{0, 0, 0, 0};
 
       // ---- layer 0: tile t = W1[tile t] . z  (one k = 32 chunk); the activation + split of tile t-1 shares its region
       {
@@ -601,7 +622,7 @@ flow_kernel_hx3(const FlowLaunch p) {
           if (sI == 0) {
 #pragma unroll
             for (int o = 0; o < OT; ++o) {
-              const f32x4 b = ldb(2 * HT + o);
+              const f32x4 b = ldb((DEPTH + 1) * HT + o);
 #pragma unroll
               for (int nt = 0; nt < NT; ++nt) out[o][nt].init(b);
             }
@@ -651,14 +672,105 @@ flow_kernel_hx3(const FlowLaunch p) {
       // ---- hidden layer, one 16-unit output tile per stage.  Tile u-1 is activated/split during pass u
       //      (one register pair per chunk region); an output-layer chunk (two hidden tiles = k 32) is
       //      consumed in the pass after its second tile.
-      {
+      if constexpr (DEPTH == 0) {
+        // ---- no hidden layer: the output layer contracts layer 0's activations, CG chunks (CG * OT tiles) per stage
+        constexpr int CG = LT::value.CG, N_OUT = LT::value.N_OUT;
+        auto out_stage = [&](auto k_c) {
+          constexpr int k = decltype(k_c)::value;
+          constexpr int c0 = k * CG;
+          constexpr int cnt = (HC - c0 < CG) ? HC - c0 : CG;
+          constexpr int NU = cnt * OT;
+          if constexpr (k + 1 < N_OUT) {
+            issue(std::integral_constant<int, LT::value.nf[LT::value.N_L0 + k + 1]>{}, gs + 1);
+          } else {
+            if ((net + 1 < NNETS) || (step + 1 < p.n_steps)) {
+              if (net + 1 == NNETS) next_src += SMALL_WORDS;     // the next step's tables sit in front of its first net
+              issue_net_start(gs + 1);
+            }
+          }
+          Unit A[3];
+          A[0] = N0;
+          if (NU > 1) A[1] = N1;
+#pragma unroll
+          for (int n = 0; n < NU; ++n) {
+            if (n + 2 < NU) load_unit(A[(n + 2) % 3], n + 2);
+            if (n == NU - 1) stage_finish(4, true);
+            mac(A[n % 3], hB[c0 + n / OT], out[n % OT]);
+            __builtin_amdgcn_sched_barrier(0);
+          }
+          stage_finish(4, false);
+        };
+        static_assert(N_OUT <= 4, "output stages of a depth-0 net");
+        out_stage(std::integral_constant<int, 0>{});
+        if constexpr (N_OUT > 1) out_stage(std::integral_constant<int, 1>{});
+        if constexpr (N_OUT > 2) out_stage(std::integral_constant<int, 2>{});
+        if constexpr (N_OUT > 3) out_stage(std::integral_constant<int, 3>{});
+#pragma unroll
+        for (int o = 0; o < OT; ++o)
+#pragma unroll
+          for (int nt = 0; nt < NT; ++nt) outF[o][nt] = out[o][nt].total();
+        st.mark(4);
+      } else {
         f32x4 pre[NT];
+        f32x4 bias;
+        if constexpr (DEPTH == 2) {
+          // ---- first of two hidden layers: like the passes below, but tile u-1 (activated during pass u) becomes a B
+          //      operand of the second hidden layer instead of being consumed by the output layer.  Fully unrolled: the
+          //      destination register of an activation must be a compile-time index.
+          bias = ldb(HT);
+          auto mid_act = [&](auto t_c, int n) {           // register pairs n, n + HC, ... of tile t (held in pre)
+            constexpr int t = decltype(t_c)::value;
+#pragma unroll
+            for (int q = n; q < 2 * NT; q += HC) {
+              const int nt = q >> 1, hp = q & 1;
+              unsigned pc[NP];
+              act_split(pre[nt], hp, nt, pc);
+#pragma unroll
+              for (int k = 0; k < NP; ++k) hBs[NHB - 1][t >> 1][nt][k][2 * (t & 1) + hp] = pc[k];
+            }
+          };
+          auto mid_pass = [&](auto u_c) {
+            constexpr int u = decltype(u_c)::value;
+            issue(std::integral_constant<int, NP * HC>{}, gs + 1);     // the next pass of this layer or pass 0 of the next one
+            Unit A[3];
+            A[0] = N0;
+            A[1] = N1;
+            const f32x4 bias_next = ldb(HT + (u + 1 < HT ? u + 1 : u));
+            Acc acc[NT];
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) acc[nt].init(bias);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int n = 0; n < HC; ++n) {
+              if (n + 2 < HC) load_unit(A[(n + 2) % 3], n + 2);
+              if (n == HC - 1) stage_finish(2, true);
+              if constexpr (u > 0) mid_act(std::integral_constant<int, (u > 0 ? u - 1 : 0)>{}, n);
+              mac(A[n % 3], hB[n], acc);
+              __builtin_amdgcn_sched_barrier(0);
+            }
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) pre[nt] = acc[nt].total();
+            bias = bias_next;
+            stage_finish(2, false);
+          };
+          auto mid_all = [&](auto self, auto u_c) -> void {
+            constexpr int u = decltype(u_c)::value;
+            if constexpr (u < HT) {
+              mid_pass(u_c);
+              self(self, std::integral_constant<int, u + 1>{});
+            }
+          };
+          mid_all(mid_all, std::integral_constant<int, 0>{});
+#pragma unroll
+          for (int n = 0; n < HC; ++n) mid_act(std::integral_constant<int, HT - 1>{}, n);
+        }
+        auto& hBin = hBs[NHB - 1];                 // the B operands of the last hidden layer
         u32x4 hO[NT][NP];
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
           for (int k = 0; k < NP; ++k) hO[nt][k] = u32x4{0, 0, 0, 0};
-        f32x4 bias = ldb(HT);
+        bias = ldb(DEPTH * HT);
         // PREV: 0 = no previous tile (u = 0); 1 = tile u-1 is the FIRST half of its output-layer chunk
         // (u odd); 2 = it is the SECOND half and chunk (u-2)/2 is consumed at the end of this pass (u even >= 2)
         auto pass = [&](int u, auto prev_c, auto last_c) {
@@ -671,7 +783,7 @@ flow_kernel_hx3(const FlowLaunch p) {
           Unit A[3];
           A[0] = N0;
           A[1] = N1;
-          const f32x4 bias_next = ldb(HT + (u + 1 < HT ? u + 1 : u));
+          const f32x4 bias_next = ldb(DEPTH * HT + (u + 1 < HT ? u + 1 : u));
           Acc acc[NT];
 #pragma unroll
           for (int nt = 0; nt < NT; ++nt) acc[nt].init(bias);
@@ -692,7 +804,7 @@ flow_kernel_hx3(const FlowLaunch p) {
                   for (int k = 0; k < NP; ++k) hO[nt][k][(PREV == 2 ? 2 : 0) + hp] = pc[k];
                 }
               }
-              mac(A[n % 3], hB[n], acc);
+              mac(A[n % 3], hBin[n], acc);
             } else {
               // output-layer chunk (u-2)/2 = hidden tiles (u-2, u-1): its tiles follow the hidden row
               mac(A[n % 3], hO, out[n - HC]);
@@ -910,13 +1022,13 @@ inline size_t flow_hx3_lds_bytes(int n_steps, int nt, int waves, int stage_frags
   return (tables + 2 * (size_t)bias_frags * 256 + (size_t)ring * stage_frags * 256 + (size_t)waves * (d + 1) * (16 * nt + 1)) * 4;
 }
 // hx3 variants are keyed like the f32 ones with the lmid-independent fields fixed:
-//   VariantKey{kind, ht, /*ksl*/ -3 (f16x3) | -6 (bf16x6), /*ks1*/ 0, ot, nt, /*lmid*/ 1, act_a, act_b}
+//   VariantKey{kind, ht, /*ksl*/ -3 (f16x3) | -6 (bf16x6), /*ks1*/ 0, ot, nt, /*lmid*/ depth (0, 1, 2), act_a, act_b}
 // The launcher sizes its own grid (it knows its waves per workgroup) and ring; the `grid` argument is ignored.
 // An 8-wave kernel whose register budget is 256 also exists as a 4-wave workgroup: when two of those fit a CU's LDS
 // (small d / K / hidden width) they run instead, staggered by about half a flow step (FlowLaunch::stagger).
-template <int KIND, int HT, int OT, int ENT, int ACTA, int ACTB, int PREC, int WV>
+template <int KIND, int HT, int OT, int ENT, int ACTA, int ACTB, int PREC, int WV, int DEPTH>
 static hipError_t hx3_launch_wv(FlowLaunch p, bool staggered, hipStream_t s) {
-  constexpr Hx3Layout L(HT, OT, hx3_pieces(PREC));
+  constexpr Hx3Layout L(HT, OT, hx3_pieces(PREC), DEPTH);
   p.n_tiles = (int32_t)((p.n + 16 * ENT - 1) / (16 * ENT));
   /* per-step tables in LDS when they fit beside the staging slots and the Z tiles, else read from the blob */
   const size_t budget = staggered ? 80 * 1024 : 160 * 1024;
@@ -937,22 +1049,22 @@ static hipError_t hx3_launch_wv(FlowLaunch p, bool staggered, hipStream_t s) {
   }
   static bool attr_set = false;
   if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute((const void*)flow_kernel_hx3<KIND, HT, OT, ENT, ACTA, ACTB, PREC, WV>,
+    hipError_t e = hipFuncSetAttribute((const void*)flow_kernel_hx3<KIND, HT, OT, ENT, ACTA, ACTB, PREC, WV, DEPTH>,
                                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e != hipSuccess) return e;
     attr_set = true;
   }
-  hipLaunchKernelGGL((flow_kernel_hx3<KIND, HT, OT, ENT, ACTA, ACTB, PREC, WV>), dim3((unsigned)grid), dim3(64 * WV), lds, s, p);
+  hipLaunchKernelGGL((flow_kernel_hx3<KIND, HT, OT, ENT, ACTA, ACTB, PREC, WV, DEPTH>), dim3((unsigned)grid), dim3(64 * WV), lds, s, p);
   return hipGetLastError();
 }
 
-#define GBNF_INSTANTIATE_HX3(KIND, HT, OT, NT, ACTA, ACTB, PREC)                                            \
+#define GBNF_INSTANTIATE_HX3(KIND, HT, OT, NT, ACTA, ACTB, PREC, DEPTH)                                     \
   namespace gbnf {                                                                                          \
-  static hipError_t launch_hx3_##KIND##_##HT##_##OT##_##NT##_##ACTA##_##ACTB##_##PREC(const FlowLaunch& p0, \
+  static hipError_t launch_hx3_##KIND##_##HT##_##OT##_##NT##_##ACTA##_##ACTB##_##PREC##_##DEPTH(const FlowLaunch& p0, \
                                                                                      unsigned, hipStream_t s) { \
-    constexpr Hx3Layout L(HT, OT, hx3_pieces(PREC));                                                        \
-    constexpr int ENT = hx3_eff_nt(HT, OT, NT, PREC, KIND, ACTA, ACTB);                                     \
-    constexpr int WAVES = hx3_waves(HT, OT, ENT, PREC, KIND, ACTA, ACTB);                                   \
+    constexpr Hx3Layout L(HT, OT, hx3_pieces(PREC), DEPTH);                                                 \
+    constexpr int ENT = hx3_eff_nt(HT, OT, NT, PREC, KIND, ACTA, ACTB, DEPTH);                              \
+    constexpr int WAVES = hx3_waves(HT, OT, ENT, PREC, KIND, ACTA, ACTB, DEPTH);                            \
     if constexpr (WAVES == 8) {                                                                             \
       static const bool no_pairs = [] { const char* e = getenv("GBNF_NO_WG_PAIRS"); return e && atoi(e) != 0; }(); \
       /* two 4-wave workgroups per CU where they fit: 80 KB each, tables included */                        \
@@ -960,14 +1072,14 @@ static hipError_t hx3_launch_wv(FlowLaunch p, bool staggered, hipStream_t s) {
                                             p0.n_steps <= LDS_TABLE_STEPS) <= 80 * 1024;                    \
       const long long waves_total = (long long)((p0.n + 16 * ENT - 1) / (16 * ENT)) * p0.n_comp * p0.n_batches; \
       if (fits4 && !no_pairs && !p0.repair && waves_total >= 2048)                                          \
-        return hx3_launch_wv<KIND, HT, OT, ENT, ACTA, ACTB, PREC, 4>(p0, true, s);                          \
+        return hx3_launch_wv<KIND, HT, OT, ENT, ACTA, ACTB, PREC, 4, DEPTH>(p0, true, s);                   \
     }                                                                                                       \
-    return hx3_launch_wv<KIND, HT, OT, ENT, ACTA, ACTB, PREC, WAVES>(p0, false, s);                         \
+    return hx3_launch_wv<KIND, HT, OT, ENT, ACTA, ACTB, PREC, WAVES, DEPTH>(p0, false, s);                  \
   }                                                                                                         \
-  static const int reg_hx3_##KIND##_##HT##_##OT##_##NT##_##ACTA##_##ACTB##_##PREC =                         \
-      (register_variant(VariantKey{KIND, HT, (PREC) == 0 ? -3 : -6, 0, OT, NT, 1, ACTA, ACTB},              \
-                        launch_hx3_##KIND##_##HT##_##OT##_##NT##_##ACTA##_##ACTB##_##PREC,                  \
-                        "flow_kernel_hx3<" #KIND "," #HT "," #OT "," #NT "," #ACTA "," #ACTB "," #PREC ">"),\
+  static const int reg_hx3_##KIND##_##HT##_##OT##_##NT##_##ACTA##_##ACTB##_##PREC##_##DEPTH =               \
+      (register_variant(VariantKey{KIND, HT, (PREC) == 0 ? -3 : -6, 0, OT, NT, DEPTH, ACTA, ACTB},          \
+                        launch_hx3_##KIND##_##HT##_##OT##_##NT##_##ACTA##_##ACTB##_##PREC##_##DEPTH,        \
+                        "flow_kernel_hx3<" #KIND "," #HT "," #OT "," #NT "," #ACTA "," #ACTB "," #PREC "," #DEPTH ">"),\
        0);                                                                                                  \
   }
 

@@ -40,9 +40,9 @@ def test_hip_matches_reference_golden(name, math, golden_case, dev):
     try:
         mix, flows = _mixture(g.specs, math)
     except native.GbnfError:
-        skw = g.cfg.get("synth_kw", {})    # depth 0 / 2 and ResidualNets: exact-f32 kernel only
-        assert math in ("f16x3", "bf16x6") and (skw.get("depth", 1) != 1 or skw.get("coupling_network") == "residual")
-        pytest.skip("split kernels: TanhNet / ReLUNet of depth 1 only; this fixture runs on the exact-f32 kernel")
+        skw = g.cfg.get("synth_kw", {})    # ResidualNets: exact-f32 kernel only
+        assert math in ("f16x3", "bf16x6") and skw.get("coupling_network") == "residual"
+        pytest.skip("split kernels: TanhNet / ReLUNet of depth 0 / 1 / 2; this fixture (ResidualNet) runs on the exact-f32 kernel")
     if stress and math == "default":             # the probe must have moved the ill-conditioned component off f16x3
         assert flows[1].info().math_mode == native.MATH["bf16x6"] and flows[1].info().probe_rel_err > 2.5e-6
     if g.base is not None:
@@ -341,16 +341,20 @@ def test_mixture_lse_edge_cases(dev):
 
 
 def test_default_math_mode_and_mode_agreement(dev):
-    """Default = split-f16 kernel where compiled (depth 1); both modes agree to ~1e-6 on the BASELINE shape."""
+    """Default = split-f16 kernel where compiled (TanhNet / ReLUNet of depth 0, 1, 2); ResidualNets stay on the exact-f32
+    kernel and refuse the split modes; both modes agree to ~1e-6 on the BASELINE shape."""
     import torch
     from gbnf_amd import native, synth
     spec = synth.synth_glow_spec(43, 215, 5, seed=1000)
     assert native.NativeFlow(spec).info().math_mode == native.MATH["f16x3"]
     assert native.NativeFlow(spec, math="f32").info().math_mode == native.MATH["f32"]
-    deep = synth.synth_glow_spec(43, 64, 3, depth=2, seed=3)
-    assert native.NativeFlow(deep).info().math_mode == native.MATH["f32"]        # falls back loudly-documented
+    for depth in (0, 2):
+        deep = synth.synth_glow_spec(43, 64, 3, depth=depth, seed=3)
+        assert native.NativeFlow(deep).info().math_mode == native.MATH["f16x3"]
+    res = synth.synth_realnvp_spec(21, 64, 3, coupling_network="residual", seed=3)
+    assert native.NativeFlow(res).info().math_mode == native.MATH["f32"]
     with pytest.raises(native.GbnfError):
-        native.NativeFlow(deep, math="f16x3")
+        native.NativeFlow(res, math="f16x3")
     x = torch.from_numpy(synth.synth_batch(4096, 43, seed=9)).to(dev)
     a = native.NativeFlow(spec, math="f32").forward(x, want_ll=True)
     b = native.NativeFlow(spec, math="f16x3").forward(x, want_ll=True)

@@ -26,6 +26,8 @@ def _cases():
         else:
             extra = dict(batch_norm=bool(rng.randint(2)), flip_init=int(rng.randint(2)))
             act = str(rng.choice(["tanh", "relu", "mixed"]))
+        if k % 4 == 3:                   # every fourth case: coupling_network_depth 0 or 2
+            extra["depth"] = int(rng.choice([0, 2]))
         cases.append((kind, d, h, K, n, act, extra, 500 + k))
     return cases
 
@@ -55,7 +57,7 @@ def test_random_shape_against_oracle(kind, d, h, K, n, act, extra, seed):
 
 # 256 < h <= 512 beyond depth 1: the reference's CLI reaches these with --h_size_factor on MINIBOONE / BSDS300
 # (utils/load_data.py:64-65) together with --coupling_network_depth 0 / 2 or --coupling_network residual
-# (models/layers.py:208-301).  They run on the 32-tile exact-f32 variants (16-sample waves).
+# (models/layers.py:208-301).  Exact-f32: the 32-tile variants (16-sample waves); depth 0 / 2 also on the split kernels.
 WIDE_CASES = [
     ("glow", 43, 430, 0, "tanh", dict(coupling="affine", permutation="shuffle")),
     ("glow", 43, 430, 2, "tanh", dict(coupling="affine", permutation="shuffle")),
@@ -81,12 +83,15 @@ def test_wide_hidden_layers_beyond_depth_one(kind, d, h, depth, act, extra):
     x = synth.synth_batch(100, d, seed=h)
     zr, lr = oracle.component_forward(spec, x)
     llr = oracle.component_log_prob(spec, x)
-    flow = native.NativeFlow(spec)                      # default mode: lands on the exact-f32 kernel here
-    assert flow.info().math_mode == native.MATH["f32"]
-    z, ldj, ll = flow.forward(torch.from_numpy(x).to(dev), want_ll=True)
-    assert rel_err(ll.cpu().numpy(), llr) < LL_RTOL
-    assert float(np.max(np.abs(ldj.cpu().numpy() - lr) / np.maximum(np.abs(llr), 1.0))) < LL_RTOL
-    np.testing.assert_allclose(z.cpu().numpy(), zr, rtol=0, atol=2e-5 * max(1.0, np.abs(zr).max()))
-    # and back: the z -> x direction runs on the same variants
+    xd = torch.from_numpy(x).to(dev)
+    modes = ["f32"] if act == "residual" else ["f32", "f16x3", "bf16x6", "default"]
+    for math in modes:
+        z, ldj, ll = native.NativeFlow(spec, math=math).forward(xd, want_ll=True)
+        assert rel_err(ll.cpu().numpy(), llr) < LL_RTOL, (math, rel_err(ll.cpu().numpy(), llr))
+        assert float(np.max(np.abs(ldj.cpu().numpy() - lr) / np.maximum(np.abs(llr), 1.0))) < LL_RTOL, math
+        np.testing.assert_allclose(z.cpu().numpy(), zr, rtol=0, atol=2e-5 * max(1.0, np.abs(zr).max()), err_msg=math)
+    # and back: the z -> x direction runs on the exact-f32 variants
+    flow = native.NativeFlow(spec, math="f32")
+    z = flow.forward(xd)[0]
     xb, ldj_inv = flow.inverse(z)
     np.testing.assert_allclose(xb.cpu().numpy(), x, rtol=0, atol=1e-4 * max(1.0, np.abs(x).max()))

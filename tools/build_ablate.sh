@@ -16,12 +16,12 @@ for what in $WHATS; do
     done
   fi
   for nt in 1 2; do
-    hipcc $F $defs -DGBNF_V_ARGS=0,14,3,$nt,0,0,0 -c variant_hx3.hip -o $OUT/${what}_$nt.o &
+    hipcc $F $defs -DGBNF_V_ARGS=0,14,3,$nt,0,0,0,1 -c variant_hx3.hip -o $OUT/${what}_$nt.o &
   done
 done
 wait
 for what in $WHATS; do
   hipcc --offload-arch=gfx950 -shared -fPIC -o ../../tools/ablate/libgbnf_hip_$what.so obj/gbnf_api.o obj/gbnf_train.o obj/gbnf_image.o \
-      $OUT/${what}_1.o $OUT/${what}_2.o obj/v_hx3_0_14_3_1_0_0_1.o obj/v_hx3_0_14_3_2_0_0_1.o
+      $OUT/${what}_1.o $OUT/${what}_2.o obj/v_hx3_0_14_3_1_0_0_1_1.o obj/v_hx3_0_14_3_2_0_0_1_1.o
 done
 echo "built: $WHATS"
