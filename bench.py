@@ -43,7 +43,9 @@ sys.path.insert(0, REPO)
 F32_MFMA_PEAK_TFLOPS = 157.3   # /opt/skills/guides/MI355X_MICROARCH.md: dense f32 matrix peak
 F16_MFMA_PEAK_TFLOPS = 2500.0  # same guide: dense bf16/f16 matrix peak (no sparsity)
 HBM_PEAK_GBS = 8000.0          # same guide: HBM3E spec peak
-GROUP = 16                     # batches per flow launch / all-gather / recursion launch, for every N
+GROUP = 32                     # batches per flow launch / all-gather / recursion launch, for every N (at 8 GPUs a rank
+                               # holds one component: a 16-batch launch is a single round of workgroups, 123 us, and the
+                               # per-group host + collective cost shows; 32 measured +10 % there, +1-3 % at N = 1)
 
 CONFIGS = {
     # name: (kind, d, h, K, default C, default batch)
@@ -167,8 +169,8 @@ def self_launch(args):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=1000)
-    ap.add_argument("--warmup", type=int, default=50)
+    ap.add_argument("--steps", type=int, default=4096)
+    ap.add_argument("--warmup", type=int, default=64)
     ap.add_argument("--prewarm", type=float, default=0.3, help="untimed launches before the warm-up steps (clock ramp): 2000 steps per unit, i.e. about this many seconds on one GPU")
     ap.add_argument("--config", default="miniboone_glow", choices=sorted(CONFIGS))
     ap.add_argument("--batch", type=int, default=None)
@@ -179,7 +181,7 @@ def main():
     ap.add_argument("--force-gather", action="store_true",
                     help="EMULATION aid: run the RCCL all-gather leg with one rank (with --components k: the per-rank load "
                          "of an 8/k-GPU run on one GPU; the cross-GPU hop itself is not exercised)")
-    ap.add_argument("--group", type=int, default=GROUP, help=f"batches per launch / all-gather (default {GROUP}, max 16)")
+    ap.add_argument("--group", type=int, default=GROUP, help=f"batches per launch / all-gather (default {GROUP}, max 32)")
     ap.add_argument("--no-extra-legs", action="store_true", help="skip the f32-exact and group-1 legs of the N=1 line")
     args = ap.parse_args()
 
@@ -224,7 +226,7 @@ def main():
     parts = sharded.partition(C, world)
     c0, c1 = parts[rank]
     rho = torch.from_numpy(rho_np).to(dev)
-    S = max(1, min(args.group, 16))
+    S = max(1, min(args.group, 32))
     xs_np = [x_np] + [synth.synth_batch(B, d, seed=100 + s) for s in range(1, S)]   # S distinct resident batches
     xs = [torch.from_numpy(a).to(dev) for a in xs_np]
 
@@ -233,6 +235,9 @@ def main():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
+
+    MAX_TIMED_LAUNCHES = 48      # launches bracketed by timing events (the average is reported as roofline.launch_ms): event
+                                 # pairs on every group of a long run cost the host more than the group's own launches
 
     def timed_run(math, group, steps, warmup, prewarm, want_gather_times=False):
         """The pipeline on this rank's components in `math` mode, groups of `group` batches: returns timing + the handles' info."""
@@ -247,7 +252,7 @@ def main():
             while done < n_steps:
                 k = min(group, n_steps - done)
                 ev = None
-                if events is not None and k == group:
+                if events is not None and k == group and len(events) < MAX_TIMED_LAUNCHES:
                     ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
                     events.append(ev)
                 last = pipe.submit(xs[:k], ev)
@@ -260,6 +265,8 @@ def main():
         # the same collectives)
         run(int(prewarm * 2000) // group * group)
         run(warmup)
+        if steps % group:           # the timed loop ends on a partial group: bind that launch shape now (untimed), every rank alike
+            pipe.submit(xs[:steps % group])
         barrier()
         events = []
         if want_gather_times and gather:

@@ -73,7 +73,7 @@ struct NetLayoutRT {
 constexpr bool lmid_is_residual(int lmid) { return lmid >= 10; }
 constexpr int lmid_mid_layers(int lmid) { return lmid >= 10 ? 2 * (lmid - 10) : lmid; }
 
-constexpr int MAX_BATCHES = 16;  // batches one launch can serve
+constexpr int MAX_BATCHES = 32;  // batches one launch can serve
 
 struct FlowLaunch {
   const uint32_t* const* blobs;  // device array: packed parameter blob per component

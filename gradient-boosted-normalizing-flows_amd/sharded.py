@@ -225,7 +225,7 @@ class GroupPipeline:
             self.post.wait_event(self.flow_done[q])
             with torch.cuda.stream(self.post):
                 ev = None
-                if self.gather_events is not None:
+                if self.gather_events is not None and len(self.gather_events) < 48:
                     ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
                     ev[0].record(self.post)
                 self.dist.all_gather_into_tensor(full[q], local[q], group=self.pg)

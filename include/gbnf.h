@@ -191,7 +191,7 @@ int gbnf_mixture_component_log_prob(const gbnf_mixture* mix, const float* x, int
 int gbnf_mixture_component_log_prob_strided(const gbnf_mixture* mix, const float* x, int64_t n,
                                             int32_t c_begin, int32_t c_end, float* ll, int64_t ll_row_stride,
                                             void* stream);
-/* Same for a GROUP of up to 16 independent batches in ONE launch: xs is a HOST array of n_batches DEVICE pointers to
+/* Same for a GROUP of up to 32 independent batches in ONE launch: xs is a HOST array of n_batches DEVICE pointers to
  * (n,d) inputs; batch b's log-densities go to columns [b*n, (b+1)*n) of the (c_end-c_begin, >= n_batches*n) table.
  * (A rank that holds few components does not fill the GPU with one batch; serving several batches per launch does,
  * and one all-gather + one recursion launch then cover the whole group.) */

@@ -9,11 +9,11 @@ python tools/bench_image.py --batch 256 --cpu-seconds 5 > $O/image_n256.json 2>/
 python tools/bench_image.py --batch 64 --cpu-seconds 0 > $O/image_n64.json 2>/dev/null
 python tools/bench_train.py --batch 4096 --cpu-steps 0 > $O/train_n4096.json 2>/dev/null
 python tools/bench_train.py --batch 65536 --cpu-steps 0 > $O/train_n65536.json 2>/dev/null
-rocprofv3 --kernel-trace --stats -d $O/prof_stats -o stats --output-format csv -- python3 bench.py --cpu-seconds 0 --steps 320 --warmup 32 --prewarm 0.05 --no-extra-legs > $O/prof_stats.log 2>&1
-rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $O/pmc_fetch -o fetch --output-format csv -- python3 bench.py --cpu-seconds 0 --steps 64 --warmup 8 --prewarm 0.01 --no-extra-legs > $O/pmc_fetch.log 2>&1
-rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $O/pmc_write -o write --output-format csv -- python3 bench.py --cpu-seconds 0 --steps 64 --warmup 8 --prewarm 0.01 --no-extra-legs > $O/pmc_write.log 2>&1
-rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_SCA -d $O/pmc_sq1 -o sq1 --output-format csv -- python3 bench.py --cpu-seconds 0 --steps 64 --warmup 8 --prewarm 0.01 --no-extra-legs > $O/pmc_sq1.log 2>&1
-rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_LDS SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_WAIT_INST_LDS -d $O/pmc_sq2 -o sq2 --output-format csv -- python3 bench.py --cpu-seconds 0 --steps 64 --warmup 8 --prewarm 0.01 --no-extra-legs > $O/pmc_sq2.log 2>&1
+rocprofv3 --kernel-trace --stats -d $O/prof_stats -o stats --output-format csv -- python3 bench.py --cpu-seconds 0 --steps 640 --warmup 64 --prewarm 0.05 --no-extra-legs > $O/prof_stats.log 2>&1
+rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $O/pmc_fetch -o fetch --output-format csv -- python3 bench.py --cpu-seconds 0 --steps 128 --warmup 32 --prewarm 0.01 --no-extra-legs > $O/pmc_fetch.log 2>&1
+rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $O/pmc_write -o write --output-format csv -- python3 bench.py --cpu-seconds 0 --steps 128 --warmup 32 --prewarm 0.01 --no-extra-legs > $O/pmc_write.log 2>&1
+rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_SCA -d $O/pmc_sq1 -o sq1 --output-format csv -- python3 bench.py --cpu-seconds 0 --steps 128 --warmup 32 --prewarm 0.01 --no-extra-legs > $O/pmc_sq1.log 2>&1
+rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_LDS SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_WAIT_INST_LDS -d $O/pmc_sq2 -o sq2 --output-format csv -- python3 bench.py --cpu-seconds 0 --steps 128 --warmup 32 --prewarm 0.01 --no-extra-legs > $O/pmc_sq2.log 2>&1
 for d in pmc_fetch pmc_write pmc_sq1 pmc_sq2; do python tools/pmc_summary.py $O/$d > $O/$d.txt 2>&1; done
 find $O/prof_stats -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} $O/kernel_stats.csv
 find $O -name "*.csv" -size +1M -delete
