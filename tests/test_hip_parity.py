@@ -104,7 +104,7 @@ def test_group_launch_equals_per_batch_launches(math, golden_case, dev):
         assert torch.equal(part[:, 3 * n:4 * n], mix.component_log_prob(xs[2], 2, 5))
         assert torch.isnan(part[:, :3 * n]).all() and torch.isnan(part[:, 4 * n:]).all()
     with pytest.raises(native.GbnfError):
-        mix.prepared_group_log_prob(xs * 4, torch.empty((8, 20 * 77), device=dev))(native._stream_ptr())    # > 16 batches
+        mix.prepared_group_log_prob(xs * 7, torch.empty((8, 35 * 77), device=dev))(native._stream_ptr())    # > 32 batches
 
 
 def test_deterministic_and_tile_independent(golden_case, dev):

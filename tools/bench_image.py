@@ -32,6 +32,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     ap.add_argument("--graph", action="store_true", help="capture one step in a HIP graph and replay it")
+    ap.add_argument("--no-streams", dest="streams", action="store_false",
+                    help="all components on one stream (default: one HIP stream per component, their launch chains overlap, "
+                         "as BoostedImageFlow.component_log_prob does)")
     a = ap.parse_args()
     from gbnf_amd import native, synth
     from oracle import gbnf_oracle as oracle
@@ -43,9 +46,22 @@ def main():
     rho = torch.clamp(1.0 / torch.pow(2.0, torch.arange(a.components * 1.0)), min=0.05).to(dev)
     ll = torch.empty((a.components, a.batch), dtype=torch.float32, device=dev)
 
+    streams = [torch.cuda.Stream() for _ in flows] if a.streams else None
+
     def step():
-        for c, f in enumerate(flows):
-            ll[c] = f.forward(x, noise, want_z=False)[2]
+        if streams is None:
+            for c, f in enumerate(flows):
+                ll[c] = f.forward(x, noise, want_z=False)[2]
+            return native.mixture_lse(ll, rho)
+        # the components are independent until the recursion: one stream each, so that their (latency-bound) launch
+        # chains overlap on the GPU
+        cur = torch.cuda.current_stream()
+        for c, (f, s_) in enumerate(zip(flows, streams)):
+            s_.wait_stream(cur)
+            with torch.cuda.stream(s_):
+                ll[c] = f.forward(x, noise, want_z=False)[2]
+        for s_ in streams:
+            cur.wait_stream(s_)
         return native.mixture_lse(ll, rho)
 
     for _ in range(a.warmup):
@@ -101,7 +117,7 @@ def main():
         "scaling": "strong", "vs_baseline": None, "dtype": "f32" if exact else "f16x3", "data": "synthetic",
         "config": {"workload": f"cifar_glow: 3x32x32, C={a.components} components, K={a.K} steps x L={a.L} levels, h={a.hidden}, "
                                f"invconv, affine, learn_top, batch={a.batch}, synthetic images + weights",
-                   "launch": "HIP graph replay" if a.graph else "stream launches"},
+                   "launch": ("HIP graph replay" if a.graph else "stream launches") + (", one stream per component" if a.streams else "")},
         # the coupling nets (99 % of the FLOPs) run on the split-f16 kernels img_mid_hx3 / img_last_hx3 unless GBNF_MATH=f32:
         # the peak is that of the pipe they run on; achieved = ALGORITHMIC f32 FLOPs (the f16 pipe executes 3x that)
         "roofline": {"kernel": "gbnf::img_conv_kernel (all convolutions, exact f32)" if exact else
