@@ -885,8 +885,8 @@ int gbnf_flow_info(const gbnf_flow* flow, gbnf_kernel_info* info) {
 
 namespace gbnf {
 
-// samples per wave: 32 (NT=2) once there is enough work to give every SIMD of the chip two
-// waves that way (256 CUs x 4 SIMDs x 2), otherwise 16 (NT=1) to expose more waves.
+// samples per wave: 32 (NT=2) once there is enough work to give every SIMD of the chip a wave that way (256 CUs x 4
+// SIMDs: the split kernels then run 4-wave workgroups, one or two per CU), otherwise 16 (NT=1) to expose more waves.
 static int pick_nt(int64_t n, int n_comp) {
   static const int forced = [] {
     const char* e = getenv("GBNF_FORCE_NT");   // tuning / test knob: 1 or 2
@@ -894,7 +894,8 @@ static int pick_nt(int64_t n, int n_comp) {
   }();
   if (forced == 1 || forced == 2) return forced;
   const int64_t waves32 = ((n + 31) / 32) * n_comp;
-  return waves32 >= 2048 ? 2 : 1;
+  static const int nt2_min = [] { const char* e = getenv("GBNF_NT2_MIN_WAVES"); return e ? atoi(e) : 1024; }();   // tuning knob
+  return waves32 >= nt2_min ? 2 : 1;
 }
 
 #if defined(GBNF_STAMPS) || defined(GBNF_TIMELINE)

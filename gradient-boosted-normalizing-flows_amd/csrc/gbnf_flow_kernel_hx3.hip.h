@@ -1078,7 +1078,9 @@ static hipError_t hx3_launch_wv(FlowLaunch p, bool staggered, hipStream_t s) {
       const bool fits4 = flow_hx3_lds_bytes(p0.n_steps, ENT, 4, L.STAGE_FRAGS, L.BIAS_FRAGS, p0.d, HX3_RING,  \
                                             p0.n_steps <= LDS_TABLE_STEPS) <= 80 * 1024;                    \
       const long long waves_total = (long long)((p0.n + 16 * ENT - 1) / (16 * ENT)) * p0.n_comp * p0.n_batches; \
-      if (fits4 && !no_pairs && !p0.repair && waves_total >= 2048)                                          \
+      /* from one 4-wave workgroup per CU on (1024 waves): a lone wave per SIMD runs a stage in half the time of two    \
+         sharing it (profiles/r2_ubench_pingpong.txt), so 256 such workgroups beat 128 8-wave ones on half the CUs */  \
+      if (fits4 && !no_pairs && !p0.repair && waves_total >= 1024)                                          \
         return hx3_launch_wv<KIND, HT, OT, ENT, ACTA, ACTB, PREC, 4, DEPTH>(p0, true, s);                   \
     }                                                                                                       \
     return hx3_launch_wv<KIND, HT, OT, ENT, ACTA, ACTB, PREC, WAVES, DEPTH>(p0, false, s);                  \
