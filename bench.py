@@ -13,7 +13,7 @@ net 21->215->215->44 tanh, shuffle permutation, affine coupling), batch 4096 syn
 already resident in HBM, random-init synthetic weights.  One "step" = one pass of the hot path over
 one batch: all C component flows + the mixture log-sum-exp  ->  G (N,).
 
-Consecutive batches are independent, so they are served in groups of S = 16 (the same S for every N: one flow launch,
+Consecutive batches are independent, so they are served in groups of S = 32 (the same S for every N: one flow launch,
 one all-gather, one recursion launch per group -- gbnf_amd.sharded.GroupPipeline, the class the GPU tests exercise).
 N > 1: the C components are sharded over the ranks (contiguous blocks, C/N each), x is replicated, one RCCL all-gather
 of float32[C/N, S*batch] per rank per group rebuilds (C, S*batch) before the recursion; total work is fixed =>
@@ -279,13 +279,16 @@ def main():
             t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             elapsed = float(t.item())
-        kern_ms = sum(a.elapsed_time(b) for a, b in events) / max(1, len(events))      # per full-group launch
+        per_launch = sorted(a.elapsed_time(b) for a, b in events)
+        kern_ms = sum(per_launch) / max(1, len(per_launch))      # per full-group launch (flow launch + its repair launch)
         gather_us = None
         if pipe.gather_events:
             gather_us = 1e3 * sum(a.elapsed_time(b) for a, b in pipe.gather_events) / len(pipe.gather_events)
         # batch 0 of a full group (slot 0 was written by an even group; any slot holds a complete group's result)
         G0 = pipe._buffers(group)[2][0][:B].cpu().numpy() if steps >= group else None
         return {"elapsed": elapsed, "kern_ms": kern_ms, "info": info, "G0": G0, "gather_us": gather_us,
+                "kern_ms_min": per_launch[0] if per_launch else None,
+                "kern_ms_median": per_launch[len(per_launch) // 2] if per_launch else None, "timed_launches": len(per_launch),
                 "name": MATH_NAME[info.math_mode], "keep": (flows, mix, pipe)}
 
     def roofline(r, group):
@@ -299,7 +302,11 @@ def main():
             "kernel": "gbnf::flow_kernel" if math == "f32" else "gbnf::flow_kernel_hx3",
             "bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
             "traffic": measured_traffic(args.config, B, C, group, math, world),
-            "launch_ms": r["kern_ms"], "flops_per_launch": flops, "batches_per_launch": group,
+            "launch_ms": r["kern_ms"], "launch_ms_median": r["kern_ms_median"], "launch_ms_min": r["kern_ms_min"],
+            "timed_launches": r["timed_launches"],
+            # SURVEY 8(d) "flows only": the ll (C, N) tables without the recursion / exchange, from the launch times
+            "flows_only_samples_per_s": B * group / (r["kern_ms"] * 1e-3) if r["kern_ms"] else None,
+            "flops_per_launch": flops, "batches_per_launch": group,
             "executed_mfma_tflops": executed, "executed_frac": executed / peak,
             "vs_f32_mfma_peak": achieved / F32_MFMA_PEAK_TFLOPS,
             "hbm_algorithmic_bytes_per_launch": alg_bytes,
