@@ -324,20 +324,27 @@ __global__ void __launch_bounds__(64 * IMG_WAVES) img_last_hx3_kernel(const Last
 
   // ---- stage strip + halo: a pixel is 4*chp contiguous bytes in HBM (a wave moves one pixel per pass, lane = 16-byte
   //      unit: fully coalesced, no index arithmetic beyond the pixel's row / column); outside the image: zeros
+  //      Direct-to-LDS DMA (global_load_lds_dwordx4: the pixel's bytes are lane-linear in HBM and in LDS): a wave issues
+  //      all its pixels back to back and waits once -- the register-staged loop (load, wait, store per pixel) made this
+  //      kernel latency-bound (74 us for 1024 workgroups at batch 256; round 2).
   {
-    const int units = chp >> 2;                             // 16-byte units per pixel
-    const unsigned char* src = reinterpret_cast<const unsigned char*>(p.h2) + (int64_t)n * H * W * (int64_t)(4 * chp);
+    const int units = chp >> 2;                             // 16-byte units per pixel (<= 64: chp <= 256)
+    typedef const __attribute__((address_space(1))) unsigned char* gbytes;
+    typedef __attribute__((address_space(3))) void* lptr;
+    gbytes src = (gbytes)(reinterpret_cast<const unsigned char*>(p.h2) + (int64_t)n * H * W * (int64_t)(4 * chp));
     for (int px = wave; px < RP * WP; px += IMG_WAVES) {
       const int rr = px / WP, cc = px - rr * WP;
       const int row = r0 + rr - 1, col = cc - 1;
-      const bool inside = row >= 0 && row < H && col >= 0 && col < W;
-      const unsigned char* s0 = src + ((int64_t)row * W + col) * (int64_t)(4 * chp);
-      for (int u = lane; u < units; u += 64) {
-        u32x4 v = {0u, 0u, 0u, 0u};
-        if (inside) v = *reinterpret_cast<const u32x4*>(s0 + 16 * u);
-        *reinterpret_cast<u32x4*>(HB + (size_t)px * pixb + 16 * u) = v;
+      const bool inside = row >= 0 && row < H && col >= 0 && col < W;      // wave-uniform
+      unsigned char* dst = HB + (size_t)px * pixb;
+      if (inside) {
+        if (lane < units)
+          __builtin_amdgcn_global_load_lds(src + ((int64_t)row * W + col) * (int64_t)(4 * chp) + 16 * lane, (lptr)dst, 16, 0, 0);
+      } else if (lane < units) {
+        *reinterpret_cast<u32x4*>(dst + 16 * lane) = u32x4{0u, 0u, 0u, 0u};
       }
     }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   }
   __syncthreads();
 
