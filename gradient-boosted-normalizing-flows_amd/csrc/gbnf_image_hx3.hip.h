@@ -83,6 +83,20 @@ __global__ void __launch_bounds__(64 * IMG_WAVES) img_mid_hx3_kernel(const MidLa
 #endif
   IMG_STAMP(-1);
 
+  // ---- the biases this wave will need (first 3x3: its tiles wave, wave + 4, ...; 1x1: its <= 4 tiles) go in flight now: read
+  //      where they are used they cost a global-memory round trip per tile with nothing to hide it (phase stamps, round 2:
+  //      the first 3x3 took 49 % of this kernel for 20 % of its MFMAs)
+  constexpr int PRE_T = 4;                                  // first-3x3 tiles per wave: chp / 16 / IMG_WAVES <= 4 (chp <= 256)
+  f32x4 pre_b[PRE_T];
+  {
+    const f32x4 __attribute__((address_space(1)))* pb4 = (const f32x4 __attribute__((address_space(1)))*)p.pre_bias;
+#pragma unroll
+    for (int q = 0; q < PRE_T; ++q) {
+      const int o = wave + q * IMG_WAVES;
+      pre_b[q] = pb4[(o < OT ? o : 0) * 4 + g];              // bias rows 16 o + 4 g .. + 3 (the array is padded to OT whole tiles)
+    }
+  }
+
   // ---- stage z1 (strip + halo, zero padded)
   {
     const float* src = p.pre_in + (int64_t)n * p.pre_in_img;
@@ -143,7 +157,7 @@ __global__ void __launch_bounds__(64 * IMG_WAVES) img_mid_hx3_kernel(const MidLa
         am[c] = f[64];
       }
     };
-    auto pre_tile = [&](int o, const u32x4 (&ah)[IMG_PRE_KC], const u32x4 (&am)[IMG_PRE_KC]) {
+    auto pre_tile = [&](int o, const f32x4& bias_o, const u32x4 (&ah)[IMG_PRE_KC], const u32x4 (&am)[IMG_PRE_KC]) {
       f32x4 acc[PT];
 #pragma unroll
       for (int pt = 0; pt < PT; ++pt) acc[pt] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -167,7 +181,7 @@ __global__ void __launch_bounds__(64 * IMG_WAVES) img_mid_hx3_kernel(const MidLa
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const int co = 16 * o + 4 * g + r;
-          v[r] = (co < p.hid && in_img) ? fmaxf(acc[pt][r] + pb[co < p.hid ? co : 0], 0.0f) : 0.0f;
+          v[r] = (co < p.hid && in_img) ? fmaxf(acc[pt][r] + bias_o[r], 0.0f) : 0.0f;
         }
         unsigned h01, m01, h23, m23;
         img_split_pair(v[0], v[1], h01, m01);
@@ -180,11 +194,15 @@ __global__ void __launch_bounds__(64 * IMG_WAVES) img_mid_hx3_kernel(const MidLa
     };
     u32x4 ah[2][IMG_PRE_KC], am[2][IMG_PRE_KC];
     load_pa(wave, ah[0], am[0]);
-    for (int o = wave; o < kt; o += 2 * IMG_WAVES) {
-      load_pa(o + IMG_WAVES, ah[1], am[1]);
-      pre_tile(o, ah[0], am[0]);
-      load_pa(o + 2 * IMG_WAVES, ah[0], am[0]);
-      if (o + IMG_WAVES < kt) pre_tile(o + IMG_WAVES, ah[1], am[1]);
+#pragma unroll
+    for (int q = 0; q < PRE_T; q += 2) {
+      const int o = wave + q * IMG_WAVES;
+      if (o < kt) {
+        load_pa(o + IMG_WAVES, ah[1], am[1]);
+        pre_tile(o, pre_b[q], ah[0], am[0]);
+        load_pa(o + 2 * IMG_WAVES, ah[0], am[0]);
+        if (o + IMG_WAVES < kt) pre_tile(o + IMG_WAVES, pre_b[q + 1 < PRE_T ? q + 1 : q], ah[1], am[1]);
+      }
     }
   }
   __syncthreads();
@@ -202,6 +220,12 @@ __global__ void __launch_bounds__(64 * IMG_WAVES) img_mid_hx3_kernel(const MidLa
   for (int q = 0; q < MAXO; ++q)
 #pragma unroll
     for (int pt = 0; pt < PT; ++pt) acc[q][pt] = f32x4{0.f, 0.f, 0.f, 0.f};
+  f32x4 mid_b[MAXO];                                       // the 1x1's biases for this wave's tiles, in flight under the MFMA stream
+  {
+    const f32x4 __attribute__((address_space(1)))* b4 = (const f32x4 __attribute__((address_space(1)))*)p.bias;
+#pragma unroll
+    for (int q = 0; q < MAXO; ++q) mid_b[q] = b4[(ow[q] < o_end ? ow[q] : o_begin) * 4 + g];
+  }
   const gv4 wp = (gv4)p.wp;
   auto load_a = [&](int c, u32x4 (&ah)[MAXO], u32x4 (&am)[MAXO]) {
     const int cc = c < KC ? c : 0;
@@ -253,7 +277,6 @@ __global__ void __launch_bounds__(64 * IMG_WAVES) img_mid_hx3_kernel(const MidLa
   // ---- relu(. + bias) -> split -> back into HB (its input role is over) -> HBM as NHWC split-f16 with 16-byte, fully
   //      coalesced copies (a lane's own 8-byte pieces would reach HBM as 32-byte fragments)
   __syncthreads();                                         // every wave is done reading HB as the 1x1's input
-  gptr bias = (gptr)p.bias;
 #pragma unroll
   for (int q = 0; q < MAXO; ++q) {
     if (ow[q] < o_end) {
@@ -265,7 +288,7 @@ __global__ void __launch_bounds__(64 * IMG_WAVES) img_mid_hx3_kernel(const MidLa
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const int co = 16 * o + 4 * g + r;
-          v[r] = co < p.hid ? fmaxf(acc[q][pt][r] + bias[co], 0.0f) : 0.0f;
+          v[r] = co < p.hid ? fmaxf(acc[q][pt][r] + mid_b[q][r], 0.0f) : 0.0f;
         }
         unsigned h01, m01, h23, m23;
         img_split_pair(v[0], v[1], h01, m01);
