@@ -650,13 +650,16 @@ __global__ void __launch_bounds__(64) flow_kernel(const FlowLaunch p) {
   }
   if (lane < d) {
     const int zslot = inv ? (int)tail[lane] : lane;
-#pragma unroll 8
+    // every row's load in flight before the first LDS store (rows past the batch re-read its last row and are zeroed)
+    float xv[16 * NT];
+    const int64_t last = p.n - 1;
+#pragma unroll
     for (int r = 0; r < 16 * NT; ++r) {
       const int64_t n = row0 + r;
-      float v = 0.0f;
-      if (n < p.n) v = xin[n * d + lane];
-      Z[zslot * ZS + r] = v;
+      xv[r] = xin[(n < p.n ? n : last) * d + lane];
     }
+#pragma unroll
+    for (int r = 0; r < 16 * NT; ++r) Z[zslot * ZS + r] = (row0 + r < p.n) ? xv[r] : 0.0f;
   }
   __syncthreads();
 

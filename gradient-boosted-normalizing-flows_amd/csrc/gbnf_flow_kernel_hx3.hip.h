@@ -369,13 +369,17 @@ flow_kernel_hx3(const FlowLaunch p) {
     }
   }
   if (lane < d) {
-#pragma unroll 8
+    // every row's load in flight before the first LDS store (branch-free: rows past the batch re-read its last row and are
+    // zeroed): eight at a time cost a global round trip per group at the head of every work item
+    float xv[16 * NT];
+    const int64_t last = p.n - 1;
+#pragma unroll
     for (int r = 0; r < 16 * NT; ++r) {
       const int64_t n = row0 + r;
-      float v = 0.0f;
-      if (n < p.n) v = xin[n * d + lane];
-      Z[lane * ZS + r] = v;
+      xv[r] = xin[(n < p.n ? n : last) * d + lane];
     }
+#pragma unroll
+    for (int r = 0; r < 16 * NT; ++r) Z[lane * ZS + r] = (row0 + r < p.n) ? xv[r] : 0.0f;
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this wave's pieces of the first stages have landed
   __syncthreads();               // tables + Z visible, every wave's pieces landed
