@@ -963,19 +963,26 @@ flow_kernel_hx3(const FlowLaunch p) {
   float quad[NT];
 #pragma unroll
   for (int nt = 0; nt < NT; ++nt) quad[nt] = 0.0f;
-  for (int j = g; j < d; j += 4) {
-    const int slot = (int)tail[j];
-    float mu = 0.0f, inv_sd = 1.0f, lsd = 0.0f;
-    if (p.base_mean != nullptr) {
-      mu = p.base_mean[j];
-      const float sd = p.base_std[j];
-      inv_sd = 1.0f / sd;
-      lsd = logf(sd);
-    }
+  if (p.base_mean == nullptr) {
+    // standard-normal base: the sum of squares runs over the slots themselves (no feature -> slot look-up, which was a
+    // dependent global load per feature at the end of every work item)
+    for (int j = g; j < d; j += 4) {
 #pragma unroll
-    for (int nt = 0; nt < NT; ++nt) {
-      const float v = (Z[slot * ZS + 16 * nt + i] - mu) * inv_sd;
-      quad[nt] += -0.5f * v * v - lsd;
+      for (int nt = 0; nt < NT; ++nt) {
+        const float v = Z[j * ZS + 16 * nt + i];
+        quad[nt] += -0.5f * v * v;
+      }
+    }
+  } else {
+    for (int j = g; j < d; j += 4) {
+      const int slot = (int)tail[j];
+      const float mu = p.base_mean[j], sd = p.base_std[j];
+      const float inv_sd = 1.0f / sd, lsd = logf(sd);
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) {
+        const float v = (Z[slot * ZS + 16 * nt + i] - mu) * inv_sd;
+        quad[nt] += -0.5f * v * v - lsd;
+      }
     }
   }
   bool any_sat = false;
