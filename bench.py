@@ -230,11 +230,25 @@ def main():
     xs_np = [x_np] + [synth.synth_batch(B, d, seed=100 + s) for s in range(1, S)]   # S distinct resident batches
     xs = [torch.from_numpy(a).to(dev) for a in xs_np]
 
-    def barrier():
+    def device_idle():
+        """torch.cuda.synchronize() with a busy wait in front: the runtime's blocking wait sleeps on an interrupt, and the
+        wake-up (measured on this pool: 70 us typically, 250-730 us now and then) would sit inside the timed region."""
+        evs = []
+        for st in {torch.cuda.current_stream(dev)} | set(extra_streams):
+            e = torch.cuda.Event()
+            e.record(st)
+            evs.append(e)
+        while not all(e.query() for e in evs):
+            pass
         torch.cuda.synchronize()
+
+    extra_streams = []               # the pipelines' exchange streams (registered by timed_run)
+
+    def barrier():
+        device_idle()
         if world > 1:
             dist.barrier()
-        torch.cuda.synchronize()
+        device_idle()
 
     MAX_TIMED_LAUNCHES = 48      # launches bracketed by timing events (the average is reported as roofline.launch_ms): event
                                  # pairs on every group of a long run cost the host more than the group's own launches
@@ -245,6 +259,8 @@ def main():
         mix = native.NativeMixture(flows)
         info = flows[0].info()
         pipe = sharded.GroupPipeline(mix, C, c0, c1, rho, B, group, gather)
+        if pipe.post is not pipe.main and pipe.post not in extra_streams:
+            extra_streams.append(pipe.post)
 
         bound = {}                       # group size -> launches bound to the resident batches (host work outside the timed region)
         event_pool = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(MAX_TIMED_LAUNCHES)]
