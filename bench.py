@@ -231,15 +231,15 @@ def main():
     xs = [torch.from_numpy(a).to(dev) for a in xs_np]
 
     def device_idle():
-        """torch.cuda.synchronize() with a busy wait in front: the runtime's blocking wait sleeps on an interrupt, and the
-        wake-up (measured on this pool: 70 us typically, 250-730 us now and then) would sit inside the timed region."""
-        evs = []
-        for st in {torch.cuda.current_stream(dev)} | set(extra_streams):
+        """torch.cuda.synchronize(), on one stream with a busy wait in front: the runtime's blocking wait sleeps on an
+        interrupt, and its wake-up (measured on this pool: 65 us typically, 250-730 us now and then) would sit inside the
+        timed region (1.1 ms at the driver's 20 steps).  With the exchange stream in use the plain blocking wait stays:
+        polling from this thread slows the collective's own host threads down (112 instead of 66 us, measured)."""
+        if not extra_streams and not os.environ.get("GBNF_BENCH_BLOCKING_SYNC"):
             e = torch.cuda.Event()
-            e.record(st)
-            evs.append(e)
-        while not all(e.query() for e in evs):
-            pass
+            e.record(torch.cuda.current_stream(dev))
+            while not e.query():
+                pass
         torch.cuda.synchronize()
 
     extra_streams = []               # the pipelines' exchange streams (registered by timed_run)
