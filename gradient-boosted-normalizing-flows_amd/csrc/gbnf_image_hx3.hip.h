@@ -28,7 +28,12 @@ __device__ __forceinline__ void img_split_pair(float x0, float x1, unsigned& hi,
   x1 = __builtin_amdgcn_fmed3f(x1, -65504.0f, 65504.0f);
   const auto h = __builtin_amdgcn_cvt_pkrtz(x0, x1);
   hi = __builtin_bit_cast(unsigned, h);
-  const auto m = __builtin_amdgcn_cvt_pkrtz(x0 - (float)h[0], x1 - (float)h[1]);
+  // the residual x - hi as ONE v_fma_mix_f32 per value (the f16 half is widened inside the instruction), as in
+  // gbnf_flow_kernel_hx3.hip.h; LLVM itself emits v_cvt_f32_f16 + v_sub_f32
+  float r0, r1;
+  asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(r0) : "v"(hi), "v"(x0));
+  asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(r1) : "v"(hi), "v"(x1));
+  const auto m = __builtin_amdgcn_cvt_pkrtz(r0, r1);
   mid = __builtin_bit_cast(unsigned, m);
 }
 
