@@ -138,10 +138,12 @@ def measured_traffic(config, B, C, S, math, world):
         rec = json.load(open(path))
     except (OSError, ValueError):
         return None
-    w = rec.get("workload", {})
-    same = (w.get("config") == config and w.get("batch") == B and w.get("components") == C and w.get("group") == S
-            and w.get("math") == math and w.get("n_gpus") == world)
-    return float(rec["traffic_bytes_per_launch"]) if same else None
+    for r in [rec] + list(rec.get("other_group_sizes", [])):
+        w = r.get("workload", {})
+        if (w.get("config") == config and w.get("batch") == B and w.get("components") == C and w.get("group") == S
+                and w.get("math") == math and w.get("n_gpus") == world):
+            return float(r["traffic_bytes_per_launch"])
+    return None
 
 
 def self_launch(args):
