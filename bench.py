@@ -47,6 +47,8 @@ GROUP = 32                     # batches per flow launch / all-gather / recursio
                                # holds one component: a 16-batch launch is a single round of workgroups, 123 us, and the
                                # per-group host + collective cost shows; 32 measured +10 % there, +1-3 % at N = 1)
 
+ROWS_PER_ROUND = 65536         # one round of the split kernel's workgroups: 256 CUs x 2 workgroups x 4 waves x 32 samples
+
 CONFIGS = {
     # name: (kind, d, h, K, default C, default batch)
     "miniboone_glow": ("glow", 43, 215, 5, 8, 4096),
@@ -77,26 +79,30 @@ def cpu_baseline(specs, rho, x_np, budget_s):
 
     Thread count: the reference sets torch.set_num_threads(cores - 1) (density_experiment.py:280-287),
     which is pathological on a many-core host for these small GEMMs (256 threads: ~100 s per pass), so
-    the baseline is given its best setting: a quick probe over {1, 4, 8, 16, 32, 64} picks the fastest,
-    and `cores` reports the threads actually used.  Then whole passes (all components + recursion) are
+    the baseline is given its best setting: a quick probe over {1, 4, 8, 16, 32, 64} threads ON THE STATED WORKLOAD (all
+    components + recursion, 1024 rows) picks the fastest, and `cores` reports the threads actually used.  Then whole passes (all components + recursion) are
     timed until ~budget_s seconds are spent (first pass untimed).  `one_thread_value` is the same whole pass (all
     components + recursion) on ONE thread over a bounded row sample (the reference scripts' own default is one worker)."""
     import torch
     from oracle import gbnf_oracle as oracle
     host_cores = os.cpu_count() or 1
     cands = [t for t in (1, 4, 8, 16, 32, 64) if t <= host_cores] or [1]
-    probe_x = x_np[: min(512, x_np.shape[0])]
+    probe_x = x_np[: min(1024, x_np.shape[0])]
     best_t, best_dt = cands[0], None
+    probe = {}
     with torch.no_grad():
+        # the probe runs the STATED workload (every component + the recursion), not one component: the best thread count
+        # of a single 1024 x 215 GEMM chain is not the best one of the whole pass on a many-core host
         for t in cands:
             torch.set_num_threads(t)
-            oracle.component_log_prob(specs[0], probe_x)             # warm
+            oracle.mixture_log_prob(specs, rho, probe_x[:128])       # warm
             t0 = time.perf_counter()
-            oracle.component_log_prob(specs[0], probe_x)
+            oracle.mixture_log_prob(specs, rho, probe_x)
             dt = time.perf_counter() - t0
+            probe[t] = probe_x.shape[0] / dt
             if best_dt is None or dt < best_dt:
                 best_t, best_dt = t, dt
-            if dt > 2.0:
+            if dt > 4.0:
                 break
         # one thread, the stated workload (all components + the recursion) on a row sample worth ~2 s
         torch.set_num_threads(1)
@@ -106,7 +112,7 @@ def cpu_baseline(specs, rho, x_np, budget_s):
         oracle.mixture_log_prob(specs, rho, x_np[:n1])
         one_thread = n1 / (time.perf_counter() - t0)
         torch.set_num_threads(best_t)
-        est = best_dt * len(specs) * x_np.shape[0] / probe_x.shape[0]
+        est = best_dt * x_np.shape[0] / probe_x.shape[0]
         n = x_np.shape[0]
         if est > budget_s / 2:                                        # keep the leg bounded: fewer rows
             n = max(256, int(x_np.shape[0] * (budget_s / 2) / est))
@@ -123,11 +129,68 @@ def cpu_baseline(specs, rho, x_np, budget_s):
     return {
         "value": n * passes / el, "unit": "samples/s", "cores": best_t, "kind": "port",
         "host_cores": host_cores, "cpu_model": _cpu_model(), "one_thread_value": one_thread,
+        "thread_probe_samples_per_s": {str(k): v for k, v in probe.items()},
         "one_thread_sample": f"one pass over {n1} rows, all {len(specs)} components + mixture recursion, 1 thread",
         "sample": f"{passes} pass(es) over {n} of the {x_np.shape[0]} rows, all {len(specs)} components + mixture "
                   f"recursion, torch-CPU oracle in the reference's op order, {best_t} threads "
                   f"(fastest of {cands}), {el:.1f} s",
     }, G, n
+
+
+def module_evaluate_leg(specs, kind, d, h, K, C, x, iters=100):
+    """What "drops into density_experiment.py unchanged" costs: the reference's evaluate loop
+    (density_experiment.py:561-573: one model(x=x, components=c) call per component, the base density and the 2-way
+    logsumexp recursion in torch ops) through the drop-in module, host time included, and the module's one-call form."""
+    import math
+    import torch
+    from gbnf_amd import BoostedFlow
+    dev = x.device
+    ns = argparse.Namespace(
+        num_flows=K, z_size=d, density_evaluation=True, device=dev, cuda=True, component_type=kind, num_components=C,
+        rho_init="decreasing", learn_top=False, y_classes=0, y_condition=False, sample_size=4, input_size=[d], h_size=h,
+        num_blocks=1, actnorm_scale=1.0, flow_permutation="shuffle", flow_coupling="affine", LU_decomposed=False,
+        num_dequant_blocks=0, coupling_network="tanh", coupling_network_depth=1, batch_norm=True)
+    model = BoostedFlow(ns).to(dev)
+    for c, sp in enumerate(specs):
+        model.load_spec(c, sp)
+    model.component = C - 1
+    model.all_trained = True
+    model.eval()
+
+    def reference_loop():
+        G_ll = None
+        for c in range(model.component + 1):
+            z_G, _, _, ldj_G, _ = model(x=x, components=c)
+            ll = torch.sum(-0.5 * math.log(2 * math.pi) - 0.5 * z_G.pow(2), dim=-1) + ldj_G
+            if c == 0:
+                G_ll = ll
+            else:
+                rho_simplex = model.rho[0:(c + 1)] / torch.sum(model.rho[0:(c + 1)])
+                last_ll = torch.log(1 - rho_simplex[c]) + G_ll
+                next_ll = torch.log(rho_simplex[c]) + ll
+                G_ll = torch.logsumexp(torch.cat([last_ll.view(-1, 1), next_ll.view(-1, 1)], dim=1), dim=1)
+        return G_ll
+
+    def timed(fn):
+        with torch.no_grad():
+            for _ in range(10):
+                out = fn()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(iters):
+                out = fn()
+            torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / iters, out
+
+    t_loop, G_loop = timed(reference_loop)
+    t_one, G_one = timed(lambda: model.log_prob(x))
+    n = x.shape[0]
+    return {"value": n / t_loop, "unit": "samples/s", "ms_per_batch": 1e3 * t_loop, "iters": iters,
+            "log_prob_one_call_value": n / t_one, "log_prob_one_call_ms": 1e3 * t_one,
+            "max_abs_diff_loop_vs_one_call": float((G_loop - G_one).abs().max().item()),
+            "note": "the reference's own evaluate loop through the drop-in BoostedFlow module: C forward calls returning "
+                    "(z, ldj) + the base density and the recursion in torch ops, host time included; "
+                    "log_prob_one_call = model.log_prob(x) (one flow launch + one recursion launch)"}, G_loop
 
 
 def measured_traffic(config, B, C, S, math, world):
@@ -149,15 +212,11 @@ def measured_traffic(config, B, C, S, math, world):
 def self_launch(args):
     """`python bench.py --gpus N` as the driver may invoke it: start the one-process-per-GPU job as a CHILD (this parent
     has not imported torch or touched the GPU, and never replaces itself) and relay rank 0's JSON line."""
-    import socket
-    s = socket.socket()
-    s.bind(("127.0.0.1", 0))
-    port = s.getsockname()[1]
-    s.close()
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
-           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    # --standalone: the launcher binds its own free rendezvous port on the loopback address (no pick-then-reuse race)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--standalone", "--local-addr", "127.0.0.1", "--nnodes=1",
+           f"--nproc-per-node={args.gpus}", os.path.abspath(__file__)] + sys.argv[1:]
     proc = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, text=True)
     lines = [l for l in proc.stdout.splitlines() if l.startswith("{")]
     for l in proc.stdout.splitlines():
@@ -210,12 +269,15 @@ def main():
     dev = torch.device("cuda", local_rank)
     gather = world > 1 or args.force_gather
     if gather:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("MASTER_PORT", "29533")
         if world > 1:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
             dist.init_process_group("nccl", device_id=dev)
-        else:
-            dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+        else:           # one rank: a file rendezvous (no port to collide on when two benches share a box)
+            import tempfile
+            rdzv = tempfile.NamedTemporaryFile(prefix="gbnf_bench_rdzv_", delete=False)
+            rdzv.close()
+            os.unlink(rdzv.name)
+            dist.init_process_group("nccl", init_method=f"file://{rdzv.name}", rank=0, world_size=1, device_id=dev)
 
     kind, d, h, K, C_def, B_def = CONFIGS[args.config]
     C = args.components or C_def
@@ -229,19 +291,35 @@ def main():
     c0, c1 = parts[rank]
     rho = torch.from_numpy(rho_np).to(dev)
     S = max(1, min(args.group, 32, args.steps))      # a run shorter than one group times one launch of that size
+    if gather:
+        # Sharded runs: a rank's launch should be a whole number of rounds of workgroups (512 slots x 128 rows = 65536
+        # row-components: two 4-wave workgroups per CU) -- a launch of 1.25 rounds takes as long as one of 2, because the
+        # tail's workgroups pair up on a quarter of the CUs instead of spreading out -- and a short run should still be
+        # several groups, so that the exchange of one overlaps the kernel of the next.  --steps 20 at one component per
+        # rank: groups of 16 + 4 batches (the 4-batch launch is one workgroup per CU) instead of one launch of 20.
+        fit = max(1, ROWS_PER_ROUND // (B * (c1 - c0)))
+        if S > fit:
+            S = S // fit * fit
     xs_np = [x_np] + [synth.synth_batch(B, d, seed=100 + s) for s in range(1, S)]   # S distinct resident batches
     xs = [torch.from_numpy(a).to(dev) for a in xs_np]
 
     def device_idle():
         """torch.cuda.synchronize(), on one stream with a busy wait in front: the runtime's blocking wait sleeps on an
         interrupt, and its wake-up (measured on this pool: 65 us typically, 250-730 us now and then) would sit inside the
-        timed region (1.1 ms at the driver's 20 steps).  With the exchange stream in use the plain blocking wait stays:
-        polling from this thread slows the collective's own host threads down (112 instead of 66 us, measured)."""
-        if not extra_streams and not os.environ.get("GBNF_BENCH_BLOCKING_SYNC"):
-            e = torch.cuda.Event()
-            e.record(torch.cuda.current_stream(dev))
-            while not e.query():
-                pass
+        timed region (1.1 ms at the driver's 20 steps).  With the exchange stream in use the poll yields the core between
+        queries (a tight poll from this thread slows the collective's own host threads down: 112 instead of 66 us, measured)."""
+        if not os.environ.get("GBNF_BENCH_BLOCKING_SYNC"):
+            evs = []
+            for st in [torch.cuda.current_stream(dev)] + extra_streams:
+                e = torch.cuda.Event()
+                e.record(st)
+                evs.append(e)
+            if extra_streams:       # the collective's proxy thread needs the core now and then: yield between polls
+                while not all(e.query() for e in evs):
+                    os.sched_yield()
+            else:
+                while not evs[0].query():
+                    pass
         torch.cuda.synchronize()
 
     extra_streams = []               # the pipelines' exchange streams (registered by timed_run)
@@ -255,7 +333,7 @@ def main():
     MAX_TIMED_LAUNCHES = 48      # launches bracketed by timing events (the average is reported as roofline.launch_ms): event
                                  # pairs on every group of a long run cost the host more than the group's own launches
 
-    def timed_run(math, group, steps, warmup, prewarm, want_gather_times=False):
+    def timed_run(math, group, steps, warmup, prewarm, want_gather_times=False, repetitions=0):
         """The pipeline on this rank's components in `math` mode, groups of `group` batches: returns timing + the handles' info."""
         flows = [native.NativeFlow(specs[c], math=math) for c in range(c0, c1)]
         mix = native.NativeMixture(flows)
@@ -278,7 +356,9 @@ def main():
                 if events is not None and k == group and len(events) < MAX_TIMED_LAUNCHES:
                     ev = event_pool[len(events)]
                     events.append(ev)
-                last = pipe.submit(bound[k], ev)
+                res = pipe.submit(bound[k], ev)
+                if k == group:
+                    last = res               # (G tensor of the slot, slot) of the last FULL group
                 done += k
                 gi += 1
             return last
@@ -290,32 +370,50 @@ def main():
         run(warmup)
         if steps % group:           # the timed loop ends on a partial group: bind and run that launch shape now (untimed), every rank alike
             run(steps % group)
-        barrier()
+        # A run shorter than 4 groups is repeated (same K steps, each repetition between barriers + device synchronisations,
+        # MAX over ranks per repetition): `value` comes from the MEDIAN repetition, so the driver's --steps 20 is not a
+        # sample of one ~1 ms launch (>= 20 timed iterations, median and min)
+        reps = repetitions if repetitions else (1 if steps >= 4 * group else 21)
         events = []
         if want_gather_times and gather:
             pipe.gather_events = []
-        t0 = time.perf_counter()
-        run(steps, events)
-        barrier()
-        elapsed = time.perf_counter() - t0
+        all_elapsed = []
+        last_full = None
+        for rep in range(reps):
+            barrier()
+            t0 = time.perf_counter()
+            last = run(steps, events)
+            barrier()
+            all_elapsed.append(time.perf_counter() - t0)
+            last_full = last if steps >= group else last_full
         if world > 1:
-            t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+            t = torch.tensor(all_elapsed, dtype=torch.float64, device=dev)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            elapsed = float(t.item())
+            all_elapsed = [float(v) for v in t.cpu()]
+        elapsed = sorted(all_elapsed)[len(all_elapsed) // 2]
         per_launch = sorted(a.elapsed_time(b) for a, b in events)
         kern_ms = sum(per_launch) / max(1, len(per_launch))      # per full-group launch (flow launch + its repair launch)
         gather_us = None
         if pipe.gather_events:
             gather_us = 1e3 * sum(a.elapsed_time(b) for a, b in pipe.gather_events) / len(pipe.gather_events)
-        # batch 0 of a full group (slot 0 was written by an even group; any slot holds a complete group's result)
-        G0 = pipe._buffers(group)[2][0][:B].cpu().numpy() if steps >= group else None
-        return {"elapsed": elapsed, "kern_ms": kern_ms, "info": info, "G0": G0, "gather_us": gather_us,
+        # batch 0 of the last full group of the timed region (the tensor its submit returned)
+        G0 = last_full[0][:B].cpu().numpy() if last_full is not None else None
+        st = mix.numerics()              # the mode the mixture runs in NOW (a failed on-device check demotes f16x3 -> bf16x6)
+        modes = [int(st.math_mode)]
+        if world > 1:
+            mt = torch.tensor([int(st.math_mode)], dtype=torch.int32, device=dev)
+            ml = [torch.zeros_like(mt) for _ in range(world)]
+            dist.all_gather(ml, mt)
+            modes = [int(v.item()) for v in ml]
+        return {"elapsed": elapsed, "elapsed_all": all_elapsed, "kern_ms": kern_ms, "info": info, "G0": G0, "gather_us": gather_us,
+                "modes": modes, "guard": {"checks": int(st.checks), "worst_rel_err": float(st.worst_rel_err),
+                                          "demoted": bool(st.demoted), "tolerance": float(st.tolerance)},
                 "kern_ms_min": per_launch[0] if per_launch else None,
                 "kern_ms_median": per_launch[len(per_launch) // 2] if per_launch else None, "timed_launches": len(per_launch),
-                "name": MATH_NAME[info.math_mode], "keep": (flows, mix, pipe)}
+                "name": MATH_NAME[max(modes)] if len(set(modes)) == 1 else "mixed", "keep": (flows, mix, pipe)}
 
     def roofline(r, group):
-        info, math = r["info"], r["name"]
+        info, math = r["info"], (r["name"] if r["name"] != "mixed" else "bf16x6")     # ranks disagree: priced as the slower mode
         flops = 2.0 * info.macs_per_sample * (c1 - c0) * B * group            # one launch serves `group` batches
         achieved = flops / (r["kern_ms"] * 1e-3) / 1e12
         executed = achieved * info.padded_macs_per_sample / info.macs_per_sample * PRODUCTS[math]
@@ -357,9 +455,14 @@ def main():
                       else f"density-eval samples/sec, {args.config}",
             "value": value, "unit": "samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * main_run["elapsed"] / args.steps, "prewarm_s": args.prewarm, "higher_is_better": True,
+            "timing": {"repetitions": len(main_run["elapsed_all"]), "value_from": "median repetition",
+                       "elapsed_ms_median": 1e3 * main_run["elapsed"], "elapsed_ms_min": 1e3 * min(main_run["elapsed_all"]),
+                       "elapsed_ms_max": 1e3 * max(main_run["elapsed_all"]),
+                       "value_at_min": B * args.steps / min(main_run["elapsed_all"])},
+            "numerics_guard": main_run["guard"], "math_modes_by_rank": [MATH_NAME[m] for m in main_run["modes"]],
             "scaling": "strong", "vs_baseline": None, "dtype": math, "data": "synthetic",
             "config": {"workload": f"{args.config}: d={d} h={h} K={K} C={C} batch={B}, x ~ N(0,1), synthetic weights",
-                       "global_batch": B, "components": C, "math": MATH_TEXT[math], "group": S,
+                       "global_batch": B, "components": C, "math": MATH_TEXT.get(math, math), "group": S,
                        "group_note": f"{S} batches per flow launch / all-gather / recursion launch (same for every N)",
                        "parallelism": ("single GPU, all components in one launch" if world == 1 and not gather else
                                        f"components sharded {C // world}/GPU + one RCCL all-gather of ll per group"),
@@ -388,6 +491,14 @@ def main():
                               "achieved_tflops": rg["achieved"], "frac": rg["frac"], "group": 1,
                               "note": "one batch per flow launch + one recursion launch (per-call latency form)"}
             del r
+            try:
+                leg, G_mod = module_evaluate_leg(specs, kind, d, h, K, C, xs[0])
+                if main_run["G0"] is not None:
+                    g0 = main_run["G0"].astype(np.float64)
+                    leg["max_rel_err_vs_pipeline"] = float(np.max(np.abs(G_mod.cpu().numpy() - g0) / np.maximum(np.abs(g0), 1.0)))
+                legs["module_evaluate_loop"] = leg
+            except Exception as e:                  # (a leg never takes the headline down)
+                legs["module_evaluate_loop"] = {"error": f"{type(e).__name__}: {e}"}
             out["legs"] = legs
         if args.cpu_seconds > 0 and world == 1:
             cb, G_cpu, n_cpu = cpu_baseline(specs, rho_np, x_np, args.cpu_seconds)

@@ -82,6 +82,31 @@ def scratch_bytes(obj):
     return worst
 
 
+def lint_object(obj):
+    """tools/isa_hazard_lint.py on a freshly compiled object: no path of any kernel may touch a v_mfma result before it exists
+    (hipcc pads that dependency along fall-through paths only; profiles/r3_mfma_hazard_root_cause.txt)."""
+    tools = os.path.join(PKG, "..", "tools")
+    if not os.path.exists(os.path.join(tools, "isa_hazard_lint.py")):
+        return
+    if tools not in sys.path:
+        sys.path.insert(0, tools)
+    import isa_hazard_lint as lint
+    bad = []
+    for name, insts in lint.disassemble(obj).items():
+        for i, j, ws, need, crossed in lint.check_kernel(insts):
+            bad.append(f"  {name[:80]}: [{insts[i].addr:#x}] {insts[i].text}  ->  [{insts[j].addr:#x}] {insts[j].text} "
+                       f"after {ws} of {need} wait states{' (across a branch)' if crossed else ''}")
+    if bad:
+        raise RuntimeError(f"{os.path.basename(obj)}: a v_mfma result is touched too early (MFMA read-after-write hazard, "
+                           "see tools/isa_hazard_lint.py):\n" + "\n".join(bad[:10]))
+
+
+def compile_and_lint(cmd):
+    run(cmd)
+    lint_object(cmd[-1])
+    return ""
+
+
 def compile_hx3(cmd):
     """A split-kernel variant: accumulators in VGPRs (the activation + split reads them directly, no v_accvgpr_read per
     value) -- unless that build spills: one wave per SIMD has 512 registers only as 256 VGPRs + 256 AGPRs, and the
@@ -98,6 +123,7 @@ def compile_hx3(cmd):
             sb2 = sb
         if sb2:
             print(f"[gbnf build] note: {os.path.basename(obj)} uses {sb2} bytes of scratch per lane", flush=True)
+    lint_object(obj)
     return ""
 
 
@@ -146,7 +172,7 @@ def main(argv=None):
     if jobs:
         print(f"[gbnf build] compiling {len(jobs)} object(s) with -j{args.j}", flush=True)
         with cf.ThreadPoolExecutor(max_workers=args.j) as ex:
-            for _ in ex.map(lambda c: compile_hx3(c) if "variant_hx3" in " ".join(c) else run(c), jobs):
+            for _ in ex.map(lambda c: compile_hx3(c) if "variant_hx3" in " ".join(c) else compile_and_lint(c), jobs):
                 pass
     if jobs or not os.path.exists(LIB):
         run([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs)

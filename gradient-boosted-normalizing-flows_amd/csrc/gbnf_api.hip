@@ -56,6 +56,22 @@ struct NetDims {
   int in_f = 0, hidden = 0, out_f = 0, depth = 0, act = 0, residual = 0;
 };
 
+// ---- numerics guard (include/gbnf.h, gbnf_numerics_status): device-side re-check of the f16x3 choice on the caller's data
+constexpr int GUARD_ROWS = 256;
+struct GuardStatus {             // pinned host memory, written by guard_compare_kernel through its device alias
+  unsigned long long checks;
+  float worst_rel_err;
+  unsigned demoted;
+};
+struct Guard {
+  unsigned* flag_dev = nullptr;          // [0] != 0: the check failed (read by every repair launch of the handle)
+  float* scratch_dev = nullptr;          // [2][n_comp][GUARD_ROWS] log-likelihoods of the check rows: f16x3 | bf16x6
+  GuardStatus* status_host = nullptr;    // hipHostMalloc, mapped
+  GuardStatus* status_dev = nullptr;     // the device's address of the same memory
+  int n_comp = 0;
+  std::atomic<long long> launches{0};
+};
+
 }  // namespace gbnf
 
 struct gbnf_flow {
@@ -83,6 +99,7 @@ struct gbnf_flow {
   size_t blob2_words = 0;
   double padded_macs2 = 0;
   int var2_ht = 0, var2_ot = 0;
+  gbnf::Guard* guard = nullptr;        // numerics guard (DEFAULT handles running f16x3 with a bf16x6 packing), else null
 };
 
 struct gbnf_mixture {
@@ -92,6 +109,7 @@ struct gbnf_mixture {
   const uint32_t** table_dev = nullptr;
   const uint32_t** table2_dev = nullptr;   // bf16x6 packings for the repair pass of an f16x3 mixture (or null)
   float* base_dev = nullptr;  // [2][d] mean, std or null
+  gbnf::Guard* guard = nullptr;        // numerics guard of an f16x3 mixture whose components are all DEFAULT handles, else null
 };
 
 namespace gbnf {
@@ -114,12 +132,63 @@ unsigned* saturation_counter() {
   std::lock_guard<std::mutex> lk(g_dev_mu);
   if (g_sat_counter[dev] == nullptr) {
     unsigned* p = nullptr;
-    const size_t bytes = sizeof(unsigned) * (SAT_MARKS + SAT_SLOTS);      // counter + the launch marks of the repair protocol
+    const size_t bytes = sizeof(unsigned long long) * (SAT_MARKS + SAT_SLOTS);      // counter + the launch marks of the repair protocol (64-bit words)
     if (hipMalloc((void**)&p, bytes) != hipSuccess) return nullptr;
     if (hipMemset(p, 0, bytes) != hipSuccess) { (void)hipFree(p); return nullptr; }
     g_sat_counter[dev] = p;
   }
   return g_sat_counter[dev];
+}
+
+// ---- launch-policy knobs (gbnf_tuning_set / _get; initialised from the environment at first use)
+struct Tuning {
+  std::atomic<int> force_nt{0}, wg_pairs{-1}, repair{1}, nt2_min_waves{1024}, check_every{256};
+  Tuning() {
+    auto env = [](const char* k) -> const char* { return getenv(k); };
+    if (const char* e = env("GBNF_FORCE_NT")) force_nt = atoi(e);
+    if (const char* e = env("GBNF_NO_WG_PAIRS")) wg_pairs = atoi(e) != 0 ? 0 : -1;
+    if (const char* e = env("GBNF_NO_REPAIR")) repair = atoi(e) != 0 ? 0 : 1;
+    if (const char* e = env("GBNF_NT2_MIN_WAVES")) nt2_min_waves = atoi(e);
+    if (const char* e = env("GBNF_CHECK_EVERY")) check_every = atoi(e);
+  }
+};
+static Tuning& tuning() {
+  static Tuning t;
+  return t;
+}
+int tuning_wg_pairs() { return tuning().wg_pairs.load(std::memory_order_relaxed); }
+static std::atomic<int>* tuning_slot(const char* key) {
+  Tuning& t = tuning();
+  if (!key) return nullptr;
+  if (!strcmp(key, "force_nt")) return &t.force_nt;
+  if (!strcmp(key, "wg_pairs")) return &t.wg_pairs;
+  if (!strcmp(key, "repair")) return &t.repair;
+  if (!strcmp(key, "nt2_min_waves")) return &t.nt2_min_waves;
+  if (!strcmp(key, "check_every")) return &t.check_every;
+  return nullptr;
+}
+
+static void free_guard(Guard* g) {
+  if (!g) return;
+  if (g->flag_dev) (void)hipFree(g->flag_dev);
+  if (g->scratch_dev) (void)hipFree(g->scratch_dev);
+  if (g->status_host) (void)hipHostFree(g->status_host);
+  delete g;
+}
+static hipError_t make_guard(int n_comp, Guard** out) {
+  Guard* g = new Guard();
+  g->n_comp = n_comp;
+  hipError_t e = hipMalloc((void**)&g->flag_dev, 16);
+  if (e == hipSuccess) e = hipMemset(g->flag_dev, 0, 16);
+  if (e == hipSuccess) e = hipMalloc((void**)&g->scratch_dev, sizeof(float) * 2 * n_comp * GUARD_ROWS);
+  if (e == hipSuccess) e = hipHostMalloc((void**)&g->status_host, sizeof(GuardStatus), hipHostMallocMapped);
+  if (e == hipSuccess) {
+    g->status_host->checks = 0; g->status_host->worst_rel_err = 0.0f; g->status_host->demoted = 0;
+    e = hipHostGetDevicePointer((void**)&g->status_dev, g->status_host, 0);
+  }
+  if (e != hipSuccess) { free_guard(g); return e; }
+  *out = g;
+  return hipSuccess;
 }
 
 // physical hidden position p = 16 t + 4 g + r  <->  logical unit 4*(4t + r) + g
@@ -376,7 +445,7 @@ int gbnf_saturation_count(int64_t* count, int32_t reset) {
   *count = 0;
   unsigned* dev = gbnf::saturation_counter();                // the CURRENT device's counter
   if (dev == nullptr) return GBNF_OK;
-  unsigned host = 0;
+  unsigned long long host = 0;
   // every stream of the device (torch's side streams are non-blocking ones: the null-stream copy alone would not
   // order against their kernels)
   hipError_t e = hipDeviceSynchronize();
@@ -720,6 +789,7 @@ static void free_flow(gbnf_flow* f) {
   if (f->self_table_dev) (void)hipFree(f->self_table_dev);
   if (f->blob2_dev) (void)hipFree(f->blob2_dev);
   if (f->self_table2_dev) (void)hipFree(f->self_table2_dev);
+  gbnf::free_guard(f->guard);
   delete f;
 }
 
@@ -858,6 +928,14 @@ int gbnf_flow_create_ex(const gbnf_flow_desc* desc, int32_t math_mode, int32_t f
       for (int nt = 1; nt <= 2; ++nt) { f->launch2_nt[nt] = nullptr; f->name2_nt[nt] = nullptr; }
     }
   }
+  // ---- a DEFAULT handle that stays on f16x3 keeps being checked against its bf16x6 packing on the caller's data
+  if (math_mode == GBNF_MATH_DEFAULT && f->math_mode == GBNF_MATH_F16X3 && f->blob2_dev != nullptr) {
+    e = make_guard(1, &f->guard);
+    if (e != hipSuccess) {
+      free_flow(f);
+      return fail(GBNF_ERR_HIP, "allocating the numerics guard failed: %s", hipGetErrorString(e));
+    }
+  }
   *out = f;
   return GBNF_OK;
 }
@@ -888,26 +966,52 @@ namespace gbnf {
 // samples per wave: 32 (NT=2) once there is enough work to give every SIMD of the chip a wave that way (256 CUs x 4
 // SIMDs: the split kernels then run 4-wave workgroups, one or two per CU), otherwise 16 (NT=1) to expose more waves.
 static int pick_nt(int64_t n, int n_comp) {
-  static const int forced = [] {
-    const char* e = getenv("GBNF_FORCE_NT");   // tuning / test knob: 1 or 2
-    return e ? atoi(e) : 0;
-  }();
+  const int forced = tuning().force_nt.load(std::memory_order_relaxed);     // tuning / test knob: 1 or 2
   if (forced == 1 || forced == 2) return forced;
   const int64_t waves32 = ((n + 31) / 32) * n_comp;
-  static const int nt2_min = [] { const char* e = getenv("GBNF_NT2_MIN_WAVES"); return e ? atoi(e) : 1024; }();   // tuning knob
-  return waves32 >= nt2_min ? 2 : 1;
+  return waves32 >= tuning().nt2_min_waves.load(std::memory_order_relaxed) ? 2 : 1;
 }
 
 #if defined(GBNF_STAMPS) || defined(GBNF_TIMELINE)
 static unsigned long long* g_stamp_buf = nullptr;
 #endif
 
-static bool repair_enabled() {
-  static const bool on = [] {
-    const char* e = getenv("GBNF_NO_REPAIR");   // diagnostic knob: time the bare f16x3 launch
-    return !(e && atoi(e) != 0);
-  }();
-  return on;
+static bool repair_enabled() { return tuning().repair.load(std::memory_order_relaxed) != 0; }   // 0: diagnostic, times the bare f16x3 launch
+
+static unsigned long long next_serial() {      // launch serial numbers: process-wide, never 0 (the memset value of the marks), never reused
+  static std::atomic<unsigned long long> launch_serial{1};
+  return launch_serial.fetch_add(1, std::memory_order_relaxed);
+}
+
+// The device side of the numerics guard: largest relative difference between the f16x3 (a) and bf16x6 (b) log-likelihoods of the
+// check rows; rows the f16x3 launch marked as out of range (NaN) belong to the repair protocol and are skipped.
+__global__ void __launch_bounds__(256) guard_compare_kernel(const float* __restrict__ a, const float* __restrict__ b, int n_comp,
+                                                            int rows, float tol, unsigned* __restrict__ flag,
+                                                            GuardStatus* __restrict__ st) {
+  __shared__ float red[4];
+  float worst = 0.0f;
+  for (int idx = threadIdx.x; idx < n_comp * rows; idx += blockDim.x) {
+    const int c = idx / rows, r = idx - c * rows;
+    const float va = a[c * GUARD_ROWS + r], vb = b[c * GUARD_ROWS + r];
+    if (va == vb || va != va) continue;                       // equal (infinities included) | marked by the f16x3 launch
+    float rel;
+    if (vb != vb || isinf(va) || isinf(vb)) rel = INFINITY;   // only one of them finite
+    else rel = fabsf(va - vb) / fmaxf(fabsf(vb), 1.0f);
+    worst = fmaxf(worst, rel);
+  }
+  for (int off = 32; off > 0; off >>= 1) worst = fmaxf(worst, __shfl_xor(worst, off));
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = worst;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    worst = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    if (!(worst <= tol)) {
+      flag[0] = 1u;
+      st->demoted = 1u;
+    }
+    st->worst_rel_err = fmaxf(st->worst_rel_err, worst);
+    st->checks = st->checks + 1ull;
+    __threadfence_system();
+  }
 }
 
 // One launch of the flow kernel of `f` (all components of `table` share its variant).  `table2` (or null): the bf16x6
@@ -916,8 +1020,15 @@ static int launch_flow(const gbnf_flow* f, const uint32_t* const* table, const u
                        int c_begin, int n_comp, const float* x,
                        int64_t n, float* z, float* ldj, float* ll, const float* base, hipStream_t stream,
                        int64_t out_stride = -1, const float* const* xs = nullptr, int n_batches = 1,
-                       int inverse = 0) {
+                       int inverse = 0, Guard* guard = nullptr) {
   if (n == 0 || n_comp == 0 || n_batches == 0) return GBNF_OK;
+  if (!use_second && guard != nullptr && f->math_mode == GBNF_MATH_F16X3 && table2 != nullptr &&
+      *(volatile unsigned*)&guard->status_host->demoted != 0u) {
+    // a check on the caller's data failed earlier: this handle runs on its bf16x6 packing from now on
+    use_second = true;
+    table = table2;
+    table2 = nullptr;
+  }
   const int mode = use_second ? GBNF_MATH_BF16X6 : f->math_mode;
   const LaunchFn* launch = use_second ? f->launch2_nt : f->launch_nt;
   const char* const* names = use_second ? f->name2_nt : f->name_nt;
@@ -938,17 +1049,52 @@ static int launch_flow(const gbnf_flow* f, const uint32_t* const* table, const u
 #if defined(GBNF_STAMPS) || defined(GBNF_TIMELINE)
   p.dbg = g_stamp_buf;
 #endif
-  p.sat = saturation_counter();
-  static std::atomic<uint32_t> launch_serial{1};
-  p.seq = launch_serial.fetch_add(1, std::memory_order_relaxed);
-  if (p.seq == 0) p.seq = launch_serial.fetch_add(1, std::memory_order_relaxed);      // 0 = the memset value of the marks
+  p.sat = reinterpret_cast<unsigned long long*>(saturation_counter());
+  p.seq = next_serial();
   hipError_t e = launch[nt](p, (unsigned)grid, stream);
   if (e != hipSuccess) return fail(GBNF_ERR_HIP, "launch of %s failed: %s", names[nt], hipGetErrorString(e));
-  if (mode == GBNF_MATH_F16X3 && table2 != nullptr && f->launch2_nt[nt] != nullptr && repair_enabled()) {
-    p.blobs = table2;
-    p.repair = 1;                      // (same seq: the launch it repairs; p.sat stays: the mark is read from there)
-    e = f->launch2_nt[nt](p, (unsigned)grid, stream);
+  const bool split_pair = mode == GBNF_MATH_F16X3 && table2 != nullptr && f->launch2_nt[nt] != nullptr;
+  if (split_pair && repair_enabled()) {
+    FlowLaunch r = p;
+    r.blobs = table2;
+    r.repair = 1;                      // (same seq: the launch it repairs; the mark is read from r.sat)
+    r.guard = guard ? guard->flag_dev : nullptr;
+    e = f->launch2_nt[nt](r, (unsigned)grid, stream);
     if (e != hipSuccess) return fail(GBNF_ERR_HIP, "repair launch of %s failed: %s", f->name2_nt[nt], hipGetErrorString(e));
+  }
+  // ---- numerics guard: this handle's first launch and every check_every-th re-check the f16x3 choice on the caller's rows
+  if (split_pair && guard != nullptr && f->launch_nt[1] != nullptr && f->launch2_nt[1] != nullptr && n_comp <= guard->n_comp) {
+    const long long k = guard->launches.fetch_add(1, std::memory_order_relaxed);
+    const int every = tuning().check_every.load(std::memory_order_relaxed);
+    if (every >= 0 && (k == 0 || (every > 0 && k % every == 0))) {
+      const int rows = (int)(n < GUARD_ROWS ? n : GUARD_ROWS);
+      FlowLaunch q = p;
+      q.n = rows; q.n_batches = 1; q.out_stride = GUARD_ROWS; q.n_tiles = (rows + 15) / 16;
+      q.z_out = nullptr; q.ldj_out = nullptr; q.repair = 0; q.guard = nullptr;
+      const unsigned mini_grid = (unsigned)(q.n_tiles * n_comp);
+      q.ll_out = guard->scratch_dev;
+      q.seq = next_serial();
+      e = f->launch_nt[1](q, mini_grid, stream);
+      if (e == hipSuccess) {
+        q.blobs = table2;
+        q.ll_out = guard->scratch_dev + (size_t)guard->n_comp * GUARD_ROWS;
+        q.seq = next_serial();
+        e = f->launch2_nt[1](q, mini_grid, stream);
+      }
+      if (e != hipSuccess) return fail(GBNF_ERR_HIP, "numerics-guard launch failed: %s", hipGetErrorString(e));
+      hipLaunchKernelGGL(guard_compare_kernel, dim3(1), dim3(256), 0, stream, (const float*)guard->scratch_dev,
+                         (const float*)(guard->scratch_dev + (size_t)guard->n_comp * GUARD_ROWS), n_comp, rows,
+                         PROBE_MAX_REL_ERR, guard->flag_dev, guard->status_dev);
+      e = hipGetLastError();
+      if (e != hipSuccess) return fail(GBNF_ERR_HIP, "numerics-guard compare launch failed: %s", hipGetErrorString(e));
+      // the launch that was just checked: re-evaluated in full on bf16x6 if (and only if) the check failed
+      FlowLaunch r = p;
+      r.blobs = table2;
+      r.repair = 2;
+      r.guard = guard->flag_dev;
+      e = f->launch2_nt[nt](r, (unsigned)grid, stream);
+      if (e != hipSuccess) return fail(GBNF_ERR_HIP, "numerics-guard re-evaluation launch failed: %s", hipGetErrorString(e));
+    }
   }
   return GBNF_OK;
 }
@@ -1139,7 +1285,8 @@ int gbnf_flow_forward(const gbnf_flow* flow, const float* x, int64_t n, float* z
   if (!flow) return fail(GBNF_ERR_INVALID, "gbnf_flow_forward: flow is null");
   if (n < 0) return fail(GBNF_ERR_INVALID, "gbnf_flow_forward: n < 0");
   if (n > 0 && !x) return fail(GBNF_ERR_INVALID, "gbnf_flow_forward: x is null");
-  return launch_flow(flow, flow->self_table_dev, flow->self_table2_dev, false, 0, 1, x, n, z, ldj, ll, nullptr, (hipStream_t)stream);
+  return launch_flow(flow, flow->self_table_dev, flow->self_table2_dev, false, 0, 1, x, n, z, ldj, ll, nullptr, (hipStream_t)stream, -1,
+                     nullptr, 1, 0, flow->guard);
 }
 
 int gbnf_flow_inverse(const gbnf_flow* flow, const float* z, int64_t n, float* x, float* ldj, void* stream) {
@@ -1207,9 +1354,15 @@ int gbnf_mixture_create(gbnf_flow* const* flows, int32_t n_flows, gbnf_mixture**
     e = hipMalloc((void**)&m->table2_dev, sizeof(uint32_t*) * n_flows);
     if (e == hipSuccess) e = hipMemcpy(m->table2_dev, table2.data(), sizeof(uint32_t*) * n_flows, hipMemcpyHostToDevice);
   }
+  if (e == hipSuccess && have2 && m->math_mode == GBNF_MATH_F16X3) {
+    bool all_default = true;
+    for (int c = 0; c < n_flows; ++c) all_default = all_default && flows[c]->requested_mode == GBNF_MATH_DEFAULT;
+    if (all_default) e = make_guard(n_flows, &m->guard);
+  }
   if (e != hipSuccess) {
     if (m->table_dev) (void)hipFree(m->table_dev);
     if (m->table2_dev) (void)hipFree(m->table2_dev);
+    free_guard(m->guard);
     delete m;
     return fail(GBNF_ERR_HIP, "gbnf_mixture_create: %s", hipGetErrorString(e));
   }
@@ -1222,6 +1375,7 @@ int gbnf_mixture_destroy(gbnf_mixture* mix) {
   if (mix->table_dev) (void)hipFree(mix->table_dev);
   if (mix->table2_dev) (void)hipFree(mix->table2_dev);
   if (mix->base_dev) (void)hipFree(mix->base_dev);
+  free_guard(mix->guard);
   delete mix;
   return GBNF_OK;
 }
@@ -1271,7 +1425,7 @@ int gbnf_mixture_component_log_prob_multi(const gbnf_mixture* mix, const float* 
   if (n < 0) return fail(GBNF_ERR_INVALID, "n < 0");
   if (n > 0 && c_end > c_begin && (!x || !ll)) return fail(GBNF_ERR_INVALID, "x / ll is null");
   return launch_flow(mix->flows[0], mix->table_dev, mix->table2_dev, mix->use_blob2, c_begin, c_end - c_begin, x, n, nullptr, nullptr, ll,
-                     mix->base_dev, (hipStream_t)stream, ll_row_stride, xs, n_batches);
+                     mix->base_dev, (hipStream_t)stream, ll_row_stride, xs, n_batches, 0, mix->guard);
 }
 
 int gbnf_mixture_lse(const float* ll, int64_t ll_row_stride, const float* rho_dev, int32_t n_components, int64_t n,
@@ -1297,6 +1451,42 @@ int gbnf_mixture_log_prob(const gbnf_mixture* mix, const float* x, int64_t n, in
   int rc = gbnf_mixture_component_log_prob(mix, x, n, 0, n_used, ll_workspace, stream);
   if (rc) return rc;
   return gbnf_mixture_lse(ll_workspace, n, rho_dev, n_used, n, out, stream);
+}
+
+static void fill_numerics(const Guard* g, int mode, gbnf_numerics_status* out) {
+  out->math_mode = mode; out->demoted = 0; out->checks = 0; out->worst_rel_err = 0.0f; out->tolerance = PROBE_MAX_REL_ERR;
+  if (g == nullptr) return;
+  const volatile GuardStatus* st = g->status_host;
+  out->demoted = st->demoted != 0u ? 1 : 0;
+  out->checks = (int64_t)st->checks;
+  out->worst_rel_err = st->worst_rel_err;
+  if (out->demoted && mode == GBNF_MATH_F16X3) out->math_mode = GBNF_MATH_BF16X6;
+}
+
+int gbnf_flow_numerics(const gbnf_flow* flow, gbnf_numerics_status* out) {
+  if (!flow || !out) return fail(GBNF_ERR_INVALID, "gbnf_flow_numerics: null argument");
+  fill_numerics(flow->guard, flow->math_mode, out);
+  return GBNF_OK;
+}
+
+int gbnf_mixture_numerics(const gbnf_mixture* mix, gbnf_numerics_status* out) {
+  if (!mix || !out) return fail(GBNF_ERR_INVALID, "gbnf_mixture_numerics: null argument");
+  fill_numerics(mix->guard, mix->math_mode, out);
+  return GBNF_OK;
+}
+
+int gbnf_tuning_set(const char* key, int32_t value) {
+  std::atomic<int>* slot = tuning_slot(key);
+  if (!slot) return fail(GBNF_ERR_INVALID, "gbnf_tuning_set: unknown key '%s'", key ? key : "(null)");
+  slot->store(value, std::memory_order_relaxed);
+  return GBNF_OK;
+}
+
+int gbnf_tuning_get(const char* key, int32_t* value) {
+  std::atomic<int>* slot = tuning_slot(key);
+  if (!slot || !value) return fail(GBNF_ERR_INVALID, "gbnf_tuning_get: unknown key '%s' or null value", key ? key : "(null)");
+  *value = slot->load(std::memory_order_relaxed);
+  return GBNF_OK;
 }
 
 int gbnf_actnorm_init(const float* z, int64_t n, int32_t d, float scale, float* bias_out, float* logs_out,

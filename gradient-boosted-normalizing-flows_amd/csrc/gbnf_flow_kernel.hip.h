@@ -94,19 +94,26 @@ struct FlowLaunch {
   int32_t n_batches;             // 1..MAX_BATCHES (z_out / ldj_out only with 1)
   int32_t inverse;               // f32 kernel only: run the flow backwards (xs = z in, z_out = x out, ldj_out = log|det dx/dz|)
   unsigned long long* dbg;       // diagnostic builds (-DGBNF_STAMPS) only: per-block phase cycle sums
-  unsigned* sat;                 // split-f16 kernel: counter of waves that stored an operand beyond the fp16 range
+  unsigned long long* sat;       // split-f16 kernel: [0] counter of waves that stored an operand beyond the fp16 range, marks behind it
   int32_t ring;                  // hx3 kernels: stage slots of the LDS weight ring (2..HX3_MAX_RING), set by the launcher
-  int32_t repair;                // hx3 kernels: 1 = only workgroups owning a sample whose outputs are NaN run (the bf16x6 pass
-                                 //   behind an f16x3 launch that marked out-of-range samples)
+  int32_t repair;                // hx3 kernels (bf16x6 instantiations): 1 = the pass behind an f16x3 launch: only workgroups owning a
+                                 //   sample whose outputs are NaN run (samples the f16x3 launch marked as out of range) -- or every
+                                 //   workgroup once *guard != 0; 2 = conditional full launch: returns at once unless *guard != 0
   int32_t lds_tables;            // hx3 kernels: per-step tables staged in LDS (else read from the blob), set by the launcher
   int32_t stagger;               // hx3 kernels, 4-wave workgroups in pairs per CU: sleeps of 2048 cycles for the one in the odd wave slots
-  uint32_t seq;                  // hx3 kernels: serial number of an f16x3 launch and its repair launch: the f16x3 launch writes it to
-                                 //   sat[SAT_MARKS + seq % SAT_SLOTS] when it marks a sample, the repair launch exits at once otherwise
+  unsigned long long seq;        // hx3 kernels: serial number of an f16x3 launch and its repair launch (process-wide, never 0, never
+                                 //   reused): the f16x3 launch raises mark slot seq % SAT_SLOTS to it (atomicMax) when it marks a sample;
+                                 //   the repair launch returns at once when the slot is below its seq (nobody from its launch on has
+                                 //   marked), runs when it is equal, and also runs when it is above (a later launch that shares the
+                                 //   slot has marked and may have hidden this launch's mark)
+  const unsigned* guard;         // hx3 kernels: the handle's numerics-guard word (device) or null: non-zero = the f16x3 arithmetic failed
+                                 //   the check on the caller's data, every repair launch re-evaluates its whole work list in bf16x6
   int32_t n_items;               // hx3 kernels: work items (component, batch, tile group) of the launch; a repair launch walks them
                                  //   with a grid of at most a few workgroups per CU
 };
-constexpr int SAT_MARKS = 2;     // layout of the per-device saturation words: [0] counter, [1] unused, [2 ..] launch marks
-constexpr int SAT_SLOTS = 64;
+// Per-device saturation words (64-bit): [0] counter of waves that marked a sample, [1] unused, [2 ..] launch marks
+constexpr int SAT_MARKS = 2;
+constexpr int SAT_SLOTS = 1024;
 
 __device__ __forceinline__ float as_f32(uint32_t u) { return __builtin_bit_cast(float, u); }
 
@@ -866,6 +873,7 @@ struct VariantKey {
 };
 using LaunchFn = hipError_t (*)(const FlowLaunch&, unsigned grid, hipStream_t);
 void register_variant(const VariantKey& key, LaunchFn fn, const char* name);
+int tuning_wg_pairs();      // launch policy of the split kernels' 4-wave workgroup pairs (gbnf_api.hip, gbnf_tuning_set "wg_pairs")
 
 #define GBNF_INSTANTIATE(KIND, HT, KSL, KS1, OT, NT, LMID, ACTA, ACTB)                                      \
   namespace gbnf {                                                                                          \

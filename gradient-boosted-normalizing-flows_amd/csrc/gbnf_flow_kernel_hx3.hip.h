@@ -139,8 +139,15 @@ __device__ __forceinline__ void split_pair_f16(float x0, float x1, unsigned (&p)
   r0 = x0 - (float)h[0];
   r1 = x1 - (float)h[1];
 #else
-  asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(r0) : "v"(hw), "v"(x0));
-  asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(r1) : "v"(hw), "v"(x1));
+  // IN PLACE (the residual overwrites x): hipcc's hazard recognizer does not see into inline asm, so an asm OUTPUT must never
+  // be a fresh register -- the allocator may hand it a register that a v_mfma issued a few instructions earlier is still
+  // going to write (its dead result), and nothing pads that write-after-write (tools/isa_hazard_lint.py found two such
+  // places, 6 wait states behind the v_mfma where 7 are needed).  x's register was last written by a VALU instruction the
+  // compiler did see.
+  r0 = x0;
+  r1 = x1;
+  asm("v_fma_mix_f32 %0, %1, -1.0, %0 op_sel_hi:[1,0,0]" : "+v"(r0) : "v"(hw));
+  asm("v_fma_mix_f32 %0, %1, -1.0, %0 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(r1) : "v"(hw));
 #endif
   const auto m = __builtin_amdgcn_cvt_pkrtz(r0, r1);
   p[1] = __builtin_bit_cast(unsigned, m);
@@ -241,8 +248,13 @@ flow_kernel_hx3(const FlowLaunch p) {
   const int i = lane & 15;
   const int g = lane >> 4;
 
-  // ---- a repair launch that has nothing to repair ends here: the f16x3 launch it follows left no mark
-  if (p.repair && p.sat != nullptr && p.sat[SAT_MARKS + p.seq % SAT_SLOTS] != p.seq) return;
+  // ---- a repair launch that has nothing to repair ends here: no launch from the one it follows on has raised the mark
+  //      slot to its serial number (FlowLaunch::seq) and the handle's numerics guard has not tripped
+  const bool redo_all = PREC == 1 && p.repair && p.guard != nullptr && p.guard[0] != 0u;
+  if (p.repair && !redo_all) {
+    if (p.repair == 2) return;
+    if (p.sat != nullptr && p.sat[SAT_MARKS + p.seq % SAT_SLOTS] < p.seq) return;
+  }
 
   // ---- work items: (component, batch, group of WAVES sample tiles).  A normal launch has one workgroup per item; a
   //      repair launch walks the items with a small grid and skips those without a marked sample.
@@ -273,7 +285,7 @@ flow_kernel_hx3(const FlowLaunch p) {
   const int64_t out_base = (int64_t)comp * p.out_stride + (int64_t)batch * p.n;
 
   // ---- repair launch: only items that own a sample marked by the f16x3 launch (NaN in its outputs) are evaluated
-  if (p.repair) {
+  if (p.repair && !redo_all) {
     bool need = false;
     if (lane < 16 * NT) {
       const int64_t n = row0 + lane;
@@ -450,22 +462,49 @@ flow_kernel_hx3(const FlowLaunch p) {
     load_unit(N0, 0);
     load_unit(N1, 1);
   };
-  // MFMA-tail guard.  The last unit of a stage that ended early runs behind the stage-end barrier; its last v_mfma is
-  // followed directly by the next stage's address arithmetic and staging DMA (hipcc reuses the chain's dead source-C
-  // registers for the DMA address, 7 wait states behind the v_mfma).  In that shape the 8-wave d=63 h=128 variant
-  // (12 MFMAs per stage, DMA-latency bound) returned whole 16-sample tiles off by 5e-2, another set of tiles on every
-  // launch (fixture g5_glow_d63_h128_c2).  Bisect on the GPU (profiles/r2_stage_boundary_bisect.txt): ending passes
-  // late cures it, so do 4-wave workgroups, fragment reads or a pause BEHIND the last unit, and 4 idle wait states
-  // there; 1 idle wait state, an extra barrier, a pause or an lgkmcnt(0) in FRONT of the last unit do not.  The weight
-  // fragments the waves consumed were identical in good and bad runs, so it is not a staging race.  The isolated
-  // sequences (dead-register overwrite, the 64-bit address add, the whole m0 / add / DMA / ds_read tail behind a dependent
-  // untied v_mfma chain: tools/ubench/mfma_tail_hazard.hip) are all handled correctly by the hardware at 0 wait states,
-  // with one and with two waves per SIMD, so the mechanism is NOT pinned down; the guard below is empirical: eight idle
-  // wait states behind the last unit of every stage kind that ends early (twice the measured need; no measurable cost).
+  // MFMA-tail guard.  ROOT CAUSE (round 3, profiles/r3_mfma_hazard_root_cause.txt): reading a v_mfma result needs 7 wait
+  // states behind the v_mfma (no hardware interlock; measured, tools/ubench/mfma_raw_latency.hip), and hipcc pads them only
+  // along the FALL-THROUGH path of a conditional branch.  With a stage ending in front of its last unit, the last hidden
+  // pass's last v_mfma (its result `pre` is the last hidden tile) is followed by the drain's
+  // `if (another net or step follows) issue_net_start()`: on the fall-through side the staging DMA's address arithmetic
+  // supplies the wait states, on the TAKEN side -- the last step of every component -- the drain's first v_exp_f32 read
+  // `pre` 1-2 wait states behind the v_mfma and got the previous contents of the registers whenever the instruction fetch
+  // at the branch target was fast: whole 16-sample tiles off by 5e-2, another set of waves on every launch (fixture
+  // g5_glow_d63_h128_c2, 100 % of launches in tools/tail_repro.py).  Only the code layout of that one variant put the
+  // reader right at the branch target, which is why nothing else failed.  The fix is the padding the compiler owes: eight
+  // idle wait states behind the last unit of every stage that ends early (whatever follows, on whichever path, is then
+  // >= 8 wait states behind the last v_mfma), no measurable cost -- and tools/isa_hazard_lint.py (tests/test_isa_lint.py)
+  // walks the control-flow graph of EVERY shipped kernel and fails the build if any path reads a v_mfma result early.
+  // (Round 2's reading -- a VALU / LDS write into the dead srcC registers -- was wrong: the hardware interlocks those,
+  // tools/ubench/mfma_srcc_war.hip, mfma_srcab_war.hip, mfma_lds_war.hip: 0 wrong results at 0 wait states under load.)
+#ifndef GBNF_HX3_TAIL_MODE
+#define GBNF_HX3_TAIL_MODE 1        // experiment knob (tools/build_tail_experiments.sh): 0 = no guard, 1 = s_nop 7 (shipped), 2 = the last
+#endif                              //   unit's A operands pinned live behind its v_mfma (no guard), 3 = both
   auto mfma_tail_guard = [&]() {
+#if GBNF_HX3_TAIL_MODE == 1 || GBNF_HX3_TAIL_MODE == 3
     __builtin_amdgcn_sched_barrier(0);
     asm volatile("s_nop 7" ::: "memory");
     __builtin_amdgcn_sched_barrier(0);
+#endif
+  };
+  auto guard_at = [&](int pos) {              // experiment: the guard's idle wait states at another place of the following pass
+#if GBNF_HX3_TAIL_MODE >= 4
+    if (pos == GBNF_HX3_TAIL_MODE) {
+      __builtin_amdgcn_sched_barrier(0);
+      asm volatile("s_nop 7" ::: "memory");
+      __builtin_amdgcn_sched_barrier(0);
+    }
+#else
+    (void)pos;
+#endif
+  };
+  auto pin_unit = [&](const Unit& a) {        // (TAIL_MODE 2 / 3) the unit's registers stay live up to here
+#if GBNF_HX3_TAIL_MODE == 2 || GBNF_HX3_TAIL_MODE == 3
+#pragma unroll
+    for (int q = 0; q < NP; ++q) asm volatile("" ::"v"(a.w[q]));
+#else
+    (void)a;
+#endif
   };
 #ifndef GBNF_HX3_PIPE_MASK
 #define GBNF_HX3_PIPE_MASK 7        // diagnostic: which stage kinds end early (1 layer-0 stages, 2 passes, 4 drain)
@@ -790,11 +829,14 @@ flow_kernel_hx3(const FlowLaunch p) {
           constexpr int NU = HC + (PREV == 2 ? OT : 0);       // consumption units of this stage
           // the stage after this one: the drain, a pass with an output-layer chunk (after an odd pass), or a plain pass
           constexpr int NF_NEXT = LAST ? NP * OT : (PREV == 1 ? NP * (HC + OT) : NP * HC);
+          guard_at(6);
           issue(std::integral_constant<int, NF_NEXT>{}, gs + 1);
+          guard_at(4);
           Unit A[3];
           A[0] = N0;
           A[1] = N1;
           const f32x4 bias_next = ldb(DEPTH * HT + (u + 1 < HT ? u + 1 : u));
+          guard_at(5);
           Acc acc[NT];
 #pragma unroll
           for (int nt = 0; nt < NT; ++nt) acc[nt].init(bias);
@@ -822,6 +864,7 @@ flow_kernel_hx3(const FlowLaunch p) {
             }
             __builtin_amdgcn_sched_barrier(0);
           }
+          pin_unit(A[(NU - 1) % 3]);
 #pragma unroll
           for (int nt = 0; nt < NT; ++nt) pre[nt] = acc[nt].total();
           bias = bias_next;
@@ -853,6 +896,7 @@ flow_kernel_hx3(const FlowLaunch p) {
         st.set(4);
         // ---- drain: last tile, last output-layer chunk (HC-1); the next net's / step's first stage goes in flight
         {
+          guard_at(7);
           if ((net + 1 < NNETS) || (step + 1 < p.n_steps)) {
             if (net + 1 == NNETS) next_src += SMALL_WORDS;     // the next step's tables sit in front of its first net
             issue_net_start(gs + 1);
@@ -1009,8 +1053,8 @@ flow_kernel_hx3(const FlowLaunch p) {
     }
   }
   if (WATCH && p.sat != nullptr && any_sat && lane == 0) {
-    atomicAdd(p.sat, 1u);
-    p.sat[SAT_MARKS + p.seq % SAT_SLOTS] = p.seq;      // tells the repair launch behind this one that it has work
+    atomicAdd(p.sat, 1ull);
+    atomicMax(p.sat + SAT_MARKS + p.seq % SAT_SLOTS, p.seq);      // tells the repair launch behind this one that it has work
   }
   if (p.z_out != nullptr && lane < d) {
     const int slot = (int)tail[lane];
@@ -1084,14 +1128,14 @@ static hipError_t hx3_launch_wv(FlowLaunch p, bool staggered, hipStream_t s) {
     constexpr int ENT = hx3_eff_nt(HT, OT, NT, PREC, KIND, ACTA, ACTB, DEPTH);                              \
     constexpr int WAVES = hx3_waves(HT, OT, ENT, PREC, KIND, ACTA, ACTB, DEPTH);                            \
     if constexpr (WAVES == 8) {                                                                             \
-      static const bool no_pairs = [] { const char* e = getenv("GBNF_NO_WG_PAIRS"); return e && atoi(e) != 0; }(); \
+      const int pairs = tuning_wg_pairs();       /* -1 automatic, 0 never, 1 whenever they fit (gbnf_tuning_set) */        \
       /* two 4-wave workgroups per CU where they fit: 80 KB each, tables included */                        \
       const bool fits4 = flow_hx3_lds_bytes(p0.n_steps, ENT, 4, L.STAGE_FRAGS, L.BIAS_FRAGS, p0.d, HX3_RING,  \
                                             p0.n_steps <= LDS_TABLE_STEPS) <= 80 * 1024;                    \
       const long long waves_total = (long long)((p0.n + 16 * ENT - 1) / (16 * ENT)) * p0.n_comp * p0.n_batches; \
       /* from one 4-wave workgroup per CU on (1024 waves): a lone wave per SIMD runs a stage in half the time of two    \
          sharing it (profiles/r2_ubench_pingpong.txt), so 256 such workgroups beat 128 8-wave ones on half the CUs */  \
-      if (fits4 && !no_pairs && !p0.repair && waves_total >= 1024)                                          \
+      if (fits4 && !p0.repair && (pairs > 0 || (pairs < 0 && waves_total >= 1024)))                         \
         return hx3_launch_wv<KIND, HT, OT, ENT, ACTA, ACTB, PREC, 4, DEPTH>(p0, true, s);                   \
     }                                                                                                       \
     return hx3_launch_wv<KIND, HT, OT, ENT, ACTA, ACTB, PREC, WAVES, DEPTH>(p0, false, s);                  \

@@ -35,6 +35,7 @@ ABI_SYMBOLS = (
     "gbnf_trainer_bind_batch_stats", "gbnf_trainer_set_batch_stats",
     "gbnf_image_flow_create", "gbnf_image_flow_destroy", "gbnf_image_flow_info", "gbnf_image_flow_workspace_bytes",
     "gbnf_image_flow_forward", "gbnf_image_flow_prior", "gbnf_image_flow_eps_floats", "gbnf_image_flow_inverse",
+    "gbnf_flow_numerics", "gbnf_mixture_numerics", "gbnf_tuning_set", "gbnf_tuning_get",
 )
 
 
@@ -98,7 +99,24 @@ class KernelInfo(C.Structure):
                 ("math_mode", C.c_int32), ("probe_rel_err", C.c_float)]
 
 
+class NumericsStatus(C.Structure):
+    """gbnf_numerics_status: the library's own re-check of a DEFAULT handle's f16x3 choice on the caller's data."""
+    _fields_ = [("math_mode", C.c_int32), ("demoted", C.c_int32), ("checks", C.c_int64),
+                ("worst_rel_err", C.c_float), ("tolerance", C.c_float)]
+
+
 _lib = None
+
+
+def tuning_set(key, value):
+    """Launch-policy knob of the library (include/gbnf.h, gbnf_tuning_set): tests, soak runs, tuning."""
+    _check(lib().gbnf_tuning_set(key.encode(), int(value)))
+
+
+def tuning_get(key):
+    v = C.c_int32()
+    _check(lib().gbnf_tuning_get(key.encode(), C.byref(v)))
+    return v.value
 
 
 def lib():
@@ -133,6 +151,10 @@ def lib():
     L.gbnf_actnorm_init.argtypes = [vp, i64, i32, C.c_float, vp, vp, vp]
     L.gbnf_boosting_weights.argtypes = [vp, i64, C.c_float, vp, vp]
     L.gbnf_flow_validate.argtypes = [C.POINTER(_FlowDesc)]
+    L.gbnf_flow_numerics.argtypes = [vp, C.POINTER(NumericsStatus)]
+    L.gbnf_mixture_numerics.argtypes = [vp, C.POINTER(NumericsStatus)]
+    L.gbnf_tuning_set.argtypes = [C.c_char_p, i32]
+    L.gbnf_tuning_get.argtypes = [C.c_char_p, C.POINTER(i32)]
     L.gbnf_trainer_create.argtypes = [C.POINTER(_FlowDesc), C.POINTER(vp)]
     L.gbnf_trainer_destroy.argtypes = [vp]
     L.gbnf_trainer_forward.argtypes = [vp, vp, i64, vp, vp, vp, vp]
@@ -259,6 +281,12 @@ class NativeFlow:
         ki = KernelInfo()
         _check(lib().gbnf_flow_info(self.handle, C.byref(ki)))
         return ki
+
+    def numerics(self):
+        """gbnf_flow_numerics: (math mode of the next launch, demoted?, completed checks, worst relative error); no sync."""
+        st = NumericsStatus()
+        _check(lib().gbnf_flow_numerics(self.handle, C.byref(st)))
+        return st
 
     def forward(self, x, want_z=True, want_ldj=True, want_ll=False):
         """x (n,d) cuda f32 -> (z|None, ldj|None, ll|None); enqueued on the current stream."""
@@ -668,6 +696,12 @@ class NativeMixture:
     @property
     def n_components(self):
         return len(self.flows)
+
+    def numerics(self):
+        """gbnf_mixture_numerics: the mixture's effective math mode and the state of its numerics guard; no sync."""
+        st = NumericsStatus()
+        _check(lib().gbnf_mixture_numerics(self.handle, C.byref(st)))
+        return st
 
     def set_base(self, mean=None, std=None):
         if mean is None:

@@ -184,7 +184,7 @@ class GroupPipeline:
         self.flow_done = [torch.cuda.Event() for _ in range(self.NBUF)]
         self.post_done = [torch.cuda.Event() for _ in range(self.NBUF)]
         self._bufs = {}        # group size -> per-slot (local, full, G)
-        self._bound = {}       # (slot, data_ptrs of the group's inputs) -> (flow launch, recursion launch)
+        self._lse = {}         # (group size, slot) -> bound recursion launch (depends on the pipeline's own buffers only)
         self.gi = 0            # groups submitted so far
         self.gather_events = None     # optional [(start, end)] timing events around the all-gathers (bench.py)
         if self.gather:
@@ -205,12 +205,15 @@ class GroupPipeline:
         return self._bufs[size]
 
     def _launches(self, q, xs):
-        key = (q,) + tuple(t.data_ptr() for t in xs)
-        if key not in self._bound:
-            local, full, G = self._buffers(len(xs))
-            self._bound[key] = (self.mix.prepared_group_log_prob(list(xs), local[q]),
-                                self.native.prepared_mixture_lse(full[q], self.rho, G[q]))
-        return self._bound[key]
+        """(flow launch, recursion launch) of the group `xs` into buffer slot q.  The flow launch keeps `xs` alive, so it is
+        NOT cached here (a caller streaming fresh batches through submit() would pin every input for the pipeline's
+        lifetime): ``bind`` hands it to the caller's token, plain ``submit(list)`` builds it per call.  The recursion
+        launch only refers to the pipeline's own buffers and is kept."""
+        local, full, G = self._buffers(len(xs))
+        key = (len(xs), q)
+        if key not in self._lse:
+            self._lse[key] = self.native.prepared_mixture_lse(full[q], self.rho, G[q])
+        return self.mix.prepared_group_log_prob(list(xs), local[q]), self._lse[key]
 
     def bind(self, xs):
         """Bind the launches of a group of input tensors for every buffer slot ahead of time: ``submit(token)`` then costs

@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define GBNF_ABI_VERSION 3
+#define GBNF_ABI_VERSION 4
 
 typedef enum gbnf_status {
   GBNF_OK = 0,
@@ -139,6 +139,39 @@ const char* gbnf_last_error(void);
  * resets the counter.  One counter per device: this reports (and resets) the CURRENT device's, after a
  * hipDeviceSynchronize() (every stream of that device). */
 int gbnf_saturation_count(int64_t* count, int32_t reset);
+
+/* Numerics guard of a GBNF_MATH_DEFAULT handle that runs on f16x3 (round 3; what the creation-time probe cannot know is
+ * the caller's data).  The library itself re-checks the choice on the data it is given: on the FIRST launch of a handle
+ * and then on every `check_every`-th (tuning key below, default 256) it evaluates up to 256 rows of the launch's first
+ * batch on f16x3 and on bf16x6 and compares the log-likelihoods ON THE DEVICE, in stream order behind the launch; if they
+ * differ by more than `tolerance` (2.5e-6 relative, a quarter of the 1e-5 parity bar) the handle's guard word is set and
+ *   - the bf16x6 pass that follows every f16x3 launch (the repair pass for out-of-range samples) re-evaluates the WHOLE
+ *     work list from then on, starting with the launch that failed the check: no result of a failed mode reaches the caller;
+ *   - the host sees the flag (pinned memory, no synchronisation) on a later call and launches bf16x6 directly.
+ * Every entry point that evaluates a flow (gbnf_flow_forward, gbnf_mixture_component_log_prob*, gbnf_mixture_log_prob)
+ * is covered, so C-ABI callers, sharded.GroupPipeline and bench.py get it like BoostedFlow does.  Handles created with
+ * an explicit GBNF_MATH_F16X3 keep the caller's choice (range repair only).  These calls never synchronise: `checks`
+ * and `worst_rel_err` are those of the checks that have COMPLETED on the device. */
+typedef struct gbnf_numerics_status {
+  int32_t math_mode;       /* GBNF_MATH_* the NEXT launch of this handle will run in                       */
+  int32_t demoted;         /* 1 = a check failed: the handle left f16x3 for bf16x6                          */
+  int64_t checks;          /* device-side checks completed so far                                           */
+  float worst_rel_err;     /* largest relative log-likelihood difference f16x3 vs bf16x6 seen by a check    */
+  float tolerance;
+} gbnf_numerics_status;
+int gbnf_flow_numerics(const gbnf_flow* flow, gbnf_numerics_status* out);
+int gbnf_mixture_numerics(const gbnf_mixture* mix, gbnf_numerics_status* out);
+
+/* Launch-policy knobs (process-wide; tests, soak runs and tuning -- the defaults are what is measured and shipped):
+ *   "force_nt"      0 = automatic | 1 | 2 : samples per wave = 16 x NT            (env GBNF_FORCE_NT at first use)
+ *   "wg_pairs"      -1 = automatic | 0 = never | 1 = whenever two 4-wave workgroups fit a CU   (env GBNF_NO_WG_PAIRS=1 -> 0)
+ *   "repair"        1 | 0 : the bf16x6 pass behind f16x3 launches                 (env GBNF_NO_REPAIR=1 -> 0)
+ *   "nt2_min_waves" 32-sample waves from this many waves on (default 1024)        (env GBNF_NT2_MIN_WAVES)
+ *   "check_every"   numerics guard: a check on launch 0 and every this many launches (default 256; 0 = first launch only;
+ *                   -1 = never)
+ * Returns GBNF_ERR_INVALID for an unknown key. */
+int gbnf_tuning_set(const char* key, int32_t value);
+int gbnf_tuning_get(const char* key, int32_t* value);
 
 /* Replaces: constructing flows[c] + .to(device)  (models/boosted_flow.py:42-50).
  * Packs (pads, tiles, folds slot maps) and uploads the parameters. */

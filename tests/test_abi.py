@@ -23,7 +23,7 @@ def test_library_exports_every_declared_symbol():
     for name in _declared_symbols():
         assert hasattr(lib, name), f"{name} missing from libgbnf_hip.so"
     lib.gbnf_version.restype = ctypes.c_int
-    assert lib.gbnf_version() == 3           # GBNF_ABI_VERSION; touches no device
+    assert lib.gbnf_version() == 4           # GBNF_ABI_VERSION; touches no device
 
 
 def test_ctypes_structs_match_header_layout():
