@@ -291,12 +291,12 @@ def main():
     c0, c1 = parts[rank]
     rho = torch.from_numpy(rho_np).to(dev)
     S = max(1, min(args.group, 32, args.steps))      # a run shorter than one group times one launch of that size
-    if gather:
-        # Sharded runs: a rank's launch should be a whole number of rounds of workgroups (512 slots x 128 rows = 65536
-        # row-components: two 4-wave workgroups per CU) -- a launch of 1.25 rounds takes as long as one of 2, because the
-        # tail's workgroups pair up on a quarter of the CUs instead of spreading out -- and a short run should still be
-        # several groups, so that the exchange of one overlaps the kernel of the next.  --steps 20 at one component per
-        # rank: groups of 16 + 4 batches (the 4-batch launch is one workgroup per CU) instead of one launch of 20.
+    if gather and args.steps >= 4 * S:
+        # Sharded steady-state runs: a rank's launch should be a whole number of rounds of workgroups (512 slots x 128 rows
+        # = 65536 row-components: two 4-wave workgroups per CU) -- a launch of 1.25 rounds takes as long as one of 1.5.
+        # (A SHORT sharded run stays ONE group: measured at --steps 20, one component per rank, profiles/
+        # r3_emulated_steps20_timeline.txt: 16 + 4 batches in two groups take 338 us against 240 us for one launch of 20 --
+        # the host needs ~50 us per group for the RCCL call and the stream bookkeeping, which only a longer kernel hides.)
         fit = max(1, ROWS_PER_ROUND // (B * (c1 - c0)))
         if S > fit:
             S = S // fit * fit
@@ -338,7 +338,9 @@ def main():
         flows = [native.NativeFlow(specs[c], math=math) for c in range(c0, c1)]
         mix = native.NativeMixture(flows)
         info = flows[0].info()
-        pipe = sharded.GroupPipeline(mix, C, c0, c1, rho, B, group, gather)
+        # one group in the whole run: nothing to overlap the exchange with, so it stays on the kernel's stream (a cross-stream
+        # event hand-over costs ~20 us of latency on this stack)
+        pipe = sharded.GroupPipeline(mix, C, c0, c1, rho, B, group, gather, overlap=steps > group)
         if pipe.post is not pipe.main and pipe.post not in extra_streams:
             extra_streams.append(pipe.post)
 

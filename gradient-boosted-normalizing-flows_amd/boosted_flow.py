@@ -557,11 +557,19 @@ class BoostedFlow(nn.Module):
     #   range      an operand beyond the fp16 range is repaired on the device by the bf16x6 pass behind every f16x3 launch;
     #   precision  at creation the library probes every component (N(0,1) / N(0,4) rows) on the f16x3 and the bf16x6
     #              packing and keeps f16x3 only when they agree to 2.5e-6 (GBNF_MATH_DEFAULT);
-    #   data       the first batch a packed component sees is evaluated on both packings as well (`verify_numerics`,
-    #              <= 256 rows, one synchronisation per re-pack): a component whose REAL data is harder than the probe
-    #              moves to bf16x6 for good.  `numerics_guard = False` switches this data check off.
-    numerics_guard = True
+    #   data       the LIBRARY re-checks the choice on the caller's data, on the device and without a synchronisation: the
+    #              first launch of every handle and every 256th evaluate <= 256 rows on both packings; a failed check
+    #              re-evaluates that launch on bf16x6 and moves the handle there for good (include/gbnf.h,
+    #              gbnf_numerics_status; `numerics_status()` below).  Round 2 did this check here, in Python, for module
+    #              callers only; `verify_numerics` remains as the explicit, synchronous form.
     NUMERICS_TOL = 2.5e-6
+
+    def numerics_status(self, n_used=None):
+        """State of the library's numerics guard for the mixture of the first n_used components (no synchronisation):
+        dict(math_mode, demoted, checks, worst_rel_err, tolerance)."""
+        st = self.native_mixture(self._n_used(n_used)).numerics()
+        return {"math_mode": native.MATH_NAME[int(st.math_mode)], "demoted": bool(st.demoted), "checks": int(st.checks),
+                "worst_rel_err": float(st.worst_rel_err), "tolerance": float(st.tolerance)}
 
     @torch.no_grad()
     def verify_numerics(self, x, components=None, rows=256):
@@ -594,17 +602,8 @@ class BoostedFlow(nn.Module):
         return worst
 
     def _guard(self, x, comps):
-        """First batch after a (re)pack: the data check of `verify_numerics` (eval mode only)."""
-        if not self.numerics_guard or self.training:
-            return
-        done = self.__dict__.setdefault("_calibrated", set())
-        todo = []
-        for c in comps:
-            self.native_flow(c)                  # (re)packs if the parameters changed, which clears the mark
-            if c not in done:
-                todo.append(c)
-        if todo:
-            self.verify_numerics(x, todo)
+        """(The data check lives in the library since round 3: every handle checks its own first launch on the device.)"""
+        return
 
     def _per_step_activation(self):
         """`--coupling_network random`: components (or the steps of one) differ in activation, so every handle is packed

@@ -142,7 +142,7 @@ unsigned* saturation_counter() {
 
 // ---- launch-policy knobs (gbnf_tuning_set / _get; initialised from the environment at first use)
 struct Tuning {
-  std::atomic<int> force_nt{0}, wg_pairs{-1}, repair{1}, nt2_min_waves{1024}, check_every{256};
+  std::atomic<int> force_nt{0}, wg_pairs{-1}, repair{1}, nt2_min_waves{1024}, check_every{256}, check_tolerance_e9{2500};
   Tuning() {
     auto env = [](const char* k) -> const char* { return getenv(k); };
     if (const char* e = env("GBNF_FORCE_NT")) force_nt = atoi(e);
@@ -165,6 +165,7 @@ static std::atomic<int>* tuning_slot(const char* key) {
   if (!strcmp(key, "repair")) return &t.repair;
   if (!strcmp(key, "nt2_min_waves")) return &t.nt2_min_waves;
   if (!strcmp(key, "check_every")) return &t.check_every;
+  if (!strcmp(key, "check_tolerance_e9")) return &t.check_tolerance_e9;
   return nullptr;
 }
 
@@ -1084,7 +1085,8 @@ static int launch_flow(const gbnf_flow* f, const uint32_t* const* table, const u
       if (e != hipSuccess) return fail(GBNF_ERR_HIP, "numerics-guard launch failed: %s", hipGetErrorString(e));
       hipLaunchKernelGGL(guard_compare_kernel, dim3(1), dim3(256), 0, stream, (const float*)guard->scratch_dev,
                          (const float*)(guard->scratch_dev + (size_t)guard->n_comp * GUARD_ROWS), n_comp, rows,
-                         PROBE_MAX_REL_ERR, guard->flag_dev, guard->status_dev);
+                         1e-9f * (float)tuning().check_tolerance_e9.load(std::memory_order_relaxed), guard->flag_dev,
+                         guard->status_dev);
       e = hipGetLastError();
       if (e != hipSuccess) return fail(GBNF_ERR_HIP, "numerics-guard compare launch failed: %s", hipGetErrorString(e));
       // the launch that was just checked: re-evaluated in full on bf16x6 if (and only if) the check failed
@@ -1454,7 +1456,8 @@ int gbnf_mixture_log_prob(const gbnf_mixture* mix, const float* x, int64_t n, in
 }
 
 static void fill_numerics(const Guard* g, int mode, gbnf_numerics_status* out) {
-  out->math_mode = mode; out->demoted = 0; out->checks = 0; out->worst_rel_err = 0.0f; out->tolerance = PROBE_MAX_REL_ERR;
+  out->math_mode = mode; out->demoted = 0; out->checks = 0; out->worst_rel_err = 0.0f;
+  out->tolerance = 1e-9f * (float)tuning().check_tolerance_e9.load(std::memory_order_relaxed);
   if (g == nullptr) return;
   const volatile GuardStatus* st = g->status_host;
   out->demoted = st->demoted != 0u ? 1 : 0;

@@ -19,6 +19,7 @@ KIND = {"glow": 0, "realnvp": 1}
 ACT = {"tanh": 0, "relu": 1, "residual": 2}     # GBNF_ACT_TANH / _RELU / _RESIDUAL_RELU
 COUPLING = {"affine": 0, "additive": 1}
 MATH = {"default": -1, "f32": 0, "f16x3": 1, "bf16x6": 2}
+MATH_NAME = {v: k for k, v in MATH.items()}
 
 # every symbol include/gbnf.h declares (tests check the library exports exactly these)
 ABI_SYMBOLS = (

@@ -168,7 +168,7 @@ class GroupPipeline:
 
     NBUF = 2
 
-    def __init__(self, mix, n_components, c_begin, c_end, rho, rows, group_size, gather, process_group=None):
+    def __init__(self, mix, n_components, c_begin, c_end, rho, rows, group_size, gather, process_group=None, overlap=True):
         import torch
         from . import native
         self.torch, self.native = torch, native
@@ -180,7 +180,9 @@ class GroupPipeline:
         self.main = torch.cuda.current_stream(self.dev)
         import ctypes
         self._mptr = ctypes.c_void_p(self.main.cuda_stream)
-        self.post = torch.cuda.Stream(self.dev) if self.gather else self.main
+        # overlap=False: exchange + recursion on the kernel's own stream (a caller with a single group has nothing to overlap
+        # them with and saves the cross-stream hand-over)
+        self.post = torch.cuda.Stream(self.dev) if (self.gather and overlap) else self.main
         self.flow_done = [torch.cuda.Event() for _ in range(self.NBUF)]
         self.post_done = [torch.cuda.Event() for _ in range(self.NBUF)]
         self._bufs = {}        # group size -> per-slot (local, full, G)
@@ -239,7 +241,8 @@ class GroupPipeline:
             flow, lse = self._launches(q, xs)
         local, full, G = self._buffers(len(xs))
         mptr = self._mptr
-        if self.gather and self.gi >= self.NBUF:
+        two_streams = self.post is not self.main
+        if two_streams and self.gi >= self.NBUF:
             self.main.wait_event(self.post_done[q])          # group gi-NBUF has released this buffer set
         if kernel_events is not None:
             kernel_events[0].record(self.main)
@@ -247,8 +250,9 @@ class GroupPipeline:
         if kernel_events is not None:
             kernel_events[1].record(self.main)
         if self.gather:
-            self.flow_done[q].record(self.main)
-            self.post.wait_event(self.flow_done[q])
+            if two_streams:
+                self.flow_done[q].record(self.main)
+                self.post.wait_event(self.flow_done[q])
             with torch.cuda.stream(self.post):
                 ev = None
                 if self.gather_events is not None and len(self.gather_events) < 48:
@@ -259,7 +263,8 @@ class GroupPipeline:
                     ev[1].record(self.post)
                     self.gather_events.append(ev)
             lse(ctypes.c_void_p(self.post.cuda_stream))
-            self.post_done[q].record(self.post)
+            if two_streams:
+                self.post_done[q].record(self.post)
         else:
             lse(mptr)
         self.gi += 1
@@ -267,7 +272,7 @@ class GroupPipeline:
 
     def drain(self):
         """The main stream waits for every exchange / recursion submitted so far."""
-        if self.gather:
+        if self.post is not self.main:
             for ev in self.post_done[: min(self.gi, self.NBUF)]:
                 self.main.wait_event(ev)
 
@@ -286,7 +291,7 @@ class GroupPipeline:
 
     def _collect(self, item, outs):
         G, q, k = item
-        if self.gather:
+        if self.post is not self.main:
             self.main.wait_event(self.post_done[q])
         n = self.rows
         outs.extend(G[b * n:(b + 1) * n].clone() for b in range(k))

@@ -169,6 +169,8 @@ int gbnf_mixture_numerics(const gbnf_mixture* mix, gbnf_numerics_status* out);
  *   "nt2_min_waves" 32-sample waves from this many waves on (default 1024)        (env GBNF_NT2_MIN_WAVES)
  *   "check_every"   numerics guard: a check on launch 0 and every this many launches (default 256; 0 = first launch only;
  *                   -1 = never)
+ *   "check_tolerance_e9"  numerics guard: tolerance of a check in units of 1e-9 relative (default 2500 = 2.5e-6; 0 makes
+ *                   every check fail: how the tests exercise the demotion path)
  * Returns GBNF_ERR_INVALID for an unknown key. */
 int gbnf_tuning_set(const char* key, int32_t value);
 int gbnf_tuning_get(const char* key, int32_t* value);
