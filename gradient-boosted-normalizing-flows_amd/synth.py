@@ -42,8 +42,18 @@ def _res_net(rng, in_f, out_f, h, blocks, gain):
     return {"act": "residual", "layers": layers}
 
 
+def _trained_like_net(rng, net):
+    """Magnitudes a TRAINED flow ends up with rather than nn.Linear's init: the coupling net's last layer shrinks towards
+    the identity transform -- every output row gets its own factor 10^-3 .. 10^-4 (weights and bias): fp16-subnormal
+    territory for the `mid` piece of a split operand (VERDICT r2 weak #2)."""
+    w, b = net["layers"][-1]
+    f = np.power(10.0, rng.uniform(-4.0, -3.0, size=(w.shape[0], 1))).astype(np.float32)
+    net["layers"][-1] = ((w * f).astype(np.float32), (b * f[:, 0]).astype(np.float32))
+    return net
+
+
 def synth_glow_spec(d, h, K, depth=1, act="tanh", coupling="affine", permutation="shuffle",
-                    seed=0, gain=1.0):
+                    seed=0, gain=1.0, trained_like=False):
     """One tabular Glow component (models/glow.py FlowStep x K) with synthetic parameters.
     ``act``: "tanh" | "relu" | "random" (each step draws one of the two, models/glow.py:295-296)."""
     rng = np.random.RandomState(seed)
@@ -62,11 +72,15 @@ def synth_glow_spec(d, h, K, depth=1, act="tanh", coupling="affine", permutation
             "perm": perm.astype(np.int64),
             "net": _net(rng, d1, out_f, h, depth, ["tanh", "relu"][act_rng.randint(2)] if act == "random" else act, gain),
         })
+        if trained_like:       # ActNorm after data-dependent init on un-normalised data + training: log-scales ~ N(0,1) out to +-3, O(1) shifts
+            steps[-1]["an_bias"] = rng.standard_normal(d).astype(np.float32)
+            steps[-1]["an_logs"] = np.clip(rng.standard_normal(d), -3.0, 3.0).astype(np.float32)
+            _trained_like_net(rng, steps[-1]["net"])
     return {"kind": "glow", "d": int(d), "coupling": coupling, "steps": steps}
 
 
 def synth_realnvp_spec(d, h, K, depth=1, coupling_network="tanh", batch_norm=True, flip_init=0,
-                       seed=0, gain=1.0):
+                       seed=0, gain=1.0, trained_like=False):
     """One RealNVPFlow component (models/realnvp.py:34-78) with synthetic parameters.
 
     ``coupling_network``: "tanh" | "relu" | "mixed" (t_net ReLU, s_net Tanh, realnvp.py:47-51) | "random" (every net
@@ -104,6 +118,13 @@ def synth_realnvp_spec(d, h, K, depth=1, coupling_network="tanh", batch_norm=Tru
                 "running_var": rng.uniform(0.5, 1.5, size=d).astype(np.float32),
                 "eps": 1e-5,
             }
+        if trained_like:
+            _trained_like_net(rng, t_net)
+            _trained_like_net(rng, s_net)
+            if bn is not None:     # running statistics of un-normalised activations: variances over four decades
+                bn["log_gamma"] = rng.uniform(-1.0, 1.0, size=d).astype(np.float32)
+                bn["running_mean"] = rng.standard_normal(d).astype(np.float32)
+                bn["running_var"] = np.power(10.0, rng.uniform(-2.0, 2.0, size=d)).astype(np.float32)
         steps.append({"flipped": bool(flipped), "bn": bn, "t_net": t_net, "s_net": s_net})
     return {"kind": "realnvp", "d": int(d), "steps": steps}
 
@@ -122,10 +143,21 @@ def synth_boosted_specs(kind, C, d, h, K, seed=1, **kw):
     return specs
 
 
-def synth_batch(N, d, seed=0, scale=1.0):
-    """z-scored-like N(0,1) inputs (the loaders z-score the data: utils/miniboone.py:57-67)."""
+def synth_batch(N, d, seed=0, scale=1.0, dist="normal", clip=None):
+    """z-scored-like N(0,1) inputs (the loaders z-score the data: utils/miniboone.py:57-67).  ``dist="student_t3"``:
+    heavy-tailed rows (Student t, 3 degrees of freedom: what z-scored real data with outliers looks like), clipped to
+    +-``clip``."""
     rng = np.random.RandomState(seed)
-    return (scale * rng.standard_normal((N, d))).astype(np.float32)
+    if dist == "normal":
+        x = rng.standard_normal((N, d))
+    elif dist == "student_t3":
+        x = rng.standard_t(3.0, size=(N, d))
+    else:
+        raise ValueError(dist)
+    x = scale * x
+    if clip is not None:
+        x = np.clip(x, -clip, clip)
+    return x.astype(np.float32)
 
 
 # ------------------------------------------------------------------ image Glow (multi-scale, conv coupling nets)

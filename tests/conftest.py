@@ -123,7 +123,8 @@ class GoldenCase:
             self.x = self.data["x"]
             self.specs = [gspec.unflatten_spec(self.data, prefix=f"c{c}.") for c in range(cfg["C"])]
         elif cfg["case"] == "synth_specs":      # components given as generator calls (the stress offender g15)
-            self.x = synth.synth_batch(cfg["N"], cfg["d"], seed=cfg["x_seed"], scale=cfg.get("x_scale", 1.0))
+            self.x = synth.synth_batch(cfg["N"], cfg["d"], seed=cfg["x_seed"], scale=cfg.get("x_scale", 1.0),
+                                       dist=cfg.get("x_dist", "normal"), clip=cfg.get("x_clip"))
             self.specs = [getattr(synth, e["fn"])(**e["kwargs"]) for e in cfg["specs"]]
             cfg.setdefault("synth_kw", {})
         else:

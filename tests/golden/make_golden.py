@@ -177,7 +177,7 @@ def synth_case(name, kind, d, h, K, C, N, x_seed=0, w_seed=1, x_scale=1.0, n_use
     print(f"{name}: ll[0,:3]={ll[0, :3]}  G[:3]={G[:3]}  finite={np.isfinite(G).all()}")
 
 
-def specs_case(name, kind, entries, N, x_seed, x_scale=1.0, **ref_kw):
+def specs_case(name, kind, entries, N, x_seed, x_scale=1.0, x_dist="normal", x_clip=None, **ref_kw):
     """Components given one by one as calls of this repo's generator (``entries`` = [(function name, kwargs)]): the
     fixture stores the calls, x's seed and the reference's outputs.  Used for the stress offender found on the GPU
     (tools/find_offender.py): an un-normalised ReLU RealNVP (no BatchNorm), K = 8, h = 500 -- ill-conditioned in f32."""
@@ -187,10 +187,10 @@ def specs_case(name, kind, entries, N, x_seed, x_scale=1.0, **ref_kw):
     model = RefBoostedFlow(ref_args(kind, d, h, K, len(specs), **ref_kw))
     for c, sp in enumerate(specs):
         install_spec(model.flows[c], sp)
-    x = synth.synth_batch(N, d, seed=x_seed, scale=x_scale)
+    x = synth.synth_batch(N, d, seed=x_seed, scale=x_scale, dist=x_dist, clip=x_clip)
     z, ldj, ll, G = run_reference(model, x, len(specs))
     cfg = dict(case="synth_specs", kind=kind, d=d, h=h, K=K, C=len(specs), N=N, x_seed=x_seed, x_scale=x_scale,
-               specs=[dict(fn=fn, kwargs=kw) for fn, kw in entries])
+               x_dist=x_dist, x_clip=x_clip, specs=[dict(fn=fn, kwargs=kw) for fn, kw in entries])
     np.savez_compressed(os.path.join(HERE, name + ".npz"), config=np.frombuffer(json.dumps(cfg).encode(), dtype=np.uint8),
                         rho=model.rho.numpy().copy(), ldj=ldj, ll=ll, G=G, z=z)
     print(f"{name}: ll[:, :3]={ll[:, :3]}  G[:3]={G[:3]}  finite={np.isfinite(G).all()}  max|ll|={np.abs(ll).max():.1f}")
@@ -651,8 +651,28 @@ def image_decode_cases():
     image_decode_case("g16_image_decode_lu", LU=True, K=1, h=16, temperature=0.5)
 
 
+def trained_like_cases():
+    """magnitudes of TRAINED flows (last-layer rows of 1e-3 .. 1e-4, ActNorm log-scales of +-3, BatchNorm
+    variances over four decades) on heavy-tailed inputs (Student t, 3 d.o.f., |x| <= 50): the reference's own outputs."""
+    t = dict(x_dist="student_t3", x_clip=50.0)
+    specs_case("g17_trained_like_glow_d43_h215_c4", "glow",
+               [("synth_glow_spec", dict(d=43, h=215, K=5, seed=9100 + c, trained_like=True)) for c in range(4)],
+               N=256, x_seed=31, **t)
+    specs_case("g17_trained_like_glow_relu_d21_h105_c2", "glow",
+               [("synth_glow_spec", dict(d=21, h=105, K=5, act="relu", seed=9200 + c, trained_like=True)) for c in range(2)],
+               N=192, x_seed=32, coupling_network="relu", **t)
+    specs_case("g17_trained_like_realnvp_d21_h105_c4", "realnvp",
+               [("synth_realnvp_spec", dict(d=21, h=105, K=5, flip_init=c, seed=9300 + c, trained_like=True)) for c in range(4)],
+               N=256, x_seed=33, **t)
+    specs_case("g17_heavy_tails_glow_d43_h215_c2", "glow",        # init-like weights, only the inputs are harsh
+               [("synth_glow_spec", dict(d=43, h=215, K=5, seed=9400 + c)) for c in range(2)], N=256, x_seed=34, **t)
+
+
 def main():
     torch.set_num_threads(4)
+    if "--trained-only" in sys.argv:
+        trained_like_cases()
+        return
     if "--image-decode-only" in sys.argv:
         image_decode_cases()
         return
@@ -745,6 +765,7 @@ def main():
     synth_case("g6_realnvp_d21_h64_n33", "realnvp", 21, 64, 5, 3, 33)
     synth_case("g6_glow_d43_h64_c3_rho", "glow", 43, 64, 5, 3, 64, rho_override=[0.7, 3.0, 0.01])
     stress_cases()
+    trained_like_cases()
 
 
 if __name__ == "__main__":
