@@ -11,7 +11,7 @@ dev = torch.device("cuda:0")
 print(f"{'fixture':38s} {'mode':7s} {'ll rel':>9s} {'G rel':>9s} {'ldj abs':>9s} {'ldj/|ll|':>9s} {'z abs':>9s}")
 for name in golden_names():
     g = GoldenCase(name)
-    for mode in ("f32", "f16x3"):
+    for mode in ("f32", "f16x3", "bf16x6", "default"):
         try:
             flows = native.flows_for_mixture(g.specs, math=mode)
         except native.GbnfError as e:
