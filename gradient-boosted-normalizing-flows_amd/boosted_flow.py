@@ -614,7 +614,8 @@ class BoostedFlow(nn.Module):
         return self._per_step_act
 
     def native_flow_exact(self, c):
-        """The exact-f32 handle of component c: the inverse direction runs on that kernel only."""
+        """The exact-f32 handle of component c (ResidualNets; the other architectures run either direction on their
+        evaluation handle since round 3)."""
         key = self._component_key(c)
         cached = self._handles_exact.get(c)
         if cached is None or cached[0] != key:
@@ -681,7 +682,8 @@ class BoostedFlow(nn.Module):
         if not all(bool(l.actnorm.inited) for l in getattr(getattr(self.flows[int(c)], "flow", None), "layers", [])):
             raise ValueError("ActNorm not initiated: run a forward pass on data first (models/layers.py:473-475)")
         with torch.cuda.device(z.device):
-            return self.native_flow_exact(int(c)).inverse(z)
+            # the component's evaluation handle runs backwards too (split kernels: 3 x the exact-f32 kernel's rate)
+            return self.native_flow(int(c)).inverse(z)
 
     def component_log_prob(self, x, n_used=None):
         """(N, C_used): ll_c(x) = log N(z_c;0,I) + ldj_c for c < n_used, all in ONE launch

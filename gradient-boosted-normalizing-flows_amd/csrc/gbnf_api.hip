@@ -1064,7 +1064,7 @@ static int launch_flow(const gbnf_flow* f, const uint32_t* const* table, const u
     if (e != hipSuccess) return fail(GBNF_ERR_HIP, "repair launch of %s failed: %s", f->name2_nt[nt], hipGetErrorString(e));
   }
   // ---- numerics guard: this handle's first launch and every check_every-th re-check the f16x3 choice on the caller's rows
-  if (split_pair && guard != nullptr && f->launch_nt[1] != nullptr && f->launch2_nt[1] != nullptr && n_comp <= guard->n_comp) {
+  if (split_pair && guard != nullptr && !inverse && f->launch_nt[1] != nullptr && f->launch2_nt[1] != nullptr && n_comp <= guard->n_comp) {
     const long long k = guard->launches.fetch_add(1, std::memory_order_relaxed);
     const int every = tuning().check_every.load(std::memory_order_relaxed);
     if (every >= 0 && (k == 0 || (every > 0 && k % every == 0))) {
@@ -1293,12 +1293,12 @@ int gbnf_flow_forward(const gbnf_flow* flow, const float* x, int64_t n, float* z
 
 int gbnf_flow_inverse(const gbnf_flow* flow, const float* z, int64_t n, float* x, float* ldj, void* stream) {
   if (!flow) return fail(GBNF_ERR_INVALID, "gbnf_flow_inverse: flow is null");
-  if (flow->math_mode != GBNF_MATH_F32)
-    return fail(GBNF_ERR_UNSUPPORTED, "gbnf_flow_inverse runs on the exact-f32 kernel: create the handle with GBNF_MATH_F32");
   if (n < 0) return fail(GBNF_ERR_INVALID, "gbnf_flow_inverse: n < 0");
   if (n > 0 && (!z || !x)) return fail(GBNF_ERR_INVALID, "gbnf_flow_inverse: z / x is null");
-  return launch_flow(flow, flow->self_table_dev, nullptr, false, 0, 1, z, n, x, ldj, nullptr, nullptr, (hipStream_t)stream, -1,
-                     nullptr, 1, 1);
+  // every math mode (round 3: the split kernels run backwards too; an f16x3 launch is followed by its bf16x6 repair pass
+  // like a forward one; the numerics guard of a DEFAULT handle keeps its verdict from the forward direction)
+  return launch_flow(flow, flow->self_table_dev, flow->self_table2_dev, false, 0, 1, z, n, x, ldj, nullptr, nullptr, (hipStream_t)stream, -1,
+                     nullptr, 1, 1, flow->guard);
 }
 
 int gbnf_mixture_create(gbnf_flow* const* flows, int32_t n_flows, gbnf_mixture** out) {

@@ -336,7 +336,14 @@ flow_kernel_hx3(const FlowLaunch p) {
   //      fragment.  A net's biases (BIAS_FRAGS fragments in front of its first stage) go to their own double-buffered area.
   using gwords = const __attribute__((address_space(1))) uint32_t*;
   using lptr = __attribute__((address_space(3))) void*;
-  gwords next_src = (gwords)blob + SMALL_WORDS;    // bias block of step 0, net 0
+  // z -> x (FlowLaunch::inverse, round 3; the exact-f32 kernel's scheme, gbnf_flow_kernel.hip.h): the steps are visited
+  // K-1 .. 0 -- within a step the nets keep their order, so only the step-to-step hop of the running pointer changes --,
+  // the in-half is read as the (already normalised) net input and un-normalised in place, the out-half gets coupling^-1
+  // and norm^-1, log|det| accumulates with the opposite sign, z comes in through the FINAL slot map, x leaves through
+  // the initial one (slot j = feature j)
+  const bool inv = p.inverse != 0;
+  const int first_step = inv ? p.n_steps - 1 : 0;
+  gwords next_src = (gwords)blob + (size_t)first_step * STEP_WORDS + SMALL_WORDS;    // bias block of the first step's net 0
   int gs = 0;                                       // stage counter: slot = gs & 1
   int nets_issued = 0;                              // nets whose first stage has been issued (bias buffer = & 1)
   const unsigned lane_b16 = (unsigned)lane * 16u;
@@ -390,8 +397,9 @@ flow_kernel_hx3(const FlowLaunch p) {
       const int64_t n = row0 + r;
       xv[r] = xin[(n < p.n ? n : last) * d + lane];
     }
+    const int slot0 = inv ? (int)blob[(size_t)p.n_steps * STEP_WORDS + lane] : lane;      // (the tail table: final slot of feature j)
 #pragma unroll
-    for (int r = 0; r < 16 * NT; ++r) Z[lane * ZS + r] = (row0 + r < p.n) ? xv[r] : 0.0f;
+    for (int r = 0; r < 16 * NT; ++r) Z[slot0 * ZS + r] = (row0 + r < p.n) ? xv[r] : 0.0f;
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this wave's pieces of the first stages have landed
   __syncthreads();               // tables + Z visible, every wave's pieces landed
@@ -522,7 +530,8 @@ flow_kernel_hx3(const FlowLaunch p) {
   };
   preload();                       // the very first stage (landed behind the prologue's barrier)
 
-  for (int step = 0; step < p.n_steps; ++step) {
+  for (int sidx = 0; sidx < p.n_steps; ++sidx) {
+    const int step = inv ? p.n_steps - 1 - sidx : sidx;
     const uint32_t* __restrict__ sp = blob + (size_t)step * STEP_WORDS;
     // ---- normalise the coupling net's inputs in place; split them into the first layer's B operand:
     //      lane (i,g), element j  <->  input feature 8g + j of sample i
@@ -530,10 +539,12 @@ flow_kernel_hx3(const FlowLaunch p) {
     {
       LaneTable tin;
       if (lds_tables) {
-        ld_const += as_f32(SM[step * SMALL_WORDS + 1]);
+        const float lc = as_f32(SM[step * SMALL_WORDS + 1]);
+        ld_const += inv ? -lc : lc;
         tin.load(SM + step * SMALL_WORDS + SMALL_HDR + g * NENT);
       } else {
-        ld_const += as_f32(sp[1]);
+        const float lc = as_f32(sp[1]);
+        ld_const += inv ? -lc : lc;
         tin.load(sp + SMALL_HDR + g * NENT);
       }
       float v[NT][NENT];
@@ -546,8 +557,10 @@ flow_kernel_hx3(const FlowLaunch p) {
 #pragma unroll
         for (int e = 0; e < NENT; ++e) {
           const bool live = tin.slot[e] >= 0;
-          const float t = norm_fn<KIND>(v[nt][e], tin.p0[e], tin.p1[e], tin.p2[e], tin.p3[e]);
-          Z[(live ? tin.slot[e] : d) * ZS + i + 16 * nt] = t;         // dead entries go to the spare slot d: no exec masking
+          // forward: normalise, keep; inverse: the stored value IS the normalised net input, the state gets norm^-1 of it
+          const float t = inv ? v[nt][e] : norm_fn<KIND>(v[nt][e], tin.p0[e], tin.p1[e], tin.p2[e], tin.p3[e]);
+          const float keep = inv ? invnorm_fn<KIND>(v[nt][e], tin.p0[e], tin.p1[e], tin.p2[e], tin.p3[e]) : t;
+          Z[(live ? tin.slot[e] : d) * ZS + i + 16 * nt] = keep;      // dead entries go to the spare slot d: no exec masking
           if constexpr (WATCH) {
             sat[nt] = sat[nt] || (live && !(__builtin_fabsf(t) <= 65504.0f));
             v[nt][e] = live ? __builtin_amdgcn_fmed3f(t, -65504.0f, 65504.0f) : 0.0f;
@@ -733,8 +746,9 @@ flow_kernel_hx3(const FlowLaunch p) {
           if constexpr (k + 1 < N_OUT) {
             issue(std::integral_constant<int, LT::value.nf[LT::value.N_L0 + k + 1]>{}, gs + 1);
           } else {
-            if ((net + 1 < NNETS) || (step + 1 < p.n_steps)) {
-              if (net + 1 == NNETS) next_src += SMALL_WORDS;     // the next step's tables sit in front of its first net
+            if ((net + 1 < NNETS) || (sidx + 1 < p.n_steps)) {
+              if (net + 1 == NNETS)     // the next step's tables sit in front of its first net (inverse: the step before this one)
+                next_src = inv ? (gwords)blob + (size_t)(step - 1) * STEP_WORDS + SMALL_WORDS : next_src + SMALL_WORDS;
               issue_net_start(gs + 1);
             }
           }
@@ -897,8 +911,9 @@ flow_kernel_hx3(const FlowLaunch p) {
         // ---- drain: last tile, last output-layer chunk (HC-1); the next net's / step's first stage goes in flight
         {
           guard_at(7);
-          if ((net + 1 < NNETS) || (step + 1 < p.n_steps)) {
-            if (net + 1 == NNETS) next_src += SMALL_WORDS;     // the next step's tables sit in front of its first net
+          if ((net + 1 < NNETS) || (sidx + 1 < p.n_steps)) {
+            if (net + 1 == NNETS)       // the next step's tables sit in front of its first net (inverse: the step before this one)
+              next_src = inv ? (gwords)blob + (size_t)(step - 1) * STEP_WORDS + SMALL_WORDS : next_src + SMALL_WORDS;
             issue_net_start(gs + 1);
           }
           Unit A[OT];
@@ -959,11 +974,17 @@ flow_kernel_hx3(const FlowLaunch p) {
           const bool live = tout.slot[e] >= 0;
 #pragma unroll
           for (int nt = 0; nt < NT; ++nt) {
-            float t = norm_fn<KIND>(v[nt][e], tout.p0[e], tout.p1[e], tout.p2[e], tout.p3[e]);
             const float shift = outA[o][nt][2 * pp], raw = outA[o][nt][2 * pp + 1];
-            float sc, lsc;
+            float sc, lsc, t;
             sigmoid_logsigmoid(raw + 2.0f, sc, lsc);
-            t = (t + shift) * sc;
+            if (!inv) {
+              t = norm_fn<KIND>(v[nt][e], tout.p0[e], tout.p1[e], tout.p2[e], tout.p3[e]);
+              t = (t + shift) * sc;
+            } else {                                                   // FlowStep.decode, models/glow.py:352-355
+              t = v[nt][e] / sc - shift;
+              t = invnorm_fn<KIND>(t, tout.p0[e], tout.p1[e], tout.p2[e], tout.p3[e]);
+              lsc = -lsc;
+            }
             Z[(live ? tout.slot[e] : d) * ZS + i + 16 * nt] = t;
             ld[nt] += live ? lsc : 0.0f;
           }
@@ -981,15 +1002,21 @@ flow_kernel_hx3(const FlowLaunch p) {
           const bool live = tout.slot[e] >= 0;
 #pragma unroll
           for (int nt = 0; nt < NT; ++nt) {
-            float t = norm_fn<KIND>(v[nt][e], tout.p0[e], tout.p1[e], tout.p2[e], tout.p3[e]);
+            float t = inv ? v[nt][e] : norm_fn<KIND>(v[nt][e], tout.p0[e], tout.p1[e], tout.p2[e], tout.p3[e]);
             if constexpr (KIND == GBNF_KIND_GLOW) {
-              t = t + outA[o][nt][r];
+              t = inv ? t - outA[o][nt][r] : t + outA[o][nt][r];      // additive, models/glow.py:328-329 / 349-350
+              if (inv) t = invnorm_fn<KIND>(t, tout.p0[e], tout.p1[e], tout.p2[e], tout.p3[e]);
               Z[(live ? tout.slot[e] : d) * ZS + i + 16 * nt] = t;
             } else {
               const float shift = outA[o][nt][r], scale = outB[o][nt][r];
-              t = shift + t * exp_fast(scale);
+              if (!inv) {
+                t = shift + t * exp_fast(scale);                       // models/transformations.py:575
+              } else {                                                 // its true inverse (the reference's own .inverse is not: SURVEY S3)
+                t = (t - shift) * exp_fast(-scale);
+                t = invnorm_fn<KIND>(t, tout.p0[e], tout.p1[e], tout.p2[e], tout.p3[e]);
+              }
               Z[(live ? tout.slot[e] : d) * ZS + i + 16 * nt] = t;
-              ld[nt] += live ? scale : 0.0f;
+              ld[nt] += live ? (inv ? -scale : scale) : 0.0f;
             }
           }
         }
@@ -1057,7 +1084,7 @@ flow_kernel_hx3(const FlowLaunch p) {
     atomicMax(p.sat + SAT_MARKS + p.seq % SAT_SLOTS, p.seq);      // tells the repair launch behind this one that it has work
   }
   if (p.z_out != nullptr && lane < d) {
-    const int slot = (int)tail[lane];
+    const int slot = inv ? lane : (int)tail[lane];
     float* zo = p.z_out + (int64_t)comp * p.n * d;
 #pragma unroll 8
     for (int r = 0; r < 16 * NT; ++r) {

@@ -200,7 +200,8 @@ int gbnf_flow_forward(const gbnf_flow* flow, const float* x, int64_t n,
 /* The flow backwards, z (n,d) -> x (n,d) and log|det dx/dz| (n,) (= -ldj of the forward pass at x): what
  * BoostedFlow.decode / Glow.decode / FlowStep.decode (models/boosted_flow.py:209-218, models/glow.py:112-123, 344-366)
  * and RealNVPFlow.decode (models/realnvp.py:97-113) are meant to do.  In the reference this direction is dead or wrong
- * on tabular data, so parity is defined by inverse(forward(x)) == x.  Needs a GBNF_MATH_F32 handle. */
+ * on tabular data, so parity is defined by inverse(forward(x)) == x (and the one case the reference can
+ * decode, additive Glow, fixture g9).  Any math mode (the split kernels run backwards since round 3; ResidualNets: f32). */
 int gbnf_flow_inverse(const gbnf_flow* flow, const float* z, int64_t n, float* x, float* ldj, void* stream);
 
 /* Replaces: the nn.ModuleList of components (models/boosted_flow.py:42).  All flows must

@@ -164,7 +164,7 @@ def test_activation_drawn_per_step(kind, d, h, K, math, dev):
         G, ll = mix.log_prob(torch.from_numpy(xs).to(dev), torch.from_numpy(rho).to(dev))
         assert rel_err(ll.cpu().numpy(), ll_ref) < LL_RTOL
         assert rel_err(G.cpu().numpy(), G_ref) < LL_RTOL
-    if math == "f32":            # the inverse direction runs on the exact-f32 kernel
+    if True:                     # the inverse direction: every math mode since round 3
         x = synth.synth_batch(200, d, seed=3)
         xd = torch.from_numpy(x).to(dev)
         z, _, _ = flows[1].forward(xd)
@@ -438,16 +438,18 @@ INV_NAMES = ["g3_glow_d43_h215_c8", "g4_realnvp_d21_h105_c8", "g5_glow_d43_h64_c
              "g5_glow_d63_h128_c2", "g6_realnvp_d21_h64_n33"]
 
 
+@pytest.mark.parametrize("math", ["f32", "f16x3", "bf16x6", "default"])
 @pytest.mark.parametrize("name", INV_NAMES)
-def test_inverse_matches_oracle_and_round_trips(name, golden_case):
+def test_inverse_matches_oracle_and_round_trips(name, math, golden_case):
     """gbnf_flow_inverse against the float64 oracle on the reference's z, plus inverse(forward(x)) == x through the
-    device kernels alone.  x tolerance 2e-5 of the data scale (f32 coupling nets on both legs)."""
+    device kernels alone, in every math mode (the split kernels run backwards since round 3).  x tolerance 2e-5 of the
+    data scale."""
     import torch
     from gbnf_amd import native
     from oracle import gbnf_oracle as oracle
     g = golden_case(name)
     for c, spec in enumerate(g.specs[:3]):
-        flow = native.NativeFlow(spec, math="f32")
+        flow = native.NativeFlow(spec, math=math)
         z_ref = g.z(c)                      # the reference's own z where the fixture holds it
         if z_ref is None:
             z_ref = oracle.component_forward(spec, g.x, backend="numpy64")[0]
@@ -470,18 +472,25 @@ def test_inverse_matches_reference_decode():
     from conftest import load_decode_case
     from gbnf_amd import native
     specs, z, x_ref = load_decode_case()
-    for c, spec in enumerate(specs):
-        x, _ = native.NativeFlow(spec, math="f32").inverse(torch.from_numpy(z).cuda())
-        assert np.abs(x.cpu().numpy() - x_ref[c]).max() <= 2e-5 * max(1.0, float(np.abs(x_ref[c]).max()))
+    for math in ("f32", "f16x3", "bf16x6", "default"):
+        for c, spec in enumerate(specs):
+            x, _ = native.NativeFlow(spec, math=math).inverse(torch.from_numpy(z).cuda())
+            assert np.abs(x.cpu().numpy() - x_ref[c]).max() <= 2e-5 * max(1.0, float(np.abs(x_ref[c]).max())), math
 
 
-def test_inverse_needs_exact_handle_and_large_n(golden_case):
+@pytest.mark.parametrize("math", ["f32", "default"])
+def test_inverse_large_n_and_out_of_range_inputs(math, golden_case):
     import torch
     from gbnf_amd import native
     g = golden_case("g3_glow_d43_h215_c8")
-    with pytest.raises(native.GbnfError):
-        native.NativeFlow(g.specs[0], math="f16x3").inverse(torch.zeros(4, 43, device="cuda"))
-    flow = native.NativeFlow(g.specs[0], math="f32")
+    flow = native.NativeFlow(g.specs[0], math=math)
+    if math == "default":      # z rows beyond the fp16 range: marked by the f16x3 pass, repaired by the bf16x6 pass, backwards too
+        zb = torch.randn(300, 43, device="cuda")
+        zb[17] *= 1e6
+        xb, _ = flow.inverse(zb)
+        xe, _ = native.NativeFlow(g.specs[0], math="f32").inverse(zb)
+        assert torch.isfinite(xb).all()
+        assert (xb - xe).abs().max().item() <= 2e-5 * float(xe.abs().max())
     x = torch.randn(20001, 43, device="cuda") * 1.5
     z, ldj, _ = flow.forward(x)
     xr, ild = flow.inverse(z)

@@ -140,13 +140,14 @@ def test_group_launch_is_launch_stable(variant, dev, policy):
                 assert rel_err(T[0].cpu().numpy(), want) < 1e-5, (math, nt, pairs)
 
 
+@pytest.mark.parametrize("math", ["f32", "f16x3", "bf16x6"])
 @pytest.mark.parametrize("kind,d,h", [("glow", 43, 215), ("glow", 63, 128), ("realnvp", 21, 105)])
-def test_inverse_is_launch_stable(kind, d, h, dev, policy):
-    """z -> x on the exact-f32 kernel (16- and 32-sample waves): bit-identical repeats, round trip."""
+def test_inverse_is_launch_stable(kind, d, h, math, dev, policy):
+    """z -> x (exact-f32 kernel and, since round 3, the split kernels; 16- and 32-sample waves): bit-identical repeats, round trip."""
     import torch
     from gbnf_amd import native, synth
     spec = synth.synth_boosted_specs(kind, 1, d, h, 3, seed=9)[0]
-    flow = native.NativeFlow(spec, math="f32")
+    flow = native.NativeFlow(spec, math=math)
     for nt in (1, 2):
         native.tuning_set("force_nt", nt)
         for n in (77, 2048):
