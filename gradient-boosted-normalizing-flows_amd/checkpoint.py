@@ -59,22 +59,27 @@ def load(model, optimizer, path, args, init_with_args=False, scheduler=None, ver
             if hasattr(flow, "set_actnorm_init"):   # after set_actnorm_init(); a trained checkpoint is initialised
                 flow.set_actnorm_init()
 
-    msg = f"Loaded pre-trained {os.path.split(path)[-1]}"
-    if init_with_args and getattr(args, "boosted", False):
-        if args.loaded_init_component is None or args.loaded_all_trained is None:
-            raise ValueError("Cannot initialize a boosted model loaded from file, intialization parameters needed.")
-        model.component = args.loaded_init_component
-        model.all_trained = args.loaded_all_trained
-        if getattr(args, "loaded_num_components", None) is not None:
-            model.num_components = args.loaded_num_components
-        msg += f"  and initialized with passed argument component={model.component} and all_trained={model.all_trained}"
+    # Boosting position: from the caller's --loaded_* arguments when asked for (the reference's `init_with_args`, used to
+    # continue training a file with a different component count), else from the file.
+    name = os.path.basename(path)
+    override = bool(init_with_args) and bool(getattr(args, "boosted", False))
+    if override:
+        component = getattr(args, "loaded_init_component", None)
+        all_trained = getattr(args, "loaded_all_trained", None)
+        if component is None or all_trained is None:
+            raise ValueError("init_with_args needs args.loaded_init_component and args.loaded_all_trained to place a boosted "
+                             "model that was loaded from a file")
+        model.component, model.all_trained = component, all_trained
+        n_loaded = getattr(args, "loaded_num_components", None)
+        if n_loaded is not None:
+            model.num_components = n_loaded
+        msg = f"{name}: parameters loaded, boosting position from the arguments (component {component}, all_trained {all_trained})"
     else:
-        msg = f"Restoring {os.path.split(path)[-1]}"
-        if "component" in ckpt:
-            model.component = ckpt["component"]
-        if "all_trained" in ckpt:
-            model.all_trained = ckpt["all_trained"]
-        msg += f", component={getattr(model, 'component', None)}, all_trained={getattr(model, 'all_trained', None)}"
+        for key in ("component", "all_trained"):
+            if key in ckpt:
+                setattr(model, key, ckpt[key])
+        msg = (f"{name}: restored, component {getattr(model, 'component', None)}, "
+               f"all_trained {getattr(model, 'all_trained', None)}")
     model.to(args.device)
     if verbose:
         logger.info(msg)
