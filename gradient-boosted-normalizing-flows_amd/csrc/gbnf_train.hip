@@ -53,6 +53,7 @@ constexpr int TR_MAX_LAYERS = 6;    // Linear layers per coupling net (depth <= 
 constexpr int TR_MAX_IN = 32;       // coupling-net input / coupled-half width
 constexpr int TR_MAX_HIDDEN = 512;  // hidden width (32 output tiles = 16 tile pairs per layer)
 constexpr int TR_LDS_BYTES = 160 * 1024;
+constexpr int TR_WS_SLACK_ROWS = 320;   // workspace rows behind the last operand region: a block of wgrad_kernel reads up to 256 rows
 #ifndef GBNF_TR_WAVES
 #define GBNF_TR_WAVES 8
 #endif
@@ -948,17 +949,21 @@ __global__ void __launch_bounds__(64 * TR_WAVES) train_kernel(const TrainLaunch 
 
 // ---------------------------------------------------------------------------------------------------------------
 // Weight / bias gradients: C (M x N, row-major) += D (M rows of np samples) . A (N rows of np samples)^T, bias += row sums of D.
-// One wave = one 64 x 64 block of C (16 accumulator tiles) over one chunk of samples (see wgrad_kernel below for the
-// operand layout).  Branch-free: operand rows past the padded matrix belong to the next workspace region and only feed
-// output rows / columns that are never stored.
+// Round 3: a workgroup of 4 waves owns a block of 64 WM x 64 WN of C (WM x WN = 2 x 2; 4 x 1 for N <= 64, 1 x 4 for M <= 64;
+// every wave a 64 x 64 sub-block = 16 accumulator tiles) over one chunk of samples, and the operand rows of a k-step are
+// staged ONCE per workgroup in LDS (round 1: every wave read its own 64 + 64 rows from HBM / L2 -- each 64-row slab of a
+// 215 x 215 layer four times over; the kernel ran at the HBM rate).  Branch-free: operand rows past the padded matrix belong
+// to the next workspace region (or the slack rows behind the last one) and only feed output rows / columns that are never stored.
 // ---------------------------------------------------------------------------------------------------------------
 struct WgProblem {
   int64_t d_row, a_row;   // first row (of np floats) of the two operands' sub-regions in the workspace
   int64_t c_off, b_off;   // float offsets of dW / db in the flat gradient buffer
   int M, N, blk_begin, nb;
   int d_rows, a_rows;     // rows of the two sub-regions (tiled as [tile][row][16 samples])
+  int wm, wn;             // the workgroup's waves: wm x wn sub-blocks of 64 x 64
 };
-constexpr int WG_PD = 2;        // 32-sample groups of operand loads in flight
+constexpr int WG_ROWS_MAX = 320;       // operand rows per k-step: 64 (wm + wn) <= 64 * 5
+constexpr int WG_THREADS = 256;        // 4 waves (one per SIMD: ~330 registers)
 
 // hi = f16(x) toward zero, mid = f16(x - hi) for 8 consecutive samples of one operand row -> one MFMA operand each.
 // No clamp: toward-zero conversion saturates at the largest finite fp16, so a value beyond the fp16 range degrades to
@@ -976,26 +981,58 @@ __device__ __forceinline__ void wg_split8(f32x4 lo, f32x4 hi4, u32x4& h, u32x4& 
 }
 
 // The contraction runs on the f16 pipe with split operands (section 4.1: three v_mfma_f32_16x16x32_f16 per product, f32
-// accumulation): one k = 32 step = 32 samples = two 16-sample tiles of the workspace; lane (i, g) of an operand
-// fragment holds samples 8 (g & 1) .. + 7 of tile (g >> 1) of row i -- 32 contiguous bytes, split in registers.
-__global__ void __launch_bounds__(64) wgrad_kernel(const WgProblem* __restrict__ probs, int n_probs,
-                                                   const float* __restrict__ ws, float* __restrict__ grads, int64_t np, int chunk,
-                                                   const unsigned* __restrict__ gmax) {
+// accumulation): one k = 32 step = 32 samples = two 16-sample tiles of the workspace.  LDS holds the k-step's operand rows
+// as 16-byte pieces (4 samples): piece (row, q), q = 0..7, at index row * 8 + (q ^ (row & 7)) -- the XOR spreads the 16
+// rows a quarter-wave reads at once over all banks.  Lane (i, g) of an operand fragment takes pieces 2g, 2g + 1 of its row
+// (samples 8 (g & 1) .. + 7 of tile g >> 1) and splits them in registers.  Global -> register -> LDS, one k-step ahead.
+__global__ void __launch_bounds__(WG_THREADS) wgrad_kernel(const WgProblem* __restrict__ probs, int n_probs,
+                                                    const float* __restrict__ ws, float* __restrict__ grads, int64_t np, int chunk,
+                                                    const unsigned* __restrict__ gmax) {
   typedef const f32x4 __attribute__((address_space(1)))* gv4;
+  extern __shared__ __attribute__((aligned(16))) f32x4 wg_stage_raw[];      // 2 x WG_ROWS_MAX * 8 pieces = 80 KB (dynamic: > 64 KB)
+  f32x4 (*stage)[WG_ROWS_MAX * 8] = reinterpret_cast<f32x4 (*)[WG_ROWS_MAX * 8]>(wg_stage_raw);
   float alpha = 1.0f, inv_alpha = 1.0f;          // the gradient-side operands were emitted on the scaled gradient
   if (gmax != nullptr) tr_grad_scale(__builtin_amdgcn_readfirstlane(*gmax), alpha, inv_alpha);
-  const int lane = threadIdx.x, i = lane & 15, g = lane >> 4;
+  const int tid = threadIdx.x, lane = tid & 63, i = lane & 15, g = lane >> 4;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   int pi = 0;
   while (pi + 1 < n_probs && (int)blockIdx.x >= probs[pi + 1].blk_begin) ++pi;
   const WgProblem P = probs[pi];
   const int blk = blockIdx.x - P.blk_begin;
-  const int m0 = (blk / P.nb) * 64, n0 = (blk % P.nb) * 64;
+  const int bm = 64 * P.wm, bn = 64 * P.wn;
+  const int m0 = (blk / P.nb) * bm, n0 = (blk % P.nb) * bn;
+  const int wmi = wave / P.wn, wni = wave - wmi * P.wn;
   const int64_t s_begin = (int64_t)blockIdx.y * chunk;       // `chunk` samples per block (a multiple of 32)
   const int64_t s_end = (s_begin + chunk < np) ? s_begin + chunk : np;
-  // element (row, sample s) of a sub-region with R rows: base + ((s / 16) * R + row) * 16 + s % 16
-  const int64_t dstep = (int64_t)P.d_rows, astep = (int64_t)P.a_rows;      // floats per sample when walking tiles (R * 16 / 16)
-  const float* Db = ws + P.d_row * np + (int64_t)(m0 + i) * 16 + 8 * (g & 1) + (g >> 1) * 16 * dstep;
-  const float* Ab = ws + P.a_row * np + (int64_t)(n0 + i) * 16 + 8 * (g & 1) + (g >> 1) * 16 * astep;
+  // ---- this thread's pieces of a k-step: piece p = tid + WG_THREADS j of (bm + bn) * 8
+  constexpr int NPC = WG_ROWS_MAX * 8 / WG_THREADS;           // 10
+  const int n_pieces = (bm + bn) * 8;
+  int64_t goff[NPC];          // float offset of the piece at sample 0
+  int gstep[NPC];             // floats per sample when walking 16-sample tiles: the sub-region's row count
+#pragma unroll
+  for (int j = 0; j < NPC; ++j) {
+    const int p = tid + WG_THREADS * j;
+    const int rl = p >> 3, q = (p & 7) ^ (rl & 7);
+    const bool isd = rl < bm;
+    const int R = isd ? P.d_rows : P.a_rows;
+    const int64_t row = isd ? (int64_t)(m0 + rl) : (int64_t)(n0 + rl - bm);
+    goff[j] = (isd ? P.d_row : P.a_row) * np + ((int64_t)(q >> 2) * R + row) * 16 + (q & 3) * 4;
+    gstep[j] = R;
+  }
+  // the pieces of the NEXT k-step travel global -> registers while this one is computed, registers -> LDS behind it
+  // (measured: a second register set, two k-steps ahead, costs the second workgroup per CU and is slower; so is an 8-wave
+  // 256 x 128 block: 442 us against 411 us for this form at N = 65536 -- the kernel runs at the HBM rate of its operand reads)
+  f32x4 pre[NPC];
+  auto fetch = [&](int64_t s) {
+#pragma unroll
+    for (int j = 0; j < NPC; ++j)
+      if (tid + WG_THREADS * j < n_pieces) pre[j] = *(gv4)(ws + goff[j] + s * gstep[j]);
+  };
+  auto stash = [&](int b) {
+#pragma unroll
+    for (int j = 0; j < NPC; ++j)
+      if (tid + WG_THREADS * j < n_pieces) stage[b][tid + WG_THREADS * j] = pre[j];
+  };
   f32x4 acc[4][4];
   f32x4 bsum[4];
   const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
@@ -1005,27 +1042,26 @@ __global__ void __launch_bounds__(64) wgrad_kernel(const WgProblem* __restrict__
 #pragma unroll
     for (int b = 0; b < 4; ++b) acc[a][b] = zero;
   }
-  f32x4 rd[WG_PD][4][2], ra[WG_PD][4][2];
-  int64_t sl = s_begin;
-  auto issue = [&](f32x4 (&d)[4][2], f32x4 (&a)[4][2]) {
-    const int64_t s = sl < s_end ? sl : s_begin;       // past the end: a valid (unused) group again
+  // LDS piece indices of this lane's fragments: D tile x -> local row 64 wmi + 16 x + i; A tile y -> bm + 64 wni + 16 y + i
+  int dix[4], aix[4];
 #pragma unroll
-    for (int t = 0; t < 4; ++t) {
-      const gv4 dp = (gv4)(Db + s * dstep + t * 256), ap = (gv4)(Ab + s * astep + t * 256);   // 16 rows further = 256 floats inside the tile
-      d[t][0] = dp[0]; d[t][1] = dp[1];
-      a[t][0] = ap[0]; a[t][1] = ap[1];
-    }
-    sl += 32;
-  };
-#pragma unroll
-  for (int j = 0; j < WG_PD; ++j) issue(rd[j], ra[j]);
-  auto body = [&](const f32x4 (&d)[4][2], const f32x4 (&a)[4][2]) {
+  for (int x = 0; x < 4; ++x) {
+    const int rd = 64 * wmi + 16 * x + i, ra = bm + 64 * wni + 16 * x + i;
+    dix[x] = rd * 8;
+    aix[x] = ra * 8;
+  }
+  const bool active = wave < P.wm * P.wn;       // (narrow problems leave waves without a sub-block: they only help staging)
+  auto compute = [&](int b) {
+    if (!active) return;
     u32x4 dh[4], dm[4], ah[4], am[4];
 #pragma unroll
     for (int x = 0; x < 4; ++x) {
-      wg_split8(d[x][0], d[x][1], dh[x], dm[x]);
-      wg_split8(a[x][0], a[x][1], ah[x], am[x]);
-      bsum[x] += d[x][0] + d[x][1];
+      const int rd = dix[x] >> 3, ra = aix[x] >> 3;
+      const f32x4 d0 = stage[b][dix[x] + ((2 * g) ^ (rd & 7))], d1 = stage[b][dix[x] + ((2 * g + 1) ^ (rd & 7))];
+      const f32x4 a0 = stage[b][aix[x] + ((2 * g) ^ (ra & 7))], a1 = stage[b][aix[x] + ((2 * g + 1) ^ (ra & 7))];
+      wg_split8(d0, d1, dh[x], dm[x]);
+      wg_split8(a0, a1, ah[x], am[x]);
+      bsum[x] += d0 + d1;
     }
 #pragma unroll
     for (int x = 0; x < 4; ++x)
@@ -1040,41 +1076,43 @@ __global__ void __launch_bounds__(64) wgrad_kernel(const WgProblem* __restrict__
 #pragma unroll
       for (int y = 0; y < 4; ++y) acc[x][y] = tr_mfma16(dh[x], ah[y], acc[x][y]);
   };
-  int64_t s = s_begin;
-  for (; s + 32 * WG_PD <= s_end; s += 32 * WG_PD) {
-#pragma unroll
-    for (int j = 0; j < WG_PD; ++j) {
-      body(rd[j], ra[j]);
-      issue(rd[j], ra[j]);
-    }
+  fetch(s_begin);
+  stash(0);
+  if (s_begin + 32 < s_end) fetch(s_begin + 32);
+  __syncthreads();
+  int b = 0;
+  for (int64_t s = s_begin; s < s_end; s += 32, b ^= 1) {
+    compute(b);
+    if (s + 32 < s_end) stash(b ^ 1);         // the pieces of k-step s + 32 (fetched one iteration ago)
+    if (s + 64 < s_end) fetch(s + 64);
+    __syncthreads();
   }
-#pragma unroll
-  for (int j = 0; j < WG_PD - 1; ++j)
-    if (s + 32 * j < s_end) body(rd[j], ra[j]);
 #pragma unroll
   for (int x = 0; x < 4; ++x) {
     tr_mfma_drain(acc[x][0], acc[x][1]);
     tr_mfma_drain(acc[x][2], acc[x][3]);
   }
+  if (!active) return;
   float* C = grads + P.c_off;
+  const int mw = m0 + 64 * wmi, nw = n0 + 64 * wni;
 #pragma unroll
   for (int x = 0; x < 4; ++x)
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-      const int m = m0 + 16 * x + 4 * g + r;
+      const int m = mw + 16 * x + 4 * g + r;
 #pragma unroll
       for (int y = 0; y < 4; ++y) {
-        const int n = n0 + 16 * y + i;
+        const int n = nw + 16 * y + i;
         if (m < P.M && n < P.N) atomicAdd(C + (size_t)m * P.N + n, acc[x][y][r] * inv_alpha);
       }
     }
-  if (n0 == 0) {     // db[m] = sum over samples of D[m][.]: lane (i,g) holds row m0+16x+i, fold r, then the 4 lane groups
+  if (nw == 0) {     // db[m] = sum over samples of D[m][.]: lane (i,g) holds row mw+16x+i, fold r, then the 4 lane groups
 #pragma unroll
     for (int x = 0; x < 4; ++x) {
       float v = bsum[x][0] + bsum[x][1] + bsum[x][2] + bsum[x][3];
       v += __shfl_xor(v, 16);
       v += __shfl_xor(v, 32);
-      const int m = m0 + 16 * x + i;
+      const int m = mw + 16 * x + i;
       if (g == 0 && m < P.M) atomicAdd(grads + P.b_off + m, v * inv_alpha);
     }
   }
@@ -1383,9 +1421,13 @@ int gbnf_trainer_create(const gbnf_flow_desc* desc, gbnf_trainer** out) {
         P.c_off = L.gW; P.b_off = L.gb;
         P.d_rows = (l == nl - 1) ? t->op : t->hp;
         P.a_rows = (l == 0) ? t->ip : t->hp;
-        P.nb = (P.N + 63) / 64;
+        // the workgroup's 4 waves as wm x wn sub-blocks of 64 x 64: a narrow side gets one column / row of waves
+        if (P.N <= 64) { P.wm = 4; P.wn = 1; }
+        else if (P.M <= 64) { P.wm = 1; P.wn = 4; }
+        else { P.wm = 2; P.wn = 2; }
+        P.nb = (P.N + 64 * P.wn - 1) / (64 * P.wn);
         P.blk_begin = blocks;
-        blocks += ((P.M + 63) / 64) * P.nb;
+        blocks += ((P.M + 64 * P.wm - 1) / (64 * P.wm)) * P.nb;
         probs.push_back(P);
       }
     }
@@ -1415,6 +1457,8 @@ int gbnf_trainer_create(const gbnf_flow_desc* desc, gbnf_trainer** out) {
                           (const void*)train_kernel<GBNF_KIND_REALNVP, 0, 2>, (const void*)train_kernel<GBNF_KIND_REALNVP, 1, 2>};
     for (int k = 0; k < 8 && e == hipSuccess; ++k)
       e = hipFuncSetAttribute(fns[k], hipFuncAttributeMaxDynamicSharedMemorySize, TR_LDS_BYTES);
+    if (e == hipSuccess)
+      e = hipFuncSetAttribute((const void*)wgrad_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * WG_ROWS_MAX * 8 * 16);
   }
   if (e != hipSuccess) {
     gbnf_trainer_destroy(t);
@@ -1445,9 +1489,9 @@ int gbnf_trainer_grad_floats(const gbnf_trainer* t, int64_t* n_floats) {
 int gbnf_trainer_workspace_bytes(const gbnf_trainer* t, int64_t n, int64_t* bytes) {
   if (!t || !bytes || n < 0) return fail(GBNF_ERR_INVALID, "gbnf_trainer_workspace_bytes: bad argument");
   const int64_t np = tr_padded(n);
-  // operand regions + 64 slack rows (a 64-row block of wgrad_kernel may run past the last region)
+  // operand regions + 256 slack rows (a 256-row block of wgrad_kernel may run past the last region)
   // ... + the gradient state of step-by-step launches (batch-statistics BatchNorm)
-  *bytes = (((int64_t)t->K * t->nnets * t->net_rows + 64) * np + (int64_t)t->d * np) * 4;
+  *bytes = (((int64_t)t->K * t->nnets * t->net_rows + TR_WS_SLACK_ROWS) * np + (int64_t)t->d * np) * 4;
   return GBNF_OK;
 }
 
@@ -1563,7 +1607,7 @@ int gbnf_trainer_backward(const gbnf_trainer* t, const float* x, int64_t n, cons
   fill_launch(t, p, x, n);
   p.g_z = g_z; p.g_ldj = g_ldj; p.g_x = g_x; p.grads = grads; p.ws = (float*)workspace; p.trace = trace;
   p.batch_stats = t->batch_stats;
-  float* gstate = (float*)workspace + ((int64_t)t->K * t->nnets * t->net_rows + 64) * p.np;   // [d][np]: gradient state between step launches
+  float* gstate = (float*)workspace + ((int64_t)t->K * t->nnets * t->net_rows + TR_WS_SLACK_ROWS) * p.np;   // [d][np]: gradient state between step launches
   hipStream_t s = (hipStream_t)stream;
   // the scale of this call's gradients: the largest upstream entry (tr_grad_scale)
   (void)hipMemsetAsync(t->gmax_dev, 0, sizeof(unsigned), s);
@@ -1604,10 +1648,10 @@ int gbnf_trainer_backward(const gbnf_trainer* t, const float* x, int64_t n, cons
   // samples per block: every block ends in 4096 atomic adds, so as many samples as still leave a few thousand waves
   static const int forced_chunk = [] { const char* e = getenv("GBNF_WGRAD_CHUNK"); return e ? atoi(e) : 0; }();
   int chunk = 512;
-  while (chunk < 4096 && (int64_t)t->wg_blocks * (p.np / (2 * chunk)) >= 3072) chunk *= 2;
+  while (chunk < 4096 && (int64_t)t->wg_blocks * (p.np / (2 * chunk)) >= 768) chunk *= 2;     // (a block = 4 waves)
   if (forced_chunk >= 32 && forced_chunk % 32 == 0) chunk = forced_chunk;
   const dim3 wgrid((unsigned)t->wg_blocks, (unsigned)((p.np + chunk - 1) / chunk));
-  hipLaunchKernelGGL(wgrad_kernel, wgrid, dim3(64), 0, s, t->probs_dev, t->n_probs, (const float*)workspace, grads, p.np, chunk,
+  hipLaunchKernelGGL(wgrad_kernel, wgrid, dim3(WG_THREADS), (size_t)2 * WG_ROWS_MAX * 8 * 16, s, t->probs_dev, t->n_probs, (const float*)workspace, grads, p.np, chunk,
                      (const unsigned*)t->gmax_dev);
   e = hipGetLastError();
   if (e != hipSuccess) return fail(GBNF_ERR_HIP, "gbnf_trainer_backward wgrad launch: %s", hipGetErrorString(e));
