@@ -34,6 +34,9 @@ def read_variants():
                 for nt in (1, 2):
                     for prec in (0, 1):
                         out.append(("hx3", kind, ht, ot, nt, acta, actb, prec, depth))
+                    if depth == 1 and nt == 1:   # the training path's forward sweep (f16x3, trace + operand saves): "hx3t";
+                        out.append(("hx3t", kind, ht, ot, nt, acta, actb, 0, depth))     # 16-sample waves only (the 32-sample form spills)
+                        out.append(("hx3b", kind, ht, ot, acta, actb))                   # ... and its backward sweep
                 continue
             toks = line.split()
             nts = (1, 2)
@@ -152,13 +155,16 @@ def main(argv=None):
         o = os.path.join(OBJ, "v_" + "_".join(str(a) for a in v) + ".o")
         objs.append(o)
         extra = []
-        if v[0] == "hx3":
+        if v[0] == "hx3b":
+            vsrc, vargs = os.path.join(HERE, "variant_bwd.hip"), v[1:]
+            extra = list(VGPR_FORM)
+        elif v[0] in ("hx3", "hx3t"):
             vsrc, vargs = os.path.join(HERE, "variant_hx3.hip"), v[1:]
             # keep MFMA accumulators in VGPRs: the tanh/split reads them directly (no v_accvgpr_read per value)
-            extra = list(VGPR_FORM)
+            extra = list(VGPR_FORM) + (["-DGBNF_V_TRAIN=1"] if v[0] == "hx3t" else [])
         else:
             vsrc, vargs = os.path.join(HERE, "variant.hip"), v
-        if args.force or not newer(o, [vsrc] + hdr):
+        if args.force or not newer(o, [vsrc] + hdr + ([os.path.join(HERE, "gbnf_train_bwd.hip.h")] if v[0] == "hx3b" else [])):
             jobs.append([HIPCC] + FLAGS + extra + ["-DGBNF_V_ARGS=" + ",".join(str(a) for a in vargs), "-c", vsrc, "-o", o])
     img_o, img_src = os.path.join(OBJ, "gbnf_image.o"), os.path.join(HERE, "gbnf_image.hip")
     objs.append(img_o)
@@ -172,7 +178,7 @@ def main(argv=None):
     if jobs:
         print(f"[gbnf build] compiling {len(jobs)} object(s) with -j{args.j}", flush=True)
         with cf.ThreadPoolExecutor(max_workers=args.j) as ex:
-            for _ in ex.map(lambda c: compile_hx3(c) if "variant_hx3" in " ".join(c) else compile_and_lint(c), jobs):
+            for _ in ex.map(lambda c: compile_hx3(c) if ("variant_hx3" in " ".join(c) or "variant_bwd" in " ".join(c)) else compile_and_lint(c), jobs):
                 pass
     if jobs or not os.path.exists(LIB):
         run([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs)

@@ -14,6 +14,7 @@
 #include <vector>
 
 #include "gbnf_flow_kernel_hx3.hip.h"
+#include "gbnf_train_bwd.hip.h"
 #include "gbnf_internal.h"
 
 namespace gbnf {
@@ -588,23 +589,23 @@ struct PackedBlob {
 };
 
 // the cheapest compiled split-kernel variant (key.ksl = -3 f16x3 / -6 bf16x6) that covers hidden width h and `ot` output tiles
-static bool choose_hx3(int kind, int h, int ot, int depth, int act_a, int act_b, int ksl_key, VariantChoice* vc) {
+static bool choose_hx3(int kind, int h, int ot, int depth, int act_a, int act_b, int ksl_key, VariantChoice* vc, int train = 0) {
   const int ht_b = ceil_div(h, 16);
   long best = -1;
   for (const Variant& v : variants()) {
     const VariantKey& k = v.key;
-    if (k.ksl != ksl_key || k.kind != kind || k.lmid != depth || k.act_a != act_a || k.act_b != act_b) continue;
+    if (k.ksl != ksl_key || k.ks1 != train || k.kind != kind || k.lmid != depth || k.act_a != act_a || k.act_b != act_b) continue;
     if (k.ht < ht_b || k.ot < ot) continue;
-    const Variant* v1 = find_variant(VariantKey{k.kind, k.ht, ksl_key, 0, k.ot, 1, depth, k.act_a, k.act_b});
-    const Variant* v2 = find_variant(VariantKey{k.kind, k.ht, ksl_key, 0, k.ot, 2, depth, k.act_a, k.act_b});
-    if (!v1 || !v2) continue;
+    const Variant* v1 = find_variant(VariantKey{k.kind, k.ht, ksl_key, train, k.ot, 1, depth, k.act_a, k.act_b});
+    const Variant* v2 = find_variant(VariantKey{k.kind, k.ht, ksl_key, train, k.ot, 2, depth, k.act_a, k.act_b});
+    if (!v1 || (!v2 && !train)) continue;      // (the TRAIN variants exist for 16-sample waves only)
     const long cost = (long)k.ht * (k.ht + 1) / 2 * 2 + k.ht * k.ot;
     if (best < 0 || cost < best) {
       best = cost;
       vc->hx3 = true; vc->np = ksl_key == -3 ? 2 : 3;
       vc->ht = k.ht; vc->ksl = ksl_key; vc->ks1 = 0; vc->ot = k.ot;
       vc->launch_nt[1] = v1->fn; vc->name_nt[1] = v1->name;
-      vc->launch_nt[2] = v2->fn; vc->name_nt[2] = v2->name;
+      vc->launch_nt[2] = v2 ? v2->fn : nullptr; vc->name_nt[2] = v2 ? v2->name : nullptr;
     }
   }
   return best >= 0;
@@ -1530,3 +1531,462 @@ int gbnf_boosting_weights(const float* G, int64_t n, float beta, float* w_out, v
 }
 
 }  // extern "C"
+
+// =====================================================================================================================
+// Live blobs: the packed f16x3 blob of a component whose parameters live in device tensors (the training path's
+// forward sweep on flow_kernel_hx3<..., TRAIN = 1>; gbnf_internal.h).
+// =====================================================================================================================
+namespace gbnf {
+
+struct LiveLayer { const float* W; const float* b; int rows, cols; };
+// one weight tile of the blob: NP fragments at word `dst`; kind 0: layer 0 (a = tile t), 1: hidden (a = out tile u, b = chunk c),
+// 2: output layer (a = chunk c, b = out tile o); rows / cols: the layer's live extent (beyond it the tile is zero).
+// The backward blob's TRANSPOSED tiles (A = W^T: tile row index = a column of W): kind 3: W3^T (a = hidden tile t, b = chunk c of
+// net outputs), 4: W2^T (a = out tile u, b = chunk c), 5: W1^T (a = chunk c of hidden units, b = tile o of net inputs)
+struct LiveTile { uint32_t dst; uint16_t lid; uint16_t kind; uint16_t a, b; float scale; int rows, cols; };
+struct LiveBias { uint32_t dst; int lid; int row; int fold; float scale; };       // scale * (b[row] + (fold ? sum_k W[row][k] : 0)), row < 0: 0
+struct LiveEntry { uint32_t dst; int m; int step; };                               // a live table entry: p0..p3 at dst + 32 / 64 / 96 / 128
+struct LiveNorm { const float *na, *nb, *mean, *var; float eps; int has_norm; uint32_t ld_dst; };
+
+struct LiveBlob {
+  int kind = 0, d = 0, K = 0, additive = 0, nnets = 1;
+  uint32_t* blob_dev = nullptr;
+  const uint32_t** table_dev = nullptr;
+  size_t blob_words = 0;
+  LiveLayer* layers_dev = nullptr;
+  LiveTile* tiles_dev = nullptr;
+  LiveBias* bias_dev = nullptr;
+  LiveEntry* entries_dev = nullptr;
+  LiveNorm* norms_dev = nullptr;
+  int n_tiles = 0, n_bias = 0, n_entries = 0;
+  LaunchFn launch_nt[3] = {nullptr, nullptr, nullptr};
+  const char* name_nt[3] = {nullptr, nullptr, nullptr};
+  // the backward sweep (bwd_kernel_hx3): transposed-weight blob, its tile records, per-entry parameter indices
+  uint32_t* blobB_dev = nullptr;
+  const uint32_t** tableB_dev = nullptr;
+  LiveTile* tilesB_dev = nullptr;
+  int n_tilesB = 0;
+  int32_t* bwd_tab_dev = nullptr;
+  int64_t* bwd_goff_dev = nullptr;
+  LaunchFn launch_bwd = nullptr;
+  const char* name_bwd = nullptr;
+  int bwd_waves = 4;                    // waves per workgroup of the backward launch (bwd_hx3_waves)
+  int ht = 0;                           // hidden tiles of the kernel variant
+};
+
+// the device twin of put_tile(): lane (i,g) of block `tile` computes its 8 values and writes 4 words per piece
+__global__ void __launch_bounds__(64) live_tiles_kernel(const LiveTile* __restrict__ tiles, const LiveLayer* __restrict__ layers,
+                                                        uint32_t* __restrict__ blob) {
+  const LiveTile T = tiles[blockIdx.x];
+  const LiveLayer L = layers[T.lid];
+  const int lane = threadIdx.x, i = lane & 15, gg = lane >> 4;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    uint32_t w[2] = {0u, 0u};
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+      const int j = 2 * q + e;
+      int row, col;                          // element W[row][col] of the layer
+      const int kslot_b = 16 * (2 * T.b + (j >> 2)) + 4 * gg + (j & 3), kslot_a = 16 * (2 * T.a + (j >> 2)) + 4 * gg + (j & 3);
+      if (T.kind == 0) { row = 16 * T.a + i; col = 8 * gg + j; }
+      else if (T.kind == 1) { row = 16 * T.a + i; col = kslot_b; }
+      else if (T.kind == 2) { row = 16 * T.b + i; col = kslot_a; }
+      else if (T.kind == 3 || T.kind == 4) { row = kslot_b; col = 16 * T.a + i; }      // contraction over W's rows
+      else { row = kslot_a; col = 16 * T.b + i; }
+      float r = (row < T.rows && col < T.cols) ? T.scale * L.W[(size_t)row * L.cols + col] : 0.0f;
+#pragma unroll
+      for (int k = 0; k < 2; ++k) {       // hi = f16(r), mid = f16(r - hi): both round to nearest, like the host packer
+        const _Float16 h = static_cast<_Float16>(r);
+        w[k] |= (uint32_t)__builtin_bit_cast(unsigned short, h) << (16 * e);
+        r -= static_cast<float>(h);
+      }
+    }
+    blob[T.dst + (size_t)lane * 4 + q] = w[0];
+    blob[T.dst + 256 + (size_t)lane * 4 + q] = w[1];
+  }
+}
+
+// biases (folded row sums in double, like the host packer), live table entries, per-step log-det constants
+__global__ void __launch_bounds__(256) live_small_kernel(const LiveBias* __restrict__ bias, int n_bias, const LiveEntry* __restrict__ ent,
+                                                         int n_ent, const LiveNorm* __restrict__ norms, int K, int d, int glow,
+                                                         const LiveLayer* __restrict__ layers, uint32_t* __restrict__ blob) {
+  auto put = [&](uint32_t off, float v) { blob[off] = __builtin_bit_cast(uint32_t, v); };
+  // biases: 16 lanes per word (the folded row sum of a tanh layer runs over up to 512 weights: one thread per row took 50 us)
+  const int n_bias_blocks = (n_bias + 15) / 16;
+  if ((int)blockIdx.x < n_bias_blocks) {
+    const int w = blockIdx.x * 16 + (threadIdx.x >> 4), sub = threadIdx.x & 15;
+    if (w < n_bias) {                       // (uniform per group of 16 lanes)
+      const LiveBias B = bias[w];
+      double acc = 0.0;
+      if (B.row >= 0) {
+        const LiveLayer L = layers[B.lid];
+        if (B.fold)
+          for (int k = sub; k < L.cols; k += 16) acc += (double)L.W[(size_t)B.row * L.cols + k];
+        if (sub == 0) acc += (double)L.b[B.row];
+      }
+#pragma unroll
+      for (int off = 8; off > 0; off >>= 1) acc += __shfl_xor(acc, off, 16);
+      if (sub == 0) put(B.dst, B.row >= 0 ? B.scale * (float)acc : 0.0f);
+    }
+    return;
+  }
+  const int t = n_bias + ((int)blockIdx.x - n_bias_blocks) * blockDim.x + threadIdx.x;
+  if (t < n_bias + n_ent) {
+    const LiveEntry E = ent[t - n_bias];
+    const LiveNorm N = norms[E.step];
+    float p0 = 0.f, p1 = 1.f, p2 = 1.f, p3 = 0.f;
+    if (glow) {
+      p0 = N.na[E.m]; p1 = expf(N.nb[E.m]); p2 = expf(-N.nb[E.m]);
+    } else if (N.has_norm) {
+      p0 = N.mean[E.m]; p1 = sqrtf(N.var[E.m] + N.eps); p2 = expf(N.na[E.m]); p3 = N.nb[E.m];
+    }
+    put(E.dst + 32, p0); put(E.dst + 64, p1); put(E.dst + 96, p2); put(E.dst + 128, p3);
+  } else if (t < n_bias + n_ent + K) {
+    const LiveNorm N = norms[t - n_bias - n_ent];
+    float acc = 0.0f;
+    if (glow) {
+      for (int m = 0; m < d; ++m) acc += N.nb[m];                       // torch.sum(logs)
+    } else if (N.has_norm) {
+      for (int m = 0; m < d; ++m) acc += N.na[m] - 0.5f * logf(N.var[m] + N.eps);    // models/layers.py:357-358
+    }
+    put(N.ld_dst, acc);
+  }
+}
+
+void live_blob_destroy(LiveBlob* lb) {
+  if (!lb) return;
+  if (lb->blob_dev) (void)hipFree(lb->blob_dev);
+  if (lb->table_dev) (void)hipFree(lb->table_dev);
+  if (lb->layers_dev) (void)hipFree(lb->layers_dev);
+  if (lb->tiles_dev) (void)hipFree(lb->tiles_dev);
+  if (lb->bias_dev) (void)hipFree(lb->bias_dev);
+  if (lb->entries_dev) (void)hipFree(lb->entries_dev);
+  if (lb->norms_dev) (void)hipFree(lb->norms_dev);
+  if (lb->blobB_dev) (void)hipFree(lb->blobB_dev);
+  if (lb->tableB_dev) (void)hipFree(lb->tableB_dev);
+  if (lb->tilesB_dev) (void)hipFree(lb->tilesB_dev);
+  if (lb->bwd_tab_dev) (void)hipFree(lb->bwd_tab_dev);
+  if (lb->bwd_goff_dev) (void)hipFree(lb->bwd_goff_dev);
+  delete lb;
+}
+
+template <typename T>
+static hipError_t upload_vec(const std::vector<T>& v, T** dev) {
+  *dev = nullptr;
+  if (v.empty()) return hipSuccess;
+  hipError_t e = hipMalloc((void**)dev, sizeof(T) * v.size());
+  if (e == hipSuccess) e = hipMemcpy(*dev, v.data(), sizeof(T) * v.size(), hipMemcpyHostToDevice);
+  return e;
+}
+
+int live_blob_create(const gbnf_flow_desc* desc, const int64_t* norm_grad_offsets, LiveBlob** out) {
+  *out = nullptr;
+  DescInfo info;
+  int rc = validate_desc(desc, &info);
+  if (rc) return rc;
+  const int d = desc->d, K = desc->n_steps;
+  const bool glow = desc->kind == GBNF_KIND_GLOW;
+  const bool additive = glow && desc->coupling == GBNF_COUPLING_ADDITIVE;
+  const int h = info.ref.hidden, depth = info.ref.depth;
+  if (depth != 1 || info.ref.residual)
+    return fail(GBNF_ERR_UNSUPPORTED, "live blob: TanhNet / ReLUNet of coupling_network_depth 1 only");
+  {   // an activation pair nobody compiled a kernel for runs on the per-step variants (as gbnf_flow_create_ex does)
+    bool compiled = false;
+    for (const Variant& v : variants())
+      compiled = compiled || (v.key.ks1 == 1 && v.key.kind == desc->kind && v.key.act_a == info.act_a && v.key.act_b == info.act_b);
+    if (!compiled) info.act_a = info.act_b = GBNF_ACT_PER_STEP;
+  }
+  VariantChoice vc;
+  if (!choose_hx3(desc->kind, h, info.ot, depth, info.act_a, info.act_b, -3, &vc, /*train=*/1)) {
+    if (info.act_a != GBNF_ACT_PER_STEP) {
+      info.act_a = info.act_b = GBNF_ACT_PER_STEP;
+      if (!choose_hx3(desc->kind, h, info.ot, depth, info.act_a, info.act_b, -3, &vc, 1))
+        return fail(GBNF_ERR_UNSUPPORTED, "live blob: no TRAIN kernel variant for kind=%d hidden=%d out_tiles=%d", desc->kind, h, info.ot);
+    } else {
+      return fail(GBNF_ERR_UNSUPPORTED, "live blob: no TRAIN kernel variant for kind=%d hidden=%d out_tiles=%d", desc->kind, h, info.ot);
+    }
+  }
+  // ---- the value-independent words: pack a copy of the descriptor whose parameter arrays are host zeros
+  static const std::vector<float> zeros((size_t)512 * 512 + 64, 0.0f);
+  std::vector<gbnf_glow_step> gsteps;
+  std::vector<gbnf_realnvp_step> rsteps;
+  std::vector<std::vector<gbnf_linear>> lin_store;
+  auto zero_net = [&](const gbnf_net& n) {
+    lin_store.emplace_back(n.layers, n.layers + n.n_layers);
+    for (gbnf_linear& l : lin_store.back()) { l.weight = zeros.data(); l.bias = zeros.data(); }
+    gbnf_net z = n;
+    z.layers = lin_store.back().data();
+    return z;
+  };
+  lin_store.reserve((size_t)2 * K);
+  gbnf_flow_desc dummy = *desc;
+  if (glow) {
+    gsteps.assign(desc->glow_steps, desc->glow_steps + K);
+    for (gbnf_glow_step& g : gsteps) { g.actnorm_bias = zeros.data(); g.actnorm_logs = zeros.data(); g.block = zero_net(g.block); }
+    dummy.glow_steps = gsteps.data();
+  } else {
+    rsteps.assign(desc->realnvp_steps, desc->realnvp_steps + K);
+    for (gbnf_realnvp_step& r : rsteps) {
+      if (r.has_batch_norm) { r.bn_log_gamma = r.bn_beta = r.bn_running_mean = r.bn_running_var = zeros.data(); }
+      r.t_net = zero_net(r.t_net);
+      r.s_net = zero_net(r.s_net);
+    }
+    dummy.realnvp_steps = rsteps.data();
+  }
+  PackedBlob pb;
+  pack_component(&dummy, info, vc, &pb);
+
+  // ---- where every value-dependent word comes from (the loops of pack_component / pack_net_hx3, recording instead of computing)
+  const int HT = vc.ht, OT = vc.ot, NP = 2, nnets = glow ? 1 : 2;
+  const Hx3Layout L(HT, OT, NP, depth);
+  const size_t NW = (size_t)L.NET_WORDS, step_words = SMALL_WORDS + nnets * NW, TW = (size_t)NP * 256;
+  const int d1 = d / 2, d2 = d - d1;
+  std::vector<LiveLayer> layers;
+  std::vector<LiveTile> tiles;
+  std::vector<LiveBias> biases;
+  std::vector<LiveEntry> entries;
+  std::vector<LiveNorm> norms(K);
+  const BwdLayout LB(HT, OT);
+  const size_t NWB = (size_t)LB.NET_WORDS, step_words_b = nnets * NWB;
+  std::vector<LiveTile> tilesB;
+  std::vector<int32_t> bwd_tab((size_t)K * 2 * 4 * NENT, -1);
+  auto add_net_bwd = [&](int lid0, size_t base, int in_f, int out_f) {       // lid0: the net's first LiveLayer (layers lid0 .. lid0 + 2)
+    int s = 0;
+    for (int i0 = 0; i0 < LB.N_L0; ++i0, ++s)
+      for (int n = 0; n < LB.nf[s] / NP; ++n) {
+        const int t = i0 * LB.ROWS0 + n / LB.K0, c = n % LB.K0;
+        tilesB.push_back(LiveTile{(uint32_t)(base + LB.off[s] + (size_t)n * TW), (uint16_t)(lid0 + 2), 3, (uint16_t)t, (uint16_t)c, 1.0f, out_f, h});
+      }
+    for (int u = 0; u < HT; ++u, ++s) {
+      for (int c = 0; c < LB.HC; ++c)
+        tilesB.push_back(LiveTile{(uint32_t)(base + LB.off[s] + (size_t)c * TW), (uint16_t)(lid0 + 1), 4, (uint16_t)u, (uint16_t)c, 1.0f, h, h});
+      if (u % 2 == 0 && u >= 2)
+        for (int o = 0; o < 2; ++o)
+          tilesB.push_back(LiveTile{(uint32_t)(base + LB.off[s] + (size_t)(LB.HC + o) * TW), (uint16_t)lid0, 5, (uint16_t)((u - 2) / 2), (uint16_t)o, 1.0f, h, in_f});
+    }
+    for (int o = 0; o < 2; ++o)
+      tilesB.push_back(LiveTile{(uint32_t)(base + LB.off[s] + (size_t)o * TW), (uint16_t)lid0, 5, (uint16_t)(LB.HC - 1), (uint16_t)o, 1.0f, h, in_f});
+  };
+  auto add_net = [&](const gbnf_net& net, size_t base, int in_f, int out_f) {
+    const bool tanh_net = net.activation == GBNF_ACT_TANH;
+    const float T = tanh_net ? 2.8853900817779268f : 1.0f, R = tanh_net ? -2.0f : 1.0f;
+    int lid[3];
+    for (int l = 0; l < 3; ++l) {
+      lid[l] = (int)layers.size();
+      layers.push_back(LiveLayer{net.layers[l].weight, net.layers[l].bias, net.layers[l].out_features, net.layers[l].in_features});
+    }
+    for (int t = 0; t < HT; ++t)
+      for (int k = 0; k < 16; ++k) {
+        const int u = 16 * t + k;
+        biases.push_back(LiveBias{(uint32_t)(base + (size_t)t * 16 + k), lid[0], u < h ? u : -1, 0, T});
+        biases.push_back(LiveBias{(uint32_t)(base + (size_t)(HT + t) * 16 + k), lid[1], u < h ? u : -1, tanh_net ? 1 : 0, T});
+      }
+    for (int o = 0; o < OT; ++o)
+      for (int k = 0; k < 16; ++k) {
+        const int r = 16 * o + k;
+        biases.push_back(LiveBias{(uint32_t)(base + (size_t)(2 * HT + o) * 16 + k), lid[2], r < out_f ? r : -1, tanh_net ? 1 : 0, 1.0f});
+      }
+    int s = 0;
+    for (int i0 = 0; i0 < L.N_L0; ++i0, ++s)
+      for (int tl = 0; tl < L.nf[s] / NP; ++tl)
+        tiles.push_back(LiveTile{(uint32_t)(base + L.off[s] + (size_t)tl * TW), (uint16_t)lid[0], 0, (uint16_t)(i0 * L.TL0 + tl), 0, T, h, in_f});
+    for (int u = 0; u < HT; ++u, ++s) {
+      for (int c = 0; c < L.HC; ++c)
+        tiles.push_back(LiveTile{(uint32_t)(base + L.off[s] + (size_t)c * TW), (uint16_t)lid[1], 1, (uint16_t)u, (uint16_t)c, T * R, h, h});
+      if (u % 2 == 0 && u >= 2)
+        for (int o = 0; o < OT; ++o)
+          tiles.push_back(LiveTile{(uint32_t)(base + L.off[s] + (size_t)(L.HC + o) * TW), (uint16_t)lid[2], 2, (uint16_t)((u - 2) / 2), (uint16_t)o, R, out_f, h});
+    }
+    for (int o = 0; o < OT; ++o)
+      tiles.push_back(LiveTile{(uint32_t)(base + L.off[s] + (size_t)o * TW), (uint16_t)lid[2], 2, (uint16_t)(L.HC - 1), (uint16_t)o, R, out_f, h});
+    return lid[0];
+  };
+  for (int s = 0; s < K; ++s) {
+    const size_t sb = step_words * s;
+    int in_f, out_f;
+    std::vector<int> src(d);             // src[j] = index into the step's parameter vectors of new logical feature j
+    LiveNorm& N = norms[s];
+    N = LiveNorm{nullptr, nullptr, nullptr, nullptr, 0.0f, 0, (uint32_t)(sb + 1)};
+    if (glow) {
+      const gbnf_glow_step& st = desc->glow_steps[s];
+      N.na = st.actnorm_bias; N.nb = st.actnorm_logs; N.has_norm = 1;
+      for (int j = 0; j < d; ++j) src[j] = (int)st.perm_indices[j];
+      in_f = d1; out_f = d2;
+    } else {
+      const gbnf_realnvp_step& st = desc->realnvp_steps[s];
+      N.has_norm = st.has_batch_norm ? 1 : 0;
+      N.na = st.bn_log_gamma; N.nb = st.bn_beta; N.mean = st.bn_running_mean; N.var = st.bn_running_var; N.eps = st.bn_eps;
+      in_f = st.flipped ? d2 : d1; out_f = st.flipped ? d1 : d2;
+      for (int j = 0; j < d; ++j) src[j] = st.flipped ? ((j < d2) ? d1 + j : j - d2) : j;
+    }
+    const bool paired = glow && !additive;
+    if (glow || N.has_norm) {            // (a RealNVP step without BatchNorm keeps the identity constants of the template)
+      for (int gg = 0; gg < 4; ++gg)
+        for (int e = 0; e < NENT; ++e) {
+          const int k = 8 * gg + e;
+          if (k < in_f) {
+            entries.push_back(LiveEntry{(uint32_t)(sb + SMALL_HDR + gg * NENT + e), src[k], s});
+            bwd_tab[((size_t)s * 2 + 0) * 4 * NENT + gg * NENT + e] = src[k];
+          }
+          const int jj = paired ? 8 * (e >> 1) + 2 * gg + (e & 1) : 16 * (e >> 2) + 4 * gg + (e & 3);
+          if (jj < out_f) {
+            entries.push_back(LiveEntry{(uint32_t)(sb + SMALL_HDR + 160 + gg * NENT + e), src[in_f + jj], s});
+            bwd_tab[((size_t)s * 2 + 1) * 4 * NENT + gg * NENT + e] = src[in_f + jj];
+          }
+        }
+    }
+    const int net_out = paired ? 2 * out_f : out_f;
+    const size_t sbb = step_words_b * s;
+    if (glow) {
+      const int l0 = add_net(desc->glow_steps[s].block, sb + SMALL_WORDS, in_f, net_out);
+      add_net_bwd(l0, sbb, in_f, net_out);
+    } else {
+      const int l0 = add_net(desc->realnvp_steps[s].t_net, sb + SMALL_WORDS, in_f, net_out);
+      const int l1 = add_net(desc->realnvp_steps[s].s_net, sb + SMALL_WORDS + NW, in_f, net_out);
+      add_net_bwd(l0, sbb, in_f, net_out);
+      add_net_bwd(l1, sbb + NWB, in_f, net_out);
+    }
+  }
+
+  LiveBlob* lb = new LiveBlob();
+  lb->kind = desc->kind; lb->d = d; lb->K = K; lb->additive = additive ? 1 : 0; lb->nnets = nnets;
+  lb->blob_words = pb.words.size();
+  lb->ht = vc.ht;
+  lb->n_tiles = (int)tiles.size(); lb->n_bias = (int)biases.size(); lb->n_entries = (int)entries.size();
+  for (int nt = 1; nt <= 2; ++nt) { lb->launch_nt[nt] = vc.launch_nt[nt]; lb->name_nt[nt] = vc.name_nt[nt]; }
+  hipError_t e = upload_blob(pb.words, &lb->blob_dev, &lb->table_dev);
+  if (e == hipSuccess) e = upload_vec(layers, &lb->layers_dev);
+  if (e == hipSuccess) e = upload_vec(tiles, &lb->tiles_dev);
+  if (e == hipSuccess) e = upload_vec(biases, &lb->bias_dev);
+  if (e == hipSuccess) e = upload_vec(entries, &lb->entries_dev);
+  if (e == hipSuccess) e = upload_vec(norms, &lb->norms_dev);
+  // ---- the backward sweep, where a variant of bwd_kernel_hx3 exists for this geometry (else the caller keeps its own)
+  if (e == hipSuccess && norm_grad_offsets != nullptr) {
+    const Variant* vb = find_variant(VariantKey{desc->kind, vc.ht, -3, 2, vc.ot, 1, 1, info.act_a, info.act_b});
+    if (vb != nullptr) {
+      const std::vector<uint32_t> zerosB(step_words_b * K + 64, 0u);      // (padding words stay zero; every tile is rewritten per call)
+      std::vector<int64_t> goff(norm_grad_offsets, norm_grad_offsets + 2 * K);
+      lb->n_tilesB = (int)tilesB.size();
+      e = upload_blob(zerosB, &lb->blobB_dev, &lb->tableB_dev);
+      if (e == hipSuccess) e = upload_vec(tilesB, &lb->tilesB_dev);
+      if (e == hipSuccess) e = upload_vec(bwd_tab, &lb->bwd_tab_dev);
+      if (e == hipSuccess) e = upload_vec(goff, &lb->bwd_goff_dev);
+      lb->launch_bwd = vb->fn;
+      lb->name_bwd = vb->name;
+      lb->bwd_waves = bwd_hx3_waves(K, LB.STAGE_FRAGS, d);
+    }
+  }
+  if (e != hipSuccess) {
+    live_blob_destroy(lb);
+    return fail(GBNF_ERR_HIP, "live blob: %s", hipGetErrorString(e));
+  }
+  *out = lb;
+  return GBNF_OK;
+}
+
+// grads[g_na / g_nb of step k + j] += sum over workgroups of partials[.][k][which][j], in a fixed order
+__global__ void __launch_bounds__(1024) bwd_param_reduce_kernel(const float* __restrict__ partials, int n_wg, int K, int d,
+                                                                const int64_t* __restrict__ goff, float* __restrict__ grads) {
+  __shared__ float red[16][64];
+  const int kw = blockIdx.x, j = threadIdx.x & 63, part = threadIdx.x >> 6;       // kw = step * 2 + which
+  const float* src = partials + kw * 64 + j;
+  const int64_t stride = (int64_t)K * 128;
+  float a0 = 0.0f, a1 = 0.0f, a2 = 0.0f, a3 = 0.0f;
+  int b = part;
+  for (; b + 48 < n_wg; b += 64) {
+    a0 += src[(int64_t)b * stride];
+    a1 += src[(int64_t)(b + 16) * stride];
+    a2 += src[(int64_t)(b + 32) * stride];
+    a3 += src[(int64_t)(b + 48) * stride];
+  }
+  for (; b < n_wg; b += 16) a0 += src[(int64_t)b * stride];
+  red[part][j] = (a0 + a1) + (a2 + a3);
+  __syncthreads();
+  if (part == 0 && j < d) {
+    float v = 0.0f;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) v += red[q][j];
+    grads[goff[kw] + j] += v;
+  }
+}
+
+bool live_blob_has_backward(const LiveBlob* lb) { return lb != nullptr && lb->launch_bwd != nullptr; }
+int live_blob_hidden_rows(const LiveBlob* lb) { return lb ? 16 * lb->ht : 0; }
+
+// g_z / g_ldj (either may be null) -> g_x (or null), the ActNorm / BatchNorm entries of `grads`, and the gradient-side
+// operands of the weight gradients in `acts` (the workspace the forward sweep filled); gmax: gmax_kernel's result
+int live_blob_backward(LiveBlob* lb, int64_t n, const float* trace, float* acts, int64_t np, int ip, int hp, int op,
+                       const float* g_z, const float* g_ldj, float* g_x, float* grads, const unsigned* gmax, void* stream) {
+  hipStream_t s = (hipStream_t)stream;
+  // the transposed tiles of the CURRENT parameter values (the forward call that wrote the trace saw the same ones)
+  hipLaunchKernelGGL(live_tiles_kernel, dim3((unsigned)lb->n_tilesB), dim3(64), 0, s, (const LiveTile*)lb->tilesB_dev,
+                     (const LiveLayer*)lb->layers_dev, lb->blobB_dev);
+  FlowLaunch p{};
+  p.blobs = lb->table_dev; p.blobs_bwd = lb->tableB_dev;
+  p.n = n; p.d = lb->d; p.n_steps = lb->K; p.n_comp = 1; p.n_batches = 1; p.additive = lb->additive;
+  p.sat = reinterpret_cast<unsigned long long*>(saturation_counter());
+  p.acts_out = acts; p.np = np; p.tr_ip = ip; p.tr_hp = hp; p.tr_op = op; p.net_rows = ip + 4 * hp + 2 * op;
+  p.bwd_tab = lb->bwd_tab_dev; p.bwd_goff = lb->bwd_goff_dev; p.trace_in = trace;
+  p.g_z = g_z; p.g_ldj = g_ldj; p.g_x = g_x; p.grads = grads; p.gmax = gmax;
+  // the workgroups' parameter-gradient sums go to the slack rows behind the last operand region (their contents are of no
+  // consequence to wgrad_kernel): 4-wave workgroups at most => np / 64 * K * 128 <= 24 np floats of the 320 np there
+  p.partials = acts + (int64_t)lb->K * lb->nnets * p.net_rows * np;
+  hipError_t e = lb->launch_bwd(p, 0u, s);
+  if (e != hipSuccess) return fail(GBNF_ERR_HIP, "launch of %s failed: %s", lb->name_bwd, hipGetErrorString(e));
+  const int n_wg = (int)((np / 16 + lb->bwd_waves - 1) / lb->bwd_waves);
+  hipLaunchKernelGGL(bwd_param_reduce_kernel, dim3((unsigned)(2 * lb->K)), dim3(1024), 0, s, (const float*)p.partials, n_wg, lb->K, lb->d,
+                     (const int64_t*)lb->bwd_goff_dev, grads);
+  e = hipGetLastError();
+  if (e != hipSuccess) return fail(GBNF_ERR_HIP, "bwd_param_reduce launch failed: %s", hipGetErrorString(e));
+  return GBNF_OK;
+}
+
+static void live_blob_repack(LiveBlob* lb, hipStream_t s) {
+  hipLaunchKernelGGL(live_tiles_kernel, dim3((unsigned)lb->n_tiles), dim3(64), 0, s, (const LiveTile*)lb->tiles_dev,
+                     (const LiveLayer*)lb->layers_dev, lb->blob_dev);
+  const int small_blocks = (lb->n_bias + 15) / 16 + (lb->n_entries + lb->K + 255) / 256;
+  hipLaunchKernelGGL(live_small_kernel, dim3((unsigned)small_blocks), dim3(256), 0, s, (const LiveBias*)lb->bias_dev, lb->n_bias,
+                     (const LiveEntry*)lb->entries_dev, lb->n_entries, (const LiveNorm*)lb->norms_dev, lb->K, lb->d,
+                     lb->kind == GBNF_KIND_GLOW ? 1 : 0, (const LiveLayer*)lb->layers_dev, lb->blob_dev);
+}
+
+int live_blob_words(const LiveBlob* lb, uint32_t* out_host, int64_t* n_words) {
+  if (n_words) *n_words = (int64_t)lb->blob_words;
+  if (out_host) {
+    live_blob_repack(const_cast<LiveBlob*>(lb), nullptr);
+    GBNF_HIP(hipDeviceSynchronize());
+    GBNF_HIP(hipMemcpy(out_host, lb->blob_dev, lb->blob_words * 4, hipMemcpyDeviceToHost));
+  }
+  return GBNF_OK;
+}
+
+int live_blob_forward(LiveBlob* lb, const float* x, int64_t n, float* z, float* ldj, float* trace, float* acts, int64_t np,
+                      int ip, int hp, int op, void* stream) {
+  hipStream_t s = (hipStream_t)stream;
+  live_blob_repack(lb, s);
+  // 32-sample waves once that still gives every SIMD of the chip a wave, else 16-sample ones (as pick_nt does)
+  int nt = pick_nt(n, 1);
+  if (lb->launch_nt[nt] == nullptr) nt = 1;
+  FlowLaunch p{};
+  p.blobs = lb->table_dev; p.z_out = z; p.ldj_out = ldj; p.ll_out = nullptr;
+  p.n_batches = 1; p.xs[0] = x;
+  p.n = n; p.out_stride = n; p.d = lb->d; p.n_steps = lb->K; p.c_begin = 0; p.n_comp = 1;
+  p.n_tiles = (int32_t)((n + 16 * nt - 1) / (16 * nt)); p.additive = lb->additive;
+  p.sat = reinterpret_cast<unsigned long long*>(saturation_counter());
+  p.seq = next_serial();
+  p.trace_out = trace; p.acts_out = acts; p.np = np; p.tr_ip = ip; p.tr_hp = hp; p.tr_op = op; p.net_rows = ip + 4 * hp + 2 * op;
+  const hipError_t e = lb->launch_nt[nt](p, 0u, s);
+  if (e != hipSuccess) return fail(GBNF_ERR_HIP, "launch of %s failed: %s", lb->name_nt[nt], hipGetErrorString(e));
+  return GBNF_OK;
+}
+
+}  // namespace gbnf
+
+// (tests) the words of a packed evaluation handle, and of a trainer's live blob after a device re-pack: tests/test_hip_train.py
+// compares them bit for bit (the device packer must reproduce the host packer)
+extern "C" int gbnf_debug_flow_blob(const gbnf_flow* flow, uint32_t* out_host, int64_t* n_words) {
+  if (!flow) return gbnf::fail(GBNF_ERR_INVALID, "gbnf_debug_flow_blob: flow is null");
+  if (n_words) *n_words = (int64_t)flow->blob_words;
+  if (out_host) GBNF_HIP(hipMemcpy(out_host, flow->blob_dev, flow->blob_words * 4, hipMemcpyDeviceToHost));
+  return GBNF_OK;
+}

@@ -110,6 +110,28 @@ struct FlowLaunch {
                                  //   the check on the caller's data, every repair launch re-evaluates its whole work list in bf16x6
   int32_t n_items;               // hx3 kernels: work items (component, batch, tile group) of the launch; a repair launch walks them
                                  //   with a grid of at most a few workgroups per CU
+  // TRAIN instantiations of the hx3 kernel (the training path's forward sweep, csrc/gbnf_train.hip): besides z / ldj the
+  // kernel saves what the backward pass needs, so that nothing is recomputed there
+  float* trace_out;              //   [n_steps][d slots][np]: every step's normalised state (slot layout)
+  float* acts_out;               //   the trainer's operand workspace: per (step, net) a region of `net_rows` rows of np floats,
+                                 //   tiled [16-sample tile][row][16]: net input (ip rows) | hidden activations (2 x hp) | the
+                                 //   backward's gradient-side rows (2 x hp + op) | net output (op rows, at row offset ip + 4 hp + op)
+  int64_t np;                    //   samples padded to whole 32-sample tiles
+  int32_t tr_ip, tr_hp, tr_op;   //   padded net-input / hidden / net-output rows (multiples of 16)
+  int32_t net_rows;              //   ip + 4 hp + 2 op
+  // the backward sweep of the training path (bwd_kernel_hx3, gbnf_train_bwd.hip.h); acts_out is read (saved activations and
+  // net outputs) and written (gradient-side operands), np / tr_* as above
+  const uint32_t* const* blobs_bwd;   // device array [1]: the packed TRANSPOSED weights (BwdLayout), steps 0 .. K-1
+  const int32_t* bwd_tab;        //   [n_steps][2 (in | out)][4 g][NENT]: index of the entry's feature in the step's parameter vectors, -1 = none
+  const int64_t* bwd_goff;       //   [n_steps][2]: float offsets of the step's two normalisation-parameter gradients in `grads`
+  const float* trace_in;         //   [n_steps][d][np]
+  const float* g_z;              //   (n, d) upstream gradient or null
+  const float* g_ldj;            //   (n,) or null
+  float* g_x;                    //   (n, d) or null
+  float* grads;                  //   flat parameter-gradient buffer (ActNorm / BatchNorm entries are accumulated here)
+  const unsigned* gmax;          //   bits of the largest |upstream entry| (gradient scaling)
+  float* partials;               //   [workgroups][n_steps][2][64]: every workgroup's sums of the normalisation-parameter gradients
+                                 //   (bwd_param_reduce_kernel adds them up in a fixed order: no atomics, bit-reproducible)
 };
 // Per-device saturation words (64-bit): [0] counter of waves that marked a sample, [1] unused, [2 ..] launch marks
 constexpr int SAT_MARKS = 2;

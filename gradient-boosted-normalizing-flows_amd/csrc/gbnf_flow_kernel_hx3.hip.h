@@ -226,10 +226,11 @@ __device__ __forceinline__ void wait_vmcnt(int n) {
   else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
 }
 
-template <int KIND, int HT, int OT, int NT, int ACTA, int ACTB, int PREC, int WV, int DEPTH>
+template <int KIND, int HT, int OT, int NT, int ACTA, int ACTB, int PREC, int WV, int DEPTH, int TRAIN = 0>
 __global__ void __launch_bounds__(64 * WV, hx3_waves_per_simd(HT, OT, NT, PREC, KIND, ACTA, ACTB, DEPTH))
 flow_kernel_hx3(const FlowLaunch p) {
   static_assert(DEPTH >= 0 && DEPTH <= 2, "coupling_network_depth 0, 1 or 2");
+  static_assert(!TRAIN || (DEPTH == 1 && PREC == 0), "the training forward exists for depth-1 nets on f16x3");
   constexpr int WAVES = WV;
   constexpr int NP = hx3_pieces(PREC);
   constexpr int NPROD = Products<NP>::N;
@@ -283,6 +284,15 @@ flow_kernel_hx3(const FlowLaunch p) {
   const int64_t row0 = ((int64_t)grp * WAVES + wave) * (16 * NT);    // rows >= n are masked everywhere
   const float* __restrict__ xin = p.xs[batch];
   const int64_t out_base = (int64_t)comp * p.out_stride + (int64_t)batch * p.n;
+  // TRAIN: lane offsets into the trace ([slot][np]) and the operand regions ([16-sample tile][row][16]); 32-bit: one
+  // (step, net) region holds net_rows * np < 2^31 floats for np up to 2 M rows
+  [[maybe_unused]] const bool tr_ok = !TRAIN || row0 < p.np;      // (the last workgroup's spare waves own no rows at all)
+  [[maybe_unused]] const int tr_np = (int)p.np, tr_row = (int)row0 + (lane & 15);
+  [[maybe_unused]] const int tr_ip = p.tr_ip, tr_hp = p.tr_hp, tr_ip16 = p.tr_ip * 16, tr_hp16 = p.tr_hp * 16, tr_op16 = p.tr_op * 16;
+  [[maybe_unused]] const int tr_net_stride = p.net_rows * (int)p.np;
+  [[maybe_unused]] const int tr_in_off = (int)(row0 >> 4) * tr_ip16 + 8 * (lane >> 4) * 16 + (lane & 15);      // net-input row 8 g + e
+  [[maybe_unused]] const int tr_h_off = (int)(row0 >> 4) * tr_hp16 + 4 * (lane >> 4) * 16 + (lane & 15);       // hidden unit 16 t + 4 g + r
+  [[maybe_unused]] const int tr_o_off = (int)(row0 >> 4) * tr_op16 + 4 * (lane >> 4) * 16 + (lane & 15);       // output row 16 o + 4 g + r
 
   // ---- repair launch: only items that own a sample marked by the f16x3 launch (NaN in its outputs) are evaluated
   if (p.repair && !redo_all) {
@@ -533,6 +543,13 @@ flow_kernel_hx3(const FlowLaunch p) {
   for (int sidx = 0; sidx < p.n_steps; ++sidx) {
     const int step = inv ? p.n_steps - 1 - sidx : sidx;
     const uint32_t* __restrict__ sp = blob + (size_t)step * STEP_WORDS;
+    // TRAIN: this step's save regions as uniform bases + 32-bit lane offsets (no 64-bit vector arithmetic per store)
+    [[maybe_unused]] float* tr_trace = nullptr;
+    [[maybe_unused]] float* tr_acts = nullptr;
+    if constexpr (TRAIN) {
+      tr_trace = p.trace_out + (int64_t)step * d * p.np;
+      tr_acts = p.acts_out + (int64_t)step * NNETS * p.net_rows * p.np;
+    }
     // ---- normalise the coupling net's inputs in place; split them into the first layer's B operand:
     //      lane (i,g), element j  <->  input feature 8g + j of sample i
     u32x4 zp[NT][NP];
@@ -561,6 +578,13 @@ flow_kernel_hx3(const FlowLaunch p) {
           const float t = inv ? v[nt][e] : norm_fn<KIND>(v[nt][e], tin.p0[e], tin.p1[e], tin.p2[e], tin.p3[e]);
           const float keep = inv ? invnorm_fn<KIND>(v[nt][e], tin.p0[e], tin.p1[e], tin.p2[e], tin.p3[e]) : t;
           Z[(live ? tin.slot[e] : d) * ZS + i + 16 * nt] = keep;      // dead entries go to the spare slot d: no exec masking
+          if constexpr (TRAIN) {
+            if (live && tr_ok) {       // the backward's inputs: the step's normalised state (slot layout) and the nets' input rows
+              tr_trace[tin.slot[e] * tr_np + tr_row + 16 * nt] = t;
+#pragma unroll
+              for (int q = 0; q < NNETS; ++q) tr_acts[q * tr_net_stride + tr_in_off + nt * tr_ip16 + e * 16] = t;
+            }
+          }
           if constexpr (WATCH) {
             sat[nt] = sat[nt] || (live && !(__builtin_fabsf(t) <= 65504.0f));
             v[nt][e] = live ? __builtin_amdgcn_fmed3f(t, -65504.0f, 65504.0f) : 0.0f;
@@ -613,7 +637,21 @@ flow_kernel_hx3(const FlowLaunch p) {
       // activate + split one register pair (values 2hp, 2hp+1 of a raw accumulator tile)
       // (the empty asm pins the computation HERE: without it LLVM sinks the whole tanh + split into the later
       //  block that first consumes the operand, un-interleaving it from this region's MFMAs)
-      auto act_split = [&](const f32x4& raw, int hp, int nt, unsigned (&pc)[NP]) {
+      // TRAIN: the activated pair (units 16 tile + 4 g + 2 hp + {0, 1} of hidden layer `layer`) also goes to the operand
+      // workspace (the activation-side operand of the next layer's weight gradient, and act' for the backward chain)
+      auto save_act = [&](float a0, float a1, bool r_form, int layer, int tile, int hp, int nt) {
+        if constexpr (TRAIN) {
+          if (!tr_ok) return;
+          if (r_form) { a0 = __builtin_fmaf(-2.0f, a0, 1.0f); a1 = __builtin_fmaf(-2.0f, a1, 1.0f); }   // tanh = 1 - 2 r
+          // rows ip + layer * hp + 16 tile + 4 g + 2 hp + {0, 1} of this net's region; [tile of 16 samples][row][16]
+          float* q = tr_acts + net * tr_net_stride + (tr_ip + layer * tr_hp) * tr_np + tr_h_off + nt * tr_hp16 + (16 * tile + 2 * hp) * 16;
+          q[0] = a0;
+          q[16] = a1;
+        } else {
+          (void)a0; (void)a1; (void)r_form; (void)layer; (void)tile; (void)hp; (void)nt;
+        }
+      };
+      auto act_split = [&](const f32x4& raw, int hp, int nt, unsigned (&pc)[NP], int layer = 0, int tile = 0) {
 #if defined(GBNF_ABLATE_ACT)      // diagnostic: no activation, no split (results wrong, timing only)
 #pragma unroll
         for (int k = 0; k < NP; ++k) pc[k] = __builtin_bit_cast(unsigned, raw[(2 * hp + k) & 3]);
@@ -625,9 +663,13 @@ flow_kernel_hx3(const FlowLaunch p) {
           // the two "+ 1" of the pair as one v_pk_add_f32
           f32x2 e = {__builtin_amdgcn_exp2f(raw[2 * hp]), __builtin_amdgcn_exp2f(raw[2 * hp + 1])};
           e = e + f32x2{1.0f, 1.0f};
-          split_pair<NP>(__builtin_amdgcn_rcpf(e[0]), __builtin_amdgcn_rcpf(e[1]), pc);
+          const float a0 = __builtin_amdgcn_rcpf(e[0]), a1 = __builtin_amdgcn_rcpf(e[1]);
+          save_act(a0, a1, true, layer, tile, hp, nt);
+          split_pair<NP>(a0, a1, pc);
         } else {
-          split_pair<NP>(act1(raw[2 * hp], nt), act1(raw[2 * hp + 1], nt), pc);
+          const float a0 = act1(raw[2 * hp], nt), a1 = act1(raw[2 * hp + 1], nt);
+          save_act(a0, a1, ACT == 3 && !relu_rt, layer, tile, hp, nt);
+          split_pair<NP>(a0, a1, pc);
         }
 #endif
 #pragma unroll
@@ -668,7 +710,7 @@ flow_kernel_hx3(const FlowLaunch p) {
 #pragma unroll
             for (int hp = 0; hp < 2; ++hp) {
               unsigned pc[NP];
-              act_split(raw[nt], hp, nt, pc);
+              act_split(raw[nt], hp, nt, pc, 0, t);
 #pragma unroll
               for (int k = 0; k < NP; ++k) hB[c][nt][k][2 * hf + hp] = pc[k];
             }
@@ -866,7 +908,7 @@ flow_kernel_hx3(const FlowLaunch p) {
                 for (int q = n; q < 2 * NT; q += HC) {
                   const int nt = q >> 1, hp = q & 1;
                   unsigned pc[NP];
-                  act_split(pre[nt], hp, nt, pc);
+                  act_split(pre[nt], hp, nt, pc, DEPTH, u - 1);
 #pragma unroll
                   for (int k = 0; k < NP; ++k) hO[nt][k][(PREV == 2 ? 2 : 0) + hp] = pc[k];
                 }
@@ -927,7 +969,7 @@ flow_kernel_hx3(const FlowLaunch p) {
 #pragma unroll
             for (int hp = 0; hp < 2; ++hp) {
               unsigned pc[NP];
-              act_split(pre[nt], hp, nt, pc);
+              act_split(pre[nt], hp, nt, pc, DEPTH, HT - 1);
 #pragma unroll
               for (int k = 0; k < NP; ++k) hO[nt][k][(odd_last ? 2 : 0) + hp] = pc[k];
             }
@@ -948,6 +990,16 @@ flow_kernel_hx3(const FlowLaunch p) {
           stage_finish(4, false);
         }
         st.mark(4);
+        if constexpr (TRAIN) if (tr_ok) {     // the net's output rows (the backward needs shift / scale)
+          float* q0 = tr_acts + net * tr_net_stride + (tr_ip + 4 * tr_hp + p.tr_op) * tr_np + tr_o_off;    // behind the gradient-side rows
+#pragma unroll
+          for (int o = 0; o < OT; ++o)
+            if (16 * o < p.tr_op)
+#pragma unroll
+              for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) q0[nt * tr_op16 + (16 * o + r) * 16] = outF[o][nt][r];
+        }
       }
       if constexpr (WATCH) {
 #pragma unroll
@@ -979,6 +1031,9 @@ flow_kernel_hx3(const FlowLaunch p) {
             sigmoid_logsigmoid(raw + 2.0f, sc, lsc);
             if (!inv) {
               t = norm_fn<KIND>(v[nt][e], tout.p0[e], tout.p1[e], tout.p2[e], tout.p3[e]);
+              if constexpr (TRAIN) {
+                if (live && tr_ok) tr_trace[tout.slot[e] * tr_np + tr_row + 16 * nt] = t;
+              }
               t = (t + shift) * sc;
             } else {                                                   // FlowStep.decode, models/glow.py:352-355
               t = v[nt][e] / sc - shift;
@@ -1003,6 +1058,9 @@ flow_kernel_hx3(const FlowLaunch p) {
 #pragma unroll
           for (int nt = 0; nt < NT; ++nt) {
             float t = inv ? v[nt][e] : norm_fn<KIND>(v[nt][e], tout.p0[e], tout.p1[e], tout.p2[e], tout.p3[e]);
+            if constexpr (TRAIN) {
+              if (live && tr_ok) tr_trace[tout.slot[e] * tr_np + tr_row + 16 * nt] = t;
+            }
             if constexpr (KIND == GBNF_KIND_GLOW) {
               t = inv ? t - outA[o][nt][r] : t + outA[o][nt][r];      // additive, models/glow.py:328-329 / 349-350
               if (inv) t = invnorm_fn<KIND>(t, tout.p0[e], tout.p1[e], tout.p2[e], tout.p3[e]);
@@ -1111,14 +1169,15 @@ inline size_t flow_hx3_lds_bytes(int n_steps, int nt, int waves, int stage_frags
   return (tables + 2 * (size_t)bias_frags * 256 + (size_t)ring * stage_frags * 256 + (size_t)waves * (d + 1) * (16 * nt + 1)) * 4;
 }
 // hx3 variants are keyed like the f32 ones with the lmid-independent fields fixed:
-//   VariantKey{kind, ht, /*ksl*/ -3 (f16x3) | -6 (bf16x6), /*ks1*/ 0, ot, nt, /*lmid*/ depth (0, 1, 2), act_a, act_b}
+//   VariantKey{kind, ht, /*ksl*/ -3 (f16x3) | -6 (bf16x6), /*ks1*/ 0 (evaluation) | 1 (training forward), ot, nt, /*lmid*/ depth (0, 1, 2), act_a, act_b}
 // The launcher sizes its own grid (it knows its waves per workgroup) and ring; the `grid` argument is ignored.
 // An 8-wave kernel whose register budget is 256 also exists as a 4-wave workgroup: when two of those fit a CU's LDS
 // (small d / K / hidden width) they run instead, staggered by about half a flow step (FlowLaunch::stagger).
-template <int KIND, int HT, int OT, int ENT, int ACTA, int ACTB, int PREC, int WV, int DEPTH>
+template <int KIND, int HT, int OT, int ENT, int ACTA, int ACTB, int PREC, int WV, int DEPTH, int TRAIN = 0>
 static hipError_t hx3_launch_wv(FlowLaunch p, bool staggered, hipStream_t s) {
   constexpr Hx3Layout L(HT, OT, hx3_pieces(PREC), DEPTH);
   p.n_tiles = (int32_t)((p.n + 16 * ENT - 1) / (16 * ENT));
+  if (TRAIN) p.n_tiles = (int32_t)(p.np / (16 * ENT));      /* every padded row: the operand workspace is summed over all np samples */
   /* per-step tables in LDS when they fit beside the staging slots and the Z tiles, else read from the blob */
   const size_t budget = staggered ? 80 * 1024 : 160 * 1024;
   p.lds_tables = p.n_steps <= LDS_TABLE_STEPS &&
@@ -1138,18 +1197,19 @@ static hipError_t hx3_launch_wv(FlowLaunch p, bool staggered, hipStream_t s) {
   }
   static bool attr_set = false;
   if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute((const void*)flow_kernel_hx3<KIND, HT, OT, ENT, ACTA, ACTB, PREC, WV, DEPTH>,
+    hipError_t e = hipFuncSetAttribute((const void*)flow_kernel_hx3<KIND, HT, OT, ENT, ACTA, ACTB, PREC, WV, DEPTH, TRAIN>,
                                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e != hipSuccess) return e;
     attr_set = true;
   }
-  hipLaunchKernelGGL((flow_kernel_hx3<KIND, HT, OT, ENT, ACTA, ACTB, PREC, WV, DEPTH>), dim3((unsigned)grid), dim3(64 * WV), lds, s, p);
+  hipLaunchKernelGGL((flow_kernel_hx3<KIND, HT, OT, ENT, ACTA, ACTB, PREC, WV, DEPTH, TRAIN>), dim3((unsigned)grid), dim3(64 * WV), lds, s, p);
   return hipGetLastError();
 }
 
-#define GBNF_INSTANTIATE_HX3(KIND, HT, OT, NT, ACTA, ACTB, PREC, DEPTH)                                     \
+// TRAIN = 1: the training path's forward sweep (trace + operand saves; registry key field ks1 = 1)
+#define GBNF_INSTANTIATE_HX3_T(KIND, HT, OT, NT, ACTA, ACTB, PREC, DEPTH, TRAIN)                            \
   namespace gbnf {                                                                                          \
-  static hipError_t launch_hx3_##KIND##_##HT##_##OT##_##NT##_##ACTA##_##ACTB##_##PREC##_##DEPTH(const FlowLaunch& p0, \
+  static hipError_t launch_hx3_##KIND##_##HT##_##OT##_##NT##_##ACTA##_##ACTB##_##PREC##_##DEPTH##_##TRAIN(const FlowLaunch& p0, \
                                                                                      unsigned, hipStream_t s) { \
     constexpr Hx3Layout L(HT, OT, hx3_pieces(PREC), DEPTH);                                                 \
     constexpr int ENT = hx3_eff_nt(HT, OT, NT, PREC, KIND, ACTA, ACTB, DEPTH);                              \
@@ -1162,16 +1222,18 @@ static hipError_t hx3_launch_wv(FlowLaunch p, bool staggered, hipStream_t s) {
       const long long waves_total = (long long)((p0.n + 16 * ENT - 1) / (16 * ENT)) * p0.n_comp * p0.n_batches; \
       /* from one 4-wave workgroup per CU on (1024 waves): a lone wave per SIMD runs a stage in half the time of two    \
          sharing it (profiles/r2_ubench_pingpong.txt), so 256 such workgroups beat 128 8-wave ones on half the CUs */  \
-      if (fits4 && !p0.repair && (pairs > 0 || (pairs < 0 && waves_total >= 1024)))                         \
-        return hx3_launch_wv<KIND, HT, OT, ENT, ACTA, ACTB, PREC, 4, DEPTH>(p0, true, s);                   \
+      /* (the training sweep's forward: measured 10 us of 105 faster at 64..256 waves too) */                \
+      if (fits4 && !p0.repair && (pairs > 0 || (pairs < 0 && (waves_total >= 1024 || TRAIN))))              \
+        return hx3_launch_wv<KIND, HT, OT, ENT, ACTA, ACTB, PREC, 4, DEPTH, TRAIN>(p0, true, s);            \
     }                                                                                                       \
-    return hx3_launch_wv<KIND, HT, OT, ENT, ACTA, ACTB, PREC, WAVES, DEPTH>(p0, false, s);                  \
+    return hx3_launch_wv<KIND, HT, OT, ENT, ACTA, ACTB, PREC, WAVES, DEPTH, TRAIN>(p0, false, s);           \
   }                                                                                                         \
-  static const int reg_hx3_##KIND##_##HT##_##OT##_##NT##_##ACTA##_##ACTB##_##PREC##_##DEPTH =               \
-      (register_variant(VariantKey{KIND, HT, (PREC) == 0 ? -3 : -6, 0, OT, NT, DEPTH, ACTA, ACTB},          \
-                        launch_hx3_##KIND##_##HT##_##OT##_##NT##_##ACTA##_##ACTB##_##PREC##_##DEPTH,        \
-                        "flow_kernel_hx3<" #KIND "," #HT "," #OT "," #NT "," #ACTA "," #ACTB "," #PREC "," #DEPTH ">"),\
+  static const int reg_hx3_##KIND##_##HT##_##OT##_##NT##_##ACTA##_##ACTB##_##PREC##_##DEPTH##_##TRAIN =     \
+      (register_variant(VariantKey{KIND, HT, (PREC) == 0 ? -3 : -6, TRAIN, OT, NT, DEPTH, ACTA, ACTB},      \
+                        launch_hx3_##KIND##_##HT##_##OT##_##NT##_##ACTA##_##ACTB##_##PREC##_##DEPTH##_##TRAIN, \
+                        "flow_kernel_hx3<" #KIND "," #HT "," #OT "," #NT "," #ACTA "," #ACTB "," #PREC "," #DEPTH "," #TRAIN ">"),\
        0);                                                                                                  \
   }
+#define GBNF_INSTANTIATE_HX3(KIND, HT, OT, NT, ACTA, ACTB, PREC, DEPTH) GBNF_INSTANTIATE_HX3_T(KIND, HT, OT, NT, ACTA, ACTB, PREC, DEPTH, 0)
 
 }  // namespace gbnf

@@ -1,5 +1,7 @@
 // gbnf_internal.h -- shared between the translation units of libgbnf_hip.so (not part of the C ABI).
 #pragma once
+#include <cstdint>
+#include "../../include/gbnf.h"
 
 namespace gbnf {
 
@@ -14,5 +16,28 @@ unsigned* saturation_counter();
 // Kernel-variant key only (not a descriptor value): the activation differs between the steps / nets of a component
 // (`--coupling_network random` in the reference); the kernel reads it per step and net from the step header.
 constexpr int GBNF_ACT_PER_STEP = 3;
+
+// ---- the training path's forward sweep on the evaluation kernels (gbnf_api.hip; used by gbnf_train.hip) -------------
+// A "live blob": the packed hx3 (f16x3) parameter blob of ONE component whose parameters live in device tensors that an
+// optimiser updates in place.  `live_blob_create` packs everything that does not depend on parameter VALUES once on the
+// host (slot maps, activation flags, layout) and records where every value-dependent word comes from;
+// `live_blob_forward` re-derives those words on the device (one gather + split kernel, ~10 us) and launches the TRAIN
+// instantiation of flow_kernel_hx3: x -> z, ldj + the trace and operand saves the backward pass needs.
+struct LiveBlob;
+// desc: a component descriptor whose parameter pointers are DEVICE pointers (perm_indices: host).  GBNF_ERR_UNSUPPORTED
+// (and *out = nullptr) when no TRAIN kernel variant covers the geometry: the caller keeps its own forward kernel.
+// norm_grad_offsets: [K][2] float offsets of every step's two normalisation-parameter gradients in the caller's flat gradient
+// buffer (null: no backward sweep wanted)
+int live_blob_create(const gbnf_flow_desc* desc, const int64_t* norm_grad_offsets, LiveBlob** out);
+bool live_blob_has_backward(const LiveBlob* lb);
+int live_blob_hidden_rows(const LiveBlob* lb);      // 16 x the hidden tiles of the kernel variant behind it
+int live_blob_backward(LiveBlob* lb, int64_t n, const float* trace, float* acts, int64_t np, int ip, int hp, int op,
+                       const float* g_z, const float* g_ldj, float* g_x, float* grads, const unsigned* gmax, void* stream);
+void live_blob_destroy(LiveBlob* lb);
+// trace: [K][d][np] normalised states (slot layout); acts: the operand workspace (FlowLaunch::acts_out); np: padded rows
+int live_blob_forward(LiveBlob* lb, const float* x, int64_t n, float* z, float* ldj, float* trace, float* acts, int64_t np,
+                      int ip, int hp, int op, void* stream);
+// (tests) the blob as the device packer left it / size in words
+int live_blob_words(const LiveBlob* lb, uint32_t* out_host, int64_t* n_words);
 
 }  // namespace gbnf

@@ -430,8 +430,17 @@ __global__ void __launch_bounds__(256) gmax_kernel(const float* __restrict__ g_z
                                                    unsigned* __restrict__ out) {
   unsigned m = 0u;
   const int64_t stride = (int64_t)gridDim.x * 256, t0 = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  if (g_z != nullptr)
-    for (int64_t e = t0; e < n * d; e += stride) m = max(m, __builtin_bit_cast(unsigned, g_z[e]) & 0x7fffffffu);
+  if (g_z != nullptr) {
+    const int64_t total = n * d;
+    const int64_t n4 = (reinterpret_cast<uintptr_t>(g_z) & 15u) == 0 ? total / 4 : 0;      // 16-byte loads where the buffer allows
+    const u32x4* g4 = reinterpret_cast<const u32x4*>(g_z);
+#pragma unroll 4
+    for (int64_t e = t0; e < n4; e += stride) {
+      const u32x4 v = g4[e];
+      m = max(max(m, v[0] & 0x7fffffffu), max(max(v[1] & 0x7fffffffu, v[2] & 0x7fffffffu), v[3] & 0x7fffffffu));
+    }
+    for (int64_t e = 4 * n4 + t0; e < total; e += stride) m = max(m, __builtin_bit_cast(unsigned, g_z[e]) & 0x7fffffffu);
+  }
   if (g_ldj != nullptr)
     for (int64_t e = t0; e < n; e += stride) m = max(m, __builtin_bit_cast(unsigned, g_ldj[e]) & 0x7fffffffu);
 #pragma unroll
@@ -1250,7 +1259,14 @@ struct gbnf_trainer {
   int batch_stats = 0;                 // BatchNorm on batch statistics (the reference's train() mode)
   std::vector<int> has_norm;           // per step
   std::vector<char> stats_bound;       // per step: bmean / bvar bound by the caller
+  LiveBlob* live = nullptr;            // round 3: the forward sweep on flow_kernel_hx3<TRAIN> (depth-1 TanhNet / ReLUNet), else null
 };
+
+// tuning / test knob: GBNF_TRAIN_PATH=old keeps the round-1 kernels for every call
+static bool tr_fast_path_enabled() {
+  static const bool on = [] { const char* e = getenv("GBNF_TRAIN_PATH"); return !(e && !strcmp(e, "old")); }();
+  return on;
+}
 
 static int ceil16(int v) { return (v + 15) / 16 * 16; }
 static int64_t tr_padded(int64_t n) { return (n + 16 * TR_MAX_NT - 1) / (16 * TR_MAX_NT) * (16 * TR_MAX_NT); }   // np: whole workgroups for every NT
@@ -1311,7 +1327,9 @@ int gbnf_trainer_create(const gbnf_flow_desc* desc, gbnf_trainer** out) {
   t->hp = ceil16(h);
   t->ip = ceil16(d2);
   t->op = ceil16(glow && !additive ? 2 * d2 : d2);
-  t->net_rows = (int64_t)t->ip + 2LL * t->n_hidden * t->hp + t->op;
+  // operand rows per (step, net): net input | hidden activations | hidden gradients | output gradient | (round 3) the net's
+  // output as the forward sweep saved it for the backward sweep
+  t->net_rows = (int64_t)t->ip + 2LL * t->n_hidden * t->hp + 2LL * t->op;
   t->hw = (h + 31) / 32 * 32; t->xw = (d2 + 31) / 32 * 32; t->ow = ((glow && !additive ? 2 * d2 : d2) + 31) / 32 * 32;
   if (t->hp > TR_MAX_HIDDEN) {
     delete t;
@@ -1464,6 +1482,20 @@ int gbnf_trainer_create(const gbnf_flow_desc* desc, gbnf_trainer** out) {
     gbnf_trainer_destroy(t);
     return fail(GBNF_ERR_HIP, "gbnf_trainer_create: %s", hipGetErrorString(e));
   }
+  // the register-chained forward sweep where a TRAIN variant of the evaluation kernel covers the geometry (else the
+  // kernels of this file do the forward too)
+  if (!residual && nl == 3 && tr_fast_path_enabled()) {
+    LiveBlob* lb = nullptr;
+    std::vector<int64_t> goff(2 * (size_t)K);
+    for (int k = 0; k < K; ++k) { goff[2 * k] = steps[k].g_na; goff[2 * k + 1] = steps[k].g_nb; }
+    // (32-bit offsets inside one step's operand region: net_rows * np must stay below 2^31 -- checked per call)
+    // (the kernels save one row per hidden unit of their COMPILED width: a variant wider than this flow's padded width -- the
+    //  nearest compiled one for an unlisted geometry -- would write past the rows the workspace has; such flows keep the old path)
+    if (live_blob_create(desc, goff.data(), &lb) == GBNF_OK) {
+      if (live_blob_hidden_rows(lb) == t->hp) t->live = lb;
+      else live_blob_destroy(lb);
+    }
+  }
   *out = t;
   return GBNF_OK;
 }
@@ -1476,6 +1508,7 @@ int gbnf_trainer_destroy(gbnf_trainer* t) {
   if (t->prep_dev) (void)hipFree(t->prep_dev);
   if (t->frag_dev) (void)hipFree(t->frag_dev);
   if (t->gmax_dev) (void)hipFree(t->gmax_dev);
+  live_blob_destroy(t->live);
   delete t;
   return GBNF_OK;
 }
@@ -1550,6 +1583,8 @@ int gbnf_trainer_bind_batch_stats(gbnf_trainer* t, int32_t step, float* mean_dev
 int gbnf_trainer_trace_floats(const gbnf_trainer* t, int64_t n, int64_t* n_floats) {
   if (!t || !n_floats || n < 0) return fail(GBNF_ERR_INVALID, "gbnf_trainer_trace_floats: bad argument");
   *n_floats = ((int64_t)t->K + 1) * t->d * tr_padded(n);     // K normalised states + the running state
+  if (t->live)       // + the operand workspace the forward sweep fills (and the slack rows wgrad_kernel may read behind it)
+    *n_floats += ((int64_t)t->K * t->nnets * t->net_rows + TR_WS_SLACK_ROWS) * tr_padded(n);
   return GBNF_OK;
 }
 
@@ -1564,6 +1599,20 @@ int gbnf_trainer_forward(const gbnf_trainer* t, const float* x, int64_t n, float
   p.z_out = z; p.ldj_out = ldj; p.trace_out = trace;
   p.batch_stats = t->batch_stats;
   hipStream_t s = (hipStream_t)stream;
+  if (t->live != nullptr && trace != nullptr && !needs_step_launches(t) && (int64_t)t->nnets * t->net_rows * p.np < (1LL << 31)) {
+    // round 3: the forward sweep on the evaluation kernel (register-chained, weights staged once per workgroup): re-pack
+    // the live parameters on the device, then x -> z, ldj + trace + the activation-side operands of the weight gradients
+    float* acts = trace + ((int64_t)t->K + 1) * t->d * p.np;
+    const int rc = live_blob_forward(t->live, x, n, z, ldj, trace, acts, p.np, t->ip, t->hp, t->op, stream);
+    if (rc) return rc;
+    // without a matching backward variant the backward kernels of this file run, on prep_kernel's fragments (valid while
+    // the parameters are what they are now: the trace contract)
+    if (!live_blob_has_backward(t->live))
+      hipLaunchKernelGGL(prep_kernel, dim3((unsigned)t->prep_blocks), dim3(64), 0, s, (const PrepProblem*)t->prep_dev, t->n_prep, t->frag_dev);
+    const hipError_t e2 = hipGetLastError();
+    if (e2 != hipSuccess) return fail(GBNF_ERR_HIP, "gbnf_trainer_forward launch: %s", hipGetErrorString(e2));
+    return GBNF_OK;
+  }
   // the parameters may have changed since the last call: split them into this call's MFMA fragments
   hipLaunchKernelGGL(prep_kernel, dim3((unsigned)t->prep_blocks), dim3(64), 0, s, (const PrepProblem*)t->prep_dev, t->n_prep, t->frag_dev);
   if (!needs_step_launches(t)) {
@@ -1617,6 +1666,22 @@ int gbnf_trainer_backward(const gbnf_trainer* t, const float* x, int64_t n, cons
     hipLaunchKernelGGL(gmax_kernel, dim3(gb ? gb : 1), dim3(256), 0, s, g_z, g_ldj, n, t->d, t->gmax_dev);
   }
   p.gmax = t->gmax_dev;
+  if (live_blob_has_backward(t->live) && trace != nullptr && !needs_step_launches(t) &&
+      (int64_t)t->nnets * t->net_rows * p.np < (1LL << 31)) {
+    // round 3: the register-chained backward sweep on what the forward sweep saved behind the trace, then the weight
+    // gradients from the operand workspace that now lives there too
+    float* acts = const_cast<float*>(trace) + ((int64_t)t->K + 1) * t->d * p.np;
+    const int rc = live_blob_backward(t->live, n, trace, acts, p.np, t->ip, t->hp, t->op, g_z, g_ldj, g_x, grads, t->gmax_dev, stream);
+    if (rc) return rc;
+    int chunk2 = 512;
+    while (chunk2 < 4096 && (int64_t)t->wg_blocks * (p.np / (2 * chunk2)) >= 768) chunk2 *= 2;
+    const dim3 wgrid2((unsigned)t->wg_blocks, (unsigned)((p.np + chunk2 - 1) / chunk2));
+    hipLaunchKernelGGL(wgrad_kernel, wgrid2, dim3(WG_THREADS), (size_t)2 * WG_ROWS_MAX * 8 * 16, s, t->probs_dev, t->n_probs,
+                       (const float*)acts, grads, p.np, chunk2, (const unsigned*)t->gmax_dev);
+    const hipError_t e2 = hipGetLastError();
+    if (e2 != hipSuccess) return fail(GBNF_ERR_HIP, "gbnf_trainer_backward launch: %s", hipGetErrorString(e2));
+    return GBNF_OK;
+  }
   // a trace is valid only while the parameters are what they were in the forward call that wrote it (include/gbnf.h):
   // that call split them into this trainer's fragment buffer, so the fragments are still the right ones
   if (trace == nullptr)
@@ -1656,6 +1721,13 @@ int gbnf_trainer_backward(const gbnf_trainer* t, const float* x, int64_t n, cons
   e = hipGetLastError();
   if (e != hipSuccess) return fail(GBNF_ERR_HIP, "gbnf_trainer_backward wgrad launch: %s", hipGetErrorString(e));
   return GBNF_OK;
+}
+
+// (tests) the live blob of a trainer after a device re-pack from the current parameter values
+int gbnf_debug_trainer_blob(const gbnf_trainer* t, uint32_t* out_host, int64_t* n_words) {
+  if (!t) return fail(GBNF_ERR_INVALID, "gbnf_debug_trainer_blob: trainer is null");
+  if (!t->live) return fail(GBNF_ERR_UNSUPPORTED, "gbnf_debug_trainer_blob: this trainer has no live blob");
+  return live_blob_words(t->live, out_host, n_words);
 }
 
 }  // extern "C"

@@ -1,0 +1,634 @@
+// gbnf_train_bwd.hip.h -- the backward sweep of the training path, register-chained (round 3).
+//
+// What loss.backward() of density_experiment.py:366-374 does to one component, given what the forward sweep
+// (flow_kernel_hx3<..., TRAIN = 1>) saved: every step's normalised state (trace), the coupling nets' inputs, hidden
+// activations and outputs (operand workspace).  Nothing is recomputed: per step, last to first,
+//
+//   coupling backward   g_z2 -> g_y2, g_shift, g_raw / g_scale   (element-wise, from the saved net outputs and the trace)
+//   dgrad chain         g_o -> W3^T -> (.) act'(h2) -> W2^T -> (.) act'(h1) -> W1^T -> g_y1      (split-f16 MFMA)
+//   normalisation bwd   g_y -> g_x, ActNorm / BatchNorm parameter gradients (16-sample sums + atomics)
+//
+// and the gradient-side operands of every weight gradient (g_o, g_a2, g_a1) go to the operand workspace for wgrad_kernel.
+// The chain has the shape of the forward chain -- a layer with K0 = ceil(OT / 2) input chunks, one with HC chunks, an output
+// layer of two tiles -- and is written like it (gbnf_flow_kernel_hx3.hip.h): a wave owns its 16 samples through all three
+// layers (D layout = B layout: the accumulator tile of one layer, times act' and split, IS the next layer's B operand),
+// the transposed weights are staged once per workgroup by LDS DMA, one stage ahead, in consumption order.
+// Reference semantics: FlowStep.encode models/glow.py:317-342, RealNVP.forward models/transformations.py:560-579,
+// _ActNorm models/layers.py:488-533, BatchNorm (running statistics) models/layers.py:337-358, TanhNet / ReLUNet :208-243.
+#pragma once
+
+#include "gbnf_flow_kernel_hx3.hip.h"
+
+#ifndef GBNF_BWD_ABLATE
+#define GBNF_BWD_ABLATE 0          // diagnostic builds (tools/build_bwd_ablations.sh, timing only): 1 no parameter sums, 2 no operand stores, 4 no activation loads
+#endif
+
+namespace gbnf {
+
+// Packed layout of one coupling net's TRANSPOSED weights (f16x3: NP = 2 fragments per tile), in consumption order:
+//   L0' stages : W3^T tile rows t (hidden tile t = 16 output units of this layer), K0 tiles (k-chunks of 32 net outputs) each,
+//                ROWS0 tile rows per stage
+//   PASS u     : W2^T row u, chunks c = 0..HC-1; then, if u is even and u >= 2, the W1^T chunk (u-2)/2: IT = 2 tiles
+//   DRAIN      : W1^T chunk HC-1
+struct BwdLayout {
+  static constexpr int MAXS = 80;
+  int HC, K0, ROWS0, N_L0, NS, NET_WORDS, STAGE_FRAGS;
+  int off[MAXS], nf[MAXS];
+  constexpr BwdLayout(int HT, int OT)
+      : HC((HT + 1) / 2), K0((OT + 1) / 2), ROWS0(1), N_L0(0), NS(0), NET_WORDS(0), STAGE_FRAGS(0), off{}, nf{} {
+    ROWS0 = (HC + 2) / K0 > 0 ? (HC + 2) / K0 : 1;
+    N_L0 = (HT + ROWS0 - 1) / ROWS0;
+    int s = 0, w = 0;
+    for (int i = 0; i < N_L0; ++i) {
+      const int cnt = (HT - i * ROWS0 < ROWS0) ? HT - i * ROWS0 : ROWS0;
+      off[s] = w; nf[s] = 2 * cnt * K0; w += nf[s] * 256; ++s;
+    }
+    for (int u = 0; u < HT; ++u) {
+      off[s] = w; nf[s] = 2 * HC + ((u % 2 == 0 && u >= 2) ? 2 * 2 : 0); w += nf[s] * 256; ++s;
+    }
+    off[s] = w; nf[s] = 2 * 2; w += nf[s] * 256; ++s;
+    NS = s;
+    NET_WORDS = w;
+    for (int k = 0; k < s; ++k) STAGE_FRAGS = nf[k] > STAGE_FRAGS ? nf[k] : STAGE_FRAGS;
+  }
+};
+template <int HT, int OT>
+struct BwdLayoutOf {
+  static constexpr BwdLayout value = BwdLayout(HT, OT);
+};
+
+// the device side of tr_grad_scale (gbnf_train.hip): alpha = the power of two that puts the largest upstream entry at [4, 8)
+__device__ __forceinline__ void bwd_grad_scale(unsigned max_bits, float& alpha, float& inv_alpha) {
+  const int e = (int)((max_bits >> 23) & 255u);
+  if (max_bits == 0u || e == 255) { alpha = 1.0f; inv_alpha = 1.0f; return; }
+  int k = 2 - (e - 127);
+  k = k > 100 ? 100 : (k < -100 ? -100 : k);
+  alpha = __builtin_bit_cast(float, (unsigned)(k + 127) << 23);
+  inv_alpha = __builtin_bit_cast(float, (unsigned)(127 - k) << 23);
+}
+
+// sum over the 16 lanes of a lane group (the wave's 16 samples): a lane group is one DPP row, so four rotate-and-add steps on
+// the VALU leave the sum in every lane (__shfl_xor compiles to ds_bpermute: 128 LDS round trips per step, a third of the kernel)
+__device__ __forceinline__ float bwd_sum16(float v) {
+  auto ror = [](float a, auto n_c) {
+    constexpr int CTRL = 0x120 + decltype(n_c)::value;      // row_ror:n
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, a), CTRL, 0xf, 0xf, false));
+  };
+  v += ror(v, std::integral_constant<int, 8>{});
+  v += ror(v, std::integral_constant<int, 4>{});
+  v += ror(v, std::integral_constant<int, 2>{});
+  v += ror(v, std::integral_constant<int, 1>{});
+  return v;
+}
+
+template <int KIND, int HT, int OT, int ACTA, int ACTB, int WV>
+__global__ void __launch_bounds__(64 * WV, WV == 8 ? 2 : 1) bwd_kernel_hx3(const FlowLaunch p) {
+  constexpr int WAVES = WV, NP = 2, NT = 1, ZS = 17, IT = 2;
+  constexpr int NNETS = (KIND == GBNF_KIND_REALNVP) ? 2 : 1;
+  using FL = Hx3LayoutOf<HT, OT, NP, 1>;                 // the forward blob: only its per-step tables are read here
+  using BL = BwdLayoutOf<HT, OT>;
+  constexpr int HC = BL::value.HC, K0 = BL::value.K0, ROWS0 = BL::value.ROWS0;
+  constexpr int STEP_WORDS_F = SMALL_WORDS + NNETS * FL::value.NET_WORDS;
+  constexpr int STEP_WORDS_B = NNETS * BL::value.NET_WORDS;
+  constexpr int STAGE_WORDS = BL::value.STAGE_FRAGS * 256;
+  using Acc = AccT<1>;
+
+  extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const int i = lane & 15, g = lane >> 4;
+  const int d = p.d, K = p.n_steps;
+  const uint32_t* __restrict__ blobF = p.blobs[0];
+  const uint32_t* __restrict__ blobB = p.blobs_bwd[0];
+  // rows >= n are padding: their upstream gradients are zero.  The last workgroup's spare waves own no rows: they shadow the
+  // last tile (same loads, same values stored twice: the vector-memory count per stage is the same for every wave) and only
+  // leave out the atomic parameter-gradient sums.
+  const int64_t row0_raw = ((int64_t)blockIdx.x * WAVES + wave) * 16;
+  const bool wave_ok = row0_raw < p.np;
+  const int64_t row0 = wave_ok ? row0_raw : p.np - 16;
+  const int np = (int)p.np;
+  const int row = (int)row0 + i;
+
+  float alpha = 1.0f, inv_alpha = 1.0f;
+  if (p.gmax != nullptr) bwd_grad_scale(__builtin_amdgcn_readfirstlane(*p.gmax), alpha, inv_alpha);
+
+  // ---- LDS: per-step tables (of the forward blob) | 2 stage slots | G tiles | scatter scratch
+  uint32_t* SM = lds;
+  uint32_t* STG = lds + K * SMALL_WORDS;
+  float* G = reinterpret_cast<float*>(STG + 2 * STAGE_WORDS) + wave * ((d + 1) * ZS);     // gradient state, slot layout (+ a spare slot)
+  float* SC = reinterpret_cast<float*>(STG + 2 * STAGE_WORDS) + WAVES * ((d + 1) * ZS) + wave * (32 * ZS);
+  // every wave's 16-sample sums of the ActNorm / BatchNorm parameter gradients: [wave][step][2][64].  (Atomic adds into the
+  // gradient buffer -- 4096 waves x 86 parameters x K steps on 430 addresses -- took 80 % of this kernel's time.)
+  float* PG = reinterpret_cast<float*>(STG + 2 * STAGE_WORDS) + WAVES * ((d + 1) * ZS) + WAVES * (32 * ZS);
+  for (int e = (int)threadIdx.x; e < WAVES * K * 128; e += 64 * WAVES) PG[e] = 0.0f;
+
+  // ---- weight staging (as in flow_kernel_hx3): the transposed blob is in consumption order, steps last to first
+  using gwords = const __attribute__((address_space(1))) uint32_t*;
+  using lptr = __attribute__((address_space(3))) void*;
+  gwords next_src = (gwords)blobB + (size_t)(K - 1) * STEP_WORDS_B;
+  int gs = 0;
+  const unsigned lane_b16 = (unsigned)lane * 16u;
+  auto dma = [&](gwords src, uint32_t* dst) {
+    const __attribute__((address_space(1))) char* base = reinterpret_cast<const __attribute__((address_space(1))) char*>(src);
+    __builtin_amdgcn_global_load_lds(base + lane_b16, (lptr)dst, 16, 0, 0);
+  };
+  auto issue = [&](auto nf_c, int into) {
+    constexpr int NF = decltype(nf_c)::value;
+    uint32_t* dst = STG + (into & 1) * STAGE_WORDS;
+#pragma unroll
+    for (int k = 0; k * WAVES < NF; ++k) {
+      const int f = wave + k * WAVES;
+      if ((k + 1) * WAVES <= NF || f < NF) dma(next_src + f * 256, dst + f * 256);
+    }
+    next_src += NF * 256;
+  };
+  issue(std::integral_constant<int, BL::value.nf[0]>{}, 0);
+  for (int s = 0; s < K; ++s) {
+    const uint32_t* src = blobF + (size_t)s * STEP_WORDS_F;
+    for (int w = (int)threadIdx.x * 4; w < SMALL_WORDS; w += 64 * WAVES * 4)
+      *reinterpret_cast<i32x4*>(SM + s * SMALL_WORDS + w) = *reinterpret_cast<const i32x4*>(src + w);
+  }
+  // ---- upstream gradients -> G (through the final slot map), scaled
+  {
+    const uint32_t* tail = blobF + (size_t)K * STEP_WORDS_F;
+    if (lane < d) {
+      const int slot = (int)tail[lane];
+      float gv[16];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int64_t n = row0 + r;
+        gv[r] = (p.g_z != nullptr && n < p.n) ? p.g_z[n * d + lane] * alpha : 0.0f;
+      }
+#pragma unroll
+      for (int r = 0; r < 16; ++r) G[slot * ZS + r] = gv[r];
+    }
+  }
+  const float gl = (p.g_ldj != nullptr && row0 + i < p.n) ? p.g_ldj[row0 + i] * alpha : 0.0f;
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+
+  bool sat = false;
+  const uint32_t* buf = STG;
+  // `later`: vector-memory operations this wave has issued BEHIND the stage's staging DMA (operand stores, activation
+  // prefetches): they may stay in flight across the barrier -- waiting for all of them (vmcnt(0)) makes every stage as long as
+  // a store's round trip to HBM.  (vmcnt counts in issue order; an underestimate is safe.)
+  auto stage_end = [&](auto later_c) {
+    constexpr int LATER = decltype(later_c)::value;
+    asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(LATER) : "memory");
+    ++gs;
+  };
+  auto frag = [&](int f) -> u32x4 { return *reinterpret_cast<const u32x4*>(buf + f * 256 + lane * 4); };
+  struct Unit { u32x4 w[NP]; };
+  auto load_unit = [&](Unit& a, int n) {
+#pragma unroll
+    for (int q = 0; q < NP; ++q) a.w[q] = frag(n * NP + q);
+  };
+  Unit N0, N1;
+  auto preload = [&]() {
+    buf = STG + (gs & 1) * STAGE_WORDS;
+    load_unit(N0, 0);
+    load_unit(N1, 1);
+  };
+  // the padding hipcc omits on the taken side of a branch between a v_mfma and the first use of its result
+  // (gbnf_flow_kernel_hx3.hip.h, mfma_tail_guard; tools/isa_hazard_lint.py checks every path of this kernel too)
+  auto mfma_tail_guard = [&]() {
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_nop 7" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+  };
+  auto stage_finish = [&](bool early, auto later_c) {        // every stage ends in front of its last unit
+    if (!early) { mfma_tail_guard(); return; }
+    stage_end(later_c);
+    preload();
+  };
+  using V0 = std::integral_constant<int, 0>;
+  using V4 = std::integral_constant<int, GBNF_BWD_ABLATE & 2 ? 0 : 4>;
+  using V8 = std::integral_constant<int, GBNF_BWD_ABLATE & 2 ? 0 : 8>;
+  preload();
+  auto mac = [&](const Unit& a, const u32x4 (&x)[NP], Acc& acc) {
+#pragma unroll
+    for (int pr = 0; pr < 3; ++pr) {
+      acc.s[0] = mfma_narrow<0>(a.w[Products<2>::W[pr]], x[Products<2>::X[pr]], acc.s[0]);
+      MFMA_ORDER_FENCE();
+    }
+  };
+  auto split4 = [&](const f32x4& v, unsigned (&lo)[NP], unsigned (&hi)[NP]) {       // a tile's 4 values -> two register pairs of pieces
+    f32x4 c;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      sat = sat || !(__builtin_fabsf(v[r]) <= 65504.0f);
+      c[r] = __builtin_amdgcn_fmed3f(v[r], -65504.0f, 65504.0f);
+    }
+    split_pair<NP>(c[0], c[1], lo);
+    split_pair<NP>(c[2], c[3], hi);
+  };
+
+  const int tile0 = (int)(row0 >> 4);
+  const int hp16 = p.tr_hp * 16, op16 = p.tr_op * 16;
+  const int h_off = tile0 * hp16 + 4 * g * 16 + i;         // unit 16 t + 4 g + r of this lane's sample: + (16 t + r) * 16
+  const int o_off = tile0 * op16 + 4 * g * 16 + i;
+
+  for (int step = K - 1; step >= 0; --step) {
+    const uint32_t* smt = SM + step * SMALL_WORDS;
+    const float* trace = p.trace_in + (int64_t)step * d * p.np;
+    float* acts = p.acts_out + (int64_t)step * NNETS * p.net_rows * p.np;
+    const int32_t* ptab = p.bwd_tab + step * (2 * 4 * NENT);
+    const int64_t g_na = p.bwd_goff[2 * step], g_nb = p.bwd_goff[2 * step + 1];
+
+    // ---- (a) coupling backward: gradient of the net output(s) in the D layout, G[out slots] <- gradient w.r.t. the normalised y2
+    LaneTable tout;
+    tout.load(smt + SMALL_HDR + 160 + g * NENT);
+    f32x4 gA[OT], gBo[OT];                       // net 0 / net 1 output gradients (rows 16 o + 4 g + r)
+#pragma unroll
+    for (int o = 0; o < OT; ++o) { gA[o] = f32x4{0.f, 0.f, 0.f, 0.f}; gBo[o] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+    float y2v[NENT];
+    {
+      const float* oA = acts + (int64_t)(p.tr_ip + 4 * p.tr_hp + p.tr_op) * np + o_off;     // the forward sweep's saved net outputs
+      const float* oB = oA + (int64_t)p.net_rows * np;
+      if (KIND == GBNF_KIND_GLOW && !p.additive) {
+        constexpr int NE = (2 * OT < NENT) ? 2 * OT : NENT;
+        float sh[NE], rw[NE], g2[NE];
+#pragma unroll
+        for (int e = 0; e < NE; ++e) {
+          const int o = e >> 1, pp = e & 1;
+          const int sl = tout.slot[e] >= 0 ? tout.slot[e] : 0;
+          sh[e] = oA[(16 * o + 2 * pp) * 16];
+          rw[e] = oA[(16 * o + 2 * pp + 1) * 16];
+          y2v[e] = trace[sl * np + row];
+          g2[e] = G[sl * ZS + i];
+        }
+#pragma unroll
+        for (int e = 0; e < NE; ++e) {
+          const int o = e >> 1, pp = e & 1;
+          const bool live = tout.slot[e] >= 0;
+          const float ex = __expf(-(rw[e] + 2.0f));
+          const float sc = 1.0f / (1.0f + ex);
+          const float omsc = ex < 1e30f ? ex * sc : 1.0f;                   // 1 - scale
+          const float gy = g2[e] * sc;
+          gA[o][2 * pp] = live ? gy : 0.0f;                                  // d/d shift
+          gA[o][2 * pp + 1] = live ? (g2[e] * (y2v[e] + sh[e]) * sc + gl) * omsc : 0.0f;   // d/d raw: z2 = (y2 + shift) s, ld += log s
+          G[(live ? tout.slot[e] : d) * ZS + i] = gy;
+        }
+      } else {
+        constexpr int NE = (4 * OT < NENT) ? 4 * OT : NENT;
+        float sv[NE], g2[NE];
+#pragma unroll
+        for (int e = 0; e < NE; ++e) {
+          const int o = e >> 2, r = e & 3;
+          const int sl = tout.slot[e] >= 0 ? tout.slot[e] : 0;
+          sv[e] = (KIND == GBNF_KIND_REALNVP) ? oB[(16 * o + r) * 16] : 0.0f;     // the log-scale net's output
+          y2v[e] = trace[sl * np + row];
+          g2[e] = G[sl * ZS + i];
+        }
+#pragma unroll
+        for (int e = 0; e < NE; ++e) {
+          const int o = e >> 2, r = e & 3;
+          const bool live = tout.slot[e] >= 0;
+          if constexpr (KIND == GBNF_KIND_GLOW) {                            // additive: z2 = y2 + h
+            gA[o][r] = live ? g2[e] : 0.0f;
+            G[(live ? tout.slot[e] : d) * ZS + i] = g2[e];
+          } else {                                                           // z2 = shift + y2 e^scale, ld += scale
+            const float es = __expf(sv[e]);
+            gA[o][r] = live ? g2[e] : 0.0f;                                  // d/d shift
+            gBo[o][r] = live ? g2[e] * y2v[e] * es + gl : 0.0f;              // d/d scale
+            G[(live ? tout.slot[e] : d) * ZS + i] = g2[e] * es;
+          }
+        }
+      }
+    }
+
+    // ---- (b) the dgrad chain of every net; its output (rows k = 16 o + 4 g + r of d loss / d net input) is summed in SC
+#pragma unroll
+    for (int net = 0; net < NNETS; ++net) {
+      const f32x4 (&gOut)[OT] = (net == 0) ? gA : gBo;
+      const int ACT = (net == 0) ? ACTA : ACTB;
+      const bool relu_rt = ACT == 3 && __builtin_amdgcn_readfirstlane(smt[2 + net]) != 0;
+      float* an = acts + (int64_t)net * p.net_rows * np;
+      const float* h1p = an + (int64_t)p.tr_ip * np + h_off;                          // saved activations (forward sweep)
+      const float* h2p = an + (int64_t)(p.tr_ip + p.tr_hp) * np + h_off;
+      float* d1p = an + (int64_t)(p.tr_ip + 2 * p.tr_hp) * np + h_off;                // gradient-side operands for wgrad_kernel
+      float* d2p = an + (int64_t)(p.tr_ip + 3 * p.tr_hp) * np + h_off;
+      float* dop = an + (int64_t)(p.tr_ip + 4 * p.tr_hp) * np + o_off;
+      auto dact = [&](float gv, float hv) {       // gv * act'(pre-activation), through the saved activation hv
+        const float t = gv * __builtin_fmaf(-hv, hv, 1.0f), r = hv > 0.0f ? gv : 0.0f;
+        if (ACT == GBNF_ACT_TANH) return t;
+        if (ACT == GBNF_ACT_RELU) return r;
+        return relu_rt ? r : t;
+      };
+      // the chain's input: the output gradient, emitted and split two tiles per k-chunk
+      u32x4 gO[K0][NP];
+#pragma unroll
+      for (int c = 0; c < K0; ++c)
+#pragma unroll
+        for (int k = 0; k < NP; ++k) gO[c][k] = u32x4{0, 0, 0, 0};
+#pragma unroll
+      for (int o = 0; o < OT; ++o) {
+        if (16 * o < p.tr_op) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) dop[(16 * o + r) * 16] = gOut[o][r];
+        }
+        unsigned lo[NP], hi[NP];
+        split4(gOut[o], lo, hi);
+#pragma unroll
+        for (int k = 0; k < NP; ++k) { gO[o >> 1][k][2 * (o & 1)] = lo[k]; gO[o >> 1][k][2 * (o & 1) + 1] = hi[k]; }
+      }
+      // all of the second hidden layer's saved activations are requested up front (layer W3^T is short)
+      f32x4 h2v[HT];
+#pragma unroll
+      for (int t = 0; t < HT; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) h2v[t][r] = (GBNF_BWD_ABLATE & 4) ? 0.5f : h2p[(16 * t + r) * 16];
+
+      u32x4 gB[HC][NP];                           // g_a2 = (W3^T g_o) * act'(h2), split: the B operands of the W2^T layer
+#pragma unroll
+      for (int k = 0; k < NP; ++k) gB[HC - 1][k] = u32x4{0, 0, 0, 0};
+      {
+        f32x4 rawp = f32x4{0.f, 0.f, 0.f, 0.f};
+        auto finish_tile = [&](int t, const f32x4& raw) {
+          f32x4 ga;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) ga[r] = dact(raw[r], h2v[t][r]);
+          if (!(GBNF_BWD_ABLATE & 2)) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) d2p[(16 * t + r) * 16] = ga[r];
+          }
+          unsigned lo[NP], hi[NP];
+          split4(ga, lo, hi);
+#pragma unroll
+          for (int k = 0; k < NP; ++k) { gB[t >> 1][k][2 * (t & 1)] = lo[k]; gB[t >> 1][k][2 * (t & 1) + 1] = hi[k]; }
+        };
+        auto l0_stage = [&](auto sI_c) {
+          constexpr int sI = decltype(sI_c)::value;
+          issue(std::integral_constant<int, BL::value.nf[sI + 1]>{}, gs + 1);
+          constexpr int t0 = sI * ROWS0;
+          constexpr int cnt = (HT - t0 < ROWS0) ? HT - t0 : ROWS0;
+          constexpr int NU = cnt * K0;
+          Unit A[3];
+          A[0] = N0;
+          if (NU > 1) A[1] = N1;
+          Acc cur;
+#pragma unroll
+          for (int n = 0; n < NU; ++n) {
+            const int t = t0 + n / K0, c = n % K0;
+            if (n + 2 < NU) load_unit(A[(n + 2) % 3], n + 2);
+            if (n == NU - 1) stage_finish(true, V0{});
+            if (c == 0) cur.init(f32x4{0.f, 0.f, 0.f, 0.f});
+            mac(A[n % 3], gO[c], cur);
+            if (c == K0 - 1) {
+              if (t > 0) finish_tile(t - 1, rawp);
+              rawp = cur.total();
+            }
+            __builtin_amdgcn_sched_barrier(0);
+          }
+          stage_finish(false, V0{});
+        };
+        auto l0_all = [&](auto self, auto s_c) -> void {
+          constexpr int sI = decltype(s_c)::value;
+          if constexpr (sI < BL::value.N_L0) {
+            l0_stage(s_c);
+            self(self, std::integral_constant<int, sI + 1>{});
+          }
+        };
+        l0_all(l0_all, std::integral_constant<int, 0>{});
+        finish_tile(HT - 1, rawp);
+      }
+
+      // ---- W2^T: one output tile per stage; tile u-1 times act'(h1) is emitted / split during pass u and consumed, two
+      //      tiles per chunk, by the W1^T tiles (two output tiles: the net input's <= 32 rows)
+      Acc outG[IT];
+#pragma unroll
+      for (int o = 0; o < IT; ++o) outG[o].init(f32x4{0.f, 0.f, 0.f, 0.f});
+      u32x4 hO[NP];
+#pragma unroll
+      for (int k = 0; k < NP; ++k) hO[k] = u32x4{0, 0, 0, 0};
+      f32x4 pre = f32x4{0.f, 0.f, 0.f, 0.f};
+      auto load_h1 = [&](int t) {
+        f32x4 v;
+        const int tt = t < HT ? t : HT - 1;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = (GBNF_BWD_ABLATE & 4) ? 0.5f : h1p[(16 * tt + r) * 16];
+        return v;
+      };
+      f32x4 hE = load_h1(0), hOd = load_h1(1);       // saved activations of the even / odd tile that is finished next
+      auto finish_h1 = [&](int t, const f32x4& hv, int half) {        // tile t of g_a1 -> operand workspace + half `half` of hO
+        f32x4 ga;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) ga[r] = dact(pre[r], hv[r]);
+        if (!(GBNF_BWD_ABLATE & 2)) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) d1p[(16 * t + r) * 16] = ga[r];
+        }
+        unsigned lo[NP], hi[NP];
+        split4(ga, lo, hi);
+#pragma unroll
+        for (int k = 0; k < NP; ++k) { hO[k][2 * half] = lo[k]; hO[k][2 * half + 1] = hi[k]; }
+      };
+      // PREV: 0 = no previous tile (u = 0); 1 = tile u-1 is even (first half of its chunk); 2 = it is odd (second half):
+      // chunk (u-2)/2 is consumed at the end of this pass
+      auto pass = [&](int u, auto prev_c, auto last_c) {
+        constexpr int PREV = decltype(prev_c)::value;
+        constexpr bool LAST = decltype(last_c)::value;
+        constexpr int NU = HC + (PREV == 2 ? IT : 0);
+        constexpr int NF_NEXT = LAST ? NP * IT : (PREV == 1 ? NP * (HC + IT) : NP * HC);
+        issue(std::integral_constant<int, NF_NEXT>{}, gs + 1);
+        __builtin_amdgcn_sched_barrier(0);         // (the 4 stores + 4 loads below stay BEHIND the staging DMA: stage_end counts on it)
+        Unit A[3];
+        A[0] = N0;
+        A[1] = N1;
+        Acc acc;
+        acc.init(f32x4{0.f, 0.f, 0.f, 0.f});
+        // (the last pass has no tile u + 1 to request: a load whose value is never used would be dropped by the compiler and the
+        // counted wait below would then let the drain's staging DMA slip)
+        if (PREV == 1) { finish_h1(u - 1, hE, 0); if constexpr (!LAST) hE = load_h1(u + 1); }
+        if (PREV == 2) { finish_h1(u - 1, hOd, 1); if constexpr (!LAST) hOd = load_h1(u + 1); }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int n = 0; n < NU; ++n) {
+          if (n + 2 < NU) load_unit(A[(n + 2) % 3], n + 2);
+          if (n == NU - 1) {
+            if constexpr (PREV == 0) stage_finish(true, V0{});
+            else if constexpr (LAST) stage_finish(true, V4{});
+            else stage_finish(true, V8{});
+          }
+          if (n < HC) mac(A[n % 3], gB[n], acc);
+          else mac(A[n % 3], hO, outG[n - HC]);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+        pre = acc.total();
+        stage_finish(false, V0{});
+      };
+      using I0 = std::integral_constant<int, 0>;
+      using I1 = std::integral_constant<int, 1>;
+      using I2 = std::integral_constant<int, 2>;
+      using BF = std::false_type;
+      using BT = std::true_type;
+      if constexpr (HT == 1) {
+        pass(0, I0{}, BT{});
+      } else {
+        pass(0, I0{}, BF{});
+        int u = 1;
+#pragma unroll 1
+        for (; u + 2 < HT; u += 2) {
+          pass(u, I1{}, BF{});
+          pass(u + 1, I2{}, BF{});
+        }
+        if constexpr (HT % 2 == 1) {
+          pass(u, I1{}, BF{});
+          pass(u + 1, I2{}, BT{});
+        } else {
+          pass(u, I1{}, BT{});
+        }
+      }
+      // ---- drain: last tile of g_a1, last W1^T chunk; the next net's / step's first stage goes in flight
+      {
+        if (net + 1 < NNETS || step > 0) {
+          if (net + 1 == NNETS) next_src = (gwords)blobB + (size_t)(step - 1) * STEP_WORDS_B;
+          issue(std::integral_constant<int, BL::value.nf[0]>{}, gs + 1);
+        }
+        Unit A[IT];
+        A[0] = N0;
+        A[1] = N1;
+        constexpr bool odd_last = ((HT - 1) & 1) != 0;
+        finish_h1(HT - 1, odd_last ? hOd : hE, odd_last ? 1 : 0);
+        if (!odd_last) {
+#pragma unroll
+          for (int k = 0; k < NP; ++k) { hO[k][2] = 0; hO[k][3] = 0; }
+        }
+#pragma unroll
+        for (int o = 0; o < IT; ++o) {
+          if (o == IT - 1) stage_finish(true, V0{});
+          mac(A[o], hO, outG[o]);
+        }
+        stage_finish(false, V0{});
+      }
+      // the net's contribution to d loss / d net input: rows k = 16 o + 4 g + r of this lane's sample
+#pragma unroll
+      for (int o = 0; o < IT; ++o) {
+        const f32x4 v = outG[o].total();
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          float* q = SC + (16 * o + 4 * g + r) * ZS + i;
+          *q = (net == 0) ? v[r] : *q + v[r];
+        }
+      }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+
+    // ---- (c) + (d): normalisation backward of every slot (in-half: pass-through gradient + the nets' contribution), its
+    //      parameter gradients summed over the wave's 16 samples
+    LaneTable tin;
+    tin.load(smt + SMALL_HDR + g * NENT);
+    auto norm_bwd = [&](const LaneTable& tb, int e, float gy, float y, int m) {
+      float gx, ga, gb;
+      if constexpr (KIND == GBNF_KIND_GLOW) {
+        gx = gy * tb.p1[e];                       // y = (x + bias) e^logs
+        ga = gx;                                  // d/d bias
+        gb = gy * y + gl;                         // d/d logs (and logdet += logs for every sample)
+      } else {
+        gx = gy * (tb.p2[e] / tb.p1[e]);          // y = (x - mean) / sqrt(var + eps) * e^log_gamma + beta
+        ga = gy * (y - tb.p3[e]) + gl;            // d/d log_gamma
+        gb = gy;                                  // d/d beta
+      }
+      if (m >= 0 && wave_ok && !(GBNF_BWD_ABLATE & 1)) {     // (uniform per lane group; a RealNVP step without BatchNorm has no parameters)
+        ga = bwd_sum16(ga);
+        gb = bwd_sum16(gb);
+        if (i == 0) {              // every (step, parameter) is met once per wave
+          float* q = PG + ((wave * K + step) * 2) * 64 + m;
+          q[0] = ga * inv_alpha;
+          q[64] = gb * inv_alpha;
+        }
+      }
+      return gx;
+    };
+#pragma unroll
+    for (int e = 0; e < NENT; ++e) {
+      const bool live = tin.slot[e] >= 0;
+      const int sl = live ? tin.slot[e] : 0;
+      const float y = trace[sl * np + row];
+      const float gy = G[sl * ZS + i] + SC[(8 * g + e) * ZS + i];
+      const int m = live ? ptab[g * NENT + e] : -1;
+      const float gx = norm_bwd(tin, e, gy, y, live ? m : -1);
+      G[(live ? tin.slot[e] : d) * ZS + i] = gx;
+    }
+    {
+      constexpr int NE = (KIND == GBNF_KIND_GLOW) ? ((2 * OT < NENT) ? 2 * OT : NENT) : ((4 * OT < NENT) ? 4 * OT : NENT);
+      const int ne = (KIND == GBNF_KIND_GLOW && p.additive) ? ((4 * OT < NENT) ? 4 * OT : NENT) : NE;
+#pragma unroll
+      for (int e = 0; e < NENT; ++e) {
+        if (e < ne) {
+          const bool live = tout.slot[e] >= 0;
+          const int sl = live ? tout.slot[e] : 0;
+          const float gy = G[sl * ZS + i];
+          const int m = live ? ptab[4 * NENT + g * NENT + e] : -1;
+          const float gx = norm_bwd(tout, e, gy, y2v[e], live ? m : -1);
+          G[(live ? tout.slot[e] : d) * ZS + i] = gx;
+        }
+      }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+  }
+
+  // ---- d loss / d x: slot j = feature j at the input of step 0
+  if (p.g_x != nullptr && lane < d) {
+#pragma unroll 8
+    for (int r = 0; r < 16; ++r) {
+      const int64_t n = row0 + r;
+      if (n < p.n) p.g_x[n * d + lane] = G[lane * ZS + r] * inv_alpha;
+    }
+  }
+  if (p.sat != nullptr && __any(sat) && lane == 0) atomicAdd(p.sat, 1ull);
+  // ---- this workgroup's parameter-gradient sums, waves added in a fixed order
+  __syncthreads();
+  for (int e = (int)threadIdx.x; e < K * 128; e += 64 * WAVES) {
+    float v = 0.0f;
+#pragma unroll
+    for (int w = 0; w < WAVES; ++w) v += PG[w * K * 128 + e];
+    p.partials[(int64_t)blockIdx.x * K * 128 + e] = v;
+  }
+}
+
+inline size_t bwd_hx3_lds_bytes(int n_steps, int waves, int stage_frags, int d) {
+  return ((size_t)n_steps * SMALL_WORDS + 2 * (size_t)stage_frags * 256 + (size_t)waves * (d + 1) * 17 + (size_t)waves * 32 * 17 +
+          (size_t)waves * n_steps * 128) * 4;
+}
+
+// 4-wave workgroups (one wave per SIMD, or two workgroups per CU) whenever their LDS fits half a CU; the 8-wave form otherwise
+inline int bwd_hx3_waves(int n_steps, int stage_frags, int d) {
+  return bwd_hx3_lds_bytes(n_steps, 4, stage_frags, d) <= 80 * 1024 ? 4 : 8;
+}
+
+template <int KIND, int HT, int OT, int ACTA, int ACTB, int WV>
+static hipError_t bwd_launch_wv(FlowLaunch p, hipStream_t s) {
+  constexpr BwdLayout L(HT, OT);
+  const size_t lds = bwd_hx3_lds_bytes(p.n_steps, WV, L.STAGE_FRAGS, p.d);
+  if (lds > 160 * 1024 || p.n_steps > LDS_TABLE_STEPS) return hipErrorInvalidValue;
+  const long long tiles = p.np / 16;               // every padded row (np is a multiple of 32): wgrad_kernel sums over all of them
+  const long long grid = (tiles + WV - 1) / WV;
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute((const void*)bwd_kernel_hx3<KIND, HT, OT, ACTA, ACTB, WV>,
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e != hipSuccess) return e;
+    attr_set = true;
+  }
+  hipLaunchKernelGGL((bwd_kernel_hx3<KIND, HT, OT, ACTA, ACTB, WV>), dim3((unsigned)grid), dim3(64 * WV), lds, s, p);
+  return hipGetLastError();
+}
+
+// registry key: VariantKey{kind, ht, -3, /*ks1*/ 2 (backward), ot, /*nt*/ 1, /*depth*/ 1, act_a, act_b}
+#define GBNF_INSTANTIATE_HX3_BWD(KIND, HT, OT, ACTA, ACTB)                                                  \
+  namespace gbnf {                                                                                          \
+  static hipError_t launch_hx3b_##KIND##_##HT##_##OT##_##ACTA##_##ACTB(const FlowLaunch& p0, unsigned, hipStream_t s) { \
+    constexpr BwdLayout L(HT, OT);                                                                          \
+    if (bwd_hx3_waves(p0.n_steps, L.STAGE_FRAGS, p0.d) == 4) return bwd_launch_wv<KIND, HT, OT, ACTA, ACTB, 4>(p0, s); \
+    return bwd_launch_wv<KIND, HT, OT, ACTA, ACTB, 8>(p0, s);                                               \
+  }                                                                                                         \
+  static const int reg_hx3b_##KIND##_##HT##_##OT##_##ACTA##_##ACTB =                                        \
+      (register_variant(VariantKey{KIND, HT, -3, 2, OT, 1, 1, ACTA, ACTB}, launch_hx3b_##KIND##_##HT##_##OT##_##ACTA##_##ACTB, \
+                        "bwd_kernel_hx3<" #KIND "," #HT "," #OT "," #ACTA "," #ACTB ">"),                   \
+       0);                                                                                                  \
+  }
+
+}  // namespace gbnf

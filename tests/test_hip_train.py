@@ -73,9 +73,11 @@ def test_trainer_forward_and_backward_match_oracle(name, golden_case):
         gx, grads = tr.backward(x, torch.from_numpy(g_z).to(dev), torch.from_numpy(g_l).to(dev), want_gx=True)
         _check_grads(grads, grads64, f"{name}[{c}]")
         assert np.abs(gx.cpu().numpy() - gx64).max() <= G_RTOL * float(np.abs(gx64).max())
-        # the same with the forward call's trace (no forward sweep inside the backward kernel): identical state
+        # the same with the forward call's trace (no forward sweep inside the backward kernel): the same state (since round 3
+        # the traced forward runs on the register-chained kernel: same arithmetic, another summation order)
         z2, ldj2, trace = tr.forward(x, want_trace=True)
-        assert torch.equal(z2, z) and torch.equal(ldj2, ldj)
+        assert rel_err(ldj2.cpu().numpy(), ldj64) < 1e-5
+        assert np.abs(z2.cpu().numpy() - z64).max() <= 1e-5 * max(1.0, float(np.abs(z64).max()))
         gx_t, grads_t = tr.backward(x, torch.from_numpy(g_z).to(dev), torch.from_numpy(g_l).to(dev), want_gx=True, trace=trace)
         _check_grads(grads_t, grads64, f"{name}[{c}] traced")
         assert np.abs(gx_t.cpu().numpy() - gx64).max() <= G_RTOL * float(np.abs(gx64).max())
@@ -447,3 +449,74 @@ def test_trainer_batch_stats_against_oracle(d, h, K, n, seed):
     z_e, ldj_e = tr.forward(xd)
     z_r, ldj_r = oracle.component_forward(spec, x, backend="numpy64")
     assert np.abs(ldj_e.cpu().numpy() - ldj_r).max() <= 1e-5 * max(1.0, float(np.abs(ldj_r).max()))
+
+
+# ---- round 3: the forward sweep on the evaluation kernel (flow_kernel_hx3<TRAIN>, device-side packing of the live parameters)
+def _blob_words(fn, handle):
+    import ctypes as C
+    from gbnf_amd import native
+    L = native.lib()
+    f = getattr(L, fn)
+    f.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(C.c_int64)]
+    f.restype = C.c_int
+    n = C.c_int64()
+    native._check(f(handle, None, C.byref(n)))
+    buf = np.zeros(n.value, dtype=np.uint32)
+    native._check(f(handle, buf.ctypes.data_as(C.c_void_p), C.byref(n)))
+    return buf
+
+
+@pytest.mark.parametrize("kind,d,h,kw", [("glow", 43, 215, {}), ("glow", 8, 64, {"act": "relu"}), ("glow", 21, 105, {"coupling": "additive"}),
+                                         ("glow", 43, 256, {"act": "random"}), ("realnvp", 21, 105, {}),
+                                         ("realnvp", 21, 105, {"coupling_network": "mixed"}), ("realnvp", 6, 30, {"batch_norm": False})])
+def test_device_packer_reproduces_the_host_packer(kind, d, h, kw):
+    """The live blob (device gather + split of the CURRENT parameter tensors) must be the blob gbnf_flow_create packs on the
+    host from the same values: weights and biases bit for bit, the table constants (expf / sqrtf on the device) to 1 ulp-ish."""
+    import torch
+    from gbnf_amd import native, synth
+    dev = torch.device("cuda:0")
+    spec = synth.synth_boosted_specs(kind, 1, d, h, 3, seed=21, **kw)[0]
+    tr = native.NativeTrainer(_dev_spec(spec, dev))
+    pats = native.activation_pattern(spec)
+    per_step = len(set(pats)) > 1 or (kind == "realnvp" and any(a != b for a, b in pats) and kw.get("coupling_network") != "mixed")
+    flow = native.NativeFlow(spec, math="f16x3", per_step_activation=per_step)
+    host = _blob_words("gbnf_debug_flow_blob", flow.handle)
+    live = _blob_words("gbnf_debug_trainer_blob", tr.handle)
+    assert host.shape == live.shape
+    diff = np.nonzero(host != live)[0]
+    if diff.size:
+        a, b = host[diff].view(np.float32), live[diff].view(np.float32)
+        assert np.all(np.abs(a - b) <= 4e-7 * np.maximum(np.abs(a), 1e-30) + 1e-30), (diff[:8], a[:8], b[:8])
+        assert diff.size < 0.01 * host.size            # only table constants may differ in the last bit
+
+
+def test_a_flow_wider_than_no_compiled_variant_keeps_the_round1_path():
+    """h = 40 with ReLU nets has no kernel variant of its own width (the nearest compiled one has 64 hidden rows): the
+    register-chained sweeps would save rows the operand workspace does not have, so such a trainer has no live blob and
+    trains on the round-1 kernels (its gradients: g10_glow_grads_additive_relu_d8 above)."""
+    import torch
+    from gbnf_amd import native, synth
+    dev = torch.device("cuda:0")
+    spec = synth.synth_boosted_specs("glow", 1, 8, 40, 3, seed=21, act="relu")[0]
+    tr = native.NativeTrainer(_dev_spec(spec, dev))
+    with pytest.raises(native.GbnfError):
+        _blob_words("gbnf_debug_trainer_blob", tr.handle)
+
+
+@pytest.mark.parametrize("kind,d,h,n", [("glow", 43, 215, 4096), ("glow", 43, 215, 77), ("realnvp", 21, 105, 2000)])
+def test_fast_forward_writes_what_the_backward_needs(kind, d, h, n):
+    """z / ldj / trace of the new forward sweep against the round-1 training kernel on the same live parameters, and the
+    saved operands (net inputs, hidden activations, net outputs) against the float64 oracle's intermediate values."""
+    import torch
+    from gbnf_amd import native, synth
+    dev = torch.device("cuda:0")
+    spec = synth.synth_boosted_specs(kind, 1, d, h, 3, seed=8)[0]
+    tr = native.NativeTrainer(_dev_spec(spec, dev))
+    x = torch.from_numpy(synth.synth_batch(n, d, seed=9)).to(dev)
+    z, ldj, trace = tr.forward(x, want_trace=True)
+    z0, ldj0 = tr.forward(x)                                  # no trace requested: the round-1 kernel
+    assert rel_err(ldj.cpu().numpy(), ldj0.cpu().numpy()) < 4e-6            # two f32 summation orders of the same products
+    np.testing.assert_allclose(z.cpu().numpy(), z0.cpu().numpy(), rtol=0, atol=2e-5 * max(1.0, float(z0.abs().max())))
+    from oracle import gbnf_oracle as oracle
+    zr, lr = oracle.component_forward(spec, x.cpu().numpy())
+    assert rel_err(ldj.cpu().numpy(), lr) < 1e-5

@@ -45,6 +45,21 @@ def test_lint_recognises_a_reader_behind_a_taken_branch():
     assert [h[:3] for h in lint.check_kernel(chain)] == [(1, 2, 0)]
 
 
+def test_lint_recognises_a_counted_wait_that_lets_the_staging_dma_slip():
+    """A stage end waits with vmcnt(N) for everything but the N operations the wave issued BEHIND its staging DMA; when the
+    compiler drops some of those (loads of values nobody reads) the DMA is no longer covered."""
+    mk = lambda addr, text: lint.Inst(addr, text.split(None, 1)[0], [t.strip() for t in text.split(None, 1)[1].split(",")] if " " in text else [], text)
+    stage = [mk(0x00, "global_load_lds_dwordx4 v[2:3], off"),
+             *[mk(0x08 + 8 * k, f"global_store_dword v[4:5], v{10 + k}, off") for k in range(4)],
+             *[mk(0x28 + 8 * k, f"global_load_dword v{20 + k}, v[4:5], off") for k in range(4)],
+             mk(0x48, "s_waitcnt vmcnt(8) lgkmcnt(0)"), mk(0x4c, "s_barrier"), mk(0x50, "s_endpgm")]
+    assert lint.check_counted_waits(stage) == []
+    del stage[5:9]                                  # the four loads were dead code
+    assert lint.check_counted_waits(stage) == [(5, 0, 4, 8)]
+    stage[5] = mk(0x48, "s_waitcnt vmcnt(4) lgkmcnt(0)")
+    assert lint.check_counted_waits(stage) == []
+
+
 @pytest.mark.skipif(not _objects(), reason="csrc/obj is empty: build the library first (python __graft_entry__.py)")
 def test_no_shipped_kernel_reads_a_matrix_result_early():
     bad = []
@@ -52,6 +67,8 @@ def test_no_shipped_kernel_reads_a_matrix_result_early():
     for f in _objects():
         for name, insts in lint.disassemble(f).items():
             n_mfma += sum(1 for x in insts if lint.is_mfma(x.mn))
+            for i, j, between, n in lint.check_counted_waits(insts):
+                bad.append(f"{os.path.basename(f)} {name[:60]}: {insts[i].text} with {between} operations behind the staging DMA")
             for i, j, ws, need, crossed in lint.check_kernel(insts):
                 bad.append(f"{os.path.basename(f)} {name[:60]}: {insts[i].text} -> {insts[j].text} after {ws} of {need} wait states"
                            f"{' (across a branch)' if crossed else ''}")

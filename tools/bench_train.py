@@ -66,9 +66,12 @@ def main():
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--cpu-steps", type=int, default=3)
+    ap.add_argument("--tune", action="append", default=[], help="key=value for gbnf_tuning_set (A/B runs)")
     a = ap.parse_args()
     cfg = CONFIGS[a.config]
     from gbnf_amd import native, synth
+    for kv in a.tune:
+        native.tuning_set(kv.split("=")[0], int(kv.split("=")[1]))
     from test_hip_train import _dev_spec
     dev = torch.device("cuda:0")
     spec = synth.synth_boosted_specs(cfg["kind"], 1, cfg["d"], cfg["h"], cfg["K"], seed=1, **cfg["kw"])[0]

@@ -181,6 +181,37 @@ def check_kernel(insts):
     return out
 
 
+def is_vmem(mn):
+    return mn.startswith(("global_", "buffer_", "flat_", "scratch_"))
+
+
+def check_counted_waits(insts):
+    """[(wait index, dma index, vector-memory operations between, N)]: a stage end of the staged kernels is
+    ``s_waitcnt vmcnt(N) ... ; s_barrier`` with N > 0 where the wave has issued N later operations BEHIND its staging DMA
+    (``global_load_lds``) that may stay in flight.  vmcnt counts in issue order, so the wait covers the DMA only if at least N
+    vector-memory instructions really sit between the two -- a load whose value is never used is dropped by the compiler, and the
+    stage would then be read before it has landed (round 3: bwd_kernel_hx3's last pass)."""
+    out = []
+    for i, ins in enumerate(insts):
+        if ins.mn != "s_waitcnt" or i + 1 >= len(insts) or insts[i + 1].mn != "s_barrier":
+            continue
+        m = re.search(r"vmcnt\((\d+)\)", ins.text)
+        if not m or int(m.group(1)) == 0:
+            continue
+        n, between = int(m.group(1)), 0
+        for j in range(i - 1, -1, -1):
+            mn = insts[j].mn
+            if mn.startswith("global_load_lds"):
+                if between < n:
+                    out.append((i, j, between, n))
+                break
+            if mn == "s_waitcnt" and "vmcnt" in insts[j].text:
+                break
+            if is_vmem(mn):
+                between += 1
+    return out
+
+
 def main(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("files", nargs="*")
@@ -195,6 +226,10 @@ def main(argv=None):
     closest = None
     for f in files:
         for name, insts in disassemble(f).items():
+            for i, j, between, n in check_counted_waits(insts):
+                bad += 1
+                print(f"{os.path.basename(f)}: {name[:70]}\n    [{insts[i].addr:#x}] {insts[i].text} leaves the staging DMA at "
+                      f"[{insts[j].addr:#x}] in flight: only {between} vector-memory operation(s) behind it")
             k = sum(1 for x in insts if is_mfma(x.mn))
             if not k:
                 continue
