@@ -1928,6 +1928,9 @@ int live_blob_backward(LiveBlob* lb, int64_t n, const float* trace, float* acts,
   p.acts_out = acts; p.np = np; p.tr_ip = ip; p.tr_hp = hp; p.tr_op = op; p.net_rows = ip + 4 * hp + 2 * op;
   p.bwd_tab = lb->bwd_tab_dev; p.bwd_goff = lb->bwd_goff_dev; p.trace_in = trace;
   p.g_z = g_z; p.g_ldj = g_ldj; p.g_x = g_x; p.grads = grads; p.gmax = gmax;
+#if defined(GBNF_STAMPS)
+  p.dbg = g_stamp_buf;
+#endif
   // the workgroups' parameter-gradient sums go to the slack rows behind the last operand region (their contents are of no
   // consequence to wgrad_kernel): 4-wave workgroups at most => np / 64 * K * 128 <= 24 np floats of the 320 np there
   p.partials = acts + (int64_t)lb->K * lb->nnets * p.net_rows * np;
@@ -1975,6 +1978,9 @@ int live_blob_forward(LiveBlob* lb, const float* x, int64_t n, float* z, float* 
   p.sat = reinterpret_cast<unsigned long long*>(saturation_counter());
   p.seq = next_serial();
   p.trace_out = trace; p.acts_out = acts; p.np = np; p.tr_ip = ip; p.tr_hp = hp; p.tr_op = op; p.net_rows = ip + 4 * hp + 2 * op;
+#if defined(GBNF_STAMPS)
+  p.dbg = g_stamp_buf;
+#endif
   const hipError_t e = lb->launch_nt[nt](p, 0u, s);
   if (e != hipSuccess) return fail(GBNF_ERR_HIP, "launch of %s failed: %s", lb->name_nt[nt], hipGetErrorString(e));
   return GBNF_OK;

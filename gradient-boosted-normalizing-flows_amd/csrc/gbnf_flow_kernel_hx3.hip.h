@@ -214,6 +214,21 @@ struct AccT {
 
 // s_waitcnt vmcnt(n) for a run-time n (an immediate in the instruction): wait until at most n of this wave's
 // vector-memory operations are outstanding (in issue order), n clamped to [0, 8]
+// a stage end that leaves the n youngest vector-memory operations of the wave in flight (n folds to a constant; even values,
+// an odd or larger one is rounded down: waiting for more is always safe)
+__device__ __forceinline__ void stage_wait_counted(int n) {
+#define GBNF_STAGE_WAIT(N) asm volatile("s_waitcnt vmcnt(" #N ") lgkmcnt(0)\n\ts_barrier" ::: "memory")
+  if (n >= 24) GBNF_STAGE_WAIT(24);
+  else if (n >= 20) GBNF_STAGE_WAIT(20);
+  else if (n >= 16) GBNF_STAGE_WAIT(16);
+  else if (n >= 12) GBNF_STAGE_WAIT(12);
+  else if (n >= 8) GBNF_STAGE_WAIT(8);
+  else if (n >= 6) GBNF_STAGE_WAIT(6);
+  else if (n >= 4) GBNF_STAGE_WAIT(4);
+  else if (n >= 2) GBNF_STAGE_WAIT(2);
+  else GBNF_STAGE_WAIT(0);
+#undef GBNF_STAGE_WAIT
+}
 __device__ __forceinline__ void wait_vmcnt(int n) {
   if (n <= 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   else if (n == 1) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
@@ -281,12 +296,15 @@ flow_kernel_hx3(const FlowLaunch p) {
   }
   const uint32_t* __restrict__ blob = p.blobs[p.c_begin + comp];
   const int d = p.d;
-  const int64_t row0 = ((int64_t)grp * WAVES + wave) * (16 * NT);    // rows >= n are masked everywhere
+  // rows >= n are masked everywhere.  TRAIN: the last workgroup's spare waves own no rows; they shadow the last tile group
+  // (same values stored twice) so that every wave issues the same vector-memory operations per stage (the counted stage waits)
+  const int64_t row0_raw = ((int64_t)grp * WAVES + wave) * (16 * NT);
+  const int64_t row0 = (TRAIN && row0_raw >= p.np) ? p.np - 16 * NT : row0_raw;
   const float* __restrict__ xin = p.xs[batch];
   const int64_t out_base = (int64_t)comp * p.out_stride + (int64_t)batch * p.n;
   // TRAIN: lane offsets into the trace ([slot][np]) and the operand regions ([16-sample tile][row][16]); 32-bit: one
   // (step, net) region holds net_rows * np < 2^31 floats for np up to 2 M rows
-  [[maybe_unused]] const bool tr_ok = !TRAIN || row0 < p.np;      // (the last workgroup's spare waves own no rows at all)
+  [[maybe_unused]] constexpr bool tr_ok = true;
   [[maybe_unused]] const int tr_np = (int)p.np, tr_row = (int)row0 + (lane & 15);
   [[maybe_unused]] const int tr_ip = p.tr_ip, tr_hp = p.tr_hp, tr_ip16 = p.tr_ip * 16, tr_hp16 = p.tr_hp * 16, tr_op16 = p.tr_op * 16;
   [[maybe_unused]] const int tr_net_stride = p.net_rows * (int)p.np;
@@ -355,6 +373,13 @@ flow_kernel_hx3(const FlowLaunch p) {
   const int first_step = inv ? p.n_steps - 1 : 0;
   gwords next_src = (gwords)blob + (size_t)first_step * STEP_WORDS + SMALL_WORDS;    // bias block of the first step's net 0
   int gs = 0;                                       // stage counter: slot = gs & 1
+  // TRAIN: operand stores this wave has issued BEHIND the staging DMA of the stage in flight.  They may stay in flight across
+  // the stage-end barrier (vmcnt counts in issue order: `s_waitcnt vmcnt(tr_later)` covers the DMA and everything older) --
+  // waiting for them too made every stage as long as a store's round trip to HBM (16 us per flow step at N = 4096).  The
+  // value is a compile-time constant at every stage end (straight-line code between issue() and stage_end()); only stores
+  // that are issued unconditionally are counted (an undercount only waits longer); tools/isa_hazard_lint.py re-counts the
+  // vector-memory instructions between every staging DMA and its counted wait in the shipped ISA.
+  [[maybe_unused]] int tr_later = 0;
   int nets_issued = 0;                              // nets whose first stage has been issued (bias buffer = & 1)
   const unsigned lane_b16 = (unsigned)lane * 16u;
   auto dma = [&](gwords src, uint32_t* dst) {
@@ -375,6 +400,10 @@ flow_kernel_hx3(const FlowLaunch p) {
       if ((k + 1) * WAVES <= NF || f < NF) dma(next_src + f * 256, dst + f * 256);
     }
     next_src += NF * 256;
+    if constexpr (TRAIN) {
+      __builtin_amdgcn_sched_barrier(0);           // nothing that is counted below moves in front of the DMA
+      tr_later = 0;
+    }
   };
   auto issue_net_start = [&](int into) {            // next_src points at a net's bias block: biases + first L0 stage
     uint32_t* bdst = BIAS + (nets_issued & 1) * LT::value.BIAS_WORDS;
@@ -440,7 +469,8 @@ flow_kernel_hx3(const FlowLaunch p) {
 #endif
 #ifndef GBNF_ABLATE_BARRIER       // diagnostic: no per-stage rendezvous (races on the staging buffers, timing only)
     // this wave's pieces of the next stage have landed, all waves are done with this slot
-    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    if constexpr (TRAIN) stage_wait_counted(tr_later);
+    else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
 #endif
 #ifdef GBNF_STAMPS
     st.mark(7);                  // bucket 7: time in the stage-end wait + barrier
@@ -641,12 +671,12 @@ flow_kernel_hx3(const FlowLaunch p) {
       // workspace (the activation-side operand of the next layer's weight gradient, and act' for the backward chain)
       auto save_act = [&](float a0, float a1, bool r_form, int layer, int tile, int hp, int nt) {
         if constexpr (TRAIN) {
-          if (!tr_ok) return;
           if (r_form) { a0 = __builtin_fmaf(-2.0f, a0, 1.0f); a1 = __builtin_fmaf(-2.0f, a1, 1.0f); }   // tanh = 1 - 2 r
           // rows ip + layer * hp + 16 tile + 4 g + 2 hp + {0, 1} of this net's region; [tile of 16 samples][row][16]
           float* q = tr_acts + net * tr_net_stride + (tr_ip + layer * tr_hp) * tr_np + tr_h_off + nt * tr_hp16 + (16 * tile + 2 * hp) * 16;
           q[0] = a0;
           q[16] = a1;
+          tr_later += 2;
         } else {
           (void)a0; (void)a1; (void)r_form; (void)layer; (void)tile; (void)hp; (void)nt;
         }
@@ -957,6 +987,8 @@ flow_kernel_hx3(const FlowLaunch p) {
             if (net + 1 == NNETS)       // the next step's tables sit in front of its first net (inverse: the step before this one)
               next_src = inv ? (gwords)blob + (size_t)(step - 1) * STEP_WORDS + SMALL_WORDS : next_src + SMALL_WORDS;
             issue_net_start(gs + 1);
+          } else if constexpr (TRAIN) {
+            tr_later = 0;                 // (no DMA to wait for: the same constant on both paths)
           }
           Unit A[OT];
           A[0] = N0;

@@ -132,6 +132,7 @@ __global__ void __launch_bounds__(64 * WV, WV == 8 ? 2 : 1) bwd_kernel_hx3(const
     const __attribute__((address_space(1))) char* base = reinterpret_cast<const __attribute__((address_space(1))) char*>(src);
     __builtin_amdgcn_global_load_lds(base + lane_b16, (lptr)dst, 16, 0, 0);
   };
+  int later = 0;             // vector-memory operations issued behind the staging DMA in flight (stage_end)
   auto issue = [&](auto nf_c, int into) {
     constexpr int NF = decltype(nf_c)::value;
     uint32_t* dst = STG + (into & 1) * STAGE_WORDS;
@@ -141,6 +142,8 @@ __global__ void __launch_bounds__(64 * WV, WV == 8 ? 2 : 1) bwd_kernel_hx3(const
       if ((k + 1) * WAVES <= NF || f < NF) dma(next_src + f * 256, dst + f * 256);
     }
     next_src += NF * 256;
+    __builtin_amdgcn_sched_barrier(0);       // nothing that is counted below moves in front of the DMA
+    later = 0;
   };
   issue(std::integral_constant<int, BL::value.nf[0]>{}, 0);
   for (int s = 0; s < K; ++s) {
@@ -169,12 +172,22 @@ __global__ void __launch_bounds__(64 * WV, WV == 8 ? 2 : 1) bwd_kernel_hx3(const
 
   bool sat = false;
   const uint32_t* buf = STG;
-  // `later`: vector-memory operations this wave has issued BEHIND the stage's staging DMA (operand stores, activation
-  // prefetches): they may stay in flight across the barrier -- waiting for all of them (vmcnt(0)) makes every stage as long as
-  // a store's round trip to HBM.  (vmcnt counts in issue order; an underestimate is safe.)
-  auto stage_end = [&](auto later_c) {
-    constexpr int LATER = decltype(later_c)::value;
-    asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(LATER) : "memory");
+  // `later`: vector-memory operations this wave has issued BEHIND the staging DMA of the stage in flight (operand stores,
+  // activation prefetches): they may stay in flight across the barrier -- waiting for all of them (vmcnt(0)) makes every
+  // stage as long as a store's round trip to HBM.  vmcnt counts in issue order and an undercount is safe; the value is a
+  // compile-time constant at every stage end (reset by issue(), straight-line code up to the wait), and
+  // tools/isa_hazard_lint.py re-counts the instructions between every staging DMA and its counted wait in the shipped ISA.
+  Stamps st;                  // diagnostic builds (-DGBNF_STAMPS, tools/build_train_stamps2.sh): cycles per phase and wave
+  auto stage_end = [&]() {
+#ifdef GBNF_STAMPS
+    const int phase_ = st.cur;
+    st.mark(phase_);
+#endif
+    stage_wait_counted(later);
+#ifdef GBNF_STAMPS
+    st.mark(7);                // bucket 7: stage-end wait + barrier
+    st.cur = phase_;
+#endif
     ++gs;
   };
   auto frag = [&](int f) -> u32x4 { return *reinterpret_cast<const u32x4*>(buf + f * 256 + lane * 4); };
@@ -196,14 +209,11 @@ __global__ void __launch_bounds__(64 * WV, WV == 8 ? 2 : 1) bwd_kernel_hx3(const
     asm volatile("s_nop 7" ::: "memory");
     __builtin_amdgcn_sched_barrier(0);
   };
-  auto stage_finish = [&](bool early, auto later_c) {        // every stage ends in front of its last unit
+  auto stage_finish = [&](bool early) {        // every stage ends in front of its last unit
     if (!early) { mfma_tail_guard(); return; }
-    stage_end(later_c);
+    stage_end();
     preload();
   };
-  using V0 = std::integral_constant<int, 0>;
-  using V4 = std::integral_constant<int, GBNF_BWD_ABLATE & 2 ? 0 : 4>;
-  using V8 = std::integral_constant<int, GBNF_BWD_ABLATE & 2 ? 0 : 8>;
   preload();
   auto mac = [&](const Unit& a, const u32x4 (&x)[NP], Acc& acc) {
 #pragma unroll
@@ -228,7 +238,9 @@ __global__ void __launch_bounds__(64 * WV, WV == 8 ? 2 : 1) bwd_kernel_hx3(const
   const int h_off = tile0 * hp16 + 4 * g * 16 + i;         // unit 16 t + 4 g + r of this lane's sample: + (16 t + r) * 16
   const int o_off = tile0 * op16 + 4 * g * 16 + i;
 
+  st.start();
   for (int step = K - 1; step >= 0; --step) {
+    st.set(0);
     const uint32_t* smt = SM + step * SMALL_WORDS;
     const float* trace = p.trace_in + (int64_t)step * d * p.np;
     float* acts = p.acts_out + (int64_t)step * NNETS * p.net_rows * p.np;
@@ -241,6 +253,27 @@ __global__ void __launch_bounds__(64 * WV, WV == 8 ? 2 : 1) bwd_kernel_hx3(const
     f32x4 gA[OT], gBo[OT];                       // net 0 / net 1 output gradients (rows 16 o + 4 g + r)
 #pragma unroll
     for (int o = 0; o < OT; ++o) { gA[o] = f32x4{0.f, 0.f, 0.f, 0.f}; gBo[o] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+    // (c)'s inputs -- the step's normalised in-half state -- are requested here: behind the chain they would be a global round
+    // trip per step with nothing to hide it
+    LaneTable tin;
+    tin.load(smt + SMALL_HDR + g * NENT);
+    float yin[NENT];
+    int mi[NENT], mo[NENT];             // parameter index of every table entry (bwd_tab), -1: none
+#pragma unroll
+    for (int e = 0; e < NENT; ++e) {
+      yin[e] = trace[(tin.slot[e] >= 0 ? tin.slot[e] : 0) * np + row];
+      mi[e] = ptab[g * NENT + e];
+      mo[e] = ptab[4 * NENT + g * NENT + e];
+    }
+    // ... and so are net 0's second-layer activations (56 loads for h = 215): one exposed round trip per step, not two
+    f32x4 h2first[HT];
+    {
+      const float* h2p0 = acts + (int64_t)(p.tr_ip + p.tr_hp) * np + h_off;
+#pragma unroll
+      for (int t = 0; t < HT; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) h2first[t][r] = (GBNF_BWD_ABLATE & 4) ? 0.5f : h2p0[(16 * t + r) * 16];
+    }
     float y2v[NENT];
     {
       const float* oA = acts + (int64_t)(p.tr_ip + 4 * p.tr_hp + p.tr_op) * np + o_off;     // the forward sweep's saved net outputs
@@ -297,6 +330,7 @@ __global__ void __launch_bounds__(64 * WV, WV == 8 ? 2 : 1) bwd_kernel_hx3(const
       }
     }
 
+    st.mark(0);                 // bucket 0: coupling backward (with the wait for its loads)
     // ---- (b) the dgrad chain of every net; its output (rows k = 16 o + 4 g + r of d loss / d net input) is summed in SC
 #pragma unroll
     for (int net = 0; net < NNETS; ++net) {
@@ -335,9 +369,14 @@ __global__ void __launch_bounds__(64 * WV, WV == 8 ? 2 : 1) bwd_kernel_hx3(const
       // all of the second hidden layer's saved activations are requested up front (layer W3^T is short)
       f32x4 h2v[HT];
 #pragma unroll
-      for (int t = 0; t < HT; ++t)
+      for (int t = 0; t < HT; ++t) {
+        if (net == 0) {
+          h2v[t] = h2first[t];
+        } else {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) h2v[t][r] = (GBNF_BWD_ABLATE & 4) ? 0.5f : h2p[(16 * t + r) * 16];
+          for (int r = 0; r < 4; ++r) h2v[t][r] = (GBNF_BWD_ABLATE & 4) ? 0.5f : h2p[(16 * t + r) * 16];
+        }
+      }
 
       u32x4 gB[HC][NP];                           // g_a2 = (W3^T g_o) * act'(h2), split: the B operands of the W2^T layer
 #pragma unroll
@@ -351,6 +390,7 @@ __global__ void __launch_bounds__(64 * WV, WV == 8 ? 2 : 1) bwd_kernel_hx3(const
           if (!(GBNF_BWD_ABLATE & 2)) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) d2p[(16 * t + r) * 16] = ga[r];
+            later += 4;
           }
           unsigned lo[NP], hi[NP];
           split4(ga, lo, hi);
@@ -371,7 +411,7 @@ __global__ void __launch_bounds__(64 * WV, WV == 8 ? 2 : 1) bwd_kernel_hx3(const
           for (int n = 0; n < NU; ++n) {
             const int t = t0 + n / K0, c = n % K0;
             if (n + 2 < NU) load_unit(A[(n + 2) % 3], n + 2);
-            if (n == NU - 1) stage_finish(true, V0{});
+            if (n == NU - 1) stage_finish(true);
             if (c == 0) cur.init(f32x4{0.f, 0.f, 0.f, 0.f});
             mac(A[n % 3], gO[c], cur);
             if (c == K0 - 1) {
@@ -380,7 +420,7 @@ __global__ void __launch_bounds__(64 * WV, WV == 8 ? 2 : 1) bwd_kernel_hx3(const
             }
             __builtin_amdgcn_sched_barrier(0);
           }
-          stage_finish(false, V0{});
+          stage_finish(false);
         };
         auto l0_all = [&](auto self, auto s_c) -> void {
           constexpr int sI = decltype(s_c)::value;
@@ -389,8 +429,12 @@ __global__ void __launch_bounds__(64 * WV, WV == 8 ? 2 : 1) bwd_kernel_hx3(const
             self(self, std::integral_constant<int, sI + 1>{});
           }
         };
+        st.mark(5);             // bucket 5: net start (output-gradient stores and split, activation requests)
+        st.set(1);
         l0_all(l0_all, std::integral_constant<int, 0>{});
         finish_tile(HT - 1, rawp);
+        st.mark(1);             // bucket 1: W3^T stages
+        st.set(2);
       }
 
       // ---- W2^T: one output tile per stage; tile u-1 times act'(h1) is emitted / split during pass u and consumed, two
@@ -417,6 +461,7 @@ __global__ void __launch_bounds__(64 * WV, WV == 8 ? 2 : 1) bwd_kernel_hx3(const
         if (!(GBNF_BWD_ABLATE & 2)) {
 #pragma unroll
           for (int r = 0; r < 4; ++r) d1p[(16 * t + r) * 16] = ga[r];
+          later += 4;
         }
         unsigned lo[NP], hi[NP];
         split4(ga, lo, hi);
@@ -439,23 +484,21 @@ __global__ void __launch_bounds__(64 * WV, WV == 8 ? 2 : 1) bwd_kernel_hx3(const
         acc.init(f32x4{0.f, 0.f, 0.f, 0.f});
         // (the last pass has no tile u + 1 to request: a load whose value is never used would be dropped by the compiler and the
         // counted wait below would then let the drain's staging DMA slip)
-        if (PREV == 1) { finish_h1(u - 1, hE, 0); if constexpr (!LAST) hE = load_h1(u + 1); }
-        if (PREV == 2) { finish_h1(u - 1, hOd, 1); if constexpr (!LAST) hOd = load_h1(u + 1); }
+        if (PREV == 1) { finish_h1(u - 1, hE, 0); if constexpr (!LAST) { hE = load_h1(u + 1); later += 4; } }
+        if (PREV == 2) { finish_h1(u - 1, hOd, 1); if constexpr (!LAST) { hOd = load_h1(u + 1); later += 4; } }
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int n = 0; n < NU; ++n) {
           if (n + 2 < NU) load_unit(A[(n + 2) % 3], n + 2);
           if (n == NU - 1) {
-            if constexpr (PREV == 0) stage_finish(true, V0{});
-            else if constexpr (LAST) stage_finish(true, V4{});
-            else stage_finish(true, V8{});
+            stage_finish(true);
           }
           if (n < HC) mac(A[n % 3], gB[n], acc);
           else mac(A[n % 3], hO, outG[n - HC]);
           __builtin_amdgcn_sched_barrier(0);
         }
         pre = acc.total();
-        stage_finish(false, V0{});
+        stage_finish(false);
       };
       using I0 = std::integral_constant<int, 0>;
       using I1 = std::integral_constant<int, 1>;
@@ -479,11 +522,15 @@ __global__ void __launch_bounds__(64 * WV, WV == 8 ? 2 : 1) bwd_kernel_hx3(const
           pass(u, I1{}, BT{});
         }
       }
+      st.mark(2);               // bucket 2: W2^T passes
+      st.set(3);
       // ---- drain: last tile of g_a1, last W1^T chunk; the next net's / step's first stage goes in flight
       {
         if (net + 1 < NNETS || step > 0) {
           if (net + 1 == NNETS) next_src = (gwords)blobB + (size_t)(step - 1) * STEP_WORDS_B;
           issue(std::integral_constant<int, BL::value.nf[0]>{}, gs + 1);
+        } else {
+          later = 0;               // (no DMA to wait for: the same constant on both paths)
         }
         Unit A[IT];
         A[0] = N0;
@@ -496,10 +543,10 @@ __global__ void __launch_bounds__(64 * WV, WV == 8 ? 2 : 1) bwd_kernel_hx3(const
         }
 #pragma unroll
         for (int o = 0; o < IT; ++o) {
-          if (o == IT - 1) stage_finish(true, V0{});
+          if (o == IT - 1) stage_finish(true);
           mac(A[o], hO, outG[o]);
         }
-        stage_finish(false, V0{});
+        stage_finish(false);
       }
       // the net's contribution to d loss / d net input: rows k = 16 o + 4 g + r of this lane's sample
 #pragma unroll
@@ -514,11 +561,10 @@ __global__ void __launch_bounds__(64 * WV, WV == 8 ? 2 : 1) bwd_kernel_hx3(const
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     __builtin_amdgcn_wave_barrier();
+    st.mark(3);                 // bucket 3: drain, net-input gradient to LDS
 
     // ---- (c) + (d): normalisation backward of every slot (in-half: pass-through gradient + the nets' contribution), its
     //      parameter gradients summed over the wave's 16 samples
-    LaneTable tin;
-    tin.load(smt + SMALL_HDR + g * NENT);
     auto norm_bwd = [&](const LaneTable& tb, int e, float gy, float y, int m) {
       float gx, ga, gb;
       if constexpr (KIND == GBNF_KIND_GLOW) {
@@ -541,34 +587,49 @@ __global__ void __launch_bounds__(64 * WV, WV == 8 ? 2 : 1) bwd_kernel_hx3(const
       }
       return gx;
     };
+    // (every LDS read of the section in front of its first write: the slots of a step are distinct, which the compiler cannot
+    //  know -- interleaved, each entry waited for its own LDS round trip behind the previous entry's write)
+    float gyi[NENT];
 #pragma unroll
     for (int e = 0; e < NENT; ++e) {
       const bool live = tin.slot[e] >= 0;
       const int sl = live ? tin.slot[e] : 0;
-      const float y = trace[sl * np + row];
-      const float gy = G[sl * ZS + i] + SC[(8 * g + e) * ZS + i];
-      const int m = live ? ptab[g * NENT + e] : -1;
-      const float gx = norm_bwd(tin, e, gy, y, live ? m : -1);
+      gyi[e] = G[sl * ZS + i] + SC[(8 * g + e) * ZS + i];
+      mi[e] = live ? mi[e] : -1;
+    }
+    constexpr int NE_O = (KIND == GBNF_KIND_GLOW) ? ((2 * OT < NENT) ? 2 * OT : NENT) : ((4 * OT < NENT) ? 4 * OT : NENT);
+    const int ne_o = (KIND == GBNF_KIND_GLOW && p.additive) ? ((4 * OT < NENT) ? 4 * OT : NENT) : NE_O;
+    float gyo[NENT];
+#pragma unroll
+    for (int e = 0; e < NENT; ++e) {
+      const bool live = tout.slot[e] >= 0;
+      gyo[e] = G[(live ? tout.slot[e] : 0) * ZS + i];
+      mo[e] = live ? mo[e] : -1;
+    }
+#pragma unroll
+    for (int e = 0; e < NENT; ++e) {
+      const bool live = tin.slot[e] >= 0;
+      const float gx = norm_bwd(tin, e, gyi[e], yin[e], mi[e]);
       G[(live ? tin.slot[e] : d) * ZS + i] = gx;
     }
-    {
-      constexpr int NE = (KIND == GBNF_KIND_GLOW) ? ((2 * OT < NENT) ? 2 * OT : NENT) : ((4 * OT < NENT) ? 4 * OT : NENT);
-      const int ne = (KIND == GBNF_KIND_GLOW && p.additive) ? ((4 * OT < NENT) ? 4 * OT : NENT) : NE;
 #pragma unroll
-      for (int e = 0; e < NENT; ++e) {
-        if (e < ne) {
-          const bool live = tout.slot[e] >= 0;
-          const int sl = live ? tout.slot[e] : 0;
-          const float gy = G[sl * ZS + i];
-          const int m = live ? ptab[4 * NENT + g * NENT + e] : -1;
-          const float gx = norm_bwd(tout, e, gy, y2v[e], live ? m : -1);
-          G[(live ? tout.slot[e] : d) * ZS + i] = gx;
-        }
+    for (int e = 0; e < NENT; ++e) {
+      if (e < ne_o) {
+        const bool live = tout.slot[e] >= 0;
+        const float gx = norm_bwd(tout, e, gyo[e], y2v[e], mo[e]);
+        G[(live ? tout.slot[e] : d) * ZS + i] = gx;
       }
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     __builtin_amdgcn_wave_barrier();
+    st.mark(4);                 // bucket 4: normalisation backward, parameter sums
   }
+#ifdef GBNF_STAMPS
+  if (p.dbg != nullptr && lane == 0) {
+#pragma unroll
+    for (int k = 0; k < 8; ++k) p.dbg[((size_t)blockIdx.x * WAVES + wave) * 8 + k] = st.acc[k];
+  }
+#endif
 
   // ---- d loss / d x: slot j = feature j at the input of step 0
   if (p.g_x != nullptr && lane < d) {
@@ -594,9 +655,10 @@ inline size_t bwd_hx3_lds_bytes(int n_steps, int waves, int stage_frags, int d) 
           (size_t)waves * n_steps * 128) * 4;
 }
 
-// 4-wave workgroups (one wave per SIMD, or two workgroups per CU) whenever their LDS fits half a CU; the 8-wave form otherwise
+// 4-wave workgroups, one wave per SIMD (the kernel keeps a whole layer of saved activations in registers: 290-330 of a lone
+// wave's 512); the 8-wave form exists for geometries whose 4-wave LDS does not fit at all
 inline int bwd_hx3_waves(int n_steps, int stage_frags, int d) {
-  return bwd_hx3_lds_bytes(n_steps, 4, stage_frags, d) <= 80 * 1024 ? 4 : 8;
+  return bwd_hx3_lds_bytes(n_steps, 4, stage_frags, d) <= 160 * 1024 ? 4 : 8;
 }
 
 template <int KIND, int HT, int OT, int ACTA, int ACTB, int WV>
