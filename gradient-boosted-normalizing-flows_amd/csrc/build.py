@@ -17,7 +17,7 @@ PKG = os.path.dirname(HERE)
 OBJ = os.path.join(HERE, "obj")
 LIB = os.path.join(PKG, "libgbnf_hip.so")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-Wno-unused-value"]
+FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-Wno-unused-value", "-Wno-inline-asm"]
 
 
 def read_variants():

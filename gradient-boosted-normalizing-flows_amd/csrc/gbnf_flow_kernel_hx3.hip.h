@@ -214,6 +214,26 @@ struct AccT {
 
 // s_waitcnt vmcnt(n) for a run-time n (an immediate in the instruction): wait until at most n of this wave's
 // vector-memory operations are outstanding (in issue order), n clamped to [0, 8]
+// One direct-to-LDS load: lane l moves 16 bytes from src + 16 l to lds_dst + 16 l.  Issued through inline asm on purpose: with
+// __builtin_amdgcn_global_load_lds anywhere in a kernel, hipcc (ROCm 7.2) stops counting LDS reads -- EVERY wait for a
+// ds_read becomes s_waitcnt lgkmcnt(0), i.e. each MFMA group waits for the fragment reads issued just before it instead of
+// the ones it consumes (round 3, tools/ubench/lgkmcnt_dma.hip: counted waits come back when the compiler does not see the
+// DMA).  The compiler then knows nothing of these loads: their completion is the stage-end `s_waitcnt vmcnt` + barrier, which
+// the kernels did by hand already, and its own vmcnt counts only ever over-wait (hidden operations are extra younger ones).
+// M0 = LDS address of the wave's 1 KiB piece; `saddr + 32-bit lane offset` form: no 64-bit vector address arithmetic.
+#ifndef GBNF_DMA_ASM
+#define GBNF_DMA_ASM 1
+#endif
+__device__ __forceinline__ void lds_dma16(const __attribute__((address_space(1))) uint32_t* src, uint32_t* lds_dst, unsigned lane_b16) {
+#if GBNF_DMA_ASM
+  const unsigned m0v = (unsigned)(uintptr_t)(__attribute__((address_space(3))) void*)lds_dst;
+  asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(lane_b16), "s"(src), "s"(m0v) : "memory", "m0");
+#else
+  const __attribute__((address_space(1))) char* base = reinterpret_cast<const __attribute__((address_space(1))) char*>(src);
+  __builtin_amdgcn_global_load_lds(base + lane_b16, (__attribute__((address_space(3))) void*)lds_dst, 16, 0, 0);
+#endif
+}
+
 // a stage end that leaves the n youngest vector-memory operations of the wave in flight (n folds to a constant; even values,
 // an odd or larger one is rounded down: waiting for more is always safe)
 __device__ __forceinline__ void stage_wait_counted(int n) {
@@ -384,9 +404,7 @@ flow_kernel_hx3(const FlowLaunch p) {
   const unsigned lane_b16 = (unsigned)lane * 16u;
   auto dma = [&](gwords src, uint32_t* dst) {
 #ifndef GBNF_ABLATE_DMA          // diagnostic: no weight staging at all (stale LDS contents, timing only)
-    // uniform base + 32-bit per-lane offset -> saddr form, no 64-bit VALU address arithmetic
-    const __attribute__((address_space(1))) char* base = reinterpret_cast<const __attribute__((address_space(1))) char*>(src);
-    __builtin_amdgcn_global_load_lds(base + lane_b16, (lptr)dst, 16, 0, 0);
+    lds_dma16(src, dst, lane_b16);
 #else
     (void)src; (void)dst;
 #endif

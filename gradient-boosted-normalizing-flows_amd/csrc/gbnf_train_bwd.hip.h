@@ -129,8 +129,7 @@ __global__ void __launch_bounds__(64 * WV, WV == 8 ? 2 : 1) bwd_kernel_hx3(const
   int gs = 0;
   const unsigned lane_b16 = (unsigned)lane * 16u;
   auto dma = [&](gwords src, uint32_t* dst) {
-    const __attribute__((address_space(1))) char* base = reinterpret_cast<const __attribute__((address_space(1))) char*>(src);
-    __builtin_amdgcn_global_load_lds(base + lane_b16, (lptr)dst, 16, 0, 0);
+    lds_dma16(src, dst, lane_b16);
   };
   int later = 0;             // vector-memory operations issued behind the staging DMA in flight (stage_end)
   auto issue = [&](auto nf_c, int into) {

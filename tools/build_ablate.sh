@@ -5,7 +5,7 @@
 set -e
 cd "$(dirname "$0")/../gradient-boosted-normalizing-flows_amd/csrc"
 OUT=/tmp/gbnf_ablate; mkdir -p $OUT ../../tools/ablate
-F="--offload-arch=gfx950 -O3 -fPIC -std=c++17 -Wno-unused-value -mllvm -amdgpu-mfma-vgpr-form=1"
+F="--offload-arch=gfx950 -O3 -fPIC -std=c++17 -Wno-unused-value -Wno-inline-asm -mllvm -amdgpu-mfma-vgpr-form=1"
 WHATS="${@:-base waves4 mfma dma barrier frag bias dma+barrier+frag+bias waves4+dma+barrier+frag+bias}"
 python3 build.py > /dev/null          # obj/gbnf_api.o, gbnf_train.o, gbnf_image.o of the shipped build
 for what in $WHATS; do

@@ -4,7 +4,7 @@
 set -e
 cd "$(dirname "$0")/../gradient-boosted-normalizing-flows_amd/csrc"
 OUT=/tmp/gbnf_tail; mkdir -p $OUT ../../tools/ablate
-F="--offload-arch=gfx950 -O3 -fPIC -std=c++17 -Wno-unused-value -mllvm -amdgpu-mfma-vgpr-form=1"
+F="--offload-arch=gfx950 -O3 -fPIC -std=c++17 -Wno-unused-value -Wno-inline-asm -mllvm -amdgpu-mfma-vgpr-form=1"
 MODES="${@:-0 1 2 3}"
 for m in $MODES; do
   for nt in 1 2; do

@@ -3,7 +3,7 @@
 set -e
 cd "$(dirname "$0")/../gradient-boosted-normalizing-flows_amd/csrc"
 OUT=/tmp/gbnf_timeline; mkdir -p $OUT
-F="--offload-arch=gfx950 -O3 -fPIC -std=c++17 -Wno-unused-value -DGBNF_TIMELINE"
+F="--offload-arch=gfx950 -O3 -fPIC -std=c++17 -Wno-unused-value -Wno-inline-asm -DGBNF_TIMELINE"
 python3 build.py > /dev/null
 for nt in 1 2; do
   hipcc $F -mllvm -amdgpu-mfma-vgpr-form=1 -DGBNF_V_ARGS=0,14,3,$nt,0,0,0,1 -c variant_hx3.hip -o $OUT/h_$nt.o &

@@ -4,7 +4,7 @@
 set -e
 cd "$(dirname "$0")/../gradient-boosted-normalizing-flows_amd/csrc"
 OUT=/tmp/gbnf_tstamps; mkdir -p $OUT
-F="--offload-arch=gfx950 -O3 -fPIC -std=c++17 -Wno-unused-value -DGBNF_STAMPS"
+F="--offload-arch=gfx950 -O3 -fPIC -std=c++17 -Wno-unused-value -Wno-inline-asm -DGBNF_STAMPS"
 hipcc $F -mllvm -amdgpu-mfma-vgpr-form=1 -DGBNF_V_ARGS=0,14,3,0,0 -c variant_bwd.hip -o $OUT/b.o &
 hipcc $F -mllvm -amdgpu-mfma-vgpr-form=1 -DGBNF_V_TRAIN=1 -DGBNF_V_ARGS=0,14,3,1,0,0,0,1 -c variant_hx3.hip -o $OUT/t.o &
 hipcc $F -c gbnf_api.hip -o $OUT/api.o &
