@@ -284,7 +284,13 @@ int gbnf_trainer_destroy(gbnf_trainer* trainer);
 /* z, ldj = flows[c](x) on the live parameters (same semantics and outputs as gbnf_flow_forward).  `trace` (optional,
  * gbnf_trainer_trace_floats(n) floats of DEVICE memory) receives every step's normalised state; handing it to
  * gbnf_trainer_backward saves that call the forward sweep and the re-splitting of the weights (valid only while the
- * parameters are unchanged and no other forward call of this trainer ran on changed parameters in between). */
+ * parameters are unchanged and no other forward call of this trainer ran on changed parameters in between).
+ * Since round 3 the trace buffer of a flow that runs on the register-chained kernels (depth-1 coupling nets of a compiled
+ * width, BatchNorm on running statistics) is also the OPERAND WORKSPACE of the step: behind the states the forward call
+ * stores the coupling nets' inputs, hidden activations and outputs (gbnf_trainer_trace_floats accounts for it:
+ * K * nets * (ip + 4 hp + 2 op) rows of n-rounded-up-to-32 floats -- 20 KB per sample for MINIBOONE, K = 5), and
+ * gbnf_trainer_backward WRITES the gradient-side operands of the weight gradients into the same buffer (its `trace`
+ * argument is const for the states only).  One trace buffer therefore serves one forward + one backward call. */
 int gbnf_trainer_trace_floats(const gbnf_trainer* trainer, int64_t n, int64_t* n_floats);
 int gbnf_trainer_forward(const gbnf_trainer* trainer, const float* x, int64_t n, float* z, float* ldj, float* trace,
                          void* stream);
@@ -306,8 +312,11 @@ int gbnf_trainer_workspace_bytes(const gbnf_trainer* trainer, int64_t n, int64_t
 
 /* Backward of (z, ldj) = flows[c](x): given g_z = dL/dz (n,d) and g_ldj = dL/dldj (n,) (either may be NULL = zero),
  * ACCUMULATES dL/dparameters into `grads` (the caller zeroes it; layout above) and writes dL/dx to g_x (n,d) unless
- * NULL.  The coupling nets' activations are recomputed; `trace` is the forward call's trace buffer or NULL (then the
- * whole forward sweep is recomputed from x as well). */
+ * NULL.  `trace` is the forward call's trace buffer or NULL.  With it, a flow on the register-chained kernels (above)
+ * recomputes nothing: the backward kernel chains W3^T -> W2^T -> W1^T on the saved activations, ActNorm / BatchNorm
+ * gradients are summed per workgroup and added in a fixed order (bit-identical from run to run; the weight gradients still
+ * use float atomics across sample blocks).  Other flows recompute the coupling nets' activations from the trace, and with
+ * NULL the whole forward sweep from x. */
 int gbnf_trainer_backward(const gbnf_trainer* trainer, const float* x, int64_t n, const float* trace, const float* g_z,
                           const float* g_ldj, float* g_x, float* grads, void* workspace, int64_t workspace_bytes,
                           void* stream);
