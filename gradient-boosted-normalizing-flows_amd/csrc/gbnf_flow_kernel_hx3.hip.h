@@ -110,7 +110,14 @@ constexpr int hx3_reg_estimate(int HT, int OT, int NT, int prec, int kind, int a
   // (a second hidden layer keeps the first one's activations AND its own, both as B operands)
   return (depth == 2 ? 2 : 1) * hc * NT * np * 4 + (nn + accs - 1) * OT * NT * 4 + NT * 4 * (1 + accs) + 2 * NT * np * 4 + 3 * np * 4 + 36 + relu;
 }
-constexpr int hx3_waves(int HT, int OT, int NT, int prec, int kind, int act_a, int act_b, int depth = 1) {
+// TRAIN kernels (trace + operand saves, ~40 more registers per sample tile): 32-sample waves run one per SIMD with the
+// 512-register budget, in 4-wave workgroups (a lone 32-sample wave does a pass in the time two co-resident 16-sample waves
+// take for theirs together with half the LDS reads and DMA issue: the forward sweep of large batches)
+constexpr bool hx3_train_wide(int HT, int OT, int NT, int prec, int kind, int act_a, int act_b, int depth, int train) {
+  return train != 0 && NT == 2 && hx3_reg_estimate(HT, OT, 2, prec, kind, act_a, act_b, depth) + 80 <= 440;
+}
+constexpr int hx3_waves(int HT, int OT, int NT, int prec, int kind, int act_a, int act_b, int depth = 1, int train = 0) {
+  if (hx3_train_wide(HT, OT, NT, prec, kind, act_a, act_b, depth, train)) return 4;
 #ifdef GBNF_HX3_FORCE_WAVES       // experiment knob: 4 = two independent 4-wave workgroups per CU (where registers and LDS allow)
   return hx3_reg_estimate(HT, OT, NT, prec, kind, act_a, act_b, depth) <= 248 ? GBNF_HX3_FORCE_WAVES : 4;
 #else
@@ -118,12 +125,14 @@ constexpr int hx3_waves(int HT, int OT, int NT, int prec, int kind, int act_a, i
 #endif
 }
 // minimum waves per SIMD the kernel is compiled for (the register budget): 2 (256 registers) or 1 (512)
-constexpr int hx3_waves_per_simd(int HT, int OT, int NT, int prec, int kind, int act_a, int act_b, int depth = 1) {
+constexpr int hx3_waves_per_simd(int HT, int OT, int NT, int prec, int kind, int act_a, int act_b, int depth = 1, int train = 0) {
+  if (hx3_train_wide(HT, OT, NT, prec, kind, act_a, act_b, depth, train)) return 1;
   return hx3_reg_estimate(HT, OT, NT, prec, kind, act_a, act_b, depth) <= 248 ? 2 : 1;
 }
 // Samples per wave actually compiled for a requested NT: 32-sample waves (NT = 2) of the widest geometries would
 // spill even with one wave per SIMD; their NT = 2 entry runs the 16-sample kernel.
-constexpr int hx3_eff_nt(int HT, int OT, int NT, int prec, int kind, int act_a, int act_b, int depth = 1) {
+constexpr int hx3_eff_nt(int HT, int OT, int NT, int prec, int kind, int act_a, int act_b, int depth = 1, int train = 0) {
+  if (train != 0 && NT == 2) return hx3_train_wide(HT, OT, NT, prec, kind, act_a, act_b, depth, train) ? 2 : 1;
   return (NT == 2 && hx3_reg_estimate(HT, OT, 2, prec, kind, act_a, act_b, depth) > 300) ? 1 : NT;
 }
 
@@ -262,7 +271,7 @@ __device__ __forceinline__ void wait_vmcnt(int n) {
 }
 
 template <int KIND, int HT, int OT, int NT, int ACTA, int ACTB, int PREC, int WV, int DEPTH, int TRAIN = 0>
-__global__ void __launch_bounds__(64 * WV, hx3_waves_per_simd(HT, OT, NT, PREC, KIND, ACTA, ACTB, DEPTH))
+__global__ void __launch_bounds__(64 * WV, hx3_waves_per_simd(HT, OT, NT, PREC, KIND, ACTA, ACTB, DEPTH, TRAIN))
 flow_kernel_hx3(const FlowLaunch p) {
   static_assert(DEPTH >= 0 && DEPTH <= 2, "coupling_network_depth 0, 1 or 2");
   static_assert(!TRAIN || (DEPTH == 1 && PREC == 0), "the training forward exists for depth-1 nets on f16x3");
@@ -1262,8 +1271,8 @@ static hipError_t hx3_launch_wv(FlowLaunch p, bool staggered, hipStream_t s) {
   static hipError_t launch_hx3_##KIND##_##HT##_##OT##_##NT##_##ACTA##_##ACTB##_##PREC##_##DEPTH##_##TRAIN(const FlowLaunch& p0, \
                                                                                      unsigned, hipStream_t s) { \
     constexpr Hx3Layout L(HT, OT, hx3_pieces(PREC), DEPTH);                                                 \
-    constexpr int ENT = hx3_eff_nt(HT, OT, NT, PREC, KIND, ACTA, ACTB, DEPTH);                              \
-    constexpr int WAVES = hx3_waves(HT, OT, ENT, PREC, KIND, ACTA, ACTB, DEPTH);                            \
+    constexpr int ENT = hx3_eff_nt(HT, OT, NT, PREC, KIND, ACTA, ACTB, DEPTH, TRAIN);                           \
+    constexpr int WAVES = hx3_waves(HT, OT, ENT, PREC, KIND, ACTA, ACTB, DEPTH, TRAIN);                         \
     if constexpr (WAVES == 8) {                                                                             \
       const int pairs = tuning_wg_pairs();       /* -1 automatic, 0 never, 1 whenever they fit (gbnf_tuning_set) */        \
       /* two 4-wave workgroups per CU where they fit: 80 KB each, tables included */                        \

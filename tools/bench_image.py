@@ -126,11 +126,26 @@ def main():
                      "peak": peak, "unit": "TFLOP/s", "frac": flops / (gpu_ms * 1e-3) / 1e12 / peak,
                      "vs_f32_mfma_peak": flops / (gpu_ms * 1e-3) / 1e12 / F32_MFMA_PEAK_TFLOPS,
                      "executed_frac": (1.0 if exact else 3.0) * flops / (gpu_ms * 1e-3) / 1e12 / peak,
-                     "traffic": None, "gpu_ms_per_step": gpu_ms, "flops_per_step": flops},
+                     "traffic": measured_traffic(a), "gpu_ms_per_step": gpu_ms, "flops_per_step": flops},
         "cpu_baseline": {"value": ns / cpu_dt, "unit": "images/s", "cores": torch.get_num_threads(), "kind": "port",
                          "sample": f"{passes} pass(es) over {ns} of the {a.batch} images, all {a.components} components + recursion, "
                                    f"torch-CPU oracle in the reference's op order"},
         "speedup_vs_cpu": (a.batch / dt) / (ns / cpu_dt), "max_rel_err_vs_cpu": err}))
+
+
+def measured_traffic(a):
+    """HBM-side bytes per benchmark step (all kernels of the step) from the PMC passes committed under profiles/
+    (2 x FETCH_SIZE + WRITE_SIZE, MI355X_MICROARCH.md) -- only for the exact workload they were taken on."""
+    try:
+        rec = json.load(open(os.path.join(ROOT, "profiles", "image_traffic.json")))
+    except (OSError, ValueError):
+        return None
+    for r in rec.get("workloads", []):
+        w = r.get("workload", {})
+        if (w.get("batch"), w.get("components"), w.get("K"), w.get("L"), w.get("hidden")) == (a.batch, a.components, a.K, a.L, a.hidden) \
+                and os.environ.get("GBNF_MATH", "default") == w.get("math", "default"):
+            return float(r["traffic_bytes_per_step"])
+    return None
 
 
 if __name__ == "__main__":

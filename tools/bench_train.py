@@ -67,6 +67,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--cpu-steps", type=int, default=3)
     ap.add_argument("--tune", action="append", default=[], help="key=value for gbnf_tuning_set (A/B runs)")
+    ap.add_argument("--no-torch-legs", action="store_true", help="skip the eager-PyTorch GPU leg (profiler runs: thousands of tiny dispatches)")
     a = ap.parse_args()
     cfg = CONFIGS[a.config]
     from gbnf_amd import native, synth
@@ -107,11 +108,12 @@ def main():
         torch.cuda.synchronize()
         fw += ev[0].elapsed_time(ev[1]); bw += ev[1].elapsed_time(ev[2])
     fw /= a.steps; bw /= a.steps
-    t_gpu_torch = timed(torch_step(spec, x, dev), a.steps, a.warmup)
+    t_gpu_torch = float("inf") if a.no_torch_legs else timed(torch_step(spec, x, dev), a.steps, a.warmup)
     torch.set_num_threads(min(8, os.cpu_count() or 1))
     xc = x.cpu()
     cpu_fn = torch_step(spec, xc, torch.device("cpu"))
-    cpu_fn()
+    if a.cpu_steps > 0:
+        cpu_fn()
     t0 = time.perf_counter()
     for _ in range(a.cpu_steps):
         cpu_fn()

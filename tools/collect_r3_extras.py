@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""gpurun_out/final/ (tools/r3_final_measure.sh) -> profiles/r3_final_*: the driver's own invocation under the profiler, the
+"""gpurun_out/final/ (tools/r3_final_b.sh, tools/r3_final_c.sh) -> profiles/r3_final_*: the driver's own invocation under the profiler, the
 emulated per-rank lines, the module evaluate loop, the training step (kernel stats, PMC).  Run after collect_final_profiles.py r3."""
 import csv
 import json
@@ -65,7 +65,7 @@ def main():
         out += [r for r in stats_rows(f"prof_train{n}") if "gbnf" in r]
         out.append("#")
         out.append("# PMC (separate passes, --steps 20), per dispatch:")
-        for f in (f"pmc_train{n}.txt", f"pmc_train_hbm{n}.txt"):
+        for f in (f"pmc_train{n}.txt", f"pmc_train_FETCH_SIZE{n}.txt", f"pmc_train_WRITE_SIZE{n}.txt"):
             keep = False
             for line in open(os.path.join(F, f)).read().split("\n"):
                 if "dispatches=" in line:
