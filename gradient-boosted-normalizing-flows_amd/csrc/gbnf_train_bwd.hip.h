@@ -81,8 +81,18 @@ __device__ __forceinline__ float bwd_sum16(float v) {
   return v;
 }
 
+// Waves per SIMD the 4-wave form is compiled for: 2 (256 registers, two workgroups share a CU and cover each other's memory
+// latency: 498 -> 3xx us at N = 65536) where the kernel fits -- its register count is 8 per hidden tile (the saved second-layer
+// activations and the split g_a2 operands) + ~125 (measured: HT = 14 -> 235) -- else 1 (512 registers).
+constexpr int bwd_hx3_occupancy(int KIND, int HT, int OT) {
+#ifdef GBNF_BWD_OCC
+  return GBNF_BWD_OCC;
+#else
+  return 8 * HT + 125 + (KIND == GBNF_KIND_REALNVP ? 8 * OT + 8 : 0) <= 250 ? 2 : 1;
+#endif
+}
 template <int KIND, int HT, int OT, int ACTA, int ACTB, int WV>
-__global__ void __launch_bounds__(64 * WV, WV == 8 ? 2 : 1) bwd_kernel_hx3(const FlowLaunch p) {
+__global__ void __launch_bounds__(64 * WV, WV == 8 ? 2 : bwd_hx3_occupancy(KIND, HT, OT)) bwd_kernel_hx3(const FlowLaunch p) {
   constexpr int WAVES = WV, NP = 2, NT = 1, ZS = 17, IT = 2;
   constexpr int NNETS = (KIND == GBNF_KIND_REALNVP) ? 2 : 1;
   using FL = Hx3LayoutOf<HT, OT, NP, 1>;                 // the forward blob: only its per-step tables are read here
@@ -257,13 +267,8 @@ __global__ void __launch_bounds__(64 * WV, WV == 8 ? 2 : 1) bwd_kernel_hx3(const
     LaneTable tin;
     tin.load(smt + SMALL_HDR + g * NENT);
     float yin[NENT];
-    int mi[NENT], mo[NENT];             // parameter index of every table entry (bwd_tab), -1: none
 #pragma unroll
-    for (int e = 0; e < NENT; ++e) {
-      yin[e] = trace[(tin.slot[e] >= 0 ? tin.slot[e] : 0) * np + row];
-      mi[e] = ptab[g * NENT + e];
-      mo[e] = ptab[4 * NENT + g * NENT + e];
-    }
+    for (int e = 0; e < NENT; ++e) yin[e] = trace[(tin.slot[e] >= 0 ? tin.slot[e] : 0) * np + row];
     // ... and so are net 0's second-layer activations (56 loads for h = 215): one exposed round trip per step, not two
     f32x4 h2first[HT];
     {
@@ -587,7 +592,16 @@ __global__ void __launch_bounds__(64 * WV, WV == 8 ? 2 : 1) bwd_kernel_hx3(const
       return gx;
     };
     // (every LDS read of the section in front of its first write: the slots of a step are distinct, which the compiler cannot
-    //  know -- interleaved, each entry waited for its own LDS round trip behind the previous entry's write)
+    //  know -- interleaved, each entry waited for its own LDS round trip behind the previous entry's write.  The two tables
+    //  are read again here rather than kept in 32-64 registers across the chain: the kernel fits 256 registers with them gone)
+    int mi[NENT], mo[NENT];             // parameter index of every table entry (bwd_tab), -1: none
+#pragma unroll
+    for (int e = 0; e < NENT; ++e) {
+      mi[e] = ptab[g * NENT + e];
+      mo[e] = ptab[4 * NENT + g * NENT + e];
+    }
+    tin.load(smt + SMALL_HDR + g * NENT);
+    tout.load(smt + SMALL_HDR + 160 + g * NENT);
     float gyi[NENT];
 #pragma unroll
     for (int e = 0; e < NENT; ++e) {
