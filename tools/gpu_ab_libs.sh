@@ -1,4 +1,5 @@
 #!/bin/bash
+# GPU box: parity + soak + training tests, then the same benchmarks on two builds of the library (A/B on ONE box; edit the list of libraries)
 D=gpurun_out/r3c18; mkdir -p $D
 ( timeout 1200 python -m pytest tests/test_hip_parity.py tests/test_hip_soak.py tests/test_hip_train.py -q -m gpu -x ) > $D/pytest.txt 2>&1
 echo "pytest rc $?"; tail -3 $D/pytest.txt
