@@ -476,16 +476,25 @@ class BoostedFlow(nn.Module):
 
     def _apply(self, fn, *a, **k):
         self.__dict__.pop("_tensor_cache", None)
+        self.__dict__.pop("_perm_cache", None)
         return super()._apply(fn, *a, **k)
 
     def _component_key(self, c):
+        """What a packed handle of component c depends on: every tensor's version counter and address, every permutation
+        (its serial and its tensor's version), every ActNorm's `inited` flag.  Built on every call of the module (40 tensors:
+        this is host time of the reference's evaluate loop), so attribute walks through nn.Module.__getattr__ are done once
+        per tensor cache, not per call."""
         params, buffers, layers = self._component_tensors(c)
-        key = [int(t._version) for t in params] + [int(t._version) for t in buffers]
+        perms = self.__dict__.setdefault("_perm_cache", {})
+        if c not in perms:
+            perms[c] = [(layer.permutation, layer.actnorm) for layer in layers]
+        key = [t._version for t in params]
+        key += [t._version for t in buffers]
         key += [t.data_ptr() for t in params]
-        for layer in layers:          # a permutation is identified by its tensor and that tensor's version counter
-            perm = layer.permutation
-            key.append((perm.indices_serial, int(perm.indices._version)))
-            key.append(bool(layer.actnorm.inited))
+        for perm, actnorm in perms[c]:    # a permutation is identified by its tensor and that tensor's version counter
+            key.append(perm.indices_serial)
+            key.append(perm.indices._version)
+            key.append(bool(actnorm.inited))
         return tuple(key)
 
     def _check_ready(self, x):
@@ -521,6 +530,9 @@ class BoostedFlow(nn.Module):
         first k (already initialised) steps, computed by the HIP path, with the statistics kernel
         gbnf_actnorm_init."""
         if self.component_type != "glow":
+            return
+        cached = self.__dict__.get("_perm_cache", {}).get(c)          # (built by _component_key: no module-tree walk per call)
+        if cached is not None and all(a.inited for _, a in cached):
             return
         layers = self.flows[c].flow.layers
         if all(bool(l.actnorm.inited) for l in layers):
