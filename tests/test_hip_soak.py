@@ -172,18 +172,22 @@ def test_training_kernels_are_launch_stable(kind, d, h, dev):
     dspec = to_device_spec(spec, dev)
     tr = native.NativeTrainer(dspec)
     n_launch = max(20, LAUNCHES // 4)
-    for n in (77, 2048):
-        x = torch.from_numpy(synth.synth_batch(n, d, seed=n + 1)).to(dev)
-        g_z = torch.from_numpy(synth.synth_batch(n, d, seed=n + 2)).to(dev)
-        g_ldj = torch.ones(n, device=dev)
-        z0 = ldj0 = gx0 = grads0 = None
-        for it in range(n_launch):
-            z, ldj, trace = tr.forward(x, want_trace=True)
-            g_x, grads = tr.backward(x, g_z, g_ldj, want_gx=True, trace=trace)
-            flat = torch.cat([g.reshape(-1) for g in grads if g is not None])
-            if it == 0:
-                z0, ldj0, gx0, grads0 = z, ldj, g_x, flat
-            else:
-                assert torch.equal(z, z0) and torch.equal(ldj, ldj0) and torch.equal(g_x, gx0), (n, it)
-                scale = float(grads0.abs().max().item())
-                assert float((flat - grads0).abs().max().item()) <= 2e-5 * scale, (n, it)
+    try:
+        for n, force_nt in ((77, 0), (2048, 0), (77, 2), (2048, 2)):     # 2: the 32-sample-wave form of the traced forward (large batches)
+            native.tuning_set("force_nt", force_nt)
+            x = torch.from_numpy(synth.synth_batch(n, d, seed=n + 1)).to(dev)
+            g_z = torch.from_numpy(synth.synth_batch(n, d, seed=n + 2)).to(dev)
+            g_ldj = torch.ones(n, device=dev)
+            z0 = ldj0 = gx0 = grads0 = None
+            for it in range(n_launch):
+                z, ldj, trace = tr.forward(x, want_trace=True)
+                g_x, grads = tr.backward(x, g_z, g_ldj, want_gx=True, trace=trace)
+                flat = torch.cat([g.reshape(-1) for g in grads if g is not None])
+                if it == 0:
+                    z0, ldj0, gx0, grads0 = z, ldj, g_x, flat
+                else:
+                    assert torch.equal(z, z0) and torch.equal(ldj, ldj0) and torch.equal(g_x, gx0), (n, it)
+                    scale = float(grads0.abs().max().item())
+                    assert float((flat - grads0).abs().max().item()) <= 2e-5 * scale, (n, it)
+    finally:
+        native.tuning_set("force_nt", 0)

@@ -87,6 +87,38 @@ def test_trainer_forward_and_backward_match_oracle(name, golden_case):
         _check_grads(only_l, l64, f"{name}[{c}] g_z=None")
 
 
+@pytest.mark.parametrize("name", ["g3_glow_d43_h215_c8", "g4_realnvp_d21_h105_c8", "g6_glow_d43_h64_n77", "g6_realnvp_d21_h64_n33",
+                                  "g5_glow_d43_h64_c2_additive", "g5_glow_d43_h64_c2_reverse_relu"])
+def test_traced_forward_on_32_sample_waves(name, golden_case):
+    """From 32768 rows on the traced forward sweep runs 32-sample waves (flow_kernel_hx3<..., NT = 2, TRAIN>, compiled with the
+    512-register budget): the same saves, two 16-sample tiles per wave.  The tuning knob forces that form at the fixtures'
+    sizes (odd tile counts, a lone tile, ragged tails: the spare half of a wave shadows the last tile)."""
+    import torch
+    from gbnf_amd import native
+    from oracle import gbnf_oracle as oracle
+    dev = torch.device("cuda:0")
+    g = golden_case(name)
+    rng = np.random.RandomState(11)
+    spec = g.specs[0]
+    tr = native.NativeTrainer(_dev_spec(spec, dev))
+    x = torch.from_numpy(g.x).to(dev)
+    g_z = rng.standard_normal(g.x.shape).astype(np.float32)
+    g_l = rng.standard_normal(g.x.shape[0]).astype(np.float32)
+    z64, ldj64 = oracle.component_forward(spec, g.x, backend="numpy64")
+    gx64, grads64 = oracle.component_grads(spec, g.x, g_z, g_l)
+    native.tuning_set("force_nt", 2)
+    try:
+        z, ldj, trace = tr.forward(x, want_trace=True)
+        gx, grads = tr.backward(x, torch.from_numpy(g_z).to(dev), torch.from_numpy(g_l).to(dev), want_gx=True, trace=trace)
+        torch.cuda.synchronize()
+    finally:
+        native.tuning_set("force_nt", 0)
+    assert rel_err(ldj.cpu().numpy(), ldj64) < 1e-5
+    assert np.abs(z.cpu().numpy() - z64).max() <= 1e-5 * max(1.0, float(np.abs(z64).max()))
+    _check_grads(grads, grads64, f"{name} NT=2")
+    assert np.abs(gx.cpu().numpy() - gx64).max() <= G_RTOL * float(np.abs(gx64).max())
+
+
 @pytest.mark.parametrize("name", GRADS_CASES)
 def test_trainer_matches_reference_backward(name):
     """g10: the reference's own nll.backward()."""
