@@ -1572,14 +1572,13 @@ struct LiveBlob {
   const char* name_bwd = nullptr;
   int bwd_waves = 4;                    // waves per workgroup of the backward launch (bwd_hx3_waves)
   int ht = 0;                           // hidden tiles of the kernel variant
+  bool tilesB_packed = false;           // the last re-pack included the transposed tiles
 };
 
-// the device twin of put_tile(): lane (i,g) of block `tile` computes its 8 values and writes 4 words per piece
-__global__ void __launch_bounds__(64) live_tiles_kernel(const LiveTile* __restrict__ tiles, const LiveLayer* __restrict__ layers,
-                                                        uint32_t* __restrict__ blob) {
-  const LiveTile T = tiles[blockIdx.x];
+// the device twin of put_tile(): lane (i,g) computes its 8 values of one tile and writes 4 words per piece
+__device__ __forceinline__ void live_tile(const LiveTile T, const LiveLayer* __restrict__ layers, uint32_t* __restrict__ blob, int lane) {
   const LiveLayer L = layers[T.lid];
-  const int lane = threadIdx.x, i = lane & 15, gg = lane >> 4;
+  const int i = lane & 15, gg = lane >> 4;
 #pragma unroll
   for (int q = 0; q < 4; ++q) {
     uint32_t w[2] = {0u, 0u};
@@ -1605,16 +1604,20 @@ __global__ void __launch_bounds__(64) live_tiles_kernel(const LiveTile* __restri
     blob[T.dst + 256 + (size_t)lane * 4 + q] = w[1];
   }
 }
+__global__ void __launch_bounds__(64) live_tiles_kernel(const LiveTile* __restrict__ tiles, const LiveLayer* __restrict__ layers,
+                                                        uint32_t* __restrict__ blob) {
+  live_tile(tiles[blockIdx.x], layers, blob, (int)threadIdx.x);
+}
 
 // biases (folded row sums in double, like the host packer), live table entries, per-step log-det constants
-__global__ void __launch_bounds__(256) live_small_kernel(const LiveBias* __restrict__ bias, int n_bias, const LiveEntry* __restrict__ ent,
-                                                         int n_ent, const LiveNorm* __restrict__ norms, int K, int d, int glow,
-                                                         const LiveLayer* __restrict__ layers, uint32_t* __restrict__ blob) {
+__device__ __forceinline__ void live_small(int block, const LiveBias* __restrict__ bias, int n_bias, const LiveEntry* __restrict__ ent,
+                                           int n_ent, const LiveNorm* __restrict__ norms, int K, int d, int glow,
+                                           const LiveLayer* __restrict__ layers, uint32_t* __restrict__ blob) {
   auto put = [&](uint32_t off, float v) { blob[off] = __builtin_bit_cast(uint32_t, v); };
   // biases: 16 lanes per word (the folded row sum of a tanh layer runs over up to 512 weights: one thread per row took 50 us)
   const int n_bias_blocks = (n_bias + 15) / 16;
-  if ((int)blockIdx.x < n_bias_blocks) {
-    const int w = blockIdx.x * 16 + (threadIdx.x >> 4), sub = threadIdx.x & 15;
+  if (block < n_bias_blocks) {
+    const int w = block * 16 + (threadIdx.x >> 4), sub = threadIdx.x & 15;
     if (w < n_bias) {                       // (uniform per group of 16 lanes)
       const LiveBias B = bias[w];
       double acc = 0.0;
@@ -1630,7 +1633,7 @@ __global__ void __launch_bounds__(256) live_small_kernel(const LiveBias* __restr
     }
     return;
   }
-  const int t = n_bias + ((int)blockIdx.x - n_bias_blocks) * blockDim.x + threadIdx.x;
+  const int t = n_bias + (block - n_bias_blocks) * blockDim.x + threadIdx.x;
   if (t < n_bias + n_ent) {
     const LiveEntry E = ent[t - n_bias];
     const LiveNorm N = norms[E.step];
@@ -1651,6 +1654,23 @@ __global__ void __launch_bounds__(256) live_small_kernel(const LiveBias* __restr
     }
     put(N.ld_dst, acc);
   }
+}
+// ONE launch re-derives everything a training step's kernels read from the live parameters: the forward blob's tiles, the
+// transposed tiles of the backward sweep (when one will follow: the trace contract), the biases / tables / log-det constants.
+// (Three launches of ~6 us each were 8 % of the N = 4096 training step.)  256 threads: four tiles per block, then the small work.
+__global__ void __launch_bounds__(256) live_pack_kernel(const LiveTile* __restrict__ tiles, int n_tiles, const LiveTile* __restrict__ tilesB,
+                                                        int n_tilesB, uint32_t* __restrict__ blobB, const LiveBias* __restrict__ bias,
+                                                        int n_bias, const LiveEntry* __restrict__ ent, int n_ent,
+                                                        const LiveNorm* __restrict__ norms, int K, int d, int glow,
+                                                        const LiveLayer* __restrict__ layers, uint32_t* __restrict__ blob) {
+  const int tile_blocks = (n_tiles + n_tilesB + 3) / 4;
+  if ((int)blockIdx.x < tile_blocks) {
+    const int t = (int)blockIdx.x * 4 + (int)(threadIdx.x >> 6), lane = (int)(threadIdx.x & 63);
+    if (t < n_tiles) live_tile(tiles[t], layers, blob, lane);
+    else if (t < n_tiles + n_tilesB) live_tile(tilesB[t - n_tiles], layers, blobB, lane);
+    return;
+  }
+  live_small((int)blockIdx.x - tile_blocks, bias, n_bias, ent, n_ent, norms, K, d, glow, layers, blob);
 }
 
 void live_blob_destroy(LiveBlob* lb) {
@@ -1918,9 +1938,11 @@ int live_blob_hidden_rows(const LiveBlob* lb) { return lb ? 16 * lb->ht : 0; }
 int live_blob_backward(LiveBlob* lb, int64_t n, const float* trace, float* acts, int64_t np, int ip, int hp, int op,
                        const float* g_z, const float* g_ldj, float* g_x, float* grads, const unsigned* gmax, void* stream) {
   hipStream_t s = (hipStream_t)stream;
-  // the transposed tiles of the CURRENT parameter values (the forward call that wrote the trace saw the same ones)
-  hipLaunchKernelGGL(live_tiles_kernel, dim3((unsigned)lb->n_tilesB), dim3(64), 0, s, (const LiveTile*)lb->tilesB_dev,
-                     (const LiveLayer*)lb->layers_dev, lb->blobB_dev);
+  // the transposed tiles were packed by the forward call that wrote the trace (the parameters are unchanged since: the trace
+  // contract of include/gbnf.h); a trainer that has not run one yet packs them here
+  if (!lb->tilesB_packed)
+    hipLaunchKernelGGL(live_tiles_kernel, dim3((unsigned)lb->n_tilesB), dim3(64), 0, s, (const LiveTile*)lb->tilesB_dev,
+                       (const LiveLayer*)lb->layers_dev, lb->blobB_dev);
   FlowLaunch p{};
   p.blobs = lb->table_dev; p.blobs_bwd = lb->tableB_dev;
   p.n = n; p.d = lb->d; p.n_steps = lb->K; p.n_comp = 1; p.n_batches = 1; p.additive = lb->additive;
@@ -1944,13 +1966,15 @@ int live_blob_backward(LiveBlob* lb, int64_t n, const float* trace, float* acts,
   return GBNF_OK;
 }
 
-static void live_blob_repack(LiveBlob* lb, hipStream_t s) {
-  hipLaunchKernelGGL(live_tiles_kernel, dim3((unsigned)lb->n_tiles), dim3(64), 0, s, (const LiveTile*)lb->tiles_dev,
-                     (const LiveLayer*)lb->layers_dev, lb->blob_dev);
+static void live_blob_repack(LiveBlob* lb, hipStream_t s, bool with_backward = false) {
+  const int n_tilesB = (with_backward && lb->launch_bwd != nullptr) ? lb->n_tilesB : 0;
   const int small_blocks = (lb->n_bias + 15) / 16 + (lb->n_entries + lb->K + 255) / 256;
-  hipLaunchKernelGGL(live_small_kernel, dim3((unsigned)small_blocks), dim3(256), 0, s, (const LiveBias*)lb->bias_dev, lb->n_bias,
+  const int tile_blocks = (lb->n_tiles + n_tilesB + 3) / 4;
+  hipLaunchKernelGGL(live_pack_kernel, dim3((unsigned)(tile_blocks + small_blocks)), dim3(256), 0, s, (const LiveTile*)lb->tiles_dev,
+                     lb->n_tiles, (const LiveTile*)lb->tilesB_dev, n_tilesB, lb->blobB_dev, (const LiveBias*)lb->bias_dev, lb->n_bias,
                      (const LiveEntry*)lb->entries_dev, lb->n_entries, (const LiveNorm*)lb->norms_dev, lb->K, lb->d,
                      lb->kind == GBNF_KIND_GLOW ? 1 : 0, (const LiveLayer*)lb->layers_dev, lb->blob_dev);
+  lb->tilesB_packed = n_tilesB > 0;
 }
 
 int live_blob_words(const LiveBlob* lb, uint32_t* out_host, int64_t* n_words) {
@@ -1966,7 +1990,7 @@ int live_blob_words(const LiveBlob* lb, uint32_t* out_host, int64_t* n_words) {
 int live_blob_forward(LiveBlob* lb, const float* x, int64_t n, float* z, float* ldj, float* trace, float* acts, int64_t np,
                       int ip, int hp, int op, void* stream) {
   hipStream_t s = (hipStream_t)stream;
-  live_blob_repack(lb, s);
+  live_blob_repack(lb, s, /*with_backward=*/true);      // (a traced forward call: the backward call follows on the same parameters)
   // 32-sample waves once that still gives every SIMD of the chip a wave, else 16-sample ones (as pick_nt does)
   int nt = pick_nt(n, 1);
   if (lb->launch_nt[nt] == nullptr) nt = 1;
