@@ -1936,7 +1936,8 @@ int live_blob_hidden_rows(const LiveBlob* lb) { return lb ? 16 * lb->ht : 0; }
 // g_z / g_ldj (either may be null) -> g_x (or null), the ActNorm / BatchNorm entries of `grads`, and the gradient-side
 // operands of the weight gradients in `acts` (the workspace the forward sweep filled); gmax: gmax_kernel's result
 int live_blob_backward(LiveBlob* lb, int64_t n, const float* trace, float* acts, int64_t np, int ip, int hp, int op,
-                       const float* g_z, const float* g_ldj, float* g_x, float* grads, const unsigned* gmax, void* stream) {
+                       const float* g_z, const float* g_ldj, float* g_x, float* grads, const unsigned* gmax, void* stream,
+                       LiveReduce* reduce_out) {
   hipStream_t s = (hipStream_t)stream;
   // the transposed tiles were packed by the forward call that wrote the trace (the parameters are unchanged since: the trace
   // contract of include/gbnf.h); a trainer that has not run one yet packs them here
@@ -1959,6 +1960,10 @@ int live_blob_backward(LiveBlob* lb, int64_t n, const float* trace, float* acts,
   hipError_t e = lb->launch_bwd(p, 0u, s);
   if (e != hipSuccess) return fail(GBNF_ERR_HIP, "launch of %s failed: %s", lb->name_bwd, hipGetErrorString(e));
   const int n_wg = (int)((np / 16 + lb->bwd_waves - 1) / lb->bwd_waves);
+  if (reduce_out != nullptr) {
+    *reduce_out = LiveReduce{p.partials, n_wg, lb->K, lb->d, lb->bwd_goff_dev};
+    return GBNF_OK;
+  }
   hipLaunchKernelGGL(bwd_param_reduce_kernel, dim3((unsigned)(2 * lb->K)), dim3(1024), 0, s, (const float*)p.partials, n_wg, lb->K, lb->d,
                      (const int64_t*)lb->bwd_goff_dev, grads);
   e = hipGetLastError();

@@ -31,8 +31,17 @@ struct LiveBlob;
 int live_blob_create(const gbnf_flow_desc* desc, const int64_t* norm_grad_offsets, LiveBlob** out);
 bool live_blob_has_backward(const LiveBlob* lb);
 int live_blob_hidden_rows(const LiveBlob* lb);      // 16 x the hidden tiles of the kernel variant behind it
+// The backward kernel leaves the ActNorm / BatchNorm parameter gradients as per-workgroup partial sums; adding them up (in a
+// fixed order) is a reduction of n_wg rows per (step, parameter array).  With `reduce_out` the caller takes that over (the
+// trainer folds it into wgrad_kernel's launch as extra blocks: one launch less per step); with null it is launched here.
+struct LiveReduce {
+  const float* partials;      // [n_wg][K][2][64]
+  int n_wg, K, d;
+  const int64_t* goff;        // [K][2] float offsets into the flat gradient buffer
+};
 int live_blob_backward(LiveBlob* lb, int64_t n, const float* trace, float* acts, int64_t np, int ip, int hp, int op,
-                       const float* g_z, const float* g_ldj, float* g_x, float* grads, const unsigned* gmax, void* stream);
+                       const float* g_z, const float* g_ldj, float* g_x, float* grads, const unsigned* gmax, void* stream,
+                       LiveReduce* reduce_out = nullptr);
 void live_blob_destroy(LiveBlob* lb);
 // trace: [K][d][np] normalised states (slot layout); acts: the operand workspace (FlowLaunch::acts_out); np: padded rows
 int live_blob_forward(LiveBlob* lb, const float* x, int64_t n, float* z, float* ldj, float* trace, float* acts, int64_t np,

@@ -1003,8 +1003,30 @@ __device__ __forceinline__ void wg_split8(f32x4 lo, f32x4 hi4, u32x4& h, u32x4& 
 // (samples 8 (g & 1) .. + 7 of tile g >> 1) and splits them in registers.  Global -> register -> LDS, one k-step ahead.
 __global__ void __launch_bounds__(WG_THREADS) wgrad_kernel(const WgProblem* __restrict__ probs, int n_probs,
                                                     const float* __restrict__ ws, float* __restrict__ grads, int64_t np, int chunk,
-                                                    const unsigned* __restrict__ gmax) {
+                                                    const unsigned* __restrict__ gmax, int n_blocks, const LiveReduce red) {
   typedef const f32x4 __attribute__((address_space(1)))* gv4;
+  // blocks behind the dW blocks (first sample chunk only): the fixed-order sum of the backward kernel's per-workgroup
+  // ActNorm / BatchNorm gradient partials, grads[goff[kw] + j] += sum_b partials[b][kw][j]  (kw = step * 2 + which)
+  if ((int)blockIdx.x >= n_blocks) {
+    if (blockIdx.y != 0 || red.partials == nullptr) return;
+    __shared__ float rsum[4][64];
+    const int kw = (int)blockIdx.x - n_blocks, j = threadIdx.x & 63, part = threadIdx.x >> 6;
+    const float* src = red.partials + kw * 64 + j;
+    const int64_t stride = (int64_t)red.K * 128;
+    float a0 = 0.0f, a1 = 0.0f, a2 = 0.0f, a3 = 0.0f;
+    int b = part;
+    for (; b + 12 < red.n_wg; b += 16) {
+      a0 += src[(int64_t)b * stride];
+      a1 += src[(int64_t)(b + 4) * stride];
+      a2 += src[(int64_t)(b + 8) * stride];
+      a3 += src[(int64_t)(b + 12) * stride];
+    }
+    for (; b < red.n_wg; b += 4) a0 += src[(int64_t)b * stride];
+    rsum[part][j] = (a0 + a1) + (a2 + a3);
+    __syncthreads();
+    if (part == 0 && j < red.d) grads[red.goff[kw] + j] += (rsum[0][j] + rsum[1][j]) + (rsum[2][j] + rsum[3][j]);
+    return;
+  }
   extern __shared__ __attribute__((aligned(16))) f32x4 wg_stage_raw[];      // 2 x WG_ROWS_MAX * 8 pieces = 80 KB (dynamic: > 64 KB)
   f32x4 (*stage)[WG_ROWS_MAX * 8] = reinterpret_cast<f32x4 (*)[WG_ROWS_MAX * 8]>(wg_stage_raw);
   float alpha = 1.0f, inv_alpha = 1.0f;          // the gradient-side operands were emitted on the scaled gradient
@@ -1678,13 +1700,15 @@ int gbnf_trainer_backward(const gbnf_trainer* t, const float* x, int64_t n, cons
     // round 3: the register-chained backward sweep on what the forward sweep saved behind the trace, then the weight
     // gradients from the operand workspace that now lives there too
     float* acts = const_cast<float*>(trace) + ((int64_t)t->K + 1) * t->d * p.np;
-    const int rc = live_blob_backward(t->live, n, trace, acts, p.np, t->ip, t->hp, t->op, g_z, g_ldj, g_x, grads, t->gmax_dev, stream);
+    LiveReduce red{};
+    const int rc = live_blob_backward(t->live, n, trace, acts, p.np, t->ip, t->hp, t->op, g_z, g_ldj, g_x, grads, t->gmax_dev, stream, &red);
     if (rc) return rc;
     int chunk2 = 512;
     while (chunk2 < 4096 && (int64_t)t->wg_blocks * (p.np / (2 * chunk2)) >= 768) chunk2 *= 2;
-    const dim3 wgrid2((unsigned)t->wg_blocks, (unsigned)((p.np + chunk2 - 1) / chunk2));
+    // (+ 2 K blocks: the sums of the backward kernel's parameter-gradient partials ride in this launch)
+    const dim3 wgrid2((unsigned)(t->wg_blocks + 2 * red.K), (unsigned)((p.np + chunk2 - 1) / chunk2));
     hipLaunchKernelGGL(wgrad_kernel, wgrid2, dim3(WG_THREADS), (size_t)2 * WG_ROWS_MAX * 8 * 16, s, t->probs_dev, t->n_probs,
-                       (const float*)acts, grads, p.np, chunk2, (const unsigned*)t->gmax_dev);
+                       (const float*)acts, grads, p.np, chunk2, (const unsigned*)t->gmax_dev, t->wg_blocks, red);
     const hipError_t e2 = hipGetLastError();
     if (e2 != hipSuccess) return fail(GBNF_ERR_HIP, "gbnf_trainer_backward launch: %s", hipGetErrorString(e2));
     return GBNF_OK;
@@ -1724,7 +1748,7 @@ int gbnf_trainer_backward(const gbnf_trainer* t, const float* x, int64_t n, cons
   if (forced_chunk >= 32 && forced_chunk % 32 == 0) chunk = forced_chunk;
   const dim3 wgrid((unsigned)t->wg_blocks, (unsigned)((p.np + chunk - 1) / chunk));
   hipLaunchKernelGGL(wgrad_kernel, wgrid, dim3(WG_THREADS), (size_t)2 * WG_ROWS_MAX * 8 * 16, s, t->probs_dev, t->n_probs, (const float*)workspace, grads, p.np, chunk,
-                     (const unsigned*)t->gmax_dev);
+                     (const unsigned*)t->gmax_dev, t->wg_blocks, LiveReduce{});
   e = hipGetLastError();
   if (e != hipSuccess) return fail(GBNF_ERR_HIP, "gbnf_trainer_backward wgrad launch: %s", hipGetErrorString(e));
   return GBNF_OK;
