@@ -74,3 +74,24 @@ def test_no_shipped_kernel_reads_a_matrix_result_early():
                            f"{' (across a branch)' if crossed else ''}")
     assert n_mfma > 100000, "the objects of every kernel variant are expected under csrc/obj"
     assert not bad, "\n".join(bad[:20])
+
+
+@pytest.mark.skipif(not _objects(), reason="csrc/obj is empty: build the library first (python __graft_entry__.py)")
+def test_staged_kernels_count_their_lds_reads():
+    """With __builtin_amdgcn_global_load_lds in a kernel hipcc (ROCm 7.2) turns EVERY wait for a ds_read into lgkmcnt(0)
+    (tools/ubench/lgkmcnt_dma.hip); the staging DMA is therefore issued from inline asm (lds_dma16).  A kernel that stages
+    through LDS DMA and reads fragments with ds_read_b128 must show counted waits -- if it does not, the builtin is back."""
+    import re
+    checked = 0
+    for f in _objects():
+        name = os.path.basename(f)
+        if not (name.startswith("v_hx3_0_14_3_2_") or name.startswith("v_hx3t_0_14_3_1_") or name.startswith("v_hx3b_0_14_3_0_0")):
+            continue
+        for kname, insts in lint.disassemble(f).items():
+            if not any(x.mn.startswith("global_load_lds") for x in insts):
+                continue
+            reads = sum(1 for x in insts if x.mn == "ds_read_b128")
+            counted = sum(1 for x in insts if x.mn == "s_waitcnt" and re.search(r"lgkmcnt\(([1-9]\d*)\)", x.text))
+            assert reads >= 50 and counted >= 10, f"{name} {kname[:60]}: {reads} ds_read_b128, {counted} counted lgkmcnt waits"
+            checked += 1
+    assert checked >= 4
