@@ -30,9 +30,11 @@ __device__ __forceinline__ void img_split_pair(float x0, float x1, unsigned& hi,
   hi = __builtin_bit_cast(unsigned, h);
   // the residual x - hi as ONE v_fma_mix_f32 per value (the f16 half is widened inside the instruction), as in
   // gbnf_flow_kernel_hx3.hip.h; LLVM itself emits v_cvt_f32_f16 + v_sub_f32
-  float r0, r1;
-  asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(r0) : "v"(hi), "v"(x0));
-  asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(r1) : "v"(hi), "v"(x1));
+  // IN PLACE: an asm output must never be a fresh register -- the allocator may hand it the dead result register of a v_mfma
+  // still in flight, and the hazard recognizer does not see into asm (gbnf_flow_kernel_hx3.hip.h, split_pair_f16)
+  float r0 = x0, r1 = x1;
+  asm("v_fma_mix_f32 %0, %1, -1.0, %0 op_sel_hi:[1,0,0]" : "+v"(r0) : "v"(hi));
+  asm("v_fma_mix_f32 %0, %1, -1.0, %0 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(r1) : "v"(hi));
   const auto m = __builtin_amdgcn_cvt_pkrtz(r0, r1);
   mid = __builtin_bit_cast(unsigned, m);
 }
