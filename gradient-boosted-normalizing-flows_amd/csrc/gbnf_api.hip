@@ -1883,6 +1883,10 @@ int live_blob_create(const gbnf_flow_desc* desc, const int64_t* norm_grad_offset
   // ---- the backward sweep, where a variant of bwd_kernel_hx3 exists for this geometry (else the caller keeps its own)
   if (e == hipSuccess && norm_grad_offsets != nullptr) {
     const Variant* vb = find_variant(VariantKey{desc->kind, vc.ht, -3, 2, vc.ot, 1, 1, info.act_a, info.act_b});
+    // (the backward kernel keeps every step's tables in LDS: flows of more than LDS_TABLE_STEPS steps, or whose tables + stage
+    //  slots + per-wave state do not fit a CU, keep the round-1 backward kernels -- the forward sweep has a global-table form)
+    if (vb != nullptr && (K > LDS_TABLE_STEPS || bwd_hx3_lds_bytes(K, bwd_hx3_waves(K, LB.STAGE_FRAGS, d), LB.STAGE_FRAGS, d) > 160 * 1024))
+      vb = nullptr;
     if (vb != nullptr) {
       const std::vector<uint32_t> zerosB(step_words_b * K + 64, 0u);      // (padding words stay zero; every tile is rewritten per call)
       std::vector<int64_t> goff(norm_grad_offsets, norm_grad_offsets + 2 * K);

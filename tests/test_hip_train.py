@@ -535,6 +535,30 @@ def test_a_flow_wider_than_no_compiled_variant_keeps_the_round1_path():
         _blob_words("gbnf_debug_trainer_blob", tr.handle)
 
 
+def test_long_flows_fall_back_for_the_backward_sweep_only():
+    """K = 14 > the 12 steps whose tables the backward kernel keeps in LDS: the traced forward still runs on the register-chained
+    kernel (tables read from the blob), the backward on the round-1 kernels -- gradients against the float64 oracle."""
+    import torch
+    from gbnf_amd import native, synth
+    from oracle import gbnf_oracle as oracle
+    dev = torch.device("cuda:0")
+    spec = synth.synth_boosted_specs("glow", 1, 8, 32, 14, seed=5)[0]
+    tr = native.NativeTrainer(_dev_spec(spec, dev))
+    rng = np.random.RandomState(3)
+    xs = synth.synth_batch(300, 8, seed=6)
+    x = torch.from_numpy(xs).to(dev)
+    g_z = rng.standard_normal(xs.shape).astype(np.float32)
+    g_l = rng.standard_normal(xs.shape[0]).astype(np.float32)
+    z64, ldj64 = oracle.component_forward(spec, xs, backend="numpy64")
+    gx64, grads64 = oracle.component_grads(spec, xs, g_z, g_l)
+    z, ldj, trace = tr.forward(x, want_trace=True)
+    assert rel_err(ldj.cpu().numpy(), ldj64) < 1e-5
+    assert np.abs(z.cpu().numpy() - z64).max() <= 1e-5 * max(1.0, float(np.abs(z64).max()))
+    gx, grads = tr.backward(x, torch.from_numpy(g_z).to(dev), torch.from_numpy(g_l).to(dev), want_gx=True, trace=trace)
+    _check_grads(grads, grads64, "K=14")
+    assert np.abs(gx.cpu().numpy() - gx64).max() <= G_RTOL * float(np.abs(gx64).max())
+
+
 @pytest.mark.parametrize("kind,d,h,n", [("glow", 43, 215, 4096), ("glow", 43, 215, 77), ("realnvp", 21, 105, 2000)])
 def test_fast_forward_writes_what_the_backward_needs(kind, d, h, n):
     """z / ldj / trace of the new forward sweep against the round-1 training kernel on the same live parameters, and the
