@@ -320,6 +320,10 @@ def _random_train_cases():
     # `--coupling_network random`: the activation changes from step to step (Glow) / net to net (RealNVP)
     cases.append(("glow", 21, 64, 6, 100, dict(act="random", coupling="affine", permutation="shuffle", depth=1), 954))
     cases.append(("realnvp", 13, 33, 6, 65, dict(coupling_network="random", batch_norm=True, flip_init=0, depth=1), 955))
+    # ... at widths with a per-step-activation variant of their own: the register-chained kernels' run-time activation flag
+    cases.append(("glow", 43, 215, 4, 300, dict(act="random", coupling="affine", permutation="shuffle", depth=1), 960))
+    cases.append(("realnvp", 21, 105, 4, 129, dict(coupling_network="random", batch_norm=True, flip_init=1, depth=1), 961))
+    cases.append(("glow", 43, 256, 3, 77, dict(act="relu", coupling="affine", permutation="reverse", depth=1), 962))
     # ResidualNet coupling networks (1 and 2 blocks)
     cases.append(("realnvp", 21, 64, 3, 100, dict(coupling_network="residual", batch_norm=True, flip_init=1, depth=1), 956))
     cases.append(("realnvp", 21, 215, 2, 2049, dict(coupling_network="residual", batch_norm=False, flip_init=0, depth=1), 957))
