@@ -1703,8 +1703,13 @@ int gbnf_trainer_backward(const gbnf_trainer* t, const float* x, int64_t n, cons
     LiveReduce red{};
     const int rc = live_blob_backward(t->live, n, trace, acts, p.np, t->ip, t->hp, t->op, g_z, g_ldj, g_x, grads, t->gmax_dev, stream, &red);
     if (rc) return rc;
+    // samples per block: the largest power of two that still leaves ~a block per CU (>= 240 blocks) -- measured at N = 65536
+    // with 1024 / 2048 / 4096 / 8192 / 16384 samples per block: 58.5 / 60.8 / 62.1 / 63.1 / 47.8 M samples/s, and 512 is the
+    // best at N = 4096; every further chunk adds a 128 x 128 tile of float atomics per block of dW, every chunk less leaves
+    // CUs idle.  (Not a power of two: 5984 samples per block ran at 55.4 M.)
     int chunk2 = 512;
-    while (chunk2 < 4096 && (int64_t)t->wg_blocks * (p.np / (2 * chunk2)) >= 768) chunk2 *= 2;
+    while ((int64_t)t->wg_blocks * (p.np / (2 * chunk2)) >= 240) chunk2 *= 2;
+    if (const char* e = getenv("GBNF_WG_CHUNK")) { if (atoi(e) > 0) chunk2 = atoi(e); }      // (A/B runs)
     // (+ 2 K blocks: the sums of the backward kernel's parameter-gradient partials ride in this launch)
     const dim3 wgrid2((unsigned)(t->wg_blocks + 2 * red.K), (unsigned)((p.np + chunk2 - 1) / chunk2));
     hipLaunchKernelGGL(wgrad_kernel, wgrid2, dim3(WG_THREADS), (size_t)2 * WG_ROWS_MAX * 8 * 16, s, t->probs_dev, t->n_probs,
