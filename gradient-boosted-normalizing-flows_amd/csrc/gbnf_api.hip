@@ -830,16 +830,19 @@ int gbnf_flow_create_ex(const gbnf_flow_desc* desc, int32_t math_mode, int32_t f
 
   if (math_mode != GBNF_MATH_F32 && math_mode != GBNF_MATH_F16X3 && math_mode != GBNF_MATH_BF16X6 && math_mode != GBNF_MATH_DEFAULT)
     return fail(GBNF_ERR_INVALID, "unknown math mode %d", math_mode);
-  const bool split_shape = depth <= 2 && !ref.residual;      // what the split kernels take: TanhNet / ReLUNet of depth 0, 1 or 2
+  // what the split kernels take: TanhNet / ReLUNet of depth 0, 1 or 2, and ResidualNets of ONE block (the reference's default
+  // coupling_network_depth = 1: two hidden -> hidden layers; round 3 -- kernel key act = GBNF_ACT_RESIDUAL_RELU, depth 2)
+  const bool split_shape = depth <= 2 && (!ref.residual || depth == 2);
+  const int act_a_split = ref.residual ? GBNF_ACT_RESIDUAL_RELU : act_a, act_b_split = ref.residual ? GBNF_ACT_RESIDUAL_RELU : act_b;
   if (!split_shape && (math_mode == GBNF_MATH_F16X3 || math_mode == GBNF_MATH_BF16X6))
-    return fail(GBNF_ERR_UNSUPPORTED, "the split kernels (f16x3 / bf16x6) support TanhNet / ReLUNet of coupling_network_depth <= 2 only (got %s%d)",
+    return fail(GBNF_ERR_UNSUPPORTED, "the split kernels (f16x3 / bf16x6) support TanhNet / ReLUNet of coupling_network_depth <= 2 and one-block ResidualNets only (got %s%d)",
                 ref.residual ? "a ResidualNet, hidden layers " : "", depth);
 
   // ---- pick compiled variants (exact geometry first, then the cheapest zero-padded superset)
   VariantChoice fast, safe, exact;
   const bool want_split = split_shape && math_mode != GBNF_MATH_F32;
-  const bool have_fast = want_split && math_mode != GBNF_MATH_BF16X6 && choose_hx3(desc->kind, h, ot, depth, act_a, act_b, -3, &fast);
-  const bool have_safe = want_split && choose_hx3(desc->kind, h, ot, depth, act_a, act_b, -6, &safe);
+  const bool have_fast = want_split && math_mode != GBNF_MATH_BF16X6 && choose_hx3(desc->kind, h, ot, depth, act_a_split, act_b_split, -3, &fast);
+  const bool have_safe = want_split && choose_hx3(desc->kind, h, ot, depth, act_a_split, act_b_split, -6, &safe);
   const bool retry_per_step = act_a != GBNF_ACT_PER_STEP && !ref.residual;   // the per-step-activation variants are generic supersets
   if (math_mode == GBNF_MATH_F16X3 && !have_fast) {
     if (retry_per_step) return gbnf_flow_create_ex(desc, math_mode, flags | GBNF_CREATE_PER_STEP_ACTIVATION, out);

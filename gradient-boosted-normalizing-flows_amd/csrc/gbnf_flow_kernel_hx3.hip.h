@@ -108,7 +108,8 @@ constexpr int hx3_reg_estimate(int HT, int OT, int NT, int prec, int kind, int a
   const int relu = (act_a != GBNF_ACT_TANH || act_b != GBNF_ACT_TANH) ? 28 : 0;   // measured: ReLU / per-step variants keep more values live
   const int accs = np == 3 ? 3 : 1;                    // running sums per output tile (Products<NP>::NACC)
   // (a second hidden layer keeps the first one's activations AND its own, both as B operands)
-  return (depth == 2 ? 2 : 1) * hc * NT * np * 4 + (nn + accs - 1) * OT * NT * 4 + NT * 4 * (1 + accs) + 2 * NT * np * 4 + 3 * np * 4 + 36 + relu;
+  const int res = act_a == 2 ? HT * NT * 4 : 0;       // a ResidualNet keeps layer 0's raw output tiles
+  return (depth == 2 ? 2 : 1) * hc * NT * np * 4 + (nn + accs - 1) * OT * NT * 4 + NT * 4 * (1 + accs) + 2 * NT * np * 4 + 3 * np * 4 + 36 + relu + res;
 }
 // TRAIN kernels (trace + operand saves, ~40 more registers per sample tile): 32-sample waves run one per SIMD with the
 // 512-register budget, in 4-wave workgroups (a lone 32-sample wave does a pass in the time two co-resident 16-sample waves
@@ -274,6 +275,11 @@ template <int KIND, int HT, int OT, int NT, int ACTA, int ACTB, int PREC, int WV
 __global__ void __launch_bounds__(64 * WV, hx3_waves_per_simd(HT, OT, NT, PREC, KIND, ACTA, ACTB, DEPTH, TRAIN))
 flow_kernel_hx3(const FlowLaunch p) {
   static_assert(DEPTH >= 0 && DEPTH <= 2, "coupling_network_depth 0, 1 or 2");
+  // ACT == 2 (GBNF_ACT_RESIDUAL_RELU): a ResidualNet of ONE block (models/layers.py:246-301) = layer 0 (no activation of its
+  // own) -> [relu -> Linear -> relu -> Linear] + layer 0's output -> final layer: the two-hidden-layer pipeline with the
+  // raw layer-0 tiles kept in registers, added to the second hidden layer's output and split WITHOUT an activation
+  static_assert((ACTA == 2) == (ACTB == 2), "both nets of a step are ResidualNets or neither is");
+  static_assert(ACTA != 2 || DEPTH == 2, "a one-block ResidualNet has two hidden layers");
   static_assert(!TRAIN || (DEPTH == 1 && PREC == 0), "the training forward exists for depth-1 nets on f16x3");
   constexpr int WAVES = WV;
   constexpr int NP = hx3_pieces(PREC);
@@ -683,11 +689,11 @@ flow_kernel_hx3(const FlowLaunch p) {
         if (ACT == GBNF_ACT_TANH) return tanh_hx3(v);
         float r = __builtin_fmaxf(v, 0.0f);
         if constexpr (WATCH) {
-          if (ACT == GBNF_ACT_RELU) amax[nt] = __builtin_fmaxf(amax[nt], r);
+          if (ACT == GBNF_ACT_RELU || ACT == 2) amax[nt] = __builtin_fmaxf(amax[nt], r);
           else amax[nt] = __builtin_fmaxf(amax[nt], relu_rt ? r : 0.0f);
           r = __builtin_fminf(r, 65504.0f);
         }
-        if (ACT == GBNF_ACT_RELU) return r;
+        if (ACT == GBNF_ACT_RELU || ACT == 2) return r;
         const float t = tanh_hx3(v);
         return relu_rt ? r : t;
       };
@@ -732,6 +738,21 @@ flow_kernel_hx3(const FlowLaunch p) {
 #pragma unroll
         for (int k = 0; k < NP; ++k) asm volatile("" : "+v"(pc[k]));
       };
+      // ResidualNet: the block's output tile = second hidden layer's tile + the raw layer-0 tile, handed to the final layer
+      // as it is (no activation): range-watched and clamped like a ReLU activation
+      constexpr bool RES = (ACTA == 2);
+      f32x4 t0r[RES ? HT : 1][NT];
+      auto res_split = [&](const f32x4& raw, const f32x4& t0, int hp, int nt, unsigned (&pc)[NP]) {
+        float v0 = raw[2 * hp] + t0[2 * hp], v1 = raw[2 * hp + 1] + t0[2 * hp + 1];
+        if constexpr (WATCH) {
+          amax[nt] = __builtin_fmaxf(amax[nt], __builtin_fmaxf(__builtin_fabsf(v0), __builtin_fabsf(v1)));
+          v0 = __builtin_amdgcn_fmed3f(v0, -65504.0f, 65504.0f);
+          v1 = __builtin_amdgcn_fmed3f(v1, -65504.0f, 65504.0f);
+        }
+        split_pair<NP>(v0, v1, pc);
+#pragma unroll
+        for (int k = 0; k < NP; ++k) asm volatile("" : "+v"(pc[k]));
+      };
       // acc[nt] += W . X[nt] for one weight tile (NP pieces) and the B operands of the wave's NT sample tiles
       auto mac = [&](const Unit& a, const u32x4 (&x)[NT][NP], Acc (&acc)[NT]) {
 #pragma unroll
@@ -762,6 +783,10 @@ flow_kernel_hx3(const FlowLaunch p) {
         f32x4 raw[NT];
         auto finish_tile = [&](int t) {       // tile t (held in raw) -> its half of chunk t/2
           const int c = t >> 1, hf = t & 1;
+          if constexpr (RES) {
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) t0r[t][nt] = raw[nt];
+          }
 #pragma unroll
           for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
@@ -965,7 +990,8 @@ flow_kernel_hx3(const FlowLaunch p) {
                 for (int q = n; q < 2 * NT; q += HC) {
                   const int nt = q >> 1, hp = q & 1;
                   unsigned pc[NP];
-                  act_split(pre[nt], hp, nt, pc, DEPTH, u - 1);
+                  if constexpr (RES) res_split(pre[nt], t0r[u - 1][nt], hp, nt, pc);
+                  else act_split(pre[nt], hp, nt, pc, DEPTH, u - 1);
 #pragma unroll
                   for (int k = 0; k < NP; ++k) hO[nt][k][(PREV == 2 ? 2 : 0) + hp] = pc[k];
                 }
@@ -993,10 +1019,19 @@ flow_kernel_hx3(const FlowLaunch p) {
         } else {
           pass(0, I0{}, BF{});
           int u = 1;
+          if constexpr (RES) {       // (the raw layer-0 tile of pass u is a register array indexed by u: compile-time passes)
+#pragma unroll
+            for (int uu = 1; uu + 2 < HT; uu += 2) {
+              pass(uu, I1{}, BF{});
+              pass(uu + 1, I2{}, BF{});
+            }
+            u = 1 + 2 * ((HT - 2) / 2);
+          } else {
 #pragma unroll 1
-          for (; u + 2 < HT; u += 2) {
-            pass(u, I1{}, BF{});
-            pass(u + 1, I2{}, BF{});
+            for (; u + 2 < HT; u += 2) {
+              pass(u, I1{}, BF{});
+              pass(u + 1, I2{}, BF{});
+            }
           }
           if constexpr (HT % 2 == 1) {       // two passes left: HT-2 (odd), HT-1 (even, last)
             pass(u, I1{}, BF{});
@@ -1028,7 +1063,8 @@ flow_kernel_hx3(const FlowLaunch p) {
 #pragma unroll
             for (int hp = 0; hp < 2; ++hp) {
               unsigned pc[NP];
-              act_split(pre[nt], hp, nt, pc, DEPTH, HT - 1);
+              if constexpr (RES) res_split(pre[nt], t0r[HT - 1][nt], hp, nt, pc);
+              else act_split(pre[nt], hp, nt, pc, DEPTH, HT - 1);
 #pragma unroll
               for (int k = 0; k < NP; ++k) hO[nt][k][(odd_last ? 2 : 0) + hp] = pc[k];
             }

@@ -52,7 +52,8 @@ enum { GBNF_COUPLING_AFFINE = 0, GBNF_COUPLING_ADDITIVE = 1 };
 /* How the coupling-network matrix products are evaluated:
  *   F32     exact f32 MFMA (v_mfma_f32_16x16x4_f32), bitwise an ordered fmaf chain (depth 0 / 1 / 2, ResidualNets of <= 2 blocks; hidden <= 512);
  *   F16X3   each f32 operand split into two fp16 pieces (22 significand bits); a.b = a_mid.b_hi + a_hi.b_mid +
- *           a_hi.b_hi on the f16 matrix pipe with f32 accumulation (TanhNet / ReLUNet, coupling_network_depth 0 / 1 / 2, hidden <= 512): the fast
+ *           a_hi.b_hi on the f16 matrix pipe with f32 accumulation (TanhNet / ReLUNet, coupling_network_depth 0 / 1 / 2, hidden <= 512;
+ *           since round 3 ResidualNets of ONE block -- the reference's default depth -- with hidden <= 256): the fast
  *           path, ~1e-7 relative in the log-likelihood on well-conditioned models.  An operand beyond the fp16 range
  *           (|v| > 65504) cannot be represented: the kernel marks such samples and a bf16x6 repair pass behind every
  *           f16x3 launch re-evaluates them (same stream, no host synchronisation), so results are range-safe;
@@ -60,7 +61,8 @@ enum { GBNF_COUPLING_AFFINE = 0, GBNF_COUPLING_ADDITIVE = 1 };
  *           ~2x the matrix work of F16X3 (same shapes as F16X3);
  *   DEFAULT per component: both split packings are built and a probe batch (128 rows ~ N(0,1) / N(0,4)) is evaluated
  *           on both at creation; F16X3 if they agree to 2.5e-6 relative in the log-likelihood, else BF16X6 (ill-conditioned
- *           models: e.g. un-normalised ReLU RealNVPs); F32 where no split kernel applies (ResidualNets).
+ *           models: e.g. un-normalised ReLU RealNVPs); F32 where no split kernel applies (ResidualNets of two blocks or wider
+ *           than 256).
  *           Env GBNF_MATH=f32|f16x3|bf16x6 overrides DEFAULT in gbnf_flow_create. */
 enum { GBNF_MATH_DEFAULT = -1, GBNF_MATH_F32 = 0, GBNF_MATH_F16X3 = 1, GBNF_MATH_BF16X6 = 2 };
 

@@ -191,7 +191,8 @@ def test_residual_coupling_networks(blocks, dev):
     d, h, K = 21, 105, 4
     specs = synth.synth_boosted_specs("realnvp", 3, d, h, K, seed=33, coupling_network="residual", depth=blocks)
     mix, flows = _mixture(specs)
-    assert flows[0].info().math_mode == native.MATH["f32"]
+    # one block (the reference's default depth) runs on the split kernels since round 3; two blocks on the exact-f32 kernel
+    assert (flows[0].info().math_mode == native.MATH["f32"]) == (blocks == 2)
     rho = oracle.rho_init(3)
     for n in (50, 5000):
         xs = synth.synth_batch(n, d, seed=n)
@@ -204,8 +205,23 @@ def test_residual_coupling_networks(blocks, dev):
     xr, ldj_inv = flows[2].inverse(z)
     assert np.abs(xr.cpu().numpy() - x).max() < 5e-4
     assert np.abs((ldj + ldj_inv).cpu().numpy()).max() < 1e-3
-    with pytest.raises(native.GbnfError):
-        native.NativeFlow(specs[0], math="f16x3")
+    if blocks == 2:
+        with pytest.raises(native.GbnfError):
+            native.NativeFlow(specs[0], math="f16x3")
+    else:                                       # every math mode against the oracle, 16- and 32-sample waves
+        xs = synth.synth_batch(700, d, seed=5)
+        z64, ldj64 = oracle.component_forward(specs[1], xs, backend="numpy64")
+        for math in ("f32", "f16x3", "bf16x6"):
+            f = native.NativeFlow(specs[1], math=math)
+            for nt in (1, 2):
+                native.tuning_set("force_nt", nt)
+                try:
+                    zz, ll_, _ = f.forward(torch.from_numpy(xs).to(dev))
+                    torch.cuda.synchronize()
+                finally:
+                    native.tuning_set("force_nt", 0)
+                assert rel_err(ll_.cpu().numpy(), ldj64) < LL_RTOL, (math, nt)
+                assert np.abs(zz.cpu().numpy() - z64).max() <= 2e-5 * max(1.0, float(np.abs(z64).max())), (math, nt)
 
 
 def test_out_of_range_samples_are_repaired(dev):
@@ -351,10 +367,12 @@ def test_default_math_mode_and_mode_agreement(dev):
     for depth in (0, 2):
         deep = synth.synth_glow_spec(43, 64, 3, depth=depth, seed=3)
         assert native.NativeFlow(deep).info().math_mode == native.MATH["f16x3"]
-    res = synth.synth_realnvp_spec(21, 64, 3, coupling_network="residual", seed=3)
-    assert native.NativeFlow(res).info().math_mode == native.MATH["f32"]
+    res = synth.synth_realnvp_spec(21, 64, 3, coupling_network="residual", seed=3)          # one block: split kernels (round 3)
+    assert native.NativeFlow(res).info().math_mode != native.MATH["f32"]
+    res2 = synth.synth_realnvp_spec(21, 64, 3, coupling_network="residual", depth=2, seed=3)  # two blocks: exact-f32 kernel only
+    assert native.NativeFlow(res2).info().math_mode == native.MATH["f32"]
     with pytest.raises(native.GbnfError):
-        native.NativeFlow(res, math="f16x3")
+        native.NativeFlow(res2, math="f16x3")
     x = torch.from_numpy(synth.synth_batch(4096, 43, seed=9)).to(dev)
     a = native.NativeFlow(spec, math="f32").forward(x, want_ll=True)
     b = native.NativeFlow(spec, math="f16x3").forward(x, want_ll=True)

@@ -45,7 +45,9 @@ def spec_for(kind, ht, ot, acta, actb, depth, seed=3):
         act = {(0, 0): "tanh", (1, 1): "relu", (3, 3): "random"}[(acta, actb)]
         return synth.synth_glow_spec(d, h, 2, depth=depth, act=act, seed=seed), d, acta == 3
     d = 21 if ot == 1 else 63
-    net = {(0, 0): "tanh", (1, 1): "relu", (1, 0): "mixed", (3, 3): "random"}[(acta, actb)]
+    net = {(0, 0): "tanh", (1, 1): "relu", (1, 0): "mixed", (3, 3): "random", (2, 2): "residual"}[(acta, actb)]
+    if net == "residual":         # the variant's depth counts hidden -> hidden layers: two per ResidualNet block
+        depth //= 2
     return synth.synth_realnvp_spec(d, h, 2, depth=depth, coupling_network=net, flip_init=1, seed=seed), d, acta == 3
 
 
