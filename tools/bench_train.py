@@ -67,6 +67,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--cpu-steps", type=int, default=3)
     ap.add_argument("--tune", action="append", default=[], help="key=value for gbnf_tuning_set (A/B runs)")
+    ap.add_argument("--graph", action="store_true", help="also time the step captured once in a HIP graph and replayed (torch.cuda.CUDAGraph)")
     ap.add_argument("--no-torch-legs", action="store_true", help="skip the eager-PyTorch GPU leg (profiler runs: thousands of tiny dispatches)")
     a = ap.parse_args()
     cfg = CONFIGS[a.config]
@@ -97,6 +98,20 @@ def main():
         return (time.perf_counter() - t0) / steps
 
     t_hip = timed(hip_step, a.steps, a.warmup)
+    t_graph = None
+    if a.graph:
+        # the library only enqueues on the current stream (no host synchronisation, no allocation of its own after the first
+        # call), so a whole training step -- pack, forward, loss gradient, backward, weight gradients -- captures into ONE graph
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(3):
+                hip_step()
+        torch.cuda.current_stream().wait_stream(side)
+        gr = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(gr):
+            out_static = hip_step()
+        t_graph = timed(gr.replay, a.steps, a.warmup)
     # kernel-only: events around forward, backward
     ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
     z, ldj, trace = tr.forward(x, want_trace=True)
@@ -123,6 +138,7 @@ def main():
     print(json.dumps({
         "metric": f"training step (forward+backward) samples/sec, one component, {a.config}", "unit": "samples/s",
         "value": n / t_hip, "ms_per_step": t_hip * 1e3, "batch": n,
+        "hip_graph_replay": None if t_graph is None else {"value": n / t_graph, "ms_per_step": t_graph * 1e3},
         "forward_kernel_ms": fw, "backward_kernels_ms": bw,
         "algorithmic_tflops": flops / t_hip / 1e12, "algorithmic_tflops_kernels_only": flops / ((fw + bw) * 1e-3) / 1e12,
         "torch_gpu_eager": {"value": n / t_gpu_torch, "ms_per_step": t_gpu_torch * 1e3},
