@@ -448,6 +448,44 @@ class BoostedImageFlow(nn.Module):
             cur.wait_stream(streams[(x.device, c)])
         return torch.stack(lls, dim=1)
 
+    def graphed_log_prob(self, batch, n_used=None):
+        """-> ``f(x, noise) -> G (N,)``: ``log_prob`` for batches of ``batch`` images captured ONCE in a HIP graph and
+        replayed (static input / output buffers, the components' streams forked and joined inside the graph).  A component is a
+        chain of ~50 short launches, so an evaluation call is host-bound as plain stream launches: the replay is 12 % faster at
+        batch 256 (tools/bench_image.py, 62 -> 69.5 k images/s).  The graph holds the packed handles of the parameters it was
+        captured with: ``f`` re-captures by itself when a parameter, permutation or ActNorm flag has changed since.  The
+        returned tensor is the graph's output buffer -- overwritten by the next call of ``f``."""
+        n_used = self.num_components if n_used is None else int(n_used)
+        dev = self.rho.device
+        state = {}
+
+        def key():
+            return tuple(id(self.native_flow(c)) for c in range(n_used))
+
+        def capture():
+            c_, h_, w_ = self.flows[0].input_size
+            xs = torch.zeros((batch, c_, h_, w_), dtype=torch.float32, device=dev)
+            ns = torch.zeros_like(xs)
+            side = torch.cuda.Stream(dev)
+            side.wait_stream(torch.cuda.current_stream(dev))
+            with torch.cuda.stream(side), torch.no_grad():
+                self.log_prob(xs, n_used, ns)                    # warm-up: stream creation, first-use attributes
+            torch.cuda.current_stream(dev).wait_stream(side)
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g), torch.no_grad():
+                out = self.log_prob(xs, n_used, ns)
+            state.update(key=key(), graph=g, x=xs, noise=ns, out=out)
+
+        def f(x, noise):
+            if state.get("key") != key():
+                capture()
+            state["x"].copy_(x)
+            state["noise"].copy_(noise)
+            state["graph"].replay()
+            return state["out"]
+
+        return f
+
     def log_prob(self, x, n_used=None, noise=None):
         """(N,): log mixture density with the reference's recursion over rho (density_experiment.py:561-573)."""
         ll = self.component_log_prob(x, n_used, noise)

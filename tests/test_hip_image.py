@@ -90,6 +90,14 @@ def test_image_module_dropin_matches_reference():
         ll = m.component_log_prob(xd, noise=nd)
         assert rel_err(ll.cpu().numpy().T, data["ll"]) < LL_RTOL
         assert rel_err(m.log_prob(xd, noise=nd).cpu().numpy(), data["G"]) < LL_RTOL
+        # the same call captured once in a HIP graph and replayed: identical results; a changed parameter re-captures
+        f = m.graphed_log_prob(xd.shape[0])
+        G_eager = m.log_prob(xd, noise=nd)
+        assert torch.equal(f(xd, nd), G_eager) and torch.equal(f(xd, nd), G_eager)
+        next(m.flows[0].parameters()).add_(1e-3)                    # (in place: the version counter moves, the handle is rebuilt)
+        G_new = m.log_prob(xd, noise=nd)
+        assert not torch.equal(G_new, G_eager)
+        assert torch.equal(f(xd, nd), G_new)
         z, z_mu, z_var, ldj, y = m(x=xd, components=1)              # fresh noise: shapes and the constant prior only
         assert y is None and z.shape == (cfg["N"], 24, 8, 8) and z_mu.shape == z.shape and z_var.shape == z.shape
         assert torch.isfinite(ldj).all()
