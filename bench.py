@@ -137,13 +137,16 @@ def cpu_baseline(specs, rho, x_np, budget_s):
     }, G, n
 
 
-def module_evaluate_leg(specs, kind, d, h, K, C, x, iters=100):
+def module_evaluate_leg(specs, kind, d, h, K, C, xs, iters=100):
     """What "drops into density_experiment.py unchanged" costs: the reference's evaluate loop
     (density_experiment.py:561-573: one model(x=x, components=c) call per component, the base density and the 2-way
-    logsumexp recursion in torch ops) through the drop-in module, host time included, and the module's one-call form."""
+    logsumexp recursion in torch ops) through the drop-in module, host time included, and the module's one-call form.
+    Every iteration evaluates ANOTHER batch tensor (xs is cycled, as a data loader would): since round 4 the module serves the
+    loop's C calls on one batch from ONE launch, and a loop over one and the same tensor would time table look-ups only."""
     import math
     import torch
     from gbnf_amd import BoostedFlow
+    x = xs[0]
     dev = x.device
     ns = argparse.Namespace(
         num_flows=K, z_size=d, density_evaluation=True, device=dev, cuda=True, component_type=kind, num_components=C,
@@ -157,7 +160,13 @@ def module_evaluate_leg(specs, kind, d, h, K, C, x, iters=100):
     model.all_trained = True
     model.eval()
 
+    if len(xs) < 2:
+        raise ValueError("module_evaluate_leg needs at least two distinct batches")
+    turn = [0]
+
     def reference_loop():
+        x = xs[turn[0] % len(xs)]
+        turn[0] += 1
         G_ll = None
         for c in range(model.component + 1):
             z_G, _, _, ldj_G, _ = model(x=x, components=c)
@@ -182,14 +191,19 @@ def module_evaluate_leg(specs, kind, d, h, K, C, x, iters=100):
             torch.cuda.synchronize()
         return (time.perf_counter() - t0) / iters, out
 
-    t_loop, G_loop = timed(reference_loop)
+    t_loop, _ = timed(reference_loop)
+    turn[0] = 0
+    with torch.no_grad():
+        G_loop = reference_loop()          # batch 0: what the pipeline's G0 and log_prob(x) below are compared with
     t_one, G_one = timed(lambda: model.log_prob(x))
     n = x.shape[0]
     return {"value": n / t_loop, "unit": "samples/s", "ms_per_batch": 1e3 * t_loop, "iters": iters,
             "log_prob_one_call_value": n / t_one, "log_prob_one_call_ms": 1e3 * t_one,
             "max_abs_diff_loop_vs_one_call": float((G_loop - G_one).abs().max().item()),
-            "note": "the reference's own evaluate loop through the drop-in BoostedFlow module: C forward calls returning "
-                    "(z, ldj) + the base density and the recursion in torch ops, host time included; "
+            "batches_cycled": len(xs),
+            "note": "the reference's own evaluate loop through the drop-in BoostedFlow module, a different batch tensor every "
+                    "iteration: C forward calls returning (z, ldj) -- the first launches all C components of the batch, the "
+                    "others read its table -- + the base density and the recursion in torch ops, host time included; "
                     "log_prob_one_call = model.log_prob(x) (one flow launch + one recursion launch)"}, G_loop
 
 
@@ -207,6 +221,51 @@ def measured_traffic(config, B, C, S, math, world):
                 and w.get("math") == math and w.get("n_gpus") == world):
             return float(r["traffic_bytes_per_launch"])
     return None
+
+
+def config_legs(args):
+    """The other BASELINE.json configurations, each as a CHILD process that runs before this one touches the GPU (a process
+    that has initialised the GPU must not start another program; the children run one after the other, alone on the device):
+    configs[1] MINIBOONE Boosted-Glow C=4 batch 4096, configs[2] HEPMASS Boosted-RealNVP C=8 batch 65536, configs[3] CIFAR-10
+    multi-scale Boosted-Glow C=4 (batch 256, HIP-graph replay of the whole step), and the one-component training step at
+    N = 65536.  Each leg carries value / dtype / roofline{frac, executed_frac, traffic} / cpu_baseline from
+    its own run (bounded CPU samples: ~3 s each); a leg that fails reports its error and never takes the headline down."""
+    py = sys.executable
+    bench = os.path.abspath(__file__)
+    tools = os.path.join(REPO, "tools")
+    cpu = str(min(3.0, args.cpu_seconds))
+    jobs = [
+        ("miniboone_glow_c4_n4096", [py, bench, "--config", "miniboone_glow", "--components", "4", "--steps", "2048", "--prewarm", "0.1",
+                                     "--cpu-seconds", cpu, "--no-extra-legs", "--no-config-legs"]),
+        ("hepmass_realnvp_c8_n65536", [py, bench, "--config", "hepmass_realnvp", "--steps", "256", "--warmup", "32", "--prewarm", "0.02",
+                                       "--cpu-seconds", cpu, "--no-extra-legs", "--no-config-legs"]),
+        ("cifar10_glow_c4_n256", [py, os.path.join(tools, "bench_image.py"), "--batch", "256", "--steps", "10", "--warmup", "2",
+                                  "--cpu-seconds", cpu]),
+        ("train_step_miniboone_c1_n65536", [py, os.path.join(tools, "bench_train.py"), "--batch", "65536", "--steps", "30", "--warmup", "5",
+                                            "--cpu-steps", "2" if args.cpu_seconds > 0 else "0", "--no-torch-legs"]),
+    ]
+    keep = ("metric", "value", "unit", "dtype", "ms_per_step", "steps", "config", "roofline", "cpu_baseline", "speedup_vs_cpu",
+            "max_rel_err_vs_cpu", "numerics_guard", "data", "batch", "stream_launches_value", "forward_kernel_ms", "backward_kernels_ms")
+    legs = {}
+    for name, cmd in jobs:
+        t0 = time.perf_counter()
+        try:
+            proc = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=240)
+            lines = [l for l in proc.stdout.splitlines() if l.startswith("{")]
+            if proc.returncode != 0 or not lines:
+                legs[name] = {"error": f"rc {proc.returncode}: {proc.stderr.strip()[-300:]}"}
+                continue
+            j = json.loads(lines[-1])
+            leg = {k: j[k] for k in keep if k in j}
+            rl = leg.get("roofline")
+            if isinstance(rl, dict):      # the fields a reader audits; the full line of each workload is under profiles/
+                leg["roofline"] = {k: rl[k] for k in ("kernel", "bound", "achieved", "peak", "unit", "frac", "executed_frac", "traffic",
+                                                       "launch_ms", "flops_per_launch", "hbm_algorithmic_bytes_per_launch") if k in rl}
+            leg["wall_s"] = time.perf_counter() - t0
+            legs[name] = leg
+        except Exception as e:
+            legs[name] = {"error": f"{type(e).__name__}: {e}"}
+    return legs
 
 
 def self_launch(args):
@@ -244,10 +303,16 @@ def main():
                          "of an 8/k-GPU run on one GPU; the cross-GPU hop itself is not exercised)")
     ap.add_argument("--group", type=int, default=GROUP, help=f"batches per launch / all-gather (default {GROUP}, max 32)")
     ap.add_argument("--no-extra-legs", action="store_true", help="skip the f32-exact and group-1 legs of the N=1 line")
+    ap.add_argument("--no-config-legs", action="store_true", help="skip legs.configs (the other BASELINE configurations, run as child processes)")
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(self_launch(args))
+
+    cfg_legs = None
+    if (args.gpus == 1 and "WORLD_SIZE" not in os.environ and not args.no_extra_legs and not args.no_config_legs
+            and args.config == "miniboone_glow" and args.components is None and args.batch is None and not args.force_gather):
+        cfg_legs = config_legs(args)          # children first: this process has not touched the GPU yet
 
     # dmabuf IPC is the only form the host driver supports (without it RCCL fails with hipIpcGetMemHandle: invalid argument)
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
@@ -494,13 +559,15 @@ def main():
                               "note": "one batch per flow launch + one recursion launch (per-call latency form)"}
             del r
             try:
-                leg, G_mod = module_evaluate_leg(specs, kind, d, h, K, C, xs[0])
+                leg, G_mod = module_evaluate_leg(specs, kind, d, h, K, C, xs)
                 if main_run["G0"] is not None:
                     g0 = main_run["G0"].astype(np.float64)
                     leg["max_rel_err_vs_pipeline"] = float(np.max(np.abs(G_mod.cpu().numpy() - g0) / np.maximum(np.abs(g0), 1.0)))
                 legs["module_evaluate_loop"] = leg
             except Exception as e:                  # (a leg never takes the headline down)
                 legs["module_evaluate_loop"] = {"error": f"{type(e).__name__}: {e}"}
+            if cfg_legs is not None:
+                legs["configs"] = cfg_legs
             out["legs"] = legs
         if args.cpu_seconds > 0 and world == 1:
             cb, G_cpu, n_cpu = cpu_baseline(specs, rho_np, x_np, args.cpu_seconds)

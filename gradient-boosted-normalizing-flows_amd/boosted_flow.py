@@ -665,6 +665,7 @@ class BoostedFlow(nn.Module):
         """x (N,d) -> z (N,d), ldj (N,) of component c  ==  self.flows[c](x)[0], [3] of the reference.
         ``differentiable``: None = recorded by autograd in train mode only (see ``_needs_grad``); True / False force it."""
         self._check_ready(x)
+        x_in = x
         x = x.contiguous().float()
         self._ensure_actnorm(x, int(c))
         with torch.cuda.device(x.device):
@@ -684,8 +685,54 @@ class BoostedFlow(nn.Module):
                                 bn.running_var.mul_(bn.momentum).add_(bn.batch_var * (1 - bn.momentum))
                 return out
             self._guard(x, [int(c)])
+            served = None if differentiable else self._serve_from_table(x, int(c), x_in)
+            if served is not None:
+                return served
             z, ldj, _ = self.native_flow(int(c)).forward(x)
         return z, ldj
+
+    # The reference's evaluate loop asks for the components of ONE batch one call at a time
+    # (density_experiment.py:561-573: ``for c in range(model.component + 1): model(x=x, components=c)``).  All of them read
+    # the same x, so in eval() mode the first call of a batch launches EVERY component in use
+    # (gbnf_mixture_component_forward: one launch, one (C, N, d) table) and the following calls are answered from that
+    # table with no launch at all.  The table is keyed on everything a result depends on: x's storage address, shape,
+    # strides and version counter (an in-place write to x bumps it), the packed handles of the components (rebuilt whenever
+    # a parameter's version counter moves: an optimiser step, load_state_dict, a new permutation), and the stream.
+    SERVE_ALL_COMPONENTS = True
+
+    def _serve_from_table(self, x, c, x_in=None):
+        """(z, ldj) of component c from the table of the batch, or None when the call is not an evaluation-loop call.
+        ``x_in`` is the tensor the caller handed over (the key), ``x`` its contiguous float32 form (what is launched)."""
+        # eval() mode only: there the module returns tensors without autograd history whatever the grad mode is (_needs_grad;
+        # the reference's evaluate() does not enter no_grad either, it detaches: density_experiment.py:545-577)
+        if not self.SERVE_ALL_COMPONENTS or self.training:
+            return None
+        n_used = self.num_components if self.all_trained else self.component + 1
+        if n_used < 2 or c >= n_used or x.shape[0] == 0:
+            return None
+        x_in = x if x_in is None else x_in
+        try:
+            xkey = (x_in.data_ptr(), x_in._version, tuple(x_in.shape), tuple(x_in.stride()), x_in.dtype, n_used,
+                    torch.cuda.current_stream(x.device).cuda_stream)
+        except RuntimeError:          # inference tensors keep no version counter: nothing to key on
+            return None
+        tab = self.__dict__.get("_component_table")
+        # entry c depends on x and on component c's parameters only: one component key per call, as the plain path costs
+        if tab is None or tab[0] != xkey or tab[4][c] != self._component_key(c):
+            if self.component_type == "glow" and not all(
+                    bool(l.actnorm.inited) for k in range(n_used) for l in self.flows[k].flow.layers):
+                return None           # the reference raises at the call of THAT component: leave it to the plain path
+            mix = self.native_mixture(n_used)              # re-packs whatever changed
+            z, ldj, _ = mix.component_forward(x, 0, n_used)
+            keys = [self._component_key(k) for k in range(n_used)]
+            # (x_in is held: its storage cannot be freed and handed to another tensor with the same address and version)
+            tab = (xkey, z, ldj, x_in, keys, mix)
+            self.__dict__["_component_table"] = tab
+        return tab[1][c], tab[2][c]
+
+    def drop_component_table(self):
+        """Forget the table of the last batch (frees its (C, N, d) device memory)."""
+        self.__dict__.pop("_component_table", None)
 
     def component_inverse(self, z, c):
         """z (N,d) -> x (N,d), log|det dx/dz| (N,) of component c: inverse of ``component_forward``."""

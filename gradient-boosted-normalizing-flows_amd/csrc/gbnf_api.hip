@@ -1069,13 +1069,19 @@ static int launch_flow(const gbnf_flow* f, const uint32_t* const* table, const u
   }
   // ---- numerics guard: this handle's first launch and every check_every-th re-check the f16x3 choice on the caller's rows
   if (split_pair && guard != nullptr && !inverse && f->launch_nt[1] != nullptr && f->launch2_nt[1] != nullptr && n_comp <= guard->n_comp) {
-    const long long k = guard->launches.fetch_add(1, std::memory_order_relaxed);
+    // (a launch that is being captured into a HIP graph is not checked: the check's launches would be baked into every replay,
+    //  and the host-side `demoted` switch is not consulted on replay -- the capture keeps the probe's verdict and the
+    //  flag-driven full re-evaluation that any earlier, un-captured check has armed)
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    if (stream != nullptr && hipStreamIsCapturing(stream, &cap) != hipSuccess) cap = hipStreamCaptureStatusNone;
+    const long long k = cap == hipStreamCaptureStatusNone ? guard->launches.fetch_add(1, std::memory_order_relaxed) : -1;
     const int every = tuning().check_every.load(std::memory_order_relaxed);
-    if (every >= 0 && (k == 0 || (every > 0 && k % every == 0))) {
+    if (k >= 0 && every >= 0 && (k == 0 || (every > 0 && k % every == 0))) {
       const int rows = (int)(n < GUARD_ROWS ? n : GUARD_ROWS);
       FlowLaunch q = p;
       q.n = rows; q.n_batches = 1; q.out_stride = GUARD_ROWS; q.n_tiles = (rows + 15) / 16;
       q.z_out = nullptr; q.ldj_out = nullptr; q.repair = 0; q.guard = nullptr;
+      q.sat = nullptr;                 // the check rows were counted (and marked) by the launch itself: not twice
       const unsigned mini_grid = (unsigned)(q.n_tiles * n_comp);
       q.ll_out = guard->scratch_dev;
       q.seq = next_serial();
@@ -1432,6 +1438,18 @@ int gbnf_mixture_component_log_prob_multi(const gbnf_mixture* mix, const float* 
   if (n > 0 && c_end > c_begin && (!x || !ll)) return fail(GBNF_ERR_INVALID, "x / ll is null");
   return launch_flow(mix->flows[0], mix->table_dev, mix->table2_dev, mix->use_blob2, c_begin, c_end - c_begin, x, n, nullptr, nullptr, ll,
                      mix->base_dev, (hipStream_t)stream, ll_row_stride, xs, n_batches, 0, mix->guard);
+}
+
+int gbnf_mixture_component_forward(const gbnf_mixture* mix, const float* x, int64_t n, int32_t c_begin, int32_t c_end,
+                                   float* z, float* ldj, float* ll, void* stream) {
+  if (!mix) return fail(GBNF_ERR_INVALID, "gbnf_mixture_component_forward: mix is null");
+  const int C = (int)mix->flows.size();
+  if (c_begin < 0 || c_end > C || c_begin > c_end)
+    return fail(GBNF_ERR_INVALID, "component range [%d,%d) outside [0,%d)", c_begin, c_end, C);
+  if (n < 0) return fail(GBNF_ERR_INVALID, "n < 0");
+  if (n > 0 && c_end > c_begin && (!x || (!z && !ldj && !ll))) return fail(GBNF_ERR_INVALID, "x is null or no output was asked for");
+  return launch_flow(mix->flows[0], mix->table_dev, mix->table2_dev, mix->use_blob2, c_begin, c_end - c_begin, x, n, z, ldj, ll,
+                     mix->base_dev, (hipStream_t)stream, n, nullptr, 1, 0, mix->guard);
 }
 
 int gbnf_mixture_lse(const float* ll, int64_t ll_row_stride, const float* rho_dev, int32_t n_components, int64_t n,

@@ -137,6 +137,21 @@ constexpr int hx3_eff_nt(int HT, int OT, int NT, int prec, int kind, int act_a, 
   return (NT == 2 && hx3_reg_estimate(HT, OT, 2, prec, kind, act_a, act_b, depth) > 300) ? 1 : NT;
 }
 
+// round-4 knobs, each A/B'd on one box (tools/build_ab.sh + tools/ab_bench.py, profiles/r4_ab_headline_knobs.txt); the defaults are
+// the shipped forms
+#ifndef GBNF_HX3_MIXLO
+#define GBNF_HX3_MIXLO 0          // 1: the f16 residual piece is converted and packed by v_fma_mixlo_f16 / v_fma_mixhi_f16 (measured: 1.2 % SLOWER)
+#endif
+#ifndef GBNF_HX3_DMA_RUNS
+#define GBNF_HX3_DMA_RUNS 1       // 1: a wave stages a RUN of consecutive fragments per stage: one M0 / base per 4 pieces (immediate offsets; +0.2 %)
+#endif
+#ifndef GBNF_HX3_DMA_AT
+#define GBNF_HX3_DMA_AT 0         // n > 0: a hidden pass issues the next stage's DMA in front of its unit n (0: at the top of the pass; measured: no change)
+#endif
+#ifndef GBNF_HX3_EDGE
+#define GBNF_HX3_EDGE 1           // 1: the step boundary (coupling epilogue, input normalisation) as direction-specialised straight-line code (+1.3 %)
+#endif
+
 // ---- operand splitting ----------------------------------------------------------------------------------------
 // f16: hi = f16(x) (toward zero), mid = f16(x - hi); 4 VALU ops per register pair: the residual x - hi is ONE
 // v_fma_mix_f32 per value (the f16 half is widened inside the instruction; LLVM itself would emit v_cvt_f32_f16 + v_sub_f32)
@@ -156,6 +171,17 @@ __device__ __forceinline__ void split_pair_f16(float x0, float x1, unsigned (&p)
   // compiler did see.
   r0 = x0;
   r1 = x1;
+#if GBNF_HX3_MIXLO
+  // round 4: the residuals are converted to f16 and packed BY the fma (v_fma_mixlo_f16 / v_fma_mixhi_f16 write the low / high
+  // half of the destination and keep the other half): two instructions instead of two v_fma_mix_f32 + v_cvt_pkrtz_f16_f32.
+  // The residual x - hi is exact in f32; its conversion rounds to nearest here (toward zero before): hi + mid is the closer sum.
+  asm("v_fma_mixlo_f16 %0, %1, -1.0, %0 op_sel_hi:[1,0,0]\n\t"
+      "v_fma_mixhi_f16 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]"
+      : "+v"(r0)
+      : "v"(hw), "v"(r1));
+  p[1] = __builtin_bit_cast(unsigned, r0);
+  return;
+#endif
   asm("v_fma_mix_f32 %0, %1, -1.0, %0 op_sel_hi:[1,0,0]" : "+v"(r0) : "v"(hw));
   asm("v_fma_mix_f32 %0, %1, -1.0, %0 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(r1) : "v"(hw));
 #endif
@@ -242,6 +268,26 @@ __device__ __forceinline__ void lds_dma16(const __attribute__((address_space(1))
   const __attribute__((address_space(1))) char* base = reinterpret_cast<const __attribute__((address_space(1))) char*>(src);
   __builtin_amdgcn_global_load_lds(base + lane_b16, (__attribute__((address_space(3))) void*)lds_dst, 16, 0, 0);
 #endif
+}
+
+// CNT (1..4) consecutive 1 KiB pieces with ONE M0 and ONE base: the instruction's immediate offset is added to the global AND
+// to the LDS address (round 4: the per-piece s_mov m0 / s_nop / 64-bit base arithmetic was 4 of the 5 instructions a piece cost)
+template <int CNT>
+__device__ __forceinline__ void lds_dma16_run(const __attribute__((address_space(1))) uint32_t* src, uint32_t* lds_dst, unsigned lane_b16) {
+  static_assert(CNT >= 1 && CNT <= 4, "immediate offsets 0 .. 3072");
+  const unsigned m0v = (unsigned)(uintptr_t)(__attribute__((address_space(3))) void*)lds_dst;
+  if constexpr (CNT == 1)
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(lane_b16), "s"(src), "s"(m0v) : "memory", "m0");
+  else if constexpr (CNT == 2)
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1\n\tglobal_load_lds_dwordx4 %0, %1 offset:1024"
+                 ::"v"(lane_b16), "s"(src), "s"(m0v) : "memory", "m0");
+  else if constexpr (CNT == 3)
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1\n\tglobal_load_lds_dwordx4 %0, %1 offset:1024\n\t"
+                 "global_load_lds_dwordx4 %0, %1 offset:2048" ::"v"(lane_b16), "s"(src), "s"(m0v) : "memory", "m0");
+  else
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1\n\tglobal_load_lds_dwordx4 %0, %1 offset:1024\n\t"
+                 "global_load_lds_dwordx4 %0, %1 offset:2048\n\tglobal_load_lds_dwordx4 %0, %1 offset:3072"
+                 ::"v"(lane_b16), "s"(src), "s"(m0v) : "memory", "m0");
 }
 
 // a stage end that leaves the n youngest vector-memory operations of the wave in flight (n folds to a constant; even values,
@@ -424,14 +470,46 @@ flow_kernel_hx3(const FlowLaunch p) {
     (void)src; (void)dst;
 #endif
   };
+  // (GBNF_HX3_DMA_RUNS) wave w stages the run [w BASE + min(w, R), ...) of BASE (+1 if w < R) consecutive fragments, four per M0 / base
+  auto dma_runs = [&](auto nf_c, gwords src, uint32_t* dst) {
+    constexpr int NF = decltype(nf_c)::value;
+    constexpr int BASE = NF / WAVES, R = NF % WAVES;
+#ifndef GBNF_ABLATE_DMA
+    const int start = wave * BASE + (wave < R ? wave : R);
+    gwords s0 = src + start * 256;
+    uint32_t* d0 = dst + start * 256;
+    auto group = [&](auto g_c) {
+      constexpr int G = decltype(g_c)::value;
+      constexpr int lo = (BASE - 4 * G) < 0 ? 0 : ((BASE - 4 * G) > 4 ? 4 : (BASE - 4 * G));              // pieces of group G without ...
+      constexpr int hi = (BASE + 1 - 4 * G) < 0 ? 0 : ((BASE + 1 - 4 * G) > 4 ? 4 : (BASE + 1 - 4 * G));  // ... and with the extra one
+      if constexpr (R == 0 || lo == hi) {
+        if constexpr (lo > 0) lds_dma16_run<lo>(s0 + G * 1024, d0 + G * 1024, lane_b16);
+      } else {
+        if (wave < R) lds_dma16_run<hi>(s0 + G * 1024, d0 + G * 1024, lane_b16);
+        else if constexpr (lo > 0) lds_dma16_run<lo>(s0 + G * 1024, d0 + G * 1024, lane_b16);
+      }
+    };
+    static_assert(BASE + 1 <= 16, "at most four groups of four pieces per wave and stage");
+    group(std::integral_constant<int, 0>{});
+    if constexpr (BASE + (R > 0) > 4) group(std::integral_constant<int, 1>{});
+    if constexpr (BASE + (R > 0) > 8) group(std::integral_constant<int, 2>{});
+    if constexpr (BASE + (R > 0) > 12) group(std::integral_constant<int, 3>{});
+#else
+    (void)src; (void)dst;
+#endif
+  };
   auto issue = [&](auto nf_c, int into) {           // the next stage: NF fragments at next_src
     constexpr int NF = decltype(nf_c)::value;
     uint32_t* dst = STG + (into & 1) * STAGE_WORDS;
+#if GBNF_HX3_DMA_RUNS
+    dma_runs(nf_c, next_src, dst);
+#else
 #pragma unroll
     for (int k = 0; k * WAVES < NF; ++k) {
       const int f = wave + k * WAVES;
       if ((k + 1) * WAVES <= NF || f < NF) dma(next_src + f * 256, dst + f * 256);
     }
+#endif
     next_src += NF * 256;
     if constexpr (TRAIN) {
       __builtin_amdgcn_sched_barrier(0);           // nothing that is counted below moves in front of the DMA
@@ -440,11 +518,15 @@ flow_kernel_hx3(const FlowLaunch p) {
   };
   auto issue_net_start = [&](int into) {            // next_src points at a net's bias block: biases + first L0 stage
     uint32_t* bdst = BIAS + (nets_issued & 1) * LT::value.BIAS_WORDS;
+#if GBNF_HX3_DMA_RUNS
+    dma_runs(std::integral_constant<int, LT::value.BIAS_FRAGS>{}, next_src, bdst);
+#else
 #pragma unroll
     for (int k = 0; k * WAVES < LT::value.BIAS_FRAGS; ++k) {
       const int f = wave + k * WAVES;
       if ((k + 1) * WAVES <= LT::value.BIAS_FRAGS || f < LT::value.BIAS_FRAGS) dma(next_src + f * 256, bdst + f * 256);
     }
+#endif
     next_src += LT::value.BIAS_WORDS;
     ++nets_issued;
     issue(std::integral_constant<int, LT::value.nf[0]>{}, into);
@@ -480,6 +562,9 @@ flow_kernel_hx3(const FlowLaunch p) {
 #pragma unroll
   for (int nt = 0; nt < NT; ++nt) ld[nt] = 0.0f;
   float ld_const = 0.0f;
+  [[maybe_unused]] float ld2[NT];  // (GBNF_HX3_EDGE) affine Glow coupling: sum of log2(1 + exp(-(raw + 2))); log|det| gets -ln 2 times it
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) ld2[nt] = 0.0f;
   bool sat[NT];                  // sample (i, nt) stored an operand beyond the fp16 range
 #pragma unroll
   for (int nt = 0; nt < NT; ++nt) sat[nt] = false;
@@ -616,6 +701,82 @@ flow_kernel_hx3(const FlowLaunch p) {
     // ---- normalise the coupling net's inputs in place; split them into the first layer's B operand:
     //      lane (i,g), element j  <->  input feature 8g + j of sample i
     u32x4 zp[NT][NP];
+#if GBNF_HX3_EDGE
+    // Round 4: direction-specialised straight-line code.  The direction (FlowLaunch::inverse) is tested ONCE per block, not per
+    // value (the per-value form cost two scalar branches and three selects per value and broke the block into 16 pieces that the
+    // scheduler could not overlap); ONE LDS address per entry serves the read and the write (dead entries use the spare slot d:
+    // whatever they read is discarded by a select); slot * ZS is a shift-add (hipcc emitted the quarter-rate v_mul_lo_u32).
+    // 32-bit LDS byte addresses (24-bit multiply-add: hipcc turned slot * ZS into the quarter-rate v_mul_lo_u32 / v_mad_u64_u32)
+    using lf32 = __attribute__((address_space(3))) float;
+    const unsigned zb_ = (unsigned)(uintptr_t)(__attribute__((address_space(3))) void*)Z + 4u * (unsigned)i;
+    auto zoff = [&](int slot) { return zb_ + (unsigned)__mul24(slot, 4 * ZS); };       // &Z[slot * ZS + i]
+    auto zld = [&](unsigned a, int nt) { return *reinterpret_cast<lf32*>((uintptr_t)(a + 64u * (unsigned)nt)); };
+    auto zst = [&](unsigned a, int nt, float v_) { *reinterpret_cast<lf32*>((uintptr_t)(a + 64u * (unsigned)nt)) = v_; };
+    {
+      LaneTable tin;
+      if (lds_tables) {
+        const float lc = as_f32(SM[step * SMALL_WORDS + 1]);
+        ld_const += inv ? -lc : lc;
+        tin.load(SM + step * SMALL_WORDS + SMALL_HDR + g * NENT);
+      } else {
+        const float lc = as_f32(sp[1]);
+        ld_const += inv ? -lc : lc;
+        tin.load(sp + SMALL_HDR + g * NENT);
+      }
+      unsigned za[NENT];
+      bool live[NENT];
+      float v[NT][NENT];
+#pragma unroll
+      for (int e = 0; e < NENT; ++e) {
+        live[e] = tin.slot[e] >= 0;
+        za[e] = zoff(live[e] ? tin.slot[e] : d);
+      }
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for (int e = 0; e < NENT; ++e) v[nt][e] = zld(za[e], nt);
+      auto edge_in = [&](auto inv_c) {
+        constexpr bool INV = decltype(inv_c)::value;
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+          for (int e = 0; e < NENT; ++e) {
+            // forward: normalise, keep; inverse: the stored value IS the normalised net input, the state gets norm^-1 of it
+            float t = v[nt][e];
+            if constexpr (!INV) {
+              t = norm_fn<KIND>(t, tin.p0[e], tin.p1[e], tin.p2[e], tin.p3[e]);
+              zst(za[e], nt, t);
+            } else {
+              zst(za[e], nt, invnorm_fn<KIND>(t, tin.p0[e], tin.p1[e], tin.p2[e], tin.p3[e]));
+            }
+            if constexpr (TRAIN && !INV) {
+              if (live[e] && tr_ok) {       // the backward's inputs: the step's normalised state (slot layout) and the nets' input rows
+                tr_trace[tin.slot[e] * tr_np + tr_row + 16 * nt] = t;
+#pragma unroll
+                for (int q = 0; q < NNETS; ++q) tr_acts[q * tr_net_stride + tr_in_off + nt * tr_ip16 + e * 16] = t;
+              }
+            }
+            if constexpr (WATCH) {
+              sat[nt] = sat[nt] || (live[e] && !(__builtin_fabsf(t) <= 65504.0f));
+              v[nt][e] = live[e] ? __builtin_amdgcn_fmed3f(t, -65504.0f, 65504.0f) : 0.0f;
+            } else {
+              v[nt][e] = live[e] ? t : 0.0f;
+            }
+          }
+      };
+      if (!inv) edge_in(std::false_type{});
+      else edge_in(std::true_type{});
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          unsigned pc[NP];
+          split_pair<NP>(v[nt][2 * q], v[nt][2 * q + 1], pc);
+#pragma unroll
+          for (int k = 0; k < NP; ++k) zp[nt][k][q] = pc[k];
+        }
+    }
+#else
     {
       LaneTable tin;
       if (lds_tables) {
@@ -664,6 +825,7 @@ flow_kernel_hx3(const FlowLaunch p) {
         }
       }
     }
+#endif
     st.mark(0);
     st.set(1);
 
@@ -968,7 +1130,11 @@ flow_kernel_hx3(const FlowLaunch p) {
           // the stage after this one: the drain, a pass with an output-layer chunk (after an odd pass), or a plain pass
           constexpr int NF_NEXT = LAST ? NP * OT : (PREV == 1 ? NP * (HC + OT) : NP * HC);
           guard_at(6);
-          issue(std::integral_constant<int, NF_NEXT>{}, gs + 1);
+          // (GBNF_HX3_DMA_AT > 0: the next stage's DMA is issued in front of unit DMA_AT instead of at the top of the pass, where all
+          //  waves of the workgroup leave the barrier together and queue on the vector-memory port; not for TRAIN: its counted
+          //  stage waits count the stores BEHIND the DMA)
+          constexpr int DMA_AT = TRAIN ? 0 : GBNF_HX3_DMA_AT;
+          if constexpr (DMA_AT == 0) issue(std::integral_constant<int, NF_NEXT>{}, gs + 1);
           guard_at(4);
           Unit A[3];
           A[0] = N0;
@@ -982,6 +1148,7 @@ flow_kernel_hx3(const FlowLaunch p) {
 #pragma unroll
           for (int n = 0; n < NU; ++n) {
             if (n + 2 < NU) load_unit(A[(n + 2) % 3], n + 2);
+            if (DMA_AT > 0 && n == (DMA_AT < NU - 1 ? DMA_AT : NU - 2)) issue(std::integral_constant<int, NF_NEXT>{}, gs + 1);
             if (n == NU - 1) stage_finish(2, true);
             if (n < HC) {
               if (PREV != 0) {
@@ -1104,6 +1271,107 @@ flow_kernel_hx3(const FlowLaunch p) {
     }
 
     // ---- coupling transform of the other half, in place, + per-lane log-det partials
+#if GBNF_HX3_EDGE
+    {
+      LaneTable tout;
+      if (lds_tables) tout.load(SM + step * SMALL_WORDS + SMALL_HDR + 160 + g * NENT);
+      else tout.load(sp + SMALL_HDR + 160 + g * NENT);
+      if (KIND == GBNF_KIND_GLOW && !p.additive) {
+        // affine coupling, models/glow.py:331-338 / 352-355: scale = sigmoid(raw + 2) = 1 / s1, s1 = 1 + exp(-(raw + 2));
+        // log scale = -ln 2 . log2(s1): the log2 terms are summed as they are and scaled once at the end of the kernel (ld2)
+        constexpr int NE = (2 * OT < NENT) ? 2 * OT : NENT;
+        unsigned za[NE];
+        bool live[NE];
+        float v[NT][NE];
+#pragma unroll
+        for (int e = 0; e < NE; ++e) {
+          live[e] = tout.slot[e] >= 0;
+          za[e] = zoff(live[e] ? tout.slot[e] : d);
+        }
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+          for (int e = 0; e < NE; ++e) v[nt][e] = zld(za[e], nt);
+        auto edge_out = [&](auto inv_c) {
+          constexpr bool INV = decltype(inv_c)::value;
+#pragma unroll
+          for (int e = 0; e < NE; ++e) {
+            const int o = e >> 1, pp = e & 1;
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+              const float shift = outA[o][nt][2 * pp], raw = outA[o][nt][2 * pp + 1];
+              const float s1 = 1.0f + __builtin_amdgcn_exp2f((raw + 2.0f) * -1.4426950408889634f);
+              const float l2 = __builtin_amdgcn_logf(s1);
+              float t;
+              if constexpr (!INV) {
+                t = norm_fn<KIND>(v[nt][e], tout.p0[e], tout.p1[e], tout.p2[e], tout.p3[e]);
+                if constexpr (TRAIN) {
+                  if (live[e] && tr_ok) tr_trace[tout.slot[e] * tr_np + tr_row + 16 * nt] = t;
+                }
+                t = (t + shift) * __builtin_amdgcn_rcpf(s1);
+                ld2[nt] += live[e] ? l2 : 0.0f;
+              } else {                                                   // FlowStep.decode, models/glow.py:352-355
+                t = v[nt][e] * s1 - shift;                               // z2 / scale - shift
+                t = invnorm_fn<KIND>(t, tout.p0[e], tout.p1[e], tout.p2[e], tout.p3[e]);
+                ld2[nt] -= live[e] ? l2 : 0.0f;
+              }
+              zst(za[e], nt, t);
+            }
+          }
+        };
+        if (!inv) edge_out(std::false_type{});
+        else edge_out(std::true_type{});
+      } else {
+        constexpr int NE = (4 * OT < NENT) ? 4 * OT : NENT;
+        unsigned za[NE];
+        bool live[NE];
+        float v[NT][NE];
+#pragma unroll
+        for (int e = 0; e < NE; ++e) {
+          live[e] = tout.slot[e] >= 0;
+          za[e] = zoff(live[e] ? tout.slot[e] : d);
+        }
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+          for (int e = 0; e < NE; ++e) v[nt][e] = zld(za[e], nt);
+        auto edge_out = [&](auto inv_c) {
+          constexpr bool INV = decltype(inv_c)::value;
+#pragma unroll
+          for (int e = 0; e < NE; ++e) {
+            const int o = e >> 2, r = e & 3;
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+              float t = v[nt][e];
+              if constexpr (!INV) {
+                t = norm_fn<KIND>(t, tout.p0[e], tout.p1[e], tout.p2[e], tout.p3[e]);
+                if constexpr (TRAIN) {
+                  if (live[e] && tr_ok) tr_trace[tout.slot[e] * tr_np + tr_row + 16 * nt] = t;
+                }
+              }
+              if constexpr (KIND == GBNF_KIND_GLOW) {                     // additive, models/glow.py:328-329 / 349-350
+                if constexpr (!INV) t = t + outA[o][nt][r];
+                else t = invnorm_fn<KIND>(t - outA[o][nt][r], tout.p0[e], tout.p1[e], tout.p2[e], tout.p3[e]);
+              } else {
+                const float shift = outA[o][nt][r], scale = outB[o][nt][r];
+                if constexpr (!INV) {
+                  t = shift + t * exp_fast(scale);                       // models/transformations.py:575
+                  ld[nt] += live[e] ? scale : 0.0f;
+                } else {                                                 // its true inverse (the reference's own .inverse is not: SURVEY S3)
+                  t = (t - shift) * exp_fast(-scale);
+                  t = invnorm_fn<KIND>(t, tout.p0[e], tout.p1[e], tout.p2[e], tout.p3[e]);
+                  ld[nt] -= live[e] ? scale : 0.0f;
+                }
+              }
+              zst(za[e], nt, t);
+            }
+          }
+        };
+        if (!inv) edge_out(std::false_type{});
+        else edge_out(std::true_type{});
+      }
+    }
+#else
     {
       LaneTable tout;
       if (lds_tables) tout.load(SM + step * SMALL_WORDS + SMALL_HDR + 160 + g * NENT);
@@ -1175,6 +1443,7 @@ flow_kernel_hx3(const FlowLaunch p) {
         }
       }
     }
+#endif
     // Z is wave-private: the wave's own LDS writes are ordered before its next reads (in-order LDS queue);
     // make that explicit for the compiler
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
@@ -1214,6 +1483,9 @@ flow_kernel_hx3(const FlowLaunch p) {
 #pragma unroll
   for (int nt = 0; nt < NT; ++nt) {
     float q = quad[nt], l = ld[nt];
+#if GBNF_HX3_EDGE
+    l = __builtin_fmaf(-0.69314718055994531f, ld2[nt], l);
+#endif
     q += __shfl_xor(q, 16); q += __shfl_xor(q, 32);
     l += __shfl_xor(l, 16); l += __shfl_xor(l, 32);
     bool bad = false;
@@ -1221,7 +1493,10 @@ flow_kernel_hx3(const FlowLaunch p) {
       const unsigned long long m = __ballot(sat[nt]);          // bit (16 g + i): fold the 4 lane groups per sample
       const unsigned rows = (unsigned)((m | (m >> 16) | (m >> 32) | (m >> 48)) & 0xffffull);
       bad_rows |= (unsigned long long)rows << (16 * nt);
-      bad = (rows >> i) & 1u;
+      // TRAIN: nothing repairs a marked row behind the training forward (the bf16x6 repair pass exists for the evaluation
+      // kernels only), and one NaN row would make the loss and every gradient NaN: the operands were CLAMPED above, the
+      // outputs stay finite (what the round-1 train_kernel does) and the launch is COUNTED (gbnf_saturation_count)
+      bad = !TRAIN && ((rows >> i) & 1u);
       any_sat = any_sat || rows != 0;
     }
     const int64_t n = row0 + 16 * nt + i;
@@ -1234,7 +1509,7 @@ flow_kernel_hx3(const FlowLaunch p) {
   }
   if (WATCH && p.sat != nullptr && any_sat && lane == 0) {
     atomicAdd(p.sat, 1ull);
-    atomicMax(p.sat + SAT_MARKS + p.seq % SAT_SLOTS, p.seq);      // tells the repair launch behind this one that it has work
+    if constexpr (!TRAIN) atomicMax(p.sat + SAT_MARKS + p.seq % SAT_SLOTS, p.seq);      // tells the repair launch behind this one that it has work
   }
   if (p.z_out != nullptr && lane < d) {
     const int slot = inv ? lane : (int)tail[lane];
@@ -1243,7 +1518,7 @@ flow_kernel_hx3(const FlowLaunch p) {
     for (int r = 0; r < 16 * NT; ++r) {
       const int64_t n = row0 + r;
       float v = Z[slot * ZS + r];
-      if (WATCH && ((bad_rows >> r) & 1ull)) v = __builtin_nanf("");
+      if (WATCH && !TRAIN && ((bad_rows >> r) & 1ull)) v = __builtin_nanf("");
       if (n < p.n) zo[n * d + lane] = v;
     }
   }

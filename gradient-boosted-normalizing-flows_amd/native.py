@@ -28,7 +28,7 @@ ABI_SYMBOLS = (
     "gbnf_flow_inverse",
     "gbnf_mixture_create", "gbnf_mixture_destroy", "gbnf_mixture_set_base",
     "gbnf_mixture_component_log_prob", "gbnf_mixture_component_log_prob_strided",
-    "gbnf_mixture_component_log_prob_multi", "gbnf_mixture_lse",
+    "gbnf_mixture_component_log_prob_multi", "gbnf_mixture_component_forward", "gbnf_mixture_lse",
     "gbnf_mixture_log_prob",
     "gbnf_actnorm_init", "gbnf_boosting_weights",
     "gbnf_flow_validate", "gbnf_trainer_create", "gbnf_trainer_destroy", "gbnf_trainer_forward",
@@ -147,6 +147,7 @@ def lib():
     L.gbnf_mixture_component_log_prob.argtypes = [vp, vp, i64, i32, i32, vp, vp]
     L.gbnf_mixture_component_log_prob_strided.argtypes = [vp, vp, i64, i32, i32, vp, i64, vp]
     L.gbnf_mixture_component_log_prob_multi.argtypes = [vp, C.POINTER(vp), i32, i64, i32, i32, vp, i64, vp]
+    L.gbnf_mixture_component_forward.argtypes = [vp, vp, i64, i32, i32, vp, vp, vp, vp]
     L.gbnf_mixture_lse.argtypes = [vp, i64, vp, i32, i64, vp, vp]
     L.gbnf_mixture_log_prob.argtypes = [vp, vp, i64, i32, vp, vp, vp, vp]
     L.gbnf_actnorm_init.argtypes = [vp, i64, i32, C.c_float, vp, vp, vp]
@@ -737,6 +738,24 @@ class NativeMixture:
             self.handle, C.c_void_p(x.data_ptr() if n else 0), n, c_begin, c_end,
             C.c_void_p(out.data_ptr() if out.numel() else 0), _stream_ptr()))
         return out
+
+    def component_forward(self, x, c_begin=0, c_end=None, want_z=True, want_ldj=True, want_ll=False):
+        """(z (C',n,d), ldj (C',n), ll (C',n)) of components [c_begin, c_end) in ONE launch (gbnf_mixture_component_forward):
+        the reference's per-component calls ``model(x=x, components=c)`` of one batch, all at once."""
+        import torch
+        _require_device_f32(x, "x")
+        if x.dim() != 2 or x.shape[1] != self.d:
+            raise GbnfError(f"x must be (n,{self.d}), got {tuple(x.shape)}")
+        c_end = self.n_components if c_end is None else c_end
+        n, k = x.shape[0], c_end - c_begin
+        z = torch.empty((k, n, self.d), dtype=torch.float32, device=x.device) if want_z else None
+        ldj = torch.empty((k, n), dtype=torch.float32, device=x.device) if want_ldj else None
+        ll = torch.empty((k, n), dtype=torch.float32, device=x.device) if want_ll else None
+        if n and k:
+            ptr = lambda t: C.c_void_p(t.data_ptr() if t is not None else 0)
+            _check(lib().gbnf_mixture_component_forward(self.handle, C.c_void_p(x.data_ptr()), n, c_begin, c_end,
+                                                        ptr(z), ptr(ldj), ptr(ll), _stream_ptr()))
+        return z, ldj, ll
 
     def prepared_component_log_prob(self, x, out, c_begin=0, c_end=None, col_offset=0):
         """Bind every argument once and return ``launch(stream_ptr)``: the per-call host cost is then one ctypes

@@ -237,6 +237,13 @@ int gbnf_mixture_component_log_prob_multi(const gbnf_mixture* mix, const float* 
                                           int64_t n, int32_t c_begin, int32_t c_end, float* ll,
                                           int64_t ll_row_stride, void* stream);
 
+/* Replaces: the calls  z, _, _, ldj, _ = model(x=x, components=c)  of the reference's evaluate loop
+ * (density_experiment.py:562-563; models/boosted_flow.py:220-228) for ALL components [c_begin, c_end) of one batch in ONE
+ * launch: z is (c_end - c_begin, n, d), ldj and ll are (c_end - c_begin, n) row-major; any of the three may be NULL (not all).
+ * The host mirror answers the loop's per-component calls from this table (BoostedFlow.encode in eval mode). */
+int gbnf_mixture_component_forward(const gbnf_mixture* mix, const float* x, int64_t n, int32_t c_begin, int32_t c_end,
+                                   float* z, float* ldj, float* ll, void* stream);
+
 /* Replaces: the recursive prefix-normalised 2-way logsumexp (density_experiment.py:567-571):
  *   G_0 = ll_0;  r_c = rho_c / sum(rho[0..c]);  G_c = LSE(log(1-r_c)+G_{c-1}, log(r_c)+ll_c).
  * ll is (n_components, n) with row stride `ll_row_stride` floats; rho_dev is the DEVICE

@@ -300,3 +300,56 @@ def test_reference_checkpoint_evaluates_like_the_reference():
     x = torch.from_numpy(synth.synth_batch(cfg["N"], cfg["d"], seed=cfg["x_seed"])).to(dev)
     assert rel_err(m.component_log_prob(x).cpu().numpy().T, data["ll"]) < LL_RTOL
     assert rel_err(m.log_prob(x).cpu().numpy(), data["G"]) < LL_RTOL
+
+
+def test_evaluate_loop_is_served_from_one_launch(golden_case):
+    """in eval() mode the first ``model(x=x, components=c)`` of a batch launches every component in use
+    (gbnf_mixture_component_forward) and the loop's following calls are answered from that table; the table is dropped when x
+    is written in place, when another tensor comes in, and when a parameter of the asked component changes."""
+    import torch
+    dev = torch.device("cuda:0")
+    g = golden_case("g2_glow_native_d43_h32_c3")
+    m = _model_from_case(g, dev)
+    m.component = g.n_used - 1
+    m.eval()
+    x = torch.from_numpy(g.x).to(dev)
+    G = _evaluate_like_reference(m, x)                      # grad mode ON, as in the reference's evaluate()
+    assert rel_err(G.cpu().numpy(), g.G) < LL_RTOL
+    tab = m.__dict__["_component_table"]
+    assert tab[1].shape == (g.n_used, x.shape[0], x.shape[1])
+    z1, _, _, l1, _ = m(x=x, components=1)
+    assert m.__dict__["_component_table"] is tab            # served: no new table
+    assert not z1.requires_grad and not l1.requires_grad
+    # the table holds what the per-component launches return, bit for bit
+    m.SERVE_ALL_COMPONENTS = False
+    z1p, _, _, l1p, _ = m(x=x, components=1)
+    m.SERVE_ALL_COMPONENTS = True
+    assert torch.equal(z1, z1p) and torch.equal(l1, l1p)
+    # (1) x written in place: same address, new version -> a new table with the new values
+    x.add_(0.125)
+    z1b, _, _, l1b, _ = m(x=x, components=1)
+    assert m.__dict__["_component_table"] is not tab
+    m.SERVE_ALL_COMPONENTS = False
+    z1q, _, _, l1q, _ = m(x=x, components=1)
+    m.SERVE_ALL_COMPONENTS = True
+    assert torch.equal(z1b, z1q) and torch.equal(l1b, l1q) and not torch.equal(l1b, l1)
+    # (2) an optimiser step on component 1 between two calls of the same batch
+    tab2 = m.__dict__["_component_table"]
+    opt = torch.optim.SGD(m.flows[1].parameters(), lr=0.5)
+    for p_ in m.flows[1].parameters():
+        p_.grad = torch.full_like(p_, 1e-2)
+    opt.step()
+    z1c, _, _, l1c, _ = m(x=x, components=1)
+    assert m.__dict__["_component_table"] is not tab2
+    assert not torch.equal(l1c, l1b)
+    z0c, _, _, l0c, _ = m(x=x, components=0)                # component 0 did not change: served from the rebuilt table
+    m.SERVE_ALL_COMPONENTS = False
+    _, _, _, l0p, _ = m(x=x, components=0)
+    _, _, _, l1r, _ = m(x=x, components=1)
+    m.SERVE_ALL_COMPONENTS = True
+    assert torch.equal(l0c, l0p) and torch.equal(l1c, l1r)
+    # (3) train() mode is never served (the call may be recorded by autograd)
+    m.train()
+    m.drop_component_table()
+    m(x=x, components=1)
+    assert "_component_table" not in m.__dict__

@@ -119,6 +119,33 @@ def test_traced_forward_on_32_sample_waves(name, golden_case):
     assert np.abs(gx.cpu().numpy() - gx64).max() <= G_RTOL * float(np.abs(gx64).max())
 
 
+@pytest.mark.parametrize("kind,d,h", [("glow", 43, 215), ("realnvp", 21, 105)])
+def test_traced_forward_keeps_out_of_range_rows_finite(kind, d, h):
+    """the traced training forward runs the f16x3 evaluation kernel with TRAIN = 1; a row whose operands
+    leave the fp16 range must be clamped and counted there (as the round-1 train_kernel does) -- marked NaN, with no repair
+    pass behind the training forward, it would make the loss and every gradient NaN."""
+    import torch
+    from gbnf_amd import native, synth
+    dev = torch.device("cuda:0")
+    spec = (synth.synth_glow_spec(d, h, 5, seed=3) if kind == "glow" else synth.synth_realnvp_spec(d, h, 5, seed=3))
+    tr = native.NativeTrainer(_dev_spec(spec, dev))
+    x = synth.synth_batch(200, d, seed=4)
+    x[7, :] = 3.0e5            # |x| > 65504: beyond the fp16 range
+    x[150, 3] = -1.0e6
+    xd = torch.from_numpy(x).to(dev)
+    native.saturation_count(reset=True)
+    z, ldj, trace = tr.forward(xd, want_trace=True)
+    assert bool(torch.isfinite(z).all()) and bool(torch.isfinite(ldj).all())
+    assert native.saturation_count(reset=True) > 0            # ... and the launch is counted
+    g_x, grads = tr.backward(xd, torch.ones_like(z) / 200, torch.ones_like(ldj) / 200, want_gx=True, trace=trace)
+    assert bool(torch.isfinite(g_x).all())
+    assert all(bool(torch.isfinite(t).all()) for t in grads if t is not None)
+    # the rows inside the range are what an all-in-range batch gives
+    keep = [r for r in range(200) if r not in (7, 150)]
+    z2, ldj2 = tr.forward(torch.from_numpy(np.ascontiguousarray(x[keep])).to(dev))
+    assert rel_err(ldj[keep].cpu().numpy(), ldj2.cpu().numpy()) < 1e-5
+
+
 @pytest.mark.parametrize("name", GRADS_CASES)
 def test_trainer_matches_reference_backward(name):
     """g10: the reference's own nll.backward()."""

@@ -66,6 +66,7 @@ def main():
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--cpu-steps", type=int, default=3)
+    ap.add_argument("--cpu-rows", type=int, default=4096, help="rows of the batch the CPU baseline leg runs on (bounded sample)")
     ap.add_argument("--tune", action="append", default=[], help="key=value for gbnf_tuning_set (A/B runs)")
     ap.add_argument("--graph", action="store_true", help="also time the step captured once in a HIP graph and replayed (torch.cuda.CUDAGraph)")
     ap.add_argument("--no-torch-legs", action="store_true", help="skip the eager-PyTorch GPU leg (profiler runs: thousands of tiny dispatches)")
@@ -123,28 +124,57 @@ def main():
         torch.cuda.synchronize()
         fw += ev[0].elapsed_time(ev[1]); bw += ev[1].elapsed_time(ev[2])
     fw /= a.steps; bw /= a.steps
-    t_gpu_torch = float("inf") if a.no_torch_legs else timed(torch_step(spec, x, dev), a.steps, a.warmup)
+    t_gpu_torch = None if a.no_torch_legs else timed(torch_step(spec, x, dev), a.steps, a.warmup)
     torch.set_num_threads(min(8, os.cpu_count() or 1))
-    xc = x.cpu()
-    cpu_fn = torch_step(spec, xc, torch.device("cpu"))
+    # CPU baseline: the same step (torch-CPU autograd over the oracle's op order) on a BOUNDED sample of the batch's rows
+    n_cpu = min(n, a.cpu_rows)
+    cpu = None
     if a.cpu_steps > 0:
+        cpu_fn = torch_step(spec, x[:n_cpu].cpu(), torch.device("cpu"))
         cpu_fn()
-    t0 = time.perf_counter()
-    for _ in range(a.cpu_steps):
-        cpu_fn()
-    t_cpu = (time.perf_counter() - t0) / a.cpu_steps if a.cpu_steps > 0 else float("inf")   # --cpu-steps 0: GPU legs only
+        t0 = time.perf_counter()
+        for _ in range(a.cpu_steps):
+            cpu_fn()
+        t_cpu = (time.perf_counter() - t0) / a.cpu_steps
+        cpu = {"value": n_cpu / t_cpu, "unit": "samples/s", "ms_per_step": t_cpu * 1e3, "cores": torch.get_num_threads(),
+               "kind": "port", "sample": f"{a.cpu_steps} step(s) over {n_cpu} of the {n} rows, forward + backward of one component, "
+                                         "torch-CPU autograd over the oracle's op order"}
     macs = sum((w.shape[0] * w.shape[1]) for st in spec["steps"] for net in ([st["net"]] if cfg["kind"] == "glow" else [st["t_net"], st["s_net"]]) for w, _ in net["layers"])
     flops = 2.0 * macs * n * 3        # forward + dgrad + wgrad
+    kern_s = (fw + bw) * 1e-3
     print(json.dumps({
         "metric": f"training step (forward+backward) samples/sec, one component, {a.config}", "unit": "samples/s",
-        "value": n / t_hip, "ms_per_step": t_hip * 1e3, "batch": n,
+        "value": n / t_hip, "ms_per_step": t_hip * 1e3, "batch": n, "dtype": "f16x3", "data": "synthetic",
+        "config": {"workload": f"{a.config}: one component, batch {n}: traced forward, loss gradient, backward (dgrad + wgrad), synthetic weights"},
         "hip_graph_replay": None if t_graph is None else {"value": n / t_graph, "ms_per_step": t_graph * 1e3},
         "forward_kernel_ms": fw, "backward_kernels_ms": bw,
-        "algorithmic_tflops": flops / t_hip / 1e12, "algorithmic_tflops_kernels_only": flops / ((fw + bw) * 1e-3) / 1e12,
-        "torch_gpu_eager": {"value": n / t_gpu_torch, "ms_per_step": t_gpu_torch * 1e3},
-        "cpu_baseline": {"value": n / t_cpu, "ms_per_step": t_cpu * 1e3, "threads": torch.get_num_threads(),
-                         "kind": "port (torch-CPU autograd over the oracle's op order)"},
-        "speedup_vs_torch_gpu_eager": t_gpu_torch / t_hip, "speedup_vs_cpu": t_cpu / t_hip}))
+        "algorithmic_tflops": flops / t_hip / 1e12, "algorithmic_tflops_kernels_only": flops / kern_s / 1e12,
+        # forward + dgrad + wgrad contractions (3 x 2 x MACs per sample) over the kernels' own time (HIP events), against the
+        # dense f16 pipe they run on (three f16 MFMAs per f32 product: executed = 3 x achieved)
+        "roofline": {"kernel": "flow_kernel_hx3<TRAIN> + bwd_kernel_hx3 + wgrad_kernel", "bound": "mfma",
+                     "achieved": flops / kern_s / 1e12, "peak": F16_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                     "frac": flops / kern_s / 1e12 / F16_MFMA_PEAK_TFLOPS, "executed_frac": 3.0 * flops / kern_s / 1e12 / F16_MFMA_PEAK_TFLOPS,
+                     "traffic": measured_traffic(a.config, n), "launch_ms": fw + bw, "flops_per_launch": flops},
+        "torch_gpu_eager": None if t_gpu_torch is None else {"value": n / t_gpu_torch, "ms_per_step": t_gpu_torch * 1e3},
+        "cpu_baseline": cpu,
+        "speedup_vs_torch_gpu_eager": None if t_gpu_torch is None else t_gpu_torch / t_hip,
+        "speedup_vs_cpu": None if cpu is None else (n / t_hip) / cpu["value"]}))
+
+
+F16_MFMA_PEAK_TFLOPS = 2500.0      # /opt/skills/guides/MI355X_MICROARCH.md: dense bf16 / f16 matrix peak
+
+
+def measured_traffic(config, n):
+    """HBM-side bytes per training step (all kernels) from the PMC passes committed under profiles/ (2 x FETCH_SIZE + WRITE_SIZE,
+    MI355X_MICROARCH.md) -- only for the exact workload they were taken on."""
+    try:
+        rec = json.load(open(os.path.join(ROOT, "profiles", "train_traffic.json")))
+    except (OSError, ValueError):
+        return None
+    for r in rec.get("workloads", []):
+        if r.get("workload", {}).get("config") == config and r.get("workload", {}).get("batch") == n:
+            return float(r["traffic_bytes_per_step"])
+    return None
 
 
 if __name__ == "__main__":
