@@ -848,6 +848,7 @@ int gbnf_image_flow_create(const gbnf_image_flow_desc* d, gbnf_image_flow** out)
                              (const void*)img_last_hx3_kernel<EPI_COUPLE_ADD, 4>, (const void*)img_last_hx3_kernel<EPI_COUPLE_ADD, 2>};
       for (int k = 0; k < 10 && e == hipSuccess; ++k)
         e = hipFuncSetAttribute(fns[k], hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      if (e == hipSuccess) e = img_net_hx3_set_attributes();
     }
     if (e != hipSuccess) rc = fail(GBNF_ERR_HIP, "gbnf_image_flow_create: %s", hipGetErrorString(e));
   }
@@ -930,7 +931,30 @@ int gbnf_image_flow_forward(const gbnf_image_flow* f, const float* x, const floa
       // coupling net on the first half
       const std::vector<PackedConv>& net = f->net[step];
       if (net.size() == 3 && net[1].x_off != 0) {
-        // split-f16 path: [first 3x3 -> relu -> split] + 1x1 in one kernel, the last 3x3 + coupling in the second
+        // split-f16 path.  Round 4: the whole coupling net in ONE kernel where a workgroup can hold the hidden activation of its
+        // rows (+ halo) in LDS: the 16 x 16 and 8 x 8 maps of a 32 x 32 input (img_net_hx3_kernel, gbnf_image_hx3.hip.h)
+        static const bool no_fuse = getenv("GBNF_IMG_NO_FUSE") != nullptr;        // diagnostic: the round-2 two-kernel form
+        if (!no_fuse && H == W && (W == 16 || W == 8) && net[2].cout <= 48 &&
+            img_net_hx3_lds(W, f->chp, net[0].cin) <= 160 * 1024) {
+          NetLaunch q{};
+          q.pre_in = cur; q.pre_in_img = img; q.pre_wp = reinterpret_cast<const unsigned*>(blob + net[0].x_off);
+          q.pre_bias = blob + net[0].b_off; q.pre_kc = net[0].kc; q.pre_cin = net[0].cin;
+          q.pre_koff = reinterpret_cast<const int*>(blob + net[0].k_off);
+          q.wp = reinterpret_cast<const unsigned*>(blob + net[1].x_off); q.bias = blob + net[1].b_off;
+          q.wp3 = reinterpret_cast<const unsigned*>(blob + net[2].x_off); q.bias3 = blob + net[2].b_off;
+          q.st = cur + (int64_t)c1 * H * W; q.st_img = img; q.ldj = ldj;
+          q.hid = net[1].cout; q.chp = f->chp; q.cout = net[2].cout; q.H = H;
+          q.sat = reinterpret_cast<unsigned long long*>(gbnf::saturation_counter());
+          q.mark = nullptr; q.only = nullptr;
+#ifdef GBNF_IMG_STAMPS
+          q.dbg = (W == GBNF_IMG_STAMPS) ? g_img_stamp_buf : nullptr;      // -DGBNF_IMG_STAMPS=16 | 8: which level is stamped
+#endif
+          hipError_t le;
+          if (f->additive) le = (W == 16) ? img_net_hx3_launch<16, EPI_COUPLE_ADD>(q, n, s) : img_net_hx3_launch<8, EPI_COUPLE_ADD>(q, n, s);
+          else le = (W == 16) ? img_net_hx3_launch<16, EPI_COUPLE_AFFINE>(q, n, s) : img_net_hx3_launch<8, EPI_COUPLE_AFFINE>(q, n, s);
+          if (le != hipSuccess) return fail(GBNF_ERR_HIP, "img_net_hx3 launch failed: %s", hipGetErrorString(le));
+          continue;
+        }
         const int PT = IMG_R * W / 16, OT = (net[1].cout + 15) / 16;
         MidLaunch m1{};
         m1.pre_in = cur; m1.pre_in_img = img; m1.pre_wp = reinterpret_cast<const unsigned*>(blob + net[0].x_off);
