@@ -169,8 +169,13 @@ def main(argv=None):
             jobs.append([HIPCC] + FLAGS + extra + ["-DGBNF_V_ARGS=" + ",".join(str(a) for a in vargs), "-c", vsrc, "-o", o])
     img_o, img_src = os.path.join(OBJ, "gbnf_image.o"), os.path.join(HERE, "gbnf_image.hip")
     objs.append(img_o)
-    if args.force or not newer(img_o, [img_src, os.path.join(HERE, "gbnf_image_hx3.hip.h"), hdr[2], hdr[3]]):
+    if args.force or not newer(img_o, [img_src, os.path.join(HERE, "gbnf_image_hx3.hip.h"), os.path.join(HERE, "gbnf_image_net.h"), hdr[2], hdr[3]]):
         jobs.append([HIPCC] + FLAGS + ["-c", img_src, "-o", img_o])
+    # the fused image coupling-net kernel: its own unit, MFMA accumulators in VGPRs (the relu + split epilogues read them directly)
+    net_o, net_src = os.path.join(OBJ, "gbnf_image_net.o"), os.path.join(HERE, "gbnf_image_net.hip")
+    objs.append(net_o)
+    if args.force or not newer(net_o, [net_src, os.path.join(HERE, "gbnf_image_net.h")]):
+        jobs.append([HIPCC] + FLAGS + VGPR_FORM + ["-c", net_src, "-o", net_o])
     keep = set(objs)
     for fn in os.listdir(OBJ):      # drop objects of variants that left the list
         p = os.path.join(OBJ, fn)

@@ -32,6 +32,7 @@
 
 #include "../../include/gbnf.h"
 #include "gbnf_internal.h"
+#include "gbnf_image_net.h"
 
 namespace gbnf {
 
@@ -42,9 +43,7 @@ constexpr int IMG_WAVES = 4;
 constexpr int IMG_PD = 4;         // weight-prefetch distance (iterations of 4 k-steps)
 constexpr int IMG_MAX_PT = 4;     // pixel tiles of 16 per strip (IMG_R * W / 16, W <= 16)
 
-enum { EPI_RELU = 0, EPI_STORE = 1, EPI_COUPLE_AFFINE = 2, EPI_COUPLE_ADD = 3, EPI_SPLIT = 4,
-       // the z -> x direction (gbnf_image_flow_inverse): coupling^-1 and Split2d's re-draw of the half it dropped
-       EPI_COUPLE_AFFINE_INV = 5, EPI_COUPLE_ADD_INV = 6, EPI_SPLIT_INV = 7 };
+// (the epilogue kinds EPI_* live in gbnf_image_net.h: shared with the fused coupling-net kernel's translation unit)
 
 struct ConvLaunch {
   const float* in;        // (n, *, H, W): first input channel of image 0
@@ -848,7 +847,6 @@ int gbnf_image_flow_create(const gbnf_image_flow_desc* d, gbnf_image_flow** out)
                              (const void*)img_last_hx3_kernel<EPI_COUPLE_ADD, 4>, (const void*)img_last_hx3_kernel<EPI_COUPLE_ADD, 2>};
       for (int k = 0; k < 10 && e == hipSuccess; ++k)
         e = hipFuncSetAttribute(fns[k], hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-      if (e == hipSuccess) e = img_net_hx3_set_attributes();
     }
     if (e != hipSuccess) rc = fail(GBNF_ERR_HIP, "gbnf_image_flow_create: %s", hipGetErrorString(e));
   }
@@ -935,7 +933,7 @@ int gbnf_image_flow_forward(const gbnf_image_flow* f, const float* x, const floa
         // rows (+ halo) in LDS: the 16 x 16 and 8 x 8 maps of a 32 x 32 input (img_net_hx3_kernel, gbnf_image_hx3.hip.h)
         static const bool no_fuse = getenv("GBNF_IMG_NO_FUSE") != nullptr;        // diagnostic: the round-2 two-kernel form
         if (!no_fuse && H == W && (W == 16 || W == 8) && net[2].cout <= 48 &&
-            img_net_hx3_lds(W, f->chp, net[0].cin) <= 160 * 1024) {
+            img_net_hx3_lds(W, f->chp, net[0].cin, net[0].kc) != 0) {
           NetLaunch q{};
           q.pre_in = cur; q.pre_in_img = img; q.pre_wp = reinterpret_cast<const unsigned*>(blob + net[0].x_off);
           q.pre_bias = blob + net[0].b_off; q.pre_kc = net[0].kc; q.pre_cin = net[0].cin;
@@ -949,9 +947,7 @@ int gbnf_image_flow_forward(const gbnf_image_flow* f, const float* x, const floa
 #ifdef GBNF_IMG_STAMPS
           q.dbg = (W == GBNF_IMG_STAMPS) ? g_img_stamp_buf : nullptr;      // -DGBNF_IMG_STAMPS=16 | 8: which level is stamped
 #endif
-          hipError_t le;
-          if (f->additive) le = (W == 16) ? img_net_hx3_launch<16, EPI_COUPLE_ADD>(q, n, s) : img_net_hx3_launch<8, EPI_COUPLE_ADD>(q, n, s);
-          else le = (W == 16) ? img_net_hx3_launch<16, EPI_COUPLE_AFFINE>(q, n, s) : img_net_hx3_launch<8, EPI_COUPLE_AFFINE>(q, n, s);
+          const hipError_t le = img_net_hx3_launch(q, W, f->additive != 0, n, s);
           if (le != hipSuccess) return fail(GBNF_ERR_HIP, "img_net_hx3 launch failed: %s", hipGetErrorString(le));
           continue;
         }

@@ -13,8 +13,6 @@
 //   img_last_hx3_kernel: stage strip + halo -> 3x3 (f16x3, contraction split over the 4 waves) -> coupling epilogue (f32)
 #pragma once
 
-#include <type_traits>
-
 namespace gbnf {
 
 using u32x4 = __attribute__((ext_vector_type(4))) unsigned;
@@ -487,499 +485,5 @@ __global__ void __launch_bounds__(64 * IMG_WAVES) img_last_hx3_kernel(const Last
   }
 }
 
-
-// ======================================================================================================================
-// Round 4: the WHOLE coupling net of an image flow step in one kernel -- first 3x3 -> relu -> 1x1 -> relu -> last 3x3 ->
-// coupling epilogue (ConvNet, models/layers.py:304-317; FlowStep.encode, models/glow.py:317-342).  The 256-channel hidden
-// activation never leaves the CU: rounds 1-3 wrote it to HBM between img_mid_hx3 (64 MB per dispatch at batch 256) and
-// img_last_hx3 (read back with its halo: 94 MB), 70 % of the path's HBM traffic and most of both kernels' time.
-//
-// A workgroup of 8 waves owns RO = 8 output rows of one image: the whole 8 x 8 map of the second level, half of a 16 x 16
-// map of the first.  The last 3x3 needs the hidden activation one row beyond the strip: RH = 9 hidden rows are computed for
-// a 16-wide half image (the other halo row lies outside the image: zero), 12.5 % recomputation.  LDS:
-//   HB   [RH * W pixels][hi: chp halfs | mid: chp halfs | 16 B pad]    the hidden activation as split f16 (144 x 1040 B = 146 KB)
-//   ZP   one all-zero pixel: what a tap reads outside the image (an address select per pixel and tap, no masking of operands)
-//   zin  [cin][RH + 2][W + 2] f32: z1 with its halo
-// Phases (a barrier between them):
-//   1  stage z1;  2  first 3x3 as a folded f16x3 GEMM (k = tap * cin + ci) -> relu -> split -> HB: wave w owns hidden tiles
-//   w, w + 8 for every pixel tile (its A fragments stay in registers over the pixel groups);  3  1x1: wave w owns output tiles
-//   w, w + 8 x ALL pixel tiles (18 accumulator tiles), A fragments from L2 one chunk ahead, B fragments = one ds_read_b128 per
-//   pixel tile and piece; relu -> split -> back into HB (in place: every wave has finished reading);  4  last 3x3: the
-//   (tap, chunk) iterations are dealt to the waves, the partial tiles meet in LDS (over HB: its role is over), wave w finishes
-//   pixel tile w with the f32 coupling epilogue.
-// Numerics: every value that is split is range-watched (one v_max3 per pair); a workgroup that met
-// |value| > 65504 raises its image's mark and the per-device counter -- gbnf_api / gbnf_image.hip re-evaluate marked images
-// on the exact-f32 kernels.
-struct NetLaunch {
-  const float* pre_in;      // (n, *, H, W) f32: the coupling net's input z1
-  int64_t pre_in_img;
-  const unsigned* pre_wp;   // f16x3 fragments of the first 3x3 with taps folded into k: [tile][pre_kc][hi|mid][64][4 u32]
-  const float* pre_bias;    // [16 * tiles]
-  const int* pre_koff;      // [32 * pre_kc] im2col offsets of the folded contraction for a 6-row staging (img_mid_hx3's table)
-  int pre_kc, pre_cin;
-  const unsigned* wp;       // 1x1: [o][c][hi|mid][64][4 u32]
-  const float* bias;
-  const unsigned* wp3;      // last 3x3: [o][tap][c][hi|mid][64][4 u32]
-  const float* bias3;
-  float* st;                // coupled half z2 (n, *, H, W) f32, first channel of image 0
-  int64_t st_img;
-  float* ldj;
-  int hid, chp, cout, H;
-  unsigned long long* sat;  // per-device counter of workgroups that met an operand beyond the fp16 range, or null
-  unsigned* mark;           // (n,) per-image marks (non-zero: re-evaluate this image on the exact-f32 path), or null
-  const unsigned* only;     // repair launches: (n,) run only images whose entry is non-zero; null = all
-  unsigned long long* dbg;  // diagnostic builds (-DGBNF_IMG_STAMPS) only: [workgroup][wave][8] phase cycle sums
-};
-
-// split with range watch: amax = max(amax, |x0|, |x1|)
-__device__ __forceinline__ void img_split_pair_w(float x0, float x1, unsigned& hi, unsigned& mid, float& amax) {
-  amax = __builtin_fmaxf(amax, __builtin_fmaxf(__builtin_fabsf(x0), __builtin_fabsf(x1)));
-  img_split_pair(x0, x1, hi, mid);
-}
-
-template <int W, int IMG_PRE_KC, int EPI>
-__global__ void __launch_bounds__(512) img_net_hx3_kernel(const NetLaunch p) {
-  static_assert(W == 16 || W == 8, "16- and 8-wide maps");
-  extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
-  typedef const u32x4 __attribute__((address_space(1)))* gv4;
-  typedef const float __attribute__((address_space(1)))* gptr;
-  constexpr int WV = 8;
-  constexpr int S = W == 16 ? 2 : 1;                // workgroups per image
-  constexpr int RO = 8;                             // output rows per workgroup
-  constexpr int RH = W == 16 ? 9 : 8;               // hidden rows per workgroup
-  constexpr int NPH = RH * W / 16, NPO = RO * W / 16;     // pixel tiles: hidden (9 | 4), output (8 | 4)
-  constexpr int ZR = RH + 2, ZW = W + 2, CSz = ZR * ZW;
-  const int lane = threadIdx.x & 63, i = lane & 15, g = lane >> 4;
-  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int n = blockIdx.x / S, strip = blockIdx.x % S;
-  if (p.only != nullptr && p.only[n] == 0u) return;
-  const int H = p.H, r0 = strip * RO;
-  const int hr0 = (S == 2 && strip == 1) ? r0 - 1 : 0;     // first hidden row (image row) held in HB
-  const int chp = p.chp, pixb = 4 * chp + 16;
-  const int OT = (p.hid + 15) >> 4, KC = chp >> 5, kt = chp >> 4;
-  unsigned char* HB = lds_raw;                              // [NPH * 16][pixb]
-  unsigned char* ZP = HB + (size_t)NPH * 16 * pixb;         // the zero pixel
-  float* zin_f = reinterpret_cast<float*>(ZP + pixb);       // [pre_cin][ZR][ZW] (32-bit words: hi | mid << 16)
-  float amax = 0.0f;
-#ifdef GBNF_IMG_STAMPS
-  unsigned long long stamp_last = 0, stamp_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-#endif
-  IMG_STAMP(-1);
-
-  // ---- phase 1: z1 (hidden rows + halo, zero padded) as SPLIT words hi | mid << 16 -- every element is split once here,
-  //      not once per wave and tap in the im2col gather below -- and the zero pixel
-  unsigned* zin = reinterpret_cast<unsigned*>(zin_f);
-  {
-    const float* src = p.pre_in + (int64_t)n * p.pre_in_img;
-    constexpr int Q = W / 4;
-    const int q = threadIdx.x % Q, rid = threadIdx.x / Q;
-    constexpr int ROWS_PER_PASS = 64 * WV / Q;
-    for (int idx = rid; idx < p.pre_cin * ZR; idx += ROWS_PER_PASS) {
-      const int ci = idx / ZR, rr = idx - ci * ZR;
-      const int row = hr0 + rr - 1;
-      f32x4 v = {0.f, 0.f, 0.f, 0.f};
-      if (row >= 0 && row < H) v = *reinterpret_cast<const f32x4*>(src + ((int64_t)ci * H + row) * W + 4 * q);
-      unsigned h01, m01, h23, m23;
-      img_split_pair_w(v[0], v[1], h01, m01, amax);
-      img_split_pair_w(v[2], v[3], h23, m23, amax);
-      unsigned* dst = zin + ci * CSz + rr * ZW + 1 + 4 * q;
-      dst[0] = __builtin_amdgcn_perm(m01, h01, 0x05040100u);      // lo16(hi pair) | lo16(mid pair) << 16: element 0
-      dst[1] = __builtin_amdgcn_perm(m01, h01, 0x07060302u);      // hi16(hi pair) | hi16(mid pair) << 16: element 1
-      dst[2] = __builtin_amdgcn_perm(m23, h23, 0x05040100u);
-      dst[3] = __builtin_amdgcn_perm(m23, h23, 0x07060302u);
-      if (q == 0) dst[-1] = 0u;
-      if (q == Q - 1) dst[4] = 0u;
-    }
-    for (int u = threadIdx.x; u < pixb / 16; u += 64 * WV) *reinterpret_cast<u32x4*>(ZP + 16 * u) = u32x4{0u, 0u, 0u, 0u};
-  }
-  __syncthreads();
-  IMG_STAMP(0);
-
-  // ---- phase 2: first 3x3 (folded contraction) -> relu -> split -> HB
-  {
-    const gv4 pw = (gv4)p.pre_wp;
-    const int kcp = p.pre_kc;
-    // this wave's two hidden tiles: A fragments and biases once, for every pixel group
-    u32x4 ah[2][IMG_PRE_KC], am[2][IMG_PRE_KC];
-    f32x4 pb[2];
-#pragma unroll
-    for (int q = 0; q < 2; ++q) {
-      const int o = wave + q * WV, oo = o < kt ? o : 0;
-#pragma unroll
-      for (int c = 0; c < IMG_PRE_KC; ++c) {
-        const gv4 f = pw + ((size_t)oo * kcp + (c < kcp ? c : 0)) * 128 + lane;
-        ah[q][c] = f[0];
-        am[q][c] = f[64];
-      }
-      pb[q] = ((const f32x4 __attribute__((address_space(1)))*)p.pre_bias)[(o < OT ? o : 0) * 4 + g];
-    }
-    // im2col offsets of this lane's 8 k-values per chunk: word offsets from the 3x3 window's corner.  The packed table
-    // (pre_koff, made for the 6-row staging of img_mid_hx3: ci * 6 ZW + dy ZW + dx) is re-based to this kernel's ZR rows per
-    // channel; a padding slot (k >= 9 cin: -1) reads the corner itself -- any finite value: its WEIGHT is zero
-    int off[IMG_PRE_KC][8];
-#pragma unroll
-    for (int c = 0; c < IMG_PRE_KC; ++c) {
-      const int* ko = p.pre_koff + 32 * (c < kcp ? c : 0) + 8 * g;
-#pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        const int o6 = ko[j];
-        const int ci = o6 / (6 * ZW);
-        off[c][j] = o6 >= 0 ? o6 + ci * (CSz - 6 * ZW) : 0;
-      }
-    }
-    constexpr int G = IMG_PRE_KC <= 2 ? (W == 16 ? 3 : 2) : (W == 16 ? 1 : (IMG_PRE_KC <= 4 ? 2 : 1));      // pixel tiles per group (a group's B operands live in registers)
-#pragma unroll 1
-    for (int pt0 = 0; pt0 < NPH; pt0 += G) {
-      u32x4 bh[IMG_PRE_KC][G], bm[IMG_PRE_KC][G];
-#pragma unroll
-      for (int c = 0; c < IMG_PRE_KC; ++c) {
-        if (c < kcp) {
-#pragma unroll
-          for (int pg = 0; pg < G; ++pg) {
-            const int ptc = pt0 + pg < NPH ? pt0 + pg : NPH - 1;          // (a group that runs past the last tile repeats it)
-            const int lin = 16 * ptc + i, pr = lin / W, pc = lin % W;
-            const unsigned* ctr = zin + pr * ZW + pc;
-            unsigned v[8];
-#pragma unroll
-            for (int j = 0; j < 8; ++j) v[j] = ctr[off[c][j]];
-            unsigned h[4], m[4];
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-              h[q] = __builtin_amdgcn_perm(v[2 * q + 1], v[2 * q], 0x05040100u);      // the two hi pieces
-              m[q] = __builtin_amdgcn_perm(v[2 * q + 1], v[2 * q], 0x07060302u);      // the two mid pieces
-            }
-            bh[c][pg] = u32x4{h[0], h[1], h[2], h[3]};
-            bm[c][pg] = u32x4{m[0], m[1], m[2], m[3]};
-          }
-        }
-      }
-#pragma unroll
-      for (int q = 0; q < 2; ++q) {
-        const int o = wave + q * WV;
-        if (o < kt) {
-          f32x4 acc[G];
-#pragma unroll
-          for (int pg = 0; pg < G; ++pg) acc[pg] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-          for (int c = 0; c < IMG_PRE_KC; ++c) {
-            if (c < kcp) {
-#pragma unroll
-              for (int pg = 0; pg < G; ++pg) {
-                acc[pg] = img_mfma16(am[q][c], bh[c][pg], acc[pg]);
-                acc[pg] = img_mfma16(ah[q][c], bm[c][pg], acc[pg]);
-                acc[pg] = img_mfma16(ah[q][c], bh[c][pg], acc[pg]);
-              }
-            }
-          }
-          img_drain(acc);
-#pragma unroll
-          for (int pg = 0; pg < G; ++pg) {
-            if (pt0 + pg >= NPH) continue;
-            const int lin = 16 * (pt0 + pg) + i;
-            float v[4];
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-              const int co = 16 * o + 4 * g + r;
-              v[r] = co < p.hid ? fmaxf(acc[pg][r] + pb[q][r], 0.0f) : 0.0f;
-            }
-            unsigned h01, m01, h23, m23;
-            img_split_pair_w(v[0], v[1], h01, m01, amax);
-            img_split_pair_w(v[2], v[3], h23, m23, amax);
-            unsigned char* px = HB + (size_t)lin * pixb + 2 * (16 * o + 4 * g);
-            *reinterpret_cast<u32x2*>(px) = u32x2{h01, h23};
-            *reinterpret_cast<u32x2*>(px + 2 * chp) = u32x2{m01, m23};
-          }
-        }
-      }
-    }
-  }
-  IMG_STAMP(1);
-  __syncthreads();
-  IMG_STAMP(2);
-
-  // ---- phase 3: 1x1 hidden -> hidden: this wave's two output tiles x every pixel tile
-  {
-    int ow[2];
-    ow[0] = wave;
-    ow[1] = wave + WV;
-    f32x4 acc[2][NPH];
-#pragma unroll
-    for (int q = 0; q < 2; ++q)
-#pragma unroll
-      for (int pt = 0; pt < NPH; ++pt) acc[q][pt] = f32x4{0.f, 0.f, 0.f, 0.f};
-    f32x4 mid_b[2];
-#pragma unroll
-    for (int q = 0; q < 2; ++q)
-      mid_b[q] = ((const f32x4 __attribute__((address_space(1)))*)p.bias)[(ow[q] < OT ? ow[q] : 0) * 4 + g];
-    const gv4 wp = (gv4)p.wp;
-    auto load_a = [&](int c, u32x4 (&ah)[2], u32x4 (&am)[2]) {
-      const int cc = c < KC ? c : 0;
-#pragma unroll
-      for (int q = 0; q < 2; ++q) {
-        const gv4 f = wp + ((size_t)(ow[q] < OT ? ow[q] : 0) * KC + cc) * 128 + lane;
-        ah[q] = f[0];
-        am[q] = f[64];
-      }
-    };
-    const unsigned char* bbase = HB + (size_t)i * pixb + 16 * g;
-    constexpr int NH1 = (NPH + 1) / 2;
-    auto half = [&](int c, auto lo_c, auto hi_c, const u32x4 (&ah)[2], const u32x4 (&am)[2]) {
-      constexpr int LO = decltype(lo_c)::value, HI = decltype(hi_c)::value;
-      u32x4 bh[HI - LO], bm[HI - LO];
-#pragma unroll
-      for (int pt = LO; pt < HI; ++pt) {
-        const unsigned char* px = bbase + (size_t)(16 * pt) * pixb + 64 * c;
-        bh[pt - LO] = *reinterpret_cast<const u32x4*>(px);
-        bm[pt - LO] = *reinterpret_cast<const u32x4*>(px + 2 * chp);
-      }
-#pragma unroll
-      for (int q = 0; q < 2; ++q) {
-        if (ow[q] < OT) {
-#pragma unroll
-          for (int pt = LO; pt < HI; ++pt) {
-            acc[q][pt] = img_mfma16(am[q], bh[pt - LO], acc[q][pt]);
-            acc[q][pt] = img_mfma16(ah[q], bm[pt - LO], acc[q][pt]);
-            acc[q][pt] = img_mfma16(ah[q], bh[pt - LO], acc[q][pt]);
-          }
-        }
-      }
-    };
-    auto chunk = [&](int c, const u32x4 (&ah)[2], const u32x4 (&am)[2]) {
-      half(c, std::integral_constant<int, 0>{}, std::integral_constant<int, NH1>{}, ah, am);
-      half(c, std::integral_constant<int, NH1>{}, std::integral_constant<int, NPH>{}, ah, am);
-    };
-    {
-      u32x4 ah[2][2], am[2][2];
-      load_a(0, ah[0], am[0]);
-      int c = 0;
-      for (; c + 2 <= KC; c += 2) {
-        load_a(c + 1, ah[1], am[1]);
-        chunk(c, ah[0], am[0]);
-        load_a(c + 2, ah[0], am[0]);
-        chunk(c + 1, ah[1], am[1]);
-      }
-      if (c < KC) chunk(c, ah[0], am[0]);
-    }
-#pragma unroll
-    for (int q = 0; q < 2; ++q) img_drain(acc[q]);
-    IMG_STAMP(3);
-    __syncthreads();                                         // every wave is done reading HB as the 1x1's input
-    IMG_STAMP(2);
-#pragma unroll
-    for (int q = 0; q < 2; ++q) {
-      if (ow[q] < OT) {
-        const int o = ow[q];
-#pragma unroll
-        for (int pt = 0; pt < NPH; ++pt) {
-          const int lin = 16 * pt + i;
-          float v[4];
-#pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            const int co = 16 * o + 4 * g + r;
-            v[r] = co < p.hid ? fmaxf(acc[q][pt][r] + mid_b[q][r], 0.0f) : 0.0f;
-          }
-          unsigned h01, m01, h23, m23;
-          img_split_pair_w(v[0], v[1], h01, m01, amax);
-          img_split_pair_w(v[2], v[3], h23, m23, amax);
-          unsigned char* px = HB + (size_t)lin * pixb + 2 * (16 * o + 4 * g);
-          *reinterpret_cast<u32x2*>(px) = u32x2{h01, h23};
-          *reinterpret_cast<u32x2*>(px + 2 * chp) = u32x2{m01, m23};
-        }
-      }
-    }
-  }
-  IMG_STAMP(4);
-  __syncthreads();
-  IMG_STAMP(2);
-
-  // ---- phase 4: last 3x3 hidden -> shift / scale, contraction (tap, chunk) dealt to the waves
-  constexpr int MAXO = 3;
-  const int OT3 = (p.cout + 15) >> 4;                       // <= 3
-  f32x4 part[MAXO][NPO];
-#pragma unroll
-  for (int o = 0; o < MAXO; ++o)
-#pragma unroll
-    for (int pt = 0; pt < NPO; ++pt) part[o][pt] = f32x4{0.f, 0.f, 0.f, 0.f};
-  {
-    const int T_all = 9 * KC;
-    const gv4 wp3 = (gv4)p.wp3;
-    const unsigned hb_a = (unsigned)(uintptr_t)(__attribute__((address_space(3))) void*)HB;
-    const unsigned zp_a = (unsigned)(uintptr_t)(__attribute__((address_space(3))) void*)ZP + 16u * g;
-    // per output pixel tile: the LDS address of the lane's centre pixel (hi piece, chunk 0) and which of its 3 x 3 neighbours
-    // lie inside the image (bit 3 (dy + 1) + (dx + 1)); a tap outside reads the zero pixel (an address select, no operand masking)
-    unsigned ctr_a[NPO], okm[NPO];
-#pragma unroll
-    for (int pt = 0; pt < NPO; ++pt) {
-      const int lin = 16 * pt + i, pr = lin / W, pc = lin % W;
-      const int row = r0 + pr;
-      ctr_a[pt] = hb_a + (unsigned)(((row - hr0) * W + pc) * pixb) + 16u * g;
-      unsigned m = 0;
-#pragma unroll
-      for (int tp = 0; tp < 9; ++tp) {
-        const int rr = row + tp / 3 - 1, cc = pc + tp % 3 - 1;
-        m |= (rr >= 0 && rr < H && cc >= 0 && cc < W) ? (1u << tp) : 0u;
-      }
-      okm[pt] = m;
-    }
-    auto load_a = [&](int t, u32x4 (&ah)[MAXO], u32x4 (&am)[MAXO]) {
-      const int tt = t < T_all ? t : 0;
-#pragma unroll
-      for (int o = 0; o < MAXO; ++o) {
-        const gv4 f = wp3 + ((size_t)(o < OT3 ? o : 0) * T_all + tt) * 128 + lane;
-        ah[o] = f[0];
-        am[o] = f[64];
-      }
-    };
-    // B operands of one HALF of the pixel tiles; the other half's reads are in flight under this half's MFMAs
-    constexpr int HP = NPO / 2;
-    auto load_b = [&](int t, int half, u32x4 (&bh)[HP], u32x4 (&bm)[HP]) {
-      const int tt = t < T_all ? t : 0;
-      const int tap = tt / KC, c = tt - tap * KC;
-      const int d = ((tap / 3 - 1) * W + (tap % 3 - 1)) * pixb + 64 * c;
-#pragma unroll
-      for (int q = 0; q < HP; ++q) {
-        const int pt = half * HP + q;
-        const bool inside = (okm[pt] >> tap) & 1u;
-        const unsigned a = inside ? ctr_a[pt] + (unsigned)d : zp_a;
-        bh[q] = *reinterpret_cast<const __attribute__((address_space(3))) u32x4*>((uintptr_t)a);
-        bm[q] = *reinterpret_cast<const __attribute__((address_space(3))) u32x4*>((uintptr_t)(a + (inside ? 2u * chp : 0u)));
-      }
-    };
-    auto mac_half = [&](auto half_c, const u32x4 (&bh)[HP], const u32x4 (&bm)[HP], const u32x4 (&ah)[MAXO], const u32x4 (&am)[MAXO]) {
-      constexpr int half = decltype(half_c)::value;
-#pragma unroll
-      for (int o = 0; o < MAXO; ++o) {
-        if (o < OT3) {
-#pragma unroll
-          for (int q = 0; q < HP; ++q) {
-            f32x4& acc = part[o][half * HP + q];
-            acc = img_mfma16(am[o], bh[q], acc);
-            acc = img_mfma16(ah[o], bm[q], acc);
-            acc = img_mfma16(ah[o], bh[q], acc);
-          }
-        }
-      }
-    };
-    using H0 = std::integral_constant<int, 0>;
-    using H1 = std::integral_constant<int, 1>;
-    u32x4 a0h[MAXO], a0m[MAXO], a1h[MAXO], a1m[MAXO];
-    u32x4 b0h[HP], b0m[HP], b1h[HP], b1m[HP];
-    int t = wave;
-    load_a(t, a0h, a0m);
-    load_b(t, 0, b0h, b0m);
-#pragma unroll 1
-    for (; t + WV < T_all; t += 2 * WV) {
-      load_a(t + WV, a1h, a1m);
-      load_b(t, 1, b1h, b1m);
-      mac_half(H0{}, b0h, b0m, a0h, a0m);
-      load_b(t + WV, 0, b0h, b0m);
-      mac_half(H1{}, b1h, b1m, a0h, a0m);
-      load_a(t + 2 * WV, a0h, a0m);
-      load_b(t + WV, 1, b1h, b1m);
-      mac_half(H0{}, b0h, b0m, a1h, a1m);
-      load_b(t + 2 * WV, 0, b0h, b0m);
-      mac_half(H1{}, b1h, b1m, a1h, a1m);
-    }
-    if (t < T_all) {
-      load_b(t, 1, b1h, b1m);
-      mac_half(H0{}, b0h, b0m, a0h, a0m);
-      mac_half(H1{}, b1h, b1m, a0h, a0m);
-    }
-  }
-#pragma unroll
-  for (int o = 0; o < MAXO; ++o) img_drain(part[o]);
-  IMG_STAMP(5);
-
-  // ---- the partial tiles meet in LDS (over HB), one output tile at a time; wave w finishes pixel tile w
-  float ld = 0.0f;
-  f32x4* red = reinterpret_cast<f32x4*>(lds_raw);          // [wave][pt][64]
-  gptr bias3 = (gptr)p.bias3;
-  float* st = p.st + (int64_t)n * p.st_img;
-#pragma unroll
-  for (int o = 0; o < MAXO; ++o) {
-    if (o < OT3) {
-      __syncthreads();                                     // nobody reads HB (or the previous tile's partials) any more
-#pragma unroll
-      for (int pt = 0; pt < NPO; ++pt) red[(wave * NPO + pt) * 64 + lane] = part[o][pt];
-      __syncthreads();
-      if (wave < NPO) {
-        const int pt = wave;
-        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int w = 0; w < WV; ++w) acc += red[(w * NPO + pt) * 64 + lane];
-        const int lin = 16 * pt + i, row = r0 + lin / W, pc = lin % W;
-        const int64_t pix = (int64_t)row * W + pc;
-        if constexpr (EPI == EPI_COUPLE_ADD) {
-#pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            const int co = 16 * o + 4 * g + r;
-            if (co < p.cout) st[(int64_t)co * H * W + pix] += acc[r] + bias3[co];        // models/glow.py:328-329
-          }
-        } else {
-#pragma unroll
-          for (int qq = 0; qq < 2; ++qq) {
-            const int co = 16 * o + 4 * g + 2 * qq, j = co >> 1;
-            if (co + 1 < p.cout) {
-              const float h0 = acc[2 * qq] + bias3[co], h1 = acc[2 * qq + 1] + bias3[co + 1];
-              float* zp = st + (int64_t)j * H * W + pix;
-              const float e = __expf(-(h1 + 2.0f));                     // scale = sigmoid(raw + 2), models/glow.py:333
-              const float sc = 1.0f / (1.0f + e);
-              *zp = (*zp + h0) * sc;                                    // models/glow.py:334-335
-              ld += -log1pf(e);                                         // log(scale), models/glow.py:338
-            }
-          }
-        }
-      }
-    }
-  }
-  if constexpr (EPI == EPI_COUPLE_AFFINE) {
-#pragma unroll
-    for (int m = 1; m < 64; m <<= 1) ld += __shfl_xor(ld, m);
-    if (lane == 0 && wave < NPO) atomicAdd(p.ldj + n, ld);
-  }
-  IMG_STAMP(6);
-#ifdef GBNF_IMG_STAMPS
-  if (p.dbg != nullptr && lane == 0)
-    for (int kk = 0; kk < 8; ++kk) p.dbg[((size_t)blockIdx.x * WV + wave) * 8 + kk] = stamp_acc[kk];
-#endif
-  // ---- range watch: any operand of this workgroup beyond the fp16 range -> the image is marked for the exact-f32 path
-  if (__any(!(amax <= 65504.0f)) && lane == 0) {
-    if (p.sat != nullptr) atomicAdd(p.sat, 1ull);
-    if (p.mark != nullptr) atomicOr(p.mark + n, 1u);
-  }
-}
-
-// LDS bytes of img_net_hx3_kernel<W, ...>
-inline size_t img_net_hx3_lds(int W, int chp, int cin) {
-  const int RH = W == 16 ? 9 : 8, NPO = 8 * W / 16;
-  const size_t pixb = 4 * (size_t)chp + 16;
-  const size_t work = ((size_t)RH * W + 1) * pixb + (size_t)cin * (RH + 2) * (W + 2) * 4;
-  const size_t red = (size_t)8 * NPO * 64 * 16;
-  return work > red ? work : red;
-}
-
-template <int W, int EPI>
-inline hipError_t img_net_hx3_launch(const NetLaunch& q, int64_t n, hipStream_t s) {
-  const size_t lds = img_net_hx3_lds(W, q.chp, q.pre_cin);
-  const dim3 grid((unsigned)(n * (W == 16 ? 2 : 1))), blk(512);
-  const int pk = q.pre_kc <= 2 ? 2 : (q.pre_kc <= 4 ? 4 : 5);
-  if (pk == 2) hipLaunchKernelGGL((img_net_hx3_kernel<W, 2, EPI>), grid, blk, lds, s, q);
-  else if (pk == 4) hipLaunchKernelGGL((img_net_hx3_kernel<W, 4, EPI>), grid, blk, lds, s, q);
-  else hipLaunchKernelGGL((img_net_hx3_kernel<W, 5, EPI>), grid, blk, lds, s, q);
-  return hipGetLastError();
-}
-
-inline hipError_t img_net_hx3_set_attributes() {
-  const void* fns[12] = {
-      (const void*)img_net_hx3_kernel<16, 2, EPI_COUPLE_AFFINE>, (const void*)img_net_hx3_kernel<16, 4, EPI_COUPLE_AFFINE>,
-      (const void*)img_net_hx3_kernel<16, 5, EPI_COUPLE_AFFINE>, (const void*)img_net_hx3_kernel<8, 2, EPI_COUPLE_AFFINE>,
-      (const void*)img_net_hx3_kernel<8, 4, EPI_COUPLE_AFFINE>, (const void*)img_net_hx3_kernel<8, 5, EPI_COUPLE_AFFINE>,
-      (const void*)img_net_hx3_kernel<16, 2, EPI_COUPLE_ADD>, (const void*)img_net_hx3_kernel<16, 4, EPI_COUPLE_ADD>,
-      (const void*)img_net_hx3_kernel<16, 5, EPI_COUPLE_ADD>, (const void*)img_net_hx3_kernel<8, 2, EPI_COUPLE_ADD>,
-      (const void*)img_net_hx3_kernel<8, 4, EPI_COUPLE_ADD>, (const void*)img_net_hx3_kernel<8, 5, EPI_COUPLE_ADD>};
-  hipError_t e = hipSuccess;
-  for (int k = 0; k < 12 && e == hipSuccess; ++k) e = hipFuncSetAttribute(fns[k], hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-  return e;
-}
 
 }  // namespace gbnf

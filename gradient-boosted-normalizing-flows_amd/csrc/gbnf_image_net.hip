@@ -1,0 +1,577 @@
+// gbnf_image_net.hip -- the whole coupling net of an image flow step in one kernel (round 4).  Its own translation unit:
+// it is compiled with the MFMA accumulators in VGPRs (-mllvm -amdgpu-mfma-vgpr-form=1, csrc/build.py: the relu + split
+// epilogues read them directly), which the exact-f32 convolution kernels of gbnf_image.hip were measured slower with.
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <type_traits>
+
+#include "gbnf_image_net.h"
+
+namespace gbnf {
+
+using f32x4 = __attribute__((ext_vector_type(4))) float;
+using u32x4 = __attribute__((ext_vector_type(4))) unsigned;
+using u32x2 = __attribute__((ext_vector_type(2))) unsigned;
+using f16x8 = __attribute__((ext_vector_type(8))) _Float16;
+
+__device__ __forceinline__ f32x4 img_mfma16(u32x4 a, u32x4 b, f32x4 c) {
+  return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+}
+// the compiler's MFMA-result hazard padding does not look across branches on this toolchain (tools/isa_hazard_lint.py checks)
+template <int N>
+__device__ __forceinline__ void img_drain(f32x4 (&c)[N]) {
+#pragma unroll
+  for (int k = 0; k < N; ++k) asm volatile("s_nop 7\n\ts_nop 7" : "+v"(c[k]));
+}
+// hi = f16(x) (toward zero), mid = f16(x - hi) for a pair, range-watched: amax = max(amax, |x0|, |x1|).  No clamp: both
+// conversions round TOWARD ZERO, so a value beyond the fp16 range converts to +-65504 (never to infinity) and every piece stays
+// finite; the result is wrong there, which is what the watch is for (the image is marked and re-evaluated in f32).
+__device__ __forceinline__ void img_split_pair_w(float x0, float x1, unsigned& hi, unsigned& mid, float& amax) {
+  amax = __builtin_fmaxf(amax, __builtin_fmaxf(__builtin_fabsf(x0), __builtin_fabsf(x1)));
+  const auto h = __builtin_amdgcn_cvt_pkrtz(x0, x1);
+  hi = __builtin_bit_cast(unsigned, h);
+  // IN PLACE (an asm output must never be a fresh register: gbnf_flow_kernel_hx3.hip.h, split_pair_f16)
+  float r0 = x0, r1 = x1;
+  asm("v_fma_mix_f32 %0, %1, -1.0, %0 op_sel_hi:[1,0,0]" : "+v"(r0) : "v"(hi));
+  asm("v_fma_mix_f32 %0, %1, -1.0, %0 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(r1) : "v"(hi));
+  const auto m = __builtin_amdgcn_cvt_pkrtz(r0, r1);
+  mid = __builtin_bit_cast(unsigned, m);
+}
+
+#ifdef GBNF_IMG_STAMPS
+#define IMG_STAMP(k)                                                                         \
+  do {                                                                                       \
+    unsigned long long t_;                                                                   \
+    __builtin_amdgcn_sched_barrier(0);                                                       \
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");              \
+    __builtin_amdgcn_sched_barrier(0);                                                       \
+    if ((k) >= 0) stamp_acc[(k)] += t_ - stamp_last;                                         \
+    stamp_last = t_;                                                                         \
+  } while (0)
+#else
+#define IMG_STAMP(k) do { } while (0)
+#endif
+
+// ======================================================================================================================
+// Round 4: the WHOLE coupling net of an image flow step in one kernel -- first 3x3 -> relu -> 1x1 -> relu -> last 3x3 ->
+// coupling epilogue (ConvNet, models/layers.py:304-317; FlowStep.encode, models/glow.py:317-342).  The 256-channel hidden
+// activation never leaves the CU: rounds 1-3 wrote it to HBM between img_mid_hx3 (64 MB per dispatch at batch 256) and
+// img_last_hx3 (read back with its halo: 94 MB), 70 % of the path's HBM traffic and most of both kernels' time.
+//
+// A workgroup of 8 waves owns RO = 8 output rows of one image: the whole 8 x 8 map of the second level, half of a 16 x 16
+// map of the first.  The last 3x3 needs the hidden activation one row beyond the strip: RH = 9 hidden rows are computed for
+// a 16-wide half image (the other halo row lies outside the image: zero), 12.5 % recomputation.  LDS:
+//   HB   [RH * W pixels][hi: chp halfs | mid: chp halfs | 16 B pad]    the hidden activation as split f16 (144 x 1040 B = 146 KB)
+//   ZP   one all-zero pixel: what a tap reads outside the image (an address select per pixel and tap, no masking of operands)
+//   zin  [cin][RH + 2][W + 2] f32: z1 with its halo
+// Phases (a barrier between them):
+//   1  stage z1;  2  first 3x3 as a folded f16x3 GEMM (k = tap * cin + ci) -> relu -> split -> HB: wave w owns hidden tiles
+//   w, w + 8 for every pixel tile (its A fragments stay in registers over the pixel groups);  3  1x1: wave w owns output tiles
+//   w, w + 8 x ALL pixel tiles (18 accumulator tiles), A fragments from L2 one chunk ahead, B fragments = one ds_read_b128 per
+//   pixel tile and piece; relu -> split -> back into HB (in place: every wave has finished reading);  4  last 3x3: the
+//   (tap, chunk) iterations are dealt to the waves, the partial tiles meet in LDS (over HB: its role is over), wave w finishes
+//   pixel tile w with the f32 coupling epilogue.
+// Numerics: every value that is split is range-watched (one v_max3 per pair); a workgroup that met
+// |value| > 65504 raises its image's mark and the per-device counter -- gbnf_api / gbnf_image.hip re-evaluate marked images
+// on the exact-f32 kernels.
+
+
+template <int W, int IMG_PRE_KC, int EPI, int OT3>
+__global__ void __launch_bounds__(512) img_net_hx3_kernel(const NetLaunch p) {
+  static_assert(OT3 >= 1 && OT3 <= 3, "the last 3x3 has at most 48 output channels");
+  static_assert(W == 16 || W == 8, "16- and 8-wide maps");
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+  typedef const u32x4 __attribute__((address_space(1)))* gv4;
+  typedef const float __attribute__((address_space(1)))* gptr;
+  constexpr int WV = 8;
+  constexpr int S = W == 16 ? 2 : 1;                // workgroups per image
+  constexpr int RO = 8;                             // output rows per workgroup
+  constexpr int RH = W == 16 ? 9 : 8;               // hidden rows per workgroup
+  constexpr int NPH = RH * W / 16, NPO = RO * W / 16;     // pixel tiles: hidden (9 | 4), output (8 | 4)
+  constexpr int ZR = RH + 2, ZW = W + 2, CSz = ZR * ZW;
+  const int lane = threadIdx.x & 63, i = lane & 15, g = lane >> 4;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int n = blockIdx.x / S, strip = blockIdx.x % S;
+  if (p.only != nullptr && p.only[n] == 0u) return;
+  const int H = p.H, r0 = strip * RO;
+  const int hr0 = (S == 2 && strip == 1) ? r0 - 1 : 0;     // first hidden row (image row) held in HB
+  const int chp = p.chp, pixb = 4 * chp + 16;
+  const int OT = (p.hid + 15) >> 4, KC = chp >> 5, kt = chp >> 4;
+  unsigned char* HB = lds_raw;                              // [NPH * 16][pixb]
+  unsigned char* ZP = HB + (size_t)NPH * 16 * pixb;         // the zero pixel
+  float* zin_f = reinterpret_cast<float*>(ZP + pixb);       // [pre_cin][ZR][ZW] (32-bit words: hi | mid << 16)
+  int* koffs = reinterpret_cast<int*>(zin_f + p.pre_cin * CSz);      // [32 * pre_kc] im2col word offsets for THIS kernel's staging
+  float amax = 0.0f;
+#ifdef GBNF_IMG_STAMPS
+  unsigned long long stamp_last = 0, stamp_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#endif
+  IMG_STAMP(-1);
+
+  // ---- phase 1: z1 (hidden rows + halo, zero padded) as SPLIT words hi | mid << 16 -- every element is split once here,
+  //      not once per wave and tap in the im2col gather below -- and the zero pixel
+  unsigned* zin = reinterpret_cast<unsigned*>(zin_f);
+  {
+    const float* src = p.pre_in + (int64_t)n * p.pre_in_img;
+    constexpr int Q = W / 4;
+    const int q = threadIdx.x % Q, rid = threadIdx.x / Q;
+    constexpr int ROWS_PER_PASS = 64 * WV / Q;
+    for (int idx = rid; idx < p.pre_cin * ZR; idx += ROWS_PER_PASS) {
+      const int ci = idx / ZR, rr = idx - ci * ZR;
+      const int row = hr0 + rr - 1;
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (row >= 0 && row < H) v = *reinterpret_cast<const f32x4*>(src + ((int64_t)ci * H + row) * W + 4 * q);
+      unsigned h01, m01, h23, m23;
+      img_split_pair_w(v[0], v[1], h01, m01, amax);
+      img_split_pair_w(v[2], v[3], h23, m23, amax);
+      unsigned* dst = zin + ci * CSz + rr * ZW + 1 + 4 * q;
+      dst[0] = __builtin_amdgcn_perm(m01, h01, 0x05040100u);      // lo16(hi pair) | lo16(mid pair) << 16: element 0
+      dst[1] = __builtin_amdgcn_perm(m01, h01, 0x07060302u);      // hi16(hi pair) | hi16(mid pair) << 16: element 1
+      dst[2] = __builtin_amdgcn_perm(m23, h23, 0x05040100u);
+      dst[3] = __builtin_amdgcn_perm(m23, h23, 0x07060302u);
+      if (q == 0) dst[-1] = 0u;
+      if (q == Q - 1) dst[4] = 0u;
+    }
+    for (int u = threadIdx.x; u < pixb / 16; u += 64 * WV) *reinterpret_cast<u32x4*>(ZP + 16 * u) = u32x4{0u, 0u, 0u, 0u};
+    // the packed im2col table (made for the 6-row staging of img_mid_hx3: ci * 6 ZW + dy ZW + dx) re-based to this kernel's ZR
+    // rows per channel; a padding slot (k >= 9 cin: -1) reads the window's corner -- any finite value will do: its WEIGHT is zero
+    if ((int)threadIdx.x < 32 * p.pre_kc) {
+      const int o6 = p.pre_koff[threadIdx.x];
+      const int ci = o6 / (6 * ZW);
+      koffs[threadIdx.x] = o6 >= 0 ? o6 + ci * (CSz - 6 * ZW) : 0;
+    }
+  }
+  __syncthreads();
+  IMG_STAMP(0);
+
+  // ---- phase 2: first 3x3 (folded contraction) -> relu -> split -> HB
+  //      (a) the im2col B operands are built ONCE per workgroup -- wave w gathers the fragment pairs w, w + 8, ... (pixel tile,
+  //      chunk) from the split words of z1 and leaves them in BF as ready-made lane-linear fragments; every wave built all of
+  //      them for itself before (27 % of the kernel for 14 % of its MFMAs).  BF sits behind the other buffers where LDS allows
+  //      and else over the tail of HB, which the first 3x3's own output fills last: a group of pixel tiles whose output reaches
+  //      into BF is computed behind a barrier that follows its B loads (every later group's fragments lie above its output).
+  unsigned char* BF = lds_raw + p.bf_off;                   // [NPH][pre_kc][hi | mid][64 lanes][16 B]
+  {
+    const int kcp = p.pre_kc;
+    for (int u = wave; u < NPH * kcp; u += WV) {
+      const int pt = u / kcp, c = u - pt * kcp;
+      const int* ko = koffs + 32 * c + 8 * g;
+      const int lin = 16 * pt + i, pr = lin / W, pc = lin % W;
+      const unsigned* ctr = zin + pr * ZW + pc;
+      int o8[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) o8[j] = ko[j];
+      unsigned v[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v[j] = ctr[o8[j]];
+      u32x4 fh, fm;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        fh[q] = __builtin_amdgcn_perm(v[2 * q + 1], v[2 * q], 0x05040100u);      // the two hi pieces
+        fm[q] = __builtin_amdgcn_perm(v[2 * q + 1], v[2 * q], 0x07060302u);      // the two mid pieces
+      }
+      *reinterpret_cast<u32x4*>(BF + ((size_t)u * 2) * 1024 + 16 * lane) = fh;
+      *reinterpret_cast<u32x4*>(BF + ((size_t)u * 2 + 1) * 1024 + 16 * lane) = fm;
+    }
+  }
+  __syncthreads();
+  {
+    const gv4 pw = (gv4)p.pre_wp;
+    const int kcp = p.pre_kc;
+    // this wave's two hidden tiles: A fragments and biases once, for every pixel group
+    u32x4 ah[2][IMG_PRE_KC], am[2][IMG_PRE_KC];
+    f32x4 pb[2];
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      const int o = wave + q * WV, oo = o < kt ? o : 0;
+#pragma unroll
+      for (int c = 0; c < IMG_PRE_KC; ++c) {
+        const gv4 f = pw + ((size_t)oo * kcp + (c < kcp ? c : 0)) * 128 + lane;
+        ah[q][c] = f[0];
+        am[q][c] = f[64];
+      }
+      pb[q] = ((const f32x4 __attribute__((address_space(1)))*)p.pre_bias)[(o < OT ? o : 0) * 4 + g];
+    }
+    constexpr int G = IMG_PRE_KC <= 2 ? (W == 16 ? 3 : 2) : (W == 16 ? 1 : (IMG_PRE_KC <= 4 ? 2 : 1));      // pixel tiles per group (a group's B operands live in registers)
+#pragma unroll 1
+    for (int pt0 = 0; pt0 < NPH; pt0 += G) {
+      u32x4 bh[IMG_PRE_KC][G], bm[IMG_PRE_KC][G];
+#pragma unroll
+      for (int c = 0; c < IMG_PRE_KC; ++c) {
+#pragma unroll
+        for (int pg = 0; pg < G; ++pg) {
+          const int ptc = pt0 + pg < NPH ? pt0 + pg : NPH - 1;          // (a group that runs past the last tile repeats it)
+          const unsigned char* f = BF + ((size_t)(ptc * kcp + (c < kcp ? c : 0)) * 2) * 1024 + 16 * lane;
+          bh[c][pg] = *reinterpret_cast<const u32x4*>(f);
+          bm[c][pg] = *reinterpret_cast<const u32x4*>(f + 1024);
+        }
+      }
+      if ((pt0 + G) * 16 * pixb > p.bf_off) __syncthreads();           // this group's output overwrites fragments: every wave holds its B operands first
+#pragma unroll
+      for (int q = 0; q < 2; ++q) {
+        const int o = wave + q * WV;
+        {                                                    // (a tile index past the end computes a valid tile again: nothing is stored)
+          f32x4 acc[G];
+#pragma unroll
+          for (int pg = 0; pg < G; ++pg) acc[pg] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+          for (int c = 0; c < IMG_PRE_KC; ++c) {
+            if (c < kcp) {
+#pragma unroll
+              for (int pg = 0; pg < G; ++pg) {
+                acc[pg] = img_mfma16(am[q][c], bh[c][pg], acc[pg]);
+                acc[pg] = img_mfma16(ah[q][c], bm[c][pg], acc[pg]);
+                acc[pg] = img_mfma16(ah[q][c], bh[c][pg], acc[pg]);
+              }
+            }
+          }
+          img_drain(acc);
+#pragma unroll
+          for (int pg = 0; pg < G; ++pg) {
+            if (pt0 + pg >= NPH || o >= kt) continue;
+            const int lin = 16 * (pt0 + pg) + i;
+            float v[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              const int co = 16 * o + 4 * g + r;
+              v[r] = co < p.hid ? fmaxf(acc[pg][r] + pb[q][r], 0.0f) : 0.0f;
+            }
+            unsigned h01, m01, h23, m23;
+            img_split_pair_w(v[0], v[1], h01, m01, amax);
+            img_split_pair_w(v[2], v[3], h23, m23, amax);
+            unsigned char* px = HB + (size_t)lin * pixb + 2 * (16 * o + 4 * g);
+            *reinterpret_cast<u32x2*>(px) = u32x2{h01, h23};
+            *reinterpret_cast<u32x2*>(px + 2 * chp) = u32x2{m01, m23};
+          }
+        }
+      }
+    }
+  }
+  IMG_STAMP(1);
+  __syncthreads();
+  IMG_STAMP(2);
+
+  // ---- phase 3: 1x1 hidden -> hidden: this wave's two output tiles x every pixel tile
+  {
+    int ow[2];
+    ow[0] = wave;
+    ow[1] = wave + WV;
+    f32x4 acc[2][NPH];
+#pragma unroll
+    for (int q = 0; q < 2; ++q)
+#pragma unroll
+      for (int pt = 0; pt < NPH; ++pt) acc[q][pt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    f32x4 mid_b[2];
+#pragma unroll
+    for (int q = 0; q < 2; ++q)
+      mid_b[q] = ((const f32x4 __attribute__((address_space(1)))*)p.bias)[(ow[q] < OT ? ow[q] : 0) * 4 + g];
+    const gv4 wp = (gv4)p.wp;
+    auto load_a = [&](int c, u32x4 (&ah)[2], u32x4 (&am)[2]) {
+      const int cc = c < KC ? c : 0;
+#pragma unroll
+      for (int q = 0; q < 2; ++q) {
+        const gv4 f = wp + ((size_t)(ow[q] < OT ? ow[q] : 0) * KC + cc) * 128 + lane;
+        ah[q] = f[0];
+        am[q] = f[64];
+      }
+    };
+    const unsigned char* bbase = HB + (size_t)i * pixb + 16 * g;
+    constexpr int NH1 = (NPH + 1) / 2;
+    auto half = [&](int c, auto lo_c, auto hi_c, const u32x4 (&ah)[2], const u32x4 (&am)[2]) {
+      constexpr int LO = decltype(lo_c)::value, HI = decltype(hi_c)::value;
+      u32x4 bh[HI - LO], bm[HI - LO];
+#pragma unroll
+      for (int pt = LO; pt < HI; ++pt) {
+        const unsigned char* px = bbase + (size_t)(16 * pt) * pixb + 64 * c;
+        bh[pt - LO] = *reinterpret_cast<const u32x4*>(px);
+        bm[pt - LO] = *reinterpret_cast<const u32x4*>(px + 2 * chp);
+      }
+#pragma unroll
+      for (int q = 0; q < 2; ++q) {                          // (an idle slot repeats tile 0: no branch in the stream, nothing stored)
+#pragma unroll
+        for (int pt = LO; pt < HI; ++pt) {
+          acc[q][pt] = img_mfma16(am[q], bh[pt - LO], acc[q][pt]);
+          acc[q][pt] = img_mfma16(ah[q], bm[pt - LO], acc[q][pt]);
+          acc[q][pt] = img_mfma16(ah[q], bh[pt - LO], acc[q][pt]);
+        }
+      }
+    };
+    auto chunk = [&](int c, const u32x4 (&ah)[2], const u32x4 (&am)[2]) {
+      half(c, std::integral_constant<int, 0>{}, std::integral_constant<int, NH1>{}, ah, am);
+      half(c, std::integral_constant<int, NH1>{}, std::integral_constant<int, NPH>{}, ah, am);
+    };
+    {
+      u32x4 ah[2][2], am[2][2];
+      load_a(0, ah[0], am[0]);
+      int c = 0;
+      for (; c + 2 <= KC; c += 2) {
+        load_a(c + 1, ah[1], am[1]);
+        chunk(c, ah[0], am[0]);
+        load_a(c + 2, ah[0], am[0]);
+        chunk(c + 1, ah[1], am[1]);
+      }
+      if (c < KC) chunk(c, ah[0], am[0]);
+    }
+#pragma unroll
+    for (int q = 0; q < 2; ++q) img_drain(acc[q]);
+    IMG_STAMP(3);
+    __syncthreads();                                         // every wave is done reading HB as the 1x1's input
+    IMG_STAMP(2);
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      if (ow[q] < OT) {
+        const int o = ow[q];
+#pragma unroll
+        for (int pt = 0; pt < NPH; ++pt) {
+          const int lin = 16 * pt + i;
+          float v[4];
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int co = 16 * o + 4 * g + r;
+            v[r] = co < p.hid ? fmaxf(acc[q][pt][r] + mid_b[q][r], 0.0f) : 0.0f;
+          }
+          unsigned h01, m01, h23, m23;
+          img_split_pair_w(v[0], v[1], h01, m01, amax);
+          img_split_pair_w(v[2], v[3], h23, m23, amax);
+          unsigned char* px = HB + (size_t)lin * pixb + 2 * (16 * o + 4 * g);
+          *reinterpret_cast<u32x2*>(px) = u32x2{h01, h23};
+          *reinterpret_cast<u32x2*>(px + 2 * chp) = u32x2{m01, m23};
+        }
+      }
+    }
+  }
+  IMG_STAMP(4);
+  __syncthreads();
+  IMG_STAMP(2);
+
+  // ---- phase 4: last 3x3 hidden -> shift / scale, contraction (tap, chunk) dealt to the waves
+  float z2v[OT3][4];        // the state values this lane's epilogue updates (pixel tile = wave)
+  {
+    const float* stq = p.st + (int64_t)n * p.st_img;
+    const int lin = 16 * (wave < NPO ? wave : 0) + i, row = r0 + lin / W, pc = lin % W;
+    const int64_t pix = (int64_t)row * W + pc;
+#pragma unroll
+    for (int o = 0; o < OT3; ++o)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int co = 16 * o + 4 * g + r;
+        const int ch = EPI == EPI_COUPLE_ADD ? co : (co >> 1);          // affine: rows (2 j, 2 j + 1) = (shift, raw scale) of channel j
+        const bool use = EPI == EPI_COUPLE_ADD ? co < p.cout : ((r & 1) == 0 && co + 1 < p.cout);
+        z2v[o][r] = use ? stq[(int64_t)ch * H * W + pix] : 0.0f;
+      }
+  }
+  constexpr int MAXO = OT3;                                 // output tiles of the last 3x3 (template: no branches around its MFMAs)
+  f32x4 part[MAXO][NPO];
+#pragma unroll
+  for (int o = 0; o < MAXO; ++o)
+#pragma unroll
+    for (int pt = 0; pt < NPO; ++pt) part[o][pt] = f32x4{0.f, 0.f, 0.f, 0.f};
+  {
+    const int T_all = 9 * KC;
+    const gv4 wp3 = (gv4)p.wp3;
+    const unsigned hb_a = (unsigned)(uintptr_t)(__attribute__((address_space(3))) void*)HB;
+    const unsigned zp_a = (unsigned)(uintptr_t)(__attribute__((address_space(3))) void*)ZP + 16u * g;
+    // per output pixel tile: the LDS address of the lane's centre pixel (hi piece, chunk 0) and which of its 3 x 3 neighbours
+    // lie inside the image (bit 3 (dy + 1) + (dx + 1)); a tap outside reads the zero pixel (an address select, no operand masking)
+    unsigned ctr_a[NPO], okm[NPO];
+#pragma unroll
+    for (int pt = 0; pt < NPO; ++pt) {
+      const int lin = 16 * pt + i, pr = lin / W, pc = lin % W;
+      const int row = r0 + pr;
+      ctr_a[pt] = hb_a + (unsigned)(((row - hr0) * W + pc) * pixb) + 16u * g;
+      unsigned m = 0;
+#pragma unroll
+      for (int tp = 0; tp < 9; ++tp) {
+        const int rr = row + tp / 3 - 1, cc = pc + tp % 3 - 1;
+        m |= (rr >= 0 && rr < H && cc >= 0 && cc < W) ? (1u << tp) : 0u;
+      }
+      okm[pt] = m;
+    }
+    auto load_a = [&](int t, u32x4 (&ah)[MAXO], u32x4 (&am)[MAXO]) {
+      const int tt = t < T_all ? t : 0;
+#pragma unroll
+      for (int o = 0; o < MAXO; ++o) {
+        const gv4 f = wp3 + ((size_t)o * T_all + tt) * 128 + lane;
+        ah[o] = f[0];
+        am[o] = f[64];
+      }
+    };
+    // B operands of one HALF of the pixel tiles; the other half's reads are in flight under this half's MFMAs
+    constexpr int HP = NPO / 2;
+    auto load_b = [&](int t, int half, u32x4 (&bh)[HP], u32x4 (&bm)[HP]) {
+      const int tt = t < T_all ? t : 0;
+      const int tap = tt / KC, c = tt - tap * KC;
+      const int d = ((tap / 3 - 1) * W + (tap % 3 - 1)) * pixb + 64 * c;
+#pragma unroll
+      for (int q = 0; q < HP; ++q) {
+        const int pt = half * HP + q;
+        const bool inside = (okm[pt] >> tap) & 1u;
+        const unsigned a = inside ? ctr_a[pt] + (unsigned)d : zp_a;
+        bh[q] = *reinterpret_cast<const __attribute__((address_space(3))) u32x4*>((uintptr_t)a);
+        bm[q] = *reinterpret_cast<const __attribute__((address_space(3))) u32x4*>((uintptr_t)(a + (inside ? 2u * chp : 0u)));
+      }
+    };
+    auto mac_half = [&](auto half_c, const u32x4 (&bh)[HP], const u32x4 (&bm)[HP], const u32x4 (&ah)[MAXO], const u32x4 (&am)[MAXO]) {
+      constexpr int half = decltype(half_c)::value;
+#pragma unroll
+      for (int o = 0; o < MAXO; ++o) {
+#pragma unroll
+        for (int q = 0; q < HP; ++q) {
+          f32x4& acc = part[o][half * HP + q];
+          acc = img_mfma16(am[o], bh[q], acc);
+          acc = img_mfma16(ah[o], bm[q], acc);
+          acc = img_mfma16(ah[o], bh[q], acc);
+        }
+      }
+    };
+    using H0 = std::integral_constant<int, 0>;
+    using H1 = std::integral_constant<int, 1>;
+    u32x4 a0h[MAXO], a0m[MAXO], a1h[MAXO], a1m[MAXO];
+    u32x4 b0h[HP], b0m[HP], b1h[HP], b1m[HP];
+    int t = wave;
+    load_a(t, a0h, a0m);
+    load_b(t, 0, b0h, b0m);
+#pragma unroll 1
+    for (; t + WV < T_all; t += 2 * WV) {
+      load_a(t + WV, a1h, a1m);
+      load_b(t, 1, b1h, b1m);
+      mac_half(H0{}, b0h, b0m, a0h, a0m);
+      load_b(t + WV, 0, b0h, b0m);
+      mac_half(H1{}, b1h, b1m, a0h, a0m);
+      load_a(t + 2 * WV, a0h, a0m);
+      load_b(t + WV, 1, b1h, b1m);
+      mac_half(H0{}, b0h, b0m, a1h, a1m);
+      load_b(t + 2 * WV, 0, b0h, b0m);
+      mac_half(H1{}, b1h, b1m, a1h, a1m);
+    }
+    if (t < T_all) {
+      load_b(t, 1, b1h, b1m);
+      mac_half(H0{}, b0h, b0m, a0h, a0m);
+      mac_half(H1{}, b1h, b1m, a0h, a0m);
+    }
+  }
+#pragma unroll
+  for (int o = 0; o < MAXO; ++o) img_drain(part[o]);
+  IMG_STAMP(5);
+
+  // ---- the partial tiles meet in LDS (over HB), one output tile at a time; wave w finishes pixel tile w
+  //      (its z2 values were requested in front of the last 3x3: a global round trip less at the tail of the workgroup)
+  float ld = 0.0f;
+  f32x4* red = reinterpret_cast<f32x4*>(lds_raw);          // [wave][pt][64]
+  gptr bias3 = (gptr)p.bias3;
+  float* st = p.st + (int64_t)n * p.st_img;
+#pragma unroll
+  for (int o = 0; o < MAXO; ++o) {
+    {
+      __syncthreads();                                     // nobody reads HB (or the previous tile's partials) any more
+#pragma unroll
+      for (int pt = 0; pt < NPO; ++pt) red[(wave * NPO + pt) * 64 + lane] = part[o][pt];
+      __syncthreads();
+      if (wave < NPO) {
+        const int pt = wave;
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int w = 0; w < WV; ++w) acc += red[(w * NPO + pt) * 64 + lane];
+        const int lin = 16 * pt + i, row = r0 + lin / W, pc = lin % W;
+        const int64_t pix = (int64_t)row * W + pc;
+        if constexpr (EPI == EPI_COUPLE_ADD) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int co = 16 * o + 4 * g + r;
+            if (co < p.cout) st[(int64_t)co * H * W + pix] = z2v[o][r] + (acc[r] + bias3[co]);        // models/glow.py:328-329
+          }
+        } else {
+#pragma unroll
+          for (int qq = 0; qq < 2; ++qq) {
+            const int co = 16 * o + 4 * g + 2 * qq, j = co >> 1;
+            if (co + 1 < p.cout) {
+              const float h0 = acc[2 * qq] + bias3[co], h1 = acc[2 * qq + 1] + bias3[co + 1];
+              float* zp = st + (int64_t)j * H * W + pix;
+              const float e = __expf(-(h1 + 2.0f));                     // scale = sigmoid(raw + 2), models/glow.py:333
+              const float sc = 1.0f / (1.0f + e);
+              *zp = (z2v[o][2 * qq] + h0) * sc;                         // models/glow.py:334-335
+              ld += -log1pf(e);                                         // log(scale), models/glow.py:338
+            }
+          }
+        }
+      }
+    }
+  }
+  if constexpr (EPI == EPI_COUPLE_AFFINE) {
+#pragma unroll
+    for (int m = 1; m < 64; m <<= 1) ld += __shfl_xor(ld, m);
+    if (lane == 0 && wave < NPO) atomicAdd(p.ldj + n, ld);
+  }
+  IMG_STAMP(6);
+#ifdef GBNF_IMG_STAMPS
+  if (p.dbg != nullptr && lane == 0)
+    for (int kk = 0; kk < 8; ++kk) p.dbg[((size_t)blockIdx.x * WV + wave) * 8 + kk] = stamp_acc[kk];
+#endif
+  // ---- range watch: any operand of this workgroup beyond the fp16 range -> the image is marked for the exact-f32 path
+  if (__any(!(amax <= 65504.0f)) && lane == 0) {
+    if (p.sat != nullptr) atomicAdd(p.sat, 1ull);
+    if (p.mark != nullptr) atomicOr(p.mark + n, 1u);
+  }
+}
+
+// LDS layout: HB | ZP | zin | [BF]; BF (the first 3x3's B fragments) goes behind the rest when that fits 160 KB, else over the
+// tail of HB (see phase 2).  *bf_off: byte offset of BF.
+static size_t img_net_hx3_layout(int W, int chp, int cin, int pre_kc, size_t* bf_off) {
+  const int RH = W == 16 ? 9 : 8, NPO = 8 * W / 16, NPH = RH * W / 16;
+  const size_t pixb = 4 * (size_t)chp + 16;
+  const size_t hb = (size_t)RH * W * pixb;
+  const size_t work = hb + pixb + (size_t)cin * (RH + 2) * (W + 2) * 4 + (size_t)32 * pre_kc * 4;      // HB | ZP | zin | im2col table
+  const size_t bf = (size_t)NPH * pre_kc * 2 * 1024;
+  size_t total = work, off = (work + 15) / 16 * 16;
+  if (off + bf <= 160 * 1024) {
+    total = off + bf;
+  } else if (bf <= hb) {
+    off = hb - bf;                                   // (hb and bf are multiples of 16)
+  } else {
+    total = 0;                                       // does not fit either way: the caller keeps the two-kernel form
+    off = 0;
+  }
+  if (bf_off) *bf_off = off;
+  const size_t red = (size_t)8 * NPO * 64 * 16;
+  return total == 0 ? 0 : (total > red ? total : red);
+}
+size_t img_net_hx3_lds(int W, int chp, int cin, int pre_kc) { return img_net_hx3_layout(W, chp, cin, pre_kc, nullptr); }
+
+template <int W, int EPI, int OT3>
+static hipError_t img_net_hx3_launch3(const NetLaunch& q0, int64_t n, hipStream_t s) {
+  NetLaunch q = q0;
+  size_t bf_off = 0;
+  const size_t lds = img_net_hx3_layout(W, q.chp, q.pre_cin, q.pre_kc, &bf_off);
+  if (lds == 0 || lds > 160 * 1024) return hipErrorInvalidValue;
+  q.bf_off = (unsigned)bf_off;
+  const dim3 grid((unsigned)(n * (W == 16 ? 2 : 1))), blk(512);
+  const int pk = q.pre_kc <= 2 ? 2 : (q.pre_kc <= 4 ? 4 : 5);
+  static bool attr_set = false;
+  if (!attr_set) {
+    const void* fns[3] = {(const void*)img_net_hx3_kernel<W, 2, EPI, OT3>, (const void*)img_net_hx3_kernel<W, 4, EPI, OT3>,
+                          (const void*)img_net_hx3_kernel<W, 5, EPI, OT3>};
+    for (int k = 0; k < 3; ++k) {
+      const hipError_t e = hipFuncSetAttribute(fns[k], hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      if (e != hipSuccess) return e;
+    }
+    attr_set = true;
+  }
+  if (pk == 2) hipLaunchKernelGGL((img_net_hx3_kernel<W, 2, EPI, OT3>), grid, blk, lds, s, q);
+  else if (pk == 4) hipLaunchKernelGGL((img_net_hx3_kernel<W, 4, EPI, OT3>), grid, blk, lds, s, q);
+  else hipLaunchKernelGGL((img_net_hx3_kernel<W, 5, EPI, OT3>), grid, blk, lds, s, q);
+  return hipGetLastError();
+}
+template <int W, int EPI>
+static hipError_t img_net_hx3_launch2(const NetLaunch& q, int64_t n, hipStream_t s) {
+  const int ot3 = (q.cout + 15) >> 4;
+  if (ot3 == 1) return img_net_hx3_launch3<W, EPI, 1>(q, n, s);
+  if (ot3 == 2) return img_net_hx3_launch3<W, EPI, 2>(q, n, s);
+  return img_net_hx3_launch3<W, EPI, 3>(q, n, s);
+}
+hipError_t img_net_hx3_launch(const NetLaunch& q, int W, bool additive, int64_t n, hipStream_t s) {
+  if (W == 16) return additive ? img_net_hx3_launch2<16, EPI_COUPLE_ADD>(q, n, s) : img_net_hx3_launch2<16, EPI_COUPLE_AFFINE>(q, n, s);
+  if (W == 8) return additive ? img_net_hx3_launch2<8, EPI_COUPLE_ADD>(q, n, s) : img_net_hx3_launch2<8, EPI_COUPLE_AFFINE>(q, n, s);
+  return hipErrorInvalidValue;
+}
+
+}  // namespace gbnf
