@@ -932,8 +932,7 @@ int gbnf_image_flow_forward(const gbnf_image_flow* f, const float* x, const floa
         // split-f16 path.  Round 4: the whole coupling net in ONE kernel where a workgroup can hold the hidden activation of its
         // rows (+ halo) in LDS: the 16 x 16 and 8 x 8 maps of a 32 x 32 input (img_net_hx3_kernel, gbnf_image_hx3.hip.h)
         static const bool no_fuse = getenv("GBNF_IMG_NO_FUSE") != nullptr;        // diagnostic: the round-2 two-kernel form
-        if (!no_fuse && H == W && (W == 16 || W == 8) && net[2].cout <= 48 &&
-            img_net_hx3_lds(W, f->chp, net[0].cin, net[0].kc) != 0) {
+        if (!no_fuse && H == W && (W == 16 || W == 8) && img_net_hx3_lds(W, f->chp, net[0].cin, net[0].kc, net[2].cout) != 0) {
           NetLaunch q{};
           q.pre_in = cur; q.pre_in_img = img; q.pre_wp = reinterpret_cast<const unsigned*>(blob + net[0].x_off);
           q.pre_bias = blob + net[0].b_off; q.pre_kc = net[0].kc; q.pre_cin = net[0].cin;

@@ -301,16 +301,22 @@ __global__ void __launch_bounds__(512) img_net_hx3_kernel(const NetLaunch p) {
       half(c, std::integral_constant<int, NH1>{}, std::integral_constant<int, NPH>{}, ah, am);
     };
     {
-      u32x4 ah[2][2], am[2][2];
+      // A fragments two chunks ahead (a chunk of an 8-wide map is 24 MFMAs: shorter than an L2 round trip under load)
+      u32x4 ah[3][2], am[3][2];
       load_a(0, ah[0], am[0]);
+      load_a(1, ah[1], am[1]);
       int c = 0;
-      for (; c + 2 <= KC; c += 2) {
-        load_a(c + 1, ah[1], am[1]);
+#pragma unroll 1
+      for (; c + 3 <= KC; c += 3) {
+        load_a(c + 2, ah[2], am[2]);
         chunk(c, ah[0], am[0]);
-        load_a(c + 2, ah[0], am[0]);
+        load_a(c + 3, ah[0], am[0]);
         chunk(c + 1, ah[1], am[1]);
+        load_a(c + 4, ah[1], am[1]);
+        chunk(c + 2, ah[2], am[2]);
       }
       if (c < KC) chunk(c, ah[0], am[0]);
+      if (c + 1 < KC) chunk(c + 1, ah[1], am[1]);
     }
 #pragma unroll
     for (int q = 0; q < 2; ++q) img_drain(acc[q]);
@@ -346,6 +352,7 @@ __global__ void __launch_bounds__(512) img_net_hx3_kernel(const NetLaunch p) {
 
   // ---- phase 4: last 3x3 hidden -> shift / scale, contraction (tap, chunk) dealt to the waves
   float z2v[OT3][4];        // the state values this lane's epilogue updates (pixel tile = wave)
+  float b3v[OT3][4];        // ... and the last 3x3's biases of its rows
   {
     const float* stq = p.st + (int64_t)n * p.st_img;
     const int lin = 16 * (wave < NPO ? wave : 0) + i, row = r0 + lin / W, pc = lin % W;
@@ -358,6 +365,7 @@ __global__ void __launch_bounds__(512) img_net_hx3_kernel(const NetLaunch p) {
         const int ch = EPI == EPI_COUPLE_ADD ? co : (co >> 1);          // affine: rows (2 j, 2 j + 1) = (shift, raw scale) of channel j
         const bool use = EPI == EPI_COUPLE_ADD ? co < p.cout : ((r & 1) == 0 && co + 1 < p.cout);
         z2v[o][r] = use ? stq[(int64_t)ch * H * W + pix] : 0.0f;
+        b3v[o][r] = p.bias3[co < p.cout ? co : 0];
       }
   }
   constexpr int MAXO = OT3;                                 // output tiles of the last 3x3 (template: no branches around its MFMAs)
@@ -426,29 +434,28 @@ __global__ void __launch_bounds__(512) img_net_hx3_kernel(const NetLaunch p) {
     };
     using H0 = std::integral_constant<int, 0>;
     using H1 = std::integral_constant<int, 1>;
-    u32x4 a0h[MAXO], a0m[MAXO], a1h[MAXO], a1m[MAXO];
+    // A fragments two iterations ahead (an iteration is 24 OT3 MFMAs), B operands half an iteration ahead
+    u32x4 a0h[MAXO], a0m[MAXO], a1h[MAXO], a1m[MAXO], a2h[MAXO], a2m[MAXO];
     u32x4 b0h[HP], b0m[HP], b1h[HP], b1m[HP];
     int t = wave;
     load_a(t, a0h, a0m);
+    load_a(t + WV, a1h, a1m);
     load_b(t, 0, b0h, b0m);
+    auto step = [&](int tt, const u32x4 (&ah)[MAXO], const u32x4 (&am)[MAXO], u32x4 (&nh)[MAXO], u32x4 (&nm)[MAXO]) {
+      load_a(tt + 2 * WV, nh, nm);
+      load_b(tt, 1, b1h, b1m);
+      mac_half(H0{}, b0h, b0m, ah, am);
+      load_b(tt + WV, 0, b0h, b0m);
+      mac_half(H1{}, b1h, b1m, ah, am);
+    };
 #pragma unroll 1
-    for (; t + WV < T_all; t += 2 * WV) {
-      load_a(t + WV, a1h, a1m);
-      load_b(t, 1, b1h, b1m);
-      mac_half(H0{}, b0h, b0m, a0h, a0m);
-      load_b(t + WV, 0, b0h, b0m);
-      mac_half(H1{}, b1h, b1m, a0h, a0m);
-      load_a(t + 2 * WV, a0h, a0m);
-      load_b(t + WV, 1, b1h, b1m);
-      mac_half(H0{}, b0h, b0m, a1h, a1m);
-      load_b(t + 2 * WV, 0, b0h, b0m);
-      mac_half(H1{}, b1h, b1m, a1h, a1m);
+    for (; t + 2 * WV < T_all; t += 3 * WV) {
+      step(t, a0h, a0m, a2h, a2m);
+      step(t + WV, a1h, a1m, a0h, a0m);
+      step(t + 2 * WV, a2h, a2m, a1h, a1m);
     }
-    if (t < T_all) {
-      load_b(t, 1, b1h, b1m);
-      mac_half(H0{}, b0h, b0m, a0h, a0m);
-      mac_half(H1{}, b1h, b1m, a0h, a0m);
-    }
+    if (t < T_all) step(t, a0h, a0m, a2h, a2m);
+    if (t + WV < T_all) step(t + WV, a1h, a1m, a0h, a0m);
   }
 #pragma unroll
   for (int o = 0; o < MAXO; ++o) img_drain(part[o]);
@@ -458,7 +465,6 @@ __global__ void __launch_bounds__(512) img_net_hx3_kernel(const NetLaunch p) {
   //      (its z2 values were requested in front of the last 3x3: a global round trip less at the tail of the workgroup)
   float ld = 0.0f;
   f32x4* red = reinterpret_cast<f32x4*>(lds_raw);          // [wave][pt][64]
-  gptr bias3 = (gptr)p.bias3;
   float* st = p.st + (int64_t)n * p.st_img;
 #pragma unroll
   for (int o = 0; o < MAXO; ++o) {
@@ -478,19 +484,19 @@ __global__ void __launch_bounds__(512) img_net_hx3_kernel(const NetLaunch p) {
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
             const int co = 16 * o + 4 * g + r;
-            if (co < p.cout) st[(int64_t)co * H * W + pix] = z2v[o][r] + (acc[r] + bias3[co]);        // models/glow.py:328-329
+            if (co < p.cout) st[(int64_t)co * H * W + pix] = z2v[o][r] + (acc[r] + b3v[o][r]);        // models/glow.py:328-329
           }
         } else {
 #pragma unroll
           for (int qq = 0; qq < 2; ++qq) {
             const int co = 16 * o + 4 * g + 2 * qq, j = co >> 1;
             if (co + 1 < p.cout) {
-              const float h0 = acc[2 * qq] + bias3[co], h1 = acc[2 * qq + 1] + bias3[co + 1];
+              const float h0 = acc[2 * qq] + b3v[o][2 * qq], h1 = acc[2 * qq + 1] + b3v[o][2 * qq + 1];
               float* zp = st + (int64_t)j * H * W + pix;
               const float e = __expf(-(h1 + 2.0f));                     // scale = sigmoid(raw + 2), models/glow.py:333
               const float sc = 1.0f / (1.0f + e);
               *zp = (z2v[o][2 * qq] + h0) * sc;                         // models/glow.py:334-335
-              ld += -log1pf(e);                                         // log(scale), models/glow.py:338
+              ld += -0.69314718055994531f * __builtin_amdgcn_logf(1.0f + e);      // log(scale) = -log(1 + e), models/glow.py:338 (v_log_f32: 1 ulp)
             }
           }
         }
@@ -535,7 +541,10 @@ static size_t img_net_hx3_layout(int W, int chp, int cin, int pre_kc, size_t* bf
   const size_t red = (size_t)8 * NPO * 64 * 16;
   return total == 0 ? 0 : (total > red ? total : red);
 }
-size_t img_net_hx3_lds(int W, int chp, int cin, int pre_kc) { return img_net_hx3_layout(W, chp, cin, pre_kc, nullptr); }
+size_t img_net_hx3_lds(int W, int chp, int cin, int pre_kc, int cout) {
+  if (cout > 48 || (W == 16 && cout > 32)) return 0;
+  return img_net_hx3_layout(W, chp, cin, pre_kc, nullptr);
+}
 
 template <int W, int EPI, int OT3>
 static hipError_t img_net_hx3_launch3(const NetLaunch& q0, int64_t n, hipStream_t s) {
@@ -566,7 +575,10 @@ static hipError_t img_net_hx3_launch2(const NetLaunch& q, int64_t n, hipStream_t
   const int ot3 = (q.cout + 15) >> 4;
   if (ot3 == 1) return img_net_hx3_launch3<W, EPI, 1>(q, n, s);
   if (ot3 == 2) return img_net_hx3_launch3<W, EPI, 2>(q, n, s);
-  return img_net_hx3_launch3<W, EPI, 3>(q, n, s);
+  // (three output tiles on 16-wide maps -- 33..48 coupling outputs, i.e. >= 32 channels at the first level -- would spill:
+  //  img_net_hx3_lds answers 0 for them and gbnf_image.hip keeps the two-kernel form)
+  if constexpr (W == 8) return img_net_hx3_launch3<W, EPI, 3>(q, n, s);
+  return hipErrorInvalidValue;
 }
 hipError_t img_net_hx3_launch(const NetLaunch& q, int W, bool additive, int64_t n, hipStream_t s) {
   if (W == 16) return additive ? img_net_hx3_launch2<16, EPI_COUPLE_ADD>(q, n, s) : img_net_hx3_launch2<16, EPI_COUPLE_AFFINE>(q, n, s);

@@ -1,5 +1,5 @@
 #!/bin/bash
-D=gpurun_out/r4k; mkdir -p $D
+D=gpurun_out/r4l; mkdir -p $D
 ( timeout 900 python -m pytest tests/test_hip_image.py tests/test_hip_baseline_configs.py -q -m gpu -x ) > $D/pytest.txt 2>&1
 echo "pytest rc $?"; tail -4 $D/pytest.txt
 for b in 256 64; do
@@ -10,7 +10,7 @@ import json
 for b in (256, 64):
     for k in ("fused",):
         try:
-            d = json.loads([l for l in open(f"gpurun_out/r4k/img_{k}_{b}.json") if l.startswith("{")][-1])
+            d = json.loads([l for l in open(f"gpurun_out/r4l/img_{k}_{b}.json") if l.startswith("{")][-1])
             print(k, b, round(d["value"]), "img/s  stream", round(d.get("stream_launches_value") or 0), "err", d.get("max_rel_err_vs_cpu"), "gpu_ms", round(d["roofline"]["gpu_ms_per_step"], 3))
         except Exception as e:
             print(k, b, "failed", e)
