@@ -65,6 +65,7 @@ struct ConvLaunch {
   const float* pre_wp;    // packed 3x3 weights [cin/16 tiles][9][pre_kc][64][4]
   const float* pre_bias;
   int pre_cin;
+  const unsigned* gate;   // repair launches: *gate == 0 (no image was marked) -> the whole launch returns at once; null = always run
 };
 
 __device__ __forceinline__ f32x4 img_mfma(float a, float b, f32x4 c) {
@@ -82,6 +83,7 @@ __device__ __forceinline__ void img_drain(f32x4 (&c)[N]) {
 template <int EPI, int PT, int KS>
 __global__ void __launch_bounds__(64 * IMG_WAVES) img_conv_kernel(const ConvLaunch p) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
+  if (p.gate != nullptr && *p.gate == 0u) return;
   typedef const float __attribute__((address_space(1)))* gptr;
   const int lane = threadIdx.x & 63, i = lane & 15, g = lane >> 4;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -350,7 +352,9 @@ __global__ void __launch_bounds__(64 * IMG_WAVES) img_conv_kernel(const ConvLaun
 // ---- dequantise + logit + first squeeze (models/glow.py:125-179; utils/utilities.py:107-119) -------------------
 // x (n, C, H, W) in [0,1] (+ uniform noise or null) -> squeezed logits (n, 4C, H/2, W/2); ldj[n] = its log-det.
 __global__ void __launch_bounds__(256) img_pre_kernel(const float* __restrict__ x, const float* __restrict__ noise, float* __restrict__ out,
-                                                      float* __restrict__ ldj, int C, int H, int W, float bounds, float ld_const) {
+                                                      float* __restrict__ ldj, int C, int H, int W, float bounds, float ld_const,
+                                                      const unsigned* gate) {
+  if (gate != nullptr && *gate == 0u) return;
   const int n = blockIdx.x, chw = C * H * W;
   const float* xi = x + (int64_t)n * chw;
   float* oi = out + (int64_t)n * chw;
@@ -378,8 +382,9 @@ __global__ void __launch_bounds__(256) img_pre_kernel(const float* __restrict__ 
 }
 
 // squeeze2d of the first `C` channels of (n, Cin_total, H, W) -> (n, 4C, H/2, W/2)
-__global__ void __launch_bounds__(256) img_squeeze_kernel(const float* __restrict__ in, int64_t in_img, float* __restrict__ out, int C, int H,
+__global__ void __launch_bounds__(256) img_squeeze_kernel(const unsigned* gate, const float* __restrict__ in, int64_t in_img, float* __restrict__ out, int C, int H,
                                                           int W) {
+  if (gate != nullptr && *gate == 0u) return;
   const int n = blockIdx.x, chw = C * H * W;
   const float* xi = in + (int64_t)n * in_img;
   float* oi = out + (int64_t)n * chw;
@@ -426,7 +431,8 @@ __global__ void __launch_bounds__(256) img_post_kernel(const float* __restrict__
 // Conv2dZeros(0) = bias * exp(3 logs), models/glow.py:62-84); optional copies of z / mean / log-var.
 __global__ void __launch_bounds__(256) img_final_kernel(const float* __restrict__ z, int64_t z_img, const float* __restrict__ prior /* [2C] */,
                                                         const float* __restrict__ ldj, float* __restrict__ ll, float* __restrict__ z_out,
-                                                        int C, int HW) {
+                                                        int C, int HW, const unsigned* gate) {
+  if (gate != nullptr && *gate == 0u) return;
   const int n = blockIdx.x;
   const float* zi = z + (int64_t)n * z_img;
   float acc = 0.0f;
@@ -446,6 +452,75 @@ __global__ void __launch_bounds__(256) img_final_kernel(const float* __restrict_
   if (threadIdx.x == 0 && ll) ll[n] = red[0] + ldj[n];
 }
 
+
+
+// ---- numerics protocol of the split-f16 coupling nets --------------------------------------------
+// A fused coupling-net workgroup that meets an operand beyond the fp16 range raises mark[image].  Behind the f16x3 pass:
+//   img_compact_kernel   the marked images' indices, in order, into list[0 .. count)
+//   img_gather_kernel    x / noise of list[0 .. min(count, R)) into a staging batch (the unused rows repeat image 0)
+//   the exact-f32 forward of that staging batch (the same launch sequence, R images: tiny grids)
+//   img_scatter_kernel   z / ldj / ll of the repaired images back; images marked beyond the R-th get NaN (never a silently
+//                        wrong value) and are counted in seen[1]
+constexpr int IMG_REPAIR_MAX = 8;     // images re-evaluated per call
+
+__global__ void __launch_bounds__(256) img_compact_kernel(const unsigned* __restrict__ mark, int n, unsigned* __restrict__ list /* [R] */,
+                                                          unsigned* __restrict__ count, unsigned* seen_host) {
+  __shared__ unsigned cnt;
+  if (threadIdx.x == 0) cnt = 0;
+  __syncthreads();
+  // in order: one wave scans (n is a batch size: a few thousand at most)
+  if (threadIdx.x < 64) {
+    unsigned base = 0;
+    for (int b0 = 0; b0 < n; b0 += 64) {
+      const int k = b0 + (int)threadIdx.x;
+      const bool m = k < n && mark[k] != 0u;
+      const unsigned long long bal = __ballot(m);
+      const unsigned before = __popcll(bal & ((1ull << threadIdx.x) - 1ull));
+      if (m && base + before < (unsigned)IMG_REPAIR_MAX) list[base + before] = (unsigned)k;
+      base += __popcll(bal);
+    }
+    if (threadIdx.x == 0) {
+      *count = base;
+      if (base != 0u && seen_host != nullptr) {
+        atomicAdd_system(seen_host, 1u);
+        if (base > (unsigned)IMG_REPAIR_MAX) atomicAdd_system(seen_host + 1, base - IMG_REPAIR_MAX);
+      }
+    }
+  }
+}
+
+__global__ void __launch_bounds__(256) img_gather_kernel(const float* __restrict__ x, const float* __restrict__ noise, int64_t chw,
+                                                         const unsigned* __restrict__ list, const unsigned* __restrict__ count,
+                                                         float* __restrict__ xs, float* __restrict__ ns) {
+  const int b = blockIdx.x;
+  const unsigned c = *count;
+  if (c == 0u) return;
+  const int64_t src = (unsigned)b < c ? (int64_t)list[b] : 0;
+  for (int64_t e = threadIdx.x; e < chw; e += 256) {
+    xs[b * chw + e] = x[src * chw + e];
+    ns[b * chw + e] = noise ? noise[src * chw + e] : 0.0f;
+  }
+}
+
+// grid = n images: an image in list[0 .. min(count, R)) takes the staging batch's results, one marked beyond that NaN
+__global__ void __launch_bounds__(256) img_scatter_kernel(const unsigned* __restrict__ mark, const unsigned* __restrict__ list,
+                                                          const unsigned* __restrict__ count, int repaired, int64_t zsz, const float* __restrict__ zr,
+                                                          const float* __restrict__ ldjr, const float* __restrict__ llr, float* __restrict__ z,
+                                                          float* __restrict__ ldj, float* __restrict__ ll) {
+  const int n = blockIdx.x;
+  if (mark[n] == 0u) return;
+  const unsigned c = !repaired ? 0u : (*count < (unsigned)IMG_REPAIR_MAX ? *count : (unsigned)IMG_REPAIR_MAX);
+  int slot = -1;
+  for (unsigned b = 0; b < c; ++b)
+    if (list[b] == (unsigned)n) slot = (int)b;
+  const float nanv = __builtin_nanf("");
+  if (z)
+    for (int64_t e = threadIdx.x; e < zsz; e += 256) z[n * zsz + e] = slot >= 0 ? zr[slot * zsz + e] : nanv;
+  if (threadIdx.x == 0) {
+    if (ldj) ldj[n] = slot >= 0 ? ldjr[slot] : nanv;
+    if (ll) ll[n] = slot >= 0 ? llr[slot] : nanv;
+  }
+}
 
 }  // namespace gbnf
 
@@ -482,6 +557,10 @@ struct gbnf_image_flow {
   double macs = 0;                           // multiply-adds per image
   int math_mode = 0;                         // GBNF_MATH_F32 or GBNF_MATH_F16X3 (the coupling nets' two wide convolutions)
   int chp = 0;                               // hidden width padded to 32 (split-f16 activation layout)
+  // numerics protocol of the split-f16 coupling nets (round 4)
+  float probe_rel_err = 0.0f;                // create-time probe: largest relative difference of ll, f16x3 vs exact f32, on 4 images
+  bool probed = false;
+  unsigned* seen_host = nullptr;             // pinned, device-visible: [0] launches that marked an image, [1] images left unrepaired
 };
 
 namespace {
@@ -698,6 +777,53 @@ extern "C" {
 void gbnf_debug_set_image_stamp_buffer(unsigned long long* p) { g_img_stamp_buf = p; }
 #endif
 
+static int64_t image_state_floats(const gbnf_image_flow* f, int64_t n);
+static int image_forward_impl(const gbnf_image_flow* f, const float* x, const float* noise, int64_t n, float* z, float* ldj, float* ll,
+                              float* workspace, hipStream_t s, bool force_f32, unsigned* mark, const unsigned* gate = nullptr);
+
+static int image_probe(gbnf_image_flow* f) {
+  constexpr int PN = 4;
+  const int64_t chw = (int64_t)f->C * f->H * f->W;
+  std::vector<float> host((size_t)2 * PN * chw);
+  uint64_t st = 0x9E3779B97F4A7C15ull;
+  for (float& v : host) {                      // splitmix64 -> [0, 1): pixels and dequantisation noise
+    st += 0x9E3779B97F4A7C15ull;
+    uint64_t zz = st;
+    zz = (zz ^ (zz >> 30)) * 0xBF58476D1CE4E5B9ull;
+    zz = (zz ^ (zz >> 27)) * 0x94D049BB133111EBull;
+    zz ^= zz >> 31;
+    v = (float)((double)(zz >> 11) / 9007199254740992.0);
+  }
+  float* dev = nullptr;
+  const int64_t wsf = image_state_floats(f, PN);
+  const size_t total = (size_t)(2 * PN * chw + 4 * PN + wsf) * 4;
+  if (hipMalloc((void**)&dev, total) != hipSuccess) return fail(GBNF_ERR_HIP, "gbnf_image_flow_create: probe allocation failed");
+  float* x = dev; float* noise = dev + PN * chw; float* ldj = noise + PN * chw; float* lla = ldj + PN; float* ldjb = lla + PN;
+  float* llb = ldjb + PN; float* ws = llb + PN;
+  int rc = GBNF_OK;
+  hipError_t e = hipMemcpy(dev, host.data(), host.size() * 4, hipMemcpyHostToDevice);
+  if (e == hipSuccess) {
+    rc = image_forward_impl(f, x, noise, PN, nullptr, ldj, lla, ws, nullptr, false, nullptr);
+    if (!rc) rc = image_forward_impl(f, x, noise, PN, nullptr, ldjb, llb, ws, nullptr, true, nullptr);
+    float a[PN], b[PN];
+    if (!rc) e = hipMemcpy(a, lla, sizeof(a), hipMemcpyDeviceToHost);
+    if (!rc && e == hipSuccess) e = hipMemcpy(b, llb, sizeof(b), hipMemcpyDeviceToHost);
+    if (!rc && e == hipSuccess) {
+      float worst = 0.0f;
+      for (int k = 0; k < PN; ++k) {
+        const float err = std::fabs(a[k] - b[k]) / std::fmax(std::fabs(b[k]), 1.0f);
+        worst = (err == err) ? std::fmax(worst, err) : INFINITY;
+      }
+      f->probe_rel_err = worst;
+      f->probed = true;
+      if (!(worst <= 2.5e-6f)) f->math_mode = GBNF_MATH_F32;
+    }
+  }
+  (void)hipFree(dev);
+  if (e != hipSuccess) return fail(GBNF_ERR_HIP, "gbnf_image_flow_create: probe failed: %s", hipGetErrorString(e));
+  return rc;
+}
+
 int gbnf_image_flow_create(const gbnf_image_flow_desc* d, gbnf_image_flow** out) {
   if (!out) return fail(GBNF_ERR_INVALID, "gbnf_image_flow_create: out is null");
   *out = nullptr;
@@ -848,8 +974,15 @@ int gbnf_image_flow_create(const gbnf_image_flow_desc* d, gbnf_image_flow** out)
       for (int k = 0; k < 10 && e == hipSuccess; ++k)
         e = hipFuncSetAttribute(fns[k], hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     }
+    if (e == hipSuccess && f->math_mode == GBNF_MATH_F16X3) {
+      e = hipHostMalloc((void**)&f->seen_host, 2 * sizeof(unsigned), hipHostMallocMapped);
+      if (e == hipSuccess) f->seen_host[0] = f->seen_host[1] = 0u;
+    }
     if (e != hipSuccess) rc = fail(GBNF_ERR_HIP, "gbnf_image_flow_create: %s", hipGetErrorString(e));
   }
+  // ---- create-time probe (as the tabular DEFAULT mode, gbnf_api.hip): 4 synthetic images through the split-f16 coupling nets
+  //      and through the exact-f32 kernels; a handle whose log-likelihoods disagree beyond 2.5e-6 runs on exact f32 from now on
+  if (rc == GBNF_OK && f->math_mode == GBNF_MATH_F16X3 && !getenv("GBNF_IMAGE_NO_PROBE")) rc = image_probe(f);
   if (rc != GBNF_OK) {
     gbnf_image_flow_destroy(f);
     return rc;
@@ -861,6 +994,7 @@ int gbnf_image_flow_create(const gbnf_image_flow_desc* d, gbnf_image_flow** out)
 int gbnf_image_flow_destroy(gbnf_image_flow* f) {
   if (!f) return GBNF_OK;
   if (f->blob_dev) (void)hipFree(f->blob_dev);
+  if (f->seen_host) (void)hipHostFree(f->seen_host);
   delete f;
   return GBNF_OK;
 }
@@ -881,34 +1015,38 @@ int gbnf_image_flow_prior(const gbnf_image_flow* f, float* host) {
   return GBNF_OK;
 }
 
-int gbnf_image_flow_workspace_bytes(const gbnf_image_flow* f, int64_t n, int64_t* bytes) {
-  if (!f || !bytes || n < 0) return fail(GBNF_ERR_INVALID, "gbnf_image_flow_workspace_bytes: bad argument");
+// floats of the state / hidden buffers of a batch of n images
+static int64_t image_state_floats(const gbnf_image_flow* f, int64_t n) {
   const int64_t chw = (int64_t)f->C * f->H * f->W;
   const int64_t hid = (int64_t)f->chp * (f->H / 2) * (f->W / 2);
-  *bytes = (2 * chw + 2 * hid) * n * 4 + 256;
+  return (2 * chw + 2 * hid) * n + 64;
+}
+
+int gbnf_image_flow_workspace_bytes(const gbnf_image_flow* f, int64_t n, int64_t* bytes) {
+  if (!f || !bytes || n < 0) return fail(GBNF_ERR_INVALID, "gbnf_image_flow_workspace_bytes: bad argument");
+  const int64_t chw = (int64_t)f->C * f->H * f->W, zsz = (int64_t)f->zC * f->zH * f->zW;
+  // main batch | marks | list + count | staging x, noise, z, ldj / ll of the repair batch | its state buffers
+  const int64_t floats = image_state_floats(f, n) + (n + 63) / 64 * 64 + 64 + IMG_REPAIR_MAX * (2 * chw + zsz) + 64 +
+                         image_state_floats(f, IMG_REPAIR_MAX);
+  *bytes = floats * 4 + 256;
   return GBNF_OK;
 }
 
-int gbnf_image_flow_forward(const gbnf_image_flow* f, const float* x, const float* noise, int64_t n, float* z, float* ldj,
-                            float* ll, void* workspace, int64_t workspace_bytes, void* stream) {
-  if (!f) return fail(GBNF_ERR_INVALID, "gbnf_image_flow_forward: flow is null");
-  if (n < 0) return fail(GBNF_ERR_INVALID, "gbnf_image_flow_forward: n < 0");
-  if (n == 0) return GBNF_OK;
-  if (!x || !ldj || !workspace) return fail(GBNF_ERR_INVALID, "gbnf_image_flow_forward: x / ldj / workspace is null");
-  int64_t need = 0;
-  gbnf_image_flow_workspace_bytes(f, n, &need);
-  if (workspace_bytes < need) return fail(GBNF_ERR_INVALID, "gbnf_image_flow_forward: workspace of %lld bytes < %lld", (long long)workspace_bytes, (long long)need);
-  hipStream_t s = (hipStream_t)stream;
+// One pass of the launch sequence over n images.  force_f32: every convolution on the exact-f32 kernels (the repair pass and
+// handles whose probe failed); mark: (n,) per-image range marks raised by the split-f16 coupling nets, or null; gate (exact-f32
+// passes only): device word, 0 = every launch of the pass returns at once.
+static int image_forward_impl(const gbnf_image_flow* f, const float* x, const float* noise, int64_t n, float* z, float* ldj, float* ll,
+                              float* workspace, hipStream_t s, bool force_f32, unsigned* mark, const unsigned* gate) {
   const int64_t chw = (int64_t)f->C * f->H * f->W;
   const int64_t hid = (int64_t)f->chp * (f->H / 2) * (f->W / 2);
-  float* SA = (float*)workspace;
+  float* SA = workspace;
   float* SB = SA + chw * n;
   float* H1 = SB + chw * n;
   float* H2 = H1 + hid * n;
   const float* blob = f->blob_dev;
 
   int C = f->C * 4, H = f->H / 2, W = f->W / 2;
-  hipLaunchKernelGGL(img_pre_kernel, dim3((unsigned)n), dim3(256), 0, s, x, noise, SA, ldj, f->C, f->H, f->W, f->bounds, (float)f->ld_const);
+  hipLaunchKernelGGL(img_pre_kernel, dim3((unsigned)n), dim3(256), 0, s, x, noise, SA, ldj, f->C, f->H, f->W, f->bounds, (float)f->ld_const, gate);
   float* cur = SA;      // current state (n, C, H, W), image stride = C*H*W
   float* oth = SB;
   size_t step = 0;
@@ -919,6 +1057,7 @@ int gbnf_image_flow_forward(const gbnf_image_flow* f, const float* x, const floa
     const int K = f->level_steps[l];
     for (int k = 0; k < K; ++k, ++step) {
       ConvLaunch p{};
+      p.gate = gate;
       p.H = H; p.W = W; p.n_strips = n_strips; p.ldj = ldj;
       // ActNorm2d + permutation: cur -> oth
       const PackedConv& m = f->mix[step];
@@ -928,7 +1067,7 @@ int gbnf_image_flow_forward(const gbnf_image_flow* f, const float* x, const floa
       std::swap(cur, oth);
       // coupling net on the first half
       const std::vector<PackedConv>& net = f->net[step];
-      if (net.size() == 3 && net[1].x_off != 0) {
+      if (!force_f32 && net.size() == 3 && net[1].x_off != 0) {
         // split-f16 path.  Round 4: the whole coupling net in ONE kernel where a workgroup can hold the hidden activation of its
         // rows (+ halo) in LDS: the 16 x 16 and 8 x 8 maps of a 32 x 32 input (img_net_hx3_kernel, gbnf_image_hx3.hip.h)
         static const bool no_fuse = getenv("GBNF_IMG_NO_FUSE") != nullptr;        // diagnostic: the round-2 two-kernel form
@@ -942,7 +1081,7 @@ int gbnf_image_flow_forward(const gbnf_image_flow* f, const float* x, const floa
           q.st = cur + (int64_t)c1 * H * W; q.st_img = img; q.ldj = ldj;
           q.hid = net[1].cout; q.chp = f->chp; q.cout = net[2].cout; q.H = H;
           q.sat = reinterpret_cast<unsigned long long*>(gbnf::saturation_counter());
-          q.mark = nullptr; q.only = nullptr;
+          q.mark = mark; q.only = nullptr;
 #ifdef GBNF_IMG_STAMPS
           q.dbg = (W == GBNF_IMG_STAMPS) ? g_img_stamp_buf : nullptr;      // -DGBNF_IMG_STAMPS=16 | 8: which level is stamped
 #endif
@@ -1015,20 +1154,86 @@ int gbnf_image_flow_forward(const gbnf_image_flow* f, const float* x, const floa
     }
     if (l < f->L - 1) {
       ConvLaunch p{};
+      p.gate = gate;
       const PackedConv& c = f->split[l];
       p.H = H; p.W = W; p.n_strips = n_strips; p.ldj = ldj;
       p.in = cur; p.in_img = img; p.wp = blob + c.w_off; p.bias = blob + c.b_off;
       p.st = cur + (int64_t)c1 * H * W; p.st_img = img; p.cin = c.cin; p.cout = c.cout; p.ks = c.ks;
       launch_conv<EPI_SPLIT>(p, (int)n, s);
-      hipLaunchKernelGGL(img_squeeze_kernel, dim3((unsigned)n), dim3(256), 0, s, (const float*)cur, img, oth, c1, H, W);
+      hipLaunchKernelGGL(img_squeeze_kernel, dim3((unsigned)n), dim3(256), 0, s, gate, (const float*)cur, img, oth, c1, H, W);
       std::swap(cur, oth);
       C = c1 * 4; H /= 2; W /= 2;
     }
   }
   hipLaunchKernelGGL(img_final_kernel, dim3((unsigned)n), dim3(256), 0, s, (const float*)cur, (int64_t)C * H * W,
-                     blob + f->prior_off, (const float*)ldj, ll, z, C, H * W);
+                     blob + f->prior_off, (const float*)ldj, ll, z, C, H * W, gate);
   const hipError_t e = hipGetLastError();
   if (e != hipSuccess) return fail(GBNF_ERR_HIP, "gbnf_image_flow_forward: %s", hipGetErrorString(e));
+  return GBNF_OK;
+}
+
+// GBNF_IMAGE_REPAIR: what follows the split-f16 pass (never a silently wrong value in any mode but 0):
+//   1 (default)  marked images get NaN outputs and raise the handle's pinned `seen` word; from the first call that has SEEN a
+//                mark on (host-side read, no synchronisation) every call carries the gated exact-f32 pass: ~52 launches that
+//                return at once unless an image of THIS call is marked (+3 % at batch 256, +8 % at 64 under graph replay; an
+//                ungated pass over 8 staging images costs 1.1 ms per call: it was measured, 103k -> 70k images/s at batch 256)
+//   2            the gated pass from the first call on: same-call repair even for the first out-of-range image of a handle
+//   0            no exact-f32 pass: out-of-range images are counted (gbnf_saturation_count) but keep clamped values (kernel timing)
+static int image_repair_mode() {
+  static const int mode = [] { const char* e = getenv("GBNF_IMAGE_REPAIR"); return e ? atoi(e) : 1; }();
+  return mode;
+}
+
+int gbnf_image_flow_forward(const gbnf_image_flow* f, const float* x, const float* noise, int64_t n, float* z, float* ldj,
+                            float* ll, void* workspace, int64_t workspace_bytes, void* stream) {
+  if (!f) return fail(GBNF_ERR_INVALID, "gbnf_image_flow_forward: flow is null");
+  if (n < 0) return fail(GBNF_ERR_INVALID, "gbnf_image_flow_forward: n < 0");
+  if (n == 0) return GBNF_OK;
+  if (!x || !ldj || !workspace) return fail(GBNF_ERR_INVALID, "gbnf_image_flow_forward: x / ldj / workspace is null");
+  int64_t need = 0;
+  gbnf_image_flow_workspace_bytes(f, n, &need);
+  if (workspace_bytes < need) return fail(GBNF_ERR_INVALID, "gbnf_image_flow_forward: workspace of %lld bytes < %lld", (long long)workspace_bytes, (long long)need);
+  hipStream_t s = (hipStream_t)stream;
+  float* ws = (float*)workspace;
+  if (f->math_mode != GBNF_MATH_F16X3) return image_forward_impl(f, x, noise, n, z, ldj, ll, ws, s, true, nullptr);
+  const int mode = image_repair_mode();
+  if (mode == 0) return image_forward_impl(f, x, noise, n, z, ldj, ll, ws, s, false, nullptr);
+  // ---- split-f16 pass with range marks; then the marked images: NaN, or the exact-f32 pass over (up to IMG_REPAIR_MAX of) them
+  constexpr int R = IMG_REPAIR_MAX;
+  const int64_t chw = (int64_t)f->C * f->H * f->W, zsz = (int64_t)f->zC * f->zH * f->zW;
+  float* q = ws + image_state_floats(f, n);
+  unsigned* mark = reinterpret_cast<unsigned*>(q); q += (n + 63) / 64 * 64;
+  unsigned* list = reinterpret_cast<unsigned*>(q); unsigned* count = list + R; q += 64;
+  float* xs = q; q += R * chw;
+  float* ns = q; q += R * chw;
+  float* zr = q; q += R * zsz;
+  float* ldjr = q; float* llr = q + R; q += 64;
+  float* wsr = q;
+  if (hipMemsetAsync(mark, 0, (size_t)n * 4, s) != hipSuccess) return fail(GBNF_ERR_HIP, "gbnf_image_flow_forward: memset failed");
+  int rc = image_forward_impl(f, x, noise, n, z, ldj, ll, ws, s, false, mark);
+  if (rc) return rc;
+  hipLaunchKernelGGL(img_compact_kernel, dim3(1), dim3(256), 0, s, (const unsigned*)mark, (int)n, list, count, f->seen_host);
+  const bool repair = mode >= 2 || (f->seen_host != nullptr && ((volatile unsigned*)f->seen_host)[0] != 0u);
+  if (repair) {
+    hipLaunchKernelGGL(img_gather_kernel, dim3(R), dim3(256), 0, s, x, noise, chw, (const unsigned*)list, (const unsigned*)count, xs, ns);
+    rc = image_forward_impl(f, xs, ns, R, zr, ldjr, llr, wsr, s, true, nullptr, count);
+    if (rc) return rc;
+  }
+  // (without the pass: count is forced to "nothing repaired", every marked image gets NaN)
+  hipLaunchKernelGGL(img_scatter_kernel, dim3((unsigned)n), dim3(256), 0, s, (const unsigned*)mark, (const unsigned*)list,
+                     (const unsigned*)count, repair ? 1 : 0, zsz, (const float*)zr, (const float*)ldjr, (const float*)llr, z, ldj, ll);
+  const hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return fail(GBNF_ERR_HIP, "gbnf_image_flow_forward (repair): %s", hipGetErrorString(e));
+  return GBNF_OK;
+}
+
+int gbnf_image_flow_numerics(const gbnf_image_flow* f, gbnf_numerics_status* out) {
+  if (!f || !out) return fail(GBNF_ERR_INVALID, "gbnf_image_flow_numerics: null argument");
+  out->math_mode = f->math_mode;
+  out->demoted = (f->probed && f->math_mode != GBNF_MATH_F16X3) ? 1 : 0;       // the create-time probe sent the handle to exact f32
+  out->checks = f->seen_host ? (int64_t)((volatile unsigned*)f->seen_host)[0] : 0;     // launches that marked (and repaired) an image
+  out->worst_rel_err = f->probe_rel_err;
+  out->tolerance = 2.5e-6f;
   return GBNF_OK;
 }
 

@@ -36,6 +36,7 @@ ABI_SYMBOLS = (
     "gbnf_trainer_bind_batch_stats", "gbnf_trainer_set_batch_stats",
     "gbnf_image_flow_create", "gbnf_image_flow_destroy", "gbnf_image_flow_info", "gbnf_image_flow_workspace_bytes",
     "gbnf_image_flow_forward", "gbnf_image_flow_prior", "gbnf_image_flow_eps_floats", "gbnf_image_flow_inverse",
+    "gbnf_image_flow_numerics",
     "gbnf_flow_numerics", "gbnf_mixture_numerics", "gbnf_tuning_set", "gbnf_tuning_get",
 )
 
@@ -172,6 +173,7 @@ def lib():
     L.gbnf_image_flow_workspace_bytes.argtypes = [vp, i64, C.POINTER(i64)]
     L.gbnf_image_flow_forward.argtypes = [vp, vp, vp, i64, vp, vp, vp, vp, i64, vp]
     L.gbnf_image_flow_prior.argtypes = [vp, C.POINTER(C.c_float)]
+    L.gbnf_image_flow_numerics.argtypes = [vp, C.POINTER(NumericsStatus)]
     L.gbnf_image_flow_eps_floats.argtypes = [vp, C.POINTER(i64)]
     L.gbnf_image_flow_inverse.argtypes = [vp, vp, vp, C.c_float, i64, vp, vp, i64, vp]
     for name in ABI_SYMBOLS:
@@ -394,6 +396,13 @@ class NativeImageFlow:
         self.z_shape = (zc.value, zh.value, zw.value)
         self.macs_per_image = macs.value
         self._ws = None
+
+    def numerics(self):
+        """gbnf_image_flow_numerics: math mode the handle runs in, the create-time probe's verdict (worst_rel_err, demoted),
+        calls that repaired an out-of-range image so far (checks); no synchronisation."""
+        st = NumericsStatus()
+        _check(lib().gbnf_image_flow_numerics(self.handle, C.byref(st)))
+        return st
 
     def prior(self):
         """(mean (Cz,), log-variance (Cz,)) of the top prior, numpy."""

@@ -161,7 +161,7 @@ def synth_batch(N, d, seed=0, scale=1.0, dist="normal", clip=None):
 
 
 # ------------------------------------------------------------------ image Glow (multi-scale, conv coupling nets)
-def _conv(rng, out_ch, in_ch, k, std, bias=False, actnorm=False, zeros_logs=False):
+def _conv(rng, out_ch, in_ch, k, std, bias=False, actnorm=False, zeros_logs=False, logs_spread=None, an_spread=None):
     """One Conv2d / Conv2dZeros of models/layers.py:577-630 as plain data:
     w (out,in,k,k); b (out,) | None; an_bias/an_logs (out,) | None (the ActNorm2d behind a Conv2d);
     logs (out,) | None (Conv2dZeros' output scale exp(3*logs))."""
@@ -172,25 +172,38 @@ def _conv(rng, out_ch, in_ch, k, std, bias=False, actnorm=False, zeros_logs=Fals
     if actnorm:
         c["an_bias"] = (0.1 * rng.standard_normal(out_ch)).astype(np.float32)
         c["an_logs"] = (0.1 * rng.standard_normal(out_ch)).astype(np.float32)
+        if an_spread is not None:      # trained-like: per-channel scales over orders of magnitude
+            c["an_logs"] = rng.uniform(-an_spread, an_spread, out_ch).astype(np.float32)
     if zeros_logs:
         c["logs"] = (0.05 * rng.standard_normal(out_ch)).astype(np.float32)
+        if logs_spread is not None:    # Conv2dZeros: output scale exp(3 logs), models/layers.py:608-630
+            c["logs"] = rng.uniform(-logs_spread, logs_spread, out_ch).astype(np.float32)
     return c
 
 
 def synth_image_glow_spec(input_size=(3, 32, 32), h=32, K=2, L=2, depth=1, coupling="affine", permutation="invconv",
-                          learn_top=True, seed=0, gain=1.0):
+                          learn_top=True, seed=0, gain=1.0, trained_like=False):
     """One image Glow component (models/glow.py:192-233 FlowNet image branch: L x [squeeze, K FlowSteps, Split2d])
     with synthetic parameters.  ``permutation``: "invconv" (a random well-conditioned C x C matrix: what
     InvertibleConv1x1.get_weight returns for either parameterisation), "shuffle" or "reverse"."""
     rng = np.random.RandomState(seed)
     C, H, W = input_size
     levels = []
+    # trained_like (fixture g18): magnitudes a trained model shows -- the coupling nets' ActNorm2d logs over +-3 (per-channel
+    # scales 0.05 .. 20 on the hidden activations: what the fp16 range of the split kernels has to carry), the steps' ActNorm2d
+    # logs over +-1 (+-3 there compounds over the steps to |z| ~ 1e3 and log-likelihoods of -1e9 .. -1e11: no model trains to
+    # that), Conv2dZeros logs over +-0.5 (output gains exp(3 logs) up to e^1.5) with small weights
+    an_step = 1.0 if trained_like else None
+    an_net = 3.0 if trained_like else None
+    zl = 0.5 if trained_like else None
     for lvl in range(L):
         C, H, W = C * 4, H // 2, W // 2
         steps = []
         for _ in range(K):
             st = {"an_bias": (0.1 * rng.standard_normal(C)).astype(np.float32),
                   "an_logs": (0.1 * rng.standard_normal(C)).astype(np.float32), "perm_w": None, "perm": None}
+            if trained_like:
+                st["an_logs"] = rng.uniform(-an_step, an_step, C).astype(np.float32)
             if permutation == "invconv":
                 q, _ = np.linalg.qr(rng.standard_normal((C, C)))
                 st["perm_w"] = (q * np.exp(0.1 * rng.standard_normal(C))[None, :]).astype(np.float32)
@@ -199,10 +212,11 @@ def synth_image_glow_spec(input_size=(3, 32, 32), h=32, K=2, L=2, depth=1, coupl
                 st["perm"] = perm[rng.permutation(C)] if permutation == "shuffle" else perm
             cin, cout = C // 2, C - C // 2
             out_ch = 2 * cout if coupling == "affine" else cout
-            convs = [_conv(rng, h, cin, 3, gain * 0.6 / np.sqrt(9 * cin), actnorm=True)]
+            convs = [_conv(rng, h, cin, 3, gain * 0.6 / np.sqrt(9 * cin), actnorm=True, an_spread=an_net)]
             for _ in range(depth):
-                convs.append(_conv(rng, h, h, 1, gain * 1.0 / np.sqrt(h), actnorm=True))
-            convs.append(_conv(rng, out_ch, h, 3, gain * 0.5 / np.sqrt(9 * h), bias=True, zeros_logs=True))
+                convs.append(_conv(rng, h, h, 1, gain * 1.0 / np.sqrt(h), actnorm=True, an_spread=an_net))
+            convs.append(_conv(rng, out_ch, h, 3, gain * (0.05 if trained_like else 0.5) / np.sqrt(9 * h), bias=True, zeros_logs=True,
+                               logs_spread=zl))
             st["convs"] = convs
             steps.append(st)
         split = None

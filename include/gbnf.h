@@ -388,6 +388,16 @@ int gbnf_image_flow_forward(const gbnf_image_flow* flow, const float* x, const f
                             float* ldj, float* ll, void* workspace, int64_t workspace_bytes, void* stream);
 /* The top prior per channel: mean (Cz,) then log-variance (Cz,) into a HOST buffer of 2 Cz floats. */
 int gbnf_image_flow_prior(const gbnf_image_flow* flow, float* mean_logvar_host);
+/* State of the image path's numerics protocol (round 4; the tabular one: gbnf_flow_numerics).  The coupling nets run on
+ * split-f16 MFMA (GBNF_MATH_F16X3) when the create-time probe -- 4 synthetic images through both arithmetic paths --
+ * agrees with the exact-f32 kernels to `tolerance` (worst_rel_err = what it measured), else the handle runs on exact f32
+ * (math_mode GBNF_MATH_F32, demoted = 1).  On split-f16 every operand is range-watched: an image that met a value beyond
+ * +-65504 is counted (gbnf_saturation_count) and never returned with its clamped value: its z / ldj / ll are NaN, and from the
+ * first call on which the handle has SEEN such an image (pinned flag, no synchronisation) every call re-evaluates its marked
+ * images on the exact-f32 kernels behind the split-f16 pass (up to 8 per call; further ones stay NaN).  Environment
+ * GBNF_IMAGE_REPAIR=2: the re-evaluation pass from the very first call on (same-call repair, ~3-8 % of a call when nothing is
+ * marked); =0: none (timing only).  `checks` = calls that marked an image so far. */
+int gbnf_image_flow_numerics(const gbnf_image_flow* flow, gbnf_numerics_status* out);
 /* The z -> x direction.  Replaces: x = self.flows[c].decode(z, None, temperature) for image input (models/glow.py:112-123):
  * FlowNet.decode (models/glow.py:254-260) = per level, last first: Split2d reverse (models/layers.py:695-699: the dropped
  * half is re-drawn as Normal(mean, exp(log-var) * temperature) with (mean, log-var) = conv(z1)), the FlowSteps backwards

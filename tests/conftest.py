@@ -21,10 +21,11 @@ def golden_names():
     """Forward/mixture fixtures (g1..g6).  g7 (ActNorm data-dependent init), g8 (boosting weights) and g9 (decode)
     have their own tests."""
     names = sorted(os.path.splitext(os.path.basename(p))[0] for p in glob.glob(os.path.join(GOLDEN_DIR, "*.npz")))
-    return [n for n in names if not n.startswith(("g7_", "g8_", "g9_", "g10_", "g11_", "g12_", "g16_"))]
+    return [n for n in names if not n.startswith(("g7_", "g8_", "g9_", "g10_", "g11_", "g12_", "g16_", "g18_"))]
 
 
-IMAGE_CASES = ("g12_image_glow_invconv_affine", "g12_image_glow_shuffle_additive", "g12_image_glow_lu")
+IMAGE_CASES = ("g12_image_glow_invconv_affine", "g12_image_glow_shuffle_additive", "g12_image_glow_lu",
+               "g18_image_glow_trained_like_h256")
 
 
 def load_image_case(name):
@@ -33,7 +34,8 @@ def load_image_case(name):
     data = dict(np.load(os.path.join(GOLDEN_DIR, name + ".npz")))
     cfg = json.loads(bytes(data["config"]).decode())
     specs = [synth.synth_image_glow_spec((3, 32, 32), cfg["h"], cfg["K"], cfg["L"], depth=cfg["depth"], coupling=cfg["coupling"],
-                                         permutation=cfg["permutation"], learn_top=cfg["learn_top"], seed=cfg["w_seed"] + c)
+                                         permutation=cfg["permutation"], learn_top=cfg["learn_top"], seed=cfg["w_seed"] + c,
+                                         trained_like=cfg.get("trained_like", False))
              for c in range(cfg["C"])]
     if cfg["LU"]:
         for c, sp in enumerate(specs):

@@ -540,7 +540,7 @@ def install_image_spec(ref_glow, spec, keep_invconv=False):
 
 
 def image_case(name, h=32, K=2, L=2, C=2, N=4, depth=1, coupling="affine", permutation="invconv", learn_top=True,
-               LU=False):
+               LU=False, trained_like=False):
     """G12: the image path (BASELINE.json configs[3] at toy size) by the reference itself:
     BoostedFlow with input_size (3,32,32) -> Glow.encode (dequantise with the fixture's noise injected through
     Tensor.uniform_, to_logits, squeeze / FlowStep / Split2d levels, learned top prior), then
@@ -552,7 +552,7 @@ def image_case(name, h=32, K=2, L=2, C=2, N=4, depth=1, coupling="affine", permu
     torch.manual_seed(7)
     model = RefBoostedFlow(a).eval()
     specs = [synth.synth_image_glow_spec(input_size, h, K, L, depth=depth, coupling=coupling, permutation=permutation,
-                                         learn_top=learn_top, seed=61 + c) for c in range(C)]
+                                         learn_top=learn_top, seed=61 + c, trained_like=trained_like) for c in range(C)]
     for c in range(C):
         install_image_spec(model.flows[c], specs[c], keep_invconv=LU)
     x, noise = synth.synth_image_batch(N, input_size, seed=31)
@@ -580,7 +580,7 @@ def image_case(name, h=32, K=2, L=2, C=2, N=4, depth=1, coupling="affine", permu
         torch.Tensor.uniform_ = orig
     out = dict(config=np.frombuffer(json.dumps(dict(case="image", h=h, K=K, L=L, C=C, N=N, depth=depth, coupling=coupling,
                                                     permutation=permutation, learn_top=learn_top, LU=LU, w_seed=61,
-                                                    x_seed=31)).encode(), dtype=np.uint8),
+                                                    x_seed=31, trained_like=trained_like)).encode(), dtype=np.uint8),
                rho=model.rho.numpy().copy(), z=np.stack(zs), ldj=np.stack(ldjs), ll=np.stack(lls), G=G.numpy().copy())
     if LU:   # the composed invconv matrices of the reference's own LU factors (not reproducible from the generator)
         for c in range(C):
@@ -678,6 +678,11 @@ def main():
         return
     if "--stress-only" in sys.argv:
         stress_cases()
+        return
+    if "--image-trained-only" in sys.argv:
+        # g18 (round 4): trained-like magnitudes on the image path -- ActNorm2d logs +-3, coupling-net ActNorm2d logs +-1.5,
+        # Conv2dZeros logs +-0.5 (gains exp(3 logs) up to e^1.5) -- at the full hidden width of BASELINE.json configs[3]
+        image_case("g18_image_glow_trained_like_h256", h=256, K=2, L=2, C=2, N=4, trained_like=True)
         return
     if "--image-only" in sys.argv:
         image_case("g12_image_glow_invconv_affine")

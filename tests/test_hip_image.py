@@ -204,3 +204,85 @@ def test_image_module_decode_and_sampling():
         assert np.abs(x.cpu().numpy() - x_ref).max() <= X_ATOL
         xs = m(z=None, temperature=0.7, components=1, reverse=True)
         assert xs.shape == (5, 3, 32, 32) and torch.isfinite(xs).all()
+
+
+def _blow_up_hidden(sp, step=0, gain_logs=12.0):
+    """Make the coupling net of one FlowStep leave the fp16 range: its first convolution's ActNorm2d scales every hidden
+    channel by e^gain_logs (hidden activations of 1e5 .. 1e7 instead of O(1)); the last convolution's weights shrink by the
+    same factor so that shift / scale -- and the exact result -- stay ordinary."""
+    import copy
+    sp = copy.deepcopy(sp)
+    net = sp["levels"][0]["steps"][step]["convs"]
+    net[0]["an_logs"] = net[0]["an_logs"] + np.float32(gain_logs)
+    net[-1]["w"] = (net[-1]["w"] * np.float32(np.exp(-gain_logs))).astype(np.float32)
+    return sp
+
+
+def test_image_out_of_range_model_is_caught_by_the_probe():
+    """a model whose hidden activations leave +-65504 must not reach the caller with clamped (wrong) values.
+    When the MODEL is the cause the create-time probe meets it on its own images and the handle runs on the exact-f32 kernels."""
+    import torch
+    from gbnf_amd import native, synth
+    from oracle import gbnf_oracle as oracle
+    dev = torch.device("cuda:0")
+    sp = _blow_up_hidden(synth.synth_image_glow_spec((3, 32, 32), h=64, K=2, L=2, seed=11))
+    x, noise = synth.synth_image_batch(6, seed=3)
+    _, _, _, ld32, ll32 = oracle.image_component_forward(sp, x, noise)           # the reference's arithmetic: torch-CPU float32
+    assert np.isfinite(ll32).all()
+    flow = native.NativeImageFlow(sp)
+    st = flow.numerics()
+    assert native.MATH_NAME[int(st.math_mode)] == "f32" and bool(st.demoted) and not (st.worst_rel_err <= st.tolerance)
+    z, ldj, ll = flow.forward(torch.from_numpy(x).to(dev), torch.from_numpy(noise).to(dev))
+    assert rel_err(ll.cpu().numpy(), ll32) < LL_RTOL
+    assert rel_err(ldj.cpu().numpy(), ld32) < LL_RTOL
+
+
+def test_image_range_marks_and_repair_without_the_probe(monkeypatch):
+    """The same model with the probe switched off (GBNF_IMAGE_NO_PROBE: the handle stays on split f16, as for a model that only
+    the caller's DATA drives out of range).  Every image is out of range.  First call: every image comes back NaN -- never a
+    clamped value -- and is counted.  From the second call on the handle has seen a mark: the first 8 marked images of a call are
+    re-evaluated on the exact-f32 kernels behind the split-f16 pass, images beyond that capacity stay NaN."""
+    import torch
+    from gbnf_amd import native, synth
+    from oracle import gbnf_oracle as oracle
+    monkeypatch.setenv("GBNF_IMAGE_NO_PROBE", "1")
+    dev = torch.device("cuda:0")
+    sp = _blow_up_hidden(synth.synth_image_glow_spec((3, 32, 32), h=64, K=2, L=2, seed=11))
+    flow = native.NativeImageFlow(sp)
+    assert native.MATH_NAME[int(flow.numerics().math_mode)] == "f16x3"
+    x, noise = synth.synth_image_batch(11, seed=3)
+    _, _, _, ld32, ll32 = oracle.image_component_forward(sp, x, noise)
+    native.saturation_count(reset=True)
+    xd, nd = torch.from_numpy(x).to(dev), torch.from_numpy(noise).to(dev)
+    z, ldj, ll = flow.forward(xd, nd)
+    assert torch.isnan(ll).all() and torch.isnan(ldj).all() and torch.isnan(z).all()       # loud, not wrong
+    assert native.saturation_count(reset=True) > 0
+    assert int(flow.numerics().checks) == 1
+    z, ldj, ll = flow.forward(xd, nd)                                  # the handle has seen a mark: gated exact-f32 pass
+    llh = ll.cpu().numpy()
+    assert rel_err(llh[:8], ll32[:8]) < LL_RTOL and rel_err(ldj.cpu().numpy()[:8], ld32[:8]) < LL_RTOL
+    assert np.isnan(llh[8:]).all() and torch.isnan(z[8:]).all()        # beyond the repair capacity
+    # a batch within the capacity is repaired completely: what the exact-f32 handle gives (log-det sums are atomic: not bit for bit)
+    z2, ldj2, ll2 = flow.forward(xd[:5], nd[:5])
+    monkeypatch.setenv("GBNF_MATH", "f32")
+    exact = native.NativeImageFlow(sp)
+    monkeypatch.delenv("GBNF_MATH")
+    z3, ldj3, ll3 = exact.forward(xd[:5], nd[:5])
+    assert rel_err(ll2.cpu().numpy(), ll3.cpu().numpy()) < 1e-6 and torch.equal(z2, z3)
+    # ... and a well-scaled batch through the same handle is untouched by the (gated) pass
+    assert int(flow.numerics().checks) == 3
+
+
+def test_image_well_scaled_model_stays_on_split_f16_and_unmarked():
+    import torch
+    from gbnf_amd import native, synth
+    dev = torch.device("cuda:0")
+    sp = synth.synth_image_glow_spec((3, 32, 32), h=256, K=2, L=2, seed=5, trained_like=True)
+    flow = native.NativeImageFlow(sp)
+    st = flow.numerics()
+    assert native.MATH_NAME[int(st.math_mode)] == "f16x3" and st.worst_rel_err <= st.tolerance
+    native.saturation_count(reset=True)
+    x, noise = synth.synth_image_batch(16, seed=9)
+    flow.forward(torch.from_numpy(x).to(dev), torch.from_numpy(noise).to(dev))
+    torch.cuda.synchronize()
+    assert native.saturation_count(reset=True) == 0 and int(flow.numerics().checks) == 0
