@@ -71,6 +71,13 @@ struct Guard {
   GuardStatus* status_dev = nullptr;     // the device's address of the same memory
   int n_comp = 0;
   std::atomic<long long> launches{0};
+  // the check rows of a launch live in scratch_dev until guard_compare_kernel has read them: a check on ANOTHER stream while one
+  // is still in flight would race on them -- such a check is skipped (the next launch checks instead)
+  hipEvent_t check_done = nullptr;       // recorded behind the last check's compare launch
+  hipStream_t check_stream = nullptr;
+  bool check_pending = false;
+  std::mutex check_mutex;
+  int device = 0;
 };
 
 }  // namespace gbnf
@@ -170,16 +177,48 @@ static std::atomic<int>* tuning_slot(const char* key) {
   return nullptr;
 }
 
-static void free_guard(Guard* g) {
+// Guards are POOLED per (device, component count): BoostedFlow re-packs a component after every optimiser step, and a new guard
+// per re-pack meant two hipMalloc, a mapped hipHostMalloc and later their frees -- device-wide synchronisations.
+static std::mutex g_guard_pool_mutex;
+static std::vector<Guard*> g_guard_pool;
+
+static void destroy_guard(Guard* g) {
   if (!g) return;
   if (g->flag_dev) (void)hipFree(g->flag_dev);
   if (g->scratch_dev) (void)hipFree(g->scratch_dev);
   if (g->status_host) (void)hipHostFree(g->status_host);
+  if (g->check_done) (void)hipEventDestroy(g->check_done);
   delete g;
 }
+static void free_guard(Guard* g) {
+  if (!g) return;
+  // the flag is cleared HERE, on the null stream (by contract nothing of the dying handle is in flight): a later create takes the
+  // guard from the pool behind its own synchronous parameter upload, which is ordered after this
+  const bool ok = hipMemsetAsync(g->flag_dev, 0, 16, nullptr) == hipSuccess;
+  std::lock_guard<std::mutex> lk(g_guard_pool_mutex);
+  if (ok && g_guard_pool.size() < 64) g_guard_pool.push_back(g);
+  else destroy_guard(g);
+}
 static hipError_t make_guard(int n_comp, Guard** out) {
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  {
+    std::lock_guard<std::mutex> lk(g_guard_pool_mutex);
+    for (size_t k = 0; k < g_guard_pool.size(); ++k) {
+      Guard* g = g_guard_pool[k];
+      if (g->n_comp == n_comp && g->device == dev) {
+        g_guard_pool.erase(g_guard_pool.begin() + (long)k);
+        g->status_host->checks = 0; g->status_host->worst_rel_err = 0.0f; g->status_host->demoted = 0;
+        g->launches.store(0);
+        g->check_pending = false;
+        *out = g;
+        return hipSuccess;
+      }
+    }
+  }
   Guard* g = new Guard();
   g->n_comp = n_comp;
+  g->device = dev;
   hipError_t e = hipMalloc((void**)&g->flag_dev, 16);
   if (e == hipSuccess) e = hipMemset(g->flag_dev, 0, 16);
   if (e == hipSuccess) e = hipMalloc((void**)&g->scratch_dev, sizeof(float) * 2 * n_comp * GUARD_ROWS);
@@ -188,7 +227,8 @@ static hipError_t make_guard(int n_comp, Guard** out) {
     g->status_host->checks = 0; g->status_host->worst_rel_err = 0.0f; g->status_host->demoted = 0;
     e = hipHostGetDevicePointer((void**)&g->status_dev, g->status_host, 0);
   }
-  if (e != hipSuccess) { free_guard(g); return e; }
+  if (e == hipSuccess) e = hipEventCreateWithFlags(&g->check_done, hipEventDisableTiming);
+  if (e != hipSuccess) { destroy_guard(g); return e; }
   *out = g;
   return hipSuccess;
 }
@@ -1076,7 +1116,19 @@ static int launch_flow(const gbnf_flow* f, const uint32_t* const* table, const u
     if (stream != nullptr && hipStreamIsCapturing(stream, &cap) != hipSuccess) cap = hipStreamCaptureStatusNone;
     const long long k = cap == hipStreamCaptureStatusNone ? guard->launches.fetch_add(1, std::memory_order_relaxed) : -1;
     const int every = tuning().check_every.load(std::memory_order_relaxed);
-    if (k >= 0 && every >= 0 && (k == 0 || (every > 0 && k % every == 0))) {
+    bool check_now = k >= 0 && every >= 0 && (k == 0 || (every > 0 && k % every == 0));
+    if (check_now) {
+      // one check in flight per guard: its rows sit in scratch_dev until the compare launch has read them
+      std::lock_guard<std::mutex> lk(guard->check_mutex);
+      if (guard->check_pending && guard->check_stream != stream && hipEventQuery(guard->check_done) == hipErrorNotReady) {
+        check_now = false;
+        guard->launches.store(0, std::memory_order_relaxed);      // (the next launch takes the check)
+      } else {
+        guard->check_pending = true;
+        guard->check_stream = stream;
+      }
+    }
+    if (check_now) {
       const int rows = (int)(n < GUARD_ROWS ? n : GUARD_ROWS);
       FlowLaunch q = p;
       q.n = rows; q.n_batches = 1; q.out_stride = GUARD_ROWS; q.n_tiles = (rows + 15) / 16;
@@ -1099,6 +1151,7 @@ static int launch_flow(const gbnf_flow* f, const uint32_t* const* table, const u
                          guard->status_dev);
       e = hipGetLastError();
       if (e != hipSuccess) return fail(GBNF_ERR_HIP, "numerics-guard compare launch failed: %s", hipGetErrorString(e));
+      (void)hipEventRecord(guard->check_done, stream);
       // the launch that was just checked: re-evaluated in full on bf16x6 if (and only if) the check failed
       FlowLaunch r = p;
       r.blobs = table2;

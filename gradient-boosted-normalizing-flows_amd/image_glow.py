@@ -454,13 +454,15 @@ class BoostedImageFlow(nn.Module):
         chain of ~50 short launches, so an evaluation call is host-bound as plain stream launches: the replay is 12 % faster at
         batch 256 (tools/bench_image.py, 62 -> 69.5 k images/s).  The graph holds the packed handles of the parameters it was
         captured with: ``f`` re-captures by itself when a parameter, permutation or ActNorm flag has changed since.  The
-        returned tensor is the graph's output buffer -- overwritten by the next call of ``f``."""
+        returned tensor is the graph's output buffer -- overwritten by the next call of ``f``.  (Numerics protocol, include/gbnf.h
+        gbnf_image_flow_numerics: whether the gated exact-f32 pass follows the split-f16 one is decided when the graph is captured;
+        an out-of-range image always comes back as NaN or repaired, never with clamped values.)"""
         n_used = self.num_components if n_used is None else int(n_used)
         dev = self.rho.device
         state = {}
 
-        def key():
-            return tuple(id(self.native_flow(c)) for c in range(n_used))
+        def handles():
+            return [self.native_flow(c) for c in range(n_used)]
 
         def capture():
             c_, h_, w_ = self.flows[0].input_size
@@ -474,10 +476,17 @@ class BoostedImageFlow(nn.Module):
             g = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g), torch.no_grad():
                 out = self.log_prob(xs, n_used, ns)
-            state.update(key=key(), graph=g, x=xs, noise=ns, out=out)
+            # the handles the graph's kernels read are HELD here: a re-pack cannot free them (and hand their address, hence their
+            # id(), to a later handle) while this graph may still be replayed
+            state.update(handles=handles(), graph=g, x=xs, noise=ns, out=out)
 
         def f(x, noise):
-            if state.get("key") != key():
+            if tuple(x.shape) != (batch,) + tuple(self.flows[0].input_size) or tuple(noise.shape) != tuple(x.shape):
+                raise native.GbnfError(f"graphed_log_prob was captured for batches of shape {(batch,) + tuple(self.flows[0].input_size)}: "
+                                       f"got x {tuple(x.shape)}, noise {tuple(noise.shape)}")
+            held = state.get("handles")
+            now = handles()
+            if held is None or len(held) != len(now) or any(a is not b for a, b in zip(held, now)):
                 capture()
             state["x"].copy_(x)
             state["noise"].copy_(noise)
