@@ -304,6 +304,10 @@ def main():
     ap.add_argument("--group", type=int, default=GROUP, help=f"batches per launch / all-gather (default {GROUP}, max 32)")
     ap.add_argument("--no-extra-legs", action="store_true", help="skip the f32-exact and group-1 legs of the N=1 line")
     ap.add_argument("--no-config-legs", action="store_true", help="skip legs.configs (the other BASELINE configurations, run as child processes)")
+    ap.add_argument("--graph-exchange", action="store_true", help="sharded runs over real ranks: capture the group (RCCL all-gather included) into a HIP graph")
+    ap.add_argument("--pipeline", default="library", choices=["library", "torch"],
+                    help="sharded runs: 'library' = RCCL called from libgbnf_hip.so, one HIP graph per group (default); 'torch' = the "
+                         "round-1..3 pipeline (torch.distributed all-gather on a second stream)")
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -388,6 +392,7 @@ def main():
         torch.cuda.synchronize()
 
     extra_streams = []               # the pipelines' exchange streams (registered by timed_run)
+    pipeline_used = {}               # which group pipeline the main run used (reported in the line)
 
     def barrier():
         device_idle()
@@ -405,9 +410,27 @@ def main():
         info = flows[0].info()
         # one group in the whole run: nothing to overlap the exchange with, so it stays on the kernel's stream (a cross-stream
         # event hand-over costs ~20 us of latency on this stack)
-        pipe = sharded.GroupPipeline(mix, C, c0, c1, rho, B, group, gather, overlap=steps > group)
-        if pipe.post is not pipe.main and pipe.post not in extra_streams:
-            extra_streams.append(pipe.post)
+        pipe = None
+        if gather and args.pipeline == "library":
+            # round 4: the exchange inside the library -- per group ONE hipGraphLaunch of {flow, repair, ncclAllGather, recursion}
+            # (sharded.LibraryGroupPipeline); a refused communicator / capture falls back to the torch.distributed pipeline
+            try:
+                # the group as ONE HIP graph where that is proven on this stack: the single-rank emulation (captured and replayed in
+                # the GPU tests).  Across real ranks the library issues the same launches and ncclAllGather directly, one call per
+                # group (a multi-rank RCCL capture has never run on hardware available to this build: --graph-exchange opts in)
+                use_graph = world == 1 or args.graph_exchange
+                pipe = sharded.LibraryGroupPipeline(mix, C, c0, c1, rho, B, group, gather, graph=use_graph, overlap=steps > group)
+                pipeline_used["kind"] = "library"
+                pipeline_used["group_graph"] = bool(use_graph)
+            except (native.GbnfError, RuntimeError, OSError) as e:
+                pipeline_used["fallback_reason"] = f"{type(e).__name__}: {e}"
+                pipe = None
+        if pipe is None:
+            pipe = sharded.GroupPipeline(mix, C, c0, c1, rho, B, group, gather, overlap=steps > group)
+            pipeline_used["kind"] = "torch.distributed" if gather else "single rank"
+        for st_ in getattr(pipe, "streams", [pipe.post]):
+            if st_ is not pipe.main and st_ not in extra_streams:
+                extra_streams.append(st_)
 
         bound = {}                       # group size -> launches bound to the resident batches (host work outside the timed region)
         event_pool = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(MAX_TIMED_LAUNCHES)]
@@ -538,7 +561,11 @@ def main():
         }
         if gather:
             out["rccl"] = {"ranks_seen": ranks_seen, "allgather_us": main_run["gather_us"],
-                           "allgather_bytes_per_rank": 4 * (c1 - c0) * S * B}
+                           "allgather_bytes_per_rank": 4 * (c1 - c0) * S * B, "pipeline": dict(pipeline_used),
+                           "graph_errors": list(getattr(main_run["keep"][2], "graph_errors", []))[:2],
+                           "note": ("library pipeline: ncclAllGather is issued by libgbnf_hip.so inside the group's HIP graph; "
+                                    "roofline.launch_ms brackets the whole group (flow launch, exchange, recursion)")
+                                   if pipeline_used.get("kind") == "library" else None}
         if world == 1 and not args.no_extra_legs:
             legs = {}
             n_leg = max(2 * S, min(args.steps, 320))

@@ -176,6 +176,10 @@ def main(argv=None):
     objs.append(net_o)
     if args.force or not newer(net_o, [net_src, os.path.join(HERE, "gbnf_image_net.h")]):
         jobs.append([HIPCC] + FLAGS + VGPR_FORM + ["-c", net_src, "-o", net_o])
+    comm_o, comm_src = os.path.join(OBJ, "gbnf_comm.o"), os.path.join(HERE, "gbnf_comm.hip")
+    objs.append(comm_o)
+    if args.force or not newer(comm_o, [comm_src, hdr[2], hdr[3]]):
+        jobs.append([HIPCC] + FLAGS + ["-c", comm_src, "-o", comm_o])
     keep = set(objs)
     for fn in os.listdir(OBJ):      # drop objects of variants that left the list
         p = os.path.join(OBJ, fn)
@@ -187,7 +191,7 @@ def main(argv=None):
             for _ in ex.map(lambda c: compile_hx3(c) if ("variant_hx3" in " ".join(c) or "variant_bwd" in " ".join(c)) else compile_and_lint(c), jobs):
                 pass
     if jobs or not os.path.exists(LIB):
-        run([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs)
+        run([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs + ["-ldl"])
         print(f"[gbnf build] linked {LIB}", flush=True)
     else:
         print("[gbnf build] up to date", flush=True)

@@ -37,6 +37,8 @@ ABI_SYMBOLS = (
     "gbnf_image_flow_create", "gbnf_image_flow_destroy", "gbnf_image_flow_info", "gbnf_image_flow_workspace_bytes",
     "gbnf_image_flow_forward", "gbnf_image_flow_prior", "gbnf_image_flow_eps_floats", "gbnf_image_flow_inverse",
     "gbnf_image_flow_numerics",
+    "gbnf_comm_unique_id", "gbnf_comm_create", "gbnf_comm_destroy", "gbnf_comm_info", "gbnf_mixture_group_log_prob",
+    "gbnf_group_graph_create", "gbnf_group_graph_launch", "gbnf_group_graph_destroy",
     "gbnf_flow_numerics", "gbnf_mixture_numerics", "gbnf_tuning_set", "gbnf_tuning_get",
 )
 
@@ -174,6 +176,14 @@ def lib():
     L.gbnf_image_flow_forward.argtypes = [vp, vp, vp, i64, vp, vp, vp, vp, i64, vp]
     L.gbnf_image_flow_prior.argtypes = [vp, C.POINTER(C.c_float)]
     L.gbnf_image_flow_numerics.argtypes = [vp, C.POINTER(NumericsStatus)]
+    L.gbnf_comm_unique_id.argtypes = [C.POINTER(C.c_uint8)]
+    L.gbnf_comm_create.argtypes = [C.POINTER(C.c_uint8), i32, i32, C.POINTER(vp)]
+    L.gbnf_comm_destroy.argtypes = [vp]
+    L.gbnf_comm_info.argtypes = [vp, C.POINTER(i32), C.POINTER(i32)]
+    L.gbnf_mixture_group_log_prob.argtypes = [vp, vp, C.POINTER(vp), i32, i64, i32, vp, vp, vp, vp, vp]
+    L.gbnf_group_graph_create.argtypes = [vp, vp, C.POINTER(vp), i32, i64, i32, vp, vp, vp, vp, C.POINTER(vp)]
+    L.gbnf_group_graph_launch.argtypes = [vp, vp]
+    L.gbnf_group_graph_destroy.argtypes = [vp]
     L.gbnf_image_flow_eps_floats.argtypes = [vp, C.POINTER(i64)]
     L.gbnf_image_flow_inverse.argtypes = [vp, vp, vp, C.c_float, i64, vp, vp, i64, vp]
     for name in ABI_SYMBOLS:
@@ -835,6 +845,99 @@ class NativeMixture:
         if getattr(self, "handle", None):
             lib().gbnf_mixture_destroy(self.handle)
             self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class Comm:
+    """An RCCL communicator owned by the library (gbnf_comm): the exchange of the component-sharded group without
+    torch.distributed on the data path.  ``Comm.from_torch_distributed()`` builds one for the ranks of an initialised process
+    group (the 128-byte id travels through a broadcast of that group -- set-up only); ``Comm(0, 1, Comm.unique_id())`` is a
+    one-rank communicator."""
+
+    def __init__(self, rank, world, unique_id):
+        if len(unique_id) != 128:
+            raise GbnfError("an RCCL unique id has 128 bytes")
+        buf = (C.c_uint8 * 128)(*unique_id)
+        h = C.c_void_p()
+        _check(lib().gbnf_comm_create(buf, int(rank), int(world), C.byref(h)))
+        self.handle, self.rank, self.world = h, int(rank), int(world)
+
+    @staticmethod
+    def unique_id():
+        buf = (C.c_uint8 * 128)()
+        _check(lib().gbnf_comm_unique_id(buf))
+        return bytes(buf)
+
+    @classmethod
+    def from_torch_distributed(cls, group=None):
+        import torch.distributed as dist
+        if not dist.is_initialized():
+            return cls(0, 1, cls.unique_id())
+        rank, world = dist.get_rank(group), dist.get_world_size(group)
+        box = [cls.unique_id() if rank == 0 else None]
+        if world > 1:
+            dist.broadcast_object_list(box, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
+        return cls(rank, world, box[0])
+
+    def close(self):
+        if getattr(self, "handle", None) is not None and _lib is not None:
+            _lib.gbnf_comm_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class GroupLaunch:
+    """One group of the component-sharded mixture bound to its buffers (gbnf_mixture_group_log_prob): ``mix`` = this rank's
+    components, ``comm`` = a ``Comm`` or None (one rank, no exchange), ``xs`` = the group's resident (n, d) batches,
+    ``ll_local`` (C/W, S n), ``ll_full`` (C, S n), ``G`` (S n).  ``launch(stream_ptr)`` enqueues flow launch -> all-gather ->
+    recursion on that stream with ONE library call; with ``graph=True`` the sequence is captured once into a HIP graph and
+    ``launch`` is a hipGraphLaunch (falls back to the plain call, with ``self.graph_error`` set, when the capture is refused)."""
+
+    def __init__(self, mix, comm, xs, n_components, rho, ll_local, ll_full, G, graph=True):
+        n = xs[0].shape[0]
+        for t in list(xs) + [rho, ll_local, G] + ([ll_full] if ll_full is not None else []):
+            _require_device_f32(t, "tensor")
+        world = comm.world if comm is not None else 1
+        if n_components % world or tuple(ll_local.shape) != (n_components // world, len(xs) * n) or G.numel() != len(xs) * n:
+            raise GbnfError("GroupLaunch: buffer shapes do not match the group")
+        if comm is not None and (ll_full is None or tuple(ll_full.shape) != (n_components, len(xs) * n)):
+            raise GbnfError("GroupLaunch: ll_full must be (C, len(xs) * n)")
+        self._keep = (mix, comm, list(xs), rho, ll_local, ll_full, G)
+        self._arr = (C.c_void_p * len(xs))(*[t.data_ptr() for t in xs])
+        ptr = lambda t: C.c_void_p(t.data_ptr() if t is not None else 0)
+        self._args = (mix.handle, comm.handle if comm is not None else C.c_void_p(0), self._arr, len(xs), n, int(n_components),
+                      ptr(rho), ptr(ll_local), ptr(ll_full), ptr(G))
+        self.graph, self.graph_error = None, None
+        if graph:
+            h = C.c_void_p()
+            rc = lib().gbnf_group_graph_create(*self._args, C.byref(h))
+            if rc == 0:
+                self.graph = h
+            else:
+                self.graph_error = lib().gbnf_last_error().decode(errors="replace")
+
+    def launch(self, stream_ptr):
+        if self.graph is not None:
+            rc = lib().gbnf_group_graph_launch(self.graph, stream_ptr)
+        else:
+            rc = lib().gbnf_mixture_group_log_prob(*self._args, stream_ptr)
+        if rc:
+            _check(rc)
+
+    def close(self):
+        if getattr(self, "graph", None) is not None and _lib is not None:
+            _lib.gbnf_group_graph_destroy(self.graph)
+            self.graph = None
 
     def __del__(self):
         try:

@@ -295,3 +295,90 @@ class GroupPipeline:
             self.main.wait_event(self.post_done[q])
         n = self.rows
         outs.extend(G[b * n:(b + 1) * n].clone() for b in range(k))
+
+
+class LibraryGroupPipeline:
+    """The group pipeline with the exchange INSIDE the library (round 4; include/gbnf.h, gbnf_mixture_group_log_prob): per group
+    the host makes ONE call -- a hipGraphLaunch of {flow launch, repair launch, ncclAllGather, recursion launch} captured once
+    per bound group and buffer slot -- instead of two ctypes calls, a torch.distributed collective and the event hand-offs
+    between two streams (``GroupPipeline``: ~50 us of host time and ~45 us of hand-off latency per group, as long as the per-rank
+    kernel itself at the driver's 20-step invocation).  NBUF = 2 buffer slots, each with its OWN stream and its OWN RCCL
+    communicator: consecutive groups are independent, so group g + 1 (slot 1) runs beside group g (slot 0) with no event
+    between them, and a slot is re-used in its own stream's order.  ``gather`` False: one rank, no exchange.
+
+    Same surface as ``GroupPipeline``: ``bind(xs)`` -> token, ``submit(token | xs, kernel_events)`` -> (G tensor of the slot,
+    slot), ``drain()``.  ``graph=False`` keeps the plain library call per group (also the automatic fall-back when a capture is
+    refused: ``graph_errors`` lists why)."""
+
+    NBUF = 2
+
+    def __init__(self, mix, n_components, c_begin, c_end, rho, rows, group_size, gather, process_group=None, graph=True, overlap=True):
+        import torch
+        from . import native
+        self.torch, self.native = torch, native
+        self.mix, self.C, self.c0, self.c1 = mix, int(n_components), int(c_begin), int(c_end)
+        self.rho, self.rows, self.S = rho, int(rows), int(group_size)
+        self.gather, self.graph = bool(gather), bool(graph)
+        self.dev = rho.device
+        self.main = torch.cuda.current_stream(self.dev)
+        nslots = self.NBUF if overlap else 1
+        self.nslots = nslots
+        self.streams = [torch.cuda.Stream(self.dev) for _ in range(nslots)] if overlap else [self.main]
+        self.post = self.streams[0]            # (bench.py registers the extra stream(s) it has to wait for)
+        self.comms = [native.Comm.from_torch_distributed(process_group) for _ in range(nslots)] if self.gather else [None] * nslots
+        if self.gather and (self.c1 - self.c0) * self.comms[0].world != self.C:
+            raise ValueError("the component blocks must be equal and contiguous rank by rank (sharded.partition)")
+        self.done = [torch.cuda.Event() for _ in range(nslots)]
+        self.start = torch.cuda.Event()
+        self._bufs = {}
+        self.gi = 0
+        self.gather_events = None
+        self.graph_errors = []
+
+    def _buffers(self, size):
+        torch = self.torch
+        if size not in self._bufs:
+            n = size * self.rows
+            local = [torch.empty((self.c1 - self.c0, n), dtype=torch.float32, device=self.dev) for _ in range(self.nslots)]
+            full = ([torch.empty((self.C, n), dtype=torch.float32, device=self.dev) for _ in range(self.nslots)]
+                    if self.gather else [None] * self.nslots)
+            G = [torch.empty(n, dtype=torch.float32, device=self.dev) for _ in range(self.nslots)]
+            self._bufs[size] = (local, full, G)
+        return self._bufs[size]
+
+    def bind(self, xs):
+        if not 1 <= len(xs) <= self.S:
+            raise ValueError(f"a group holds 1..{self.S} batches")
+        xs = list(xs)
+        local, full, G = self._buffers(len(xs))
+        launches = []
+        for q in range(self.nslots):
+            with self.torch.cuda.device(self.dev):
+                gl = self.native.GroupLaunch(self.mix, self.comms[q], xs, self.C, self.rho, local[q], full[q], G[q], graph=self.graph)
+            if gl.graph_error:
+                self.graph_errors.append(gl.graph_error)
+            launches.append(gl)
+        return _BoundGroup(xs, launches)
+
+    def submit(self, xs, kernel_events=None):
+        import ctypes
+        q = self.gi % self.nslots
+        token = xs if isinstance(xs, _BoundGroup) else self.bind(xs)
+        _, _, G = self._buffers(len(token.xs))
+        st = self.streams[q]
+        if st is not self.main and self.gi < self.nslots:
+            self.start.record(self.main)            # the slot's stream starts behind whatever the caller enqueued before
+            st.wait_event(self.start)
+        if kernel_events is not None:
+            kernel_events[0].record(st)
+        token.launches[q].launch(ctypes.c_void_p(st.cuda_stream))
+        if kernel_events is not None:               # (library mode: the events bracket the WHOLE group, exchange and recursion included)
+            kernel_events[1].record(st)
+        self.done[q].record(st)
+        self.gi += 1
+        return G[q], q
+
+    def drain(self):
+        for q in range(min(self.gi, self.nslots)):
+            if self.streams[q] is not self.main:
+                self.main.wait_event(self.done[q])

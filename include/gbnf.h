@@ -256,6 +256,35 @@ int gbnf_mixture_lse(const float* ll, int64_t ll_row_stride, const float* rho_de
 int gbnf_mixture_log_prob(const gbnf_mixture* mix, const float* x, int64_t n, int32_t n_used,
                           const float* rho_dev, float* ll_workspace, float* out, void* stream);
 
+/* ---- the component-sharded group inside the library (multi-GPU, round 4) -------------------------------------------------
+ * Replaces: the serial component loop + recursion of density_experiment.py:561-573 when the C components are sharded over W
+ * GPUs (BASELINE.json north star: one component block per GPU, an RCCL all-gather of log p_c(x), then the mixture recursion).
+ * RCCL is bound directly (librccl.so is loaded at first use: no torch.distributed on the data path):
+ *   gbnf_comm_unique_id   rank 0 makes the 128-byte id (ncclGetUniqueId) and hands it to the other ranks through the caller's
+ *                         own rendezvous (the host mirror uses the torch.distributed store);
+ *   gbnf_comm_create      every rank of the group, collectively (ncclCommInitRank); world = 1 is allowed.
+ * gbnf_mixture_group_log_prob: ONE call = flow launch of this rank's components (the mixture holds exactly its block, in global
+ * component order rank by rank) over n_batches batches -> ncclAllGather of its (C/W, n_batches n) table into ll_full
+ * (C, n_batches n), component order -> recursion -> G (n_batches n), all on `stream`.  comm NULL: one rank, no exchange (ll_full
+ * unused).  All buffers are caller-owned device memory.
+ * gbnf_group_graph_*: the same sequence captured ONCE into a HIP graph (bound to these very buffers; an un-captured warm-up call
+ * runs first) and replayed with one hipGraphLaunch per group.  A capture that the runtime or RCCL refuses is reported as an
+ * error: the caller keeps gbnf_mixture_group_log_prob. */
+typedef struct gbnf_comm gbnf_comm;
+typedef struct gbnf_group_graph gbnf_group_graph;
+int gbnf_comm_unique_id(uint8_t* id128);
+int gbnf_comm_create(const uint8_t* id128, int32_t rank, int32_t world, gbnf_comm** out);
+int gbnf_comm_destroy(gbnf_comm* comm);
+int gbnf_comm_info(const gbnf_comm* comm, int32_t* rank, int32_t* world);
+int gbnf_mixture_group_log_prob(const gbnf_mixture* mix, gbnf_comm* comm, const float* const* xs, int32_t n_batches, int64_t n,
+                                int32_t n_components, const float* rho_dev, float* ll_local, float* ll_full, float* G,
+                                void* stream);
+int gbnf_group_graph_create(const gbnf_mixture* mix, gbnf_comm* comm, const float* const* xs, int32_t n_batches, int64_t n,
+                            int32_t n_components, const float* rho_dev, float* ll_local, float* ll_full, float* G,
+                            gbnf_group_graph** out);
+int gbnf_group_graph_launch(gbnf_group_graph* graph, void* stream);
+int gbnf_group_graph_destroy(gbnf_group_graph* graph);
+
 /* Replaces: _ActNorm.initialize_parameters (models/layers.py:473-486), the data-dependent initialisation the
  * reference runs on the first training batches (density_experiment.py:346-356):
  *   bias = -mean_0(z);  logs = log(scale / (sqrt(mean_0((z + bias)^2)) + 1e-6)).

@@ -128,3 +128,85 @@ def test_group_pipeline_on_rccl_world_size_one():
     assert rel_err(outs[0], g.G) < 1e-5
     for a, b, c in zip(outs, outs2, ref):
         assert np.array_equal(a, c) and np.array_equal(b, c)
+
+
+def _library_pipeline_worker(rank, world, port, name, ret):
+    """World size 1 on RCCL again, but the exchange is issued by the LIBRARY (gbnf_comm / gbnf_mixture_group_log_prob): per
+    group one hipGraphLaunch of {flow launch, repair launch, ncclAllGather, recursion launch}, two buffer slots on two streams
+    with a communicator each."""
+    import torch
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    torch.cuda.set_device(0)
+    dev = torch.device("cuda:0")
+    dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    try:
+        from conftest import GoldenCase
+        from gbnf_amd import native, sharded, synth
+        g = GoldenCase(name)
+        C = len(g.specs)
+        c0, c1 = sharded.partition(C, world)[rank]
+        mix = native.NativeMixture([native.NativeFlow(g.specs[c]) for c in range(c0, c1)])
+        rho = torch.from_numpy(g.rho).to(dev)
+        n, d = g.x.shape
+        xs = [torch.from_numpy(g.x).to(dev)] + [torch.from_numpy(synth.synth_batch(n, d, seed=40 + k)).to(dev) for k in range(6)]
+        ref = [mix.log_prob(x, rho)[0] for x in xs]                                      # per-batch launches, no exchange
+        out = {}
+        for graph in (True, False):
+            pipe = sharded.LibraryGroupPipeline(mix, C, c0, c1, rho, n, 3, gather=True, graph=graph)
+            tokens = [pipe.bind(xs[0:3]), pipe.bind(xs[3:6]), pipe.bind(xs[6:7])]
+            got = []
+            for rep in range(2):                         # twice: replays of the captured graphs, both slots re-used
+                res = []
+                for t in tokens:
+                    G, q = pipe.submit(t)
+                    pipe.drain()
+                    torch.cuda.synchronize()
+                    res.extend(G[b * n:(b + 1) * n].clone() for b in range(len(t.xs)))
+                got.append([r.cpu().numpy() for r in res])
+            out[graph] = (got, list(pipe.graph_errors), [tok.launches[0].graph is not None for tok in tokens])
+        # back to back without host synchronisation: the two slots overlap, a slot is re-used in its own stream's order
+        pipe = sharded.LibraryGroupPipeline(mix, C, c0, c1, rho, n, 3, gather=True, graph=True)
+        ta, tb = pipe.bind(xs[0:3]), pipe.bind(xs[3:6])
+        keep = []
+        for k in range(6):
+            G, q = pipe.submit(ta if k % 2 == 0 else tb)
+            if k >= 4:
+                keep.append((G, k % 2))
+        pipe.drain()
+        torch.cuda.synchronize()
+        tail = [(G.cpu().numpy(), which) for G, which in keep]
+        info = native.Comm.from_torch_distributed()
+        ret[rank] = (out, [r.cpu().numpy() for r in ref], tail, (info.rank, info.world))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_library_group_pipeline_on_rccl_world_size_one():
+    """RCCL called from the library, the group as one HIP graph.  Results bit-identical to per-batch launches
+    (the same kernels), with and without the graph; the capture itself must have succeeded on this stack."""
+    import torch.multiprocessing as mp
+    from conftest import GoldenCase, rel_err
+    name = "g3_glow_d43_h215_c8"
+    g = GoldenCase(name)
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_library_pipeline_worker, args=(1, _free_port(), name, ret), nprocs=1, join=True)
+    out, ref, tail, (rank, world) = ret[0]
+    assert (rank, world) == (0, 1)
+    n = g.x.shape[0]
+    for graph in (True, False):
+        got, errors, captured = out[graph]
+        if graph:
+            assert not errors and all(captured), f"graph capture refused: {errors}"
+        for rep in got:
+            assert len(rep) == 7
+            for a, c in zip(rep, ref):
+                assert np.array_equal(a, c)
+        assert rel_err(got[0][0], g.G) < 1e-5
+    for G, which in tail:
+        base = 0 if which == 0 else 3
+        for b in range(3):
+            assert np.array_equal(G[b * n:(b + 1) * n], ref[base + b])
