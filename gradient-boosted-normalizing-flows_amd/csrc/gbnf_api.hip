@@ -1747,6 +1747,29 @@ __global__ void __launch_bounds__(256) live_pack_kernel(const LiveTile* __restri
   live_small((int)blockIdx.x - tile_blocks, bias, n_bias, ent, n_ent, norms, K, d, glow, layers, blob);
 }
 
+// The table entries and the log-det constant of ONE BatchNorm step re-derived from BATCH statistics (train() mode of the reference,
+// models/layers.py:338-346: batch mean and unbiased variance of the step's input), behind bn_stats_kernel and in front of the launch
+// of the step range that starts with it.
+__global__ void __launch_bounds__(256) live_norm_step_kernel(const LiveEntry* __restrict__ ent, int n_ent, const LiveNorm* __restrict__ norms,
+                                                             int step, int d, const float* __restrict__ bmean, const float* __restrict__ bvar,
+                                                             uint32_t* __restrict__ blob) {
+  const LiveNorm N = norms[step];
+  if (!N.has_norm) return;
+  auto put = [&](uint32_t off, float v) { blob[off] = __builtin_bit_cast(uint32_t, v); };
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t < n_ent) {
+    const LiveEntry E = ent[t];
+    if (E.step == step) {
+      put(E.dst + 32, bmean[E.m]);
+      put(E.dst + 64, sqrtf(bvar[E.m] + N.eps));
+    }
+  } else if (t == n_ent) {
+    float acc = 0.0f;
+    for (int m = 0; m < d; ++m) acc += N.na[m] - 0.5f * logf(bvar[m] + N.eps);    // models/layers.py:357-358 on the batch variance
+    put(N.ld_dst, acc);
+  }
+}
+
 void live_blob_destroy(LiveBlob* lb) {
   if (!lb) return;
   if (lb->blob_dev) (void)hipFree(lb->blob_dev);
@@ -2015,7 +2038,7 @@ int live_blob_hidden_rows(const LiveBlob* lb) { return lb ? 16 * lb->ht : 0; }
 // operands of the weight gradients in `acts` (the workspace the forward sweep filled); gmax: gmax_kernel's result
 int live_blob_backward(LiveBlob* lb, int64_t n, const float* trace, float* acts, int64_t np, int ip, int hp, int op,
                        const float* g_z, const float* g_ldj, float* g_x, float* grads, const unsigned* gmax, void* stream,
-                       LiveReduce* reduce_out) {
+                       LiveReduce* reduce_out, const LiveRange* range) {
   hipStream_t s = (hipStream_t)stream;
   // the transposed tiles were packed by the forward call that wrote the trace (the parameters are unchanged since: the trace
   // contract of include/gbnf.h); a trainer that has not run one yet packs them here
@@ -2035,11 +2058,14 @@ int live_blob_backward(LiveBlob* lb, int64_t n, const float* trace, float* acts,
   // the workgroups' parameter-gradient sums go to the slack rows behind the last operand region (their contents are of no
   // consequence to wgrad_kernel): 4-wave workgroups at most => np / 64 * K * 128 <= 24 np floats of the 320 np there
   p.partials = acts + (int64_t)lb->K * lb->nnets * p.net_rows * np;
+  if (range != nullptr) {
+    p.k_begin = range->k_begin; p.k_end = range->k_end; p.state_in = range->state_in; p.state_out = range->state_out;
+  }
   hipError_t e = lb->launch_bwd(p, 0u, s);
   if (e != hipSuccess) return fail(GBNF_ERR_HIP, "launch of %s failed: %s", lb->name_bwd, hipGetErrorString(e));
   const int n_wg = (int)((np / 16 + lb->bwd_waves - 1) / lb->bwd_waves);
   if (reduce_out != nullptr) {
-    *reduce_out = LiveReduce{p.partials, n_wg, lb->K, lb->d, lb->bwd_goff_dev};
+    *reduce_out = LiveReduce{p.partials, n_wg, lb->K, lb->d, lb->bwd_goff_dev, 0u};
     return GBNF_OK;
   }
   hipLaunchKernelGGL(bwd_param_reduce_kernel, dim3((unsigned)(2 * lb->K)), dim3(1024), 0, s, (const float*)p.partials, n_wg, lb->K, lb->d,
@@ -2071,9 +2097,14 @@ int live_blob_words(const LiveBlob* lb, uint32_t* out_host, int64_t* n_words) {
 }
 
 int live_blob_forward(LiveBlob* lb, const float* x, int64_t n, float* z, float* ldj, float* trace, float* acts, int64_t np,
-                      int ip, int hp, int op, void* stream) {
+                      int ip, int hp, int op, void* stream, const LiveRange* range) {
   hipStream_t s = (hipStream_t)stream;
-  live_blob_repack(lb, s, /*with_backward=*/true);      // (a traced forward call: the backward call follows on the same parameters)
+  if (range == nullptr || range->repack)
+    live_blob_repack(lb, s, /*with_backward=*/true);      // (a traced forward call: the backward call follows on the same parameters)
+  if (range != nullptr && range->bmean != nullptr)
+    hipLaunchKernelGGL(live_norm_step_kernel, dim3((unsigned)((lb->n_entries + 1 + 255) / 256)), dim3(256), 0, s,
+                       (const LiveEntry*)lb->entries_dev, lb->n_entries, (const LiveNorm*)lb->norms_dev, range->k_begin, lb->d,
+                       range->bmean, range->bvar, lb->blob_dev);
   // 32-sample waves once that still gives every SIMD of the chip a wave, else 16-sample ones (as pick_nt does)
   int nt = pick_nt(n, 1);
   if (lb->launch_nt[nt] == nullptr) nt = 1;
@@ -2085,6 +2116,10 @@ int live_blob_forward(LiveBlob* lb, const float* x, int64_t n, float* z, float* 
   p.sat = reinterpret_cast<unsigned long long*>(saturation_counter());
   p.seq = next_serial();
   p.trace_out = trace; p.acts_out = acts; p.np = np; p.tr_ip = ip; p.tr_hp = hp; p.tr_op = op; p.net_rows = ip + 4 * hp + 2 * op;
+  if (range != nullptr) {
+    p.k_begin = range->k_begin; p.k_end = range->k_end; p.state_in = range->state_in; p.state_out = range->state_out;
+    p.ldj_accumulate = range->ldj_accumulate;
+  }
 #if defined(GBNF_STAMPS)
   p.dbg = g_stamp_buf;
 #endif

@@ -132,6 +132,14 @@ struct FlowLaunch {
   const unsigned* gmax;          //   bits of the largest |upstream entry| (gradient scaling)
   float* partials;               //   [workgroups][n_steps][2][64]: every workgroup's sums of the normalisation-parameter gradients
                                  //   (bwd_param_reduce_kernel adds them up in a fixed order: no atomics, bit-reproducible)
+  // step RANGES of the two training sweeps (round 4: BatchNorm on batch statistics -- a step's statistics need the whole batch, so
+  // the sweep is cut in front of every BatchNorm step and the state is parked in HBM in slot layout [d][np] between the launches)
+  int32_t k_begin, k_end;        //   steps [k_begin, k_end) of this launch; k_end == 0: all n_steps
+  const float* state_in;         //   forward: state at the input of step k_begin (null: the rows of xs); backward: the SCALED gradient
+                                 //   state behind step k_end - 1 (null: g_z / g_ldj rows)
+  float* state_out;              //   forward: state behind step k_end - 1 (null: the flow ends here: z_out / ldj_out); backward: gradient
+                                 //   state in front of step k_begin (null: g_x rows)
+  int32_t ldj_accumulate;        //   forward: ldj_out += this range's log-det instead of =
 };
 // Per-device saturation words (64-bit): [0] counter of waves that marked a sample, [1] unused, [2 ..] launch marks
 constexpr int SAT_MARKS = 2;

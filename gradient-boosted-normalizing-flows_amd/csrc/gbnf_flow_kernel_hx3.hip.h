@@ -451,7 +451,10 @@ flow_kernel_hx3(const FlowLaunch p) {
   // and norm^-1, log|det| accumulates with the opposite sign, z comes in through the FINAL slot map, x leaves through
   // the initial one (slot j = feature j)
   const bool inv = p.inverse != 0;
-  const int first_step = inv ? p.n_steps - 1 : 0;
+  // TRAIN: a step range [kb, ke) of the sweep (FlowLaunch::k_begin / k_end; the whole flow by default)
+  const int kb = TRAIN ? p.k_begin : 0;
+  const int ke = (TRAIN && p.k_end > 0) ? p.k_end : p.n_steps;
+  const int first_step = inv ? p.n_steps - 1 : kb;
   gwords next_src = (gwords)blob + (size_t)first_step * STEP_WORDS + SMALL_WORDS;    // bias block of the first step's net 0
   int gs = 0;                                       // stage counter: slot = gs & 1
   // TRAIN: operand stores this wave has issued BEHIND the staging DMA of the stage in flight.  They may stay in flight across
@@ -541,7 +544,13 @@ flow_kernel_hx3(const FlowLaunch p) {
         *reinterpret_cast<i32x4*>(SM + s * SMALL_WORDS + w) = *reinterpret_cast<const i32x4*>(src + w);
     }
   }
-  if (lane < d) {
+  if (TRAIN && p.state_in != nullptr) {
+    // the state parked by the launch of the previous step range: slot layout [d][np], 16 NT consecutive rows per slot
+    constexpr int RW = 16 * NT, SPP = 64 / RW;       // rows of the wave's tile, slots per pass
+    const int r = lane % RW, s0 = lane / RW;
+    const float* sin = p.state_in + row0 + r;
+    for (int slot = s0; slot < d; slot += SPP) Z[slot * ZS + r] = sin[(int64_t)slot * p.np];
+  } else if (lane < d) {
     // every row's load in flight before the first LDS store (branch-free: rows past the batch re-read its last row and are
     // zeroed): eight at a time cost a global round trip per group at the head of every work item
     float xv[16 * NT];
@@ -688,7 +697,7 @@ flow_kernel_hx3(const FlowLaunch p) {
   };
   preload();                       // the very first stage (landed behind the prologue's barrier)
 
-  for (int sidx = 0; sidx < p.n_steps; ++sidx) {
+  for (int sidx = kb; sidx < ke; ++sidx) {
     const int step = inv ? p.n_steps - 1 - sidx : sidx;
     const uint32_t* __restrict__ sp = blob + (size_t)step * STEP_WORDS;
     // TRAIN: this step's save regions as uniform bases + 32-bit lane offsets (no 64-bit vector arithmetic per store)
@@ -1032,7 +1041,7 @@ flow_kernel_hx3(const FlowLaunch p) {
           if constexpr (k + 1 < N_OUT) {
             issue(std::integral_constant<int, LT::value.nf[LT::value.N_L0 + k + 1]>{}, gs + 1);
           } else {
-            if ((net + 1 < NNETS) || (sidx + 1 < p.n_steps)) {
+            if ((net + 1 < NNETS) || (sidx + 1 < ke)) {
               if (net + 1 == NNETS)     // the next step's tables sit in front of its first net (inverse: the step before this one)
                 next_src = inv ? (gwords)blob + (size_t)(step - 1) * STEP_WORDS + SMALL_WORDS : next_src + SMALL_WORDS;
               issue_net_start(gs + 1);
@@ -1212,7 +1221,7 @@ flow_kernel_hx3(const FlowLaunch p) {
         // ---- drain: last tile, last output-layer chunk (HC-1); the next net's / step's first stage goes in flight
         {
           guard_at(7);
-          if ((net + 1 < NNETS) || (sidx + 1 < p.n_steps)) {
+          if ((net + 1 < NNETS) || (sidx + 1 < ke)) {
             if (net + 1 == NNETS)       // the next step's tables sit in front of its first net (inverse: the step before this one)
               next_src = inv ? (gwords)blob + (size_t)(step - 1) * STEP_WORDS + SMALL_WORDS : next_src + SMALL_WORDS;
             issue_net_start(gs + 1);
@@ -1501,17 +1510,26 @@ flow_kernel_hx3(const FlowLaunch p) {
     }
     const int64_t n = row0 + 16 * nt + i;
     if (g == 0 && n < p.n) {
-      const float ldj = l + ld_const;
+      float ldj = l + ld_const;
+      if constexpr (TRAIN) {
+        if (p.ldj_accumulate && p.ldj_out) ldj += p.ldj_out[out_base + n];      // the ranges before this one
+      }
       const float nanv = __builtin_nanf("");
       if (p.ldj_out) p.ldj_out[out_base + n] = bad ? nanv : ldj;
       if (p.ll_out) p.ll_out[out_base + n] = bad ? nanv : (q - 0.91893853320467274f * (float)d) + ldj;
     }
   }
+  if (TRAIN && p.state_out != nullptr) {        // the range does not end the flow: park the state (slot layout), no z
+    constexpr int RW = 16 * NT, SPP = 64 / RW;
+    const int r = lane % RW, s0 = lane / RW;
+    float* sout = p.state_out + row0 + r;
+    for (int slot = s0; slot < d; slot += SPP) sout[(int64_t)slot * p.np] = Z[slot * ZS + r];
+  }
   if (WATCH && p.sat != nullptr && any_sat && lane == 0) {
     atomicAdd(p.sat, 1ull);
     if constexpr (!TRAIN) atomicMax(p.sat + SAT_MARKS + p.seq % SAT_SLOTS, p.seq);      // tells the repair launch behind this one that it has work
   }
-  if (p.z_out != nullptr && lane < d) {
+  if (p.z_out != nullptr && lane < d && !(TRAIN && p.state_out != nullptr)) {
     const int slot = inv ? lane : (int)tail[lane];
     float* zo = p.z_out + (int64_t)comp * p.n * d;
 #pragma unroll 8

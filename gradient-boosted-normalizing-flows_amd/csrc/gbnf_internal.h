@@ -38,14 +38,29 @@ struct LiveReduce {
   const float* partials;      // [n_wg][K][2][64]
   int n_wg, K, d;
   const int64_t* goff;        // [K][2] float offsets into the flat gradient buffer
+  unsigned skip_steps;        // bit k: step k's two sums are NOT added (they were, by an earlier launch: batch-statistics BatchNorm)
+};
+// One step RANGE of a training sweep (round 4: BatchNorm on batch statistics; FlowLaunch::k_begin ..).  Forward: state_in / state_out =
+// the state parked in slot layout [d][np] (null: x rows / the flow's z, ldj outputs); bmean / bvar: device (d,) batch statistics
+// of step k_begin's BatchNorm, or null (running statistics: what the re-pack derived); repack: re-derive the blob from the live
+// parameters first (the first range of a sweep).  Backward: state_in / state_out = the scaled gradient state behind step
+// k_end - 1 / in front of step k_begin (null: g_z rows / g_x rows).
+struct LiveRange {
+  int k_begin, k_end;
+  const float* state_in;
+  float* state_out;
+  int ldj_accumulate;
+  bool repack;
+  const float* bmean;
+  const float* bvar;
 };
 int live_blob_backward(LiveBlob* lb, int64_t n, const float* trace, float* acts, int64_t np, int ip, int hp, int op,
                        const float* g_z, const float* g_ldj, float* g_x, float* grads, const unsigned* gmax, void* stream,
-                       LiveReduce* reduce_out = nullptr);
+                       LiveReduce* reduce_out = nullptr, const LiveRange* range = nullptr);
 void live_blob_destroy(LiveBlob* lb);
 // trace: [K][d][np] normalised states (slot layout); acts: the operand workspace (FlowLaunch::acts_out); np: padded rows
 int live_blob_forward(LiveBlob* lb, const float* x, int64_t n, float* z, float* ldj, float* trace, float* acts, int64_t np,
-                      int ip, int hp, int op, void* stream);
+                      int ip, int hp, int op, void* stream, const LiveRange* range = nullptr);
 // (tests) the blob as the device packer left it / size in words
 int live_blob_words(const LiveBlob* lb, uint32_t* out_host, int64_t* n_words);
 

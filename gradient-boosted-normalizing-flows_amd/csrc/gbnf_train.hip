@@ -1011,6 +1011,7 @@ __global__ void __launch_bounds__(WG_THREADS) wgrad_kernel(const WgProblem* __re
     if (blockIdx.y != 0 || red.partials == nullptr) return;
     __shared__ float rsum[4][64];
     const int kw = (int)blockIdx.x - n_blocks, j = threadIdx.x & 63, part = threadIdx.x >> 6;
+    if ((red.skip_steps >> (kw >> 1)) & 1u) return;           // added already (a BatchNorm step of a batch-statistics sweep)
     const float* src = red.partials + kw * 64 + j;
     const int64_t stride = (int64_t)red.K * 128;
     float a0 = 0.0f, a1 = 0.0f, a2 = 0.0f, a3 = 0.0f;
@@ -1202,6 +1203,43 @@ __global__ void __launch_bounds__(256) bn_stats_kernel(const TrStep* __restrict_
   }
 }
 
+// The same statistics for large batches (round 4): one block per slot reads a 65536-row column in 87 us -- four of them were 23 % of
+// the HEPMASS train() step.  Three launches over (slot, row chunk) blocks, every sum in a fixed order (bit-reproducible):
+//   pass 1: chunk sums -> ps[slot][NB];  pass 2: mean from them (every block adds the NB sums in the same order), chunk sums of
+//   the centred squares -> pq[slot][NB];  finalize: mean, unbiased variance -> the caller's buffers.
+constexpr int BN_CHUNKS = 64;
+__global__ void __launch_bounds__(256) bn_stats_part_kernel(const float* __restrict__ st, int64_t n, int64_t np, int nb, int pass,
+                                                            const float* __restrict__ ps, float* __restrict__ out) {
+  __shared__ float red[4];
+  const int slot = blockIdx.x, b = blockIdx.y;
+  const float* col = st + (size_t)slot * np;
+  const int64_t per = (n + nb - 1) / nb, s0 = (int64_t)b * per, s1 = s0 + per < n ? s0 + per : n;
+  float mean = 0.0f;
+  if (pass == 2) {
+    float tot = 0.0f;
+    for (int q = 0; q < nb; ++q) tot += ps[slot * nb + q];
+    mean = tot / (float)n;
+  }
+  float a = 0.0f;
+  for (int64_t s = s0 + threadIdx.x; s < s1; s += 256) {
+    const float c = col[s] - mean;
+    a += pass == 2 ? c * c : c;
+  }
+  const float tot = tr_block_sum(a, red);
+  if (threadIdx.x == 0) out[slot * nb + b] = tot;
+}
+__global__ void __launch_bounds__(64) bn_stats_final_kernel(const TrStep* __restrict__ steps, int k, int d, int64_t n, int nb,
+                                                            const float* __restrict__ ps, const float* __restrict__ pq) {
+  const int slot = threadIdx.x;
+  if (slot >= d) return;
+  const TrStep& S = steps[k];
+  float a = 0.0f, b = 0.0f;
+  for (int q = 0; q < nb; ++q) { a += ps[slot * nb + q]; b += pq[slot * nb + q]; }
+  const int f = S.feat[slot];
+  S.bmean[f] = a / (float)n;
+  S.bvar[f] = b / (float)(n - 1);
+}
+
 // Backward through the batch statistics of step k, applied to the gradient state the step's backward launch left behind
 // (which treated mean / var as constants):   g_x -= (gamma / sigma) * S1 / n  +  x_hat / (sigma (n - 1)) * S2,
 // S1 = sum g_y = d/d beta,  S2 = gamma sum g_y x_hat + sum g_ldj = d/d log_gamma -- both already in `grads`.
@@ -1285,10 +1323,13 @@ struct gbnf_trainer {
   int hw = 0, xw = 0, ow = 0;
   int residual = 0;                    // ResidualNet coupling networks
   unsigned* gmax_dev = nullptr;        // bits of the largest |upstream gradient| of the current backward call (gradient scaling)
+  float* bn_part_dev = nullptr;        // [2][64 slots][BN_CHUNKS]: chunk sums of the batch statistics (bn_stats_part_kernel)
   int batch_stats = 0;                 // BatchNorm on batch statistics (the reference's train() mode)
   std::vector<int> has_norm;           // per step
   std::vector<char> stats_bound;       // per step: bmean / bvar bound by the caller
+  std::vector<float*> bmean_ptr, bvar_ptr;   // per step: the caller's device buffers (host copies of TrStep::bmean / bvar)
   LiveBlob* live = nullptr;            // round 3: the forward sweep on flow_kernel_hx3<TRAIN> (depth-1 TanhNet / ReLUNet), else null
+  mutable int last_fwd_ranges = 0, last_bwd_ranges = 0;     // (tests) launches of the register-chained kernels by the last forward / backward call; 0 = the round-1 kernels ran
 };
 
 // tuning / test knob: GBNF_TRAIN_PATH=old keeps the round-1 kernels for every call
@@ -1497,6 +1538,7 @@ int gbnf_trainer_create(const gbnf_flow_desc* desc, gbnf_trainer** out) {
   if (e == hipSuccess) e = hipMemcpy(t->prep_dev, preps.data(), sizeof(PrepProblem) * preps.size(), hipMemcpyHostToDevice);
   if (e == hipSuccess) e = hipMalloc((void**)&t->frag_dev, (size_t)frag_off * 16);
   if (e == hipSuccess) e = hipMalloc((void**)&t->gmax_dev, sizeof(unsigned));
+  if (e == hipSuccess) e = hipMalloc((void**)&t->bn_part_dev, sizeof(float) * 2 * 64 * BN_CHUNKS);
   if (e == hipSuccess) {
     const void* fns[8] = {(const void*)train_kernel<GBNF_KIND_GLOW, 0, 1>, (const void*)train_kernel<GBNF_KIND_GLOW, 1, 1>,
                           (const void*)train_kernel<GBNF_KIND_REALNVP, 0, 1>, (const void*)train_kernel<GBNF_KIND_REALNVP, 1, 1>,
@@ -1537,6 +1579,7 @@ int gbnf_trainer_destroy(gbnf_trainer* t) {
   if (t->prep_dev) (void)hipFree(t->prep_dev);
   if (t->frag_dev) (void)hipFree(t->frag_dev);
   if (t->gmax_dev) (void)hipFree(t->gmax_dev);
+  if (t->bn_part_dev) (void)hipFree(t->bn_part_dev);
   live_blob_destroy(t->live);
   delete t;
   return GBNF_OK;
@@ -1577,6 +1620,20 @@ static void fill_launch(const gbnf_trainer* t, TrainLaunch& p, const float* x, i
   p.k_begin = 0; p.k_end = t->K;
 }
 
+// batch mean / unbiased variance of step k's input state (slot layout) into the caller's buffers
+static void launch_bn_stats(const gbnf_trainer* t, int k, const float* state, int64_t n, int64_t np, hipStream_t s) {
+  if (n < 16384) {
+    hipLaunchKernelGGL(bn_stats_kernel, dim3((unsigned)t->d), dim3(256), 0, s, (const TrStep*)t->steps_dev, k, state, n, np);
+    return;
+  }
+  const int nb = BN_CHUNKS;
+  float* ps = t->bn_part_dev;
+  float* pq = t->bn_part_dev + 64 * BN_CHUNKS;
+  hipLaunchKernelGGL(bn_stats_part_kernel, dim3((unsigned)t->d, (unsigned)nb), dim3(256), 0, s, state, n, np, nb, 1, (const float*)nullptr, ps);
+  hipLaunchKernelGGL(bn_stats_part_kernel, dim3((unsigned)t->d, (unsigned)nb), dim3(256), 0, s, state, n, np, nb, 2, (const float*)ps, pq);
+  hipLaunchKernelGGL(bn_stats_final_kernel, dim3(1), dim3(64), 0, s, (const TrStep*)t->steps_dev, k, t->d, n, nb, (const float*)ps, (const float*)pq);
+}
+
 // batch-statistics mode is on and some step has a BatchNorm whose statistics must come from the batch
 static bool needs_step_launches(const gbnf_trainer* t) {
   if (!t->batch_stats) return false;
@@ -1606,6 +1663,9 @@ int gbnf_trainer_bind_batch_stats(gbnf_trainer* t, int32_t step, float* mean_dev
                                  hipMemcpyHostToDevice);
   if (e != hipSuccess) return fail(GBNF_ERR_HIP, "gbnf_trainer_bind_batch_stats: %s", hipGetErrorString(e));
   t->stats_bound[step] = 1;
+  if ((int)t->bmean_ptr.size() != t->K) { t->bmean_ptr.assign(t->K, nullptr); t->bvar_ptr.assign(t->K, nullptr); }
+  t->bmean_ptr[step] = mean_dev;
+  t->bvar_ptr[step] = var_dev;
   return GBNF_OK;
 }
 
@@ -1628,12 +1688,40 @@ int gbnf_trainer_forward(const gbnf_trainer* t, const float* x, int64_t n, float
   p.z_out = z; p.ldj_out = ldj; p.trace_out = trace;
   p.batch_stats = t->batch_stats;
   hipStream_t s = (hipStream_t)stream;
-  if (t->live != nullptr && trace != nullptr && !needs_step_launches(t) && (int64_t)t->nnets * t->net_rows * p.np < (1LL << 31)) {
+  if (t->live != nullptr && trace != nullptr && (int64_t)t->nnets * t->net_rows * p.np < (1LL << 31) &&
+      (!needs_step_launches(t) || (ldj != nullptr && n >= 2 && (int)t->bmean_ptr.size() == t->K))) {
     // round 3: the forward sweep on the evaluation kernel (register-chained, weights staged once per workgroup): re-pack
     // the live parameters on the device, then x -> z, ldj + trace + the activation-side operands of the weight gradients
     float* acts = trace + ((int64_t)t->K + 1) * t->d * p.np;
-    const int rc = live_blob_forward(t->live, x, n, z, ldj, trace, acts, p.np, t->ip, t->hp, t->op, stream);
-    if (rc) return rc;
+    t->last_fwd_ranges = 1;
+    if (!needs_step_launches(t)) {
+      const int rc = live_blob_forward(t->live, x, n, z, ldj, trace, acts, p.np, t->ip, t->hp, t->op, stream);
+      if (rc) return rc;
+    } else {
+      t->last_fwd_ranges = 0;
+      // round 4: BatchNorm on batch statistics (the reference's train() mode, models/layers.py:338-346) on the same kernels: the
+      // sweep is cut in front of every BatchNorm step -- its statistics need the whole batch: one column reduction of the parked
+      // state (bn_stats_kernel), the step's table entries re-derived from them (live_norm_step_kernel) -- and the state is parked
+      // in HBM in slot layout between the launches (the last d * np floats of the trace buffer)
+      float* state = trace + (int64_t)t->K * t->d * p.np;
+      const unsigned nb = (unsigned)((p.np + 255) / 256);
+      hipLaunchKernelGGL(rows_to_slots_kernel, dim3(nb), dim3(256), 0, s, x, state, n, p.np, t->d);
+      bool first = true;
+      for (int k0 = 0; k0 < t->K;) {
+        int k1 = k0 + 1;
+        while (k1 < t->K && !t->has_norm[k1]) ++k1;
+        LiveRange rg{k0, k1, state, k1 < t->K ? state : nullptr, k0 > 0 ? 1 : 0, first, nullptr, nullptr};
+        if (t->has_norm[k0]) {
+          launch_bn_stats(t, k0, state, n, p.np, s);
+          rg.bmean = t->bmean_ptr[k0]; rg.bvar = t->bvar_ptr[k0];
+        }
+        const int rc = live_blob_forward(t->live, x, n, z, ldj, trace, acts, p.np, t->ip, t->hp, t->op, stream, &rg);
+        if (rc) return rc;
+        ++t->last_fwd_ranges;
+        first = false;
+        k0 = k1;
+      }
+    }
     // without a matching backward variant the backward kernels of this file run, on prep_kernel's fragments (valid while
     // the parameters are what they are now: the trace contract)
     if (!live_blob_has_backward(t->live))
@@ -1643,6 +1731,7 @@ int gbnf_trainer_forward(const gbnf_trainer* t, const float* x, int64_t n, float
     return GBNF_OK;
   }
   // the parameters may have changed since the last call: split them into this call's MFMA fragments
+  t->last_fwd_ranges = 0;
   hipLaunchKernelGGL(prep_kernel, dim3((unsigned)t->prep_blocks), dim3(64), 0, s, (const PrepProblem*)t->prep_dev, t->n_prep, t->frag_dev);
   if (!needs_step_launches(t)) {
     launch_train<0>(t, p, s);
@@ -1656,7 +1745,7 @@ int gbnf_trainer_forward(const gbnf_trainer* t, const float* x, int64_t n, float
     hipLaunchKernelGGL(rows_to_slots_kernel, dim3(nb), dim3(256), 0, s, x, state, n, p.np, t->d);
     for (int k = 0; k < t->K; ++k) {
       if (t->has_norm[k])
-        hipLaunchKernelGGL(bn_stats_kernel, dim3((unsigned)t->d), dim3(256), 0, s, (const TrStep*)t->steps_dev, k, (const float*)state, n, p.np);
+        launch_bn_stats(t, k, state, n, p.np, s);
       TrainLaunch q = p;
       q.k_begin = k; q.k_end = k + 1;
       q.state_in = state; q.state_out = state;
@@ -1695,14 +1784,47 @@ int gbnf_trainer_backward(const gbnf_trainer* t, const float* x, int64_t n, cons
     hipLaunchKernelGGL(gmax_kernel, dim3(gb ? gb : 1), dim3(256), 0, s, g_z, g_ldj, n, t->d, t->gmax_dev);
   }
   p.gmax = t->gmax_dev;
-  if (live_blob_has_backward(t->live) && trace != nullptr && !needs_step_launches(t) &&
-      (int64_t)t->nnets * t->net_rows * p.np < (1LL << 31)) {
+  if (live_blob_has_backward(t->live) && trace != nullptr && (int64_t)t->nnets * t->net_rows * p.np < (1LL << 31) &&
+      (!needs_step_launches(t) || (int)t->bmean_ptr.size() == t->K)) {
     // round 3: the register-chained backward sweep on what the forward sweep saved behind the trace, then the weight
     // gradients from the operand workspace that now lives there too
     float* acts = const_cast<float*>(trace) + ((int64_t)t->K + 1) * t->d * p.np;
     LiveReduce red{};
-    const int rc = live_blob_backward(t->live, n, trace, acts, p.np, t->ip, t->hp, t->op, g_z, g_ldj, g_x, grads, t->gmax_dev, stream, &red);
-    if (rc) return rc;
+    t->last_bwd_ranges = 1;
+    if (!needs_step_launches(t)) {
+      const int rc = live_blob_backward(t->live, n, trace, acts, p.np, t->ip, t->hp, t->op, g_z, g_ldj, g_x, grads, t->gmax_dev, stream, &red);
+      if (rc) return rc;
+    } else {
+      t->last_bwd_ranges = 0;
+      // round 4, the mirror image of the forward: one launch per step range, last range first; behind a range that starts with a
+      // BatchNorm step its two parameter sums are added up (they are that step's d/d beta and d/d log_gamma: exactly the two batch
+      // sums the correction needs) and the parked gradient state is corrected for the dependence of the batch statistics on
+      // every sample (bn_bwd_fix_kernel); the last launch's state goes out as g_x rows
+      std::vector<int> starts;
+      for (int k0 = 0; k0 < t->K;) { starts.push_back(k0); int k1 = k0 + 1; while (k1 < t->K && !t->has_norm[k1]) ++k1; k0 = k1; }
+      unsigned done = 0u;
+      for (int ri = (int)starts.size() - 1; ri >= 0; --ri) {
+        const int k0 = starts[ri], k1 = ri + 1 < (int)starts.size() ? starts[ri + 1] : t->K;
+        LiveRange rg{k0, k1, k1 < t->K ? gstate : nullptr, gstate, 0, false, nullptr, nullptr};
+        const int rc = live_blob_backward(t->live, n, trace, acts, p.np, t->ip, t->hp, t->op, g_z, g_ldj, nullptr, grads, t->gmax_dev, stream, &red, &rg);
+        if (rc) return rc;
+        ++t->last_bwd_ranges;
+        if (t->has_norm[k0]) {
+          LiveReduce one = red;
+          one.skip_steps = ~(1u << k0);
+          hipLaunchKernelGGL(wgrad_kernel, dim3((unsigned)(2 * red.K), 1u), dim3(WG_THREADS), 0, s, t->probs_dev, t->n_probs, (const float*)acts, grads,
+                             p.np, 512, (const unsigned*)t->gmax_dev, 0, one);
+          done |= 1u << k0;
+          const dim3 fg((unsigned)((n + 255) / 256), (unsigned)t->d);
+          hipLaunchKernelGGL(bn_bwd_fix_kernel, fg, dim3(256), 0, s, (const TrStep*)t->steps_dev, k0, t->d, trace, (const float*)grads,
+                             gstate, n, p.np, (const unsigned*)t->gmax_dev);
+        }
+      }
+      if (g_x != nullptr)
+        hipLaunchKernelGGL(slots_to_rows_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, (const float*)gstate, g_x, n, p.np, t->d,
+                           (const unsigned*)t->gmax_dev);
+      red.skip_steps = done;
+    }
     // samples per block: the largest power of two that still leaves ~a block per CU (>= 240 blocks) -- measured at N = 65536
     // with 1024 / 2048 / 4096 / 8192 / 16384 samples per block: 58.5 / 60.8 / 62.1 / 63.1 / 47.8 M samples/s, and 512 is the
     // best at N = 4096; every further chunk adds a 128 x 128 tile of float atomics per block of dW, every chunk less leaves
@@ -1720,6 +1842,7 @@ int gbnf_trainer_backward(const gbnf_trainer* t, const float* x, int64_t n, cons
   }
   // a trace is valid only while the parameters are what they were in the forward call that wrote it (include/gbnf.h):
   // that call split them into this trainer's fragment buffer, so the fragments are still the right ones
+  t->last_bwd_ranges = 0;
   if (trace == nullptr)
     hipLaunchKernelGGL(prep_kernel, dim3((unsigned)t->prep_blocks), dim3(64), 0, s, (const PrepProblem*)t->prep_dev, t->n_prep, t->frag_dev);
   if (!needs_step_launches(t)) {
@@ -1756,6 +1879,15 @@ int gbnf_trainer_backward(const gbnf_trainer* t, const float* x, int64_t n, cons
                      (const unsigned*)t->gmax_dev, t->wg_blocks, LiveReduce{});
   e = hipGetLastError();
   if (e != hipSuccess) return fail(GBNF_ERR_HIP, "gbnf_trainer_backward wgrad launch: %s", hipGetErrorString(e));
+  return GBNF_OK;
+}
+
+// (tests) how the last forward / backward call of a trainer ran: launches of the register-chained kernels (1 = the whole sweep in one
+// launch, > 1 = one per step range of a batch-statistics BatchNorm sweep), 0 = the round-1 per-step kernels
+int gbnf_debug_trainer_last_path(const gbnf_trainer* t, int32_t* fwd_ranges, int32_t* bwd_ranges) {
+  if (!t) return fail(GBNF_ERR_INVALID, "gbnf_debug_trainer_last_path: trainer is null");
+  if (fwd_ranges) *fwd_ranges = t->last_fwd_ranges;
+  if (bwd_ranges) *bwd_ranges = t->last_bwd_ranges;
   return GBNF_OK;
 }
 

@@ -108,6 +108,7 @@ __global__ void __launch_bounds__(64 * WV, WV == 8 ? 2 : bwd_hx3_occupancy(KIND,
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   const int i = lane & 15, g = lane >> 4;
   const int d = p.d, K = p.n_steps;
+  const int kb = p.k_begin, ke = p.k_end > 0 ? p.k_end : K;       // this launch's step range (FlowLaunch::k_begin / k_end)
   const uint32_t* __restrict__ blobF = p.blobs[0];
   const uint32_t* __restrict__ blobB = p.blobs_bwd[0];
   // rows >= n are padding: their upstream gradients are zero.  The last workgroup's spare waves own no rows: they shadow the
@@ -135,7 +136,7 @@ __global__ void __launch_bounds__(64 * WV, WV == 8 ? 2 : bwd_hx3_occupancy(KIND,
   // ---- weight staging (as in flow_kernel_hx3): the transposed blob is in consumption order, steps last to first
   using gwords = const __attribute__((address_space(1))) uint32_t*;
   using lptr = __attribute__((address_space(3))) void*;
-  gwords next_src = (gwords)blobB + (size_t)(K - 1) * STEP_WORDS_B;
+  gwords next_src = (gwords)blobB + (size_t)(ke - 1) * STEP_WORDS_B;
   int gs = 0;
   const unsigned lane_b16 = (unsigned)lane * 16u;
   auto dma = [&](gwords src, uint32_t* dst) {
@@ -160,8 +161,13 @@ __global__ void __launch_bounds__(64 * WV, WV == 8 ? 2 : bwd_hx3_occupancy(KIND,
     for (int w = (int)threadIdx.x * 4; w < SMALL_WORDS; w += 64 * WAVES * 4)
       *reinterpret_cast<i32x4*>(SM + s * SMALL_WORDS + w) = *reinterpret_cast<const i32x4*>(src + w);
   }
-  // ---- upstream gradients -> G (through the final slot map), scaled
-  {
+  // ---- upstream gradients -> G (through the final slot map), scaled -- or the gradient state the launch of the following step
+  //      range parked (slot layout [d][np], already scaled)
+  if (p.state_in != nullptr) {
+    const int r = lane & 15, s0 = lane >> 4;
+    const float* gin = p.state_in + row0 + r;
+    for (int slot = s0; slot < d; slot += 4) G[slot * ZS + r] = gin[(int64_t)slot * p.np];
+  } else {
     const uint32_t* tail = blobF + (size_t)K * STEP_WORDS_F;
     if (lane < d) {
       const int slot = (int)tail[lane];
@@ -248,7 +254,7 @@ __global__ void __launch_bounds__(64 * WV, WV == 8 ? 2 : bwd_hx3_occupancy(KIND,
   const int o_off = tile0 * op16 + 4 * g * 16 + i;
 
   st.start();
-  for (int step = K - 1; step >= 0; --step) {
+  for (int step = ke - 1; step >= kb; --step) {
     st.set(0);
     const uint32_t* smt = SM + step * SMALL_WORDS;
     const float* trace = p.trace_in + (int64_t)step * d * p.np;
@@ -530,7 +536,7 @@ __global__ void __launch_bounds__(64 * WV, WV == 8 ? 2 : bwd_hx3_occupancy(KIND,
       st.set(3);
       // ---- drain: last tile of g_a1, last W1^T chunk; the next net's / step's first stage goes in flight
       {
-        if (net + 1 < NNETS || step > 0) {
+        if (net + 1 < NNETS || step > kb) {
           if (net + 1 == NNETS) next_src = (gwords)blobB + (size_t)(step - 1) * STEP_WORDS_B;
           issue(std::integral_constant<int, BL::value.nf[0]>{}, gs + 1);
         } else {
@@ -644,8 +650,15 @@ __global__ void __launch_bounds__(64 * WV, WV == 8 ? 2 : bwd_hx3_occupancy(KIND,
   }
 #endif
 
-  // ---- d loss / d x: slot j = feature j at the input of step 0
-  if (p.g_x != nullptr && lane < d) {
+  // ---- the gradient state in front of step kb: parked for the launch of the preceding range (slot layout, still scaled) ...
+  if (p.state_out != nullptr) {
+    const int r = lane & 15, s0 = lane >> 4;
+    float* gout = p.state_out + row0 + r;
+    if (wave_ok)
+      for (int slot = s0; slot < d; slot += 4) gout[(int64_t)slot * p.np] = G[slot * ZS + r];
+  }
+  // ---- ... or d loss / d x: slot j = feature j at the input of step 0
+  if (p.state_out == nullptr && p.g_x != nullptr && lane < d) {
 #pragma unroll 8
     for (int r = 0; r < 16; ++r) {
       const int64_t n = row0 + r;
@@ -655,7 +668,7 @@ __global__ void __launch_bounds__(64 * WV, WV == 8 ? 2 : bwd_hx3_occupancy(KIND,
   if (p.sat != nullptr && __any(sat) && lane == 0) atomicAdd(p.sat, 1ull);
   // ---- this workgroup's parameter-gradient sums, waves added in a fixed order
   __syncthreads();
-  for (int e = (int)threadIdx.x; e < K * 128; e += 64 * WAVES) {
+  for (int e = kb * 128 + (int)threadIdx.x; e < ke * 128; e += 64 * WAVES) {        // (this range's steps only)
     float v = 0.0f;
 #pragma unroll
     for (int w = 0; w < WAVES; ++w) v += PG[w * K * 128 + e];

@@ -472,7 +472,27 @@ def test_train_mode_batch_norm_matches_reference():
     assert torch.isfinite(ldj2).all() and not torch.allclose(ldj2, ldj.detach())
 
 
-@pytest.mark.parametrize("d,h,K,n,seed", [(21, 33, 3, 100, 1), (6, 16, 4, 17, 2), (43, 64, 2, 257, 3)])
+def _has_live_blob(tr):
+    import ctypes as C
+    from gbnf_amd import native
+    L = native.lib()
+    L.gbnf_debug_trainer_blob.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(C.c_int64)]
+    n = C.c_int64()
+    return L.gbnf_debug_trainer_blob(tr.handle, None, C.byref(n)) == 0
+
+
+def _last_path(tr):
+    """(forward, backward) launches of the register-chained kernels by the trainer's last calls; 0 = the round-1 kernels ran."""
+    import ctypes as C
+    from gbnf_amd import native
+    L = native.lib()
+    L.gbnf_debug_trainer_last_path.argtypes = [C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
+    a, b = C.c_int32(), C.c_int32()
+    assert L.gbnf_debug_trainer_last_path(tr.handle, C.byref(a), C.byref(b)) == 0
+    return a.value, b.value
+
+
+@pytest.mark.parametrize("d,h,K,n,seed", [(21, 33, 3, 100, 1), (6, 16, 4, 17, 2), (43, 64, 2, 257, 3), (21, 105, 5, 1000, 4)])
 def test_trainer_batch_stats_against_oracle(d, h, K, n, seed):
     import torch
     from gbnf_amd import native, synth
@@ -490,6 +510,12 @@ def test_trainer_batch_stats_against_oracle(d, h, K, n, seed):
     x = synth.synth_batch(n, d, seed=seed + 5)
     xd = torch.from_numpy(x).to(dev)
     z, ldj, trace = tr.forward(xd, want_trace=True)
+    # round 4: the sweep runs on the register-chained kernels, one launch per step range (a range starts at every BatchNorm step:
+    # steps 0 .. K-2 carry one, models/realnvp.py:71-74)
+    chained = _has_live_blob(tr)          # (a width with no TRAIN variant of its own keeps the round-1 kernels: 0 chained launches)
+    assert _last_path(tr)[0] == (max(K - 1, 1) if chained else 0)
+    if (d, h) == (21, 105):
+        assert chained                    # the HEPMASS geometry (BASELINE.json configs[2]) must be on the fast path
     z64, ldj64, stats = oracle.component_forward_train(spec, x)
     assert np.abs(z.cpu().numpy() - z64).max() <= 2e-5 * max(1.0, float(np.abs(z64).max()))
     assert np.abs(ldj.cpu().numpy() - ldj64).max() <= 1e-5 * max(1.0, float(np.abs(ldj64).max()))
@@ -504,6 +530,7 @@ def test_trainer_batch_stats_against_oracle(d, h, K, n, seed):
     g_l = rng.standard_normal(n).astype(np.float32)
     gx64, grads64 = oracle.component_grads(spec, x, g_z, g_l, train=True)
     gx, grads = tr.backward(xd, torch.from_numpy(g_z).to(dev), torch.from_numpy(g_l).to(dev), want_gx=True, trace=trace)
+    assert _last_path(tr)[1] == (max(K - 1, 1) if chained else 0)
     _check_grads(grads, grads64, "batch-stats", floor=0.05 * max(float(np.abs(g).max()) for g in grads64 if g is not None))
     assert np.abs(gx.cpu().numpy() - gx64).max() <= G_RTOL * float(np.abs(gx64).max())
     with pytest.raises(native.GbnfError):          # the statistics need the forward call's trace

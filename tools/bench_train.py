@@ -69,6 +69,7 @@ def main():
     ap.add_argument("--cpu-rows", type=int, default=4096, help="rows of the batch the CPU baseline leg runs on (bounded sample)")
     ap.add_argument("--tune", action="append", default=[], help="key=value for gbnf_tuning_set (A/B runs)")
     ap.add_argument("--graph", action="store_true", help="also time the step captured once in a HIP graph and replayed (torch.cuda.CUDAGraph)")
+    ap.add_argument("--batch-stats", action="store_true", help="RealNVP: BatchNorm on batch statistics (the reference's train() mode, its default training configuration)")
     ap.add_argument("--no-torch-legs", action="store_true", help="skip the eager-PyTorch GPU leg (profiler runs: thousands of tiny dispatches)")
     a = ap.parse_args()
     cfg = CONFIGS[a.config]
@@ -78,7 +79,15 @@ def main():
     from test_hip_train import _dev_spec
     dev = torch.device("cuda:0")
     spec = synth.synth_boosted_specs(cfg["kind"], 1, cfg["d"], cfg["h"], cfg["K"], seed=1, **cfg["kw"])[0]
-    tr = native.NativeTrainer(_dev_spec(spec, dev))
+    dv = _dev_spec(spec, dev)
+    if a.batch_stats:
+        for st in dv["steps"]:
+            if st.get("bn") is not None:
+                st["bn"]["batch_mean"] = torch.zeros(cfg["d"], device=dev)
+                st["bn"]["batch_var"] = torch.zeros(cfg["d"], device=dev)
+    tr = native.NativeTrainer(dv)
+    if a.batch_stats:
+        tr.set_batch_stats(True)
     x = torch.from_numpy(synth.synth_batch(a.batch, cfg["d"], seed=0)).to(dev)
     n = a.batch
 
@@ -144,7 +153,7 @@ def main():
     kern_s = (fw + bw) * 1e-3
     print(json.dumps({
         "metric": f"training step (forward+backward) samples/sec, one component, {a.config}", "unit": "samples/s",
-        "value": n / t_hip, "ms_per_step": t_hip * 1e3, "batch": n, "dtype": "f16x3", "data": "synthetic",
+        "value": n / t_hip, "ms_per_step": t_hip * 1e3, "batch": n, "dtype": "f16x3", "data": "synthetic", "batch_stats": bool(a.batch_stats),
         "config": {"workload": f"{a.config}: one component, batch {n}: traced forward, loss gradient, backward (dgrad + wgrad), synthetic weights"},
         "hip_graph_replay": None if t_graph is None else {"value": n / t_graph, "ms_per_step": t_graph * 1e3},
         "forward_kernel_ms": fw, "backward_kernels_ms": bw,
