@@ -192,6 +192,30 @@ def module_evaluate_leg(specs, kind, d, h, K, C, xs, iters=100):
         return (time.perf_counter() - t0) / iters, out
 
     t_loop, _ = timed(reference_loop)
+    # ... taken apart: the module calls alone (the first of a batch launches all C components, the others read its table) and
+    # the caller's own torch ops alone (the module's outputs precomputed): ~17 small eager launches per component
+    def calls_only():
+        xb = xs[turn[0] % len(xs)]
+        turn[0] += 1
+        return [model(x=xb, components=c) for c in range(model.component + 1)]
+
+    pre = [(o[0], o[3]) for o in calls_only()]
+
+    def ops_only():
+        G_ll = None
+        for c, (z_G, ldj_G) in enumerate(pre):
+            ll = torch.sum(-0.5 * math.log(2 * math.pi) - 0.5 * z_G.pow(2), dim=-1) + ldj_G
+            if c == 0:
+                G_ll = ll
+            else:
+                rho_simplex = model.rho[0:(c + 1)] / torch.sum(model.rho[0:(c + 1)])
+                last_ll = torch.log(1 - rho_simplex[c]) + G_ll
+                next_ll = torch.log(rho_simplex[c]) + ll
+                G_ll = torch.logsumexp(torch.cat([last_ll.view(-1, 1), next_ll.view(-1, 1)], dim=1), dim=1)
+        return G_ll
+
+    t_calls, _ = timed(calls_only)
+    t_ops, _ = timed(ops_only)
     turn[0] = 0
     with torch.no_grad():
         G_loop = reference_loop()          # batch 0: what the pipeline's G0 and log_prob(x) below are compared with
@@ -201,6 +225,10 @@ def module_evaluate_leg(specs, kind, d, h, K, C, xs, iters=100):
             "log_prob_one_call_value": n / t_one, "log_prob_one_call_ms": 1e3 * t_one,
             "max_abs_diff_loop_vs_one_call": float((G_loop - G_one).abs().max().item()),
             "batches_cycled": len(xs),
+            "module_calls_only_ms": 1e3 * t_calls, "callers_torch_ops_only_ms": 1e3 * t_ops,
+            "value_if_the_callers_ops_were_free": n / t_calls,
+            "bound": "the CALLER's own eager torch ops (base density + recursion: ~17 launches per component, host-bound) -- "
+                     "callers_torch_ops_only_ms is this loop with the module's outputs precomputed",
             "note": "the reference's own evaluate loop through the drop-in BoostedFlow module, a different batch tensor every "
                     "iteration: C forward calls returning (z, ldj) -- the first launches all C components of the batch, the "
                     "others read its table -- + the base density and the recursion in torch ops, host time included; "
