@@ -178,7 +178,17 @@ int gbnf_tuning_set(const char* key, int32_t value);
 int gbnf_tuning_get(const char* key, int32_t* value);
 
 /* Replaces: constructing flows[c] + .to(device)  (models/boosted_flow.py:42-50).
- * Packs (pads, tiles, folds slot maps) and uploads the parameters. */
+ * Packs (pads, tiles, folds slot maps) and uploads the parameters.
+ * LIMITS (enforced: GBNF_ERR_UNSUPPORTED with the reason in gbnf_last_error; nothing falls back to a non-HIP path):
+ *   features                1 <= d <= 64                 (a sample tile's features are LDS slots of one wave; the reference's five
+ *                                                         tabular datasets have d = 6, 8, 21, 43, 63)
+ *   coupling-net input      <= 32 features               (d / 2, or d - d / 2 for a flipped RealNVP step: one k = 32 MFMA chunk)
+ *   hidden width            1 <= h <= 512                (TanhNet / ReLUNet at coupling_network_depth 0, 1, 2; the split kernels cover
+ *                                                         every depth to 512, one-block ResidualNets to 256; two-block ResidualNets and
+ *                                                         wider ones run on the exact-f32 kernel)
+ *   coupling_network_depth  0, 1, 2; ResidualNet blocks 1, 2 (RealNVP only, as in the reference)
+ *   flow steps              any K (per-step tables are staged in LDS up to K = 12, read from the blob beyond)
+ *   activations             tanh / relu, also drawn per step or per net (`--coupling_network random`) */
 int gbnf_flow_create(const gbnf_flow_desc* desc, gbnf_flow** out);
 /* Same with an explicit GBNF_MATH_* mode (gbnf_flow_create uses GBNF_MATH_DEFAULT, or env GBNF_MATH=f32|f16x3|bf16x6). */
 int gbnf_flow_create_mode(const gbnf_flow_desc* desc, int32_t math_mode, gbnf_flow** out);
@@ -403,6 +413,11 @@ typedef struct gbnf_image_flow_desc {
 
 typedef struct gbnf_image_flow gbnf_image_flow;
 
+/* LIMITS of the image path (enforced with GBNF_ERR_UNSUPPORTED): square inputs whose maps are 16 or 8 wide after squeezing --
+ * 32 x 32 inputs with 1 or 2 levels (the reference's CIFAR-10 / SVHN loaders; its 28 x 28 and 28 x 20 inputs are not built);
+ * <= 64 channels per level; coupling ConvNets of hidden width <= 256 with 2 .. 5 convolutions (coupling_network_depth 0 .. 3);
+ * the split-f16 kernels serve depth 1 with <= 16 input channels of the first 3 x 3, everything else runs on the exact-f32
+ * convolution kernels.  Not built: y-conditioning, learned dequantisation flows, data-dependent ActNorm2d initialisation. */
 int gbnf_image_flow_create(const gbnf_image_flow_desc* desc, gbnf_image_flow** out);
 int gbnf_image_flow_destroy(gbnf_image_flow* flow);
 /* Shape of z (per image) and the algorithmic multiply-adds per image; any pointer may be NULL. */
