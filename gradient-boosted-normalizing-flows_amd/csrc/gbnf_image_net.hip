@@ -374,7 +374,82 @@ __global__ void __launch_bounds__(512) img_net_hx3_kernel(const NetLaunch p) {
   for (int o = 0; o < MAXO; ++o)
 #pragma unroll
     for (int pt = 0; pt < NPO; ++pt) part[o][pt] = f32x4{0.f, 0.f, 0.f, 0.f};
-  {
+  if constexpr (W == 16) {
+    // 16-wide maps: a pixel tile IS an image row, so the 3 x 3 runs "input-row stationary": wave w takes the 32-channel chunks
+    // c = w, w + 8, ...; every hidden row j of the strip is read ONCE per output tile (two ds_read_b128) and multiplied by all nine
+    // taps' weights (resident in registers): tap (dy, dx) of input row j belongs to output row j - dy, and its column shift is a
+    // DPP row shift of the B operand itself (a 16-lane DPP row = the 16 columns of one k group; the lane shifted in from outside
+    // the row is zero = the 'same' padding).  27 MFMAs per two LDS reads and 16 v_mov_dpp instead of 3 per two reads: the
+    // (tap, chunk) form below spent more time fetching B operands and selecting their addresses than in its MFMAs.
+    const gv4 wp3 = (gv4)p.wp3;
+    const int T_all = 9 * KC;
+    const int sh = r0 - hr0;                                // hidden row index of output row 0 (0 | 1)
+    const unsigned char* rowb = HB + (size_t)i * pixb + 16 * g;
+    auto shift_cols = [&](const u32x4& b, u32x4& l, u32x4& r) {
+      // l: lane col holds column col - 1 (tap dx = -1), r: column col + 1.  Inline asm: on this toolchain
+      // __builtin_amdgcn_update_dpp over the elements of a vector is folded to its FIRST element for all four.
+      asm volatile(
+          "s_nop 1\n\t"
+          "v_mov_b32_dpp %0, %8 row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+          "v_mov_b32_dpp %1, %9 row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+          "v_mov_b32_dpp %2, %10 row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+          "v_mov_b32_dpp %3, %11 row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+          "v_mov_b32_dpp %4, %8 row_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+          "v_mov_b32_dpp %5, %9 row_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+          "v_mov_b32_dpp %6, %10 row_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+          "v_mov_b32_dpp %7, %11 row_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:1"
+          : "=&v"(l[0]), "=&v"(l[1]), "=&v"(l[2]), "=&v"(l[3]), "=&v"(r[0]), "=&v"(r[1]), "=&v"(r[2]), "=&v"(r[3])
+          : "v"(b[0]), "v"(b[1]), "v"(b[2]), "v"(b[3]));
+    };
+#pragma unroll 1
+    for (int c = wave; c < KC; c += WV) {
+#pragma unroll
+      for (int o = 0; o < MAXO; ++o) {
+        u32x4 ah[9], am[9];
+#pragma unroll
+        for (int tp = 0; tp < 9; ++tp) {
+          const gv4 f = wp3 + ((size_t)o * T_all + tp * KC + c) * 128 + lane;
+          ah[tp] = f[0];
+          am[tp] = f[64];
+        }
+        auto load_row = [&](int j, u32x4& bh, u32x4& bm) {             // hidden row j (relative to output row 0)
+          const int hr = j + sh;                                        // its index in HB; outside [0, RH): outside the image
+          const unsigned char* px = rowb + (size_t)((hr < 0 ? 0 : (hr >= RH ? RH - 1 : hr)) * 16) * pixb + 64 * c;
+          bh = *reinterpret_cast<const u32x4*>(px);
+          bm = *reinterpret_cast<const u32x4*>(px + 2 * chp);
+        };
+        u32x4 bh[2], bm[2];
+        load_row(-1, bh[0], bm[0]);
+#pragma unroll
+        for (int j = -1; j <= NPO; ++j) {
+          const int cur = (j + 1) & 1;
+          if (j < NPO) load_row(j + 1, bh[cur ^ 1], bm[cur ^ 1]);
+          const int hr = j + sh;
+          if (hr >= 0 && hr < RH && r0 + j >= 0 && r0 + j < H) {       // (uniform) the row exists
+            u32x4 sbh[3], sbm[3];
+            sbh[1] = bh[cur];
+            sbm[1] = bm[cur];
+            shift_cols(bh[cur], sbh[0], sbh[2]);
+            shift_cols(bm[cur], sbm[0], sbm[2]);
+#pragma unroll
+            for (int dx = 0; dx < 3; ++dx) {
+#pragma unroll
+              for (int dy = -1; dy <= 1; ++dy) {
+                const int orow = j - dy;
+                if (orow < 0 || orow >= NPO) continue;
+                const int tp = (dy + 1) * 3 + dx;
+                f32x4& acc = part[o][orow];
+                acc = img_mfma16(am[tp], sbh[dx], acc);
+                acc = img_mfma16(ah[tp], sbm[dx], acc);
+                acc = img_mfma16(ah[tp], sbh[dx], acc);
+              }
+            }
+          }
+        }
+        __builtin_amdgcn_sched_barrier(0);                              // the next tile's 18 weight fragments must not be hoisted over this one's accumulators
+      }
+    }
+  } else {
     const int T_all = 9 * KC;
     const gv4 wp3 = (gv4)p.wp3;
     const unsigned hb_a = (unsigned)(uintptr_t)(__attribute__((address_space(3))) void*)HB;
