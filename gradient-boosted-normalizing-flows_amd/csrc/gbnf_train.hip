@@ -36,6 +36,7 @@
 #include <cstdint>
 #include <cstdlib>
 #include <cstring>
+#include <type_traits>
 #include <vector>
 
 #include "../../include/gbnf.h"
@@ -979,38 +980,67 @@ struct WgProblem {
   int wm, wn;             // the workgroup's waves: wm x wn sub-blocks of 64 x 64
 };
 constexpr int WG_ROWS_MAX = 320;       // operand rows per k-step: 64 (wm + wn) <= 64 * 5
+#ifndef GBNF_WG_ABL
+#define GBNF_WG_ABL 0
+#endif
 constexpr int WG_THREADS = 256;        // 4 waves (one per SIMD: ~330 registers)
 
 // hi = f16(x) toward zero, mid = f16(x - hi) for 8 consecutive samples of one operand row -> one MFMA operand each.
 // No clamp: toward-zero conversion saturates at the largest finite fp16, so a value beyond the fp16 range degrades to
 // a finite wrong number (<= 131008) instead of an infinity -- the forward path saturates such values anyway.
+// 16 VALU instructions: the residual x - hi is ONE v_fma_mix_f32 per value (the f16 half is widened inside the instruction;
+// exact, like the v_cvt_f32_f16 + v_sub_f32 pair LLVM writes for `x - (float)hi`).  (v_fma_mixlo/hi_f16 would convert and pack
+// the residuals too, 8 instructions -- but round to nearest: an out-of-range value's residual becomes an infinity.)
 __device__ __forceinline__ void wg_split8(f32x4 lo, f32x4 hi4, u32x4& h, u32x4& m) {
 #pragma unroll
-  for (int q = 0; q < 2; ++q) {
-    const auto a = __builtin_amdgcn_cvt_pkrtz(lo[2 * q], lo[2 * q + 1]);
-    const auto b = __builtin_amdgcn_cvt_pkrtz(hi4[2 * q], hi4[2 * q + 1]);
-    h[q] = __builtin_bit_cast(unsigned, a);
-    h[2 + q] = __builtin_bit_cast(unsigned, b);
-    m[q] = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(lo[2 * q] - (float)a[0], lo[2 * q + 1] - (float)a[1]));
-    m[2 + q] = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(hi4[2 * q] - (float)b[0], hi4[2 * q + 1] - (float)b[1]));
+  for (int q = 0; q < 4; ++q) {
+    const f32x4& v = q < 2 ? lo : hi4;
+    const int e = 2 * (q & 1);
+    const unsigned hw = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(v[e], v[e + 1]));
+    h[q] = hw;
+    // IN PLACE (an asm output must never be a fresh register: gbnf_flow_kernel_hx3.hip.h, split_pair_f16)
+    float r0 = v[e], r1 = v[e + 1];
+    asm("v_fma_mix_f32 %0, %1, -1.0, %0 op_sel_hi:[1,0,0]" : "+v"(r0) : "v"(hw));
+    asm("v_fma_mix_f32 %0, %1, -1.0, %0 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(r1) : "v"(hw));
+    m[q] = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(r0, r1));
   }
 }
 
 // The contraction runs on the f16 pipe with split operands (section 4.1: three v_mfma_f32_16x16x32_f16 per product, f32
-// accumulation): one k = 32 step = 32 samples = two 16-sample tiles of the workspace.  LDS holds the k-step's operand rows
-// as 16-byte pieces (4 samples): piece (row, q), q = 0..7, at index row * 8 + (q ^ (row & 7)) -- the XOR spreads the 16
-// rows a quarter-wave reads at once over all banks.  Lane (i, g) of an operand fragment takes pieces 2g, 2g + 1 of its row
-// (samples 8 (g & 1) .. + 7 of tile g >> 1) and splits them in registers.  Global -> register -> LDS, one k-step ahead.
-__global__ void __launch_bounds__(WG_THREADS) wgrad_kernel(const WgProblem* __restrict__ probs, int n_probs,
+// accumulation): one k = 32 step = 32 samples = two 16-sample tiles of the workspace.  Round 4: the operands are split ONCE per
+// workgroup, on their way from HBM into LDS (round 3 kept f32 in LDS and every wave split its own fragments -- each row of a
+// 2 x 2 workgroup twice, of a 4 x 1 one up to four times: 8 splits + 48 MFMAs per wave and k-step, VALU-bound at 2.1 TB/s of
+// operand reads).  A thread carries "double pieces": 8 consecutive samples of one row (k group gq = 0..3 of the step: samples
+// 8 (gq & 1) .. + 7 of tile gq >> 1), two 16-byte global loads one k-step ahead, split into one hi and one mid MFMA operand and
+// written to LDS as 16-byte slots: row r owns 8 slots (128 bytes = one pass over the banks), operand (gq, hi | mid) sits in slot
+// (2 gq + mid) ^ (r & 7) -- the 8 rows that 8 neighbouring lanes read at once hit 8 different slots, and so do the 2 rows x 4
+// groups they write at once (SQ_LDS_BANK_CONFLICT: half of the LDS cycles with the XOR on (r >> 1), a 256-byte model).  The
+// compute loop is 16 ds_read_b128 + 48 MFMAs per wave and k-step; the bias gradients (row sums of D) are summed by the staging
+// threads from the f32 values they hold anyway.
+__global__ void __launch_bounds__(WG_THREADS, 2) wgrad_kernel(const WgProblem* __restrict__ probs, int n_probs,
                                                     const float* __restrict__ ws, float* __restrict__ grads, int64_t np, int chunk,
                                                     const unsigned* __restrict__ gmax, int n_blocks, const LiveReduce red) {
   typedef const f32x4 __attribute__((address_space(1)))* gv4;
+  extern __shared__ __attribute__((aligned(16))) u32x4 wg_stage_raw[];      // 2 x WG_ROWS_MAX * 8 slots = 80 KB (dynamic: > 64 KB)
   // blocks behind the dW blocks (first sample chunk only): the fixed-order sum of the backward kernel's per-workgroup
   // ActNorm / BatchNorm gradient partials, grads[goff[kw] + j] += sum_b partials[b][kw][j]  (kw = step * 2 + which)
-  if ((int)blockIdx.x >= n_blocks) {
-    if (blockIdx.y != 0 || red.partials == nullptr) return;
-    __shared__ float rsum[4][64];
-    const int kw = (int)blockIdx.x - n_blocks, j = threadIdx.x & 63, part = threadIdx.x >> 6;
+  // Workgroups are dealt to the 8 XCDs round-robin in launch order, each XCD with its own L2.  The blocks of one problem and
+  // sample chunk read the same operand rows (a 2 x 2 blocking reads every row twice): work item W = (L mod 8) T / 8 + L / 8 of
+  // launch index L gives every XCD a contiguous range of (chunk, block) pairs, so the readers of a row share an L2 and run at
+  // about the same time (the grid's x extent is a multiple of 8; blocks past the last problem and partial sum return).
+  int bx = blockIdx.x, by = blockIdx.y;
+  {
+    const int G = gridDim.x, T = G * (int)gridDim.y, L = by * G + bx;
+    if ((T & 7) == 0) {
+      const int W = (L & 7) * (T >> 3) + (L >> 3);
+      by = W / G;
+      bx = W - by * G;
+    }
+  }
+  if (bx >= n_blocks) {
+    if (by != 0 || red.partials == nullptr || bx - n_blocks >= 2 * red.K) return;
+    float (*rsum)[64] = reinterpret_cast<float (*)[64]>(wg_stage_raw);       // (no static LDS: two 80 KB workgroups fill a CU's 160 KB)
+    const int kw = bx - n_blocks, j = threadIdx.x & 63, part = threadIdx.x >> 6;
     if ((red.skip_steps >> (kw >> 1)) & 1u) return;           // added already (a BatchNorm step of a batch-statistics sweep)
     const float* src = red.partials + kw * 64 + j;
     const int64_t stride = (int64_t)red.K * 128;
@@ -1028,110 +1058,162 @@ __global__ void __launch_bounds__(WG_THREADS) wgrad_kernel(const WgProblem* __re
     if (part == 0 && j < red.d) grads[red.goff[kw] + j] += (rsum[0][j] + rsum[1][j]) + (rsum[2][j] + rsum[3][j]);
     return;
   }
-  extern __shared__ __attribute__((aligned(16))) f32x4 wg_stage_raw[];      // 2 x WG_ROWS_MAX * 8 pieces = 80 KB (dynamic: > 64 KB)
-  f32x4 (*stage)[WG_ROWS_MAX * 8] = reinterpret_cast<f32x4 (*)[WG_ROWS_MAX * 8]>(wg_stage_raw);
+  u32x4 (*stage)[WG_ROWS_MAX * 8] = reinterpret_cast<u32x4 (*)[WG_ROWS_MAX * 8]>(wg_stage_raw);
   float alpha = 1.0f, inv_alpha = 1.0f;          // the gradient-side operands were emitted on the scaled gradient
   if (gmax != nullptr) tr_grad_scale(__builtin_amdgcn_readfirstlane(*gmax), alpha, inv_alpha);
   const int tid = threadIdx.x, lane = tid & 63, i = lane & 15, g = lane >> 4;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   int pi = 0;
-  while (pi + 1 < n_probs && (int)blockIdx.x >= probs[pi + 1].blk_begin) ++pi;
+  while (pi + 1 < n_probs && bx >= probs[pi + 1].blk_begin) ++pi;
   const WgProblem P = probs[pi];
-  const int blk = blockIdx.x - P.blk_begin;
+  const int blk = bx - P.blk_begin;
   const int bm = 64 * P.wm, bn = 64 * P.wn;
   const int m0 = (blk / P.nb) * bm, n0 = (blk % P.nb) * bn;
   const int wmi = wave / P.wn, wni = wave - wmi * P.wn;
-  const int64_t s_begin = (int64_t)blockIdx.y * chunk;       // `chunk` samples per block (a multiple of 32)
+  const int64_t s_begin = (int64_t)by * chunk;       // `chunk` samples per block (a multiple of 32)
   const int64_t s_end = (s_begin + chunk < np) ? s_begin + chunk : np;
-  // ---- this thread's pieces of a k-step: piece p = tid + WG_THREADS j of (bm + bn) * 8
-  constexpr int NPC = WG_ROWS_MAX * 8 / WG_THREADS;           // 10
-  const int n_pieces = (bm + bn) * 8;
-  int64_t goff[NPC];          // float offset of the piece at sample 0
-  int gstep[NPC];             // floats per sample when walking 16-sample tiles: the sub-region's row count
-#pragma unroll
-  for (int j = 0; j < NPC; ++j) {
-    const int p = tid + WG_THREADS * j;
-    const int rl = p >> 3, q = (p & 7) ^ (rl & 7);
-    const bool isd = rl < bm;
+  // ---- this thread's double pieces of a k-step: piece j = 0 .. wm + wn - 1 is k group gq = tid & 3 of local row 64 j + tid / 4;
+  //      pieces j < wm are D rows, the others A rows (uniform: the region, its row count and the 64-row block are scalars)
+  constexpr int NPC = WG_ROWS_MAX / 64;                       // 5
+  const int npc = P.wm + P.wn;
+  // (the per-thread offsets are recomputed where they are used, from a copy of tid the compiler cannot see through: kept in
+  // registers across the loop they are the values that get spilled at two waves per SIMD -- and a scratch reload inside the loop
+  // is a vmcnt(0) wait, i.e. the end of the prefetch)
+  auto opaque_tid = [&]() { int t = tid; asm volatile("" : "+v"(t)); return t; };
+  auto piece_src = [&](int t, int j, int64_t s) -> gv4 {
+    const int q = t & 3, r = t >> 2;
+    const bool isd = j < P.wm;
     const int R = isd ? P.d_rows : P.a_rows;
-    const int64_t row = isd ? (int64_t)(m0 + rl) : (int64_t)(n0 + rl - bm);
-    goff[j] = (isd ? P.d_row : P.a_row) * np + ((int64_t)(q >> 2) * R + row) * 16 + (q & 3) * 4;
-    gstep[j] = R;
-  }
-  // the pieces of the NEXT k-step travel global -> registers while this one is computed, registers -> LDS behind it
-  // (measured: a second register set, two k-steps ahead, costs the second workgroup per CU and is slower; so is an 8-wave
-  // 256 x 128 block: 442 us against 411 us for this form at N = 65536 -- the kernel runs at the HBM rate of its operand reads)
-  f32x4 pre[NPC];
-  auto fetch = [&](int64_t s) {
-#pragma unroll
-    for (int j = 0; j < NPC; ++j)
-      if (tid + WG_THREADS * j < n_pieces) pre[j] = *(gv4)(ws + goff[j] + s * gstep[j]);
+    const int64_t base = (isd ? P.d_row : P.a_row) * np + (int64_t)(isd ? m0 + 64 * j : n0 + 64 * (j - P.wm)) * 16 + s * R;      // (scalar)
+    return (gv4)(ws + base + (unsigned)(((q >> 1) * R + r) * 16 + (q & 1) * 8));
   };
-  auto stash = [&](int b) {
+  auto slot_of = [&](int t) { const int q = t & 3, r = t >> 2; return r * 8 + ((2 * q) ^ (r & 7)); };   // piece 0's hi operand (piece j: + 512 j; mid: ^ 1)
+  // the pieces of the next TWO k-steps travel global -> registers while this one is computed (two register sets, used in turn),
+  // registers -> split -> LDS behind it.  Measured at N = 65536 with one set (a load had one compute phase to land): 365 us, of
+  // which the MFMAs hid completely (351 us without them) -- the loop ran at the latency of its loads (~2 us under load).
+  f32x4 pre0[NPC][2], pre1[NPC][2];
+  float bs[NPC - 1];          // row sums of this thread's D pieces (the bias gradient); wm <= 4
 #pragma unroll
-    for (int j = 0; j < NPC; ++j)
-      if (tid + WG_THREADS * j < n_pieces) stage[b][tid + WG_THREADS * j] = pre[j];
+  for (int j = 0; j < NPC - 1; ++j) bs[j] = 0.0f;
+  auto fetch = [&](auto np_c, f32x4 (&pre)[NPC][2], int64_t s) {
+    const int t = opaque_tid();
+#pragma unroll
+    for (int j = 0; j < decltype(np_c)::value; ++j) {
+      const gv4 src = piece_src(t, j, s);
+      pre[j][0] = src[0];
+      pre[j][1] = src[1];
+    }
+  };
+  auto stash = [&](auto np_c, const f32x4 (&pre)[NPC][2], int b, bool count) {
+    const int slot0 = slot_of(opaque_tid());
+#pragma unroll
+    for (int j = 0; j < decltype(np_c)::value; ++j) {
+#if GBNF_WG_ABL == 5                                  // (diagnostic: the loads alone -- no split, no LDS traffic, no MFMA)
+      bs[0] += pre[j][0][0] + pre[j][1][3];
+      continue;
+#endif
+      u32x4 h, m;
+      wg_split8(pre[j][0], pre[j][1], h, m);
+      stage[b][slot0 + 512 * j] = h;
+      stage[b][(slot0 ^ 1) + 512 * j] = m;
+      if (j < NPC - 1 && count && j < P.wm) {               // (uniform: D pieces of the blocks that own the bias, real k-steps)
+        const f32x4 t = pre[j][0] + pre[j][1];
+        bs[j] += (t[0] + t[1]) + (t[2] + t[3]);
+      }
+    }
   };
   f32x4 acc[4][4];
-  f32x4 bsum[4];
   const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-  for (int a = 0; a < 4; ++a) {
-    bsum[a] = zero;
+  for (int a = 0; a < 4; ++a)
 #pragma unroll
     for (int b = 0; b < 4; ++b) acc[a][b] = zero;
-  }
-  // LDS piece indices of this lane's fragments: D tile x -> local row 64 wmi + 16 x + i; A tile y -> bm + 64 wni + 16 y + i
-  int dix[4], aix[4];
-#pragma unroll
-  for (int x = 0; x < 4; ++x) {
-    const int rd = 64 * wmi + 16 * x + i, ra = bm + 64 * wni + 16 * x + i;
-    dix[x] = rd * 8;
-    aix[x] = ra * 8;
-  }
   const bool active = wave < P.wm * P.wn;       // (narrow problems leave waves without a sub-block: they only help staging)
   auto compute = [&](int b) {
     if (!active) return;
-    u32x4 dh[4], dm[4], ah[4], am[4];
+    // LDS slots of this lane's fragments: D tile x -> local row 64 wmi + 16 x + i; A tile y -> bm + 64 wni + 16 y + i
+    // (the XOR term of row 64 w + 16 x + i is i & 7 for every x: tile x sits 128 slots behind tile 0)
+    const int tl = opaque_tid(), li = tl & 15, lg = (tl >> 4) & 3;
+    const int dix0 = (64 * wmi + li) * 8 + ((2 * lg) ^ (li & 7));
+    const int aix0 = (bm + 64 * wni + li) * 8 + ((2 * lg) ^ (li & 7));
+    // (two A tiles at a time, the D fragments one tile row at a time and read twice: 24 operand registers live instead of 64, 24
+    // ds_read_b128 per k-step instead of 16 -- the two prefetch sets need the room at two waves per SIMD)
 #pragma unroll
-    for (int x = 0; x < 4; ++x) {
-      const int rd = dix[x] >> 3, ra = aix[x] >> 3;
-      const f32x4 d0 = stage[b][dix[x] + ((2 * g) ^ (rd & 7))], d1 = stage[b][dix[x] + ((2 * g + 1) ^ (rd & 7))];
-      const f32x4 a0 = stage[b][aix[x] + ((2 * g) ^ (ra & 7))], a1 = stage[b][aix[x] + ((2 * g + 1) ^ (ra & 7))];
-      wg_split8(d0, d1, dh[x], dm[x]);
-      wg_split8(a0, a1, ah[x], am[x]);
-      bsum[x] += d0 + d1;
+    for (int yh = 0; yh < 2; ++yh) {
+      u32x4 ah[2], am[2];
+#pragma unroll
+      for (int y = 0; y < 2; ++y) {
+        ah[y] = stage[b][aix0 + 128 * (2 * yh + y)];
+        am[y] = stage[b][(aix0 ^ 1) + 128 * (2 * yh + y)];
+      }
+#pragma unroll
+      for (int x = 0; x < 4; ++x) {
+        const u32x4 dh = stage[b][dix0 + 128 * x], dm = stage[b][(dix0 ^ 1) + 128 * x];
+#pragma unroll
+        for (int y = 0; y < 2; ++y) acc[x][2 * yh + y] = tr_mfma16(dm, ah[y], acc[x][2 * yh + y]);
+#pragma unroll
+        for (int y = 0; y < 2; ++y) acc[x][2 * yh + y] = tr_mfma16(dh, am[y], acc[x][2 * yh + y]);
+#pragma unroll
+        for (int y = 0; y < 2; ++y) acc[x][2 * yh + y] = tr_mfma16(dh, ah[y], acc[x][2 * yh + y]);
+      }
     }
-#pragma unroll
-    for (int x = 0; x < 4; ++x)
-#pragma unroll
-      for (int y = 0; y < 4; ++y) acc[x][y] = tr_mfma16(dm[x], ah[y], acc[x][y]);
-#pragma unroll
-    for (int x = 0; x < 4; ++x)
-#pragma unroll
-      for (int y = 0; y < 4; ++y) acc[x][y] = tr_mfma16(dh[x], am[y], acc[x][y]);
-#pragma unroll
-    for (int x = 0; x < 4; ++x)
-#pragma unroll
-      for (int y = 0; y < 4; ++y) acc[x][y] = tr_mfma16(dh[x], ah[y], acc[x][y]);
   };
-  fetch(s_begin);
-  stash(0);
-  if (s_begin + 32 < s_end) fetch(s_begin + 32);
-  __syncthreads();
-  int b = 0;
-  for (int64_t s = s_begin; s < s_end; s += 32, b ^= 1) {
-    compute(b);
-    if (s + 32 < s_end) stash(b ^ 1);         // the pieces of k-step s + 32 (fetched one iteration ago)
-    if (s + 64 < s_end) fetch(s + 64);
+  // (one loop per piece count wm + wn = 2 .. 5: no branches around the loads and the splits)
+  // Every path through the loop issues the same loads in the same order (past the end of the chunk: its last k-step again, staged
+  // into a buffer nobody computes on): the compiler's s_waitcnt vmcnt(N) in front of a split then names exactly the loads of the
+  // OTHER register set -- with a conditional fetch anywhere it has to assume the worst and waits for everything in flight.
+  auto run = [&](auto np_c) {
+    const int64_t s_last = s_end - 32;
+    auto at = [&](int64_t s) { return s < s_end ? s : s_last; };
+    fetch(np_c, pre0, s_begin);
+    fetch(np_c, pre1, at(s_begin + 32));
+    stash(np_c, pre0, 0, n0 == 0);
+    fetch(np_c, pre0, at(s_begin + 64));
     __syncthreads();
+    // at the top: LDS buffer 0 holds k-step s; pre1 = k-step s + 32 and pre0 = k-step s + 64 are in flight
+    int64_t s = s_begin;
+    for (; s + 32 < s_end; s += 64) {
+#if GBNF_WG_ABL != 2 && GBNF_WG_ABL != 5            // (diagnostic builds: 1 = no atomics, 2 = no MFMA loop, 5 = loads only)
+      compute(0);
+#endif
+      stash(np_c, pre1, 1, n0 == 0);
+      fetch(np_c, pre1, at(s + 96));
+      __syncthreads();
+#if GBNF_WG_ABL != 2 && GBNF_WG_ABL != 5
+      compute(1);
+#endif
+      stash(np_c, pre0, 0, n0 == 0 && s + 64 < s_end);
+      fetch(np_c, pre0, at(s + 128));
+      __syncthreads();
+    }
+    if (s < s_end) compute(0);                          // an odd number of k-steps: the last one is in buffer 0
+  };
+  switch (npc) {
+    case 2: run(std::integral_constant<int, 2>{}); break;
+    case 3: run(std::integral_constant<int, 3>{}); break;
+    case 4: run(std::integral_constant<int, 4>{}); break;
+    default: run(std::integral_constant<int, 5>{}); break;
   }
 #pragma unroll
   for (int x = 0; x < 4; ++x) {
     tr_mfma_drain(acc[x][0], acc[x][1]);
     tr_mfma_drain(acc[x][2], acc[x][3]);
   }
+  if (n0 == 0) {     // db[m] = sum over samples of D[m][.]: the 4 threads of a row (k groups 0..3) are neighbours
+#pragma unroll
+    for (int j = 0; j < NPC - 1; ++j)
+      if (j < P.wm) {
+        float v = bs[j];
+        v += __shfl_xor(v, 1);
+        v += __shfl_xor(v, 2);
+        const int m = m0 + 64 * j + (tid >> 2);
+        if ((tid & 3) == 0 && m < P.M) atomicAdd(grads + P.b_off + m, v * inv_alpha);
+      }
+  }
   if (!active) return;
+#if GBNF_WG_ABL == 1
+  if (np > 0) return;
+#endif
   float* C = grads + P.c_off;
   const int mw = m0 + 64 * wmi, nw = n0 + 64 * wni;
 #pragma unroll
@@ -1145,16 +1227,6 @@ __global__ void __launch_bounds__(WG_THREADS) wgrad_kernel(const WgProblem* __re
         if (m < P.M && n < P.N) atomicAdd(C + (size_t)m * P.N + n, acc[x][y][r] * inv_alpha);
       }
     }
-  if (nw == 0) {     // db[m] = sum over samples of D[m][.]: lane (i,g) holds row mw+16x+i, fold r, then the 4 lane groups
-#pragma unroll
-    for (int x = 0; x < 4; ++x) {
-      float v = bsum[x][0] + bsum[x][1] + bsum[x][2] + bsum[x][3];
-      v += __shfl_xor(v, 16);
-      v += __shfl_xor(v, 32);
-      const int m = mw + 16 * x + i;
-      if (g == 0 && m < P.M) atomicAdd(grads + P.b_off + m, v * inv_alpha);
-    }
-  }
 }
 
 // ---- batch-statistics BatchNorm (models/layers.py:338-358 in train mode): the pieces that need the whole batch ----------
@@ -1812,7 +1884,7 @@ int gbnf_trainer_backward(const gbnf_trainer* t, const float* x, int64_t n, cons
         if (t->has_norm[k0]) {
           LiveReduce one = red;
           one.skip_steps = ~(1u << k0);
-          hipLaunchKernelGGL(wgrad_kernel, dim3((unsigned)(2 * red.K), 1u), dim3(WG_THREADS), 0, s, t->probs_dev, t->n_probs, (const float*)acts, grads,
+          hipLaunchKernelGGL(wgrad_kernel, dim3((unsigned)(2 * red.K), 1u), dim3(WG_THREADS), 1024, s, t->probs_dev, t->n_probs, (const float*)acts, grads,
                              p.np, 512, (const unsigned*)t->gmax_dev, 0, one);
           done |= 1u << k0;
           const dim3 fg((unsigned)((n + 255) / 256), (unsigned)t->d);
@@ -1825,15 +1897,15 @@ int gbnf_trainer_backward(const gbnf_trainer* t, const float* x, int64_t n, cons
                            (const unsigned*)t->gmax_dev);
       red.skip_steps = done;
     }
-    // samples per block: the largest power of two that still leaves ~a block per CU (>= 240 blocks) -- measured at N = 65536
-    // with 1024 / 2048 / 4096 / 8192 / 16384 samples per block: 58.5 / 60.8 / 62.1 / 63.1 / 47.8 M samples/s, and 512 is the
-    // best at N = 4096; every further chunk adds a 128 x 128 tile of float atomics per block of dW, every chunk less leaves
-    // CUs idle.  (Not a power of two: 5984 samples per block ran at 55.4 M.)
+    // samples per block: the largest power of two that still leaves two blocks per CU (>= 480 blocks; two 80 KB workgroups fit a
+    // CU since round 4) -- measured at N = 65536 with 1024 / 2048 / 4096 / 8192 samples per block: 63.8 / 64.0 / 64.6 / 56.8 M
+    // samples/s, and 512 is the best at N = 4096; every further chunk adds a 128 x 128 tile of float atomics per block of dW,
+    // every chunk less leaves CUs idle.  (Not a power of two: 4000 / 4128 / 4384 samples per block ran within 1 % of 4096.)
     int chunk2 = 512;
-    while ((int64_t)t->wg_blocks * (p.np / (2 * chunk2)) >= 240) chunk2 *= 2;
+    while ((int64_t)t->wg_blocks * (p.np / (2 * chunk2)) >= 480) chunk2 *= 2;
     if (const char* e = getenv("GBNF_WG_CHUNK")) { if (atoi(e) > 0) chunk2 = atoi(e); }      // (A/B runs)
     // (+ 2 K blocks: the sums of the backward kernel's parameter-gradient partials ride in this launch)
-    const dim3 wgrid2((unsigned)(t->wg_blocks + 2 * red.K), (unsigned)((p.np + chunk2 - 1) / chunk2));
+    const dim3 wgrid2((unsigned)((t->wg_blocks + 2 * red.K + 7) / 8 * 8), (unsigned)((p.np + chunk2 - 1) / chunk2));     // (x: a multiple of 8, see the kernel)
     hipLaunchKernelGGL(wgrad_kernel, wgrid2, dim3(WG_THREADS), (size_t)2 * WG_ROWS_MAX * 8 * 16, s, t->probs_dev, t->n_probs,
                        (const float*)acts, grads, p.np, chunk2, (const unsigned*)t->gmax_dev, t->wg_blocks, red);
     const hipError_t e2 = hipGetLastError();
@@ -1874,7 +1946,7 @@ int gbnf_trainer_backward(const gbnf_trainer* t, const float* x, int64_t n, cons
   int chunk = 512;
   while (chunk < 4096 && (int64_t)t->wg_blocks * (p.np / (2 * chunk)) >= 768) chunk *= 2;     // (a block = 4 waves)
   if (forced_chunk >= 32 && forced_chunk % 32 == 0) chunk = forced_chunk;
-  const dim3 wgrid((unsigned)t->wg_blocks, (unsigned)((p.np + chunk - 1) / chunk));
+  const dim3 wgrid((unsigned)((t->wg_blocks + 7) / 8 * 8), (unsigned)((p.np + chunk - 1) / chunk));
   hipLaunchKernelGGL(wgrad_kernel, wgrid, dim3(WG_THREADS), (size_t)2 * WG_ROWS_MAX * 8 * 16, s, t->probs_dev, t->n_probs, (const float*)workspace, grads, p.np, chunk,
                      (const unsigned*)t->gmax_dev, t->wg_blocks, LiveReduce{});
   e = hipGetLastError();
