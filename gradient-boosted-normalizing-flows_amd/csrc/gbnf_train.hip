@@ -31,6 +31,7 @@
 //   compute_kl_pq_loss (density_experiment.py:606-660).
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cmath>
 #include <cstddef>
 #include <cstdint>
@@ -966,24 +967,29 @@ __global__ void __launch_bounds__(64 * TR_WAVES) train_kernel(const TrainLaunch 
 
 // ---------------------------------------------------------------------------------------------------------------
 // Weight / bias gradients: C (M x N, row-major) += D (M rows of np samples) . A (N rows of np samples)^T, bias += row sums of D.
-// Round 3: a workgroup of 4 waves owns a block of 64 WM x 64 WN of C (WM x WN = 2 x 2; 4 x 1 for N <= 64, 1 x 4 for M <= 64;
-// every wave a 64 x 64 sub-block = 16 accumulator tiles) over one chunk of samples, and the operand rows of a k-step are
-// staged ONCE per workgroup in LDS (round 1: every wave read its own 64 + 64 rows from HBM / L2 -- each 64-row slab of a
-// 215 x 215 layer four times over; the kernel ran at the HBM rate).  Branch-free: operand rows past the padded matrix belong
-// to the next workspace region (or the slack rows behind the last one) and only feed output rows / columns that are never stored.
+// Round 4: a workgroup of 8 waves owns a block of bm x bn of C (bm, bn = 64 | 128 | 256: a 224 x 224 layer is ONE block) over one
+// chunk of samples, and the operand rows of a k-step are staged once per workgroup in LDS, split into (hi, mid) fp16 operands on
+// the way.  Why one block: the kernel runs at the rate of its operand loads (the loads alone, nothing else in the loop: 330 of
+// 365 us at N = 65536 with round 3's 128 x 128 blocks, which read every row of the 224 x 224 layer twice -- from memory: the two
+// readers of a row do not meet in an L2, 60 streaming workgroups per XCD turn over its 4 MB in two k-steps).  Rounds 1-3: every
+// wave read its own 64 + 64 rows (each slab four times over), then 4-wave workgroups of 128 x 128 with f32 rows in LDS and every
+// wave splitting its own fragments.  Branch-free: operand rows past the padded matrix belong to the next workspace region (or
+// the slack rows behind the last one) and only feed output rows / columns that are never stored.
 // ---------------------------------------------------------------------------------------------------------------
 struct WgProblem {
   int64_t d_row, a_row;   // first row (of np floats) of the two operands' sub-regions in the workspace
   int64_t c_off, b_off;   // float offsets of dW / db in the flat gradient buffer
   int M, N, blk_begin, nb;
   int d_rows, a_rows;     // rows of the two sub-regions (tiled as [tile][row][16 samples])
-  int wm, wn;             // the workgroup's waves: wm x wn sub-blocks of 64 x 64
+  int bm, bn;             // the block: 64 | 128 | 256 rows of D, of A
+  int wm, wn;             // the workgroup's 8 waves: wm x wn, every wave (bm / wm) x (bn / wn) of the block
 };
-constexpr int WG_ROWS_MAX = 320;       // operand rows per k-step: 64 (wm + wn) <= 64 * 5
+constexpr int WG_ROWS_MAX = 512;       // operand rows per k-step: bm + bn
 #ifndef GBNF_WG_ABL
 #define GBNF_WG_ABL 0
 #endif
-constexpr int WG_THREADS = 256;        // 4 waves (one per SIMD: ~330 registers)
+constexpr int WG_THREADS = 512;        // 8 waves, two per SIMD: 256 registers each
+constexpr size_t WG_LDS_BYTES = (size_t)2 * WG_ROWS_MAX * 8 * 16;     // two k-steps of (hi, mid) rows: 128 KB
 
 // hi = f16(x) toward zero, mid = f16(x - hi) for 8 consecutive samples of one operand row -> one MFMA operand each.
 // No clamp: toward-zero conversion saturates at the largest finite fp16, so a value beyond the fp16 range degrades to
@@ -1007,168 +1013,142 @@ __device__ __forceinline__ void wg_split8(f32x4 lo, f32x4 hi4, u32x4& h, u32x4& 
 }
 
 // The contraction runs on the f16 pipe with split operands (section 4.1: three v_mfma_f32_16x16x32_f16 per product, f32
-// accumulation): one k = 32 step = 32 samples = two 16-sample tiles of the workspace.  Round 4: the operands are split ONCE per
-// workgroup, on their way from HBM into LDS (round 3 kept f32 in LDS and every wave split its own fragments -- each row of a
-// 2 x 2 workgroup twice, of a 4 x 1 one up to four times: 8 splits + 48 MFMAs per wave and k-step, VALU-bound at 2.1 TB/s of
-// operand reads).  A thread carries "double pieces": 8 consecutive samples of one row (k group gq = 0..3 of the step: samples
-// 8 (gq & 1) .. + 7 of tile gq >> 1), two 16-byte global loads one k-step ahead, split into one hi and one mid MFMA operand and
-// written to LDS as 16-byte slots: row r owns 8 slots (128 bytes = one pass over the banks), operand (gq, hi | mid) sits in slot
-// (2 gq + mid) ^ (r & 7) -- the 8 rows that 8 neighbouring lanes read at once hit 8 different slots, and so do the 2 rows x 4
-// groups they write at once (SQ_LDS_BANK_CONFLICT: half of the LDS cycles with the XOR on (r >> 1), a 256-byte model).  The
-// compute loop is 16 ds_read_b128 + 48 MFMAs per wave and k-step; the bias gradients (row sums of D) are summed by the staging
-// threads from the f32 values they hold anyway.
-__global__ void __launch_bounds__(WG_THREADS, 2) wgrad_kernel(const WgProblem* __restrict__ probs, int n_probs,
-                                                    const float* __restrict__ ws, float* __restrict__ grads, int64_t np, int chunk,
-                                                    const unsigned* __restrict__ gmax, int n_blocks, const LiveReduce red) {
+// accumulation): one k = 32 step = 32 samples = two 16-sample tiles of the workspace.  A thread carries "double pieces": samples
+// 4 q .. 4 q + 3 of BOTH tiles of one row (q = tid & 3; row tid / 4 of a 128-row slab) -- two 16-byte global loads, each of
+// which a wave issues over 1 KB of contiguous memory (16 rows x 64 bytes of one tile).  The 8 values are k group q of the step:
+// the contraction does not care in which order the 32 samples of a k-step are numbered as long as D and A number them alike,
+// and both go through this staging.  They are split into one hi and one mid MFMA operand and written to LDS as 16-byte slots:
+// row r owns 8 slots (128 bytes = one pass over the banks), operand (q, hi | mid) sits in slot (2 q + mid) ^ (r & 7) -- the 8 rows
+// that 8 neighbouring lanes read at once hit 8 different slots, and so do the 2 rows x 4 groups they write at once.  A 64-row
+// operand has half a piece per thread: the upper 4 waves carry the lower waves' pieces again (same loads, same LDS slots, same
+// values) so that every wave issues the same loads -- the compiler's s_waitcnt vmcnt(N) in front of a split then names exactly
+// the loads of the OTHER register set; with a conditional fetch anywhere it has to assume the worst and waits for everything
+// in flight.  The bias gradients (row sums of D) are summed by the staging threads from the f32 values they hold anyway.
+template <int ND, int NA, int TM, int TN, bool TWO>
+__device__ __forceinline__ void wgrad_block(const WgProblem& P, const float* __restrict__ ws, float* __restrict__ grads, int64_t np,
+                                            int64_t s_begin, int64_t s_end, int m0, int n0, float inv_alpha, u32x4* wg_stage_raw) {
   typedef const f32x4 __attribute__((address_space(1)))* gv4;
-  extern __shared__ __attribute__((aligned(16))) u32x4 wg_stage_raw[];      // 2 x WG_ROWS_MAX * 8 slots = 80 KB (dynamic: > 64 KB)
-  // blocks behind the dW blocks (first sample chunk only): the fixed-order sum of the backward kernel's per-workgroup
-  // ActNorm / BatchNorm gradient partials, grads[goff[kw] + j] += sum_b partials[b][kw][j]  (kw = step * 2 + which)
-  // Workgroups are dealt to the 8 XCDs round-robin in launch order, each XCD with its own L2.  The blocks of one problem and
-  // sample chunk read the same operand rows (a 2 x 2 blocking reads every row twice): work item W = (L mod 8) T / 8 + L / 8 of
-  // launch index L gives every XCD a contiguous range of (chunk, block) pairs, so the readers of a row share an L2 and run at
-  // about the same time (the grid's x extent is a multiple of 8; blocks past the last problem and partial sum return).
-  int bx = blockIdx.x, by = blockIdx.y;
-  {
-    const int G = gridDim.x, T = G * (int)gridDim.y, L = by * G + bx;
-    if ((T & 7) == 0) {
-      const int W = (L & 7) * (T >> 3) + (L >> 3);
-      by = W / G;
-      bx = W - by * G;
-    }
-  }
-  if (bx >= n_blocks) {
-    if (by != 0 || red.partials == nullptr || bx - n_blocks >= 2 * red.K) return;
-    float (*rsum)[64] = reinterpret_cast<float (*)[64]>(wg_stage_raw);       // (no static LDS: two 80 KB workgroups fill a CU's 160 KB)
-    const int kw = bx - n_blocks, j = threadIdx.x & 63, part = threadIdx.x >> 6;
-    if ((red.skip_steps >> (kw >> 1)) & 1u) return;           // added already (a BatchNorm step of a batch-statistics sweep)
-    const float* src = red.partials + kw * 64 + j;
-    const int64_t stride = (int64_t)red.K * 128;
-    float a0 = 0.0f, a1 = 0.0f, a2 = 0.0f, a3 = 0.0f;
-    int b = part;
-    for (; b + 12 < red.n_wg; b += 16) {
-      a0 += src[(int64_t)b * stride];
-      a1 += src[(int64_t)(b + 4) * stride];
-      a2 += src[(int64_t)(b + 8) * stride];
-      a3 += src[(int64_t)(b + 12) * stride];
-    }
-    for (; b < red.n_wg; b += 4) a0 += src[(int64_t)b * stride];
-    rsum[part][j] = (a0 + a1) + (a2 + a3);
-    __syncthreads();
-    if (part == 0 && j < red.d) grads[red.goff[kw] + j] += (rsum[0][j] + rsum[1][j]) + (rsum[2][j] + rsum[3][j]);
-    return;
-  }
+  constexpr int NPC = ND + NA;
   u32x4 (*stage)[WG_ROWS_MAX * 8] = reinterpret_cast<u32x4 (*)[WG_ROWS_MAX * 8]>(wg_stage_raw);
-  float alpha = 1.0f, inv_alpha = 1.0f;          // the gradient-side operands were emitted on the scaled gradient
-  if (gmax != nullptr) tr_grad_scale(__builtin_amdgcn_readfirstlane(*gmax), alpha, inv_alpha);
-  const int tid = threadIdx.x, lane = tid & 63, i = lane & 15, g = lane >> 4;
+  const int tid = threadIdx.x;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  int pi = 0;
-  while (pi + 1 < n_probs && bx >= probs[pi + 1].blk_begin) ++pi;
-  const WgProblem P = probs[pi];
-  const int blk = bx - P.blk_begin;
-  const int bm = 64 * P.wm, bn = 64 * P.wn;
-  const int m0 = (blk / P.nb) * bm, n0 = (blk % P.nb) * bn;
   const int wmi = wave / P.wn, wni = wave - wmi * P.wn;
-  const int64_t s_begin = (int64_t)by * chunk;       // `chunk` samples per block (a multiple of 32)
-  const int64_t s_end = (s_begin + chunk < np) ? s_begin + chunk : np;
-  // ---- this thread's double pieces of a k-step: piece j = 0 .. wm + wn - 1 is k group gq = tid & 3 of local row 64 j + tid / 4;
-  //      pieces j < wm are D rows, the others A rows (uniform: the region, its row count and the 64-row block are scalars)
-  constexpr int NPC = WG_ROWS_MAX / 64;                       // 5
-  const int npc = P.wm + P.wn;
   // (the per-thread offsets are recomputed where they are used, from a copy of tid the compiler cannot see through: kept in
-  // registers across the loop they are the values that get spilled at two waves per SIMD -- and a scratch reload inside the loop
-  // is a vmcnt(0) wait, i.e. the end of the prefetch)
-  auto opaque_tid = [&]() { int t = tid; asm volatile("" : "+v"(t)); return t; };
-  auto piece_src = [&](int t, int j, int64_t s) -> gv4 {
-    const int q = t & 3, r = t >> 2;
-    const bool isd = j < P.wm;
-    const int R = isd ? P.d_rows : P.a_rows;
-    const int64_t base = (isd ? P.d_row : P.a_row) * np + (int64_t)(isd ? m0 + 64 * j : n0 + 64 * (j - P.wm)) * 16 + s * R;      // (scalar)
-    return (gv4)(ws + base + (unsigned)(((q >> 1) * R + r) * 16 + (q & 1) * 8));
+  // registers across the loop they are the values that get spilled -- and a scratch reload inside the loop is a vmcnt(0) wait,
+  // i.e. the end of the prefetch)
+  // (and tid itself comes from the wave number, a scalar, and the lane count: not a register that lives across the loop either)
+  auto opaque_tid = [&]() {
+    int t = (wave << 6) + (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+    asm volatile("" : "+v"(t));
+    return t;
   };
-  auto slot_of = [&](int t) { const int q = t & 3, r = t >> 2; return r * 8 + ((2 * q) ^ (r & 7)); };   // piece 0's hi operand (piece j: + 512 j; mid: ^ 1)
-  // the pieces of the next TWO k-steps travel global -> registers while this one is computed (two register sets, used in turn),
-  // registers -> split -> LDS behind it.  Measured at N = 65536 with one set (a load had one compute phase to land): 365 us, of
-  // which the MFMAs hid completely (351 us without them) -- the loop ran at the latency of its loads (~2 us under load).
-  f32x4 pre0[NPC][2], pre1[NPC][2];
-  float bs[NPC - 1];          // row sums of this thread's D pieces (the bias gradient); wm <= 4
+  // piece j < ND: D rows 128 j + t / 4 (a 64-row operand: (t / 4) & 63, the upper waves repeat the lower ones'); then the A pieces
+  auto piece_row = [&](int t, int j) {
+    const bool isd = j < ND;
+    const int jj = isd ? j : j - ND;
+    const int rows = isd ? P.bm : P.bn;
+    return 128 * jj + ((t >> 2) & (rows < 128 ? 63 : 127));
+  };
+  auto piece_src = [&](int t, int j, int64_t s) -> gv4 {
+    const int q = t & 3;
+    const bool isd = j < ND;
+    const int R = isd ? P.d_rows : P.a_rows;
+    const int64_t base = (isd ? P.d_row : P.a_row) * np + (int64_t)(isd ? m0 : n0) * 16 + s * R;      // (scalar)
+    return (gv4)(ws + base + (unsigned)(piece_row(t, j) * 16 + q * 4));
+  };
+  auto piece_tile = [&](int j) { return (j < ND ? P.d_rows : P.a_rows) * 4; };     // f32x4 steps from tile 0 to tile 1 of the k-step
+  auto piece_slot = [&](int t, int j) {                   // the hi operand's LDS slot (mid: ^ 1)
+    const int r = (j < ND ? 0 : P.bm) + piece_row(t, j);
+    return r * 8 + ((2 * (t & 3)) ^ (r & 7));
+  };
+  f32x4 pre0[NPC][2], pre1[TWO ? NPC : 1][2];
+  float bs[ND];               // row sums of this thread's D pieces (the bias gradient)
 #pragma unroll
-  for (int j = 0; j < NPC - 1; ++j) bs[j] = 0.0f;
-  auto fetch = [&](auto np_c, f32x4 (&pre)[NPC][2], int64_t s) {
+  for (int j = 0; j < ND; ++j) bs[j] = 0.0f;
+  auto fetch = [&](auto& pre, int64_t s) {
     const int t = opaque_tid();
 #pragma unroll
-    for (int j = 0; j < decltype(np_c)::value; ++j) {
+    for (int j = 0; j < NPC; ++j) {
       const gv4 src = piece_src(t, j, s);
       pre[j][0] = src[0];
-      pre[j][1] = src[1];
+      pre[j][1] = src[piece_tile(j)];
     }
   };
-  auto stash = [&](auto np_c, const f32x4 (&pre)[NPC][2], int b, bool count) {
-    const int slot0 = slot_of(opaque_tid());
+  auto stash = [&](const auto& pre, int b, bool count) {
+    const int t = opaque_tid();
 #pragma unroll
-    for (int j = 0; j < decltype(np_c)::value; ++j) {
+    for (int j = 0; j < NPC; ++j) {
 #if GBNF_WG_ABL == 5                                  // (diagnostic: the loads alone -- no split, no LDS traffic, no MFMA)
       bs[0] += pre[j][0][0] + pre[j][1][3];
       continue;
 #endif
       u32x4 h, m;
       wg_split8(pre[j][0], pre[j][1], h, m);
-      stage[b][slot0 + 512 * j] = h;
-      stage[b][(slot0 ^ 1) + 512 * j] = m;
-      if (j < NPC - 1 && count && j < P.wm) {               // (uniform: D pieces of the blocks that own the bias, real k-steps)
-        const f32x4 t = pre[j][0] + pre[j][1];
-        bs[j] += (t[0] + t[1]) + (t[2] + t[3]);
+      const int sl = piece_slot(t, j);
+      stage[b][sl] = h;
+      stage[b][sl ^ 1] = m;
+      if (j < ND && count) {                               // (uniform: the blocks that own the bias, real k-steps)
+        const f32x4 u = pre[j][0] + pre[j][1];
+        bs[j] += (u[0] + u[1]) + (u[2] + u[3]);
       }
     }
   };
-  f32x4 acc[4][4];
+  f32x4 acc[TM][TN];
   const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-  for (int a = 0; a < 4; ++a)
+  for (int x = 0; x < TM; ++x)
 #pragma unroll
-    for (int b = 0; b < 4; ++b) acc[a][b] = zero;
-  const bool active = wave < P.wm * P.wn;       // (narrow problems leave waves without a sub-block: they only help staging)
+    for (int y = 0; y < TN; ++y) acc[x][y] = zero;
   auto compute = [&](int b) {
-    if (!active) return;
-    // LDS slots of this lane's fragments: D tile x -> local row 64 wmi + 16 x + i; A tile y -> bm + 64 wni + 16 y + i
-    // (the XOR term of row 64 w + 16 x + i is i & 7 for every x: tile x sits 128 slots behind tile 0)
+    // LDS slots of this lane's fragments: D tile x -> local row 16 (TM wmi + x) + i; A tile y -> bm + 16 (TN wni + y) + i
+    // (the XOR term of a row 16 t + i is i & 7: tile t + 1 sits 128 slots behind tile t)
     const int tl = opaque_tid(), li = tl & 15, lg = (tl >> 4) & 3;
-    const int dix0 = (64 * wmi + li) * 8 + ((2 * lg) ^ (li & 7));
-    const int aix0 = (bm + 64 * wni + li) * 8 + ((2 * lg) ^ (li & 7));
-    // (two A tiles at a time, the D fragments one tile row at a time and read twice: 24 operand registers live instead of 64, 24
-    // ds_read_b128 per k-step instead of 16 -- the two prefetch sets need the room at two waves per SIMD)
+    const int dix0 = (16 * TM * wmi + li) * 8 + ((2 * lg) ^ (li & 7));
+    const int aix0 = (P.bm + 16 * TN * wni + li) * 8 + ((2 * lg) ^ (li & 7));
+    // (at most two A tiles at a time, the D fragments one tile row at a time: 24 operand registers live -- the accumulators
+    // and the two prefetch sets need the room at two waves per SIMD)
+    constexpr int YS = TN < 2 ? TN : 2;
 #pragma unroll
-    for (int yh = 0; yh < 2; ++yh) {
-      u32x4 ah[2], am[2];
+    for (int yh = 0; yh < TN / YS; ++yh) {
+      u32x4 ah[YS], am[YS];
 #pragma unroll
-      for (int y = 0; y < 2; ++y) {
-        ah[y] = stage[b][aix0 + 128 * (2 * yh + y)];
-        am[y] = stage[b][(aix0 ^ 1) + 128 * (2 * yh + y)];
+      for (int y = 0; y < YS; ++y) {
+        ah[y] = stage[b][aix0 + 128 * (YS * yh + y)];
+        am[y] = stage[b][(aix0 ^ 1) + 128 * (YS * yh + y)];
       }
+      // (the next tile row's D fragments are read under this one's MFMAs, and no further ahead: left to itself the scheduler
+      // hoists all TM rows' reads to the top -- 64 registers for the 128 x 64 wave tile, which then spills its prefetch set)
+      u32x4 dh[2], dm[2];
+      dh[0] = stage[b][dix0];
+      dm[0] = stage[b][dix0 ^ 1];
 #pragma unroll
-      for (int x = 0; x < 4; ++x) {
-        const u32x4 dh = stage[b][dix0 + 128 * x], dm = stage[b][(dix0 ^ 1) + 128 * x];
+      for (int x = 0; x < TM; ++x) {
+        const int c = x & 1;
+        if (x + 1 < TM) {
+          dh[c ^ 1] = stage[b][dix0 + 128 * (x + 1)];
+          dm[c ^ 1] = stage[b][(dix0 ^ 1) + 128 * (x + 1)];
+        }
 #pragma unroll
-        for (int y = 0; y < 2; ++y) acc[x][2 * yh + y] = tr_mfma16(dm, ah[y], acc[x][2 * yh + y]);
+        for (int y = 0; y < YS; ++y) acc[x][YS * yh + y] = tr_mfma16(dm[c], ah[y], acc[x][YS * yh + y]);
 #pragma unroll
-        for (int y = 0; y < 2; ++y) acc[x][2 * yh + y] = tr_mfma16(dh, am[y], acc[x][2 * yh + y]);
+        for (int y = 0; y < YS; ++y) acc[x][YS * yh + y] = tr_mfma16(dh[c], am[y], acc[x][YS * yh + y]);
 #pragma unroll
-        for (int y = 0; y < 2; ++y) acc[x][2 * yh + y] = tr_mfma16(dh, ah[y], acc[x][2 * yh + y]);
+        for (int y = 0; y < YS; ++y) acc[x][YS * yh + y] = tr_mfma16(dh[c], ah[y], acc[x][YS * yh + y]);
+        __builtin_amdgcn_sched_barrier(0);
       }
     }
   };
-  // (one loop per piece count wm + wn = 2 .. 5: no branches around the loads and the splits)
-  // Every path through the loop issues the same loads in the same order (past the end of the chunk: its last k-step again, staged
-  // into a buffer nobody computes on): the compiler's s_waitcnt vmcnt(N) in front of a split then names exactly the loads of the
-  // OTHER register set -- with a conditional fetch anywhere it has to assume the worst and waits for everything in flight.
-  auto run = [&](auto np_c) {
-    const int64_t s_last = s_end - 32;
-    auto at = [&](int64_t s) { return s < s_end ? s : s_last; };
-    fetch(np_c, pre0, s_begin);
-    fetch(np_c, pre1, at(s_begin + 32));
-    stash(np_c, pre0, 0, n0 == 0);
-    fetch(np_c, pre0, at(s_begin + 64));
+  // Two k-steps of loads in flight (two register sets, used in turn; one set for the 128 x 64 wave tile, whose 128 accumulator
+  // registers leave no room for the second).  Every path through the loop issues the same loads in the same order: past the end
+  // of the chunk its last k-step again, staged into a buffer nobody computes on.
+  const int64_t s_last = s_end - 32;
+  auto at = [&](int64_t s) { return s < s_end ? s : s_last; };
+  const bool own_bias = n0 == 0;
+  if constexpr (TWO) {
+    fetch(pre0, s_begin);
+    fetch(pre1, at(s_begin + 32));
+    stash(pre0, 0, own_bias);
+    fetch(pre0, at(s_begin + 64));
     __syncthreads();
     // at the top: LDS buffer 0 holds k-step s; pre1 = k-step s + 32 and pre0 = k-step s + 64 are in flight
     int64_t s = s_begin;
@@ -1176,57 +1156,144 @@ __global__ void __launch_bounds__(WG_THREADS, 2) wgrad_kernel(const WgProblem* _
 #if GBNF_WG_ABL != 2 && GBNF_WG_ABL != 5            // (diagnostic builds: 1 = no atomics, 2 = no MFMA loop, 5 = loads only)
       compute(0);
 #endif
-      stash(np_c, pre1, 1, n0 == 0);
-      fetch(np_c, pre1, at(s + 96));
+      stash(pre1, 1, own_bias);
+      fetch(pre1, at(s + 96));
       __syncthreads();
 #if GBNF_WG_ABL != 2 && GBNF_WG_ABL != 5
       compute(1);
 #endif
-      stash(np_c, pre0, 0, n0 == 0 && s + 64 < s_end);
-      fetch(np_c, pre0, at(s + 128));
+      stash(pre0, 0, own_bias && s + 64 < s_end);
+      fetch(pre0, at(s + 128));
       __syncthreads();
     }
+#if GBNF_WG_ABL != 2 && GBNF_WG_ABL != 5
     if (s < s_end) compute(0);                          // an odd number of k-steps: the last one is in buffer 0
-  };
-  switch (npc) {
-    case 2: run(std::integral_constant<int, 2>{}); break;
-    case 3: run(std::integral_constant<int, 3>{}); break;
-    case 4: run(std::integral_constant<int, 4>{}); break;
-    default: run(std::integral_constant<int, 5>{}); break;
+#endif
+  } else {
+    fetch(pre0, s_begin);
+    stash(pre0, 0, own_bias);
+    fetch(pre0, at(s_begin + 32));
+    __syncthreads();
+    int b = 0;
+    for (int64_t s = s_begin; s < s_end; s += 32, b ^= 1) {
+#if GBNF_WG_ABL != 2 && GBNF_WG_ABL != 5
+      compute(b);
+#endif
+      stash(pre0, b ^ 1, own_bias && s + 32 < s_end);
+      fetch(pre0, at(s + 64));
+      __syncthreads();
+    }
   }
 #pragma unroll
-  for (int x = 0; x < 4; ++x) {
-    tr_mfma_drain(acc[x][0], acc[x][1]);
-    tr_mfma_drain(acc[x][2], acc[x][3]);
+  for (int x = 0; x < TM; ++x) {
+    if constexpr (TN >= 2) {
+#pragma unroll
+      for (int y = 0; y < TN; y += 2) tr_mfma_drain(acc[x][y], acc[x][y + 1]);
+    } else {
+      tr_mfma_drain(acc[x][0], acc[x][0]);
+    }
   }
   if (n0 == 0) {     // db[m] = sum over samples of D[m][.]: the 4 threads of a row (k groups 0..3) are neighbours
 #pragma unroll
-    for (int j = 0; j < NPC - 1; ++j)
-      if (j < P.wm) {
-        float v = bs[j];
-        v += __shfl_xor(v, 1);
-        v += __shfl_xor(v, 2);
-        const int m = m0 + 64 * j + (tid >> 2);
-        if ((tid & 3) == 0 && m < P.M) atomicAdd(grads + P.b_off + m, v * inv_alpha);
-      }
+    for (int j = 0; j < ND; ++j) {
+      float v = bs[j];
+      v += __shfl_xor(v, 1);
+      v += __shfl_xor(v, 2);
+      const int te = opaque_tid();
+      const int rl = 128 * j + (te >> 2);                 // (a 64-row operand: the upper waves hold copies)
+      const int m = m0 + rl;
+      if ((te & 3) == 0 && rl < P.bm && m < P.M) atomicAdd(grads + P.b_off + m, v * inv_alpha);
+    }
   }
-  if (!active) return;
 #if GBNF_WG_ABL == 1
   if (np > 0) return;
 #endif
   float* C = grads + P.c_off;
-  const int mw = m0 + 64 * wmi, nw = n0 + 64 * wni;
+  const int lane = opaque_tid() & 63, i = lane & 15, g = lane >> 4;
+  const int mw = m0 + 16 * TM * wmi, nw = n0 + 16 * TN * wni;
 #pragma unroll
-  for (int x = 0; x < 4; ++x)
+  for (int x = 0; x < TM; ++x)
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const int m = mw + 16 * x + 4 * g + r;
 #pragma unroll
-      for (int y = 0; y < 4; ++y) {
+      for (int y = 0; y < TN; ++y) {
         const int n = nw + 16 * y + i;
         if (m < P.M && n < P.N) atomicAdd(C + (size_t)m * P.N + n, acc[x][y][r] * inv_alpha);
       }
     }
+}
+
+__global__ void __launch_bounds__(WG_THREADS) wgrad_kernel(const WgProblem* __restrict__ probs, int n_probs,
+                                                    const float* __restrict__ ws, float* __restrict__ grads, int64_t np, int chunk,
+                                                    const unsigned* __restrict__ gmax, int n_blocks, const LiveReduce red) {
+  extern __shared__ __attribute__((aligned(16))) u32x4 wg_stage_raw[];      // WG_LDS_BYTES (dynamic: > 64 KB)
+  // Launch index L = y G + x is dealt out in order (round-robin over the XCDs, a workgroup to every CU as it falls free); work
+  // item L is chunk L mod Y of block L / Y, and the host numbers the blocks heaviest first (a 256 x 256 block streams 64 KB per
+  // k-step, a 256 x 64 one 40 KB: a CU pulls ~24 GB/s whatever it does, so the time of a block is its bytes): the light blocks
+  // fill in behind the heavy ones instead of the heavy ones finishing alone.
+  int bx, by;
+  {
+    const int Y = gridDim.y, L = (int)blockIdx.y * (int)gridDim.x + (int)blockIdx.x;
+    bx = L / Y;
+    by = L - bx * Y;
+  }
+  // blocks behind the dW blocks (first sample chunk only): the fixed-order sum of the backward kernel's per-workgroup
+  // ActNorm / BatchNorm gradient partials, grads[goff[kw] + j] += sum_b partials[b][kw][j]  (kw = step * 2 + which)
+  if (bx >= n_blocks) {
+    if (by != 0 || red.partials == nullptr || bx - n_blocks >= 2 * red.K) return;
+    float (*rsum)[64] = reinterpret_cast<float (*)[64]>(wg_stage_raw);       // (no static LDS)
+    const int kw = bx - n_blocks, j = threadIdx.x & 63, part = threadIdx.x >> 6;      // 8 parts
+    if ((red.skip_steps >> (kw >> 1)) & 1u) return;           // added already (a BatchNorm step of a batch-statistics sweep)
+    const float* src = red.partials + kw * 64 + j;
+    const int64_t stride = (int64_t)red.K * 128;
+    float a0 = 0.0f, a1 = 0.0f, a2 = 0.0f, a3 = 0.0f;
+    int b = part;
+    for (; b + 24 < red.n_wg; b += 32) {
+      a0 += src[(int64_t)b * stride];
+      a1 += src[(int64_t)(b + 8) * stride];
+      a2 += src[(int64_t)(b + 16) * stride];
+      a3 += src[(int64_t)(b + 24) * stride];
+    }
+    for (; b < red.n_wg; b += 8) a0 += src[(int64_t)b * stride];
+    rsum[part][j] = (a0 + a1) + (a2 + a3);
+    __syncthreads();
+    if (part == 0 && j < red.d)
+      grads[red.goff[kw] + j] += ((rsum[0][j] + rsum[1][j]) + (rsum[2][j] + rsum[3][j])) + ((rsum[4][j] + rsum[5][j]) + (rsum[6][j] + rsum[7][j]));
+    return;
+  }
+  float alpha = 1.0f, inv_alpha = 1.0f;          // the gradient-side operands were emitted on the scaled gradient
+  if (gmax != nullptr) tr_grad_scale(__builtin_amdgcn_readfirstlane(*gmax), alpha, inv_alpha);
+  int pi = 0;
+  while (pi + 1 < n_probs && bx >= probs[pi + 1].blk_begin) ++pi;
+  const WgProblem P = probs[pi];
+  const int blk = bx - P.blk_begin;
+  const int m0 = (blk / P.nb) * P.bm, n0 = (blk % P.nb) * P.bn;
+  const int64_t s_begin = (int64_t)by * chunk;       // `chunk` samples per block (a multiple of 32)
+  const int64_t s_end = (s_begin + chunk < np) ? s_begin + chunk : np;
+  // pieces per thread (a 64-row operand: one, repeated by the upper waves) and the wave's tile of the block, see wg_shape()
+#define WG_CASE(BM, BN, ND, NA, TM, TN) \
+  if (P.bm == BM && P.bn == BN) return wgrad_block<ND, NA, TM, TN, (TM * TN < 32)>(P, ws, grads, np, s_begin, s_end, m0, n0, inv_alpha, wg_stage_raw)
+  WG_CASE(256, 256, 2, 2, 8, 4);
+  WG_CASE(256, 128, 2, 1, 4, 4);
+  WG_CASE(256, 64, 2, 1, 2, 4);
+  WG_CASE(128, 256, 1, 2, 4, 4);
+  WG_CASE(64, 256, 1, 2, 4, 2);
+  WG_CASE(128, 128, 1, 1, 4, 2);
+  WG_CASE(128, 64, 1, 1, 2, 2);
+  WG_CASE(64, 128, 1, 1, 2, 2);
+  WG_CASE(64, 64, 1, 1, 2, 1);
+#undef WG_CASE
+}
+// the block of a problem and its 8 waves (wm x wn; every wave TM x TN tiles of 16 x 16 with TM = bm / (16 wm), TN = bn / (16 wn))
+static void wg_shape(int M, int N, WgProblem& P) {
+  P.bm = M <= 64 ? 64 : (M <= 128 ? 128 : 256);
+  P.bn = N <= 64 ? 64 : (N <= 128 ? 128 : 256);
+  struct S { int bm, bn, wm, wn; };
+  static const S table[] = {{256, 256, 2, 4}, {256, 128, 4, 2}, {256, 64, 8, 1}, {128, 256, 2, 4}, {64, 256, 1, 8},
+                            {128, 128, 2, 4}, {128, 64, 4, 2},  {64, 128, 2, 4}, {64, 64, 2, 4}};
+  for (const S& e : table)
+    if (e.bm == P.bm && e.bn == P.bn) { P.wm = e.wm; P.wn = e.wn; }
 }
 
 // ---- batch-statistics BatchNorm (models/layers.py:338-358 in train mode): the pieces that need the whole batch ----------
@@ -1581,16 +1648,20 @@ int gbnf_trainer_create(const gbnf_flow_desc* desc, gbnf_trainer** out) {
         P.c_off = L.gW; P.b_off = L.gb;
         P.d_rows = (l == nl - 1) ? t->op : t->hp;
         P.a_rows = (l == 0) ? t->ip : t->hp;
-        // the workgroup's 4 waves as wm x wn sub-blocks of 64 x 64: a narrow side gets one column / row of waves
-        if (P.N <= 64) { P.wm = 4; P.wn = 1; }
-        else if (P.M <= 64) { P.wm = 1; P.wn = 4; }
-        else { P.wm = 2; P.wn = 2; }
-        P.nb = (P.N + 64 * P.wn - 1) / (64 * P.wn);
+        wg_shape(P.M, P.N, P);
+        P.nb = (P.N + P.bn - 1) / P.bn;
         P.blk_begin = blocks;
-        blocks += ((P.M + 64 * P.wm - 1) / (64 * P.wm)) * P.nb;
+        blocks += ((P.M + P.bm - 1) / P.bm) * P.nb;
         probs.push_back(P);
       }
     }
+  }
+  // heaviest blocks first (see wgrad_kernel): the problems in the order of the operand rows a block streams per k-step
+  std::stable_sort(probs.begin(), probs.end(), [](const WgProblem& a, const WgProblem& b) { return a.bm + a.bn > b.bm + b.bn; });
+  blocks = 0;
+  for (WgProblem& P : probs) {
+    P.blk_begin = blocks;
+    blocks += ((P.M + P.bm - 1) / P.bm) * P.nb;
   }
   t->grad_floats = goff;
   t->n_probs = (int)probs.size();
@@ -1619,7 +1690,7 @@ int gbnf_trainer_create(const gbnf_flow_desc* desc, gbnf_trainer** out) {
     for (int k = 0; k < 8 && e == hipSuccess; ++k)
       e = hipFuncSetAttribute(fns[k], hipFuncAttributeMaxDynamicSharedMemorySize, TR_LDS_BYTES);
     if (e == hipSuccess)
-      e = hipFuncSetAttribute((const void*)wgrad_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * WG_ROWS_MAX * 8 * 16);
+      e = hipFuncSetAttribute((const void*)wgrad_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)WG_LDS_BYTES);
   }
   if (e != hipSuccess) {
     gbnf_trainer_destroy(t);
@@ -1884,7 +1955,7 @@ int gbnf_trainer_backward(const gbnf_trainer* t, const float* x, int64_t n, cons
         if (t->has_norm[k0]) {
           LiveReduce one = red;
           one.skip_steps = ~(1u << k0);
-          hipLaunchKernelGGL(wgrad_kernel, dim3((unsigned)(2 * red.K), 1u), dim3(WG_THREADS), 1024, s, t->probs_dev, t->n_probs, (const float*)acts, grads,
+          hipLaunchKernelGGL(wgrad_kernel, dim3((unsigned)(2 * red.K), 1u), dim3(WG_THREADS), 2048, s, t->probs_dev, t->n_probs, (const float*)acts, grads,
                              p.np, 512, (const unsigned*)t->gmax_dev, 0, one);
           done |= 1u << k0;
           const dim3 fg((unsigned)((n + 255) / 256), (unsigned)t->d);
@@ -1897,16 +1968,17 @@ int gbnf_trainer_backward(const gbnf_trainer* t, const float* x, int64_t n, cons
                            (const unsigned*)t->gmax_dev);
       red.skip_steps = done;
     }
-    // samples per block: the largest power of two that still leaves two blocks per CU (>= 480 blocks; two 80 KB workgroups fit a
-    // CU since round 4) -- measured at N = 65536 with 1024 / 2048 / 4096 / 8192 samples per block: 63.8 / 64.0 / 64.6 / 56.8 M
-    // samples/s, and 512 is the best at N = 4096; every further chunk adds a 128 x 128 tile of float atomics per block of dW,
-    // every chunk less leaves CUs idle.  (Not a power of two: 4000 / 4128 / 4384 samples per block ran within 1 % of 4096.)
-    int chunk2 = 512;
-    while ((int64_t)t->wg_blocks * (p.np / (2 * chunk2)) >= 480) chunk2 *= 2;
+    // samples per block: the largest power of two in [128, 2048] that still leaves ~a block per CU (>= 240 blocks; one 128 KB
+    // workgroup of 8 waves per CU).  Measured (MINIBOONE step, 15 blocks per chunk): N = 65536 with 1024 / 2048 / 4096 samples
+    // per block 64.9 / 66.7 / 63.8 M samples/s, N = 16384 with 512 / 1024 / 2048: 46.1 / 49.2 / 41.2 M, N = 4096 with 128 / 256 /
+    // 512: 16.5 / 19.1 / 18.8 M; every further chunk adds a bm x bn tile of float atomics per block of dW, every chunk less leaves
+    // CUs idle.
+    int chunk2 = 128;
+    while (chunk2 < 2048 && (int64_t)t->wg_blocks * (p.np / (2 * chunk2)) >= 240) chunk2 *= 2;
     if (const char* e = getenv("GBNF_WG_CHUNK")) { if (atoi(e) > 0) chunk2 = atoi(e); }      // (A/B runs)
     // (+ 2 K blocks: the sums of the backward kernel's parameter-gradient partials ride in this launch)
-    const dim3 wgrid2((unsigned)((t->wg_blocks + 2 * red.K + 7) / 8 * 8), (unsigned)((p.np + chunk2 - 1) / chunk2));     // (x: a multiple of 8, see the kernel)
-    hipLaunchKernelGGL(wgrad_kernel, wgrid2, dim3(WG_THREADS), (size_t)2 * WG_ROWS_MAX * 8 * 16, s, t->probs_dev, t->n_probs,
+    const dim3 wgrid2((unsigned)(t->wg_blocks + 2 * red.K), (unsigned)((p.np + chunk2 - 1) / chunk2));
+    hipLaunchKernelGGL(wgrad_kernel, wgrid2, dim3(WG_THREADS), WG_LDS_BYTES, s, t->probs_dev, t->n_probs,
                        (const float*)acts, grads, p.np, chunk2, (const unsigned*)t->gmax_dev, t->wg_blocks, red);
     const hipError_t e2 = hipGetLastError();
     if (e2 != hipSuccess) return fail(GBNF_ERR_HIP, "gbnf_trainer_backward launch: %s", hipGetErrorString(e2));
@@ -1946,8 +2018,8 @@ int gbnf_trainer_backward(const gbnf_trainer* t, const float* x, int64_t n, cons
   int chunk = 512;
   while (chunk < 4096 && (int64_t)t->wg_blocks * (p.np / (2 * chunk)) >= 768) chunk *= 2;     // (a block = 4 waves)
   if (forced_chunk >= 32 && forced_chunk % 32 == 0) chunk = forced_chunk;
-  const dim3 wgrid((unsigned)((t->wg_blocks + 7) / 8 * 8), (unsigned)((p.np + chunk - 1) / chunk));
-  hipLaunchKernelGGL(wgrad_kernel, wgrid, dim3(WG_THREADS), (size_t)2 * WG_ROWS_MAX * 8 * 16, s, t->probs_dev, t->n_probs, (const float*)workspace, grads, p.np, chunk,
+  const dim3 wgrid((unsigned)t->wg_blocks, (unsigned)((p.np + chunk - 1) / chunk));
+  hipLaunchKernelGGL(wgrad_kernel, wgrid, dim3(WG_THREADS), WG_LDS_BYTES, s, t->probs_dev, t->n_probs, (const float*)workspace, grads, p.np, chunk,
                      (const unsigned*)t->gmax_dev, t->wg_blocks, LiveReduce{});
   e = hipGetLastError();
   if (e != hipSuccess) return fail(GBNF_ERR_HIP, "gbnf_trainer_backward wgrad launch: %s", hipGetErrorString(e));
