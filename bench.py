@@ -566,8 +566,12 @@ def main():
         math = main_run["name"]
         rl = roofline(main_run, S)
         rl["note"] = ("achieved = ALGORITHMIC f32 flops / launch time (HIP events around the launch); the split paths run "
-                      "3x / 6x (+padding) that on the f16 pipe (executed_*). The binding limit is instruction issue: VALU "
-                      "(tanh, hi/mid split) and MFMA serialise on a SIMD (tools/ubench), see DESIGN.md section 4")
+                      "3x / 6x (+padding) that on the f16 pipe (executed_*). Measured model (profiles/r4_ubench_balance.txt, "
+                      "r4_ablation_upper_bounds.txt): a SIMD spends 17.6 cycles per MFMA on the matrix pipe + weight-fragment "
+                      "reads and ~0.5 cycle per issue cycle of vector work next to it (tanh + hi/mid split: 5 cycles per MFMA in "
+                      "a hidden pass -> 20.0, a whole flow step's mix -> 22.2, layer 0 52.7), at 2, 3 or 4 waves per SIMD alike; "
+                      "moving the weights (L2 -> LDS DMA 11 %, LDS -> register fragments 12 %) is the rest. Bias reads and the "
+                      "stage barrier are worth 0.9 % / 0.5 % end to end. See DESIGN.md section 4")
         out = {
             "metric": "density-eval samples/sec, Boosted-Glow C=8 MINIBOONE d=43" if args.config == "miniboone_glow"
                       else f"density-eval samples/sec, {args.config}",
