@@ -28,7 +28,7 @@ def pmc(name):
         return out
     for l in open(path).read().split("\n"):
         if l.startswith("TOTAL"):
-            out["__total__"] = {kv.split("=")[0]: float(kv.split("=")[1]) for kv in l.split(":", 1)[1].split()}
+            out["__total__"] = {kv.split("=")[0]: float(kv.split("=")[1]) for kv in l.split("dispatches):", 1)[1].split()}
         elif l and not l.startswith(" "):
             nm, _, rest = l.rpartition("  dispatches=")
             cur = out.setdefault(nm, {"dispatches": int(rest)})
