@@ -634,3 +634,42 @@ def test_fast_forward_writes_what_the_backward_needs(kind, d, h, n):
     from oracle import gbnf_oracle as oracle
     zr, lr = oracle.component_forward(spec, x.cpu().numpy())
     assert rel_err(ldj.cpu().numpy(), lr) < 1e-5
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind,d,h,K", [("glow", 43, 215, 5), ("realnvp", 21, 105, 5)])
+def test_weight_gradients_are_additive_over_the_batch_at_full_size(kind, d, h, K):
+    """Size-independent property at BASELINE's N = 65536 (the oracle cannot run a backward pass of that size in seconds): with
+    fixed normalisation statistics the parameter gradients of a batch are the SUM of the gradients of its parts.  One call on
+    65536 rows (wgrad_kernel: 8-wave blocks, 32 sample chunks per block column, two k-steps of loads in flight, float atomics)
+    against eight calls on 8192 rows each (other chunk counts, other block counts per CU), and g_x row for row."""
+    import torch
+    from gbnf_amd import native, synth
+    dev = torch.device("cuda:0")
+    spec = synth.synth_glow_spec(d, h, K, seed=31) if kind == "glow" else synth.synth_realnvp_spec(d, h, K, seed=31)
+    n, parts = 65536, 8
+    x = torch.from_numpy(synth.synth_batch(n, d, seed=32)).to(dev)
+    gen = torch.Generator(device="cpu").manual_seed(33)
+    g_z = torch.randn(n, d, generator=gen).to(dev)
+    g_l = torch.randn(n, generator=gen).to(dev)
+    tr = native.NativeTrainer(_dev_spec(spec, dev))
+    _, _, trace = tr.forward(x, want_trace=True)
+    gx_full, grads_full = tr.backward(x, g_z, g_l, want_gx=True, trace=trace)
+    grads_full = [None if g is None else g.double().cpu() for g in grads_full]
+    gx_full = gx_full.cpu()
+    acc = [None if g is None else torch.zeros_like(g) for g in grads_full]
+    m = n // parts
+    for p in range(parts):
+        sl = slice(p * m, (p + 1) * m)
+        xp = x[sl].contiguous()
+        _, _, tp = tr.forward(xp, want_trace=True)
+        gx, grads = tr.backward(xp, g_z[sl].contiguous(), g_l[sl].contiguous(), want_gx=True, trace=tp)
+        for a, g in zip(acc, grads):
+            if g is not None:
+                a += g.double().cpu()
+        assert (gx.cpu() - gx_full[sl]).abs().max() <= 1e-5 * max(1.0, float(gx_full[sl].abs().max()))
+    for k, (a, b) in enumerate(zip(acc, grads_full)):
+        if b is None:
+            continue
+        scale = max(float(b.abs().max()), 1e-3)
+        assert float((a - b).abs().max()) <= G_RTOL * scale, f"{kind}: gradient {k} shape {tuple(b.shape)}: {float((a - b).abs().max())} vs scale {scale}"
