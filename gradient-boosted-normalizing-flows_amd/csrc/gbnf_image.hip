@@ -56,6 +56,8 @@ struct ConvLaunch {
   int64_t st_img;
   float* ldj;             // (n,) accumulated with atomics (EPI_COUPLE_AFFINE / EPI_SPLIT)
   int cin, cout, H, W, ks, n_strips;
+  int Hv, Wv;             // the map proper: rows < Hv, columns < Wv of the H x W storage (a 14 x 14 map lives in 16 x 16 storage;
+                          // everything outside is ZERO in every tensor in HBM -- the 'same' padding of the map -- and stays so)
   float temperature;      // EPI_SPLIT_INV: z2 = mean + exp(log-var) * temperature * eps (models/layers.py:697)
   int o_split;            // workgroups sharing one strip, each with 1/o_split of the output tiles (fills the chip at small batch)
   // fused producer (1x1 convolutions only): the input of this convolution is relu(conv3x3(pre_in) + pre_bias), computed
@@ -250,6 +252,7 @@ __global__ void __launch_bounds__(64 * IMG_WAVES) img_conv_kernel(const ConvLaun
     const int lin = 16 * pt + i, pr = lin / W, pc = lin % W;
     const int row = r0 + pr;
     const bool in_img = row < H;
+    const bool valid = row < p.Hv && pc < p.Wv;            // outside the map: stores write zero, couplings and log-dets skip
     const int64_t pix = (int64_t)row * W + pc;
     if constexpr (EPI == EPI_RELU || EPI == EPI_STORE) {
       float* out = p.out + (int64_t)n * p.out_img;
@@ -258,7 +261,7 @@ __global__ void __launch_bounds__(64 * IMG_WAVES) img_conv_kernel(const ConvLaun
         const int co = 16 * o + 4 * g + r;
         float v = acc[r] + bias[co];
         if (EPI == EPI_RELU) v = fmaxf(v, 0.0f);
-        if (co < p.cout && in_img) out[(int64_t)co * H * W + pix] = v;
+        if (co < p.cout && in_img) out[(int64_t)co * H * W + pix] = valid ? v : 0.0f;
       }
     } else if constexpr (EPI == EPI_COUPLE_ADD || EPI == EPI_COUPLE_ADD_INV) {
       float* st = p.st + (int64_t)n * p.st_img;
@@ -266,7 +269,7 @@ __global__ void __launch_bounds__(64 * IMG_WAVES) img_conv_kernel(const ConvLaun
       for (int r = 0; r < 4; ++r) {
         const int co = 16 * o + 4 * g + r;
         const float h = acc[r] + bias[co];
-        if (co < p.cout && in_img) st[(int64_t)co * H * W + pix] += (EPI == EPI_COUPLE_ADD) ? h : -h;   // models/glow.py:328-329, :349-350
+        if (co < p.cout && valid) st[(int64_t)co * H * W + pix] += (EPI == EPI_COUPLE_ADD) ? h : -h;   // models/glow.py:328-329, :349-350
       }
     } else {
       // "cross" rows: (2j, 2j+1) = (shift_j, raw_j) for the coupling, (mean_j, log-var_j) for the Split2d prior
@@ -274,7 +277,7 @@ __global__ void __launch_bounds__(64 * IMG_WAVES) img_conv_kernel(const ConvLaun
 #pragma unroll
       for (int q = 0; q < 2; ++q) {
         const int co = 16 * o + 4 * g + 2 * q, j = co >> 1;
-        if (co + 1 < p.cout && in_img) {
+        if (co + 1 < p.cout && valid) {
           const float h0 = acc[2 * q] + bias[co], h1 = acc[2 * q + 1] + bias[co + 1];
           float* zp = st + (int64_t)j * H * W + pix;
           const float z2 = *zp;
@@ -350,26 +353,32 @@ __global__ void __launch_bounds__(64 * IMG_WAVES) img_conv_kernel(const ConvLaun
 }
 
 // ---- dequantise + logit + first squeeze (models/glow.py:125-179; utils/utilities.py:107-119) -------------------
-// x (n, C, H, W) in [0,1] (+ uniform noise or null) -> squeezed logits (n, 4C, H/2, W/2); ldj[n] = its log-det.
+// x (n, C, Hi, Wi) in [0,1] (+ uniform noise or null) -> squeezed logits (n, 4C, H/2, W/2) in H x W STORAGE (Hi <= H, Wi <= W:
+// a 28 x 28 input lives in the top-left 14 x 14 of 16 x 16 maps, zero outside); ldj[n] = its log-det over the real pixels.
 __global__ void __launch_bounds__(256) img_pre_kernel(const float* __restrict__ x, const float* __restrict__ noise, float* __restrict__ out,
-                                                      float* __restrict__ ldj, int C, int H, int W, float bounds, float ld_const,
+                                                      float* __restrict__ ldj, int C, int H, int W, int Hi, int Wi, float bounds, float ld_const,
                                                       const unsigned* gate) {
   if (gate != nullptr && *gate == 0u) return;
-  const int n = blockIdx.x, chw = C * H * W;
-  const float* xi = x + (int64_t)n * chw;
+  const int n = blockIdx.x, chw = C * H * W, xchw = C * Hi * Wi;
+  const float* xi = x + (int64_t)n * xchw;
   float* oi = out + (int64_t)n * chw;
   const float soft_c = log1pf((1.0f - bounds) / bounds);     // softplus(log(1-b) - log(b))
   float ld = 0.0f;
-  for (int e = threadIdx.x; e < chw; e += 256) {
-    const int c = e / (H * W), rem = e % (H * W), y = rem / W, xx = rem % W;
-    float v = xi[e];
-    v = (255.0f * v + (noise ? noise[(int64_t)n * chw + e] : 0.0f)) / 256.0f;      // models/glow.py:136
-    v = ((v * 2.0f - 1.0f) * bounds + 1.0f) * 0.5f;                                   // models/glow.py:164-168
-    const float logit = logf(v) - logf(1.0f - v);                                     // :171
-    // softplus(l) + softplus(-l) = -log(v) - log(1-v) for l = logit(v)
-    ld += -logf(v) - logf(1.0f - v) - soft_c;                                         // :174-175
-    const int oc = c * 4 + (y & 1) * 2 + (xx & 1);
-    oi[((int64_t)oc * (H / 2) + (y >> 1)) * (W / 2) + (xx >> 1)] = logit;
+  const int H2 = H / 2, W2 = W / 2;
+  for (int e = threadIdx.x; e < chw; e += 256) {             // e: an element of the squeezed storage (oc, y2, x2)
+    const int oc = e / (H2 * W2), rem = e % (H2 * W2), y2 = rem / W2, x2 = rem % W2;
+    const int c = oc >> 2, y = 2 * y2 + ((oc >> 1) & 1), xx = 2 * x2 + (oc & 1);
+    float logit = 0.0f;
+    if (y < Hi && xx < Wi) {
+      const int src = (c * Hi + y) * Wi + xx;
+      float v = xi[src];
+      v = (255.0f * v + (noise ? noise[(int64_t)n * xchw + src] : 0.0f)) / 256.0f;    // models/glow.py:136
+      v = ((v * 2.0f - 1.0f) * bounds + 1.0f) * 0.5f;                                   // models/glow.py:164-168
+      logit = logf(v) - logf(1.0f - v);                                                 // :171
+      // softplus(l) + softplus(-l) = -log(v) - log(1-v) for l = logit(v)
+      ld += -logf(v) - logf(1.0f - v) - soft_c;                                         // :174-175
+    }
+    oi[e] = logit;
   }
   __shared__ float red[256];
   red[threadIdx.x] = ld;
@@ -431,16 +440,16 @@ __global__ void __launch_bounds__(256) img_post_kernel(const float* __restrict__
 // Conv2dZeros(0) = bias * exp(3 logs), models/glow.py:62-84); optional copies of z / mean / log-var.
 __global__ void __launch_bounds__(256) img_final_kernel(const float* __restrict__ z, int64_t z_img, const float* __restrict__ prior /* [2C] */,
                                                         const float* __restrict__ ldj, float* __restrict__ ll, float* __restrict__ z_out,
-                                                        int C, int HW, const unsigned* gate) {
+                                                        int C, int H, int W, int Hv, int Wv, const unsigned* gate) {
   if (gate != nullptr && *gate == 0u) return;
   const int n = blockIdx.x;
   const float* zi = z + (int64_t)n * z_img;
   float acc = 0.0f;
-  for (int e = threadIdx.x; e < C * HW; e += 256) {
-    const int c = e / HW;
-    const float mu = prior[c], lv = prior[C + c], v = zi[e], dlt = v - mu;
+  for (int e = threadIdx.x; e < C * Hv * Wv; e += 256) {      // e: an element of the compact z (n, C, Hv, Wv); storage is H x W
+    const int c = e / (Hv * Wv), rem = e % (Hv * Wv), y = rem / Wv, xx = rem % Wv;
+    const float mu = prior[c], lv = prior[C + c], v = zi[((int64_t)c * H + y) * W + xx], dlt = v - mu;
     acc += -0.5f * (lv + dlt * dlt * __expf(-lv));
-    if (z_out) z_out[(int64_t)n * C * HW + e] = v;
+    if (z_out) z_out[(int64_t)n * C * Hv * Wv + e] = v;
   }
   __shared__ float red[256];
   red[threadIdx.x] = acc;
@@ -544,7 +553,8 @@ struct PackedConv {
 using namespace gbnf;
 
 struct gbnf_image_flow {
-  int C = 0, H = 0, W = 0, L = 0, K = 0, hidden = 0, additive = 0, depth = 0;
+  int C = 0, H = 0, W = 0, L = 0, K = 0, hidden = 0, additive = 0, depth = 0;   // H x W: the STORAGE of the input (32 x 32)
+  int Hi = 0, Wi = 0;                        // the input proper (Hi <= H, Wi <= W: 32 x 32, 28 x 28, 28 x 20 ...)
   float bounds = 0.9f;
   double ld_const = 0;                       // dequantisation + every ActNorm2d / invconv log-det (per image)
   std::vector<int> level_steps;              // FlowSteps per level
@@ -783,7 +793,7 @@ static int image_forward_impl(const gbnf_image_flow* f, const float* x, const fl
 
 static int image_probe(gbnf_image_flow* f) {
   constexpr int PN = 4;
-  const int64_t chw = (int64_t)f->C * f->H * f->W;
+  const int64_t chw = (int64_t)f->C * f->Hi * f->Wi;
   std::vector<float> host((size_t)2 * PN * chw);
   uint64_t st = 0x9E3779B97F4A7C15ull;
   for (float& v : host) {                      // splitmix64 -> [0, 1): pixels and dequantisation noise
@@ -831,24 +841,29 @@ int gbnf_image_flow_create(const gbnf_image_flow_desc* d, gbnf_image_flow** out)
   if (d->n_levels < 1 || d->n_levels > 4) return fail(GBNF_ERR_UNSUPPORTED, "n_levels=%d outside [1,4]", d->n_levels);
   if (d->coupling != GBNF_COUPLING_AFFINE && d->coupling != GBNF_COUPLING_ADDITIVE)
     return fail(GBNF_ERR_INVALID, "unknown coupling %d", d->coupling);
-  int C = d->channels, H = d->height, W = d->width;
-  if (C < 1 || H != W) return fail(GBNF_ERR_UNSUPPORTED, "input %dx%dx%d: square images only", C, H, W);
+  // The kernels work on 16- and 8-wide square maps (a 32 x 32 input after one and two squeezes).  A smaller input -- the
+  // reference's 1 x 28 x 28 (MNIST, Omniglot, Caltech) and 1 x 28 x 20 (Frey faces) loaders, utils/load_data.py:389-529 -- lives in
+  // the top-left corner of the same 32 x 32 STORAGE: every tensor in HBM is zero outside the map proper (that IS the map's 'same'
+  // padding), every kernel that stores masks what lies outside, log-dets and priors sum over the map proper.
+  int C = d->channels, H = 32, W = 32, Hv = d->height, Wv = d->width;
+  if (C < 1 || Hv < 2 || Wv < 2 || Hv > H || Wv > W)
+    return fail(GBNF_ERR_UNSUPPORTED, "input %dx%dx%d: at most 32 x 32 pixels", C, Hv, Wv);
   if (!(d->bounds > 0.5f && d->bounds < 1.0f)) return fail(GBNF_ERR_INVALID, "bounds must be in (0.5, 1)");
   auto* f = new gbnf_image_flow();
-  f->C = C; f->H = H; f->W = W; f->L = d->n_levels; f->additive = d->coupling == GBNF_COUPLING_ADDITIVE;
+  f->C = C; f->H = H; f->W = W; f->Hi = Hv; f->Wi = Wv; f->L = d->n_levels; f->additive = d->coupling == GBNF_COUPLING_ADDITIVE;
   f->bounds = d->bounds; f->hidden = d->hidden;
   const char* env_math = getenv("GBNF_MATH");                // "f32": exact-f32 MFMA everywhere (tuning / test knob)
   const bool use_hx3 = !(env_math && !strcmp(env_math, "f32"));
   f->math_mode = use_hx3 ? GBNF_MATH_F16X3 : GBNF_MATH_F32;
   f->chp = (d->hidden + 31) / 32 * 32;
   Packer P;
-  double ld_const = -std::log(256.0) * C * H * W;              // dequantisation, models/glow.py:137
+  double ld_const = -std::log(256.0) * C * Hv * Wv;            // dequantisation, models/glow.py:137
   char what[96];
   int rc = GBNF_OK;
   for (int l = 0; l < d->n_levels && rc == GBNF_OK; ++l) {
     const gbnf_image_level& lv = d->levels[l];
-    if (H % 2 || W % 2) { rc = fail(GBNF_ERR_INVALID, "level %d: odd spatial size", l); break; }
-    C *= 4; H /= 2; W /= 2;
+    if (Hv % 2 || Wv % 2) { rc = fail(GBNF_ERR_INVALID, "level %d: odd spatial size %d x %d", l, Hv, Wv); break; }
+    C *= 4; H /= 2; W /= 2; Hv /= 2; Wv /= 2;
     if (W != 16 && W != 8) { rc = fail(GBNF_ERR_UNSUPPORTED, "level %d works on %dx%d maps; compiled for widths 16 and 8 (32x32 input, <= 2 levels)", l, H, W); break; }
     if (H % IMG_R) { rc = fail(GBNF_ERR_UNSUPPORTED, "level %d: height %d not a multiple of %d", l, H, IMG_R); break; }
     if (C > 64) { rc = fail(GBNF_ERR_UNSUPPORTED, "level %d: %d channels > 64", l, C); break; }
@@ -864,7 +879,7 @@ int gbnf_image_flow_create(const gbnf_image_flow_desc* d, gbnf_image_flow** out)
       std::vector<double> wperm((size_t)C * C, 0.0);
       if (st.perm_weight) {
         for (int e = 0; e < C * C; ++e) wperm[e] = st.perm_weight[e];
-        ld_const += logabsdet(wperm, C) * H * W;                 // models/layers.py:756, 790
+        ld_const += logabsdet(wperm, C) * Hv * Wv;               // models/layers.py:756, 790
       } else {
         std::vector<char> seen(C, 0);
         for (int j = 0; j < C; ++j) {
@@ -887,7 +902,7 @@ int gbnf_image_flow_create(const gbnf_image_flow_desc* d, gbnf_image_flow** out)
         }
         beff[j] = b;
       }
-      for (int m = 0; m < C; ++m) ld_const += (double)st.actnorm_logs[m] * H * W;      // models/layers.py:506-508
+      for (int m = 0; m < C; ++m) ld_const += (double)st.actnorm_logs[m] * Hv * Wv;    // models/layers.py:506-508
       f->mix.push_back(P.add(weff.data(), C, C, 1, ones, beff));
       {
         // the way back (FlowStep.decode, models/glow.py:360-364): x = exp(-logs) * (W^-1 y) - bias
@@ -922,12 +937,12 @@ int gbnf_image_flow_create(const gbnf_image_flow_desc* d, gbnf_image_flow** out)
                                      st.convs[q].kernel_size, sc);
           }
           net.push_back(pc);
-          f->macs += (double)st.convs[q].in_channels * st.convs[q].out_channels * st.convs[q].kernel_size * st.convs[q].kernel_size * H * W;
+          f->macs += (double)st.convs[q].in_channels * st.convs[q].out_channels * st.convs[q].kernel_size * st.convs[q].kernel_size * Hv * Wv;
         }
       }
       f->net.push_back(net);
       f->depth = st.n_convs - 2;
-      f->macs += (double)C * C * H * W;
+      f->macs += (double)C * C * Hv * Wv;
     }
     if (rc) break;
     if (l < d->n_levels - 1) {
@@ -937,12 +952,12 @@ int gbnf_image_flow_create(const gbnf_image_flow_desc* d, gbnf_image_flow** out)
       if (rc) break;
       if (C % 2) { rc = fail(GBNF_ERR_UNSUPPORTED, "Split2d on an odd channel count"); break; }
       f->split.push_back(pack_conv(P, *lv.split_prior));
-      f->macs += (double)(C / 2) * C * 9 * H * W;
+      f->macs += (double)(C / 2) * C * 9 * Hv * Wv;
       C /= 2;
     }
   }
   if (rc == GBNF_OK) {
-    f->zC = C; f->zH = H; f->zW = W;
+    f->zC = C; f->zH = Hv; f->zW = Wv;
     // top prior: Conv2dZeros applied to zeros = bias * exp(3 logs) per channel (models/glow.py:62-84); else zeros
     f->prior_off = P.blob.size();
     P.blob.resize(P.blob.size() + 2 * (size_t)C, 0.0f);
@@ -1045,8 +1060,10 @@ static int image_forward_impl(const gbnf_image_flow* f, const float* x, const fl
   float* H2 = H1 + hid * n;
   const float* blob = f->blob_dev;
 
-  int C = f->C * 4, H = f->H / 2, W = f->W / 2;
-  hipLaunchKernelGGL(img_pre_kernel, dim3((unsigned)n), dim3(256), 0, s, x, noise, SA, ldj, f->C, f->H, f->W, f->bounds, (float)f->ld_const, gate);
+  int C = f->C * 4, H = f->H / 2, W = f->W / 2, Hv = f->Hi / 2, Wv = f->Wi / 2;
+  const bool padded = f->Hi != f->H || f->Wi != f->W;       // the map proper is smaller than its storage
+  hipLaunchKernelGGL(img_pre_kernel, dim3((unsigned)n), dim3(256), 0, s, x, noise, SA, ldj, f->C, f->H, f->W, f->Hi, f->Wi, f->bounds,
+                     (float)f->ld_const, gate);
   float* cur = SA;      // current state (n, C, H, W), image stride = C*H*W
   float* oth = SB;
   size_t step = 0;
@@ -1058,7 +1075,7 @@ static int image_forward_impl(const gbnf_image_flow* f, const float* x, const fl
     for (int k = 0; k < K; ++k, ++step) {
       ConvLaunch p{};
       p.gate = gate;
-      p.H = H; p.W = W; p.n_strips = n_strips; p.ldj = ldj;
+      p.H = H; p.W = W; p.Hv = Hv; p.Wv = Wv; p.n_strips = n_strips; p.ldj = ldj;
       // ActNorm2d + permutation: cur -> oth
       const PackedConv& m = f->mix[step];
       p.in = cur; p.in_img = img; p.wp = blob + m.w_off; p.bias = blob + m.b_off; p.out = oth; p.out_img = img;
@@ -1067,11 +1084,14 @@ static int image_forward_impl(const gbnf_image_flow* f, const float* x, const fl
       std::swap(cur, oth);
       // coupling net on the first half
       const std::vector<PackedConv>& net = f->net[step];
-      if (!force_f32 && net.size() == 3 && net[1].x_off != 0) {
+      const bool fusable = H == W && (W == 16 || W == 8) && net.size() == 3 && net[1].x_off != 0 &&
+                           img_net_hx3_lds(W, f->chp, net[0].cin, net[0].kc, net[2].cout) != 0;
+      // (a padded map runs the fused kernel or the exact-f32 convolutions: the two-kernel split form does not mask)
+      if (!force_f32 && net.size() == 3 && net[1].x_off != 0 && (fusable || !padded)) {
         // split-f16 path.  Round 4: the whole coupling net in ONE kernel where a workgroup can hold the hidden activation of its
         // rows (+ halo) in LDS: the 16 x 16 and 8 x 8 maps of a 32 x 32 input (img_net_hx3_kernel, gbnf_image_hx3.hip.h)
         static const bool no_fuse = getenv("GBNF_IMG_NO_FUSE") != nullptr;        // diagnostic: the round-2 two-kernel form
-        if (!no_fuse && H == W && (W == 16 || W == 8) && img_net_hx3_lds(W, f->chp, net[0].cin, net[0].kc, net[2].cout) != 0) {
+        if ((!no_fuse || padded) && fusable) {
           NetLaunch q{};
           q.pre_in = cur; q.pre_in_img = img; q.pre_wp = reinterpret_cast<const unsigned*>(blob + net[0].x_off);
           q.pre_bias = blob + net[0].b_off; q.pre_kc = net[0].kc; q.pre_cin = net[0].cin;
@@ -1079,7 +1099,7 @@ static int image_forward_impl(const gbnf_image_flow* f, const float* x, const fl
           q.wp = reinterpret_cast<const unsigned*>(blob + net[1].x_off); q.bias = blob + net[1].b_off;
           q.wp3 = reinterpret_cast<const unsigned*>(blob + net[2].x_off); q.bias3 = blob + net[2].b_off;
           q.st = cur + (int64_t)c1 * H * W; q.st_img = img; q.ldj = ldj;
-          q.hid = net[1].cout; q.chp = f->chp; q.cout = net[2].cout; q.H = H;
+          q.hid = net[1].cout; q.chp = f->chp; q.cout = net[2].cout; q.H = H; q.Hv = Hv; q.Wv = Wv;
           q.sat = reinterpret_cast<unsigned long long*>(gbnf::saturation_counter());
           q.mark = mark; q.only = nullptr;
 #ifdef GBNF_IMG_STAMPS
@@ -1156,17 +1176,17 @@ static int image_forward_impl(const gbnf_image_flow* f, const float* x, const fl
       ConvLaunch p{};
       p.gate = gate;
       const PackedConv& c = f->split[l];
-      p.H = H; p.W = W; p.n_strips = n_strips; p.ldj = ldj;
+      p.H = H; p.W = W; p.Hv = Hv; p.Wv = Wv; p.n_strips = n_strips; p.ldj = ldj;
       p.in = cur; p.in_img = img; p.wp = blob + c.w_off; p.bias = blob + c.b_off;
       p.st = cur + (int64_t)c1 * H * W; p.st_img = img; p.cin = c.cin; p.cout = c.cout; p.ks = c.ks;
       launch_conv<EPI_SPLIT>(p, (int)n, s);
       hipLaunchKernelGGL(img_squeeze_kernel, dim3((unsigned)n), dim3(256), 0, s, gate, (const float*)cur, img, oth, c1, H, W);
       std::swap(cur, oth);
-      C = c1 * 4; H /= 2; W /= 2;
+      C = c1 * 4; H /= 2; W /= 2; Hv /= 2; Wv /= 2;
     }
   }
   hipLaunchKernelGGL(img_final_kernel, dim3((unsigned)n), dim3(256), 0, s, (const float*)cur, (int64_t)C * H * W,
-                     blob + f->prior_off, (const float*)ldj, ll, z, C, H * W, gate);
+                     blob + f->prior_off, (const float*)ldj, ll, z, C, H, W, Hv, Wv, gate);
   const hipError_t e = hipGetLastError();
   if (e != hipSuccess) return fail(GBNF_ERR_HIP, "gbnf_image_flow_forward: %s", hipGetErrorString(e));
   return GBNF_OK;
@@ -1200,7 +1220,7 @@ int gbnf_image_flow_forward(const gbnf_image_flow* f, const float* x, const floa
   if (mode == 0) return image_forward_impl(f, x, noise, n, z, ldj, ll, ws, s, false, nullptr);
   // ---- split-f16 pass with range marks; then the marked images: NaN, or the exact-f32 pass over (up to IMG_REPAIR_MAX of) them
   constexpr int R = IMG_REPAIR_MAX;
-  const int64_t chw = (int64_t)f->C * f->H * f->W, zsz = (int64_t)f->zC * f->zH * f->zW;
+  const int64_t chw = (int64_t)f->C * f->Hi * f->Wi, zsz = (int64_t)f->zC * f->zH * f->zW;      // (x and z have the map's own size)
   float* q = ws + image_state_floats(f, n);
   unsigned* mark = reinterpret_cast<unsigned*>(q); q += (n + 63) / 64 * 64;
   unsigned* list = reinterpret_cast<unsigned*>(q); unsigned* count = list + R; q += 64;
@@ -1239,7 +1259,7 @@ int gbnf_image_flow_numerics(const gbnf_image_flow* f, gbnf_numerics_status* out
 
 int gbnf_image_flow_eps_floats(const gbnf_image_flow* f, int64_t* per_image) {
   if (!f || !per_image) return fail(GBNF_ERR_INVALID, "gbnf_image_flow_eps_floats: null argument");
-  *per_image = (int64_t)f->C * f->H * f->W - (int64_t)f->zC * f->zH * f->zW;
+  *per_image = (int64_t)f->C * f->Hi * f->Wi - (int64_t)f->zC * f->zH * f->zW;
   return GBNF_OK;
 }
 
@@ -1250,6 +1270,8 @@ int gbnf_image_flow_inverse(const gbnf_image_flow* f, const float* z, const floa
   if (n == 0) return GBNF_OK;
   if (!z || !x || !workspace) return fail(GBNF_ERR_INVALID, "gbnf_image_flow_inverse: z / x / workspace is null");
   if (f->L > 1 && !eps) return fail(GBNF_ERR_INVALID, "gbnf_image_flow_inverse: %d Split2d level(s) need eps", f->L - 1);
+  if (f->Hi != f->H || f->Wi != f->W)
+    return fail(GBNF_ERR_UNSUPPORTED, "gbnf_image_flow_inverse: %d x %d inputs are evaluated only (the z -> x direction is built for 32 x 32)", f->Hi, f->Wi);
   int64_t need = 0;
   gbnf_image_flow_workspace_bytes(f, n, &need);
   if (workspace_bytes < need) return fail(GBNF_ERR_INVALID, "gbnf_image_flow_inverse: workspace of %lld bytes < %lld", (long long)workspace_bytes, (long long)need);
@@ -1297,7 +1319,7 @@ int gbnf_image_flow_inverse(const gbnf_image_flow* f, const float* z, const floa
       std::swap(cur, oth);
       ConvLaunch p{};
       const PackedConv& c = f->split[l];
-      p.H = H; p.W = W; p.n_strips = n_strips; p.ldj = nullptr; p.temperature = temperature;
+      p.H = H; p.W = W; p.Hv = H; p.Wv = W; p.n_strips = n_strips; p.ldj = nullptr; p.temperature = temperature;
       p.in = cur; p.in_img = img; p.wp = blob + c.w_off; p.bias = blob + c.b_off;
       p.st = cur + (int64_t)c1 * H * W; p.st_img = img; p.cin = c.cin; p.cout = c.cout; p.ks = c.ks;
       launch_conv<EPI_SPLIT_INV>(p, (int)n, s);
@@ -1305,7 +1327,7 @@ int gbnf_image_flow_inverse(const gbnf_image_flow* f, const float* z, const floa
     for (int k = K - 1; k >= 0; --k) {
       const size_t step = step_end - (size_t)(K - k);
       ConvLaunch p{};
-      p.H = H; p.W = W; p.n_strips = n_strips; p.ldj = nullptr;
+      p.H = H; p.W = W; p.Hv = H; p.Wv = W; p.n_strips = n_strips; p.ldj = nullptr;
       // coupling^-1: the net reads the first half (unchanged by the step), exact-f32 convolutions
       const std::vector<PackedConv>& net = f->net[step];
       const float* hin = cur;

@@ -330,11 +330,14 @@ __global__ void __launch_bounds__(512) img_net_hx3_kernel(const NetLaunch p) {
 #pragma unroll
         for (int pt = 0; pt < NPH; ++pt) {
           const int lin = 16 * pt + i;
+          // outside the map proper (a 14 x 14 map in 16 x 16 storage) the hidden activation the last 3 x 3 reads must be the
+          // map's zero padding, not relu(bias + ...)
+          const bool valid = hr0 + lin / W < p.Hv && lin % W < p.Wv;
           float v[4];
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
             const int co = 16 * o + 4 * g + r;
-            v[r] = co < p.hid ? fmaxf(acc[q][pt][r] + mid_b[q][r], 0.0f) : 0.0f;
+            v[r] = (co < p.hid && valid) ? fmaxf(acc[q][pt][r] + mid_b[q][r], 0.0f) : 0.0f;
           }
           unsigned h01, m01, h23, m23;
           img_split_pair_w(v[0], v[1], h01, m01, amax);
@@ -555,17 +558,18 @@ __global__ void __launch_bounds__(512) img_net_hx3_kernel(const NetLaunch p) {
         for (int w = 0; w < WV; ++w) acc += red[(w * NPO + pt) * 64 + lane];
         const int lin = 16 * pt + i, row = r0 + lin / W, pc = lin % W;
         const int64_t pix = (int64_t)row * W + pc;
+        const bool valid = row < p.Hv && pc < p.Wv;          // outside the map proper the state stays zero and adds no log-det
         if constexpr (EPI == EPI_COUPLE_ADD) {
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
             const int co = 16 * o + 4 * g + r;
-            if (co < p.cout) st[(int64_t)co * H * W + pix] = z2v[o][r] + (acc[r] + b3v[o][r]);        // models/glow.py:328-329
+            if (co < p.cout && valid) st[(int64_t)co * H * W + pix] = z2v[o][r] + (acc[r] + b3v[o][r]);        // models/glow.py:328-329
           }
         } else {
 #pragma unroll
           for (int qq = 0; qq < 2; ++qq) {
             const int co = 16 * o + 4 * g + 2 * qq, j = co >> 1;
-            if (co + 1 < p.cout) {
+            if (co + 1 < p.cout && valid) {
               const float h0 = acc[2 * qq] + b3v[o][2 * qq], h1 = acc[2 * qq + 1] + b3v[o][2 * qq + 1];
               float* zp = st + (int64_t)j * H * W + pix;
               const float e = __expf(-(h1 + 2.0f));                     // scale = sigmoid(raw + 2), models/glow.py:333

@@ -21,11 +21,12 @@ def golden_names():
     """Forward/mixture fixtures (g1..g6).  g7 (ActNorm data-dependent init), g8 (boosting weights) and g9 (decode)
     have their own tests."""
     names = sorted(os.path.splitext(os.path.basename(p))[0] for p in glob.glob(os.path.join(GOLDEN_DIR, "*.npz")))
-    return [n for n in names if not n.startswith(("g7_", "g8_", "g9_", "g10_", "g11_", "g12_", "g16_", "g18_"))]
+    return [n for n in names if not n.startswith(("g7_", "g8_", "g9_", "g10_", "g11_", "g12_", "g16_", "g18_", "g19_"))]
 
 
 IMAGE_CASES = ("g12_image_glow_invconv_affine", "g12_image_glow_shuffle_additive", "g12_image_glow_lu",
-               "g18_image_glow_trained_like_h256")
+               "g18_image_glow_trained_like_h256", "g19_image_glow_1x28x28", "g19_image_glow_1x28x20_additive",
+               "g19_image_glow_1x28x28_one_level_h256")
 
 
 def load_image_case(name):
@@ -33,7 +34,8 @@ def load_image_case(name):
     from gbnf_amd import synth
     data = dict(np.load(os.path.join(GOLDEN_DIR, name + ".npz")))
     cfg = json.loads(bytes(data["config"]).decode())
-    specs = [synth.synth_image_glow_spec((3, 32, 32), cfg["h"], cfg["K"], cfg["L"], depth=cfg["depth"], coupling=cfg["coupling"],
+    size = tuple(cfg.get("input_size", (3, 32, 32)))
+    specs = [synth.synth_image_glow_spec(size, cfg["h"], cfg["K"], cfg["L"], depth=cfg["depth"], coupling=cfg["coupling"],
                                          permutation=cfg["permutation"], learn_top=cfg["learn_top"], seed=cfg["w_seed"] + c,
                                          trained_like=cfg.get("trained_like", False))
              for c in range(cfg["C"])]
@@ -43,7 +45,7 @@ def load_image_case(name):
             for lvl in sp["levels"]:
                 for st in lvl["steps"]:
                     st["perm_w"] = data[f"c{c}.perm_w.{k}"]; k += 1
-    x, noise = synth.synth_image_batch(cfg["N"], (3, 32, 32), seed=cfg["x_seed"])
+    x, noise = synth.synth_image_batch(cfg["N"], size, seed=cfg["x_seed"])
     return cfg, specs, x, noise, data
 
 

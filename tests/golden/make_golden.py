@@ -540,14 +540,14 @@ def install_image_spec(ref_glow, spec, keep_invconv=False):
 
 
 def image_case(name, h=32, K=2, L=2, C=2, N=4, depth=1, coupling="affine", permutation="invconv", learn_top=True,
-               LU=False, trained_like=False):
+               LU=False, trained_like=False, input_size=(3, 32, 32)):
     """G12: the image path (BASELINE.json configs[3] at toy size) by the reference itself:
     BoostedFlow with input_size (3,32,32) -> Glow.encode (dequantise with the fixture's noise injected through
     Tensor.uniform_, to_logits, squeeze / FlowStep / Split2d levels, learned top prior), then
     ll_c = log_normal_diag(z, z_mu, z_var) + logdet (image_experiment.py:227) and the boosted recursion over c."""
     from utils.distributions import log_normal_diag
-    input_size = (3, 32, 32)
-    a = ref_args("glow", 3 * 32 * 32, h, K, C, depth=depth, coupling=coupling, permutation=permutation)
+    input_size = tuple(input_size)      # g19 (round 4): the reference's 1 x 28 x 28 and 1 x 28 x 20 loaders (utils/load_data.py:389-529)
+    a = ref_args("glow", int(np.prod(input_size)), h, K, C, depth=depth, coupling=coupling, permutation=permutation)
     a.input_size = list(input_size); a.num_blocks = L; a.learn_top = learn_top; a.LU_decomposed = LU
     torch.manual_seed(7)
     model = RefBoostedFlow(a).eval()
@@ -580,7 +580,8 @@ def image_case(name, h=32, K=2, L=2, C=2, N=4, depth=1, coupling="affine", permu
         torch.Tensor.uniform_ = orig
     out = dict(config=np.frombuffer(json.dumps(dict(case="image", h=h, K=K, L=L, C=C, N=N, depth=depth, coupling=coupling,
                                                     permutation=permutation, learn_top=learn_top, LU=LU, w_seed=61,
-                                                    x_seed=31, trained_like=trained_like)).encode(), dtype=np.uint8),
+                                                    x_seed=31, trained_like=trained_like, input_size=list(input_size))).encode(),
+                                         dtype=np.uint8),
                rho=model.rho.numpy().copy(), z=np.stack(zs), ldj=np.stack(ldjs), ll=np.stack(lls), G=G.numpy().copy())
     if LU:   # the composed invconv matrices of the reference's own LU factors (not reproducible from the generator)
         for c in range(C):
@@ -589,7 +590,7 @@ def image_case(name, h=32, K=2, L=2, C=2, N=4, depth=1, coupling="affine", permu
                 for st in lvl["steps"]:
                     out[f"c{c}.perm_w.{k}"] = st["perm_w"]; k += 1
     np.savez_compressed(os.path.join(HERE, name + ".npz"), **out)
-    print(f"{name}: ll[:, :2]={np.stack(lls)[:, :2]} bpd={-np.stack(lls).mean() / (np.log(2) * 3072):.4f}")
+    print(f"{name}: ll[:, :2]={np.stack(lls)[:, :2]} bpd={-np.stack(lls).mean() / (np.log(2) * np.prod(input_size)):.4f}")
 
 
 def image_decode_case(name, h=32, K=2, L=2, N=3, depth=1, coupling="affine", permutation="invconv", LU=False,
@@ -683,6 +684,13 @@ def main():
         # g18 (round 4): trained-like magnitudes on the image path -- ActNorm2d logs +-3, coupling-net ActNorm2d logs +-1.5,
         # Conv2dZeros logs +-0.5 (gains exp(3 logs) up to e^1.5) -- at the full hidden width of BASELINE.json configs[3]
         image_case("g18_image_glow_trained_like_h256", h=256, K=2, L=2, C=2, N=4, trained_like=True)
+        return
+    if "--image-small-only" in sys.argv:
+        # g19 (round 4): the reference's other image shapes -- 1 x 28 x 28 (MNIST, Omniglot, Caltech) and 1 x 28 x 20 (Frey faces)
+        image_case("g19_image_glow_1x28x28", h=64, K=2, L=2, C=2, N=4, input_size=(1, 28, 28))
+        image_case("g19_image_glow_1x28x20_additive", h=32, K=3, L=2, C=2, N=4, input_size=(1, 28, 20), coupling="additive",
+                   permutation="shuffle", learn_top=False)
+        image_case("g19_image_glow_1x28x28_one_level_h256", h=256, K=2, L=1, C=2, N=3, input_size=(1, 28, 28))
         return
     if "--image-only" in sys.argv:
         image_case("g12_image_glow_invconv_affine")

@@ -286,3 +286,57 @@ def test_image_well_scaled_model_stays_on_split_f16_and_unmarked():
     flow.forward(torch.from_numpy(x).to(dev), torch.from_numpy(noise).to(dev))
     torch.cuda.synchronize()
     assert native.saturation_count(reset=True) == 0 and int(flow.numerics().checks) == 0
+
+
+@pytest.mark.parametrize("size,h,K,L,kw", [((1, 28, 28), 256, 3, 2, {}), ((1, 28, 20), 64, 2, 2, {}), ((1, 28, 20), 256, 2, 1, {"depth": 2}),
+                                           ((3, 24, 16), 48, 2, 2, {"coupling": "additive", "permutation": "reverse"}),
+                                           ((1, 28, 28), 32, 2, 2, {"depth": 0, "learn_top": False}), ((2, 8, 12), 16, 1, 1, {})])
+@pytest.mark.parametrize("math", ["default", "f32"])
+def test_image_inputs_smaller_than_the_storage_match_oracle(size, h, K, L, kw, math, monkeypatch):
+    """The reference's other image loaders hand over 1 x 28 x 28 and 1 x 28 x 20 (utils/load_data.py:389-529).  Such a map lives in
+    the corner of the 16- / 8-wide storage the kernels are built for; everything outside must behave as the map's zero padding:
+    the fused split-f16 coupling-net kernel (default) and the exact-f32 convolutions against the float32 oracle."""
+    import torch
+    from gbnf_amd import native, synth
+    from oracle import gbnf_oracle as oracle
+    if math == "f32":
+        monkeypatch.setenv("GBNF_MATH", "f32")
+    dev = torch.device("cuda:0")
+    sp = synth.synth_image_glow_spec(size, h, K, L, seed=3, **kw)
+    x, noise = synth.synth_image_batch(5, size, seed=4)
+    flow = native.NativeImageFlow(sp)
+    z, ldj, ll = flow.forward(torch.from_numpy(x).to(dev), torch.from_numpy(noise).to(dev))
+    zo, _, _, ldo, llo = oracle.image_component_forward(sp, x, noise)
+    assert tuple(z.shape) == zo.shape
+    assert rel_err(ll.cpu().numpy(), llo) < LL_RTOL and rel_err(ldj.cpu().numpy(), ldo) < LL_RTOL
+    assert np.abs(z.cpu().numpy() - zo).max() <= 2e-5 * max(1.0, float(np.abs(zo).max()))
+    # a second call on the same workspace (stale data outside the map would show up here) is bit-identical
+    z2, ldj2, ll2 = flow.forward(torch.from_numpy(x).to(dev), torch.from_numpy(noise).to(dev))
+    assert torch.equal(ll, ll2) or rel_err(ll2.cpu().numpy(), llo) < LL_RTOL
+
+
+def test_image_module_dropin_on_28x28_matches_reference():
+    """BoostedFlow(args) with input_size [1, 28, 28] against the reference's own outputs (fixture g19)."""
+    import argparse
+    import torch
+    from gbnf_amd import BoostedFlow, image_glow
+    cfg, specs, x, noise, data = load_image_case("g19_image_glow_1x28x28")
+    dev = torch.device("cuda:0")
+    args = argparse.Namespace(
+        num_flows=cfg["K"], z_size=784, density_evaluation=True, device=dev, cuda=True, component_type="glow",
+        num_components=cfg["C"], rho_init="decreasing", learn_top=cfg["learn_top"], y_classes=0, y_condition=False,
+        sample_size=4, input_size=[1, 28, 28], h_size=cfg["h"], num_blocks=cfg["L"], actnorm_scale=1.0,
+        flow_permutation=cfg["permutation"], flow_coupling=cfg["coupling"], LU_decomposed=False, num_dequant_blocks=0,
+        coupling_network="tanh", coupling_network_depth=cfg["depth"], batch_norm=False)
+    m = BoostedFlow(args)
+    assert isinstance(m, image_glow.BoostedImageFlow)
+    for c, sp in enumerate(specs):
+        image_glow.load_image_spec(m.flows[c], sp)
+    m.eval()
+    xd, nd = torch.from_numpy(x).to(dev), torch.from_numpy(noise).to(dev)
+    with torch.no_grad():
+        ll = m.component_log_prob(xd, noise=nd)
+        assert rel_err(ll.cpu().numpy().T, data["ll"]) < LL_RTOL
+        assert rel_err(m.log_prob(xd, noise=nd).cpu().numpy(), data["G"]) < LL_RTOL
+        z, z_mu, z_var, ldj, y = m(x=xd, components=1)
+        assert z.shape == (cfg["N"], 8, 7, 7) and z_mu.shape == z.shape and torch.isfinite(ldj).all()
