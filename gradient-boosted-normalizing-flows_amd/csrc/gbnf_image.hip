@@ -407,28 +407,42 @@ __global__ void __launch_bounds__(256) img_squeeze_kernel(const unsigned* gate, 
 // unsqueeze2d (utils/utilities.py:121-135) of (n, 4C, H/2, W/2) into the first C channels of (n, Ctot, H, W); the next
 // `C_eps` channels are filled from eps (n, C_eps, H, W) (the standard-normal draws Split2d's reverse scales in place)
 __global__ void __launch_bounds__(256) img_unsqueeze_kernel(const float* __restrict__ in, float* __restrict__ out, int64_t out_img, int C, int H,
-                                                            int W, const float* __restrict__ eps, int C_eps) {
+                                                            int W, const float* __restrict__ eps, int C_eps, int Hv, int Wv) {
   const int n = blockIdx.x, chw = C * H * W;
   const float* xi = in + (int64_t)n * chw;
   float* oi = out + (int64_t)n * out_img;
   for (int e = threadIdx.x; e < chw; e += 256) {
     const int c = e / (H * W), rem = e % (H * W), y = rem / W, xx = rem % W;
     const int ic = c * 4 + (y & 1) * 2 + (xx & 1);
-    oi[e] = xi[((int64_t)ic * (H / 2) + (y >> 1)) * (W / 2) + (xx >> 1)];
+    oi[e] = xi[((int64_t)ic * (H / 2) + (y >> 1)) * (W / 2) + (xx >> 1)];      // (zero outside the map proper, like its input)
   }
-  if (eps != nullptr) {
+  if (eps != nullptr) {                                      // eps (n, C_eps, Hv, Wv) has the map's own size: zero around it
     const int ehw = C_eps * H * W;
-    for (int e = threadIdx.x; e < ehw; e += 256) oi[chw + e] = eps[(int64_t)n * ehw + e];
+    for (int e = threadIdx.x; e < ehw; e += 256) {
+      const int c = e / (H * W), rem = e % (H * W), y = rem / W, xx = rem % W;
+      oi[chw + e] = (y < Hv && xx < Wv) ? eps[(((int64_t)n * C_eps + c) * Hv + y) * Wv + xx] : 0.0f;
+    }
+  }
+}
+
+// z (n, C, Hv, Wv) of the map's own size into the top-left corner of zeroed (n, C, H, W) storage
+__global__ void __launch_bounds__(256) img_embed_kernel(const float* __restrict__ z, float* __restrict__ out, int C, int H, int W, int Hv, int Wv) {
+  const int n = blockIdx.x, chw = C * H * W;
+  float* oi = out + (int64_t)n * chw;
+  for (int e = threadIdx.x; e < chw; e += 256) {
+    const int c = e / (H * W), rem = e % (H * W), y = rem / W, xx = rem % W;
+    oi[e] = (y < Hv && xx < Wv) ? z[(((int64_t)n * C + c) * Hv + y) * Wv + xx] : 0.0f;
   }
 }
 
 // the last unsqueeze + to_logits(reverse=True) (models/glow.py:151-158): (n, 4C, H/2, W/2) logits -> x (n, C, H, W)
-__global__ void __launch_bounds__(256) img_post_kernel(const float* __restrict__ in, float* __restrict__ x, int C, int H, int W, float bounds) {
-  const int n = blockIdx.x, chw = C * H * W;
+__global__ void __launch_bounds__(256) img_post_kernel(const float* __restrict__ in, float* __restrict__ x, int C, int H, int W, int Hi, int Wi,
+                                                       float bounds) {
+  const int n = blockIdx.x, chw = C * H * W, xchw = C * Hi * Wi;        // storage H x W, x (n, C, Hi, Wi)
   const float* xi = in + (int64_t)n * chw;
-  float* oi = x + (int64_t)n * chw;
-  for (int e = threadIdx.x; e < chw; e += 256) {
-    const int c = e / (H * W), rem = e % (H * W), y = rem / W, xx = rem % W;
+  float* oi = x + (int64_t)n * xchw;
+  for (int e = threadIdx.x; e < xchw; e += 256) {
+    const int c = e / (Hi * Wi), rem = e % (Hi * Wi), y = rem / Wi, xx = rem % Wi;
     const int ic = c * 4 + (y & 1) * 2 + (xx & 1);
     const float v = xi[((int64_t)ic * (H / 2) + (y >> 1)) * (W / 2) + (xx >> 1)];
     const float sg = 1.0f / (__expf(-v) + 1.0f);
@@ -1270,8 +1284,6 @@ int gbnf_image_flow_inverse(const gbnf_image_flow* f, const float* z, const floa
   if (n == 0) return GBNF_OK;
   if (!z || !x || !workspace) return fail(GBNF_ERR_INVALID, "gbnf_image_flow_inverse: z / x / workspace is null");
   if (f->L > 1 && !eps) return fail(GBNF_ERR_INVALID, "gbnf_image_flow_inverse: %d Split2d level(s) need eps", f->L - 1);
-  if (f->Hi != f->H || f->Wi != f->W)
-    return fail(GBNF_ERR_UNSUPPORTED, "gbnf_image_flow_inverse: %d x %d inputs are evaluated only (the z -> x direction is built for 32 x 32)", f->Hi, f->Wi);
   int64_t need = 0;
   gbnf_image_flow_workspace_bytes(f, n, &need);
   if (workspace_bytes < need) return fail(GBNF_ERR_INVALID, "gbnf_image_flow_inverse: workspace of %lld bytes < %lld", (long long)workspace_bytes, (long long)need);
@@ -1285,17 +1297,17 @@ int gbnf_image_flow_inverse(const gbnf_image_flow* f, const float* z, const floa
   const float* blob = f->blob_dev;
 
   // level shapes on the way in, and where each Split2d level's eps starts (level 0 first, each (n, C_l/2, H_l, W_l))
-  std::vector<int> LC(f->L), LH(f->L), LW(f->L);
+  std::vector<int> LC(f->L), LH(f->L), LW(f->L), LHv(f->L), LWv(f->L);
   std::vector<int64_t> eps_off(f->L, 0);
   {
-    int C = f->C, H = f->H, W = f->W;
+    int C = f->C, H = f->H, W = f->W, Hv = f->Hi, Wv = f->Wi;
     int64_t off = 0;
     for (int l = 0; l < f->L; ++l) {
-      C *= 4; H /= 2; W /= 2;
-      LC[l] = C; LH[l] = H; LW[l] = W;
+      C *= 4; H /= 2; W /= 2; Hv /= 2; Wv /= 2;
+      LC[l] = C; LH[l] = H; LW[l] = W; LHv[l] = Hv; LWv[l] = Wv;
       if (l < f->L - 1) {
         eps_off[l] = off;
-        off += (int64_t)(C / 2) * H * W * n;
+        off += (int64_t)(C / 2) * Hv * Wv * n;                  // (eps has the map's own size)
         C /= 2;
       }
     }
@@ -1305,9 +1317,9 @@ int gbnf_image_flow_inverse(const gbnf_image_flow* f, const float* z, const floa
 
   float* cur = SA;
   float* oth = SB;
-  (void)hipMemcpyAsync(cur, z, (size_t)n * f->zC * f->zH * f->zW * 4, hipMemcpyDeviceToDevice, s);
+  hipLaunchKernelGGL(img_embed_kernel, dim3((unsigned)n), dim3(256), 0, s, z, cur, f->zC, LH[f->L - 1], LW[f->L - 1], f->zH, f->zW);
   for (int l = f->L - 1; l >= 0; --l) {
-    const int C = LC[l], H = LH[l], W = LW[l];
+    const int C = LC[l], H = LH[l], W = LW[l], Hv = LHv[l], Wv = LWv[l];
     const int64_t img = (int64_t)C * H * W;
     const int n_strips = H / IMG_R;
     const int c1 = C / 2;
@@ -1315,11 +1327,11 @@ int gbnf_image_flow_inverse(const gbnf_image_flow* f, const float* z, const floa
     if (l < f->L - 1) {
       // the state of level l+1 (n, 4 c1, H/2, W/2) -> first c1 channels of this level; eps into the other half; Split2d reverse
       hipLaunchKernelGGL(img_unsqueeze_kernel, dim3((unsigned)n), dim3(256), 0, s, (const float*)cur, oth, img, c1, H, W,
-                         eps + eps_off[l], C - c1);
+                         eps + eps_off[l], C - c1, Hv, Wv);
       std::swap(cur, oth);
       ConvLaunch p{};
       const PackedConv& c = f->split[l];
-      p.H = H; p.W = W; p.Hv = H; p.Wv = W; p.n_strips = n_strips; p.ldj = nullptr; p.temperature = temperature;
+      p.H = H; p.W = W; p.Hv = Hv; p.Wv = Wv; p.n_strips = n_strips; p.ldj = nullptr; p.temperature = temperature;
       p.in = cur; p.in_img = img; p.wp = blob + c.w_off; p.bias = blob + c.b_off;
       p.st = cur + (int64_t)c1 * H * W; p.st_img = img; p.cin = c.cin; p.cout = c.cout; p.ks = c.ks;
       launch_conv<EPI_SPLIT_INV>(p, (int)n, s);
@@ -1327,7 +1339,7 @@ int gbnf_image_flow_inverse(const gbnf_image_flow* f, const float* z, const floa
     for (int k = K - 1; k >= 0; --k) {
       const size_t step = step_end - (size_t)(K - k);
       ConvLaunch p{};
-      p.H = H; p.W = W; p.Hv = H; p.Wv = W; p.n_strips = n_strips; p.ldj = nullptr;
+      p.H = H; p.W = W; p.Hv = Hv; p.Wv = Wv; p.n_strips = n_strips; p.ldj = nullptr;
       // coupling^-1: the net reads the first half (unchanged by the step), exact-f32 convolutions
       const std::vector<PackedConv>& net = f->net[step];
       const float* hin = cur;
@@ -1361,7 +1373,7 @@ int gbnf_image_flow_inverse(const gbnf_image_flow* f, const float* z, const floa
     }
     step_end -= (size_t)K;
   }
-  hipLaunchKernelGGL(img_post_kernel, dim3((unsigned)n), dim3(256), 0, s, (const float*)cur, x, f->C, f->H, f->W, f->bounds);
+  hipLaunchKernelGGL(img_post_kernel, dim3((unsigned)n), dim3(256), 0, s, (const float*)cur, x, f->C, f->H, f->W, f->Hi, f->Wi, f->bounds);
   const hipError_t e = hipGetLastError();
   if (e != hipSuccess) return fail(GBNF_ERR_HIP, "gbnf_image_flow_inverse: %s", hipGetErrorString(e));
   return GBNF_OK;

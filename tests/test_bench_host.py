@@ -30,7 +30,7 @@ def test_traffic_lookup_matches_only_the_measured_workloads():
     assert b.measured_traffic("miniboone_glow", 4096, 8, 7, "f16x3", 1) is None          # never measured
     assert b.measured_traffic("miniboone_glow", 4096, 8, g, "f32", 1) is None            # another kernel
     assert b.measured_traffic("miniboone_glow", 4096, 8, g, "f16x3", 8) is None          # another rank count
-    assert b.measured_traffic("hepmass_realnvp", 65536, 8, g, "f16x3", 1) is None
+    assert b.measured_traffic("hepmass_realnvp", 4096, 8, g, "f16x3", 1) is None         # another batch size (N = 65536 is measured since round 4)
 
 
 def test_driver_invocation_parses_and_defaults_finish_quickly():

@@ -340,3 +340,25 @@ def test_image_module_dropin_on_28x28_matches_reference():
         assert rel_err(m.log_prob(xd, noise=nd).cpu().numpy(), data["G"]) < LL_RTOL
         z, z_mu, z_var, ldj, y = m(x=xd, components=1)
         assert z.shape == (cfg["N"], 8, 7, 7) and z_mu.shape == z.shape and torch.isfinite(ldj).all()
+
+
+@pytest.mark.parametrize("size,h,K,L,kw", [((1, 28, 28), 64, 2, 2, {}), ((1, 28, 20), 32, 2, 2, {"coupling": "additive", "permutation": "shuffle"}),
+                                           ((1, 28, 28), 32, 2, 1, {}), ((3, 24, 16), 32, 1, 2, {"depth": 2})])
+def test_image_inverse_on_inputs_smaller_than_the_storage(size, h, K, L, kw):
+    """z -> x for the padded maps against the float64 oracle's Glow.decode (Split2d draws injected)."""
+    import torch
+    from gbnf_amd import native, synth
+    from oracle import gbnf_oracle as oracle
+    dev = torch.device("cuda:0")
+    sp = synth.synth_image_glow_spec(size, h, K, L, seed=8, **kw)
+    flow = native.NativeImageFlow(sp)
+    rng = np.random.RandomState(9)
+    n = 3
+    z = (0.7 * rng.standard_normal((n,) + flow.z_shape)).astype(np.float32)
+    shapes = oracle.image_split_shapes(sp, size)
+    assert [tuple(s) for s in shapes] == [tuple(s) for s in flow.split_shapes()]
+    eps = [rng.standard_normal((n,) + tuple(sh)).astype(np.float32) for sh in shapes]
+    x = flow.inverse(torch.from_numpy(z).to(dev), [torch.from_numpy(e).to(dev) for e in eps], 0.9)
+    x_or = oracle.image_component_inverse(sp, z, eps, 0.9, dtype=torch.float64)
+    assert tuple(x.shape) == x_or.shape
+    assert np.abs(x.cpu().numpy() - x_or).max() <= 2e-5

@@ -28,6 +28,8 @@ def main():
     ap.add_argument("--K", type=int, default=8)
     ap.add_argument("--L", type=int, default=2)
     ap.add_argument("--hidden", type=int, default=256)
+    ap.add_argument("--input", type=int, nargs=3, default=[3, 32, 32], metavar=("C", "H", "W"),
+                    help="image shape: 3 32 32 (CIFAR: BASELINE configs[3], the default), 1 28 28 (MNIST / Omniglot / Caltech), 1 28 20 (Frey faces)")
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
@@ -42,9 +44,10 @@ def main():
     from gbnf_amd import native, synth
     from oracle import gbnf_oracle as oracle
     dev = torch.device("cuda:0")
-    specs = [synth.synth_image_glow_spec((3, 32, 32), a.hidden, a.K, a.L, seed=100 + c) for c in range(a.components)]
+    size = tuple(a.input)
+    specs = [synth.synth_image_glow_spec(size, a.hidden, a.K, a.L, seed=100 + c) for c in range(a.components)]
     flows = [native.NativeImageFlow(sp) for sp in specs]
-    x_np, noise_np = synth.synth_image_batch(a.batch, seed=0)
+    x_np, noise_np = synth.synth_image_batch(a.batch, size, seed=0)
     x, noise = torch.from_numpy(x_np).to(dev), torch.from_numpy(noise_np).to(dev)
     rho = torch.clamp(1.0 / torch.pow(2.0, torch.arange(a.components * 1.0)), min=0.05).to(dev)
     ll = torch.empty((a.components, a.batch), dtype=torch.float32, device=dev)
@@ -122,17 +125,18 @@ def main():
         cpu_dt = (time.perf_counter() - t0) / passes
     err = float(np.abs(G.cpu().numpy()[:ns] - G_cpu).max() / np.abs(G_cpu).max())
     print(json.dumps({
-        "metric": "density-eval images/sec, CIFAR-10 3x32x32 multi-scale Boosted-Glow", "value": a.batch / dt, "unit": "images/s",
+        "metric": "density-eval images/sec, CIFAR-10 3x32x32 multi-scale Boosted-Glow" if size == (3, 32, 32)
+                  else f"density-eval images/sec, {size[0]}x{size[1]}x{size[2]} multi-scale Boosted-Glow", "value": a.batch / dt, "unit": "images/s",
         "n_gpus": 1, "steps": a.steps, "warmup": a.warmup, "ms_per_step": dt * 1e3, "higher_is_better": True,
         "scaling": "strong", "vs_baseline": None, "dtype": "f32" if exact else "f16x3", "data": "synthetic",
         "stream_launches_value": stream_rate,
-        "config": {"workload": f"cifar_glow: 3x32x32, C={a.components} components, K={a.K} steps x L={a.L} levels, h={a.hidden}, "
+        "config": {"workload": f"{'cifar_glow' if size == (3, 32, 32) else 'image_glow'}: {size[0]}x{size[1]}x{size[2]}, C={a.components} components, K={a.K} steps x L={a.L} levels, h={a.hidden}, "
                                f"invconv, affine, learn_top, batch={a.batch}, synthetic images + weights",
                    "launch": ("HIP graph replay" if a.graph else "stream launches") + (", one stream per component" if a.streams else "")},
         # the coupling nets (99 % of the FLOPs) run on the split-f16 kernels img_mid_hx3 / img_last_hx3 unless GBNF_MATH=f32:
         # the peak is that of the pipe they run on; achieved = ALGORITHMIC f32 FLOPs (the f16 pipe executes 3x that)
         "roofline": {"kernel": "gbnf::img_conv_kernel (all convolutions, exact f32)" if exact else
-                               "gbnf::img_mid_hx3_kernel + img_last_hx3_kernel (coupling nets, f16x3) + img_conv_kernel (1x1 mixes, f32)",
+                               "gbnf::img_net_hx3_kernel (one fused kernel per coupling net, f16x3) + img_conv_kernel (1x1 mixes, Split2d priors: f32)",
                      "bound": "mfma", "achieved": flops / (gpu_ms * 1e-3) / 1e12,
                      "peak": peak, "unit": "TFLOP/s", "frac": flops / (gpu_ms * 1e-3) / 1e12 / peak,
                      "vs_f32_mfma_peak": flops / (gpu_ms * 1e-3) / 1e12 / F32_MFMA_PEAK_TFLOPS,
@@ -153,7 +157,8 @@ def measured_traffic(a):
         return None
     for r in rec.get("workloads", []):
         w = r.get("workload", {})
-        if (w.get("batch"), w.get("components"), w.get("K"), w.get("L"), w.get("hidden")) == (a.batch, a.components, a.K, a.L, a.hidden) \
+        if tuple(w.get("input", (3, 32, 32))) == tuple(a.input) and \
+                (w.get("batch"), w.get("components"), w.get("K"), w.get("L"), w.get("hidden")) == (a.batch, a.components, a.K, a.L, a.hidden) \
                 and os.environ.get("GBNF_MATH", "default") == w.get("math", "default"):
             return float(r["traffic_bytes_per_step"])
     return None
