@@ -390,6 +390,61 @@ __global__ void __launch_bounds__(256) img_pre_kernel(const float* __restrict__ 
   if (threadIdx.x == 0) ldj[n] = red[0] + ld_const;
 }
 
+// ---- ActNorm2d + invertible 1x1 convolution / Permute2d of a FlowStep (models/glow.py:319-322; layers.py:488-533, 756-796):
+// out[co][pixel] = sum_ci Weff[co][ci] in[ci][pixel] + beff[co], one thread per pixel, the C inputs in registers, an ordered
+// fmaf chain per output (exact f32).  3 MB in, 3 MB out per 256-image launch at the 16-wide level: the implicit-GEMM kernel
+// (img_conv_kernel<EPI_STORE, ., 1>: 1024 workgroups that stage a strip in LDS for 12 x 12 MFMAs) took 7.6 us for it, 13 % of the
+// path's GPU time for its two levels.  CP: channels padded to the instantiation (4 .. 64).
+template <int CP>
+__global__ void __launch_bounds__(64) img_mix_kernel(const float* __restrict__ in, float* __restrict__ out, const float* __restrict__ wb /* [C][CP] | [C] */,
+                                                     int C, int HW, int W, int Hv, int Wv, int64_t total /* n HW */, const unsigned* gate) {
+  if (gate != nullptr && *gate == 0u) return;
+  const int64_t t = (int64_t)blockIdx.x * 64 + threadIdx.x;          // (one wave per workgroup: a 64-image batch still fills the chip)
+  if (t >= total) return;
+  const int64_t n = t / HW;
+  const int pix = (int)(t - n * HW);
+  const float* xi = in + n * (int64_t)C * HW + pix;
+  float* oi = out + n * (int64_t)C * HW + pix;
+  float v[CP];
+#pragma unroll
+  for (int ci = 0; ci < CP; ++ci) v[ci] = ci < C ? xi[(int64_t)ci * HW] : 0.0f;
+  const bool valid = pix / W < Hv && pix % W < Wv;           // outside the map proper the state stays zero
+  // the matrix is the same for every lane: rows padded to CP with zeros, read through the scalar cache (s_load), no LDS
+  // (a staged copy in LDS cost one dependent ds_read per multiply: 25 us for C = 24)
+  // (four rows per trip: their scalar loads are in flight together -- one row per trip waited ~0.3 us for each)
+  for (int co0 = 0; co0 < C; co0 += 4) {
+    float acc[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int co = co0 + q < C ? co0 + q : C - 1;
+      const float* wr = wb + co * CP;
+      acc[q] = wb[C * CP + co];
+#pragma unroll
+      for (int ci = 0; ci < CP; ++ci) acc[q] = fmaf(wr[ci], v[ci], acc[q]);
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+      if (co0 + q < C) oi[(int64_t)(co0 + q) * HW] = valid ? acc[q] : 0.0f;
+  }
+}
+static int mix_pad(int C) { return C <= 4 ? 4 : C <= 8 ? 8 : C <= 12 ? 12 : C <= 16 ? 16 : C <= 24 ? 24 : C <= 32 ? 32 : C <= 48 ? 48 : 64; }
+static bool launch_mix(const float* in, float* out, const float* wb, int C, int H, int W, int Hv, int Wv, int64_t n, const unsigned* gate, hipStream_t s) {
+  const int64_t total = n * H * W;
+  const dim3 grid((unsigned)((total + 63) / 64)), blk(64);
+#define GBNF_MIX(CPV) hipLaunchKernelGGL((img_mix_kernel<CPV>), grid, blk, 0, s, in, out, wb, C, H * W, W, Hv, Wv, total, gate)
+  if (C <= 4) GBNF_MIX(4);
+  else if (C <= 8) GBNF_MIX(8);
+  else if (C <= 12) GBNF_MIX(12);
+  else if (C <= 16) GBNF_MIX(16);
+  else if (C <= 24) GBNF_MIX(24);
+  else if (C <= 32) GBNF_MIX(32);
+  else if (C <= 48) GBNF_MIX(48);
+  else if (C <= 64) GBNF_MIX(64);
+  else return false;
+#undef GBNF_MIX
+  return true;
+}
+
 // squeeze2d of the first `C` channels of (n, Cin_total, H, W) -> (n, 4C, H/2, W/2)
 __global__ void __launch_bounds__(256) img_squeeze_kernel(const unsigned* gate, const float* __restrict__ in, int64_t in_img, float* __restrict__ out, int C, int H,
                                                           int W) {
@@ -560,6 +615,7 @@ struct PackedConv {
   size_t x_off = 0;              // f16x3 fragments (wide convolutions; first 3x3: taps folded into k), 0 = none
   size_t k_off = 0;              // first 3x3: im2col offset table
   int kc = 0;                    // first 3x3: 32-wide chunks of the folded contraction
+  size_t p_off = 0;              // 1x1 mixes: the plain row-major [cout][cin] matrix and [cout] bias behind it (img_mix_kernel), 0 = none
 };
 
 }  // namespace gbnf
@@ -919,6 +975,14 @@ int gbnf_image_flow_create(const gbnf_image_flow_desc* d, gbnf_image_flow** out)
       for (int m = 0; m < C; ++m) ld_const += (double)st.actnorm_logs[m] * Hv * Wv;    // models/layers.py:506-508
       f->mix.push_back(P.add(weff.data(), C, C, 1, ones, beff));
       {
+        PackedConv& pm = f->mix.back();                          // ... and the plain matrix + bias for img_mix_kernel
+        pm.p_off = P.blob.size();
+        const int CP = mix_pad(C);                               // rows padded with zeros to the kernel's instantiation
+        for (int j = 0; j < C; ++j)
+          for (int m = 0; m < CP; ++m) P.blob.push_back(m < C ? weff[(size_t)j * C + m] : 0.0f);
+        for (int j = 0; j < C; ++j) P.blob.push_back((float)beff[j]);
+      }
+      {
         // the way back (FlowStep.decode, models/glow.py:360-364): x = exp(-logs) * (W^-1 y) - bias
         std::vector<double> winv;
         if (!invert(wperm, C, &winv)) { rc = fail(GBNF_ERR_INVALID, "level %d step %d: singular 1x1 convolution", l, k); break; }
@@ -1092,9 +1156,13 @@ static int image_forward_impl(const gbnf_image_flow* f, const float* x, const fl
       p.H = H; p.W = W; p.Hv = Hv; p.Wv = Wv; p.n_strips = n_strips; p.ldj = ldj;
       // ActNorm2d + permutation: cur -> oth
       const PackedConv& m = f->mix[step];
-      p.in = cur; p.in_img = img; p.wp = blob + m.w_off; p.bias = blob + m.b_off; p.out = oth; p.out_img = img;
-      p.cin = C; p.cout = C; p.ks = 1;
-      launch_conv<EPI_STORE>(p, (int)n, s);
+      static const bool no_mix_kernel = getenv("GBNF_IMG_NO_MIX_KERNEL") != nullptr;     // diagnostic: the implicit-GEMM form
+      // (below ~8 k pixels per launch a thread per pixel leaves most of the chip idle: the implicit-GEMM form spreads the channels)
+      if (no_mix_kernel || m.p_off == 0 || n * H * W < 8192 || !launch_mix(cur, oth, blob + m.p_off, C, H, W, Hv, Wv, n, gate, s)) {
+        p.in = cur; p.in_img = img; p.wp = blob + m.w_off; p.bias = blob + m.b_off; p.out = oth; p.out_img = img;
+        p.cin = C; p.cout = C; p.ks = 1;
+        launch_conv<EPI_STORE>(p, (int)n, s);
+      }
       std::swap(cur, oth);
       // coupling net on the first half
       const std::vector<PackedConv>& net = f->net[step];
