@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Randomised stress of the image path (multi-scale Glow on 3x32x32) against the float64 oracle (opt-in, GPU).
+"""Randomised stress of the image path (multi-scale Glow; 3x32x32, 1x28x28, 1x28x20 and other shapes) against the float64 oracle (opt-in, GPU).
 usage: python tools/stress_image.py [cases] [seed]"""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -20,8 +20,12 @@ def main():
                  permutation=str(rng.choice(["invconv", "shuffle", "reverse"])), learn_top=bool(rng.randint(2)))
         n = int(rng.choice([1, 2, 3, 5, 16, 33, 64]))
         tag = f"n={n} {c}"
-        sp = synth.synth_image_glow_spec((3, 32, 32), seed=900 + k, **c)
-        x, noise = synth.synth_image_batch(n, seed=901 + k)
+        # the reference's image shapes (utils/load_data.py) and a few others that fit the 32 x 32 storage
+        shapes = [(3, 32, 32), (3, 32, 32), (1, 28, 28), (1, 28, 20), (3, 24, 16), (2, 8, 12), (1, 32, 20)]
+        size = shapes[int(rng.randint(len(shapes)))]
+        tag += f" size={size}"
+        sp = synth.synth_image_glow_spec(size, seed=900 + k, **c)
+        x, noise = synth.synth_image_batch(n, size, seed=901 + k)
         try:
             flow = native.NativeImageFlow(sp)
         except native.GbnfError as e:
