@@ -3,7 +3,7 @@
 # the W-wide level is stamped, tools/image_stamps2.py).  Never shipped.
 set -e
 cd "$(dirname "$0")/../gradient-boosted-normalizing-flows_amd/csrc"
-F="--offload-arch=gfx950 -O3 -fPIC -std=c++17 -Wno-unused-value -Wno-inline-asm -DGBNF_IMG_STAMPS=${1:-16}"
+F="--offload-arch=gfx950 -O3 -fPIC -std=c++17 -Wno-unused-value -Wno-inline-asm -DGBNF_IMG_STAMPS=${1:-16} ${GBNF_STAMP_EXTRA:-}"
 hipcc $F -c gbnf_image.hip -o /tmp/gbnf_image_stamps.o &
 hipcc $F -mllvm -amdgpu-mfma-vgpr-form=1 -c gbnf_image_net.hip -o /tmp/gbnf_image_net_stamps.o &
 wait
