@@ -19,10 +19,19 @@ __device__ __forceinline__ f32x4 img_mfma16(u32x4 a, u32x4 b, f32x4 c) {
   return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
 }
 // the compiler's MFMA-result hazard padding does not look across branches on this toolchain (tools/isa_hazard_lint.py checks)
-template <int N>
-__device__ __forceinline__ void img_drain(f32x4 (&c)[N]) {
-#pragma unroll
-  for (int k = 0; k < N; ++k) asm volatile("s_nop 7\n\ts_nop 7" : "+v"(c[k]));
+// (ONE pair of s_nop for all the tiles: every tile is an operand of the same asm, so no MFMA can be scheduled behind it and no
+// read in front of it; a pair per tile idled 16 cycles x 9 tiles at the end of every 1x1 pass)
+__device__ __forceinline__ void img_drain(f32x4 (&c)[1]) { asm volatile("s_nop 7\n\ts_nop 7" : "+v"(c[0])); }
+__device__ __forceinline__ void img_drain(f32x4 (&c)[2]) { asm volatile("s_nop 7\n\ts_nop 7" : "+v"(c[0]), "+v"(c[1])); }
+__device__ __forceinline__ void img_drain(f32x4 (&c)[3]) { asm volatile("s_nop 7\n\ts_nop 7" : "+v"(c[0]), "+v"(c[1]), "+v"(c[2])); }
+__device__ __forceinline__ void img_drain(f32x4 (&c)[4]) {
+  asm volatile("s_nop 7\n\ts_nop 7" : "+v"(c[0]), "+v"(c[1]), "+v"(c[2]), "+v"(c[3]));
+}
+__device__ __forceinline__ void img_drain(f32x4 (&c)[8]) {
+  asm volatile("s_nop 7\n\ts_nop 7" : "+v"(c[0]), "+v"(c[1]), "+v"(c[2]), "+v"(c[3]), "+v"(c[4]), "+v"(c[5]), "+v"(c[6]), "+v"(c[7]));
+}
+__device__ __forceinline__ void img_drain(f32x4 (&c)[9]) {
+  asm volatile("s_nop 7\n\ts_nop 7" : "+v"(c[0]), "+v"(c[1]), "+v"(c[2]), "+v"(c[3]), "+v"(c[4]), "+v"(c[5]), "+v"(c[6]), "+v"(c[7]), "+v"(c[8]));
 }
 // hi = f16(x) (toward zero), mid = f16(x - hi) for a pair, range-watched: amax = max(amax, |x0|, |x1|).  No clamp: both
 // conversions round TOWARD ZERO, so a value beyond the fp16 range converts to +-65504 (never to infinity) and every piece stays
