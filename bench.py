@@ -267,7 +267,7 @@ def config_legs(args):
                                      "--cpu-seconds", cpu, "--no-extra-legs", "--no-config-legs"]),
         ("hepmass_realnvp_c8_n65536", [py, bench, "--config", "hepmass_realnvp", "--steps", "256", "--warmup", "32", "--prewarm", "0.02",
                                        "--cpu-seconds", cpu, "--no-extra-legs", "--no-config-legs"]),
-        ("cifar10_glow_c4_n256", [py, os.path.join(tools, "bench_image.py"), "--batch", "256", "--steps", "10", "--warmup", "2",
+        ("cifar10_glow_c4_n256", [py, os.path.join(tools, "bench_image.py"), "--batch", "256", "--steps", "40", "--warmup", "5",
                                   "--cpu-seconds", cpu]),
         ("train_step_miniboone_c1_n65536", [py, os.path.join(tools, "bench_train.py"), "--batch", "65536", "--steps", "30", "--warmup", "5",
                                             "--cpu-steps", "2" if args.cpu_seconds > 0 else "0", "--no-torch-legs"]),

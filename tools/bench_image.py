@@ -30,8 +30,8 @@ def main():
     ap.add_argument("--hidden", type=int, default=256)
     ap.add_argument("--input", type=int, nargs=3, default=[3, 32, 32], metavar=("C", "H", "W"),
                     help="image shape: 3 32 32 (CIFAR: BASELINE configs[3], the default), 1 28 28 (MNIST / Omniglot / Caltech), 1 28 20 (Frey faces)")
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=40)        # (10 steps read 6 % low: the first replays of a fresh graph are slower)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     ap.add_argument("--graph", dest="graph", action="store_true", default=True,
                     help="capture one step in a HIP graph and replay it (default since round 3: a step is ~200 short launches and "

@@ -15,6 +15,8 @@ run bench_emul8_default python bench.py --force-gather --components 1 --cpu-seco
 run bench_emul8_default_torch python bench.py --force-gather --components 1 --cpu-seconds 0 --no-extra-legs --pipeline torch
 run image_n256 python tools/bench_image.py --batch 256 --cpu-seconds 5
 run image_n64 python tools/bench_image.py --batch 64 --cpu-seconds 0
+run image_1x28x28_n256 python tools/bench_image.py --batch 256 --input 1 28 28 --cpu-seconds 3
+run image_1x28x20_n256 python tools/bench_image.py --batch 256 --input 1 28 20 --cpu-seconds 0
 run train_n4096 python tools/bench_train.py --batch 4096 --cpu-steps 0
 run train_n65536 python tools/bench_train.py --batch 65536 --cpu-steps 2
 run train_hepmass_bs_n65536 python tools/bench_train.py --config hepmass_realnvp --batch 65536 --batch-stats --cpu-steps 0 --no-torch-legs
