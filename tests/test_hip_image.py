@@ -362,3 +362,26 @@ def test_image_inverse_on_inputs_smaller_than_the_storage(size, h, K, L, kw):
     x_or = oracle.image_component_inverse(sp, z, eps, 0.9, dtype=torch.float64)
     assert tuple(x.shape) == x_or.shape
     assert np.abs(x.cpu().numpy() - x_or).max() <= 2e-5
+
+
+def test_image_range_marks_and_repair_on_a_map_smaller_than_its_storage(monkeypatch):
+    """The marks -> gather -> exact-f32 pass -> scatter protocol with x, noise and z of the map's own size (1 x 28 x 28 in 16 x 16
+    storage): first call NaN and counted, second call repaired to the float32 oracle."""
+    import torch
+    from gbnf_amd import native, synth
+    from oracle import gbnf_oracle as oracle
+    monkeypatch.setenv("GBNF_IMAGE_NO_PROBE", "1")
+    dev = torch.device("cuda:0")
+    size = (1, 28, 28)
+    sp = _blow_up_hidden(synth.synth_image_glow_spec(size, h=64, K=2, L=2, seed=11))
+    flow = native.NativeImageFlow(sp)
+    assert native.MATH_NAME[int(flow.numerics().math_mode)] == "f16x3"
+    x, noise = synth.synth_image_batch(6, size, seed=3)
+    zo, _, _, ld32, ll32 = oracle.image_component_forward(sp, x, noise)
+    xd, nd = torch.from_numpy(x).to(dev), torch.from_numpy(noise).to(dev)
+    z, ldj, ll = flow.forward(xd, nd)
+    assert torch.isnan(ll).all() and torch.isnan(z).all()
+    z, ldj, ll = flow.forward(xd, nd)
+    assert tuple(z.shape) == zo.shape
+    assert rel_err(ll.cpu().numpy(), ll32) < LL_RTOL and rel_err(ldj.cpu().numpy(), ld32) < LL_RTOL
+    assert np.abs(z.cpu().numpy() - zo).max() <= 2e-5 * max(1.0, float(np.abs(zo).max()))
