@@ -256,7 +256,7 @@ def config_legs(args):
     that has initialised the GPU must not start another program; the children run one after the other, alone on the device):
     configs[1] MINIBOONE Boosted-Glow C=4 batch 4096, configs[2] HEPMASS Boosted-RealNVP C=8 batch 65536, configs[3] CIFAR-10
     multi-scale Boosted-Glow C=4 (batch 256, HIP-graph replay of the whole step), and the one-component training step at
-    N = 65536.  Each leg carries value / dtype / roofline{frac, executed_frac, traffic} / cpu_baseline from
+    N = 65536, and configs[4]'s per-rank load emulated on this GPU.  Each leg carries value / dtype / roofline{frac, executed_frac, traffic} / cpu_baseline from
     its own run (bounded CPU samples: ~3 s each); a leg that fails reports its error and never takes the headline down."""
     py = sys.executable
     bench = os.path.abspath(__file__)
@@ -271,9 +271,17 @@ def config_legs(args):
                                   "--cpu-seconds", cpu]),
         ("train_step_miniboone_c1_n65536", [py, os.path.join(tools, "bench_train.py"), "--batch", "65536", "--steps", "30", "--warmup", "5",
                                             "--cpu-steps", "2" if args.cpu_seconds > 0 else "0", "--no-torch-legs"]),
+        # configs[4] (MINIBOONE C = 8 sharded one component per GPU) as far as one GPU can show it: ONE rank's share of the 8-GPU
+        # run -- one component on every batch, the gather of the full (8, S N) table through the library's RCCL communicator
+        # (world size 1: the copy, not the xGMI hop), the recursion -- at the driver's own --steps 20 and in steady state
+        ("miniboone_glow_c8_one_rank_of_8_emulated_steps20", [py, bench, "--force-gather", "--components", "1", "--steps", "20", "--warmup", "5",
+                                                              "--cpu-seconds", "0", "--no-extra-legs", "--no-config-legs"]),
+        ("miniboone_glow_c8_one_rank_of_8_emulated", [py, bench, "--force-gather", "--components", "1", "--cpu-seconds", "0",
+                                                      "--no-extra-legs", "--no-config-legs"]),
     ]
     keep = ("metric", "value", "unit", "dtype", "ms_per_step", "steps", "config", "roofline", "cpu_baseline", "speedup_vs_cpu",
-            "max_rel_err_vs_cpu", "numerics_guard", "data", "batch", "stream_launches_value", "forward_kernel_ms", "backward_kernels_ms")
+            "max_rel_err_vs_cpu", "numerics_guard", "data", "batch", "stream_launches_value", "forward_kernel_ms", "backward_kernels_ms",
+            "timing")
     legs = {}
     for name, cmd in jobs:
         t0 = time.perf_counter()
