@@ -89,6 +89,9 @@ __device__ __forceinline__ void img_split_pair_w(float x0, float x1, unsigned& h
 // FULL: the map fills its storage and the hidden width fills its padding (hid == chp) -- the CIFAR configuration: every
 // per-value select on "channel exists" / "pixel belongs to the map" drops out of the tile epilogues (26 -> 22 vector and ~10
 // scalar instructions fewer per 16 x 16 tile).
+#ifndef GBNF_IMG_ABL
+#define GBNF_IMG_ABL 0
+#endif
 template <int W, int IMG_PRE_KC, int EPI, int OT3, bool FULL>
 __global__ void __launch_bounds__(512) img_net_hx3_kernel(const NetLaunch p) {
   static_assert(OT3 >= 1 && OT3 <= 3, "the last 3x3 has at most 48 output channels");
@@ -234,9 +237,13 @@ __global__ void __launch_bounds__(512) img_net_hx3_kernel(const NetLaunch p) {
             if (c < kcp) {
 #pragma unroll
               for (int pg = 0; pg < G; ++pg) {
+#if GBNF_IMG_ABL != 1                                   // (diagnostic builds, first 3x3: 1 = no MFMAs, 2 = no split, 3 = no LDS stores)
                 acc[pg] = img_mfma16(am[q][c], bh[c][pg], acc[pg]);
                 acc[pg] = img_mfma16(ah[q][c], bm[c][pg], acc[pg]);
                 acc[pg] = img_mfma16(ah[q][c], bh[c][pg], acc[pg]);
+#else
+                acc[pg] += __builtin_bit_cast(f32x4, bh[c][pg]);
+#endif
               }
             }
           }
@@ -252,11 +259,21 @@ __global__ void __launch_bounds__(512) img_net_hx3_kernel(const NetLaunch p) {
               v[r] = (FULL || co < p.hid) ? fmaxf(acc[pg][r] + pb[q][r], 0.0f) : 0.0f;
             }
             unsigned h01, m01, h23, m23;
+#if GBNF_IMG_ABL == 2
+            h01 = __builtin_bit_cast(unsigned, v[0]); m01 = __builtin_bit_cast(unsigned, v[1]);
+            h23 = __builtin_bit_cast(unsigned, v[2]); m23 = __builtin_bit_cast(unsigned, v[3]);
+#else
             img_split_pair_w(v[0], v[1], h01, m01, amax);
             img_split_pair_w(v[2], v[3], h23, m23, amax);
+#endif
             unsigned char* px = HB + (size_t)lin * pixb + 2 * (16 * o + 4 * g);
-            *reinterpret_cast<u32x2*>(px) = u32x2{h01, h23};
-            *reinterpret_cast<u32x2*>(px + 2 * chp) = u32x2{m01, m23};
+#if GBNF_IMG_ABL == 3
+            if (h01 == 0x12345678u && m23 == 0x9abcdef0u)
+#endif
+            {
+              *reinterpret_cast<u32x2*>(px) = u32x2{h01, h23};
+              *reinterpret_cast<u32x2*>(px + 2 * chp) = u32x2{m01, m23};
+            }
           }
         }
       }

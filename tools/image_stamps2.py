@@ -3,7 +3,7 @@
     tools/build_image_stamps.sh 16 && python tools/image_stamps2.py 256 16"""
 import ctypes as C, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-os.environ["GBNF_LIB_PATH"] = os.path.join(ROOT, "tools", "libgbnf_image_stamps.so")
+os.environ.setdefault("GBNF_LIB_PATH", os.path.join(ROOT, "tools", "libgbnf_image_stamps.so"))
 sys.path.insert(0, ROOT)
 import numpy as np, torch
 from gbnf_amd import native, synth
