@@ -445,31 +445,32 @@ static bool launch_mix(const float* in, float* out, const float* wb, int C, int 
   return true;
 }
 
-// squeeze2d of the first `C` channels of (n, Cin_total, H, W) -> (n, 4C, H/2, W/2)
+// squeeze2d of the first `C` channels of (n, Cin_total, H, W) -> (n, 4C, Ho, Wo) storage with Ho >= H / 2, Wo >= W / 2 (the kernels
+// work on maps at least 8 wide: the 4 x 4 map of a third level lives in the corner of 8 x 8 storage), zero outside
 __global__ void __launch_bounds__(256) img_squeeze_kernel(const unsigned* gate, const float* __restrict__ in, int64_t in_img, float* __restrict__ out, int C, int H,
-                                                          int W) {
+                                                          int W, int Ho, int Wo) {
   if (gate != nullptr && *gate == 0u) return;
-  const int n = blockIdx.x, chw = C * H * W;
+  const int n = blockIdx.x, ochw = 4 * C * Ho * Wo;
   const float* xi = in + (int64_t)n * in_img;
-  float* oi = out + (int64_t)n * chw;
-  for (int e = threadIdx.x; e < chw; e += 256) {
-    const int c = e / (H * W), rem = e % (H * W), y = rem / W, xx = rem % W;
-    const int oc = c * 4 + (y & 1) * 2 + (xx & 1);
-    oi[((int64_t)oc * (H / 2) + (y >> 1)) * (W / 2) + (xx >> 1)] = xi[e];
+  float* oi = out + (int64_t)n * ochw;
+  for (int e = threadIdx.x; e < ochw; e += 256) {
+    const int oc = e / (Ho * Wo), rem = e % (Ho * Wo), y2 = rem / Wo, x2 = rem % Wo;
+    const int c = oc >> 2, y = 2 * y2 + ((oc >> 1) & 1), xx = 2 * x2 + (oc & 1);
+    oi[e] = (y < H && xx < W) ? xi[((int64_t)c * H + y) * W + xx] : 0.0f;
   }
 }
 
 // unsqueeze2d (utils/utilities.py:121-135) of (n, 4C, H/2, W/2) into the first C channels of (n, Ctot, H, W); the next
 // `C_eps` channels are filled from eps (n, C_eps, H, W) (the standard-normal draws Split2d's reverse scales in place)
 __global__ void __launch_bounds__(256) img_unsqueeze_kernel(const float* __restrict__ in, float* __restrict__ out, int64_t out_img, int C, int H,
-                                                            int W, const float* __restrict__ eps, int C_eps, int Hv, int Wv) {
-  const int n = blockIdx.x, chw = C * H * W;
-  const float* xi = in + (int64_t)n * chw;
+                                                            int W, const float* __restrict__ eps, int C_eps, int Hv, int Wv, int Hs, int Ws) {
+  const int n = blockIdx.x, chw = C * H * W;                 // in: (n, 4C, Hs, Ws) storage with Hs >= H / 2, Ws >= W / 2
+  const float* xi = in + (int64_t)n * 4 * C * Hs * Ws;
   float* oi = out + (int64_t)n * out_img;
   for (int e = threadIdx.x; e < chw; e += 256) {
     const int c = e / (H * W), rem = e % (H * W), y = rem / W, xx = rem % W;
     const int ic = c * 4 + (y & 1) * 2 + (xx & 1);
-    oi[e] = xi[((int64_t)ic * (H / 2) + (y >> 1)) * (W / 2) + (xx >> 1)];      // (zero outside the map proper, like its input)
+    oi[e] = xi[((int64_t)ic * Hs + (y >> 1)) * Ws + (xx >> 1)];      // (zero outside the map proper, like its input)
   }
   if (eps != nullptr) {                                      // eps (n, C_eps, Hv, Wv) has the map's own size: zero around it
     const int ehw = C_eps * H * W;
@@ -624,6 +625,7 @@ using namespace gbnf;
 
 struct gbnf_image_flow {
   int C = 0, H = 0, W = 0, L = 0, K = 0, hidden = 0, additive = 0, depth = 0;   // H x W: the STORAGE of the input (32 x 32)
+  int64_t state_img = 0;                     // floats of the largest state tensor of one image over the levels (storage)
   int Hi = 0, Wi = 0;                        // the input proper (Hi <= H, Wi <= W: 32 x 32, 28 x 28, 28 x 20 ...)
   float bounds = 0.9f;
   double ld_const = 0;                       // dequantisation + every ActNorm2d / invconv log-det (per image)
@@ -920,7 +922,7 @@ int gbnf_image_flow_create(const gbnf_image_flow_desc* d, gbnf_image_flow** out)
     return fail(GBNF_ERR_UNSUPPORTED, "input %dx%dx%d: at most 32 x 32 pixels", C, Hv, Wv);
   if (!(d->bounds > 0.5f && d->bounds < 1.0f)) return fail(GBNF_ERR_INVALID, "bounds must be in (0.5, 1)");
   auto* f = new gbnf_image_flow();
-  f->C = C; f->H = H; f->W = W; f->Hi = Hv; f->Wi = Wv; f->L = d->n_levels; f->additive = d->coupling == GBNF_COUPLING_ADDITIVE;
+  f->C = C; f->H = H; f->W = W; f->Hi = Hv; f->Wi = Wv; f->L = d->n_levels; f->state_img = (int64_t)C * H * W; f->additive = d->coupling == GBNF_COUPLING_ADDITIVE;
   f->bounds = d->bounds; f->hidden = d->hidden;
   const char* env_math = getenv("GBNF_MATH");                // "f32": exact-f32 MFMA everywhere (tuning / test knob)
   const bool use_hx3 = !(env_math && !strcmp(env_math, "f32"));
@@ -934,6 +936,8 @@ int gbnf_image_flow_create(const gbnf_image_flow_desc* d, gbnf_image_flow** out)
     const gbnf_image_level& lv = d->levels[l];
     if (Hv % 2 || Wv % 2) { rc = fail(GBNF_ERR_INVALID, "level %d: odd spatial size %d x %d", l, Hv, Wv); break; }
     C *= 4; H /= 2; W /= 2; Hv /= 2; Wv /= 2;
+    if (H < 8) H = W = 8;                                        // (a third level's 4 x 4 map: the corner of 8 x 8 storage)
+    f->state_img = std::max(f->state_img, (int64_t)C * H * W);
     if (W != 16 && W != 8) { rc = fail(GBNF_ERR_UNSUPPORTED, "level %d works on %dx%d maps; compiled for widths 16 and 8 (32x32 input, <= 2 levels)", l, H, W); break; }
     if (H % IMG_R) { rc = fail(GBNF_ERR_UNSUPPORTED, "level %d: height %d not a multiple of %d", l, H, IMG_R); break; }
     if (C > 64) { rc = fail(GBNF_ERR_UNSUPPORTED, "level %d: %d channels > 64", l, C); break; }
@@ -1110,14 +1114,14 @@ int gbnf_image_flow_prior(const gbnf_image_flow* f, float* host) {
 
 // floats of the state / hidden buffers of a batch of n images
 static int64_t image_state_floats(const gbnf_image_flow* f, int64_t n) {
-  const int64_t chw = (int64_t)f->C * f->H * f->W;
+  const int64_t chw = f->state_img;
   const int64_t hid = (int64_t)f->chp * (f->H / 2) * (f->W / 2);
   return (2 * chw + 2 * hid) * n + 64;
 }
 
 int gbnf_image_flow_workspace_bytes(const gbnf_image_flow* f, int64_t n, int64_t* bytes) {
   if (!f || !bytes || n < 0) return fail(GBNF_ERR_INVALID, "gbnf_image_flow_workspace_bytes: bad argument");
-  const int64_t chw = (int64_t)f->C * f->H * f->W, zsz = (int64_t)f->zC * f->zH * f->zW;
+  const int64_t chw = f->state_img, zsz = (int64_t)f->zC * f->zH * f->zW;
   // main batch | marks | list + count | staging x, noise, z, ldj / ll of the repair batch | its state buffers
   const int64_t floats = image_state_floats(f, n) + (n + 63) / 64 * 64 + 64 + IMG_REPAIR_MAX * (2 * chw + zsz) + 64 +
                          image_state_floats(f, IMG_REPAIR_MAX);
@@ -1130,7 +1134,7 @@ int gbnf_image_flow_workspace_bytes(const gbnf_image_flow* f, int64_t n, int64_t
 // passes only): device word, 0 = every launch of the pass returns at once.
 static int image_forward_impl(const gbnf_image_flow* f, const float* x, const float* noise, int64_t n, float* z, float* ldj, float* ll,
                               float* workspace, hipStream_t s, bool force_f32, unsigned* mark, const unsigned* gate) {
-  const int64_t chw = (int64_t)f->C * f->H * f->W;
+  const int64_t chw = f->state_img;
   const int64_t hid = (int64_t)f->chp * (f->H / 2) * (f->W / 2);
   float* SA = workspace;
   float* SB = SA + chw * n;
@@ -1262,9 +1266,10 @@ static int image_forward_impl(const gbnf_image_flow* f, const float* x, const fl
       p.in = cur; p.in_img = img; p.wp = blob + c.w_off; p.bias = blob + c.b_off;
       p.st = cur + (int64_t)c1 * H * W; p.st_img = img; p.cin = c.cin; p.cout = c.cout; p.ks = c.ks;
       launch_conv<EPI_SPLIT>(p, (int)n, s);
-      hipLaunchKernelGGL(img_squeeze_kernel, dim3((unsigned)n), dim3(256), 0, s, gate, (const float*)cur, img, oth, c1, H, W);
+      const int Hn = H / 2 < 8 ? 8 : H / 2, Wn = W / 2 < 8 ? 8 : W / 2;      // storage of the next level (at least 8 wide)
+      hipLaunchKernelGGL(img_squeeze_kernel, dim3((unsigned)n), dim3(256), 0, s, gate, (const float*)cur, img, oth, c1, H, W, Hn, Wn);
       std::swap(cur, oth);
-      C = c1 * 4; H /= 2; W /= 2; Hv /= 2; Wv /= 2;
+      C = c1 * 4; H = Hn; W = Wn; Hv /= 2; Wv /= 2;
     }
   }
   hipLaunchKernelGGL(img_final_kernel, dim3((unsigned)n), dim3(256), 0, s, (const float*)cur, (int64_t)C * H * W,
@@ -1356,7 +1361,7 @@ int gbnf_image_flow_inverse(const gbnf_image_flow* f, const float* z, const floa
   gbnf_image_flow_workspace_bytes(f, n, &need);
   if (workspace_bytes < need) return fail(GBNF_ERR_INVALID, "gbnf_image_flow_inverse: workspace of %lld bytes < %lld", (long long)workspace_bytes, (long long)need);
   hipStream_t s = (hipStream_t)stream;
-  const int64_t chw = (int64_t)f->C * f->H * f->W;
+  const int64_t chw = f->state_img;
   const int64_t hid = (int64_t)f->chp * (f->H / 2) * (f->W / 2);
   float* SA = (float*)workspace;
   float* SB = SA + chw * n;
@@ -1371,7 +1376,7 @@ int gbnf_image_flow_inverse(const gbnf_image_flow* f, const float* z, const floa
     int C = f->C, H = f->H, W = f->W, Hv = f->Hi, Wv = f->Wi;
     int64_t off = 0;
     for (int l = 0; l < f->L; ++l) {
-      C *= 4; H /= 2; W /= 2; Hv /= 2; Wv /= 2;
+      C *= 4; H = H / 2 < 8 ? 8 : H / 2; W = W / 2 < 8 ? 8 : W / 2; Hv /= 2; Wv /= 2;
       LC[l] = C; LH[l] = H; LW[l] = W; LHv[l] = Hv; LWv[l] = Wv;
       if (l < f->L - 1) {
         eps_off[l] = off;
@@ -1395,7 +1400,7 @@ int gbnf_image_flow_inverse(const gbnf_image_flow* f, const float* z, const floa
     if (l < f->L - 1) {
       // the state of level l+1 (n, 4 c1, H/2, W/2) -> first c1 channels of this level; eps into the other half; Split2d reverse
       hipLaunchKernelGGL(img_unsqueeze_kernel, dim3((unsigned)n), dim3(256), 0, s, (const float*)cur, oth, img, c1, H, W,
-                         eps + eps_off[l], C - c1, Hv, Wv);
+                         eps + eps_off[l], C - c1, Hv, Wv, LH[l + 1], LW[l + 1]);
       std::swap(cur, oth);
       ConvLaunch p{};
       const PackedConv& c = f->split[l];

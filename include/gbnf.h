@@ -414,9 +414,10 @@ typedef struct gbnf_image_flow_desc {
 typedef struct gbnf_image_flow gbnf_image_flow;
 
 /* LIMITS of the image path (enforced with GBNF_ERR_UNSUPPORTED): inputs of at most 32 x 32 pixels with even sides at every squeeze,
- * 1 or 2 levels -- the reference's CIFAR-10 / SVHN (3 x 32 x 32), MNIST / Omniglot / Caltech (1 x 28 x 28) and Frey faces (1 x 28 x 20)
- * loaders, utils/load_data.py:389-529.  The kernels work on 16- and 8-wide square maps; a smaller map lives in the top-left corner
- * of that storage, zero outside (x, z, eps and noise at the boundary always have the map's own size);
+ * 1 to 3 levels -- the reference's CIFAR-10 / SVHN (3 x 32 x 32), MNIST / Omniglot / Caltech (1 x 28 x 28) and Frey faces (1 x 28 x 20)
+ * loaders, utils/load_data.py:389-529.  The kernels work on 16- and 8-wide square maps; a smaller map (a 14 x 14 first level, the
+ * 4 x 4 map of a third level) lives in the top-left corner of that storage, zero outside (x, z, eps and noise at the boundary
+ * always have the map's own size);
  * <= 64 channels per level; coupling ConvNets of hidden width <= 256 with 2 .. 5 convolutions (coupling_network_depth 0 .. 3);
  * the split-f16 kernels serve depth 1 with <= 16 input channels of the first 3 x 3, everything else runs on the exact-f32
  * convolution kernels.  Not built: y-conditioning, learned dequantisation flows, data-dependent ActNorm2d initialisation. */
