@@ -533,6 +533,45 @@ __global__ void __launch_bounds__(256) img_final_kernel(const float* __restrict_
 
 
 
+// ---- data-dependent ActNorm2d initialisation (models/layers.py:473-486): per-channel statistics over (n, the map proper) of the
+// tensor that reaches an ActNorm2d: mean[c] = mean(t), var[c] = mean((t - mean)^2) (two passes, like the reference; one block
+// per channel, fixed-order sums: bit-reproducible).  t: (n, C, H, W) storage with image stride t_img.
+__global__ void __launch_bounds__(256) img_channel_stats_kernel(const float* __restrict__ t, int64_t t_img, int64_t n, int H, int W, int Hv, int Wv,
+                                                                float* __restrict__ mean_out, float* __restrict__ var_out) {
+  __shared__ float red[256];
+  const int c = blockIdx.x;
+  const int64_t per = (int64_t)Hv * Wv, total = n * per;
+  auto at = [&](int64_t e) {
+    const int64_t img = e / per;
+    const int rem = (int)(e - img * per), y = rem / Wv, xx = rem - y * Wv;
+    return t[img * t_img + ((int64_t)c * H + y) * W + xx];
+  };
+  auto block_sum = [&](float v) {
+    red[threadIdx.x] = v;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+      if ((int)threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s];
+      __syncthreads();
+    }
+    const float r = red[0];
+    __syncthreads();
+    return r;
+  };
+  float a = 0.0f;
+  for (int64_t e = threadIdx.x; e < total; e += 256) a += at(e);
+  const float mean = block_sum(a) / (float)total;
+  float b = 0.0f;
+  for (int64_t e = threadIdx.x; e < total; e += 256) {
+    const float d = at(e) - mean;
+    b += d * d;
+  }
+  const float var = block_sum(b) / (float)total;
+  if (threadIdx.x == 0) {
+    mean_out[c] = mean;
+    var_out[c] = var;
+  }
+}
+
 // ---- numerics protocol of the split-f16 coupling nets --------------------------------------------
 // A fused coupling-net workgroup that meets an operand beyond the fp16 range raises mark[image].  Behind the f16x3 pass:
 //   img_compact_kernel   the marked images' indices, in order, into list[0 .. count)
@@ -860,8 +899,10 @@ void gbnf_debug_set_image_stamp_buffer(unsigned long long* p) { g_img_stamp_buf 
 #endif
 
 static int64_t image_state_floats(const gbnf_image_flow* f, int64_t n);
+struct ActNormStats;
 static int image_forward_impl(const gbnf_image_flow* f, const float* x, const float* noise, int64_t n, float* z, float* ldj, float* ll,
-                              float* workspace, hipStream_t s, bool force_f32, unsigned* mark, const unsigned* gate = nullptr);
+                              float* workspace, hipStream_t s, bool force_f32, unsigned* mark, const unsigned* gate = nullptr,
+                              ActNormStats* stats = nullptr);
 
 static int image_probe(gbnf_image_flow* f) {
   constexpr int PN = 4;
@@ -906,8 +947,12 @@ static int image_probe(gbnf_image_flow* f) {
   return rc;
 }
 
-int gbnf_image_flow_create(const gbnf_image_flow_desc* d, gbnf_image_flow** out) {
+int gbnf_image_flow_create(const gbnf_image_flow_desc* d, gbnf_image_flow** out) { return gbnf_image_flow_create_mode(d, GBNF_MATH_DEFAULT, out); }
+
+int gbnf_image_flow_create_mode(const gbnf_image_flow_desc* d, int32_t math_mode, gbnf_image_flow** out) {
   if (!out) return fail(GBNF_ERR_INVALID, "gbnf_image_flow_create: out is null");
+  if (math_mode != GBNF_MATH_DEFAULT && math_mode != GBNF_MATH_F32 && math_mode != GBNF_MATH_F16X3)
+    return fail(GBNF_ERR_INVALID, "gbnf_image_flow_create_mode: math mode %d (image components: DEFAULT, F32, F16X3)", math_mode);
   *out = nullptr;
   if (!d || !d->levels) return fail(GBNF_ERR_INVALID, "gbnf_image_flow_create: null descriptor");
   if (d->n_levels < 1 || d->n_levels > 4) return fail(GBNF_ERR_UNSUPPORTED, "n_levels=%d outside [1,4]", d->n_levels);
@@ -925,7 +970,7 @@ int gbnf_image_flow_create(const gbnf_image_flow_desc* d, gbnf_image_flow** out)
   f->C = C; f->H = H; f->W = W; f->Hi = Hv; f->Wi = Wv; f->L = d->n_levels; f->state_img = (int64_t)C * H * W; f->additive = d->coupling == GBNF_COUPLING_ADDITIVE;
   f->bounds = d->bounds; f->hidden = d->hidden;
   const char* env_math = getenv("GBNF_MATH");                // "f32": exact-f32 MFMA everywhere (tuning / test knob)
-  const bool use_hx3 = !(env_math && !strcmp(env_math, "f32"));
+  const bool use_hx3 = math_mode != GBNF_MATH_F32 && !(env_math && !strcmp(env_math, "f32"));
   f->math_mode = use_hx3 ? GBNF_MATH_F16X3 : GBNF_MATH_F32;
   f->chp = (d->hidden + 31) / 32 * 32;
   Packer P;
@@ -1132,9 +1177,19 @@ int gbnf_image_flow_workspace_bytes(const gbnf_image_flow* f, int64_t n, int64_t
 // One pass of the launch sequence over n images.  force_f32: every convolution on the exact-f32 kernels (the repair pass and
 // handles whose probe failed); mark: (n,) per-image range marks raised by the split-f16 coupling nets, or null; gate (exact-f32
 // passes only): device word, 0 = every launch of the pass returns at once.
+// `stats` (exact-f32 passes only): stop at ActNorm2d number stats->index of the component (module order: a step's own ActNorm2d,
+// then the one behind each Conv2d of its coupling net) and leave the per-channel statistics of the tensor that reaches it.
+struct ActNormStats {
+  int index;
+  float* mean;
+  float* var;
+  int channels;      // out: channels of that ActNorm2d (-1: index past the last one)
+};
 static int image_forward_impl(const gbnf_image_flow* f, const float* x, const float* noise, int64_t n, float* z, float* ldj, float* ll,
-                              float* workspace, hipStream_t s, bool force_f32, unsigned* mark, const unsigned* gate) {
+                              float* workspace, hipStream_t s, bool force_f32, unsigned* mark, const unsigned* gate, ActNormStats* stats) {
   const int64_t chw = f->state_img;
+  int an_index = 0;                       // ActNorm2d counter (stats)
+  if (stats != nullptr) stats->channels = -1;
   const int64_t hid = (int64_t)f->chp * (f->H / 2) * (f->W / 2);
   float* SA = workspace;
   float* SB = SA + chw * n;
@@ -1158,6 +1213,11 @@ static int image_forward_impl(const gbnf_image_flow* f, const float* x, const fl
       ConvLaunch p{};
       p.gate = gate;
       p.H = H; p.W = W; p.Hv = Hv; p.Wv = Wv; p.n_strips = n_strips; p.ldj = ldj;
+      if (stats != nullptr && an_index++ == stats->index) {      // the step's own ActNorm2d: the state as it stands
+        hipLaunchKernelGGL(img_channel_stats_kernel, dim3((unsigned)C), dim3(256), 0, s, (const float*)cur, img, n, H, W, Hv, Wv, stats->mean, stats->var);
+        stats->channels = C;
+        return hipGetLastError() == hipSuccess ? GBNF_OK : fail(GBNF_ERR_HIP, "gbnf_image_flow_actnorm_stats: launch failed");
+      }
       // ActNorm2d + permutation: cur -> oth
       const PackedConv& m = f->mix[step];
       static const bool no_mix_kernel = getenv("GBNF_IMG_NO_MIX_KERNEL") != nullptr;     // diagnostic: the implicit-GEMM form
@@ -1238,6 +1298,24 @@ static int image_forward_impl(const gbnf_image_flow* f, const float* x, const fl
       const float* hin = cur;
       int64_t hin_img = img;
       float* hb[2] = {H1, H2};
+      if (stats != nullptr && stats->index < an_index + (int)net.size() - 1) {
+        // an ActNorm2d inside this coupling net: the convolutions in front of it one by one (relu(ActNorm2d(conv)) each), then
+        // the raw output of its own convolution -- its folded scale and bias are the identity while it is un-initialised
+        const int tq = stats->index - an_index;
+        for (int q = 0; q <= tq; ++q) {
+          const PackedConv& c = net[q];
+          p.in = hin; p.in_img = hin_img; p.wp = blob + c.w_off; p.bias = blob + c.b_off;
+          p.out = hb[q & 1]; p.out_img = (int64_t)c.cout * H * W; p.cin = c.cin; p.cout = c.cout; p.ks = c.ks;
+          p.pre_in = nullptr;
+          if (q < tq) launch_conv<EPI_RELU>(p, (int)n, s);
+          else launch_conv<EPI_STORE>(p, (int)n, s);
+          hin = hb[q & 1]; hin_img = p.out_img;
+        }
+        hipLaunchKernelGGL(img_channel_stats_kernel, dim3((unsigned)net[tq].cout), dim3(256), 0, s, hin, hin_img, n, H, W, Hv, Wv, stats->mean, stats->var);
+        stats->channels = net[tq].cout;
+        return hipGetLastError() == hipSuccess ? GBNF_OK : fail(GBNF_ERR_HIP, "gbnf_image_flow_actnorm_stats: launch failed");
+      }
+      an_index += (int)net.size() - 1;
       for (size_t q = 0; q + 1 < net.size(); ++q) {
         const PackedConv& c = net[q];
         if (q == 0 && net.size() >= 3 && c.cin <= 16) continue;     // fused into the 1x1 that follows
@@ -1331,6 +1409,23 @@ int gbnf_image_flow_forward(const gbnf_image_flow* f, const float* x, const floa
                      (const unsigned*)count, repair ? 1 : 0, zsz, (const float*)zr, (const float*)ldjr, (const float*)llr, z, ldj, ll);
   const hipError_t e = hipGetLastError();
   if (e != hipSuccess) return fail(GBNF_ERR_HIP, "gbnf_image_flow_forward (repair): %s", hipGetErrorString(e));
+  return GBNF_OK;
+}
+
+int gbnf_image_flow_actnorm_stats(const gbnf_image_flow* f, const float* x, const float* noise, int64_t n, int32_t index,
+                                  float* mean_dev, float* var_dev, int32_t* channels, void* workspace, int64_t workspace_bytes, void* stream) {
+  if (!f || !x || !mean_dev || !var_dev || !workspace) return fail(GBNF_ERR_INVALID, "gbnf_image_flow_actnorm_stats: null argument");
+  if (n < 1 || index < 0) return fail(GBNF_ERR_INVALID, "gbnf_image_flow_actnorm_stats: n = %lld, index = %d", (long long)n, index);
+  int64_t need = 0;
+  gbnf_image_flow_workspace_bytes(f, n, &need);
+  if (workspace_bytes < need) return fail(GBNF_ERR_INVALID, "gbnf_image_flow_actnorm_stats: workspace of %lld bytes < %lld", (long long)workspace_bytes, (long long)need);
+  float* ws = (float*)workspace;
+  float* ldj = ws + image_state_floats(f, n);               // (scratch: the pass's own log-det accumulator)
+  ActNormStats st{index, mean_dev, var_dev, -1};
+  const int rc = image_forward_impl(f, x, noise, n, nullptr, ldj, nullptr, ws, (hipStream_t)stream, true, nullptr, nullptr, &st);
+  if (rc) return rc;
+  if (st.channels < 0) return fail(GBNF_ERR_INVALID, "gbnf_image_flow_actnorm_stats: the component has fewer than %d ActNorm2d layers", index + 1);
+  if (channels) *channels = st.channels;
   return GBNF_OK;
 }
 

@@ -8,8 +8,9 @@ reference checkpoint loads with ``load_state_dict``; every call that computes go
 Reference anchors: Glow (models/glow.py:12-110), FlowNet image branch (:192-252), FlowStep (:264-342), ActNorm2d /
 Conv2d / Conv2dZeros / Permute2d / Split2d / SqueezeLayer / InvertibleConv1x1 (models/layers.py:548-796), BoostedFlow
 (models/boosted_flow.py), the image likelihood ll = log_normal_diag(z, z_mu, z_var) + logdet (image_experiment.py:227).
-Not on the path: y_condition, learned dequantisation flows, data-dependent ActNorm initialisation (load a trained
-checkpoint or call ``set_actnorm_init``), sampling, training.
+Not on the path: y_condition, learned dequantisation flows, training.  An un-initialised model (fresh from the constructor)
+is initialised from data with ``BoostedImageFlow.initialize_actnorms(x)`` -- what the reference's first training-mode forward
+does (models/layers.py:473-486) -- or by loading a trained checkpoint / ``set_actnorm_init``.
 """
 from __future__ import annotations
 
@@ -418,6 +419,42 @@ class BoostedImageFlow(nn.Module):
         prior = self._prior_on(handle, x.device)
         shape = (x.shape[0],) + tuple(zz.shape[1:])
         return zz, prior[0].expand(shape), prior[1].expand(shape), ldj, None      # broadcast views: same values, no copies
+
+    @torch.no_grad()
+    def initialize_actnorms(self, x, components=None, noise=None):
+        """The data-dependent initialisation of every ActNorm2d of a component (the step's own and the ones behind the coupling
+        nets' Conv2d layers) from the batch ``x``: what the reference's FIRST forward in training mode does, layer by layer
+        (models/layers.py:473-486: bias = -mean, logs = log(scale / (sqrt(mean((x + bias)^2)) + 1e-6)) over (N, H, W), each layer
+        seeing the outputs of the layers initialised before it).  The statistics come from the library
+        (gbnf_image_flow_actnorm_stats, exact-f32 kernels); layers already initialised are left alone.  ``components``: an index,
+        a list, or None = all.  ``noise``: the dequantisation noise (None: drawn once, as the reference's forward would)."""
+        self._check(x)
+        x = x.contiguous().float()
+        noise = torch.rand_like(x) if noise is None else noise.contiguous().float()
+        comps = range(self.num_components) if components is None else ([int(components)] if isinstance(components, int) else list(components))
+        for c in comps:
+            glow = self.flows[c]
+            acts = glow._actnorms()
+            for idx, m in enumerate(acts):
+                if m.inited:
+                    continue
+                # every layer not yet initialised is the identity (bias = logs = 0): mark all as usable for packing, pack on exact f32
+                flags = [a.inited for a in acts]
+                for a in acts:
+                    a.inited = True
+                try:
+                    with torch.cuda.device(x.device):
+                        handle = native.NativeImageFlow(image_spec_from_glow_module(glow), math="f32")
+                        mean, var = handle.actnorm_stats(x, noise, idx)
+                finally:
+                    for a, fl in zip(acts, flags):
+                        a.inited = fl
+                if mean.numel() != m.num_features:
+                    raise native.GbnfError(f"ActNorm2d {idx} of component {c} has {m.num_features} channels, the library counted {mean.numel()}")
+                m.bias.data.copy_((-mean).view_as(m.bias))
+                m.logs.data.copy_(torch.log(float(m.scale) / (torch.sqrt(var) + 1e-6)).view_as(m.logs))
+                m.inited = True
+        self._handles.clear()
 
     def component_log_prob(self, x, n_used=None, noise=None):
         """(N, C_used): ll_c = log_normal_diag(z, z_mu, z_var) + logdet (image_experiment.py:227); the SAME noise for every

@@ -36,7 +36,7 @@ ABI_SYMBOLS = (
     "gbnf_trainer_bind_batch_stats", "gbnf_trainer_set_batch_stats",
     "gbnf_image_flow_create", "gbnf_image_flow_destroy", "gbnf_image_flow_info", "gbnf_image_flow_workspace_bytes",
     "gbnf_image_flow_forward", "gbnf_image_flow_prior", "gbnf_image_flow_eps_floats", "gbnf_image_flow_inverse",
-    "gbnf_image_flow_numerics",
+    "gbnf_image_flow_numerics", "gbnf_image_flow_create_mode", "gbnf_image_flow_actnorm_stats",
     "gbnf_comm_unique_id", "gbnf_comm_create", "gbnf_comm_destroy", "gbnf_comm_info", "gbnf_mixture_group_log_prob",
     "gbnf_group_graph_create", "gbnf_group_graph_launch", "gbnf_group_graph_destroy",
     "gbnf_flow_numerics", "gbnf_mixture_numerics", "gbnf_tuning_set", "gbnf_tuning_get",
@@ -170,6 +170,8 @@ def lib():
     L.gbnf_trainer_workspace_bytes.argtypes = [vp, i64, C.POINTER(i64)]
     L.gbnf_trainer_backward.argtypes = [vp, vp, i64, vp, vp, vp, vp, vp, vp, i64, vp]
     L.gbnf_image_flow_create.argtypes = [C.POINTER(_ImageFlowDesc), C.POINTER(vp)]
+    L.gbnf_image_flow_create_mode.argtypes = [C.POINTER(_ImageFlowDesc), i32, C.POINTER(vp)]
+    L.gbnf_image_flow_actnorm_stats.argtypes = [vp, vp, vp, i64, i32, vp, vp, C.POINTER(i32), vp, i64, vp]
     L.gbnf_image_flow_destroy.argtypes = [vp]
     L.gbnf_image_flow_info.argtypes = [vp, C.POINTER(i32), C.POINTER(i32), C.POINTER(i32), C.POINTER(C.c_double)]
     L.gbnf_image_flow_workspace_bytes.argtypes = [vp, i64, C.POINTER(i64)]
@@ -350,7 +352,7 @@ class NativeImageFlow:
     """One packed image Glow component (gbnf_image_flow).  ``spec``: the image flow spec of ``synth.synth_image_glow_spec``
     / ``spec.image_spec_from_glow_module`` (numpy arrays)."""
 
-    def __init__(self, spec):
+    def __init__(self, spec, math="default"):
         keep = _Keep()
 
         def conv(c):
@@ -396,7 +398,9 @@ class NativeImageFlow:
             keep.refs.append(top)
             desc.learn_top = C.pointer(top)
         h = C.c_void_p()
-        _check(lib().gbnf_image_flow_create(C.byref(desc), C.byref(h)))
+        if math not in ("default", "f32", "f16x3"):
+            raise GbnfError(f"image components run in math mode default | f32 | f16x3, not {math!r}")
+        _check(lib().gbnf_image_flow_create_mode(C.byref(desc), MATH[math], C.byref(h)))
         del keep
         self.handle = h
         self.input_size = tuple(int(v) for v in spec["input_size"])
@@ -413,6 +417,29 @@ class NativeImageFlow:
         st = NumericsStatus()
         _check(lib().gbnf_image_flow_numerics(self.handle, C.byref(st)))
         return st
+
+    def actnorm_stats(self, x, noise, index):
+        """gbnf_image_flow_actnorm_stats: (mean (C,), var (C,)) device tensors of the tensor that reaches ActNorm2d number
+        ``index`` (module order) on the batch -- the two numbers the reference's data-dependent initialisation needs
+        (models/layers.py:473-486)."""
+        import torch
+        _require_device_f32(x, "x")
+        if x.dim() != 4 or tuple(x.shape[1:]) != self.input_size:
+            raise GbnfError(f"x must be (n,{self.input_size}), got {tuple(x.shape)}")
+        if noise is not None:
+            _require_device_f32(noise, "noise")
+        n = x.shape[0]
+        nb = C.c_int64()
+        _check(lib().gbnf_image_flow_workspace_bytes(self.handle, n, C.byref(nb)))
+        if self._ws is None or self._ws.numel() * 4 < nb.value or self._ws.device != x.device:
+            self._ws = torch.empty((nb.value + 3) // 4, dtype=torch.float32, device=x.device)
+        mean = torch.empty(512, dtype=torch.float32, device=x.device)
+        var = torch.empty(512, dtype=torch.float32, device=x.device)
+        ch = C.c_int32()
+        ptr = lambda t: C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
+        _check(lib().gbnf_image_flow_actnorm_stats(self.handle, ptr(x), ptr(noise), n, int(index), ptr(mean), ptr(var), C.byref(ch),
+                                                   ptr(self._ws), self._ws.numel() * 4, _stream_ptr()))
+        return mean[: ch.value], var[: ch.value]
 
     def prior(self):
         """(mean (Cz,), log-variance (Cz,)) of the top prior, numpy."""

@@ -420,8 +420,11 @@ typedef struct gbnf_image_flow gbnf_image_flow;
  * always have the map's own size);
  * <= 64 channels per level; coupling ConvNets of hidden width <= 256 with 2 .. 5 convolutions (coupling_network_depth 0 .. 3);
  * the split-f16 kernels serve depth 1 with <= 16 input channels of the first 3 x 3, everything else runs on the exact-f32
- * convolution kernels.  Not built: y-conditioning, learned dequantisation flows, data-dependent ActNorm2d initialisation. */
+ * convolution kernels.  Not built: y-conditioning, learned dequantisation flows, image training. */
 int gbnf_image_flow_create(const gbnf_image_flow_desc* desc, gbnf_image_flow** out);
+/* ... with an explicit GBNF_MATH_* mode: DEFAULT (what gbnf_image_flow_create does: split-f16 coupling nets if the create-time
+ * probe passes), F32 (exact-f32 convolutions everywhere, no probe), F16X3. */
+int gbnf_image_flow_create_mode(const gbnf_image_flow_desc* desc, int32_t math_mode, gbnf_image_flow** out);
 int gbnf_image_flow_destroy(gbnf_image_flow* flow);
 /* Shape of z (per image) and the algorithmic multiply-adds per image; any pointer may be NULL. */
 int gbnf_image_flow_info(const gbnf_image_flow* flow, int32_t* z_channels, int32_t* z_height, int32_t* z_width,
@@ -445,6 +448,18 @@ int gbnf_image_flow_prior(const gbnf_image_flow* flow, float* mean_logvar_host);
  * GBNF_IMAGE_REPAIR=2: the re-evaluation pass from the very first call on (same-call repair, ~3-8 % of a call when nothing is
  * marked); =0: none (timing only).  `checks` = calls that marked an image so far. */
 int gbnf_image_flow_numerics(const gbnf_image_flow* flow, gbnf_numerics_status* out);
+/* Replaces (one layer at a time): _ActNorm.initialize_parameters for ActNorm2d (models/layers.py:473-486, 548-557), the
+ * data-dependent initialisation the first training-mode forward of an image Glow performs layer by layer.  ActNorm2d number
+ * `index` of the component in module order -- per FlowStep its own ActNorm2d, then the one behind each Conv2d of its coupling
+ * net (models/glow.py:283-308, models/layers.py:577-606) -- sees a tensor (n, channels, H, W); this call evaluates the component
+ * on (x, noise) up to that tensor with the exact-f32 kernels and writes mean_dev[c] = mean over (n, H, W) and var_dev[c] =
+ * mean((t - mean)^2) (device, `channels` floats each; *channels is set).  The caller sets bias = -mean,
+ * logs = log(scale / (sqrt(var) + 1e-6)), re-creates the handle and moves to the next index: the reference's sequence.  Valid for
+ * a layer whose bias and logs are still zero (an un-initialised ActNorm2d is the identity).  index past the last layer:
+ * GBNF_ERR_INVALID.  workspace: gbnf_image_flow_workspace_bytes(flow, n). */
+int gbnf_image_flow_actnorm_stats(const gbnf_image_flow* flow, const float* x, const float* noise, int64_t n, int32_t index,
+                                  float* mean_dev, float* var_dev, int32_t* channels, void* workspace, int64_t workspace_bytes,
+                                  void* stream);
 /* The z -> x direction.  Replaces: x = self.flows[c].decode(z, None, temperature) for image input (models/glow.py:112-123):
  * FlowNet.decode (models/glow.py:254-260) = per level, last first: Split2d reverse (models/layers.py:695-699: the dropped
  * half is re-drawn as Normal(mean, exp(log-var) * temperature) with (mean, log-var) = conv(z1)), the FlowSteps backwards

@@ -510,6 +510,53 @@ def image_component_forward(spec, x, noise, dtype=None):
     return z.numpy(), z_mu.numpy(), z_var.numpy(), ld.numpy(), ll.numpy()
 
 
+def image_actnorm_init(spec, x, noise, scale=1.0, dtype=None):
+    """The data-dependent ActNorm2d initialisation an image Glow performs on its first training-mode forward
+    (models/layers.py:473-486, 495-503 via Glow.encode, models/glow.py:92-110): every ActNorm2d -- a FlowStep's own
+    (models/glow.py:283, 319) and the one behind each Conv2d of its coupling net (models/layers.py:577-606) -- takes
+    bias = -mean(input), logs = log(scale / (sqrt(mean((input + bias)^2)) + 1e-6)) over (N, H, W) of the tensor that reaches it,
+    in forward order, each layer seeing the outputs of the layers initialised before it.  Writes the numbers into `spec` IN
+    PLACE (its an_bias / an_logs entries must be zero on entry) and returns them as a list of (bias, logs) in module order."""
+    dtype = dtype or torch.float32
+    out = []
+
+    def init(holder, t):
+        bias = -t.mean(dim=[0, 2, 3])
+        var = ((t + bias.view(1, -1, 1, 1)) ** 2).mean(dim=[0, 2, 3])
+        logs = torch.log(scale / (torch.sqrt(var) + 1e-6))
+        holder["an_bias"] = bias.to(torch.float32).numpy().copy()
+        holder["an_logs"] = logs.to(torch.float32).numpy().copy()
+        out.append((holder["an_bias"], holder["an_logs"]))
+
+    x = _t(x, dtype).clone()
+    x = (255.0 * x + _t(noise, dtype)) / 256.0
+    bounds = torch.tensor(spec["bounds"], dtype=dtype)
+    x = ((x * 2.0 - 1.0) * bounds + 1.0) / 2.0
+    z = torch.log(x) - torch.log(1.0 - x)
+    ld = torch.zeros(z.shape[0], dtype=dtype)
+    for lvl in spec["levels"]:
+        z = image_squeeze(z)
+        for st in lvl["steps"]:
+            init(st, z)
+            C = z.shape[1]
+            # the coupling net's ActNorm2d layers see relu(ActNorm2d(conv(.))) of the layers in front of them, on the step's z1
+            zz = (z + _t(st["an_bias"], dtype).view(1, -1, 1, 1)) * torch.exp(_t(st["an_logs"], dtype).view(1, -1, 1, 1))
+            if st["perm_w"] is not None:
+                zz = torch.nn.functional.conv2d(zz, _t(st["perm_w"], dtype).view(C, C, 1, 1))
+            else:
+                zz = zz[:, torch.as_tensor(np.asarray(st["perm"]), dtype=torch.long)]
+            h = zz[:, : C // 2]
+            for c in st["convs"][:-1]:
+                w = _t(c["w"], dtype)
+                raw = torch.nn.functional.conv2d(h, w, None if c["b"] is None else _t(c["b"], dtype), padding=w.shape[-1] // 2)
+                init(c, raw)
+                h = torch.relu(image_conv(c, h, dtype))
+            z, ld = image_flow_step(spec, st, z, ld, dtype)
+        if lvl["split"] is not None:
+            z = z[:, : z.shape[1] // 2]
+    return out
+
+
 def image_unsqueeze(x, factor=2):
     """unsqueeze2d, utils/utilities.py:121-135."""
     B, C, H, W = x.shape

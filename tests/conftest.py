@@ -21,7 +21,7 @@ def golden_names():
     """Forward/mixture fixtures (g1..g6).  g7 (ActNorm data-dependent init), g8 (boosting weights) and g9 (decode)
     have their own tests."""
     names = sorted(os.path.splitext(os.path.basename(p))[0] for p in glob.glob(os.path.join(GOLDEN_DIR, "*.npz")))
-    return [n for n in names if not n.startswith(("g7_", "g8_", "g9_", "g10_", "g11_", "g12_", "g16_", "g18_", "g19_"))]
+    return [n for n in names if not n.startswith(("g7_", "g8_", "g9_", "g10_", "g11_", "g12_", "g16_", "g18_", "g19_", "g20_"))]
 
 
 IMAGE_CASES = ("g12_image_glow_invconv_affine", "g12_image_glow_shuffle_additive", "g12_image_glow_lu",
@@ -47,6 +47,41 @@ def load_image_case(name):
                     st["perm_w"] = data[f"c{c}.perm_w.{k}"]; k += 1
     x, noise = synth.synth_image_batch(cfg["N"], size, seed=cfg["x_seed"])
     return cfg, specs, x, noise, data
+
+
+IMAGE_ACTNORM_INIT_CASES = ("g20_image_actnorm_init_3x32x32", "g20_image_actnorm_init_1x28x28")
+
+
+def load_image_actnorm_init_case(name, device="cpu"):
+    """g20: (cfg, mirror module with the reference's freshly constructed parameters loaded and every ActNorm2d un-initialised,
+    x, noise, [(bias, logs) of every ActNorm2d after the reference's first training-mode forward, module order])."""
+    import argparse
+    import torch
+    from gbnf_amd import BoostedFlow
+    data = dict(np.load(os.path.join(GOLDEN_DIR, name + ".npz")))
+    cfg = json.loads(bytes(data["config"]).decode())
+    size = list(cfg["input_size"])
+    args = argparse.Namespace(
+        num_flows=cfg["K"], z_size=int(np.prod(size)), density_evaluation=True, device=torch.device(device), cuda=device != "cpu",
+        component_type="glow", num_components=1, rho_init="decreasing", learn_top=True, y_classes=0, y_condition=False,
+        sample_size=4, input_size=size, h_size=cfg["h"], num_blocks=cfg["L"], actnorm_scale=1.0, flow_permutation="invconv",
+        flow_coupling="affine", LU_decomposed=False, num_dequant_blocks=0, coupling_network="tanh", coupling_network_depth=1,
+        batch_norm=False)
+    m = BoostedFlow(args)
+    sd = {k[len("before."):]: torch.from_numpy(v) for k, v in data.items() if k.startswith("before.")}
+    m.flows[0].load_state_dict(sd)
+    for a in m.flows[0]._actnorms():
+        a.inited = False
+    if device != "cpu":
+        m = m.to(device)
+    x, noise = synth_image_batch_of(cfg)
+    after = [(data[f"after.bias.{i}"], data[f"after.logs.{i}"]) for i in range(cfg["n_actnorm"])]
+    return cfg, m, x, noise, after, data
+
+
+def synth_image_batch_of(cfg):
+    from gbnf_amd import synth
+    return synth.synth_image_batch(cfg["N"], tuple(cfg["input_size"]), seed=cfg["x_seed"])
 
 
 IMAGE_DECODE_CASES = ("g16_image_decode_invconv_affine", "g16_image_decode_shuffle_additive", "g16_image_decode_lu")

@@ -593,6 +593,46 @@ def image_case(name, h=32, K=2, L=2, C=2, N=4, depth=1, coupling="affine", permu
     print(f"{name}: ll[:, :2]={np.stack(lls)[:, :2]} bpd={-np.stack(lls).mean() / (np.log(2) * np.prod(input_size)):.4f}")
 
 
+def image_actnorm_init_case(name, h=32, K=2, L=2, N=6, input_size=(3, 32, 32)):
+    """G20 (round 4): the data-dependent ActNorm2d initialisation of an image Glow by the reference itself -- a freshly
+    constructed BoostedFlow (the reference's own parameter initialisation), ONE forward in training mode on a batch
+    (models/layers.py:473-486 runs inside every un-initialised ActNorm2d), the dequantisation noise injected.  Saved: every
+    tensor of component 0's state_dict BEFORE the call, x, noise, and bias / logs of every ActNorm2d AFTER it, in module order."""
+    input_size = tuple(input_size)
+    a = ref_args("glow", int(np.prod(input_size)), h, K, 1, permutation="invconv")
+    a.input_size = list(input_size); a.num_blocks = L; a.learn_top = True; a.LU_decomposed = False
+    torch.manual_seed(11)
+    model = RefBoostedFlow(a)
+    model.train()
+    before = {k: v.detach().clone().numpy() for k, v in model.flows[0].state_dict().items()}
+    x, noise = synth.synth_image_batch(N, input_size, seed=37)
+    orig = torch.Tensor.uniform_
+    noise_t = torch.from_numpy(noise)
+
+    def injected(self, a=0.0, b=1.0):
+        self.copy_(noise_t)
+        return self
+    try:
+        torch.Tensor.uniform_ = injected
+        with torch.no_grad():
+            z, mu, var, ldj, _ = model(x=torch.from_numpy(x).clone(), components=0)
+    finally:
+        torch.Tensor.uniform_ = orig
+    from models.layers import ActNorm2d as RefActNorm2d
+    acts = [m for m in model.flows[0].modules() if isinstance(m, RefActNorm2d)]
+    assert all(m.inited for m in acts)
+    out = dict(config=np.frombuffer(json.dumps(dict(case="image_actnorm_init", h=h, K=K, L=L, N=N, input_size=list(input_size),
+                                                    x_seed=37, n_actnorm=len(acts))).encode(), dtype=np.uint8),
+               ldj=ldj.numpy().copy(), z=z.numpy().copy())
+    for k, v in before.items():
+        out["before." + k] = v
+    for i, m in enumerate(acts):
+        out[f"after.bias.{i}"] = m.bias.detach().numpy().reshape(-1).copy()
+        out[f"after.logs.{i}"] = m.logs.detach().numpy().reshape(-1).copy()
+    np.savez_compressed(os.path.join(HERE, name + ".npz"), **out)
+    print(f"{name}: {len(acts)} ActNorm2d layers, logs[0][:3]={out['after.logs.0'][:3]}, ldj[:2]={ldj.numpy()[:2]}")
+
+
 def image_decode_case(name, h=32, K=2, L=2, N=3, depth=1, coupling="affine", permutation="invconv", LU=False,
                       temperature=0.7):
     """G16: the image z -> x direction by the reference itself: Glow.decode(z, None, temperature) (models/glow.py:112-123;
@@ -684,6 +724,10 @@ def main():
         # g18 (round 4): trained-like magnitudes on the image path -- ActNorm2d logs +-3, coupling-net ActNorm2d logs +-1.5,
         # Conv2dZeros logs +-0.5 (gains exp(3 logs) up to e^1.5) -- at the full hidden width of BASELINE.json configs[3]
         image_case("g18_image_glow_trained_like_h256", h=256, K=2, L=2, C=2, N=4, trained_like=True)
+        return
+    if "--image-actnorm-init-only" in sys.argv:
+        image_actnorm_init_case("g20_image_actnorm_init_3x32x32")
+        image_actnorm_init_case("g20_image_actnorm_init_1x28x28", h=16, K=2, L=2, N=5, input_size=(1, 28, 28))
         return
     if "--image-small-only" in sys.argv:
         # g19 (round 4): the reference's other image shapes -- 1 x 28 x 28 (MNIST, Omniglot, Caltech) and 1 x 28 x 20 (Frey faces)

@@ -388,3 +388,36 @@ def test_image_range_marks_and_repair_on_a_map_smaller_than_its_storage(monkeypa
     assert tuple(z.shape) == zo.shape
     assert rel_err(ll.cpu().numpy(), ll32) < LL_RTOL and rel_err(ldj.cpu().numpy(), ld32) < LL_RTOL
     assert np.abs(z.cpu().numpy() - zo).max() <= 2e-5 * max(1.0, float(np.abs(zo).max()))
+
+
+from conftest import IMAGE_ACTNORM_INIT_CASES, load_image_actnorm_init_case  # noqa: E402
+
+
+@pytest.mark.parametrize("name", IMAGE_ACTNORM_INIT_CASES)
+def test_image_actnorm_data_init_matches_reference(name):
+    """g20: BoostedImageFlow.initialize_actnorms on a freshly constructed model (the reference's own parameter initialisation,
+    loaded through load_state_dict) against what the reference's first training-mode forward left in every ActNorm2d -- the
+    FlowSteps' own and the ones inside the coupling nets -- and the initialised model's output against the reference's output of
+    that call.  The statistics come from gbnf_image_flow_actnorm_stats (exact-f32 kernels), layer by layer."""
+    import torch
+    cfg, m, x, noise, after, data = load_image_actnorm_init_case(name, device="cuda:0")
+    dev = torch.device("cuda:0")
+    xd, nd = torch.from_numpy(x).to(dev), torch.from_numpy(noise).to(dev)
+    glow = m.flows[0]
+    assert not any(a.inited for a in glow._actnorms())
+    with pytest.raises(ValueError):
+        m.eval(); m.component_log_prob(xd, noise=nd)            # un-initialised: loud, like the reference (models/layers.py:473-475)
+    m.initialize_actnorms(xd, noise=nd)
+    acts = glow._actnorms()
+    assert all(a.inited for a in acts) and len(acts) == len(after)
+    for a, (rb, rl) in zip(acts, after):
+        assert np.abs(a.bias.detach().cpu().numpy().reshape(-1) - rb).max() <= 1e-5 * max(1.0, float(np.abs(rb).max()))
+        assert np.abs(a.logs.detach().cpu().numpy().reshape(-1) - rl).max() <= 1e-5 * max(1.0, float(np.abs(rl).max()))
+    m.eval()
+    zz, ldj, ll = m.native_flow(0).forward(xd, nd)
+    assert rel_err(ldj.cpu().numpy(), data["ldj"]) < LL_RTOL
+    assert np.abs(zz.cpu().numpy() - data["z"]).max() <= 2e-5 * max(1.0, float(np.abs(data["z"]).max()))
+    # a second call leaves an initialised model alone
+    before = [a.logs.detach().clone() for a in acts]
+    m.initialize_actnorms(xd * 0.5, noise=nd)
+    assert all(torch.equal(b, a.logs.detach()) for b, a in zip(before, acts))

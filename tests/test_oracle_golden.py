@@ -185,3 +185,29 @@ def test_oracle_train_mode_batch_norm_matches_reference():
         np.testing.assert_allclose(0.9 * st["bn"]["running_mean"] + 0.1 * m, data["running_mean"][k], rtol=0, atol=1e-6)
         np.testing.assert_allclose(0.9 * st["bn"]["running_var"] + 0.1 * v, data["running_var"][k], rtol=0, atol=1e-6)
         k += 1
+
+
+from conftest import IMAGE_ACTNORM_INIT_CASES, load_image_actnorm_init_case  # noqa: E402
+
+
+@pytest.mark.parametrize("name", IMAGE_ACTNORM_INIT_CASES)
+def test_oracle_image_actnorm_init_matches_reference(name):
+    """g20: the oracle's restatement of the data-dependent ActNorm2d initialisation against what the reference's first
+    training-mode forward left in its ActNorm2d layers (a freshly constructed reference model, its own parameter init)."""
+    from gbnf_amd import image_glow
+    from oracle import gbnf_oracle as oracle
+    cfg, m, x, noise, after, data = load_image_actnorm_init_case(name)
+    glow = m.flows[0]
+    acts = glow._actnorms()
+    assert len(acts) == cfg["n_actnorm"] and all(float(a.logs.abs().max()) == 0.0 and float(a.bias.abs().max()) == 0.0 for a in acts)
+    for a in acts:
+        a.inited = True                                    # (packing flag only: the numbers are still the identity)
+    spec = image_glow.image_spec_from_glow_module(glow)
+    got = oracle.image_actnorm_init(spec, x, noise)
+    assert len(got) == len(after)
+    for (b, l), (rb, rl) in zip(got, after):
+        assert np.abs(b - rb).max() <= 1e-5 * max(1.0, float(np.abs(rb).max()))
+        assert np.abs(l - rl).max() <= 1e-5 * max(1.0, float(np.abs(rl).max()))
+    # ... and the initialised model's forward is the reference's own output of that first call
+    z, _, _, ld, _ = oracle.image_component_forward(spec, x, noise)
+    assert rel_err(ld, data["ldj"]) < 1e-5 and np.abs(z - data["z"]).max() <= 2e-5 * max(1.0, float(np.abs(data["z"]).max()))
