@@ -127,12 +127,12 @@ def main():
     z, ldj, trace = tr.forward(x, want_trace=True)
     g_z = (z / n).contiguous(); g_l = torch.full((n,), -1.0 / n, device=dev)
     torch.cuda.synchronize()
-    fw = bw = 0.0
+    fws, bws = [], []
     for _ in range(a.steps):
         ev[0].record(); tr.forward(x, want_trace=True); ev[1].record(); tr.backward(x, g_z, g_l, trace=trace); ev[2].record()
         torch.cuda.synchronize()
-        fw += ev[0].elapsed_time(ev[1]); bw += ev[1].elapsed_time(ev[2])
-    fw /= a.steps; bw /= a.steps
+        fws.append(ev[0].elapsed_time(ev[1])); bws.append(ev[1].elapsed_time(ev[2]))
+    fw, bw = float(np.median(fws)), float(np.median(bws))          # (medians: one hiccup of the box must not move the kernel times)
     t_gpu_torch = None if a.no_torch_legs else timed(torch_step(spec, x, dev), a.steps, a.warmup)
     torch.set_num_threads(min(8, os.cpu_count() or 1))
     # CPU baseline: the same step (torch-CPU autograd over the oracle's op order) on a BOUNDED sample of the batch's rows
