@@ -199,7 +199,7 @@ def test_oracle_image_actnorm_init_matches_reference(name):
     cfg, m, x, noise, after, data = load_image_actnorm_init_case(name)
     glow = m.flows[0]
     acts = glow._actnorms()
-    assert len(acts) == cfg["n_actnorm"] and all(float(a.logs.abs().max()) == 0.0 and float(a.bias.abs().max()) == 0.0 for a in acts)
+    assert len(acts) == cfg["n_actnorm"] and all(float(a.logs.detach().abs().max()) == 0.0 and float(a.bias.detach().abs().max()) == 0.0 for a in acts)
     for a in acts:
         a.inited = True                                    # (packing flag only: the numbers are still the identity)
     spec = image_glow.image_spec_from_glow_module(glow)

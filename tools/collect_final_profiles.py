@@ -142,11 +142,13 @@ def main():
                               "WRITE_SIZE_kb_per_step": wt["WRITE_SIZE"] / steps,
                               "traffic_bytes_per_step": (ft["FETCH_SIZE"] * 2048 + wt["WRITE_SIZE"] * 1024) / steps}]}
         json.dump(rec, open(os.path.join(P, "train_traffic.json"), "w"), indent=1)
-    for nm, title in (("stats_train", "MINIBOONE Glow one component, N = 65536 (tools/bench_train.py --batch 65536)"),
+    for nm, title in (("stats_hm", "configs[2] HEPMASS Boosted-RealNVP C = 8, N = 65536 (bench.py --config hepmass_realnvp --batch 65536 --steps 64)"),
+                      ("stats_c4", "configs[1] MINIBOONE Boosted-Glow C = 4, N = 4096 (bench.py --components 4 --steps 128)"),
+                      ("stats_train", "MINIBOONE Glow one component, N = 65536 (tools/bench_train.py --batch 65536)"),
                       ("stats_train_bs", "HEPMASS RealNVP one component, N = 65536, BatchNorm on batch statistics (tools/bench_train.py --config hepmass_realnvp --batch-stats)")):
         rows = stats_rows(nm, 12)
         if rows:
-            open(os.path.join(P, f"{tag}_final_{nm}.txt"), "w").write(f"# rocprofv3 --kernel-trace --stats, training step: {title}\n" + "\n".join(rows) + "\n")
+            open(os.path.join(P, f"{tag}_final_{nm}.txt"), "w").write(f"# rocprofv3 --kernel-trace --stats: {title}\n" + "\n".join(rows) + "\n")
     lines = [("bench_default", "bench_line"), ("bench_steps20", "bench_line_driver_invocation_steps20"),
              ("bench_hepmass", "bench_line_hepmass_realnvp_n65536"), ("bench_c4", "bench_line_miniboone_c4"), ("bench_bf16x6", "bench_line_bf16x6"),
              ("bench_emul8_steps20", "bench_line_emulated_8gpu_c1_steps20"), ("bench_emul8_default", "bench_line_emulated_8gpu_c1"),

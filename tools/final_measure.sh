@@ -50,7 +50,9 @@ prof pmc_write_train --pmc WRITE_SIZE -d $O/pmc_write_train -o w --output-format
 TRB="python3 tools/bench_train.py --config hepmass_realnvp --batch 65536 --batch-stats --cpu-steps 0 --no-torch-legs --steps 20 --warmup 3"
 prof stats_train_bs --stats -d $O/stats_train_bs -o s --output-format csv -- $TRB
 for d in pmc_fetch pmc_write pmc_sq1 pmc_sq2 pmc_fetch_s20 pmc_write_s20 pmc_fetch_c4 pmc_write_c4 pmc_fetch_hm pmc_write_hm pmc_fetch_img pmc_write_img pmc_sq_img pmc_fetch_train pmc_write_train; do python tools/pmc_summary.py $O/$d > $O/$d.txt 2>&1; done
-for d in prof_stats stats_img stats_train stats_train_bs; do find $O/$d -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} $O/$d.kernel_stats.csv; done
+prof stats_hm --stats -d $O/stats_hm -o s --output-format csv -- $HM
+prof stats_c4 --stats -d $O/stats_c4 -o s --output-format csv -- $C4
+for d in prof_stats stats_img stats_train stats_train_bs stats_hm stats_c4; do find $O/$d -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} $O/$d.kernel_stats.csv; done
 find $O -name "*.csv" -size +1M -delete
 find $O -name "*.db" -delete
 cat $O/rc.txt
