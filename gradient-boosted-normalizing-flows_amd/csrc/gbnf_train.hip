@@ -1288,9 +1288,11 @@ __global__ void __launch_bounds__(WG_THREADS) wgrad_kernel(const WgProblem* __re
 #undef WG_CASE
 }
 // the block of a problem and its 8 waves (wm x wn; every wave TM x TN tiles of 16 x 16 with TM = bm / (16 wm), TN = bn / (16 wn))
-static void wg_shape(int M, int N, WgProblem& P) {
-  P.bm = M <= 64 ? 64 : (M <= 128 ? 128 : 256);
-  P.bn = N <= 64 ? 64 : (N <= 128 ? 128 : 256);
+// (cap: largest block edge -- 256 for big batches, where every operand row must be loaded once; 128 for small ones, where the
+// operands fit the L2s and what counts is the number of workgroups)
+static void wg_shape(int M, int N, WgProblem& P, int cap = 256) {
+  P.bm = M <= 64 ? 64 : (M <= 128 || cap <= 128 ? 128 : 256);
+  P.bn = N <= 64 ? 64 : (N <= 128 || cap <= 128 ? 128 : 256);
   struct S { int bm, bn, wm, wn; };
   static const S table[] = {{256, 256, 2, 4}, {256, 128, 4, 2}, {256, 64, 8, 1}, {128, 256, 2, 4}, {64, 256, 1, 8},
                             {128, 128, 2, 4}, {128, 64, 4, 2},  {64, 128, 2, 4}, {64, 64, 2, 4}};
@@ -1458,6 +1460,8 @@ struct gbnf_trainer {
   TrStep* steps_dev = nullptr;
   int* tail_dev = nullptr;
   WgProblem* probs_dev = nullptr;
+  WgProblem* probs_small_dev = nullptr;     // the same problems cut into blocks of at most 128 x 128 (small batches)
+  int wg_blocks_small = 0;
   PrepProblem* prep_dev = nullptr;
   u32x4* frag_dev = nullptr;           // split-f16 weight fragments, rebuilt by prep_kernel at the start of every call
   int n_probs = 0, wg_blocks = 0, n_prep = 0, prep_blocks = 0;
@@ -1679,6 +1683,19 @@ int gbnf_trainer_create(const gbnf_flow_desc* desc, gbnf_trainer** out) {
   if (e == hipSuccess) e = hipMemcpy(t->tail_dev, tail.data(), sizeof(int) * 64, hipMemcpyHostToDevice);
   if (e == hipSuccess) e = hipMalloc((void**)&t->probs_dev, sizeof(WgProblem) * probs.size());
   if (e == hipSuccess) e = hipMemcpy(t->probs_dev, probs.data(), sizeof(WgProblem) * probs.size(), hipMemcpyHostToDevice);
+  {
+    std::vector<WgProblem> small = probs;
+    int b = 0;
+    for (WgProblem& P : small) {
+      wg_shape(P.M, P.N, P, 128);
+      P.nb = (P.N + P.bn - 1) / P.bn;
+      P.blk_begin = b;
+      b += ((P.M + P.bm - 1) / P.bm) * P.nb;
+    }
+    t->wg_blocks_small = b;
+    if (e == hipSuccess) e = hipMalloc((void**)&t->probs_small_dev, sizeof(WgProblem) * small.size());
+    if (e == hipSuccess) e = hipMemcpy(t->probs_small_dev, small.data(), sizeof(WgProblem) * small.size(), hipMemcpyHostToDevice);
+  }
   if (e == hipSuccess) e = hipMalloc((void**)&t->prep_dev, sizeof(PrepProblem) * preps.size());
   if (e == hipSuccess) e = hipMemcpy(t->prep_dev, preps.data(), sizeof(PrepProblem) * preps.size(), hipMemcpyHostToDevice);
   if (e == hipSuccess) e = hipMalloc((void**)&t->frag_dev, (size_t)frag_off * 16);
@@ -1721,6 +1738,7 @@ int gbnf_trainer_destroy(gbnf_trainer* t) {
   if (t->steps_dev) (void)hipFree(t->steps_dev);
   if (t->tail_dev) (void)hipFree(t->tail_dev);
   if (t->probs_dev) (void)hipFree(t->probs_dev);
+  if (t->probs_small_dev) (void)hipFree(t->probs_small_dev);
   if (t->prep_dev) (void)hipFree(t->prep_dev);
   if (t->frag_dev) (void)hipFree(t->frag_dev);
   if (t->gmax_dev) (void)hipFree(t->gmax_dev);
@@ -1975,13 +1993,18 @@ int gbnf_trainer_backward(const gbnf_trainer* t, const float* x, int64_t n, cons
     // per block 64.9 / 66.7 / 63.8 M samples/s, N = 16384 with 512 / 1024 / 2048: 46.1 / 49.2 / 41.2 M, N = 4096 with 128 / 256 /
     // 512: 16.5 / 19.1 / 18.8 M; every further chunk adds a bm x bn tile of float atomics per block of dW, every chunk less leaves
     // CUs idle.
+    // (up to 16 k rows the operands fit the L2s: blocks of at most 128 x 128 -- twice the workgroups)
+    static const int small_np = [] { const char* e = getenv("GBNF_WG_SMALL_NP"); return e ? atoi(e) : 16384; }();
+    const bool small = p.np <= small_np && t->probs_small_dev != nullptr;
+    const WgProblem* wg_probs = small ? t->probs_small_dev : t->probs_dev;
+    const int wg_blocks = small ? t->wg_blocks_small : t->wg_blocks;
     int chunk2 = 128;
-    while (chunk2 < 2048 && (int64_t)t->wg_blocks * (p.np / (2 * chunk2)) >= 240) chunk2 *= 2;
+    while (chunk2 < 2048 && (int64_t)wg_blocks * (p.np / (2 * chunk2)) >= 240) chunk2 *= 2;
     if (const char* e = getenv("GBNF_WG_CHUNK")) { if (atoi(e) > 0) chunk2 = atoi(e); }      // (A/B runs)
     // (+ 2 K blocks: the sums of the backward kernel's parameter-gradient partials ride in this launch)
-    const dim3 wgrid2((unsigned)(t->wg_blocks + 2 * red.K), (unsigned)((p.np + chunk2 - 1) / chunk2));
-    hipLaunchKernelGGL(wgrad_kernel, wgrid2, dim3(WG_THREADS), WG_LDS_BYTES, s, t->probs_dev, t->n_probs,
-                       (const float*)acts, grads, p.np, chunk2, (const unsigned*)t->gmax_dev, t->wg_blocks, red);
+    const dim3 wgrid2((unsigned)(wg_blocks + 2 * red.K), (unsigned)((p.np + chunk2 - 1) / chunk2));
+    hipLaunchKernelGGL(wgrad_kernel, wgrid2, dim3(WG_THREADS), WG_LDS_BYTES, s, wg_probs, t->n_probs,
+                       (const float*)acts, grads, p.np, chunk2, (const unsigned*)t->gmax_dev, wg_blocks, red);
     const hipError_t e2 = hipGetLastError();
     if (e2 != hipSuccess) return fail(GBNF_ERR_HIP, "gbnf_trainer_backward launch: %s", hipGetErrorString(e2));
     return GBNF_OK;
