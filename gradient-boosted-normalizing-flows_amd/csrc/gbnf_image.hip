@@ -59,6 +59,8 @@ struct ConvLaunch {
   int Hv, Wv;             // the map proper: rows < Hv, columns < Wv of the H x W storage (a 14 x 14 map lives in 16 x 16 storage;
                           // everything outside is ZERO in every tensor in HBM -- the 'same' padding of the map -- and stays so)
   float temperature;      // EPI_SPLIT_INV: z2 = mean + exp(log-var) * temperature * eps (models/layers.py:697)
+  int c_chunk;            // input channels staged per pass (a multiple of 16; 0 = all: 3 x 3 convolutions from > 256 channels do not
+                          // fit the LDS at once and stage their input in two halves; split-contraction form only)
   int o_split;            // workgroups sharing one strip, each with 1/o_split of the output tiles (fills the chip at small batch)
   // fused producer (1x1 convolutions only): the input of this convolution is relu(conv3x3(pre_in) + pre_bias), computed
   // for the strip straight into LDS instead of being read from `in` (the ConvNet's first layer never touches HBM)
@@ -171,24 +173,26 @@ __global__ void __launch_bounds__(64 * IMG_WAVES) img_conv_kernel(const ConvLaun
       load9(o + 2 * IMG_WAVES, af[0]);
       if (o + IMG_WAVES < kc) pre_tile(o + IMG_WAVES, af[1]);
     }
-  } else
-  // ---- stage the strip (+ halo, zero padded) of every input channel: one image row = W/4 16-byte loads
-  {
+  }
+  // ---- stage the strip (+ halo, zero padded) of the input channels [cb, cb + cn): one image row = W/4 16-byte loads
+  const int c_chunk = (p.c_chunk > 0 && p.c_chunk < cin_pad) ? p.c_chunk : cin_pad;
+  auto stage_channels = [&](int cb, int cn) {
     const float* src = p.in + (int64_t)n * p.in_img;
     constexpr int Q = W / 4;                                 // float4s per image row
     const int q = threadIdx.x % Q, rid = threadIdx.x / Q;
     constexpr int ROWS_PER_PASS = 64 * IMG_WAVES / Q;
-    for (int idx = rid; idx < cin_pad * RP; idx += ROWS_PER_PASS) {
-      const int ci = idx / RP, rr = idx - ci * RP;
+    for (int idx = rid; idx < cn * RP; idx += ROWS_PER_PASS) {
+      const int cl = idx / RP, rr = idx - cl * RP, ci = cb + cl;
       const int row = r0 + rr - HALO;
       f32x4 v = {0.f, 0.f, 0.f, 0.f};
       if (ci < p.cin && row >= 0 && row < H) v = *reinterpret_cast<const f32x4*>(src + ((int64_t)ci * H + row) * W + 4 * q);
-      float* dst = lds + ci * CS + rr * WP + HALO + 4 * q;
+      float* dst = lds + cl * CS + rr * WP + HALO + 4 * q;
       dst[0] = v[0]; dst[1] = v[1]; dst[2] = v[2]; dst[3] = v[3];
       if (HALO && q == 0) dst[-1] = 0.0f;                    // left / right zero columns
       if (HALO && q == Q - 1) dst[4] = 0.0f;
     }
-  }
+  };
+  if (!(KS == 1 && p.pre_in != nullptr)) stage_channels(0, c_chunk);
   __syncthreads();
 
   // pixel of lane i in tile pt: linear index 16 pt + i inside the strip (row-major over IMG_R x W)
@@ -205,18 +209,22 @@ __global__ void __launch_bounds__(64 * IMG_WAVES) img_conv_kernel(const ConvLaun
   const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
 
   // one output tile over the iterations [t_begin, t_end) with stride t_step: acc[pt] += ...
-  auto run_tile = [&](int o, int t_begin, int t_end, int t_step, f32x4 (&acc)[PT]) {
+  // (iterations t = (tap, c) over the kcc 16-channel groups staged at the moment, the first of which is group cb16 of the
+  // convolution: the weight fragment of an iteration is (tap, cb16 + c) of the tile)
+  auto run_tile = [&](int o, int t_begin, int t_end, int t_step, f32x4 (&acc)[PT], int cb16 = 0, int kcc_ = -1) {
+    const int kcc = kcc_ < 0 ? kc : kcc_;
     const gptr wo = wp + ((size_t)o * T_all) * 256 + lane * 4;
+    auto widx = [&](int t) { const int tap = t / kcc; return tap * kc + cb16 + (t - tap * kcc); };
     f32x4 ring[IMG_PD];
     int tl = t_begin;
 #pragma unroll
-    for (int j = 0; j < IMG_PD; ++j) {                       // unconditional: past the end re-reads the last fragment
+    for (int j = 0; j < IMG_PD; ++j) {                       // unconditional: past the end re-reads the first fragment
       const int tt = tl < t_end ? tl : 0;
-      ring[j] = *reinterpret_cast<const f32x4 __attribute__((address_space(1)))*>(wo + (size_t)tt * 256);
+      ring[j] = *reinterpret_cast<const f32x4 __attribute__((address_space(1)))*>(wo + (size_t)widx(tt) * 256);
       tl += t_step;
     }
     auto body = [&](const f32x4& a, int t) {
-      const int tap = t / kc, c = t - tap * kc;
+      const int tap = t / kcc, c = t - tap * kcc;
       const int dy = tap / KS - half, dx = tap % KS - half;
       const float* b0 = lds + (16 * c) * CS + dy * WP + dx;
 #pragma unroll
@@ -231,7 +239,7 @@ __global__ void __launch_bounds__(64 * IMG_WAVES) img_conv_kernel(const ConvLaun
       for (int j = 0; j < IMG_PD; ++j) {
         body(ring[j], t);
         const int tt = tl < t_end ? tl : 0;
-        ring[j] = *reinterpret_cast<const f32x4 __attribute__((address_space(1)))*>(wo + (size_t)tt * 256);
+        ring[j] = *reinterpret_cast<const f32x4 __attribute__((address_space(1)))*>(wo + (size_t)widx(tt) * 256);
         tl += t_step;
         t += t_step;
       }
@@ -317,14 +325,23 @@ __global__ void __launch_bounds__(64 * IMG_WAVES) img_conv_kernel(const ConvLaun
     constexpr int MAXO = IMG_WAVES - 1;
     f32x4 part[MAXO][PT];
 #pragma unroll
-    for (int o = 0; o < MAXO; ++o) {
+    for (int o = 0; o < MAXO; ++o)
 #pragma unroll
       for (int pt = 0; pt < PT; ++pt) part[o][pt] = zero;
-      if (o < OT) {
-        run_tile(o, wave, T_all, IMG_WAVES, part[o]);
-        img_drain(part[o]);
+    for (int cb = 0; cb < cin_pad; cb += c_chunk) {          // (one pass unless the input channels are staged in halves)
+      const int cn = cb + c_chunk <= cin_pad ? c_chunk : cin_pad - cb;
+      if (cb > 0) {
+        __syncthreads();                                     // everybody is done with the previous channels
+        stage_channels(cb, cn);
+        __syncthreads();
       }
+#pragma unroll
+      for (int o = 0; o < MAXO; ++o)
+        if (o < OT) run_tile(o, wave, taps * (cn >> 4), IMG_WAVES, part[o], cb >> 4, cn >> 4);
     }
+#pragma unroll
+    for (int o = 0; o < MAXO; ++o)
+      if (o < OT) img_drain(part[o]);
     __syncthreads();                                         // nobody reads the strip any more
     f32x4* red = reinterpret_cast<f32x4*>(lds);              // [wave][o][pt][64]
 #pragma unroll
@@ -867,9 +884,14 @@ void launch_conv(const ConvLaunch& p, int n, hipStream_t s) {
   const int per_ch = (IMG_R + 2 * halo) * (p.W + 2 * halo);
   const int kc = (p.cin + 15) / 16, OT = (p.cout + 15) / 16, PT = IMG_R * p.W / 16;
   size_t lds = (size_t)kc * 16 * per_ch * 4;
+  ConvLaunch q = p;
+  q.c_chunk = 0;
+  if (lds > 150 * 1024 && OT < IMG_WAVES && p.pre_in == nullptr) {      // a 3 x 3 from 512 channels: its strip in two halves
+    q.c_chunk = ((kc + 1) / 2) * 16;
+    lds = (size_t)q.c_chunk * per_ch * 4;
+  }
   if (p.pre_in != nullptr) lds += (size_t)((p.pre_cin + 15) / 16) * 16 * (IMG_R + 2) * (p.W + 2) * 4;
   if (OT < IMG_WAVES) lds = std::max(lds, (size_t)IMG_WAVES * (IMG_WAVES - 1) * PT * 64 * 16);
-  ConvLaunch q = p;
   q.o_split = 1;
   if (OT >= 2 * IMG_WAVES && (int64_t)n * p.n_strips < 512) q.o_split = 2;      // < 2 workgroups per CU otherwise
   if (OT >= 4 * IMG_WAVES && (int64_t)n * p.n_strips < 256) q.o_split = 4;
@@ -970,7 +992,9 @@ int gbnf_image_flow_create_mode(const gbnf_image_flow_desc* d, int32_t math_mode
   f->C = C; f->H = H; f->W = W; f->Hi = Hv; f->Wi = Wv; f->L = d->n_levels; f->state_img = (int64_t)C * H * W; f->additive = d->coupling == GBNF_COUPLING_ADDITIVE;
   f->bounds = d->bounds; f->hidden = d->hidden;
   const char* env_math = getenv("GBNF_MATH");                // "f32": exact-f32 MFMA everywhere (tuning / test knob)
-  const bool use_hx3 = math_mode != GBNF_MATH_F32 && !(env_math && !strcmp(env_math, "f32"));
+  // (hidden widths above 256 -- the usual Glow width is 512 -- run on the exact-f32 convolutions: the split-f16 kernels keep a
+  // strip's hidden activation in LDS, 150 KB at 256 channels)
+  const bool use_hx3 = math_mode != GBNF_MATH_F32 && !(env_math && !strcmp(env_math, "f32")) && d->hidden <= 256;
   f->math_mode = use_hx3 ? GBNF_MATH_F16X3 : GBNF_MATH_F32;
   f->chp = (d->hidden + 31) / 32 * 32;
   Packer P;
@@ -1047,7 +1071,7 @@ int gbnf_image_flow_create_mode(const gbnf_image_flow_desc* d, int32_t math_mode
       // ConvNet: Conv2d 3x3 (+ActNorm2d), [Conv2d 1x1 (+ActNorm2d)] x depth, Conv2dZeros 3x3
       if (st.n_convs < 2 || st.n_convs > 5 || !st.convs) { rc = fail(GBNF_ERR_INVALID, "level %d step %d: needs 2..5 convolutions", l, k); break; }
       const int hdim = st.convs[0].out_channels;
-      if (hdim < 1 || hdim > 256) { rc = fail(GBNF_ERR_UNSUPPORTED, "hidden width %d outside [1,256]", hdim); break; }
+      if (hdim < 1 || hdim > 512) { rc = fail(GBNF_ERR_UNSUPPORTED, "hidden width %d outside [1,512]", hdim); break; }
       std::vector<PackedConv> net;
       for (int q = 0; q < st.n_convs && rc == GBNF_OK; ++q) {
         const bool first = q == 0, last = q == st.n_convs - 1;

@@ -292,7 +292,10 @@ def test_image_well_scaled_model_stays_on_split_f16_and_unmarked():
                                            ((3, 24, 16), 48, 2, 2, {"coupling": "additive", "permutation": "reverse"}),
                                            ((1, 28, 28), 32, 2, 2, {"depth": 0, "learn_top": False}), ((2, 8, 12), 16, 1, 1, {}),
                                            # three levels: the 4 x 4 (3 x 3) map of the last one in the corner of 8 x 8 storage
-                                           ((3, 32, 32), 64, 2, 3, {}), ((1, 24, 24), 32, 1, 3, {"coupling": "additive"}), ((1, 16, 16), 32, 2, 2, {})])
+                                           ((3, 32, 32), 64, 2, 3, {}), ((1, 24, 24), 32, 1, 3, {"coupling": "additive"}), ((1, 16, 16), 32, 2, 2, {}),
+                                           # hidden widths above 256 (the usual Glow width is 512): exact-f32 convolutions, the last 3 x 3's
+                                           # 512-channel strip staged in two halves
+                                           ((3, 32, 32), 512, 1, 2, {}), ((1, 28, 28), 384, 1, 2, {"coupling": "additive"}), ((3, 32, 32), 300, 1, 1, {"depth": 2})])
 @pytest.mark.parametrize("math", ["default", "f32"])
 def test_image_inputs_smaller_than_the_storage_match_oracle(size, h, K, L, kw, math, monkeypatch):
     """The reference's other image loaders hand over 1 x 28 x 28 and 1 x 28 x 20 (utils/load_data.py:389-529).  Such a map lives in
@@ -346,7 +349,7 @@ def test_image_module_dropin_on_28x28_matches_reference():
 
 @pytest.mark.parametrize("size,h,K,L,kw", [((1, 28, 28), 64, 2, 2, {}), ((1, 28, 20), 32, 2, 2, {"coupling": "additive", "permutation": "shuffle"}),
                                            ((1, 28, 28), 32, 2, 1, {}), ((3, 24, 16), 32, 1, 2, {"depth": 2}),
-                                           ((3, 32, 32), 32, 2, 3, {}), ((1, 24, 24), 32, 1, 3, {})])
+                                           ((3, 32, 32), 32, 2, 3, {}), ((1, 24, 24), 32, 1, 3, {}), ((3, 32, 32), 512, 1, 2, {})])
 def test_image_inverse_on_inputs_smaller_than_the_storage(size, h, K, L, kw):
     """z -> x for the padded maps against the float64 oracle's Glow.decode (Split2d draws injected)."""
     import torch
