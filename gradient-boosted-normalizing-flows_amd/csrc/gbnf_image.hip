@@ -624,6 +624,15 @@ __global__ void __launch_bounds__(256) img_compact_kernel(const unsigned* __rest
   }
 }
 
+// z -> x on the split-f16 coupling nets: an image whose hidden activation left the fp16 range comes back as NaN (never a clamped
+// value) and raises the handle's `seen` word -- from then on the handle's inverse runs on the exact-f32 convolutions
+__global__ void __launch_bounds__(256) img_nan_marked_kernel(const unsigned* __restrict__ mark, float* __restrict__ x, int64_t chw, unsigned* seen_host) {
+  const int n = blockIdx.x;
+  if (mark[n] == 0u) return;
+  for (int64_t e = threadIdx.x; e < chw; e += 256) x[(int64_t)n * chw + e] = __builtin_nanf("");
+  if (threadIdx.x == 0 && seen_host != nullptr) atomicAdd_system(seen_host, 1u);
+}
+
 __global__ void __launch_bounds__(256) img_gather_kernel(const float* __restrict__ x, const float* __restrict__ noise, int64_t chw,
                                                          const unsigned* __restrict__ list, const unsigned* __restrict__ count,
                                                          float* __restrict__ xs, float* __restrict__ ns) {
@@ -1067,6 +1076,15 @@ int gbnf_image_flow_create_mode(const gbnf_image_flow_desc* d, int32_t math_mode
           for (int j = 0; j < C; ++j) wi[(size_t)m * C + j] = (float)winv[(size_t)m * C + j];
         }
         f->mix_inv.push_back(P.add(wi.data(), C, C, 1, rs, bi));
+        {
+          // ... and the plain matrix diag(rs) . W^-1 with its bias for img_mix_kernel
+          PackedConv& pm = f->mix_inv.back();
+          pm.p_off = P.blob.size();
+          const int CP = mix_pad(C);
+          for (int m = 0; m < C; ++m)
+            for (int j = 0; j < CP; ++j) P.blob.push_back(j < C ? (float)(rs[m] * (double)wi[(size_t)m * C + j]) : 0.0f);
+          for (int m = 0; m < C; ++m) P.blob.push_back((float)bi[m]);
+        }
       }
       // ConvNet: Conv2d 3x3 (+ActNorm2d), [Conv2d 1x1 (+ActNorm2d)] x depth, Conv2dZeros 3x3
       if (st.n_convs < 2 || st.n_convs > 5 || !st.convs) { rc = fail(GBNF_ERR_INVALID, "level %d step %d: needs 2..5 convolutions", l, k); break; }
@@ -1509,6 +1527,15 @@ int gbnf_image_flow_inverse(const gbnf_image_flow* f, const float* z, const floa
 
   float* cur = SA;
   float* oth = SB;
+  // split-f16 coupling nets (the fused kernel, as the forward) unless the handle runs on exact f32 or has SEEN an out-of-range
+  // image before (either direction): such a call runs the exact-f32 convolutions.  Marks of THIS call: NaN for the image.
+  const bool fast = f->math_mode == GBNF_MATH_F16X3 && image_repair_mode() != 0 &&
+                    !(f->seen_host != nullptr && ((volatile unsigned*)f->seen_host)[0] != 0u);
+  unsigned* mark = nullptr;
+  if (fast) {
+    mark = reinterpret_cast<unsigned*>((float*)workspace + image_state_floats(f, n));
+    if (hipMemsetAsync(mark, 0, (size_t)n * 4, s) != hipSuccess) return fail(GBNF_ERR_HIP, "gbnf_image_flow_inverse: memset failed");
+  }
   hipLaunchKernelGGL(img_embed_kernel, dim3((unsigned)n), dim3(256), 0, s, z, cur, f->zC, LH[f->L - 1], LW[f->L - 1], f->zH, f->zW);
   for (int l = f->L - 1; l >= 0; --l) {
     const int C = LC[l], H = LH[l], W = LW[l], Hv = LHv[l], Wv = LWv[l];
@@ -1532,12 +1559,30 @@ int gbnf_image_flow_inverse(const gbnf_image_flow* f, const float* z, const floa
       const size_t step = step_end - (size_t)(K - k);
       ConvLaunch p{};
       p.H = H; p.W = W; p.Hv = Hv; p.Wv = Wv; p.n_strips = n_strips; p.ldj = nullptr;
-      // coupling^-1: the net reads the first half (unchanged by the step), exact-f32 convolutions
+      // coupling^-1: the net reads the first half (unchanged by the step)
       const std::vector<PackedConv>& net = f->net[step];
+      const bool fusable = fast && H == W && (W == 16 || W == 8) && net.size() == 3 && net[1].x_off != 0 &&
+                           img_net_hx3_lds(W, f->chp, net[0].cin, net[0].kc, net[2].cout) != 0;
+      bool coupled = false;
+      if (fusable) {                                          // the fused split-f16 coupling-net kernel with the epilogue's way back
+        NetLaunch q{};
+        q.pre_in = cur; q.pre_in_img = img; q.pre_wp = reinterpret_cast<const unsigned*>(blob + net[0].x_off);
+        q.pre_bias = blob + net[0].b_off; q.pre_kc = net[0].kc; q.pre_cin = net[0].cin;
+        q.pre_koff = reinterpret_cast<const int*>(blob + net[0].k_off);
+        q.wp = reinterpret_cast<const unsigned*>(blob + net[1].x_off); q.bias = blob + net[1].b_off;
+        q.wp3 = reinterpret_cast<const unsigned*>(blob + net[2].x_off); q.bias3 = blob + net[2].b_off;
+        q.st = cur + (int64_t)c1 * H * W; q.st_img = img; q.ldj = nullptr;
+        q.hid = net[1].cout; q.chp = f->chp; q.cout = net[2].cout; q.H = H; q.Hv = Hv; q.Wv = Wv; q.inverse = 1;
+        q.sat = reinterpret_cast<unsigned long long*>(gbnf::saturation_counter());
+        q.mark = mark; q.only = nullptr;
+        const hipError_t le = img_net_hx3_launch(q, W, f->additive != 0, n, s);
+        if (le != hipSuccess) return fail(GBNF_ERR_HIP, "img_net_hx3 launch (inverse) failed: %s", hipGetErrorString(le));
+        coupled = true;
+      }
       const float* hin = cur;
       int64_t hin_img = img;
       float* hb[2] = {H1, H2};
-      for (size_t q = 0; q + 1 < net.size(); ++q) {
+      for (size_t q = 0; !coupled && q + 1 < net.size(); ++q) {      // exact-f32 convolutions
         const PackedConv& c = net[q];
         if (q == 0 && net.size() >= 3 && c.cin <= 16) continue;     // fused into the 1x1 that follows
         p.in = hin; p.in_img = hin_img; p.wp = blob + c.w_off; p.bias = blob + c.b_off;
@@ -1551,21 +1596,27 @@ int gbnf_image_flow_inverse(const gbnf_image_flow* f, const float* z, const floa
         p.pre_in = nullptr;
         hin = hb[q & 1]; hin_img = p.out_img;
       }
-      const PackedConv& c = net.back();
-      p.in = hin; p.in_img = hin_img; p.wp = blob + c.w_off; p.bias = blob + c.b_off; p.out = nullptr;
-      p.st = cur + (int64_t)c1 * H * W; p.st_img = img; p.cin = c.cin; p.cout = c.cout; p.ks = c.ks;
-      if (f->additive) launch_conv<EPI_COUPLE_ADD_INV>(p, (int)n, s);
-      else launch_conv<EPI_COUPLE_AFFINE_INV>(p, (int)n, s);
+      if (!coupled) {
+        const PackedConv& c = net.back();
+        p.in = hin; p.in_img = hin_img; p.wp = blob + c.w_off; p.bias = blob + c.b_off; p.out = nullptr;
+        p.st = cur + (int64_t)c1 * H * W; p.st_img = img; p.cin = c.cin; p.cout = c.cout; p.ks = c.ks;
+        if (f->additive) launch_conv<EPI_COUPLE_ADD_INV>(p, (int)n, s);
+        else launch_conv<EPI_COUPLE_AFFINE_INV>(p, (int)n, s);
+      }
       // (invconv / Permute2d)^-1 + ActNorm2d reverse: cur -> oth
       const PackedConv& m = f->mix_inv[step];
-      p.in = cur; p.in_img = img; p.wp = blob + m.w_off; p.bias = blob + m.b_off; p.out = oth; p.out_img = img; p.st = nullptr;
-      p.cin = C; p.cout = C; p.ks = 1;
-      launch_conv<EPI_STORE>(p, (int)n, s);
+      if (m.p_off == 0 || n * H * W < 8192 || !launch_mix(cur, oth, blob + m.p_off, C, H, W, Hv, Wv, n, nullptr, s)) {
+        p.in = cur; p.in_img = img; p.wp = blob + m.w_off; p.bias = blob + m.b_off; p.out = oth; p.out_img = img; p.st = nullptr;
+        p.cin = C; p.cout = C; p.ks = 1;
+        launch_conv<EPI_STORE>(p, (int)n, s);
+      }
       std::swap(cur, oth);
     }
     step_end -= (size_t)K;
   }
   hipLaunchKernelGGL(img_post_kernel, dim3((unsigned)n), dim3(256), 0, s, (const float*)cur, x, f->C, f->H, f->W, f->Hi, f->Wi, f->bounds);
+  if (fast)
+    hipLaunchKernelGGL(img_nan_marked_kernel, dim3((unsigned)n), dim3(256), 0, s, (const unsigned*)mark, x, (int64_t)f->C * f->Hi * f->Wi, f->seen_host);
   const hipError_t e = hipGetLastError();
   if (e != hipSuccess) return fail(GBNF_ERR_HIP, "gbnf_image_flow_inverse: %s", hipGetErrorString(e));
   return GBNF_OK;

@@ -26,6 +26,7 @@ struct NetLaunch {
   int64_t st_img;
   float* ldj;
   int hid, chp, cout, H;
+  int inverse;              // 1: the coupling's way back (models/glow.py:349-355): z2 - h, or z2 / scale - shift; no log-det
   int Hv, Wv;               // the map proper inside its H x W storage (gbnf_image.hip, ConvLaunch): rows < Hv, columns < Wv
   unsigned bf_off;          // byte offset of the first 3x3's B-fragment buffer in LDS (set by img_net_hx3_launch)
   unsigned long long* sat;  // per-device counter of workgroups that met an operand beyond the fp16 range, or null

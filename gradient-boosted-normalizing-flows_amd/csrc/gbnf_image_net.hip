@@ -595,7 +595,8 @@ __global__ void __launch_bounds__(512) img_net_hx3_kernel(const NetLaunch p) {
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
             const int co = 16 * o + 4 * g + r;
-            if (co < p.cout && valid) st[(int64_t)co * H * W + pix] = z2v[o][r] + (acc[r] + b3v[o][r]);        // models/glow.py:328-329
+            const float hh = acc[r] + b3v[o][r];
+            if (co < p.cout && valid) st[(int64_t)co * H * W + pix] = p.inverse ? z2v[o][r] - hh : z2v[o][r] + hh;   // models/glow.py:328-329, 349-350
           }
         } else {
 #pragma unroll
@@ -606,8 +607,12 @@ __global__ void __launch_bounds__(512) img_net_hx3_kernel(const NetLaunch p) {
               float* zp = st + (int64_t)j * H * W + pix;
               const float e = __expf(-(h1 + 2.0f));                     // scale = sigmoid(raw + 2), models/glow.py:333
               const float sc = 1.0f / (1.0f + e);
-              *zp = (z2v[o][2 * qq] + h0) * sc;                         // models/glow.py:334-335
-              ld += -0.69314718055994531f * __builtin_amdgcn_logf(1.0f + e);      // log(scale) = -log(1 + e), models/glow.py:338 (v_log_f32: 1 ulp)
+              if (p.inverse) {
+                *zp = z2v[o][2 * qq] * (1.0f + e) - h0;                 // z2 / scale - shift, models/glow.py:352-355
+              } else {
+                *zp = (z2v[o][2 * qq] + h0) * sc;                       // models/glow.py:334-335
+                ld += -0.69314718055994531f * __builtin_amdgcn_logf(1.0f + e);    // log(scale) = -log(1 + e), models/glow.py:338 (v_log_f32: 1 ulp)
+              }
             }
           }
         }
@@ -617,7 +622,7 @@ __global__ void __launch_bounds__(512) img_net_hx3_kernel(const NetLaunch p) {
   if constexpr (EPI == EPI_COUPLE_AFFINE) {
 #pragma unroll
     for (int m = 1; m < 64; m <<= 1) ld += __shfl_xor(ld, m);
-    if (lane == 0 && wave < NPO) atomicAdd(p.ldj + n, ld);
+    if (lane == 0 && wave < NPO && !p.inverse) atomicAdd(p.ldj + n, ld);
   }
   IMG_STAMP(6);
 #ifdef GBNF_IMG_STAMPS

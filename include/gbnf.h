@@ -468,7 +468,10 @@ int gbnf_image_flow_actnorm_stats(const gbnf_image_flow* flow, const float* x, c
  * z (n,Cz,Hz,Wz); x (n,C,H,W).  eps: the standard-normal draws behind Split2d's samples (the caller's RNG, so that
  * sampling is reproducible and testable): level 0 first, each level a contiguous (n, C_l/2, H_l, W_l) array,
  * gbnf_image_flow_eps_floats() floats per image in all (= C*H*W - Cz*Hz*Wz); may be NULL for a one-level flow.
- * The coupling networks run on the exact-f32 convolution kernels.  workspace as for gbnf_image_flow_forward. */
+ * The coupling networks run on the fused split-f16 kernel like the forward (round 4) where the handle does; an image whose
+ * hidden activation leaves the fp16 range comes back as NaN (never a clamped value) and raises the handle's `seen` word
+ * (gbnf_image_flow_numerics.checks) -- from the next call on the handle's inverse runs on the exact-f32 convolution kernels,
+ * as it always does for a handle created with GBNF_MATH_F32 or demoted by the probe.  workspace as for gbnf_image_flow_forward. */
 int gbnf_image_flow_eps_floats(const gbnf_image_flow* flow, int64_t* per_image);
 int gbnf_image_flow_inverse(const gbnf_image_flow* flow, const float* z, const float* eps, float temperature, int64_t n,
                             float* x, void* workspace, int64_t workspace_bytes, void* stream);

@@ -424,3 +424,36 @@ def test_image_actnorm_data_init_matches_reference(name):
     before = [a.logs.detach().clone() for a in acts]
     m.initialize_actnorms(xd * 0.5, noise=nd)
     assert all(torch.equal(b, a.logs.detach()) for b, a in zip(before, acts))
+
+
+def test_image_inverse_on_split_f16_marks_then_runs_exact(monkeypatch):
+    """z -> x runs the fused split-f16 coupling-net kernel like the forward.  An image whose hidden activation leaves the fp16
+    range comes back as NaN (never a clamped value) and raises the handle's `seen` word; from the next call on the handle's
+    inverse runs on the exact-f32 convolutions and matches the oracle."""
+    import torch
+    from gbnf_amd import native, synth
+    from oracle import gbnf_oracle as oracle
+    monkeypatch.setenv("GBNF_IMAGE_NO_PROBE", "1")
+    dev = torch.device("cuda:0")
+    size = (3, 32, 32)
+    sp = _blow_up_hidden(synth.synth_image_glow_spec(size, h=64, K=2, L=2, seed=11))
+    flow = native.NativeImageFlow(sp)
+    assert native.MATH_NAME[int(flow.numerics().math_mode)] == "f16x3"
+    rng = np.random.RandomState(5)
+    n = 4
+    z = (0.7 * rng.standard_normal((n,) + flow.z_shape)).astype(np.float32)
+    eps = [rng.standard_normal((n,) + tuple(sh)).astype(np.float32) for sh in flow.split_shapes()]
+    zd, ed = torch.from_numpy(z).to(dev), [torch.from_numpy(e).to(dev) for e in eps]
+    x1 = flow.inverse(zd, ed, 0.9)
+    torch.cuda.synchronize()
+    assert torch.isnan(x1).all()                               # every image of this model is out of range: loud, not wrong
+    assert int(flow.numerics().checks) >= 1
+    x2 = flow.inverse(zd, ed, 0.9)                             # the handle has seen a mark: exact-f32 convolutions
+    x_or = oracle.image_component_inverse(sp, z, eps, 0.9, dtype=torch.float64)
+    assert np.abs(x2.cpu().numpy() - x_or).max() <= 2e-5
+    # a well-scaled model stays on the fast kernels and agrees with the exact-f32 handle
+    sp2 = synth.synth_image_glow_spec(size, h=64, K=2, L=2, seed=12)
+    fast = native.NativeImageFlow(sp2)
+    exact = native.NativeImageFlow(sp2, math="f32")
+    xa, xb = fast.inverse(zd, ed, 0.9), exact.inverse(zd, ed, 0.9)
+    assert int(fast.numerics().checks) == 0 and float((xa - xb).abs().max()) <= 2e-5
