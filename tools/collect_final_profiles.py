@@ -149,6 +149,11 @@ def main():
         rows = stats_rows(nm, 12)
         if rows:
             open(os.path.join(P, f"{tag}_final_{nm}.txt"), "w").write(f"# rocprofv3 --kernel-trace --stats: {title}\n" + "\n".join(rows) + "\n")
+    inv = os.path.join(F, "image_inverse.txt")
+    if os.path.exists(inv):
+        keep = [l for l in open(inv).read().splitlines() if l.startswith("one component")]
+        open(os.path.join(P, f"{tag}_final_image_inverse.txt"), "w").write(
+            "# tools/bench_image_inverse.py: z -> x (sampling) and x -> z of ONE image Glow component (K = 8, L = 2, h = 256), plain stream launches\n" + "\n".join(keep) + "\n")
     lines = [("bench_default", "bench_line"), ("bench_steps20", "bench_line_driver_invocation_steps20"),
              ("bench_hepmass", "bench_line_hepmass_realnvp_n65536"), ("bench_c4", "bench_line_miniboone_c4"), ("bench_bf16x6", "bench_line_bf16x6"),
              ("bench_emul8_steps20", "bench_line_emulated_8gpu_c1_steps20"), ("bench_emul8_default", "bench_line_emulated_8gpu_c1"),
