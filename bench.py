@@ -461,6 +461,14 @@ def main():
             except (native.GbnfError, RuntimeError, OSError) as e:
                 pipeline_used["fallback_reason"] = f"{type(e).__name__}: {e}"
                 pipe = None
+            if world > 1:
+                # every rank or none: a rank that could not build the library pipeline takes all of them to the torch.distributed form
+                # (two forms in one job would wait for each other's collectives forever)
+                okt = torch.tensor([1 if pipe is not None else 0], dtype=torch.int32, device=dev)
+                dist.all_reduce(okt, op=dist.ReduceOp.MIN)
+                if pipe is not None and int(okt.item()) == 0:
+                    pipeline_used["fallback_reason"] = "another rank could not build the library pipeline"
+                    pipe = None
         if pipe is None:
             pipe = sharded.GroupPipeline(mix, C, c0, c1, rho, B, group, gather, overlap=steps > group)
             pipeline_used["kind"] = "torch.distributed" if gather else "single rank"
