@@ -69,7 +69,6 @@ struct ConvLaunch {
   const float* pre_wp;    // packed 3x3 weights [cin/16 tiles][9][pre_kc][64][4]
   const float* pre_bias;
   int pre_cin;
-  const unsigned* gate;   // repair launches: *gate == 0 (no image was marked) -> the whole launch returns at once; null = always run
 };
 
 __device__ __forceinline__ f32x4 img_mfma(float a, float b, f32x4 c) {
@@ -84,15 +83,14 @@ __device__ __forceinline__ void img_drain(f32x4 (&c)[N]) {
 
 // EPI: see enum.  PT: pixel tiles per strip (2 or 4).  KS: 1 or 3 (a 1x1 convolution stages no halo: half the LDS,
 // two workgroups per CU).
+// The work of one workgroup: strip `strip` of image `n`, share `osp` of the output tiles.  A device function so that the repair
+// kernel (img_repair_kernel: one workgroup walks a marked image through the whole exact-f32 sequence) runs the same code.
 template <int EPI, int PT, int KS>
-__global__ void __launch_bounds__(64 * IMG_WAVES) img_conv_kernel(const ConvLaunch p) {
+__device__ __forceinline__ void img_conv_body(const ConvLaunch& p, const int n, const int strip, const int osp) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
-  if (p.gate != nullptr && *p.gate == 0u) return;
   typedef const float __attribute__((address_space(1)))* gptr;
   const int lane = threadIdx.x & 63, i = lane & 15, g = lane >> 4;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int osp = blockIdx.x % p.o_split, bid = blockIdx.x / p.o_split;
-  const int n = bid / p.n_strips, strip = bid % p.n_strips;
   constexpr int W = 16 * PT / IMG_R;                        // the strip is IMG_R full rows: W = 16 (PT = 4) or 8 (PT = 2)
   constexpr int HALO = KS >> 1;
   constexpr int WP = W + 2 * HALO, RP = IMG_R + 2 * HALO, CS = RP * WP;   // padded row / rows / channel stride in LDS
@@ -369,14 +367,18 @@ __global__ void __launch_bounds__(64 * IMG_WAVES) img_conv_kernel(const ConvLaun
   }
 }
 
+template <int EPI, int PT, int KS>
+__global__ void __launch_bounds__(64 * IMG_WAVES) img_conv_kernel(const ConvLaunch p) {
+  const int osp = blockIdx.x % p.o_split, bid = blockIdx.x / p.o_split;
+  img_conv_body<EPI, PT, KS>(p, bid / p.n_strips, bid % p.n_strips, osp);
+}
+
 // ---- dequantise + logit + first squeeze (models/glow.py:125-179; utils/utilities.py:107-119) -------------------
 // x (n, C, Hi, Wi) in [0,1] (+ uniform noise or null) -> squeezed logits (n, 4C, H/2, W/2) in H x W STORAGE (Hi <= H, Wi <= W:
 // a 28 x 28 input lives in the top-left 14 x 14 of 16 x 16 maps, zero outside); ldj[n] = its log-det over the real pixels.
-__global__ void __launch_bounds__(256) img_pre_kernel(const float* __restrict__ x, const float* __restrict__ noise, float* __restrict__ out,
-                                                      float* __restrict__ ldj, int C, int H, int W, int Hi, int Wi, float bounds, float ld_const,
-                                                      const unsigned* gate) {
-  if (gate != nullptr && *gate == 0u) return;
-  const int n = blockIdx.x, chw = C * H * W, xchw = C * Hi * Wi;
+__device__ __forceinline__ void img_pre_body(const float* __restrict__ x, const float* __restrict__ noise, float* __restrict__ out,
+                                             float* __restrict__ ldj, int C, int H, int W, int Hi, int Wi, float bounds, float ld_const, const int n) {
+  const int chw = C * H * W, xchw = C * Hi * Wi;
   const float* xi = x + (int64_t)n * xchw;
   float* oi = out + (int64_t)n * chw;
   const float soft_c = log1pf((1.0f - bounds) / bounds);     // softplus(log(1-b) - log(b))
@@ -405,6 +407,11 @@ __global__ void __launch_bounds__(256) img_pre_kernel(const float* __restrict__ 
     __syncthreads();
   }
   if (threadIdx.x == 0) ldj[n] = red[0] + ld_const;
+  __syncthreads();                                           // (red is reused by the caller's next phase in the repair kernel)
+}
+__global__ void __launch_bounds__(256) img_pre_kernel(const float* __restrict__ x, const float* __restrict__ noise, float* __restrict__ out,
+                                                      float* __restrict__ ldj, int C, int H, int W, int Hi, int Wi, float bounds, float ld_const) {
+  img_pre_body(x, noise, out, ldj, C, H, W, Hi, Wi, bounds, ld_const, (int)blockIdx.x);
 }
 
 // ---- ActNorm2d + invertible 1x1 convolution / Permute2d of a FlowStep (models/glow.py:319-322; layers.py:488-533, 756-796):
@@ -414,8 +421,7 @@ __global__ void __launch_bounds__(256) img_pre_kernel(const float* __restrict__ 
 // path's GPU time for its two levels.  CP: channels padded to the instantiation (4 .. 64).
 template <int CP>
 __global__ void __launch_bounds__(64) img_mix_kernel(const float* __restrict__ in, float* __restrict__ out, const float* __restrict__ wb /* [C][CP] | [C] */,
-                                                     int C, int HW, int W, int Hv, int Wv, int64_t total /* n HW */, const unsigned* gate) {
-  if (gate != nullptr && *gate == 0u) return;
+                                                     int C, int HW, int W, int Hv, int Wv, int64_t total /* n HW */) {
   const int64_t t = (int64_t)blockIdx.x * 64 + threadIdx.x;          // (one wave per workgroup: a 64-image batch still fills the chip)
   if (t >= total) return;
   const int64_t n = t / HW;
@@ -445,10 +451,10 @@ __global__ void __launch_bounds__(64) img_mix_kernel(const float* __restrict__ i
   }
 }
 static int mix_pad(int C) { return C <= 4 ? 4 : C <= 8 ? 8 : C <= 12 ? 12 : C <= 16 ? 16 : C <= 24 ? 24 : C <= 32 ? 32 : C <= 48 ? 48 : 64; }
-static bool launch_mix(const float* in, float* out, const float* wb, int C, int H, int W, int Hv, int Wv, int64_t n, const unsigned* gate, hipStream_t s) {
+static bool launch_mix(const float* in, float* out, const float* wb, int C, int H, int W, int Hv, int Wv, int64_t n, hipStream_t s) {
   const int64_t total = n * H * W;
   const dim3 grid((unsigned)((total + 63) / 64)), blk(64);
-#define GBNF_MIX(CPV) hipLaunchKernelGGL((img_mix_kernel<CPV>), grid, blk, 0, s, in, out, wb, C, H * W, W, Hv, Wv, total, gate)
+#define GBNF_MIX(CPV) hipLaunchKernelGGL((img_mix_kernel<CPV>), grid, blk, 0, s, in, out, wb, C, H * W, W, Hv, Wv, total)
   if (C <= 4) GBNF_MIX(4);
   else if (C <= 8) GBNF_MIX(8);
   else if (C <= 12) GBNF_MIX(12);
@@ -464,10 +470,9 @@ static bool launch_mix(const float* in, float* out, const float* wb, int C, int 
 
 // squeeze2d of the first `C` channels of (n, Cin_total, H, W) -> (n, 4C, Ho, Wo) storage with Ho >= H / 2, Wo >= W / 2 (the kernels
 // work on maps at least 8 wide: the 4 x 4 map of a third level lives in the corner of 8 x 8 storage), zero outside
-__global__ void __launch_bounds__(256) img_squeeze_kernel(const unsigned* gate, const float* __restrict__ in, int64_t in_img, float* __restrict__ out, int C, int H,
-                                                          int W, int Ho, int Wo) {
-  if (gate != nullptr && *gate == 0u) return;
-  const int n = blockIdx.x, ochw = 4 * C * Ho * Wo;
+__device__ __forceinline__ void img_squeeze_body(const float* __restrict__ in, int64_t in_img, float* __restrict__ out, int C, int H, int W, int Ho,
+                                                 int Wo, const int n) {
+  const int ochw = 4 * C * Ho * Wo;
   const float* xi = in + (int64_t)n * in_img;
   float* oi = out + (int64_t)n * ochw;
   for (int e = threadIdx.x; e < ochw; e += 256) {
@@ -476,44 +481,52 @@ __global__ void __launch_bounds__(256) img_squeeze_kernel(const unsigned* gate, 
     oi[e] = (y < H && xx < W) ? xi[((int64_t)c * H + y) * W + xx] : 0.0f;
   }
 }
+__global__ void __launch_bounds__(256) img_squeeze_kernel(const float* __restrict__ in, int64_t in_img, float* __restrict__ out, int C, int H, int W,
+                                                          int Ho, int Wo) {
+  img_squeeze_body(in, in_img, out, C, H, W, Ho, Wo, (int)blockIdx.x);
+}
 
 // unsqueeze2d (utils/utilities.py:121-135) of (n, 4C, H/2, W/2) into the first C channels of (n, Ctot, H, W); the next
 // `C_eps` channels are filled from eps (n, C_eps, H, W) (the standard-normal draws Split2d's reverse scales in place)
-__global__ void __launch_bounds__(256) img_unsqueeze_kernel(const float* __restrict__ in, float* __restrict__ out, int64_t out_img, int C, int H,
-                                                            int W, const float* __restrict__ eps, int C_eps, int Hv, int Wv, int Hs, int Ws) {
-  const int n = blockIdx.x, chw = C * H * W;                 // in: (n, 4C, Hs, Ws) storage with Hs >= H / 2, Ws >= W / 2
-  const float* xi = in + (int64_t)n * 4 * C * Hs * Ws;
-  float* oi = out + (int64_t)n * out_img;
+// (body: xi / oi / ei = this image's input, output and eps)
+__device__ __forceinline__ void img_unsqueeze_body(const float* __restrict__ xi, float* __restrict__ oi, int C, int H, int W,
+                                                   const float* __restrict__ ei, int C_eps, int Hv, int Wv, int Hs, int Ws) {
+  const int chw = C * H * W;                                 // in: (4C, Hs, Ws) storage with Hs >= H / 2, Ws >= W / 2
   for (int e = threadIdx.x; e < chw; e += 256) {
     const int c = e / (H * W), rem = e % (H * W), y = rem / W, xx = rem % W;
     const int ic = c * 4 + (y & 1) * 2 + (xx & 1);
     oi[e] = xi[((int64_t)ic * Hs + (y >> 1)) * Ws + (xx >> 1)];      // (zero outside the map proper, like its input)
   }
-  if (eps != nullptr) {                                      // eps (n, C_eps, Hv, Wv) has the map's own size: zero around it
+  if (ei != nullptr) {                                       // eps (n, C_eps, Hv, Wv) has the map's own size: zero around it
     const int ehw = C_eps * H * W;
     for (int e = threadIdx.x; e < ehw; e += 256) {
       const int c = e / (H * W), rem = e % (H * W), y = rem / W, xx = rem % W;
-      oi[chw + e] = (y < Hv && xx < Wv) ? eps[(((int64_t)n * C_eps + c) * Hv + y) * Wv + xx] : 0.0f;
+      oi[chw + e] = (y < Hv && xx < Wv) ? ei[((int64_t)c * Hv + y) * Wv + xx] : 0.0f;
     }
   }
 }
+__global__ void __launch_bounds__(256) img_unsqueeze_kernel(const float* __restrict__ in, float* __restrict__ out, int64_t out_img, int C, int H,
+                                                            int W, const float* __restrict__ eps, int C_eps, int Hv, int Wv, int Hs, int Ws) {
+  const int64_t n = blockIdx.x;
+  img_unsqueeze_body(in + n * 4 * C * Hs * Ws, out + n * out_img, C, H, W, eps ? eps + n * C_eps * Hv * Wv : nullptr, C_eps, Hv, Wv, Hs, Ws);
+}
 
 // z (n, C, Hv, Wv) of the map's own size into the top-left corner of zeroed (n, C, H, W) storage
-__global__ void __launch_bounds__(256) img_embed_kernel(const float* __restrict__ z, float* __restrict__ out, int C, int H, int W, int Hv, int Wv) {
-  const int n = blockIdx.x, chw = C * H * W;
-  float* oi = out + (int64_t)n * chw;
+__device__ __forceinline__ void img_embed_body(const float* __restrict__ zi, float* __restrict__ oi, int C, int H, int W, int Hv, int Wv) {
+  const int chw = C * H * W;
   for (int e = threadIdx.x; e < chw; e += 256) {
     const int c = e / (H * W), rem = e % (H * W), y = rem / W, xx = rem % W;
-    oi[e] = (y < Hv && xx < Wv) ? z[(((int64_t)n * C + c) * Hv + y) * Wv + xx] : 0.0f;
+    oi[e] = (y < Hv && xx < Wv) ? zi[((int64_t)c * Hv + y) * Wv + xx] : 0.0f;
   }
+}
+__global__ void __launch_bounds__(256) img_embed_kernel(const float* __restrict__ z, float* __restrict__ out, int C, int H, int W, int Hv, int Wv) {
+  const int64_t n = blockIdx.x;
+  img_embed_body(z + n * C * Hv * Wv, out + n * C * H * W, C, H, W, Hv, Wv);
 }
 
 // the last unsqueeze + to_logits(reverse=True) (models/glow.py:151-158): (n, 4C, H/2, W/2) logits -> x (n, C, H, W)
-__global__ void __launch_bounds__(256) img_post_kernel(const float* __restrict__ in, float* __restrict__ x, int C, int H, int W, int Hi, int Wi,
-                                                       float bounds) {
-  const int n = blockIdx.x, chw = C * H * W, xchw = C * Hi * Wi;        // storage H x W, x (n, C, Hi, Wi)
-  const float* xi = in + (int64_t)n * chw;
-  float* oi = x + (int64_t)n * xchw;
+__device__ __forceinline__ void img_post_body(const float* __restrict__ xi, float* __restrict__ oi, int C, int H, int W, int Hi, int Wi, float bounds) {
+  const int xchw = C * Hi * Wi;                              // storage H x W, x (C, Hi, Wi)
   for (int e = threadIdx.x; e < xchw; e += 256) {
     const int c = e / (Hi * Wi), rem = e % (Hi * Wi), y = rem / Wi, xx = rem % Wi;
     const int ic = c * 4 + (y & 1) * 2 + (xx & 1);
@@ -522,21 +535,23 @@ __global__ void __launch_bounds__(256) img_post_kernel(const float* __restrict__
     oi[e] = ((sg * 2.0f - 1.0f) / bounds + 1.0f) * 0.5f;
   }
 }
+__global__ void __launch_bounds__(256) img_post_kernel(const float* __restrict__ in, float* __restrict__ x, int C, int H, int W, int Hi, int Wi,
+                                                       float bounds) {
+  const int64_t n = blockIdx.x;
+  img_post_body(in + n * C * H * W, x + n * C * Hi * Wi, C, H, W, Hi, Wi, bounds);
+}
 
 // ll[n] = sum -0.5 (log-var + (z - mean)^2 exp(-log-var)) + ldj[n]  with per-channel prior constants (Glow.prior on zeros:
 // Conv2dZeros(0) = bias * exp(3 logs), models/glow.py:62-84); optional copies of z / mean / log-var.
-__global__ void __launch_bounds__(256) img_final_kernel(const float* __restrict__ z, int64_t z_img, const float* __restrict__ prior /* [2C] */,
-                                                        const float* __restrict__ ldj, float* __restrict__ ll, float* __restrict__ z_out,
-                                                        int C, int H, int W, int Hv, int Wv, const unsigned* gate) {
-  if (gate != nullptr && *gate == 0u) return;
-  const int n = blockIdx.x;
-  const float* zi = z + (int64_t)n * z_img;
+// (body: zi = this image's state, zo = its compact z output or null; returns the prior's log-density sum in every thread)
+__device__ __forceinline__ float img_final_body(const float* __restrict__ zi, const float* __restrict__ prior /* [2C] */, float* __restrict__ zo,
+                                                int C, int H, int W, int Hv, int Wv) {
   float acc = 0.0f;
-  for (int e = threadIdx.x; e < C * Hv * Wv; e += 256) {      // e: an element of the compact z (n, C, Hv, Wv); storage is H x W
+  for (int e = threadIdx.x; e < C * Hv * Wv; e += 256) {      // e: an element of the compact z (C, Hv, Wv); storage is H x W
     const int c = e / (Hv * Wv), rem = e % (Hv * Wv), y = rem / Wv, xx = rem % Wv;
     const float mu = prior[c], lv = prior[C + c], v = zi[((int64_t)c * H + y) * W + xx], dlt = v - mu;
     acc += -0.5f * (lv + dlt * dlt * __expf(-lv));
-    if (z_out) z_out[(int64_t)n * C * Hv * Wv + e] = v;
+    if (zo) zo[e] = v;
   }
   __shared__ float red[256];
   red[threadIdx.x] = acc;
@@ -545,7 +560,16 @@ __global__ void __launch_bounds__(256) img_final_kernel(const float* __restrict_
     if ((int)threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s];
     __syncthreads();
   }
-  if (threadIdx.x == 0 && ll) ll[n] = red[0] + ldj[n];
+  const float r = red[0];
+  __syncthreads();
+  return r;
+}
+__global__ void __launch_bounds__(256) img_final_kernel(const float* __restrict__ z, int64_t z_img, const float* __restrict__ prior /* [2C] */,
+                                                        const float* __restrict__ ldj, float* __restrict__ ll, float* __restrict__ z_out,
+                                                        int C, int H, int W, int Hv, int Wv) {
+  const int64_t n = blockIdx.x;
+  const float r = img_final_body(z + n * z_img, prior, z_out ? z_out + n * C * Hv * Wv : nullptr, C, H, W, Hv, Wv);
+  if (threadIdx.x == 0 && ll) ll[n] = r + ldj[n];
 }
 
 
@@ -589,80 +613,182 @@ __global__ void __launch_bounds__(256) img_channel_stats_kernel(const float* __r
   }
 }
 
-// ---- numerics protocol of the split-f16 coupling nets --------------------------------------------
-// A fused coupling-net workgroup that meets an operand beyond the fp16 range raises mark[image].  Behind the f16x3 pass:
-//   img_compact_kernel   the marked images' indices, in order, into list[0 .. count)
-//   img_gather_kernel    x / noise of list[0 .. min(count, R)) into a staging batch (the unused rows repeat image 0)
-//   the exact-f32 forward of that staging batch (the same launch sequence, R images: tiny grids)
-//   img_scatter_kernel   z / ldj / ll of the repaired images back; images marked beyond the R-th get NaN (never a silently
-//                        wrong value) and are counted in seen[1]
-constexpr int IMG_REPAIR_MAX = 8;     // images re-evaluated per call
+// ---- numerics protocol of the split-f16 coupling nets ---------------------------------------------------------------
+// A fused coupling-net workgroup that meets an operand beyond the fp16 range raises mark[image].  Behind the f16x3 pass, on the
+// same stream, in the same call (round 5: no capacity, no "armed from the next call on"):
+//   img_compact_kernel   the marked images' indices, in order, into list[0 .. count) (every one of them); on the handle's first
+//                        launch and every `check_every`-th after it, also up to IMG_CHECK_MAX unmarked images into the check list
+//   img_repair_kernel    ONE launch that returns at once when its list is empty.  Otherwise workgroup b walks image list[b]
+//                        through the WHOLE exact-f32 sequence -- every launch of the exact-f32 pass as a recorded op (RepairOp),
+//                        the image's tensors in a workgroup-private workspace, the strips of a convolution one after the other
+//                        through the very body the stand-alone kernels run (img_conv_body) -- and writes z / ldj / ll (or x, on
+//                        the way back) of that image over what the split-f16 pass left there.  Slow per image (one workgroup
+//                        instead of the chip) and rare by construction: a model that drives ordinary data out of range is
+//                        demoted by the create-time probe.
+//   the same kernel in CHECK mode in front of it: the check list's images on exact f32, compared with the split-f16 result in
+//   place; a difference beyond the tolerance raises the handle's device word `force_all` (the repair launch of this and every
+//   later call then re-evaluates ALL images: nothing of a failed mode reaches the caller, also under graph replay) and a pinned
+//   host word (later calls run the exact-f32 kernels directly).
+constexpr int IMG_CHECK_MAX = 2;
+constexpr int IMG_REPAIR_WGS = 256;        // workgroups (= private workspaces) of a repair launch
+constexpr uintptr_t IMG_REC_BASE = 0x100000000000ull;       // workspace address the ops are recorded against
 
-__global__ void __launch_bounds__(256) img_compact_kernel(const unsigned* __restrict__ mark, int n, unsigned* __restrict__ list /* [R] */,
-                                                          unsigned* __restrict__ count, unsigned* seen_host) {
-  __shared__ unsigned cnt;
-  if (threadIdx.x == 0) cnt = 0;
-  __syncthreads();
+enum { ROP_PRE = 0, ROP_CONV, ROP_SQUEEZE, ROP_FINAL, ROP_EMBED, ROP_UNSQUEEZE, ROP_POST };
+struct RepairOp {
+  int kind, epi, pt, ks;
+  ConvLaunch p;           // ROP_CONV: workspace pointers relative to IMG_REC_BASE, parameter pointers absolute
+  int64_t a, b, c;        // the other ops: float offsets into the private workspace (source, destination, log-det slot)
+  int i[8];
+  float f[2];
+  const float* prior;     // ROP_FINAL
+  int64_t eps_img, eps_lvl;   // ROP_UNSQUEEZE: eps of this level = eps + eps_lvl * n_batch + image * eps_img (0 / 0: none)
+};
+
+struct RepairArgs {
+  const RepairOp* ops;
+  int n_ops, check;
+  const unsigned* list;       // image indices
+  const unsigned* count;      // entries of list
+  unsigned* force_all;        // device word: non-zero = every image of the call (repair mode reads, check mode raises)
+  const unsigned* mark;       // check mode: (n,) marks of the split-f16 pass
+  int64_t n;                  // images of the call
+  float* ws;
+  int64_t ws_stride;          // floats of one workgroup's workspace
+  const float* x; const float* noise; float* z; float* ldj; float* ll;      // forward
+  const float* zin; const float* eps; float* xout; float temperature;      // z -> x
+  int64_t xchw, zsz;
+  float tol;
+  unsigned* host_words;       // pinned: [2] checks completed, [3] checks failed, [4] worst relative difference (float bits)
+};
+
+__global__ void __launch_bounds__(256) img_compact_kernel(const unsigned* __restrict__ mark, int n, unsigned* __restrict__ list,
+                                                          unsigned* __restrict__ count /* [0] marked, [1] check entries */,
+                                                          unsigned* __restrict__ check_list, unsigned* __restrict__ dev_state /* [0] launches */,
+                                                          unsigned* host_words, int check_every) {
   // in order: one wave scans (n is a batch size: a few thousand at most)
-  if (threadIdx.x < 64) {
-    unsigned base = 0;
-    for (int b0 = 0; b0 < n; b0 += 64) {
-      const int k = b0 + (int)threadIdx.x;
-      const bool m = k < n && mark[k] != 0u;
-      const unsigned long long bal = __ballot(m);
-      const unsigned before = __popcll(bal & ((1ull << threadIdx.x) - 1ull));
-      if (m && base + before < (unsigned)IMG_REPAIR_MAX) list[base + before] = (unsigned)k;
-      base += __popcll(bal);
-    }
-    if (threadIdx.x == 0) {
-      *count = base;
-      if (base != 0u && seen_host != nullptr) {
-        atomicAdd_system(seen_host, 1u);
-        if (base > (unsigned)IMG_REPAIR_MAX) atomicAdd_system(seen_host + 1, base - IMG_REPAIR_MAX);
-      }
+  if (threadIdx.x >= 64) return;
+  unsigned base = 0, nchk = 0;
+  bool check = false;
+  if (check_list != nullptr) {
+    unsigned serial = 0;
+    if (threadIdx.x == 0) { serial = dev_state[0]; dev_state[0] = serial + 1u; }
+    serial = __shfl(serial, 0);
+    check = check_every >= 0 && (serial == 0u || (check_every > 0 && serial % (unsigned)check_every == 0u));
+  }
+  for (int b0 = 0; b0 < n; b0 += 64) {
+    const int k = b0 + (int)threadIdx.x;
+    const bool m = k < n && mark[k] != 0u;
+    const unsigned long long bal = __ballot(m);
+    if (m) list[base + __popcll(bal & ((1ull << threadIdx.x) - 1ull))] = (unsigned)k;
+    base += __popcll(bal);
+    if (check && nchk < (unsigned)IMG_CHECK_MAX) {
+      const unsigned long long free = __ballot(k < n && !m);
+      const unsigned before = __popcll(free & ((1ull << threadIdx.x) - 1ull));
+      if (k < n && !m && nchk + before < (unsigned)IMG_CHECK_MAX) check_list[nchk + before] = (unsigned)k;
+      nchk = min(nchk + (unsigned)__popcll(free), (unsigned)IMG_CHECK_MAX);
     }
   }
-}
-
-// z -> x on the split-f16 coupling nets: an image whose hidden activation left the fp16 range comes back as NaN (never a clamped
-// value) and raises the handle's `seen` word -- from then on the handle's inverse runs on the exact-f32 convolutions
-__global__ void __launch_bounds__(256) img_nan_marked_kernel(const unsigned* __restrict__ mark, float* __restrict__ x, int64_t chw, unsigned* seen_host) {
-  const int n = blockIdx.x;
-  if (mark[n] == 0u) return;
-  for (int64_t e = threadIdx.x; e < chw; e += 256) x[(int64_t)n * chw + e] = __builtin_nanf("");
-  if (threadIdx.x == 0 && seen_host != nullptr) atomicAdd_system(seen_host, 1u);
-}
-
-__global__ void __launch_bounds__(256) img_gather_kernel(const float* __restrict__ x, const float* __restrict__ noise, int64_t chw,
-                                                         const unsigned* __restrict__ list, const unsigned* __restrict__ count,
-                                                         float* __restrict__ xs, float* __restrict__ ns) {
-  const int b = blockIdx.x;
-  const unsigned c = *count;
-  if (c == 0u) return;
-  const int64_t src = (unsigned)b < c ? (int64_t)list[b] : 0;
-  for (int64_t e = threadIdx.x; e < chw; e += 256) {
-    xs[b * chw + e] = x[src * chw + e];
-    ns[b * chw + e] = noise ? noise[src * chw + e] : 0.0f;
-  }
-}
-
-// grid = n images: an image in list[0 .. min(count, R)) takes the staging batch's results, one marked beyond that NaN
-__global__ void __launch_bounds__(256) img_scatter_kernel(const unsigned* __restrict__ mark, const unsigned* __restrict__ list,
-                                                          const unsigned* __restrict__ count, int repaired, int64_t zsz, const float* __restrict__ zr,
-                                                          const float* __restrict__ ldjr, const float* __restrict__ llr, float* __restrict__ z,
-                                                          float* __restrict__ ldj, float* __restrict__ ll) {
-  const int n = blockIdx.x;
-  if (mark[n] == 0u) return;
-  const unsigned c = !repaired ? 0u : (*count < (unsigned)IMG_REPAIR_MAX ? *count : (unsigned)IMG_REPAIR_MAX);
-  int slot = -1;
-  for (unsigned b = 0; b < c; ++b)
-    if (list[b] == (unsigned)n) slot = (int)b;
-  const float nanv = __builtin_nanf("");
-  if (z)
-    for (int64_t e = threadIdx.x; e < zsz; e += 256) z[n * zsz + e] = slot >= 0 ? zr[slot * zsz + e] : nanv;
   if (threadIdx.x == 0) {
-    if (ldj) ldj[n] = slot >= 0 ? ldjr[slot] : nanv;
-    if (ll) ll[n] = slot >= 0 ? llr[slot] : nanv;
+    count[0] = base;
+    count[1] = nchk;
+    if (base != 0u && host_words != nullptr) {
+      atomicAdd_system(host_words, 1u);             // calls that marked an image
+      atomicAdd_system(host_words + 1, base);       // images re-evaluated on exact f32
+    }
+  }
+}
+
+template <int EPI>
+__device__ __forceinline__ void img_repair_conv(const ConvLaunch& p, const int pt, const int ks) {
+  for (int strip = 0; strip < p.n_strips; ++strip) {
+    if (pt == 4 && ks == 3) img_conv_body<EPI, 4, 3>(p, 0, strip, 0);
+    else if (pt == 4) { if constexpr (EPI == EPI_RELU || EPI == EPI_STORE) img_conv_body<EPI, 4, 1>(p, 0, strip, 0); }
+    else if (ks == 3) img_conv_body<EPI, 2, 3>(p, 0, strip, 0);
+    else { if constexpr (EPI == EPI_RELU || EPI == EPI_STORE) img_conv_body<EPI, 2, 1>(p, 0, strip, 0); }
+    __syncthreads();                                         // the next strip restages the LDS
+  }
+}
+
+// INV: the z -> x sequence (its own instantiation: each carries only the epilogues its direction uses)
+template <bool INV>
+__global__ void __launch_bounds__(64 * IMG_WAVES) img_repair_kernel(const RepairArgs a) {
+  unsigned cnt = *a.count;
+  bool all = false;
+  if (!a.check && *a.force_all != 0u) { cnt = (unsigned)a.n; all = true; }
+  if (cnt == 0u) return;
+  float* wsb = a.ws + (int64_t)blockIdx.x * a.ws_stride;
+  const int64_t delta = reinterpret_cast<const char*>(wsb) - reinterpret_cast<const char*>(IMG_REC_BASE);
+  auto rb = [&](const float* q) -> float* { return q ? reinterpret_cast<float*>(reinterpret_cast<uintptr_t>(q) + delta) : nullptr; };
+  for (unsigned b = blockIdx.x; b < cnt; b += gridDim.x) {
+    const int64_t img = all ? (int64_t)b : (int64_t)a.list[b];
+    for (int k = 0; k < a.n_ops; ++k) {
+      const RepairOp& op = a.ops[k];
+      switch (op.kind) {
+        case ROP_CONV: {
+          ConvLaunch p = op.p;
+          p.in = rb(p.in); p.out = rb(p.out); p.st = rb(p.st); p.pre_in = rb(p.pre_in); p.ldj = rb(p.ldj);
+          p.temperature = a.temperature;
+          if constexpr (!INV) {
+            if (op.epi == EPI_RELU) img_repair_conv<EPI_RELU>(p, op.pt, op.ks);
+            else if (op.epi == EPI_STORE) img_repair_conv<EPI_STORE>(p, op.pt, op.ks);
+            else if (op.epi == EPI_COUPLE_AFFINE) img_repair_conv<EPI_COUPLE_AFFINE>(p, op.pt, op.ks);
+            else if (op.epi == EPI_COUPLE_ADD) img_repair_conv<EPI_COUPLE_ADD>(p, op.pt, op.ks);
+            else img_repair_conv<EPI_SPLIT>(p, op.pt, op.ks);
+          } else {
+            if (op.epi == EPI_RELU) img_repair_conv<EPI_RELU>(p, op.pt, op.ks);
+            else if (op.epi == EPI_STORE) img_repair_conv<EPI_STORE>(p, op.pt, op.ks);
+            else if (op.epi == EPI_COUPLE_AFFINE_INV) img_repair_conv<EPI_COUPLE_AFFINE_INV>(p, op.pt, op.ks);
+            else if (op.epi == EPI_COUPLE_ADD_INV) img_repair_conv<EPI_COUPLE_ADD_INV>(p, op.pt, op.ks);
+            else img_repair_conv<EPI_SPLIT_INV>(p, op.pt, op.ks);
+          }
+          break;
+        }
+        case ROP_PRE:
+          if constexpr (!INV)
+            img_pre_body(a.x + img * a.xchw, a.noise ? a.noise + img * a.xchw : nullptr, wsb + op.b, wsb + op.c, op.i[0], op.i[1], op.i[2],
+                         op.i[3], op.i[4], op.f[0], op.f[1], 0);
+          break;
+        case ROP_SQUEEZE:
+          if constexpr (!INV) img_squeeze_body(wsb + op.a, 0, wsb + op.b, op.i[0], op.i[1], op.i[2], op.i[3], op.i[4], 0);
+          break;
+        case ROP_FINAL:
+          if constexpr (!INV) {
+            float* zo = (a.check || a.z == nullptr) ? nullptr : a.z + img * a.zsz;
+            const float r = img_final_body(wsb + op.a, op.prior, zo, op.i[0], op.i[1], op.i[2], op.i[3], op.i[4]);
+            if (threadIdx.x == 0) {
+              const float ldv = __hip_atomic_load(wsb + op.c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), llv = r + ldv;
+              if (!a.check) {
+                a.ldj[img] = ldv;
+                if (a.ll) a.ll[img] = llv;
+              } else if (a.mark[img] == 0u) {                 // (a marked image is repaired anyway)
+                const float got = a.ll ? a.ll[img] : a.ldj[img], want = a.ll ? llv : ldv;
+                const float err = fabsf(got - want) / fmaxf(fabsf(want), 1.0f);
+                atomicAdd_system(a.host_words + 2, 1u);
+                atomicMax_system(a.host_words + 4, __float_as_uint(err == err ? err : INFINITY));
+                if (!(err <= a.tol)) {
+                  atomicExch(a.force_all, 1u);
+                  atomicAdd_system(a.host_words + 3, 1u);
+                }
+              }
+            }
+          }
+          break;
+        case ROP_EMBED:
+          if constexpr (INV) img_embed_body(a.zin + img * a.zsz, wsb + op.b, op.i[0], op.i[1], op.i[2], op.i[3], op.i[4]);
+          break;
+        case ROP_UNSQUEEZE:
+          if constexpr (INV)
+            img_unsqueeze_body(wsb + op.a, wsb + op.b, op.i[0], op.i[1], op.i[2],
+                               op.eps_img ? a.eps + op.eps_lvl * a.n + img * op.eps_img : nullptr, op.i[3], op.i[4], op.i[5], op.i[6], op.i[7]);
+          break;
+        case ROP_POST:
+          if constexpr (INV) img_post_body(wsb + op.a, a.xout + img * a.xchw, op.i[0], op.i[1], op.i[2], op.i[3], op.i[4], op.f[0]);
+          break;
+        default: break;
+      }
+      __threadfence();                                       // the next op reads what this one wrote (other waves, global memory)
+      __syncthreads();
+    }
   }
 }
 
@@ -707,7 +833,15 @@ struct gbnf_image_flow {
   // numerics protocol of the split-f16 coupling nets (round 4)
   float probe_rel_err = 0.0f;                // create-time probe: largest relative difference of ll, f16x3 vs exact f32, on 4 images
   bool probed = false;
-  unsigned* seen_host = nullptr;             // pinned, device-visible: [0] launches that marked an image, [1] images left unrepaired
+  // pinned, device-visible: [0] calls that marked an image, [1] images re-evaluated on exact f32, [2] on-data checks completed,
+  // [3] on-data checks failed (non-zero: the handle runs on the exact-f32 kernels from the next call on), [4] worst relative
+  // difference a check has seen (float bits)
+  unsigned* host_words = nullptr;
+  unsigned* dev_state = nullptr;             // device: [0] launches so far (the check schedule), [1] force_all (a check failed)
+  RepairOp* ops_dev = nullptr;               // the exact-f32 sequence of ONE image as recorded ops: forward [0, n_ops_fwd), then z -> x
+  int n_ops_fwd = 0, n_ops_inv = 0;
+  size_t repair_lds_fwd = 0, repair_lds_inv = 0;
+  bool on_data_demoted() const { return host_words != nullptr && ((volatile unsigned*)host_words)[3] != 0u; }
 };
 
 namespace {
@@ -887,8 +1021,22 @@ PackedConv pack_conv(Packer& P, const gbnf_conv& c, std::vector<double>* scale_o
 unsigned long long* g_img_stamp_buf = nullptr;
 #endif
 
+// image_forward_impl / image_inverse_impl in RECORD mode: no launches; every launch of the exact-f32 sequence for one image
+// becomes a RepairOp (workspace = IMG_REC_BASE) for img_repair_kernel
+struct Recorder {
+  std::vector<RepairOp> ops;
+  size_t lds = 0;
+  const float* ws = nullptr;
+  RepairOp& add(int kind) {
+    ops.emplace_back();
+    std::memset(&ops.back(), 0, sizeof(RepairOp));
+    ops.back().kind = kind;
+    return ops.back();
+  }
+};
+
 template <int EPI>
-void launch_conv(const ConvLaunch& p, int n, hipStream_t s) {
+void launch_conv(const ConvLaunch& p, int n, hipStream_t s, Recorder* rec = nullptr) {
   const int halo = p.ks >> 1;
   const int per_ch = (IMG_R + 2 * halo) * (p.W + 2 * halo);
   const int kc = (p.cin + 15) / 16, OT = (p.cout + 15) / 16, PT = IMG_R * p.W / 16;
@@ -904,6 +1052,13 @@ void launch_conv(const ConvLaunch& p, int n, hipStream_t s) {
   q.o_split = 1;
   if (OT >= 2 * IMG_WAVES && (int64_t)n * p.n_strips < 512) q.o_split = 2;      // < 2 workgroups per CU otherwise
   if (OT >= 4 * IMG_WAVES && (int64_t)n * p.n_strips < 256) q.o_split = 4;
+  if (rec != nullptr) {
+    RepairOp& op = rec->add(ROP_CONV);
+    q.o_split = 1;
+    op.epi = EPI; op.pt = PT; op.ks = p.ks; op.p = q;
+    rec->lds = std::max(rec->lds, lds);
+    return;
+  }
   const dim3 grid((unsigned)(n * p.n_strips * q.o_split)), blk(64 * IMG_WAVES);
   if (PT == 4 && p.ks == 3) hipLaunchKernelGGL((img_conv_kernel<EPI, 4, 3>), grid, blk, lds, s, q);
   else if (PT == 4) hipLaunchKernelGGL((img_conv_kernel<EPI, 4, 1>), grid, blk, lds, s, q);
@@ -931,9 +1086,10 @@ void gbnf_debug_set_image_stamp_buffer(unsigned long long* p) { g_img_stamp_buf 
 
 static int64_t image_state_floats(const gbnf_image_flow* f, int64_t n);
 struct ActNormStats;
+static int image_record_repair_ops(gbnf_image_flow* f);
 static int image_forward_impl(const gbnf_image_flow* f, const float* x, const float* noise, int64_t n, float* z, float* ldj, float* ll,
-                              float* workspace, hipStream_t s, bool force_f32, unsigned* mark, const unsigned* gate = nullptr,
-                              ActNormStats* stats = nullptr);
+                              float* workspace, hipStream_t s, bool force_f32, unsigned* mark, ActNormStats* stats = nullptr,
+                              Recorder* rec = nullptr);
 
 static int image_probe(gbnf_image_flow* f) {
   constexpr int PN = 4;
@@ -1159,10 +1315,13 @@ int gbnf_image_flow_create_mode(const gbnf_image_flow_desc* d, int32_t math_mode
         e = hipFuncSetAttribute(fns[k], hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     }
     if (e == hipSuccess && f->math_mode == GBNF_MATH_F16X3) {
-      e = hipHostMalloc((void**)&f->seen_host, 2 * sizeof(unsigned), hipHostMallocMapped);
-      if (e == hipSuccess) f->seen_host[0] = f->seen_host[1] = 0u;
+      e = hipHostMalloc((void**)&f->host_words, 8 * sizeof(unsigned), hipHostMallocMapped);
+      if (e == hipSuccess) std::memset(f->host_words, 0, 8 * sizeof(unsigned));
+      if (e == hipSuccess) e = hipMalloc((void**)&f->dev_state, 2 * sizeof(unsigned));
+      if (e == hipSuccess) e = hipMemset(f->dev_state, 0, 2 * sizeof(unsigned));
     }
     if (e != hipSuccess) rc = fail(GBNF_ERR_HIP, "gbnf_image_flow_create: %s", hipGetErrorString(e));
+    if (rc == GBNF_OK && f->math_mode == GBNF_MATH_F16X3) rc = image_record_repair_ops(f);
   }
   // ---- create-time probe (as the tabular DEFAULT mode, gbnf_api.hip): 4 synthetic images through the split-f16 coupling nets
   //      and through the exact-f32 kernels; a handle whose log-likelihoods disagree beyond 2.5e-6 runs on exact f32 from now on
@@ -1178,7 +1337,9 @@ int gbnf_image_flow_create_mode(const gbnf_image_flow_desc* d, int32_t math_mode
 int gbnf_image_flow_destroy(gbnf_image_flow* f) {
   if (!f) return GBNF_OK;
   if (f->blob_dev) (void)hipFree(f->blob_dev);
-  if (f->seen_host) (void)hipHostFree(f->seen_host);
+  if (f->host_words) (void)hipHostFree(f->host_words);
+  if (f->dev_state) (void)hipFree(f->dev_state);
+  if (f->ops_dev) (void)hipFree(f->ops_dev);
   delete f;
   return GBNF_OK;
 }
@@ -1206,19 +1367,22 @@ static int64_t image_state_floats(const gbnf_image_flow* f, int64_t n) {
   return (2 * chw + 2 * hid) * n + 64;
 }
 
+// workspace behind the main batch's state buffers (split-f16 handles): marks | list | check list, counts | the repair
+// workgroups' private workspaces
+static int64_t image_repair_workgroups(int64_t n) { return n < IMG_REPAIR_WGS ? n : IMG_REPAIR_WGS; }
+static int64_t image_mark_floats(int64_t n) { return (n + 63) / 64 * 64; }
+
 int gbnf_image_flow_workspace_bytes(const gbnf_image_flow* f, int64_t n, int64_t* bytes) {
   if (!f || !bytes || n < 0) return fail(GBNF_ERR_INVALID, "gbnf_image_flow_workspace_bytes: bad argument");
-  const int64_t chw = f->state_img, zsz = (int64_t)f->zC * f->zH * f->zW;
-  // main batch | marks | list + count | staging x, noise, z, ldj / ll of the repair batch | its state buffers
-  const int64_t floats = image_state_floats(f, n) + (n + 63) / 64 * 64 + 64 + IMG_REPAIR_MAX * (2 * chw + zsz) + 64 +
-                         image_state_floats(f, IMG_REPAIR_MAX);
+  int64_t floats = image_state_floats(f, n);
+  if (f->math_mode == GBNF_MATH_F16X3) floats += 2 * image_mark_floats(n) + 64 + image_repair_workgroups(n) * image_state_floats(f, 1);
   *bytes = floats * 4 + 256;
   return GBNF_OK;
 }
 
 // One pass of the launch sequence over n images.  force_f32: every convolution on the exact-f32 kernels (the repair pass and
-// handles whose probe failed); mark: (n,) per-image range marks raised by the split-f16 coupling nets, or null; gate (exact-f32
-// passes only): device word, 0 = every launch of the pass returns at once.
+// handles whose probe failed); mark: (n,) per-image range marks raised by the split-f16 coupling nets, or null; rec (with
+// force_f32, n = 1, workspace = IMG_REC_BASE, ldj = a workspace slot): record the sequence for img_repair_kernel, launch nothing.
 // `stats` (exact-f32 passes only): stop at ActNorm2d number stats->index of the component (module order: a step's own ActNorm2d,
 // then the one behind each Conv2d of its coupling net) and leave the per-channel statistics of the tensor that reaches it.
 struct ActNormStats {
@@ -1228,7 +1392,7 @@ struct ActNormStats {
   int channels;      // out: channels of that ActNorm2d (-1: index past the last one)
 };
 static int image_forward_impl(const gbnf_image_flow* f, const float* x, const float* noise, int64_t n, float* z, float* ldj, float* ll,
-                              float* workspace, hipStream_t s, bool force_f32, unsigned* mark, const unsigned* gate, ActNormStats* stats) {
+                              float* workspace, hipStream_t s, bool force_f32, unsigned* mark, ActNormStats* stats, Recorder* rec) {
   const int64_t chw = f->state_img;
   int an_index = 0;                       // ActNorm2d counter (stats)
   if (stats != nullptr) stats->channels = -1;
@@ -1241,8 +1405,14 @@ static int image_forward_impl(const gbnf_image_flow* f, const float* x, const fl
 
   int C = f->C * 4, H = f->H / 2, W = f->W / 2, Hv = f->Hi / 2, Wv = f->Wi / 2;
   const bool padded = f->Hi != f->H || f->Wi != f->W;       // the map proper is smaller than its storage
-  hipLaunchKernelGGL(img_pre_kernel, dim3((unsigned)n), dim3(256), 0, s, x, noise, SA, ldj, f->C, f->H, f->W, f->Hi, f->Wi, f->bounds,
-                     (float)f->ld_const, gate);
+  if (rec != nullptr) {
+    RepairOp& op = rec->add(ROP_PRE);
+    op.b = SA - workspace; op.c = ldj - workspace;
+    op.i[0] = f->C; op.i[1] = f->H; op.i[2] = f->W; op.i[3] = f->Hi; op.i[4] = f->Wi; op.f[0] = f->bounds; op.f[1] = (float)f->ld_const;
+  } else {
+    hipLaunchKernelGGL(img_pre_kernel, dim3((unsigned)n), dim3(256), 0, s, x, noise, SA, ldj, f->C, f->H, f->W, f->Hi, f->Wi, f->bounds,
+                       (float)f->ld_const);
+  }
   float* cur = SA;      // current state (n, C, H, W), image stride = C*H*W
   float* oth = SB;
   size_t step = 0;
@@ -1253,7 +1423,6 @@ static int image_forward_impl(const gbnf_image_flow* f, const float* x, const fl
     const int K = f->level_steps[l];
     for (int k = 0; k < K; ++k, ++step) {
       ConvLaunch p{};
-      p.gate = gate;
       p.H = H; p.W = W; p.Hv = Hv; p.Wv = Wv; p.n_strips = n_strips; p.ldj = ldj;
       if (stats != nullptr && an_index++ == stats->index) {      // the step's own ActNorm2d: the state as it stands
         hipLaunchKernelGGL(img_channel_stats_kernel, dim3((unsigned)C), dim3(256), 0, s, (const float*)cur, img, n, H, W, Hv, Wv, stats->mean, stats->var);
@@ -1264,10 +1433,10 @@ static int image_forward_impl(const gbnf_image_flow* f, const float* x, const fl
       const PackedConv& m = f->mix[step];
       static const bool no_mix_kernel = getenv("GBNF_IMG_NO_MIX_KERNEL") != nullptr;     // diagnostic: the implicit-GEMM form
       // (below ~8 k pixels per launch a thread per pixel leaves most of the chip idle: the implicit-GEMM form spreads the channels)
-      if (no_mix_kernel || m.p_off == 0 || n * H * W < 8192 || !launch_mix(cur, oth, blob + m.p_off, C, H, W, Hv, Wv, n, gate, s)) {
+      if (rec != nullptr || no_mix_kernel || m.p_off == 0 || n * H * W < 8192 || !launch_mix(cur, oth, blob + m.p_off, C, H, W, Hv, Wv, n, s)) {
         p.in = cur; p.in_img = img; p.wp = blob + m.w_off; p.bias = blob + m.b_off; p.out = oth; p.out_img = img;
         p.cin = C; p.cout = C; p.ks = 1;
-        launch_conv<EPI_STORE>(p, (int)n, s);
+        launch_conv<EPI_STORE>(p, (int)n, s, rec);
       }
       std::swap(cur, oth);
       // coupling net on the first half
@@ -1368,47 +1537,83 @@ static int image_forward_impl(const gbnf_image_flow* f, const float* x, const fl
           p.pre_in = cur; p.pre_in_img = img; p.pre_wp = blob + net[0].w_off; p.pre_bias = blob + net[0].b_off;
           p.pre_cin = net[0].cin;
         }
-        launch_conv<EPI_RELU>(p, (int)n, s);
+        launch_conv<EPI_RELU>(p, (int)n, s, rec);
         p.pre_in = nullptr;
         hin = hb[q & 1]; hin_img = p.out_img;
       }
       const PackedConv& c = net.back();
       p.in = hin; p.in_img = hin_img; p.wp = blob + c.w_off; p.bias = blob + c.b_off; p.out = nullptr;
       p.st = cur + (int64_t)c1 * H * W; p.st_img = img; p.cin = c.cin; p.cout = c.cout; p.ks = c.ks;
-      if (f->additive) launch_conv<EPI_COUPLE_ADD>(p, (int)n, s);
-      else launch_conv<EPI_COUPLE_AFFINE>(p, (int)n, s);
+      if (f->additive) launch_conv<EPI_COUPLE_ADD>(p, (int)n, s, rec);
+      else launch_conv<EPI_COUPLE_AFFINE>(p, (int)n, s, rec);
     }
     if (l < f->L - 1) {
       ConvLaunch p{};
-      p.gate = gate;
       const PackedConv& c = f->split[l];
       p.H = H; p.W = W; p.Hv = Hv; p.Wv = Wv; p.n_strips = n_strips; p.ldj = ldj;
       p.in = cur; p.in_img = img; p.wp = blob + c.w_off; p.bias = blob + c.b_off;
       p.st = cur + (int64_t)c1 * H * W; p.st_img = img; p.cin = c.cin; p.cout = c.cout; p.ks = c.ks;
-      launch_conv<EPI_SPLIT>(p, (int)n, s);
+      launch_conv<EPI_SPLIT>(p, (int)n, s, rec);
       const int Hn = H / 2 < 8 ? 8 : H / 2, Wn = W / 2 < 8 ? 8 : W / 2;      // storage of the next level (at least 8 wide)
-      hipLaunchKernelGGL(img_squeeze_kernel, dim3((unsigned)n), dim3(256), 0, s, gate, (const float*)cur, img, oth, c1, H, W, Hn, Wn);
+      if (rec != nullptr) {
+        RepairOp& op = rec->add(ROP_SQUEEZE);
+        op.a = cur - workspace; op.b = oth - workspace;
+        op.i[0] = c1; op.i[1] = H; op.i[2] = W; op.i[3] = Hn; op.i[4] = Wn;
+      } else {
+        hipLaunchKernelGGL(img_squeeze_kernel, dim3((unsigned)n), dim3(256), 0, s, (const float*)cur, img, oth, c1, H, W, Hn, Wn);
+      }
       std::swap(cur, oth);
       C = c1 * 4; H = Hn; W = Wn; Hv /= 2; Wv /= 2;
     }
   }
+  if (rec != nullptr) {
+    RepairOp& op = rec->add(ROP_FINAL);
+    op.a = cur - workspace; op.c = ldj - workspace; op.prior = blob + f->prior_off;
+    op.i[0] = C; op.i[1] = H; op.i[2] = W; op.i[3] = Hv; op.i[4] = Wv;
+    return GBNF_OK;
+  }
   hipLaunchKernelGGL(img_final_kernel, dim3((unsigned)n), dim3(256), 0, s, (const float*)cur, (int64_t)C * H * W,
-                     blob + f->prior_off, (const float*)ldj, ll, z, C, H, W, Hv, Wv, gate);
+                     blob + f->prior_off, (const float*)ldj, ll, z, C, H, W, Hv, Wv);
   const hipError_t e = hipGetLastError();
   if (e != hipSuccess) return fail(GBNF_ERR_HIP, "gbnf_image_flow_forward: %s", hipGetErrorString(e));
   return GBNF_OK;
 }
 
-// GBNF_IMAGE_REPAIR: what follows the split-f16 pass (never a silently wrong value in any mode but 0):
-//   1 (default)  marked images get NaN outputs and raise the handle's pinned `seen` word; from the first call that has SEEN a
-//                mark on (host-side read, no synchronisation) every call carries the gated exact-f32 pass: ~52 launches that
-//                return at once unless an image of THIS call is marked (+3 % at batch 256, +8 % at 64 under graph replay; an
-//                ungated pass over 8 staging images costs 1.1 ms per call: it was measured, 103k -> 70k images/s at batch 256)
-//   2            the gated pass from the first call on: same-call repair even for the first out-of-range image of a handle
-//   0            no exact-f32 pass: out-of-range images are counted (gbnf_saturation_count) but keep clamped values (kernel timing)
+// GBNF_IMAGE_REPAIR=0: no pass behind the split-f16 kernels -- out-of-range images are counted (gbnf_saturation_count) but keep
+// their clamped values (kernel timing only).  Anything else (default): the same-call protocol above.
 static int image_repair_mode() {
   static const int mode = [] { const char* e = getenv("GBNF_IMAGE_REPAIR"); return e ? atoi(e) : 1; }();
   return mode;
+}
+
+// The part of a call's workspace behind the main batch's buffers
+struct RepairSpace {
+  unsigned* mark;
+  unsigned* list;
+  unsigned* check_list;
+  unsigned* count;      // [0] marked images, [1] check entries
+  float* wsr;           // image_repair_workgroups(n) private workspaces of image_state_floats(f, 1) floats
+};
+static RepairSpace repair_space(const gbnf_image_flow* f, float* ws, int64_t n) {
+  RepairSpace r;
+  float* q = ws + image_state_floats(f, n);
+  r.mark = reinterpret_cast<unsigned*>(q); q += image_mark_floats(n);
+  r.list = reinterpret_cast<unsigned*>(q); q += image_mark_floats(n);
+  r.check_list = reinterpret_cast<unsigned*>(q); r.count = r.check_list + 16; q += 64;
+  r.wsr = q;
+  return r;
+}
+
+static void launch_repair(const gbnf_image_flow* f, bool inverse, RepairArgs a, int64_t n, hipStream_t s) {
+  a.ops = f->ops_dev + (inverse ? f->n_ops_fwd : 0);
+  a.n_ops = inverse ? f->n_ops_inv : f->n_ops_fwd;
+  a.n = n;
+  a.ws_stride = image_state_floats(f, 1);
+  a.force_all = f->dev_state + 1;
+  a.host_words = f->host_words;
+  const dim3 grid((unsigned)image_repair_workgroups(n)), blk(64 * IMG_WAVES);
+  if (inverse) hipLaunchKernelGGL((img_repair_kernel<true>), grid, blk, f->repair_lds_inv, s, a);
+  else hipLaunchKernelGGL((img_repair_kernel<false>), grid, blk, f->repair_lds_fwd, s, a);
 }
 
 int gbnf_image_flow_forward(const gbnf_image_flow* f, const float* x, const float* noise, int64_t n, float* z, float* ldj,
@@ -1422,33 +1627,28 @@ int gbnf_image_flow_forward(const gbnf_image_flow* f, const float* x, const floa
   if (workspace_bytes < need) return fail(GBNF_ERR_INVALID, "gbnf_image_flow_forward: workspace of %lld bytes < %lld", (long long)workspace_bytes, (long long)need);
   hipStream_t s = (hipStream_t)stream;
   float* ws = (float*)workspace;
-  if (f->math_mode != GBNF_MATH_F16X3) return image_forward_impl(f, x, noise, n, z, ldj, ll, ws, s, true, nullptr);
-  const int mode = image_repair_mode();
-  if (mode == 0) return image_forward_impl(f, x, noise, n, z, ldj, ll, ws, s, false, nullptr);
-  // ---- split-f16 pass with range marks; then the marked images: NaN, or the exact-f32 pass over (up to IMG_REPAIR_MAX of) them
-  constexpr int R = IMG_REPAIR_MAX;
-  const int64_t chw = (int64_t)f->C * f->Hi * f->Wi, zsz = (int64_t)f->zC * f->zH * f->zW;      // (x and z have the map's own size)
-  float* q = ws + image_state_floats(f, n);
-  unsigned* mark = reinterpret_cast<unsigned*>(q); q += (n + 63) / 64 * 64;
-  unsigned* list = reinterpret_cast<unsigned*>(q); unsigned* count = list + R; q += 64;
-  float* xs = q; q += R * chw;
-  float* ns = q; q += R * chw;
-  float* zr = q; q += R * zsz;
-  float* ldjr = q; float* llr = q + R; q += 64;
-  float* wsr = q;
-  if (hipMemsetAsync(mark, 0, (size_t)n * 4, s) != hipSuccess) return fail(GBNF_ERR_HIP, "gbnf_image_flow_forward: memset failed");
-  int rc = image_forward_impl(f, x, noise, n, z, ldj, ll, ws, s, false, mark);
+  // exact f32: the handle's mode, or a split-f16 handle whose on-data check has failed (pinned word, no synchronisation)
+  if (f->math_mode != GBNF_MATH_F16X3 || f->on_data_demoted()) return image_forward_impl(f, x, noise, n, z, ldj, ll, ws, s, true, nullptr);
+  if (image_repair_mode() == 0) return image_forward_impl(f, x, noise, n, z, ldj, ll, ws, s, false, nullptr);
+  // ---- split-f16 pass with range marks; the on-data check (first launch, every check_every-th); the marked images on exact f32
+  const RepairSpace r = repair_space(f, ws, n);
+  if (hipMemsetAsync(r.mark, 0, (size_t)n * 4, s) != hipSuccess) return fail(GBNF_ERR_HIP, "gbnf_image_flow_forward: memset failed");
+  const int rc = image_forward_impl(f, x, noise, n, z, ldj, ll, ws, s, false, r.mark);
   if (rc) return rc;
-  hipLaunchKernelGGL(img_compact_kernel, dim3(1), dim3(256), 0, s, (const unsigned*)mark, (int)n, list, count, f->seen_host);
-  const bool repair = mode >= 2 || (f->seen_host != nullptr && ((volatile unsigned*)f->seen_host)[0] != 0u);
-  if (repair) {
-    hipLaunchKernelGGL(img_gather_kernel, dim3(R), dim3(256), 0, s, x, noise, chw, (const unsigned*)list, (const unsigned*)count, xs, ns);
-    rc = image_forward_impl(f, xs, ns, R, zr, ldjr, llr, wsr, s, true, nullptr, count);
-    if (rc) return rc;
-  }
-  // (without the pass: count is forced to "nothing repaired", every marked image gets NaN)
-  hipLaunchKernelGGL(img_scatter_kernel, dim3((unsigned)n), dim3(256), 0, s, (const unsigned*)mark, (const unsigned*)list,
-                     (const unsigned*)count, repair ? 1 : 0, zsz, (const float*)zr, (const float*)ldjr, (const float*)llr, z, ldj, ll);
+  int32_t every = 256, tol_e9 = 2500;
+  (void)gbnf_tuning_get("check_every", &every);
+  (void)gbnf_tuning_get("check_tolerance_e9", &tol_e9);
+  hipLaunchKernelGGL(img_compact_kernel, dim3(1), dim3(256), 0, s, (const unsigned*)r.mark, (int)n, r.list, r.count, r.check_list,
+                     f->dev_state, f->host_words, (int)every);
+  RepairArgs a{};
+  a.mark = r.mark; a.ws = r.wsr;
+  a.x = x; a.noise = noise; a.z = z; a.ldj = ldj; a.ll = ll;
+  a.xchw = (int64_t)f->C * f->Hi * f->Wi; a.zsz = (int64_t)f->zC * f->zH * f->zW;      // (x and z have the map's own size)
+  a.tol = 1e-9f * (float)tol_e9;
+  a.check = 1; a.list = r.check_list; a.count = r.count + 1;
+  launch_repair(f, false, a, n, s);
+  a.check = 0; a.list = r.list; a.count = r.count;
+  launch_repair(f, false, a, n, s);
   const hipError_t e = hipGetLastError();
   if (e != hipSuccess) return fail(GBNF_ERR_HIP, "gbnf_image_flow_forward (repair): %s", hipGetErrorString(e));
   return GBNF_OK;
@@ -1464,7 +1664,7 @@ int gbnf_image_flow_actnorm_stats(const gbnf_image_flow* f, const float* x, cons
   float* ws = (float*)workspace;
   float* ldj = ws + image_state_floats(f, n);               // (scratch: the pass's own log-det accumulator)
   ActNormStats st{index, mean_dev, var_dev, -1};
-  const int rc = image_forward_impl(f, x, noise, n, nullptr, ldj, nullptr, ws, (hipStream_t)stream, true, nullptr, nullptr, &st);
+  const int rc = image_forward_impl(f, x, noise, n, nullptr, ldj, nullptr, ws, (hipStream_t)stream, true, nullptr, &st);
   if (rc) return rc;
   if (st.channels < 0) return fail(GBNF_ERR_INVALID, "gbnf_image_flow_actnorm_stats: the component has fewer than %d ActNorm2d layers", index + 1);
   if (channels) *channels = st.channels;
@@ -1474,10 +1674,27 @@ int gbnf_image_flow_actnorm_stats(const gbnf_image_flow* f, const float* x, cons
 int gbnf_image_flow_numerics(const gbnf_image_flow* f, gbnf_numerics_status* out) {
   if (!f || !out) return fail(GBNF_ERR_INVALID, "gbnf_image_flow_numerics: null argument");
   out->math_mode = f->math_mode;
-  out->demoted = (f->probed && f->math_mode != GBNF_MATH_F16X3) ? 1 : 0;       // the create-time probe sent the handle to exact f32
-  out->checks = f->seen_host ? (int64_t)((volatile unsigned*)f->seen_host)[0] : 0;     // launches that marked (and repaired) an image
+  // the create-time probe, or an on-data check, sent the handle to exact f32
+  out->demoted = ((f->probed && f->math_mode != GBNF_MATH_F16X3) || f->on_data_demoted()) ? 1 : 0;
+  if (f->on_data_demoted()) out->math_mode = GBNF_MATH_F32;
+  out->checks = f->host_words ? (int64_t)((volatile unsigned*)f->host_words)[0] : 0;     // calls that marked (and repaired) an image
   out->worst_rel_err = f->probe_rel_err;
   out->tolerance = 2.5e-6f;
+  return GBNF_OK;
+}
+
+int gbnf_image_flow_repair_counts(const gbnf_image_flow* f, int64_t* marked_calls, int64_t* repaired_images, int64_t* data_checks,
+                                  int64_t* failed_checks, float* worst_check_rel_err) {
+  if (!f) return fail(GBNF_ERR_INVALID, "gbnf_image_flow_repair_counts: flow is null");
+  volatile unsigned* w = (volatile unsigned*)f->host_words;
+  if (marked_calls) *marked_calls = w ? w[0] : 0;
+  if (repaired_images) *repaired_images = w ? w[1] : 0;
+  if (data_checks) *data_checks = w ? w[2] : 0;
+  if (failed_checks) *failed_checks = w ? w[3] : 0;
+  if (worst_check_rel_err) {
+    const unsigned bits = w ? w[4] : 0u;
+    std::memcpy(worst_check_rel_err, &bits, 4);
+  }
   return GBNF_OK;
 }
 
@@ -1487,20 +1704,13 @@ int gbnf_image_flow_eps_floats(const gbnf_image_flow* f, int64_t* per_image) {
   return GBNF_OK;
 }
 
-int gbnf_image_flow_inverse(const gbnf_image_flow* f, const float* z, const float* eps, float temperature, int64_t n, float* x,
-                            void* workspace, int64_t workspace_bytes, void* stream) {
-  if (!f) return fail(GBNF_ERR_INVALID, "gbnf_image_flow_inverse: flow is null");
-  if (n < 0) return fail(GBNF_ERR_INVALID, "gbnf_image_flow_inverse: n < 0");
-  if (n == 0) return GBNF_OK;
-  if (!z || !x || !workspace) return fail(GBNF_ERR_INVALID, "gbnf_image_flow_inverse: z / x / workspace is null");
-  if (f->L > 1 && !eps) return fail(GBNF_ERR_INVALID, "gbnf_image_flow_inverse: %d Split2d level(s) need eps", f->L - 1);
-  int64_t need = 0;
-  gbnf_image_flow_workspace_bytes(f, n, &need);
-  if (workspace_bytes < need) return fail(GBNF_ERR_INVALID, "gbnf_image_flow_inverse: workspace of %lld bytes < %lld", (long long)workspace_bytes, (long long)need);
-  hipStream_t s = (hipStream_t)stream;
+// The z -> x launch sequence over n images.  fast: the fused split-f16 coupling-net kernel (marks raised in `mark`), else the
+// exact-f32 convolutions; rec (exact f32, n = 1, workspace = IMG_REC_BASE): record the sequence for img_repair_kernel.
+static int image_inverse_impl(const gbnf_image_flow* f, const float* z, const float* eps, float temperature, int64_t n, float* x,
+                              float* workspace, hipStream_t s, bool fast, unsigned* mark, Recorder* rec) {
   const int64_t chw = f->state_img;
   const int64_t hid = (int64_t)f->chp * (f->H / 2) * (f->W / 2);
-  float* SA = (float*)workspace;
+  float* SA = workspace;
   float* SB = SA + chw * n;
   float* H1 = SB + chw * n;
   float* H2 = H1 + hid * n;
@@ -1508,7 +1718,7 @@ int gbnf_image_flow_inverse(const gbnf_image_flow* f, const float* z, const floa
 
   // level shapes on the way in, and where each Split2d level's eps starts (level 0 first, each (n, C_l/2, H_l, W_l))
   std::vector<int> LC(f->L), LH(f->L), LW(f->L), LHv(f->L), LWv(f->L);
-  std::vector<int64_t> eps_off(f->L, 0);
+  std::vector<int64_t> eps_off(f->L, 0);         // per image of the batch: the level's eps starts at eps_off * n
   {
     int C = f->C, H = f->H, W = f->W, Hv = f->Hi, Wv = f->Wi;
     int64_t off = 0;
@@ -1517,7 +1727,7 @@ int gbnf_image_flow_inverse(const gbnf_image_flow* f, const float* z, const floa
       LC[l] = C; LH[l] = H; LW[l] = W; LHv[l] = Hv; LWv[l] = Wv;
       if (l < f->L - 1) {
         eps_off[l] = off;
-        off += (int64_t)(C / 2) * Hv * Wv * n;                  // (eps has the map's own size)
+        off += (int64_t)(C / 2) * Hv * Wv;                      // (eps has the map's own size)
         C /= 2;
       }
     }
@@ -1527,16 +1737,13 @@ int gbnf_image_flow_inverse(const gbnf_image_flow* f, const float* z, const floa
 
   float* cur = SA;
   float* oth = SB;
-  // split-f16 coupling nets (the fused kernel, as the forward) unless the handle runs on exact f32 or has SEEN an out-of-range
-  // image before (either direction): such a call runs the exact-f32 convolutions.  Marks of THIS call: NaN for the image.
-  const bool fast = f->math_mode == GBNF_MATH_F16X3 && image_repair_mode() != 0 &&
-                    !(f->seen_host != nullptr && ((volatile unsigned*)f->seen_host)[0] != 0u);
-  unsigned* mark = nullptr;
-  if (fast) {
-    mark = reinterpret_cast<unsigned*>((float*)workspace + image_state_floats(f, n));
-    if (hipMemsetAsync(mark, 0, (size_t)n * 4, s) != hipSuccess) return fail(GBNF_ERR_HIP, "gbnf_image_flow_inverse: memset failed");
+  if (rec != nullptr) {
+    RepairOp& op = rec->add(ROP_EMBED);
+    op.b = cur - workspace;
+    op.i[0] = f->zC; op.i[1] = LH[f->L - 1]; op.i[2] = LW[f->L - 1]; op.i[3] = f->zH; op.i[4] = f->zW;
+  } else {
+    hipLaunchKernelGGL(img_embed_kernel, dim3((unsigned)n), dim3(256), 0, s, z, cur, f->zC, LH[f->L - 1], LW[f->L - 1], f->zH, f->zW);
   }
-  hipLaunchKernelGGL(img_embed_kernel, dim3((unsigned)n), dim3(256), 0, s, z, cur, f->zC, LH[f->L - 1], LW[f->L - 1], f->zH, f->zW);
   for (int l = f->L - 1; l >= 0; --l) {
     const int C = LC[l], H = LH[l], W = LW[l], Hv = LHv[l], Wv = LWv[l];
     const int64_t img = (int64_t)C * H * W;
@@ -1545,15 +1752,22 @@ int gbnf_image_flow_inverse(const gbnf_image_flow* f, const float* z, const floa
     const int K = f->level_steps[l];
     if (l < f->L - 1) {
       // the state of level l+1 (n, 4 c1, H/2, W/2) -> first c1 channels of this level; eps into the other half; Split2d reverse
-      hipLaunchKernelGGL(img_unsqueeze_kernel, dim3((unsigned)n), dim3(256), 0, s, (const float*)cur, oth, img, c1, H, W,
-                         eps + eps_off[l], C - c1, Hv, Wv, LH[l + 1], LW[l + 1]);
+      if (rec != nullptr) {
+        RepairOp& op = rec->add(ROP_UNSQUEEZE);
+        op.a = cur - workspace; op.b = oth - workspace;
+        op.i[0] = c1; op.i[1] = H; op.i[2] = W; op.i[3] = C - c1; op.i[4] = Hv; op.i[5] = Wv; op.i[6] = LH[l + 1]; op.i[7] = LW[l + 1];
+        op.eps_img = (int64_t)(C - c1) * Hv * Wv; op.eps_lvl = eps_off[l];
+      } else {
+        hipLaunchKernelGGL(img_unsqueeze_kernel, dim3((unsigned)n), dim3(256), 0, s, (const float*)cur, oth, img, c1, H, W,
+                           eps + eps_off[l] * n, C - c1, Hv, Wv, LH[l + 1], LW[l + 1]);
+      }
       std::swap(cur, oth);
       ConvLaunch p{};
       const PackedConv& c = f->split[l];
       p.H = H; p.W = W; p.Hv = Hv; p.Wv = Wv; p.n_strips = n_strips; p.ldj = nullptr; p.temperature = temperature;
       p.in = cur; p.in_img = img; p.wp = blob + c.w_off; p.bias = blob + c.b_off;
       p.st = cur + (int64_t)c1 * H * W; p.st_img = img; p.cin = c.cin; p.cout = c.cout; p.ks = c.ks;
-      launch_conv<EPI_SPLIT_INV>(p, (int)n, s);
+      launch_conv<EPI_SPLIT_INV>(p, (int)n, s, rec);
     }
     for (int k = K - 1; k >= 0; --k) {
       const size_t step = step_end - (size_t)(K - k);
@@ -1592,7 +1806,7 @@ int gbnf_image_flow_inverse(const gbnf_image_flow* f, const float* z, const floa
           p.pre_in = cur; p.pre_in_img = img; p.pre_wp = blob + net[0].w_off; p.pre_bias = blob + net[0].b_off;
           p.pre_cin = net[0].cin;
         }
-        launch_conv<EPI_RELU>(p, (int)n, s);
+        launch_conv<EPI_RELU>(p, (int)n, s, rec);
         p.pre_in = nullptr;
         hin = hb[q & 1]; hin_img = p.out_img;
       }
@@ -1600,25 +1814,86 @@ int gbnf_image_flow_inverse(const gbnf_image_flow* f, const float* z, const floa
         const PackedConv& c = net.back();
         p.in = hin; p.in_img = hin_img; p.wp = blob + c.w_off; p.bias = blob + c.b_off; p.out = nullptr;
         p.st = cur + (int64_t)c1 * H * W; p.st_img = img; p.cin = c.cin; p.cout = c.cout; p.ks = c.ks;
-        if (f->additive) launch_conv<EPI_COUPLE_ADD_INV>(p, (int)n, s);
-        else launch_conv<EPI_COUPLE_AFFINE_INV>(p, (int)n, s);
+        if (f->additive) launch_conv<EPI_COUPLE_ADD_INV>(p, (int)n, s, rec);
+        else launch_conv<EPI_COUPLE_AFFINE_INV>(p, (int)n, s, rec);
       }
       // (invconv / Permute2d)^-1 + ActNorm2d reverse: cur -> oth
       const PackedConv& m = f->mix_inv[step];
-      if (m.p_off == 0 || n * H * W < 8192 || !launch_mix(cur, oth, blob + m.p_off, C, H, W, Hv, Wv, n, nullptr, s)) {
+      if (rec != nullptr || m.p_off == 0 || n * H * W < 8192 || !launch_mix(cur, oth, blob + m.p_off, C, H, W, Hv, Wv, n, s)) {
         p.in = cur; p.in_img = img; p.wp = blob + m.w_off; p.bias = blob + m.b_off; p.out = oth; p.out_img = img; p.st = nullptr;
         p.cin = C; p.cout = C; p.ks = 1;
-        launch_conv<EPI_STORE>(p, (int)n, s);
+        launch_conv<EPI_STORE>(p, (int)n, s, rec);
       }
       std::swap(cur, oth);
     }
     step_end -= (size_t)K;
   }
+  if (rec != nullptr) {
+    RepairOp& op = rec->add(ROP_POST);
+    op.a = cur - workspace;
+    op.i[0] = f->C; op.i[1] = f->H; op.i[2] = f->W; op.i[3] = f->Hi; op.i[4] = f->Wi; op.f[0] = f->bounds;
+    return GBNF_OK;
+  }
   hipLaunchKernelGGL(img_post_kernel, dim3((unsigned)n), dim3(256), 0, s, (const float*)cur, x, f->C, f->H, f->W, f->Hi, f->Wi, f->bounds);
-  if (fast)
-    hipLaunchKernelGGL(img_nan_marked_kernel, dim3((unsigned)n), dim3(256), 0, s, (const unsigned*)mark, x, (int64_t)f->C * f->Hi * f->Wi, f->seen_host);
   const hipError_t e = hipGetLastError();
   if (e != hipSuccess) return fail(GBNF_ERR_HIP, "gbnf_image_flow_inverse: %s", hipGetErrorString(e));
+  return GBNF_OK;
+}
+
+// Records the exact-f32 sequences of one image (forward, then z -> x) and uploads them: img_repair_kernel's programme
+static int image_record_repair_ops(gbnf_image_flow* f) {
+  float* base = reinterpret_cast<float*>(IMG_REC_BASE);
+  float* ldj_slot = base + image_state_floats(f, 1) - 64;       // (the spare floats behind the state buffers)
+  Recorder fw, bw;
+  int rc = image_forward_impl(f, nullptr, nullptr, 1, nullptr, ldj_slot, nullptr, base, nullptr, true, nullptr, nullptr, &fw);
+  if (!rc) rc = image_inverse_impl(f, nullptr, nullptr, 1.0f, 1, nullptr, base, nullptr, false, nullptr, &bw);
+  if (rc) return rc;
+  f->n_ops_fwd = (int)fw.ops.size(); f->n_ops_inv = (int)bw.ops.size();
+  f->repair_lds_fwd = fw.lds; f->repair_lds_inv = bw.lds;
+  std::vector<RepairOp> all(fw.ops);
+  all.insert(all.end(), bw.ops.begin(), bw.ops.end());
+  hipError_t e = hipMalloc((void**)&f->ops_dev, all.size() * sizeof(RepairOp));
+  if (e == hipSuccess) e = hipMemcpy(f->ops_dev, all.data(), all.size() * sizeof(RepairOp), hipMemcpyHostToDevice);
+  // (the kernel also has a little static LDS -- the reduction buffers of its elementwise ops: 160 KB of dynamic LDS would not fit)
+  if (e == hipSuccess) e = hipFuncSetAttribute((const void*)img_repair_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024);
+  if (e == hipSuccess) e = hipFuncSetAttribute((const void*)img_repair_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024);
+  if (e == hipSuccess && std::max(fw.lds, bw.lds) > (size_t)156 * 1024)
+    return fail(GBNF_ERR_UNSUPPORTED, "gbnf_image_flow_create: a convolution of the exact-f32 sequence needs %zu bytes of LDS", std::max(fw.lds, bw.lds));
+  if (e != hipSuccess) return fail(GBNF_ERR_HIP, "gbnf_image_flow_create: repair programme: %s", hipGetErrorString(e));
+  return GBNF_OK;
+}
+
+int gbnf_image_flow_inverse(const gbnf_image_flow* f, const float* z, const float* eps, float temperature, int64_t n, float* x,
+                            void* workspace, int64_t workspace_bytes, void* stream) {
+  if (!f) return fail(GBNF_ERR_INVALID, "gbnf_image_flow_inverse: flow is null");
+  if (n < 0) return fail(GBNF_ERR_INVALID, "gbnf_image_flow_inverse: n < 0");
+  if (n == 0) return GBNF_OK;
+  if (!z || !x || !workspace) return fail(GBNF_ERR_INVALID, "gbnf_image_flow_inverse: z / x / workspace is null");
+  if (f->L > 1 && !eps) return fail(GBNF_ERR_INVALID, "gbnf_image_flow_inverse: %d Split2d level(s) need eps", f->L - 1);
+  int64_t need = 0;
+  gbnf_image_flow_workspace_bytes(f, n, &need);
+  if (workspace_bytes < need) return fail(GBNF_ERR_INVALID, "gbnf_image_flow_inverse: workspace of %lld bytes < %lld", (long long)workspace_bytes, (long long)need);
+  hipStream_t s = (hipStream_t)stream;
+  float* ws = (float*)workspace;
+  // split-f16 coupling nets (the fused kernel, as the forward) unless the handle runs on exact f32 (its mode, or a failed on-data
+  // check of the forward direction).  An image whose hidden activation leaves the fp16 range is re-evaluated on exact f32 by the
+  // repair launch behind the pass, in this call.
+  const bool fast = f->math_mode == GBNF_MATH_F16X3 && !f->on_data_demoted();
+  if (!fast || image_repair_mode() == 0) return image_inverse_impl(f, z, eps, temperature, n, x, ws, s, fast, nullptr, nullptr);
+  const RepairSpace r = repair_space(f, ws, n);
+  if (hipMemsetAsync(r.mark, 0, (size_t)n * 4, s) != hipSuccess) return fail(GBNF_ERR_HIP, "gbnf_image_flow_inverse: memset failed");
+  const int rc = image_inverse_impl(f, z, eps, temperature, n, x, ws, s, true, r.mark, nullptr);
+  if (rc) return rc;
+  hipLaunchKernelGGL(img_compact_kernel, dim3(1), dim3(256), 0, s, (const unsigned*)r.mark, (int)n, r.list, r.count, (unsigned*)nullptr,
+                     f->dev_state, f->host_words, -1);
+  RepairArgs a{};
+  a.mark = r.mark; a.ws = r.wsr;
+  a.zin = z; a.eps = eps; a.xout = x; a.temperature = temperature;
+  a.xchw = (int64_t)f->C * f->Hi * f->Wi; a.zsz = (int64_t)f->zC * f->zH * f->zW;
+  a.check = 0; a.list = r.list; a.count = r.count;
+  launch_repair(f, true, a, n, s);
+  const hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return fail(GBNF_ERR_HIP, "gbnf_image_flow_inverse (repair): %s", hipGetErrorString(e));
   return GBNF_OK;
 }
 

@@ -492,8 +492,10 @@ class BoostedImageFlow(nn.Module):
         batch 256 (tools/bench_image.py, 62 -> 69.5 k images/s).  The graph holds the packed handles of the parameters it was
         captured with: ``f`` re-captures by itself when a parameter, permutation or ActNorm flag has changed since.  The
         returned tensor is the graph's output buffer -- overwritten by the next call of ``f``.  (Numerics protocol, include/gbnf.h
-        gbnf_image_flow_numerics: whether the gated exact-f32 pass follows the split-f16 one is decided when the graph is captured;
-        an out-of-range image always comes back as NaN or repaired, never with clamped values.)"""
+        gbnf_image_flow_numerics: the range marks, the repair launch and the periodic on-data check are part of every call's
+        launch sequence and are counted on the device, so a replay repairs an out-of-range image exactly like a stream call; when
+        an on-data check has demoted a handle, ``f`` re-captures so that the graph runs the exact-f32 kernels directly instead of
+        the split-f16 pass + full repair.)"""
         n_used = self.num_components if n_used is None else int(n_used)
         dev = self.rho.device
         state = {}
@@ -515,7 +517,7 @@ class BoostedImageFlow(nn.Module):
                 out = self.log_prob(xs, n_used, ns)
             # the handles the graph's kernels read are HELD here: a re-pack cannot free them (and hand their address, hence their
             # id(), to a later handle) while this graph may still be replayed
-            state.update(handles=handles(), graph=g, x=xs, noise=ns, out=out)
+            state.update(handles=handles(), graph=g, x=xs, noise=ns, out=out, demoted=[bool(h.numerics().demoted) for h in handles()])
 
         def f(x, noise):
             if tuple(x.shape) != (batch,) + tuple(self.flows[0].input_size) or tuple(noise.shape) != tuple(x.shape):
@@ -523,7 +525,8 @@ class BoostedImageFlow(nn.Module):
                                        f"got x {tuple(x.shape)}, noise {tuple(noise.shape)}")
             held = state.get("handles")
             now = handles()
-            if held is None or len(held) != len(now) or any(a is not b for a, b in zip(held, now)):
+            if (held is None or len(held) != len(now) or any(a is not b for a, b in zip(held, now))
+                    or state["demoted"] != [bool(h.numerics().demoted) for h in now]):
                 capture()
             state["x"].copy_(x)
             state["noise"].copy_(noise)

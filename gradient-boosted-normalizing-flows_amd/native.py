@@ -36,7 +36,7 @@ ABI_SYMBOLS = (
     "gbnf_trainer_bind_batch_stats", "gbnf_trainer_set_batch_stats",
     "gbnf_image_flow_create", "gbnf_image_flow_destroy", "gbnf_image_flow_info", "gbnf_image_flow_workspace_bytes",
     "gbnf_image_flow_forward", "gbnf_image_flow_prior", "gbnf_image_flow_eps_floats", "gbnf_image_flow_inverse",
-    "gbnf_image_flow_numerics", "gbnf_image_flow_create_mode", "gbnf_image_flow_actnorm_stats",
+    "gbnf_image_flow_numerics", "gbnf_image_flow_repair_counts", "gbnf_image_flow_create_mode", "gbnf_image_flow_actnorm_stats",
     "gbnf_comm_unique_id", "gbnf_comm_create", "gbnf_comm_destroy", "gbnf_comm_info", "gbnf_mixture_group_log_prob",
     "gbnf_group_graph_create", "gbnf_group_graph_launch", "gbnf_group_graph_destroy",
     "gbnf_flow_numerics", "gbnf_mixture_numerics", "gbnf_tuning_set", "gbnf_tuning_get",
@@ -178,6 +178,7 @@ def lib():
     L.gbnf_image_flow_forward.argtypes = [vp, vp, vp, i64, vp, vp, vp, vp, i64, vp]
     L.gbnf_image_flow_prior.argtypes = [vp, C.POINTER(C.c_float)]
     L.gbnf_image_flow_numerics.argtypes = [vp, C.POINTER(NumericsStatus)]
+    L.gbnf_image_flow_repair_counts.argtypes = [vp, C.POINTER(i64), C.POINTER(i64), C.POINTER(i64), C.POINTER(i64), C.POINTER(C.c_float)]
     L.gbnf_comm_unique_id.argtypes = [C.POINTER(C.c_uint8)]
     L.gbnf_comm_create.argtypes = [C.POINTER(C.c_uint8), i32, i32, C.POINTER(vp)]
     L.gbnf_comm_destroy.argtypes = [vp]
@@ -417,6 +418,15 @@ class NativeImageFlow:
         st = NumericsStatus()
         _check(lib().gbnf_image_flow_numerics(self.handle, C.byref(st)))
         return st
+
+    def repair_counts(self):
+        """gbnf_image_flow_repair_counts: what the same-call protocol behind the split-f16 pass has done so far (pinned
+        words, no synchronisation): calls that marked an image, images re-evaluated on exact f32, on-data checks completed /
+        failed, the worst relative difference a check has seen."""
+        a, b, c, d, w = C.c_int64(), C.c_int64(), C.c_int64(), C.c_int64(), C.c_float()
+        _check(lib().gbnf_image_flow_repair_counts(self.handle, C.byref(a), C.byref(b), C.byref(c), C.byref(d), C.byref(w)))
+        return {"marked_calls": a.value, "repaired_images": b.value, "data_checks": c.value, "failed_checks": d.value,
+                "worst_check_rel_err": w.value}
 
     def actnorm_stats(self, x, noise, index):
         """gbnf_image_flow_actnorm_stats: (mean (C,), var (C,)) device tensors of the tensor that reaches ActNorm2d number

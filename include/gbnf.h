@@ -438,16 +438,28 @@ int gbnf_image_flow_forward(const gbnf_image_flow* flow, const float* x, const f
                             float* ldj, float* ll, void* workspace, int64_t workspace_bytes, void* stream);
 /* The top prior per channel: mean (Cz,) then log-variance (Cz,) into a HOST buffer of 2 Cz floats. */
 int gbnf_image_flow_prior(const gbnf_image_flow* flow, float* mean_logvar_host);
-/* State of the image path's numerics protocol (round 4; the tabular one: gbnf_flow_numerics).  The coupling nets run on
+/* State of the image path's numerics protocol (the tabular one: gbnf_flow_numerics).  The coupling nets run on
  * split-f16 MFMA (GBNF_MATH_F16X3) when the create-time probe -- 4 synthetic images through both arithmetic paths --
  * agrees with the exact-f32 kernels to `tolerance` (worst_rel_err = what it measured), else the handle runs on exact f32
- * (math_mode GBNF_MATH_F32, demoted = 1).  On split-f16 every operand is range-watched: an image that met a value beyond
- * +-65504 is counted (gbnf_saturation_count) and never returned with its clamped value: its z / ldj / ll are NaN, and from the
- * first call on which the handle has SEEN such an image (pinned flag, no synchronisation) every call re-evaluates its marked
- * images on the exact-f32 kernels behind the split-f16 pass (up to 8 per call; further ones stay NaN).  Environment
- * GBNF_IMAGE_REPAIR=2: the re-evaluation pass from the very first call on (same-call repair, ~3-8 % of a call when nothing is
- * marked); =0: none (timing only).  `checks` = calls that marked an image so far. */
+ * (math_mode GBNF_MATH_F32, demoted = 1).  On split-f16 every operand is range-watched, and what the watch finds is dealt
+ * with IN THE SAME CALL, on the same stream, for every image concerned (round 5: no capacity, no "from the next call on"):
+ *   - range: an image that met a value beyond +-65504 is counted (gbnf_saturation_count) and marked; ONE repair launch behind
+ *     the split-f16 pass (it returns at once when no image of the call is marked) walks every marked image through the
+ *     exact-f32 sequence and overwrites its z / ldj / ll (x on the way back): the caller sees what a GBNF_MATH_F32 handle
+ *     returns, never NaN and never a clamped value.  Slow per image (one workgroup each), rare by construction.
+ *   - precision on the caller's data: on a handle's first forward launch and every `check_every`-th after it (gbnf_tuning_set;
+ *     counted on the device, so HIP-graph replays are covered) up to 2 unmarked images are evaluated on exact f32 as well and
+ *     compared with the split-f16 result on the device (`check_tolerance_e9`).  A failed check makes the repair launch of that
+ *     very call -- and of every later one -- re-evaluate ALL images, and raises a pinned word: later (non-captured) calls run
+ *     the exact-f32 kernels directly (math_mode reads GBNF_MATH_F32, demoted = 1).
+ * Environment GBNF_IMAGE_REPAIR=0: nothing behind the split-f16 pass (timing only: out-of-range images keep clamped values).
+ * `checks` = calls that marked an image so far; gbnf_image_flow_repair_counts has the rest.  Never synchronises. */
 int gbnf_image_flow_numerics(const gbnf_image_flow* flow, gbnf_numerics_status* out);
+/* Counters of that protocol (pinned host words the device updates; no synchronisation; any pointer may be NULL): calls that
+ * marked an image, images re-evaluated on exact f32, on-data checks completed / failed, the worst relative log-likelihood
+ * difference a check has seen. */
+int gbnf_image_flow_repair_counts(const gbnf_image_flow* flow, int64_t* marked_calls, int64_t* repaired_images,
+                                  int64_t* data_checks, int64_t* failed_checks, float* worst_check_rel_err);
 /* Replaces (one layer at a time): _ActNorm.initialize_parameters for ActNorm2d (models/layers.py:473-486, 548-557), the
  * data-dependent initialisation the first training-mode forward of an image Glow performs layer by layer.  ActNorm2d number
  * `index` of the component in module order -- per FlowStep its own ActNorm2d, then the one behind each Conv2d of its coupling
@@ -468,10 +480,10 @@ int gbnf_image_flow_actnorm_stats(const gbnf_image_flow* flow, const float* x, c
  * z (n,Cz,Hz,Wz); x (n,C,H,W).  eps: the standard-normal draws behind Split2d's samples (the caller's RNG, so that
  * sampling is reproducible and testable): level 0 first, each level a contiguous (n, C_l/2, H_l, W_l) array,
  * gbnf_image_flow_eps_floats() floats per image in all (= C*H*W - Cz*Hz*Wz); may be NULL for a one-level flow.
- * The coupling networks run on the fused split-f16 kernel like the forward (round 4) where the handle does; an image whose
- * hidden activation leaves the fp16 range comes back as NaN (never a clamped value) and raises the handle's `seen` word
- * (gbnf_image_flow_numerics.checks) -- from the next call on the handle's inverse runs on the exact-f32 convolution kernels,
- * as it always does for a handle created with GBNF_MATH_F32 or demoted by the probe.  workspace as for gbnf_image_flow_forward. */
+ * The coupling networks run on the fused split-f16 kernel like the forward where the handle does; an image whose hidden
+ * activation leaves the fp16 range is re-evaluated on the exact-f32 sequence by the repair launch behind the pass, in this
+ * call (see gbnf_image_flow_numerics).  A handle created with GBNF_MATH_F32, demoted by the probe or by an on-data check of
+ * the forward direction runs the exact-f32 convolution kernels.  workspace as for gbnf_image_flow_forward. */
 int gbnf_image_flow_eps_floats(const gbnf_image_flow* flow, int64_t* per_image);
 int gbnf_image_flow_inverse(const gbnf_image_flow* flow, const float* z, const float* eps, float temperature, int64_t n,
                             float* x, void* workspace, int64_t workspace_bytes, void* stream);

@@ -239,9 +239,50 @@ def test_image_out_of_range_model_is_caught_by_the_probe():
 
 def test_image_range_marks_and_repair_without_the_probe(monkeypatch):
     """The same model with the probe switched off (GBNF_IMAGE_NO_PROBE: the handle stays on split f16, as for a model that only
-    the caller's DATA drives out of range).  Every image is out of range.  First call: every image comes back NaN -- never a
-    clamped value -- and is counted.  From the second call on the handle has seen a mark: the first 8 marked images of a call are
-    re-evaluated on the exact-f32 kernels behind the split-f16 pass, images beyond that capacity stay NaN."""
+    the caller's DATA drives out of range).  EVERY image of the batch is out of range.  The very first call -- and every later
+    one -- returns what the exact-f32 handle returns for every image: the repair launch behind the split-f16 pass walks each
+    marked image through the exact-f32 sequence in the same call, without a capacity (no NaN where the
+    reference is finite)."""
+    import torch
+    from gbnf_amd import native, synth
+    from oracle import gbnf_oracle as oracle
+    monkeypatch.setenv("GBNF_IMAGE_NO_PROBE", "1")
+    native.tuning_set("check_every", -1)           # (range protocol alone: the on-data check has its own test)
+    try:
+        dev = torch.device("cuda:0")
+        sp = _blow_up_hidden(synth.synth_image_glow_spec((3, 32, 32), h=64, K=2, L=2, seed=11))
+        flow = native.NativeImageFlow(sp)
+        assert native.MATH_NAME[int(flow.numerics().math_mode)] == "f16x3"
+        x, noise = synth.synth_image_batch(11, seed=3)
+        zo, _, _, ld32, ll32 = oracle.image_component_forward(sp, x, noise)
+        native.saturation_count(reset=True)
+        xd, nd = torch.from_numpy(x).to(dev), torch.from_numpy(noise).to(dev)
+        z, ldj, ll = flow.forward(xd, nd)                                  # FIRST call, 11 marked images (> the old capacity of 8)
+        assert native.saturation_count(reset=True) > 0
+        assert rel_err(ll.cpu().numpy(), ll32) < LL_RTOL and rel_err(ldj.cpu().numpy(), ld32) < LL_RTOL
+        assert np.abs(z.cpu().numpy() - zo).max() <= 2e-5 * max(1.0, float(np.abs(zo).max()))
+        rc = flow.repair_counts()
+        assert int(flow.numerics().checks) == 1 and rc["marked_calls"] == 1 and rc["repaired_images"] == 11
+        # ... exactly what the exact-f32 handle gives (the same code on the same image; log-det sums are atomic: not bit for bit)
+        monkeypatch.setenv("GBNF_MATH", "f32")
+        exact = native.NativeImageFlow(sp)
+        monkeypatch.delenv("GBNF_MATH")
+        z3, ldj3, ll3 = exact.forward(xd, nd)
+        assert rel_err(ll.cpu().numpy(), ll3.cpu().numpy()) < 1e-6 and torch.equal(z, z3)
+        # more images than repair workgroups (256): the workgroups loop
+        xb, nb_ = synth.synth_image_batch(300, seed=4)
+        z4, ldj4, ll4 = flow.forward(torch.from_numpy(xb).to(dev), torch.from_numpy(nb_).to(dev), want_z=False)
+        _, _, ll5 = exact.forward(torch.from_numpy(xb).to(dev), torch.from_numpy(nb_).to(dev), want_z=False)
+        assert torch.isfinite(ll4).all() and rel_err(ll4.cpu().numpy(), ll5.cpu().numpy()) < 1e-6
+        assert flow.repair_counts()["repaired_images"] == 311
+    finally:
+        native.tuning_set("check_every", 256)
+
+
+def test_image_graph_captured_before_any_mark_repairs_a_later_batch(monkeypatch):
+    """a HIP graph of the call captured while the handle had never seen a mark must still repair an
+    out-of-range batch it is replayed on later -- the repair launch is part of every call's sequence from the start, and the
+    on-data check schedule is counted on the device."""
     import torch
     from gbnf_amd import native, synth
     from oracle import gbnf_oracle as oracle
@@ -249,28 +290,56 @@ def test_image_range_marks_and_repair_without_the_probe(monkeypatch):
     dev = torch.device("cuda:0")
     sp = _blow_up_hidden(synth.synth_image_glow_spec((3, 32, 32), h=64, K=2, L=2, seed=11))
     flow = native.NativeImageFlow(sp)
-    assert native.MATH_NAME[int(flow.numerics().math_mode)] == "f16x3"
-    x, noise = synth.synth_image_batch(11, seed=3)
+    x, noise = synth.synth_image_batch(5, seed=3)
     _, _, _, ld32, ll32 = oracle.image_component_forward(sp, x, noise)
-    native.saturation_count(reset=True)
+    xs, ns = torch.zeros(5, 3, 32, 32, device=dev), torch.zeros(5, 3, 32, 32, device=dev)
+    xs.fill_(0.5); ns.fill_(0.5)
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        flow.forward(xs, ns)                                            # warm-up (allocates the workspace) outside the capture
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, stream=side):
+            z, ldj, ll = flow.forward(xs, ns)
+    xs.copy_(torch.from_numpy(x)); ns.copy_(torch.from_numpy(noise))
+    g.replay()
+    torch.cuda.synchronize()
+    assert rel_err(ll.cpu().numpy(), ll32) < LL_RTOL and rel_err(ldj.cpu().numpy(), ld32) < LL_RTOL
+
+
+def test_image_on_data_check_demotes_and_repairs_the_failing_call(monkeypatch):
+    """The periodic on-data precision check (first launch, every check_every-th): with the tolerance forced to zero the first
+    call's check fails -> the repair launch of THAT call re-evaluates every image (results = the exact-f32 handle's), the pinned
+    word is raised and the next call runs the exact-f32 kernels directly."""
+    import torch
+    from gbnf_amd import native, synth
+    dev = torch.device("cuda:0")
+    sp = synth.synth_image_glow_spec((3, 32, 32), h=64, K=2, L=2, seed=5)
+    x, noise = synth.synth_image_batch(6, seed=9)
     xd, nd = torch.from_numpy(x).to(dev), torch.from_numpy(noise).to(dev)
-    z, ldj, ll = flow.forward(xd, nd)
-    assert torch.isnan(ll).all() and torch.isnan(ldj).all() and torch.isnan(z).all()       # loud, not wrong
-    assert native.saturation_count(reset=True) > 0
-    assert int(flow.numerics().checks) == 1
-    z, ldj, ll = flow.forward(xd, nd)                                  # the handle has seen a mark: gated exact-f32 pass
-    llh = ll.cpu().numpy()
-    assert rel_err(llh[:8], ll32[:8]) < LL_RTOL and rel_err(ldj.cpu().numpy()[:8], ld32[:8]) < LL_RTOL
-    assert np.isnan(llh[8:]).all() and torch.isnan(z[8:]).all()        # beyond the repair capacity
-    # a batch within the capacity is repaired completely: what the exact-f32 handle gives (log-det sums are atomic: not bit for bit)
-    z2, ldj2, ll2 = flow.forward(xd[:5], nd[:5])
-    monkeypatch.setenv("GBNF_MATH", "f32")
-    exact = native.NativeImageFlow(sp)
-    monkeypatch.delenv("GBNF_MATH")
-    z3, ldj3, ll3 = exact.forward(xd[:5], nd[:5])
-    assert rel_err(ll2.cpu().numpy(), ll3.cpu().numpy()) < 1e-6 and torch.equal(z2, z3)
-    # ... and a well-scaled batch through the same handle is untouched by the (gated) pass
-    assert int(flow.numerics().checks) == 3
+    exact = native.NativeImageFlow(sp, math="f32")
+    z3, ldj3, ll3 = exact.forward(xd, nd)
+    flow = native.NativeImageFlow(sp)
+    assert native.MATH_NAME[int(flow.numerics().math_mode)] == "f16x3"
+    z0, ldj0, ll0 = flow.forward(xd, nd)                                  # ordinary tolerance: the check passes
+    torch.cuda.synchronize()
+    rc = flow.repair_counts()
+    assert rc["data_checks"] == 2 and rc["failed_checks"] == 0 and rc["worst_check_rel_err"] < 2.5e-6 and rc["marked_calls"] == 0
+    flow2 = native.NativeImageFlow(sp)
+    native.tuning_set("check_tolerance_e9", 0)
+    try:
+        z, ldj, ll = flow2.forward(xd, nd)
+        torch.cuda.synchronize()
+    finally:
+        native.tuning_set("check_tolerance_e9", 2500)
+    rc = flow2.repair_counts()
+    assert rc["failed_checks"] >= 1
+    assert torch.equal(z, z3) and rel_err(ll.cpu().numpy(), ll3.cpu().numpy()) < 1e-6        # the failing call itself: all on exact f32
+    st = flow2.numerics()
+    assert bool(st.demoted) and native.MATH_NAME[int(st.math_mode)] == "f32"
+    z2, ldj2, ll2 = flow2.forward(xd, nd)                                 # from now on: the exact-f32 kernels directly
+    assert torch.equal(z2, z3)
 
 
 def test_image_well_scaled_model_stays_on_split_f16_and_unmarked():
@@ -286,6 +355,8 @@ def test_image_well_scaled_model_stays_on_split_f16_and_unmarked():
     flow.forward(torch.from_numpy(x).to(dev), torch.from_numpy(noise).to(dev))
     torch.cuda.synchronize()
     assert native.saturation_count(reset=True) == 0 and int(flow.numerics().checks) == 0
+    rc = flow.repair_counts()                                   # nothing marked, nothing repaired; the first launch's on-data check passed
+    assert rc["marked_calls"] == 0 and rc["repaired_images"] == 0 and rc["failed_checks"] == 0 and rc["data_checks"] == 2
 
 
 @pytest.mark.parametrize("size,h,K,L,kw", [((1, 28, 28), 256, 3, 2, {}), ((1, 28, 20), 64, 2, 2, {}), ((1, 28, 20), 256, 2, 1, {"depth": 2}),
@@ -371,8 +442,8 @@ def test_image_inverse_on_inputs_smaller_than_the_storage(size, h, K, L, kw):
 
 
 def test_image_range_marks_and_repair_on_a_map_smaller_than_its_storage(monkeypatch):
-    """The marks -> gather -> exact-f32 pass -> scatter protocol with x, noise and z of the map's own size (1 x 28 x 28 in 16 x 16
-    storage): first call NaN and counted, second call repaired to the float32 oracle."""
+    """The marks -> repair launch protocol with x, noise and z of the map's own size (1 x 28 x 28 in 16 x 16 storage): the first
+    call is repaired to the float32 oracle."""
     import torch
     from gbnf_amd import native, synth
     from oracle import gbnf_oracle as oracle
@@ -385,12 +456,11 @@ def test_image_range_marks_and_repair_on_a_map_smaller_than_its_storage(monkeypa
     x, noise = synth.synth_image_batch(6, size, seed=3)
     zo, _, _, ld32, ll32 = oracle.image_component_forward(sp, x, noise)
     xd, nd = torch.from_numpy(x).to(dev), torch.from_numpy(noise).to(dev)
-    z, ldj, ll = flow.forward(xd, nd)
-    assert torch.isnan(ll).all() and torch.isnan(z).all()
-    z, ldj, ll = flow.forward(xd, nd)
-    assert tuple(z.shape) == zo.shape
-    assert rel_err(ll.cpu().numpy(), ll32) < LL_RTOL and rel_err(ldj.cpu().numpy(), ld32) < LL_RTOL
-    assert np.abs(z.cpu().numpy() - zo).max() <= 2e-5 * max(1.0, float(np.abs(zo).max()))
+    for _ in range(2):
+        z, ldj, ll = flow.forward(xd, nd)
+        assert tuple(z.shape) == zo.shape
+        assert rel_err(ll.cpu().numpy(), ll32) < LL_RTOL and rel_err(ldj.cpu().numpy(), ld32) < LL_RTOL
+        assert np.abs(z.cpu().numpy() - zo).max() <= 2e-5 * max(1.0, float(np.abs(zo).max()))
 
 
 from conftest import IMAGE_ACTNORM_INIT_CASES, load_image_actnorm_init_case  # noqa: E402
@@ -426,17 +496,17 @@ def test_image_actnorm_data_init_matches_reference(name):
     assert all(torch.equal(b, a.logs.detach()) for b, a in zip(before, acts))
 
 
-def test_image_inverse_on_split_f16_marks_then_runs_exact(monkeypatch):
+@pytest.mark.parametrize("size,L", [((3, 32, 32), 2), ((1, 28, 28), 2), ((3, 32, 32), 3)])
+def test_image_inverse_on_split_f16_repairs_in_the_same_call(size, L, monkeypatch):
     """z -> x runs the fused split-f16 coupling-net kernel like the forward.  An image whose hidden activation leaves the fp16
-    range comes back as NaN (never a clamped value) and raises the handle's `seen` word; from the next call on the handle's
-    inverse runs on the exact-f32 convolutions and matches the oracle."""
+    range is re-evaluated on the exact-f32 sequence by the repair launch of the same call: the first call already matches the
+    oracle (round 4 returned NaN once)."""
     import torch
     from gbnf_amd import native, synth
     from oracle import gbnf_oracle as oracle
     monkeypatch.setenv("GBNF_IMAGE_NO_PROBE", "1")
     dev = torch.device("cuda:0")
-    size = (3, 32, 32)
-    sp = _blow_up_hidden(synth.synth_image_glow_spec(size, h=64, K=2, L=2, seed=11))
+    sp = _blow_up_hidden(synth.synth_image_glow_spec(size, h=64, K=2, L=L, seed=11))
     flow = native.NativeImageFlow(sp)
     assert native.MATH_NAME[int(flow.numerics().math_mode)] == "f16x3"
     rng = np.random.RandomState(5)
@@ -444,16 +514,15 @@ def test_image_inverse_on_split_f16_marks_then_runs_exact(monkeypatch):
     z = (0.7 * rng.standard_normal((n,) + flow.z_shape)).astype(np.float32)
     eps = [rng.standard_normal((n,) + tuple(sh)).astype(np.float32) for sh in flow.split_shapes()]
     zd, ed = torch.from_numpy(z).to(dev), [torch.from_numpy(e).to(dev) for e in eps]
-    x1 = flow.inverse(zd, ed, 0.9)
-    torch.cuda.synchronize()
-    assert torch.isnan(x1).all()                               # every image of this model is out of range: loud, not wrong
-    assert int(flow.numerics().checks) >= 1
-    x2 = flow.inverse(zd, ed, 0.9)                             # the handle has seen a mark: exact-f32 convolutions
     x_or = oracle.image_component_inverse(sp, z, eps, 0.9, dtype=torch.float64)
-    assert np.abs(x2.cpu().numpy() - x_or).max() <= 2e-5
-    # a well-scaled model stays on the fast kernels and agrees with the exact-f32 handle
-    sp2 = synth.synth_image_glow_spec(size, h=64, K=2, L=2, seed=12)
-    fast = native.NativeImageFlow(sp2)
-    exact = native.NativeImageFlow(sp2, math="f32")
-    xa, xb = fast.inverse(zd, ed, 0.9), exact.inverse(zd, ed, 0.9)
-    assert int(fast.numerics().checks) == 0 and float((xa - xb).abs().max()) <= 2e-5
+    for _ in range(2):
+        x1 = flow.inverse(zd, ed, 0.9)
+        assert np.abs(x1.cpu().numpy() - x_or).max() <= 2e-5
+    assert int(flow.numerics().checks) == 2 and flow.repair_counts()["repaired_images"] == 2 * n
+    if size == (3, 32, 32) and L == 2:
+        # a well-scaled model stays on the fast kernels and agrees with the exact-f32 handle
+        sp2 = synth.synth_image_glow_spec(size, h=64, K=2, L=2, seed=12)
+        fast = native.NativeImageFlow(sp2)
+        exact = native.NativeImageFlow(sp2, math="f32")
+        xa, xb = fast.inverse(zd, ed, 0.9), exact.inverse(zd, ed, 0.9)
+        assert int(fast.numerics().checks) == 0 and float((xa - xb).abs().max()) <= 2e-5
