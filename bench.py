@@ -341,9 +341,10 @@ def main():
     ap.add_argument("--no-extra-legs", action="store_true", help="skip the f32-exact and group-1 legs of the N=1 line")
     ap.add_argument("--no-config-legs", action="store_true", help="skip legs.configs (the other BASELINE configurations, run as child processes)")
     ap.add_argument("--graph-exchange", action="store_true", help="sharded runs over real ranks: capture the group (RCCL all-gather included) into a HIP graph")
-    ap.add_argument("--pipeline", default="library", choices=["library", "torch"],
-                    help="sharded runs: 'library' = RCCL called from libgbnf_hip.so, one HIP graph per group (default); 'torch' = the "
-                         "round-1..3 pipeline (torch.distributed all-gather on a second stream)")
+    ap.add_argument("--pipeline", default="auto", choices=["auto", "library", "torch"],
+                    help="sharded runs: 'library' = RCCL called from libgbnf_hip.so, one HIP graph per group; 'torch' = the "
+                         "torch.distributed all-gather on a second stream; 'auto' (default) = library for the one-rank emulation, "
+                         "torch across real ranks (the library form has never run on more than one rank: ADVICE r4)")
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -447,7 +448,17 @@ def main():
         # one group in the whole run: nothing to overlap the exchange with, so it stays on the kernel's stream (a cross-stream
         # event hand-over costs ~20 us of latency on this stack)
         pipe = None
-        if gather and args.pipeline == "library":
+        want_library = args.pipeline == "library" or (args.pipeline == "auto" and world == 1)
+        if gather and want_library and world > 1:
+            # agree BEFORE anything collective is attempted: a local probe on every rank (librccl loadable, an id obtainable),
+            # the flags meet in one all_reduce(MIN); only a unanimous yes goes on to build communicators
+            ok, why = native.Comm.probe()
+            okt = torch.tensor([1 if ok else 0], dtype=torch.int32, device=dev)
+            dist.all_reduce(okt, op=dist.ReduceOp.MIN)
+            if int(okt.item()) == 0:
+                want_library = False
+                pipeline_used["fallback_reason"] = why or "another rank cannot load RCCL"
+        if gather and want_library:
             # round 4: the exchange inside the library -- per group ONE hipGraphLaunch of {flow, repair, ncclAllGather, recursion}
             # (sharded.LibraryGroupPipeline); a refused communicator / capture falls back to the torch.distributed pipeline
             try:
@@ -458,7 +469,7 @@ def main():
                 pipe = sharded.LibraryGroupPipeline(mix, C, c0, c1, rho, B, group, gather, graph=use_graph, overlap=steps > group)
                 pipeline_used["kind"] = "library"
                 pipeline_used["group_graph"] = bool(use_graph)
-            except (native.GbnfError, RuntimeError, OSError) as e:
+            except Exception as e:          # (GbnfError, ValueError, RuntimeError, OSError: every rank raises or none -- see Comm.from_torch_distributed)
                 pipeline_used["fallback_reason"] = f"{type(e).__name__}: {e}"
                 pipe = None
             if world > 1:
@@ -581,6 +592,8 @@ def main():
         value = B * args.steps / main_run["elapsed"]
         math = main_run["name"]
         rl = roofline(main_run, S)
+        if pipeline_used.get("kind") == "library":
+            rl["kernel"] += " + exchange + recursion (library pipeline: the events bracket the whole group; the two slots' groups overlap)"
         rl["note"] = ("achieved = ALGORITHMIC f32 flops / launch time (HIP events around the launch); the split paths run "
                       "3x / 6x (+padding) that on the f16 pipe (executed_*). Measured model (profiles/r4_ubench_balance.txt, "
                       "r4_ablation_upper_bounds.txt): a SIMD spends 17.6 cycles per MFMA on the matrix pipe + weight-fragment "
@@ -612,7 +625,9 @@ def main():
                            "allgather_bytes_per_rank": 4 * (c1 - c0) * S * B, "pipeline": dict(pipeline_used),
                            "graph_errors": list(getattr(main_run["keep"][2], "graph_errors", []))[:2],
                            "note": ("library pipeline: ncclAllGather is issued by libgbnf_hip.so inside the group's HIP graph; "
-                                    "roofline.launch_ms brackets the whole group (flow launch, exchange, recursion)")
+                                    "roofline.launch_ms brackets the WHOLE group (flow launch, exchange, recursion) on its slot's stream, "
+                                    "and the two slots' groups overlap: launch_ms / achieved / flows_only_samples_per_s of this run are "
+                                    "whole-group, overlapped times -- not the flow kernel alone (that is the N=1 line's roofline)")
                                    if pipeline_used.get("kind") == "library" else None}
         if world == 1 and not args.no_extra_legs:
             legs = {}

@@ -910,15 +910,45 @@ class Comm:
         _check(lib().gbnf_comm_unique_id(buf))
         return bytes(buf)
 
+    @staticmethod
+    def probe():
+        """Local, non-collective: can this process build a communicator at all (librccl loadable, its symbols bound, an id
+        obtainable)?  -> (ok, reason)."""
+        try:
+            Comm.unique_id()
+            return True, ""
+        except Exception as e:                 # GbnfError (dlopen / UNSUPPORTED), OSError (library missing)
+            return False, f"{type(e).__name__}: {e}"
+
     @classmethod
     def from_torch_distributed(cls, group=None):
+        """The ranks AGREE before anything that can block: every rank probes locally, the flags meet in one
+        all_reduce(MIN), and only then does rank 0 broadcast the id (always: ``None`` if it could not make one) and every rank
+        enter ncclCommInitRank.  A rank that cannot load RCCL therefore makes every rank raise GbnfError instead of leaving its
+        peers inside a collective."""
+        import torch
         import torch.distributed as dist
         if not dist.is_initialized():
             return cls(0, 1, cls.unique_id())
         rank, world = dist.get_rank(group), dist.get_world_size(group)
-        box = [cls.unique_id() if rank == 0 else None]
-        if world > 1:
-            dist.broadcast_object_list(box, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
+        if world == 1:
+            return cls(0, 1, cls.unique_id())
+        ok, why = cls.probe()
+        dev = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend(group) == "nccl" else torch.device("cpu")
+        flag = torch.tensor([1 if ok else 0], dtype=torch.int32, device=dev)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=group)
+        if int(flag.item()) == 0:
+            raise GbnfError("no library communicator: " + (why if not ok else "another rank cannot load RCCL"))
+        uid = None
+        if rank == 0:
+            try:
+                uid = cls.unique_id()
+            except Exception:
+                uid = None
+        box = [uid]
+        dist.broadcast_object_list(box, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
+        if box[0] is None:
+            raise GbnfError("no library communicator: rank 0 could not obtain an RCCL unique id")
         return cls(rank, world, box[0])
 
     def close(self):

@@ -306,8 +306,15 @@ class LibraryGroupPipeline:
     communicator: consecutive groups are independent, so group g + 1 (slot 1) runs beside group g (slot 0) with no event
     between them, and a slot is re-used in its own stream's order.  ``gather`` False: one rank, no exchange.
 
+    The two slots' collectives run on two communicators of one device with no order between them: that relies on both being
+    co-resident (two ncclAllGather kernels of a few workgroups each; true on every run so far, all of them one rank per box --
+    a real multi-rank run of this form has not happened yet, which is why ``bench.py`` keeps ``GroupPipeline`` as the default
+    for world > 1).
+
     Same surface as ``GroupPipeline``: ``bind(xs)`` -> token, ``submit(token | xs, kernel_events)`` -> (G tensor of the slot,
-    slot), ``drain()``.  ``graph=False`` keeps the plain library call per group (also the automatic fall-back when a capture is
+    slot), ``drain()``.  The returned G is the slot's LIVE buffer: it is overwritten by the submit after the next one;
+    ``self.done[slot]`` is recorded behind the group -- wait on it (or ``drain()``) before reading, and read before re-using
+    the slot.  ``graph=False`` keeps the plain library call per group (also the automatic fall-back when a capture is
     refused: ``graph_errors`` lists why)."""
 
     NBUF = 2
@@ -329,7 +336,7 @@ class LibraryGroupPipeline:
         if self.gather and (self.c1 - self.c0) * self.comms[0].world != self.C:
             raise ValueError("the component blocks must be equal and contiguous rank by rank (sharded.partition)")
         self.done = [torch.cuda.Event() for _ in range(nslots)]
-        self.start = torch.cuda.Event()
+        self.starts = [torch.cuda.Event() for _ in range(nslots)]
         self._bufs = {}
         self.gi = 0
         self.gather_events = None
@@ -366,9 +373,12 @@ class LibraryGroupPipeline:
         token = xs if isinstance(xs, _BoundGroup) else self.bind(xs)
         _, _, G = self._buffers(len(token.xs))
         st = self.streams[q]
-        if st is not self.main and self.gi < self.nslots:
-            self.start.record(self.main)            # the slot's stream starts behind whatever the caller enqueued before
-            st.wait_event(self.start)
+        if st is not self.main:
+            # every group starts behind whatever the caller has enqueued on the main stream so far (a fresh host-to-device copy of
+            # its batches, an update of rho): an event record + wait, ~3 us of host time per group
+            ev = self.starts[q]
+            ev.record(self.main)
+            st.wait_event(ev)
         if kernel_events is not None:
             kernel_events[0].record(st)
         token.launches[q].launch(ctypes.c_void_p(st.cuda_stream))

@@ -103,3 +103,46 @@ def test_row_partition_covers_ragged_batches():
     assert sharded.row_partition(10, 4) == [(0, 3), (3, 6), (6, 8), (8, 10)]
     assert sharded.row_partition(3, 4) == [(0, 1), (1, 2), (2, 3), (3, 3)]
     assert sharded.row_partition(8, 1) == [(0, 8)]
+
+
+def _comm_worker(rank, world, port, bad_rank, id_fails, ret):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from gbnf_amd import native
+        made = []
+        if rank == bad_rank:
+            native.Comm.probe = staticmethod(lambda: (False, "librccl.so: cannot open shared object file (injected)"))
+        else:
+            native.Comm.probe = staticmethod(lambda: (True, ""))
+        if id_fails:                                       # rank 0's id request fails AFTER a unanimous probe
+            def boom():
+                raise native.GbnfError("ncclGetUniqueId failed (injected)")
+            native.Comm.unique_id = staticmethod(boom)
+        else:
+            native.Comm.unique_id = staticmethod(lambda: bytes(128))
+        native.Comm.__init__ = lambda self, r, w, uid: made.append((r, w, len(uid)))      # (no RCCL here: the hand-shake only)
+        try:
+            native.Comm.from_torch_distributed()
+            ret[rank] = ("ok", made)
+        except native.GbnfError as e:
+            ret[rank] = ("raised", str(e))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(120)
+@pytest.mark.parametrize("bad_rank,id_fails", [(1, False), (0, False), (-1, True), (-1, False)])
+def test_library_communicator_handshake_never_leaves_a_rank_behind(bad_rank, id_fails):
+    """the ranks agree BEFORE any collective of the communicator set-up.  A rank whose local probe fails (RCCL not
+    loadable) makes every rank raise; so does an id request that fails on rank 0 after a unanimous probe (rank 0 still performs
+    the broadcast, sending None); with neither, every rank reaches ncclCommInitRank with the same 128-byte id.  No case hangs."""
+    world = 2
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_comm_worker, args=(world, _free_port(), bad_rank, id_fails, ret), nprocs=world, join=True)
+    if bad_rank >= 0 or id_fails:
+        assert all(ret[r][0] == "raised" for r in range(world)), dict(ret)
+    else:
+        assert [ret[r] for r in range(world)] == [("ok", [(r, world, 128)]) for r in range(world)]
