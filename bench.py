@@ -251,6 +251,18 @@ def measured_traffic(config, B, C, S, math, world):
     return None
 
 
+def traffic_source():
+    """Where `roofline.traffic` comes from: NOT counted in this run -- looked up in the committed PMC passes of the same workload."""
+    path = os.path.join(REPO, "profiles", "headline_traffic.json")
+    try:
+        rec = json.load(open(path))
+    except (OSError, ValueError):
+        return None
+    return {"file": "profiles/headline_traffic.json", "pmc_summary": rec.get("source"), "taken": rec.get("taken"),
+            "note": "looked up by exact workload (config, batch, components, group, math, n_gpus) in the committed rocprofv3 --pmc passes "
+                    "(FETCH_SIZE x 2 + WRITE_SIZE, separate passes); not counted in this run -- null when this run's workload has no pass"}
+
+
 def config_legs(args):
     """The other BASELINE.json configurations, each as a CHILD process that runs before this one touches the GPU (a process
     that has initialised the GPU must not start another program; the children run one after the other, alone on the device):
@@ -567,7 +579,7 @@ def main():
         return {
             "kernel": "gbnf::flow_kernel" if math == "f32" else "gbnf::flow_kernel_hx3",
             "bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
-            "traffic": measured_traffic(args.config, B, C, group, math, world),
+            "traffic": measured_traffic(args.config, B, C, group, math, world), "traffic_source": traffic_source(),
             "launch_ms": r["kern_ms"], "launch_ms_median": r["kern_ms_median"], "launch_ms_min": r["kern_ms_min"],
             "timed_launches": r["timed_launches"],
             # SURVEY 8(d) "flows only": the ll (C, N) tables without the recursion / exchange, from the launch times
@@ -641,6 +653,15 @@ def main():
                 del r
             except native.GbnfError as e:
                 legs["f32_exact"] = {"error": str(e)}
+            try:       # the f32-faithful split mode (>= 24-bit operands, f32 range) on the same workload
+                r = timed_run("bf16x6", S, n_leg, 2 * S, 0.0)
+                rb = roofline(r, S)
+                legs["bf16x6"] = {"value": B * n_leg / r["elapsed"], "unit": "samples/s", "dtype": "bf16x6", "steps": n_leg,
+                                  "launch_ms": r["kern_ms"], "achieved_tflops": rb["achieved"], "peak": rb["peak"], "frac": rb["frac"],
+                                  "executed_frac": rb["executed_frac"], "group": S}
+                del r
+            except native.GbnfError as e:
+                legs["bf16x6"] = {"error": str(e)}
             r = timed_run(args.math, 1, n_leg, 16, 0.0)
             rg = roofline(r, 1)
             legs["group1"] = {"value": B * n_leg / r["elapsed"], "unit": "samples/s", "dtype": r["name"], "steps": n_leg,
@@ -668,6 +689,22 @@ def main():
                 out["max_rel_err_vs_cpu"] = err
         elif args.cpu_seconds > 0:
             out["cpu_baseline"] = None     # reported on the N=1 run only
+        # the figures a reader of a TRUNCATED line (the driver keeps the tail) needs, once more at the very end
+        lg = out.get("legs", {})
+        out["tail_summary"] = {
+            "value": value, "unit": "samples/s", "dtype": math, "group": S, "ms_per_step": out["ms_per_step"],
+            "roofline_frac": rl["frac"], "roofline_executed_frac": rl["executed_frac"], "launch_ms": rl["launch_ms"],
+            "traffic": rl["traffic"], "traffic_file": "profiles/headline_traffic.json (looked up, not counted in this run)",
+            "group1_value": (lg.get("group1") or {}).get("value"), "group1_frac": (lg.get("group1") or {}).get("frac"),
+            "f32_exact_value": (lg.get("f32_exact") or {}).get("value"), "f32_exact_frac_of_f32_peak": (lg.get("f32_exact") or {}).get("frac"),
+            "bf16x6_value": (lg.get("bf16x6") or {}).get("value"), "bf16x6_executed_frac_of_bf16_peak": (lg.get("bf16x6") or {}).get("executed_frac"),
+            "module_evaluate_loop_value": (lg.get("module_evaluate_loop") or {}).get("value"),
+            "module_calls_only_ms": (lg.get("module_evaluate_loop") or {}).get("module_calls_only_ms"),
+            "cpu_baseline_value": (out.get("cpu_baseline") or {}).get("value"), "cpu_cores": (out.get("cpu_baseline") or {}).get("cores"),
+            "max_rel_err_vs_cpu": out.get("max_rel_err_vs_cpu"),
+            "configs": {k: (v.get("value"), (v.get("roofline") or {}).get("frac"), (v.get("roofline") or {}).get("executed_frac"))
+                        for k, v in (lg.get("configs") or {}).items() if isinstance(v, dict)},
+        }
         line = json.dumps(out)
     else:
         line = None

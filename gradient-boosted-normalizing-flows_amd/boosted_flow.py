@@ -35,6 +35,37 @@ from . import spec as gspec
 
 
 # ----------------------------------------------------------------------------- parameter holders
+
+_VERSION = __import__("operator").attrgetter("_version")
+_DATA_PTR = torch.Tensor.data_ptr
+
+
+def _raw_stream(device):
+    """The current stream's handle on ``device`` as an int (no Stream object: this runs on every module call)."""
+    try:
+        return torch._C._cuda_getCurrentRawStream(device.index if device.index is not None else torch.cuda.current_device())
+    except AttributeError:
+        return torch.cuda.current_stream(device).cuda_stream
+
+
+class _ComponentTable:
+    """One batch's (z, ldj) of every component in use (BoostedFlow._serve_from_table) + the ready 5-tuples the module returns."""
+    __slots__ = ("xkey", "x_in", "version", "stream", "n_used", "z", "ldj", "keys", "mix", "outs")
+
+    def __init__(self, xkey, x_in, z, ldj, keys, mix):
+        self.xkey, self.x_in, self.z, self.ldj, self.keys, self.mix = xkey, x_in, z, ldj, keys, mix
+        self.version, self.n_used, self.stream = xkey[1], xkey[5], xkey[6]
+        self.outs = None
+
+    def serve(self, model, x, c):
+        """The early look-up of BoostedFlow.forward: the same tensor object at the same version, on the same stream, the same
+        components in use, component c's parameters untouched -> the ready tuple; anything else -> None (the full path)."""
+        if (not 0 <= c < self.n_used or x._version != self.version or not model.SERVE_ALL_COMPONENTS
+                or (model.num_components if model.all_trained else model.component + 1) != self.n_used
+                or _raw_stream(x.device) != self.stream or model._component_key(c) != self.keys[c]):
+            return None
+        return self.outs[c]
+
 class _CouplingNet(nn.Module):
     """TanhNet / ReLUNet parameter layout: ``network`` = Linear, [act, Linear] x depth, act, Linear
     (models/layers.py:208-243).  nn.Linear's default init is what the reference uses."""
@@ -377,14 +408,22 @@ class BoostedFlow(nn.Module):
         raise ValueError("z_k can only be sampled from ['c', '1:c-1', '1:c', '-c'] "
                          "(corresponding to 'new', 'fixed', or new+fixed components)")
 
+    def _prior_views(self, c, n):
+        """Glow.prior / RealNVPFlow.prior: prior_h (zeros) repeated over the batch, returned as-is -- as broadcast VIEWS here
+        (same values and shapes, no copy kernel per call), kept per (component, batch size) while prior_h is the same tensor."""
+        cache = self.__dict__.setdefault("_prior_cache", {})
+        ph = self.flows[c].prior_h
+        hit = cache.get((c, n))
+        if hit is None or hit[0] is not ph:
+            h = ph.expand(n, -1)
+            hit = (ph, h[:, : self.z_size], h[:, self.z_size:])
+            cache[(c, n)] = hit
+        return hit[1], hit[2]
+
     def encode(self, x, y_onehot, components):
         c = self._sample_component(components) if isinstance(components, str) else int(components)
         z, ldj = self.component_forward(x, c)
-        flow = self.flows[c]
-        # Glow.prior / RealNVPFlow.prior: prior_h (zeros) repeated over the batch, returned as-is -- as a broadcast VIEW
-        # here (same values and shapes, no copy kernel per call)
-        h = flow.prior_h.expand(x.shape[0], -1)
-        z_mu, z_var = h[:, : self.z_size], h[:, self.z_size:]
+        z_mu, z_var = self._prior_views(c, x.shape[0])
         return z, z_mu, z_var, ldj, None
 
     @torch.no_grad()
@@ -404,6 +443,13 @@ class BoostedFlow(nn.Module):
     def forward(self, x=None, y_onehot=None, z=None, temperature=None, components=None, reverse=False):
         if reverse:
             return self.decode(z, y_onehot, temperature, components)
+        # the evaluate loop's calls 2 .. C of a batch (density_experiment.py:562-563): the SAME tensor object again, another
+        # component -- answered from the batch's table before anything else is looked at (see _serve_from_table)
+        tab = self.__dict__.get("_component_table")
+        if tab is not None and x is tab.x_in and type(components) is int and not self.training:
+            out = tab.serve(self, x, components)
+            if out is not None:
+                return out
         return self.encode(x, y_onehot, components)
 
     @torch.no_grad()
@@ -475,27 +521,34 @@ class BoostedFlow(nn.Module):
         return cache[c]
 
     def _apply(self, fn, *a, **k):
-        self.__dict__.pop("_tensor_cache", None)
-        self.__dict__.pop("_perm_cache", None)
+        for name in ("_tensor_cache", "_perm_cache", "_key_cache", "_prior_cache", "_component_table"):
+            self.__dict__.pop(name, None)
         return super()._apply(fn, *a, **k)
+
+    def load_state_dict(self, *a, **k):
+        for name in ("_tensor_cache", "_perm_cache", "_key_cache", "_prior_cache", "_component_table"):      # (assign=True swaps tensor objects)
+            self.__dict__.pop(name, None)
+        return super().load_state_dict(*a, **k)
 
     def _component_key(self, c):
         """What a packed handle of component c depends on: every tensor's version counter and address, every permutation
         (its serial and its tensor's version), every ActNorm's `inited` flag.  Built on every call of the module (40 tensors:
         this is host time of the reference's evaluate loop), so attribute walks through nn.Module.__getattr__ are done once
         per tensor cache, not per call."""
-        params, buffers, layers = self._component_tensors(c)
-        perms = self.__dict__.setdefault("_perm_cache", {})
-        if c not in perms:
-            perms[c] = [(layer.permutation, layer.actnorm) for layer in layers]
-        key = [t._version for t in params]
-        key += [t._version for t in buffers]
-        key += [t.data_ptr() for t in params]
-        for perm, actnorm in perms[c]:    # a permutation is identified by its tensor and that tensor's version counter
-            key.append(perm.indices_serial)
-            key.append(perm.indices._version)
-            key.append(bool(actnorm.inited))
-        return tuple(key)
+        kc = self.__dict__.setdefault("_key_cache", {}).get(c)
+        if kc is None:
+            params, buffers, layers = self._component_tensors(c)
+            perms = self.__dict__.setdefault("_perm_cache", {})
+            if c not in perms:
+                perms[c] = [(layer.permutation, layer.actnorm) for layer in layers]
+            kc = (params + buffers, params, perms[c])
+            self.__dict__["_key_cache"][c] = kc
+        tensors, params, perms = kc
+        # (C-level loops: 40 tensors cost ~8 us here against ~14 us as list comprehensions -- this runs on every module call)
+        key = (tuple(map(_VERSION, tensors)), tuple(map(_DATA_PTR, params)))
+        if perms:                         # a permutation is identified by its tensor and that tensor's version counter
+            key += tuple((perm.indices_serial, perm.indices._version, bool(actnorm.inited)) for perm, actnorm in perms)
+        return key
 
     def _check_ready(self, x):
         if not isinstance(x, torch.Tensor) or not x.is_cuda:
@@ -699,6 +752,13 @@ class BoostedFlow(nn.Module):
     # strides and version counter (an in-place write to x bumps it), the packed handles of the components (rebuilt whenever
     # a parameter's version counter moves: an optimiser step, load_state_dict, a new permutation), and the stream.
     SERVE_ALL_COMPONENTS = True
+    # What a caller must know: (1) the (z, ldj) a served call returns are VIEWS of the batch's (C, N, d) / (C, N)
+    # table, exactly as the reference's outputs are fresh tensors only until the caller writes to them -- an in-place edit of a
+    # served z changes what a later call for the same batch and component returns; clone before editing.  (2) The key cannot see
+    # writes that bypass the version counter (``x.data.copy_``, a HIP-graph replay into a static input buffer, DLPack / custom
+    # kernels writing through a raw pointer): call ``drop_component_table()`` after such a write, or set
+    # ``model.SERVE_ALL_COMPONENTS = False``.  (3) The table holds x and C N d floats until the next batch comes in or
+    # ``drop_component_table()`` is called.
 
     def _serve_from_table(self, x, c, x_in=None):
         """(z, ldj) of component c from the table of the batch, or None when the call is not an evaluation-loop call.
@@ -713,22 +773,25 @@ class BoostedFlow(nn.Module):
         x_in = x if x_in is None else x_in
         try:
             xkey = (x_in.data_ptr(), x_in._version, tuple(x_in.shape), tuple(x_in.stride()), x_in.dtype, n_used,
-                    torch.cuda.current_stream(x.device).cuda_stream)
+                    _raw_stream(x.device))
         except RuntimeError:          # inference tensors keep no version counter: nothing to key on
             return None
         tab = self.__dict__.get("_component_table")
         # entry c depends on x and on component c's parameters only: one component key per call, as the plain path costs
-        if tab is None or tab[0] != xkey or tab[4][c] != self._component_key(c):
+        if tab is None or tab.xkey != xkey or tab.keys[c] != self._component_key(c):
             if self.component_type == "glow" and not all(
                     bool(l.actnorm.inited) for k in range(n_used) for l in self.flows[k].flow.layers):
                 return None           # the reference raises at the call of THAT component: leave it to the plain path
             mix = self.native_mixture(n_used)              # re-packs whatever changed
             z, ldj, _ = mix.component_forward(x, 0, n_used)
-            keys = [self._component_key(k) for k in range(n_used)]
-            # (x_in is held: its storage cannot be freed and handed to another tensor with the same address and version)
-            tab = (xkey, z, ldj, x_in, keys, mix)
+            # (x_in is held: its storage cannot be freed and handed to another tensor with the same address and version;
+            #  the keys are the ones native_mixture has just validated the handles against)
+            tab = _ComponentTable(xkey, x_in, z, ldj, [self._handles[k][0] for k in range(n_used)], mix)
+            zs, ls = z.unbind(0), ldj.unbind(0)
+            n = x.shape[0]
+            tab.outs = [(zs[k], *self._prior_views(k, n), ls[k], None) for k in range(n_used)]
             self.__dict__["_component_table"] = tab
-        return tab[1][c], tab[2][c]
+        return tab.z[c], tab.ldj[c]
 
     def drop_component_table(self):
         """Forget the table of the last batch (frees its (C, N, d) device memory)."""

@@ -1079,6 +1079,12 @@ static int launch_flow(const gbnf_flow* f, const uint32_t* const* table, const u
   const char* const* names = use_second ? f->name2_nt : f->name_nt;
   int nt = pick_nt(n * n_batches, n_comp);
   if (launch[nt] == nullptr) nt = 1;                // geometry compiled for 16-sample waves only
+  // (Launch geometry, measured in round 5 and NOT shipped: a group whose last round of 32-sample waves is a quarter full -- one
+  //  rank of eight at the driver's --steps 20: 20 batches x 4096 rows x 1 component = 2560 waves = 1.25 rounds of 2048 -- split
+  //  by whole batches into the full rounds + the rest as a second launch of 16-sample waves over every CU: 118.9 + 48.8 us
+  //  against 171.2 us for the one launch, and the second launch's own repair launch takes the difference back:
+  //  profiles/r5_emulated_rank_steps20_*_kernel_stats.csv.  The hardware's own tail -- 128 workgroups, one per CU, each a lone
+  //  wave per SIMD -- already runs at 0.44 of a round.)
   const int64_t tiles = (n + 16 * nt - 1) / (16 * nt);
   // f32 kernel: one wave (= block) per tile; the split kernels size their own grid
   const int64_t grid = tiles * n_comp * n_batches;

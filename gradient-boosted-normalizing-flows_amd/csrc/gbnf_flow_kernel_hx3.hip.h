@@ -1576,7 +1576,8 @@ static hipError_t hx3_launch_wv(FlowLaunch p, bool staggered, hipStream_t s) {
   long long grid = (long long)((p.n_tiles + WV - 1) / WV) * p.n_comp * p.n_batches;
   if (grid > 0x7fffffffLL) return hipErrorInvalidValue;
   p.n_items = (int32_t)grid;
-  if (p.repair && grid > 512) grid = 512;           // a repair launch walks the items: one or two workgroups per CU
+  if (p.repair && grid > 256) grid = 256;           // a repair launch walks the items with one workgroup per CU (it almost always returns at once:
+                                                    // 512 workgroups of 160 KB of LDS took 7-10 us to do that, profiles/r5_emulated_rank_steps20_*)
   if (staggered) {
     // A start offset between the two co-resident workgroups was measured and bought nothing
     // (profiles/r2_wg_pairs_stagger_hx32.txt): off by default; GBNF_STAGGER = sleeps of 2048 cycles for experiments

@@ -1807,6 +1807,8 @@ static bool needs_step_launches(const gbnf_trainer* t) {
 
 int gbnf_trainer_set_batch_stats(gbnf_trainer* t, int32_t on) {
   if (!t) return fail(GBNF_ERR_INVALID, "gbnf_trainer_set_batch_stats: trainer is null");
+  // (the step ranges of a batch-statistics sweep are tracked in a 32-bit mask: LiveReduce::skip_steps)
+  if (on && t->K > 32) return fail(GBNF_ERR_UNSUPPORTED, "gbnf_trainer_set_batch_stats: batch statistics support at most 32 steps (K = %d)", t->K);
   if (on && t->kind == GBNF_KIND_REALNVP)
     for (size_t k = 0; k < t->has_norm.size(); ++k)
       if (t->has_norm[k] && !t->stats_bound[k])

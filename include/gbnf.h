@@ -364,7 +364,11 @@ int gbnf_trainer_workspace_bytes(const gbnf_trainer* trainer, int64_t n, int64_t
  * recomputes nothing: the backward kernel chains W3^T -> W2^T -> W1^T on the saved activations, ActNorm / BatchNorm
  * gradients are summed per workgroup and added in a fixed order (bit-identical from run to run; the weight gradients still
  * use float atomics across sample blocks).  Other flows recompute the coupling nets' activations from the trace, and with
- * NULL the whole forward sweep from x. */
+ * NULL the whole forward sweep from x.
+ * Batch-statistics mode (gbnf_trainer_set_batch_stats): the BatchNorm entries of `grads` (log_gamma, beta of every step) MUST
+ * be zero on entry -- the correction for the statistics' dependence on every sample reads THIS call's two batch sums from
+ * them; accumulate several calls by adding up separately zeroed buffers (what the Python mirror does: a fresh buffer per
+ * call).  That mode needs n >= 2 (unbiased variance) and K <= 32. */
 int gbnf_trainer_backward(const gbnf_trainer* trainer, const float* x, int64_t n, const float* trace, const float* g_z,
                           const float* g_ldj, float* g_x, float* grads, void* workspace, int64_t workspace_bytes,
                           void* stream);

@@ -316,9 +316,13 @@ def test_evaluate_loop_is_served_from_one_launch(golden_case):
     G = _evaluate_like_reference(m, x)                      # grad mode ON, as in the reference's evaluate()
     assert rel_err(G.cpu().numpy(), g.G) < LL_RTOL
     tab = m.__dict__["_component_table"]
-    assert tab[1].shape == (g.n_used, x.shape[0], x.shape[1])
+    assert tab.z.shape == (g.n_used, x.shape[0], x.shape[1])
     z1, _, _, l1, _ = m(x=x, components=1)
     assert m.__dict__["_component_table"] is tab            # served: no new table
+    assert m(x=x, components=1) is m(x=x, components=1)     # ... by the early look-up of forward(): the batch's ready tuple
+    xv = x.view_as(x)                                       # another tensor object on the same storage and version: the full key
+    z1v, _, _, l1v, _ = m(x=xv, components=1)
+    assert m.__dict__["_component_table"] is tab and torch.equal(z1v, z1) and torch.equal(l1v, l1)
     assert not z1.requires_grad and not l1.requires_grad
     # the table holds what the per-component launches return, bit for bit
     m.SERVE_ALL_COMPONENTS = False

@@ -110,6 +110,7 @@ def main():
                             how + "; `bench.py --config hepmass_realnvp --batch 65536` (BASELINE configs[2])")]
     if head:
         head["source"] = "profiles/" + name
+        head["taken"] = __import__("datetime").date.today().isoformat() + f" (round {tag}, tools/final_measure.sh)"
         head["other_group_sizes"] = [o for o in others if o]
         json.dump(head, open(os.path.join(P, "headline_traffic.json"), "w"), indent=1)
     # image: all gbnf:: kernels of the run / steps
