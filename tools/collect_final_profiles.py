@@ -3,7 +3,7 @@
 bench lines of every configuration, rocprofv3 kernel stats, the PMC passes, and the traffic tables the bench lines read
 (profiles/headline_traffic.json, image_traffic.json, train_traffic.json).
 
-    python tools/collect_final_profiles.py [round-tag, default r4]
+    python tools/collect_final_profiles.py [round-tag, default r5]
 """
 import csv
 import json
@@ -65,7 +65,7 @@ def traffic_entry(fetch_name, write_name, workload, how):
 
 
 def main():
-    tag = sys.argv[1] if len(sys.argv) > 1 else "r4"
+    tag = sys.argv[1] if len(sys.argv) > 1 else "r5"
     _, d = last_json(os.path.join(F, "bench_default.json"))
     group = d["config"]["group"]
     # ---- headline: kernel stats + PMC

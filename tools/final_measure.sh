@@ -1,6 +1,6 @@
 # End-of-round measurement on ONE box (GPU side): bench lines of every configuration, rocprofv3 kernel stats of the headline
 # command, and the separate --pmc passes (FETCH_SIZE / WRITE_SIZE / SQ) of the headline AND of the other configurations, so that
-# every line's roofline.traffic is a measured number.  Output: gpurun_out/final/ -> tools/collect_final_profiles.py r4
+# every line's roofline.traffic is a measured number.  Output: gpurun_out/final/ -> tools/collect_final_profiles.py r5
 set -x
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 O=gpurun_out/final; mkdir -p $O; : > $O/rc.txt
