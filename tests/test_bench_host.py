@@ -39,3 +39,15 @@ def test_driver_invocation_parses_and_defaults_finish_quickly():
         assert flag in out
     b = _bench()
     assert b.GROUP <= 32 and set(b.CONFIGS) >= {"miniboone_glow", "hepmass_realnvp"}
+
+
+def test_traffic_is_labelled_as_a_lookup_with_its_source_and_date():
+    """roofline.traffic is NOT counted in the run; the line says where it comes from and when it was taken."""
+    b = _bench()
+    src = b.traffic_source()
+    assert src["file"] == "profiles/headline_traffic.json" and "not counted in this run" in src["note"]
+    assert src["pmc_summary"] and os.path.exists(os.path.join(REPO, src["pmc_summary"]))
+    assert src["taken"]                                       # the date of the PMC passes (tools/collect_final_profiles.py)
+    text = open(os.path.join(REPO, "bench.py")).read()
+    assert '"--pipeline", default="auto"' in text             # real ranks stay on the torch.distributed pipeline (ADVICE r4)
+    assert "tail_summary" in text
