@@ -26,6 +26,20 @@ def main():
         tag += f" size={size}"
         sp = synth.synth_image_glow_spec(size, seed=900 + k, **c)
         x, noise = synth.synth_image_batch(n, size, seed=901 + k)
+        # every third case: the coupling net of a random step leaves the fp16 range (its first convolution's ActNorm2d scales the
+        # hidden activation by e^12, the last convolution's weights shrink by the same factor: the exact result stays ordinary) with
+        # the create-time probe off -- the handle stays on split f16 and every image has to come back through the repair launch
+        blown = (k % 3 == 2) and c["depth"] == 1
+        os.environ.pop("GBNF_IMAGE_NO_PROBE", None)
+        if blown:
+            import copy
+            sp = copy.deepcopy(sp)
+            lv = sp["levels"][int(rng.randint(len(sp["levels"])))]
+            net = lv["steps"][int(rng.randint(len(lv["steps"])))]["convs"]
+            net[0]["an_logs"] = net[0]["an_logs"] + np.float32(12.0)
+            net[-1]["w"] = (net[-1]["w"] * np.float32(np.exp(-12.0))).astype(np.float32)
+            os.environ["GBNF_IMAGE_NO_PROBE"] = "1"
+            tag += " BLOWN"
         try:
             flow = native.NativeImageFlow(sp)
         except native.GbnfError as e:
@@ -36,8 +50,19 @@ def main():
         e_ld = float(np.max(np.abs(ldj.cpu().numpy() - ld64) / np.maximum(np.abs(ld64), 1.0)))
         e_z = float(np.abs(z.cpu().numpy() - z64).max() / max(1.0, float(np.abs(z64).max())))
         ok = e_ll < 1e-5 and e_ld < 1e-5 and e_z < 2e-4
+        note = ""
+        if blown:
+            rc = flow.repair_counts()
+            note = f" | math {native.MATH_NAME[int(flow.numerics().math_mode)]} marked calls {rc['marked_calls']} repaired {rc['repaired_images']}"
+            # the way back through the same handle: z -> x must return the images' dequantised values
+            try:
+                eps = [torch.from_numpy(np.random.RandomState(k).standard_normal((n,) + tuple(sh)).astype(np.float32)).to(dev) for sh in flow.split_shapes()]
+                xi = flow.inverse(z, eps, 1.0)
+                ok = ok and bool(torch.isfinite(xi).all())
+            except native.GbnfError as e:
+                note += " | inverse: " + str(e)[:60]
         bad += 0 if ok else 1
-        print("ok  " if ok else "FAIL", tag, f"| ll {e_ll:.1e} ldj {e_ld:.1e} z {e_z:.1e}")
+        print("ok  " if ok else "FAIL", tag, f"| ll {e_ll:.1e} ldj {e_ld:.1e} z {e_z:.1e}" + note)
     print(f"{cases} cases, {bad} failures")
     sys.exit(1 if bad else 0)
 
