@@ -24,7 +24,7 @@ wait
 for name in "${names[@]}"; do
   api=obj/gbnf_api.o; [[ "$name" == tl_* ]] && api=$OUT/api_tl.o
   python3 ../../tools/isa_hazard_lint.py $OUT/${name}_1.o $OUT/${name}_2.o > $OUT/${name}.lint 2>&1 || { echo "LINT FAILED for $name"; tail -5 $OUT/${name}.lint; }
-  objs=$(ls obj/v_*.o | grep -v "v_hx3_0_14_3_[12]_0_0_0_1.o")
-  hipcc --offload-arch=gfx950 -shared -fPIC -o ../../tools/ablate/libgbnf_hip_$name.so $api obj/gbnf_train.o obj/gbnf_image.o $OUT/${name}_1.o $OUT/${name}_2.o $objs
+  objs=$(ls obj/*.o | grep -v "v_hx3_0_14_3_[12]_0_0_0_1.o" | grep -v "obj/gbnf_api.o")      # every other object of the shipped build
+  hipcc --offload-arch=gfx950 -shared -fPIC -o ../../tools/ablate/libgbnf_hip_$name.so $api $OUT/${name}_1.o $OUT/${name}_2.o $objs -ldl
 done
 echo "built: ${names[*]}"
