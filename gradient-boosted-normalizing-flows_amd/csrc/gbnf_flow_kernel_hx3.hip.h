@@ -1608,11 +1608,12 @@ static hipError_t hx3_launch_wv(FlowLaunch p, bool staggered, hipStream_t s) {
       /* two 4-wave workgroups per CU where they fit: 80 KB each, tables included */                        \
       const bool fits4 = flow_hx3_lds_bytes(p0.n_steps, ENT, 4, L.STAGE_FRAGS, L.BIAS_FRAGS, p0.d, HX3_RING,  \
                                             p0.n_steps <= LDS_TABLE_STEPS) <= 80 * 1024;                    \
-      const long long waves_total = (long long)((p0.n + 16 * ENT - 1) / (16 * ENT)) * p0.n_comp * p0.n_batches; \
-      /* from one 4-wave workgroup per CU on (1024 waves): a lone wave per SIMD runs a stage in half the time of two    \
-         sharing it (profiles/r2_ubench_pingpong.txt), so 256 such workgroups beat 128 8-wave ones on half the CUs */  \
-      /* (the training sweep's forward: measured 10 us of 105 faster at 64..256 waves too) */                \
-      if (fits4 && !p0.repair && (pairs > 0 || (pairs < 0 && (waves_total >= 1024 || TRAIN))))              \
+      /* a lone wave per SIMD runs a stage in half the time of two sharing it (profiles/r2_ubench_pingpong.txt): 4-wave        \
+         workgroups spread the same waves over twice the CUs.  Round 5: ALWAYS where they fit, not only from 1024 waves on --  \
+         at the reference's own batch sizes (density_experiment.py:80-81: 512 rows to train on, 1024 to evaluate) one           \
+         log_prob call of the MINIBOONE C = 8 model takes 47.6 us instead of 63.5 (19.9 vs 15.3 M samples/s at 1024 rows,       \
+         10.0 vs 7.7 M at 512; tools/bench_latency.py, profiles/r5_latency_small_batches.txt) */                              \
+      if (fits4 && !p0.repair && pairs != 0)                                                                \
         return hx3_launch_wv<KIND, HT, OT, ENT, ACTA, ACTB, PREC, 4, DEPTH, TRAIN>(p0, true, s);            \
     }                                                                                                       \
     return hx3_launch_wv<KIND, HT, OT, ENT, ACTA, ACTB, PREC, WAVES, DEPTH, TRAIN>(p0, false, s);           \

@@ -166,7 +166,7 @@ int gbnf_mixture_numerics(const gbnf_mixture* mix, gbnf_numerics_status* out);
 
 /* Launch-policy knobs (process-wide; tests, soak runs and tuning -- the defaults are what is measured and shipped):
  *   "force_nt"      0 = automatic | 1 | 2 : samples per wave = 16 x NT            (env GBNF_FORCE_NT at first use)
- *   "wg_pairs"      -1 = automatic | 0 = never | 1 = whenever two 4-wave workgroups fit a CU   (env GBNF_NO_WG_PAIRS=1 -> 0)
+ *   "wg_pairs"      -1 = automatic (since round 5: whenever two 4-wave workgroups fit a CU -- small batches too) | 0 = never | 1 = the same as -1   (env GBNF_NO_WG_PAIRS=1 -> 0)
  *   "repair"        1 | 0 : the bf16x6 pass behind f16x3 launches                 (env GBNF_NO_REPAIR=1 -> 0)
  *   "nt2_min_waves" 32-sample waves from this many waves on (default 1024)        (env GBNF_NT2_MIN_WAVES)
  *   "check_every"   numerics guard: a check on launch 0 and every this many launches (default 256; 0 = first launch only;
