@@ -797,6 +797,19 @@ class BoostedFlow(nn.Module):
         """Forget the table of the last batch (frees its (C, N, d) device memory)."""
         self.__dict__.pop("_component_table", None)
 
+    def invalidate_packed(self):
+        """Forget every packed copy of the parameters (evaluation handles, mixtures, the batch table): the next call re-packs from
+        the live tensors.  The packed copies are keyed on the tensors' version counters, addresses and permutation serials, which
+        every ordinary update moves (optimiser steps, ``load_state_dict``, ``p.add_()`` / ``p.copy_()`` under ``no_grad``, ``.to()``);
+        what they CANNOT see is an in-place write through ``.data`` (``p.data.clamp_()``, ``p.data.copy_(w)``: PyTorch bumps no
+        counter for it) or through a raw pointer -- call this after such a write.  (The training handles read the live tensors
+        on every call and need nothing.)"""
+        self._handles = {}
+        self._handles_exact = {}
+        self._mixture = None
+        for name in ("_component_table", "_key_cache", "_prior_cache"):
+            self.__dict__.pop(name, None)
+
     def component_inverse(self, z, c):
         """z (N,d) -> x (N,d), log|det dx/dz| (N,) of component c: inverse of ``component_forward``."""
         self._check_ready(z)

@@ -352,6 +352,17 @@ def test_evaluate_loop_is_served_from_one_launch(golden_case):
     _, _, _, l1r, _ = m(x=x, components=1)
     m.SERVE_ALL_COMPONENTS = True
     assert torch.equal(l0c, l0p) and torch.equal(l1c, l1r)
+    # (2b) a write through .data moves neither the version counter nor the address (PyTorch semantics): invalidate_packed() is the
+    #      documented way to make such a write visible to the evaluation handles
+    w = next(iter(m.flows[1].parameters()))
+    w.data.mul_(1.5)
+    _, _, _, l1stale, _ = m(x=x, components=1)
+    assert torch.equal(l1stale, l1c)                        # (unseen, as documented)
+    m.invalidate_packed()
+    _, _, _, l1new, _ = m(x=x, components=1)
+    assert not torch.equal(l1new, l1c)
+    w.data.div_(1.5)
+    m.invalidate_packed()
     # (3) train() mode is never served (the call may be recorded by autograd)
     m.train()
     m.drop_component_table()
