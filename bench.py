@@ -670,6 +670,31 @@ def main():
                               "note": "one batch per flow launch + one recursion launch (per-call latency form)"}
             del r
             try:
+                # the reference's OWN batch sizes (density_experiment.py:80-81: 512 rows per training batch, 1024 per evaluation
+                # batch), one log_prob call per batch: flow launch + its repair launch + recursion launch, plain stream launches
+                flows_s = [native.NativeFlow(specs[c], math=args.math) for c in range(C)]
+                mix_s = native.NativeMixture(flows_s)
+                small = {}
+                for nb in (512, 1024):
+                    xb = xs[0][:nb].contiguous()
+                    llb = torch.empty((C, nb), dtype=torch.float32, device=dev)
+                    Gb = torch.empty(nb, dtype=torch.float32, device=dev)
+                    for _ in range(20):
+                        mix_s.log_prob(xb, rho, ll_out=llb, out=Gb)
+                    torch.cuda.synchronize()
+                    t0 = time.perf_counter()
+                    for _ in range(300):
+                        mix_s.log_prob(xb, rho, ll_out=llb, out=Gb)
+                    torch.cuda.synchronize()
+                    dt = (time.perf_counter() - t0) / 300
+                    small[str(nb)] = {"value": nb / dt, "unit": "samples/s", "us_per_call": 1e6 * dt}
+                legs["reference_batch_sizes"] = dict(small, note="one model.log_prob(x) call per batch of 512 / 1024 rows (the reference's "
+                                                     "--batch_size / --eval_batch_size defaults): latency-bound, one wave's serial pass "
+                                                     "through the flow; tools/bench_latency.py, profiles/r5_latency_small_batches.txt")
+                del flows_s, mix_s
+            except native.GbnfError as e:
+                legs["reference_batch_sizes"] = {"error": str(e)}
+            try:
                 leg, G_mod = module_evaluate_leg(specs, kind, d, h, K, C, xs)
                 if main_run["G0"] is not None:
                     g0 = main_run["G0"].astype(np.float64)
@@ -698,6 +723,8 @@ def main():
             "group1_value": (lg.get("group1") or {}).get("value"), "group1_frac": (lg.get("group1") or {}).get("frac"),
             "f32_exact_value": (lg.get("f32_exact") or {}).get("value"), "f32_exact_frac_of_f32_peak": (lg.get("f32_exact") or {}).get("frac"),
             "bf16x6_value": (lg.get("bf16x6") or {}).get("value"), "bf16x6_executed_frac_of_bf16_peak": (lg.get("bf16x6") or {}).get("executed_frac"),
+            "log_prob_call_at_1024_rows_value": ((lg.get("reference_batch_sizes") or {}).get("1024") or {}).get("value"),
+            "log_prob_call_at_512_rows_value": ((lg.get("reference_batch_sizes") or {}).get("512") or {}).get("value"),
             "module_evaluate_loop_value": (lg.get("module_evaluate_loop") or {}).get("value"),
             "module_calls_only_ms": (lg.get("module_evaluate_loop") or {}).get("module_calls_only_ms"),
             "cpu_baseline_value": (out.get("cpu_baseline") or {}).get("value"), "cpu_cores": (out.get("cpu_baseline") or {}).get("cores"),
