@@ -1159,9 +1159,11 @@ int gbnf_image_flow_create_mode(const gbnf_image_flow_desc* d, int32_t math_mode
   const char* env_math = getenv("GBNF_MATH");                // "f32": exact-f32 MFMA everywhere (tuning / test knob)
   // (hidden widths above 256 -- the usual Glow width is 512 -- run on the exact-f32 convolutions: the split-f16 kernels keep a
   // strip's hidden activation in LDS, 150 KB at 256 channels)
-  const bool use_hx3 = math_mode != GBNF_MATH_F32 && !(env_math && !strcmp(env_math, "f32")) && d->hidden <= 256;
+  // (round 5: the fused split-f16 kernel takes hidden widths to 512 -- the usual Glow width -- in two halves of the hidden channels,
+  //  gbnf_image_net.hip; such a width is padded to a multiple of 64: both halves whole 32-channel chunks)
+  const bool use_hx3 = math_mode != GBNF_MATH_F32 && !(env_math && !strcmp(env_math, "f32")) && d->hidden <= 512;
   f->math_mode = use_hx3 ? GBNF_MATH_F16X3 : GBNF_MATH_F32;
-  f->chp = (d->hidden + 31) / 32 * 32;
+  f->chp = d->hidden > 256 ? (d->hidden + 63) / 64 * 64 : (d->hidden + 31) / 32 * 32;
   Packer P;
   double ld_const = -std::log(256.0) * C * Hv * Wv;            // dequantisation, models/glow.py:137
   char what[96];
@@ -1256,7 +1258,7 @@ int gbnf_image_flow_create_mode(const gbnf_image_flow_desc* d, int32_t math_mode
           PackedConv pc = pack_conv(P, st.convs[q], &sc);
           // split-f16 path (coupling_network_depth == 1, first 3x3 with <= 16 input channels): extra fragment sets
           if (use_hx3 && st.n_convs == 3 && c1 <= 16) {
-            const int chp = (hdim + 31) / 32 * 32;
+            const int chp = hdim > 256 ? (hdim + 63) / 64 * 64 : (hdim + 31) / 32 * 32;
             if (q == 0) pc.x_off = pack_folded(P, st.convs[q].weight, chp, hdim, c1, W, sc, &pc.k_off, &pc.kc);
             else pc.x_off = pack_hx3(P, st.convs[q].weight, st.convs[q].out_channels, st.convs[q].in_channels,
                                      st.convs[q].kernel_size, sc);
@@ -1444,7 +1446,8 @@ static int image_forward_impl(const gbnf_image_flow* f, const float* x, const fl
       const bool fusable = H == W && (W == 16 || W == 8) && net.size() == 3 && net[1].x_off != 0 &&
                            img_net_hx3_lds(W, f->chp, net[0].cin, net[0].kc, net[2].cout) != 0;
       // (a padded map runs the fused kernel or the exact-f32 convolutions: the two-kernel split form does not mask)
-      if (!force_f32 && net.size() == 3 && net[1].x_off != 0 && (fusable || !padded)) {
+      // (hidden widths above 256 exist on the fused kernel only)
+      if (!force_f32 && net.size() == 3 && net[1].x_off != 0 && (fusable || (!padded && f->chp <= 256))) {
         // split-f16 path.  Round 4: the whole coupling net in ONE kernel where a workgroup can hold the hidden activation of its
         // rows (+ halo) in LDS: the 16 x 16 and 8 x 8 maps of a 32 x 32 input (img_net_hx3_kernel, gbnf_image_hx3.hip.h)
         static const bool no_fuse = getenv("GBNF_IMG_NO_FUSE") != nullptr;        // diagnostic: the round-2 two-kernel form

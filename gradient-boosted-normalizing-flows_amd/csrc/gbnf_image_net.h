@@ -38,7 +38,8 @@ struct NetLaunch {
 // LDS bytes of img_net_hx3_kernel for W-wide maps (16 | 8), hidden width padded to chp, cin input channels of the first 3x3
 // in pre_kc 32-wide chunks of its folded contraction, cout outputs of the last 3x3; 0 = this geometry has no fused kernel
 size_t img_net_hx3_lds(int W, int chp, int cin, int pre_kc, int cout);
-// One launch for n images (W = H = 16 | 8): grid n * (W == 16 ? 2 : 1) workgroups of 512 threads.
+// One launch for n images (W = H = 16 | 8): grid n * (W == 16 ? 2 : 1) workgroups of 512 threads (hidden widths above 256: n * 4
+// workgroups on 16-wide maps).
 hipError_t img_net_hx3_launch(const NetLaunch& q, int W, bool additive, int64_t n, hipStream_t s);
 
 }  // namespace gbnf

@@ -27,6 +27,9 @@ __device__ __forceinline__ void img_drain(f32x4 (&c)[3]) { asm volatile("s_nop 7
 __device__ __forceinline__ void img_drain(f32x4 (&c)[4]) {
   asm volatile("s_nop 7\n\ts_nop 7" : "+v"(c[0]), "+v"(c[1]), "+v"(c[2]), "+v"(c[3]));
 }
+__device__ __forceinline__ void img_drain(f32x4 (&c)[6]) {
+  asm volatile("s_nop 7\n\ts_nop 7" : "+v"(c[0]), "+v"(c[1]), "+v"(c[2]), "+v"(c[3]), "+v"(c[4]), "+v"(c[5]));
+}
 __device__ __forceinline__ void img_drain(f32x4 (&c)[8]) {
   asm volatile("s_nop 7\n\ts_nop 7" : "+v"(c[0]), "+v"(c[1]), "+v"(c[2]), "+v"(c[3]), "+v"(c[4]), "+v"(c[5]), "+v"(c[6]), "+v"(c[7]));
 }
@@ -92,7 +95,13 @@ __device__ __forceinline__ void img_split_pair_w(float x0, float x1, unsigned& h
 #ifndef GBNF_IMG_ABL
 #define GBNF_IMG_ABL 0
 #endif
-template <int W, int IMG_PRE_KC, int EPI, int OT3, bool FULL>
+// KH (round 5): hidden widths 257 .. 512 -- the usual Glow width is 512 -- in KH = 2 HALVES of the hidden channels.  HB holds 256
+// channels at a time (the same 1040-byte pixels): the first 3x3 writes half 0 of its output, the 1x1 accumulates its k chunks into
+// ALL of the wave's output tiles (four instead of two: w, w + 8, w + 16, w + 24), the first 3x3 writes half 1 over it, the 1x1 takes
+// those chunks; then the 1x1's output goes back to HB half by half, each followed by its share of the last 3x3's contraction.
+// No activation is recomputed; what it costs is accumulator registers -- 4 output tiles x every pixel tile -- so a 16-wide map is
+// cut into S = 4 strips of RO = 4 output rows (RH = 6 hidden rows with the halo, 96 accumulator registers) instead of two of 8.
+template <int W, int IMG_PRE_KC, int EPI, int OT3, bool FULL, int KH>
 __global__ void __launch_bounds__(512) img_net_hx3_kernel(const NetLaunch p) {
   static_assert(OT3 >= 1 && OT3 <= 3, "the last 3x3 has at most 48 output channels");
   static_assert(W == 16 || W == 8, "16- and 8-wide maps");
@@ -100,9 +109,10 @@ __global__ void __launch_bounds__(512) img_net_hx3_kernel(const NetLaunch p) {
   typedef const u32x4 __attribute__((address_space(1)))* gv4;
   typedef const float __attribute__((address_space(1)))* gptr;
   constexpr int WV = 8;
-  constexpr int S = W == 16 ? 2 : 1;                // workgroups per image
-  constexpr int RO = 8;                             // output rows per workgroup
-  constexpr int RH = W == 16 ? 9 : 8;               // hidden rows per workgroup
+  static_assert(KH == 1 || KH == 2, "one or two halves of the hidden channels");
+  constexpr int RO = (W == 16 && KH == 2) ? 4 : 8;  // output rows per workgroup
+  constexpr int S = W == 16 ? 16 / RO : 1;          // workgroups per image
+  constexpr int RH = S == 1 ? RO : (S == 2 ? RO + 1 : RO + 2);      // hidden rows per workgroup: the strip + the halo rows inside the image (8 | 9 | 6)
   constexpr int NPH = RH * W / 16, NPO = RO * W / 16;     // pixel tiles: hidden (9 | 4), output (8 | 4)
   constexpr int ZR = RH + 2, ZW = W + 2, CSz = ZR * ZW;
   const int lane = threadIdx.x & 63, i = lane & 15, g = lane >> 4;
@@ -110,9 +120,10 @@ __global__ void __launch_bounds__(512) img_net_hx3_kernel(const NetLaunch p) {
   const int n = blockIdx.x / S, strip = blockIdx.x % S;
   if (p.only != nullptr && p.only[n] == 0u) return;
   const int H = p.H, r0 = strip * RO;
-  const int hr0 = (S == 2 && strip == 1) ? r0 - 1 : 0;     // first hidden row (image row) held in HB
-  const int chp = p.chp, pixb = 4 * chp + 16;
-  const int OT = (p.hid + 15) >> 4, KC = chp >> 5, kt = chp >> 4;
+  const int hr0 = S == 1 ? 0 : (r0 - 1 < 0 ? 0 : (r0 - 1 > H - RH ? H - RH : r0 - 1));     // first hidden row (image row) held in HB
+  const int chp = p.chp, chh = chp / KH, pixb = 4 * chh + 16;       // chh: the channels HB holds at a time
+  const int OT = (p.hid + 15) >> 4, KC = chp >> 5, kt = chp >> 4, KCH = chh >> 5;
+  const int TH = chh >> 4;                                  // 16-channel tiles of one half: half hf = tiles [TH hf, TH (hf + 1))
   unsigned char* HB = lds_raw;                              // [NPH * 16][pixb]
   unsigned char* ZP = HB + (size_t)NPH * 16 * pixb;         // the zero pixel
   float* zin_f = reinterpret_cast<float*>(ZP + pixb);       // [pre_cin][ZR][ZW] (32-bit words: hi | mid << 16)
@@ -193,15 +204,31 @@ __global__ void __launch_bounds__(512) img_net_hx3_kernel(const NetLaunch p) {
 #ifdef GBNF_IMG_STAMP_BF
   IMG_STAMP(0);                                              // (diagnostic: the B-fragment build counted with the staging phase)
 #endif
+  // ---- phase 3 state: this wave's NQ output tiles of the 1x1 x every pixel tile (it accumulates over the halves of its input)
+  constexpr int NQ = 2 * KH;
+  int ow[NQ];
+  f32x4 acc[NQ][NPH];
+  f32x4 mid_b[NQ];
+#pragma unroll
+  for (int q = 0; q < NQ; ++q) {
+    // tiles (wave, wave + 8) of half q / 2 (a half of fewer than 16 tiles leaves the upper slots idle: index OT = "no tile")
+    ow[q] = (wave + (q & 1) * WV < TH && TH * (q >> 1) + wave + (q & 1) * WV < OT) ? TH * (q >> 1) + wave + (q & 1) * WV : OT;
+#pragma unroll
+    for (int pt = 0; pt < NPH; ++pt) acc[q][pt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    mid_b[q] = ((const f32x4 __attribute__((address_space(1)))*)p.bias)[(ow[q] < OT ? ow[q] : 0) * 4 + g];
+  }
+#pragma unroll
+  for (int hf = 0; hf < KH; ++hf) {
+  if (hf > 0) __syncthreads();                               // every wave is done reading the previous half as the 1x1's input
   {
     const gv4 pw = (gv4)p.pre_wp;
     const int kcp = p.pre_kc;
-    // this wave's two hidden tiles: A fragments and biases once, for every pixel group
+    // this wave's two hidden tiles (of this half): A fragments and biases once, for every pixel group
     u32x4 ah[2][IMG_PRE_KC], am[2][IMG_PRE_KC];
     f32x4 pb[2];
 #pragma unroll
     for (int q = 0; q < 2; ++q) {
-      const int o = wave + q * WV, oo = o < kt ? o : 0;
+      const int lt = wave + q * WV, o = lt < TH ? TH * hf + lt : kt, oo = o < kt ? o : 0;
 #pragma unroll
       for (int c = 0; c < IMG_PRE_KC; ++c) {
         const gv4 f = pw + ((size_t)oo * kcp + (c < kcp ? c : 0)) * 128 + lane;
@@ -227,7 +254,7 @@ __global__ void __launch_bounds__(512) img_net_hx3_kernel(const NetLaunch p) {
       if ((pt0 + G) * 16 * pixb > p.bf_off) __syncthreads();           // this group's output overwrites fragments: every wave holds its B operands first
 #pragma unroll
       for (int q = 0; q < 2; ++q) {
-        const int o = wave + q * WV;
+        const int lt = wave + q * WV, o = lt < TH ? TH * hf + lt : kt;      // (kt: past the end)
         {                                                    // (a tile index past the end computes a valid tile again: nothing is stored)
           f32x4 acc[G];
 #pragma unroll
@@ -266,13 +293,13 @@ __global__ void __launch_bounds__(512) img_net_hx3_kernel(const NetLaunch p) {
             img_split_pair_w(v[0], v[1], h01, m01, amax);
             img_split_pair_w(v[2], v[3], h23, m23, amax);
 #endif
-            unsigned char* px = HB + (size_t)lin * pixb + 2 * (16 * o + 4 * g);
+            unsigned char* px = HB + (size_t)lin * pixb + 2 * (16 * lt + 4 * g);
 #if GBNF_IMG_ABL == 3
             if (h01 == 0x12345678u && m23 == 0x9abcdef0u)
 #endif
             {
               *reinterpret_cast<u32x2*>(px) = u32x2{h01, h23};
-              *reinterpret_cast<u32x2*>(px + 2 * chp) = u32x2{m01, m23};
+              *reinterpret_cast<u32x2*>(px + 2 * chh) = u32x2{m01, m23};
             }
           }
         }
@@ -283,25 +310,13 @@ __global__ void __launch_bounds__(512) img_net_hx3_kernel(const NetLaunch p) {
   __syncthreads();
   IMG_STAMP(2);
 
-  // ---- phase 3: 1x1 hidden -> hidden: this wave's two output tiles x every pixel tile
+  // ---- phase 3: 1x1 hidden -> hidden: this wave's NQ output tiles x every pixel tile, the k chunks of THIS half of its input
   {
-    int ow[2];
-    ow[0] = wave;
-    ow[1] = wave + WV;
-    f32x4 acc[2][NPH];
-#pragma unroll
-    for (int q = 0; q < 2; ++q)
-#pragma unroll
-      for (int pt = 0; pt < NPH; ++pt) acc[q][pt] = f32x4{0.f, 0.f, 0.f, 0.f};
-    f32x4 mid_b[2];
-#pragma unroll
-    for (int q = 0; q < 2; ++q)
-      mid_b[q] = ((const f32x4 __attribute__((address_space(1)))*)p.bias)[(ow[q] < OT ? ow[q] : 0) * 4 + g];
     const gv4 wp = (gv4)p.wp;
-    auto load_a = [&](int c, u32x4 (&ah)[2], u32x4 (&am)[2]) {
+    auto load_a = [&](int c, u32x4 (&ah)[NQ], u32x4 (&am)[NQ]) {            // c: chunk of the WHOLE contraction
       const int cc = c < KC ? c : 0;
 #pragma unroll
-      for (int q = 0; q < 2; ++q) {
+      for (int q = 0; q < NQ; ++q) {
         const gv4 f = wp + ((size_t)(ow[q] < OT ? ow[q] : 0) * KC + cc) * 128 + lane;
         ah[q] = f[0];
         am[q] = f[64];
@@ -309,17 +324,17 @@ __global__ void __launch_bounds__(512) img_net_hx3_kernel(const NetLaunch p) {
     };
     const unsigned char* bbase = HB + (size_t)i * pixb + 16 * g;
     constexpr int NH1 = (NPH + 1) / 2;
-    auto half = [&](int c, auto lo_c, auto hi_c, const u32x4 (&ah)[2], const u32x4 (&am)[2]) {
+    auto half = [&](int c, auto lo_c, auto hi_c, const u32x4 (&ah)[NQ], const u32x4 (&am)[NQ]) {       // c: chunk within HB
       constexpr int LO = decltype(lo_c)::value, HI = decltype(hi_c)::value;
       u32x4 bh[HI - LO], bm[HI - LO];
 #pragma unroll
       for (int pt = LO; pt < HI; ++pt) {
         const unsigned char* px = bbase + (size_t)(16 * pt) * pixb + 64 * c;
         bh[pt - LO] = *reinterpret_cast<const u32x4*>(px);
-        bm[pt - LO] = *reinterpret_cast<const u32x4*>(px + 2 * chp);
+        bm[pt - LO] = *reinterpret_cast<const u32x4*>(px + 2 * chh);
       }
 #pragma unroll
-      for (int q = 0; q < 2; ++q) {                          // (an idle slot repeats tile 0: no branch in the stream, nothing stored)
+      for (int q = 0; q < NQ; ++q) {                         // (an idle slot repeats tile 0: no branch in the stream, nothing stored)
 #pragma unroll
         for (int pt = LO; pt < HI; ++pt) {
           acc[q][pt] = img_mfma16(am[q], bh[pt - LO], acc[q][pt]);
@@ -328,13 +343,13 @@ __global__ void __launch_bounds__(512) img_net_hx3_kernel(const NetLaunch p) {
         }
       }
     };
-    auto chunk = [&](int c, const u32x4 (&ah)[2], const u32x4 (&am)[2]) {
+    auto chunk = [&](int c, const u32x4 (&ah)[NQ], const u32x4 (&am)[NQ]) {
       half(c, std::integral_constant<int, 0>{}, std::integral_constant<int, NH1>{}, ah, am);
       half(c, std::integral_constant<int, NH1>{}, std::integral_constant<int, NPH>{}, ah, am);
     };
-    {
+    if constexpr (KH == 1) {
       // A fragments two chunks ahead (a chunk of an 8-wide map is 24 MFMAs: shorter than an L2 round trip under load)
-      u32x4 ah[3][2], am[3][2];
+      u32x4 ah[3][NQ], am[3][NQ];
       load_a(0, ah[0], am[0]);
       load_a(1, ah[1], am[1]);
       int c = 0;
@@ -349,16 +364,47 @@ __global__ void __launch_bounds__(512) img_net_hx3_kernel(const NetLaunch p) {
       }
       if (c < KC) chunk(c, ah[0], am[0]);
       if (c + 1 < KC) chunk(c + 1, ah[1], am[1]);
+    } else {
+      // (four output tiles per wave: the A fragments one chunk ahead -- two sets of 4 x (hi, mid) are 64 registers beside 64 .. 96
+      //  accumulator registers; a chunk is 48 .. 72 MFMAs here)
+      u32x4 ah[2][NQ], am[2][NQ];
+      const int c0 = hf * KCH;
+      load_a(c0, ah[0], am[0]);
+      int c = 0;
+#pragma unroll 1
+      for (; c + 2 <= KCH; c += 2) {
+        load_a(c0 + c + 1, ah[1], am[1]);
+        chunk(c, ah[0], am[0]);
+        load_a(c + 2 < KCH ? c0 + c + 2 : c0, ah[0], am[0]);
+        chunk(c + 1, ah[1], am[1]);
+      }
+      if (c < KCH) chunk(c, ah[0], am[0]);
     }
+  }
+  }      // halves of the hidden channels (first 3x3 + its share of the 1x1's contraction)
 #pragma unroll
-    for (int q = 0; q < 2; ++q) img_drain(acc[q]);
-    IMG_STAMP(3);
-    __syncthreads();                                         // every wave is done reading HB as the 1x1's input
+  for (int q = 0; q < NQ; ++q) img_drain(acc[q]);
+  IMG_STAMP(3);
+
+  // ---- the 1x1's output (relu, split) goes back to HB half by half; each half is followed by its share of the last 3x3's
+  //      contraction (phase 4).  KH = 1: one round, the sequence of round 4.
+  float z2v[OT3][4];        // the state values this lane's epilogue updates (pixel tile = wave)
+  float b3v[OT3][4];        // ... and the last 3x3's biases of its rows
+  constexpr int MAXO = OT3;                                 // output tiles of the last 3x3 (template: no branches around its MFMAs)
+  f32x4 part[MAXO][NPO];
+#pragma unroll
+  for (int o = 0; o < MAXO; ++o)
+#pragma unroll
+    for (int pt = 0; pt < NPO; ++pt) part[o][pt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int rf = 0; rf < KH; ++rf) {
+  {
+    __syncthreads();                                         // every wave is done reading HB (the 1x1's input / the previous round's last 3x3)
     IMG_STAMP(2);
 #pragma unroll
-    for (int q = 0; q < 2; ++q) {
+    for (int q = 2 * rf; q < 2 * rf + 2; ++q) {
       if (ow[q] < OT) {
-        const int o = ow[q];
+        const int o = ow[q] - TH * rf;                       // the tile's place in HB
 #pragma unroll
         for (int pt = 0; pt < NPH; ++pt) {
           const int lin = 16 * pt + i;
@@ -368,7 +414,7 @@ __global__ void __launch_bounds__(512) img_net_hx3_kernel(const NetLaunch p) {
           float v[4];
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
-            const int co = 16 * o + 4 * g + r;
+            const int co = 16 * ow[q] + 4 * g + r;
             v[r] = (FULL || (co < p.hid && valid)) ? fmaxf(acc[q][pt][r] + mid_b[q][r], 0.0f) : 0.0f;
           }
           unsigned h01, m01, h23, m23;
@@ -376,7 +422,7 @@ __global__ void __launch_bounds__(512) img_net_hx3_kernel(const NetLaunch p) {
           img_split_pair_w(v[2], v[3], h23, m23, amax);
           unsigned char* px = HB + (size_t)lin * pixb + 2 * (16 * o + 4 * g);
           *reinterpret_cast<u32x2*>(px) = u32x2{h01, h23};
-          *reinterpret_cast<u32x2*>(px + 2 * chp) = u32x2{m01, m23};
+          *reinterpret_cast<u32x2*>(px + 2 * chh) = u32x2{m01, m23};
         }
       }
     }
@@ -385,10 +431,8 @@ __global__ void __launch_bounds__(512) img_net_hx3_kernel(const NetLaunch p) {
   __syncthreads();
   IMG_STAMP(2);
 
-  // ---- phase 4: last 3x3 hidden -> shift / scale, contraction (tap, chunk) dealt to the waves
-  float z2v[OT3][4];        // the state values this lane's epilogue updates (pixel tile = wave)
-  float b3v[OT3][4];        // ... and the last 3x3's biases of its rows
-  {
+  // ---- phase 4: last 3x3 hidden -> shift / scale, contraction (tap, chunk) dealt to the waves (this round's chunks)
+  if (rf == 0) {
     const float* stq = p.st + (int64_t)n * p.st_img;
     const int lin = 16 * (wave < NPO ? wave : 0) + i, row = r0 + lin / W, pc = lin % W;
     const int64_t pix = (int64_t)row * W + pc;
@@ -403,12 +447,6 @@ __global__ void __launch_bounds__(512) img_net_hx3_kernel(const NetLaunch p) {
         b3v[o][r] = p.bias3[co < p.cout ? co : 0];
       }
   }
-  constexpr int MAXO = OT3;                                 // output tiles of the last 3x3 (template: no branches around its MFMAs)
-  f32x4 part[MAXO][NPO];
-#pragma unroll
-  for (int o = 0; o < MAXO; ++o)
-#pragma unroll
-    for (int pt = 0; pt < NPO; ++pt) part[o][pt] = f32x4{0.f, 0.f, 0.f, 0.f};
   if constexpr (W == 16) {
     // 16-wide maps: a pixel tile IS an image row, so the 3 x 3 runs "input-row stationary": wave w takes the 32-channel chunks
     // c = w, w + 8, ...; every hidden row j of the strip is read ONCE per output tile (two ds_read_b128) and multiplied by all nine
@@ -437,13 +475,13 @@ __global__ void __launch_bounds__(512) img_net_hx3_kernel(const NetLaunch p) {
           : "v"(b[0]), "v"(b[1]), "v"(b[2]), "v"(b[3]));
     };
 #pragma unroll 1
-    for (int c = wave; c < KC; c += WV) {
+    for (int c = wave; c < KCH; c += WV) {                  // chunk c of HB = chunk rf KCH + c of the contraction
 #pragma unroll
       for (int o = 0; o < MAXO; ++o) {
         u32x4 ah[9], am[9];
 #pragma unroll
         for (int tp = 0; tp < 9; ++tp) {
-          const gv4 f = wp3 + ((size_t)o * T_all + tp * KC + c) * 128 + lane;
+          const gv4 f = wp3 + ((size_t)o * T_all + tp * KC + rf * KCH + c) * 128 + lane;
           ah[tp] = f[0];
           am[tp] = f[64];
         }
@@ -451,7 +489,7 @@ __global__ void __launch_bounds__(512) img_net_hx3_kernel(const NetLaunch p) {
           const int hr = j + sh;                                        // its index in HB; outside [0, RH): outside the image
           const unsigned char* px = rowb + (size_t)((hr < 0 ? 0 : (hr >= RH ? RH - 1 : hr)) * 16) * pixb + 64 * c;
           bh = *reinterpret_cast<const u32x4*>(px);
-          bm = *reinterpret_cast<const u32x4*>(px + 2 * chp);
+          bm = *reinterpret_cast<const u32x4*>(px + 2 * chh);
         };
         u32x4 bh[2], bm[2];
         load_row(-1, bh[0], bm[0]);
@@ -485,7 +523,7 @@ __global__ void __launch_bounds__(512) img_net_hx3_kernel(const NetLaunch p) {
       }
     }
   } else {
-    const int T_all = 9 * KC;
+    const int T_all = 9 * KC, T_h = 9 * KCH;                 // (tap, chunk) iterations: of the whole contraction / of this round
     const gv4 wp3 = (gv4)p.wp3;
     const unsigned hb_a = (unsigned)(uintptr_t)(__attribute__((address_space(3))) void*)HB;
     const unsigned zp_a = (unsigned)(uintptr_t)(__attribute__((address_space(3))) void*)ZP + 16u * g;
@@ -506,10 +544,11 @@ __global__ void __launch_bounds__(512) img_net_hx3_kernel(const NetLaunch p) {
       okm[pt] = m;
     }
     auto load_a = [&](int t, u32x4 (&ah)[MAXO], u32x4 (&am)[MAXO]) {
-      const int tt = t < T_all ? t : 0;
+      const int tt = t < T_h ? t : 0;
+      const int tap = tt / KCH, c = tt - tap * KCH;
 #pragma unroll
       for (int o = 0; o < MAXO; ++o) {
-        const gv4 f = wp3 + ((size_t)o * T_all + tt) * 128 + lane;
+        const gv4 f = wp3 + ((size_t)o * T_all + tap * KC + rf * KCH + c) * 128 + lane;
         ah[o] = f[0];
         am[o] = f[64];
       }
@@ -517,8 +556,8 @@ __global__ void __launch_bounds__(512) img_net_hx3_kernel(const NetLaunch p) {
     // B operands of one HALF of the pixel tiles; the other half's reads are in flight under this half's MFMAs
     constexpr int HP = NPO / 2;
     auto load_b = [&](int t, int half, u32x4 (&bh)[HP], u32x4 (&bm)[HP]) {
-      const int tt = t < T_all ? t : 0;
-      const int tap = tt / KC, c = tt - tap * KC;
+      const int tt = t < T_h ? t : 0;
+      const int tap = tt / KCH, c = tt - tap * KCH;
       const int d = ((tap / 3 - 1) * W + (tap % 3 - 1)) * pixb + 64 * c;
 #pragma unroll
       for (int q = 0; q < HP; ++q) {
@@ -526,7 +565,7 @@ __global__ void __launch_bounds__(512) img_net_hx3_kernel(const NetLaunch p) {
         const bool inside = (okm[pt] >> tap) & 1u;
         const unsigned a = inside ? ctr_a[pt] + (unsigned)d : zp_a;
         bh[q] = *reinterpret_cast<const __attribute__((address_space(3))) u32x4*>((uintptr_t)a);
-        bm[q] = *reinterpret_cast<const __attribute__((address_space(3))) u32x4*>((uintptr_t)(a + (inside ? 2u * chp : 0u)));
+        bm[q] = *reinterpret_cast<const __attribute__((address_space(3))) u32x4*>((uintptr_t)(a + (inside ? 2u * chh : 0u)));
       }
     };
     auto mac_half = [&](auto half_c, const u32x4 (&bh)[HP], const u32x4 (&bm)[HP], const u32x4 (&ah)[MAXO], const u32x4 (&am)[MAXO]) {
@@ -559,14 +598,15 @@ __global__ void __launch_bounds__(512) img_net_hx3_kernel(const NetLaunch p) {
       mac_half(H1{}, b1h, b1m, ah, am);
     };
 #pragma unroll 1
-    for (; t + 2 * WV < T_all; t += 3 * WV) {
+    for (; t + 2 * WV < T_h; t += 3 * WV) {
       step(t, a0h, a0m, a2h, a2m);
       step(t + WV, a1h, a1m, a0h, a0m);
       step(t + 2 * WV, a2h, a2m, a1h, a1m);
     }
-    if (t < T_all) step(t, a0h, a0m, a2h, a2m);
-    if (t + WV < T_all) step(t + WV, a1h, a1m, a0h, a0m);
+    if (t < T_h) step(t, a0h, a0m, a2h, a2m);
+    if (t + WV < T_h) step(t + WV, a1h, a1m, a0h, a0m);
   }
+  }      // rounds: halves of the 1x1's output and their share of the last 3x3's contraction
 #pragma unroll
   for (int o = 0; o < MAXO; ++o) img_drain(part[o]);
   IMG_STAMP(5);
@@ -637,20 +677,25 @@ __global__ void __launch_bounds__(512) img_net_hx3_kernel(const NetLaunch p) {
 }
 
 // LDS layout: HB | ZP | zin | [BF]; BF (the first 3x3's B fragments) goes behind the rest when that fits 160 KB, else over the
-// tail of HB (see phase 2).  *bf_off: byte offset of BF.
+// tail of HB (see phase 2).  *bf_off: byte offset of BF.  Hidden widths above 256 (KH = 2: HB holds half the channels at a time and
+// is written twice) need BF beside HB -- the second half's first 3x3 reads it again.
+static int img_net_hx3_halves(int chp) { return chp > 256 ? 2 : 1; }
 static size_t img_net_hx3_layout(int W, int chp, int cin, int pre_kc, size_t* bf_off) {
-  const int RH = W == 16 ? 9 : 8, NPO = 8 * W / 16, NPH = RH * W / 16;
-  const size_t pixb = 4 * (size_t)chp + 16;
+  const int KH = img_net_hx3_halves(chp);
+  if (chp > 512 || (KH == 2 && chp % 64 != 0)) return 0;
+  const int RO = (W == 16 && KH == 2) ? 4 : 8, S = W == 16 ? 16 / RO : 1, RH = S == 1 ? RO : (S == 2 ? RO + 1 : RO + 2);
+  const int NPO = RO * W / 16, NPH = RH * W / 16;
+  const size_t pixb = 4 * (size_t)(chp / KH) + 16;
   const size_t hb = (size_t)RH * W * pixb;
   const size_t work = hb + pixb + (size_t)cin * (RH + 2) * (W + 2) * 4 + (size_t)32 * pre_kc * 4;      // HB | ZP | zin | im2col table
   const size_t bf = (size_t)NPH * pre_kc * 2 * 1024;
   size_t total = work, off = (work + 15) / 16 * 16;
   if (off + bf <= 160 * 1024) {
     total = off + bf;
-  } else if (bf <= hb) {
+  } else if (bf <= hb && KH == 1) {
     off = hb - bf;                                   // (hb and bf are multiples of 16)
   } else {
-    total = 0;                                       // does not fit either way: the caller keeps the two-kernel form
+    total = 0;                                       // does not fit either way: the caller keeps the two-kernel form / the exact-f32 kernels
     off = 0;
   }
   if (bf_off) *bf_off = off;
@@ -662,21 +707,22 @@ size_t img_net_hx3_lds(int W, int chp, int cin, int pre_kc, int cout) {
   return img_net_hx3_layout(W, chp, cin, pre_kc, nullptr);
 }
 
-template <int W, int EPI, int OT3>
-static hipError_t img_net_hx3_launch3(const NetLaunch& q0, int64_t n, hipStream_t s) {
+template <int W, int EPI, int OT3, int KH>
+static hipError_t img_net_hx3_launch4(const NetLaunch& q0, int64_t n, hipStream_t s) {
   NetLaunch q = q0;
   size_t bf_off = 0;
   const size_t lds = img_net_hx3_layout(W, q.chp, q.pre_cin, q.pre_kc, &bf_off);
   if (lds == 0 || lds > 160 * 1024) return hipErrorInvalidValue;
   q.bf_off = (unsigned)bf_off;
-  const dim3 grid((unsigned)(n * (W == 16 ? 2 : 1))), blk(512);
+  constexpr int RO = (W == 16 && KH == 2) ? 4 : 8;
+  const dim3 grid((unsigned)(n * (W == 16 ? 16 / RO : 1))), blk(512);
   const int pk = q.pre_kc <= 2 ? 2 : (q.pre_kc <= 4 ? 4 : 5);
   const bool full = q.hid == q.chp && q.Hv >= q.H && q.Wv >= W;
   static bool attr_set = false;
   if (!attr_set) {
-    const void* fns[6] = {(const void*)img_net_hx3_kernel<W, 2, EPI, OT3, false>, (const void*)img_net_hx3_kernel<W, 4, EPI, OT3, false>,
-                          (const void*)img_net_hx3_kernel<W, 5, EPI, OT3, false>, (const void*)img_net_hx3_kernel<W, 2, EPI, OT3, true>,
-                          (const void*)img_net_hx3_kernel<W, 4, EPI, OT3, true>, (const void*)img_net_hx3_kernel<W, 5, EPI, OT3, true>};
+    const void* fns[6] = {(const void*)img_net_hx3_kernel<W, 2, EPI, OT3, false, KH>, (const void*)img_net_hx3_kernel<W, 4, EPI, OT3, false, KH>,
+                          (const void*)img_net_hx3_kernel<W, 5, EPI, OT3, false, KH>, (const void*)img_net_hx3_kernel<W, 2, EPI, OT3, true, KH>,
+                          (const void*)img_net_hx3_kernel<W, 4, EPI, OT3, true, KH>, (const void*)img_net_hx3_kernel<W, 5, EPI, OT3, true, KH>};
     for (int k = 0; k < 6; ++k) {
       const hipError_t e = hipFuncSetAttribute(fns[k], hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
       if (e != hipSuccess) return e;
@@ -684,15 +730,20 @@ static hipError_t img_net_hx3_launch3(const NetLaunch& q0, int64_t n, hipStream_
     attr_set = true;
   }
   if (full) {
-    if (pk == 2) hipLaunchKernelGGL((img_net_hx3_kernel<W, 2, EPI, OT3, true>), grid, blk, lds, s, q);
-    else if (pk == 4) hipLaunchKernelGGL((img_net_hx3_kernel<W, 4, EPI, OT3, true>), grid, blk, lds, s, q);
-    else hipLaunchKernelGGL((img_net_hx3_kernel<W, 5, EPI, OT3, true>), grid, blk, lds, s, q);
+    if (pk == 2) hipLaunchKernelGGL((img_net_hx3_kernel<W, 2, EPI, OT3, true, KH>), grid, blk, lds, s, q);
+    else if (pk == 4) hipLaunchKernelGGL((img_net_hx3_kernel<W, 4, EPI, OT3, true, KH>), grid, blk, lds, s, q);
+    else hipLaunchKernelGGL((img_net_hx3_kernel<W, 5, EPI, OT3, true, KH>), grid, blk, lds, s, q);
   } else {
-    if (pk == 2) hipLaunchKernelGGL((img_net_hx3_kernel<W, 2, EPI, OT3, false>), grid, blk, lds, s, q);
-    else if (pk == 4) hipLaunchKernelGGL((img_net_hx3_kernel<W, 4, EPI, OT3, false>), grid, blk, lds, s, q);
-    else hipLaunchKernelGGL((img_net_hx3_kernel<W, 5, EPI, OT3, false>), grid, blk, lds, s, q);
+    if (pk == 2) hipLaunchKernelGGL((img_net_hx3_kernel<W, 2, EPI, OT3, false, KH>), grid, blk, lds, s, q);
+    else if (pk == 4) hipLaunchKernelGGL((img_net_hx3_kernel<W, 4, EPI, OT3, false, KH>), grid, blk, lds, s, q);
+    else hipLaunchKernelGGL((img_net_hx3_kernel<W, 5, EPI, OT3, false, KH>), grid, blk, lds, s, q);
   }
   return hipGetLastError();
+}
+template <int W, int EPI, int OT3>
+static hipError_t img_net_hx3_launch3(const NetLaunch& q, int64_t n, hipStream_t s) {
+  if (img_net_hx3_halves(q.chp) == 2) return img_net_hx3_launch4<W, EPI, OT3, 2>(q, n, s);
+  return img_net_hx3_launch4<W, EPI, OT3, 1>(q, n, s);
 }
 template <int W, int EPI>
 static hipError_t img_net_hx3_launch2(const NetLaunch& q, int64_t n, hipStream_t s) {

@@ -366,7 +366,11 @@ def test_image_well_scaled_model_stays_on_split_f16_and_unmarked():
                                            ((3, 32, 32), 64, 2, 3, {}), ((1, 24, 24), 32, 1, 3, {"coupling": "additive"}), ((1, 16, 16), 32, 2, 2, {}),
                                            # hidden widths above 256 (the usual Glow width is 512): exact-f32 convolutions, the last 3 x 3's
                                            # 512-channel strip staged in two halves
-                                           ((3, 32, 32), 512, 1, 2, {}), ((1, 28, 28), 384, 1, 2, {"coupling": "additive"}), ((3, 32, 32), 300, 1, 1, {"depth": 2})])
+                                           ((3, 32, 32), 512, 1, 2, {}), ((1, 28, 28), 384, 1, 2, {"coupling": "additive"}), ((3, 32, 32), 300, 1, 1, {"depth": 2}),
+                                           # ... and since round 5 on the fused split-f16 kernel in two halves of the hidden channels (depth 1):
+                                           # halves of 16, 12, 10 and 9.x tiles, both couplings, maps smaller than their storage
+                                           ((3, 32, 32), 320, 2, 2, {}), ((1, 28, 20), 448, 1, 2, {}), ((3, 32, 32), 290, 1, 2, {"coupling": "additive"}),
+                                           ((1, 28, 28), 512, 2, 2, {"permutation": "shuffle"})])
 @pytest.mark.parametrize("math", ["default", "f32"])
 def test_image_inputs_smaller_than_the_storage_match_oracle(size, h, K, L, kw, math, monkeypatch):
     """The reference's other image loaders hand over 1 x 28 x 28 and 1 x 28 x 20 (utils/load_data.py:389-529).  Such a map lives in
@@ -381,6 +385,8 @@ def test_image_inputs_smaller_than_the_storage_match_oracle(size, h, K, L, kw, m
     sp = synth.synth_image_glow_spec(size, h, K, L, seed=3, **kw)
     x, noise = synth.synth_image_batch(5, size, seed=4)
     flow = native.NativeImageFlow(sp)
+    if math == "default" and kw.get("depth", 1) == 1:      # every depth-1 width up to 512 runs on split f16 (round 5: above 256 in two halves)
+        assert native.MATH_NAME[int(flow.numerics().math_mode)] == "f16x3", flow.numerics().worst_rel_err
     z, ldj, ll = flow.forward(torch.from_numpy(x).to(dev), torch.from_numpy(noise).to(dev))
     zo, _, _, ldo, llo = oracle.image_component_forward(sp, x, noise)
     assert tuple(z.shape) == zo.shape

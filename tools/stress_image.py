@@ -15,7 +15,7 @@ def main():
     dev = torch.device("cuda:0")
     bad = 0
     for k in range(cases):
-        c = dict(h=int(rng.choice([8, 16, 24, 32, 48, 64, 100, 128, 200, 256])), K=int(rng.randint(1, 5)), L=int(rng.choice([1, 2, 2, 3])),
+        c = dict(h=int(rng.choice([8, 16, 24, 32, 48, 64, 100, 128, 200, 256, 257, 300, 320, 384, 448, 500, 512])), K=int(rng.randint(1, 5)), L=int(rng.choice([1, 2, 2, 3])),
                  depth=int(rng.choice([0, 1, 1, 1, 2])), coupling=str(rng.choice(["affine", "additive"])),
                  permutation=str(rng.choice(["invconv", "shuffle", "reverse"])), learn_top=bool(rng.randint(2)))
         n = int(rng.choice([1, 2, 3, 5, 16, 33, 64]))
