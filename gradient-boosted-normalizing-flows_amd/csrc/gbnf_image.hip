@@ -879,9 +879,10 @@ unsigned short f16_bits(float x) {
   return b;
 }
 
-// f16x3 A fragments of a convolution: [o][tap][c][hi|mid][64 lanes][8 halfs], k = 32c + 8g + j; returns the float offset
-size_t pack_hx3(Packer& P, const float* w, int cout, int cin, int ks, const std::vector<double>& row_scale) {
-  const int OT = (cout + 15) / 16, KC = (cin + 31) / 32, taps = ks * ks;
+// f16x3 A fragments of a convolution: [o][tap][c][hi|mid][64 lanes][8 halfs], k = 32c + 8g + j, c over the input channels
+// padded to cin_pad (the activation layout's padded hidden width: zero fragments past cin); returns the float offset
+size_t pack_hx3(Packer& P, const float* w, int cout, int cin, int cin_pad, int ks, const std::vector<double>& row_scale) {
+  const int OT = (cout + 15) / 16, KC = (cin_pad + 31) / 32, taps = ks * ks;
   while (P.blob.size() % 4) P.blob.push_back(0.0f);                     // 16-byte aligned fragments
   const size_t off = P.blob.size();
   P.blob.resize(off + (size_t)OT * taps * KC * 2 * 64 * 4, 0.0f);
@@ -1260,7 +1261,7 @@ int gbnf_image_flow_create_mode(const gbnf_image_flow_desc* d, int32_t math_mode
           if (use_hx3 && st.n_convs == 3 && c1 <= 16) {
             const int chp = hdim > 256 ? (hdim + 63) / 64 * 64 : (hdim + 31) / 32 * 32;
             if (q == 0) pc.x_off = pack_folded(P, st.convs[q].weight, chp, hdim, c1, W, sc, &pc.k_off, &pc.kc);
-            else pc.x_off = pack_hx3(P, st.convs[q].weight, st.convs[q].out_channels, st.convs[q].in_channels,
+            else pc.x_off = pack_hx3(P, st.convs[q].weight, st.convs[q].out_channels, st.convs[q].in_channels, chp,
                                      st.convs[q].kernel_size, sc);
           }
           net.push_back(pc);

@@ -370,7 +370,10 @@ def test_image_well_scaled_model_stays_on_split_f16_and_unmarked():
                                            # ... and since round 5 on the fused split-f16 kernel in two halves of the hidden channels (depth 1):
                                            # halves of 16, 12, 10 and 9.x tiles, both couplings, maps smaller than their storage
                                            ((3, 32, 32), 320, 2, 2, {}), ((1, 28, 20), 448, 1, 2, {}), ((3, 32, 32), 290, 1, 2, {"coupling": "additive"}),
-                                           ((1, 28, 28), 512, 2, 2, {"permutation": "shuffle"})])
+                                           ((1, 28, 28), 512, 2, 2, {"permutation": "shuffle"}),
+                                           # widths whose padding to 64 holds a whole empty 32-channel chunk of the contraction
+                                           ((1, 32, 20), 257, 2, 1, {"coupling": "additive", "permutation": "reverse"}), ((3, 32, 32), 330, 1, 2, {}),
+                                           ((1, 28, 28), 460, 1, 2, {})])
 @pytest.mark.parametrize("math", ["default", "f32"])
 def test_image_inputs_smaller_than_the_storage_match_oracle(size, h, K, L, kw, math, monkeypatch):
     """The reference's other image loaders hand over 1 x 28 x 28 and 1 x 28 x 20 (utils/load_data.py:389-529).  Such a map lives in

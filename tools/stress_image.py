@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Randomised stress of the image path (multi-scale Glow; 3x32x32, 1x28x28, 1x28x20 and other shapes) against the float64 oracle (opt-in, GPU).
-usage: python tools/stress_image.py [cases] [seed]"""
+usage: python tools/stress_image.py [cases] [seed] [only-this-case]"""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -12,6 +12,7 @@ from oracle import gbnf_oracle as oracle
 def main():
     cases = int(sys.argv[1]) if len(sys.argv) > 1 else 30
     rng = np.random.RandomState(int(sys.argv[2]) if len(sys.argv) > 2 else 17)
+    only = int(sys.argv[3]) if len(sys.argv) > 3 else -1   # run this case alone (the random stream stays the one of the full run)
     dev = torch.device("cuda:0")
     bad = 0
     for k in range(cases):
@@ -40,6 +41,8 @@ def main():
             net[-1]["w"] = (net[-1]["w"] * np.float32(np.exp(-12.0))).astype(np.float32)
             os.environ["GBNF_IMAGE_NO_PROBE"] = "1"
             tag += " BLOWN"
+        if only >= 0 and k != only:
+            continue
         try:
             flow = native.NativeImageFlow(sp)
         except native.GbnfError as e:
@@ -58,7 +61,10 @@ def main():
             try:
                 eps = [torch.from_numpy(np.random.RandomState(k).standard_normal((n,) + tuple(sh)).astype(np.float32)).to(dev) for sh in flow.split_shapes()]
                 xi = flow.inverse(z, eps, 1.0)
-                ok = ok and bool(torch.isfinite(xi).all())
+                fin = torch.isfinite(xi).reshape(n, -1).all(1)
+                ok = ok and bool(fin.all())
+                if not bool(fin.all()):
+                    note += f" | inverse: images {(~fin).nonzero().flatten().tolist()} not finite"
             except native.GbnfError as e:
                 note += " | inverse: " + str(e)[:60]
         bad += 0 if ok else 1
