@@ -80,10 +80,15 @@ __device__ __forceinline__ void img_split_pair_w(float x0, float x1, unsigned& h
 // Phases (a barrier between them):
 //   1  stage z1;  2  first 3x3 as a folded f16x3 GEMM (k = tap * cin + ci) -> relu -> split -> HB: wave w owns hidden tiles
 //   w, w + 8 for every pixel tile (its A fragments stay in registers over the pixel groups);  3  1x1: wave w owns output tiles
-//   w, w + 8 x ALL pixel tiles (18 accumulator tiles), A fragments from L2 one chunk ahead, B fragments = one ds_read_b128 per
-//   pixel tile and piece; relu -> split -> back into HB (in place: every wave has finished reading);  4  last 3x3: the
-//   (tap, chunk) iterations are dealt to the waves, the partial tiles meet in LDS (over HB: its role is over), wave w finishes
-//   pixel tile w with the f32 coupling epilogue.
+//   w, w + 8 x ALL pixel tiles (18 accumulator tiles), A fragments from L2 two chunks ahead, B fragments = one ds_read_b128 per
+//   pixel tile and piece, two tiles ahead; relu -> split -> back into HB (in place: every wave has finished reading);  4  last
+//   3x3: the (tap, chunk) iterations are dealt to the waves, the partial tiles meet in LDS (over HB: its role is over), wave w
+//   finishes pixel tile w with the f32 coupling epilogue.
+// Round 5 (stamps, tools/image_stamps2.py: 49.8 k -> 46.9 k cycles per wave at W = 16): the FIRST weight fragments of every phase
+// are requested a phase ahead (64 + 147 KB per workgroup through the CU's L2 port, 1 - 2.3 k cycles that every wave stood through
+// at the phase's start); phase 2 is one software pipeline per wave; the 1x1's B fragments come through a ring two tiles ahead so
+// that the wave that is left alone on its SIMD at the end of the phase keeps the matrix pipe busy; biases are the accumulators'
+// initial values.
 // Numerics: every value that is split is range-watched (one v_max3 per pair); a workgroup that met
 // |value| > 65504 raises its image's mark and the per-device counter -- gbnf_api / gbnf_image.hip re-evaluate marked images
 // on the exact-f32 kernels.
@@ -92,9 +97,6 @@ __device__ __forceinline__ void img_split_pair_w(float x0, float x1, unsigned& h
 // FULL: the map fills its storage and the hidden width fills its padding (hid == chp) -- the CIFAR configuration: every
 // per-value select on "channel exists" / "pixel belongs to the map" drops out of the tile epilogues (26 -> 22 vector and ~10
 // scalar instructions fewer per 16 x 16 tile).
-#ifndef GBNF_IMG_ABL
-#define GBNF_IMG_ABL 0
-#endif
 // KH (round 5): hidden widths 257 .. 512 -- the usual Glow width is 512 -- in KH = 2 HALVES of the hidden channels.  HB holds 256
 // channels at a time (the same 1040-byte pixels): the first 3x3 writes half 0 of its output, the 1x1 accumulates its k chunks into
 // ALL of the wave's output tiles (four instead of two: w, w + 8, w + 16, w + 24), the first 3x3 writes half 1 over it, the 1x1 takes
@@ -133,6 +135,33 @@ __global__ void __launch_bounds__(512) img_net_hx3_kernel(const NetLaunch p) {
   unsigned long long stamp_last = 0, stamp_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 #endif
   IMG_STAMP(-1);
+
+  // ---- the first 3x3's A fragments and biases of this wave's two hidden tiles: requested HERE, a phase and two barriers ahead of
+  //      their use (read where the phase starts they were a global round trip -- 1.7 k of the kernel's 50 k cycles -- with nothing to
+  //      hide it; same for the 1x1's and the last 3x3's first fragments below).  Chunks past pre_kc get ZERO fragments.
+  //      (a slot past the end of a half of fewer than 16 tiles repeats the half's FIRST tile, stores included: the same values to the
+  //      same addresses as the wave that owns it -- no branch in the first 3x3's pipeline)
+  u32x4 pre_ah[2][IMG_PRE_KC], pre_am[2][IMG_PRE_KC];
+  f32x4 pre_pb[2];
+  int pre_lt[2], pre_o[2];
+  auto pre_load = [&](int hf) {
+    const gv4 pw = (gv4)p.pre_wp;
+    const int kcp = p.pre_kc;
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      pre_lt[q] = wave + q * WV < TH ? wave + q * WV : 0;
+      pre_o[q] = TH * hf + pre_lt[q];
+#pragma unroll
+      for (int c = 0; c < IMG_PRE_KC; ++c) {
+        const gv4 f = pw + ((size_t)pre_o[q] * kcp + (c < kcp ? c : 0)) * 128 + lane;
+        const u32x4 z4 = {0u, 0u, 0u, 0u};
+        pre_ah[q][c] = c < kcp ? f[0] : z4;
+        pre_am[q][c] = c < kcp ? f[64] : z4;
+      }
+      pre_pb[q] = ((const f32x4 __attribute__((address_space(1)))*)p.pre_bias)[(pre_o[q] < OT ? pre_o[q] : 0) * 4 + g];
+    }
+  };
+  if constexpr (KH == 1) pre_load(0);          // (KH = 2 keeps four output tiles of accumulators per wave: no registers to spare)
 
   // ---- phase 1: z1 (hidden rows + halo, zero padded) as SPLIT words hi | mid << 16 -- every element is split once here,
   //      not once per wave and tap in the im2col gather below -- and the zero pixel
@@ -213,14 +242,115 @@ __global__ void __launch_bounds__(512) img_net_hx3_kernel(const NetLaunch p) {
   for (int q = 0; q < NQ; ++q) {
     // tiles (wave, wave + 8) of half q / 2 (a half of fewer than 16 tiles leaves the upper slots idle: index OT = "no tile")
     ow[q] = (wave + (q & 1) * WV < TH && TH * (q >> 1) + wave + (q & 1) * WV < OT) ? TH * (q >> 1) + wave + (q & 1) * WV : OT;
-#pragma unroll
-    for (int pt = 0; pt < NPH; ++pt) acc[q][pt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    // (the accumulators START at the bias of their rows -- D layout: row 4 g + r -- instead of adding it in the tile epilogue: four
+    //  vector instructions less per tile, in the phases that are bound by the vector issue port)
     mid_b[q] = ((const f32x4 __attribute__((address_space(1)))*)p.bias)[(ow[q] < OT ? ow[q] : 0) * 4 + g];
+#pragma unroll
+    for (int pt = 0; pt < NPH; ++pt) acc[q][pt] = mid_b[q];
   }
+  // (KH = 1) the 1x1's first two chunks of A fragments: requested under the last round of the first 3x3's pipeline
+  u32x4 p3_ah[2][NQ], p3_am[2][NQ];
+  auto p3_load = [&](int c, u32x4 (&ah)[NQ], u32x4 (&am)[NQ]) {            // c: chunk of the WHOLE contraction
+    const gv4 wp = (gv4)p.wp;
+    const int cc = c < KC ? c : 0;
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) {
+      const gv4 f = wp + ((size_t)(ow[q] < OT ? ow[q] : 0) * KC + cc) * 128 + lane;
+      ah[q] = f[0];
+      am[q] = f[64];
+    }
+  };
 #pragma unroll
   for (int hf = 0; hf < KH; ++hf) {
   if (hf > 0) __syncthreads();                               // every wave is done reading the previous half as the 1x1's input
-  {
+  if constexpr (KH == 1) {
+    // Round 5: the phase as ONE software pipeline per wave.  A step = (chunk c, pixel tile pg) of a group of G pixel tiles: its B
+    // fragment pair comes from BF two steps ahead, its 6 MFMAs (two hidden tiles x three products) are followed IN PROGRAM ORDER by
+    // the relu -> split -> store of one finished tile of the PREVIOUS group -- vector work that issues while the matrix pipe
+    // runs.  Before, a group was [B loads, 36 MFMAs, drain, 6 tile epilogues] and both waves of a SIMD went through the same
+    // sequence at the same time: the phase took the SUM of its matrix, vector and LDS times (stamps: 9.7 k cycles at W = 16
+    // for 3.6 k of matrix pipe per SIMD).  Chunks past pre_kc (the compiled chunk count is the next of 2 / 4 / 5) multiply ZERO
+    // A fragments with chunk 0's B fragments: no branch inside the pipeline.
+    const int kcp = p.pre_kc;
+    u32x4 (&ah)[2][IMG_PRE_KC] = pre_ah, (&am)[2][IMG_PRE_KC] = pre_am;
+    f32x4 (&pb)[2] = pre_pb;
+    int (&lt2)[2] = pre_lt, (&o2)[2] = pre_o;
+#ifdef GBNF_IMG_STAMP_A
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // (diagnostic: the wait for this wave's A fragments in bucket 7)
+    IMG_STAMP(7);
+#endif
+    constexpr int G = IMG_PRE_KC <= 2 ? (W == 16 ? 3 : 2) : (W == 16 ? 1 : (IMG_PRE_KC <= 4 ? 2 : 1));      // pixel tiles per group
+    constexpr int NG = (NPH + G - 1) / G, STEPS = IMG_PRE_KC * G, NS = NG * STEPS;
+    constexpr int TPS = (2 * G + STEPS - 1) / STEPS;                // finished tiles handed to a step (2 G per group)
+    auto load_b = [&](int t, u32x4& bh, u32x4& bm) {                // global step t = (group, chunk, pixel tile of the group)
+      const int gi = t / STEPS, st = t - gi * STEPS, c = st / G, pg = st - c * G;
+      const int ptc = gi * G + pg < NPH ? gi * G + pg : NPH - 1;    // (a group that runs past the last tile repeats it)
+      const unsigned char* f = BF + ((size_t)(ptc * kcp + (c < kcp ? c : 0)) * 2) * 1024 + 16 * lane;
+      bh = *reinterpret_cast<const u32x4*>(f);
+      bm = *reinterpret_cast<const u32x4*>(f + 1024);
+    };
+    auto tile_out = [&](const f32x4& a, int q, int pt) {            // relu(. + bias) -> split -> HB
+      if (pt >= NPH) return;                                        // (compile time)
+      const int lin = 16 * pt + i;
+      float v[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int co = 16 * o2[q] + 4 * g + r;
+        v[r] = (FULL || co < p.hid) ? fmaxf(a[r], 0.0f) : 0.0f;
+      }
+      unsigned h01, m01, h23, m23;
+      img_split_pair_w(v[0], v[1], h01, m01, amax);
+      img_split_pair_w(v[2], v[3], h23, m23, amax);
+      unsigned char* px = HB + (size_t)lin * pixb + 2 * (16 * lt2[q] + 4 * g);
+      *reinterpret_cast<u32x2*>(px) = u32x2{h01, h23};
+      *reinterpret_cast<u32x2*>(px + 2 * chh) = u32x2{m01, m23};
+    };
+    u32x4 bh[3], bm[3];
+    load_b(0, bh[0], bm[0]);
+    if (NS > 1) load_b(1, bh[1], bm[1]);
+    f32x4 cur[2][G], pend[2][G];
+#pragma unroll
+    for (int gi = 0; gi <= NG; ++gi) {                              // (the extra round finishes the last group's tiles)
+      // the finished group's output reaches into BF: every wave holds the B fragments of that group and the ones before it first
+      // (the fragments of later groups lie above its output: 16 pixb >= 2048 pre_kc wherever BF has to share HB's tail)
+      if (gi > 0 && gi * G * 16 * pixb > (int)p.bf_off) __syncthreads();
+      if constexpr (KH == 1) {
+        if (gi == NG) { p3_load(0, p3_ah[0], p3_am[0]); p3_load(1, p3_ah[1], p3_am[1]); }
+      }
+#pragma unroll
+      for (int st = 0; st < STEPS; ++st) {
+        const int t = gi * STEPS + st, c = st / G, pg = st - c * G;
+        if (gi < NG) {
+          if (t + 2 < NS) load_b(t + 2, bh[(t + 2) % 3], bm[(t + 2) % 3]);
+#pragma unroll
+          for (int q = 0; q < 2; ++q) {
+            if (c == 0) cur[q][pg] = pb[q];                  // (the bias of the tile's rows: see the 1x1's accumulators)
+            cur[q][pg] = img_mfma16(am[q][c], bh[t % 3], cur[q][pg]);
+            cur[q][pg] = img_mfma16(ah[q][c], bm[t % 3], cur[q][pg]);
+            cur[q][pg] = img_mfma16(ah[q][c], bh[t % 3], cur[q][pg]);
+          }
+        }
+        if (gi > 0) {
+#pragma unroll
+          for (int k = st * TPS; k < (st + 1) * TPS && k < 2 * G; ++k) tile_out(pend[k / G][k % G], k / G, (gi - 1) * G + k % G);
+        }
+        // the order inside a step: the look-ahead B fragments, then an MFMA every few vector instructions, the tile's stores last
+        __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+#pragma unroll
+        for (int m = 0; m < 6; ++m) {
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+          __builtin_amdgcn_sched_group_barrier(0x002, 4 * TPS, 0);
+        }
+        __builtin_amdgcn_sched_group_barrier(0x200, 2 * TPS, 0);
+      }
+#pragma unroll
+      for (int q = 0; q < 2; ++q)
+#pragma unroll
+        for (int pg = 0; pg < G; ++pg) pend[q][pg] = cur[q][pg];
+    }
+  } else {
+    // KH = 2 (hidden widths 257 .. 512): group by group -- B loads, MFMAs, tile epilogues -- as in round 4.  Four output tiles of 1x1
+    // accumulators per wave are live across this phase; the pipelined form above spills beside them.
     const gv4 pw = (gv4)p.pre_wp;
     const int kcp = p.pre_kc;
     // this wave's two hidden tiles (of this half): A fragments and biases once, for every pixel group
@@ -258,19 +388,15 @@ __global__ void __launch_bounds__(512) img_net_hx3_kernel(const NetLaunch p) {
         {                                                    // (a tile index past the end computes a valid tile again: nothing is stored)
           f32x4 acc[G];
 #pragma unroll
-          for (int pg = 0; pg < G; ++pg) acc[pg] = f32x4{0.f, 0.f, 0.f, 0.f};
+          for (int pg = 0; pg < G; ++pg) acc[pg] = pb[q];
 #pragma unroll
           for (int c = 0; c < IMG_PRE_KC; ++c) {
             if (c < kcp) {
 #pragma unroll
               for (int pg = 0; pg < G; ++pg) {
-#if GBNF_IMG_ABL != 1                                   // (diagnostic builds, first 3x3: 1 = no MFMAs, 2 = no split, 3 = no LDS stores)
                 acc[pg] = img_mfma16(am[q][c], bh[c][pg], acc[pg]);
                 acc[pg] = img_mfma16(ah[q][c], bm[c][pg], acc[pg]);
                 acc[pg] = img_mfma16(ah[q][c], bh[c][pg], acc[pg]);
-#else
-                acc[pg] += __builtin_bit_cast(f32x4, bh[c][pg]);
-#endif
               }
             }
           }
@@ -283,20 +409,12 @@ __global__ void __launch_bounds__(512) img_net_hx3_kernel(const NetLaunch p) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
               const int co = 16 * o + 4 * g + r;
-              v[r] = (FULL || co < p.hid) ? fmaxf(acc[pg][r] + pb[q][r], 0.0f) : 0.0f;
+              v[r] = (FULL || co < p.hid) ? fmaxf(acc[pg][r], 0.0f) : 0.0f;
             }
             unsigned h01, m01, h23, m23;
-#if GBNF_IMG_ABL == 2
-            h01 = __builtin_bit_cast(unsigned, v[0]); m01 = __builtin_bit_cast(unsigned, v[1]);
-            h23 = __builtin_bit_cast(unsigned, v[2]); m23 = __builtin_bit_cast(unsigned, v[3]);
-#else
             img_split_pair_w(v[0], v[1], h01, m01, amax);
             img_split_pair_w(v[2], v[3], h23, m23, amax);
-#endif
             unsigned char* px = HB + (size_t)lin * pixb + 2 * (16 * lt + 4 * g);
-#if GBNF_IMG_ABL == 3
-            if (h01 == 0x12345678u && m23 == 0x9abcdef0u)
-#endif
             {
               *reinterpret_cast<u32x2*>(px) = u32x2{h01, h23};
               *reinterpret_cast<u32x2*>(px + 2 * chh) = u32x2{m01, m23};
@@ -312,58 +430,58 @@ __global__ void __launch_bounds__(512) img_net_hx3_kernel(const NetLaunch p) {
 
   // ---- phase 3: 1x1 hidden -> hidden: this wave's NQ output tiles x every pixel tile, the k chunks of THIS half of its input
   {
-    const gv4 wp = (gv4)p.wp;
-    auto load_a = [&](int c, u32x4 (&ah)[NQ], u32x4 (&am)[NQ]) {            // c: chunk of the WHOLE contraction
-      const int cc = c < KC ? c : 0;
-#pragma unroll
-      for (int q = 0; q < NQ; ++q) {
-        const gv4 f = wp + ((size_t)(ow[q] < OT ? ow[q] : 0) * KC + cc) * 128 + lane;
-        ah[q] = f[0];
-        am[q] = f[64];
-      }
-    };
+    auto load_a = p3_load;
     const unsigned char* bbase = HB + (size_t)i * pixb + 16 * g;
-    constexpr int NH1 = (NPH + 1) / 2;
-    auto half = [&](int c, auto lo_c, auto hi_c, const u32x4 (&ah)[NQ], const u32x4 (&am)[NQ]) {       // c: chunk within HB
-      constexpr int LO = decltype(lo_c)::value, HI = decltype(hi_c)::value;
-      u32x4 bh[HI - LO], bm[HI - LO];
+    // B fragments: ONE pixel tile (hi, mid) per step, requested D steps ahead of its MFMAs into a ring of D + 1 register pairs.
+    // (Round 4 read half a chunk's tiles, waited, and issued their MFMAs: a wave alone on its SIMD -- the younger of the two falls
+    //  behind and finishes the phase by itself, stamps: 11.8 k vs 17.9 k cycles for the same work -- stood at every one of those
+    //  waits with the matrix pipe empty.)  The ring's position is a compile-time function of the step inside an unrolled loop body
+    //  (3 NPH or 2 NPH steps: multiples of D + 1); a request past the last chunk re-reads chunk 0 and is dropped.
+    constexpr int D = KH == 1 ? 2 : 1, SL = D + 1;
+    u32x4 rb_h[SL], rb_m[SL];
+    auto load_b = [&](int c, int pt, u32x4& bh, u32x4& bm) {               // c: chunk within HB
+      const unsigned char* px = bbase + (size_t)(16 * pt) * pixb + 64 * (c < KCH ? c : 0);
+      bh = *reinterpret_cast<const u32x4*>(px);
+      bm = *reinterpret_cast<const u32x4*>(px + 2 * chh);
+    };
+    auto chunk = [&](auto k_c, int c, const u32x4 (&ah)[NQ], const u32x4 (&am)[NQ]) {      // k: position in the unrolled body
+      constexpr int k = decltype(k_c)::value;
 #pragma unroll
-      for (int pt = LO; pt < HI; ++pt) {
-        const unsigned char* px = bbase + (size_t)(16 * pt) * pixb + 64 * c;
-        bh[pt - LO] = *reinterpret_cast<const u32x4*>(px);
-        bm[pt - LO] = *reinterpret_cast<const u32x4*>(px + 2 * chh);
-      }
+      for (int pt = 0; pt < NPH; ++pt) {
+        const int t = k * NPH + pt;
+        load_b(c + (pt + D) / NPH, (pt + D) % NPH, rb_h[(t + D) % SL], rb_m[(t + D) % SL]);
 #pragma unroll
-      for (int q = 0; q < NQ; ++q) {                         // (an idle slot repeats tile 0: no branch in the stream, nothing stored)
-#pragma unroll
-        for (int pt = LO; pt < HI; ++pt) {
-          acc[q][pt] = img_mfma16(am[q], bh[pt - LO], acc[q][pt]);
-          acc[q][pt] = img_mfma16(ah[q], bm[pt - LO], acc[q][pt]);
-          acc[q][pt] = img_mfma16(ah[q], bh[pt - LO], acc[q][pt]);
+        for (int q = 0; q < NQ; ++q) {                       // (an idle slot repeats tile 0: no branch in the stream, nothing stored)
+          acc[q][pt] = img_mfma16(am[q], rb_h[t % SL], acc[q][pt]);
+          acc[q][pt] = img_mfma16(ah[q], rb_m[t % SL], acc[q][pt]);
+          acc[q][pt] = img_mfma16(ah[q], rb_h[t % SL], acc[q][pt]);
         }
+        __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, 3 * NQ, 0);
       }
     };
-    auto chunk = [&](int c, const u32x4 (&ah)[NQ], const u32x4 (&am)[NQ]) {
-      half(c, std::integral_constant<int, 0>{}, std::integral_constant<int, NH1>{}, ah, am);
-      half(c, std::integral_constant<int, NH1>{}, std::integral_constant<int, NPH>{}, ah, am);
-    };
+    using K0 = std::integral_constant<int, 0>;
+    using K1 = std::integral_constant<int, 1>;
+    using K2 = std::integral_constant<int, 2>;
+#pragma unroll
+    for (int t = 0; t < D; ++t) load_b(t / NPH, t % NPH, rb_h[t % SL], rb_m[t % SL]);
     if constexpr (KH == 1) {
       // A fragments two chunks ahead (a chunk of an 8-wide map is 24 MFMAs: shorter than an L2 round trip under load)
       u32x4 ah[3][NQ], am[3][NQ];
-      load_a(0, ah[0], am[0]);
-      load_a(1, ah[1], am[1]);
+#pragma unroll
+      for (int q = 0; q < NQ; ++q) { ah[0][q] = p3_ah[0][q]; am[0][q] = p3_am[0][q]; ah[1][q] = p3_ah[1][q]; am[1][q] = p3_am[1][q]; }
       int c = 0;
 #pragma unroll 1
       for (; c + 3 <= KC; c += 3) {
         load_a(c + 2, ah[2], am[2]);
-        chunk(c, ah[0], am[0]);
+        chunk(K0{}, c, ah[0], am[0]);
         load_a(c + 3, ah[0], am[0]);
-        chunk(c + 1, ah[1], am[1]);
+        chunk(K1{}, c + 1, ah[1], am[1]);
         load_a(c + 4, ah[1], am[1]);
-        chunk(c + 2, ah[2], am[2]);
+        chunk(K2{}, c + 2, ah[2], am[2]);
       }
-      if (c < KC) chunk(c, ah[0], am[0]);
-      if (c + 1 < KC) chunk(c + 1, ah[1], am[1]);
+      if (c < KC) chunk(K0{}, c, ah[0], am[0]);
+      if (c + 1 < KC) chunk(K1{}, c + 1, ah[1], am[1]);
     } else {
       // (four output tiles per wave: the A fragments one chunk ahead -- two sets of 4 x (hi, mid) are 64 registers beside 64 .. 96
       //  accumulator registers; a chunk is 48 .. 72 MFMAs here)
@@ -374,11 +492,11 @@ __global__ void __launch_bounds__(512) img_net_hx3_kernel(const NetLaunch p) {
 #pragma unroll 1
       for (; c + 2 <= KCH; c += 2) {
         load_a(c0 + c + 1, ah[1], am[1]);
-        chunk(c, ah[0], am[0]);
+        chunk(K0{}, c, ah[0], am[0]);
         load_a(c + 2 < KCH ? c0 + c + 2 : c0, ah[0], am[0]);
-        chunk(c + 1, ah[1], am[1]);
+        chunk(K1{}, c + 1, ah[1], am[1]);
       }
-      if (c < KCH) chunk(c, ah[0], am[0]);
+      if (c < KCH) chunk(K0{}, c, ah[0], am[0]);
     }
   }
   }      // halves of the hidden channels (first 3x3 + its share of the 1x1's contraction)
@@ -396,6 +514,37 @@ __global__ void __launch_bounds__(512) img_net_hx3_kernel(const NetLaunch p) {
   for (int o = 0; o < MAXO; ++o)
 #pragma unroll
     for (int pt = 0; pt < NPO; ++pt) part[o][pt] = f32x4{0.f, 0.f, 0.f, 0.f};
+  // (KH = 1) the last 3x3's first A fragments -- 16-wide maps: the nine taps of this wave's chunk for output tile 0; 8-wide: the
+  // first two (tap, chunk) iterations -- requested in front of the 1x1's relu / split / stores and the barrier behind them
+  // (not for two output tiles on a 16-wide map: 64 accumulator registers beside the nine taps' 72)
+  constexpr bool P4 = KH == 1 && (W == 8 || OT3 == 1);
+  constexpr int P4N = P4 ? (W == 16 ? 9 : 2 * OT3) : 1;
+  u32x4 p4_ah[P4N], p4_am[P4N];
+  if constexpr (P4) {
+    const gv4 wp3 = (gv4)p.wp3;
+    if constexpr (W == 16) {
+      const int c = wave < KCH ? wave : 0;
+#pragma unroll
+      for (int tp = 0; tp < 9; ++tp) {
+        const gv4 f = wp3 + ((size_t)tp * KC + c) * 128 + lane;
+        p4_ah[tp] = f[0];
+        p4_am[tp] = f[64];
+      }
+    } else {
+      const int T_h = 9 * KCH;
+#pragma unroll
+      for (int k = 0; k < 2; ++k) {
+        const int t = wave + k * WV, tt = t < T_h ? t : 0;
+        const int tap = tt / KCH, c = tt - tap * KCH;
+#pragma unroll
+        for (int o = 0; o < OT3; ++o) {
+          const gv4 f = wp3 + ((size_t)o * (9 * KC) + tap * KC + c) * 128 + lane;
+          p4_ah[k * OT3 + o] = f[0];
+          p4_am[k * OT3 + o] = f[64];
+        }
+      }
+    }
+  }
 #pragma unroll
   for (int rf = 0; rf < KH; ++rf) {
   {
@@ -415,7 +564,7 @@ __global__ void __launch_bounds__(512) img_net_hx3_kernel(const NetLaunch p) {
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
             const int co = 16 * ow[q] + 4 * g + r;
-            v[r] = (FULL || (co < p.hid && valid)) ? fmaxf(acc[q][pt][r] + mid_b[q][r], 0.0f) : 0.0f;
+            v[r] = (FULL || (co < p.hid && valid)) ? fmaxf(acc[q][pt][r], 0.0f) : 0.0f;
           }
           unsigned h01, m01, h23, m23;
           img_split_pair_w(v[0], v[1], h01, m01, amax);
@@ -479,11 +628,16 @@ __global__ void __launch_bounds__(512) img_net_hx3_kernel(const NetLaunch p) {
 #pragma unroll
       for (int o = 0; o < MAXO; ++o) {
         u32x4 ah[9], am[9];
+        if (P4 && o == 0 && c == wave) {                                  // (uniform) the fragments requested ahead
 #pragma unroll
-        for (int tp = 0; tp < 9; ++tp) {
-          const gv4 f = wp3 + ((size_t)o * T_all + tp * KC + rf * KCH + c) * 128 + lane;
-          ah[tp] = f[0];
-          am[tp] = f[64];
+          for (int tp = 0; tp < 9; ++tp) { ah[tp] = p4_ah[tp < P4N ? tp : 0]; am[tp] = p4_am[tp < P4N ? tp : 0]; }
+        } else {
+#pragma unroll
+          for (int tp = 0; tp < 9; ++tp) {
+            const gv4 f = wp3 + ((size_t)o * T_all + tp * KC + rf * KCH + c) * 128 + lane;
+            ah[tp] = f[0];
+            am[tp] = f[64];
+          }
         }
         auto load_row = [&](int j, u32x4& bh, u32x4& bm) {             // hidden row j (relative to output row 0)
           const int hr = j + sh;                                        // its index in HB; outside [0, RH): outside the image
@@ -587,8 +741,16 @@ __global__ void __launch_bounds__(512) img_net_hx3_kernel(const NetLaunch p) {
     u32x4 a0h[MAXO], a0m[MAXO], a1h[MAXO], a1m[MAXO], a2h[MAXO], a2m[MAXO];
     u32x4 b0h[HP], b0m[HP], b1h[HP], b1m[HP];
     int t = wave;
-    load_a(t, a0h, a0m);
-    load_a(t + WV, a1h, a1m);
+    if constexpr (P4) {
+#pragma unroll
+      for (int o = 0; o < MAXO; ++o) {
+        a0h[o] = p4_ah[o < P4N ? o : 0]; a0m[o] = p4_am[o < P4N ? o : 0];
+        a1h[o] = p4_ah[MAXO + o < P4N ? MAXO + o : 0]; a1m[o] = p4_am[MAXO + o < P4N ? MAXO + o : 0];
+      }
+    } else {
+      load_a(t, a0h, a0m);
+      load_a(t + WV, a1h, a1m);
+    }
     load_b(t, 0, b0h, b0m);
     auto step = [&](int tt, const u32x4 (&ah)[MAXO], const u32x4 (&am)[MAXO], u32x4 (&nh)[MAXO], u32x4 (&nm)[MAXO]) {
       load_a(tt + 2 * WV, nh, nm);

@@ -22,7 +22,7 @@ for _ in range(3):
 torch.cuda.synchronize()
 a = buf.cpu().numpy().reshape(wgs, 8, 8).astype(np.float64)
 names = ["stage z1 (+ barrier)", "first 3x3 -> relu -> split -> LDS", "barrier waits", "1x1 MFMA stream", "1x1 relu + split + LDS stores",
-         "last 3x3 MFMA stream", "reduction + coupling epilogue"]
+         "last 3x3 MFMA stream", "reduction + coupling epilogue", "(diagnostic bucket 7: -DGBNF_IMG_STAMP_A = wait for the first 3x3's A fragments)"]
 tot = a.sum(2).mean()
 print(f"W = {W}, {wgs} workgroups x 8 waves: {tot:.0f} shader cycles per wave on average (max wave {a.sum(2).max():.0f})")
 for k, nm in enumerate(names):
