@@ -1652,6 +1652,7 @@ struct LiveBlob {
   const char* name_bwd = nullptr;
   int bwd_waves = 4;                    // waves per workgroup of the backward launch (bwd_hx3_waves)
   int ht = 0;                           // hidden tiles of the kernel variant
+  int depth = 1;                        // coupling_network_depth: hidden -> hidden layers per net
   bool tilesB_packed = false;           // the last re-pack included the transposed tiles
 };
 
@@ -1811,8 +1812,8 @@ int live_blob_create(const gbnf_flow_desc* desc, const int64_t* norm_grad_offset
   const bool glow = desc->kind == GBNF_KIND_GLOW;
   const bool additive = glow && desc->coupling == GBNF_COUPLING_ADDITIVE;
   const int h = info.ref.hidden, depth = info.ref.depth;
-  if (depth != 1 || info.ref.residual)
-    return fail(GBNF_ERR_UNSUPPORTED, "live blob: TanhNet / ReLUNet of coupling_network_depth 1 only");
+  if (depth > 2 || info.ref.residual)
+    return fail(GBNF_ERR_UNSUPPORTED, "live blob: TanhNet / ReLUNet of coupling_network_depth 0, 1 or 2 only");
   {   // an activation pair nobody compiled a kernel for runs on the per-step variants (as gbnf_flow_create_ex does)
     bool compiled = false;
     for (const Variant& v : variants())
@@ -1869,59 +1870,86 @@ int live_blob_create(const gbnf_flow_desc* desc, const int64_t* norm_grad_offset
   std::vector<LiveBias> biases;
   std::vector<LiveEntry> entries;
   std::vector<LiveNorm> norms(K);
-  const BwdLayout LB(HT, OT);
+  const BwdLayout LB(HT, OT, depth);
   const size_t NWB = (size_t)LB.NET_WORDS, step_words_b = nnets * NWB;
   std::vector<LiveTile> tilesB;
   std::vector<int32_t> bwd_tab((size_t)K * 2 * 4 * NENT, -1);
-  auto add_net_bwd = [&](int lid0, size_t base, int in_f, int out_f) {       // lid0: the net's first LiveLayer (layers lid0 .. lid0 + 2)
+  // (the stage order of BwdLayout: the output layer's transpose, the hidden -> hidden layers' from the last to the first, layer 0's)
+  auto add_net_bwd = [&](int lid0, size_t base, int in_f, int out_f) {       // lid0: the net's first LiveLayer (layers lid0 .. lid0 + depth + 1)
     int s = 0;
     for (int i0 = 0; i0 < LB.N_L0; ++i0, ++s)
       for (int n = 0; n < LB.nf[s] / NP; ++n) {
         const int t = i0 * LB.ROWS0 + n / LB.K0, c = n % LB.K0;
-        tilesB.push_back(LiveTile{(uint32_t)(base + LB.off[s] + (size_t)n * TW), (uint16_t)(lid0 + 2), 3, (uint16_t)t, (uint16_t)c, 1.0f, out_f, h});
+        tilesB.push_back(LiveTile{(uint32_t)(base + LB.off[s] + (size_t)n * TW), (uint16_t)(lid0 + depth + 1), 3, (uint16_t)t, (uint16_t)c, 1.0f, out_f, h});
       }
-    for (int u = 0; u < HT; ++u, ++s) {
-      for (int c = 0; c < LB.HC; ++c)
-        tilesB.push_back(LiveTile{(uint32_t)(base + LB.off[s] + (size_t)c * TW), (uint16_t)(lid0 + 1), 4, (uint16_t)u, (uint16_t)c, 1.0f, h, h});
-      if (u % 2 == 0 && u >= 2)
-        for (int o = 0; o < 2; ++o)
-          tilesB.push_back(LiveTile{(uint32_t)(base + LB.off[s] + (size_t)(LB.HC + o) * TW), (uint16_t)lid0, 5, (uint16_t)((u - 2) / 2), (uint16_t)o, 1.0f, h, in_f});
+    if (depth >= 1) {
+      for (int j = depth; j >= 2; --j)
+        for (int u = 0; u < HT; ++u, ++s)
+          for (int c = 0; c < LB.HC; ++c)
+            tilesB.push_back(LiveTile{(uint32_t)(base + LB.off[s] + (size_t)c * TW), (uint16_t)(lid0 + j), 4, (uint16_t)u, (uint16_t)c, 1.0f, h, h});
+      for (int u = 0; u < HT; ++u, ++s) {
+        for (int c = 0; c < LB.HC; ++c)
+          tilesB.push_back(LiveTile{(uint32_t)(base + LB.off[s] + (size_t)c * TW), (uint16_t)(lid0 + 1), 4, (uint16_t)u, (uint16_t)c, 1.0f, h, h});
+        if (u % 2 == 0 && u >= 2)
+          for (int o = 0; o < 2; ++o)
+            tilesB.push_back(LiveTile{(uint32_t)(base + LB.off[s] + (size_t)(LB.HC + o) * TW), (uint16_t)lid0, 5, (uint16_t)((u - 2) / 2), (uint16_t)o, 1.0f, h, in_f});
+      }
+      for (int o = 0; o < 2; ++o)
+        tilesB.push_back(LiveTile{(uint32_t)(base + LB.off[s] + (size_t)o * TW), (uint16_t)lid0, 5, (uint16_t)(LB.HC - 1), (uint16_t)o, 1.0f, h, in_f});
+    } else {
+      for (int k = 0; k < LB.N_IN; ++k, ++s) {
+        const int c0 = k * LB.CGI, cnt = std::min(LB.CGI, LB.HC - c0);
+        for (int cc = 0; cc < cnt; ++cc)
+          for (int o = 0; o < 2; ++o)
+            tilesB.push_back(LiveTile{(uint32_t)(base + LB.off[s] + (size_t)(cc * 2 + o) * TW), (uint16_t)lid0, 5, (uint16_t)(c0 + cc), (uint16_t)o, 1.0f, h, in_f});
+      }
     }
-    for (int o = 0; o < 2; ++o)
-      tilesB.push_back(LiveTile{(uint32_t)(base + LB.off[s] + (size_t)o * TW), (uint16_t)lid0, 5, (uint16_t)(LB.HC - 1), (uint16_t)o, 1.0f, h, in_f});
   };
+  // (the loops of pack_net_hx3, every depth: layer 0, `depth` hidden -> hidden layers, the output layer)
   auto add_net = [&](const gbnf_net& net, size_t base, int in_f, int out_f) {
     const bool tanh_net = net.activation == GBNF_ACT_TANH;
     const float T = tanh_net ? 2.8853900817779268f : 1.0f, R = tanh_net ? -2.0f : 1.0f;
-    int lid[3];
-    for (int l = 0; l < 3; ++l) {
+    int lid[4];
+    for (int l = 0; l < depth + 2; ++l) {
       lid[l] = (int)layers.size();
       layers.push_back(LiveLayer{net.layers[l].weight, net.layers[l].bias, net.layers[l].out_features, net.layers[l].in_features});
     }
+    const int lout = lid[depth + 1];
     for (int t = 0; t < HT; ++t)
       for (int k = 0; k < 16; ++k) {
         const int u = 16 * t + k;
         biases.push_back(LiveBias{(uint32_t)(base + (size_t)t * 16 + k), lid[0], u < h ? u : -1, 0, T});
-        biases.push_back(LiveBias{(uint32_t)(base + (size_t)(HT + t) * 16 + k), lid[1], u < h ? u : -1, tanh_net ? 1 : 0, T});
+        for (int j = 1; j <= depth; ++j)
+          biases.push_back(LiveBias{(uint32_t)(base + (size_t)(j * HT + t) * 16 + k), lid[j], u < h ? u : -1, tanh_net ? 1 : 0, T});
       }
     for (int o = 0; o < OT; ++o)
       for (int k = 0; k < 16; ++k) {
         const int r = 16 * o + k;
-        biases.push_back(LiveBias{(uint32_t)(base + (size_t)(2 * HT + o) * 16 + k), lid[2], r < out_f ? r : -1, tanh_net ? 1 : 0, 1.0f});
+        biases.push_back(LiveBias{(uint32_t)(base + (size_t)((depth + 1) * HT + o) * 16 + k), lout, r < out_f ? r : -1, tanh_net ? 1 : 0, 1.0f});
       }
     int s = 0;
     for (int i0 = 0; i0 < L.N_L0; ++i0, ++s)
       for (int tl = 0; tl < L.nf[s] / NP; ++tl)
         tiles.push_back(LiveTile{(uint32_t)(base + L.off[s] + (size_t)tl * TW), (uint16_t)lid[0], 0, (uint16_t)(i0 * L.TL0 + tl), 0, T, h, in_f});
-    for (int u = 0; u < HT; ++u, ++s) {
-      for (int c = 0; c < L.HC; ++c)
-        tiles.push_back(LiveTile{(uint32_t)(base + L.off[s] + (size_t)c * TW), (uint16_t)lid[1], 1, (uint16_t)u, (uint16_t)c, T * R, h, h});
-      if (u % 2 == 0 && u >= 2)
-        for (int o = 0; o < OT; ++o)
-          tiles.push_back(LiveTile{(uint32_t)(base + L.off[s] + (size_t)(L.HC + o) * TW), (uint16_t)lid[2], 2, (uint16_t)((u - 2) / 2), (uint16_t)o, R, out_f, h});
+    for (int jl = 1; jl <= depth; ++jl)
+      for (int u = 0; u < HT; ++u, ++s) {
+        for (int c = 0; c < L.HC; ++c)
+          tiles.push_back(LiveTile{(uint32_t)(base + L.off[s] + (size_t)c * TW), (uint16_t)lid[jl], 1, (uint16_t)u, (uint16_t)c, T * R, h, h});
+        if (jl == depth && u % 2 == 0 && u >= 2)
+          for (int o = 0; o < OT; ++o)
+            tiles.push_back(LiveTile{(uint32_t)(base + L.off[s] + (size_t)(L.HC + o) * TW), (uint16_t)lout, 2, (uint16_t)((u - 2) / 2), (uint16_t)o, R, out_f, h});
+      }
+    if (depth >= 1) {
+      for (int o = 0; o < OT; ++o)
+        tiles.push_back(LiveTile{(uint32_t)(base + L.off[s] + (size_t)o * TW), (uint16_t)lout, 2, (uint16_t)(L.HC - 1), (uint16_t)o, R, out_f, h});
+    } else {
+      for (int k = 0; k < L.N_OUT; ++k, ++s) {
+        const int c0 = k * L.CG, cnt = std::min(L.CG, L.HC - c0);
+        for (int cc = 0; cc < cnt; ++cc)
+          for (int o = 0; o < OT; ++o)
+            tiles.push_back(LiveTile{(uint32_t)(base + L.off[s] + (size_t)(cc * OT + o) * TW), (uint16_t)lout, 2, (uint16_t)(c0 + cc), (uint16_t)o, R, out_f, h});
+      }
     }
-    for (int o = 0; o < OT; ++o)
-      tiles.push_back(LiveTile{(uint32_t)(base + L.off[s] + (size_t)o * TW), (uint16_t)lid[2], 2, (uint16_t)(L.HC - 1), (uint16_t)o, R, out_f, h});
     return lid[0];
   };
   for (int s = 0; s < K; ++s) {
@@ -1975,6 +2003,7 @@ int live_blob_create(const gbnf_flow_desc* desc, const int64_t* norm_grad_offset
   lb->kind = desc->kind; lb->d = d; lb->K = K; lb->additive = additive ? 1 : 0; lb->nnets = nnets;
   lb->blob_words = pb.words.size();
   lb->ht = vc.ht;
+  lb->depth = depth;
   lb->n_tiles = (int)tiles.size(); lb->n_bias = (int)biases.size(); lb->n_entries = (int)entries.size();
   for (int nt = 1; nt <= 2; ++nt) { lb->launch_nt[nt] = vc.launch_nt[nt]; lb->name_nt[nt] = vc.name_nt[nt]; }
   hipError_t e = upload_blob(pb.words, &lb->blob_dev, &lb->table_dev);
@@ -1985,7 +2014,7 @@ int live_blob_create(const gbnf_flow_desc* desc, const int64_t* norm_grad_offset
   if (e == hipSuccess) e = upload_vec(norms, &lb->norms_dev);
   // ---- the backward sweep, where a variant of bwd_kernel_hx3 exists for this geometry (else the caller keeps its own)
   if (e == hipSuccess && norm_grad_offsets != nullptr) {
-    const Variant* vb = find_variant(VariantKey{desc->kind, vc.ht, -3, 2, vc.ot, 1, 1, info.act_a, info.act_b});
+    const Variant* vb = find_variant(VariantKey{desc->kind, vc.ht, -3, 2, vc.ot, 1, depth, info.act_a, info.act_b});
     // (the backward kernel keeps every step's tables in LDS: flows of more than LDS_TABLE_STEPS steps, or whose tables + stage
     //  slots + per-wave state do not fit a CU, keep the round-1 backward kernels -- the forward sweep has a global-table form)
     if (vb != nullptr && (K > LDS_TABLE_STEPS || bwd_hx3_lds_bytes(K, bwd_hx3_waves(K, LB.STAGE_FRAGS, d), LB.STAGE_FRAGS, d) > 160 * 1024))
@@ -2055,7 +2084,7 @@ int live_blob_backward(LiveBlob* lb, int64_t n, const float* trace, float* acts,
   p.blobs = lb->table_dev; p.blobs_bwd = lb->tableB_dev;
   p.n = n; p.d = lb->d; p.n_steps = lb->K; p.n_comp = 1; p.n_batches = 1; p.additive = lb->additive;
   p.sat = reinterpret_cast<unsigned long long*>(saturation_counter());
-  p.acts_out = acts; p.np = np; p.tr_ip = ip; p.tr_hp = hp; p.tr_op = op; p.net_rows = ip + 4 * hp + 2 * op;
+  p.acts_out = acts; p.np = np; p.tr_ip = ip; p.tr_hp = hp; p.tr_op = op; p.net_rows = ip + 2 * (lb->depth + 1) * hp + 2 * op;
   p.bwd_tab = lb->bwd_tab_dev; p.bwd_goff = lb->bwd_goff_dev; p.trace_in = trace;
   p.g_z = g_z; p.g_ldj = g_ldj; p.g_x = g_x; p.grads = grads; p.gmax = gmax;
 #if defined(GBNF_STAMPS)
@@ -2121,7 +2150,7 @@ int live_blob_forward(LiveBlob* lb, const float* x, int64_t n, float* z, float* 
   p.n_tiles = (int32_t)((n + 16 * nt - 1) / (16 * nt)); p.additive = lb->additive;
   p.sat = reinterpret_cast<unsigned long long*>(saturation_counter());
   p.seq = next_serial();
-  p.trace_out = trace; p.acts_out = acts; p.np = np; p.tr_ip = ip; p.tr_hp = hp; p.tr_op = op; p.net_rows = ip + 4 * hp + 2 * op;
+  p.trace_out = trace; p.acts_out = acts; p.np = np; p.tr_ip = ip; p.tr_hp = hp; p.tr_op = op; p.net_rows = ip + 2 * (lb->depth + 1) * hp + 2 * op;
   if (range != nullptr) {
     p.k_begin = range->k_begin; p.k_end = range->k_end; p.state_in = range->state_in; p.state_out = range->state_out;
     p.ldj_accumulate = range->ldj_accumulate;

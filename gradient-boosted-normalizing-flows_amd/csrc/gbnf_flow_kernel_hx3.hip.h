@@ -326,7 +326,7 @@ flow_kernel_hx3(const FlowLaunch p) {
   // raw layer-0 tiles kept in registers, added to the second hidden layer's output and split WITHOUT an activation
   static_assert((ACTA == 2) == (ACTB == 2), "both nets of a step are ResidualNets or neither is");
   static_assert(ACTA != 2 || DEPTH == 2, "a one-block ResidualNet has two hidden layers");
-  static_assert(!TRAIN || (DEPTH == 1 && PREC == 0), "the training forward exists for depth-1 nets on f16x3");
+  static_assert(!TRAIN || (PREC == 0 && ACTA != 2), "the training forward exists for TanhNet / ReLUNet (depth 0, 1, 2) on f16x3");
   constexpr int WAVES = WV;
   constexpr int NP = hx3_pieces(PREC);
   constexpr int NPROD = Products<NP>::N;
@@ -1045,6 +1045,8 @@ flow_kernel_hx3(const FlowLaunch p) {
               if (net + 1 == NNETS)     // the next step's tables sit in front of its first net (inverse: the step before this one)
                 next_src = inv ? (gwords)blob + (size_t)(step - 1) * STEP_WORDS + SMALL_WORDS : next_src + SMALL_WORDS;
               issue_net_start(gs + 1);
+            } else if constexpr (TRAIN) {
+              tr_later = 0;               // (no DMA to wait for: the same constant on both paths)
             }
           }
           Unit A[3];
@@ -1083,7 +1085,7 @@ flow_kernel_hx3(const FlowLaunch p) {
             for (int q = n; q < 2 * NT; q += HC) {
               const int nt = q >> 1, hp = q & 1;
               unsigned pc[NP];
-              act_split(pre[nt], hp, nt, pc);
+              act_split(pre[nt], hp, nt, pc, 1, t);
 #pragma unroll
               for (int k = 0; k < NP; ++k) hBs[NHB - 1][t >> 1][nt][k][2 * (t & 1) + hp] = pc[k];
             }
@@ -1261,16 +1263,17 @@ flow_kernel_hx3(const FlowLaunch p) {
           stage_finish(4, false);
         }
         st.mark(4);
-        if constexpr (TRAIN) if (tr_ok) {     // the net's output rows (the backward needs shift / scale)
-          float* q0 = tr_acts + net * tr_net_stride + (tr_ip + 4 * tr_hp + p.tr_op) * tr_np + tr_o_off;    // behind the gradient-side rows
+      }
+      if constexpr (TRAIN) if (tr_ok) {     // the net's output rows (the backward needs shift / scale)
+        // behind the gradient-side rows: input | DEPTH + 1 activation regions | DEPTH + 1 gradient regions | output gradient | output
+        float* q0 = tr_acts + net * tr_net_stride + (tr_ip + 2 * (DEPTH + 1) * tr_hp + p.tr_op) * tr_np + tr_o_off;
 #pragma unroll
-          for (int o = 0; o < OT; ++o)
-            if (16 * o < p.tr_op)
+        for (int o = 0; o < OT; ++o)
+          if (16 * o < p.tr_op)
 #pragma unroll
-              for (int nt = 0; nt < NT; ++nt)
+            for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) q0[nt * tr_op16 + (16 * o + r) * 16] = outF[o][nt][r];
-        }
+              for (int r = 0; r < 4; ++r) q0[nt * tr_op16 + (16 * o + r) * 16] = outF[o][nt][r];
       }
       if constexpr (WATCH) {
 #pragma unroll

@@ -25,17 +25,21 @@
 
 namespace gbnf {
 
-// Packed layout of one coupling net's TRANSPOSED weights (f16x3: NP = 2 fragments per tile), in consumption order:
-//   L0' stages : W3^T tile rows t (hidden tile t = 16 output units of this layer), K0 tiles (k-chunks of 32 net outputs) each,
-//                ROWS0 tile rows per stage
-//   PASS u     : W2^T row u, chunks c = 0..HC-1; then, if u is even and u >= 2, the W1^T chunk (u-2)/2: IT = 2 tiles
-//   DRAIN      : W1^T chunk HC-1
+// Packed layout of one coupling net's TRANSPOSED weights (f16x3: NP = 2 fragments per tile), in consumption order.  The net has
+// layer 0 (input -> hidden), DEPTH hidden -> hidden layers 1 .. DEPTH and the output layer DEPTH + 1 (coupling_network_depth 0, 1, 2):
+//   L0' stages : W(DEPTH+1)^T tile rows t (hidden tile t = 16 output units of this layer), K0 tiles (k-chunks of 32 net outputs)
+//                each, ROWS0 tile rows per stage
+//   MID u      : (DEPTH = 2) W2^T row u, chunks c = 0..HC-1
+//   PASS u     : (DEPTH >= 1) W1^T row u, chunks c = 0..HC-1; then, if u is even and u >= 2, the W0^T chunk (u-2)/2: IT = 2 tiles
+//   DRAIN      : (DEPTH >= 1) W0^T chunk HC-1
+//   IN k       : (DEPTH = 0) W0^T chunks k CGI .. : IT tiles each
 struct BwdLayout {
-  static constexpr int MAXS = 80;
-  int HC, K0, ROWS0, N_L0, NS, NET_WORDS, STAGE_FRAGS;
+  static constexpr int MAXS = 96;
+  int HC, K0, ROWS0, N_L0, NS, NET_WORDS, STAGE_FRAGS, DEPTH, CGI, N_IN;
   int off[MAXS], nf[MAXS];
-  constexpr BwdLayout(int HT, int OT)
-      : HC((HT + 1) / 2), K0((OT + 1) / 2), ROWS0(1), N_L0(0), NS(0), NET_WORDS(0), STAGE_FRAGS(0), off{}, nf{} {
+  constexpr BwdLayout(int HT, int OT, int depth = 1)
+      : HC((HT + 1) / 2), K0((OT + 1) / 2), ROWS0(1), N_L0(0), NS(0), NET_WORDS(0), STAGE_FRAGS(0), DEPTH(depth), CGI(1), N_IN(0),
+        off{}, nf{} {
     ROWS0 = (HC + 2) / K0 > 0 ? (HC + 2) / K0 : 1;
     N_L0 = (HT + ROWS0 - 1) / ROWS0;
     int s = 0, w = 0;
@@ -43,18 +47,31 @@ struct BwdLayout {
       const int cnt = (HT - i * ROWS0 < ROWS0) ? HT - i * ROWS0 : ROWS0;
       off[s] = w; nf[s] = 2 * cnt * K0; w += nf[s] * 256; ++s;
     }
-    for (int u = 0; u < HT; ++u) {
-      off[s] = w; nf[s] = 2 * HC + ((u % 2 == 0 && u >= 2) ? 2 * 2 : 0); w += nf[s] * 256; ++s;
+    if (depth >= 1) {
+      for (int j = depth; j >= 2; --j)
+        for (int u = 0; u < HT; ++u) {
+          off[s] = w; nf[s] = 2 * HC; w += nf[s] * 256; ++s;
+        }
+      for (int u = 0; u < HT; ++u) {
+        off[s] = w; nf[s] = 2 * HC + ((u % 2 == 0 && u >= 2) ? 2 * 2 : 0); w += nf[s] * 256; ++s;
+      }
+      off[s] = w; nf[s] = 2 * 2; w += nf[s] * 256; ++s;
+    } else {
+      CGI = (HC + 2) / 2;                                 // chunks per stage: about the fragments of a pass
+      N_IN = (HC + CGI - 1) / CGI;
+      for (int k = 0; k < N_IN; ++k) {
+        const int cnt = (HC - k * CGI < CGI) ? HC - k * CGI : CGI;
+        off[s] = w; nf[s] = 2 * 2 * cnt; w += nf[s] * 256; ++s;
+      }
     }
-    off[s] = w; nf[s] = 2 * 2; w += nf[s] * 256; ++s;
     NS = s;
     NET_WORDS = w;
     for (int k = 0; k < s; ++k) STAGE_FRAGS = nf[k] > STAGE_FRAGS ? nf[k] : STAGE_FRAGS;
   }
 };
-template <int HT, int OT>
+template <int HT, int OT, int DEPTH>
 struct BwdLayoutOf {
-  static constexpr BwdLayout value = BwdLayout(HT, OT);
+  static constexpr BwdLayout value = BwdLayout(HT, OT, DEPTH);
 };
 
 // the device side of tr_grad_scale (gbnf_train.hip): alpha = the power of two that puts the largest upstream entry at [4, 8)
@@ -84,19 +101,22 @@ __device__ __forceinline__ float bwd_sum16(float v) {
 // Waves per SIMD the 4-wave form is compiled for: 2 (256 registers, two workgroups share a CU and cover each other's memory
 // latency: 498 -> 3xx us at N = 65536) where the kernel fits -- its register count is 8 per hidden tile (the saved second-layer
 // activations and the split g_a2 operands) + ~125 (measured: HT = 14 -> 235) -- else 1 (512 registers).
-constexpr int bwd_hx3_occupancy(int KIND, int HT, int OT) {
+constexpr int bwd_hx3_occupancy(int KIND, int HT, int OT, int DEPTH = 1) {
 #ifdef GBNF_BWD_OCC
   return GBNF_BWD_OCC;
 #else
-  return 8 * HT + 125 + (KIND == GBNF_KIND_REALNVP ? 8 * OT + 8 : 0) <= 250 ? 2 : 1;
+  // (two hidden -> hidden layers: a second set of split gradient operands, 4 registers per hidden tile)
+  return (DEPTH == 2 ? 12 : 8) * HT + 125 + (KIND == GBNF_KIND_REALNVP ? 8 * OT + 8 : 0) <= 250 ? 2 : 1;
 #endif
 }
-template <int KIND, int HT, int OT, int ACTA, int ACTB, int WV>
-__global__ void __launch_bounds__(64 * WV, WV == 8 ? 2 : bwd_hx3_occupancy(KIND, HT, OT)) bwd_kernel_hx3(const FlowLaunch p) {
+template <int KIND, int HT, int OT, int ACTA, int ACTB, int WV, int DEPTH = 1>
+__global__ void __launch_bounds__(64 * WV, WV == 8 ? 2 : bwd_hx3_occupancy(KIND, HT, OT, DEPTH)) bwd_kernel_hx3(const FlowLaunch p) {
+  static_assert(DEPTH >= 0 && DEPTH <= 2, "coupling_network_depth 0, 1 or 2");
   constexpr int WAVES = WV, NP = 2, NT = 1, ZS = 17, IT = 2;
   constexpr int NNETS = (KIND == GBNF_KIND_REALNVP) ? 2 : 1;
-  using FL = Hx3LayoutOf<HT, OT, NP, 1>;                 // the forward blob: only its per-step tables are read here
-  using BL = BwdLayoutOf<HT, OT>;
+  constexpr int NH = DEPTH + 1;                          // hidden activations per net: operand rows in | NH x act | NH x grad | out grad | out
+  using FL = Hx3LayoutOf<HT, OT, NP, DEPTH>;             // the forward blob: only its per-step tables are read here
+  using BL = BwdLayoutOf<HT, OT, DEPTH>;
   constexpr int HC = BL::value.HC, K0 = BL::value.K0, ROWS0 = BL::value.ROWS0;
   constexpr int STEP_WORDS_F = SMALL_WORDS + NNETS * FL::value.NET_WORDS;
   constexpr int STEP_WORDS_B = NNETS * BL::value.NET_WORDS;
@@ -275,10 +295,10 @@ __global__ void __launch_bounds__(64 * WV, WV == 8 ? 2 : bwd_hx3_occupancy(KIND,
     float yin[NENT];
 #pragma unroll
     for (int e = 0; e < NENT; ++e) yin[e] = trace[(tin.slot[e] >= 0 ? tin.slot[e] : 0) * np + row];
-    // ... and so are net 0's second-layer activations (56 loads for h = 215): one exposed round trip per step, not two
+    // ... and so are net 0's last-hidden-layer activations (56 loads for h = 215): one exposed round trip per step, not two
     f32x4 h2first[HT];
     {
-      const float* h2p0 = acts + (int64_t)(p.tr_ip + p.tr_hp) * np + h_off;
+      const float* h2p0 = acts + (int64_t)(p.tr_ip + DEPTH * p.tr_hp) * np + h_off;
 #pragma unroll
       for (int t = 0; t < HT; ++t)
 #pragma unroll
@@ -286,7 +306,7 @@ __global__ void __launch_bounds__(64 * WV, WV == 8 ? 2 : bwd_hx3_occupancy(KIND,
     }
     float y2v[NENT];
     {
-      const float* oA = acts + (int64_t)(p.tr_ip + 4 * p.tr_hp + p.tr_op) * np + o_off;     // the forward sweep's saved net outputs
+      const float* oA = acts + (int64_t)(p.tr_ip + 2 * NH * p.tr_hp + p.tr_op) * np + o_off;     // the forward sweep's saved net outputs
       const float* oB = oA + (int64_t)p.net_rows * np;
       if (KIND == GBNF_KIND_GLOW && !p.additive) {
         constexpr int NE = (2 * OT < NENT) ? 2 * OT : NENT;
@@ -348,11 +368,14 @@ __global__ void __launch_bounds__(64 * WV, WV == 8 ? 2 : bwd_hx3_occupancy(KIND,
       const int ACT = (net == 0) ? ACTA : ACTB;
       const bool relu_rt = ACT == 3 && __builtin_amdgcn_readfirstlane(smt[2 + net]) != 0;
       float* an = acts + (int64_t)net * p.net_rows * np;
-      const float* h1p = an + (int64_t)p.tr_ip * np + h_off;                          // saved activations (forward sweep)
-      const float* h2p = an + (int64_t)(p.tr_ip + p.tr_hp) * np + h_off;
-      float* d1p = an + (int64_t)(p.tr_ip + 2 * p.tr_hp) * np + h_off;                // gradient-side operands for wgrad_kernel
-      float* d2p = an + (int64_t)(p.tr_ip + 3 * p.tr_hp) * np + h_off;
-      float* dop = an + (int64_t)(p.tr_ip + 4 * p.tr_hp) * np + o_off;
+      // saved activations (forward sweep) of hidden layer l: rows ip + l hp; gradient-side operands for wgrad_kernel: ip + (NH + l) hp
+      const float* h1p = an + (int64_t)p.tr_ip * np + h_off;                          // layer 0 (the last pass layer's act')
+      const float* h2p = an + (int64_t)(p.tr_ip + DEPTH * p.tr_hp) * np + h_off;      // the last hidden layer
+      [[maybe_unused]] const float* hmp = an + (int64_t)(p.tr_ip + p.tr_hp) * np + h_off;      // (DEPTH = 2) the middle one
+      float* d1p = an + (int64_t)(p.tr_ip + NH * p.tr_hp) * np + h_off;
+      float* d2p = an + (int64_t)(p.tr_ip + (NH + DEPTH) * p.tr_hp) * np + h_off;
+      [[maybe_unused]] float* dmp = an + (int64_t)(p.tr_ip + (NH + 1) * p.tr_hp) * np + h_off;
+      float* dop = an + (int64_t)(p.tr_ip + 2 * NH * p.tr_hp) * np + o_off;
       auto dact = [&](float gv, float hv) {       // gv * act'(pre-activation), through the saved activation hv
         const float t = gv * __builtin_fmaf(-hv, hv, 1.0f), r = hv > 0.0f ? gv : 0.0f;
         if (ACT == GBNF_ACT_TANH) return t;
@@ -447,11 +470,122 @@ __global__ void __launch_bounds__(64 * WV, WV == 8 ? 2 : bwd_hx3_occupancy(KIND,
         st.set(2);
       }
 
-      // ---- W2^T: one output tile per stage; tile u-1 times act'(h1) is emitted / split during pass u and consumed, two
-      //      tiles per chunk, by the W1^T tiles (two output tiles: the net input's <= 32 rows)
       Acc outG[IT];
 #pragma unroll
       for (int o = 0; o < IT; ++o) outG[o].init(f32x4{0.f, 0.f, 0.f, 0.f});
+      // ---- (DEPTH = 2) W2^T: one output tile per stage; tile u-1 times act'(h of the middle layer) is emitted / split during pass u
+      //      into the second operand set gB2 -- the B operands of the W1^T passes.  Fully unrolled: the destination register of
+      //      a finished tile is a compile-time index.
+      u32x4 gB2[DEPTH == 2 ? HC : 1][NP];
+      if constexpr (DEPTH == 2) {
+#pragma unroll
+        for (int k = 0; k < NP; ++k) gB2[HC - 1][k] = u32x4{0, 0, 0, 0};
+        f32x4 prem = f32x4{0.f, 0.f, 0.f, 0.f};
+        auto load_hm = [&](int t) {
+          f32x4 v;
+          const int tt = t < HT ? t : HT - 1;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) v[r] = (GBNF_BWD_ABLATE & 4) ? 0.5f : hmp[(16 * tt + r) * 16];
+          return v;
+        };
+        f32x4 hmv[2] = {load_hm(0), load_hm(1)};       // saved activations of the even / odd tile that is finished next
+        auto finish_mid = [&](auto t_c) {              // tile t of the middle layer's gradient -> operand workspace + gB2
+          constexpr int t = decltype(t_c)::value;
+          f32x4 ga;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) ga[r] = dact(prem[r], hmv[t & 1][r]);
+          if (!(GBNF_BWD_ABLATE & 2)) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) dmp[(16 * t + r) * 16] = ga[r];
+            later += 4;
+          }
+          unsigned lo[NP], hi[NP];
+          split4(ga, lo, hi);
+#pragma unroll
+          for (int k = 0; k < NP; ++k) { gB2[t >> 1][k][2 * (t & 1)] = lo[k]; gB2[t >> 1][k][2 * (t & 1) + 1] = hi[k]; }
+        };
+        auto mid_pass = [&](auto u_c) {
+          constexpr int u = decltype(u_c)::value;
+          issue(std::integral_constant<int, NP * HC>{}, gs + 1);      // the next pass of this layer or pass 0 of the W1^T layer
+          __builtin_amdgcn_sched_barrier(0);       // (the stores + loads below stay BEHIND the staging DMA: stage_end counts on it)
+          Unit A[3];
+          A[0] = N0;
+          A[1] = N1;
+          Acc acc;
+          acc.init(f32x4{0.f, 0.f, 0.f, 0.f});
+          if constexpr (u > 0) {
+            finish_mid(std::integral_constant<int, (u > 0 ? u - 1 : 0)>{});
+            // (the last pass has no tile u + 1 to request: a load whose value is never used would be dropped by the compiler and the
+            //  counted wait below would then let the next stage's staging DMA slip)
+            if constexpr (u + 1 < HT) {
+              hmv[(u - 1) & 1] = load_hm(u + 1);
+              later += 4;
+            }
+          }
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int n = 0; n < HC; ++n) {
+            if (n + 2 < HC) load_unit(A[(n + 2) % 3], n + 2);
+            if (n == HC - 1) stage_finish(true);
+            mac(A[n % 3], gB[n], acc);
+            __builtin_amdgcn_sched_barrier(0);
+          }
+          prem = acc.total();
+          stage_finish(false);
+        };
+        auto mid_all = [&](auto self, auto u_c) -> void {
+          constexpr int u = decltype(u_c)::value;
+          if constexpr (u < HT) {
+            mid_pass(u_c);
+            self(self, std::integral_constant<int, u + 1>{});
+          }
+        };
+        mid_all(mid_all, std::integral_constant<int, 0>{});
+        finish_mid(std::integral_constant<int, HT - 1>{});
+      }
+      auto& gBin = [&]() -> auto& {                 // the B operands of the W1^T passes
+        if constexpr (DEPTH == 2) return gB2;
+        else return gB;
+      }();
+      if constexpr (DEPTH == 0) {
+        // ---- no hidden -> hidden layer: W0^T contracts the layer-0 gradient gB, CGI chunks (IT tiles each) per stage
+        constexpr int CGI = BL::value.CGI, N_IN = BL::value.N_IN;
+        auto in_stage = [&](auto k_c) {
+          constexpr int k = decltype(k_c)::value;
+          constexpr int c0 = k * CGI;
+          constexpr int cnt = (HC - c0 < CGI) ? HC - c0 : CGI;
+          constexpr int NU = cnt * IT;
+          if constexpr (k + 1 < N_IN) {
+            issue(std::integral_constant<int, BL::value.nf[BL::value.N_L0 + k + 1]>{}, gs + 1);
+          } else {
+            if (net + 1 < NNETS || step > kb) {
+              if (net + 1 == NNETS) next_src = (gwords)blobB + (size_t)(step - 1) * STEP_WORDS_B;
+              issue(std::integral_constant<int, BL::value.nf[0]>{}, gs + 1);
+            } else {
+              later = 0;               // (no DMA to wait for: the same constant on both paths)
+            }
+          }
+          Unit A[3];
+          A[0] = N0;
+          if (NU > 1) A[1] = N1;
+#pragma unroll
+          for (int n = 0; n < NU; ++n) {
+            if (n + 2 < NU) load_unit(A[(n + 2) % 3], n + 2);
+            if (n == NU - 1) stage_finish(true);
+            mac(A[n % 3], gB[c0 + n / IT], outG[n % IT]);
+            __builtin_amdgcn_sched_barrier(0);
+          }
+          stage_finish(false);
+        };
+        static_assert(N_IN <= 4, "input stages of a depth-0 net");
+        st.set(3);
+        in_stage(std::integral_constant<int, 0>{});
+        if constexpr (N_IN > 1) in_stage(std::integral_constant<int, 1>{});
+        if constexpr (N_IN > 2) in_stage(std::integral_constant<int, 2>{});
+        if constexpr (N_IN > 3) in_stage(std::integral_constant<int, 3>{});
+      } else {
+      // ---- W2^T: one output tile per stage; tile u-1 times act'(h1) is emitted / split during pass u and consumed, two
+      //      tiles per chunk, by the W1^T tiles (two output tiles: the net input's <= 32 rows)
       u32x4 hO[NP];
 #pragma unroll
       for (int k = 0; k < NP; ++k) hO[k] = u32x4{0, 0, 0, 0};
@@ -503,7 +637,7 @@ __global__ void __launch_bounds__(64 * WV, WV == 8 ? 2 : bwd_hx3_occupancy(KIND,
           if (n == NU - 1) {
             stage_finish(true);
           }
-          if (n < HC) mac(A[n % 3], gB[n], acc);
+          if (n < HC) mac(A[n % 3], gBin[n], acc);
           else mac(A[n % 3], hO, outG[n - HC]);
           __builtin_amdgcn_sched_barrier(0);
         }
@@ -557,6 +691,7 @@ __global__ void __launch_bounds__(64 * WV, WV == 8 ? 2 : bwd_hx3_occupancy(KIND,
           mac(A[o], hO, outG[o]);
         }
         stage_finish(false);
+      }
       }
       // the net's contribution to d loss / d net input: rows k = 16 o + 4 g + r of this lane's sample
 #pragma unroll
@@ -687,35 +822,35 @@ inline int bwd_hx3_waves(int n_steps, int stage_frags, int d) {
   return bwd_hx3_lds_bytes(n_steps, 4, stage_frags, d) <= 160 * 1024 ? 4 : 8;
 }
 
-template <int KIND, int HT, int OT, int ACTA, int ACTB, int WV>
+template <int KIND, int HT, int OT, int ACTA, int ACTB, int WV, int DEPTH>
 static hipError_t bwd_launch_wv(FlowLaunch p, hipStream_t s) {
-  constexpr BwdLayout L(HT, OT);
+  constexpr BwdLayout L(HT, OT, DEPTH);
   const size_t lds = bwd_hx3_lds_bytes(p.n_steps, WV, L.STAGE_FRAGS, p.d);
   if (lds > 160 * 1024 || p.n_steps > LDS_TABLE_STEPS) return hipErrorInvalidValue;
   const long long tiles = p.np / 16;               // every padded row (np is a multiple of 32): wgrad_kernel sums over all of them
   const long long grid = (tiles + WV - 1) / WV;
   static bool attr_set = false;
   if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute((const void*)bwd_kernel_hx3<KIND, HT, OT, ACTA, ACTB, WV>,
+    hipError_t e = hipFuncSetAttribute((const void*)bwd_kernel_hx3<KIND, HT, OT, ACTA, ACTB, WV, DEPTH>,
                                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e != hipSuccess) return e;
     attr_set = true;
   }
-  hipLaunchKernelGGL((bwd_kernel_hx3<KIND, HT, OT, ACTA, ACTB, WV>), dim3((unsigned)grid), dim3(64 * WV), lds, s, p);
+  hipLaunchKernelGGL((bwd_kernel_hx3<KIND, HT, OT, ACTA, ACTB, WV, DEPTH>), dim3((unsigned)grid), dim3(64 * WV), lds, s, p);
   return hipGetLastError();
 }
 
-// registry key: VariantKey{kind, ht, -3, /*ks1*/ 2 (backward), ot, /*nt*/ 1, /*depth*/ 1, act_a, act_b}
-#define GBNF_INSTANTIATE_HX3_BWD(KIND, HT, OT, ACTA, ACTB)                                                  \
+// registry key: VariantKey{kind, ht, -3, /*ks1*/ 2 (backward), ot, /*nt*/ 1, depth, act_a, act_b}
+#define GBNF_INSTANTIATE_HX3_BWD(KIND, HT, OT, ACTA, ACTB, DEPTH)                                           \
   namespace gbnf {                                                                                          \
-  static hipError_t launch_hx3b_##KIND##_##HT##_##OT##_##ACTA##_##ACTB(const FlowLaunch& p0, unsigned, hipStream_t s) { \
-    constexpr BwdLayout L(HT, OT);                                                                          \
-    if (bwd_hx3_waves(p0.n_steps, L.STAGE_FRAGS, p0.d) == 4) return bwd_launch_wv<KIND, HT, OT, ACTA, ACTB, 4>(p0, s); \
-    return bwd_launch_wv<KIND, HT, OT, ACTA, ACTB, 8>(p0, s);                                               \
+  static hipError_t launch_hx3b_##KIND##_##HT##_##OT##_##ACTA##_##ACTB##_##DEPTH(const FlowLaunch& p0, unsigned, hipStream_t s) { \
+    constexpr BwdLayout L(HT, OT, DEPTH);                                                                   \
+    if (bwd_hx3_waves(p0.n_steps, L.STAGE_FRAGS, p0.d) == 4) return bwd_launch_wv<KIND, HT, OT, ACTA, ACTB, 4, DEPTH>(p0, s); \
+    return bwd_launch_wv<KIND, HT, OT, ACTA, ACTB, 8, DEPTH>(p0, s);                                        \
   }                                                                                                         \
-  static const int reg_hx3b_##KIND##_##HT##_##OT##_##ACTA##_##ACTB =                                        \
-      (register_variant(VariantKey{KIND, HT, -3, 2, OT, 1, 1, ACTA, ACTB}, launch_hx3b_##KIND##_##HT##_##OT##_##ACTA##_##ACTB, \
-                        "bwd_kernel_hx3<" #KIND "," #HT "," #OT "," #ACTA "," #ACTB ">"),                   \
+  static const int reg_hx3b_##KIND##_##HT##_##OT##_##ACTA##_##ACTB##_##DEPTH =                              \
+      (register_variant(VariantKey{KIND, HT, -3, 2, OT, 1, DEPTH, ACTA, ACTB}, launch_hx3b_##KIND##_##HT##_##OT##_##ACTA##_##ACTB##_##DEPTH, \
+                        "bwd_kernel_hx3<" #KIND "," #HT "," #OT "," #ACTA "," #ACTB "," #DEPTH ">"),        \
        0);                                                                                                  \
   }
 

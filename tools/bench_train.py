@@ -19,7 +19,12 @@ import numpy as np
 import torch
 
 CONFIGS = {"miniboone_glow": dict(kind="glow", d=43, h=215, K=5, kw={}),
-           "hepmass_realnvp": dict(kind="realnvp", d=21, h=105, K=5, kw={})}
+           "hepmass_realnvp": dict(kind="realnvp", d=21, h=105, K=5, kw={}),
+           # the other coupling networks the reference constructs (--coupling_network_depth 0 / 2, --coupling_network residual)
+           "miniboone_glow_depth0": dict(kind="glow", d=43, h=215, K=5, kw={"depth": 0}),
+           "miniboone_glow_depth2": dict(kind="glow", d=43, h=215, K=5, kw={"depth": 2}),
+           "hepmass_realnvp_depth2": dict(kind="realnvp", d=21, h=105, K=5, kw={"depth": 2}),
+           "hepmass_realnvp_residual": dict(kind="realnvp", d=21, h=105, K=5, kw={"coupling_network": "residual"})}
 
 
 def torch_step(spec, x, dev, dtype=torch.float32):
