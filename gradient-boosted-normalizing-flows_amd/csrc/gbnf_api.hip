@@ -1812,8 +1812,9 @@ int live_blob_create(const gbnf_flow_desc* desc, const int64_t* norm_grad_offset
   const bool glow = desc->kind == GBNF_KIND_GLOW;
   const bool additive = glow && desc->coupling == GBNF_COUPLING_ADDITIVE;
   const int h = info.ref.hidden, depth = info.ref.depth;
-  if (depth > 2 || info.ref.residual)
-    return fail(GBNF_ERR_UNSUPPORTED, "live blob: TanhNet / ReLUNet of coupling_network_depth 0, 1 or 2 only");
+  if (depth > 2)
+    return fail(GBNF_ERR_UNSUPPORTED, "live blob: TanhNet / ReLUNet of coupling_network_depth 0, 1 or 2 and one-block ResidualNets only");
+  if (info.ref.residual) info.act_a = info.act_b = GBNF_ACT_RESIDUAL_RELU;      // the kernels' key of a ResidualNet (depth 2 = one block)
   {   // an activation pair nobody compiled a kernel for runs on the per-step variants (as gbnf_flow_create_ex does)
     bool compiled = false;
     for (const Variant& v : variants())

@@ -326,7 +326,7 @@ flow_kernel_hx3(const FlowLaunch p) {
   // raw layer-0 tiles kept in registers, added to the second hidden layer's output and split WITHOUT an activation
   static_assert((ACTA == 2) == (ACTB == 2), "both nets of a step are ResidualNets or neither is");
   static_assert(ACTA != 2 || DEPTH == 2, "a one-block ResidualNet has two hidden layers");
-  static_assert(!TRAIN || (PREC == 0 && ACTA != 2), "the training forward exists for TanhNet / ReLUNet (depth 0, 1, 2) on f16x3");
+  static_assert(!TRAIN || PREC == 0, "the training forward runs on f16x3");
   constexpr int WAVES = WV;
   constexpr int NP = hx3_pieces(PREC);
   constexpr int NPROD = Products<NP>::N;
@@ -913,8 +913,9 @@ flow_kernel_hx3(const FlowLaunch p) {
       // as it is (no activation): range-watched and clamped like a ReLU activation
       constexpr bool RES = (ACTA == 2);
       f32x4 t0r[RES ? HT : 1][NT];
-      auto res_split = [&](const f32x4& raw, const f32x4& t0, int hp, int nt, unsigned (&pc)[NP]) {
+      auto res_split = [&](const f32x4& raw, const f32x4& t0, int hp, int nt, unsigned (&pc)[NP], int tile) {
         float v0 = raw[2 * hp] + t0[2 * hp], v1 = raw[2 * hp + 1] + t0[2 * hp + 1];
+        save_act(v0, v1, false, 2, tile, hp, nt);            // TRAIN: the final layer's input t (operand rows of hidden "layer" 2)
         if constexpr (WATCH) {
           amax[nt] = __builtin_fmaxf(amax[nt], __builtin_fmaxf(__builtin_fabsf(v0), __builtin_fabsf(v1)));
           v0 = __builtin_amdgcn_fmed3f(v0, -65504.0f, 65504.0f);
@@ -1168,7 +1169,7 @@ flow_kernel_hx3(const FlowLaunch p) {
                 for (int q = n; q < 2 * NT; q += HC) {
                   const int nt = q >> 1, hp = q & 1;
                   unsigned pc[NP];
-                  if constexpr (RES) res_split(pre[nt], t0r[u - 1][nt], hp, nt, pc);
+                  if constexpr (RES) res_split(pre[nt], t0r[u - 1][nt], hp, nt, pc, u - 1);
                   else act_split(pre[nt], hp, nt, pc, DEPTH, u - 1);
 #pragma unroll
                   for (int k = 0; k < NP; ++k) hO[nt][k][(PREV == 2 ? 2 : 0) + hp] = pc[k];
@@ -1241,7 +1242,7 @@ flow_kernel_hx3(const FlowLaunch p) {
 #pragma unroll
             for (int hp = 0; hp < 2; ++hp) {
               unsigned pc[NP];
-              if constexpr (RES) res_split(pre[nt], t0r[HT - 1][nt], hp, nt, pc);
+              if constexpr (RES) res_split(pre[nt], t0r[HT - 1][nt], hp, nt, pc, HT - 1);
               else act_split(pre[nt], hp, nt, pc, DEPTH, HT - 1);
 #pragma unroll
               for (int k = 0; k < NP; ++k) hO[nt][k][(odd_last ? 2 : 0) + hp] = pc[k];

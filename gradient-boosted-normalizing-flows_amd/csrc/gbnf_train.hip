@@ -1717,7 +1717,7 @@ int gbnf_trainer_create(const gbnf_flow_desc* desc, gbnf_trainer** out) {
   }
   // the register-chained forward sweep where a TRAIN variant of the evaluation kernel covers the geometry (else the
   // kernels of this file do the forward too)
-  if (!residual && nl >= 2 && nl <= 4 && tr_fast_path_enabled()) {       // TanhNet / ReLUNet of coupling_network_depth 0, 1, 2
+  if (nl >= 2 && nl <= 4 && (!residual || nl == 4) && tr_fast_path_enabled()) {       // TanhNet / ReLUNet of depth 0, 1, 2; one-block ResidualNets
     LiveBlob* lb = nullptr;
     std::vector<int64_t> goff(2 * (size_t)K);
     for (int k = 0; k < K; ++k) { goff[2 * k] = steps[k].g_na; goff[2 * k + 1] = steps[k].g_nb; }

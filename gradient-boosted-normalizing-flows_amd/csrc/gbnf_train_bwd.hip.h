@@ -112,6 +112,13 @@ constexpr int bwd_hx3_occupancy(int KIND, int HT, int OT, int DEPTH = 1) {
 template <int KIND, int HT, int OT, int ACTA, int ACTB, int WV, int DEPTH = 1>
 __global__ void __launch_bounds__(64 * WV, WV == 8 ? 2 : bwd_hx3_occupancy(KIND, HT, OT, DEPTH)) bwd_kernel_hx3(const FlowLaunch p) {
   static_assert(DEPTH >= 0 && DEPTH <= 2, "coupling_network_depth 0, 1 or 2");
+  // ACT == 2 (GBNF_ACT_RESIDUAL_RELU): a ResidualNet of ONE block (models/layers.py:246-301) = layer 0 -> [relu -> Linear -> relu ->
+  // Linear] + layer 0's output -> final layer.  Backward: the final layer's input gradient g_t passes the block's exit unchanged
+  // (no activation in front of the final layer), runs back through the two inner layers with relu', and is ADDED to the block's
+  // input gradient (the skip connection): DEPTH = 2 with the raw g_t tiles kept in registers.
+  constexpr bool RES = ACTA == 2;
+  static_assert((ACTA == 2) == (ACTB == 2), "both nets of a step are ResidualNets or neither is");
+  static_assert(!RES || DEPTH == 2, "a one-block ResidualNet has two hidden -> hidden layers");
   constexpr int WAVES = WV, NP = 2, NT = 1, ZS = 17, IT = 2;
   constexpr int NNETS = (KIND == GBNF_KIND_REALNVP) ? 2 : 1;
   constexpr int NH = DEPTH + 1;                          // hidden activations per net: operand rows in | NH x act | NH x grad | out grad | out
@@ -302,7 +309,7 @@ __global__ void __launch_bounds__(64 * WV, WV == 8 ? 2 : bwd_hx3_occupancy(KIND,
 #pragma unroll
       for (int t = 0; t < HT; ++t)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) h2first[t][r] = (GBNF_BWD_ABLATE & 4) ? 0.5f : h2p0[(16 * t + r) * 16];
+        for (int r = 0; r < 4; ++r) h2first[t][r] = ((GBNF_BWD_ABLATE & 4) || RES) ? 0.5f : h2p0[(16 * t + r) * 16];
     }
     float y2v[NENT];
     {
@@ -379,7 +386,7 @@ __global__ void __launch_bounds__(64 * WV, WV == 8 ? 2 : bwd_hx3_occupancy(KIND,
       auto dact = [&](float gv, float hv) {       // gv * act'(pre-activation), through the saved activation hv
         const float t = gv * __builtin_fmaf(-hv, hv, 1.0f), r = hv > 0.0f ? gv : 0.0f;
         if (ACT == GBNF_ACT_TANH) return t;
-        if (ACT == GBNF_ACT_RELU) return r;
+        if (ACT == GBNF_ACT_RELU || ACT == 2) return r;
         return relu_rt ? r : t;
       };
       // the chain's input: the output gradient, emitted and split two tiles per k-chunk
@@ -403,7 +410,9 @@ __global__ void __launch_bounds__(64 * WV, WV == 8 ? 2 : bwd_hx3_occupancy(KIND,
       f32x4 h2v[HT];
 #pragma unroll
       for (int t = 0; t < HT; ++t) {
-        if (net == 0) {
+        if constexpr (RES) {
+          h2v[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+        } else if (net == 0) {
           h2v[t] = h2first[t];
         } else {
 #pragma unroll
@@ -411,6 +420,7 @@ __global__ void __launch_bounds__(64 * WV, WV == 8 ? 2 : bwd_hx3_occupancy(KIND,
         }
       }
 
+      f32x4 gskip[RES ? HT : 1];                  // (ResidualNet) g_t, tile by tile: added to the block's input gradient
       u32x4 gB[HC][NP];                           // g_a2 = (W3^T g_o) * act'(h2), split: the B operands of the W2^T layer
 #pragma unroll
       for (int k = 0; k < NP; ++k) gB[HC - 1][k] = u32x4{0, 0, 0, 0};
@@ -418,8 +428,13 @@ __global__ void __launch_bounds__(64 * WV, WV == 8 ? 2 : bwd_hx3_occupancy(KIND,
         f32x4 rawp = f32x4{0.f, 0.f, 0.f, 0.f};
         auto finish_tile = [&](int t, const f32x4& raw) {
           f32x4 ga;
+          if constexpr (RES) {
+            ga = raw;                              // d/dt: the final layer reads t itself
+            gskip[t] = raw;
+          } else {
 #pragma unroll
-          for (int r = 0; r < 4; ++r) ga[r] = dact(raw[r], h2v[t][r]);
+            for (int r = 0; r < 4; ++r) ga[r] = dact(raw[r], h2v[t][r]);
+          }
           if (!(GBNF_BWD_ABLATE & 2)) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) d2p[(16 * t + r) * 16] = ga[r];
@@ -602,6 +617,7 @@ __global__ void __launch_bounds__(64 * WV, WV == 8 ? 2 : bwd_hx3_occupancy(KIND,
         f32x4 ga;
 #pragma unroll
         for (int r = 0; r < 4; ++r) ga[r] = dact(pre[r], hv[r]);
+        if constexpr (RES) ga += gskip[t];          // (t is a compile-time index here: the ResidualNet passes are fully unrolled)
         if (!(GBNF_BWD_ABLATE & 2)) {
 #pragma unroll
           for (int r = 0; r < 4; ++r) d1p[(16 * t + r) * 16] = ga[r];
@@ -654,10 +670,19 @@ __global__ void __launch_bounds__(64 * WV, WV == 8 ? 2 : bwd_hx3_occupancy(KIND,
       } else {
         pass(0, I0{}, BF{});
         int u = 1;
+        if constexpr (RES) {       // (the skip tile of pass u is a register array indexed by u: compile-time passes)
+#pragma unroll
+          for (int uu = 1; uu + 2 < HT; uu += 2) {
+            pass(uu, I1{}, BF{});
+            pass(uu + 1, I2{}, BF{});
+          }
+          u = 1 + 2 * ((HT - 2) / 2);
+        } else {
 #pragma unroll 1
-        for (; u + 2 < HT; u += 2) {
-          pass(u, I1{}, BF{});
-          pass(u + 1, I2{}, BF{});
+          for (; u + 2 < HT; u += 2) {
+            pass(u, I1{}, BF{});
+            pass(u + 1, I2{}, BF{});
+          }
         }
         if constexpr (HT % 2 == 1) {
           pass(u, I1{}, BF{});

@@ -333,10 +333,11 @@ int gbnf_trainer_destroy(gbnf_trainer* trainer);
  * gbnf_trainer_trace_floats(n) floats of DEVICE memory) receives every step's normalised state; handing it to
  * gbnf_trainer_backward saves that call the forward sweep and the re-splitting of the weights (valid only while the
  * parameters are unchanged and no other forward call of this trainer ran on changed parameters in between).
- * Since round 3 the trace buffer of a flow that runs on the register-chained kernels (depth-1 coupling nets of a compiled
- * width, BatchNorm on running statistics) is also the OPERAND WORKSPACE of the step: behind the states the forward call
- * stores the coupling nets' inputs, hidden activations and outputs (gbnf_trainer_trace_floats accounts for it:
- * K * nets * (ip + 4 hp + 2 op) rows of n-rounded-up-to-32 floats -- 20 KB per sample for MINIBOONE, K = 5), and
+ * Since round 3 the trace buffer of a flow that runs on the register-chained kernels (TanhNet / ReLUNet coupling nets of
+ * coupling_network_depth 0, 1, 2 and one-block ResidualNets -- the depths other than 1 since round 5 -- of a compiled width)
+ * is also the OPERAND WORKSPACE of the step: behind the states the forward call stores the coupling nets' inputs, hidden
+ * activations and outputs (gbnf_trainer_trace_floats accounts for it: K * nets * (ip + 2 L hp + 2 op) rows of
+ * n-rounded-up-to-32 floats, L = hidden layers per net -- 20 KB per sample for MINIBOONE, K = 5, depth 1), and
  * gbnf_trainer_backward WRITES the gradient-side operands of the weight gradients into the same buffer (its `trace`
  * argument is const for the states only).  One trace buffer therefore serves one forward + one backward call. */
 int gbnf_trainer_trace_floats(const gbnf_trainer* trainer, int64_t n, int64_t* n_floats);
