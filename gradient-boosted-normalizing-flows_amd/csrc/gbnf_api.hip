@@ -1803,14 +1803,9 @@ static hipError_t upload_vec(const std::vector<T>& v, T** dev) {
   return e;
 }
 
-int live_blob_create(const gbnf_flow_desc* desc, const int64_t* norm_grad_offsets, LiveBlob** out) {
-  *out = nullptr;
-  DescInfo info;
-  int rc = validate_desc(desc, &info);
-  if (rc) return rc;
-  const int d = desc->d, K = desc->n_steps;
-  const bool glow = desc->kind == GBNF_KIND_GLOW;
-  const bool additive = glow && desc->coupling == GBNF_COUPLING_ADDITIVE;
+// The TRAIN kernel variant of a flow: the exact padded width if one is compiled, else the cheapest zero-padded superset (the
+// per-step-activation variants are generic supersets).  GBNF_OK and *vc, or UNSUPPORTED.
+static int live_choose(const gbnf_flow_desc* desc, DescInfo& info, VariantChoice* vc) {
   const int h = info.ref.hidden, depth = info.ref.depth;
   if (depth > 2)
     return fail(GBNF_ERR_UNSUPPORTED, "live blob: TanhNet / ReLUNet of coupling_network_depth 0, 1 or 2 and one-block ResidualNets only");
@@ -1821,16 +1816,40 @@ int live_blob_create(const gbnf_flow_desc* desc, const int64_t* norm_grad_offset
       compiled = compiled || (v.key.ks1 == 1 && v.key.kind == desc->kind && v.key.act_a == info.act_a && v.key.act_b == info.act_b);
     if (!compiled) info.act_a = info.act_b = GBNF_ACT_PER_STEP;
   }
-  VariantChoice vc;
-  if (!choose_hx3(desc->kind, h, info.ot, depth, info.act_a, info.act_b, -3, &vc, /*train=*/1)) {
-    if (info.act_a != GBNF_ACT_PER_STEP) {
+  if (!choose_hx3(desc->kind, h, info.ot, depth, info.act_a, info.act_b, -3, vc, /*train=*/1)) {
+    if (info.act_a != GBNF_ACT_PER_STEP && !info.ref.residual) {
       info.act_a = info.act_b = GBNF_ACT_PER_STEP;
-      if (!choose_hx3(desc->kind, h, info.ot, depth, info.act_a, info.act_b, -3, &vc, 1))
+      if (!choose_hx3(desc->kind, h, info.ot, depth, info.act_a, info.act_b, -3, vc, 1))
         return fail(GBNF_ERR_UNSUPPORTED, "live blob: no TRAIN kernel variant for kind=%d hidden=%d out_tiles=%d", desc->kind, h, info.ot);
     } else {
       return fail(GBNF_ERR_UNSUPPORTED, "live blob: no TRAIN kernel variant for kind=%d hidden=%d out_tiles=%d", desc->kind, h, info.ot);
     }
   }
+  return GBNF_OK;
+}
+
+// Hidden rows (16 x hidden tiles) of the TRAIN variant a trainer of this flow would run, 0 if none: the trainer sizes its
+// operand workspace by it (round 5: a width without a variant of its own trains on the next wider one, its extra rows are zeros)
+int live_blob_train_rows(const gbnf_flow_desc* desc) {
+  DescInfo info;
+  if (validate_desc(desc, &info)) return 0;
+  VariantChoice vc;
+  if (live_choose(desc, info, &vc)) return 0;
+  return 16 * vc.ht;
+}
+
+int live_blob_create(const gbnf_flow_desc* desc, const int64_t* norm_grad_offsets, LiveBlob** out) {
+  *out = nullptr;
+  DescInfo info;
+  int rc = validate_desc(desc, &info);
+  if (rc) return rc;
+  const int d = desc->d, K = desc->n_steps;
+  const bool glow = desc->kind == GBNF_KIND_GLOW;
+  const bool additive = glow && desc->coupling == GBNF_COUPLING_ADDITIVE;
+  const int h = info.ref.hidden, depth = info.ref.depth;
+  VariantChoice vc;
+  rc = live_choose(desc, info, &vc);
+  if (rc) return rc;
   // ---- the value-independent words: pack a copy of the descriptor whose parameter arrays are host zeros
   static const std::vector<float> zeros((size_t)512 * 512 + 64, 0.0f);
   std::vector<gbnf_glow_step> gsteps;

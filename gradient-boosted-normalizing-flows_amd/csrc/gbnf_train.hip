@@ -43,6 +43,9 @@
 #include "../../include/gbnf.h"
 #include "gbnf_internal.h"
 
+// (declared here, not in gbnf_internal.h: every kernel object depends on that header)  gbnf_api.hip
+namespace gbnf { int live_blob_train_rows(const gbnf_flow_desc* desc); }
+
 namespace gbnf {
 
 using f32x4 = __attribute__((ext_vector_type(4))) float;
@@ -1540,24 +1543,41 @@ int gbnf_trainer_create(const gbnf_flow_desc* desc, gbnf_trainer** out) {
   t->residual = residual ? 1 : 0;
   t->n_hidden = nl - 1;
   t->hp = ceil16(h);
+  // (round 5) a width no TRAIN kernel variant is compiled for trains on the next wider one: the operand rows follow the VARIANT's
+  // hidden tiles (the extra units have zero weights: their activations, gradients and operand rows are zeros)
+  const bool chained_shape = nl >= 2 && nl <= 4 && (!residual || nl == 4) && tr_fast_path_enabled();
+  int hp_wide = 0;
+  if (chained_shape) {
+    const int rows = live_blob_train_rows(desc);
+    if (rows > t->hp && rows <= TR_MAX_HIDDEN) hp_wide = rows;
+  }
   t->ip = ceil16(d2);
   t->op = ceil16(glow && !additive ? 2 * d2 : d2);
   // operand rows per (step, net): net input | hidden activations | hidden gradients | output gradient | (round 3) the net's
   // output as the forward sweep saved it for the backward sweep
   t->net_rows = (int64_t)t->ip + 2LL * t->n_hidden * t->hp + 2LL * t->op;
-  t->hw = (h + 31) / 32 * 32; t->xw = (d2 + 31) / 32 * 32; t->ow = ((glow && !additive ? 2 * d2 : d2) + 31) / 32 * 32;
+  t->xw = (d2 + 31) / 32 * 32; t->ow = ((glow && !additive ? 2 * d2 : d2) + 31) / 32 * 32;
   if (t->hp > TR_MAX_HIDDEN) {
     delete t;
     return fail(GBNF_ERR_UNSUPPORTED, "gbnf_trainer_create: hidden width %d > %d", h, TR_MAX_HIDDEN);
   }
-  const size_t common = (size_t)d + (size_t)t->ip + 2 * (size_t)t->op + (residual ? t->hp : 0);   // f32 rows: state, GX, O, O2, (RT)
   const size_t tables = (size_t)K * (384 + 2 * TR_MAX_LAYERS * 8 + 8) * 4;
-  for (int nt = 1; nt <= TR_MAX_NT; ++nt) {
-    const size_t S = 16 * nt + 1;
-    const size_t split = 16 * nt * ((size_t)(4 * t->xw + 16) + (size_t)t->n_hidden * (4 * t->hw + 16) + (size_t)(4 * t->ow + 16));
-    t->lds_fwd[nt] = tables + common * S * 4 + 64 * TR_WAVES * nt + 16 + split;
-    t->lds_bwd[nt] = tables + (common + (size_t)K * d) * S * 4 + 64 * TR_WAVES * nt + 16 + split;
-  }
+  auto size_lds = [&](int hp) {        // the per-step kernels' LDS at a padded hidden width
+    t->hp = hp;
+    t->hw = (hp + 31) / 32 * 32;
+    const size_t common = (size_t)d + (size_t)t->ip + 2 * (size_t)t->op + (residual ? t->hp : 0);   // f32 rows: state, GX, O, O2, (RT)
+    for (int nt = 1; nt <= TR_MAX_NT; ++nt) {
+      const size_t S = 16 * nt + 1;
+      const size_t split = 16 * nt * ((size_t)(4 * t->xw + 16) + (size_t)t->n_hidden * (4 * t->hw + 16) + (size_t)(4 * t->ow + 16));
+      t->lds_fwd[nt] = tables + common * S * 4 + 64 * TR_WAVES * nt + 16 + split;
+      t->lds_bwd[nt] = tables + (common + (size_t)K * d) * S * 4 + 64 * TR_WAVES * nt + 16 + split;
+    }
+  };
+  // (the variant's wider rows only if the per-step kernels -- untraced forward calls, the fall-backs -- still fit with them)
+  const int hp_own = t->hp;
+  if (hp_wide) size_lds(hp_wide);
+  if (!hp_wide || t->lds_bwd[1] > (size_t)TR_LDS_BYTES) size_lds(hp_own);
+  t->net_rows = (int64_t)t->ip + 2LL * t->n_hidden * t->hp + 2LL * t->op;
   if (t->lds_bwd[1] > (size_t)TR_LDS_BYTES) {
     const size_t need = t->lds_bwd[1];
     delete t;
@@ -1717,7 +1737,7 @@ int gbnf_trainer_create(const gbnf_flow_desc* desc, gbnf_trainer** out) {
   }
   // the register-chained forward sweep where a TRAIN variant of the evaluation kernel covers the geometry (else the
   // kernels of this file do the forward too)
-  if (nl >= 2 && nl <= 4 && (!residual || nl == 4) && tr_fast_path_enabled()) {       // TanhNet / ReLUNet of depth 0, 1, 2; one-block ResidualNets
+  if (chained_shape) {       // TanhNet / ReLUNet of depth 0, 1, 2; one-block ResidualNets
     LiveBlob* lb = nullptr;
     std::vector<int64_t> goff(2 * (size_t)K);
     for (int k = 0; k < K; ++k) { goff[2 * k] = steps[k].g_na; goff[2 * k + 1] = steps[k].g_nb; }

@@ -637,17 +637,41 @@ def test_depth_0_and_2_train_on_the_register_chained_kernels(kind, d, h, K, n, k
     _check_grads(grads2, grads64, f"{kind} d={d} h={h} NT=2")
 
 
-def test_a_flow_wider_than_no_compiled_variant_keeps_the_round1_path():
-    """h = 40 with ReLU nets has no kernel variant of its own width (the nearest compiled one has 64 hidden rows): the
-    register-chained sweeps would save rows the operand workspace does not have, so such a trainer has no live blob and
-    trains on the round-1 kernels (its gradients: g10_glow_grads_additive_relu_d8 above)."""
+@pytest.mark.parametrize("kind,d,h,K,n,kw", [("glow", 8, 40, 3, 77, {"act": "relu"}), ("glow", 63, 315, 2, 100, {}), ("glow", 21, 50, 2, 33, {"depth": 2}),
+                                             ("realnvp", 13, 33, 3, 65, {"coupling_network": "relu"}), ("realnvp", 21, 150, 2, 40, {"coupling_network": "residual", "seed": 103})])
+def test_a_width_without_a_variant_of_its_own_trains_on_the_next_wider_one(kind, d, h, K, n, kw):
+    """h = 40 with ReLU nets has no kernel variant of its own width (the nearest compiled one has 64 hidden rows); BSDS300 at the
+    reference's h = 5 D = 315 has 320 rows against 384.  Rounds 3-4 kept such flows on the round-1 kernels (the register-chained sweeps
+    save a row per hidden unit of their COMPILED width).  Round 5: the trainer sizes its operand workspace by the variant (the extra
+    units have zero weights: zero activations, zero gradients, zero operand rows) -- gradients against the float64 oracle, the chained
+    kernels asserted."""
     import torch
     from gbnf_amd import native, synth
+    from oracle import gbnf_oracle as oracle
     dev = torch.device("cuda:0")
-    spec = synth.synth_boosted_specs("glow", 1, 8, 40, 3, seed=21, act="relu")[0]
+    kw = dict(kw)
+    seed = kw.pop("seed", 21)
+    spec = (synth.synth_glow_spec(d, h, K, seed=seed, **kw) if kind == "glow" else synth.synth_realnvp_spec(d, h, K, seed=seed, **kw))
     tr = native.NativeTrainer(_dev_spec(spec, dev))
-    with pytest.raises(native.GbnfError):
-        _blob_words("gbnf_debug_trainer_blob", tr.handle)
+    assert _has_live_blob(tr)
+    xs = synth.synth_batch(n, d, seed=22)
+    rng = np.random.RandomState(23)
+    g_z = rng.standard_normal(xs.shape).astype(np.float32)
+    g_l = rng.standard_normal(n).astype(np.float32)
+    x = torch.from_numpy(xs).to(dev)
+    z64, ldj64 = oracle.component_forward(spec, xs, backend="numpy64")
+    gx64, grads64 = oracle.component_grads(spec, xs, g_z, g_l)
+    z, ldj, trace = tr.forward(x, want_trace=True)
+    gx, grads = tr.backward(x, torch.from_numpy(g_z).to(dev), torch.from_numpy(g_l).to(dev), want_gx=True, trace=trace)
+    assert _last_path(tr) == (1, 1)
+    assert np.abs(z.cpu().numpy() - z64).max() <= 2e-5 * max(1.0, float(np.abs(z64).max()))
+    _check_grads(grads, grads64, f"{kind} d={d} h={h} {kw}")
+    assert np.abs(gx.cpu().numpy() - gx64).max() <= G_RTOL * max(float(np.abs(gx64).max()), 1e-3)
+    # the per-step kernels (an untraced forward, a backward without a trace) work on the widened rows too
+    z0, ldj0 = tr.forward(x)
+    assert np.abs(z0.cpu().numpy() - z64).max() <= 2e-5 * max(1.0, float(np.abs(z64).max()))
+    gx0, grads0 = tr.backward(x, torch.from_numpy(g_z).to(dev), torch.from_numpy(g_l).to(dev), want_gx=True)
+    _check_grads(grads0, grads64, f"{kind} d={d} h={h} {kw} (per-step kernels)")
 
 
 def test_long_flows_fall_back_for_the_backward_sweep_only():

@@ -24,6 +24,10 @@ run train_n4096 python tools/bench_train.py --batch 4096 --cpu-steps 0
 run train_n65536 python tools/bench_train.py --batch 65536 --cpu-steps 2
 run train_hepmass_bs_n65536 python tools/bench_train.py --config hepmass_realnvp --batch 65536 --batch-stats --cpu-steps 0 --no-torch-legs
 run train_hepmass_n65536 python tools/bench_train.py --config hepmass_realnvp --batch 65536 --cpu-steps 0 --no-torch-legs
+run train_glow_depth0_n65536 python tools/bench_train.py --config miniboone_glow_depth0 --batch 65536 --cpu-steps 0 --no-torch-legs
+run train_glow_depth2_n65536 python tools/bench_train.py --config miniboone_glow_depth2 --batch 65536 --cpu-steps 0 --no-torch-legs
+run train_hepmass_depth2_n65536 python tools/bench_train.py --config hepmass_realnvp_depth2 --batch 65536 --cpu-steps 0 --no-torch-legs
+run train_hepmass_residual_n65536 python tools/bench_train.py --config hepmass_realnvp_residual --batch 65536 --cpu-steps 0 --no-torch-legs
 run module_eval python tools/bench_module_eval.py
 prof() { name=$1; shift; timeout 420 rocprofv3 --kernel-trace "$@" > $O/$name.log 2>&1; echo "rc $? $name" >> $O/rc.txt; }
 HEAD="python3 bench.py --cpu-seconds 0 --steps 128 --warmup 32 --prewarm 0.01 --no-extra-legs"
