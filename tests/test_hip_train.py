@@ -596,7 +596,9 @@ def test_device_packer_reproduces_the_host_packer(kind, d, h, kw):
                                              #  stress_train.py brackets such cases with a shifted ReLU, the fixed cases here avoid them)
                                              ("realnvp", 21, 64, 3, 100, {"coupling_network": "residual", "batch_norm": False, "seed": 101}),
                                              ("realnvp", 43, 215, 2, 2049, {"coupling_network": "residual", "seed": 101}),
-                                             ("realnvp", 8, 250, 2, 1, {"coupling_network": "residual"})])
+                                             ("realnvp", 8, 250, 2, 1, {"coupling_network": "residual"}),
+                                             ("realnvp", 21, 300, 2, 65, {"coupling_network": "residual", "seed": 102}),      # 24 / 32 hidden tiles
+                                             ("realnvp", 21, 512, 2, 33, {"coupling_network": "residual", "seed": 102})])
 def test_depth_0_and_2_train_on_the_register_chained_kernels(kind, d, h, K, n, kw):
     """TanhNet / ReLUNet of coupling_network_depth 0 and 2 (models/layers.py:208-243, density_experiment.py:118) ran
     the round-1 per-step kernels (23 M samples/s against 51-63 M at depth 1).  Round 5: flow_kernel_hx3<..., DEPTH, TRAIN> saves the
