@@ -540,15 +540,23 @@ class BoostedFlow(nn.Module):
             params, buffers, layers = self._component_tensors(c)
             perms = self.__dict__.setdefault("_perm_cache", {})
             if c not in perms:
-                perms[c] = [(layer.permutation, layer.actnorm) for layer in layers]
+                # (permutation, actnorm, its index tensor): `perm.indices` is a buffer -- an nn.Module.__getattr__ walk per access, 5
+                # per component and call -- so the tensor object is kept.  Re-assigning `perm.indices` bumps the serial, the key changes,
+                # and native_flow drops this cache before it re-packs (`_forget_component`).
+                perms[c] = [(layer.permutation, layer.actnorm, layer.permutation.indices) for layer in layers]
             kc = (params + buffers, params, perms[c])
             self.__dict__["_key_cache"][c] = kc
         tensors, params, perms = kc
         # (C-level loops: 40 tensors cost ~8 us here against ~14 us as list comprehensions -- this runs on every module call)
         key = (tuple(map(_VERSION, tensors)), tuple(map(_DATA_PTR, params)))
         if perms:                         # a permutation is identified by its tensor and that tensor's version counter
-            key += tuple((perm.indices_serial, perm.indices._version, bool(actnorm.inited)) for perm, actnorm in perms)
+            key += tuple([(p.indices_serial, t._version, bool(a.inited)) for p, a, t in perms])
         return key
+
+    def _forget_component(self, c):
+        """Drop the per-component tensor look-ups of the key (a key mismatch may mean a tensor OBJECT was replaced)."""
+        for name in ("_key_cache", "_perm_cache", "_tensor_cache"):
+            self.__dict__.get(name, {}).pop(c, None)
 
     def _check_ready(self, x):
         if not isinstance(x, torch.Tensor) or not x.is_cuda:
@@ -585,7 +593,7 @@ class BoostedFlow(nn.Module):
         if self.component_type != "glow":
             return
         cached = self.__dict__.get("_perm_cache", {}).get(c)          # (built by _component_key: no module-tree walk per call)
-        if cached is not None and all(a.inited for _, a in cached):
+        if cached is not None and all(a.inited for _, a, _t in cached):
             return
         layers = self.flows[c].flow.layers
         if all(bool(l.actnorm.inited) for l in layers):
@@ -610,6 +618,8 @@ class BoostedFlow(nn.Module):
         key = self._component_key(c)
         cached = self._handles.get(c)
         if cached is None or cached[0] != key:
+            self._forget_component(c)
+            key = self._component_key(c)
             math = self.__dict__.setdefault("_math_override", {}).get(c, "default")
             handle = native.NativeFlow(gspec.spec_from_component(self.flows[c]), math=math,
                                        per_step_activation=self._per_step_activation())
@@ -779,14 +789,22 @@ class BoostedFlow(nn.Module):
         tab = self.__dict__.get("_component_table")
         # entry c depends on x and on component c's parameters only: one component key per call, as the plain path costs
         if tab is None or tab.xkey != xkey or tab.keys[c] != self._component_key(c):
-            if self.component_type == "glow" and not all(
-                    bool(l.actnorm.inited) for k in range(n_used) for l in self.flows[k].flow.layers):
-                return None           # the reference raises at the call of THAT component: leave it to the plain path
-            mix = self.native_mixture(n_used)              # re-packs whatever changed
+            # A new batch.  ONE pass over the components' keys (round 5: this call was 115 us of host time -- the condition above,
+            # native_mixture's walk over the handles and the ActNorm check each went through the keys / the layers again): if they
+            # are the keys the previous table was built on, its mixture and its `inited` check still stand (`inited` is in the key)
+            keys = [self._component_key(k) for k in range(n_used)]
+            if tab is not None and tab.n_used == n_used and tab.keys == keys and self._mixture is not None \
+                    and self._mixture.get(n_used, (None, None))[1] is tab.mix:
+                mix = tab.mix
+            else:
+                if self.component_type == "glow" and not all(
+                        bool(l.actnorm.inited) for k in range(n_used) for l in self.flows[k].flow.layers):
+                    return None           # the reference raises at the call of THAT component: leave it to the plain path
+                mix = self.native_mixture(n_used)              # re-packs whatever changed
+                keys = [self._handles[k][0] for k in range(n_used)]     # (the keys native_mixture has just validated the handles against)
             z, ldj, _ = mix.component_forward(x, 0, n_used)
-            # (x_in is held: its storage cannot be freed and handed to another tensor with the same address and version;
-            #  the keys are the ones native_mixture has just validated the handles against)
-            tab = _ComponentTable(xkey, x_in, z, ldj, [self._handles[k][0] for k in range(n_used)], mix)
+            # (x_in is held: its storage cannot be freed and handed to another tensor with the same address and version)
+            tab = _ComponentTable(xkey, x_in, z, ldj, keys, mix)
             zs, ls = z.unbind(0), ldj.unbind(0)
             n = x.shape[0]
             tab.outs = [(zs[k], *self._prior_views(k, n), ls[k], None) for k in range(n_used)]

@@ -29,6 +29,8 @@ struct LiveBlob;
 // norm_grad_offsets: [K][2] float offsets of every step's two normalisation-parameter gradients in the caller's flat gradient
 // buffer (null: no backward sweep wanted)
 int live_blob_create(const gbnf_flow_desc* desc, const int64_t* norm_grad_offsets, LiveBlob** out);
+// Hidden rows (16 x hidden tiles) of the TRAIN variant a trainer of this flow would run, 0 if none
+int live_blob_train_rows(const gbnf_flow_desc* desc);
 bool live_blob_has_backward(const LiveBlob* lb);
 int live_blob_hidden_rows(const LiveBlob* lb);      // 16 x the hidden tiles of the kernel variant behind it
 // The backward kernel leaves the ActNorm / BatchNorm parameter gradients as per-workgroup partial sums; adding them up (in a

@@ -43,8 +43,6 @@
 #include "../../include/gbnf.h"
 #include "gbnf_internal.h"
 
-// (declared here, not in gbnf_internal.h: every kernel object depends on that header)  gbnf_api.hip
-namespace gbnf { int live_blob_train_rows(const gbnf_flow_desc* desc); }
 
 namespace gbnf {
 

@@ -5,7 +5,8 @@
 // activations and outputs (operand workspace).  Nothing is recomputed: per step, last to first,
 //
 //   coupling backward   g_z2 -> g_y2, g_shift, g_raw / g_scale   (element-wise, from the saved net outputs and the trace)
-//   dgrad chain         g_o -> W3^T -> (.) act'(h2) -> W2^T -> (.) act'(h1) -> W1^T -> g_y1      (split-f16 MFMA)
+//   dgrad chain         g_o -> W3^T -> (.) act'(h2) -> W2^T -> (.) act'(h1) -> W1^T -> g_y1      (split-f16 MFMA; written for depth 1:
+//                       depth 0 has no W2^T link, depth 2 one more, a one-block ResidualNet is depth 2 with its skip -- template DEPTH)
 //   normalisation bwd   g_y -> g_x, ActNorm / BatchNorm parameter gradients (16-sample sums + atomics)
 //
 // and the gradient-side operands of every weight gradient (g_o, g_a2, g_a1) go to the operand workspace for wgrad_kernel.

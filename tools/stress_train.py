@@ -27,8 +27,10 @@ def gen_case(rng, k):
                      permutation=str(rng.choice(["shuffle", "reverse"])), depth=depth)
         spec = synth.synth_glow_spec(d, h, K, seed=5000 + k, **extra)
     else:
-        extra = dict(coupling_network=str(rng.choice(["tanh", "relu", "mixed", "random"])), batch_norm=bool(rng.randint(2)),
+        extra = dict(coupling_network=str(rng.choice(["tanh", "relu", "mixed", "random", "residual"])), batch_norm=bool(rng.randint(2)),
                      flip_init=int(rng.randint(2)), depth=depth)
+        if extra["coupling_network"] == "residual":
+            extra["depth"] = 1 if depth < 2 else 2          # blocks: mostly one (the register-chained kernels), sometimes two (per-step kernels)
         spec = synth.synth_realnvp_spec(d, h, K, seed=5000 + k, **extra)
     return kind, d, h, K, n, extra, spec
 
