@@ -872,10 +872,10 @@ int gbnf_flow_create_ex(const gbnf_flow_desc* desc, int32_t math_mode, int32_t f
     return fail(GBNF_ERR_INVALID, "unknown math mode %d", math_mode);
   // what the split kernels take: TanhNet / ReLUNet of depth 0, 1 or 2, and ResidualNets of ONE block (the reference's default
   // coupling_network_depth = 1: two hidden -> hidden layers; round 3 -- kernel key act = GBNF_ACT_RESIDUAL_RELU, depth 2)
-  const bool split_shape = depth <= 2 && (!ref.residual || depth == 2);
+  const bool split_shape = ref.residual ? (depth == 2 || depth == 4) : depth <= 2;      // (round 5: two-block ResidualNets too)
   const int act_a_split = ref.residual ? GBNF_ACT_RESIDUAL_RELU : act_a, act_b_split = ref.residual ? GBNF_ACT_RESIDUAL_RELU : act_b;
   if (!split_shape && (math_mode == GBNF_MATH_F16X3 || math_mode == GBNF_MATH_BF16X6))
-    return fail(GBNF_ERR_UNSUPPORTED, "the split kernels (f16x3 / bf16x6) support TanhNet / ReLUNet of coupling_network_depth <= 2 and one-block ResidualNets only (got %s%d)",
+    return fail(GBNF_ERR_UNSUPPORTED, "the split kernels (f16x3 / bf16x6) support TanhNet / ReLUNet of coupling_network_depth <= 2 and ResidualNets of one or two blocks only (got %s%d)",
                 ref.residual ? "a ResidualNet, hidden layers " : "", depth);
 
   // ---- pick compiled variants (exact geometry first, then the cheapest zero-padded superset)

@@ -59,7 +59,7 @@ constexpr int hx3_pieces(int prec) { return prec == 0 ? 2 : 3; }
 //     DRAIN  : output-layer chunk HC-1
 //   DEPTH == 0 (the output layer reads layer 0's activations): OUT stages of CG = TL0 / OT chunks, OT tiles each
 struct Hx3Layout {
-  static constexpr int MAXS = 80;
+  static constexpr int MAXS = 144;
   int NP, HC, TL0, N_L0, NS, BIAS_FRAGS, BIAS_WORDS, NET_WORDS, STAGE_FRAGS, DEPTH, CG, N_OUT;
   int off[MAXS];   // word offset of stage s from the start of the net block
   int nf[MAXS];    // fragments in stage s
@@ -108,8 +108,10 @@ constexpr int hx3_reg_estimate(int HT, int OT, int NT, int prec, int kind, int a
   const int relu = (act_a != GBNF_ACT_TANH || act_b != GBNF_ACT_TANH) ? 28 : 0;   // measured: ReLU / per-step variants keep more values live
   const int accs = np == 3 ? 3 : 1;                    // running sums per output tile (Products<NP>::NACC)
   // (a second hidden layer keeps the first one's activations AND its own, both as B operands)
-  const int res = act_a == 2 ? HT * NT * 4 : 0;       // a ResidualNet keeps layer 0's raw output tiles
-  return (depth == 2 ? 2 : 1) * hc * NT * np * 4 + (nn + accs - 1) * OT * NT * 4 + NT * 4 * (1 + accs) + 2 * NT * np * 4 + 3 * np * 4 + 36 + relu + res;
+  // a ResidualNet keeps layer 0's raw output tiles; two blocks (three fully unrolled middle layers): measured 135 registers over the
+  // 256 of two waves per SIMD at 7 hidden tiles -- one wave per SIMD from the smallest geometry on
+  const int res = act_a == 2 ? HT * NT * 4 + (depth == 4 ? 100 : 0) : 0;
+  return (depth >= 2 ? 2 : 1) * hc * NT * np * 4 + (nn + accs - 1) * OT * NT * 4 + NT * 4 * (1 + accs) + 2 * NT * np * 4 + 3 * np * 4 + 36 + relu + res;
 }
 // TRAIN kernels (trace + operand saves, ~40 more registers per sample tile): 32-sample waves run one per SIMD with the
 // 512-register budget, in 4-wave workgroups (a lone 32-sample wave does a pass in the time two co-resident 16-sample waves
@@ -320,12 +322,16 @@ __device__ __forceinline__ void wait_vmcnt(int n) {
 template <int KIND, int HT, int OT, int NT, int ACTA, int ACTB, int PREC, int WV, int DEPTH, int TRAIN = 0>
 __global__ void __launch_bounds__(64 * WV, hx3_waves_per_simd(HT, OT, NT, PREC, KIND, ACTA, ACTB, DEPTH, TRAIN))
 flow_kernel_hx3(const FlowLaunch p) {
-  static_assert(DEPTH >= 0 && DEPTH <= 2, "coupling_network_depth 0, 1 or 2");
+  static_assert((DEPTH >= 0 && DEPTH <= 2) || (DEPTH == 4 && ACTA == 2), "coupling_network_depth 0, 1 or 2; ResidualNets of one or two blocks");
   // ACT == 2 (GBNF_ACT_RESIDUAL_RELU): a ResidualNet of ONE block (models/layers.py:246-301) = layer 0 (no activation of its
   // own) -> [relu -> Linear -> relu -> Linear] + layer 0's output -> final layer: the two-hidden-layer pipeline with the
   // raw layer-0 tiles kept in registers, added to the second hidden layer's output and split WITHOUT an activation
   static_assert((ACTA == 2) == (ACTB == 2), "both nets of a step are ResidualNets or neither is");
-  static_assert(ACTA != 2 || DEPTH == 2, "a one-block ResidualNet has two hidden layers");
+  static_assert(ACTA != 2 || DEPTH == 2 || DEPTH == 4, "a ResidualNet has two hidden -> hidden layers per block");
+  // Two blocks (round 5, evaluation only): DEPTH = 4.  The hidden -> hidden layers 1 .. DEPTH - 1 run as "middle" layers that ping-pong
+  // between the two register sets of B operands; behind layer 2 (the first block's second Linear) the skip sum t = a2 + t0 replaces
+  // the raw layer-0 tiles AND is what the second block starts from (relu(t)); the last layer's output + t goes to the final layer.
+  static_assert(!TRAIN || DEPTH <= 2, "the training forward covers depth 0, 1, 2 and one-block ResidualNets");
   static_assert(!TRAIN || PREC == 0, "the training forward runs on f16x3");
   constexpr int WAVES = WV;
   constexpr int NP = hx3_pieces(PREC);
@@ -940,7 +946,7 @@ flow_kernel_hx3(const FlowLaunch p) {
 
       // layer-0 output = B operands of the first hidden layer (DEPTH == 0: of the output layer); with two hidden layers
       // the first one's output goes to the second set
-      constexpr int NHB = DEPTH == 2 ? 2 : 1;
+      constexpr int NHB = DEPTH >= 2 ? 2 : 1;
       u32x4 hBs[NHB][HC][NT][NP];
       auto& hB = hBs[0];
 #pragma unroll
@@ -1075,58 +1081,85 @@ flow_kernel_hx3(const FlowLaunch p) {
       } else {
         f32x4 pre[NT];
         f32x4 bias;
-        if constexpr (DEPTH == 2) {
-          // ---- first of two hidden layers: like the passes below, but tile u-1 (activated during pass u) becomes a B
-          //      operand of the second hidden layer instead of being consumed by the output layer.  Fully unrolled: the
+        if constexpr (DEPTH >= 2) {
+          // ---- the hidden layers in front of the last one (one for DEPTH = 2, three for a two-block ResidualNet): like the passes
+          //      below, but tile u-1 (activated during pass u) becomes a B operand of the NEXT hidden layer instead of being
+          //      consumed by the output layer -- layer j reads set (j - 1) & 1 and writes set j & 1.  Fully unrolled: the
           //      destination register of an activation must be a compile-time index.
-          bias = ldb(HT);
-          auto mid_act = [&](auto t_c, int n) {           // register pairs n, n + HC, ... of tile t (held in pre)
-            constexpr int t = decltype(t_c)::value;
+          auto mid_layer = [&](auto j_c) {
+            constexpr int J = decltype(j_c)::value;
+            auto& hIn = hBs[(J - 1) & 1];
+            auto& hOut = hBs[J & 1];
+            if constexpr (J >= 3) {                 // (a set that is written a second time: the phantom half of an odd tile count stays zero)
 #pragma unroll
-            for (int q = n; q < 2 * NT; q += HC) {
-              const int nt = q >> 1, hp = q & 1;
-              unsigned pc[NP];
-              act_split(pre[nt], hp, nt, pc, 1, t);
+              for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
-              for (int k = 0; k < NP; ++k) hBs[NHB - 1][t >> 1][nt][k][2 * (t & 1) + hp] = pc[k];
+                for (int k = 0; k < NP; ++k) hOut[HC - 1][nt][k] = u32x4{0, 0, 0, 0};
             }
-          };
-          auto mid_pass = [&](auto u_c) {
-            constexpr int u = decltype(u_c)::value;
-            issue(std::integral_constant<int, NP * HC>{}, gs + 1);     // the next pass of this layer or pass 0 of the next one
-            Unit A[3];
-            A[0] = N0;
-            A[1] = N1;
-            const f32x4 bias_next = ldb(HT + (u + 1 < HT ? u + 1 : u));
-            Acc acc[NT];
+            bias = ldb(J * HT);
+            auto mid_act = [&](auto t_c, int n) {           // register pairs n, n + HC, ... of tile t (held in pre)
+              constexpr int t = decltype(t_c)::value;
 #pragma unroll
-            for (int nt = 0; nt < NT; ++nt) acc[nt].init(bias);
-            __builtin_amdgcn_sched_barrier(0);
+              for (int q = n; q < 2 * NT; q += HC) {
+                const int nt = q >> 1, hp = q & 1;
+                unsigned pc[NP];
+                if constexpr (RES && (J & 1) == 0) {
+                  // the second Linear of a block that is not the last: t = its output + the skip source; t replaces the source
+                  f32x4 tv = pre[nt];
+                  tv[2 * hp] += t0r[t][nt][2 * hp];
+                  tv[2 * hp + 1] += t0r[t][nt][2 * hp + 1];
+                  t0r[t][nt][2 * hp] = tv[2 * hp];
+                  t0r[t][nt][2 * hp + 1] = tv[2 * hp + 1];
+                  act_split(tv, hp, nt, pc, J, t);
+                } else {
+                  act_split(pre[nt], hp, nt, pc, J, t);
+                }
 #pragma unroll
-            for (int n = 0; n < HC; ++n) {
-              if (n + 2 < HC) load_unit(A[(n + 2) % 3], n + 2);
-              if (n == HC - 1) stage_finish(2, true);
-              if constexpr (u > 0) mid_act(std::integral_constant<int, (u > 0 ? u - 1 : 0)>{}, n);
-              mac(A[n % 3], hB[n], acc);
+                for (int k = 0; k < NP; ++k) hOut[t >> 1][nt][k][2 * (t & 1) + hp] = pc[k];
+              }
+            };
+            auto mid_pass = [&](auto u_c) {
+              constexpr int u = decltype(u_c)::value;
+              issue(std::integral_constant<int, NP * HC>{}, gs + 1);     // the next pass of this layer or pass 0 of the next one
+              Unit A[3];
+              A[0] = N0;
+              A[1] = N1;
+              const f32x4 bias_next = ldb(J * HT + (u + 1 < HT ? u + 1 : u));
+              Acc acc[NT];
+#pragma unroll
+              for (int nt = 0; nt < NT; ++nt) acc[nt].init(bias);
               __builtin_amdgcn_sched_barrier(0);
-            }
 #pragma unroll
-            for (int nt = 0; nt < NT; ++nt) pre[nt] = acc[nt].total();
-            bias = bias_next;
-            stage_finish(2, false);
-          };
-          auto mid_all = [&](auto self, auto u_c) -> void {
-            constexpr int u = decltype(u_c)::value;
-            if constexpr (u < HT) {
-              mid_pass(u_c);
-              self(self, std::integral_constant<int, u + 1>{});
-            }
-          };
-          mid_all(mid_all, std::integral_constant<int, 0>{});
+              for (int n = 0; n < HC; ++n) {
+                if (n + 2 < HC) load_unit(A[(n + 2) % 3], n + 2);
+                if (n == HC - 1) stage_finish(2, true);
+                if constexpr (u > 0) mid_act(std::integral_constant<int, (u > 0 ? u - 1 : 0)>{}, n);
+                mac(A[n % 3], hIn[n], acc);
+                __builtin_amdgcn_sched_barrier(0);
+              }
 #pragma unroll
-          for (int n = 0; n < HC; ++n) mid_act(std::integral_constant<int, HT - 1>{}, n);
+              for (int nt = 0; nt < NT; ++nt) pre[nt] = acc[nt].total();
+              bias = bias_next;
+              stage_finish(2, false);
+            };
+            auto mid_all = [&](auto self, auto u_c) -> void {
+              constexpr int u = decltype(u_c)::value;
+              if constexpr (u < HT) {
+                mid_pass(u_c);
+                self(self, std::integral_constant<int, u + 1>{});
+              }
+            };
+            mid_all(mid_all, std::integral_constant<int, 0>{});
+#pragma unroll
+            for (int n = 0; n < HC; ++n) mid_act(std::integral_constant<int, HT - 1>{}, n);
+          };
+          mid_layer(std::integral_constant<int, 1>{});
+          if constexpr (DEPTH == 4) {
+            mid_layer(std::integral_constant<int, 2>{});
+            mid_layer(std::integral_constant<int, 3>{});
+          }
         }
-        auto& hBin = hBs[NHB - 1];                 // the B operands of the last hidden layer
+        auto& hBin = hBs[(DEPTH - 1) & 1];         // the B operands of the last hidden layer (set 0: layer 0's output, DEPTH = 1)
         u32x4 hO[NT][NP];
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt)

@@ -47,14 +47,14 @@ enum { GBNF_KIND_GLOW = 0, GBNF_KIND_REALNVP = 1 };
  * layers in the order initial_layer, (blocks[b].linear_layers[0], blocks[b].linear_layers[1]) for b < B, final_layer:
  *     t = initial(x);  t += lin1_b(relu(lin0_b(relu(t)))) for every block;  out = final(t)
  * One block (the reference's default depth): the split kernels, every hidden width, both directions and training; two blocks: the
- * exact-f32 kernel and the per-step training kernels (B <= 2). */
+ * split kernels to hidden width 256 (round 5), the exact-f32 kernel beyond, the per-step training kernels (B <= 2). */
 enum { GBNF_ACT_TANH = 0, GBNF_ACT_RELU = 1, GBNF_ACT_RESIDUAL_RELU = 2 };
 enum { GBNF_COUPLING_AFFINE = 0, GBNF_COUPLING_ADDITIVE = 1 };
 /* How the coupling-network matrix products are evaluated:
  *   F32     exact f32 MFMA (v_mfma_f32_16x16x4_f32), bitwise an ordered fmaf chain (depth 0 / 1 / 2, ResidualNets of <= 2 blocks; hidden <= 512);
  *   F16X3   each f32 operand split into two fp16 pieces (22 significand bits); a.b = a_mid.b_hi + a_hi.b_mid +
  *           a_hi.b_hi on the f16 matrix pipe with f32 accumulation (TanhNet / ReLUNet, coupling_network_depth 0 / 1 / 2, hidden <= 512;
- *           ResidualNets of ONE block -- the reference's default depth -- at every width too, since round 5): the fast
+ *           ResidualNets of one block -- the reference's default depth -- at every width and of two blocks to 256, round 5): the fast
  *           path, ~1e-7 relative in the log-likelihood on well-conditioned models.  An operand beyond the fp16 range
  *           (|v| > 65504) cannot be represented: the kernel marks such samples and a bf16x6 repair pass behind every
  *           f16x3 launch re-evaluates them (same stream, no host synchronisation), so results are range-safe;
@@ -62,7 +62,7 @@ enum { GBNF_COUPLING_AFFINE = 0, GBNF_COUPLING_ADDITIVE = 1 };
  *           ~2x the matrix work of F16X3 (same shapes as F16X3);
  *   DEFAULT per component: both split packings are built and a probe batch (128 rows ~ N(0,1) / N(0,4)) is evaluated
  *           on both at creation; F16X3 if they agree to 2.5e-6 relative in the log-likelihood, else BF16X6 (ill-conditioned
- *           models: e.g. un-normalised ReLU RealNVPs); F32 where no split kernel applies (ResidualNets of two blocks).
+ *           models: e.g. un-normalised ReLU RealNVPs); F32 where no split kernel applies (two-block ResidualNets wider than 256).
  *           Env GBNF_MATH=f32|f16x3|bf16x6 overrides DEFAULT in gbnf_flow_create. */
 enum { GBNF_MATH_DEFAULT = -1, GBNF_MATH_F32 = 0, GBNF_MATH_F16X3 = 1, GBNF_MATH_BF16X6 = 2 };
 
@@ -184,8 +184,8 @@ int gbnf_tuning_get(const char* key, int32_t* value);
  *                                                         tabular datasets have d = 6, 8, 21, 43, 63)
  *   coupling-net input      <= 32 features               (d / 2, or d - d / 2 for a flipped RealNVP step: one k = 32 MFMA chunk)
  *   hidden width            1 <= h <= 512                (TanhNet / ReLUNet at coupling_network_depth 0, 1, 2; the split kernels cover
- *                                                         every depth and one-block ResidualNets to 512; two-block ResidualNets
- *                                                         run on the exact-f32 kernel)
+ *                                                         every depth and one-block ResidualNets to 512, two-block ResidualNets
+ *                                                         to 256 -- wider ones run on the exact-f32 kernel)
  *   coupling_network_depth  0, 1, 2; ResidualNet blocks 1, 2 (RealNVP only, as in the reference)
  *   flow steps              any K (per-step tables are staged in LDS up to K = 12, read from the blob beyond)
  *   activations             tanh / relu, also drawn per step or per net (`--coupling_network random`) */

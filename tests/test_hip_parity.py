@@ -184,15 +184,16 @@ def test_activation_drawn_per_step(kind, d, h, K, math, dev):
 @pytest.mark.parametrize("blocks", [1, 2])
 def test_residual_coupling_networks(blocks, dev):
     """`--coupling_network residual` (RealNVP: models/realnvp.py:57, ResidualNet models/layers.py:246-301): forward at
-    16- and 32-sample wave tiles, the inverse direction, and the loud refusals (f16x3 math, training)."""
+    16- and 32-sample wave tiles, the inverse direction, every math mode -- one and two blocks."""
     import torch
     from gbnf_amd import native, synth
     from oracle import gbnf_oracle as oracle
     d, h, K = 21, 105, 4
     specs = synth.synth_boosted_specs("realnvp", 3, d, h, K, seed=33, coupling_network="residual", depth=blocks)
     mix, flows = _mixture(specs)
-    # one block (the reference's default depth) runs on the split kernels since round 3; two blocks on the exact-f32 kernel
-    assert (flows[0].info().math_mode == native.MATH["f32"]) == (blocks == 2)
+    # one block (the reference's default depth) runs on the split kernels since round 3, two blocks since round 5 (DEPTH = 4: three
+    # middle layers ping-pong between the two operand sets, the skip source is replaced behind the first block)
+    assert flows[0].info().math_mode != native.MATH["f32"]
     rho = oracle.rho_init(3)
     for n in (50, 5000):
         xs = synth.synth_batch(n, d, seed=n)
@@ -205,10 +206,7 @@ def test_residual_coupling_networks(blocks, dev):
     xr, ldj_inv = flows[2].inverse(z)
     assert np.abs(xr.cpu().numpy() - x).max() < 5e-4
     assert np.abs((ldj + ldj_inv).cpu().numpy()).max() < 1e-3
-    if blocks == 2:
-        with pytest.raises(native.GbnfError):
-            native.NativeFlow(specs[0], math="f16x3")
-    else:                                       # every math mode against the oracle, 16- and 32-sample waves
+    if True:                                    # every math mode against the oracle, 16- and 32-sample waves
         xs = synth.synth_batch(700, d, seed=5)
         z64, ldj64 = oracle.component_forward(specs[1], xs, backend="numpy64")
         for math in ("f32", "f16x3", "bf16x6"):
@@ -398,10 +396,15 @@ def test_default_math_mode_and_mode_agreement(dev):
         assert native.NativeFlow(deep).info().math_mode == native.MATH["f16x3"]
     res = synth.synth_realnvp_spec(21, 64, 3, coupling_network="residual", seed=3)          # one block: split kernels (round 3)
     assert native.NativeFlow(res).info().math_mode != native.MATH["f32"]
-    res2 = synth.synth_realnvp_spec(21, 64, 3, coupling_network="residual", depth=2, seed=3)  # two blocks: exact-f32 kernel only
-    assert native.NativeFlow(res2).info().math_mode == native.MATH["f32"]
+    res2 = synth.synth_realnvp_spec(21, 64, 3, coupling_network="residual", depth=2, seed=3)  # two blocks: split kernels since round 5 (h <= 256)
+    assert native.NativeFlow(res2).info().math_mode != native.MATH["f32"]
+    res2w = synth.synth_realnvp_spec(21, 300, 2, coupling_network="residual", depth=2, seed=3)   # ... wider: the exact-f32 kernel
+    assert native.NativeFlow(res2w).info().math_mode == native.MATH["f32"]
     with pytest.raises(native.GbnfError):
-        native.NativeFlow(res2, math="f16x3")
+        native.NativeFlow(res2w, math="f16x3")
+    res3 = synth.synth_realnvp_spec(21, 64, 2, coupling_network="residual", depth=3, seed=3)   # three blocks: nowhere
+    with pytest.raises(native.GbnfError):
+        native.NativeFlow(res3)
     x = torch.from_numpy(synth.synth_batch(4096, 43, seed=9)).to(dev)
     a = native.NativeFlow(spec, math="f32").forward(x, want_ll=True)
     b = native.NativeFlow(spec, math="f16x3").forward(x, want_ll=True)
