@@ -1257,8 +1257,9 @@ int gbnf_image_flow_create_mode(const gbnf_image_flow_desc* d, int32_t math_mode
         if (rc == GBNF_OK) {
           std::vector<double> sc;
           PackedConv pc = pack_conv(P, st.convs[q], &sc);
-          // split-f16 path (coupling_network_depth == 1, first 3x3 with <= 16 input channels): extra fragment sets
-          if (use_hx3 && st.n_convs == 3 && c1 <= 16) {
+          // split-f16 path (coupling_network_depth == 1, first 3x3 with <= 24 input channels -- the 48-channel third level of a
+          // 3 x 32 x 32 input, round 5 -- its folded contraction 9 cin <= 224 = 7 chunks): extra fragment sets
+          if (use_hx3 && st.n_convs == 3 && c1 <= 24) {
             const int chp = hdim > 256 ? (hdim + 63) / 64 * 64 : (hdim + 31) / 32 * 32;
             if (q == 0) pc.x_off = pack_folded(P, st.convs[q].weight, chp, hdim, c1, W, sc, &pc.k_off, &pc.kc);
             else pc.x_off = pack_hx3(P, st.convs[q].weight, st.convs[q].out_channels, st.convs[q].in_channels, chp,
@@ -1448,7 +1449,8 @@ static int image_forward_impl(const gbnf_image_flow* f, const float* x, const fl
                            img_net_hx3_lds(W, f->chp, net[0].cin, net[0].kc, net[2].cout) != 0;
       // (a padded map runs the fused kernel or the exact-f32 convolutions: the two-kernel split form does not mask)
       // (hidden widths above 256 exist on the fused kernel only)
-      if (!force_f32 && net.size() == 3 && net[1].x_off != 0 && (fusable || (!padded && f->chp <= 256))) {
+      // (more than 5 chunks of the folded first 3x3 -- more than 17 input channels -- exist on the fused kernel only)
+      if (!force_f32 && net.size() == 3 && net[1].x_off != 0 && (fusable || (!padded && f->chp <= 256 && net[0].kc <= 5))) {
         // split-f16 path.  Round 4: the whole coupling net in ONE kernel where a workgroup can hold the hidden activation of its
         // rows (+ halo) in LDS: the 16 x 16 and 8 x 8 maps of a 32 x 32 input (img_net_hx3_kernel, gbnf_image_hx3.hip.h)
         static const bool no_fuse = getenv("GBNF_IMG_NO_FUSE") != nullptr;        // diagnostic: the round-2 two-kernel form

@@ -866,6 +866,7 @@ static size_t img_net_hx3_layout(int W, int chp, int cin, int pre_kc, size_t* bf
 }
 size_t img_net_hx3_lds(int W, int chp, int cin, int pre_kc, int cout) {
   if (cout > 48 || (W == 16 && cout > 32)) return 0;
+  if (pre_kc > 7 || (pre_kc > 5 && (W != 8 || chp > 256))) return 0;      // 6 / 7 chunks: the 8-wide instantiations of one half only
   return img_net_hx3_layout(W, chp, cin, pre_kc, nullptr);
 }
 
@@ -878,8 +879,24 @@ static hipError_t img_net_hx3_launch4(const NetLaunch& q0, int64_t n, hipStream_
   q.bf_off = (unsigned)bf_off;
   constexpr int RO = (W == 16 && KH == 2) ? 4 : 8;
   const dim3 grid((unsigned)(n * (W == 16 ? 16 / RO : 1))), blk(512);
-  const int pk = q.pre_kc <= 2 ? 2 : (q.pre_kc <= 4 ? 4 : 5);
+  const int pk = q.pre_kc <= 2 ? 2 : (q.pre_kc <= 4 ? 4 : (q.pre_kc <= 5 ? 5 : 7));
   const bool full = q.hid == q.chp && q.Hv >= q.H && q.Wv >= W;
+  if constexpr (W == 8 && KH == 1) {
+    // 6 / 7 chunks (18 .. 24 input channels: the third level of a 3 x 32 x 32 input, a 4 x 4 map in 8 x 8 storage -- never FULL)
+    if (pk == 7) {
+      static bool attr7 = false;
+      if (!attr7) {
+        const hipError_t e = hipFuncSetAttribute((const void*)img_net_hx3_kernel<W, 7, EPI, OT3, false, KH>,
+                                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e != hipSuccess) return e;
+        attr7 = true;
+      }
+      hipLaunchKernelGGL((img_net_hx3_kernel<W, 7, EPI, OT3, false, KH>), grid, blk, lds, s, q);
+      return hipGetLastError();
+    }
+  } else {
+    if (pk == 7) return hipErrorInvalidValue;
+  }
   static bool attr_set = false;
   if (!attr_set) {
     const void* fns[6] = {(const void*)img_net_hx3_kernel<W, 2, EPI, OT3, false, KH>, (const void*)img_net_hx3_kernel<W, 4, EPI, OT3, false, KH>,

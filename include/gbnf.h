@@ -425,7 +425,8 @@ typedef struct gbnf_image_flow gbnf_image_flow;
  * always have the map's own size);
  * <= 64 channels per level; coupling ConvNets of hidden width <= 512 with 2 .. 5 convolutions (coupling_network_depth 0 .. 3);
  * the split-f16 kernels serve depth 1, every hidden width (above 256 the fused kernel works in two halves of the hidden
- * channels) and <= 16 input channels of the first 3 x 3, everything else runs on the exact-f32 convolution kernels.  Not built: y-conditioning, learned dequantisation flows, image training. */
+ * channels) and <= 24 input channels of the first 3 x 3 (the 48-channel third level of a 3 x 32 x 32 input), everything else
+ * runs on the exact-f32 convolution kernels.  Not built: y-conditioning, learned dequantisation flows, image training. */
 int gbnf_image_flow_create(const gbnf_image_flow_desc* desc, gbnf_image_flow** out);
 /* ... with an explicit GBNF_MATH_* mode: DEFAULT (what gbnf_image_flow_create does: split-f16 coupling nets if the create-time
  * probe passes), F32 (exact-f32 convolutions everywhere, no probe), F16X3. */
