@@ -452,7 +452,7 @@ def main():
     MAX_TIMED_LAUNCHES = 48      # launches bracketed by timing events (the average is reported as roofline.launch_ms): event
                                  # pairs on every group of a long run cost the host more than the group's own launches
 
-    def timed_run(math, group, steps, warmup, prewarm, want_gather_times=False, repetitions=0):
+    def timed_run(math, group, steps, warmup, prewarm, want_gather_times=False, repetitions=0, fresh=False):
         """The pipeline on this rank's components in `math` mode, groups of `group` batches: returns timing + the handles' info."""
         flows = [native.NativeFlow(specs[c], math=math) for c in range(c0, c1)]
         mix = native.NativeMixture(flows)
@@ -507,13 +507,15 @@ def main():
             last = None
             while done < n_steps:
                 k = min(group, n_steps - done)
-                if k not in bound:
+                if k not in bound and not fresh:
                     bound[k] = pipe.bind(xs[:k])
                 ev = None
                 if events is not None and k == group and len(events) < MAX_TIMED_LAUNCHES:
                     ev = event_pool[len(events)]
                     events.append(ev)
-                res = pipe.submit(bound[k], ev)
+                # (fresh: the group's tensors are handed over as a new list every time -- the per-group host work of a caller whose
+                #  batches come from a loader stays INSIDE the timed region: legs.fresh_batches)
+                res = pipe.submit(list(xs[:k]) if fresh else bound[k], ev)
                 if k == group:
                     last = res               # (G tensor of the slot, slot) of the last FULL group
                 done += k
@@ -662,6 +664,15 @@ def main():
                 del r
             except native.GbnfError as e:
                 legs["bf16x6"] = {"error": str(e)}
+            if not gather:
+                try:
+                    r = timed_run(args.math, S, max(n_leg, 4 * S), 2 * S, 0.0, fresh=True)
+                    legs["fresh_batches"] = {"value": B * max(n_leg, 4 * S) / r["elapsed"], "unit": "samples/s", "dtype": r["name"], "group": S,
+                                             "note": "the headline workload with every group submitted as a NEW list of batch tensors (no launches bound "
+                                                     "ahead of the timed region): what a loader-fed caller of the group API pays per group"}
+                    del r
+                except Exception as e:
+                    legs["fresh_batches"] = {"error": f"{type(e).__name__}: {e}"}
             r = timed_run(args.math, 1, n_leg, 16, 0.0)
             rg = roofline(r, 1)
             legs["group1"] = {"value": B * n_leg / r["elapsed"], "unit": "samples/s", "dtype": r["name"], "steps": n_leg,
@@ -721,6 +732,7 @@ def main():
             "roofline_frac": rl["frac"], "roofline_executed_frac": rl["executed_frac"], "launch_ms": rl["launch_ms"],
             "traffic": rl["traffic"], "traffic_file": "profiles/headline_traffic.json (looked up, not counted in this run)",
             "group1_value": (lg.get("group1") or {}).get("value"), "group1_frac": (lg.get("group1") or {}).get("frac"),
+            "fresh_batches_value": (lg.get("fresh_batches") or {}).get("value"),
             "f32_exact_value": (lg.get("f32_exact") or {}).get("value"), "f32_exact_frac_of_f32_peak": (lg.get("f32_exact") or {}).get("frac"),
             "bf16x6_value": (lg.get("bf16x6") or {}).get("value"), "bf16x6_executed_frac_of_bf16_peak": (lg.get("bf16x6") or {}).get("executed_frac"),
             "log_prob_call_at_1024_rows_value": ((lg.get("reference_batch_sizes") or {}).get("1024") or {}).get("value"),
