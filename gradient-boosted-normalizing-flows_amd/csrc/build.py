@@ -34,8 +34,8 @@ def read_variants():
                 for nt in (1, 2):
                     for prec in (0, 1):
                         out.append(("hx3", kind, ht, ot, nt, acta, actb, prec, depth))
-                    if depth <= 2:               # the training path's forward sweep (f16x3, trace + operand saves): "hx3t", every net
-                        out.append(("hx3t", kind, ht, ot, nt, acta, actb, 0, depth))     # and depth to 2; 32-sample waves: one per SIMD
+                    if True:                     # the training path's forward sweep (f16x3, trace + operand saves): "hx3t", every net
+                        out.append(("hx3t", kind, ht, ot, nt, acta, actb, 0, depth))     # and depth; 32-sample waves: one per SIMD
                         if nt == 1:
                             out.append(("hx3b", kind, ht, ot, acta, actb, depth))        # ... and its backward sweep
                 continue

@@ -1807,8 +1807,8 @@ static hipError_t upload_vec(const std::vector<T>& v, T** dev) {
 // per-step-activation variants are generic supersets).  GBNF_OK and *vc, or UNSUPPORTED.
 static int live_choose(const gbnf_flow_desc* desc, DescInfo& info, VariantChoice* vc) {
   const int h = info.ref.hidden, depth = info.ref.depth;
-  if (depth > 2)
-    return fail(GBNF_ERR_UNSUPPORTED, "live blob: TanhNet / ReLUNet of coupling_network_depth 0, 1 or 2 and one-block ResidualNets only");
+  if (info.ref.residual ? (depth != 2 && depth != 4) : depth > 2)
+    return fail(GBNF_ERR_UNSUPPORTED, "live blob: TanhNet / ReLUNet of coupling_network_depth 0, 1 or 2 and ResidualNets of one or two blocks only");
   if (info.ref.residual) info.act_a = info.act_b = GBNF_ACT_RESIDUAL_RELU;      // the kernels' key of a ResidualNet (depth 2 = one block)
   {   // an activation pair nobody compiled a kernel for runs on the per-step variants (as gbnf_flow_create_ex does)
     bool compiled = false;
@@ -1929,7 +1929,7 @@ int live_blob_create(const gbnf_flow_desc* desc, const int64_t* norm_grad_offset
   auto add_net = [&](const gbnf_net& net, size_t base, int in_f, int out_f) {
     const bool tanh_net = net.activation == GBNF_ACT_TANH;
     const float T = tanh_net ? 2.8853900817779268f : 1.0f, R = tanh_net ? -2.0f : 1.0f;
-    int lid[4];
+    int lid[6];
     for (int l = 0; l < depth + 2; ++l) {
       lid[l] = (int)layers.size();
       layers.push_back(LiveLayer{net.layers[l].weight, net.layers[l].bias, net.layers[l].out_features, net.layers[l].in_features});

@@ -331,7 +331,7 @@ flow_kernel_hx3(const FlowLaunch p) {
   // Two blocks (round 5, evaluation only): DEPTH = 4.  The hidden -> hidden layers 1 .. DEPTH - 1 run as "middle" layers that ping-pong
   // between the two register sets of B operands; behind layer 2 (the first block's second Linear) the skip sum t = a2 + t0 replaces
   // the raw layer-0 tiles AND is what the second block starts from (relu(t)); the last layer's output + t goes to the final layer.
-  static_assert(!TRAIN || DEPTH <= 2, "the training forward covers depth 0, 1, 2 and one-block ResidualNets");
+  // (TRAIN at DEPTH = 4: relu(a0), relu(a1), relu(t1), relu(a3) and t2 go to the operand rows of "hidden layers" 0 .. 4)
   static_assert(!TRAIN || PREC == 0, "the training forward runs on f16x3");
   constexpr int WAVES = WV;
   constexpr int NP = hx3_pieces(PREC);
@@ -921,7 +921,7 @@ flow_kernel_hx3(const FlowLaunch p) {
       f32x4 t0r[RES ? HT : 1][NT];
       auto res_split = [&](const f32x4& raw, const f32x4& t0, int hp, int nt, unsigned (&pc)[NP], int tile) {
         float v0 = raw[2 * hp] + t0[2 * hp], v1 = raw[2 * hp + 1] + t0[2 * hp + 1];
-        save_act(v0, v1, false, 2, tile, hp, nt);            // TRAIN: the final layer's input t (operand rows of hidden "layer" 2)
+        save_act(v0, v1, false, DEPTH, tile, hp, nt);        // TRAIN: the final layer's input t (operand rows of hidden "layer" DEPTH)
         if constexpr (WATCH) {
           amax[nt] = __builtin_fmaxf(amax[nt], __builtin_fmaxf(__builtin_fabsf(v0), __builtin_fabsf(v1)));
           v0 = __builtin_amdgcn_fmed3f(v0, -65504.0f, 65504.0f);

@@ -1543,7 +1543,7 @@ int gbnf_trainer_create(const gbnf_flow_desc* desc, gbnf_trainer** out) {
   t->hp = ceil16(h);
   // (round 5) a width no TRAIN kernel variant is compiled for trains on the next wider one: the operand rows follow the VARIANT's
   // hidden tiles (the extra units have zero weights: their activations, gradients and operand rows are zeros)
-  const bool chained_shape = nl >= 2 && nl <= 4 && (!residual || nl == 4) && tr_fast_path_enabled();
+  const bool chained_shape = (residual ? (nl == 4 || nl == 6) : (nl >= 2 && nl <= 4)) && tr_fast_path_enabled();
   int hp_wide = 0;
   if (chained_shape) {
     const int rows = live_blob_train_rows(desc);

@@ -102,24 +102,29 @@ __device__ __forceinline__ float bwd_sum16(float v) {
 // Waves per SIMD the 4-wave form is compiled for: 2 (256 registers, two workgroups share a CU and cover each other's memory
 // latency: 498 -> 3xx us at N = 65536) where the kernel fits -- its register count is 8 per hidden tile (the saved second-layer
 // activations and the split g_a2 operands) + ~125 (measured: HT = 14 -> 235) -- else 1 (512 registers).
-constexpr int bwd_hx3_occupancy(int KIND, int HT, int OT, int DEPTH = 1) {
+constexpr int bwd_hx3_occupancy(int KIND, int HT, int OT, int DEPTH = 1, bool RES = false) {
 #ifdef GBNF_BWD_OCC
   return GBNF_BWD_OCC;
 #else
   // (two hidden -> hidden layers: a second set of split gradient operands, 4 registers per hidden tile)
-  return (DEPTH == 2 ? 12 : 8) * HT + 125 + (KIND == GBNF_KIND_REALNVP ? 8 * OT + 8 : 0) <= 250 ? 2 : 1;
+  // (a one-block ResidualNet at 7 hidden tiles spills 65 registers with two waves per SIMD and is still 12 % faster than with one:
+  //  measured 0.98 against 1.10 ms of backward + wgrad at N = 65536 -- the skip tiles are NOT counted here)
+  return (DEPTH >= 2 ? 12 : 8) * HT + ((void)RES, 0) + (DEPTH == 4 ? 60 : 0) + 125 + (KIND == GBNF_KIND_REALNVP ? 8 * OT + 8 : 0) <= 250 ? 2 : 1;
 #endif
 }
 template <int KIND, int HT, int OT, int ACTA, int ACTB, int WV, int DEPTH = 1>
-__global__ void __launch_bounds__(64 * WV, WV == 8 ? 2 : bwd_hx3_occupancy(KIND, HT, OT, DEPTH)) bwd_kernel_hx3(const FlowLaunch p) {
-  static_assert(DEPTH >= 0 && DEPTH <= 2, "coupling_network_depth 0, 1 or 2");
+__global__ void __launch_bounds__(64 * WV, WV == 8 ? 2 : bwd_hx3_occupancy(KIND, HT, OT, DEPTH, ACTA == 2)) bwd_kernel_hx3(const FlowLaunch p) {
+  static_assert((DEPTH >= 0 && DEPTH <= 2) || (DEPTH == 4 && ACTA == 2), "coupling_network_depth 0, 1 or 2; ResidualNets of one or two blocks");
   // ACT == 2 (GBNF_ACT_RESIDUAL_RELU): a ResidualNet of ONE block (models/layers.py:246-301) = layer 0 -> [relu -> Linear -> relu ->
   // Linear] + layer 0's output -> final layer.  Backward: the final layer's input gradient g_t passes the block's exit unchanged
   // (no activation in front of the final layer), runs back through the two inner layers with relu', and is ADDED to the block's
   // input gradient (the skip connection): DEPTH = 2 with the raw g_t tiles kept in registers.
   constexpr bool RES = ACTA == 2;
   static_assert((ACTA == 2) == (ACTB == 2), "both nets of a step are ResidualNets or neither is");
-  static_assert(!RES || DEPTH == 2, "a one-block ResidualNet has two hidden -> hidden layers");
+  static_assert(!RES || DEPTH == 2 || DEPTH == 4, "a ResidualNet has two hidden -> hidden layers per block");
+  // Two blocks (DEPTH = 4): three middle layers J = 4, 3, 2 ping-pong between the operand sets; behind layer 3 (the second block's
+  // first Linear) the gradient meets the second block's skip path -- g_t1 = relu'(t1) (W3^T g_a3) + g_t2 -- and g_t1 REPLACES the kept
+  // skip gradient (what the first block's skip hands to layer 0's output).
   constexpr int WAVES = WV, NP = 2, NT = 1, ZS = 17, IT = 2;
   constexpr int NNETS = (KIND == GBNF_KIND_REALNVP) ? 2 : 1;
   constexpr int NH = DEPTH + 1;                          // hidden activations per net: operand rows in | NH x act | NH x grad | out grad | out
@@ -489,10 +494,94 @@ __global__ void __launch_bounds__(64 * WV, WV == 8 ? 2 : bwd_hx3_occupancy(KIND,
       Acc outG[IT];
 #pragma unroll
       for (int o = 0; o < IT; ++o) outG[o].init(f32x4{0.f, 0.f, 0.f, 0.f});
+      // ---- (DEPTH >= 2) the middle layers J = DEPTH .. 2: WJ^T, one output tile per stage; tile u-1 times act'(saved activation of
+      //      layer J - 1) is emitted / split during pass u into the OTHER operand set -- gB -> gB2 -> gB -> gB2: the B operands of the
+      //      next layer down.  Fully unrolled: the destination register of a finished tile is a compile-time index.
+      u32x4 gB2[DEPTH >= 2 ? HC : 1][NP];
+      if constexpr (DEPTH == 4) {
+        auto mid_layer = [&](auto j_c, auto& gIn, auto& gOut) {
+          constexpr int J = decltype(j_c)::value;
+          const float* hjp = an + (int64_t)(p.tr_ip + (J - 1) * p.tr_hp) * np + h_off;           // saved activations of layer J - 1
+          float* djp = an + (int64_t)(p.tr_ip + (NH + J - 1) * p.tr_hp) * np + h_off;         // ... and its gradient-side operand rows
+#pragma unroll
+          for (int k = 0; k < NP; ++k) gOut[HC - 1][k] = u32x4{0, 0, 0, 0};
+          f32x4 prem = f32x4{0.f, 0.f, 0.f, 0.f};
+          auto load_hm = [&](int t) {
+            f32x4 v;
+            const int tt = t < HT ? t : HT - 1;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] = (GBNF_BWD_ABLATE & 4) ? 0.5f : hjp[(16 * tt + r) * 16];
+            return v;
+          };
+          f32x4 hmv[2] = {load_hm(0), load_hm(1)};       // saved activations of the even / odd tile that is finished next
+          auto finish_mid = [&](auto t_c) {              // tile t of this layer's input gradient -> operand workspace + gOut
+            constexpr int t = decltype(t_c)::value;
+            f32x4 ga;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) ga[r] = dact(prem[r], hmv[t & 1][r]);
+            if constexpr (RES && (J & 1) == 1 && J > 1) {       // the entry of a block that is not the first: + the skip path, and on
+              ga += gskip[t];
+              gskip[t] = ga;
+            }
+            if (!(GBNF_BWD_ABLATE & 2)) {
+#pragma unroll
+              for (int r = 0; r < 4; ++r) djp[(16 * t + r) * 16] = ga[r];
+              later += 4;
+            }
+            unsigned lo[NP], hi[NP];
+            split4(ga, lo, hi);
+#pragma unroll
+            for (int k = 0; k < NP; ++k) { gOut[t >> 1][k][2 * (t & 1)] = lo[k]; gOut[t >> 1][k][2 * (t & 1) + 1] = hi[k]; }
+          };
+          auto mid_pass = [&](auto u_c) {
+            constexpr int u = decltype(u_c)::value;
+            issue(std::integral_constant<int, NP * HC>{}, gs + 1);      // the next pass of this layer or pass 0 of the next layer down
+            __builtin_amdgcn_sched_barrier(0);       // (the stores + loads below stay BEHIND the staging DMA: stage_end counts on it)
+            Unit A[3];
+            A[0] = N0;
+            A[1] = N1;
+            Acc acc;
+            acc.init(f32x4{0.f, 0.f, 0.f, 0.f});
+            if constexpr (u > 0) {
+              finish_mid(std::integral_constant<int, (u > 0 ? u - 1 : 0)>{});
+              // (the last pass has no tile u + 1 to request: a load whose value is never used would be dropped by the compiler and the
+              //  counted wait below would then let the next stage's staging DMA slip)
+              if constexpr (u + 1 < HT) {
+                hmv[(u - 1) & 1] = load_hm(u + 1);
+                later += 4;
+              }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int n = 0; n < HC; ++n) {
+              if (n + 2 < HC) load_unit(A[(n + 2) % 3], n + 2);
+              if (n == HC - 1) stage_finish(true);
+              mac(A[n % 3], gIn[n], acc);
+              __builtin_amdgcn_sched_barrier(0);
+            }
+            prem = acc.total();
+            stage_finish(false);
+          };
+          auto mid_all = [&](auto self, auto u_c) -> void {
+            constexpr int u = decltype(u_c)::value;
+            if constexpr (u < HT) {
+              mid_pass(u_c);
+              self(self, std::integral_constant<int, u + 1>{});
+            }
+          };
+          mid_all(mid_all, std::integral_constant<int, 0>{});
+          finish_mid(std::integral_constant<int, HT - 1>{});
+        };
+        mid_layer(std::integral_constant<int, 4>{}, gB, gB2);
+        mid_layer(std::integral_constant<int, 3>{}, gB2, gB);
+        mid_layer(std::integral_constant<int, 2>{}, gB, gB2);
+      }
+      // (DEPTH = 2 keeps its own hand-written block below: the generic form compiled, for the one-block ResidualNet at 16 hidden tiles,
+      //  to a kernel that faulted in workgroups with spare waves -- 101 spilled registers, cause not found, HISTORY round 5 -- while this
+      //  form of the same arithmetic is the one every depth-2 test and stress run of the round has passed on)
       // ---- (DEPTH = 2) W2^T: one output tile per stage; tile u-1 times act'(h of the middle layer) is emitted / split during pass u
       //      into the second operand set gB2 -- the B operands of the W1^T passes.  Fully unrolled: the destination register of
       //      a finished tile is a compile-time index.
-      u32x4 gB2[DEPTH == 2 ? HC : 1][NP];
       if constexpr (DEPTH == 2) {
 #pragma unroll
         for (int k = 0; k < NP; ++k) gB2[HC - 1][k] = u32x4{0, 0, 0, 0};
@@ -560,7 +649,7 @@ __global__ void __launch_bounds__(64 * WV, WV == 8 ? 2 : bwd_hx3_occupancy(KIND,
         finish_mid(std::integral_constant<int, HT - 1>{});
       }
       auto& gBin = [&]() -> auto& {                 // the B operands of the W1^T passes
-        if constexpr (DEPTH == 2) return gB2;
+        if constexpr (DEPTH >= 2) return gB2;
         else return gB;
       }();
       if constexpr (DEPTH == 0) {

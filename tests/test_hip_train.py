@@ -597,6 +597,11 @@ def test_device_packer_reproduces_the_host_packer(kind, d, h, kw):
                                              ("realnvp", 21, 64, 3, 100, {"coupling_network": "residual", "batch_norm": False, "seed": 101}),
                                              ("realnvp", 43, 215, 2, 2049, {"coupling_network": "residual", "seed": 101}),
                                              ("realnvp", 8, 250, 2, 1, {"coupling_network": "residual"}),
+                                             # two blocks (DEPTH = 4: three middle layers in both sweeps, the skip gradient replaced behind the second block's entry)
+                                             ("realnvp", 21, 105, 3, 100, {"coupling_network": "residual", "depth": 2, "seed": 104}),
+                                             ("realnvp", 21, 64, 2, 33, {"coupling_network": "residual", "depth": 2, "batch_norm": False, "seed": 104}),
+                                             ("realnvp", 43, 215, 2, 257, {"coupling_network": "residual", "depth": 2, "seed": 104}),
+                                             ("realnvp", 8, 40, 3, 77, {"coupling_network": "residual", "depth": 2, "seed": 104}),
                                              ("realnvp", 21, 300, 2, 65, {"coupling_network": "residual", "seed": 102}),      # 24 / 32 hidden tiles
                                              ("realnvp", 21, 512, 2, 33, {"coupling_network": "residual", "seed": 102})])
 def test_depth_0_and_2_train_on_the_register_chained_kernels(kind, d, h, K, n, kw):

@@ -24,7 +24,8 @@ CONFIGS = {"miniboone_glow": dict(kind="glow", d=43, h=215, K=5, kw={}),
            "miniboone_glow_depth0": dict(kind="glow", d=43, h=215, K=5, kw={"depth": 0}),
            "miniboone_glow_depth2": dict(kind="glow", d=43, h=215, K=5, kw={"depth": 2}),
            "hepmass_realnvp_depth2": dict(kind="realnvp", d=21, h=105, K=5, kw={"depth": 2}),
-           "hepmass_realnvp_residual": dict(kind="realnvp", d=21, h=105, K=5, kw={"coupling_network": "residual"})}
+           "hepmass_realnvp_residual": dict(kind="realnvp", d=21, h=105, K=5, kw={"coupling_network": "residual"}),
+           "hepmass_realnvp_residual2": dict(kind="realnvp", d=21, h=105, K=5, kw={"coupling_network": "residual", "depth": 2})}
 
 
 def torch_step(spec, x, dev, dtype=torch.float32):
