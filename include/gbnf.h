@@ -47,7 +47,8 @@ enum { GBNF_KIND_GLOW = 0, GBNF_KIND_REALNVP = 1 };
  * layers in the order initial_layer, (blocks[b].linear_layers[0], blocks[b].linear_layers[1]) for b < B, final_layer:
  *     t = initial(x);  t += lin1_b(relu(lin0_b(relu(t)))) for every block;  out = final(t)
  * One block (the reference's default depth): the split kernels, every hidden width, both directions and training; two blocks: the
- * split kernels to hidden width 256 (round 5), the exact-f32 kernel beyond, the per-step training kernels (B <= 2). */
+ * split kernels and the register-chained training kernels to hidden width 256 (round 5), the exact-f32 kernel and the per-step
+ * training kernels beyond (B <= 2). */
 enum { GBNF_ACT_TANH = 0, GBNF_ACT_RELU = 1, GBNF_ACT_RESIDUAL_RELU = 2 };
 enum { GBNF_COUPLING_AFFINE = 0, GBNF_COUPLING_ADDITIVE = 1 };
 /* How the coupling-network matrix products are evaluated:
