@@ -363,6 +363,24 @@ def test_evaluate_loop_is_served_from_one_launch(golden_case):
     assert not torch.equal(l1new, l1c)
     w.data.div_(1.5)
     m.invalidate_packed()
+    # (2c) round 5: the key keeps the permutations' index TENSORS instead of walking `perm.indices` per call.  A re-assigned
+    #      permutation (set_indices: a new tensor object, the serial moves) and an in-place edit of the index tensor (its version
+    #      moves) must both re-pack component 1 and be served with the new values; component 0 stays untouched
+    _, _, _, l1a, _ = m(x=x, components=1)
+    perm = m.flows[1].flow.layers[0].permutation
+    old_idx = perm.indices.clone()
+    new_idx = torch.roll(old_idx, 1)
+    perm.set_indices(new_idx.tolist())
+    _, _, _, l1b2, _ = m(x=x, components=1)
+    m.SERVE_ALL_COMPONENTS = False
+    _, _, _, l1b2p, _ = m(x=x, components=1)
+    m.SERVE_ALL_COMPONENTS = True
+    assert torch.equal(l1b2, l1b2p) and not torch.equal(l1b2, l1a)
+    with torch.no_grad():
+        perm.indices.copy_(old_idx.to(perm.indices.device))          # in place: same tensor object, new version
+        perm._rebuild_inverse()
+    _, _, _, l1back, _ = m(x=x, components=1)
+    assert torch.equal(l1back, l1a)
     # (3) train() mode is never served (the call may be recorded by autograd)
     m.train()
     m.drop_component_table()
