@@ -283,6 +283,11 @@ def config_legs(args):
                                   "--cpu-seconds", cpu]),
         ("train_step_miniboone_c1_n65536", [py, os.path.join(tools, "bench_train.py"), "--batch", "65536", "--steps", "30", "--warmup", "5",
                                             "--cpu-steps", "2" if args.cpu_seconds > 0 else "0", "--no-torch-legs"]),
+        # the other coupling networks the reference constructs (round 5: on the register-chained training kernels too)
+        ("train_step_hepmass_residual_c1_n65536", [py, os.path.join(tools, "bench_train.py"), "--config", "hepmass_realnvp_residual", "--batch", "65536",
+                                                   "--steps", "20", "--warmup", "5", "--cpu-steps", "0", "--no-torch-legs"]),
+        ("train_step_miniboone_depth2_c1_n65536", [py, os.path.join(tools, "bench_train.py"), "--config", "miniboone_glow_depth2", "--batch", "65536",
+                                                   "--steps", "20", "--warmup", "5", "--cpu-steps", "0", "--no-torch-legs"]),
         # configs[4] (MINIBOONE C = 8 sharded one component per GPU) as far as one GPU can show it: ONE rank's share of the 8-GPU
         # run -- one component on every batch, the gather of the full (8, S N) table through the library's RCCL communicator
         # (world size 1: the copy, not the xGMI hop), the recursion -- at the driver's own --steps 20 and in steady state
