@@ -602,6 +602,10 @@ def test_device_packer_reproduces_the_host_packer(kind, d, h, kw):
                                              ("realnvp", 21, 64, 2, 33, {"coupling_network": "residual", "depth": 2, "batch_norm": False, "seed": 104}),
                                              ("realnvp", 43, 215, 2, 257, {"coupling_network": "residual", "depth": 2, "seed": 104}),
                                              ("realnvp", 8, 40, 3, 77, {"coupling_network": "residual", "depth": 2, "seed": 104}),
+                                             # 16 hidden tiles with a ragged batch (n < np, spare waves in the backward's last workgroup: the shape of the
+                                             #  round's fault -- HISTORY -- in an unshipped form of the depth-2 backward), one and two blocks
+                                             ("realnvp", 21, 250, 3, 17, {"coupling_network": "residual", "seed": 105}),
+                                             ("realnvp", 21, 250, 2, 33, {"coupling_network": "residual", "depth": 2, "seed": 105}),
                                              ("realnvp", 21, 300, 2, 65, {"coupling_network": "residual", "seed": 102}),      # 24 / 32 hidden tiles
                                              ("realnvp", 21, 512, 2, 33, {"coupling_network": "residual", "seed": 102})])
 def test_depth_0_and_2_train_on_the_register_chained_kernels(kind, d, h, K, n, kw):
