@@ -836,14 +836,20 @@ __global__ void __launch_bounds__(64 * WV, WV == 8 ? 2 : bwd_hx3_occupancy(KIND,
         ga = gy * (y - tb.p3[e]) + gl;            // d/d log_gamma
         gb = gy;                                  // d/d beta
       }
-      if (m >= 0 && wave_ok && !(GBNF_BWD_ABLATE & 1)) {     // (uniform per lane group; a RealNVP step without BatchNorm has no parameters)
+      if (!(GBNF_BWD_ABLATE & 1)) {
+        // NO divergent block here (round 5).  Every lane of a 16-lane group holds the group's sum and stores it -- the same value to
+        // the same address; a group without a parameter (m < 0: uniform per lane group, a RealNVP step without BatchNorm has none) and
+        // a spare wave store into the wave's scatter scratch, which is dead at this point (gyi has been read).  Why: an unshipped
+        // variant of this kernel (one-block ResidualNet, 16 hidden tiles, 101 spilled registers) reloaded an ADDRESS register from
+        // its spill slot with valid values in the lanes i == 0 only -- the lanes of the `if (i == 0)` block that used to stand here
+        // -- and float data in all others (rocgdb register dump, HISTORY): under that much register pressure hipcc let a value that
+        // is live across the divergent block be (re)defined inside it.  No divergent region, nothing to get wrong.
         ga = bwd_sum16(ga);
         gb = bwd_sum16(gb);
-        if (i == 0) {              // every (step, parameter) is met once per wave
-          float* q = PG + ((wave * K + step) * 2) * 64 + m;
-          q[0] = ga * inv_alpha;
-          q[64] = gb * inv_alpha;
-        }
+        const bool keep = m >= 0 && wave_ok;
+        float* q = keep ? PG + ((wave * K + step) * 2) * 64 + m : SC + 2 * g;
+        q[0] = ga * inv_alpha;
+        q[keep ? 64 : 1] = gb * inv_alpha;
       }
       return gx;
     };

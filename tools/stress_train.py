@@ -99,6 +99,25 @@ def main():
                     kink = dev_ps >= 0.3 * errs[0][0]
                 except Exception:
                     pass
+            if not kink:
+                # third witness: the float64 forward itself -- the smallest |ReLU pre-activation| of the batch.  One within float32
+                # round-off of zero (a few 1e-6 for sums of 256 .. 512 split-f16 products) is a sample whose path a float32 kernel may
+                # legitimately take the other way: its whole contribution moves (1 / n of a gradient's scale, on the layers below it)
+                class _MinOps(oracle._TorchGradOps):
+                    smallest = float("inf")
+                    def relu(self, a):
+                        _MinOps.smallest = min(_MinOps.smallest, float(a.detach().abs().min()))
+                        return torch.relu(a)
+                mops = _MinOps()
+                zt, ldt = torch.tensor(x.astype(np.float64)), mops.zeros(n)
+                for st_ in spec["steps"]:
+                    if kind == "glow":
+                        zt, ldt = oracle.glow_step(mops, spec, st_, zt, ldt)
+                    else:
+                        zt, sl_ = oracle.realnvp_step(mops, spec, st_, zt)
+                if _MinOps.smallest < 5e-6:
+                    kink = True
+                    print(f"     (smallest |ReLU pre-activation| of the batch in float64: {_MinOps.smallest:.1e})")
             bad += 0 if kink else 1
             print("KINK" if kink else "FAIL", tag, "| worst tensors", [(f"{e:.1e}", i, sh) for e, i, sh in errs],
                   f"| outside the ReLU-threshold bracket by {worst_out:.1e}")
