@@ -492,13 +492,18 @@ def _last_path(tr):
     return a.value, b.value
 
 
-@pytest.mark.parametrize("d,h,K,n,seed", [(21, 33, 3, 100, 1), (6, 16, 4, 17, 2), (43, 64, 2, 257, 3), (21, 105, 5, 1000, 4)])
-def test_trainer_batch_stats_against_oracle(d, h, K, n, seed):
+@pytest.mark.parametrize("d,h,K,n,seed,kw", [(21, 33, 3, 100, 1, {}), (6, 16, 4, 17, 2, {}), (43, 64, 2, 257, 3, {}), (21, 105, 5, 1000, 4, {}),
+                                             # round 5: the other coupling networks in the reference's default training mode (BatchNorm on batch
+                                             # statistics): depth 0 / 2 and ResidualNets of one and two blocks, one launch per step range
+                                             (21, 105, 3, 300, 5, {"depth": 2}), (21, 105, 3, 129, 6, {"depth": 0}),
+                                             (21, 105, 4, 200, 7, {"coupling_network": "residual"}),
+                                             (21, 64, 3, 100, 9, {"coupling_network": "residual", "depth": 2})])
+def test_trainer_batch_stats_against_oracle(d, h, K, n, seed, kw):
     import torch
     from gbnf_amd import native, synth
     from oracle import gbnf_oracle as oracle
     dev = torch.device("cuda:0")
-    spec = synth.synth_realnvp_spec(d, h, K, seed=seed, flip_init=seed % 2)
+    spec = synth.synth_realnvp_spec(d, h, K, seed=seed, flip_init=seed % 2, **kw)
     dv = _dev_spec(spec, dev)
     for st in dv["steps"]:
         if st["bn"] is not None:
@@ -514,8 +519,8 @@ def test_trainer_batch_stats_against_oracle(d, h, K, n, seed):
     # steps 0 .. K-2 carry one, models/realnvp.py:71-74)
     chained = _has_live_blob(tr)          # (a width with no TRAIN variant of its own keeps the round-1 kernels: 0 chained launches)
     assert _last_path(tr)[0] == (max(K - 1, 1) if chained else 0)
-    if (d, h) == (21, 105):
-        assert chained                    # the HEPMASS geometry (BASELINE.json configs[2]) must be on the fast path
+    if (d, h) == (21, 105) or kw:
+        assert chained                    # the HEPMASS geometry (BASELINE.json configs[2]) and every other coupling network: the fast path
     z64, ldj64, stats = oracle.component_forward_train(spec, x)
     assert np.abs(z.cpu().numpy() - z64).max() <= 2e-5 * max(1.0, float(np.abs(z64).max()))
     assert np.abs(ldj.cpu().numpy() - ldj64).max() <= 1e-5 * max(1.0, float(np.abs(ldj64).max()))
