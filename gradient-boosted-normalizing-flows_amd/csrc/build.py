@@ -27,6 +27,11 @@ def read_variants():
             line = line.split("#")[0].strip()
             if not line:
                 continue
+            if line.startswith("coop"):    # the latency form of an hx3 line's f16x3 kernel: coop KIND HT OT ACTA ACTB (depth 1)
+                kind, ht, ot, acta, actb = (int(v) for v in line.split()[1:6])
+                for form in (1, 2, 3):       # 16-sample tiles / 4 waves, 32 / 4, 32 / 8
+                    out.append(("coop", kind, ht, ot, form, acta, actb))
+                continue
             if line.startswith("hx3"):     # both split precisions: 0 = f16x3, 1 = bf16x6 (its repair pass / safe mode)
                 vals = [int(v) for v in line.split()[1:]]
                 kind, ht, ot, acta, actb = vals[:5]
@@ -159,13 +164,17 @@ def main(argv=None):
         if v[0] == "hx3b":
             vsrc, vargs = os.path.join(HERE, "variant_bwd.hip"), v[1:]
             extra = list(VGPR_FORM)
+        elif v[0] == "coop":
+            vsrc, vargs = os.path.join(HERE, "variant_coop.hip"), v[1:]
+            extra = list(VGPR_FORM)
         elif v[0] in ("hx3", "hx3t"):
             vsrc, vargs = os.path.join(HERE, "variant_hx3.hip"), v[1:]
             # keep MFMA accumulators in VGPRs: the tanh/split reads them directly (no v_accvgpr_read per value)
             extra = list(VGPR_FORM) + (["-DGBNF_V_TRAIN=1"] if v[0] == "hx3t" else [])
         else:
             vsrc, vargs = os.path.join(HERE, "variant.hip"), v
-        if args.force or not newer(o, [vsrc] + hdr + ([os.path.join(HERE, "gbnf_train_bwd.hip.h")] if v[0] == "hx3b" else [])):
+        if args.force or not newer(o, [vsrc] + hdr + ([os.path.join(HERE, "gbnf_train_bwd.hip.h")] if v[0] == "hx3b" else [])
+                                   + ([os.path.join(HERE, "gbnf_flow_kernel_coop.hip.h")] if v[0] == "coop" else [])):
             jobs.append([HIPCC] + FLAGS + extra + ["-DGBNF_V_ARGS=" + ",".join(str(a) for a in vargs), "-c", vsrc, "-o", o])
     img_o, img_src = os.path.join(OBJ, "gbnf_image.o"), os.path.join(HERE, "gbnf_image.hip")
     objs.append(img_o)
@@ -188,7 +197,7 @@ def main(argv=None):
     if jobs:
         print(f"[gbnf build] compiling {len(jobs)} object(s) with -j{args.j}", flush=True)
         with cf.ThreadPoolExecutor(max_workers=args.j) as ex:
-            for _ in ex.map(lambda c: compile_hx3(c) if ("variant_hx3" in " ".join(c) or "variant_bwd" in " ".join(c)) else compile_and_lint(c), jobs):
+            for _ in ex.map(lambda c: compile_hx3(c) if ("variant_hx3" in " ".join(c) or "variant_bwd" in " ".join(c) or "variant_coop" in " ".join(c)) else compile_and_lint(c), jobs):
                 pass
     if jobs or not os.path.exists(LIB):
         run([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs + ["-ldl"])

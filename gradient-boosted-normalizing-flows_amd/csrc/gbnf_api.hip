@@ -93,6 +93,10 @@ struct gbnf_flow {
   int var_ht = 0, var_ksl = 0, var_ks1 = 0, var_ot = 0;  // geometry of the compiled variant the blob was packed for
   gbnf::LaunchFn launch_nt[3] = {nullptr, nullptr, nullptr};  // index = NT
   const char* name_nt[3] = {nullptr, nullptr, nullptr};
+  // f16x3 handles of a depth-1 TanhNet / ReLUNet whose geometry has a cooperative (latency-form) variant: the same blob on
+  // flow_kernel_coop (csrc/gbnf_flow_kernel_coop.hip.h), taken by launch_flow for calls of a few sample tiles (pick_coop)
+  gbnf::LaunchFn launch_coop_nt[4] = {nullptr, nullptr, nullptr, nullptr};      // index = form: 1 = 16-sample tiles / 4 waves, 2 = 32 / 4, 3 = 32 / 8
+  const char* name_coop_nt[4] = {nullptr, nullptr, nullptr, nullptr};
   uint32_t* blob_dev = nullptr;
   const uint32_t** self_table_dev = nullptr;  // 1-entry blob table for single-flow launches
   size_t blob_words = 0;
@@ -151,6 +155,7 @@ unsigned* saturation_counter() {
 // ---- launch-policy knobs (gbnf_tuning_set / _get; initialised from the environment at first use)
 struct Tuning {
   std::atomic<int> force_nt{0}, wg_pairs{-1}, repair{1}, nt2_min_waves{1024}, check_every{256}, check_tolerance_e9{2500};
+  std::atomic<int> coop{-1}, coop_max_wgs{256};        // latency-form kernel: -1 automatic, 0 never, 1 / 2 / 3 always form 1 / 2 / 3
   Tuning() {
     auto env = [](const char* k) -> const char* { return getenv(k); };
     if (const char* e = env("GBNF_FORCE_NT")) force_nt = atoi(e);
@@ -169,6 +174,8 @@ static std::atomic<int>* tuning_slot(const char* key) {
   Tuning& t = tuning();
   if (!key) return nullptr;
   if (!strcmp(key, "force_nt")) return &t.force_nt;
+  if (!strcmp(key, "coop")) return &t.coop;
+  if (!strcmp(key, "coop_max_wgs")) return &t.coop_max_wgs;
   if (!strcmp(key, "wg_pairs")) return &t.wg_pairs;
   if (!strcmp(key, "repair")) return &t.repair;
   if (!strcmp(key, "nt2_min_waves")) return &t.nt2_min_waves;
@@ -917,6 +924,14 @@ int gbnf_flow_create_ex(const gbnf_flow_desc* desc, int32_t math_mode, int32_t f
     f->var_ht = vc.ht; f->var_ksl = vc.ksl; f->var_ks1 = vc.ks1; f->var_ot = vc.ot;
     for (int nt = 1; nt <= 2; ++nt) { f->launch_nt[nt] = vc.launch_nt[nt]; f->name_nt[nt] = vc.name_nt[nt]; }
     f->macs = pb.macs; f->padded_macs = pb.padded; f->blob_words = pb.words.size();
+    if (mode == GBNF_MATH_F16X3 && vc.hx3 && depth == 1 && !ref.residual) {
+      // the latency form reads the SAME blob: a variant of exactly the packed geometry and activation key
+      for (int nt = 1; nt <= 3; ++nt) {
+        const Variant* v = find_variant(VariantKey{desc->kind, vc.ht, -13, 0, vc.ot, nt, 1, act_a_split, act_b_split});
+        f->launch_coop_nt[nt] = v ? v->fn : nullptr;
+        f->name_coop_nt[nt] = v ? v->name : nullptr;
+      }
+    }
     return upload_blob(pb.words, &f->blob_dev, &f->self_table_dev);
   };
   auto install_secondary = [&](const VariantChoice& vc, const PackedBlob& pb) -> hipError_t {
@@ -967,6 +982,7 @@ int gbnf_flow_create_ex(const gbnf_flow_desc* desc, int32_t math_mode, int32_t f
       f->padded_macs = f->padded_macs2;
       f->var_ht = f->var2_ht; f->var_ot = f->var2_ot; f->var_ksl = -6;
       f->math_mode = GBNF_MATH_BF16X6;
+      for (int nt = 1; nt <= 3; ++nt) { f->launch_coop_nt[nt] = nullptr; f->name_coop_nt[nt] = nullptr; }
       // the f16x3 packing is of no further use
       (void)hipFree(f->blob2_dev); (void)hipFree(f->self_table2_dev);
       f->blob2_dev = nullptr; f->self_table2_dev = nullptr; f->blob2_words = 0;
@@ -1015,6 +1031,22 @@ static int pick_nt(int64_t n, int n_comp) {
   if (forced == 1 || forced == 2) return forced;
   const int64_t waves32 = ((n + 31) / 32) * n_comp;
   return waves32 >= tuning().nt2_min_waves.load(std::memory_order_relaxed) ? 2 : 1;
+}
+
+// The latency form (flow_kernel_coop: the waves of a workgroup share ONE sample tile) pays off while every workgroup gets a CU to
+// itself: one component's weights then stream through that CU's L2 port once per tile, whatever the tile's size -- that stream
+// (~35 B/clk per CU, 1.5 MB per MINIBOONE component) is what a tile costs.  0 = the throughput kernel; forms 1 / 2 / 3 = 16-sample
+// tiles on 4 waves / 32-sample tiles on 4 waves / 32-sample tiles on 8 waves: the smallest tile that still fills at most
+// coop_max_wgs workgroups (more CUs at work), 32-sample tiles on eight waves (the same bytes per workgroup, twice the waves under it).
+static int pick_coop(const gbnf_flow* f, int64_t n, int n_comp, int n_batches) {
+  const int mode = tuning().coop.load(std::memory_order_relaxed);
+  if (mode == 0) return 0;
+  if (mode >= 1 && mode <= 3) return f->launch_coop_nt[mode] ? mode : 0;
+  const int64_t max_wgs = tuning().coop_max_wgs.load(std::memory_order_relaxed);
+  const int64_t wg16 = ((n + 15) / 16) * n_comp * n_batches, wg32 = ((n + 31) / 32) * n_comp * n_batches;
+  if (wg16 <= max_wgs && f->launch_coop_nt[1]) return 1;
+  if (wg32 <= max_wgs) return f->launch_coop_nt[3] ? 3 : (f->launch_coop_nt[2] ? 2 : 0);
+  return 0;
 }
 
 #if defined(GBNF_STAMPS) || defined(GBNF_TIMELINE)
@@ -1079,6 +1111,8 @@ static int launch_flow(const gbnf_flow* f, const uint32_t* const* table, const u
   const char* const* names = use_second ? f->name2_nt : f->name_nt;
   int nt = pick_nt(n * n_batches, n_comp);
   if (launch[nt] == nullptr) nt = 1;                // geometry compiled for 16-sample waves only
+  // a call of a few sample tiles: the latency form (forward, f16x3 only; its repair launch is the bf16x6 kernel's as ever)
+  const int coop_nt = (mode == GBNF_MATH_F16X3 && !use_second && !inverse) ? pick_coop(f, n, n_comp, n_batches) : 0;
   // (Launch geometry, measured in round 5 and NOT shipped: a group whose last round of 32-sample waves is a quarter full -- one
   //  rank of eight at the driver's --steps 20: 20 batches x 4096 rows x 1 component = 2560 waves = 1.25 rounds of 2048 -- split
   //  by whole batches into the full rounds + the rest as a second launch of 16-sample waves over every CU: 118.9 + 48.8 us
@@ -1102,8 +1136,8 @@ static int launch_flow(const gbnf_flow* f, const uint32_t* const* table, const u
 #endif
   p.sat = reinterpret_cast<unsigned long long*>(saturation_counter());
   p.seq = next_serial();
-  hipError_t e = launch[nt](p, (unsigned)grid, stream);
-  if (e != hipSuccess) return fail(GBNF_ERR_HIP, "launch of %s failed: %s", names[nt], hipGetErrorString(e));
+  hipError_t e = coop_nt ? f->launch_coop_nt[coop_nt](p, (unsigned)grid, stream) : launch[nt](p, (unsigned)grid, stream);
+  if (e != hipSuccess) return fail(GBNF_ERR_HIP, "launch of %s failed: %s", coop_nt ? f->name_coop_nt[coop_nt] : names[nt], hipGetErrorString(e));
   const bool split_pair = mode == GBNF_MATH_F16X3 && table2 != nullptr && f->launch2_nt[nt] != nullptr;
   if (split_pair && repair_enabled()) {
     FlowLaunch r = p;
@@ -1814,6 +1848,11 @@ static int live_choose(const gbnf_flow_desc* desc, DescInfo& info, VariantChoice
     bool compiled = false;
     for (const Variant& v : variants())
       compiled = compiled || (v.key.ks1 == 1 && v.key.kind == desc->kind && v.key.act_a == info.act_a && v.key.act_b == info.act_b);
+    // (a ResidualNet never takes the per-step-activation variants: they have no skip connection -- RES is a compile-time
+    //  property of the act-2 kernels.  Glow + ResidualNet has no TRAIN variant, so such a descriptor keeps the per-step trainer:
+    //  ADVICE r5)
+    if (!compiled && info.ref.residual)
+      return fail(GBNF_ERR_UNSUPPORTED, "live blob: no TRAIN kernel variant with a skip connection for kind=%d (ResidualNets train on the chained kernels for RealNVP only)", desc->kind);
     if (!compiled) info.act_a = info.act_b = GBNF_ACT_PER_STEP;
   }
   if (!choose_hx3(desc->kind, h, info.ot, depth, info.act_a, info.act_b, -3, vc, /*train=*/1)) {

@@ -127,6 +127,20 @@ constexpr int hx3_waves(int HT, int OT, int NT, int prec, int kind, int act_a, i
   return hx3_reg_estimate(HT, OT, NT, prec, kind, act_a, act_b, depth) <= 248 ? 8 : 4;
 #endif
 }
+#ifndef GBNF_HX3_F16_CHAINS_NT1
+#define GBNF_HX3_F16_CHAINS_NT1 1   // f16x3 running sums per hidden tile of a 16-sample wave: 3 = one per product (round 6, measured: 43.6 us
+                                    // against 41.0 us for the single chain on one log_prob launch at 64-2048 rows: the extra zero-inits and
+                                    // adds cost more than the dependent-MFMA latency they hide -- gpurun_out/latency_ablate.txt); 1 = shipped
+#endif
+#ifndef GBNF_HX3_F16_CHAINS_NT2
+#define GBNF_HX3_F16_CHAINS_NT2 1   // ... of a 32-sample wave (two sample tiles: two chains already)
+#endif
+// f16x3 running sums per hidden tile (flow_kernel_hx3, `HCH`): three for 16-sample waves of the geometries with registers to spare
+// (ResidualNets and the widest nets already spill: they keep the single sum)
+constexpr int hx3_f16_hidden_chains(int HT, int OT, int NT, int kind, int act_a, int act_b, int depth) {
+  if (NT != 1) return GBNF_HX3_F16_CHAINS_NT2;
+  return (act_a != 2 && hx3_reg_estimate(HT, OT, 1, 0, kind, act_a, act_b, depth) <= 200) ? GBNF_HX3_F16_CHAINS_NT1 : 1;
+}
 // minimum waves per SIMD the kernel is compiled for (the register budget): 2 (256 registers) or 1 (512)
 constexpr int hx3_waves_per_simd(int HT, int OT, int NT, int prec, int kind, int act_a, int act_b, int depth = 1, int train = 0) {
   if (hx3_train_wide(HT, OT, NT, prec, kind, act_a, act_b, depth, train)) return 1;
@@ -153,6 +167,7 @@ constexpr int hx3_eff_nt(int HT, int OT, int NT, int prec, int kind, int act_a, 
 #ifndef GBNF_HX3_EDGE
 #define GBNF_HX3_EDGE 1           // 1: the step boundary (coupling epilogue, input normalisation) as direction-specialised straight-line code (+1.3 %)
 #endif
+
 
 // ---- operand splitting ----------------------------------------------------------------------------------------
 // f16: hi = f16(x) (toward zero), mid = f16(x - hi); 4 VALU ops per register pair: the residual x - hi is ONE
@@ -238,6 +253,7 @@ template <> struct Products<3> { static constexpr int N = 6, NACC = 3; static co
 // the running sums of one 16x16 output tile
 template <int NACC>
 struct AccT {
+  static constexpr int N = NACC;
   f32x4 s[NACC];
   __device__ __forceinline__ void init(f32x4 bias) {
     s[0] = bias;
@@ -337,6 +353,16 @@ flow_kernel_hx3(const FlowLaunch p) {
   constexpr int NP = hx3_pieces(PREC);
   constexpr int NPROD = Products<NP>::N;
   using Acc = AccT<Products<NP>::NACC>;
+  // Running sums of a HIDDEN tile (a tile lives for one pass: 3 HC dependent v_mfma per sample tile).  Round 6 experiment
+  // (GBNF_HX3_F16_CHAINS_NT1 = 3): one sum per product, three independent chains for a 16-sample wave alone on its SIMD --
+  // measured SLOWER than the single chain (see the knob): the latency form is not bound by the dependent-MFMA latency.
+  constexpr int HCH = NP == 3 ? 3 : hx3_f16_hidden_chains(HT, OT, NT, KIND, ACTA, ACTB, DEPTH);
+  using AccH = AccT<HCH>;
+  auto acc_of = [](auto n_c, int pr) constexpr {
+    constexpr int NA = decltype(n_c)::value;
+    if constexpr (NA == Products<NP>::NACC) return Products<NP>::ACC[pr];
+    else return pr % NA;
+  };
   constexpr int ZS = 16 * NT + 1;
   constexpr int NNETS = (KIND == GBNF_KIND_REALNVP) ? 2 : 1;
   using LT = Hx3LayoutOf<HT, OT, NP, DEPTH>;          // LT::value: the layout (a static member: usable inside the lambdas below)
@@ -932,12 +958,13 @@ flow_kernel_hx3(const FlowLaunch p) {
         for (int k = 0; k < NP; ++k) asm volatile("" : "+v"(pc[k]));
       };
       // acc[nt] += W . X[nt] for one weight tile (NP pieces) and the B operands of the wave's NT sample tiles
-      auto mac = [&](const Unit& a, const u32x4 (&x)[NT][NP], Acc (&acc)[NT]) {
+      auto mac = [&](const Unit& a, const u32x4 (&x)[NT][NP], auto& acc) {
+        using AT = std::remove_reference_t<decltype(acc[0])>;
 #pragma unroll
         for (int pr = 0; pr < NPROD; ++pr) {
 #pragma unroll
           for (int nt = 0; nt < NT; ++nt) {
-            f32x4& t = acc[nt].s[Products<NP>::ACC[pr]];
+            f32x4& t = acc[nt].s[acc_of(std::integral_constant<int, AT::N>{}, pr)];
             t = mfma_narrow<PREC>(a.w[Products<NP>::W[pr]], x[nt][Products<NP>::X[pr]], t);
             MFMA_ORDER_FENCE();
           }
@@ -999,13 +1026,13 @@ flow_kernel_hx3(const FlowLaunch p) {
               if (tl + 2 < cnt) load_unit(A[(tl + 2) % 3], tl + 2);
               const f32x4 bias_next = ldb(t + 1 < HT ? t + 1 : t);
               if (tl == cnt - 1) stage_finish(1, true);
-              Acc cur[NT];
+              AccH cur[NT];
 #pragma unroll
               for (int nt = 0; nt < NT; ++nt) cur[nt].init(bias);
               // first product, then the previous tile's activation + split, then the rest
 #pragma unroll
               for (int nt = 0; nt < NT; ++nt) {
-                f32x4& t0_ = cur[nt].s[Products<NP>::ACC[0]];
+                f32x4& t0_ = cur[nt].s[acc_of(std::integral_constant<int, HCH>{}, 0)];
                 t0_ = mfma_narrow<PREC>(A[tl % 3].w[Products<NP>::W[0]], zp[nt][Products<NP>::X[0]], t0_);
                 MFMA_ORDER_FENCE();
               }
@@ -1014,7 +1041,7 @@ flow_kernel_hx3(const FlowLaunch p) {
               for (int pr = 1; pr < NPROD; ++pr)
 #pragma unroll
                 for (int nt = 0; nt < NT; ++nt) {
-                  f32x4& tp = cur[nt].s[Products<NP>::ACC[pr]];
+                  f32x4& tp = cur[nt].s[acc_of(std::integral_constant<int, HCH>{}, pr)];
                   tp = mfma_narrow<PREC>(A[tl % 3].w[Products<NP>::W[pr]], zp[nt][Products<NP>::X[pr]], tp);
                   MFMA_ORDER_FENCE();
                 }
@@ -1125,7 +1152,7 @@ flow_kernel_hx3(const FlowLaunch p) {
               A[0] = N0;
               A[1] = N1;
               const f32x4 bias_next = ldb(J * HT + (u + 1 < HT ? u + 1 : u));
-              Acc acc[NT];
+              AccH acc[NT];
 #pragma unroll
               for (int nt = 0; nt < NT; ++nt) acc[nt].init(bias);
               __builtin_amdgcn_sched_barrier(0);
@@ -1186,7 +1213,7 @@ flow_kernel_hx3(const FlowLaunch p) {
           A[1] = N1;
           const f32x4 bias_next = ldb(DEPTH * HT + (u + 1 < HT ? u + 1 : u));
           guard_at(5);
-          Acc acc[NT];
+          AccH acc[NT];
 #pragma unroll
           for (int nt = 0; nt < NT; ++nt) acc[nt].init(bias);
           __builtin_amdgcn_sched_barrier(0);

@@ -770,3 +770,35 @@ def test_weight_gradients_are_additive_over_the_batch_at_full_size(kind, d, h, K
             continue
         scale = max(float(b.abs().max()), 1e-3)
         assert float((a - b).abs().max()) <= G_RTOL * scale, f"{kind}: gradient {k} shape {tuple(b.shape)}: {float((a - b).abs().max())} vs scale {scale}"
+
+
+@pytest.mark.parametrize("d,h,K,n,blocks", [(43, 215, 2, 129, 1), (21, 64, 3, 77, 2), (8, 250, 2, 33, 1)])
+def test_a_glow_residualnet_descriptor_keeps_the_per_step_trainer(d, h, K, n, blocks):
+    """gbnf.h is a public ABI, and a Glow descriptor whose coupling net is a ResidualNet -- a combination the
+    Python front end rejects and the reference cannot construct -- used to be matched to the per-step-activation
+    TRAIN variants, which have no skip connection: silently wrong values and gradients.  live_choose now refuses (no act-2 TRAIN
+    variant exists for kind GLOW), so the trainer keeps the round-1 per-step kernels: no live blob, forward and gradients
+    against the float64 oracle."""
+    import torch
+    from gbnf_amd import native, synth
+    from oracle import gbnf_oracle as oracle
+    dev = torch.device("cuda:0")
+    spec = synth.synth_glow_spec(d, h, K, seed=31)
+    rng = np.random.RandomState(32)
+    for st in spec["steps"]:
+        st["net"] = synth._res_net(rng, d // 2, 2 * (d - d // 2), h, blocks, 1.0)
+    xs = synth.synth_batch(n, d, seed=33)
+    g_z = rng.standard_normal(xs.shape).astype(np.float32)
+    g_l = rng.standard_normal(n).astype(np.float32)
+    tr = native.NativeTrainer(_dev_spec(spec, dev))
+    assert not _has_live_blob(tr)
+    x = torch.from_numpy(xs).to(dev)
+    z, ldj, trace = tr.forward(x, want_trace=True)
+    z64, ldj64 = oracle.component_forward(spec, xs, backend="numpy64")
+    assert np.abs(ldj.cpu().numpy() - ldj64).max() <= 1e-5 * max(1.0, float(np.abs(ldj64).max()))
+    assert np.abs(z.cpu().numpy() - z64).max() <= 2e-5 * max(1.0, float(np.abs(z64).max()))
+    gx64, grads64 = oracle.component_grads(spec, xs, g_z, g_l)
+    gx, grads = tr.backward(x, torch.from_numpy(g_z).to(dev), torch.from_numpy(g_l).to(dev), want_gx=True, trace=trace)
+    assert _last_path(tr) == (0, 0)
+    _check_grads(grads, grads64, f"glow residual d={d} h={h} K={K} n={n}")
+    assert np.abs(gx.cpu().numpy() - gx64).max() <= G_RTOL * max(float(np.abs(gx64).max()), 1e-3)
