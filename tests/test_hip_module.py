@@ -313,6 +313,7 @@ def test_evaluate_loop_is_served_from_one_launch(golden_case):
     m.component = g.n_used - 1
     m.eval()
     x = torch.from_numpy(g.x).to(dev)
+    m.SERVE_ALL_COMPONENTS = "any"                          # the liberal form (what `with m.serving_loop():` sets); the default: next test
     G = _evaluate_like_reference(m, x)                      # grad mode ON, as in the reference's evaluate()
     assert rel_err(G.cpu().numpy(), g.G) < LL_RTOL
     tab = m.__dict__["_component_table"]
@@ -327,7 +328,7 @@ def test_evaluate_loop_is_served_from_one_launch(golden_case):
     # the table holds what the per-component launches return, bit for bit
     m.SERVE_ALL_COMPONENTS = False
     z1p, _, _, l1p, _ = m(x=x, components=1)
-    m.SERVE_ALL_COMPONENTS = True
+    m.SERVE_ALL_COMPONENTS = "any"
     assert torch.equal(z1, z1p) and torch.equal(l1, l1p)
     # (1) x written in place: same address, new version -> a new table with the new values
     x.add_(0.125)
@@ -335,7 +336,7 @@ def test_evaluate_loop_is_served_from_one_launch(golden_case):
     assert m.__dict__["_component_table"] is not tab
     m.SERVE_ALL_COMPONENTS = False
     z1q, _, _, l1q, _ = m(x=x, components=1)
-    m.SERVE_ALL_COMPONENTS = True
+    m.SERVE_ALL_COMPONENTS = "any"
     assert torch.equal(z1b, z1q) and torch.equal(l1b, l1q) and not torch.equal(l1b, l1)
     # (2) an optimiser step on component 1 between two calls of the same batch
     tab2 = m.__dict__["_component_table"]
@@ -350,7 +351,7 @@ def test_evaluate_loop_is_served_from_one_launch(golden_case):
     m.SERVE_ALL_COMPONENTS = False
     _, _, _, l0p, _ = m(x=x, components=0)
     _, _, _, l1r, _ = m(x=x, components=1)
-    m.SERVE_ALL_COMPONENTS = True
+    m.SERVE_ALL_COMPONENTS = "any"
     assert torch.equal(l0c, l0p) and torch.equal(l1c, l1r)
     # (2b) a write through .data moves neither the version counter nor the address (PyTorch semantics): invalidate_packed() is the
     #      documented way to make such a write visible to the evaluation handles
@@ -374,7 +375,7 @@ def test_evaluate_loop_is_served_from_one_launch(golden_case):
     _, _, _, l1b2, _ = m(x=x, components=1)
     m.SERVE_ALL_COMPONENTS = False
     _, _, _, l1b2p, _ = m(x=x, components=1)
-    m.SERVE_ALL_COMPONENTS = True
+    m.SERVE_ALL_COMPONENTS = "any"
     assert torch.equal(l1b2, l1b2p) and not torch.equal(l1b2, l1a)
     with torch.no_grad():
         perm.indices.copy_(old_idx.to(perm.indices.device))          # in place: same tensor object, new version
@@ -386,3 +387,69 @@ def test_evaluate_loop_is_served_from_one_launch(golden_case):
     m.drop_component_table()
     m(x=x, components=1)
     assert "_component_table" not in m.__dict__
+
+
+def test_the_default_cache_serves_one_loop_and_nothing_else(golden_case):
+    """VERDICT r5 item 9 / ADVICE r4: by default the table of a batch lives for ONE pass of the evaluate loop -- started by the call
+    for component 0, every entry handed out once in the loop's order, dropped with the last one.  A write that bypasses the version
+    counter between two loops (x.data.copy_) is therefore seen; repeated and out-of-order calls take the plain path; the views a
+    caller gets are never handed out again."""
+    import torch
+    dev = torch.device("cuda:0")
+    g = golden_case("g2_glow_native_d43_h32_c3")
+    m = _model_from_case(g, dev)
+    m.component = g.n_used - 1
+    m.eval()
+    assert m.SERVE_ALL_COMPONENTS is True
+    x = torch.from_numpy(g.x).to(dev)
+    # one loop: one table, gone when the last component has been served
+    z0, _, _, l0, _ = m(x=x, components=0)
+    tab = m.__dict__["_component_table"]
+    assert tab.next_c == 1 and tab.z.shape[0] == g.n_used
+    outs = [(z0, l0)]
+    for c in range(1, g.n_used):
+        zc, _, _, lc, _ = m(x=x, components=c)
+        assert zc.data_ptr() == tab.z[c].data_ptr()         # served from the table (a view of it)
+        outs.append((zc, lc))
+    assert "_component_table" not in m.__dict__
+    G = _evaluate_like_reference(m, x)
+    assert rel_err(G.cpu().numpy(), g.G) < LL_RTOL and "_component_table" not in m.__dict__
+    # the same loop again after a write that moves NO version counter: fresh values
+    x.data.copy_(x.data + 0.25)
+    l_new = [m(x=x, components=c)[3] for c in range(g.n_used)]
+    m.SERVE_ALL_COMPONENTS = False
+    l_plain = [m(x=x, components=c)[3] for c in range(g.n_used)]
+    m.SERVE_ALL_COMPONENTS = True
+    for c in range(g.n_used):
+        assert torch.equal(l_new[c], l_plain[c]) and not torch.equal(l_new[c], outs[c][1])
+    # `x.data = other`: the same tensor object and version on other storage, in the MIDDLE of a loop -- the early look-up compares the address
+    m(x=x, components=0)
+    other = (x.data * 0.5).contiguous()
+    keep = x.data
+    x.data = other
+    _, _, _, l1_other, _ = m(x=x, components=1)
+    m.SERVE_ALL_COMPONENTS = False
+    _, _, _, l1_ref, _ = m(x=x, components=1)
+    m.SERVE_ALL_COMPONENTS = True
+    assert torch.equal(l1_other, l1_ref)
+    x.data = keep
+    # a repeated / out-of-order component is not served from a table (and ends the loop's table)
+    m(x=x, components=0)
+    assert "_component_table" in m.__dict__
+    a = m(x=x, components=2)
+    assert "_component_table" not in m.__dict__
+    b = m(x=x, components=2)
+    assert a[0].data_ptr() != b[0].data_ptr() and torch.equal(a[0], b[0])
+    # a served view is the caller's own: editing it changes nothing anybody else will ever get
+    z0, _, _, _, _ = m(x=x, components=0)
+    z1, _, _, _, _ = m(x=x, components=1)
+    z1_before = z1.clone()
+    z1.zero_()
+    z1_again = m(x=x, components=1)[0]                      # (a repeated call: plain path)
+    assert torch.equal(z1_again, z1_before)
+    # the scoped liberal form
+    with m.serving_loop():
+        m(x=x, components=1)
+        p = m(x=x, components=1)
+        assert m(x=x, components=1) is p and "_component_table" in m.__dict__
+    assert "_component_table" not in m.__dict__ and m.SERVE_ALL_COMPONENTS is True
