@@ -568,15 +568,8 @@ def main():
         # event hand-over costs ~20 us of latency on this stack)
         pipe = None
         want_library = args.pipeline == "library" or (args.pipeline == "auto" and world == 1)
-        if gather and want_library and world > 1:
-            # agree BEFORE anything collective is attempted: a local probe on every rank (librccl loadable, an id obtainable),
-            # the flags meet in one all_reduce(MIN); only a unanimous yes goes on to build communicators
-            ok, why = native.Comm.probe()
-            okt = torch.tensor([1 if ok else 0], dtype=torch.int32, device=dev)
-            dist.all_reduce(okt, op=dist.ReduceOp.MIN)
-            if int(okt.item()) == 0:
-                want_library = False
-                pipeline_used["fallback_reason"] = why or "another rank cannot load RCCL"
+        # (the ranks agree inside native.Comm.from_torch_distributed -- a local probe on every rank, the flags meet in one all_reduce(MIN)
+        #  before anything of the communicator set-up can block, and a refusal raises on EVERY rank: no second hand-shake here)
         if gather and want_library:
             # round 4: the exchange inside the library -- per group ONE hipGraphLaunch of {flow, repair, ncclAllGather, recursion}
             # (sharded.LibraryGroupPipeline); a refused communicator / capture falls back to the torch.distributed pipeline

@@ -1735,7 +1735,7 @@ int gbnf_trainer_create(const gbnf_flow_desc* desc, gbnf_trainer** out) {
   }
   // the register-chained forward sweep where a TRAIN variant of the evaluation kernel covers the geometry (else the
   // kernels of this file do the forward too)
-  if (chained_shape) {       // TanhNet / ReLUNet of depth 0, 1, 2; one-block ResidualNets
+  if (chained_shape) {       // TanhNet / ReLUNet of depth 0, 1, 2; RealNVP ResidualNets of one or two blocks (live_choose refuses what has no TRAIN variant)
     LiveBlob* lb = nullptr;
     std::vector<int64_t> goff(2 * (size_t)K);
     for (int k = 0; k < K; ++k) { goff[2 * k] = steps[k].g_na; goff[2 * k + 1] = steps[k].g_nb; }

@@ -102,18 +102,18 @@ __device__ __forceinline__ float bwd_sum16(float v) {
 // Waves per SIMD the 4-wave form is compiled for: 2 (256 registers, two workgroups share a CU and cover each other's memory
 // latency: 498 -> 3xx us at N = 65536) where the kernel fits -- its register count is 8 per hidden tile (the saved second-layer
 // activations and the split g_a2 operands) + ~125 (measured: HT = 14 -> 235) -- else 1 (512 registers).
-constexpr int bwd_hx3_occupancy(int KIND, int HT, int OT, int DEPTH = 1, bool RES = false) {
+constexpr int bwd_hx3_occupancy(int KIND, int HT, int OT, int DEPTH = 1) {
 #ifdef GBNF_BWD_OCC
   return GBNF_BWD_OCC;
 #else
   // (two hidden -> hidden layers: a second set of split gradient operands, 4 registers per hidden tile)
   // (a one-block ResidualNet at 7 hidden tiles spills 65 registers with two waves per SIMD and is still 12 % faster than with one:
   //  measured 0.98 against 1.10 ms of backward + wgrad at N = 65536 -- the skip tiles are NOT counted here)
-  return (DEPTH >= 2 ? 12 : 8) * HT + ((void)RES, 0) + (DEPTH == 4 ? 60 : 0) + 125 + (KIND == GBNF_KIND_REALNVP ? 8 * OT + 8 : 0) <= 250 ? 2 : 1;
+  return (DEPTH >= 2 ? 12 : 8) * HT + (DEPTH == 4 ? 60 : 0) + 125 + (KIND == GBNF_KIND_REALNVP ? 8 * OT + 8 : 0) <= 250 ? 2 : 1;
 #endif
 }
 template <int KIND, int HT, int OT, int ACTA, int ACTB, int WV, int DEPTH = 1>
-__global__ void __launch_bounds__(64 * WV, WV == 8 ? 2 : bwd_hx3_occupancy(KIND, HT, OT, DEPTH, ACTA == 2)) bwd_kernel_hx3(const FlowLaunch p) {
+__global__ void __launch_bounds__(64 * WV, WV == 8 ? 2 : bwd_hx3_occupancy(KIND, HT, OT, DEPTH)) bwd_kernel_hx3(const FlowLaunch p) {
   static_assert((DEPTH >= 0 && DEPTH <= 2) || (DEPTH == 4 && ACTA == 2), "coupling_network_depth 0, 1 or 2; ResidualNets of one or two blocks");
   // ACT == 2 (GBNF_ACT_RESIDUAL_RELU): a ResidualNet of ONE block (models/layers.py:246-301) = layer 0 -> [relu -> Linear -> relu ->
   // Linear] + layer 0's output -> final layer.  Backward: the final layer's input gradient g_t passes the block's exit unchanged

@@ -934,7 +934,10 @@ class Comm:
         if world == 1:
             return cls(0, 1, cls.unique_id())
         ok, why = cls.probe()
-        dev = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend(group) == "nccl" else torch.device("cpu")
+        # the hand-shake tensor lives where the group can reduce it: a group whose backend string mentions nccl (plain "nccl", or a
+        # composite like "cpu:gloo,cuda:nccl") takes a device tensor, anything else a host tensor
+        use_cuda = "nccl" in str(dist.get_backend(group)).lower() and torch.cuda.is_available()
+        dev = torch.device("cuda", torch.cuda.current_device()) if use_cuda else torch.device("cpu")
         flag = torch.tensor([1 if ok else 0], dtype=torch.int32, device=dev)
         dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=group)
         if int(flag.item()) == 0:

@@ -335,7 +335,7 @@ int gbnf_trainer_destroy(gbnf_trainer* trainer);
  * gbnf_trainer_backward saves that call the forward sweep and the re-splitting of the weights (valid only while the
  * parameters are unchanged and no other forward call of this trainer ran on changed parameters in between).
  * Since round 3 the trace buffer of a flow that runs on the register-chained kernels (TanhNet / ReLUNet coupling nets of
- * coupling_network_depth 0, 1, 2 and one-block ResidualNets -- the depths other than 1 since round 5 -- of a compiled width)
+ * coupling_network_depth 0, 1, 2 and RealNVP ResidualNets of one or two blocks -- all but depth 1 since round 5 -- of a compiled width)
  * is also the OPERAND WORKSPACE of the step: behind the states the forward call stores the coupling nets' inputs, hidden
  * activations and outputs (gbnf_trainer_trace_floats accounts for it: K * nets * (ip + 2 L hp + 2 op) rows of
  * n-rounded-up-to-32 floats, L = hidden layers per net -- 20 KB per sample for MINIBOONE, K = 5, depth 1), and
