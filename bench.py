@@ -128,8 +128,8 @@ def compact_line(out, full_record=FULL_RECORD):
             "fresh_batches": val("fresh_batches"),
             "log_prob_us_per_call": {k: (v.get("us_per_call") if isinstance(v, dict) else None) for k, v in small.items() if k.isdigit()},
             "module_evaluate_loop": val("module_evaluate_loop"), "module_calls_only_ms": val("module_evaluate_loop", "module_calls_only_ms"),
-            "boosted_step_batch512_ms": val("boosted_step_batch512", "ms_per_step"),
-            "boosted_step_batch512_library_ms": val("boosted_step_batch512", "library_ms_per_step"),
+            "boosted_step_batch512_ms": ((lg.get("configs") or {}).get("boosted_step_batch512") or {}).get("ms_per_step"),
+            "boosted_step_batch512_library_ms": ((lg.get("configs") or {}).get("boosted_step_batch512") or {}).get("library_ms_per_step"),
         }
         cfgs = lg.get("configs") or {}
         line["configs"] = {_short(k, 60): ([v.get("value"), (v.get("roofline") or {}).get("frac"), (v.get("roofline") or {}).get("executed_frac")]
@@ -387,6 +387,9 @@ def config_legs(args):
                                                    "--steps", "20", "--warmup", "5", "--cpu-steps", "0", "--no-torch-legs"]),
         ("train_step_miniboone_depth2_c1_n65536", [py, os.path.join(tools, "bench_train.py"), "--config", "miniboone_glow_depth2", "--batch", "65536",
                                                    "--steps", "20", "--warmup", "5", "--cpu-steps", "0", "--no-torch-legs"]),
+        # the reference's OWN training step (density_experiment.py:606-674 at --batch_size 512: weights from the fixed components, resample,
+        # recorded forward, nll, backward, Adam) through the drop-in module, and the library's share of it
+        ("boosted_step_batch512", [py, os.path.join(tools, "bench_boosted_step.py"), "--batch", "512", "--steps", "200"]),
         # configs[4] (MINIBOONE C = 8 sharded one component per GPU) as far as one GPU can show it: ONE rank's share of the 8-GPU
         # run -- one component on every batch, the gather of the full (8, S N) table through the library's RCCL communicator
         # (world size 1: the copy, not the xGMI hop), the recursion -- at the driver's own --steps 20 and in steady state
@@ -397,7 +400,7 @@ def config_legs(args):
     ]
     keep = ("metric", "value", "unit", "dtype", "ms_per_step", "steps", "config", "roofline", "cpu_baseline", "speedup_vs_cpu",
             "max_rel_err_vs_cpu", "numerics_guard", "data", "batch", "stream_launches_value", "forward_kernel_ms", "backward_kernels_ms",
-            "timing")
+            "timing", "library_ms_per_step", "library_weights_ms", "library_forward_ms", "library_backward_ms", "ms_per_step_gpu_events")
     legs = {}
     for name, cmd in jobs:
         t0 = time.perf_counter()

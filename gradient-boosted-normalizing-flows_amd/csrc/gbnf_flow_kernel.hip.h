@@ -46,7 +46,7 @@ constexpr int ZSLOTS = 64;   // features per sample <= 64
 constexpr int NENT = 8;      // per-lane table entries (in: k-steps, out: coupled features)
 constexpr int SMALL_HDR = 16;
 constexpr int SMALL_WORDS = SMALL_HDR + 10 * 4 * NENT;  // header + {slot,p0..p3} x {in,out}
-constexpr int LDS_TABLE_STEPS = 12;  // per-step tables are staged in LDS when K <= this
+constexpr int LDS_TABLE_STEPS = 24;  // per-step tables are staged in LDS when K <= this and they fit (round 6: 12 -> 24, the chained backward sweep needs them there)
 
 // Packed-parameter layout of one coupling network, in 32-bit words (host packer and kernel
 // share it).  HT = hidden tiles of 16 units, KS1 = first-layer k-steps, OT = output tiles of

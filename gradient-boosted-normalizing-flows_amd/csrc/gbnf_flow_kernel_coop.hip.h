@@ -36,6 +36,9 @@ namespace gbnf {
 #ifndef GBNF_COOP_HOIST_TABLES
 #define GBNF_COOP_HOIST_TABLES 1   // 1: a step's lane tables are loaded ahead of the barrier in front of their use
 #endif
+#ifndef GBNF_COOP_XB_ALL
+#define GBNF_COOP_XB_ALL 0         // 1: four-wave forms read every chunk of layer 0's activations once per layer, all reads in flight at its top (measured: 21.9 vs 21.1 us, no gain)
+#endif
 #ifndef GBNF_COOP_RING
 #define GBNF_COOP_RING 16          // weight fragments (1 KiB each) a wave keeps in flight
 #endif
@@ -438,6 +441,28 @@ __global__ void __launch_bounds__(64 * WV, 1) flow_kernel_coop(const FlowLaunch 
 #else
       // ---- hidden layer: this wave's tiles, one chunk (two tiles) at a time, over all HC contraction chunks
       u32x4 hO[CPW][NT][NP];
+#if GBNF_COOP_XB_ALL
+      // one wave per SIMD (512 registers): every chunk's B operand is read ONCE, all reads in flight at the top of the layer
+      constexpr bool XB_ALL = WAVES == 4;
+#else
+      constexpr bool XB_ALL = false;
+#endif
+      u32x4 xBall[XB_ALL ? HC : 1][NT][NP];
+      if constexpr (XB_ALL) {
+#pragma unroll
+        for (int c = 0; c < HC; ++c)
+#pragma unroll
+          for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+            for (int k = 0; k < NP; ++k) xBall[c][nt][k] = *reinterpret_cast<const u32x4*>(actb + ((c * NT + nt) * NP + k) * 256 + lane_w4);
+        // (pinned HERE: left alone, LLVM sinks every read back down to the MFMA that consumes it)
+#pragma unroll
+        for (int c = 0; c < HC; ++c)
+#pragma unroll
+          for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+            for (int k = 0; k < NP; ++k) asm volatile("" : "+v"(xBall[c][nt][k]));
+      }
 #pragma unroll
       for (int grp = 0; grp < CPW; ++grp) {
         f32x4 acc[2][NT];
@@ -454,7 +479,10 @@ __global__ void __launch_bounds__(64 * WV, 1) flow_kernel_coop(const FlowLaunch 
 #pragma unroll
           for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
-            for (int k = 0; k < NP; ++k) xB[nt][k] = *reinterpret_cast<const u32x4*>(actb + ((c * NT + nt) * NP + k) * 256 + lane_w4);
+            for (int k = 0; k < NP; ++k) {
+              if constexpr (XB_ALL) xB[nt][k] = xBall[c][nt][k];
+              else xB[nt][k] = *reinterpret_cast<const u32x4*>(actb + ((c * NT + nt) * NP + k) * 256 + lane_w4);
+            }
 #pragma unroll
           for (int jj = 0; jj < 2; ++jj) {
             u32x4 w[NP];

@@ -1671,7 +1671,7 @@ static hipError_t hx3_launch_wv(FlowLaunch p, bool staggered, hipStream_t s) {
       const int pairs = tuning_wg_pairs();       /* -1 automatic, 0 never, 1 whenever they fit (gbnf_tuning_set) */        \
       /* two 4-wave workgroups per CU where they fit: 80 KB each, tables included */                        \
       const bool fits4 = flow_hx3_lds_bytes(p0.n_steps, ENT, 4, L.STAGE_FRAGS, L.BIAS_FRAGS, p0.d, HX3_RING,  \
-                                            p0.n_steps <= LDS_TABLE_STEPS) <= 80 * 1024;                    \
+                                            p0.n_steps <= 12) <= 80 * 1024;  /* (tables of 13 .. LDS_TABLE_STEPS steps: in LDS only if they fit beside the pair form) */                    \
       /* a lone wave per SIMD runs a stage in half the time of two sharing it (profiles/r2_ubench_pingpong.txt): 4-wave        \
          workgroups spread the same waves over twice the CUs.  Round 5: ALWAYS where they fit, not only from 1024 waves on --  \
          at the reference's own batch sizes (density_experiment.py:80-81: 512 rows to train on, 1024 to evaluate) one           \

@@ -72,6 +72,7 @@ def _worst_case_record(b):
                                      "4096": {"value": 2.0e7 / 3, "us_per_call": 90.123456}, "note": long}
     legs["configs"] = {f"some_other_baseline_configuration_with_a_long_name_{i:02d}_n65536": dict(child) for i in range(16)}
     legs["configs"]["failed_leg"] = {"error": long}
+    legs["configs"]["boosted_step_batch512"] = {"value": 4.5e5, "ms_per_step": 1.13, "library_ms_per_step": 0.31, "note": long}
     return {"metric": "density-eval samples/sec, Boosted-Glow C=8 MINIBOONE d=43", "value": 74451234.56789, "unit": "samples/s", "n_gpus": 8,
             "steps": 4096, "warmup": 64, "ms_per_step": 0.0550212345, "prewarm_s": 0.3, "higher_is_better": True,
             "timing": {"repetitions": 21, "value_from": "median repetition", "elapsed_ms_median": 1.1, "elapsed_ms_min": 1.0, "elapsed_ms_max": 1.3,
@@ -107,6 +108,10 @@ def test_the_drivers_line_stays_short_whatever_the_run_measured():
     rec["legs"]["configs"] = dict(list(rec["legs"]["configs"].items())[:8])
     j = json.loads(b.compact_line(rec))
     assert "dropped_for_length" not in j and len(j["configs"]) == 8 and j["legs_summary"]["group1"][0] > 0
+    assert j["legs_summary"]["boosted_step_batch512_library_ms"] is None      # (that leg was cut from this record with the other eight)
+    rec["legs"]["configs"]["boosted_step_batch512"] = {"value": 4.5e5, "ms_per_step": 1.13, "library_ms_per_step": 0.31}
+    j = json.loads(b.compact_line(rec))
+    assert j["legs_summary"]["boosted_step_batch512_library_ms"] == 0.31 and j["legs_summary"]["boosted_step_batch512_ms"] == 1.13
     # a sharded line (no legs, no cpu baseline) is just as parseable
     rec = _worst_case_record(b)
     del rec["legs"]

@@ -802,3 +802,31 @@ def test_a_glow_residualnet_descriptor_keeps_the_per_step_trainer(d, h, K, n, bl
     assert _last_path(tr) == (0, 0)
     _check_grads(grads, grads64, f"glow residual d={d} h={h} K={K} n={n}")
     assert np.abs(gx.cpu().numpy() - gx64).max() <= G_RTOL * max(float(np.abs(gx64).max()), 1e-3)
+
+
+@pytest.mark.parametrize("kind,d,h,K,n", [("glow", 21, 64, 16, 100), ("realnvp", 8, 40, 20, 65)])
+def test_flows_of_more_than_twelve_steps_train_on_the_chained_kernels(kind, d, h, K, n):
+    """the chained backward sweep keeps every step's tables in LDS and refused K > 12 (LDS_TABLE_STEPS); such flows
+    fell back to the round-1 per-step kernels.  Round 6: 24 steps of tables (32 KB) -- one launch each way asserted, gradients against
+    the float64 autograd oracle."""
+    import torch
+    from gbnf_amd import native, synth
+    from oracle import gbnf_oracle as oracle
+    dev = torch.device("cuda:0")
+    spec = (synth.synth_glow_spec(d, h, K, seed=41, gain=0.5) if kind == "glow" else synth.synth_realnvp_spec(d, h, K, seed=41, gain=0.5))
+    xs = synth.synth_batch(n, d, seed=42)
+    rng = np.random.RandomState(43)
+    g_z = rng.standard_normal(xs.shape).astype(np.float32)
+    g_l = rng.standard_normal(n).astype(np.float32)
+    tr = native.NativeTrainer(_dev_spec(spec, dev))
+    assert _has_live_blob(tr)
+    x = torch.from_numpy(xs).to(dev)
+    z, ldj, trace = tr.forward(x, want_trace=True)
+    z64, ldj64 = oracle.component_forward(spec, xs, backend="numpy64")
+    assert np.abs(ldj.cpu().numpy() - ldj64).max() <= 1e-5 * max(1.0, float(np.abs(ldj64).max()))
+    assert np.abs(z.cpu().numpy() - z64).max() <= 2e-5 * max(1.0, float(np.abs(z64).max()))
+    gx64, grads64 = oracle.component_grads(spec, xs, g_z, g_l)
+    gx, grads = tr.backward(x, torch.from_numpy(g_z).to(dev), torch.from_numpy(g_l).to(dev), want_gx=True, trace=trace)
+    assert _last_path(tr) == (1, 1)
+    _check_grads(grads, grads64, f"{kind} K={K}")
+    assert np.abs(gx.cpu().numpy() - gx64).max() <= G_RTOL * max(float(np.abs(gx64).max()), 1e-3)

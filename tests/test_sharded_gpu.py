@@ -104,10 +104,21 @@ def _nccl_pipeline_worker(rank, world, port, name, ret):
         # the same groups again: every launch is already bound, buffers are re-used across the two slots
         outs2 = pipe.log_prob_groups([xs[0:3], xs[3:6], xs[6:7]])
         torch.cuda.synchronize()
-        ref = [mix.log_prob(x, rho)[0] for x in xs]                                      # per-batch launches, no exchange
+        # per-batch launches, no exchange.  Since round 6 the launch policy picks the kernel FORM by the size of the call (the latency
+        # form for calls of a few sample tiles: another summation order of the output layer, 1e-7): a group of three batches and a lone
+        # batch may run different forms.  Bit-equality is the pipeline's property under ONE form (pinned here: the throughput kernel);
+        # under the automatic policy the per-batch results agree to 2e-6 (checked by the caller as `ref_auto`)
+        ref_auto = [mix.log_prob(x, rho)[0] for x in xs]
+        native.tuning_set("coop", 0)
+        outs = pipe.log_prob_groups([xs[0:3], xs[3:6], xs[6:7]])
+        pipe.drain()
+        outs2 = pipe.log_prob_groups([xs[0:3], xs[3:6], xs[6:7]])
+        torch.cuda.synchronize()
+        ref = [mix.log_prob(x, rho)[0] for x in xs]
+        native.tuning_set("coop", -1)
         torch.cuda.synchronize()
         ret[rank] = ([o.cpu().numpy() for o in outs], [o.cpu().numpy() for o in outs2], [r.cpu().numpy() for r in ref],
-                     n_gathers)
+                     n_gathers, [r.cpu().numpy() for r in ref_auto])
     finally:
         dist.destroy_process_group()
 
@@ -123,8 +134,10 @@ def test_group_pipeline_on_rccl_world_size_one():
     mgr = mp.Manager()
     ret = mgr.dict()
     mp.spawn(_nccl_pipeline_worker, args=(1, _free_port(), name, ret), nprocs=1, join=True)
-    outs, outs2, ref, n_gathers = ret[0]
+    outs, outs2, ref, n_gathers, ref_auto = ret[0]
     assert len(outs) == 7 and n_gathers == 3
+    for a, c in zip(outs, ref_auto):
+        assert rel_err(c, a) < 2e-6
     assert rel_err(outs[0], g.G) < 1e-5
     for a, b, c in zip(outs, outs2, ref):
         assert np.array_equal(a, c) and np.array_equal(b, c)
@@ -152,6 +165,10 @@ def _library_pipeline_worker(rank, world, port, name, ret):
         rho = torch.from_numpy(g.rho).to(dev)
         n, d = g.x.shape
         xs = [torch.from_numpy(g.x).to(dev)] + [torch.from_numpy(synth.synth_batch(n, d, seed=40 + k)).to(dev) for k in range(6)]
+        # (bit-equality of grouped and per-batch launches holds under ONE kernel form: the automatic policy of round 6 picks the form by
+        #  the size of the call -- pinned to the throughput kernel here; test_group_pipeline_on_rccl_world_size_one checks the automatic
+        #  policy's per-batch results to 2e-6)
+        native.tuning_set("coop", 0)
         ref = [mix.log_prob(x, rho)[0] for x in xs]                                      # per-batch launches, no exchange
         out = {}
         for graph in (True, False):

@@ -90,9 +90,37 @@ def main():
     ev[1].record(); torch.cuda.synchronize()
     gpu = ev[0].elapsed_time(ev[1]) / a.steps * 1e-3
     prof_note = "GPU-side time between events around the loop (the stream is never empty if host < GPU)"
+    # the library's own share of a step: its three calls in tight loops of their own (host launch cost + GPU time, synchronised at the end):
+    # the sample weights from the fixed components (one mixture launch + the weights kernel), the recorded forward of the component in
+    # training (live re-pack + TRAIN sweep) and its backward (gradient scaling, backward sweep, weight gradients)
+    def loop_ms(fn, iters=200):
+        for _ in range(10):
+            fn()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(iters):
+            fn()
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / iters * 1e3
+    tr = m.native_trainer(C - 1)
+    g_z = torch.randn_like(x)
+    g_l = torch.randn(a.batch, device=dev)
+    with torch.no_grad():
+        lib_w = loop_ms(lambda: m.boosting_weights(x))
+        keep = {}
+
+        def fwd():
+            keep["t"] = tr.forward(x, want_trace=True)
+        lib_f = loop_ms(fwd)
+        lib_b = loop_ms(lambda: tr.backward(x, g_z, g_l, want_gx=False, trace=keep["t"][2]))
     print(json.dumps({"metric": "boosted training step (weights + resample + forward + backward + Adam), MINIBOONE Glow",
+                      "value": a.batch / wall, "unit": "samples/s", "ms_per_step": wall * 1e3,
                       "batch": a.batch, "components": C, "reference_style": a.reference_style, "ms_per_step_wall": wall * 1e3, "ms_per_step_gpu_events": gpu * 1e3,
-                      "samples_per_s": a.batch / wall, "note": prof_note}))
+                      "library_ms_per_step": lib_w + lib_f + lib_b, "library_weights_ms": lib_w, "library_forward_ms": lib_f, "library_backward_ms": lib_b,
+                      "samples_per_s": a.batch / wall, "data": "synthetic", "dtype": "f16x3",
+                      "config": {"workload": f"one boosted training step of density_experiment.py:606-674 at the reference's batch {a.batch} "
+                                             f"(--batch_size, density_experiment.py:80): MINIBOONE Glow d=43 h=215 K=5, component {C} of {C} in training"},
+                      "note": prof_note + "; library_*: the library's three calls of a step in tight loops of their own (host launch cost + GPU time)"}))
 
 
 if __name__ == "__main__":
