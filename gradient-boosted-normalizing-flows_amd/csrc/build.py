@@ -28,8 +28,9 @@ def read_variants():
             if not line:
                 continue
             if line.startswith("coop"):    # the latency form of an hx3 line's f16x3 kernel: coop KIND HT OT ACTA ACTB (depth 1)
-                kind, ht, ot, acta, actb = (int(v) for v in line.split()[1:6])
-                for form in (1, 2, 3):       # 16-sample tiles / 4 waves, 32 / 4, 32 / 8
+                toks = line.split()
+                kind, ht, ot, acta, actb = (int(v) for v in toks[1:6])
+                for form in (int(ch) for ch in (toks[6] if len(toks) > 6 else "123")):       # 1 = 16-sample tiles / 4 waves, 2 = 32 / 4, 3 = 32 / 8
                     out.append(("coop", kind, ht, ot, form, acta, actb))
                 continue
             if line.startswith("hx3"):     # both split precisions: 0 = f16x3, 1 = bf16x6 (its repair pass / safe mode)

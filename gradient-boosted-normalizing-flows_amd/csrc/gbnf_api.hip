@@ -1037,7 +1037,8 @@ static int pick_nt(int64_t n, int n_comp) {
 // itself: one component's weights then stream through that CU's L2 port once per tile, whatever the tile's size -- that stream
 // (~35 B/clk per CU, 1.5 MB per MINIBOONE component) is what a tile costs.  0 = the throughput kernel; forms 1 / 2 / 3 = 16-sample
 // tiles on 4 waves / 32-sample tiles on 4 waves / 32-sample tiles on 8 waves: the smallest tile that still fills at most
-// coop_max_wgs workgroups (more CUs at work), 32-sample tiles on eight waves (the same bytes per workgroup, twice the waves under it).
+// coop_max_wgs workgroups (more CUs at work); of the 32-sample forms the eight-wave one where it is built (csrc/variants.list builds
+// it for the geometries it wins on: Glow from 14 hidden tiles on -- the same bytes per workgroup, twice the waves under them).
 static int pick_coop(const gbnf_flow* f, int64_t n, int n_comp, int n_batches) {
   const int mode = tuning().coop.load(std::memory_order_relaxed);
   if (mode == 0) return 0;

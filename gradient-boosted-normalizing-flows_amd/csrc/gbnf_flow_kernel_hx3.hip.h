@@ -1677,7 +1677,14 @@ static hipError_t hx3_launch_wv(FlowLaunch p, bool staggered, hipStream_t s) {
          at the reference's own batch sizes (density_experiment.py:80-81: 512 rows to train on, 1024 to evaluate) one           \
          log_prob call of the MINIBOONE C = 8 model takes 47.6 us instead of 63.5 (19.9 vs 15.3 M samples/s at 1024 rows,       \
          10.0 vs 7.7 M at 512; tools/bench_latency.py, profiles/r5_latency_small_batches.txt) */                              \
-      if (fits4 && !p0.repair && pairs != 0)                                                                \
+      /* Round 6 (tools/ab_wg8.sh, profiles/r6_ab_workgroup_forms.txt): a LONG launch of a geometry with heavy stages (>= 16 KiB of     \
+         weight fragments per stage: MINIBOONE, 20) runs 1.1-1.3 % faster as ONE 8-wave workgroup per CU -- half the L2 -> LDS    \
+         weight DMA per CU -- than as two 4-wave ones: 78.7 vs 77.8 M samples/s on the headline, 75.1 vs 74.1 M at the driver's    \
+         --steps 20, 154.1 vs 152.3 M at C = 4; short launches (the 1.25-round launch of one rank of eight: 262 vs 226 us) and    \
+         light stages (HEPMASS RealNVP, 10 KiB: 111.3 vs 114.0 M) keep the pairs */                                                \
+      const long long items4 = (long long)((((p0.n + 16 * ENT - 1) / (16 * ENT)) + 3) / 4) * p0.n_comp * p0.n_batches;             \
+      const bool long_heavy = pairs == -1 && !TRAIN && L.STAGE_FRAGS >= 16 && items4 >= 4096;                                      \
+      if (fits4 && !p0.repair && pairs != 0 && !long_heavy)                                                 \
         return hx3_launch_wv<KIND, HT, OT, ENT, ACTA, ACTB, PREC, 4, DEPTH, TRAIN>(p0, true, s);            \
     }                                                                                                       \
     return hx3_launch_wv<KIND, HT, OT, ENT, ACTA, ACTB, PREC, WAVES, DEPTH, TRAIN>(p0, false, s);           \
