@@ -34,13 +34,15 @@ def read_variants():
                     out.append(("coop", kind, ht, ot, form, acta, actb))
                 continue
             if line.startswith("hx3"):     # both split precisions: 0 = f16x3, 1 = bf16x6 (its repair pass / safe mode)
-                vals = [int(v) for v in line.split()[1:]]
+                toks = line.split()[1:]
+                eval_only = toks[-1] == "eval"          # no training sweeps for this geometry (hx3t / hx3b): the trainer keeps the per-step kernels
+                vals = [int(v) for v in (toks[:-1] if eval_only else toks)]
                 kind, ht, ot, acta, actb = vals[:5]
                 depth = vals[5] if len(vals) > 5 else 1          # coupling_network_depth: 0, 1 (default) or 2
                 for nt in (1, 2):
                     for prec in (0, 1):
                         out.append(("hx3", kind, ht, ot, nt, acta, actb, prec, depth))
-                    if True:                     # the training path's forward sweep (f16x3, trace + operand saves): "hx3t", every net
+                    if not eval_only:            # the training path's forward sweep (f16x3, trace + operand saves): "hx3t", every net
                         out.append(("hx3t", kind, ht, ot, nt, acta, actb, 0, depth))     # and depth; 32-sample waves: one per SIMD
                         if nt == 1:
                             out.append(("hx3b", kind, ht, ot, acta, actb, depth))        # ... and its backward sweep

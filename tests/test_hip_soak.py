@@ -31,7 +31,7 @@ def hx3_variants():
         for line in f:
             line = line.split("#")[0].strip()
             if line.startswith("hx3"):
-                v = [int(t) for t in line.split()[1:]]
+                v = [int(t) for t in line.split()[1:] if t.lstrip('-').isdigit()]       # (a trailing `eval`: no training sweeps, csrc/build.py)
                 out.append(tuple(v[:5]) + ((v[5],) if len(v) > 5 else (1,)))
     return sorted(set(out))
 

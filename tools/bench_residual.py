@@ -22,12 +22,13 @@ def main():
     ap.add_argument("--K", type=int, default=5)
     ap.add_argument("--batch", type=int, default=65536)
     ap.add_argument("--iters", type=int, default=30)
+    ap.add_argument("--blocks", type=int, default=1)
     a = ap.parse_args()
     dev = torch.device("cuda:0")
-    specs = synth.synth_boosted_specs("realnvp", a.components, a.d, a.hidden, a.K, seed=1, coupling_network="residual", depth=1)
+    specs = synth.synth_boosted_specs("realnvp", a.components, a.d, a.hidden, a.K, seed=1, coupling_network="residual", depth=a.blocks)
     x = torch.from_numpy(synth.synth_batch(a.batch, a.d, seed=0)).to(dev)
     rho = torch.from_numpy(oracle.rho_init(a.components)).to(dev)
-    out = {"workload": f"Boosted-RealNVP, ResidualNet coupling (1 block), d={a.d} h={a.hidden} K={a.K} C={a.components} batch={a.batch}"}
+    out = {"workload": f"Boosted-RealNVP, ResidualNet coupling ({a.blocks} block(s)), d={a.d} h={a.hidden} K={a.K} C={a.components} batch={a.batch}"}
     ref = None
     for math in ("f32", "f16x3", "bf16x6", "default"):
         flows = [native.NativeFlow(s, math=math) for s in specs]

@@ -3,7 +3,7 @@
 bench lines of every configuration, rocprofv3 kernel stats, the PMC passes, and the traffic tables the bench lines read
 (profiles/headline_traffic.json, image_traffic.json, train_traffic.json).
 
-    python tools/collect_final_profiles.py [round-tag, default r5]
+    python tools/collect_final_profiles.py [round-tag, default r6]
 """
 import csv
 import json
@@ -65,7 +65,7 @@ def traffic_entry(fetch_name, write_name, workload, how):
 
 
 def main():
-    tag = sys.argv[1] if len(sys.argv) > 1 else "r5"
+    tag = sys.argv[1] if len(sys.argv) > 1 else "r6"
     _, d = last_json(os.path.join(F, "bench_default.json"))
     group = d["config"]["group"]
     # ---- headline: kernel stats + PMC
@@ -123,8 +123,9 @@ def main():
                               "FETCH_SIZE_kb_per_step": fi["FETCH_SIZE"] / steps, "WRITE_SIZE_kb_per_step": wi["WRITE_SIZE"] / steps,
                               "traffic_bytes_per_step": (fi["FETCH_SIZE"] * 2048 + wi["WRITE_SIZE"] * 1024) / steps}]}
         json.dump(rec, open(os.path.join(P, "image_traffic.json"), "w"), indent=1)
-        img = [f"# rocprofv3 --kernel-trace --stats of `python3 tools/bench_image.py --batch 256 --cpu-seconds 0 --steps 5 --warmup 2 --no-graph` (CIFAR-shaped Boosted-Glow,",
-               "# C = 4 components on 4 HIP streams, K = 8, L = 2, h = 256), MI355X, end of the round; then the PMC passes (--steps 10 --warmup 2):"]
+        img = [f"# rocprofv3 --kernel-trace --stats of `python3 tools/bench_image.py --batch 256 --cpu-seconds 0 --steps 120 --warmup 5 --no-graph` (CIFAR-shaped Boosted-Glow,",
+               "# C = 4 components on 4 HIP streams, K = 8, L = 2, h = 256), MI355X, end of the round; round 6: 120 + 5 steps, the one-time on-data checks of",
+               "# img_repair_kernel are amortised as in a long run; then the PMC passes (--steps 10 --warmup 2):"]
         img += stats_rows("stats_img")
         img.append("# all gbnf:: kernels of the 12 steps: FETCH_SIZE %.0f KB, WRITE_SIZE %.0f KB => HBM-side traffic per step (2 x FETCH + WRITE) = %.1f MB = %.2f MB per image and component"
                    % (fi["FETCH_SIZE"], wi["WRITE_SIZE"], rec["workloads"][0]["traffic_bytes_per_step"] / 1e6, rec["workloads"][0]["traffic_bytes_per_step"] / 1e6 / 1024))
@@ -150,6 +151,28 @@ def main():
         rows = stats_rows(nm, 12)
         if rows:
             open(os.path.join(P, f"{tag}_final_{nm}.txt"), "w").write(f"# rocprofv3 --kernel-trace --stats: {title}\n" + "\n".join(rows) + "\n")
+    # ---- the latency form: kernel stats of whole log_prob calls + SQ / traffic counters of the bare launch at 512 rows
+    lat = ["# rocprofv3 --kernel-trace --stats of `python3 tools/latency_one.py <n> -1 300 call`: 300 model.log_prob(x) calls (flow launch + its repair",
+           "# launch + recursion launch, default math, the shipped launch policy) of the MINIBOONE Boosted-Glow C = 8 at the reference's batch sizes"]
+    for n_ in (512, 1024):
+        rows = stats_rows(f"stats_latency_n{n_}", 6)
+        if rows:
+            lat += [f"# n = {n_}:"] + rows
+    for f in ("pmc_sq1_latency", "pmc_sq2_latency", "pmc_fetch_latency", "pmc_write_latency"):
+        for nm, v in pmc(f).items():
+            if nm.startswith("void gbnf::flow_kernel_coop"):
+                lat.append(f"# {f}: {nm}  dispatches={v['dispatches']}")
+                lat += ["#      %-32s %16.0f per dispatch" % (k, x) for k, x in v.items() if k != "dispatches"]
+    if len(lat) > 2:
+        txt = os.path.join(F, "latency.txt")
+        if os.path.exists(txt):
+            lat += ["# tools/bench_latency.py (one log_prob call, us) and tools/latency_ablate.py (bare flow launch by kernel form, us):"] + \
+                   ["# " + l for l in open(txt).read().splitlines() if l.startswith(("n =", "shipped"))]
+        open(os.path.join(P, f"{tag}_final_latency_form.txt"), "w").write("\n".join(lat) + "\n")
+    cg = os.path.join(F, "coop_geometries.txt")
+    if os.path.exists(cg):
+        open(os.path.join(P, f"{tag}_final_coop_geometries.txt"), "w").write(
+            "# tools/bench_coop_geometries.py: GPU time (us) of one flow launch per kernel form, geometry and batch size (see profiles/r6_coop_geometries.txt)\n" + open(cg).read())
     inv = os.path.join(F, "image_inverse.txt")
     if os.path.exists(inv):
         keep = [l for l in open(inv).read().splitlines() if l.startswith("one component")]
@@ -166,7 +189,8 @@ def main():
              ("train_hepmass_n65536", "train_step_line_hepmass_n65536"), ("module_eval", "module_evaluate_loop_line"),
              ("train_glow_depth0_n65536", "train_step_line_glow_depth0_n65536"), ("train_glow_depth2_n65536", "train_step_line_glow_depth2_n65536"),
              ("train_hepmass_depth2_n65536", "train_step_line_hepmass_depth2_n65536"),
-             ("train_hepmass_residual_n65536", "train_step_line_hepmass_residual_n65536")]
+             ("train_hepmass_residual_n65536", "train_step_line_hepmass_residual_n65536"),
+             ("boosted_step_n512", "boosted_step_line_n512"), ("bench_full_record_last", "bench_full_record")]
     for src, dst in lines:
         path = os.path.join(F, src + ".json")
         if not os.path.exists(path):
