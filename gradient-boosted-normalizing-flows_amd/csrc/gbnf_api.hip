@@ -95,8 +95,8 @@ struct gbnf_flow {
   const char* name_nt[3] = {nullptr, nullptr, nullptr};
   // f16x3 handles of a depth-1 TanhNet / ReLUNet whose geometry has a cooperative (latency-form) variant: the same blob on
   // flow_kernel_coop (csrc/gbnf_flow_kernel_coop.hip.h), taken by launch_flow for calls of a few sample tiles (pick_coop)
-  gbnf::LaunchFn launch_coop_nt[4] = {nullptr, nullptr, nullptr, nullptr};      // index = form: 1 = 16-sample tiles / 4 waves, 2 = 32 / 4, 3 = 32 / 8
-  const char* name_coop_nt[4] = {nullptr, nullptr, nullptr, nullptr};
+  gbnf::LaunchFn launch_coop_nt[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};      // index = form: 1 = 16-sample tiles / 4 waves, 2 = 32 / 4, 3 = 32 / 8, 4 = 16 / 8
+  const char* name_coop_nt[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
   uint32_t* blob_dev = nullptr;
   const uint32_t** self_table_dev = nullptr;  // 1-entry blob table for single-flow launches
   size_t blob_words = 0;
@@ -926,7 +926,7 @@ int gbnf_flow_create_ex(const gbnf_flow_desc* desc, int32_t math_mode, int32_t f
     f->macs = pb.macs; f->padded_macs = pb.padded; f->blob_words = pb.words.size();
     if (mode == GBNF_MATH_F16X3 && vc.hx3 && depth == 1 && !ref.residual) {
       // the latency form reads the SAME blob: a variant of exactly the packed geometry and activation key
-      for (int nt = 1; nt <= 3; ++nt) {
+      for (int nt = 1; nt <= 4; ++nt) {
         const Variant* v = find_variant(VariantKey{desc->kind, vc.ht, -13, 0, vc.ot, nt, 1, act_a_split, act_b_split});
         f->launch_coop_nt[nt] = v ? v->fn : nullptr;
         f->name_coop_nt[nt] = v ? v->name : nullptr;
@@ -982,7 +982,7 @@ int gbnf_flow_create_ex(const gbnf_flow_desc* desc, int32_t math_mode, int32_t f
       f->padded_macs = f->padded_macs2;
       f->var_ht = f->var2_ht; f->var_ot = f->var2_ot; f->var_ksl = -6;
       f->math_mode = GBNF_MATH_BF16X6;
-      for (int nt = 1; nt <= 3; ++nt) { f->launch_coop_nt[nt] = nullptr; f->name_coop_nt[nt] = nullptr; }
+      for (int nt = 1; nt <= 4; ++nt) { f->launch_coop_nt[nt] = nullptr; f->name_coop_nt[nt] = nullptr; }
       // the f16x3 packing is of no further use
       (void)hipFree(f->blob2_dev); (void)hipFree(f->self_table2_dev);
       f->blob2_dev = nullptr; f->self_table2_dev = nullptr; f->blob2_words = 0;
@@ -1042,7 +1042,7 @@ static int pick_nt(int64_t n, int n_comp) {
 static int pick_coop(const gbnf_flow* f, int64_t n, int n_comp, int n_batches) {
   const int mode = tuning().coop.load(std::memory_order_relaxed);
   if (mode == 0) return 0;
-  if (mode >= 1 && mode <= 3) return f->launch_coop_nt[mode] ? mode : 0;
+  if (mode >= 1 && mode <= 4) return f->launch_coop_nt[mode] ? mode : 0;
   const int64_t max_wgs = tuning().coop_max_wgs.load(std::memory_order_relaxed);
   const int64_t wg16 = ((n + 15) / 16) * n_comp * n_batches, wg32 = ((n + 31) / 32) * n_comp * n_batches;
   if (wg16 <= max_wgs && f->launch_coop_nt[1]) return 1;

@@ -30,8 +30,16 @@
 
 namespace gbnf {
 
+#ifdef GBNF_COOP_ABLATE_BARRIER    // diagnostic: no workgroup barriers inside the step loop (races, timing only)
+#define GBNF_COOP_SYNC() __builtin_amdgcn_wave_barrier()
+#else
+#define GBNF_COOP_SYNC() __syncthreads()
+#endif
 #ifndef GBNF_COOP_L1_JOINT
 #define GBNF_COOP_L1_JOINT 0       // 1: the hidden layer accumulates all of a wave's tiles at once (a chunk's B operands read once); measured slower
+#endif
+#ifndef GBNF_COOP_PR_OUTER
+#define GBNF_COOP_PR_OUTER 1       // 1: the products of the tiles of a group are interleaved (a dependent MFMA is G MFMAs behind its predecessor)
 #endif
 #ifndef GBNF_COOP_HOIST_TABLES
 #define GBNF_COOP_HOIST_TABLES 1   // 1: a step's lane tables are loaded ahead of the barrier in front of their use
@@ -77,6 +85,8 @@ __global__ void __launch_bounds__(64 * WV, 1) flow_kernel_coop(const FlowLaunch 
   constexpr int R = F >= GBNF_COOP_RING ? GBNF_COOP_RING : (F >= 8 ? 8 : 4);       // ring depth (fragments in flight per wave)
   constexpr int FP = (F + R - 1) / R * R;                  // positions per (step, net), padded: the ring slot of a position is the same in every net
   static_assert(N_L0 <= 2, "layer 0 spans at most two stages of the blob");
+  // product-outer MFMA order (see layer 0): measured +4 % for 32-sample tiles, -5 % for 16-sample ones (profiles/r6_latency_ablations.txt)
+  constexpr bool PRO = GBNF_COOP_PR_OUTER != 0 && NT == 2;
 
   extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
   const int lane = threadIdx.x & 63;
@@ -160,7 +170,12 @@ __global__ void __launch_bounds__(64 * WV, 1) flow_kernel_coop(const FlowLaunch 
   // offset as the SCALAR offset -- no vector address arithmetic per load (the global_load form cost two VALU adds per fragment)
   const auto blob_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)p.blobs[p.c_begin + comp], 0, 0x7fffffff, 0x00020000);
   auto fetch_from = [&](int net_words, int pos) {                    // pos < F; net_words: the net block's word offset in the blob (uniform)
+#ifdef GBNF_COOP_ABLATE_LOADS      // diagnostic: every fragment is the blob's first one, loaded once (timing only)
+    if (net_words != SMALL_WORDS) return;
+    ring[pos % R] = __builtin_amdgcn_raw_buffer_load_b128(blob_rsrc, lane_b16, SMALL_WORDS * 4, 0);
+#else
     ring[pos % R] = __builtin_amdgcn_raw_buffer_load_b128(blob_rsrc, lane_b16, (net_words + frag_off(pos)) * 4, 0);
+#endif
   };
 
   // ---- biases of one step (all nets) -> BIAS[buf]; 16 bytes per thread and trip
@@ -325,6 +340,11 @@ __global__ void __launch_bounds__(64 * WV, 1) flow_kernel_coop(const FlowLaunch 
 #pragma unroll
       for (int nt = 0; nt < NT; ++nt) amax[nt] = 0.0f;
       auto act_split = [&](const f32x4& raw, int hp, int nt, unsigned (&pc)[NP]) {
+#ifdef GBNF_COOP_ABLATE_ACT        // diagnostic: no activation, no split (results wrong, timing only)
+        pc[0] = __builtin_bit_cast(unsigned, raw[2 * hp]); pc[1] = __builtin_bit_cast(unsigned, raw[2 * hp + 1]);
+        (void)nt;
+        return;
+#endif
         float a0, a1;
         if (ACTN == GBNF_ACT_TANH) {
           f32x2 e = {__builtin_amdgcn_exp2f(raw[2 * hp]), __builtin_amdgcn_exp2f(raw[2 * hp + 1])};
@@ -353,6 +373,46 @@ __global__ void __launch_bounds__(64 * WV, 1) flow_kernel_coop(const FlowLaunch 
 
       // ---- layer 0: this wave's TPW tiles -> ACT
       u32x4 own[CPW][NT][NP];
+      if constexpr (PRO) {
+      // product-outer order: the three products of a weight tile go to the same accumulator, and a dependent v_mfma whose destination
+      // the register allocator did not keep in place waits out the whole pipeline (+ s_nop); with the products of SEVERAL tiles
+      // interleaved a chain's next link is G MFMAs away
+      {
+        f32x4 acc0[TPW][NT];
+        u32x4 w0[TPW][NP];
+#pragma unroll
+        for (int j = 0; j < TPW; ++j) {
+          const int t = t_first + j;
+#pragma unroll
+          for (int q = 0; q < NP; ++q) { w0[j][q] = take(); refill(); }
+          const f32x4 bias = ldb(t < HT ? t : 0);
+#pragma unroll
+          for (int nt = 0; nt < NT; ++nt) acc0[j][nt] = bias;
+        }
+#pragma unroll
+        for (int pr = 0; pr < 3; ++pr)
+#pragma unroll
+          for (int j = 0; j < TPW; ++j)
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+              acc0[j][nt] = mfma_narrow<0>(w0[j][Products<2>::W[pr]], zp[nt][Products<2>::X[pr]], acc0[j][nt]);
+              MFMA_ORDER_FENCE();
+            }
+#pragma unroll
+        for (int j = 0; j < TPW; ++j) {
+          const bool real = t_first + j < HT;
+#pragma unroll
+          for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+            for (int hp = 0; hp < 2; ++hp) {
+              unsigned pc[NP];
+              act_split(acc0[j][nt], hp, nt, pc);
+#pragma unroll
+              for (int k = 0; k < NP; ++k) own[j / 2][nt][k][2 * (j & 1) + hp] = real ? pc[k] : 0u;
+            }
+        }
+      }
+      } else {
 #pragma unroll
       for (int j = 0; j < TPW; ++j) {
         const int t = t_first + j;
@@ -375,6 +435,7 @@ __global__ void __launch_bounds__(64 * WV, 1) flow_kernel_coop(const FlowLaunch 
             for (int k = 0; k < NP; ++k) own[j / 2][nt][k][2 * (j & 1) + hp] = real ? pc[k] : 0u;
           }
       }
+      }
       uint32_t* actb = ACT + (NNETS > 1 ? (net & 1) * ACT_WORDS : 0);
 #pragma unroll
       for (int cl = 0; cl < CPW; ++cl)
@@ -384,7 +445,7 @@ __global__ void __launch_bounds__(64 * WV, 1) flow_kernel_coop(const FlowLaunch 
           for (int k = 0; k < NP; ++k)
             *reinterpret_cast<u32x4*>(actb + (((CPW * wave + cl) * NT + nt) * NP + k) * 256 + lane_w4) = own[cl][nt][k];
       st.mark(1);
-      __syncthreads();                                    // B1: every chunk of layer 0's activations is in ACT
+      GBNF_COOP_SYNC();                                   // B1: every chunk of layer 0's activations is in ACT
       st.mark(2);
       if (net == 0) {
         if (wave == 0) {
@@ -415,6 +476,22 @@ __global__ void __launch_bounds__(64 * WV, 1) flow_kernel_coop(const FlowLaunch 
           for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
             for (int k = 0; k < NP; ++k) xB[nt][k] = *reinterpret_cast<const u32x4*>(actb + ((c * NT + nt) * NP + k) * 256 + lane_w4);
+      if constexpr (PRO) {
+          u32x4 wj[TPW][NP];
+#pragma unroll
+          for (int j = 0; j < TPW; ++j)
+#pragma unroll
+            for (int q = 0; q < NP; ++q) { wj[j][q] = take(); refill(); }
+#pragma unroll
+          for (int pr = 0; pr < 3; ++pr)
+#pragma unroll
+            for (int j = 0; j < TPW; ++j)
+#pragma unroll
+              for (int nt = 0; nt < NT; ++nt) {
+                acc[j][nt] = mfma_narrow<0>(wj[j][Products<2>::W[pr]], xB[nt][Products<2>::X[pr]], acc[j][nt]);
+                MFMA_ORDER_FENCE();
+              }
+      } else {
 #pragma unroll
           for (int j = 0; j < TPW; ++j) {
             u32x4 w[NP];
@@ -422,6 +499,7 @@ __global__ void __launch_bounds__(64 * WV, 1) flow_kernel_coop(const FlowLaunch 
             for (int q = 0; q < NP; ++q) { w[q] = take(); refill(); }
             mac(w, xB, acc[j]);
           }
+      }
         }
 #pragma unroll
         for (int j = 0; j < TPW; ++j) {
@@ -480,9 +558,29 @@ __global__ void __launch_bounds__(64 * WV, 1) flow_kernel_coop(const FlowLaunch 
           for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
             for (int k = 0; k < NP; ++k) {
+#ifdef GBNF_COOP_ABLATE_XB         // diagnostic: no LDS reads of layer 0's activations (timing only)
+              xB[nt][k] = zp[nt][k];
+              continue;
+#endif
               if constexpr (XB_ALL) xB[nt][k] = xBall[c][nt][k];
               else xB[nt][k] = *reinterpret_cast<const u32x4*>(actb + ((c * NT + nt) * NP + k) * 256 + lane_w4);
             }
+      if constexpr (PRO) {
+          u32x4 wj[2][NP];
+#pragma unroll
+          for (int jj = 0; jj < 2; ++jj)
+#pragma unroll
+            for (int q = 0; q < NP; ++q) { wj[jj][q] = take(); refill(); }
+#pragma unroll
+          for (int pr = 0; pr < 3; ++pr)
+#pragma unroll
+            for (int jj = 0; jj < 2; ++jj)
+#pragma unroll
+              for (int nt = 0; nt < NT; ++nt) {
+                acc[jj][nt] = mfma_narrow<0>(wj[jj][Products<2>::W[pr]], xB[nt][Products<2>::X[pr]], acc[jj][nt]);
+                MFMA_ORDER_FENCE();
+              }
+      } else {
 #pragma unroll
           for (int jj = 0; jj < 2; ++jj) {
             u32x4 w[NP];
@@ -490,6 +588,7 @@ __global__ void __launch_bounds__(64 * WV, 1) flow_kernel_coop(const FlowLaunch 
             for (int q = 0; q < NP; ++q) { w[q] = take(); refill(); }
             mac(w, xB, acc[jj]);
           }
+      }
         }
 #pragma unroll
         for (int jj = 0; jj < 2; ++jj) {
@@ -516,6 +615,22 @@ __global__ void __launch_bounds__(64 * WV, 1) flow_kernel_coop(const FlowLaunch 
         for (int nt = 0; nt < NT; ++nt) outp[o][nt] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
 #pragma unroll
       for (int cl = 0; cl < CPW; ++cl) {
+      if constexpr (PRO) {
+        u32x4 wo[OT][NP];
+#pragma unroll
+        for (int o = 0; o < OT; ++o)
+#pragma unroll
+          for (int q = 0; q < NP; ++q) { wo[o][q] = take(); refill(); }
+#pragma unroll
+        for (int pr = 0; pr < 3; ++pr)
+#pragma unroll
+          for (int o = 0; o < OT; ++o)
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {           // (a phantom chunk's B operand is zero: its products add nothing)
+              outp[o][nt] = mfma_narrow<0>(wo[o][Products<2>::W[pr]], hO[cl][nt][Products<2>::X[pr]], outp[o][nt]);
+              MFMA_ORDER_FENCE();
+            }
+      } else {
 #pragma unroll
         for (int o = 0; o < OT; ++o) {
           u32x4 w[NP];
@@ -523,6 +638,7 @@ __global__ void __launch_bounds__(64 * WV, 1) flow_kernel_coop(const FlowLaunch 
           for (int q = 0; q < NP; ++q) { w[q] = take(); refill(); }
           mac(w, hO[cl], outp[o]);            // (a phantom chunk's B operand is zero: its products add nothing)
         }
+      }
       }
       // the padding positions of the sequence: their look-ahead fetches (the next net's first fragments)
 #pragma unroll
@@ -538,7 +654,7 @@ __global__ void __launch_bounds__(64 * WV, 1) flow_kernel_coop(const FlowLaunch 
           *reinterpret_cast<f32x4*>(RED + (((net * WAVES + wave) * OT + o) * NT + nt) * 256 + lane_w4) = outp[o][nt];
     }
     st.mark(4);
-    __syncthreads();                                      // B2: every wave's partial sums are in RED
+    GBNF_COOP_SYNC();                                     // B2: every wave's partial sums are in RED
     st.mark(5);
 
     // ---- coupling transform of the other half + log-det partials: output tile (o, nt) on wave (o NT + nt) % 4
@@ -598,7 +714,7 @@ __global__ void __launch_bounds__(64 * WV, 1) flow_kernel_coop(const FlowLaunch 
           }
         }
     }
-    __syncthreads();                                      // B3: the step's state is in Z
+    GBNF_COOP_SYNC();                                     // B3: the step's state is in Z
     st.mark(6);
   }
 
@@ -696,9 +812,9 @@ static hipError_t coop_launch(FlowLaunch p, hipStream_t s) {
 }
 
 // registry key: VariantKey{kind, ht, /*ksl*/ -13 (cooperative f16x3), 0, ot, FORM, /*depth*/ 1, act_a, act_b};
-// FORM 1 = 16-sample tiles on 4 waves, 2 = 32-sample tiles on 4 waves, 3 = 32-sample tiles on 8 waves
-constexpr int coop_form_nt(int form) { return form == 1 ? 1 : 2; }
-constexpr int coop_form_waves(int form) { return form == 3 ? 8 : 4; }
+// FORM 1 = 16-sample tiles on 4 waves, 2 = 32-sample tiles on 4 waves, 3 = 32-sample tiles on 8 waves, 4 = 16-sample tiles on 8 waves
+constexpr int coop_form_nt(int form) { return (form == 1 || form == 4) ? 1 : 2; }
+constexpr int coop_form_waves(int form) { return form >= 3 ? 8 : 4; }
 #define GBNF_INSTANTIATE_COOP(KIND, HT, OT, FORM, ACTA, ACTB)                                                   \
   namespace gbnf {                                                                                              \
   static hipError_t launch_coop_##KIND##_##HT##_##OT##_##FORM##_##ACTA##_##ACTB(const FlowLaunch& p0, unsigned, \

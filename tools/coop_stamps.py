@@ -16,8 +16,8 @@ flows = [native.NativeFlow(s, math="f16x3") for s in specs]
 mix = native.NativeMixture(flows)
 native.tuning_set("repair", 0); native.tuning_set("coop", mode)
 x = torch.from_numpy(synth.synth_batch(n, d, seed=0)).to(dev)
-rows = 16 if mode == 1 else 32
-W = 8 if mode == 3 else 4
+rows = 16 if mode in (1, 4) else 32
+W = 8 if mode >= 3 else 4
 nwg = C_ * ((n + rows - 1) // rows)
 buf = torch.zeros((nwg * W + 64) * 8, dtype=torch.int64, device=dev)
 L = native.lib()
