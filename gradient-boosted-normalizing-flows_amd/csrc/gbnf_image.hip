@@ -1257,9 +1257,9 @@ int gbnf_image_flow_create_mode(const gbnf_image_flow_desc* d, int32_t math_mode
         if (rc == GBNF_OK) {
           std::vector<double> sc;
           PackedConv pc = pack_conv(P, st.convs[q], &sc);
-          // split-f16 path (coupling_network_depth == 1, first 3x3 with <= 24 input channels -- the 48-channel third level of a
+          // split-f16 path (coupling_network_depth 1 at every width, 0 / 2 to h = 256 since round 6; first 3x3 with <= 24 input channels -- the 48-channel third level of a
           // 3 x 32 x 32 input, round 5 -- its folded contraction 9 cin <= 224 = 7 chunks): extra fragment sets
-          if (use_hx3 && st.n_convs == 3 && c1 <= 24) {
+          if (use_hx3 && c1 <= 24 && (st.n_convs == 3 || ((st.n_convs == 2 || st.n_convs == 4) && hdim <= 256))) {
             const int chp = hdim > 256 ? (hdim + 63) / 64 * 64 : (hdim + 31) / 32 * 32;
             if (q == 0) pc.x_off = pack_folded(P, st.convs[q].weight, chp, hdim, c1, W, sc, &pc.k_off, &pc.kc);
             else pc.x_off = pack_hx3(P, st.convs[q].weight, st.convs[q].out_channels, st.convs[q].in_channels, chp,
@@ -1445,12 +1445,14 @@ static int image_forward_impl(const gbnf_image_flow* f, const float* x, const fl
       std::swap(cur, oth);
       // coupling net on the first half
       const std::vector<PackedConv>& net = f->net[step];
-      const bool fusable = H == W && (W == 16 || W == 8) && net.size() == 3 && net[1].x_off != 0 &&
-                           img_net_hx3_lds(W, f->chp, net[0].cin, net[0].kc, net[2].cout) != 0;
+      // (round 6: coupling_network_depth 0 / 2 -- nets of 2 / 4 convolutions -- on the fused kernel too, hidden widths to 256)
+      const size_t NC = net.size();
+      const bool fusable = H == W && (W == 16 || W == 8) && (NC == 3 || ((NC == 2 || NC == 4) && f->chp <= 256)) && net[NC - 1].x_off != 0 &&
+                           img_net_hx3_lds(W, f->chp, net[0].cin, net[0].kc, net[NC - 1].cout) != 0;
       // (a padded map runs the fused kernel or the exact-f32 convolutions: the two-kernel split form does not mask)
       // (hidden widths above 256 exist on the fused kernel only)
       // (more than 5 chunks of the folded first 3x3 -- more than 17 input channels -- exist on the fused kernel only)
-      if (!force_f32 && net.size() == 3 && net[1].x_off != 0 && (fusable || (!padded && f->chp <= 256 && net[0].kc <= 5))) {
+      if (!force_f32 && net[NC - 1].x_off != 0 && (fusable || (NC == 3 && !padded && f->chp <= 256 && net[0].kc <= 5))) {
         // split-f16 path.  Round 4: the whole coupling net in ONE kernel where a workgroup can hold the hidden activation of its
         // rows (+ halo) in LDS: the 16 x 16 and 8 x 8 maps of a 32 x 32 input (img_net_hx3_kernel, gbnf_image_hx3.hip.h)
         static const bool no_fuse = getenv("GBNF_IMG_NO_FUSE") != nullptr;        // diagnostic: the round-2 two-kernel form
@@ -1459,10 +1461,12 @@ static int image_forward_impl(const gbnf_image_flow* f, const float* x, const fl
           q.pre_in = cur; q.pre_in_img = img; q.pre_wp = reinterpret_cast<const unsigned*>(blob + net[0].x_off);
           q.pre_bias = blob + net[0].b_off; q.pre_kc = net[0].kc; q.pre_cin = net[0].cin;
           q.pre_koff = reinterpret_cast<const int*>(blob + net[0].k_off);
+          q.n_mid = (int)NC - 2;
           q.wp = reinterpret_cast<const unsigned*>(blob + net[1].x_off); q.bias = blob + net[1].b_off;
-          q.wp3 = reinterpret_cast<const unsigned*>(blob + net[2].x_off); q.bias3 = blob + net[2].b_off;
+          if (NC == 4) { q.wp2 = reinterpret_cast<const unsigned*>(blob + net[2].x_off); q.bias2 = blob + net[2].b_off; }
+          q.wp3 = reinterpret_cast<const unsigned*>(blob + net[NC - 1].x_off); q.bias3 = blob + net[NC - 1].b_off;
           q.st = cur + (int64_t)c1 * H * W; q.st_img = img; q.ldj = ldj;
-          q.hid = net[1].cout; q.chp = f->chp; q.cout = net[2].cout; q.H = H; q.Hv = Hv; q.Wv = Wv;
+          q.hid = net[0].cout; q.chp = f->chp; q.cout = net[NC - 1].cout; q.H = H; q.Hv = Hv; q.Wv = Wv;
           q.sat = reinterpret_cast<unsigned long long*>(gbnf::saturation_counter());
           q.mark = mark; q.only = nullptr;
 #ifdef GBNF_IMG_STAMPS
@@ -1472,6 +1476,8 @@ static int image_forward_impl(const gbnf_image_flow* f, const float* x, const fl
           if (le != hipSuccess) return fail(GBNF_ERR_HIP, "img_net_hx3 launch failed: %s", hipGetErrorString(le));
           continue;
         }
+      }
+      if (!force_f32 && NC == 3 && net[1].x_off != 0 && !padded && f->chp <= 256 && net[0].kc <= 5) {      // the round-2 two-kernel form (depth 1 only)
         const int PT = IMG_R * W / 16, OT = (net[1].cout + 15) / 16;
         MidLaunch m1{};
         m1.pre_in = cur; m1.pre_in_img = img; m1.pre_wp = reinterpret_cast<const unsigned*>(blob + net[0].x_off);
@@ -1781,18 +1787,21 @@ static int image_inverse_impl(const gbnf_image_flow* f, const float* z, const fl
       p.H = H; p.W = W; p.Hv = Hv; p.Wv = Wv; p.n_strips = n_strips; p.ldj = nullptr;
       // coupling^-1: the net reads the first half (unchanged by the step)
       const std::vector<PackedConv>& net = f->net[step];
-      const bool fusable = fast && H == W && (W == 16 || W == 8) && net.size() == 3 && net[1].x_off != 0 &&
-                           img_net_hx3_lds(W, f->chp, net[0].cin, net[0].kc, net[2].cout) != 0;
+      const size_t NC = net.size();
+      const bool fusable = fast && H == W && (W == 16 || W == 8) && (NC == 3 || ((NC == 2 || NC == 4) && f->chp <= 256)) && net[NC - 1].x_off != 0 &&
+                           img_net_hx3_lds(W, f->chp, net[0].cin, net[0].kc, net[NC - 1].cout) != 0;
       bool coupled = false;
       if (fusable) {                                          // the fused split-f16 coupling-net kernel with the epilogue's way back
         NetLaunch q{};
         q.pre_in = cur; q.pre_in_img = img; q.pre_wp = reinterpret_cast<const unsigned*>(blob + net[0].x_off);
         q.pre_bias = blob + net[0].b_off; q.pre_kc = net[0].kc; q.pre_cin = net[0].cin;
         q.pre_koff = reinterpret_cast<const int*>(blob + net[0].k_off);
+        q.n_mid = (int)NC - 2;
         q.wp = reinterpret_cast<const unsigned*>(blob + net[1].x_off); q.bias = blob + net[1].b_off;
-        q.wp3 = reinterpret_cast<const unsigned*>(blob + net[2].x_off); q.bias3 = blob + net[2].b_off;
+        if (NC == 4) { q.wp2 = reinterpret_cast<const unsigned*>(blob + net[2].x_off); q.bias2 = blob + net[2].b_off; }
+        q.wp3 = reinterpret_cast<const unsigned*>(blob + net[NC - 1].x_off); q.bias3 = blob + net[NC - 1].b_off;
         q.st = cur + (int64_t)c1 * H * W; q.st_img = img; q.ldj = nullptr;
-        q.hid = net[1].cout; q.chp = f->chp; q.cout = net[2].cout; q.H = H; q.Hv = Hv; q.Wv = Wv; q.inverse = 1;
+        q.hid = net[0].cout; q.chp = f->chp; q.cout = net[NC - 1].cout; q.H = H; q.Hv = Hv; q.Wv = Wv; q.inverse = 1;
         q.sat = reinterpret_cast<unsigned long long*>(gbnf::saturation_counter());
         q.mark = mark; q.only = nullptr;
         const hipError_t le = img_net_hx3_launch(q, W, f->additive != 0, n, s);

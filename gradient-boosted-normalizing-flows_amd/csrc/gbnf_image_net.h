@@ -20,6 +20,9 @@ struct NetLaunch {
   int pre_kc, pre_cin;
   const unsigned* wp;       // 1x1: [o][c][hi|mid][64][4 u32]
   const float* bias;
+  int n_mid;                // round 6: 1x1 layers between the two 3x3s (coupling_network_depth): 1, or 0 / 2 for hidden widths to 256
+  const unsigned* wp2;      //   the second 1x1 (n_mid == 2), as wp
+  const float* bias2;
   const unsigned* wp3;      // last 3x3: [o][tap][c][hi|mid][64][4 u32]
   const float* bias3;
   float* st;                // coupled half z2 (n, *, H, W) f32, first channel of image 0

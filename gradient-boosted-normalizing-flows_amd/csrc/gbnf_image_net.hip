@@ -131,6 +131,11 @@ __global__ void __launch_bounds__(512) img_net_hx3_kernel(const NetLaunch p) {
   float* zin_f = reinterpret_cast<float*>(ZP + pixb);       // [pre_cin][ZR][ZW] (32-bit words: hi | mid << 16)
   int* koffs = reinterpret_cast<int*>(zin_f + p.pre_cin * CSz);      // [32 * pre_kc] im2col word offsets for THIS kernel's staging
   float amax = 0.0f;
+  // Round 6: ConvNets of coupling_network_depth 0 and 2 (models/layers.py:304-317: [Conv2d 1x1 -> ReLU] x num_layers between the two
+  // 3x3s) on this kernel -- n_mid 1x1 layers (0, 1 or 2; hidden widths to 256): none = the last 3x3 reads the first one's output as
+  // it stands in HB; two = the first 1x1's output goes back into HB (relu, split) and the phase runs again on the second layer's weights.
+  const int n_mid = KH == 1 ? p.n_mid : 1;
+  const unsigned* wp_cur = p.wp;          // the 1x1 layer whose fragments p3_load fetches
 #ifdef GBNF_IMG_STAMPS
   unsigned long long stamp_last = 0, stamp_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 #endif
@@ -244,20 +249,49 @@ __global__ void __launch_bounds__(512) img_net_hx3_kernel(const NetLaunch p) {
     ow[q] = (wave + (q & 1) * WV < TH && TH * (q >> 1) + wave + (q & 1) * WV < OT) ? TH * (q >> 1) + wave + (q & 1) * WV : OT;
     // (the accumulators START at the bias of their rows -- D layout: row 4 g + r -- instead of adding it in the tile epilogue: four
     //  vector instructions less per tile, in the phases that are bound by the vector issue port)
-    mid_b[q] = ((const f32x4 __attribute__((address_space(1)))*)p.bias)[(ow[q] < OT ? ow[q] : 0) * 4 + g];
+    mid_b[q] = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (n_mid > 0) mid_b[q] = ((const f32x4 __attribute__((address_space(1)))*)p.bias)[(ow[q] < OT ? ow[q] : 0) * 4 + g];
 #pragma unroll
     for (int pt = 0; pt < NPH; ++pt) acc[q][pt] = mid_b[q];
   }
   // (KH = 1) the 1x1's first two chunks of A fragments: requested under the last round of the first 3x3's pipeline
   u32x4 p3_ah[2][NQ], p3_am[2][NQ];
   auto p3_load = [&](int c, u32x4 (&ah)[NQ], u32x4 (&am)[NQ]) {            // c: chunk of the WHOLE contraction
-    const gv4 wp = (gv4)p.wp;
+    const gv4 wp = (gv4)wp_cur;
     const int cc = c < KC ? c : 0;
 #pragma unroll
     for (int q = 0; q < NQ; ++q) {
       const gv4 f = wp + ((size_t)(ow[q] < OT ? ow[q] : 0) * KC + cc) * 128 + lane;
       ah[q] = f[0];
       am[q] = f[64];
+    }
+  };
+  // the 1x1's output tiles of round rf (relu, split) -> HB, in place of the layer's input (every wave has finished reading it)
+  auto write_back = [&](int rf) {
+#pragma unroll
+    for (int q = 2 * rf; q < 2 * rf + 2; ++q) {
+      if (ow[q] < OT) {
+        const int o = ow[q] - TH * rf;                       // the tile's place in HB
+#pragma unroll
+        for (int pt = 0; pt < NPH; ++pt) {
+          const int lin = 16 * pt + i;
+          // outside the map proper (a 14 x 14 map in 16 x 16 storage) the hidden activation the last 3 x 3 reads must be the
+          // map's zero padding, not relu(bias + ...)
+          const bool valid = FULL || (hr0 + lin / W < p.Hv && lin % W < p.Wv);
+          float v[4];
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int co = 16 * ow[q] + 4 * g + r;
+            v[r] = (FULL || (co < p.hid && valid)) ? fmaxf(acc[q][pt][r], 0.0f) : 0.0f;
+          }
+          unsigned h01, m01, h23, m23;
+          img_split_pair_w(v[0], v[1], h01, m01, amax);
+          img_split_pair_w(v[2], v[3], h23, m23, amax);
+          unsigned char* px = HB + (size_t)lin * pixb + 2 * (16 * o + 4 * g);
+          *reinterpret_cast<u32x2*>(px) = u32x2{h01, h23};
+          *reinterpret_cast<u32x2*>(px + 2 * chh) = u32x2{m01, m23};
+        }
+      }
     }
   };
 #pragma unroll
@@ -292,11 +326,13 @@ __global__ void __launch_bounds__(512) img_net_hx3_kernel(const NetLaunch p) {
     auto tile_out = [&](const f32x4& a, int q, int pt) {            // relu(. + bias) -> split -> HB
       if (pt >= NPH) return;                                        // (compile time)
       const int lin = 16 * pt + i;
+      // (no 1x1 behind it: what the last 3x3 reads outside the map proper must be the map's zero padding -- see the 1x1's write-back)
+      const bool pv = FULL || n_mid > 0 || (hr0 + lin / W < p.Hv && lin % W < p.Wv);
       float v[4];
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int co = 16 * o2[q] + 4 * g + r;
-        v[r] = (FULL || co < p.hid) ? fmaxf(a[r], 0.0f) : 0.0f;
+        v[r] = (FULL || (co < p.hid && pv)) ? fmaxf(a[r], 0.0f) : 0.0f;
       }
       unsigned h01, m01, h23, m23;
       img_split_pair_w(v[0], v[1], h01, m01, amax);
@@ -315,7 +351,7 @@ __global__ void __launch_bounds__(512) img_net_hx3_kernel(const NetLaunch p) {
       // (the fragments of later groups lie above its output: 16 pixb >= 2048 pre_kc wherever BF has to share HB's tail)
       if (gi > 0 && gi * G * 16 * pixb > (int)p.bf_off) __syncthreads();
       if constexpr (KH == 1) {
-        if (gi == NG) { p3_load(0, p3_ah[0], p3_am[0]); p3_load(1, p3_ah[1], p3_am[1]); }
+        if (gi == NG && n_mid > 0) { p3_load(0, p3_ah[0], p3_am[0]); p3_load(1, p3_ah[1], p3_am[1]); }
       }
 #pragma unroll
       for (int st = 0; st < STEPS; ++st) {
@@ -429,7 +465,26 @@ __global__ void __launch_bounds__(512) img_net_hx3_kernel(const NetLaunch p) {
   IMG_STAMP(2);
 
   // ---- phase 3: 1x1 hidden -> hidden: this wave's NQ output tiles x every pixel tile, the k chunks of THIS half of its input
-  {
+  //      (round 6: once per 1x1 layer -- n_mid = 0, 1 or 2 for hidden widths to 256; the layers behind the first find their input in HB)
+#pragma unroll 1
+  for (int m = 0; m < n_mid; ++m) {
+    if (KH == 1 && m > 0) {
+      // the layer in front is through: its output (relu, split) replaces its input in HB; the accumulators start again at THIS layer's biases
+#pragma unroll
+      for (int q = 0; q < NQ; ++q) img_drain(acc[q]);
+      __syncthreads();                                       // every wave is done reading HB as that layer's input
+      write_back(0);
+      wp_cur = p.wp2;
+#pragma unroll
+      for (int q = 0; q < NQ; ++q) {
+        mid_b[q] = ((const f32x4 __attribute__((address_space(1)))*)p.bias2)[(ow[q] < OT ? ow[q] : 0) * 4 + g];
+#pragma unroll
+        for (int pt = 0; pt < NPH; ++pt) acc[q][pt] = mid_b[q];
+      }
+      p3_load(0, p3_ah[0], p3_am[0]);
+      p3_load(1, p3_ah[1], p3_am[1]);
+      __syncthreads();
+    }
     auto load_a = p3_load;
     const unsigned char* bbase = HB + (size_t)i * pixb + 16 * g;
     // B fragments: ONE pixel tile (hi, mid) per step, requested D steps ahead of its MFMAs into a ring of D + 1 register pairs.
@@ -550,31 +605,7 @@ __global__ void __launch_bounds__(512) img_net_hx3_kernel(const NetLaunch p) {
   {
     __syncthreads();                                         // every wave is done reading HB (the 1x1's input / the previous round's last 3x3)
     IMG_STAMP(2);
-#pragma unroll
-    for (int q = 2 * rf; q < 2 * rf + 2; ++q) {
-      if (ow[q] < OT) {
-        const int o = ow[q] - TH * rf;                       // the tile's place in HB
-#pragma unroll
-        for (int pt = 0; pt < NPH; ++pt) {
-          const int lin = 16 * pt + i;
-          // outside the map proper (a 14 x 14 map in 16 x 16 storage) the hidden activation the last 3 x 3 reads must be the
-          // map's zero padding, not relu(bias + ...)
-          const bool valid = FULL || (hr0 + lin / W < p.Hv && lin % W < p.Wv);
-          float v[4];
-#pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            const int co = 16 * ow[q] + 4 * g + r;
-            v[r] = (FULL || (co < p.hid && valid)) ? fmaxf(acc[q][pt][r], 0.0f) : 0.0f;
-          }
-          unsigned h01, m01, h23, m23;
-          img_split_pair_w(v[0], v[1], h01, m01, amax);
-          img_split_pair_w(v[2], v[3], h23, m23, amax);
-          unsigned char* px = HB + (size_t)lin * pixb + 2 * (16 * o + 4 * g);
-          *reinterpret_cast<u32x2*>(px) = u32x2{h01, h23};
-          *reinterpret_cast<u32x2*>(px + 2 * chh) = u32x2{m01, m23};
-        }
-      }
-    }
+    if (n_mid > 0) write_back(rf);
   }
   IMG_STAMP(4);
   __syncthreads();

@@ -28,6 +28,7 @@ def main():
     ap.add_argument("--K", type=int, default=8)
     ap.add_argument("--L", type=int, default=2)
     ap.add_argument("--hidden", type=int, default=256)
+    ap.add_argument("--depth", type=int, default=1, help="--coupling_network_depth: 1x1 layers between the two 3x3s (0, 1, 2)")
     ap.add_argument("--input", type=int, nargs=3, default=[3, 32, 32], metavar=("C", "H", "W"),
                     help="image shape: 3 32 32 (CIFAR: BASELINE configs[3], the default), 1 28 28 (MNIST / Omniglot / Caltech), 1 28 20 (Frey faces)")
     ap.add_argument("--steps", type=int, default=40)        # (10 steps read 6 % low: the first replays of a fresh graph are slower)
@@ -45,7 +46,7 @@ def main():
     from oracle import gbnf_oracle as oracle
     dev = torch.device("cuda:0")
     size = tuple(a.input)
-    specs = [synth.synth_image_glow_spec(size, a.hidden, a.K, a.L, seed=100 + c) for c in range(a.components)]
+    specs = [synth.synth_image_glow_spec(size, a.hidden, a.K, a.L, seed=100 + c, depth=a.depth) for c in range(a.components)]
     flows = [native.NativeImageFlow(sp) for sp in specs]
     x_np, noise_np = synth.synth_image_batch(a.batch, size, seed=0)
     x, noise = torch.from_numpy(x_np).to(dev), torch.from_numpy(noise_np).to(dev)

@@ -195,6 +195,9 @@ def main():
         path = os.path.join(F, src + ".json")
         if not os.path.exists(path):
             continue
+        if src == "bench_full_record_last":       # the default run's FULL record (pretty-printed): every leg in full, notes, thread probes
+            open(os.path.join(P, f"{tag}_final_{dst}.json"), "w").write(open(path).read())
+            continue
         try:
             l, dd = last_json(path)
         except Exception as e:
