@@ -184,7 +184,8 @@ def main():
              ("bench_emul8_default_torch", "bench_line_emulated_8gpu_c1_torch_pipeline"),
              ("image_n256", "image_cifar_c4_n256_line"), ("image_n64", "image_cifar_c4_n64_line"),
              ("image_1x28x28_n256", "image_1x28x28_c4_n256_line"), ("image_1x28x20_n256", "image_1x28x20_c4_n256_line"),
-             ("image_h512_n256", "image_cifar_c4_h512_n256_line"), ("image_h384_n256", "image_cifar_c4_h384_n256_line"), ("train_n4096", "train_step_line_n4096"),
+             ("image_h512_n256", "image_cifar_c4_h512_n256_line"), ("image_h384_n256", "image_cifar_c4_h384_n256_line"),
+             ("image_depth0_n256", "image_cifar_c4_depth0_n256_line"), ("image_depth2_n256", "image_cifar_c4_depth2_n256_line"), ("train_n4096", "train_step_line_n4096"),
              ("train_n65536", "train_step_line_n65536"), ("train_hepmass_bs_n65536", "train_step_line_hepmass_batchstats_n65536"),
              ("train_hepmass_n65536", "train_step_line_hepmass_n65536"), ("module_eval", "module_evaluate_loop_line"),
              ("train_glow_depth0_n65536", "train_step_line_glow_depth0_n65536"), ("train_glow_depth2_n65536", "train_step_line_glow_depth2_n65536"),

@@ -19,6 +19,8 @@ run image_1x28x28_n256 python tools/bench_image.py --batch 256 --input 1 28 28 -
 run image_1x28x20_n256 python tools/bench_image.py --batch 256 --input 1 28 20 --cpu-seconds 0
 run image_h512_n256 python tools/bench_image.py --batch 256 --hidden 512 --cpu-seconds 0
 run image_h384_n256 python tools/bench_image.py --batch 256 --hidden 384 --cpu-seconds 0
+run image_depth0_n256 python tools/bench_image.py --batch 256 --depth 0 --cpu-seconds 0
+run image_depth2_n256 python tools/bench_image.py --batch 256 --depth 2 --cpu-seconds 0
 (python tools/bench_image_inverse.py; python tools/bench_image_inverse.py --batch 64; python tools/bench_image_inverse.py --input 1 28 28) > $O/image_inverse.txt 2>&1
 run train_n4096 python tools/bench_train.py --batch 4096 --cpu-steps 0
 run train_n65536 python tools/bench_train.py --batch 65536 --cpu-steps 2
