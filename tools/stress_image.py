@@ -30,7 +30,7 @@ def main():
         # every third case: the coupling net of a random step leaves the fp16 range (its first convolution's ActNorm2d scales the
         # hidden activation by e^12, the last convolution's weights shrink by the same factor: the exact result stays ordinary) with
         # the create-time probe off -- the handle stays on split f16 and every image has to come back through the repair launch
-        blown = (k % 3 == 2) and c["depth"] == 1
+        blown = (k % 3 == 2) and (c["depth"] == 1 or c["h"] <= 256)       # (round 6: depth 0 / 2 run the split-f16 kernel too, to h = 256)
         os.environ.pop("GBNF_IMAGE_NO_PROBE", None)
         if blown:
             import copy
