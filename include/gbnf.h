@@ -167,7 +167,16 @@ int gbnf_mixture_numerics(const gbnf_mixture* mix, gbnf_numerics_status* out);
 
 /* Launch-policy knobs (process-wide; tests, soak runs and tuning -- the defaults are what is measured and shipped):
  *   "force_nt"      0 = automatic | 1 | 2 : samples per wave = 16 x NT            (env GBNF_FORCE_NT at first use)
- *   "wg_pairs"      -1 = automatic (since round 5: whenever two 4-wave workgroups fit a CU -- small batches too) | 0 = never | 1 = the same as -1   (env GBNF_NO_WG_PAIRS=1 -> 0)
+ *   "wg_pairs"      -1 = automatic (two 4-wave workgroups per CU whenever they fit -- small batches too, round 5 --, except LONG launches of
+ *                   geometries with heavy weight stages, which run as one 8-wave workgroup per CU: +1.2 % on the headline, round 6) |
+ *                   0 = never (always 8-wave workgroups) | 1 = pairs whenever they fit                (env GBNF_NO_WG_PAIRS=1 -> 0)
+ *   "coop"          the LATENCY form of the f16x3 flow kernel (csrc/gbnf_flow_kernel_coop.hip.h, round 6: the waves of a workgroup share
+ *                   ONE sample tile; one log_prob call at the reference's 512 / 1024-row batches 48 -> 29 / 37 us): -1 = automatic (taken
+ *                   while every workgroup gets a CU to itself) | 0 = never | 1 / 2 / 3 = always form 1 / 2 / 3 (16-sample tiles on 4 waves,
+ *                   32 on 4, 32 on 8) where the geometry has it.  Forward direction, depth-1 TanhNet / ReLUNet geometries listed as
+ *                   `coop` lines in csrc/variants.list.  Results of the forms agree to 2e-6 (another summation order of the output layer):
+ *                   a lone batch and the same batch inside a longer launch may differ in the last bits.
+ *   "coop_max_wgs"  the latency form is taken while the call's sample tiles x components fill at most this many workgroups (default 256)
  *   "repair"        1 | 0 : the bf16x6 pass behind f16x3 launches                 (env GBNF_NO_REPAIR=1 -> 0)
  *   "nt2_min_waves" 32-sample waves from this many waves on (default 1024)        (env GBNF_NT2_MIN_WAVES)
  *   "check_every"   numerics guard: a check on launch 0 and every this many launches (default 256; 0 = first launch only;
@@ -184,11 +193,12 @@ int gbnf_tuning_get(const char* key, int32_t* value);
  *   features                1 <= d <= 64                 (a sample tile's features are LDS slots of one wave; the reference's five
  *                                                         tabular datasets have d = 6, 8, 21, 43, 63)
  *   coupling-net input      <= 32 features               (d / 2, or d - d / 2 for a flipped RealNVP step: one k = 32 MFMA chunk)
- *   hidden width            1 <= h <= 512                (TanhNet / ReLUNet at coupling_network_depth 0, 1, 2; the split kernels cover
- *                                                         every depth and one-block ResidualNets to 512, two-block ResidualNets
- *                                                         to 256 -- wider ones run on the exact-f32 kernel)
+ *   hidden width            1 <= h <= 512                (TanhNet / ReLUNet at coupling_network_depth 0, 1, 2 and ResidualNets of one or two
+ *                                                         blocks: all on the split kernels at every width -- two-block ResidualNets above
+ *                                                         256 since round 6, evaluation; their TRAINING keeps the per-step kernels)
  *   coupling_network_depth  0, 1, 2; ResidualNet blocks 1, 2 (RealNVP only, as in the reference)
- *   flow steps              any K (per-step tables are staged in LDS up to K = 12, read from the blob beyond)
+ *   flow steps              any K (per-step tables are staged in LDS up to K = 24 where they fit, read from the blob beyond; the chained
+ *                                                         training sweeps take K <= 24)
  *   activations             tanh / relu, also drawn per step or per net (`--coupling_network random`) */
 int gbnf_flow_create(const gbnf_flow_desc* desc, gbnf_flow** out);
 /* Same with an explicit GBNF_MATH_* mode (gbnf_flow_create uses GBNF_MATH_DEFAULT, or env GBNF_MATH=f32|f16x3|bf16x6). */
@@ -425,9 +435,9 @@ typedef struct gbnf_image_flow gbnf_image_flow;
  * 4 x 4 map of a third level) lives in the top-left corner of that storage, zero outside (x, z, eps and noise at the boundary
  * always have the map's own size);
  * <= 64 channels per level; coupling ConvNets of hidden width <= 512 with 2 .. 5 convolutions (coupling_network_depth 0 .. 3);
- * the split-f16 kernels serve depth 1, every hidden width (above 256 the fused kernel works in two halves of the hidden
- * channels) and <= 24 input channels of the first 3 x 3 (the 48-channel third level of a 3 x 32 x 32 input), everything else
- * runs on the exact-f32 convolution kernels.  Not built: y-conditioning, learned dequantisation flows, image training. */
+ * the split-f16 kernels serve depth 1 at every hidden width (above 256 the fused kernel works in two halves of the hidden
+ * channels), depth 0 and 2 to hidden width 256 (round 6), and <= 24 input channels of the first 3 x 3 (the 48-channel third level of a
+ * 3 x 32 x 32 input); everything else runs on the exact-f32 convolution kernels.  Not built: y-conditioning, learned dequantisation flows, image training. */
 int gbnf_image_flow_create(const gbnf_image_flow_desc* desc, gbnf_image_flow** out);
 /* ... with an explicit GBNF_MATH_* mode: DEFAULT (what gbnf_image_flow_create does: split-f16 coupling nets if the create-time
  * probe passes), F32 (exact-f32 convolutions everywhere, no probe), F16X3. */
