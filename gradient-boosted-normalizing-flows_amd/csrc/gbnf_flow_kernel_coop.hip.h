@@ -323,9 +323,7 @@ __global__ void __launch_bounds__(64 * WV, 1) flow_kernel_coop(const FlowLaunch 
       const int ACTN = net == 0 ? ACT_A : ACT_B;
       const int net_base = step * STEP_WORDS + SMALL_WORDS + net * NET_WORDS;
       // the (step, net) behind this one: where the ring's look-ahead reads once it runs past this net's last fragment
-      const bool more = (net + 1 < NNETS) || more_steps;
       const int net_next = (net + 1 < NNETS) ? net_base + NET_WORDS : (more_steps ? (step + 1) * STEP_WORDS + SMALL_WORDS : net_base);
-      (void)more;
       int pos = 0;                      // sequence position (a constant at every use after unrolling)
       auto take = [&]() -> u32x4 { return ring[pos % R]; };
       auto refill = [&]() {            // the slot of position `pos` is free: fetch position pos + R into it
