@@ -69,8 +69,10 @@ inline size_t flow_coop_lds_bytes(int n_steps, int nt, int ht, int ot, int nnets
 // work under it)
 template <int KIND, int HT, int OT, int NT, int ACTA, int ACTB, int WV>
 __global__ void __launch_bounds__(64 * WV, 1) flow_kernel_coop(const FlowLaunch p) {
-  static_assert(ACTA == GBNF_ACT_TANH || ACTA == GBNF_ACT_RELU, "TanhNet / ReLUNet");
-  static_assert(ACTB == GBNF_ACT_TANH || ACTB == GBNF_ACT_RELU, "TanhNet / ReLUNet");
+  // ACT 3 (GBNF_ACT_PER_STEP): the activation of a step's net comes from the step header (`--coupling_network random`, and every uniform
+  // net of an activation pair without a variant of its own): both are computed and one is selected, as flow_kernel_hx3 does
+  static_assert(ACTA == GBNF_ACT_TANH || ACTA == GBNF_ACT_RELU || ACTA == 3, "TanhNet / ReLUNet");
+  static_assert(ACTB == GBNF_ACT_TANH || ACTB == GBNF_ACT_RELU || ACTB == 3, "TanhNet / ReLUNet");
   constexpr int NP = 2, WAVES = WV;
   constexpr int NNETS = (KIND == GBNF_KIND_REALNVP) ? 2 : 1;
   using LT = Hx3LayoutOf<HT, OT, NP, 1>;
@@ -321,6 +323,7 @@ __global__ void __launch_bounds__(64 * WV, 1) flow_kernel_coop(const FlowLaunch 
     for (int net = 0; net < NNETS; ++net) {
       constexpr int ACT_A = ACTA, ACT_B = ACTB;
       const int ACTN = net == 0 ? ACT_A : ACT_B;
+      const bool relu_rt = ACTN == 3 && __builtin_amdgcn_readfirstlane((int)sp[2 + net]) != 0;
       const int net_base = step * STEP_WORDS + SMALL_WORDS + net * NET_WORDS;
       // the (step, net) behind this one: where the ring's look-ahead reads once it runs past this net's last fragment
       const int net_next = (net + 1 < NNETS) ? net_base + NET_WORDS : (more_steps ? (step + 1) * STEP_WORDS + SMALL_WORDS : net_base);
@@ -349,12 +352,18 @@ __global__ void __launch_bounds__(64 * WV, 1) flow_kernel_coop(const FlowLaunch 
           e = e + f32x2{1.0f, 1.0f};
           a0 = __builtin_amdgcn_rcpf(e[0]);
           a1 = __builtin_amdgcn_rcpf(e[1]);
-        } else {
+        } else if (ACTN == GBNF_ACT_RELU) {
           a0 = __builtin_fmaxf(raw[2 * hp], 0.0f);
           a1 = __builtin_fmaxf(raw[2 * hp + 1], 0.0f);
           amax[nt] = __builtin_fmaxf(amax[nt], __builtin_fmaxf(a0, a1));
           a0 = __builtin_fminf(a0, 65504.0f);
           a1 = __builtin_fminf(a1, 65504.0f);
+        } else {                       // per step: the packer folded the tanh pre-scale into this net's layers only if it IS a tanh net
+          const float r0 = __builtin_fmaxf(raw[2 * hp], 0.0f), r1 = __builtin_fmaxf(raw[2 * hp + 1], 0.0f);
+          amax[nt] = __builtin_fmaxf(amax[nt], relu_rt ? __builtin_fmaxf(r0, r1) : 0.0f);
+          const float t0 = tanh_hx3(raw[2 * hp]), t1 = tanh_hx3(raw[2 * hp + 1]);
+          a0 = relu_rt ? __builtin_fminf(r0, 65504.0f) : t0;
+          a1 = relu_rt ? __builtin_fminf(r1, 65504.0f) : t1;
         }
         split_pair<NP>(a0, a1, pc);
       };

@@ -30,7 +30,7 @@ def test_every_cooperative_line_has_its_evaluation_line():
     for t in coops:
         key = tuple(int(v) for v in t[1:6])
         assert key + (1,) in hx3, f"coop {key}: no `hx3` line of the same geometry (the latency form reads that line's blob)"
-        assert key[3] in (0, 1) and key[4] in (0, 1), "TanhNet / ReLUNet only"
+        assert key[3] in (0, 1, 3) and key[4] in (0, 1, 3), "TanhNet / ReLUNet (3 = the activation per step)"
         forms = t[6] if len(t) > 6 else "123"
         assert forms and set(forms) <= set("123") and len(set(forms)) == len(forms), forms
 
