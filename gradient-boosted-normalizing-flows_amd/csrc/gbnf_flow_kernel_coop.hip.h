@@ -4,24 +4,26 @@
 // 1024 to evaluate) gives flow_kernel_hx3 at most one 16-sample wave per SIMD, and that wave walks 5 steps x 17 stages ALONE:
 // 41 us whatever the batch, 64 rows or 2048 (profiles/r6_latency_ablations.txt: 15 us of it waiting for the stage's weights /
 // barrier / fragments, 7 us activations, the rest the wave's own serial MFMA + VALU issue; more accumulator chains bought
-// nothing).  Here the FOUR waves of a workgroup share ONE tile of 16 NT samples of one component:
+// nothing).  Here the WV (4 or 8) waves of a workgroup share ONE tile of 16 NT samples of one component:
 //
 //   * wave w owns the hidden chunks [w CPW, (w+1) CPW) (a chunk = two 16-unit tiles = one k = 32 B operand) of every layer: a
-//     quarter of the MFMAs, of the tanh / split work and of the weight fragments per wave;
+//     quarter (an eighth) of the MFMAs, of the tanh / split work and of the weight fragments per wave;
 //   * layer 0's activations meet in LDS (already split, already in B-operand order: D layout == B layout, so a wave stores its
 //     two tiles of a chunk as the 16 bytes per lane the consumers read back with one lane-linear ds_read_b128);
 //   * the output layer is split along K: a wave contracts the chunks it produced itself, straight from its registers, and the
-//     four partial sums of every output tile meet in LDS; the coupling epilogue of output tile (o, nt) runs on wave (o NT + nt) % 4;
+//     WV partial sums of every output tile meet in LDS; the coupling epilogue of output tile (o, nt) runs on wave (o NT + nt) % WV;
 //   * weights: every fragment is used by exactly one wave, so nothing is staged -- each wave streams its own fragments
-//     L2 -> registers (global_load_dwordx4, 1 KiB per wave-instruction, the hx3 blob as gbnf_flow_create packed it) through a
-//     ring of COOP_RING fragments that runs ahead across layers, nets and steps (weights do not depend on data);
+//     L2 -> registers (buffer_load_dwordx4 with a scalar offset, 1 KiB per wave-instruction, the hx3 blob as gbnf_flow_create
+//     packed it) through a ring of GBNF_COOP_RING fragments that runs ahead across layers, nets and steps (weights do not depend on data);
 //   * 3 workgroup barriers per net (+1 per step) instead of 17 stage barriers.
 //
 // Same blob, same arithmetic per product (f16x3: 3 x v_mfma_f32_16x16x32_f16 on (hi, mid) pieces, f32 accumulate), same
 // range protocol as flow_kernel_hx3 (out-of-range rows are marked NaN and the bf16x6 repair launch behind the call
-// re-evaluates them).  Forward direction, depth-1 TanhNet / ReLUNet.  Forms (the registry's `nt` field): 1 = 16-sample tiles on 4
-// waves, 2 = 32-sample tiles on 4 waves, 3 = 32-sample tiles on 8 waves.  The launcher picks this kernel when a call has so few
-// sample tiles that every workgroup gets a CU to itself (gbnf_api.hip, pick_coop).
+// re-evaluates them).  Forward direction, depth-1 TanhNet / ReLUNet (also with the activation drawn per step).  Forms (the registry's
+// `nt` field): 1 = 16-sample tiles on 4 waves, 2 = 32-sample tiles on 4 waves, 3 = 32-sample tiles on 8 waves (4 = 16 on 8: measured,
+// not built).  The launcher picks this kernel when a call has so few sample tiles that every workgroup gets a CU to itself
+// (gbnf_api.hip, pick_coop); csrc/variants.list says which forms are built for which geometry (measured: profiles/r6_coop_geometries.txt).
+// What bounds it: profiles/r6_latency_ablations.txt (3) -- the L2 -> CU weight stream and, right under it, the wave's dependent issue.
 //
 // Reference semantics: the same as gbnf_flow_kernel_hx3.hip.h (models/glow.py:317-342, models/transformations.py:560-579).
 #pragma once
@@ -122,7 +124,7 @@ __global__ void __launch_bounds__(64 * WV, 1) flow_kernel_coop(const FlowLaunch 
   // ---- LDS: per-step tables | Z | ACT (hidden activations, split, B-operand order) | RED (output-layer partials) | biases x 2 | tail
   const bool lds_tables = p.lds_tables != 0;
   uint32_t* SM = lds;
-  float* Z = reinterpret_cast<float*>(lds + (lds_tables ? p.n_steps * SMALL_WORDS : 0));     // [d + 1][ZS], shared by the four waves
+  float* Z = reinterpret_cast<float*>(lds + (lds_tables ? p.n_steps * SMALL_WORDS : 0));     // [d + 1][ZS], shared by the workgroup's waves
   uint32_t* ACT = reinterpret_cast<uint32_t*>(Z) + (((d + 1) * ZS + 3) & ~3);                // (16-byte aligned: SMALL_WORDS is a multiple of 4)
   constexpr int ACT_WORDS = WAVES * CPW * NT * NP * 256;                                         // one net's activations: [chunk][nt][piece][lane][4]
   uint32_t* RED = ACT + (NNETS > 1 ? 2 : 1) * ACT_WORDS;                                     // [net][wave][o][nt][lane][4] f32
@@ -664,7 +666,7 @@ __global__ void __launch_bounds__(64 * WV, 1) flow_kernel_coop(const FlowLaunch 
     GBNF_COOP_SYNC();                                     // B2: every wave's partial sums are in RED
     st.mark(5);
 
-    // ---- coupling transform of the other half + log-det partials: output tile (o, nt) on wave (o NT + nt) % 4
+    // ---- coupling transform of the other half + log-det partials: output tile (o, nt) on wave (o NT + nt) % WV
 #if GBNF_COOP_HOIST_TABLES
     if (more_steps) load_tin(step + 1);
 #else
@@ -725,7 +727,7 @@ __global__ void __launch_bounds__(64 * WV, 1) flow_kernel_coop(const FlowLaunch 
     st.mark(6);
   }
 
-  // ---- log-det partials and range marks of the four waves meet; then base density + outputs
+  // ---- log-det partials and range marks of the waves meet; then base density + outputs
 #pragma unroll
   for (int nt = 0; nt < NT; ++nt) {
 #pragma unroll
