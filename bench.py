@@ -555,9 +555,9 @@ def main():
 
     def barrier():
         device_idle()
-        if world > 1:
+        if world > 1:          # (one rank: nothing was enqueued since the device went idle -- a second wait would only add its host time to the timed region)
             dist.barrier()
-        device_idle()
+            device_idle()
 
     MAX_TIMED_LAUNCHES = 48      # launches bracketed by timing events (the average is reported as roofline.launch_ms): event
                                  # pairs on every group of a long run cost the host more than the group's own launches

@@ -1050,7 +1050,7 @@ static int pick_coop(const gbnf_flow* f, int64_t n, int n_comp, int n_batches) {
   return 0;
 }
 
-#if defined(GBNF_STAMPS) || defined(GBNF_TIMELINE)
+#if defined(GBNF_STAMPS) || defined(GBNF_TIMELINE) || defined(GBNF_CLOCK)
 static unsigned long long* g_stamp_buf = nullptr;
 #endif
 
@@ -1132,7 +1132,7 @@ static int launch_flow(const gbnf_flow* f, const uint32_t* const* table, const u
   p.base_mean = base; p.base_std = base ? base + f->d : nullptr;
   p.n = n; p.out_stride = out_stride < 0 ? n * n_batches : out_stride; p.d = f->d; p.n_steps = f->n_steps; p.c_begin = c_begin; p.n_comp = n_comp;
   p.n_tiles = (int32_t)tiles; p.additive = f->additive;
-#if defined(GBNF_STAMPS) || defined(GBNF_TIMELINE)
+#if defined(GBNF_STAMPS) || defined(GBNF_TIMELINE) || defined(GBNF_CLOCK)
   p.dbg = g_stamp_buf;
 #endif
   p.sat = reinterpret_cast<unsigned long long*>(saturation_counter());
@@ -1379,7 +1379,7 @@ __global__ void __launch_bounds__(64) actnorm_finalize_kernel(const float* __res
 static float* g_actnorm_ws[gbnf::MAX_DEVICES] = {};   // per device: 2 x AN_MAX_BLOCKS x 64 floats, allocated on first use, never freed
 static std::mutex g_actnorm_mu;
 
-#if defined(GBNF_STAMPS) || defined(GBNF_TIMELINE)
+#if defined(GBNF_STAMPS) || defined(GBNF_TIMELINE) || defined(GBNF_CLOCK)
 // diagnostic builds only (not part of include/gbnf.h): device buffer of 8 u64 per block
 extern "C" int gbnf_debug_set_stamp_buffer(void* dev) { gbnf::g_stamp_buf = (unsigned long long*)dev; return 0; }
 #endif

@@ -388,6 +388,10 @@ flow_kernel_hx3(const FlowLaunch p) {
   // ---- work items: (component, batch, group of WAVES sample tiles).  A normal launch has one workgroup per item; a
   //      repair launch walks the items with a small grid and skips those without a marked sample.
   const int n_groups = (p.n_tiles + WAVES - 1) / WAVES;
+#ifdef GBNF_CLOCK                 // diagnostic (tools/clock_probe.py): the clock this workgroup ran at = d s_memtime / d s_memrealtime x 100 MHz
+  unsigned long long ck_c0 = 0, ck_r0 = 0;                                   // (MI355X_MICROARCH.md, "DVFS give-back" item 6)
+  asm volatile("s_memtime %0\n\ts_memrealtime %1\n\ts_waitcnt lgkmcnt(0)" : "=s"(ck_c0), "=s"(ck_r0)::"memory");
+#endif
   // (only the bf16x6 kernels serve repair launches: for the f16x3 instantiations the update is the constant -1, a single pass)
   for (int item = blockIdx.x; item >= 0;
        item = (PREC == 1 && p.repair && item + (int)gridDim.x < p.n_items) ? item + (int)gridDim.x : -1) {
@@ -1612,6 +1616,16 @@ flow_kernel_hx3(const FlowLaunch p) {
   }
 #endif
   }    // work items
+#ifdef GBNF_CLOCK
+  {
+    unsigned long long ck_c1 = 0, ck_r1 = 0;
+    asm volatile("s_memtime %0\n\ts_memrealtime %1\n\ts_waitcnt lgkmcnt(0)" : "=s"(ck_c1), "=s"(ck_r1)::"memory");
+    if (p.dbg != nullptr && threadIdx.x == 0) {       // a buffer of their own: no output depends on the stamps
+      p.dbg[(size_t)blockIdx.x * 2 + 0] = ck_c1 - ck_c0;
+      p.dbg[(size_t)blockIdx.x * 2 + 1] = ck_r1 - ck_r0;
+    }
+  }
+#endif
 }
 
 // LDS bytes of a launch with `ring` stage slots.
