@@ -573,7 +573,7 @@ def main():
         want_library = args.pipeline == "library" or (args.pipeline == "auto" and world == 1)
         # (the ranks agree inside native.Comm.from_torch_distributed -- a local probe on every rank, the flags meet in one all_reduce(MIN)
         #  before anything of the communicator set-up can block, and a refusal raises on EVERY rank: no second hand-shake here)
-        if gather and want_library:
+        if (gather and want_library) or (not gather and args.pipeline == "library"):
             # round 4: the exchange inside the library -- per group ONE hipGraphLaunch of {flow, repair, ncclAllGather, recursion}
             # (sharded.LibraryGroupPipeline); a refused communicator / capture falls back to the torch.distributed pipeline
             try:
