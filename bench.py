@@ -562,7 +562,7 @@ def main():
     MAX_TIMED_LAUNCHES = 48      # launches bracketed by timing events (the average is reported as roofline.launch_ms): event
                                  # pairs on every group of a long run cost the host more than the group's own launches
 
-    def timed_run(math, group, steps, warmup, prewarm, want_gather_times=False, repetitions=0, fresh=False):
+    def timed_run(math, group, steps, warmup, prewarm, want_gather_times=False, repetitions=0, fresh=False, graph_slots=False):
         """The pipeline on this rank's components in `math` mode, groups of `group` batches: returns timing + the handles' info."""
         flows = [native.NativeFlow(specs[c], math=math) for c in range(c0, c1)]
         mix = native.NativeMixture(flows)
@@ -573,7 +573,11 @@ def main():
         want_library = args.pipeline == "library" or (args.pipeline == "auto" and world == 1)
         # (the ranks agree inside native.Comm.from_torch_distributed -- a local probe on every rank, the flags meet in one all_reduce(MIN)
         #  before anything of the communicator set-up can block, and a refusal raises on EVERY rank: no second hand-shake here)
-        if (gather and want_library) or (not gather and args.pipeline == "library"):
+        # graph_slots (one rank, no exchange): every group as ONE HIP graph {flow launch, repair launch, recursion} on two alternating
+        # streams -- what pays for SMALL groups, whose launches are as long as the gaps between them (one batch per launch: 62.3 against
+        # 58.1 M samples/s, 640 batches, one box, alternating x 3; 2 and 4 batches per launch: 69.7 / 73.6 against 70.3 / 74.3 M -- no
+        # gain from two batches on, so the headline's groups of 20 stay plain stream launches)
+        if (gather and want_library) or (not gather and (args.pipeline == "library" or graph_slots)):
             # round 4: the exchange inside the library -- per group ONE hipGraphLaunch of {flow, repair, ncclAllGather, recursion}
             # (sharded.LibraryGroupPipeline); a refused communicator / capture falls back to the torch.distributed pipeline
             try:
@@ -782,12 +786,19 @@ def main():
                     del r, rb_
                 except Exception as e:
                     legs["fresh_batches"] = {"error": f"{type(e).__name__}: {e}"}
-            r = timed_run(args.math, 1, n_leg, 16, 0.0)
-            rg = roofline(r, 1)
-            legs["group1"] = {"value": B * n_leg / r["elapsed"], "unit": "samples/s", "dtype": r["name"], "steps": n_leg,
-                              "launch_ms": r["kern_ms"], "ms_per_batch": 1e3 * r["elapsed"] / n_leg,
-                              "achieved_tflops": rg["achieved"], "frac": rg["frac"], "group": 1,
-                              "note": "one batch per flow launch + one recursion launch (per-call latency form)"}
+            # (at least 640 batches behind a short settle phase: at the driver's --steps 20 this leg used to time 40 launches -- 3 ms --
+            #  straight after an idle device, and read 45 M samples/s where a second of the same calls runs at 58 M)
+            n_g1 = max(n_leg, 640)
+            r = timed_run(args.math, 1, n_g1, 64, 0.05, graph_slots=True)
+            ms_batch = 1e3 * r["elapsed"] / n_g1
+            flops_b = 2.0 * r["info"].macs_per_sample * C * B
+            legs["group1"] = {"value": B * n_g1 / r["elapsed"], "unit": "samples/s", "dtype": r["name"], "steps": n_g1,
+                              "launch_ms": r["kern_ms"], "ms_per_batch": ms_batch,
+                              "achieved_tflops": flops_b / (ms_batch * 1e-3) / 1e12, "frac": flops_b / (ms_batch * 1e-3) / 1e12 / F16_MFMA_PEAK_TFLOPS,
+                              "group": 1,
+                              "note": "one batch per flow launch + one recursion launch (BASELINE's literal 'batch 4096' call), every batch a HIP graph "
+                                      "{flow, repair, recursion} on one of two alternating streams: consecutive (independent) batches overlap. launch_ms "
+                                      "brackets a whole batch on its slot (two slots overlap); frac = algorithmic FLOP per batch / ms_per_batch / peak"}
             del r
             try:
                 # the reference's OWN batch sizes (density_experiment.py:80-81: 512 rows per training batch, 1024 per evaluation
