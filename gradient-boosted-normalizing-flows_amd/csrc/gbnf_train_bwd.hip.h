@@ -20,6 +20,9 @@
 
 #include "gbnf_flow_kernel_hx3.hip.h"
 
+#ifndef GBNF_BWD_PREFETCH
+#define GBNF_BWD_PREFETCH 0        // 1: L2-warming look-ahead of the saved operands (see bwd_warm_lines)
+#endif
 #ifndef GBNF_BWD_ABLATE
 #define GBNF_BWD_ABLATE 0          // diagnostic builds (tools/build_bwd_ablations.sh, timing only): 1 no parameter sums, 2 no operand stores, 4 no activation loads
 #endif
@@ -99,6 +102,16 @@ __device__ __forceinline__ float bwd_sum16(float v) {
   return v;
 }
 
+// L2-warming look-ahead (GBNF_BWD_PREFETCH): one LDS-DMA dword per lane from 64 DIFFERENT cache lines (lane l reads the first word of
+// line l of a block) into a dead 256-byte LDS cell -- no register is written, so nothing can be clobbered when the data lands, and the
+// kernel's real loads of those lines (the saved activations a pass needs two tiles ahead, the next step's boundary operands) then
+// find them in the L2 / Infinity Cache instead of waiting out an HBM round trip with nothing on the SIMD to switch to.  Counts as ONE
+// vector-memory operation (vmcnt) like every LDS-DMA; the dword form is what tools/isa_hazard_lint.py tells from a staging DMA (x4).
+__device__ __forceinline__ void bwd_warm_lines(const float* base, unsigned lane_off, uint32_t* dead_cell) {
+  const unsigned m0v = (unsigned)(uintptr_t)(__attribute__((address_space(3))) void*)dead_cell;
+  asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %0, %1" ::"v"(lane_off), "s"(base), "s"(m0v) : "memory", "m0");
+}
+
 // Waves per SIMD the 4-wave form is compiled for: 2 (256 registers, two workgroups share a CU and cover each other's memory
 // latency: 498 -> 3xx us at N = 65536) where the kernel fits -- its register count is 8 per hidden tile (the saved second-layer
 // activations and the split g_a2 operands) + ~125 (measured: HT = 14 -> 235) -- else 1 (512 registers).
@@ -165,6 +178,7 @@ __global__ void __launch_bounds__(64 * WV, WV == 8 ? 2 : bwd_hx3_occupancy(KIND,
   // gradient buffer -- 4096 waves x 86 parameters x K steps on 430 addresses -- took 80 % of this kernel's time.)
   float* PG = reinterpret_cast<float*>(STG + 2 * STAGE_WORDS) + WAVES * ((d + 1) * ZS) + WAVES * (32 * ZS);
   for (int e = (int)threadIdx.x; e < WAVES * K * 128; e += 64 * WAVES) PG[e] = 0.0f;
+  [[maybe_unused]] uint32_t* WARM = reinterpret_cast<uint32_t*>(PG + WAVES * K * 128);      // (GBNF_BWD_PREFETCH) 64 dead words
 
   // ---- weight staging (as in flow_kernel_hx3): the transposed blob is in consumption order, steps last to first
   using gwords = const __attribute__((address_space(1))) uint32_t*;
@@ -317,6 +331,31 @@ __global__ void __launch_bounds__(64 * WV, WV == 8 ? 2 : bwd_hx3_occupancy(KIND,
 #pragma unroll
         for (int r = 0; r < 4; ++r) h2first[t][r] = ((GBNF_BWD_ABLATE & 4) || RES) ? 0.5f : h2p0[(16 * t + r) * 16];
     }
+#if GBNF_BWD_PREFETCH
+    {
+      // this step's layer-0 activations (the W1^T passes ask for them two tiles ahead: less than an HBM round trip), and what the
+      // step BEFORE this one (the next to be processed) reads at its top: its last-hidden-layer activations, net outputs, trace
+      const unsigned l128 = (unsigned)lane * 128u;
+      const int hp_lines = (p.tr_hp * 64 + 127) / 128, op_lines = (p.tr_op * 64 + 127) / 128;
+      const bool prev = step > kb;
+      const float* actp = prev ? acts - (int64_t)NNETS * p.net_rows * np : acts;          // (the first step: its own rows again)
+#pragma unroll
+      for (int net = 0; net < NNETS; ++net) {
+        const float* a0b = acts + (int64_t)net * p.net_rows * np + (int64_t)p.tr_ip * np + tile0 * hp16;
+        const float* a1b = actp + (int64_t)net * p.net_rows * np + (int64_t)(p.tr_ip + DEPTH * p.tr_hp) * np + tile0 * hp16;
+        const float* ob = actp + (int64_t)net * p.net_rows * np + (int64_t)(p.tr_ip + 2 * NH * p.tr_hp + p.tr_op) * np + tile0 * op16;
+        for (int l0 = 0; l0 < hp_lines; l0 += 64) {
+          const unsigned lo = (unsigned)(l0 + lane < hp_lines ? l0 + lane : hp_lines - 1) * 128u;
+          bwd_warm_lines(a0b, lo, WARM);
+          bwd_warm_lines(a1b, lo, WARM);
+        }
+        bwd_warm_lines(ob, (unsigned)(lane < op_lines ? lane : op_lines - 1) * 128u, WARM);
+      }
+      (void)l128;
+      const float* trp = prev ? trace - (int64_t)d * p.np : trace;
+      bwd_warm_lines(trp + row0, (unsigned)(lane < d ? lane : d - 1) * (unsigned)np * 4u, WARM);
+    }
+#endif
     float y2v[NENT];
     {
       const float* oA = acts + (int64_t)(p.tr_ip + 2 * NH * p.tr_hp + p.tr_op) * np + o_off;     // the forward sweep's saved net outputs
@@ -934,7 +973,7 @@ __global__ void __launch_bounds__(64 * WV, WV == 8 ? 2 : bwd_hx3_occupancy(KIND,
 
 inline size_t bwd_hx3_lds_bytes(int n_steps, int waves, int stage_frags, int d) {
   return ((size_t)n_steps * SMALL_WORDS + 2 * (size_t)stage_frags * 256 + (size_t)waves * (d + 1) * 17 + (size_t)waves * 32 * 17 +
-          (size_t)waves * n_steps * 128) * 4;
+          (size_t)waves * n_steps * 128 + (GBNF_BWD_PREFETCH ? 64 : 0)) * 4;
 }
 
 // 4-wave workgroups, one wave per SIMD (the kernel keeps a whole layer of saved activations in registers: 290-330 of a lone
