@@ -26,6 +26,8 @@ misspelt kwarg); image inputs dispatch to ``image_glow.BoostedImageFlow`` (``Boo
 """
 from __future__ import annotations
 
+import math
+
 import numpy as np
 import torch
 import torch.nn as nn
@@ -465,6 +467,21 @@ class BoostedFlow(nn.Module):
             if out is not None:
                 return out
         return self.encode(x, y_onehot, components)
+
+    @torch.no_grad()
+    def _rho_gradient_g(self, x):
+        """models/boosted_flow.py:98-107 (its only callers are commented out upstream, :180): log-density of x under the NEW
+        component, log N(z; 0, I) + ldj of ``forward(x, components="c")``."""
+        z_g, _, _, ldj_g, _ = self.forward(x=x, components="c")
+        return (torch.sum(-0.5 * math.log(2 * math.pi) - 0.5 * z_g * z_g, dim=-1) + ldj_g).detach()
+
+    @torch.no_grad()
+    def _rho_gradient_G(self, x):
+        """models/boosted_flow.py:109-118: the same under ONE fixed component drawn from rho ("-c" once all are trained, else
+        "1:c-1") -- the draw is the reference's torch.multinomial (_sample_component)."""
+        fixed = "-c" if self.all_trained else "1:c-1"
+        z_G, _, _, ldj_G, _ = self.forward(x=x, components=fixed)
+        return (torch.sum(-0.5 * math.log(2 * math.pi) - 0.5 * z_G * z_G, dim=-1) + ldj_G).detach()
 
     @torch.no_grad()
     def _rho_gradients(self, x):

@@ -234,6 +234,32 @@ def test_update_rho_second_boosting_pass_component_zero(golden_case):
     assert torch.equal(m.rho, before)
 
 
+def test_rho_gradient_helpers_of_the_reference_class(golden_case):
+    """models/boosted_flow.py:98-118 (`_rho_gradient_g`, `_rho_gradient_G`: part of the class's surface, their callers are commented
+    out upstream): the new component's log-density, and that of ONE fixed component drawn from rho."""
+    import torch
+    dev = torch.device("cuda:0")
+    g = golden_case("g6_glow_d43_h64_c3_rho")
+    m = _model_from_case(g, dev)
+    x = torch.from_numpy(g.x).to(dev)
+    m.component = 2
+    g_ll = m._rho_gradient_g(x)
+    assert not g_ll.requires_grad and rel_err(g_ll.cpu().numpy(), g.ll[2]) < LL_RTOL
+    torch.manual_seed(5)
+    seen = set()
+    for _ in range(12):           # "1:c-1": a fixed component j < c, drawn by torch.multinomial over rho[0:c]
+        G_ll = m._rho_gradient_G(x).cpu().numpy()
+        j = int(np.argmin([rel_err(G_ll, g.ll[k]) for k in range(3)]))
+        assert j < 2 and rel_err(G_ll, g.ll[j]) < LL_RTOL
+        seen.add(j)
+    assert seen == {0, 1}
+    m.all_trained = True          # "-c": any component but the current one
+    m.component = 0
+    for _ in range(6):
+        G_ll = m._rho_gradient_G(x).cpu().numpy()
+        assert min(rel_err(G_ll, g.ll[k]) for k in (1, 2)) < LL_RTOL
+
+
 def test_boosting_weights_match_reference(golden_case):
     """G8: sample weights for the next component; kernel vs the reference's own statements, and the
     module method on top of the fixed components' mixture density."""
