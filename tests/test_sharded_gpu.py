@@ -227,3 +227,43 @@ def test_library_group_pipeline_on_rccl_world_size_one():
         base = 0 if which == 0 else 3
         for b in range(3):
             assert np.array_equal(G[b * n:(b + 1) * n], ref[base + b])
+
+
+def test_library_group_pipeline_without_exchange_one_batch_per_graph():
+    """One rank, no communicator (`gather=False`): every group -- here ONE batch -- is a HIP graph {flow launch, repair launch,
+    recursion launch} on one of two alternating streams.  This is what `bench.py`'s `group1` leg runs (BASELINE's literal
+    "batch 4096" call, consecutive batches overlapping): results bit-identical to plain per-batch calls, slots re-used in their
+    own stream's order without host synchronisation in between."""
+    import torch
+    from conftest import GoldenCase, rel_err
+    from gbnf_amd import native, sharded, synth
+    dev = torch.device("cuda:0")
+    torch.cuda.set_device(dev)
+    g = GoldenCase("g3_glow_d43_h215_c8")
+    C = len(g.specs)
+    mix = native.NativeMixture([native.NativeFlow(s) for s in g.specs])
+    rho = torch.from_numpy(g.rho).to(dev)
+    n, d = g.x.shape
+    xs = [torch.from_numpy(g.x).to(dev)] + [torch.from_numpy(synth.synth_batch(n, d, seed=70 + k)).to(dev) for k in range(4)]
+    ref = [mix.log_prob(x, rho)[0].cpu().numpy() for x in xs]            # (a lone batch and a group of one: the same kernel form)
+    for graph in (True, False):
+        pipe = sharded.LibraryGroupPipeline(mix, C, 0, C, rho, n, 1, gather=False, graph=graph)
+        tokens = [pipe.bind([x]) for x in xs]
+        assert not pipe.graph_errors, pipe.graph_errors
+        if graph:
+            assert all(t.launches[q].graph is not None for t in tokens for q in range(pipe.nslots))
+        for rep in range(2):
+            for k, t in enumerate(tokens):
+                G, q = pipe.submit(t)
+                pipe.done[q].synchronize()
+                assert np.array_equal(G.cpu().numpy(), ref[k])
+        # back to back, no host synchronisation: 12 submissions over the two slots, the last two results checked
+        last = {}
+        for k in range(12):
+            G, q = pipe.submit(tokens[k % len(tokens)])
+            last[q] = (G, k % len(tokens))
+        pipe.drain()
+        torch.cuda.synchronize()
+        for q, (G, k) in last.items():
+            assert np.array_equal(G.cpu().numpy(), ref[k])
+    assert rel_err(ref[0], g.G) < 1e-5
