@@ -20,7 +20,8 @@ using f32x2 = __attribute__((ext_vector_type(2))) float;
 using f16x8 = __attribute__((ext_vector_type(8))) _Float16;
 using u32x4 = __attribute__((ext_vector_type(4))) unsigned;
 #define FENCE() __builtin_amdgcn_sched_barrier(0)
-static int WARM = 3;      // launches before the one that is read (argv[1]: ~20000 = a second of load, for the clock)
+static int WARM = 3;      // launches, the last one is read
+static int PASSES_RT = 64; // passes per launch (argv[2]: 400000 = ~0.5 s per launch: the clock the chip HOLDS under the stream)
 
 struct PairState { float a, b; f32x2 e; float r0, r1; unsigned hi, mid; };
 template <int STEP>
@@ -66,11 +67,14 @@ __device__ __forceinline__ void spread(PairState (&ps)[NP > 0 ? NP : 1], F&& mfm
 #define DEF_MPU 3
 #endif
 template <int NM, int NPAIR, int FRAGS, int MPU = DEF_MPU, int MAXT = 512>
-__global__ void __launch_bounds__(MAXT) k(float* out, unsigned long long* cyc, int seed) {
+__global__ void __launch_bounds__(MAXT) k(float* out, unsigned long long* cyc, int seed, int passes) {
   const int lane = threadIdx.x & 63;
   extern __shared__ __attribute__((aligned(16))) unsigned frag_lds[];
   constexpr int NU = NM / MPU;
-  for (int w = threadIdx.x; w < 2 * NU * 256; w += blockDim.x) frag_lds[w] = 0x3c003c00u + w * 7u + seed;
+  // operands with random mantissas and signs (f16 pairs in [0.5, 2)): the power an MFMA draws depends on its data (MI355X_MICROARCH.md, DVFS)
+  auto rnd = [](unsigned x) { x ^= x >> 16; x *= 0x7feb352du; x ^= x >> 15; x *= 0x846ca68bu; x ^= x >> 16; return x; };
+  auto f16pair = [&](unsigned x) { const unsigned r = rnd(x); return (r & 0x83ff83ffu) | 0x38003800u | ((r >> 3) & 0x04000400u); };
+  for (int w = threadIdx.x; w < 2 * NU * 256; w += blockDim.x) frag_lds[w] = f16pair(w * 7u + seed + blockIdx.x * 977u);
 #ifdef SHAPE16
   f32x4 acc[2] = {f32x4{0, 0, 0, 0}, f32x4{0, 0, 0, 0}};
 #else
@@ -79,7 +83,7 @@ __global__ void __launch_bounds__(MAXT) k(float* out, unsigned long long* cyc, i
 #endif
   f16x8 bv[2];
   for (int i = 0; i < 2; ++i) {
-    u32x4 t = u32x4{0x3c003c00u + seed + i, 0x38003800u + threadIdx.x, 0x34003400u + i, 0x30003000u};
+    u32x4 t = u32x4{f16pair(seed + i + threadIdx.x * 31u), f16pair(threadIdx.x * 131u + i), f16pair(threadIdx.x * 17u + 5u * i + 3u), f16pair(threadIdx.x + 1000u * i)};
     bv[i] = __builtin_bit_cast(f16x8, t);
   }
   PairState ps[NPAIR > 0 ? NPAIR : 1];
@@ -107,7 +111,7 @@ __global__ void __launch_bounds__(MAXT) k(float* out, unsigned long long* cyc, i
   FENCE();
   asm volatile("s_memtime %0\n\ts_memrealtime %1\n\ts_waitcnt lgkmcnt(0)" : "=s"(t0), "=s"(r0)::"memory");
   FENCE();
-  constexpr int PASSES = 64;
+  const int PASSES = passes;
   for (int p = 0; p < PASSES; ++p) {
     load_unit(0, 0); load_unit(1, 1);
     spread<0, NM, 9 * NPAIR, NPAIR>(ps, mfma1);
@@ -130,7 +134,7 @@ static void run(const char* what, std::initializer_list<int> wave_counts = {8, 4
     float* out; unsigned long long* cyc;
     hipMalloc(&out, blocks * 1024 * 4); hipMalloc(&cyc, (blocks * 16 + 2) * 8);
     hipFuncSetAttribute((const void*)k<NM, NPAIR, FRAGS, MPU, MAXT>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
-    for (int rep = 0; rep < WARM; ++rep) hipLaunchKernelGGL((k<NM, NPAIR, FRAGS, MPU, MAXT>), dim3(blocks), dim3(64 * waves), 2 * (NM / MPU) * 1024, 0, out, cyc, rep);
+    for (int rep = 0; rep < WARM; ++rep) hipLaunchKernelGGL((k<NM, NPAIR, FRAGS, MPU, MAXT>), dim3(blocks), dim3(64 * waves), 2 * (NM / MPU) * 1024, 0, out, cyc, rep, PASSES_RT);
     hipDeviceSynchronize();
     static unsigned long long h[256 * 16 + 2];
     hipMemcpy(h, cyc, blocks * waves * 8, hipMemcpyDeviceToHost);
@@ -145,6 +149,7 @@ static void run(const char* what, std::initializer_list<int> wave_counts = {8, 4
 
 int main(int argc, char** argv) {
   if (argc > 1) WARM = atoi(argv[1]);
+  if (argc > 2) PASSES_RT = atoi(argv[2]);
 #ifdef SHAPE16          // the shipped shape on the same harness (-DSHAPE16): per 32 hidden units TWO passes of <42, 4>
   run<42, 0, 1>("16x16x32: mfma + LDS frags");
   run<42, 4, 1>("16x16x32: spread (hidden pass, 16 units)");
