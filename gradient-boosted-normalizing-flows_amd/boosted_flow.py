@@ -551,6 +551,41 @@ class BoostedFlow(nn.Module):
             cache[c] = (list(flow.parameters()), list(flow.buffers()), layers)
         return cache[c]
 
+    def train(self, mode=True):
+        """nn.Module.train, plus a look at the library's range counter where the reference's loop switches modes anyway (once per epoch:
+        density_experiment.py:336 ``model.train()``, :545 ``model.eval()``).  The TRAINING kernels saturate a split-f16 operand beyond
+        +-65504 instead of repairing the sample (include/gbnf.h, gbnf_saturation_count): the step stays finite and its gradients are
+        wrong for those samples.  Leaving training mode with more marked waves than it began with is reported -- a warning, not an
+        error: the counter is per device, and an evaluation launch in between (the fixed components' boosting weights), which repairs
+        what it marks, raises it too.  ``BoostedFlow.check_numerics()`` is the strict form."""
+        mode = bool(mode)
+        out = super().train(mode)
+        try:
+            on_device = self.rho.is_cuda
+        except AttributeError:                 # (nn.Module.__init__ -> not constructed yet)
+            return out
+        if on_device:
+            snap = self.__dict__.get("_sat_at_train")
+            if mode and snap is None:
+                self.__dict__["_sat_at_train"] = self._range_counter()
+            elif not mode and snap is not None:
+                del self.__dict__["_sat_at_train"]
+                now = self._range_counter()
+                if now is not None and now > snap:
+                    import warnings
+                    warnings.warn(f"{now - snap} wave(s) met a split-f16 operand beyond +-65504 while the model was in training mode: the "
+                                  "training kernels saturate there (gradients of those samples are wrong; an evaluation launch repairs what "
+                                  "it marks and counts too).  An exploding model or inputs far off the scale the flow was fitted on -- "
+                                  "normalise the inputs; BoostedFlow.check_numerics() raises on the same counter", RuntimeWarning, stacklevel=2)
+        return out
+
+    def _range_counter(self):
+        try:
+            with torch.cuda.device(self.rho.device):
+                return native.saturation_count(reset=False)
+        except Exception:                      # (no library / no device: the calls that need them raise on their own)
+            return None
+
     def _apply(self, fn, *a, **k):
         for name in ("_tensor_cache", "_perm_cache", "_key_cache", "_prior_cache", "_component_table", "_component_meta"):
             self.__dict__.pop(name, None)

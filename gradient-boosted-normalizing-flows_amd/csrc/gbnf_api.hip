@@ -1692,9 +1692,14 @@ struct LiveBlob {
 };
 
 // the device twin of put_tile(): lane (i,g) computes its 8 values of one tile and writes 4 words per piece
-__device__ __forceinline__ void live_tile(const LiveTile T, const LiveLayer* __restrict__ layers, uint32_t* __restrict__ blob, int lane) {
+// (sat: the device's range counter -- a weight beyond the fp16 range, +-65504 after the tanh pre-scale, cannot be split: hi rounds to inf, the
+//  residual to -inf, a ReLU of the NaN they produce is 0.  No trained model has such weights; a diverged one is COUNTED here like every other
+//  operand that leaves the range (gbnf_saturation_count), not passed over in silence)
+__device__ __forceinline__ void live_tile(const LiveTile T, const LiveLayer* __restrict__ layers, uint32_t* __restrict__ blob, int lane,
+                                          unsigned* __restrict__ sat) {
   const LiveLayer L = layers[T.lid];
   const int i = lane & 15, gg = lane >> 4;
+  bool big = false;
 #pragma unroll
   for (int q = 0; q < 4; ++q) {
     uint32_t w[2] = {0u, 0u};
@@ -1709,6 +1714,7 @@ __device__ __forceinline__ void live_tile(const LiveTile T, const LiveLayer* __r
       else if (T.kind == 3 || T.kind == 4) { row = kslot_b; col = 16 * T.a + i; }      // contraction over W's rows
       else { row = kslot_a; col = 16 * T.b + i; }
       float r = (row < T.rows && col < T.cols) ? T.scale * L.W[(size_t)row * L.cols + col] : 0.0f;
+      big = big || !(__builtin_fabsf(r) <= 65504.0f);
 #pragma unroll
       for (int k = 0; k < 2; ++k) {       // hi = f16(r), mid = f16(r - hi): both round to nearest, like the host packer
         const _Float16 h = static_cast<_Float16>(r);
@@ -1719,10 +1725,11 @@ __device__ __forceinline__ void live_tile(const LiveTile T, const LiveLayer* __r
     blob[T.dst + (size_t)lane * 4 + q] = w[0];
     blob[T.dst + 256 + (size_t)lane * 4 + q] = w[1];
   }
+  if (sat != nullptr && __any(big) && lane == 0) atomicAdd(sat, 1u);
 }
 __global__ void __launch_bounds__(64) live_tiles_kernel(const LiveTile* __restrict__ tiles, const LiveLayer* __restrict__ layers,
-                                                        uint32_t* __restrict__ blob) {
-  live_tile(tiles[blockIdx.x], layers, blob, (int)threadIdx.x);
+                                                        uint32_t* __restrict__ blob, unsigned* __restrict__ sat) {
+  live_tile(tiles[blockIdx.x], layers, blob, (int)threadIdx.x, sat);
 }
 
 // biases (folded row sums in double, like the host packer), live table entries, per-step log-det constants
@@ -1778,12 +1785,13 @@ __global__ void __launch_bounds__(256) live_pack_kernel(const LiveTile* __restri
                                                         int n_tilesB, uint32_t* __restrict__ blobB, const LiveBias* __restrict__ bias,
                                                         int n_bias, const LiveEntry* __restrict__ ent, int n_ent,
                                                         const LiveNorm* __restrict__ norms, int K, int d, int glow,
-                                                        const LiveLayer* __restrict__ layers, uint32_t* __restrict__ blob) {
+                                                        const LiveLayer* __restrict__ layers, uint32_t* __restrict__ blob,
+                                                        unsigned* __restrict__ sat) {
   const int tile_blocks = (n_tiles + n_tilesB + 3) / 4;
   if ((int)blockIdx.x < tile_blocks) {
     const int t = (int)blockIdx.x * 4 + (int)(threadIdx.x >> 6), lane = (int)(threadIdx.x & 63);
-    if (t < n_tiles) live_tile(tiles[t], layers, blob, lane);
-    else if (t < n_tiles + n_tilesB) live_tile(tilesB[t - n_tiles], layers, blobB, lane);
+    if (t < n_tiles) live_tile(tiles[t], layers, blob, lane, sat);
+    else if (t < n_tiles + n_tilesB) live_tile(tilesB[t - n_tiles], layers, blobB, lane, nullptr);      // (the same weights, transposed)
     return;
   }
   live_small((int)blockIdx.x - tile_blocks, bias, n_bias, ent, n_ent, norms, K, d, glow, layers, blob);
@@ -2139,7 +2147,7 @@ int live_blob_backward(LiveBlob* lb, int64_t n, const float* trace, float* acts,
   // contract of include/gbnf.h); a trainer that has not run one yet packs them here
   if (!lb->tilesB_packed)
     hipLaunchKernelGGL(live_tiles_kernel, dim3((unsigned)lb->n_tilesB), dim3(64), 0, s, (const LiveTile*)lb->tilesB_dev,
-                       (const LiveLayer*)lb->layers_dev, lb->blobB_dev);
+                       (const LiveLayer*)lb->layers_dev, lb->blobB_dev, (unsigned*)nullptr);
   FlowLaunch p{};
   p.blobs = lb->table_dev; p.blobs_bwd = lb->tableB_dev;
   p.n = n; p.d = lb->d; p.n_steps = lb->K; p.n_comp = 1; p.n_batches = 1; p.additive = lb->additive;
@@ -2177,7 +2185,7 @@ static void live_blob_repack(LiveBlob* lb, hipStream_t s, bool with_backward = f
   hipLaunchKernelGGL(live_pack_kernel, dim3((unsigned)(tile_blocks + small_blocks)), dim3(256), 0, s, (const LiveTile*)lb->tiles_dev,
                      lb->n_tiles, (const LiveTile*)lb->tilesB_dev, n_tilesB, lb->blobB_dev, (const LiveBias*)lb->bias_dev, lb->n_bias,
                      (const LiveEntry*)lb->entries_dev, lb->n_entries, (const LiveNorm*)lb->norms_dev, lb->K, lb->d,
-                     lb->kind == GBNF_KIND_GLOW ? 1 : 0, (const LiveLayer*)lb->layers_dev, lb->blob_dev);
+                     lb->kind == GBNF_KIND_GLOW ? 1 : 0, (const LiveLayer*)lb->layers_dev, lb->blob_dev, saturation_counter());
   lb->tilesB_packed = n_tilesB > 0;
 }
 

@@ -830,3 +830,47 @@ def test_flows_of_more_than_twelve_steps_train_on_the_chained_kernels(kind, d, h
     assert _last_path(tr) == (1, 1)
     _check_grads(grads, grads64, f"{kind} K={K}")
     assert np.abs(gx.cpu().numpy() - gx64).max() <= G_RTOL * max(float(np.abs(gx64).max()), 1e-3)
+
+
+def test_leaving_training_mode_reports_saturated_training_kernels():
+    """The training kernels saturate a split-f16 operand beyond +-65504 (include/gbnf.h, gbnf_saturation_count: no repair pass in
+    training) -- finite steps with wrong gradients.  The module looks at the library's counter where the reference's loop switches
+    modes anyway (density_experiment.py:336 / :545): model.eval() after a healthy epoch is silent, after a blown one it warns."""
+    import warnings
+    import torch
+    from gbnf_amd import BoostedFlow, native
+    dev = torch.device("cuda:0")
+    torch.manual_seed(3)
+    m = BoostedFlow(_args("glow", 8, 32, 3, 1, dev, act="relu")).to(dev)
+    x = torch.randn(256, 8, device=dev)
+
+    def epoch():
+        m.train()
+        z, _, _, ldj, _ = m(x=x, components=0)
+        loss = torch.mean(-(torch.sum(-0.5 * np.log(2 * np.pi) - 0.5 * z.pow(2), dim=-1) + ldj))
+        loss.backward()
+        return float(loss.detach())
+
+    native.saturation_count(reset=True)
+    assert np.isfinite(epoch())
+    with warnings.catch_warnings():
+        warnings.simplefilter("error")
+        m.eval()                                   # healthy: nothing to report
+    with torch.no_grad():                          # a ReLU net that has blown up: weights of a few hundred, second-layer activations ~1e6
+        m.flows[0].flow.layers[0].block.network[0].weight.mul_(2000.0)
+        m.flows[0].flow.layers[0].block.network[2].weight.mul_(2000.0)
+    epoch()
+    with pytest.warns(RuntimeWarning, match="65504"):
+        m.eval()
+    with warnings.catch_warnings():                # reported once per training period
+        warnings.simplefilter("error")
+        m.eval()
+    assert native.saturation_count(reset=True) > 0      # (and the strict form sees the same counter)
+    # WEIGHTS beyond the fp16 range cannot be split at all (hi rounds to inf, the residual to -inf, a ReLU of their NaN is 0: a finite,
+    # wrong step): the device packer counts them like every other operand that leaves the range
+    with torch.no_grad():
+        m.flows[0].flow.layers[0].block.network[0].weight.mul_(1e5)
+    epoch()
+    with pytest.warns(RuntimeWarning, match="65504"):
+        m.eval()
+    native.saturation_count(reset=True)                 # (left clean for the other tests)
