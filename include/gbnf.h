@@ -137,7 +137,8 @@ const char* gbnf_last_error(void);
 
 /* The split-f16 kernels (evaluation, training) represent an f32 operand by two fp16 pieces: beyond +-65504 it cannot be
  * stored (the normalised input of a coupling net, a ReLU activation; in training also scaled gradients).  The EVALUATION
- * kernels repair such samples themselves (bf16x6 pass, see GBNF_MATH_F16X3); the training kernels saturate.  This
+ * kernels repair such samples themselves (bf16x6 pass, see GBNF_MATH_F16X3); the training kernels saturate (and a trainer's
+ * re-pack counts a WEIGHT beyond the range: it cannot be split at all).  This
  * returns how many waves ran into that since the last reset -- 0 for z-scored data on a trained flow -- and optionally
  * resets the counter.  One counter per device: this reports (and resets) the CURRENT device's, after a
  * hipDeviceSynchronize() (every stream of that device). */
