@@ -325,7 +325,8 @@ class NativeFlow:
         return z, ldj, ll
 
     def inverse(self, z, want_ldj=True):
-        """z (n,d) -> (x (n,d), log|det dx/dz| (n,) | None).  Needs a handle created with math="f32"."""
+        """z (n,d) -> (x (n,d), log|det dx/dz| (n,) | None): the flow's steps last to first (gbnf_flow_inverse), in the handle's math
+        mode (the same kernels under a runtime flag)."""
         import torch
         _require_device_f32(z, "z")
         if z.dim() != 2 or z.shape[1] != self.d:

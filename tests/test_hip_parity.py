@@ -412,22 +412,33 @@ def test_default_math_mode_and_mode_agreement(dev):
     np.testing.assert_allclose(b[0].cpu().numpy(), a[0].cpu().numpy(), rtol=0, atol=1e-5)
 
 
-@pytest.mark.parametrize("math", ["f32", "f16x3"])
-@pytest.mark.parametrize("kind,d,h,K", [("glow", 43, 64, 13), ("realnvp", 21, 64, 14), ("glow", 6, 30, 1)])
-def test_many_and_few_steps_against_oracle(kind, d, h, K, math, dev):
-    """K > 12 takes the per-step tables from global memory instead of LDS; K = 1 is the minimum."""
+@pytest.mark.parametrize("math", ["f32", "f16x3", "bf16x6"])
+@pytest.mark.parametrize("kind,d,h,K,n", [("glow", 43, 64, 13, 300), ("realnvp", 21, 64, 14, 300), ("glow", 6, 30, 1, 300),
+                                          # more than LDS_TABLE_STEPS (24 since round 6) steps: the per-step tables come from the blob in
+                                          # global memory -- 300 rows: the latency form of the kernel (f16x3), 5000: the throughput kernel
+                                          ("glow", 43, 64, 26, 300), ("glow", 43, 64, 26, 5000), ("realnvp", 21, 64, 25, 300),
+                                          ("realnvp", 21, 64, 25, 5000), ("glow", 43, 215, 27, 4096)])
+def test_many_and_few_steps_against_oracle(kind, d, h, K, n, math, dev):
+    """K > LDS_TABLE_STEPS takes the per-step tables from global memory instead of LDS (K = 13 / 14: from LDS, or from global memory where
+    they do not fit beside a pair of workgroups); K = 1 is the minimum.  Both directions."""
     import torch
     from gbnf_amd import native, synth
     from oracle import gbnf_oracle as oracle
     spec = (synth.synth_glow_spec(d, h, K, seed=7) if kind == "glow"
             else synth.synth_realnvp_spec(d, h, K, flip_init=1, seed=7))
-    x = synth.synth_batch(300, d, seed=8)
-    z, ldj, ll = native.NativeFlow(spec, math=math).forward(torch.from_numpy(x).to(dev), want_ll=True)
+    x = synth.synth_batch(n, d, seed=8)
+    flow = native.NativeFlow(spec, math=math)
+    xd = torch.from_numpy(x).to(dev)
+    z, ldj, ll = flow.forward(xd, want_ll=True)
     zr, lr = oracle.component_forward(spec, x)
     llr = oracle.component_log_prob(spec, x)
     assert rel_err(ll.cpu().numpy(), llr) < LL_RTOL
     assert rel_err(ldj.cpu().numpy(), lr) < LL_RTOL
     np.testing.assert_allclose(z.cpu().numpy(), zr, rtol=0, atol=2e-5 * max(1.0, np.abs(zr).max()))
+    if K > 24:                         # the way back through the same tables (a float32 round trip of K steps: 1e-4 of the data's scale)
+        xb, ldb = flow.inverse(z)
+        np.testing.assert_allclose(xb.cpu().numpy(), x, rtol=0, atol=1e-4 * max(1.0, np.abs(x).max()))
+        assert rel_err(ldb.cpu().numpy(), -lr) < 10 * LL_RTOL
 
 
 def test_empty_batch_and_errors(dev):
