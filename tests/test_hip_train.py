@@ -874,3 +874,31 @@ def test_leaving_training_mode_reports_saturated_training_kernels():
     with pytest.warns(RuntimeWarning, match="65504"):
         m.eval()
     native.saturation_count(reset=True)                 # (left clean for the other tests)
+
+
+@pytest.mark.parametrize("kind,d,h,K,n", [("glow", 8, 40, 26, 65), ("realnvp", 6, 30, 27, 100)])
+def test_flows_of_more_than_twenty_four_steps_train_behind_the_chained_limit(kind, d, h, K, n):
+    """K > LDS_TABLE_STEPS (24): the chained backward sweep refuses (its tables live in LDS), the traced forward reads its tables from
+    global memory, and the backward runs on the round-1 per-step kernels (bwd path 0).  Gradients against the float64 autograd oracle."""
+    import torch
+    from gbnf_amd import native, synth
+    from oracle import gbnf_oracle as oracle
+    dev = torch.device("cuda:0")
+    spec = (synth.synth_glow_spec(d, h, K, seed=51, gain=0.5) if kind == "glow" else synth.synth_realnvp_spec(d, h, K, seed=51, gain=0.5))
+    xs = synth.synth_batch(n, d, seed=52)
+    rng = np.random.RandomState(53)
+    g_z = rng.standard_normal(xs.shape).astype(np.float32)
+    g_l = rng.standard_normal(n).astype(np.float32)
+    tr = native.NativeTrainer(_dev_spec(spec, dev))
+    x = torch.from_numpy(xs).to(dev)
+    z, ldj, trace = tr.forward(x, want_trace=True)
+    z64, ldj64 = oracle.component_forward(spec, xs, backend="numpy64")
+    assert np.abs(ldj.cpu().numpy() - ldj64).max() <= 1e-5 * max(1.0, float(np.abs(ldj64).max()))
+    assert np.abs(z.cpu().numpy() - z64).max() <= 2e-5 * max(1.0, float(np.abs(z64).max()))
+    gx64, grads64 = oracle.component_grads(spec, xs, g_z, g_l)
+    gx, grads = tr.backward(x, torch.from_numpy(g_z).to(dev), torch.from_numpy(g_l).to(dev), want_gx=True, trace=trace)
+    assert _last_path(tr)[1] == 0                       # the backward sweep: per-step kernels
+    _check_grads(grads, grads64, f"{kind} K={K}")
+    assert np.abs(gx.cpu().numpy() - gx64).max() <= G_RTOL * max(float(np.abs(gx64).max()), 1e-3)
+    gx2, grads2 = tr.backward(x, torch.from_numpy(g_z).to(dev), torch.from_numpy(g_l).to(dev), want_gx=True, trace=None)
+    _check_grads(grads2, grads64, f"{kind} K={K} (no trace)")
