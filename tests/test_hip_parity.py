@@ -417,7 +417,9 @@ def test_default_math_mode_and_mode_agreement(dev):
                                           # more than LDS_TABLE_STEPS (24 since round 6) steps: the per-step tables come from the blob in
                                           # global memory -- 300 rows: the latency form of the kernel (f16x3), 5000: the throughput kernel
                                           ("glow", 43, 64, 26, 300), ("glow", 43, 64, 26, 5000), ("realnvp", 21, 64, 25, 300),
-                                          ("realnvp", 21, 64, 25, 5000), ("glow", 43, 215, 27, 4096)])
+                                          ("realnvp", 21, 64, 25, 5000), ("glow", 43, 215, 27, 4096),
+                                          # exactly LDS_TABLE_STEPS steps at the widest d: the largest table + state footprint in LDS
+                                          ("glow", 64, 64, 24, 300), ("realnvp", 64, 105, 24, 5000)])
 def test_many_and_few_steps_against_oracle(kind, d, h, K, n, math, dev):
     """K > LDS_TABLE_STEPS takes the per-step tables from global memory instead of LDS (K = 13 / 14: from LDS, or from global memory where
     they do not fit beside a pair of workgroups); K = 1 is the minimum.  Both directions."""
