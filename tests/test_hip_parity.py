@@ -561,3 +561,41 @@ def test_inverse_large_n_and_out_of_range_inputs(math, golden_case):
     assert (ild + ldj).abs().max().item() <= 1e-5 * float(ldj.abs().max())
     xe, _ = flow.inverse(torch.zeros(0, 43, device="cuda"))
     assert xe.shape == (0, 43)
+
+
+@pytest.mark.parametrize("kind,d,h,K", [("glow", 43, 215, 20), ("realnvp", 21, 105, 24)])
+def test_thirteen_to_twenty_four_steps_on_every_workgroup_form(kind, d, h, K, dev):
+    """13 .. LDS_TABLE_STEPS steps: the throughput kernel keeps the per-step tables in LDS as ONE 8-wave workgroup per CU and reads them from
+    the blob as a PAIR of 4-wave workgroups when they do not fit beside the pair (hx3 launcher, `fits4`): both forms, 16- and 32-sample
+    waves, f16x3 and bf16x6, against the oracle."""
+    import torch
+    from gbnf_amd import native, synth
+    from oracle import gbnf_oracle as oracle
+    spec = (synth.synth_glow_spec(d, h, K, seed=17) if kind == "glow" else synth.synth_realnvp_spec(d, h, K, flip_init=1, seed=17))
+    x = synth.synth_batch(5000, d, seed=18)
+    xd = torch.from_numpy(x).to(dev)
+    # (reference: the float64 oracle; the bar: 1e-5, or three times what the float32 oracle -- the reference's own arithmetic -- is off it:
+    #  24 RealNVP steps sum log-scales of both signs, and two float32 implementations of that sum differ by ~1e-5 of its size)
+    z64, l64 = oracle.component_forward(spec, x, backend="numpy64")
+    ll64 = np.sum(-0.5 * np.log(2 * np.pi) - 0.5 * z64 * z64, axis=1) + l64
+    z32, l32 = oracle.component_forward(spec, x)
+    ll32 = oracle.component_log_prob(spec, x)
+    tol_l = max(LL_RTOL, 3.0 * rel_err(l32, l64))
+    tol_ll = max(LL_RTOL, 3.0 * rel_err(ll32, ll64))
+    lr, llr = l64, ll64
+    saved = {k: native.tuning_get(k) for k in ("force_nt", "wg_pairs", "coop")}
+    try:
+        native.tuning_set("coop", 0)
+        for math in ("f16x3", "bf16x6"):
+            flow = native.NativeFlow(spec, math=math)
+            for nt in (1, 2):
+                for pairs in (0, 1):
+                    native.tuning_set("force_nt", nt)
+                    native.tuning_set("wg_pairs", pairs)
+                    _, ldj, ll = flow.forward(xd, want_z=False, want_ll=True)
+                    assert rel_err(ll.cpu().numpy(), llr) < tol_ll, (math, nt, pairs, tol_ll)
+                    assert rel_err(ldj.cpu().numpy(), lr) < tol_l, (math, nt, pairs, tol_l)
+            flow.close()
+    finally:
+        for k, v in saved.items():
+            native.tuning_set(k, v)
