@@ -554,10 +554,10 @@ class BoostedFlow(nn.Module):
     def train(self, mode=True):
         """nn.Module.train, plus a look at the library's range counter where the reference's loop switches modes anyway (once per epoch:
         density_experiment.py:336 ``model.train()``, :545 ``model.eval()``).  The TRAINING kernels saturate a split-f16 operand beyond
-        +-65504 instead of repairing the sample (include/gbnf.h, gbnf_saturation_count): the step stays finite and its gradients are
-        wrong for those samples.  Leaving training mode with more marked waves than it began with is reported -- a warning, not an
-        error: the counter is per device, and an evaluation launch in between (the fixed components' boosting weights), which repairs
-        what it marks, raises it too.  ``BoostedFlow.check_numerics()`` is the strict form."""
+        +-65504 instead of repairing the sample (include/gbnf.h, gbnf_training_saturation_count: their own counter -- an evaluation launch
+        in between, e.g. the fixed components' boosting weights, repairs what it marks and does not count here): the step stays finite
+        and its gradients are wrong for those samples.  Leaving training mode with more such waves than it began with is reported (a
+        RuntimeWarning: the counter is per device, not per model).  ``BoostedFlow.check_numerics()`` is the strict form."""
         mode = bool(mode)
         out = super().train(mode)
         try:
@@ -573,16 +573,16 @@ class BoostedFlow(nn.Module):
                 now = self._range_counter()
                 if now is not None and now > snap:
                     import warnings
-                    warnings.warn(f"{now - snap} wave(s) met a split-f16 operand beyond +-65504 while the model was in training mode: the "
-                                  "training kernels saturate there (gradients of those samples are wrong; an evaluation launch repairs what "
-                                  "it marks and counts too).  An exploding model or inputs far off the scale the flow was fitted on -- "
-                                  "normalise the inputs; BoostedFlow.check_numerics() raises on the same counter", RuntimeWarning, stacklevel=2)
+                    warnings.warn(f"{now - snap} wave(s) of TRAINING kernels met a split-f16 operand beyond +-65504 while the model was in "
+                                  "training mode: they saturate there -- the steps stayed finite, the gradients of those samples were wrong.  An "
+                                  "exploding model (activations, gradients or weights beyond the fp16 range) or inputs far off the scale the "
+                                  "flow was fitted on: normalise the inputs, lower the learning rate", RuntimeWarning, stacklevel=2)
         return out
 
     def _range_counter(self):
         try:
             with torch.cuda.device(self.rho.device):
-                return native.saturation_count(reset=False)
+                return native.training_saturation_count(reset=False)
         except Exception:                      # (no library / no device: the calls that need them raise on their own)
             return None
 

@@ -151,6 +151,10 @@ unsigned* saturation_counter() {
   }
   return g_sat_counter[dev];
 }
+unsigned* training_saturation_counter() {
+  unsigned* p = saturation_counter();
+  return p ? p + 2 : nullptr;          // 64-bit word [1] (SAT_MARKS = 2: words [0] and [1] are counters, the launch marks follow)
+}
 
 // ---- launch-policy knobs (gbnf_tuning_set / _get; initialised from the environment at first use)
 struct Tuning {
@@ -497,10 +501,26 @@ int gbnf_saturation_count(int64_t* count, int32_t reset) {
   unsigned long long host = 0;
   // every stream of the device (torch's side streams are non-blocking ones: the null-stream copy alone would not
   // order against their kernels)
+  unsigned long long both[2] = {0, 0};      // [0] evaluation kernels (repaired in the same call), [1] training kernels (saturated)
+  hipError_t e = hipDeviceSynchronize();
+  if (e == hipSuccess) e = hipMemcpy(both, dev, sizeof(both), hipMemcpyDeviceToHost);
+  if (e == hipSuccess && reset) e = hipMemset(dev, 0, sizeof(both));
+  if (e != hipSuccess) return fail(GBNF_ERR_HIP, "gbnf_saturation_count: %s", hipGetErrorString(e));
+  host = both[0] + both[1];
+  *count = (int64_t)host;
+  return GBNF_OK;
+}
+
+int gbnf_training_saturation_count(int64_t* count, int32_t reset) {
+  if (count == nullptr) return fail(GBNF_ERR_INVALID, "gbnf_training_saturation_count: count is null");
+  *count = 0;
+  unsigned* dev = gbnf::training_saturation_counter();
+  if (dev == nullptr) return GBNF_OK;
+  unsigned long long host = 0;
   hipError_t e = hipDeviceSynchronize();
   if (e == hipSuccess) e = hipMemcpy(&host, dev, sizeof(host), hipMemcpyDeviceToHost);
   if (e == hipSuccess && reset) e = hipMemset(dev, 0, sizeof(host));
-  if (e != hipSuccess) return fail(GBNF_ERR_HIP, "gbnf_saturation_count: %s", hipGetErrorString(e));
+  if (e != hipSuccess) return fail(GBNF_ERR_HIP, "gbnf_training_saturation_count: %s", hipGetErrorString(e));
   *count = (int64_t)host;
   return GBNF_OK;
 }
@@ -2151,7 +2171,7 @@ int live_blob_backward(LiveBlob* lb, int64_t n, const float* trace, float* acts,
   FlowLaunch p{};
   p.blobs = lb->table_dev; p.blobs_bwd = lb->tableB_dev;
   p.n = n; p.d = lb->d; p.n_steps = lb->K; p.n_comp = 1; p.n_batches = 1; p.additive = lb->additive;
-  p.sat = reinterpret_cast<unsigned long long*>(saturation_counter());
+  p.sat = reinterpret_cast<unsigned long long*>(training_saturation_counter());
   p.acts_out = acts; p.np = np; p.tr_ip = ip; p.tr_hp = hp; p.tr_op = op; p.net_rows = ip + 2 * (lb->depth + 1) * hp + 2 * op;
   p.bwd_tab = lb->bwd_tab_dev; p.bwd_goff = lb->bwd_goff_dev; p.trace_in = trace;
   p.g_z = g_z; p.g_ldj = g_ldj; p.g_x = g_x; p.grads = grads; p.gmax = gmax;
@@ -2185,7 +2205,7 @@ static void live_blob_repack(LiveBlob* lb, hipStream_t s, bool with_backward = f
   hipLaunchKernelGGL(live_pack_kernel, dim3((unsigned)(tile_blocks + small_blocks)), dim3(256), 0, s, (const LiveTile*)lb->tiles_dev,
                      lb->n_tiles, (const LiveTile*)lb->tilesB_dev, n_tilesB, lb->blobB_dev, (const LiveBias*)lb->bias_dev, lb->n_bias,
                      (const LiveEntry*)lb->entries_dev, lb->n_entries, (const LiveNorm*)lb->norms_dev, lb->K, lb->d,
-                     lb->kind == GBNF_KIND_GLOW ? 1 : 0, (const LiveLayer*)lb->layers_dev, lb->blob_dev, saturation_counter());
+                     lb->kind == GBNF_KIND_GLOW ? 1 : 0, (const LiveLayer*)lb->layers_dev, lb->blob_dev, training_saturation_counter());
   lb->tilesB_packed = n_tilesB > 0;
 }
 
@@ -2216,7 +2236,7 @@ int live_blob_forward(LiveBlob* lb, const float* x, int64_t n, float* z, float* 
   p.n_batches = 1; p.xs[0] = x;
   p.n = n; p.out_stride = n; p.d = lb->d; p.n_steps = lb->K; p.c_begin = 0; p.n_comp = 1;
   p.n_tiles = (int32_t)((n + 16 * nt - 1) / (16 * nt)); p.additive = lb->additive;
-  p.sat = reinterpret_cast<unsigned long long*>(saturation_counter());
+  p.sat = reinterpret_cast<unsigned long long*>(training_saturation_counter());      // (TRAIN instantiations touch the counter word only, never the marks)
   p.seq = next_serial();
   p.trace_out = trace; p.acts_out = acts; p.np = np; p.tr_ip = ip; p.tr_hp = hp; p.tr_op = op; p.net_rows = ip + 2 * (lb->depth + 1) * hp + 2 * op;
   if (range != nullptr) {

@@ -12,6 +12,11 @@ int fail(int code, const char* fmt, ...);
 // could not be allocated.  Call it at launch time, with the launch's device current.  Read and reset by
 // gbnf_saturation_count().
 unsigned* saturation_counter();
+// The same device's counter of the TRAINING kernels (word [1] of the same allocation): the traced forward sweep, the backward sweep, the
+// per-step training kernels and the trainer's weight re-pack count here -- they saturate and have no repair pass, so THIS count means wrong
+// gradients, while word [0] (evaluation: every marked sample is re-evaluated in the same call) is a data-quality alarm.  gbnf_saturation_count()
+// reports their sum, gbnf_training_saturation_count() this word alone.
+unsigned* training_saturation_counter();
 
 // Kernel-variant key only (not a descriptor value): the activation differs between the steps / nets of a component
 // (`--coupling_network random` in the reference); the kernel reads it per step and net from the step header.

@@ -1792,7 +1792,7 @@ static void fill_launch(const gbnf_trainer* t, TrainLaunch& p, const float* x, i
   p.dbg = g_train_stamp_buf;
 #endif
   p.steps = t->steps_dev; p.tail = t->tail_dev; p.x = x;
-  p.sat = saturation_counter();
+  p.sat = training_saturation_counter();
   p.n = n; p.np = tr_padded(n);
   p.d = t->d; p.K = t->K; p.kind = t->kind; p.additive = t->additive;
   p.residual = t->residual;

@@ -23,7 +23,7 @@ MATH_NAME = {v: k for k, v in MATH.items()}
 
 # every symbol include/gbnf.h declares (tests check the library exports exactly these)
 ABI_SYMBOLS = (
-    "gbnf_version", "gbnf_last_error", "gbnf_saturation_count",
+    "gbnf_version", "gbnf_last_error", "gbnf_saturation_count", "gbnf_training_saturation_count",
     "gbnf_flow_create", "gbnf_flow_create_mode", "gbnf_flow_create_ex", "gbnf_flow_destroy", "gbnf_flow_info", "gbnf_flow_forward",
     "gbnf_flow_inverse",
     "gbnf_mixture_create", "gbnf_mixture_destroy", "gbnf_mixture_set_base",
@@ -138,6 +138,7 @@ def lib():
     L.gbnf_last_error.restype = C.c_char_p
     L.gbnf_flow_create.argtypes = [C.POINTER(_FlowDesc), C.POINTER(vp)]
     L.gbnf_saturation_count.argtypes = [C.POINTER(C.c_int64), i32]
+    L.gbnf_training_saturation_count.argtypes = [C.POINTER(C.c_int64), i32]
     L.gbnf_flow_create_mode.argtypes = [C.POINTER(_FlowDesc), i32, C.POINTER(vp)]
     L.gbnf_flow_create_ex.argtypes = [C.POINTER(_FlowDesc), i32, i32, C.POINTER(vp)]
     L.gbnf_flow_destroy.argtypes = [vp]
@@ -711,6 +712,14 @@ def saturation_count(reset=False):
     z-scored data on a trained flow.  Synchronises with the device (gbnf_saturation_count)."""
     n = C.c_int64(0)
     _check(lib().gbnf_saturation_count(C.byref(n), 1 if reset else 0))
+    return int(n.value)
+
+
+def training_saturation_count(reset=False):
+    """The part of ``saturation_count`` that came from TRAINING launches (forward / backward sweeps of a trainer, its weight re-pack):
+    they saturate and are not repaired -- non-zero means steps with wrong gradients (gbnf_training_saturation_count).  Synchronises."""
+    n = C.c_int64(0)
+    _check(lib().gbnf_training_saturation_count(C.byref(n), 1 if reset else 0))
     return int(n.value)
 
 

@@ -143,6 +143,11 @@ const char* gbnf_last_error(void);
  * resets the counter.  One counter per device: this reports (and resets) the CURRENT device's, after a
  * hipDeviceSynchronize() (every stream of that device). */
 int gbnf_saturation_count(int64_t* count, int32_t reset);
+/* The part of that count that came from TRAINING launches (gbnf_trainer_forward / _backward: traced and untraced sweeps, the weight
+ * re-pack): these saturate and are NOT repaired, so a non-zero value means steps with wrong gradients -- while the rest of
+ * gbnf_saturation_count() (evaluation launches) was re-evaluated in the same call.  Same device, same synchronisation; `reset` clears
+ * this part only.  (The drop-in module reads it when it leaves training mode: BoostedFlow.train / .eval.) */
+int gbnf_training_saturation_count(int64_t* count, int32_t reset);
 
 /* Numerics guard of a GBNF_MATH_DEFAULT handle that runs on f16x3 (round 3; what the creation-time probe cannot know is
  * the caller's data).  The library itself re-checks the choice on the data it is given: on the FIRST launch of a handle
