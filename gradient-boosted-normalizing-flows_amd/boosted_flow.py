@@ -995,10 +995,12 @@ class BoostedFlow(nn.Module):
         repair such samples themselves (bf16x6 pass), so for them this is a data-quality alarm; the TRAINING kernels
         saturate there, so after a training epoch a non-zero count means wrong gradients.  Synchronises with the device;
         call it once per epoch, not per step."""
-        n = native.saturation_count(reset=reset)
+        n_train = native.training_saturation_count(reset=False)
+        n = native.saturation_count(reset=reset)           # (the sum; resets both parts)
         if n:
-            raise FloatingPointError(f"{n} wave(s) met a split-f16 operand beyond +-65504 (evaluation: repaired on the "
-                                     "device; training: saturated, gradients of those samples are wrong) -- normalise the inputs")
+            raise FloatingPointError(f"{n} wave(s) met a split-f16 operand beyond +-65504: {n - n_train} of evaluation launches (repaired on "
+                                     f"the device), {n_train} of training launches (saturated: gradients of those samples are wrong) -- "
+                                     "normalise the inputs")
 
     def _n_used(self, n_used):
         if n_used is None:

@@ -479,3 +479,25 @@ def test_the_default_cache_serves_one_loop_and_nothing_else(golden_case):
         p = m(x=x, components=1)
         assert m(x=x, components=1) is p and "_component_table" in m.__dict__
     assert "_component_table" not in m.__dict__ and m.SERVE_ALL_COMPONENTS is True
+
+
+def test_check_numerics_is_the_strict_form(golden_case):
+    """BoostedFlow.check_numerics(): raises once any launch since the last check met an operand beyond the fp16 range -- saying how many
+    waves of evaluation launches (repaired in the same call: the result is right) and of training launches (saturated) -- and resets."""
+    import torch
+    from gbnf_amd import BoostedFlow, native
+    dev = torch.device("cuda:0")
+    g = golden_case("g6_glow_d43_h64_c3_rho")
+    m = _model_from_case(g, dev)
+    x = torch.from_numpy(g.x).to(dev)
+    native.saturation_count(reset=True)
+    G = m.log_prob(x)
+    BoostedFlow.check_numerics()                        # z-scored data on a sane model: silent
+    xbig = x.clone()
+    xbig[5] = 2.0e5
+    G2 = m.log_prob(xbig)
+    assert bool(torch.isfinite(G2[torch.arange(len(x), device=dev) != 5]).all())
+    assert rel_err(G2[:5].cpu().numpy(), G[:5].cpu().numpy()) == 0.0          # the other rows are untouched
+    with pytest.raises(FloatingPointError, match="0 of training launches"):
+        BoostedFlow.check_numerics()
+    BoostedFlow.check_numerics()                        # the check reset the counter
