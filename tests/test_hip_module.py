@@ -501,3 +501,29 @@ def test_check_numerics_is_the_strict_form(golden_case):
     with pytest.raises(FloatingPointError, match="0 of training launches"):
         BoostedFlow.check_numerics()
     BoostedFlow.check_numerics()                        # the check reset the counter
+
+
+def test_the_module_methods_no_other_test_calls(golden_case):
+    """`base_dist` (the reference class's property: models/generative_flow.py:38-41), `numerics_status`, `verify_numerics`,
+    `native_flow_exact`: each once, on a reference fixture."""
+    import torch
+    from gbnf_amd import native
+    dev = torch.device("cuda:0")
+    g = golden_case("g4_realnvp_d21_h105_c8")
+    m = _model_from_case(g, dev).to(dev)
+    m.component = g.n_used - 1
+    x = torch.from_numpy(g.x).to(dev)
+    bd = m.base_dist                                  # Normal(base_dist_mean, base_dist_var): registered buffers, as upstream
+    assert isinstance(bd, torch.distributions.Normal) and tuple(bd.loc.shape) == (m.z_size,) and bd.loc.is_cuda
+    assert float(bd.scale.min()) == 3.0 and "base_dist_mean" in dict(m.named_buffers())
+    G = m.log_prob(x)
+    assert rel_err(G.cpu().numpy(), g.G) < LL_RTOL
+    st = m.numerics_status()
+    assert set(st) == {"math_mode", "demoted", "checks", "worst_rel_err", "tolerance"} and st["math_mode"] in ("f16x3", "bf16x6", "f32")
+    assert st["demoted"] is False and st["worst_rel_err"] <= st["tolerance"]
+    worst = m.verify_numerics(x)                      # f16x3 against bf16x6 on the caller's rows: a sane model stays where it is
+    assert 0.0 <= worst < 2.5e-6 and not m.__dict__.get("_math_override")
+    exact = m.native_flow_exact(0)
+    assert exact.info().math_mode == native.MATH["f32"] and m.native_flow_exact(0) is exact      # cached per parameter state
+    z, ldj, ll = exact.forward(x, want_ll=True)
+    assert rel_err(ll.cpu().numpy(), g.ll[0]) < LL_RTOL
