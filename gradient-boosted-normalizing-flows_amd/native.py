@@ -351,55 +351,61 @@ class NativeFlow:
             pass
 
 
+def image_flow_desc_from_spec(spec):
+    """image flow spec (synth.synth_image_glow_spec / spec.image_spec_from_glow_module) -> (ctypes gbnf_image_flow_desc, keep-alive object)."""
+    keep = _Keep()
+
+    def conv(c):
+        w = np.asarray(c["w"])
+        cc = _Conv()
+        cc.weight = keep.f32(w)
+        for field, key in (("bias", "b"), ("actnorm_bias", "an_bias"), ("actnorm_logs", "an_logs"), ("logs", "logs")):
+            if c[key] is not None:
+                setattr(cc, field, keep.f32(np.asarray(c[key]).reshape(-1)))
+        cc.out_channels, cc.in_channels, cc.kernel_size = int(w.shape[0]), int(w.shape[1]), int(w.shape[2])
+        return cc
+
+    desc = _ImageFlowDesc()
+    desc.channels, desc.height, desc.width = (int(v) for v in spec["input_size"])
+    desc.n_levels = len(spec["levels"])
+    desc.coupling = COUPLING[spec.get("coupling") or "affine"]
+    desc.hidden = int(spec["hidden"])
+    desc.bounds = float(spec.get("bounds", 0.9))
+    levels = (_ImageLevel * desc.n_levels)()
+    for l, lv in enumerate(spec["levels"]):
+        steps = (_ImageStep * len(lv["steps"]))()
+        for k, st in enumerate(lv["steps"]):
+            s_ = _ImageStep()
+            s_.actnorm_bias = keep.f32(np.asarray(st["an_bias"]).reshape(-1))
+            s_.actnorm_logs = keep.f32(np.asarray(st["an_logs"]).reshape(-1))
+            if st.get("perm_w") is not None:
+                s_.perm_weight = keep.f32(st["perm_w"])
+            else:
+                s_.perm_indices = keep.i64(st["perm"])
+            arr = (_Conv * len(st["convs"]))(*[conv(c) for c in st["convs"]])
+            keep.refs.append(arr)
+            s_.n_convs, s_.convs = len(st["convs"]), arr
+            steps[k] = s_
+        keep.refs.append(steps)
+        levels[l].n_steps, levels[l].steps = len(lv["steps"]), steps
+        if lv["split"] is not None:
+            sp = conv(lv["split"])
+            keep.refs.append(sp)
+            levels[l].split_prior = C.pointer(sp)
+    desc.levels = levels
+    if spec.get("learn_top") is not None:
+        top = conv(spec["learn_top"])
+        keep.refs.append(top)
+        desc.learn_top = C.pointer(top)
+    return desc, keep
+
+
 class NativeImageFlow:
     """One packed image Glow component (gbnf_image_flow).  ``spec``: the image flow spec of ``synth.synth_image_glow_spec``
     / ``spec.image_spec_from_glow_module`` (numpy arrays)."""
 
     def __init__(self, spec, math="default"):
-        keep = _Keep()
-
-        def conv(c):
-            w = np.asarray(c["w"])
-            cc = _Conv()
-            cc.weight = keep.f32(w)
-            for field, key in (("bias", "b"), ("actnorm_bias", "an_bias"), ("actnorm_logs", "an_logs"), ("logs", "logs")):
-                if c[key] is not None:
-                    setattr(cc, field, keep.f32(np.asarray(c[key]).reshape(-1)))
-            cc.out_channels, cc.in_channels, cc.kernel_size = int(w.shape[0]), int(w.shape[1]), int(w.shape[2])
-            return cc
-
-        desc = _ImageFlowDesc()
-        desc.channels, desc.height, desc.width = (int(v) for v in spec["input_size"])
-        desc.n_levels = len(spec["levels"])
-        desc.coupling = COUPLING[spec.get("coupling") or "affine"]
-        desc.hidden = int(spec["hidden"])
-        desc.bounds = float(spec.get("bounds", 0.9))
-        levels = (_ImageLevel * desc.n_levels)()
-        for l, lv in enumerate(spec["levels"]):
-            steps = (_ImageStep * len(lv["steps"]))()
-            for k, st in enumerate(lv["steps"]):
-                s_ = _ImageStep()
-                s_.actnorm_bias = keep.f32(np.asarray(st["an_bias"]).reshape(-1))
-                s_.actnorm_logs = keep.f32(np.asarray(st["an_logs"]).reshape(-1))
-                if st.get("perm_w") is not None:
-                    s_.perm_weight = keep.f32(st["perm_w"])
-                else:
-                    s_.perm_indices = keep.i64(st["perm"])
-                arr = (_Conv * len(st["convs"]))(*[conv(c) for c in st["convs"]])
-                keep.refs.append(arr)
-                s_.n_convs, s_.convs = len(st["convs"]), arr
-                steps[k] = s_
-            keep.refs.append(steps)
-            levels[l].n_steps, levels[l].steps = len(lv["steps"]), steps
-            if lv["split"] is not None:
-                sp = conv(lv["split"])
-                keep.refs.append(sp)
-                levels[l].split_prior = C.pointer(sp)
-        desc.levels = levels
-        if spec.get("learn_top") is not None:
-            top = conv(spec["learn_top"])
-            keep.refs.append(top)
-            desc.learn_top = C.pointer(top)
+        desc, keep = image_flow_desc_from_spec(spec)
         h = C.c_void_p()
         if math not in ("default", "f32", "f16x3"):
             raise GbnfError(f"image components run in math mode default | f32 | f16x3, not {math!r}")
