@@ -380,6 +380,9 @@ def config_legs(args):
                                        "--cpu-seconds", cpu, "--no-extra-legs", "--no-config-legs"]),
         ("cifar10_glow_c4_n256", [py, os.path.join(tools, "bench_image.py"), "--batch", "256", "--steps", "40", "--warmup", "5",
                                   "--cpu-seconds", cpu]),
+        # ... and at the reference's own evaluation batch (image_experiment.py:64: --eval_batch_size 1024)
+        ("cifar10_glow_c4_n1024", [py, os.path.join(tools, "bench_image.py"), "--batch", "1024", "--steps", "20", "--warmup", "3",
+                                   "--cpu-seconds", "0"]),
         ("train_step_miniboone_c1_n65536", [py, os.path.join(tools, "bench_train.py"), "--batch", "65536", "--steps", "30", "--warmup", "5",
                                             "--cpu-steps", "2" if args.cpu_seconds > 0 else "0", "--no-torch-legs"]),
         # the other coupling networks the reference constructs (round 5: on the register-chained training kernels too)
