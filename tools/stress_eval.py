@@ -32,6 +32,8 @@ for k in range(cases):
     except native.GbnfError as e:
         print("skip (unsupported):", tag, "|", str(e)[:90]); continue
     x = synth.synth_batch(n, d, seed=k, scale=float(10.0 ** rng.uniform(-1, 0.5)))      # the data need not be exactly z-scored
+    if os.environ.get("GBNF_STRESS_ONLY") and not any(w in tag for w in os.environ["GBNF_STRESS_ONLY"].split("|")):
+        continue                                   # (re-judge named cases of a stream: every draw above has been made)
     # (beyond ~3x the unit scale random ReLU RealNVPs without BatchNorm overflow exp(scale) in float32 -- oracle and kernels alike)
     rho = oracle.rho_init(C)
     ll_ref, G_ref = oracle.mixture_log_prob(specs, rho, x)
@@ -43,16 +45,22 @@ for k in range(cases):
     if not ok:
         # unnormalised ReLU nets without BatchNorm can be ill-conditioned in f32: arbitrate with float64 -- the case is fine
         # if the kernels are no further from float64 than ~3x what the reference's own f32 arithmetic (the oracle) is
-        e_ref, e_gpu = 0.0, 0.0
+        e_ref, e_gpu, n_blown = 0.0, 0.0, 0
         for c, sp in enumerate(specs):
             z64, l64 = oracle.component_forward(sp, x, backend="numpy64")
             ll64 = (-0.5 * z64 ** 2 - 0.5 * np.log(2 * np.pi)).sum(1) + l64
-            e_ref = max(e_ref, float(np.max(np.abs(ll_ref[c] - ll64) / np.maximum(np.abs(ll64), 1.0))))
-            e_gpu = max(e_gpu, float(np.max(np.abs(ll[c].cpu().numpy() - ll64) / np.maximum(np.abs(ll64), 1.0))))
+            # a row the component throws beyond |z| = 1e4 (log-density below -5e7: an exploded sample of a random ReLU RealNVP) has no
+            # float32 answer to compare with -- the exact-f32 kernel, the split kernels and torch's float32 differ from float64 and from
+            # each other by 1e-4 there (tools/debug_eval_case.py); such rows are counted, not judged
+            sane = np.isfinite(z64).all(1) & (np.abs(z64).max(1) <= 1e4)
+            n_blown += int((~sane).sum())
+            if sane.any():
+                e_ref = max(e_ref, float(np.max((np.abs(ll_ref[c] - ll64) / np.maximum(np.abs(ll64), 1.0))[sane])))
+                e_gpu = max(e_gpu, float(np.max((np.abs(ll[c].cpu().numpy() - ll64) / np.maximum(np.abs(ll64), 1.0))[sane])))
         # (a net output s enters as exp(s): an absolute f32 rounding error of 1e-6 * |terms of s| is a RELATIVE error of
         # the component's density; summation order decides who is luckier -- the mixture G must still meet the bar)
         ok = e_gpu <= max(1e-5, 3.0 * e_ref) or (e2 < 1e-5 and e_gpu < 3e-5)
-        note = f" | vs float64: kernels {e_gpu:.1e}, the f32 oracle itself {e_ref:.1e}"
+        note = f" | vs float64: kernels {e_gpu:.1e}, the f32 oracle itself {e_ref:.1e}" + (f" ({n_blown} exploded row(s) left out)" if n_blown else "")
     # the z -> x direction (exact-f32 kernel, hidden <= 256): x -> z -> x must come back, log-dets must cancel
     inv_note = ""
     if h <= 256:
@@ -69,11 +77,22 @@ for k in range(cases):
             if not inv_ok:
                 # an ill-conditioned row (an outlier the flow stretches by e^scale: one float32 ulp of z is a visible step in x): the
                 # reference's own float32 arithmetic -- the oracle's inverse of the SAME z -- must then be as far from x as the kernel is
-                xo, _ = oracle.component_inverse(specs[C - 1], z.cpu().numpy(), backend="torch")
-                eo = float(np.abs(np.asarray(xo) - x).max() / max(1.0, float(np.abs(x).max())))
-                if eo >= 0.3 * ex:
+                # ... or not finite at all; the float64 oracle's inverse of that z is the second witness: if even float64 arithmetic
+                # cannot get x back from the float32 z, the row was lost on the way IN (tools/debug_eval_case.py prints it row by row)
+                zn = z.cpu().numpy()
+                sc = max(1.0, float(np.abs(x).max()))
+                xo, _ = oracle.component_inverse(specs[C - 1], zn, backend="torch")
+                xo64, _ = oracle.component_inverse(specs[C - 1], zn.astype(np.float64), backend="numpy64")
+                ek = np.abs(xr.cpu().numpy() - x).max(1) / sc
+                eo_r = np.abs(np.asarray(xo) - x).max(1) / sc
+                e64_r = np.abs(np.asarray(xo64) - x).max(1) / sc
+                el_r = (ldj + ldj_inv).abs().cpu().numpy() / max(1.0, float(ldj.abs().max()))
+                badrows = (ek >= 2e-4) | (el_r >= 1e-4)
+                lost = ~np.isfinite(eo_r) | ~np.isfinite(e64_r) | ((ek >= 2e-4) & ((eo_r >= 0.3 * ek) | (e64_r >= 0.3 * ek)))
+                if bool((lost | ~badrows).all()):        # every row that does not come back is one the float32 z has lost
                     inv_ok = True
-                    inv_note += f" (the f32 oracle's inverse of the same z: {eo:.1e} -- conditioning)"
+                    inv_note += (f" ({int(badrows.sum())} row(s) the float32 z has lost: the f32 / f64 oracle's inverse of the SAME z is off by as "
+                                 "much, or not finite -- conditioning)")
             ok = ok and inv_ok
         except native.GbnfError as e:
             inv_note = " | inverse: unsupported"
